@@ -1,0 +1,89 @@
+"""
+TEST INFRASTRUCTURE ONLY.  The fixture zoo: small seeded sample sets (numpy only, reproducible on any
+box) that exercise every branch of the hot path.  The shapes follow the *specs* of the reference's own
+fixture zoo (getdist/tests/test_distributions.py:129-257: plain / correlated / tight Gaussians,
+bi/tri-modal mixtures, hard cuts on one or both axes, flat-between-bounds) and of
+getdist/tests/getdist_test.py:181-225 (periodic angle), plus weighted variants.
+"""
+
+import numpy as np
+
+from getdist_amd import synth
+
+KW1_VARIANTS = ({}, dict(boundary_correction_order=0, mult_bias_correction_order=0),
+                dict(boundary_correction_order=2, mult_bias_correction_order=1),
+                dict(boundary_correction_order=1, mult_bias_correction_order=2),
+                dict(smooth_scale_1D=0.3), dict(smooth_scale_1D=2))
+KW2_VARIANTS = ({}, dict(boundary_correction_order=0, mult_bias_correction_order=0), dict(fine_bins_2D=64),
+                dict(smooth_scale_2D=0.3), dict(mult_bias_correction_order=2))
+
+
+def _rng(k):
+    return np.random.default_rng(np.random.SeedSequence([synth.BASE_SEED, 1000 + k]))
+
+
+def shapes_fixture(N=20000):
+    """Eight parameters forming pairs of distinct 2D shapes."""
+    r = _rng(1)
+    cols = []
+    # (s0,s1): bimodal mixture, equal widths
+    comp = r.random(N) < 0.4
+    cols.append(np.where(comp, r.normal(-1.2, 0.5, N), r.normal(1.0, 0.7, N)))
+    cols.append(np.where(comp, r.normal(0.8, 0.4, N), r.normal(-0.5, 0.6, N)))
+    # (s2,s3): tight correlation rho=0.99
+    z0, z1 = r.standard_normal(N), r.standard_normal(N)
+    cols.append(z0)
+    cols.append(0.99 * z0 + np.sqrt(1 - 0.99**2) * z1)
+    # (s4,s5): cut correlated rho=0.95 with s5>0.3 and s4<1.2 (rejection sampling)
+    out4, out5 = [], []
+    need = N
+    while need > 0:
+        a = r.standard_normal(4 * need)
+        b = 0.95 * a + np.sqrt(1 - 0.95**2) * r.standard_normal(4 * need)
+        keep = (b > 0.3) & (a < 1.2)
+        out4.append(a[keep][:need])
+        out5.append(b[keep][:need])
+        need -= len(out4[-1])
+    cols.append(np.concatenate(out4))
+    cols.append(np.concatenate(out5))
+    # (s6,s7): flat between four cuts
+    cols.append(r.uniform(-1.0, 2.0, N))
+    cols.append(r.uniform(0.0, 1.0, N))
+    names = ["s%d" % i for i in range(8)]
+    ranges = {"s4": (None, 1.2), "s5": (0.3, None), "s6": (-1.0, 2.0), "s7": (0.0, 1.0)}
+    return np.column_stack(cols), names, ranges
+
+
+def periodic_fixture(N=4000):
+    r = _rng(2)
+    angle = r.normal(0, 1, N) % (2 * np.pi)
+    radius = np.abs(r.normal(2, 0.5, N))
+    return np.column_stack([angle, radius]), ["angle", "radius"], {"angle": (0, 2 * np.pi, True), "radius": (0, 5)}
+
+
+def fixture_zoo():
+    """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
+    zoo = []
+    s, w, names, ranges = synth.config_c1(100_000)
+    zoo.append(dict(name="c1_100k", samples=s, weights=w, names=names, ranges=ranges,
+                    pairs=[(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)], kw1=({},), kw2=({},)))
+    s, w, names, ranges = synth.config_c1(20_000, bounded=True)
+    zoo.append(dict(name="c1_bounded", samples=s, weights=w, names=names, ranges=ranges,
+                    pairs=[(0, 3), (2, 3), (3, 2)], kw1=KW1_VARIANTS, kw2=KW2_VARIANTS))
+    s, w, names, ranges = synth.block_recipe(10, 20_000, weighted=True, stream=11)
+    zoo.append(dict(name="block10_weighted", samples=s, weights=w, names=names, ranges=ranges,
+                    pairs=[(0, 1), (0, 5), (5, 6), (4, 9), (3, 4), (8, 9)], kw1=KW1_VARIANTS[:2], kw2=KW2_VARIANTS[:2]))
+    s, w, names, ranges = synth.block_recipe(50, 20_000, weighted=False, stream=12)
+    zoo.append(dict(name="block50", samples=s, weights=w, names=names, ranges=ranges,
+                    pairs=[(15, 16), (20, 21), (25, 26), (30, 31), (35, 36), (40, 41), (38, 39), (48, 49), (39, 49),
+                           (18, 19), (24, 29), (16, 19), (21, 24), (36, 39)], kw1=({},), kw2=({},)))
+    s, names, ranges = shapes_fixture()
+    zoo.append(dict(name="shapes", samples=s, weights=None, names=names, ranges=ranges,
+                    pairs=[(0, 1), (2, 3), (4, 5), (6, 7), (0, 6), (5, 7)], kw1=KW1_VARIANTS, kw2=KW2_VARIANTS[:3]))
+    r = _rng(3)
+    zoo.append(dict(name="shapes_intweights", samples=s, weights=r.integers(1, 6, len(s)).astype(float), names=names,
+                    ranges=ranges, pairs=[(0, 1), (4, 5)], kw1=({},), kw2=({},)))
+    s, names, ranges = periodic_fixture()
+    zoo.append(dict(name="periodic", samples=s, weights=None, names=names, ranges=ranges,
+                    pairs=[(0, 1), (1, 0)], kw1=({}, dict(fine_bins=64)), kw2=(dict(fine_bins_2D=32), dict(fine_bins_2D=64))))
+    return zoo

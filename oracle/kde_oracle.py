@@ -1,0 +1,1050 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Parity status: PINNED against the imported
+reference (oracle/validate_against_reference.py) and the committed fixtures in tests/golden/.
+
+A plain numpy/scipy restatement of GetDist 1.7.7's hot path.  Every function names the reference
+lines it follows (paths relative to /root/reference/getdist).  The arithmetic is deliberately kept
+in the reference's evaluation order (same numpy reductions, same scipy solvers with the same
+arguments) so that results agree with the reference to the last bit on the same numpy/scipy build.
+
+Nothing in ``getdist_amd`` may import this module.
+"""
+
+import numpy as np
+from scipy import fftpack
+from scipy.optimize import brentq, fsolve, minimize
+
+# analysis_defaults.ini:1-76 -- the values actually in force (the ini always overrides the class
+# literals, mcsamples.py:491-492)
+DEFAULT_SETTINGS = dict(
+    range_confidence=0.001,
+    range_ND_contour=-1,
+    fine_bins=1024,
+    smooth_scale_1D=-1.0,
+    boundary_correction_order=1,
+    mult_bias_correction_order=1,
+    smooth_scale_2D=-1.0,
+    max_corr_2D=0.99,
+    fine_bins_2D=256,
+    use_effective_samples_2D=False,
+    num_bins=100,
+    num_bins_2D=40,
+    contours=(0.68, 0.95, 0.99),
+)
+
+
+class BandwidthFailure(Exception):
+    pass
+
+
+# ----------------------------------------------------------------------------------------------
+# FFT sizes (convolve.py:5-193)
+# ----------------------------------------------------------------------------------------------
+def _fft_size_table():
+    # convolve.py:5-190 is a literal table; its content is exactly: 2^a 3^b 5^c for the (b,c) rows
+    # below with the listed ranges of a, plus the two stragglers 7*2^25 and 81*2^24.
+    rows = {(0, 0): (1, 29), (0, 1): (1, 28), (1, 0): (1, 29), (1, 1): (5, 27), (2, 0): (4, 27), (2, 1): (4, 25),
+            (3, 0): (4, 26)}
+    vals = [7 * 2**25, 81 * 2**24]
+    for (b, c), (alo, ahi) in rows.items():
+        vals += [2**a * 3**b * 5**c for a in range(alo, ahi + 1)]
+    return np.array(sorted(vals), dtype=np.int64)
+
+
+FFT_SIZES = _fft_size_table()
+
+
+def nearest_fft_number(x):
+    """convolve.py:192-193"""
+    return np.maximum(x, FFT_SIZES[np.searchsorted(FFT_SIZES, x)])
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutions (convolve.py:196-444)
+# ----------------------------------------------------------------------------------------------
+def _centered(arr, newsize):
+    """convolve.py:439-444"""
+    start = (np.array(arr.shape) - newsize) // 2
+    end = start + newsize
+    return arr[tuple(slice(start[k], end[k]) for k in range(len(end)))]
+
+
+def conv1d_fft(x, y, mode, largest_size=0):
+    """convolve.py:371-401 (no cache: caching only avoids recomputing identical FFTs)"""
+    size = x.size + y.size - 1
+    fsize = nearest_fft_number(np.maximum(largest_size, size))
+    res = np.fft.irfft(np.fft.rfft(x, fsize) * np.fft.rfft(y, fsize))[0:size]
+    if mode == "same":
+        return res[(y.size - 1) // 2:(y.size - 1) // 2 + x.size]
+    if mode == "full":
+        return res
+    if mode == "valid":
+        return res[y.size - 1:x.size]
+    raise ValueError(mode)
+
+
+def conv1d_periodic(x, y):
+    """convolve.py:326-367"""
+    xc = x[:-1].copy()
+    xc[0] += x[-1]
+    n = xc.shape[0]
+    m = y.shape[0]
+    hpad = np.zeros(n, dtype=float)
+    hpad[:m] = y
+    hpad = np.roll(hpad, -(m // 2))
+    res = np.fft.irfft(np.fft.rfft(xc) * np.fft.rfft(hpad), n=n)
+    return np.append(res, res[0])
+
+
+def conv1d(x, y, mode, largest_size=0):
+    """convolve.py:196-202"""
+    if mode == "periodic":
+        return conv1d_periodic(x, y)
+    if min(x.shape[0], y.shape[0]) > 1000:
+        return conv1d_fft(x, y, mode, largest_size)
+    return np.convolve(x, y, mode)
+
+
+def conv2d_fft(in1, in2, mode, largest_size=0):
+    """convolve.py:405-436"""
+    s1 = np.array(in1.shape)
+    s2 = np.array(in2.shape)
+    size = s1 + s2 - 1
+    fsize = nearest_fft_number(np.maximum(largest_size, size))
+    axes = list(range(-len(fsize), 0))
+    xf = np.fft.rfftn(in1, fsize, axes)
+    yf = np.fft.rfftn(in2, fsize, axes)
+    ret = np.fft.irfftn(xf * yf, fsize, axes)[tuple(slice(0, int(sz)) for sz in size)]
+    if mode == "full":
+        return ret
+    if mode == "same":
+        return _centered(ret, s1)
+    if mode == "valid":
+        return _centered(ret, s1 - s2 + 1)
+    raise ValueError(mode)
+
+
+def conv2d_periodic(x, y, periodic_x=True, periodic_y=True):
+    """convolve.py:215-323"""
+    ny, nx = x.shape
+    ky, kx = y.shape
+    if periodic_x and periodic_y:
+        xc = x[:-1, :-1].copy()
+        xc[0, :] += x[-1, :-1]
+        xc[:, 0] += x[:-1, -1]
+        xc[0, 0] += x[-1, -1]
+    elif periodic_x:
+        xc = x[:, :-1].copy()
+        xc[:, 0] += x[:, -1]
+    elif periodic_y:
+        xc = x[:-1, :].copy()
+        xc[0, :] += x[-1, :]
+    else:
+        return conv2d_fft(x, y, "same")
+    n_y, n_x = xc.shape
+    hpad = np.zeros((n_y, n_x), dtype=float)
+    hpad[:ky, :kx] = y
+    hpad = np.roll(hpad, -(ky // 2), axis=0)
+    hpad = np.roll(hpad, -(kx // 2), axis=1)
+    result = np.fft.irfftn(np.fft.rfftn(xc) * np.fft.rfftn(hpad), (n_y, n_x), axes=(0, 1))
+    out = np.empty((ny, nx))
+    if periodic_x and periodic_y:
+        out[:-1, :-1] = result
+        out[-1, :-1] = result[0, :]
+        out[:-1, -1] = result[:, 0]
+        out[-1, -1] = result[0, 0]
+    elif periodic_x:
+        out[:, :-1] = result
+        out[:, -1] = result[:, 0]
+    else:
+        out[:-1, :] = result
+        out[-1, :] = result[0, :]
+    return out
+
+
+def conv2d(x, y, mode, largest_size=0):
+    """convolve.py:205-212"""
+    if mode in ("periodic", "periodic_both"):
+        return conv2d_periodic(x, y, True, True)
+    if mode == "periodic_x":
+        return conv2d_periodic(x, y, True, False)
+    if mode == "periodic_y":
+        return conv2d_periodic(x, y, False, True)
+    return conv2d_fft(x, y, mode, largest_size)
+
+
+def auto_convolve(x, n=None, normalize=True):
+    """convolve.py:458-478: lag sums sum_i x_i x_{i+k}, k=0..n-1 (optionally / number of terms)"""
+    s = nearest_fft_number(2 * x.size)
+    xt = fftpack.rfft(x, s)
+    auto = np.empty((xt.size // 2) + 1)
+    auto[0] = xt[0] ** 2
+    auto[-1] = xt[-1] ** 2
+    auto[1:-1] = xt[1:-2:2] ** 2 + xt[2:-1:2] ** 2
+    n = n or x.size
+    res = fftpack.idct(auto, type=1)[0:n] / s
+    if normalize:
+        res /= np.arange(x.size, x.size - n, -1)
+    return res
+
+
+def dct2d(a):
+    """convolve.py:565-566"""
+    return fftpack.dct(fftpack.dct(a, axis=0), axis=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# 1D ISJ bandwidth (kde_bandwidth.py:47-135)
+# ----------------------------------------------------------------------------------------------
+_ROOTPI = np.sqrt(np.pi)
+_PISQ = np.pi**2
+_LMAX = 7
+# kde_bandwidth.py:50-56
+_CONSTS_1D = np.array([(1 + 0.5 ** (j + 0.5)) / 3 * np.prod(np.arange(1, 2 * j, 2)) / (_ROOTPI / np.sqrt(2.0))
+                       for j in range(_LMAX - 1, 1, -1)])
+
+
+def isj_fixed_point(h, N, I, logI, a2):
+    """kde_bandwidth.py:59-73"""
+    if h <= 0:
+        return h - 1
+    f = 2 * np.pi ** (2 * _LMAX) * np.dot(a2, np.exp(_LMAX * logI - I * (_PISQ * h**2)))
+    for j, const in zip(range(_LMAX - 1, 1, -1), _CONSTS_1D):
+        t_j = (const / N / f) ** (2 / (3.0 + 2 * j))
+        f = 2 * np.pi ** (2 * j) * np.dot(a2, np.exp(j * logI - I * (_PISQ * t_j)))
+        if not f:
+            raise Exception("zero f in _bandwidth_fixed_point (non-convergence)")
+    return h - (2 * N * _ROOTPI * f) ** (-1.0 / 5)
+
+
+def isj_bandwidth_binned(data, Neff):
+    """kde_bandwidth.py:102-135 -- returns hfrac (fraction of the bin range) or None"""
+    import warnings
+
+    I = np.arange(1, data.size) ** 2
+    logI = np.log(I)
+    a = fftpack.dct(data / np.sum(data))
+    a2 = (a[1:] / 2) ** 2
+    try:
+        n_scaling = Neff ** (-1.0 / 5)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hfrac = 0.53 * n_scaling
+            hfrac = fsolve(isj_fixed_point, hfrac, (Neff, I, logI, a2), xtol=hfrac / 20, factor=1)[0]
+        if hfrac < 0.019 * n_scaling:
+            try:
+                hfrac = brentq(isj_fixed_point, 0.019 * n_scaling, 0.5, (Neff, I, logI, a2), xtol=hfrac / 20)
+            except Exception:
+                pass
+        return hfrac
+    except Exception:
+        return None
+
+
+def trunc_bin_samples(samples, range_min=None, range_max=None, nbins=2046, edge_fac=0.1):
+    """kde_bandwidth.py:76-87 (truncating bin index, no +0.5)"""
+    mx = np.max(samples)
+    mn = np.min(samples)
+    delta = mx - mn
+    if range_min is None:
+        range_min = mn - delta * edge_fac
+    if range_max is None:
+        range_max = mx + delta * edge_fac
+    R = range_max - range_min
+    dx = R / (nbins - 1)
+    bins = (samples - range_min) / dx
+    return bins.astype(int), R
+
+
+# ----------------------------------------------------------------------------------------------
+# 2D bandwidth optimiser (kde_bandwidth.py:140-309)
+# ----------------------------------------------------------------------------------------------
+_K = np.array([1 / np.sqrt(2 * np.pi)] +
+              [(-1) ** j * np.prod(np.arange(1, 2 * j, 2)) / np.sqrt(2 * np.pi) for j in range(1, 5)])
+_KODD = np.array([1] + [np.prod(np.arange(1, 2 * j, 2)) / 2.0 ** (j + 1) / np.sqrt(np.pi) for j in range(1, 9)])
+
+
+class Optimizer2D:
+    """kde_bandwidth.py:146-309.  ``trace`` (if a dict) collects intermediate scalars for goldens."""
+
+    def __init__(self, data, Neff, correlation, do_correlation=True, fallback_t=None, trace=None):
+        size = data.shape[0]
+        if size != data.shape[1]:
+            raise ValueError("KernelOptimizer2D only handles square arrays currently")
+        self.a2 = dct2d(data / np.sum(data))[1:, 1:] ** 2
+        self.I = np.arange(1, size, dtype=np.float64) ** 2
+        self.logI = np.log(self.I)
+        self.do_correlation = do_correlation
+        if do_correlation:
+            self.aFFT = np.fft.fft2(data[:, :] / np.sum(data))
+            self.aFFT *= np.conj(self.aFFT)
+        self.N = Neff
+        self.corr = correlation
+        self.trace = trace
+        try:
+            self.t_star = brentq(self.fixed_point_2d, 0, 0.1, xtol=0.001**2)
+            if trace is not None:
+                trace["t_brent"] = self.t_star
+            if fallback_t and self.t_star > 0.01 and self.t_star > 2 * fallback_t:
+                self.t_star = fallback_t
+        except Exception:
+            if fallback_t is not None:
+                self.t_star = fallback_t
+            else:
+                raise
+        if trace is not None:
+            trace["t_star"] = self.t_star
+
+    def fixed_point_2d(self, t):
+        sum_func = self.func2d([0, 2], t) + self.func2d([2, 0], t) + 2 * self.func2d([1, 1], t)
+        time = (2 * np.pi * self.N * sum_func) ** (-1.0 / 3)
+        return (t - time) / time
+
+    def psi(self, s, time):
+        w = -self.I * (_PISQ * time)
+        wx = np.exp(w + self.logI * s[0])
+        wy = np.exp(w + self.logI * s[1])
+        return (-1) ** np.sum(s) * wy.dot(self.a2).dot(wx.T) * np.pi ** (2 * np.sum(s)) / 4
+
+    def func2d(self, s, t):
+        sums = np.sum(s)
+        if sums <= 4:
+            sum_func = self.func2d([s[0] + 1, s[1]], t) + self.func2d([s[0], s[1] + 1], t)
+            const = (1 + 0.5 ** (sums + 1)) / 3
+            time = (-2 * const * _K[s[0]] * _K[s[1]] / self.N / sum_func) ** (1.0 / (2 + sums))
+            return self.psi(s, time)
+        return self.psi(s, t)
+
+    def func2d_odd(self, s, t):
+        sums = np.sum(s)
+        if sums <= 8:
+            sum_func = self.func2d_odd([s[0] + 2, s[1]], t) + self.func2d_odd([s[0], s[1] + 2], t)
+            const = 8 * (1 - 2.0 ** (-sums - 1)) / 3.0
+            time = (const * self.p00 * _KODD[s[0]] * _KODD[s[1]] / self.N**2 / sum_func**2) ** (1.0 / (3 + sums))
+            return self.psi_odd(s, time)
+        return self.psi_odd(s, t)
+
+    def psi_odd(self, s, time):
+        f = np.fft.fftfreq(self.aFFT.shape[0], d=1.0 / self.aFFT.shape[0])
+        w = np.exp(-(f**2) * (4 * _PISQ * time))
+        wx = w * f ** s[0]
+        wy = w * f ** s[1]
+        return wy.dot(self.aFFT).real.dot(wx.T) * (2 * np.pi) ** (np.sum(s))
+
+    def amise(self, cov, corr=None):
+        hx = cov[0]
+        hy = cov[1]
+        c = corr if corr is not None else cov[2]
+        var = 1.0 / (4 * np.pi * hx * hy * np.sqrt(1 - c**2) * self.N)
+        bias = 0.25 * (hx**4 * self.p[4, 0] + hy**4 * self.p[0, 4] + 2 * hx**2 * hy**2 * self.p[2, 2] * (2 * c**2 + 1)
+                       + 4 * c * hx * hy * (hx**2 * self.p[3, 1] + hy**2 * self.p[1, 3]))
+        if bias < 0:
+            raise Exception("bias not positive definite")
+        return var + bias
+
+    def get_h(self, do_correlation=None):
+        if do_correlation is None:
+            do_correlation = self.do_correlation
+        p = np.zeros((5, 5))
+        tpsi = self.t_star
+        p_02 = self.func2d([0, 2], tpsi)
+        p_20 = self.func2d([2, 0], tpsi)
+        p_11 = self.func2d([1, 1], tpsi)
+        h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * self.N * p_20 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+        h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * self.N * p_02 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+        if self.trace is not None:
+            self.trace.update(p_02=p_02, p_20=p_20, p_11=p_11, h_x0=h_x, h_y0=h_y)
+        corr = 0
+        if not do_correlation:
+            return h_x, h_y, corr
+        p[0, 4] = p_02
+        p[4, 0] = p_20
+        p[2, 2] = p_11
+        p[0, 0] = self.func2d([0, 0], tpsi)
+        self.p00 = p[0, 0]
+        p[1, 3] = self.func2d_odd([1, 3], tpsi)
+        p[3, 1] = self.func2d_odd([3, 1], tpsi)
+        self.p = p
+        if self.trace is not None:
+            self.trace.update(p_00=p[0, 0], p_13=p[1, 3], p_31=p[3, 1])
+        AMISE = self.amise(np.array([h_x, h_y, 0]))
+        if self.corr:
+            try:
+                res = minimize(self.amise, np.array([h_x, h_y]) / np.sqrt(1 - abs(self.corr)), (self.corr,),
+                               method="TNC", bounds=[(0.001, 0.3), (0.001, 0.3)])
+                if res.success:
+                    AMISEcorr = self.amise(res.x, self.corr)
+                    if AMISEcorr < AMISE:
+                        h_x, h_y = res.x
+                        corr = self.corr
+                        AMISE = AMISEcorr
+            except Exception:
+                pass
+        try:
+            res = minimize(self.amise, np.array([h_x, h_y, self.corr]), (None,), method="TNC",
+                           bounds=[(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)])
+            if res.success:
+                AMISEopt = self.amise(res.x)
+                if AMISEopt < AMISE * 0.9:
+                    h_x, h_y, corr = res.x
+        except Exception:
+            pass
+        return h_x, h_y, corr
+
+
+# ----------------------------------------------------------------------------------------------
+# contour levels (densities.py:19-56)
+# ----------------------------------------------------------------------------------------------
+def contour_levels(inbins, contours=(0.68, 0.95), missing_norm=0, half_edge=True):
+    levels = np.zeros(len(contours))
+    if half_edge:
+        abins = inbins.copy()
+        last = [-1] + [slice(None, None, None) for _ in abins.shape[1:]]
+        first = [0] + [slice(None, None, None) for _ in abins.shape[1:]]
+        for _ in abins.shape:
+            abins[tuple(last)] /= 2
+            abins[tuple(first)] /= 2
+            last = np.roll(last, 1)
+            first = np.roll(first, 1)
+    else:
+        abins = inbins
+    norm = np.sum(abins)
+    targets = (1 - np.array(contours)) * norm - missing_norm
+    bins = abins.reshape(-1)
+    indexes = inbins.reshape(-1).argsort()
+    sortgrid = bins[indexes]
+    cumsum = np.cumsum(sortgrid)
+    ixs = np.searchsorted(cumsum, targets)
+    for i, ix in enumerate(ixs):
+        if ix == 0:
+            raise ValueError("Contour level outside plotted ranges")
+        h = cumsum[ix] - cumsum[ix - 1]
+        d = (cumsum[ix] - targets[i]) / h
+        levels[i] = sortgrid[ix] * (1 - d) + d * sortgrid[ix - 1]
+    return levels
+
+
+# ----------------------------------------------------------------------------------------------
+# per-parameter state (paramnames.py:69-154 attributes written by the hot path)
+# ----------------------------------------------------------------------------------------------
+class ParamState:
+    def __init__(self, name, limmin=None, limmax=None, periodic=False):
+        self.name = name
+        self.limmin = limmin
+        self.limmax = limmax
+        self.periodic = periodic
+        self.N_eff_kde = None
+        self.kde_h = None
+        self.reset_limits()
+
+    def reset_limits(self):
+        """mcsamples.py:461-465"""
+        self.has_limits_bot = self.limmin is not None
+        self.has_limits_top = self.limmax is not None
+
+
+class Kernel1D:
+    """mcsamples.py:129-135"""
+
+    def __init__(self, winw, h):
+        self.winw = winw
+        self.h = h
+        self.x = np.arange(-winw, winw + 1)
+        Win = np.exp(-((self.x / h) ** 2) / 2.0)
+        self.Win = Win / np.sum(Win)
+
+
+class OracleSamples:
+    """
+    The weighted-sample statistics + KDE path of chains.WeightedSamples / mcsamples.MCSamples,
+    restated over plain arrays.  ``samples`` is (N, n) row-major like the reference's.
+    """
+
+    def __init__(self, samples, weights=None, names=None, ranges=None, settings=None, sampler="mcmc", periodic=()):
+        samples = np.asarray(samples, dtype=np.float64)
+        if samples.ndim == 1:
+            samples = samples.reshape(-1, 1)
+        self.samples = samples
+        self.numrows, self.n = samples.shape
+        # chains.py:310-316
+        if weights is not None:
+            self.weights = np.asarray(weights, dtype=np.float64)
+            self.norm = np.sum(self.weights)
+        else:
+            self.weights = np.ones(self.numrows)
+            self.norm = np.float64(self.numrows)
+        self.sampler = sampler
+        self.settings = dict(DEFAULT_SETTINGS)
+        if settings:
+            self.settings.update(settings)
+        self.names = list(names) if names is not None else ["param%d" % (i + 1) for i in range(self.n)]
+        self.index = {nm: i for i, nm in enumerate(self.names)}
+        ranges = ranges or {}
+        self.pars = []
+        for nm in self.names:
+            r = tuple(ranges.get(nm, (None, None)))
+            lo, hi = r[0], r[1]
+            is_periodic = nm in periodic or (len(r) > 2 and bool(r[2]))  # parampriors.py:6-139 triplet form
+            self.pars.append(ParamState(nm, lo, hi, is_periodic))
+        self.update_base_statistics()
+
+    # ---- moments (chains.py:373-412, 709-780) ------------------------------------------------
+    def update_base_statistics(self):
+        """chains.py:1340-1352 + mcsamples.py:552-576"""
+        w = self.weights
+        self.means = w.dot(self.samples) / self.norm  # chains.py:379
+        self.vars = np.empty(self.n)
+        for i in range(self.n):  # chains.py:409-410
+            self.vars[i] = w.dot((self.samples[:, i] - self.means[i]) ** 2) / self.norm
+        self.sddev = np.sqrt(self.vars)
+        self.mean_mult = self.norm / self.numrows
+        self.max_mult = np.max(w)
+        self.fullcov = self.cov()
+        self.corrmat = cov_to_corr(self.fullcov)
+        for p in self.pars:
+            p.reset_limits()
+            p.N_eff_kde = None
+
+    def mean(self, vec):
+        """chains.py:665-677"""
+        return self.weights.dot(vec) / self.norm
+
+    def var(self, vec):
+        """chains.py:679-694"""
+        return np.dot((vec - self.mean(vec)) ** 2, self.weights) / self.norm
+
+    def cov(self, pars=None):
+        """chains.py:709-733 (two-pass, upper triangle of dot products)"""
+        if pars is None:
+            pars = list(range(self.n))
+        diffs = [self.samples[:, i] - self.means[i] for i in pars]
+        n = len(pars)
+        cov = np.empty((n, n))
+        for i, diff in enumerate(diffs):
+            wd = diff * self.weights
+            for j in range(i, n):
+                cov[i, j] = wd.dot(diffs[j])
+                cov[j, i] = cov[i, j]
+        cov /= self.norm
+        return cov
+
+    # ---- weighted quantiles (chains.py:793-838) -----------------------------------------------
+    def confidence_data(self, vec):
+        idx = vec.argsort()
+        return vec, np.sum(self.weights), idx, np.cumsum(self.weights[idx])
+
+    def confidence(self, cd, limfrac, upper=False):
+        vec, norm, idx, cumsum = cd
+        target = norm * limfrac if not upper else norm * (1 - limfrac)
+        ix = np.searchsorted(cumsum, target)
+        return vec[idx[np.minimum(ix, idx.shape[0] - 1)]]
+
+    # ---- autocorrelation / N_eff (chains.py:423-574) -------------------------------------------
+    def autocorrelation(self, vec, max_off, weight_units=True, normalized=True):
+        d = (vec - self.mean(vec)) * self.weights
+        corr = auto_convolve(d, n=max_off + 1, normalize=True)
+        if normalized:
+            corr /= self.var(vec)
+        if weight_units:
+            return corr * d.size / self.norm
+        return corr
+
+    def correlation_length(self, vec, weight_units=True, min_corr=0.05):
+        corr = self.autocorrelation(vec, self.numrows // 10, weight_units=weight_units)
+        ix = np.argmin(corr > min_corr * corr[0])
+        return corr[0] + 2 * np.sum(corr[1:ix])
+
+    def neff_gaussian_kde(self, vec, h=0.2, scale=None, maxoff=None, min_corr=0.05):
+        """chains.py:477-574"""
+        w = self.weights
+        if self.sampler in ("nested", "uncorrelated"):
+            return self.norm**2 / np.dot(w, w)
+        d = vec
+        kernel_std = (scale or np.sqrt(self.var(d))) * h
+        if maxoff is None:
+            maxoff = int(self.correlation_length(d, weight_units=False) * 1.5) + 4
+        maxoff = min(maxoff, self.numrows // 10)
+        uncorr_len = self.numrows // 2
+        uncorr_term = 0
+        nav = 0
+        for k in range(uncorr_len, uncorr_len + 5):
+            nav += self.numrows - k
+            diff2 = (d[:-k] - d[k:]) ** 2 / kernel_std**2
+            uncorr_term += np.dot(np.exp(-diff2 / 4) * w[:-k], w[k:])
+        uncorr_term /= nav
+        corr = np.zeros(maxoff + 1)
+        corr[0] = np.dot(w, w)
+        n = float(self.numrows)
+
+        def corr_k(_k):
+            return (np.dot(np.exp(-((d[:-_k] - d[_k:]) ** 2) / (4 * kernel_std**2)) * w[:-_k], w[_k:])
+                    - (n - _k) * uncorr_term)
+
+        threshold = min_corr * corr[0]
+        corr[1] = corr_k(1)
+        if corr[1] < threshold:
+            N = corr[0]
+        else:
+            corr[2] = corr_k(2)
+            if corr[2] > threshold:
+                max_k = maxoff
+                while max_k > 10:
+                    test_val = corr_k(max_k // 3)
+                    if test_val >= threshold:
+                        break
+                    max_k //= 3
+                step_size = 1 if max_k < 20 else max_k // 10
+                cum_sum = corr[1] + corr[2]
+                for k in range(3, maxoff + 1, step_size):
+                    test_val = corr_k(k)
+                    if test_val < threshold:
+                        break
+                    if k > 3:
+                        cum_sum += test_val * step_size
+                    else:
+                        cum_sum += (test_val * step_size) / 2
+                N = corr[0] + 2 * cum_sum
+            else:
+                N = corr[0] + 2 * corr[1]
+        return self.norm**2 / N
+
+    def neff_1d(self, j):
+        """mcsamples.py:1230-1235"""
+        par = self.pars[j]
+        if par.N_eff_kde is None:
+            par.N_eff_kde = self.neff_gaussian_kde(self.samples[:, j], scale=par.sigma_range)
+        return par.N_eff_kde
+
+    # ---- ranges and limits (mcsamples.py:1421-1484) -------------------------------------------
+    def init_param(self, j):
+        par = self.pars[j]
+        vec = self.samples[:, j]
+        par.err = self.sddev[j]
+        par.mean = self.means[j]
+        par.param_min = np.min(vec)
+        par.param_max = np.max(vec)
+        cd = self.confidence_data(vec)
+        rc = self.settings["range_confidence"]
+        confids = self.confidence(cd, np.array([rc, 1 - rc] + list(np.linspace(0.1, 0.9, 9))))
+        par.range_min, par.range_max = confids[0:2]
+        confids[1:-1] = confids[2:]
+        confids[0] = par.param_min
+        confids[-1] = par.param_max
+        diffs = confids[4:] - confids[:-4]
+        scale = np.min(diffs) / 1.049
+        if np.all(diffs > par.err * 1.049) and np.all(diffs < scale * 1.5):
+            par.sigma_range = scale
+        else:
+            par.sigma_range = min(par.err, scale)
+        smooth = par.sigma_range * 0.4
+        if par.has_limits_bot:
+            if par.range_min - par.limmin > 2 * smooth and par.param_min - par.limmin > smooth:
+                par.has_limits_bot = False
+            else:
+                par.range_min = par.limmin
+        if par.has_limits_top:
+            if par.limmax - par.range_max > 2 * smooth and par.limmax - par.param_max > smooth:
+                par.has_limits_top = False
+            else:
+                par.range_max = par.limmax
+        if not par.has_limits_bot:
+            par.range_min -= smooth * 2
+        if not par.has_limits_top:
+            par.range_max += smooth * 2
+        par.has_limits = par.has_limits_top or par.has_limits_bot
+        return par
+
+    def bin_samples(self, vec, par, num_fine_bins, borderfrac=0.1):
+        """mcsamples.py:1486-1498"""
+        border = (par.range_max - par.range_min) * borderfrac
+        binmin = min(par.param_min, par.range_min)
+        if not par.has_limits_bot:
+            binmin -= border
+        binmax = max(par.param_max, par.range_max)
+        if not par.has_limits_top:
+            binmax += border
+        fine_width = (binmax - binmin) / (num_fine_bins - 1)
+        ix = ((vec - binmin) / fine_width + 0.5).astype(int)
+        return ix, fine_width, binmin, binmax
+
+    # ---- 1D density (mcsamples.py:1237-1283, 1517-1686) ---------------------------------------
+    def auto_bandwidth_1d(self, bins, j, mult_bias_correction_order, kernel_order=1, trace=None):
+        par = self.pars[j]
+        N_eff = self.neff_1d(j)
+        h = isj_bandwidth_binned(bins, N_eff)
+        if trace is not None:
+            trace["h_isj"] = h
+        bin_range = max(par.param_max, par.range_max) - min(par.param_min, par.range_min)
+        if h is None or h < 0.01 * N_eff ** (-1.0 / 5) * (par.range_max - par.range_min) / bin_range:
+            h = 1.06 * par.sigma_range * N_eff ** (-1.0 / 5) / bin_range
+        par.kde_h = h
+        m = mult_bias_correction_order
+        if kernel_order > 1:
+            m = max(m, 1)
+        if m:
+            return h * N_eff ** (1.0 / 5 - 1.0 / (4 * m + 5))
+        return h
+
+    def density_1d(self, j, trace=None, **kwargs):
+        """Returns dict(x, P, view_ranges, + intermediates).  mcsamples.py:1517-1686 (no meanlikes)."""
+        if isinstance(j, str):
+            j = self.index[j]
+        S = self.settings
+        par = self.init_param(j)
+        num_bins = kwargs.get("num_bins", S["num_bins"])
+        smooth_scale_1D = kwargs.get("smooth_scale_1D", S["smooth_scale_1D"])
+        bco = kwargs.get("boundary_correction_order", S["boundary_correction_order"])
+        mbc = kwargs.get("mult_bias_correction_order", S["mult_bias_correction_order"])
+        fine_bins = kwargs.get("fine_bins", S["fine_bins"])
+        paramrange = par.range_max - par.range_min
+        if paramrange <= 0:
+            raise ValueError("Parameter range is <= 0: " + par.name)
+        width = paramrange / (num_bins - 1)
+        ix_, fine_width, binmin, binmax = self.bin_samples(self.samples[:, j], par, fine_bins)
+        bins = np.bincount(ix_, weights=self.weights, minlength=fine_bins)
+        if smooth_scale_1D <= 0:
+            bandwidth = self.auto_bandwidth_1d(bins, j, mbc, bco, trace=trace) * (binmax - binmin)
+            bandwidth = min(bandwidth, paramrange / 4)
+            smooth_1D = bandwidth * abs(smooth_scale_1D) / fine_width
+        elif smooth_scale_1D < 1.0:
+            smooth_1D = smooth_scale_1D * par.err / fine_width
+        else:
+            smooth_1D = smooth_scale_1D * width / fine_width
+        smooth_1D = min(max(1.0, smooth_1D), fine_bins // 2)
+        winw = min(int(round(2.5 * smooth_1D)), ((fine_bins - 1) if par.periodic else fine_bins) // 2 - 2)
+        kernel = Kernel1D(winw, smooth_1D)
+        mode = "periodic" if par.periodic else "same"
+        P = conv1d(bins, kernel.Win, mode)
+        fine_x = np.linspace(binmin, binmax, fine_bins)
+        if par.has_limits and not par.periodic and bco >= 0:
+            prior_mask = np.ones(fine_bins + 2 * winw)
+            if par.has_limits_bot:
+                prior_mask[winw] = 0.5
+                prior_mask[:winw] = 0
+            if par.has_limits_top:
+                prior_mask[-(winw + 1)] = 0.5
+                prior_mask[-winw:] = 0
+            a0 = conv1d(prior_mask, kernel.Win, "valid")
+            ix = np.nonzero(a0 * P)
+            a0 = a0[ix]
+            normed = P[ix] / a0
+            if bco == 0:
+                P[ix] = normed
+            elif bco <= 2:
+                xWin = kernel.Win * kernel.x
+                a1 = conv1d(prior_mask, xWin, "valid")[ix]
+                a2 = conv1d(prior_mask, xWin * kernel.x, "valid")[ix]
+                xP = conv1d(bins, xWin, "same")[ix]
+                if bco == 1:
+                    corrected = (P[ix] * a2 - xP * a1) / (a0 * a2 - a1**2)
+                else:
+                    a3 = conv1d(prior_mask, xWin * kernel.x**2, "valid")[ix]
+                    a4 = conv1d(prior_mask, xWin * kernel.x**3, "valid")[ix]
+                    x2P = conv1d(bins, xWin * kernel.x, "same")[ix]
+                    denom = a4 * a2 * a0 - a4 * a1**2 - a2**3 - a3**2 * a0 + 2 * a1 * a2 * a3
+                    A = a4 * a2 - a3**2
+                    B = a2 * a3 - a4 * a1
+                    C = a3 * a1 - a2**2
+                    corrected = (P[ix] * A + xP * B + x2P * C) / denom
+                P[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+            else:
+                raise ValueError("Unknown boundary_correction_order (expected 0, 1, 2)")
+        elif not par.periodic and bco == 2:
+            xWin2 = kernel.Win * kernel.x**2
+            x2P = conv1d(bins, xWin2, "same")
+            a2 = np.sum(xWin2)
+            a4 = np.dot(xWin2, kernel.x**2)
+            corrected = (P * a4 - a2 * x2P) / (a4 - a2**2)
+            ix = P > 0
+            P[ix] *= np.exp(np.minimum(corrected[ix] / P[ix], 2) - 1)
+        if mbc:
+            if not par.periodic:
+                prior_mask = np.ones(fine_bins)
+                if par.has_limits_bot:
+                    prior_mask[0] *= 0.5
+                if par.has_limits_top:
+                    prior_mask[-1] *= 0.5
+                a0 = conv1d(prior_mask, kernel.Win, "same")
+            for _ in range(mbc):
+                prob1 = P.copy()
+                prob1[prob1 == 0] = 1
+                fine = bins / prob1
+                conv = conv1d(fine, kernel.Win, mode)
+                P = P * conv
+                if not par.periodic:
+                    P /= a0
+        mx = np.max(P)
+        if mx == 0:
+            raise ValueError("no samples in bin")
+        P /= mx
+        return dict(x=fine_x, P=P, view_ranges=[par.range_min, par.range_max], bins=bins, ix=ix_, binmin=binmin,
+                    binmax=binmax, fine_width=fine_width, winw=winw, smooth_1D=smooth_1D)
+
+    # ---- 2D density (mcsamples.py:1285-1419, 1748-2010) ---------------------------------------
+    def make_2d_hist(self, ixs, iys, xsize, ysize):
+        """mcsamples.py:1724-1728"""
+        flatix = ixs + iys * xsize
+        return np.bincount(flatix, weights=self.weights, minlength=xsize * ysize).reshape((ysize, xsize)), flatix
+
+    def auto_bandwidth_2d(self, bins, jx, jy, corr, rangex, rangey, base_fine_bins_2D, mbc, min_corr=0.2, trace=None):
+        parx, pary = self.pars[jx], self.pars[jy]
+        S = self.settings
+        max_corr = S["max_corr_2D"]
+        if S["use_effective_samples_2D"] and abs(corr) < 0.999:
+            raise NotImplementedError("use_effective_samples_2D (off by default) is not restated")
+        N_eff = min(self.neff_1d(jx), self.neff_1d(jy))
+        has_limits = parx.has_limits or pary.has_limits
+        do_correlated = not parx.has_limits or not pary.has_limits
+
+        def fallback_widths():
+            _hx = parx.sigma_range / N_eff ** (1.0 / 6)
+            _hy = pary.sigma_range / N_eff ** (1.0 / 6)
+            return _hx, _hy, max(min(corr, max_corr), -max_corr)
+
+        branch = None
+        if min_corr < abs(corr) <= max_corr and do_correlated:
+            branch = "A"
+            i, j = jx, jy
+            imax, imin = None, None
+            if parx.has_limits_bot:
+                imin = parx.range_min
+            if parx.has_limits_top:
+                imax = parx.range_max
+            if pary.has_limits:
+                i, j = j, i
+                if pary.has_limits_bot:
+                    imin = pary.range_min
+                if pary.has_limits_top:
+                    imax = pary.range_max
+            cov = self.fullcov[np.ix_([i, j], [i, j])]
+            Sm = np.linalg.cholesky(cov)
+            ichol = np.linalg.inv(Sm)
+            Sm *= ichol[0, 0]
+            r = ichol[1, :] / ichol[0, 0]
+            p1 = self.samples[:, i]
+            p2 = r[0] * self.samples[:, i] + r[1] * self.samples[:, j]
+            bin1, r1 = trunc_bin_samples(p1, nbins=base_fine_bins_2D, range_min=imin, range_max=imax)
+            bin2, r2 = trunc_bin_samples(p2, nbins=base_fine_bins_2D)
+            rotbins, _ = self.make_2d_hist(bin1, bin2, base_fine_bins_2D, base_fine_bins_2D)
+            if trace is not None:
+                trace.update(rot_r=r, rot_r1=r1, rot_r2=r2, rot_sum=float(np.sum(rotbins)))
+            try:
+                opt = Optimizer2D(rotbins, N_eff, 0, do_correlation=not has_limits, trace=trace)
+                hx, hy, c = opt.get_h()
+                hx *= r1
+                hy *= r2
+                kernelC = Sm.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(Sm.T)
+                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
+                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
+                if pary.has_limits:
+                    hx, hy = hy, hx
+            except ValueError:
+                hx, hy, c = fallback_widths()
+        elif abs(corr) > max_corr or not do_correlated and corr > 0.8:
+            branch = "B"
+            c = max(min(corr, max_corr), -max_corr)
+            hx = parx.sigma_range / N_eff ** (1.0 / 6)
+            hy = pary.sigma_range / N_eff ** (1.0 / 6)
+        else:
+            branch = "C"
+            try:
+                opt = Optimizer2D(bins, N_eff, corr, do_correlation=not has_limits,
+                                  fallback_t=(min(pary.sigma_range / rangey, parx.sigma_range / rangex)
+                                              / N_eff ** (1.0 / 6)) ** 2, trace=trace)
+                hx, hy, c = opt.get_h()
+                hx *= rangex
+                hy *= rangey
+            except ValueError:
+                hx, hy, c = fallback_widths()
+        if mbc:
+            scale = 1.1 * N_eff ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + mbc)))
+            hx *= scale
+            hy *= scale
+        if trace is not None:
+            trace.update(branch=branch, N_eff=N_eff, hx=hx, hy=hy, c=c)
+        return hx, hy, c
+
+    def density_2d(self, j, j2, trace=None, **kwargs):
+        """Returns dict(x, y, P[y,x], view_ranges, ...).  mcsamples.py:1748-2010 (no meanlikes/mask_function)."""
+        if isinstance(j, str):
+            j = self.index[j]
+        if isinstance(j2, str):
+            j2 = self.index[j2]
+        S = self.settings
+        parx = self.init_param(j)
+        pary = self.init_param(j2)
+        base_fine_bins_2D = kwargs.get("fine_bins_2D", S["fine_bins_2D"])
+        bco = kwargs.get("boundary_correction_order", S["boundary_correction_order"])
+        mbc = kwargs.get("mult_bias_correction_order", S["mult_bias_correction_order"])
+        smooth_scale_2D = float(kwargs.get("smooth_scale_2D", S["smooth_scale_2D"]))
+        max_corr = S["max_corr_2D"]
+        has_prior = parx.has_limits or pary.has_limits
+        corr = self.corrmat[j2][j]
+        actual_corr = corr
+        if abs(abs(corr) - 1.0) <= 1e-8:
+            corr = np.sign(corr) * max_corr
+        if abs(corr) < 0.1:
+            corr = 0.0
+        angle_scale = max(0.2, np.sqrt(1 - min(max_corr, abs(corr)) ** 2))
+        nbin2D = int(round(S["num_bins_2D"] / angle_scale))
+        fine_bins_2D = base_fine_bins_2D
+        if corr:
+            scaled = 192 * int(3 / angle_scale) // 3
+            if base_fine_bins_2D < scaled and int(1 / angle_scale) > 1:
+                fine_bins_2D = scaled
+        ixs, finewidthx, xbinmin, xbinmax = self.bin_samples(self.samples[:, j], parx, fine_bins_2D)
+        iys, finewidthy, ybinmin, ybinmax = self.bin_samples(self.samples[:, j2], pary, fine_bins_2D)
+        xsize = ysize = fine_bins_2D
+        histbins, flatix = self.make_2d_hist(ixs, iys, xsize, ysize)
+        if smooth_scale_2D < 0:
+            rx, ry, corr = self.auto_bandwidth_2d(histbins, j, j2, actual_corr, xbinmax - xbinmin, ybinmax - ybinmin,
+                                                  base_fine_bins_2D, mbc, trace=trace)
+            rx = rx * abs(smooth_scale_2D) / finewidthx
+            ry = ry * abs(smooth_scale_2D) / finewidthy
+        elif smooth_scale_2D < 1.0:
+            rx = smooth_scale_2D * parx.err / finewidthx
+            ry = smooth_scale_2D * pary.err / finewidthy
+        else:
+            rx = smooth_scale_2D * fine_bins_2D / nbin2D
+            ry = smooth_scale_2D * fine_bins_2D / nbin2D
+        smooth_scale = float(max(rx, ry))
+        winw = max(1, int(round(2.5 * smooth_scale)))
+        Cinv = np.linalg.inv(np.array([[ry**2, rx * ry * corr], [rx * ry * corr, rx**2]]))
+        ix1, ix2 = np.mgrid[-winw:winw + 1, -winw:winw + 1]
+        Win = np.exp(-(ix1**2 * Cinv[0, 0] + ix2**2 * Cinv[1, 1] + 2 * Cinv[1, 0] * ix1 * ix2) / 2)
+        Win /= np.sum(Win)
+        convolvesize = xsize + 2 * winw + Win.shape[0]
+        if parx.periodic and pary.periodic:
+            mode = "periodic_both"
+        elif parx.periodic:
+            mode = "periodic_x"
+        elif pary.periodic:
+            mode = "periodic_y"
+        else:
+            mode = "same"
+        bins2D = conv2d(histbins, Win, mode, largest_size=convolvesize)
+        if has_prior and bco >= 0 or mbc:
+            prior_mask = np.ones((ysize + 2 * winw, xsize + 2 * winw))
+        if has_prior and bco >= 0 and not (parx.periodic and pary.periodic):
+            _set_edge_mask_2d(parx, pary, prior_mask, winw)
+            a00 = conv2d(prior_mask, Win, "valid", largest_size=convolvesize)
+            ix = a00 * bins2D > np.max(bins2D) * 1e-8
+            a00 = a00[ix]
+            normed = bins2D[ix] / a00
+            if bco == 0:
+                bins2D[ix] = normed
+            elif bco == 1:
+                indexes = np.arange(-winw, winw + 1)
+                y = np.empty(Win.shape)
+                for i in range(Win.shape[0]):
+                    y[:, i] = indexes
+                winx = Win * indexes
+                winy = Win * y
+                a10 = conv2d(prior_mask, winx, "valid", largest_size=convolvesize)[ix]
+                a01 = conv2d(prior_mask, winy, "valid", largest_size=convolvesize)[ix]
+                a20 = conv2d(prior_mask, winx * indexes, "valid", largest_size=convolvesize)[ix]
+                a02 = conv2d(prior_mask, winy * y, "valid", largest_size=convolvesize)[ix]
+                a11 = conv2d(prior_mask, winy * indexes, "valid", largest_size=convolvesize)[ix]
+                xP = conv2d(histbins, winx, mode, largest_size=convolvesize)[ix]
+                yP = conv2d(histbins, winy, mode, largest_size=convolvesize)[ix]
+                denom = a20 * a01**2 + a10**2 * a02 - a00 * a02 * a20 + a11**2 * a00 - 2 * a01 * a10 * a11
+                A = a11**2 - a02 * a20
+                Ax = a10 * a02 - a01 * a11
+                Ay = a01 * a20 - a10 * a11
+                corrected = (bins2D[ix] * A + xP * Ax + yP * Ay) / denom
+                bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+            else:
+                raise ValueError("unknown boundary_correction_order (expected 0 or 1)")
+        if mbc and not (parx.periodic and pary.periodic):
+            _set_all_edge_mask_2d(prior_mask, winw, parx.periodic, pary.periodic)
+            a00 = conv2d(prior_mask, Win, "valid", largest_size=convolvesize)
+            for _ in range(mbc):
+                box = histbins.copy()
+                ix2_ = bins2D > np.max(bins2D) * 1e-8
+                box[ix2_] /= bins2D[ix2_]
+                bins2D *= conv2d(box, Win, mode, largest_size=convolvesize)
+                bins2D /= a00
+        x = np.linspace(xbinmin, xbinmax, xsize)
+        y = np.linspace(ybinmin, ybinmax, ysize)
+        mx = np.max(bins2D)
+        if mx == 0:
+            raise ValueError("no samples in bin")
+        bins2D /= mx
+        if trace is not None:
+            trace.update(fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr_used=corr, actual_corr=actual_corr)
+        return dict(x=x, y=y, P=bins2D, view_ranges=[(parx.range_min, parx.range_max), (pary.range_min, pary.range_max)],
+                    histbins=histbins, flatix=flatix, fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr=corr)
+
+    # ---- convergence (chains.py:1446-1486; mcsamples.py:964-985) --------------------------------
+    def gelman_rubin_eigenvalues(self, chain_offsets, nparam=None):
+        nparam = nparam or self.n
+        chains = [OracleSamples(self.samples[a:b], self.weights[a:b])
+                  for a, b in zip(chain_offsets[:-1], chain_offsets[1:])]
+        meanscov = np.zeros((nparam, nparam))
+        means = self.means[:nparam]
+        meancov = np.zeros(meanscov.shape)
+        for ch in chains:
+            diff = ch.means[:nparam] - means
+            meanscov += np.outer(diff, diff)
+            meancov += ch.fullcov[:nparam, :nparam]
+        meanscov /= len(chains) - 1
+        meancov /= len(chains)
+        w, U = np.linalg.eigh(meancov)
+        if np.min(w) > 0:
+            U /= np.sqrt(w)
+            return np.linalg.eigvalsh(np.dot(U.T, meanscov).dot(U))
+        return None
+
+    def mean_var_test(self, chain_offsets, nparam=None):
+        """mcsamples.py:964-985: sqrt(var(chain means) / mean(chain var)) per parameter"""
+        nparam = nparam or self.n
+        chains = [OracleSamples(self.samples[a:b], self.weights[a:b])
+                  for a, b in zip(chain_offsets[:-1], chain_offsets[1:])]
+        between = np.zeros(nparam)
+        within = np.zeros(nparam)
+        for ch in chains:
+            between += (ch.means[:nparam] - self.means[:nparam]) ** 2
+        between /= len(chains) - 1
+        for j in range(nparam):
+            for ch in chains:
+                within[j] += np.dot(ch.weights, (ch.samples[:, j] - ch.means[j]) ** 2)
+            within[j] /= self.norm
+        return np.sqrt(between / within)
+
+
+def cov_to_corr(cov):
+    """chains.py:155-169"""
+    cov = cov.copy()
+    for i, di in enumerate(np.sqrt(cov.diagonal())):
+        if di:
+            cov[i, :] /= di
+            cov[:, i] /= di
+    return cov
+
+
+def _set_edge_mask_2d(parx, pary, prior_mask, winw):
+    """mcsamples.py:1688-1703"""
+    if not parx.periodic:
+        if parx.has_limits_bot:
+            prior_mask[:, winw] /= 2
+            prior_mask[:, :winw] = 0
+        if parx.has_limits_top:
+            prior_mask[:, -(winw + 1)] /= 2
+            prior_mask[:, -winw:] = 0
+    if not pary.periodic:
+        if pary.has_limits_bot:
+            prior_mask[winw, :] /= 2
+            prior_mask[:winw:] = 0
+        if pary.has_limits_top:
+            prior_mask[-(winw + 1), :] /= 2
+            prior_mask[-winw:, :] = 0
+
+
+def _set_all_edge_mask_2d(prior_mask, winw, periodic_x=False, periodic_y=False):
+    """mcsamples.py:1705-1712"""
+    if not periodic_x:
+        prior_mask[:, :winw] = 0
+        prior_mask[:, -winw:] = 0
+    if not periodic_y:
+        prior_mask[:winw:] = 0
+        prior_mask[-winw:, :] = 0

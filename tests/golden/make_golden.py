@@ -1,0 +1,139 @@
+"""
+Generates tests/golden/*.npz by importing the REAL GetDist 1.7.7 from /root/reference (build container
+only; the reference never travels).  Inputs are regenerated on any box from seeds by
+oracle/fixtures.py + getdist_amd/synth.py, so only reference OUTPUTS are stored here.
+
+    python tests/golden/make_golden.py
+"""
+
+import logging
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from getdist import MCSamples  # noqa: E402  (the reference)
+from getdist.convolve import nearestFFTnumber  # noqa: E402
+
+from getdist_amd import synth  # noqa: E402
+from oracle.fixtures import fixture_zoo  # noqa: E402
+
+logging.getLogger().setLevel(logging.ERROR)
+
+PAR_ATTS = ("param_min", "param_max", "range_min", "range_max", "sigma_range", "err", "mean", "has_limits_bot",
+            "has_limits_top", "N_eff_kde", "kde_h")
+FULL_GRID_PAIRS = 1  # pairs per fixture whose full default-settings P grid is stored (others: strided)
+
+
+def kwkey(kw):
+    return ",".join("%s=%s" % (k, kw[k]) for k in sorted(kw)) or "default"
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def golden_for_fixture(name, samples, weights, names, ranges, pairs, kw1, kw2):
+    out = {}
+    ref = MCSamples(samples=np.ascontiguousarray(samples), weights=weights, names=names, ranges=ranges)
+    out["means"] = ref.means
+    out["vars"] = ref.vars
+    out["cov"] = ref.fullcov
+    out["corr"] = ref.getCorrelationMatrix()
+    fracs = np.array([0.001, 0.999] + list(np.linspace(0.1, 0.9, 9)))
+    out["quantile_fracs"] = fracs
+    out["quantiles"] = np.array([ref.confidence(j, fracs) for j in range(len(names))])
+    for j, nm in enumerate(names):
+        for kw in kw1:
+            d = ref.get1DDensityGridData(nm, **kw)
+            key = "p1d/%s/%s" % (nm, kwkey(kw))
+            out[key + "/P"] = d.P
+            out[key + "/x0x1"] = np.array([d.x[0], d.x[-1]])
+            if not kw:
+                par = ref.paramNames.parWithName(nm)
+                out["par/%s" % nm] = np.array([float(getattr(par, a)) for a in PAR_ATTS])
+                ix, fw, bmin, bmax = ref._binSamples(ref.samples[:, j], par, ref.fine_bins)
+                out["bin1d/%s/edges" % nm] = np.array([bmin, bmax, fw])
+                out["bin1d/%s/ix_head" % nm] = ix[:1024].astype(np.int32)
+                out["bin1d/%s/ix_crc" % nm] = crc(ix.astype(np.int32))
+                out["hist1d/%s" % nm] = np.bincount(ix, weights=ref.weights, minlength=ref.fine_bins)
+    # capture the bandwidth triple of every 2D call
+    captured = []
+    orig = ref.getAutoBandwidth2D
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        captured.append(r)
+        return r
+
+    ref.getAutoBandwidth2D = spy
+    for ip, (a, b) in enumerate(pairs):
+        for kw in kw2:
+            captured.clear()
+            d = ref.get2DDensityGridData(names[a], names[b], get_density=False, **kw)
+            key = "p2d/%s/%s/%s" % (names[a], names[b], kwkey(kw))
+            F = d.P.shape[0]
+            out[key + "/F"] = np.int32(F)
+            st = max(1, F // 64)
+            out[key + "/stride"] = np.int32(st)
+            if (not kw and ip < FULL_GRID_PAIRS and F <= 256) or F <= 64:
+                out[key + "/P"] = d.P
+            else:
+                out[key + "/Pstrided"] = d.P[::st, ::st].copy()
+            out[key + "/Psum"] = np.float64(np.sum(d.P))
+            out[key + "/contours"] = np.asarray(d.contours, dtype=float)
+            out[key + "/xy"] = np.array([d.x[0], d.x[-1], d.y[0], d.y[-1]])
+            if captured:
+                out[key + "/hxhyc"] = np.array(captured[0], dtype=float)
+            if not kw:
+                parx, pary = ref.paramNames.parWithName(names[a]), ref.paramNames.parWithName(names[b])
+                ixs = ref._binSamples(ref.samples[:, a], parx, F)[0]
+                iys = ref._binSamples(ref.samples[:, b], pary, F)[0]
+                hist, flat = ref._make2Dhist(ixs, iys, F, F)
+                out[key + "/flatix_crc"] = crc(flat.astype(np.int32))
+                out[key + "/hist_blocksum"] = hist.reshape(F // st, st, F // st, st).sum(axis=(1, 3))
+    return out
+
+
+def golden_convergence():
+    samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
+    chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
+    ws = [weights[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    ref = MCSamples(samples=chains, weights=ws, loglikes=[np.zeros(len(w)) for w in ws], names=names)
+    out = dict(gr_eigenvalues=ref.getGelmanRubinEigenvalues(), gr=np.float64(ref.getGelmanRubin()),
+               means=ref.means, cov=ref.fullcov)
+    chainlist = ref.getSeparateChains()
+    for ch in chainlist:
+        ch.setDiffs()
+    between = np.zeros(ref.n)
+    within = np.zeros(ref.n)
+    for ch in chainlist:
+        between += (ch.getMeans() - ref.means) ** 2
+    between /= len(chainlist) - 1
+    for j in range(ref.n):
+        for ch in chainlist:
+            within[j] += np.dot(ch.weights, ch.diffs[j] ** 2)
+        within[j] /= ref.norm
+    out["meanvar"] = np.sqrt(between / within)
+    return out
+
+
+def main():
+    xs = np.unique(np.concatenate([np.arange(1, 3000), np.geomspace(3000, 2.0e9, 1500).astype(np.int64)]))
+    np.savez_compressed(os.path.join(HERE, "fftnumbers.npz"), x=xs, y=nearestFFTnumber(xs))
+    np.savez_compressed(os.path.join(HERE, "convergence.npz"), **golden_convergence())
+    for fx in fixture_zoo():
+        out = golden_for_fixture(**fx)
+        path = os.path.join(HERE, "fixture_%s.npz" % fx["name"])
+        np.savez_compressed(path, **out)
+        print(fx["name"], len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""Helpers shared by the golden-vector tests (oracle vs goldens on CPU; HIP path vs goldens on GPU)."""
+
+import os
+import zlib
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+PAR_ATTS = ("param_min", "param_max", "range_min", "range_max", "sigma_range", "err", "mean", "has_limits_bot",
+            "has_limits_top", "N_eff_kde", "kde_h")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, "fixture_%s.npz" % name))
+
+
+def kwkey(kw):
+    return ",".join("%s=%s" % (k, kw[k]) for k in sorted(kw)) or "default"
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    den = np.max(np.abs(b)) or 1.0
+    return float(np.max(np.abs(a - b)) / den)
+
+
+def check_grid_2d(gold, key, P, tol):
+    """Compare a computed P[y,x] grid with whichever form the golden file holds."""
+    st = int(gold[key + "/stride"])
+    if key + "/P" in gold.files:
+        assert relerr(P, gold[key + "/P"]) <= tol, key
+    else:
+        assert relerr(P[::st, ::st], gold[key + "/Pstrided"]) <= tol, key
+    assert abs(np.sum(P) - float(gold[key + "/Psum"])) <= tol * float(gold[key + "/Psum"]) * 10, key

@@ -1,0 +1,74 @@
+"""
+CPU tests: the oracle (oracle/kde_oracle.py) against the committed reference outputs in tests/golden/
+(made by tests/golden/make_golden.py from the real GetDist 1.7.7).  This is what pins the oracle.
+"""
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import kde_oracle as ko
+
+FIXTURES = ["c1_100k", "c1_bounded", "block10_weighted", "block50", "shapes", "shapes_intweights", "periodic"]
+TOL_MOMENT = 1e-13  # BLAS summation order differs with memory layout
+TOL_GRID = 1e-10
+
+
+def test_fft_numbers():
+    g = np.load(gu.GOLDEN_DIR + "/fftnumbers.npz")
+    assert np.array_equal(ko.nearest_fft_number(g["x"]), g["y"])
+
+
+def test_convergence_golden():
+    from getdist_amd import synth
+
+    g = np.load(gu.GOLDEN_DIR + "/convergence.npz")
+    samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
+    orc = ko.OracleSamples(samples, weights, names=names)
+    assert gu.relerr(orc.means, g["means"]) < TOL_MOMENT
+    assert gu.relerr(orc.fullcov, g["cov"]) < TOL_MOMENT
+    D = orc.gelman_rubin_eigenvalues(offsets)
+    assert gu.relerr(D, g["gr_eigenvalues"]) < 1e-11
+    assert abs(np.max(D) - float(g["gr"])) < 1e-11 * float(g["gr"])
+    assert gu.relerr(orc.mean_var_test(offsets), g["meanvar"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_matches_golden(zoo, name):
+    fx = zoo[name]
+    g = gu.load(name)
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    assert gu.relerr(orc.means, g["means"]) < TOL_MOMENT
+    assert gu.relerr(orc.vars, g["vars"]) < TOL_MOMENT
+    assert gu.relerr(orc.fullcov, g["cov"]) < TOL_MOMENT
+    assert gu.relerr(orc.corrmat, g["corr"]) < TOL_MOMENT
+    fracs = g["quantile_fracs"]
+    for j in range(orc.n):
+        q = orc.confidence(orc.confidence_data(orc.samples[:, j]), fracs)
+        assert np.array_equal(q, g["quantiles"][j])
+    for j, nm in enumerate(fx["names"]):
+        for kw in fx["kw1"]:
+            d = orc.density_1d(j, **kw)
+            key = "p1d/%s/%s" % (nm, gu.kwkey(kw))
+            assert gu.relerr(d["P"], g[key + "/P"]) < TOL_GRID, key
+            assert np.array_equal([d["x"][0], d["x"][-1]], g[key + "/x0x1"]), key
+            if not kw:
+                par = orc.pars[j]
+                got = np.array([float(getattr(par, a)) for a in gu.PAR_ATTS])
+                assert gu.relerr(got, g["par/%s" % nm]) < 1e-12, (nm, got, g["par/%s" % nm])
+                assert np.array_equal(d["ix"][:1024].astype(np.int32), g["bin1d/%s/ix_head" % nm])
+                assert gu.crc(d["ix"].astype(np.int32)) == g["bin1d/%s/ix_crc" % nm]
+                assert gu.relerr(d["bins"], g["hist1d/%s" % nm]) < 1e-15
+    for (a, b) in fx["pairs"]:
+        for kw in fx["kw2"]:
+            tr = {}
+            d = orc.density_2d(a, b, trace=tr, **kw)
+            key = "p2d/%s/%s/%s" % (fx["names"][a], fx["names"][b], gu.kwkey(kw))
+            assert d["P"].shape[0] == int(g[key + "/F"]), key
+            gu.check_grid_2d(g, key, d["P"], TOL_GRID)
+            if key + "/hxhyc" in g.files:
+                assert gu.relerr([tr["hx"], tr["hy"], tr["c"]], g[key + "/hxhyc"]) < 1e-11, key
+            lev = ko.contour_levels(d["P"], (0.68, 0.95, 0.99))
+            assert gu.relerr(lev, g[key + "/contours"]) < TOL_GRID, key
+            if not kw:
+                assert gu.crc(d["flatix"].astype(np.int32)) == g[key + "/flatix_crc"], key
