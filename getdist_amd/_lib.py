@@ -1,0 +1,346 @@
+"""
+ctypes binding of libgdhip.so (the C ABI in include/gdhip.h).  This is the thin Python->HIP seam; there
+is NO CPU fallback: if the library or a GPU is missing, every compute entry point raises.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgdhip.so")
+
+GD_OK, GD_ERR_BADARG, GD_ERR_NOMEM, GD_ERR_HIP, GD_ERR_EMPTY, GD_ERR_SOLVER, GD_ERR_FFT, GD_ERR_NODEVICE = \
+    0, -1, -2, -3, -4, -5, -6, -7
+
+
+class GdhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libgdhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_native(force=False):
+    """Compile libgdhip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force:
+        for f in os.listdir(os.path.join(_HERE, "csrc")):
+            if f.endswith(".o") or f.endswith(".so"):
+                os.remove(os.path.join(_HERE, "csrc", f))
+    subprocess.run(["bash", script], check=True)
+    return LIB_PATH
+
+
+_p = C.c_void_p
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+_pd = C.POINTER(C.c_double)
+_pi32 = C.POINTER(C.c_int32)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/gdhip.h declares (tests check this)
+SIGNATURES = {
+    "gd_device_count": (C.c_int, []),
+    "gd_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "gd_destroy": (None, [_p]),
+    "gd_last_error": (C.c_char_p, [_p]),
+    "gd_version": (C.c_char_p, []),
+    "gd_device_info": (C.c_int, [_p, _pi64]),
+    "gd_sync": (C.c_int, [_p]),
+    "gd_dev_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "gd_dev_free": (C.c_int, [_p, _p]),
+    "gd_memcpy_h2d": (C.c_int, [_p, _p, _p, _i64]),
+    "gd_memcpy_d2h": (C.c_int, [_p, _p, _p, _i64]),
+    "gd_memset": (C.c_int, [_p, _p, C.c_int, _i64]),
+    "gd_timer_start": (C.c_int, [_p]),
+    "gd_timer_stop_ms": (C.c_int, [_p, _pd]),
+    "gd_upload": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "gd_num_rows": (C.c_int, [_p, _pi64, _pi64]),
+    "gd_column_ptr": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "gd_weight_stats": (C.c_int, [_p, _i64, _i64, _f64, _pd]),
+    "gd_col_stats": (C.c_int, [_p, _i64, _i64, _pd]),
+    "gd_cov": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _pd, _pd]),
+    "gd_quantiles": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd]),
+    "gd_autocov_lags": (C.c_int, [_p, _i32, _f64, _i64, _i32, _pd]),
+    "gd_kde_lag_sums": (C.c_int, [_p, _i32, _f64, _pi64, _i32, _pd]),
+    "gd_hist1d": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, _pd]),
+    "gd_bin_indices": (C.c_int, [_p, _i32, _f64, _f64, _i32, _i32, _pi32, _pi64]),
+    "gd_prebin": (C.c_int, [_p, _i32, _f64, _f64, _i32, _p]),
+    "gd_hist2d": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _i32, _p]),
+    "gd_hist2d_prebinned": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
+    "gd_minmax_affine": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd]),
+    "gd_hist2d_sheared": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _i32, _p]),
+    "gd_dct1d": (C.c_int, [_p, _i32, _i32, _pd, _pd]),
+    "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
+    "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
+    "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgdhip.so and attach prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libgdhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or getdist_amd/csrc/build.sh (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_pi32)
+
+
+def _f64arr(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32arr(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _p()
+        ctx._check(ctx.lib.gd_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.gd_dev_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def to_host(self, shape, dtype=np.float64, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        self.ctx._check(self.ctx.lib.gd_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset_bytes, out.nbytes))
+        return out
+
+    def from_host(self, arr, offset_bytes=0):
+        arr = np.ascontiguousarray(arr)
+        self.ctx._check(self.ctx.lib.gd_memcpy_h2d(self.ctx.h, self.ptr + offset_bytes, arr.ctypes.data, arr.nbytes))
+
+
+class Context:
+    """One GPU, one stream, one resident sample set.  Thin, typed wrappers over the C ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = None
+        if self.lib.gd_device_count() <= 0:
+            raise RuntimeError("getdist_amd needs a HIP device (no CPU fallback): none visible")
+        h = _p()
+        rc = self.lib.gd_create(int(device), C.byref(h))
+        if rc != 0:
+            raise GdhipError(rc, "gd_create(device=%d) failed" % device)
+        self.h = h
+        self.device = device
+        self.N = self.n = 0
+        self.weighted = False
+
+    def close(self):
+        if self.h:
+            self.lib.gd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.gd_last_error(self.h)
+            raise GdhipError(rc, msg.decode() if msg else "?")
+
+    # ---- memory / info
+    def device_info(self):
+        a = np.zeros(6, dtype=np.int64)
+        self._check(self.lib.gd_device_info(self.h, a.ctypes.data_as(_pi64)))
+        return dict(cu_count=int(a[0]), lds_bytes=int(a[1]), hbm_total=int(a[2]), hbm_free=int(a[3]),
+                    clock_khz=int(a[4]), wave=int(a[5]))
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def sync(self):
+        self._check(self.lib.gd_sync(self.h))
+
+    def timer_start(self):
+        self._check(self.lib.gd_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_double()
+        self._check(self.lib.gd_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- sample set
+    def upload(self, samples, weights=None):
+        s = np.asarray(samples)
+        if s.dtype != np.float64:
+            s = s.astype(np.float64)
+        if s.ndim == 1:
+            s = s.reshape(-1, 1)
+        if not (s.flags.c_contiguous or s.flags.f_contiguous):
+            s = np.ascontiguousarray(s)
+        N, n = s.shape
+        rs, cs = s.strides[0] // 8, s.strides[1] // 8
+        if n == 1:
+            rs, cs = 1, N
+        w = None if weights is None else _f64arr(weights)
+        self._keep = (s, w)
+        self._check(self.lib.gd_upload(self.h, s.ctypes.data, N, n, rs, cs, None if w is None else w.ctypes.data))
+        self._keep = None
+        self.N, self.n, self.weighted = N, n, w is not None
+
+    def column_ptr(self, j):
+        p = _p()
+        self._check(self.lib.gd_column_ptr(self.h, int(j), C.byref(p)))
+        return p.value
+
+    # ---- moments
+    def weight_stats(self, lo=0, hi=None, thresh=np.inf):
+        out = np.zeros(4)
+        self._check(self.lib.gd_weight_stats(self.h, lo, self.N if hi is None else hi, float(thresh), _dp(out)))
+        return dict(norm=out[0], max_w=out[1], sum_w2=out[2], n_above=out[3])
+
+    def col_stats(self, lo=0, hi=None):
+        out = np.zeros((self.n, 4))
+        self._check(self.lib.gd_col_stats(self.h, lo, self.N if hi is None else hi, _dp(out)))
+        return out
+
+    def cov(self, cols=None, lo=0, hi=None):
+        cols = _i32arr(np.arange(self.n) if cols is None else cols)
+        m = len(cols)
+        means, cov, norm = np.zeros(m), np.zeros((m, m)), C.c_double()
+        self._check(self.lib.gd_cov(self.h, _ip(cols), m, lo, self.N if hi is None else hi, _dp(means), _dp(cov),
+                                    C.byref(norm)))
+        return means, cov, norm.value
+
+    def quantiles(self, cols, targets, lo=0, hi=None):
+        cols = _i32arr(cols)
+        targets = _f64arr(targets).reshape(len(cols), -1)
+        out = np.zeros_like(targets)
+        self._check(self.lib.gd_quantiles(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi, _dp(targets),
+                                          targets.shape[1], _dp(out)))
+        return out
+
+    def autocov_lags(self, col, mean, k0, nlags):
+        out = np.zeros(nlags)
+        self._check(self.lib.gd_autocov_lags(self.h, int(col), float(mean), int(k0), int(nlags), _dp(out)))
+        return out
+
+    def kde_lag_sums(self, col, inv4s2, lags):
+        lags = np.ascontiguousarray(lags, dtype=np.int64)
+        out = np.zeros(len(lags))
+        self._check(self.lib.gd_kde_lag_sums(self.h, int(col), float(inv4s2), lags.ctypes.data_as(_pi64), len(lags),
+                                             _dp(out)))
+        return out
+
+    # ---- binning
+    def hist1d(self, cols, binmin, width, F):
+        cols, binmin, width = _i32arr(cols), _f64arr(binmin), _f64arr(width)
+        out = np.zeros((len(cols), F))
+        self._check(self.lib.gd_hist1d(self.h, _ip(cols), len(cols), _dp(binmin), _dp(width), int(F), _dp(out)))
+        return out
+
+    def bin_indices(self, col, binmin, width, F, round_half=True):
+        idx = np.zeros(self.N, dtype=np.int32)
+        bad = C.c_int64()
+        self._check(self.lib.gd_bin_indices(self.h, int(col), float(binmin), float(width), int(bool(round_half)), int(F),
+                                            _ip(idx), C.byref(bad)))
+        return idx, bad.value
+
+    def prebin(self, col, binmin, width, F, buf=None):
+        buf = buf or self.alloc(self.N * 2 + 64)
+        self._check(self.lib.gd_prebin(self.h, int(col), float(binmin), float(width), int(F), buf.ptr))
+        return buf
+
+    def hist2d(self, colx, coly, bx, wx, by, wy, F, out=None):
+        colx, coly = _i32arr(colx), _i32arr(coly)
+        B = len(colx)
+        out = out or self.alloc(B * F * F * 8)
+        bx, wx, by, wy = _f64arr(bx), _f64arr(wx), _f64arr(by), _f64arr(wy)
+        self._check(self.lib.gd_hist2d(self.h, B, _ip(colx), _ip(coly), _dp(bx), _dp(wx), _dp(by), _dp(wy), int(F),
+                                       out.ptr))
+        return out
+
+    def hist2d_prebinned(self, idx_x, idx_y, F, out=None):
+        B = len(idx_x)
+        out = out or self.alloc(B * F * F * 8)
+        ax = (_p * B)(*[b.ptr for b in idx_x])
+        ay = (_p * B)(*[b.ptr for b in idx_y])
+        self._check(self.lib.gd_hist2d_prebinned(self.h, B, ax, ay, int(F), out.ptr))
+        return out
+
+    def minmax_affine(self, coli, colj, a, b):
+        coli, colj, a, b = _i32arr(coli), _i32arr(colj), _f64arr(a), _f64arr(b)
+        out = np.zeros((len(coli), 2))
+        self._check(self.lib.gd_minmax_affine(self.h, len(coli), _ip(coli), _ip(colj), _dp(a), _dp(b), _dp(out)))
+        return out
+
+    def hist2d_sheared(self, coli, colj, r0, r1, xmin, dx, ymin, dy, F, out=None):
+        coli, colj = _i32arr(coli), _i32arr(colj)
+        B = len(coli)
+        out = out or self.alloc(B * F * F * 8)
+        arrs = [_f64arr(v) for v in (r0, r1, xmin, dx, ymin, dy)]
+        self._check(self.lib.gd_hist2d_sheared(self.h, B, _ip(coli), _ip(colj), *[_dp(v) for v in arrs], int(F),
+                                               out.ptr))
+        return out
+
+    # ---- densities
+    def dct1d(self, hist):
+        hist = _f64arr(hist)
+        B, F = hist.shape
+        out = np.zeros_like(hist)
+        self._check(self.lib.gd_dct1d(self.h, B, F, _dp(hist), _dp(out)))
+        return out
+
+    def density1d(self, hist, smooth, winw, flags, bco, mbc):
+        hist = _f64arr(hist)
+        B, F = hist.shape
+        smooth, winw, flags = _f64arr(smooth), _i32arr(winw), _i32arr(flags)
+        P = np.zeros_like(hist)
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_density1d(self.h, B, F, _dp(hist), _dp(smooth), _ip(winw), _ip(flags), int(bco),
+                                          int(mbc), _dp(P), _ip(status)))
+        return P, status
+
+    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t):
+        neff, do_corr, fallback_t = _f64arr(neff), _i32arr(do_corr), _f64arr(fallback_t)
+        out = np.zeros((B, 8))
+        self._check(self.lib.gd_kopt2d(self.h, B, F, d_hist.ptr if isinstance(d_hist, DevBuf) else d_hist, _dp(neff),
+                                       _ip(do_corr), _dp(fallback_t), _dp(out)))
+        return out
+
+    def density2d(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, out=None):
+        out = out or self.alloc(B * F * F * 8)
+        rx, ry, corr, winw, flags = _f64arr(rx), _f64arr(ry), _f64arr(corr), _i32arr(winw), _i32arr(flags)
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_density2d(self.h, B, F, d_hist.ptr if isinstance(d_hist, DevBuf) else d_hist, _dp(rx),
+                                          _dp(ry), _dp(corr), _ip(winw), _ip(flags), int(bco), int(mbc), out.ptr,
+                                          _ip(status)))
+        return out, status

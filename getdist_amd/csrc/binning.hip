@@ -1,0 +1,465 @@
+// Weighted binning: fused bin-index computation + LDS-privatised histograms (1D and stripe-tiled 2D).
+//
+// Index arithmetic is the reference's, in IEEE fp64 with true division and no FMA contraction (this
+// file is compiled with -ffp-contract=off): ix = (int)((x - binmin) / width + 0.5)  (mcsamples.py:1497)
+// and the truncating form (int)((x - range_min) / dx) of kde_bandwidth.py:86-87.
+//
+// 2D layout: an F x F fp64 histogram (512 KB at F=256) does not fit the 160 KB LDS, so a workgroup owns a
+// stripe of R rows (R*F bins <= 128 KB of LDS), scans its chunk of samples and accumulates only the
+// samples whose y index falls in the stripe.  The stripes of one (pair, chunk) unit are given block ids
+// that are congruent mod 8, i.e. land on the same XCD, so that the repeated reads of the same sample
+// range are served by that XCD's L2.  Unit-weight sample sets use u32 LDS counters (twice the rows per
+// stripe, native ds_add_u32); weighted ones use fp64 LDS atomics (ds_add_f64).
+#include "ctx.hpp"
+
+#define LDS_HIST_BYTES (128 * 1024)
+
+__device__ __forceinline__ int bin_round(double x, double binmin, double width) {
+    return (int)((x - binmin) / width + 0.5);
+}
+__device__ __forceinline__ int bin_trunc(double x, double binmin, double width) {
+    return (int)((x - binmin) / width);
+}
+
+// ---- 1D -----------------------------------------------------------------------------------------------
+// grid (nblk, ncols); 256 threads = 4 waves, one private histogram copy per wave.
+template <bool HAS_W>
+__global__ void __launch_bounds__(256) k_hist1d(const double* __restrict__ cols, int64_t ld,
+                                                const int32_t* __restrict__ colidx, const double* __restrict__ w,
+                                                int64_t N, const double* __restrict__ binmin,
+                                                const double* __restrict__ width, int F, double* __restrict__ part) {
+    extern __shared__ double sh[];  // 4 * F
+    const int c = blockIdx.y;
+    const double* x = cols + (int64_t)colidx[c] * ld;
+    const double b0 = binmin[c], wd = width[c];
+    for (int i = threadIdx.x; i < 4 * F; i += 256) sh[i] = 0;
+    __syncthreads();
+    double* mine = sh + (threadIdx.x >> 6) * F;
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    const int64_t Ne = N & ~(int64_t)1;
+    for (int64_t i = 2 * gtid; i < Ne; i += 2 * gsz) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + i);
+        double2 wv = make_double2(1.0, 1.0);
+        if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
+        const int i0 = bin_round(xv.x, b0, wd), i1 = bin_round(xv.y, b0, wd);
+        if ((unsigned)i0 < (unsigned)F) atomicAdd(&mine[i0], wv.x);
+        if ((unsigned)i1 < (unsigned)F) atomicAdd(&mine[i1], wv.y);
+    }
+    if (gtid == 0 && Ne < N) {
+        const int i0 = bin_round(x[Ne], b0, wd);
+        if ((unsigned)i0 < (unsigned)F) atomicAdd(&mine[i0], HAS_W ? w[Ne] : 1.0);
+    }
+    __syncthreads();
+    double* p = part + ((int64_t)c * gridDim.x + blockIdx.x) * F;
+    for (int i = threadIdx.x; i < F; i += 256) p[i] = (sh[i] + sh[F + i]) + (sh[2 * F + i] + sh[3 * F + i]);
+}
+
+// out[c][f] = sum_b part[c][b][f]
+__global__ void k_hist1d_reduce(const double* __restrict__ part, int nblk, int F, double* __restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const double* p = part + (int64_t)blockIdx.y * nblk * F + f;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += p[(int64_t)b * F];
+    out[(int64_t)blockIdx.y * F + f] = s;
+}
+
+template <bool ROUND, typename T>
+__global__ void k_bin_indices(const double* __restrict__ x, int64_t N, double binmin, double width, int F,
+                              T* __restrict__ idx, unsigned long long* __restrict__ n_bad) {
+    unsigned long long bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = ROUND ? bin_round(x[i], binmin, width) : bin_trunc(x[i], binmin, width);
+        idx[i] = (T)v;
+        bad += ((unsigned)v >= (unsigned)F);
+    }
+    if (n_bad && bad) atomicAdd(n_bad, bad);
+}
+
+// u16 bin indices, 8 samples (4 x double2 in, one 16-byte store out) per thread-iteration.
+__global__ void __launch_bounds__(256) k_prebin(const double* __restrict__ x, int64_t N, double binmin, double width,
+                                                int F, unsigned short* __restrict__ idx) {
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    const int64_t N8 = N & ~(int64_t)7;
+    for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
+        double2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2*>(x + i + 2 * q);
+        unsigned short o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = bin_round(v[q].x, binmin, width), b = bin_round(v[q].y, binmin, width);
+            o[2 * q] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
+            o[2 * q + 1] = (unsigned)b < (unsigned)F ? (unsigned short)b : (unsigned short)0xFFFF;
+        }
+        uint4 pk;
+        pk.x = o[0] | ((unsigned)o[1] << 16);
+        pk.y = o[2] | ((unsigned)o[3] << 16);
+        pk.z = o[4] | ((unsigned)o[5] << 16);
+        pk.w = o[6] | ((unsigned)o[7] << 16);
+        *reinterpret_cast<uint4*>(idx + i) = pk;
+    }
+    if (gtid == 0)
+        for (int64_t i = N8; i < N; ++i) {
+            const int a = bin_round(x[i], binmin, width);
+            idx[i] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
+        }
+}
+
+// ---- 2D -----------------------------------------------------------------------------------------------
+struct Hist2DPair {   // per-pair parameters, device array
+    const double* x;  // column for the x index (or x_i of the shear)
+    const double* y;  // column for the y index (or x_j of the shear)
+    const unsigned short* ix;  // prebinned variants
+    const unsigned short* iy;
+    double bx, wx, by, wy;  // bin origin / width for x and y
+    double r0, r1;          // shear: y value = r0*x + r1*y
+};
+
+template <typename BinT>
+__device__ __forceinline__ void lds_add(BinT* p, double w);
+template <>
+__device__ __forceinline__ void lds_add<double>(double* p, double w) {
+    atomicAdd(p, w);
+}
+template <>
+__device__ __forceinline__ void lds_add<unsigned int>(unsigned int* p, double) {
+    atomicAdd(p, 1u);
+}
+
+// decode the 1-D grid: stripes of one unit share an XCD (block id mod 8)
+__device__ __forceinline__ void decode_block(int nstripes, int nchunks, int& pair, int& chunk, int& stripe) {
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    stripe = q % nstripes;
+    const int unit = (q / nstripes) * 8 + xcd;
+    pair = unit / nchunks;
+    chunk = unit % nchunks;
+}
+
+template <typename BinT>
+__device__ __forceinline__ void flush_stripe(const BinT* sh, int row0, int R, int F, double* __restrict__ hist,
+                                             bool exclusive) {
+    const int nb = R * F;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        const int r = row0 + i / F;
+        if (r >= F) break;
+        const double v = (double)sh[i];
+        double* dst = hist + (int64_t)r * F + (i % F);
+        if (exclusive)
+            *dst = v;
+        else if (v != 0)
+            unsafeAtomicAdd(dst, v);
+    }
+}
+
+// MODE 0: rounded indices from two fp64 columns; MODE 1: sheared (truncating) indices; MODE 2: prebinned u16.
+template <int MODE, bool HAS_W, typename BinT>
+__global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ pairs, int B,
+                                                 const double* __restrict__ w, int64_t N, int F, int R, int nstripes,
+                                                 int nchunks, double* __restrict__ hist_all) {
+    extern __shared__ double sh_raw[];
+    BinT* sh = reinterpret_cast<BinT*>(sh_raw);
+    int pair, chunk, stripe;
+    decode_block(nstripes, nchunks, pair, chunk, stripe);
+    if (pair >= B) return;
+    const Hist2DPair P = pairs[pair];
+    const int row0 = stripe * R;
+    for (int i = threadIdx.x; i < R * F; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    // rows of this chunk, aligned to 8 samples
+    int64_t per = (N + nchunks - 1) / nchunks;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t lo = (int64_t)chunk * per;
+    int64_t hi = lo + per;
+    if (hi > N) hi = N;
+    if (MODE == 2) {
+        const int64_t hi8 = lo + ((hi - lo) & ~(int64_t)7);
+        for (int64_t i = lo + 8 * (int64_t)threadIdx.x; i < hi8; i += 8 * (int64_t)blockDim.x) {
+            const uint4 ax = *reinterpret_cast<const uint4*>(P.ix + i);
+            const uint4 ay = *reinterpret_cast<const uint4*>(P.iy + i);
+            const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned cx = (xs[q] >> (16 * h)) & 0xFFFFu, cy = (ys[q] >> (16 * h)) & 0xFFFFu;
+                    const unsigned r = cy - (unsigned)row0;
+                    if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F)
+                        lds_add<BinT>(&sh[r * F + cx], HAS_W ? w[i + 2 * q + h] : 1.0);
+                }
+            }
+        }
+        if (threadIdx.x == 0)
+            for (int64_t i = hi8; i < hi; ++i) {
+                const unsigned cx = P.ix[i], cy = P.iy[i];
+                const unsigned r = cy - (unsigned)row0;
+                if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F)
+                    lds_add<BinT>(&sh[r * F + cx], HAS_W ? w[i] : 1.0);
+            }
+    } else {
+        const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
+        for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * (int64_t)blockDim.x) {
+            const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
+            const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+            double2 wv = make_double2(1.0, 1.0);
+            if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
+            int cx0, cy0, cx1, cy1;
+            if (MODE == 0) {
+                cx0 = bin_round(xv.x, P.bx, P.wx), cy0 = bin_round(yv.x, P.by, P.wy);
+                cx1 = bin_round(xv.y, P.bx, P.wx), cy1 = bin_round(yv.y, P.by, P.wy);
+            } else {
+                cx0 = bin_trunc(xv.x, P.bx, P.wx), cx1 = bin_trunc(xv.y, P.bx, P.wx);
+                const double p0 = P.r0 * xv.x + P.r1 * yv.x, p1 = P.r0 * xv.y + P.r1 * yv.y;
+                cy0 = bin_trunc(p0, P.by, P.wy), cy1 = bin_trunc(p1, P.by, P.wy);
+            }
+            unsigned r = (unsigned)cy0 - (unsigned)row0;
+            if (r < (unsigned)R && (unsigned)cx0 < (unsigned)F && (unsigned)cy0 < (unsigned)F)
+                lds_add<BinT>(&sh[r * F + cx0], wv.x);
+            r = (unsigned)cy1 - (unsigned)row0;
+            if (r < (unsigned)R && (unsigned)cx1 < (unsigned)F && (unsigned)cy1 < (unsigned)F)
+                lds_add<BinT>(&sh[r * F + cx1], wv.y);
+        }
+        if (threadIdx.x == 0 && hi2 < hi) {
+            const double xv = P.x[hi2], yv = P.y[hi2];
+            int cx, cy;
+            if (MODE == 0) {
+                cx = bin_round(xv, P.bx, P.wx), cy = bin_round(yv, P.by, P.wy);
+            } else {
+                cx = bin_trunc(xv, P.bx, P.wx);
+                cy = bin_trunc(P.r0 * xv + P.r1 * yv, P.by, P.wy);
+            }
+            const unsigned r = (unsigned)cy - (unsigned)row0;
+            if (r < (unsigned)R && (unsigned)cx < (unsigned)F && (unsigned)cy < (unsigned)F)
+                lds_add<BinT>(&sh[r * F + cx], HAS_W ? w[hi2] : 1.0);
+        }
+    }
+    __syncthreads();
+    flush_stripe<BinT>(sh, row0, R, F, hist_all + (int64_t)pair * F * F, nchunks == 1);
+}
+
+// min / max of a*x + b*y over the samples; grid (nblk, B)
+__global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N, double* __restrict__ part) {
+    __shared__ double red[16];
+    const Hist2DPair P = pairs[blockIdx.y];
+    double mn = INFINITY, mx = -INFINITY;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t Ne = N & ~(int64_t)1;
+    for (int64_t i = 2 * gtid; i < Ne; i += 2 * gsz) {
+        const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
+        const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+        const double p0 = P.r0 * xv.x + P.r1 * yv.x, p1 = P.r0 * xv.y + P.r1 * yv.y;
+        mn = fmin(mn, fmin(p0, p1));
+        mx = fmax(mx, fmax(p0, p1));
+    }
+    if (gtid == 0 && Ne < N) {
+        const double p0 = P.r0 * P.x[Ne] + P.r1 * P.y[Ne];
+        mn = fmin(mn, p0);
+        mx = fmax(mx, p0);
+    }
+    const double r0 = block_min(mn, red), r1 = block_max(mx, red);
+    if (threadIdx.x == 0) {
+        double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        p[0] = r0, p[1] = r1;
+    }
+}
+
+// =============================================================================================================
+template <int MODE>
+static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist) {
+    GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins_2D out of range");
+    const bool has_w = ctx->w != nullptr;
+    const int binbytes = has_w ? 8 : 4;
+    int R = LDS_HIST_BYTES / (F * binbytes);
+    GD_REQUIRE(R >= 1, "fine_bins_2D too large for the LDS stripe");
+    if (R > F) R = F;
+    const int nstripes = (F + R - 1) / R;
+    int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
+    if (nchunks < 1) nchunks = 1;
+    if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+    const int units = (B * nchunks + 7) / 8 * 8;
+    const int64_t nblocks = (int64_t)units * nstripes;
+    Hist2DPair* d_pairs = (Hist2DPair*)gd_scratch2(ctx, (int64_t)B * sizeof(Hist2DPair));
+    if (!d_pairs) return GD_ERR_NOMEM;
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    if (nchunks > 1) GD_HIP(hipMemsetAsync(d_hist, 0, (size_t)B * F * F * 8, ctx->stream));
+    const size_t lds = (size_t)R * F * binbytes;
+    if (has_w) {
+        auto kern = k_hist2d<MODE, true, double>;
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        kern<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->w, ctx->N, F, R, nstripes, nchunks, d_hist);
+    } else {
+        auto kern = k_hist2d<MODE, false, unsigned int>;
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        kern<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, nullptr, ctx->N, F, R, nstripes, nchunks,
+                                                            d_hist);
+    }
+    GD_KERNEL_CHECK();
+    GD_HIP(hipStreamSynchronize(ctx->stream));  // hp / d_pairs lifetime
+    return GD_OK;
+}
+
+extern "C" {
+
+int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+              double* out) {
+    GD_REQUIRE(ctx && cols && binmin && width && out && ncols > 0, "bad argument");
+    GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins out of range (2..4096)");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    const int nblk = ctx->cu_count;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_part = take((int64_t)ncols * nblk * F * 8), o_out = take((int64_t)ncols * F * 8),
+                  o_idx = take((int64_t)ncols * 4), o_b = take((int64_t)ncols * 8), o_w = take((int64_t)ncols * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_part = (double*)(base + o_part);
+    double* d_out = (double*)(base + o_out);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    double* d_b = (double*)(base + o_b);
+    double* d_w = (double*)(base + o_w);
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_b, binmin, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_w, width, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid(nblk, ncols);
+    const size_t lds = (size_t)4 * F * 8;
+    if (ctx->w) {
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist1d<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
+        k_hist1d<true><<<grid, 256, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_b, d_w, F, d_part);
+    } else {
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist1d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
+        k_hist1d<false><<<grid, 256, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_b, d_w, F, d_part);
+    }
+    GD_KERNEL_CHECK();
+    k_hist1d_reduce<<<dim3((F + 255) / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, F, d_out);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * F * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
+                   int32_t* idx_out, int64_t* n_out_of_range) {
+    GD_REQUIRE(ctx && idx_out, "bad argument");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
+    char* base = (char*)gd_scratch(ctx, ctx->N * 4 + 256);
+    if (!base) return GD_ERR_NOMEM;
+    unsigned long long* d_bad = (unsigned long long*)base;
+    int32_t* d_idx = (int32_t*)(base + 256);
+    GD_HIP(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    const double* x = ctx->cols + (int64_t)col * ctx->ld;
+    if (round_half)
+        k_bin_indices<true, int32_t><<<4 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, d_idx, d_bad);
+    else
+        k_bin_indices<false, int32_t><<<4 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, d_idx, d_bad);
+    GD_KERNEL_CHECK();
+    unsigned long long bad = 0;
+    GD_HIP(hipMemcpyAsync(idx_out, d_idx, (size_t)ctx->N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_out_of_range) *n_out_of_range = (int64_t)bad;
+    return GD_OK;
+}
+
+int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16) {
+    GD_REQUIRE(ctx && d_idx_u16, "bad argument");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
+    GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
+    const double* x = ctx->cols + (int64_t)col * ctx->ld;
+    k_prebin<<<8 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, (unsigned short*)d_idx_u16);
+    GD_KERNEL_CHECK();
+    return GD_OK;
+}
+
+int gd_hist2d(gd_ctx* ctx, int32_t B, const int32_t* colx, const int32_t* coly, const double* binminx,
+              const double* widthx, const double* binminy, const double* widthy, int32_t F, void* d_hist) {
+    GD_REQUIRE(ctx && colx && coly && binminx && widthx && binminy && widthy && d_hist && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    std::vector<Hist2DPair> hp((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(colx[b] >= 0 && colx[b] < ctx->n && coly[b] >= 0 && coly[b] < ctx->n, "column out of range");
+        Hist2DPair& p = hp[b];
+        memset(&p, 0, sizeof p);
+        p.x = ctx->cols + (int64_t)colx[b] * ctx->ld;
+        p.y = ctx->cols + (int64_t)coly[b] * ctx->ld;
+        p.bx = binminx[b], p.wx = widthx[b], p.by = binminy[b], p.wy = widthy[b];
+    }
+    return launch_hist2d<0>(ctx, B, hp, F, (double*)d_hist);
+}
+
+int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
+                        void* d_hist) {
+    GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    std::vector<Hist2DPair> hp((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        Hist2DPair& p = hp[b];
+        memset(&p, 0, sizeof p);
+        p.ix = (const unsigned short*)d_idx_x[b];
+        p.iy = (const unsigned short*)d_idx_y[b];
+        GD_REQUIRE(p.ix && p.iy, "null index column");
+    }
+    return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+}
+
+int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* r0,
+                      const double* r1, const double* xmin, const double* dx, const double* ymin, const double* dy,
+                      int32_t F, void* d_hist) {
+    GD_REQUIRE(ctx && coli && colj && r0 && r1 && xmin && dx && ymin && dy && d_hist && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    std::vector<Hist2DPair> hp((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(coli[b] >= 0 && coli[b] < ctx->n && colj[b] >= 0 && colj[b] < ctx->n, "column out of range");
+        Hist2DPair& p = hp[b];
+        memset(&p, 0, sizeof p);
+        p.x = ctx->cols + (int64_t)coli[b] * ctx->ld;
+        p.y = ctx->cols + (int64_t)colj[b] * ctx->ld;
+        p.bx = xmin[b], p.wx = dx[b], p.by = ymin[b], p.wy = dy[b], p.r0 = r0[b], p.r1 = r1[b];
+    }
+    return launch_hist2d<1>(ctx, B, hp, F, (double*)d_hist);
+}
+
+int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* a,
+                     const double* b, double* out) {
+    GD_REQUIRE(ctx && coli && colj && a && b && out && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    std::vector<Hist2DPair> hp((size_t)B);
+    for (int q = 0; q < B; ++q) {
+        GD_REQUIRE(coli[q] >= 0 && coli[q] < ctx->n && colj[q] >= 0 && colj[q] < ctx->n, "column out of range");
+        Hist2DPair& p = hp[q];
+        memset(&p, 0, sizeof p);
+        p.x = ctx->cols + (int64_t)coli[q] * ctx->ld;
+        p.y = ctx->cols + (int64_t)colj[q] * ctx->ld;
+        p.r0 = a[q], p.r1 = b[q];
+    }
+    int nblk = (4 * ctx->cu_count + B - 1) / B;
+    if (nblk < 8) nblk = 8;
+    if (nblk > 1024) nblk = 1024;
+    const int64_t o_part = ((int64_t)B * sizeof(Hist2DPair) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, o_part + (int64_t)B * nblk * 16);
+    if (!base) return GD_ERR_NOMEM;
+    Hist2DPair* d_pairs = (Hist2DPair*)base;
+    double* d_part = (double*)(base + o_part);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    k_minmax_affine<<<dim3(nblk, B), 256, 0, ctx->stream>>>(d_pairs, ctx->N, d_part);
+    GD_KERNEL_CHECK();
+    std::vector<double> h((size_t)B * nblk * 2);
+    GD_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < B; ++q) {
+        double mn = INFINITY, mx = -INFINITY;
+        for (int k = 0; k < nblk; ++k) {
+            const double v0 = h[((size_t)q * nblk + k) * 2], v1 = h[((size_t)q * nblk + k) * 2 + 1];
+            if (v0 < mn) mn = v0;
+            if (v1 > mx) mx = v1;
+        }
+        out[2 * q] = mn, out[2 * q + 1] = mx;
+    }
+    return GD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// Context, device memory, sample upload (SoA transpose), event timers.
+#include <stdarg.h>
+
+#include "ctx.hpp"
+
+int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+static int grow(gd_ctx* ctx, void** p, int64_t* have, int64_t bytes) {
+    if (bytes <= *have) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    int64_t want = bytes + bytes / 8;
+    if (hipMalloc(p, (size_t)want) != hipSuccess) {
+        *p = nullptr;
+        gd_fail(ctx, GD_ERR_NOMEM, "scratch allocation of %lld bytes failed", (long long)want);
+        return -1;
+    }
+    *have = want;
+    return 0;
+}
+void* gd_scratch(gd_ctx* ctx, int64_t bytes) {
+    return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes) ? nullptr : ctx->scratch;
+}
+void* gd_scratch2(gd_ctx* ctx, int64_t bytes) {
+    return grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes) ? nullptr : ctx->scratch2;
+}
+
+extern void gd_fft_cache_destroy(gd_ctx* ctx);
+
+extern "C" {
+
+const char* gd_version(void) { return "gdhip 0.1 (gfx950)"; }
+
+int gd_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int gd_create(int device, gd_ctx** out) {
+    if (!out) return GD_ERR_BADARG;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return GD_ERR_NODEVICE;
+    if (device < 0 || device >= c) return GD_ERR_BADARG;
+    gd_ctx* ctx = new gd_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return GD_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return GD_OK;
+}
+
+void gd_destroy(gd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    gd_fft_cache_destroy(ctx);
+    if (ctx->cols) (void)hipFree(ctx->cols);
+    if (ctx->w) (void)hipFree(ctx->w);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* gd_last_error(gd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gd_device_info(gd_ctx* ctx, int64_t* info) {
+    GD_REQUIRE(ctx && info, "null argument");
+    GD_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    GD_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    size_t fr = 0, tot = 0;
+    GD_HIP(hipMemGetInfo(&fr, &tot));
+    info[0] = prop.multiProcessorCount;
+    info[1] = (int64_t)prop.sharedMemPerBlock;
+    info[2] = (int64_t)tot;
+    info[3] = (int64_t)fr;
+    info[4] = prop.clockRate;
+    info[5] = prop.warpSize;
+    return GD_OK;
+}
+
+int gd_sync(gd_ctx* ctx) {
+    GD_REQUIRE(ctx, "null context");
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_dev_alloc(gd_ctx* ctx, int64_t bytes, void** d_out) {
+    GD_REQUIRE(ctx && d_out && bytes >= 0, "bad argument");
+    GD_HIP(hipSetDevice(ctx->device));
+    *d_out = nullptr;
+    GD_HIP(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 8)));
+    return GD_OK;
+}
+
+int gd_dev_free(gd_ctx* ctx, void* d_ptr) {
+    GD_REQUIRE(ctx, "null context");
+    if (d_ptr) {
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_HIP(hipFree(d_ptr));
+    }
+    return GD_OK;
+}
+
+int gd_memcpy_h2d(gd_ctx* ctx, void* d_dst, const void* src, int64_t bytes) {
+    GD_REQUIRE(ctx && d_dst && src && bytes >= 0, "bad argument");
+    GD_HIP(hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes) {
+    GD_REQUIRE(ctx && dst && d_src && bytes >= 0, "bad argument");
+    GD_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes) {
+    GD_REQUIRE(ctx && d_dst && bytes >= 0, "bad argument");
+    GD_HIP(hipMemsetAsync(d_dst, value, (size_t)bytes, ctx->stream));
+    return GD_OK;
+}
+
+int gd_timer_start(gd_ctx* ctx) {
+    GD_REQUIRE(ctx, "null context");
+    GD_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return GD_OK;
+}
+
+int gd_timer_stop_ms(gd_ctx* ctx, double* ms_out) {
+    GD_REQUIRE(ctx && ms_out, "null argument");
+    GD_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    GD_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    GD_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = ms;
+    return GD_OK;
+}
+
+}  // extern "C"
+
+// ---- upload -----------------------------------------------------------------------------------------
+// Row-major (N x n) -> SoA.  32x32 tile transpose through LDS; reads and writes both coalesced.
+__global__ void transpose_rows_to_cols(const double* __restrict__ X, int64_t N, int64_t n, int64_t row_stride,
+                                       double* __restrict__ cols, int64_t ld) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int64_t r = r0 + k, c = c0 + threadIdx.x;
+        if (r < N && c < n) tile[k][threadIdx.x] = X[r * row_stride + c];
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int64_t c = c0 + k, r = r0 + threadIdx.x;
+        if (r < N && c < n) cols[c * ld + r] = tile[threadIdx.x][k];
+    }
+}
+
+extern "C" {
+
+int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
+              const double* weights) {
+    GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
+    GD_HIP(hipSetDevice(ctx->device));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->cols) (void)hipFree(ctx->cols);
+    if (ctx->w) (void)hipFree(ctx->w);
+    ctx->cols = ctx->w = nullptr;
+    ctx->N = ctx->n = ctx->ld = 0;
+    const int64_t ld = (N + 511) / 512 * 512;
+    GD_HIP(hipMalloc((void**)&ctx->cols, (size_t)(ld * n * 8)));
+    if (row_stride == 1) {
+        // column-major host input: one contiguous copy per column
+        for (int64_t j = 0; j < n; ++j)
+            GD_HIP(hipMemcpyAsync(ctx->cols + j * ld, X + j * col_stride, (size_t)(N * 8), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    } else {
+        GD_REQUIRE(col_stride == 1 && row_stride >= n, "samples must be C- or Fortran-contiguous");
+        // stage row blocks through scratch and transpose on the device
+        const int64_t rows_per = 4 << 20;  // 4M rows x n x 8 B per staged block
+        for (int64_t r0 = 0; r0 < N; r0 += rows_per) {
+            int64_t nr = (N - r0 < rows_per) ? N - r0 : rows_per;
+            double* stage = (double*)gd_scratch(ctx, nr * row_stride * 8);
+            if (!stage) return GD_ERR_NOMEM;
+            GD_HIP(hipMemcpyAsync(stage, X + r0 * row_stride, (size_t)(nr * row_stride * 8), hipMemcpyHostToDevice,
+                                  ctx->stream));
+            dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((n + 31) / 32)), block(32, 8);
+            transpose_rows_to_cols<<<grid, block, 0, ctx->stream>>>(stage, nr, n, row_stride, ctx->cols + r0, ld);
+            GD_KERNEL_CHECK();
+            GD_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (weights) {
+        GD_HIP(hipMalloc((void**)&ctx->w, (size_t)(ld * 8)));
+        GD_HIP(hipMemcpyAsync(ctx->w, weights, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
+    }
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->N = N;
+    ctx->n = n;
+    ctx->ld = ld;
+    return GD_OK;
+}
+
+int gd_num_rows(gd_ctx* ctx, int64_t* N, int64_t* n) {
+    GD_REQUIRE(ctx && N && n, "null argument");
+    *N = ctx->N;
+    *n = ctx->n;
+    return GD_OK;
+}
+
+int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out) {
+    GD_REQUIRE(ctx && d_out, "null argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    if (j == -2) {
+        *d_out = ctx->w;
+        return GD_OK;
+    }
+    GD_REQUIRE(j >= 0 && j < ctx->n, "column out of range");
+    *d_out = ctx->cols + j * ctx->ld;
+    return GD_OK;
+}
+
+}  // extern "C"

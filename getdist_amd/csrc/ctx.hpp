@@ -1,0 +1,105 @@
+// Internal header of libgdhip.so (gfx950 only).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gdhip.h"
+
+struct FftPlanCache;  // density2d.hip
+
+struct gd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 256;
+    std::string err;
+    // sample set: SoA, column j at cols + j*ld, ld = N rounded up to 512 elements
+    double* cols = nullptr;
+    double* w = nullptr;  // nullptr => unit weights
+    int64_t N = 0, n = 0, ld = 0;
+    // reusable scratch (grown on demand)
+    void* scratch = nullptr;
+    int64_t scratch_bytes = 0;
+    void* scratch2 = nullptr;
+    int64_t scratch2_bytes = 0;
+    FftPlanCache* fft = nullptr;
+};
+
+int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
+void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure
+void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
+
+#define GD_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return gd_fail(ctx, e__ == hipErrorOutOfMemory ? GD_ERR_NOMEM : GD_ERR_HIP, "%s: %s (%s:%d)", #call, \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                              \
+    } while (0)
+
+#define GD_KERNEL_CHECK() GD_HIP(hipGetLastError())
+
+#define GD_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) return gd_fail(ctx, GD_ERR_BADARG, "%s", msg); \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------------------------------
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+
+// Block-wide sum; result valid in thread 0.  `red` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ double block_min(double v, double* red) {
+    v = wave_min(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double r = red[0];
+    if (threadIdx.x == 0)
+        for (int i = 1; i < nw; ++i) r = fmin(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double r = red[0];
+    if (threadIdx.x == 0)
+        for (int i = 1; i < nw; ++i) r = fmax(r, red[i]);
+    return r;
+}

@@ -1,0 +1,609 @@
+// Weighted moments, covariance, sort-free weighted quantiles, autocovariance lags, Gaussian-kernel lag sums.
+// All streaming kernels read the SoA columns with 16-byte (double2) loads, coalesced across the wave.
+#include "ctx.hpp"
+
+#define NBLK_STREAM 1024  // blocks per column for streaming reductions (x 256 threads): >> 256 CUs
+
+// Stream rows [lo,hi) of x (and w) with double2 loads; f(xval, wval) per element.
+template <bool HAS_W, class F>
+__device__ __forceinline__ void stream_xw(const double* __restrict__ x, const double* __restrict__ w, int64_t lo,
+                                          int64_t hi, F f) {
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t a = (lo + 1) & ~(int64_t)1, b = hi & ~(int64_t)1;  // 16-byte aligned body [a,b)
+    if (b <= a) {
+        if (gtid == 0)
+            for (int64_t i = lo; i < hi; ++i) f(x[i], HAS_W ? w[i] : 1.0);
+        return;
+    }
+    if (gtid == 0) {
+        if (lo < a) f(x[lo], HAS_W ? w[lo] : 1.0);
+        if (b < hi) f(x[b], HAS_W ? w[b] : 1.0);
+    }
+    for (int64_t i = a + 2 * gtid; i < b; i += 2 * gsz) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + i);
+        double2 wv = make_double2(1.0, 1.0);
+        if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
+        f(xv.x, wv.x);
+        f(xv.y, wv.y);
+    }
+}
+
+// ---- weight statistics --------------------------------------------------------------------------------
+__global__ void k_weight_stats(const double* __restrict__ w, int64_t lo, int64_t hi, double thresh,
+                               double* __restrict__ part) {
+    __shared__ double red[16];
+    double s = 0, s2 = 0, mx = -INFINITY, cnt = 0;
+    stream_xw<false>(w, nullptr, lo, hi, [&](double v, double) {
+        s += v;
+        s2 += v * v;
+        mx = fmax(mx, v);
+        cnt += (v > thresh) ? 1.0 : 0.0;
+    });
+    double r0 = block_sum(s, red), r1 = block_max(mx, red), r2 = block_sum(s2, red), r3 = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        double* p = part + (int64_t)blockIdx.x * 4;
+        p[0] = r0, p[1] = r1, p[2] = r2, p[3] = r3;
+    }
+}
+
+// ---- column statistics ----------------------------------------------------------------------------------
+// pass 1: min, max, sum w, sum w x      pass 2: sum w (x-mean)^2
+template <bool HAS_W>
+__global__ void k_col_pass1(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                            const double* __restrict__ w, int64_t lo, int64_t hi, double* __restrict__ part) {
+    __shared__ double red[16];
+    const int c = colidx ? colidx[blockIdx.y] : blockIdx.y;
+    const double* x = cols + (int64_t)c * ld;
+    double mn = INFINITY, mx = -INFINITY, sw = 0, swx = 0;
+    stream_xw<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+        sw += wt;
+        swx += wt * v;
+    });
+    double r0 = block_min(mn, red), r1 = block_max(mx, red), r2 = block_sum(sw, red), r3 = block_sum(swx, red);
+    if (threadIdx.x == 0) {
+        double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        p[0] = r0, p[1] = r1, p[2] = r2, p[3] = r3;
+    }
+}
+
+// one block per column: reduce the pass-1 partials; res[c] = {min, max, sumw, mean}
+__global__ void k_col_fin1(const double* __restrict__ part, int nblk, double* __restrict__ res) {
+    __shared__ double red[16];
+    const double* p = part + (int64_t)blockIdx.x * nblk * 4;
+    double mn = INFINITY, mx = -INFINITY, sw = 0, swx = 0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        mn = fmin(mn, p[i * 4 + 0]);
+        mx = fmax(mx, p[i * 4 + 1]);
+        sw += p[i * 4 + 2];
+        swx += p[i * 4 + 3];
+    }
+    double r0 = block_min(mn, red), r1 = block_max(mx, red), r2 = block_sum(sw, red), r3 = block_sum(swx, red);
+    if (threadIdx.x == 0) {
+        double* o = res + (int64_t)blockIdx.x * 4;
+        o[0] = r0, o[1] = r1, o[2] = r2, o[3] = r3 / r2;
+    }
+}
+
+template <bool HAS_W>
+__global__ void k_col_pass2(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                            const double* __restrict__ w, int64_t lo, int64_t hi, const double* __restrict__ res,
+                            double* __restrict__ part) {
+    __shared__ double red[16];
+    const int c = colidx ? colidx[blockIdx.y] : blockIdx.y;
+    const double* x = cols + (int64_t)c * ld;
+    const double mean = res[(int64_t)blockIdx.y * 4 + 3];
+    double s = 0;
+    stream_xw<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        const double d = v - mean;
+        s += wt * (d * d);
+    });
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// out[c] = {min, max, mean, var}
+__global__ void k_col_fin2(const double* __restrict__ part, int nblk, const double* __restrict__ res,
+                           double* __restrict__ out) {
+    __shared__ double red[16];
+    const double* p = part + (int64_t)blockIdx.x * nblk;
+    double s = 0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += p[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const double* q = res + (int64_t)blockIdx.x * 4;
+        double* o = out + (int64_t)blockIdx.x * 4;
+        o[0] = q[0], o[1] = q[1], o[2] = q[3], o[3] = r / q[2];
+    }
+}
+
+// ---- weighted covariance (two-pass) -----------------------------------------------------------------------
+// One block = one 64x64 tile of column pairs over one chunk of rows; 256 threads, 4x4 outputs per thread.
+#define CT 64
+#define CRB 64
+template <bool HAS_W>
+__global__ void __launch_bounds__(256) k_cov_tile(const double* __restrict__ cols, int64_t ld,
+                                                  const int32_t* __restrict__ colidx, int m,
+                                                  const double* __restrict__ res, const double* __restrict__ w,
+                                                  int64_t lo, int64_t hi, int64_t rows_per_chunk,
+                                                  const int2* __restrict__ tiles, double* __restrict__ part) {
+    __shared__ double sI[CRB][CT + 1];
+    __shared__ double sJ[CRB][CT + 1];
+    const int2 tl = tiles[blockIdx.y];
+    const int ci0 = tl.x * CT, cj0 = tl.y * CT;
+    const bool diag = (tl.x == tl.y);
+    const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+    const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
+    int64_t c_hi = c_lo + rows_per_chunk;
+    if (c_hi > hi) c_hi = hi;
+    for (int64_t r0 = c_lo; r0 < c_hi; r0 += CRB) {
+        __syncthreads();
+        // stage d = x - mean for the I tile (weighted) and the J tile
+        for (int e = threadIdx.x; e < CT * CRB; e += 256) {
+            const int r = e % CRB, c = e / CRB;
+            const int64_t row = r0 + r;
+            double vi = 0, vj = 0;
+            if (row < c_hi) {
+                const double wt = HAS_W ? w[row] : 1.0;
+                if (ci0 + c < m) {
+                    const int cc = colidx[ci0 + c];
+                    vi = (cols[(int64_t)cc * ld + row] - res[(int64_t)(ci0 + c) * 4 + 3]) * wt;
+                }
+                if (!diag && cj0 + c < m) {
+                    const int cc = colidx[cj0 + c];
+                    vj = cols[(int64_t)cc * ld + row] - res[(int64_t)(cj0 + c) * 4 + 3];
+                } else if (diag && ci0 + c < m) {
+                    const int cc = colidx[ci0 + c];
+                    vj = cols[(int64_t)cc * ld + row] - res[(int64_t)(ci0 + c) * 4 + 3];
+                }
+            }
+            sI[r][c] = vi;
+            sJ[r][c] = vj;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < CRB; ++r) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = sI[r][ti * 4 + u];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[v] = sJ[r][tj * 4 + v];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+        }
+    }
+    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (CT * CT);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) p[(ti * 4 + u) * CT + tj * 4 + v] = acc[u][v];
+}
+
+// cov[i][j] = sum over chunks / norm, mirrored
+__global__ void k_cov_fin(const double* __restrict__ part, int nchunks, const int2* __restrict__ tiles, int m,
+                          const double* __restrict__ res, double* __restrict__ cov) {
+    const int2 tl = tiles[blockIdx.y];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= CT * CT) return;
+    const int i = tl.x * CT + e / CT, j = tl.y * CT + e % CT;
+    if (i >= m || j >= m) return;
+    const double* p = part + (int64_t)blockIdx.y * nchunks * (CT * CT) + e;
+    double s = 0;
+    for (int c = 0; c < nchunks; ++c) s += p[(int64_t)c * (CT * CT)];
+    const double norm = res[2];
+    cov[(int64_t)i * m + j] = s / norm;
+    cov[(int64_t)j * m + i] = s / norm;
+}
+
+// ---- sort-free weighted quantiles: MSB radix select, 8 bits per pass ---------------------------------------
+#define QK_MAX 16
+struct QState {  // per column
+    unsigned long long prefix[QK_MAX];  // selected key bits so far (right-aligned)
+    double cum_below[QK_MAX];           // weight strictly below the selected prefix bucket
+    double target[QK_MAX];
+    int slot[QK_MAX];                   // target -> unique-prefix slot
+    unsigned long long uprefix[QK_MAX];
+    int nuniq;
+    int k;
+};
+
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+template <bool HAS_W>
+__global__ void k_qsel_pass(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                            const double* __restrict__ w, int64_t lo, int64_t hi, int pass,
+                            const QState* __restrict__ st, double* __restrict__ ghist) {
+    __shared__ double h[QK_MAX * 256];
+    __shared__ unsigned long long upre[QK_MAX];
+    __shared__ int nu;
+    const int c = blockIdx.y;
+    const double* x = cols + (int64_t)colidx[c] * ld;
+    if (threadIdx.x == 0) nu = (pass == 0) ? 1 : st[c].nuniq;
+    if (threadIdx.x < QK_MAX) upre[threadIdx.x] = st[c].uprefix[threadIdx.x];
+    __syncthreads();
+    const int nuniq = nu;
+    for (int i = threadIdx.x; i < nuniq * 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    stream_xw<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        const unsigned long long key = f64_key(v);
+        const int bin = (int)((key >> shift) & 255ull);
+        if (pass == 0) {
+            atomicAdd(&h[bin], wt);
+        } else {
+            const unsigned long long top = key >> (shift + 8);
+            for (int u = 0; u < nuniq; ++u)
+                if (top == upre[u]) {
+                    atomicAdd(&h[u * 256 + bin], wt);
+                    break;
+                }
+        }
+    });
+    __syncthreads();
+    double* g = ghist + (int64_t)c * QK_MAX * 256;
+    for (int i = threadIdx.x; i < nuniq * 256; i += blockDim.x) {
+        const double v = h[i];
+        if (v != 0) unsafeAtomicAdd(&g[i], v);
+    }
+}
+
+// one thread per column: consume the histograms, extend each target's prefix by 8 bits, dedupe prefixes.
+__global__ void k_qsel_scan(QState* __restrict__ st, double* __restrict__ ghist, int ncols, int pass) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    QState& s = st[c];
+    double* g = ghist + (int64_t)c * QK_MAX * 256;
+    for (int t = 0; t < s.k; ++t) {
+        const double* h = g + (pass == 0 ? 0 : s.slot[t]) * 256;
+        double cum = s.cum_below[t];
+        int pick = -1, last_nonempty = -1;
+        double cum_at_last = cum;
+        for (int b = 0; b < 256; ++b) {
+            const double hv = h[b];
+            if (hv != 0) {
+                last_nonempty = b;
+                cum_at_last = cum;
+            }
+            if (cum + hv >= s.target[t] && hv != 0) {
+                pick = b;
+                break;
+            }
+            cum += hv;
+        }
+        if (pick < 0) {  // target beyond the total weight: the reference clamps to the last element
+            pick = last_nonempty < 0 ? 0 : last_nonempty;
+            cum = cum_at_last;
+        }
+        s.prefix[t] = (s.prefix[t] << 8) | (unsigned long long)pick;
+        s.cum_below[t] = cum;
+    }
+    // unique prefixes for the next pass
+    int nu = 0;
+    for (int t = 0; t < s.k; ++t) {
+        int f = -1;
+        for (int u = 0; u < nu; ++u)
+            if (s.uprefix[u] == s.prefix[t]) f = u;
+        if (f < 0) {
+            f = nu;
+            s.uprefix[nu++] = s.prefix[t];
+        }
+        s.slot[t] = f;
+    }
+    s.nuniq = nu;
+    for (int i = 0; i < QK_MAX * 256; ++i) g[i] = 0;
+}
+
+__global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols * k) return;
+    out[i] = key_f64(st[i / k].prefix[i % k]);
+}
+
+// ---- autocovariance lag sums: out[l] = sum_i d_i d_{i+k0+l},  d = (x-mean)*w ---------------------------------
+#define AL 32     // lags per launch
+#define AT 2048   // rows per tile
+template <bool HAS_W>
+__global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ x, const double* __restrict__ w,
+                                                 int64_t N, double mean, int64_t k0, double* __restrict__ part) {
+    __shared__ double sB[AT + AL];
+    __shared__ double red[16];
+    double acc[AL];
+#pragma unroll
+    for (int l = 0; l < AL; ++l) acc[l] = 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * AT; t0 < N; t0 += (int64_t)gridDim.x * AT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < AT + AL; e += 256) {
+            const int64_t r = t0 + k0 + e;
+            sB[e] = (r < N) ? (x[r] - mean) * (HAS_W ? w[r] : 1.0) : 0.0;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < AT; e += 256) {
+            const int64_t r = t0 + e;
+            if (r < N) {
+                const double a = (x[r] - mean) * (HAS_W ? w[r] : 1.0);
+#pragma unroll
+                for (int l = 0; l < AL; ++l) acc[l] = fma(a, sB[e + l], acc[l]);
+            }
+        }
+    }
+    for (int l = 0; l < AL; ++l) {
+        const double r = block_sum(acc[l], red);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * AL + l] = r;
+    }
+}
+
+__global__ void k_sum_partials(const double* __restrict__ part, int nblk, int stride, double* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += part[(int64_t)i * stride + blockIdx.x];
+    const double r = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+// ---- Gaussian-kernel lag sums: out[l] = sum_i exp(-(x_i - x_{i+k})^2 * c) w_i w_{i+k} -----------------------
+template <bool HAS_W>
+__global__ void k_kde_lag(const double* __restrict__ x, const double* __restrict__ w, int64_t N, double c,
+                          const int64_t* __restrict__ lags, double* __restrict__ part) {
+    __shared__ double red[16];
+    const int64_t k = lags[blockIdx.y];
+    const int64_t M = N - k;
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = x[i] - x[i + k];
+        double e = exp(-(d * d) * c);
+        if (HAS_W) e = e * w[i] * w[i + k];
+        s += e;
+    }
+    const double r = block_sum(s, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// =============================================================================================================
+extern "C" {
+
+int gd_weight_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double thresh, double* out4) {
+    GD_REQUIRE(ctx && out4, "null argument");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    if (!ctx->w) {
+        const double cnt = (double)(hi - lo);
+        out4[0] = cnt, out4[1] = 1.0, out4[2] = cnt, out4[3] = (1.0 > thresh) ? cnt : 0.0;
+        return GD_OK;
+    }
+    const int nblk = NBLK_STREAM;
+    double* part = (double*)gd_scratch(ctx, (int64_t)nblk * 4 * 8);
+    if (!part) return GD_ERR_NOMEM;
+    k_weight_stats<<<nblk, 256, 0, ctx->stream>>>(ctx->w, lo, hi, thresh, part);
+    GD_KERNEL_CHECK();
+    std::vector<double> h((size_t)nblk * 4);
+    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    double s = 0, mx = -INFINITY, s2 = 0, cnt = 0;
+    for (int i = 0; i < nblk; ++i) {
+        s += h[i * 4], s2 += h[i * 4 + 2], cnt += h[i * 4 + 3];
+        if (h[i * 4 + 1] > mx) mx = h[i * 4 + 1];
+    }
+    out4[0] = s, out4[1] = mx, out4[2] = s2, out4[3] = cnt;
+    return GD_OK;
+}
+
+// shared by gd_col_stats / gd_cov: d_res[c] = {min,max,sumw,mean}; optional variance into d_out (n x 4)
+static int col_stats_device(gd_ctx* ctx, const int32_t* d_colidx, int ncols, int64_t lo, int64_t hi, double* d_res,
+                            double* d_part, double* d_out) {
+    const int nblk = NBLK_STREAM;
+    dim3 grid(nblk, ncols);
+    if (ctx->w)
+        k_col_pass1<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, ctx->w, lo, hi, d_part);
+    else
+        k_col_pass1<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, nullptr, lo, hi, d_part);
+    GD_KERNEL_CHECK();
+    k_col_fin1<<<ncols, 256, 0, ctx->stream>>>(d_part, nblk, d_res);
+    GD_KERNEL_CHECK();
+    if (d_out) {
+        if (ctx->w)
+            k_col_pass2<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, ctx->w, lo, hi, d_res, d_part);
+        else
+            k_col_pass2<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, nullptr, lo, hi, d_res,
+                                                              d_part);
+        GD_KERNEL_CHECK();
+        k_col_fin2<<<ncols, 256, 0, ctx->stream>>>(d_part, nblk, d_res, d_out);
+        GD_KERNEL_CHECK();
+    }
+    return GD_OK;
+}
+
+int gd_col_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double* out) {
+    GD_REQUIRE(ctx && out, "null argument");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    const int n = (int)ctx->n;
+    const int64_t bytes = ((int64_t)n * NBLK_STREAM * 4 + (int64_t)n * 8) * 8;
+    double* base = (double*)gd_scratch(ctx, bytes);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_part = base;
+    double* d_res = base + (int64_t)n * NBLK_STREAM * 4;
+    double* d_out = d_res + (int64_t)n * 4;
+    int rc = col_stats_device(ctx, nullptr, n, lo, hi, d_res, d_part, d_out);
+    if (rc) return rc;
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, double* means_out, double* cov_out,
+           double* norm_out) {
+    GD_REQUIRE(ctx && cols && means_out && cov_out && norm_out && m > 0, "bad argument");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    for (int i = 0; i < m; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    const int nt = (m + CT - 1) / CT;
+    std::vector<int2> tiles;
+    for (int a = 0; a < nt; ++a)
+        for (int b = a; b < nt; ++b) tiles.push_back(make_int2(a, b));
+    const int ntp = (int)tiles.size();
+    const int64_t rows = hi - lo;
+    int nchunks = (2 * ctx->cu_count + ntp - 1) / ntp;
+    if (nchunks > (rows + CRB - 1) / CRB) nchunks = (int)((rows + CRB - 1) / CRB);
+    if (nchunks < 1) nchunks = 1;
+    int64_t rows_per_chunk = (rows + nchunks - 1) / nchunks;
+    rows_per_chunk = (rows_per_chunk + CRB - 1) / CRB * CRB;
+    nchunks = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
+    // scratch layout
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_part1 = take((int64_t)m * NBLK_STREAM * 4 * 8), o_res = take((int64_t)m * 4 * 8),
+                  o_idx = take((int64_t)m * 4), o_tiles = take((int64_t)ntp * 8),
+                  o_cpart = take((int64_t)ntp * nchunks * CT * CT * 8), o_cov = take((int64_t)m * m * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_part1 = (double*)(base + o_part1);
+    double* d_res = (double*)(base + o_res);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    int2* d_tiles = (int2*)(base + o_tiles);
+    double* d_cpart = (double*)(base + o_cpart);
+    double* d_cov = (double*)(base + o_cov);
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntp * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
+    if (rc) return rc;
+    dim3 grid(nchunks, ntp);
+    if (ctx->w)
+        k_cov_tile<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, ctx->w, lo, hi,
+                                                         rows_per_chunk, d_tiles, d_cpart);
+    else
+        k_cov_tile<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, nullptr, lo, hi,
+                                                          rows_per_chunk, d_tiles, d_cpart);
+    GD_KERNEL_CHECK();
+    k_cov_fin<<<dim3((CT * CT + 255) / 256, ntp), 256, 0, ctx->stream>>>(d_cpart, nchunks, d_tiles, m, d_res, d_cov);
+    GD_KERNEL_CHECK();
+    std::vector<double> hres((size_t)m * 4);
+    GD_HIP(hipMemcpyAsync(hres.data(), d_res, hres.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(cov_out, d_cov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < m; ++i) means_out[i] = hres[(size_t)i * 4 + 3];
+    *norm_out = hres[2];
+    return GD_OK;
+}
+
+int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets,
+                 int32_t k, double* out) {
+    GD_REQUIRE(ctx && cols && targets && out && ncols > 0, "bad argument");
+    GD_REQUIRE(k > 0 && k <= QK_MAX, "at most 16 quantiles per call");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    std::vector<QState> hst((size_t)ncols);
+    memset(hst.data(), 0, hst.size() * sizeof(QState));
+    for (int c = 0; c < ncols; ++c) {
+        hst[c].k = k;
+        hst[c].nuniq = 1;
+        for (int t = 0; t < k; ++t) hst[c].target[t] = targets[(size_t)c * k + t];
+    }
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_st = take((int64_t)ncols * sizeof(QState)), o_h = take((int64_t)ncols * QK_MAX * 256 * 8),
+                  o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    QState* d_st = (QState*)(base + o_st);
+    double* d_h = (double*)(base + o_h);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    double* d_out = (double*)(base + o_out);
+    GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_h, 0, (size_t)ncols * QK_MAX * 256 * 8, ctx->stream));
+    const int nblk = 2 * ctx->cu_count;
+    for (int pass = 0; pass < 8; ++pass) {
+        dim3 grid(nblk, ncols);
+        if (ctx->w)
+            k_qsel_pass<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, pass, d_st, d_h);
+        else
+            k_qsel_pass<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, pass, d_st,
+                                                               d_h);
+        GD_KERNEL_CHECK();
+        k_qsel_scan<<<(ncols + 63) / 64, 64, 0, ctx->stream>>>(d_st, d_h, ncols, pass);
+        GD_KERNEL_CHECK();
+    }
+    k_qsel_out<<<(ncols * k + 255) / 256, 256, 0, ctx->stream>>>(d_st, ncols, k, d_out);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out) {
+    GD_REQUIRE(ctx && out && nlags > 0, "bad argument");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n && k0 >= 0, "bad column / lag");
+    const int nblk = 2 * ctx->cu_count;
+    double* part = (double*)gd_scratch(ctx, ((int64_t)nblk * AL + AL) * 8);
+    if (!part) return GD_ERR_NOMEM;
+    double* d_out = part + (int64_t)nblk * AL;
+    const double* x = ctx->cols + (int64_t)col * ctx->ld;
+    for (int32_t done = 0; done < nlags; done += AL) {
+        if (ctx->w)
+            k_autocov<true><<<nblk, 256, 0, ctx->stream>>>(x, ctx->w, ctx->N, mean, k0 + done, part);
+        else
+            k_autocov<false><<<nblk, 256, 0, ctx->stream>>>(x, nullptr, ctx->N, mean, k0 + done, part);
+        GD_KERNEL_CHECK();
+        k_sum_partials<<<AL, 256, 0, ctx->stream>>>(part, nblk, AL, d_out);
+        GD_KERNEL_CHECK();
+        const int take = (nlags - done < AL) ? nlags - done : AL;
+        GD_HIP(hipMemcpyAsync(out + done, d_out, (size_t)take * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GD_OK;
+}
+
+int gd_kde_lag_sums(gd_ctx* ctx, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out) {
+    GD_REQUIRE(ctx && lags && out && nlags > 0 && nlags <= 64, "bad argument");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
+    for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
+    const int nblk = 2 * ctx->cu_count;
+    int64_t off_l = ((int64_t)nlags * nblk * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, off_l + nlags * 8 + 256 + nlags * 8);
+    if (!base) return GD_ERR_NOMEM;
+    double* part = (double*)base;
+    int64_t* d_lags = (int64_t*)(base + off_l);
+    double* d_out = (double*)(base + off_l + ((int64_t)nlags * 8 + 255) / 256 * 256);
+    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
+    const double* x = ctx->cols + (int64_t)col * ctx->ld;
+    dim3 grid(nblk, nlags);
+    if (ctx->w)
+        k_kde_lag<true><<<grid, 256, 0, ctx->stream>>>(x, ctx->w, ctx->N, inv4s2, d_lags, part);
+    else
+        k_kde_lag<false><<<grid, 256, 0, ctx->stream>>>(x, nullptr, ctx->N, inv4s2, d_lags, part);
+    GD_KERNEL_CHECK();
+    // partials are laid out [lag][block]: reduce each row
+    std::vector<double> h((size_t)nlags * nblk);
+    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    (void)d_out;
+    for (int l = 0; l < nlags; ++l) {
+        double s = 0;
+        for (int b = 0; b < nblk; ++b) s += h[(size_t)l * nblk + b];
+        out[l] = s;
+    }
+    return GD_OK;
+}
+
+}  // extern "C"

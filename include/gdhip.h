@@ -1,0 +1,164 @@
+/*
+ * gdhip.h -- C ABI of libgdhip.so: the MI355X (gfx950) implementation of GetDist's weighted-sample
+ * statistics + 1D/2D kernel-density hot path.
+ *
+ * The reference (GetDist 1.7.7) is pure Python and has NO FFI seam for this path: every
+ * entry point below replaces a span of numpy/scipy calls inside the reference's Python methods; the
+ * span is cited as file:line under /root/reference/getdist/.  The binding a maintainer would add is a
+ * ctypes stub (getdist_amd/_lib.py, and INTEGRATION.md).
+ *
+ * Conventions: all entry points are extern "C", return 0 on success or a negative gd_status; no C++
+ * exception crosses the ABI; sizes are int64_t; floating point is IEEE fp64 throughout; "d_" pointers
+ * are DEVICE pointers obtained from gd_dev_alloc (opaque to the caller), everything else is host
+ * memory owned by the caller.  A gd_ctx is bound to one device and one stream and is not thread-safe;
+ * use one ctx per thread/GPU.  gd_last_error(ctx) returns a static/ctx-owned message for the last
+ * failing call.
+ */
+#ifndef GDHIP_H
+#define GDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gd_ctx gd_ctx;
+
+typedef enum gd_status {
+    GD_OK = 0,
+    GD_ERR_BADARG = -1,    /* -> ValueError / SettingError in the Python layer */
+    GD_ERR_NOMEM = -2,     /* -> MemoryError */
+    GD_ERR_HIP = -3,       /* -> RuntimeError (message holds hipGetErrorString) */
+    GD_ERR_EMPTY = -4,     /* "no samples in bin" -> DensitiesError (densities.py:83-84) */
+    GD_ERR_SOLVER = -5,    /* bandwidth root-find failed -> fallback / BandwidthError (mcsamples.py:1258-1268) */
+    GD_ERR_FFT = -6,       /* rocFFT failure */
+    GD_ERR_NODEVICE = -7   /* no HIP device visible */
+} gd_status;
+
+/* ---------------------------------------------------------------- context / memory ------------- */
+int gd_device_count(void);
+int gd_create(int device, gd_ctx** out);
+void gd_destroy(gd_ctx* ctx);
+const char* gd_last_error(gd_ctx* ctx);
+const char* gd_version(void);
+/* info[0]=CU count, [1]=LDS bytes/block, [2]=total HBM bytes, [3]=free HBM bytes, [4]=clock kHz, [5]=warp size */
+int gd_device_info(gd_ctx* ctx, int64_t* info6);
+int gd_sync(gd_ctx* ctx);
+int gd_dev_alloc(gd_ctx* ctx, int64_t bytes, void** d_out);
+int gd_dev_free(gd_ctx* ctx, void* d_ptr);
+int gd_memcpy_h2d(gd_ctx* ctx, void* d_dst, const void* src, int64_t bytes);
+int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
+int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
+/* HIP-event timing on the ctx stream (bench.py measures kernels with these, not torch events) */
+int gd_timer_start(gd_ctx* ctx);
+int gd_timer_stop_ms(gd_ctx* ctx, double* ms_out);
+
+/* ---------------------------------------------------------------- sample set -------------------
+ * Replaces WeightedSamples.setSamples/_weightsChanged (chains.py:276-323): the library keeps its own
+ * column-major (SoA) fp64 copy of the N x n sample array and of the weights in HBM.
+ * X[i*row_stride + j*col_stride] is sample i of parameter j (strides in elements); weights may be
+ * NULL (unit weights: chains.py:313-315).  Re-uploading replaces the previous set. */
+int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
+              const double* weights);
+int gd_num_rows(gd_ctx* ctx, int64_t* N, int64_t* n);
+/* device pointer to column j (N doubles) / weights (NULL if unit) -- for tests and zero-copy users */
+int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out);
+
+/* ---------------------------------------------------------------- weighted moments -------------
+ * gd_weight_stats: norm=sum w (chains.py:312), max w (chains.py:1349), sum w^2 (chains.py:499,536),
+ *   count of w > thresh (mcsamples.py:559-560).   out4 = {norm, max_w, sum_w2, n_above}
+ * gd_col_stats: per column over rows [row_lo,row_hi): min, max (mcsamples.py:1434-1435), weighted mean
+ *   (chains.py:379), weighted variance about that mean (chains.py:409-410). out = n x 4 {min,max,mean,var}
+ * gd_cov: two-pass weighted covariance of the listed columns over rows [row_lo,row_hi)
+ *   (chains.py:709-733 + mean_diffs :763-780); means_out m, cov_out m x m, norm_out 1. */
+int gd_weight_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double thresh, double* out4);
+int gd_col_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double* out);
+int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t row_lo, int64_t row_hi, double* means_out,
+           double* cov_out, double* norm_out);
+
+/* ---------------------------------------------------------------- weighted quantiles -----------
+ * Replaces initParamConfidenceData + confidence (chains.py:793-838: argsort, cumsum(w[idx]),
+ * searchsorted(cumsum, target), x[idx[min(ix,N-1)]]) by a sort-free MSB radix select.
+ * targets are cumulative-weight targets (norm*limfrac, computed by the caller exactly as the
+ * reference does); out[c*k + t] = smallest sample value v of column cols[c] whose cumulative weight
+ * sum_{x<=v} w reaches targets[c*k+t] (the maximum if none does). */
+int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
+                 const double* targets, int32_t k, double* out);
+
+/* ---------------------------------------------------------------- autocorrelation / N_eff ------
+ * gd_autocov_lags: out[l] = sum_{i} d_i d_{i+k0+l}, d=(x-mean)*w, l<nlags -- the un-normalised lag
+ *   sums convolve.autoConvolve (convolve.py:458-478) obtains by FFT for chains.py:441.
+ * gd_kde_lag_sums: out[l] = sum_i exp(-(x_i-x_{i+k_l})^2 * inv4s2) w_i w_{i+k_l}
+ *   (corr_k and the uncorrelated-term loop of getEffectiveSamplesGaussianKDE, chains.py:514-540). */
+int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out);
+int gd_kde_lag_sums(gd_ctx* ctx, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out);
+
+/* ---------------------------------------------------------------- binning ----------------------
+ * Index rule (mcsamples.py:1497): ix = (int)((x - binmin)/fine_width + 0.5), IEEE fp64, no FMA
+ * contraction, true division.  Truncating rule (kde_bandwidth.py:86-87): (int)((x - range_min)/dx).
+ * gd_hist1d: fused index + weighted bincount (mcsamples.py:1554) for ncols columns -> out ncols x F.
+ * gd_bin_indices: writes the int32 indices (tests: bit-exact index parity; n_out_of_range counts
+ *   indices outside [0,F)).
+ * gd_prebin: u16 bin-index columns kept on the device for the batched 2D path; d_idx is N u16.
+ * gd_hist2d: weighted 2D histogram hist[iy*F+ix] (mcsamples.py:1724-1728) for B pairs, direct from the
+ *   fp64 columns (x index from colx with rule `round`, y from coly) -> d_hist B x F x F (device).
+ * gd_hist2d_prebinned: same from u16 index columns produced by gd_prebin.
+ * gd_minmax_affine: min/max over samples of a*x_i + b*x_j (the sheared coordinate p2,
+ *   mcsamples.py:1373 + kde_bandwidth.py:77-78); out 2*B.
+ * gd_hist2d_sheared: rotated histogram of mcsamples.py:1372-1378: x index = trunc((x_i - xmin)/dx),
+ *   y index = trunc(((r0*x_i + r1*x_j) - ymin)/dy). */
+int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+              int32_t F, double* out);
+int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
+                   int32_t* idx_out, int64_t* n_out_of_range);
+int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16);
+int gd_hist2d(gd_ctx* ctx, int32_t B, const int32_t* colx, const int32_t* coly, const double* binminx,
+              const double* widthx, const double* binminy, const double* widthy, int32_t F, void* d_hist);
+int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
+                        void* d_hist);
+int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* a,
+                     const double* b, double* out);
+int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* r0,
+                      const double* r1, const double* xmin, const double* dx, const double* ymin, const double* dy,
+                      int32_t F, void* d_hist);
+
+/* ---------------------------------------------------------------- 1D density -------------------
+ * gd_dct1d: a = DCT-II(data/sum(data)) (scipy.fftpack.dct type 2, unnormalised), for the Botev ISJ
+ *   fixed point (kde_bandwidth.py:113-117).  in/out host arrays B x F.
+ * gd_density1d: everything after the bandwidth for B parameters (mcsamples.py:1588-1668): Gaussian
+ *   taps (Kernel1D :129-135), 'same' convolution (convolve.py:196-202), boundary correction of order
+ *   bco (0,1,2; mcsamples.py:1600-1647), mbc rounds of multiplicative bias correction (:1649-1666),
+ *   normalize("max") (densities.py:71-92).  hist: B x F (host); smooth[b] in fine-bin units, winw[b];
+ *   flags[b] bit0=has_limits_bot bit1=has_limits_top bit2=periodic.  P_out: B x F.
+ *   status_out[b] = GD_OK or GD_ERR_EMPTY. */
+int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_out);
+int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* smooth, const int32_t* winw,
+                 const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out);
+
+/* ---------------------------------------------------------------- 2D bandwidth -----------------
+ * gd_kopt2d: KernelOptimizer2D.__init__ + the psi functionals get_h needs (kde_bandwidth.py:146-270)
+ *   for B square histograms (device, B x F x F): a2 = dct2d(data/sum)[1:,1:]^2 (:151), t* by Brent's
+ *   method on the 2D fixed point over [0,0.1] with xtol=1e-6 (:162,177-196; scipy brentq semantics:
+ *   rtol=4eps, maxiter=100), the fallback_t rules (:164-175; fallback_t<=0 means None),
+ *   psi_02, psi_20, psi_11 = func2d at t* (:245-247), and when do_corr[b]: psi_00 (:267) and the odd
+ *   functionals psi_13, psi_31 from |fft2|^2 (:156-157,198-214,269-270).
+ *   out: B x 8 = {t_star, p02, p20, p11, p00, p13, p31, status(0 ok, <0 gd_status)}. */
+int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
+              const double* fallback_t, double* out);
+
+/* ---------------------------------------------------------------- 2D density -------------------
+ * gd_density2d: everything after the bandwidth for B pairs sharing F (mcsamples.py:1857-1990):
+ *   window synthesis from (rx, ry, corr, winw) (:1863-1867), zero-padded linear FFT convolution via
+ *   rocFFT (convolve.py:405-436), linear boundary correction of order bco (0/1) where a parameter has a
+ *   limit (:1905-1961; flags[b] bit0/1 = x bot/top, bit2/3 = y bot/top), mbc rounds of multiplicative
+ *   bias correction (:1963-1976), normalize("max") (:1990).
+ *   d_hist: B x F x F (device, [y][x]); d_P_out: B x F x F (device).  status_out[b] as gd_density1d. */
+int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry,
+                 const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
+                 void* d_P_out, int32_t* status_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDHIP_H */

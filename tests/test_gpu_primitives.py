@@ -1,0 +1,191 @@
+"""GPU parity tests of the O(N) kernels, through the C ABI, against numpy / the oracle on seeded inputs."""
+
+import numpy as np
+import pytest
+
+from getdist_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from getdist_amd._lib import Context
+
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=["weighted", "unit"])
+def data(request, ctx):
+    N = 300_001  # odd on purpose: exercises the unaligned tails
+    s, w, names, ranges = synth.block_recipe(10, N, weighted=(request.param == "weighted"), stream=21)
+    ctx.upload(s, w)
+    return s, (w if w is not None else np.ones(N)), w is not None
+
+
+def test_upload_layouts(ctx):
+    r = np.random.default_rng(1)
+    a = r.standard_normal((1000, 7))
+    for arr in (a, np.asfortranarray(a)):
+        ctx.upload(arr, None)
+        st = ctx.col_stats()
+        assert np.array_equal(st[:, 0], a.min(axis=0))
+        assert np.array_equal(st[:, 1], a.max(axis=0))
+
+
+def test_col_stats_and_cov(ctx, data):
+    s, w, _ = data
+    norm = w.sum()
+    st = ctx.col_stats()
+    assert np.array_equal(st[:, 0], s.min(axis=0))
+    assert np.array_equal(st[:, 1], s.max(axis=0))
+    means = w.dot(s) / norm
+    assert np.allclose(st[:, 2], means, rtol=1e-12, atol=1e-14)
+    var = np.array([w.dot((s[:, i] - means[i]) ** 2) / norm for i in range(s.shape[1])])
+    assert np.allclose(st[:, 3], var, rtol=1e-12)
+    m, cov, nrm = ctx.cov()
+    d = s - means
+    ref = (d * w[:, None]).T @ d / norm
+    assert abs(nrm - norm) <= 1e-12 * norm
+    assert np.allclose(cov, ref, rtol=1e-11, atol=1e-13)
+    assert np.array_equal(cov, cov.T)
+    # row sub-range and column subset (chain slices for Gelman-Rubin)
+    lo, hi = 1001, 200_000
+    m2, cov2, n2 = ctx.cov(cols=[3, 7, 1], lo=lo, hi=hi)
+    ws, ss = w[lo:hi], s[lo:hi][:, [3, 7, 1]]
+    mm = ws.dot(ss) / ws.sum()
+    assert np.allclose(m2, mm, rtol=1e-12, atol=1e-14)
+    dd = ss - mm
+    assert np.allclose(cov2, (dd * ws[:, None]).T @ dd / ws.sum(), rtol=1e-11, atol=1e-13)
+    ws_ = ctx.weight_stats(thresh=2.0)
+    assert abs(ws_["norm"] - norm) <= 1e-12 * norm
+    assert ws_["max_w"] == w.max()
+    assert abs(ws_["sum_w2"] - w.dot(w)) <= 1e-12 * w.dot(w)
+    assert ws_["n_above"] == np.sum(w > 2.0)
+
+
+def test_quantiles_match_argsort_semantics(ctx, data):
+    s, w, weighted = data
+    fracs = np.array([0.001, 0.999] + list(np.linspace(0.1, 0.9, 9)) + [1.0, 2.0, 0.0])
+    norm = np.sum(w)
+    cols = [0, 4, 9]
+    targets = np.tile(norm * fracs, (len(cols), 1))
+    got = ctx.quantiles(cols, targets)
+    for ci, c in enumerate(cols):
+        idx = s[:, c].argsort()
+        cum = np.cumsum(w[idx])
+        ix = np.searchsorted(cum, targets[ci])
+        want = s[:, c][idx[np.minimum(ix, len(idx) - 1)]]
+        if weighted:  # summation order may move a knife-edge pick by one sample
+            pos_got = np.searchsorted(s[:, c][idx], got[ci])
+            pos_want = np.searchsorted(s[:, c][idx], want)
+            assert np.all(np.abs(pos_got - pos_want) <= 1)
+            assert np.mean(got[ci] == want) > 0.8
+        else:
+            assert np.array_equal(got[ci], want)
+
+
+def test_bin_indices_bit_exact(ctx, data):
+    s, w, _ = data
+    for c, F in ((0, 1024), (4, 256), (7, 960)):
+        x = s[:, c]
+        binmin = x.min() - 0.1 * (x.max() - x.min())
+        width = (x.max() + 0.1 * (x.max() - x.min()) - binmin) / (F - 1)
+        idx, bad = ctx.bin_indices(c, binmin, width, F, round_half=True)
+        assert bad == 0
+        assert np.array_equal(idx, ((x - binmin) / width + 0.5).astype(int))
+        idx, bad = ctx.bin_indices(c, binmin, width, F, round_half=False)
+        assert np.array_equal(idx, ((x - binmin) / width).astype(int))
+
+
+def test_hist1d(ctx, data):
+    s, w, weighted = data
+    cols = [0, 3, 9]
+    F = 1024
+    bm, wd = [], []
+    for c in cols:
+        x = s[:, c]
+        bm.append(x.min())
+        wd.append((x.max() - x.min()) / (F - 1))
+    h = ctx.hist1d(cols, bm, wd, F)
+    for k, c in enumerate(cols):
+        ix = ((s[:, c] - bm[k]) / wd[k] + 0.5).astype(int)
+        ref = np.bincount(ix, weights=w, minlength=F)
+        if weighted:
+            assert np.allclose(h[k], ref, rtol=1e-12, atol=1e-12)
+        else:
+            assert np.array_equal(h[k], ref)
+
+
+@pytest.mark.parametrize("F", [256, 384, 64])
+def test_hist2d_direct_and_prebinned(ctx, data, F):
+    s, w, weighted = data
+    pairs = [(0, 1), (5, 6), (2, 9), (9, 2)]
+    bx, wx, by, wy = [], [], [], []
+
+    def edges(c):
+        x = s[:, c]
+        b0 = x.min() - 0.05 * (x.max() - x.min())
+        return b0, (x.max() - b0) / (F - 1)
+
+    for a, b in pairs:
+        e = edges(a), edges(b)
+        bx.append(e[0][0]), wx.append(e[0][1]), by.append(e[1][0]), wy.append(e[1][1])
+    d = ctx.hist2d([p[0] for p in pairs], [p[1] for p in pairs], bx, wx, by, wy, F)
+    H = d.to_host((len(pairs), F, F))
+    pre = {c: ctx.prebin(c, *edges(c), F) for c in {p for pr in pairs for p in pr}}
+    d2 = ctx.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F)
+    H2 = d2.to_host((len(pairs), F, F))
+    for k, (a, b) in enumerate(pairs):
+        ixs = ((s[:, a] - bx[k]) / wx[k] + 0.5).astype(int)
+        iys = ((s[:, b] - by[k]) / wy[k] + 0.5).astype(int)
+        ref = np.bincount(ixs + iys * F, weights=w, minlength=F * F).reshape(F, F)
+        if weighted:
+            assert np.allclose(H[k], ref, rtol=1e-12, atol=1e-12)
+            assert np.allclose(H2[k], ref, rtol=1e-12, atol=1e-12)
+        else:
+            assert np.array_equal(H[k], ref)
+            assert np.array_equal(H2[k], ref)
+    # single-pair launch takes the chunked (atomic-merge) path
+    d1 = ctx.hist2d([0], [1], bx[:1], wx[:1], by[:1], wy[:1], F)
+    H1 = d1.to_host((1, F, F))
+    assert np.allclose(H1[0], H[0], rtol=1e-12, atol=1e-12)
+
+
+def test_sheared_hist_and_minmax(ctx, data):
+    s, w, _ = data
+    F = 256
+    r0, r1 = -0.37, 1.21
+    mm = ctx.minmax_affine([5], [6], [r0], [r1])
+    p2 = r0 * s[:, 5] + r1 * s[:, 6]
+    assert mm[0, 0] == p2.min() and mm[0, 1] == p2.max()
+    from oracle.kde_oracle import trunc_bin_samples
+
+    b1, R1 = trunc_bin_samples(s[:, 5], nbins=F)
+    b2, R2 = trunc_bin_samples(p2, nbins=F)
+    x = s[:, 5]
+    xmin = x.min() - (x.max() - x.min()) * 0.1
+    ymin = p2.min() - (p2.max() - p2.min()) * 0.1
+    d = ctx.hist2d_sheared([5], [6], [r0], [r1], [xmin], [R1 / (F - 1)], [ymin], [R2 / (F - 1)], F)
+    H = d.to_host((F, F))
+    ref = np.bincount(b1 + b2 * F, weights=w, minlength=F * F).reshape(F, F)
+    assert np.allclose(H, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_lag_sums(ctx, data):
+    s, w, _ = data
+    x = s[:, 2]
+    mean = w.dot(x) / w.sum()
+    d = (x - mean) * w
+    got = ctx.autocov_lags(2, mean, 0, 40)
+    ref = np.array([np.dot(d[:len(d) - k], d[k:]) for k in range(40)])
+    assert np.allclose(got, ref, rtol=1e-11, atol=1e-9 * abs(ref[0]))
+    got = ctx.autocov_lags(2, mean, 37, 5)
+    assert np.allclose(got, [np.dot(d[:len(d) - k], d[k:]) for k in range(37, 42)], rtol=1e-9, atol=1e-9 * abs(ref[0]))
+    lags = np.array([1, 2, 7, len(x) // 2, len(x) // 2 + 4])
+    c = 1.0 / (4 * 0.3**2)
+    got = ctx.kde_lag_sums(2, c, lags)
+    ref = [np.dot(np.exp(-((x[:-k] - x[k:]) ** 2) * c) * w[:-k], w[k:]) for k in lags]
+    assert np.allclose(got, ref, rtol=1e-12)
