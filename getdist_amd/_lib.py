@@ -52,6 +52,7 @@ SIGNATURES = {
     "gd_dev_free": (C.c_int, [_p, _p]),
     "gd_memcpy_h2d": (C.c_int, [_p, _p, _p, _i64]),
     "gd_memcpy_d2h": (C.c_int, [_p, _p, _p, _i64]),
+    "gd_memcpy_d2d": (C.c_int, [_p, _p, _p, _i64]),
     "gd_memset": (C.c_int, [_p, _p, C.c_int, _i64]),
     "gd_timer_start": (C.c_int, [_p]),
     "gd_timer_stop_ms": (C.c_int, [_p, _pd]),
@@ -188,6 +189,9 @@ class Context:
 
     def sync(self):
         self._check(self.lib.gd_sync(self.h))
+
+    def copy_d2d(self, dst, dst_off, src, src_off, nbytes):
+        self._check(self.lib.gd_memcpy_d2d(self.h, dst.ptr + dst_off, src.ptr + src_off, int(nbytes)))
 
     def timer_start(self):
         self._check(self.lib.gd_timer_start(self.h))

@@ -34,7 +34,6 @@ void* gd_scratch2(gd_ctx* ctx, int64_t bytes) {
     return grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes) ? nullptr : ctx->scratch2;
 }
 
-extern void gd_fft_cache_destroy(gd_ctx* ctx);
 
 extern "C" {
 
@@ -70,6 +69,7 @@ void gd_destroy(gd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     gd_fft_cache_destroy(ctx);
+    for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
     if (ctx->cols) (void)hipFree(ctx->cols);
     if (ctx->w) (void)hipFree(ctx->w);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -132,6 +132,12 @@ int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes) {
     GD_REQUIRE(ctx && dst && d_src && bytes >= 0, "bad argument");
     GD_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes) {
+    GD_REQUIRE(ctx && d_dst && d_src && bytes >= 0, "bad argument");
+    GD_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return GD_OK;
 }
 

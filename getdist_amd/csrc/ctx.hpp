@@ -29,7 +29,15 @@ struct gd_ctx {
     void* scratch2 = nullptr;
     int64_t scratch2_bytes = 0;
     FftPlanCache* fft = nullptr;
+    std::map<int, double*> dctmat;  // F -> F x F DCT-II matrix 2cos(pi k (2n+1) / 2F) (kopt2d.hip)
 };
+
+// fft.hip: batched 2D real FFTs through rocFFT (plans cached per ctx); n0 = slow axis, n1 = fast axis.
+// r2c: in batch x n0 x n1 doubles -> out batch x n0 x (n1/2+1) complex.  c2r is unnormalised and
+// overwrites its input.
+int gd_fft_r2c_2d(gd_ctx* ctx, int n0, int n1, int batch, const double* d_in, double2* d_out);
+int gd_fft_c2r_2d(gd_ctx* ctx, int n0, int n1, int batch, double2* d_in, double* d_out);
+void gd_fft_cache_destroy(gd_ctx* ctx);
 
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure

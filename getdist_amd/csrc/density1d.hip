@@ -1,5 +1,288 @@
+// 1D density on the device: DCT-II for the ISJ bandwidth functional, Gaussian tap convolution,
+// boundary correction (orders 0/1/2), multiplicative bias correction, max-normalisation.
+// One workgroup per parameter; everything (F <= 4096 bins, <= F taps) lives in LDS.
 #include "ctx.hpp"
-extern "C" {
-int gd_dct1d(gd_ctx* ctx, int32_t, int32_t, const double*, double*) { return gd_fail(ctx, GD_ERR_BADARG, "nyi"); }
-int gd_density1d(gd_ctx* ctx, int32_t, int32_t, const double*, const double*, const int32_t*, const int32_t*, int32_t, int32_t, double*, int32_t*) { return gd_fail(ctx, GD_ERR_BADARG, "nyi"); }
+
+// ---- DCT-II (scipy.fftpack.dct type 2, unnormalised): a[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2F)) ----------
+// tab[m] = cos(pi m / (2F)), m in [0,4F), built with exact octant reduction.
+__global__ void k_cos_table(int F, double* __restrict__ tab) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= 4 * F) return;
+    // angle = pi*m/(2F); reduce to [0, pi/2] exactly in integers
+    int q = m / F;          // quadrant 0..3
+    int r = m - q * F;      // angle = q*pi/2 + pi*r/(2F)
+    const double c = cospi((double)r / (2.0 * F)), s = sinpi((double)r / (2.0 * F));
+    double v;
+    switch (q) {
+        case 0: v = c; break;
+        case 1: v = -s; break;
+        case 2: v = -c; break;
+        default: v = s; break;
+    }
+    tab[m] = v;
 }
+
+// grid (ceil(F/256), B); hist/out are device arrays B x F
+__global__ void __launch_bounds__(256) k_dct1d(const double* __restrict__ hist, int F, const double* __restrict__ tab,
+                                               double* __restrict__ out) {
+    extern __shared__ double xs[];  // F normalised data
+    __shared__ double red[16];
+    const double* h = hist + (int64_t)blockIdx.y * F;
+    double s = 0;
+    for (int i = threadIdx.x; i < F; i += 256) s += h[i];
+    s = block_sum(s, red);
+    __shared__ double total;
+    if (threadIdx.x == 0) total = s;
+    __syncthreads();
+    for (int i = threadIdx.x; i < F; i += 256) xs[i] = h[i] / total;
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= F) return;
+    const int F4 = 4 * F;
+    int m = k % F4, step = (2 * k) % F4;
+    double a0 = 0, a1 = 0;
+    int n = 0;
+    for (; n + 1 < F; n += 2) {
+        a0 = fma(xs[n], tab[m], a0);
+        m += step;
+        if (m >= F4) m -= F4;
+        a1 = fma(xs[n + 1], tab[m], a1);
+        m += step;
+        if (m >= F4) m -= F4;
+    }
+    if (n < F) a0 = fma(xs[n], tab[m], a0);
+    out[(int64_t)blockIdx.y * F + k] = 2.0 * (a0 + a1);
+}
+
+// ---- density assembly -------------------------------------------------------------------------------------
+struct D1Args {
+    int F, bco, mbc;
+};
+
+__device__ __forceinline__ double edge_mask(int idx, int F, bool bot, bool top) {
+    // prior_mask of mcsamples.py:1602-1608 expressed on the un-padded index idx = n - i
+    if (idx < 0) return bot ? 0.0 : 1.0;
+    if (idx == 0) return bot ? 0.5 : 1.0;
+    if (idx > F - 1) return top ? 0.0 : 1.0;
+    if (idx == F - 1) return top ? 0.5 : 1.0;
+    return 1.0;
+}
+
+__global__ void __launch_bounds__(256) k_density1d(const double* __restrict__ hist, const double* __restrict__ smooth,
+                                                   const int* __restrict__ winw, const int* __restrict__ flags,
+                                                   D1Args A, double* __restrict__ Pout, int* __restrict__ status) {
+    extern __shared__ double sh[];
+    const int F = A.F, b = blockIdx.x, tid = threadIdx.x;
+    double* bins = sh;          // F
+    double* P = bins + F;       // F
+    double* fine = P + F;       // F (also the circular copy in periodic mode)
+    double* Win = fine + F;     // 2w+1 <= F
+    __shared__ double red[16];
+    __shared__ double bc;
+    const int w = winw[b];
+    const double hh = smooth[b];
+    const bool bot = flags[b] & 1, top = flags[b] & 2, periodic = flags[b] & 4;
+    const bool has_limits = bot || top;
+    const int M = 2 * w + 1;
+    for (int i = tid; i < F; i += 256) bins[i] = hist[(int64_t)b * F + i];
+    // Kernel1D (mcsamples.py:129-135)
+    double s = 0;
+    for (int j = tid; j < M; j += 256) {
+        const double x = (double)(j - w) / hh;
+        const double v = exp(-(x * x) / 2.0);
+        Win[j] = v;
+        s += v;
+    }
+    s = block_sum(s, red);
+    if (tid == 0) bc = s;
+    __syncthreads();
+    const double wsum = bc;
+    for (int j = tid; j < M; j += 256) Win[j] = Win[j] / wsum;
+    __syncthreads();
+    const int Fc = F - 1;  // circular length in periodic mode (convolve.py:337-339)
+    if (periodic) {
+        for (int i = tid; i < Fc; i += 256) fine[i] = bins[i] + (i == 0 ? bins[F - 1] : 0.0);
+        __syncthreads();
+    }
+    // first convolution + boundary correction, per output bin
+    for (int n = tid; n < F; n += 256) {
+        double p0 = 0;
+        if (periodic) {
+            const int nn = (n == F - 1) ? 0 : n;
+            for (int i = -w; i <= w; ++i) {
+                int idx = nn - i;
+                idx %= Fc;
+                if (idx < 0) idx += Fc;
+                p0 = fma(Win[i + w], fine[idx], p0);
+            }
+            P[n] = p0;
+            continue;
+        }
+        double xP = 0, x2P = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        const bool need_mask = has_limits && A.bco >= 0;
+        for (int i = -w; i <= w; ++i) {
+            const int idx = n - i;
+            const double wi = Win[i + w];
+            const double di = (double)i;
+            const double xw = wi * di;        // kernel.Win * kernel.x
+            const double x2w = xw * di;       // xWin * kernel.x
+            const double v = (idx >= 0 && idx < F) ? bins[idx] : 0.0;
+            p0 = fma(wi, v, p0);
+            xP = fma(xw, v, xP);
+            x2P = fma(x2w, v, x2P);
+            if (need_mask) {
+                const double m = edge_mask(idx, F, bot, top);
+                a0 = fma(wi, m, a0);
+                a1 = fma(xw, m, a1);
+                a2 = fma(x2w, m, a2);
+                a3 = fma(x2w * di, m, a3);
+                a4 = fma(x2w * di * di, m, a4);
+            }
+        }
+        double pv = p0;
+        if (need_mask) {
+            if (a0 * p0 != 0.0) {
+                const double normed = p0 / a0;
+                if (A.bco == 0) {
+                    pv = normed;
+                } else {
+                    double corrected;
+                    if (A.bco == 1) {
+                        corrected = (p0 * a2 - xP * a1) / (a0 * a2 - a1 * a1);
+                    } else {
+                        const double denom = a4 * a2 * a0 - a4 * (a1 * a1) - a2 * a2 * a2 - a3 * a3 * a0 + 2 * a1 * a2 * a3;
+                        const double Aq = a4 * a2 - a3 * a3, Bq = a2 * a3 - a4 * a1, Cq = a3 * a1 - a2 * a2;
+                        corrected = (p0 * Aq + xP * Bq + x2P * Cq) / denom;
+                    }
+                    pv = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
+                }
+            }
+        } else if (A.bco == 2) {
+            // higher-order kernel for unbounded parameters (mcsamples.py:1638-1647)
+            double s2 = 0, s4 = 0;
+            for (int i = -w; i <= w; ++i) {
+                const double di = (double)i, xw2 = Win[i + w] * (di * di);
+                s2 += xw2;
+                s4 = fma(xw2, di * di, s4);
+            }
+            const double corrected = (p0 * s4 - s2 * x2P) / (s4 - s2 * s2);
+            if (p0 > 0) pv = p0 * exp(fmin(corrected / p0, 2.0) - 1.0);
+        }
+        P[n] = pv;
+    }
+    __syncthreads();
+    // multiplicative bias correction (mcsamples.py:1649-1666)
+    for (int round = 0; round < A.mbc; ++round) {
+        if (periodic) {
+            // fine = bins / prob1, made circular
+            for (int i = tid; i < Fc; i += 256) {
+                const double p1 = (P[i] == 0.0) ? 1.0 : P[i];
+                double v = bins[i] / p1;
+                if (i == 0) {
+                    const double pl = (P[F - 1] == 0.0) ? 1.0 : P[F - 1];
+                    v += bins[F - 1] / pl;
+                }
+                fine[i] = v;
+            }
+        } else {
+            for (int i = tid; i < F; i += 256) fine[i] = bins[i] / ((P[i] == 0.0) ? 1.0 : P[i]);
+        }
+        __syncthreads();
+        double newp[16];  // F <= 4096 -> at most 16 outputs per thread
+        int cnt = 0;
+        for (int n = tid; n < F; n += 256, ++cnt) {
+            double c0 = 0, a0 = 0;
+            if (periodic) {
+                const int nn = (n == F - 1) ? 0 : n;
+                for (int i = -w; i <= w; ++i) {
+                    int idx = (nn - i) % Fc;
+                    if (idx < 0) idx += Fc;
+                    c0 = fma(Win[i + w], fine[idx], c0);
+                }
+                newp[cnt] = P[n] * c0;
+            } else {
+                for (int i = -w; i <= w; ++i) {
+                    const int idx = n - i;
+                    if (idx >= 0 && idx < F) {
+                        const double wi = Win[i + w];
+                        c0 = fma(wi, fine[idx], c0);
+                        const double m = (idx == 0 && bot) ? 0.5 : ((idx == F - 1 && top) ? 0.5 : 1.0);
+                        a0 = fma(wi, m, a0);
+                    }
+                }
+                newp[cnt] = (P[n] * c0) / a0;
+            }
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int n = tid; n < F; n += 256, ++cnt) P[n] = newp[cnt];
+        __syncthreads();
+    }
+    double mx = -INFINITY;
+    for (int n = tid; n < F; n += 256) mx = fmax(mx, P[n]);
+    mx = block_max(mx, red);
+    if (tid == 0) {
+        bc = mx;
+        status[b] = (mx == 0.0) ? GD_ERR_EMPTY : GD_OK;
+    }
+    __syncthreads();
+    mx = bc;
+    for (int n = tid; n < F; n += 256) Pout[(int64_t)b * F + n] = (mx == 0.0) ? 0.0 : P[n] / mx;
+}
+
+extern "C" {
+
+int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_out) {
+    GD_REQUIRE(ctx && hist && a_out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins out of range (2..4096)");
+    const int64_t nb = (int64_t)B * F * 8;
+    char* base = (char*)gd_scratch(ctx, 2 * nb + (int64_t)4 * F * 8 + 512);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_in = (double*)base;
+    double* d_out = (double*)(base + (nb + 255) / 256 * 256);
+    double* d_tab = (double*)(base + 2 * ((nb + 255) / 256 * 256));
+    GD_HIP(hipMemcpyAsync(d_in, hist, (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    k_cos_table<<<(4 * F + 255) / 256, 256, 0, ctx->stream>>>(F, d_tab);
+    GD_KERNEL_CHECK();
+    k_dct1d<<<dim3((F + 255) / 256, B), 256, (size_t)F * 8, ctx->stream>>>(d_in, F, d_tab, d_out);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(a_out, d_out, (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* smooth, const int32_t* winw,
+                 const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out) {
+    GD_REQUIRE(ctx && hist && smooth && winw && flags && P_out && status_out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins out of range (8..4096)");
+    GD_REQUIRE(bco >= -1 && bco <= 2, "Unknown boundary_correction_order (expected 0, 1, 2)");
+    GD_REQUIRE(mbc >= 0 && mbc <= 8, "mult_bias_correction_order out of range");
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(winw[b] >= 0 && 2 * winw[b] + 1 <= F, "window wider than the grid");
+        GD_REQUIRE(smooth[b] > 0, "smoothing scale must be positive");
+    }
+    const int64_t nb = ((int64_t)B * F * 8 + 255) / 256 * 256, ns = ((int64_t)B * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, 2 * nb + 4 * ns);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_hist = (double*)base;
+    double* d_P = (double*)(base + nb);
+    double* d_smooth = (double*)(base + 2 * nb);
+    int* d_winw = (int*)(base + 2 * nb + ns);
+    int* d_flags = (int*)(base + 2 * nb + 2 * ns);
+    int* d_status = (int*)(base + 2 * nb + 3 * ns);
+    GD_HIP(hipMemcpyAsync(d_hist, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_smooth, smooth, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_winw, winw, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_flags, flags, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    D1Args A{F, bco, mbc};
+    const size_t lds = (size_t)4 * F * 8;
+    GD_HIP(hipFuncSetAttribute((const void*)k_density1d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
+    k_density1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_smooth, d_winw, d_flags, A, d_P, d_status);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(P_out, d_P, (size_t)B * F * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+}  // extern "C"

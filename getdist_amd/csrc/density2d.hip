@@ -1,5 +1,344 @@
+// 2D density assembly on the device for a batch of pairs sharing the fine grid size F
+// (mcsamples.py:1857-1990): Gaussian window synthesis, zero-padded linear convolution through rocFFT,
+// linear boundary correction, multiplicative bias correction, max-normalisation.
+//
+// Frame convention: every operand lives in an S x S real frame (S >= F + 2*winw, FFT-friendly).  The
+// (F+2w)^2 prior mask sits at the frame origin, the F^2 histogram at offset (w,w), and each window is
+// stored centred-with-wrap, so that one circular convolution gives the reference's 'same' result for
+// the histogram and its 'valid' result for the mask at frame positions [w, F+w)^2 (convolve.py:405-444).
 #include "ctx.hpp"
-void gd_fft_cache_destroy(gd_ctx*) {}
-extern "C" {
-int gd_density2d(gd_ctx* ctx, int32_t, int32_t, const void*, const double*, const double*, const double*, const int32_t*, const int32_t*, int32_t, int32_t, void*, int32_t*) { return gd_fail(ctx, GD_ERR_BADARG, "nyi"); }
+
+struct D2Pair {
+    double c00, c11, c10;  // inverse bandwidth matrix (mcsamples.py:1864)
+    int w;                 // winw
+    int flags;             // bit0/1 x bot/top, bit2/3 y bot/top
+};
+
+__device__ __forceinline__ double win_raw(const D2Pair& p, int i1, int i2) {
+    // mcsamples.py:1865-1866: i1 = row (y) offset, i2 = column (x) offset
+    const double a = (double)(i1 * i1) * p.c00 + (double)(i2 * i2) * p.c11 + 2.0 * p.c10 * (double)(i1 * i2);
+    return exp(-a / 2.0);
 }
+
+__global__ void k_win_sum(const D2Pair* __restrict__ pairs, double* __restrict__ wsum) {
+    __shared__ double red[16];
+    const D2Pair p = pairs[blockIdx.x];
+    const int M = 2 * p.w + 1;
+    double s = 0;
+    for (int e = threadIdx.x; e < M * M; e += blockDim.x) s += win_raw(p, e / M - p.w, e % M - p.w);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) wsum[blockIdx.x] = s;
+}
+
+// window * x^px * y^py, centred with wrap, in an S x S frame (zero elsewhere). grid (blocks, B)
+__global__ void k_fill_window(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, int S, int px, int py,
+                              double* __restrict__ frames) {
+    const D2Pair p = pairs[blockIdx.y];
+    double* fr = frames + (int64_t)blockIdx.y * S * S;
+    const double ws = wsum[blockIdx.y];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
+        const int r = e / S, c = e % S;
+        const int i1 = (r <= S / 2) ? r : r - S, i2 = (c <= S / 2) ? c : c - S;
+        double v = 0;
+        if (i1 >= -p.w && i1 <= p.w && i2 >= -p.w && i2 <= p.w) {
+            v = win_raw(p, i1, i2) / ws;
+            for (int q = 0; q < px; ++q) v = v * (double)i2;
+            for (int q = 0; q < py; ++q) v = v * (double)i1;
+        }
+        fr[e] = v;
+    }
+}
+
+// histogram (or any F x F array) placed at offset (w,w)
+__global__ void k_fill_embed(const D2Pair* __restrict__ pairs, const double* __restrict__ src, int F, int S,
+                             double* __restrict__ frames) {
+    const int w = pairs[blockIdx.y].w;
+    const double* s = src + (int64_t)blockIdx.y * F * F;
+    double* fr = frames + (int64_t)blockIdx.y * S * S;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
+        const int r = e / S - w, c = e % S - w;
+        fr[e] = (r >= 0 && r < F && c >= 0 && c < F) ? s[(int64_t)r * F + c] : 0.0;
+    }
+}
+
+// prior masks (mcsamples.py:1688-1712) at the frame origin, size (F+2w)^2, zero outside.
+// kind 0: edge mask of _setEdgeMask2D;  kind 1: the same followed by _setAllEdgeMask2D (edge_applied says
+// whether the half-weights of kind 0 were applied before).
+__device__ __forceinline__ double mask_1d(int p, int F, int w, bool bot, bool top, bool all_edges) {
+    if (p < 0 || p >= F + 2 * w) return 0.0;
+    double v = 1.0;
+    if (bot) {
+        if (p == w) v = 0.5;
+        if (p < w) v = 0.0;
+    }
+    if (top) {
+        if (p == F + w - 1) v = 0.5;
+        if (p > F + w - 1) v = 0.0;
+    }
+    if (all_edges && (p < w || p >= F + w)) v = 0.0;
+    return v;
+}
+__global__ void k_fill_mask(const D2Pair* __restrict__ pairs, int F, int S, int kind, int edge_applied,
+                            double* __restrict__ frames) {
+    const D2Pair p = pairs[blockIdx.y];
+    double* fr = frames + (int64_t)blockIdx.y * S * S;
+    const bool use_edges = (kind == 0) || edge_applied;
+    const bool xb = use_edges && (p.flags & 1), xt = use_edges && (p.flags & 2), yb = use_edges && (p.flags & 4),
+               yt = use_edges && (p.flags & 8);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
+        const int r = e / S, c = e % S;
+        fr[e] = mask_1d(c, F, p.w, xb, xt, kind == 1) * mask_1d(r, F, p.w, yb, yt, kind == 1);
+    }
+}
+
+// out = a * b * scale (complex), n elements per batch entry
+__global__ void k_cmul(const double2* __restrict__ a, const double2* __restrict__ b, int64_t n, double scale,
+                       double2* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 x = a[i], y = b[i];
+        out[i] = make_double2((x.x * y.x - x.y * y.y) * scale, (x.x * y.y + x.y * y.x) * scale);
+    }
+}
+
+// crop frame positions [w, F+w)^2 into an F x F array
+__global__ void k_crop(const D2Pair* __restrict__ pairs, const double* __restrict__ frames, int F, int S,
+                       double* __restrict__ dst) {
+    const int w = pairs[blockIdx.y].w;
+    const double* fr = frames + (int64_t)blockIdx.y * S * S;
+    double* d = dst + (int64_t)blockIdx.y * F * F;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x)
+        d[e] = fr[(int64_t)(e / F + w) * S + (e % F + w)];
+}
+
+__global__ void k_pair_max(const double* __restrict__ a, int FF, double* __restrict__ mx) {
+    __shared__ double red[16];
+    const double* p = a + (int64_t)blockIdx.x * FF;
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < FF; i += blockDim.x) m = fmax(m, p[i]);
+    m = block_max(m, red);
+    if (threadIdx.x == 0) mx[blockIdx.x] = m;
+}
+
+struct BcArrays {
+    double *P, *a00, *a10, *a01, *a20, *a02, *a11, *xP, *yP;
+};
+
+// linear boundary correction (mcsamples.py:1921-1961), in place on P; only pairs with a limit
+__global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF, int bco) {
+    const int b = blockIdx.y;
+    if ((pairs[b].flags & 15) == 0) return;
+    const double thresh = mx[b] * 1e-8;
+    const int64_t o = (int64_t)b * FF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
+        const double P = A.P[o + i], a00 = A.a00[o + i];
+        if (!(a00 * P > thresh)) continue;
+        const double normed = P / a00;
+        if (bco == 0) {
+            A.P[o + i] = normed;
+            continue;
+        }
+        const double a10 = A.a10[o + i], a01 = A.a01[o + i], a20 = A.a20[o + i], a02 = A.a02[o + i],
+                     a11 = A.a11[o + i], xP = A.xP[o + i], yP = A.yP[o + i];
+        const double denom = a20 * (a01 * a01) + (a10 * a10) * a02 - a00 * a02 * a20 + (a11 * a11) * a00 - 2 * a01 * a10 * a11;
+        const double Aq = a11 * a11 - a02 * a20;
+        const double Ax = a10 * a02 - a01 * a11;
+        const double Ay = a01 * a20 - a10 * a11;
+        const double corrected = (P * Aq + xP * Ax + yP * Ay) / denom;
+        A.P[o + i] = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
+    }
+}
+
+// box = hist / bins2D where bins2D > max*1e-8 (mcsamples.py:1969-1971), embedded at (w,w)
+__global__ void k_fill_box(const D2Pair* __restrict__ pairs, const double* __restrict__ hist, const double* __restrict__ P,
+                           const double* __restrict__ mx, int F, int S, double* __restrict__ frames) {
+    const int w = pairs[blockIdx.y].w;
+    const double thresh = mx[blockIdx.y] * 1e-8;
+    const int64_t o = (int64_t)blockIdx.y * F * F;
+    double* fr = frames + (int64_t)blockIdx.y * S * S;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
+        const int r = e / S - w, c = e % S - w;
+        double v = 0;
+        if (r >= 0 && r < F && c >= 0 && c < F) {
+            const double h = hist[o + (int64_t)r * F + c], p = P[o + (int64_t)r * F + c];
+            v = (p > thresh) ? h / p : h;
+        }
+        fr[e] = v;
+    }
+}
+
+// bins2D = bins2D * conv / a00
+__global__ void k_mbc_update(double* __restrict__ P, const double* __restrict__ conv, const double* __restrict__ a00,
+                             int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        P[i] = (P[i] * conv[i]) / a00[i];
+}
+
+__global__ void k_normalise(double* __restrict__ P, const double* __restrict__ mx, int FF, int* __restrict__ status) {
+    const double m = mx[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[blockIdx.y] = (m == 0.0) ? GD_ERR_EMPTY : GD_OK;
+    double* p = P + (int64_t)blockIdx.y * FF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x)
+        p[i] = (m == 0.0) ? 0.0 : p[i] / m;
+}
+
+static int next_fft_size(int n) {
+    // smallest even 2^a 3^b 5^c >= n
+    int best = 1 << 30;
+    for (long long p2 = 2; p2 < (1 << 28); p2 *= 2)
+        for (long long p3 = 1; p2 * p3 < (1 << 28); p3 *= 3)
+            for (long long p5 = 1; p2 * p3 * p5 < (1 << 28); p5 *= 5) {
+                const long long v = p2 * p3 * p5;
+                if (v >= n && v < best) best = (int)v;
+            }
+    return best;
+}
+
+extern "C" {
+
+int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
+                 const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P_out,
+                 int32_t* status_out) {
+    GD_REQUIRE(ctx && d_hist_v && rx && ry && corr && winw && flags && d_P_out && status_out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins_2D out of range");
+    GD_REQUIRE(bco >= -1 && bco <= 1, "unknown boundary_correction_order (expected 0 or 1)");
+    GD_REQUIRE(mbc >= 0 && mbc <= 8, "mult_bias_correction_order out of range");
+    const double* d_hist = (const double*)d_hist_v;
+    double* d_P = (double*)d_P_out;
+    std::vector<D2Pair> hp((size_t)B);
+    int maxw = 1;
+    bool any_limits = false;
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(winw[b] >= 1 && winw[b] <= 2 * F, "bad window half-width");
+        GD_REQUIRE(rx[b] > 0 && ry[b] > 0 && fabs(corr[b]) < 1, "bad bandwidth matrix");
+        const double a = ry[b] * ry[b], d = rx[b] * rx[b], o = rx[b] * ry[b] * corr[b];
+        const double det = a * d - o * o;
+        hp[b].c00 = d / det;
+        hp[b].c11 = a / det;
+        hp[b].c10 = -o / det;
+        hp[b].w = winw[b];
+        hp[b].flags = flags[b] & 15;
+        if (winw[b] > maxw) maxw = winw[b];
+        if (hp[b].flags) any_limits = true;
+    }
+    const bool do_bc = any_limits && bco >= 0;
+    const int S = next_fft_size(F + 2 * maxw);
+    const int Sh = S / 2 + 1;
+    const int64_t FF = (int64_t)F * F, SS = (int64_t)S * S, SC = (int64_t)S * Sh;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+                  o_status = take((int64_t)B * 4), o_RF = take(B * SS * 8), o_RO = take(B * SS * 8),
+                  o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16), o_ZM = take(do_bc || mbc ? B * SC * 16 : 0),
+                  o_ZK = take(do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(B * SC * 16),
+                  o_arr = take((do_bc ? (bco == 1 ? 8 : 1) : 0) * B * FF * 8), o_a00m = take(mbc ? B * FF * 8 : 0),
+                  o_conv = take(mbc ? B * FF * 8 : 0);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
+    double* d_wsum = (double*)(base + o_wsum);
+    double* d_mx = (double*)(base + o_mx);
+    int* d_status = (int*)(base + o_status);
+    double* RF = (double*)(base + o_RF);
+    double* RO = (double*)(base + o_RO);
+    double2* ZH = (double2*)(base + o_ZH);
+    double2* ZW = (double2*)(base + o_ZW);
+    double2* ZM = (double2*)(base + o_ZM);
+    double2* ZK = (double2*)(base + o_ZK);
+    double2* ZP = (double2*)(base + o_ZP);
+    double* arr = (double*)(base + o_arr);
+    double* d_a00m = (double*)(base + o_a00m);
+    double* d_conv = (double*)(base + o_conv);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    const dim3 gS(128, B), gF(64, B);
+    const double scale = 1.0 / ((double)S * (double)S);
+    const int cm_blocks = 2048;
+    int rc;
+#define FWD(frames, Z)                                        \
+    do {                                                      \
+        rc = gd_fft_r2c_2d(ctx, S, S, B, frames, Z);          \
+        if (rc) return rc;                                    \
+    } while (0)
+    // product of two spectra -> inverse -> crop into dst (B x F x F)
+#define CONV_TO(ZA, ZB, dst)                                                              \
+    do {                                                                                  \
+        k_cmul<<<cm_blocks, 256, 0, ctx->stream>>>(ZA, ZB, B * SC, scale, ZP);            \
+        GD_KERNEL_CHECK();                                                                \
+        rc = gd_fft_c2r_2d(ctx, S, S, B, ZP, RO);                                         \
+        if (rc) return rc;                                                                \
+        k_crop<<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst);                      \
+        GD_KERNEL_CHECK();                                                                \
+    } while (0)
+
+    k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
+    GD_KERNEL_CHECK();
+    // spectra of the window and of the histogram
+    k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, RF);
+    GD_KERNEL_CHECK();
+    FWD(RF, ZW);
+    k_fill_embed<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, F, S, RF);
+    GD_KERNEL_CHECK();
+    FWD(RF, ZH);
+    CONV_TO(ZH, ZW, d_P);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884)
+    if (do_bc) {
+        BcArrays A;
+        A.P = d_P;
+        A.a00 = arr;
+        A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
+        k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+        GD_KERNEL_CHECK();
+        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
+        GD_KERNEL_CHECK();
+        FWD(RF, ZM);
+        CONV_TO(ZM, ZW, A.a00);
+        if (bco == 1) {
+            A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
+            A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
+            struct Mom {
+                int px, py;
+                double* mask_dst;
+                double* hist_dst;
+            } moms[5] = {{1, 0, A.a10, A.xP}, {0, 1, A.a01, A.yP}, {2, 0, A.a20, nullptr}, {0, 2, A.a02, nullptr},
+                         {1, 1, A.a11, nullptr}};
+            for (const Mom& m : moms) {
+                k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, m.px, m.py, RF);
+                GD_KERNEL_CHECK();
+                FWD(RF, ZK);
+                CONV_TO(ZM, ZK, m.mask_dst);
+                if (m.hist_dst) CONV_TO(ZH, ZK, m.hist_dst);
+            }
+        }
+        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco);
+        GD_KERNEL_CHECK();
+    }
+    if (mbc > 0) {
+        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 1, do_bc ? 1 : 0, RF);
+        GD_KERNEL_CHECK();
+        FWD(RF, ZM);
+        CONV_TO(ZM, ZW, d_a00m);
+        for (int round = 0; round < mbc; ++round) {
+            k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+            GD_KERNEL_CHECK();
+            k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, d_mx, F, S, RF);
+            GD_KERNEL_CHECK();
+            FWD(RF, ZH);  // ZH is free to reuse: the histogram spectrum is no longer needed
+            CONV_TO(ZH, ZW, d_conv);
+            k_mbc_update<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
+            GD_KERNEL_CHECK();
+        }
+    }
+    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+    GD_KERNEL_CHECK();
+    k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+#undef FWD
+#undef CONV_TO
+    return GD_OK;
+}
+
+}  // extern "C"

@@ -1,4 +1,457 @@
+// 2D bandwidth optimiser (Botev ISJ in two dimensions) on the device.
+//
+// Per pair: a2 = dct2d(hist/sum)[1:,1:]^2 by two small fp64 GEMMs against a cached DCT-II matrix, then ONE
+// workgroup per pair runs the whole scalar solve without leaving the device: Brent's method on the
+// fixed point t = xi(t) (scipy brentq control flow), each function evaluation being four dependent
+// "levels" of bilinear forms  wy . a2 . wx  over the 255x255 coefficient grid (streamed from L2), then the
+// psi functionals get_h needs, and -- when the pair is unbounded -- the odd functionals from |fft2|^2
+// (rocFFT).  Reference: kde_bandwidth.py:146-270.
 #include "ctx.hpp"
-extern "C" {
-int gd_kopt2d(gd_ctx* ctx, int32_t, int32_t, const void*, const double*, const int32_t*, const double*, double*) { return gd_fail(ctx, GD_ERR_BADARG, "nyi"); }
+
+#define KT 1024
+#define MAXF 6  // forms per level
+#define PI 3.141592653589793238462643383279502884
+#define PISQ (PI * PI)
+
+// ---- small fp64 GEMM: C[i][j] = sum_p A[i][p] B[j][p]  (NT), M=N=K=F, batched ---------------------------------
+// EPI 0: plain store.  EPI 1: v = acc / sums[b]; out[j][i] = v*v (transposed, squared).
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, int64_t strideA,
+                                                 const double* __restrict__ Bm, int64_t strideB, int F,
+                                                 double* __restrict__ Cm, int64_t strideC,
+                                                 const double* __restrict__ sums) {
+    __shared__ double As[16][65];
+    __shared__ double Bs[16][65];
+    const int b = blockIdx.z;
+    const double* Ab = A + (int64_t)b * strideA;
+    const double* Bb = Bm + (int64_t)b * strideB;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+    for (int p0 = 0; p0 < F; p0 += 16) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int pp = e & 15, ii = e >> 4;
+            const int p = p0 + pp;
+            As[pp][ii] = (i0 + ii < F && p < F) ? Ab[(int64_t)(i0 + ii) * F + p] : 0.0;
+            Bs[pp][ii] = (j0 + ii < F && p < F) ? Bb[(int64_t)(j0 + ii) * F + p] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = As[pp][ty * 4 + u];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bb[v] = Bs[pp][tx * 4 + v];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], bb[v], acc[u][v]);
+        }
+    }
+    double* Cb = Cm + (int64_t)b * strideC;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+            if (i < F && j < F) {
+                if (EPI == 0) {
+                    Cb[(int64_t)i * F + j] = acc[u][v];
+                } else {
+                    const double val = acc[u][v] / sums[b];
+                    Cb[(int64_t)j * F + i] = val * val;
+                }
+            }
+        }
 }
+
+// DCT-II matrix: D[k][n] = 2 cos(pi k (2n+1) / (2F))   (scipy.fftpack.dct type 2, unnormalised)
+__global__ void k_dct_matrix(int F, double* __restrict__ D) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= F * F) return;
+    const int k = e / F, n = e % F;
+    const long long m = ((long long)k * (2 * n + 1)) % (4LL * F);  // angle = pi*m/(2F)
+    const int q = (int)(m / F);
+    const int r = (int)(m - (long long)q * F);
+    const double c = cospi((double)r / (2.0 * F)), s = sinpi((double)r / (2.0 * F));
+    double v = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    D[e] = 2.0 * v;
+}
+
+// per-pair histogram sums
+__global__ void k_hist_sums(const double* __restrict__ hist, int FF, double* __restrict__ sums) {
+    __shared__ double red[16];
+    const double* h = hist + (int64_t)blockIdx.x * FF;
+    double s = 0;
+    for (int i = threadIdx.x; i < FF; i += blockDim.x) s += h[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+
+// gather + normalise the histograms that need the power spectrum
+__global__ void k_gather_norm(const double* __restrict__ hist, const int* __restrict__ which, const double* __restrict__ sums,
+                              int FF, double* __restrict__ out) {
+    const int b = which[blockIdx.y];
+    const double s = sums[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x)
+        out[(int64_t)blockIdx.y * FF + i] = hist[(int64_t)b * FF + i] / s;
+}
+
+// full F x F power spectrum |Z|^2 from the hermitian half Z[F][F/2+1]
+__global__ void k_power_full(const double2* __restrict__ Z, int F, double* __restrict__ out) {
+    const int Fh = F / 2 + 1;
+    const double2* Zb = Z + (int64_t)blockIdx.y * F * Fh;
+    double* ob = out + (int64_t)blockIdx.y * F * F;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        const int i = e / F, j = e % F;
+        double2 z;
+        if (j < Fh)
+            z = Zb[(int64_t)i * Fh + j];
+        else
+            z = Zb[(int64_t)((F - i) % F) * Fh + (F - j)];
+        ob[e] = z.x * z.x + z.y * z.y;
+    }
+}
+
+// ---- the per-pair solver ----------------------------------------------------------------------------------------
+struct KoptLds {
+    double* wx;   // MAXF x F
+    double* wy;   // MAXF x F
+    double* res;  // MAXF results + scratch
+    double* red;  // 16
+};
+
+// Evaluate m bilinear forms  sum_ij wy_q[i] M[i][j] wx_q[j]  for the weight sets currently in LDS.
+__device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L) {
+    const int jx = threadIdx.x & 255, g = threadIdx.x >> 8;  // 4 row groups x 256 columns
+    const int rows_per = (F + 3) / 4;
+    const int r_lo = g * rows_per, r_hi = min(F, r_lo + rows_per);
+    double val[MAXF];
+#pragma unroll
+    for (int q = 0; q < MAXF; ++q) val[q] = 0;
+    for (int j0 = 0; j0 < F; j0 += 256) {
+        const int j = j0 + jx;
+        if (j < F) {
+            double acc[MAXF];
+#pragma unroll
+            for (int q = 0; q < MAXF; ++q) acc[q] = 0;
+            for (int i = r_lo; i < r_hi; ++i) {
+                const double a = M[(int64_t)i * F + j];
+#pragma unroll
+                for (int q = 0; q < MAXF; ++q)
+                    if (q < m) acc[q] = fma(L.wy[q * F + i], a, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < MAXF; ++q)
+                if (q < m) val[q] = fma(acc[q], L.wx[q * F + j], val[q]);
+        }
+    }
+    for (int q = 0; q < m; ++q) {
+        const double r = block_sum(val[q], L.red);
+        if (threadIdx.x == 0) L.res[q] = r;
+    }
+    __syncthreads();
+}
+
+// even functionals: psi([s0,s1], time) for the forms of one level (all with s0+s1 = Lsum)
+__device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, const double* times, double* out, KoptLds L) {
+    const int m = Lsum + 1;  // forms [a, Lsum-a], a = 0..Lsum   (m <= MAXF)
+    __syncthreads();
+    for (int e = threadIdx.x; e < m * F; e += KT) {
+        const int q = e / F, k = e % F;
+        double vx = 0, vy = 0;
+        if (k > 0) {
+            const double I = (double)k * (double)k;
+            const double logI = log(I);
+            const double w = -I * (PISQ * times[q]);
+            vx = exp(w + logI * (double)q);
+            vy = exp(w + logI * (double)(Lsum - q));
+        }
+        L.wx[e] = vx;
+        L.wy[e] = vy;
+    }
+    __syncthreads();
+    bilinear_forms(SQ, F, m, L);
+    const double sgn = (Lsum & 1) ? -1.0 : 1.0;
+    const double ppow = pow(PI, (double)(2 * Lsum));
+    for (int q = 0; q < m; ++q) out[q] = sgn * L.res[q] * ppow / 4.0;
+    __syncthreads();
+}
+
+// kde_bandwidth.py:140-143
+__device__ __forceinline__ double odd_dfact(int j) {  // prod(arange(1, 2j, 2)) = (2j-1)!!
+    double p = 1.0;
+    for (int q = 1; q < 2 * j; q += 2) p *= (double)q;
+    return p;
+}
+__device__ __forceinline__ double k_even(int j) {
+    const double v = odd_dfact(j) / sqrt(2.0 * PI);
+    return (j == 0) ? 1.0 / sqrt(2.0 * PI) : ((j & 1) ? -v : v);
+}
+__device__ __forceinline__ double k_odd(int j) {
+    return (j == 0) ? 1.0 : odd_dfact(j) / pow(2.0, (double)(j + 1)) / sqrt(PI);
+}
+
+// func2d for every [a, L-a], L = 5 .. Lmin (memoised recursion of kde_bandwidth.py:188-196).
+// lev[L][a] receives func2d([a, L-a], t).
+__device__ void func2d_levels(const double* __restrict__ SQ, int F, double N, double t, int Lmin, double lev[6][MAXF],
+                              KoptLds L) {
+    double times[MAXF];
+    for (int q = 0; q < MAXF; ++q) times[q] = t;
+    psi_level(SQ, F, 5, times, lev[5], L);
+    for (int Ls = 4; Ls >= Lmin; --Ls) {
+        const double cst = (1.0 + pow(0.5, (double)(Ls + 1))) / 3.0;
+        for (int a = 0; a <= Ls; ++a) {
+            const double sum_func = lev[Ls + 1][a + 1] + lev[Ls + 1][a];
+            times[a] = pow(-2.0 * cst * k_even(a) * k_even(Ls - a) / N / sum_func, 1.0 / (2.0 + Ls));
+        }
+        psi_level(SQ, F, Ls, times, lev[Ls], L);
+    }
+}
+
+__device__ double fixed_point_2d(const double* __restrict__ SQ, int F, double N, double t, double lev[6][MAXF],
+                                 KoptLds L) {
+    func2d_levels(SQ, F, N, t, 2, lev, L);
+    const double sum_func = lev[2][0] + lev[2][2] + 2.0 * lev[2][1];
+    const double time = pow(2.0 * PI * N * sum_func, -1.0 / 3.0);
+    return (t - time) / time;
+}
+
+// odd functionals: psi_odd for forms [1+2q, Lsum-1-2q]
+__device__ void psi_odd_level(const double* __restrict__ PW, int F, int Lsum, int m, const double* times, double* out,
+                              KoptLds L) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < m * F; e += KT) {
+        const int q = e / F, k = e % F;
+        const double f = (k <= (F - 1) / 2) ? (double)k : (double)(k - F);
+        const double w = exp(-(f * f) * (4.0 * PISQ * times[q]));
+        const int s0 = 1 + 2 * q, s1 = Lsum - s0;
+        L.wx[e] = w * pow(f, (double)s0);
+        L.wy[e] = w * pow(f, (double)s1);
+    }
+    __syncthreads();
+    bilinear_forms(PW, F, m, L);
+    const double ppow = pow(2.0 * PI, (double)Lsum);
+    for (int q = 0; q < m; ++q) out[q] = L.res[q] * ppow;
+    __syncthreads();
+}
+
+struct KoptPair {
+    double N, fallback_t;
+    int do_corr, pw_index;
+};
+
+__global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all, const double* __restrict__ PW_all,
+                                               const KoptPair* __restrict__ pairs, int F, double* __restrict__ out) {
+    extern __shared__ double lds[];
+    KoptLds L;
+    L.wx = lds;
+    L.wy = lds + MAXF * F;
+    L.res = L.wy + MAXF * F;
+    L.red = L.res + 8;
+    const int b = blockIdx.x;
+    const KoptPair P = pairs[b];
+    const double* SQ = SQ_all + (int64_t)b * F * F;
+    const double N = P.N;
+    double lev[6][MAXF];
+    for (int a = 0; a < 6; ++a)
+        for (int q = 0; q < MAXF; ++q) lev[a][q] = 0;
+
+    // ---- Brent's method (scipy.optimize.brentq: xtol=1e-6, rtol=4eps, maxiter=100) on [0, 0.1] ----
+    const double xtol = 0.001 * 0.001, rtol = 4.0 * 2.220446049250313e-16;
+    double xpre = 0.0, xcur = 0.1, xblk = 0.0, fblk = 0.0, spre = 0.0, scur = 0.0;
+    double fpre = fixed_point_2d(SQ, F, N, xpre, lev, L);
+    double fcur = fixed_point_2d(SQ, F, N, xcur, lev, L);
+    double t_star = 0.0;
+    int status = GD_OK;
+    bool done = false;
+    if (fpre != fpre || fcur != fcur) {
+        status = GD_ERR_SOLVER;
+        done = true;
+    } else if (fpre == 0) {
+        t_star = xpre;
+        done = true;
+    } else if (fcur == 0) {
+        t_star = xcur;
+        done = true;
+    } else if (signbit(fpre) == signbit(fcur)) {
+        status = GD_ERR_SOLVER;  // "f(a) and f(b) must have different signs"
+        done = true;
+    }
+    if (!done) {
+        status = GD_ERR_SOLVER;  // convergence error unless we return inside the loop
+        for (int it = 0; it < 100; ++it) {
+            if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+                xblk = xpre;
+                fblk = fpre;
+                spre = scur = xcur - xpre;
+            }
+            if (fabs(fblk) < fabs(fcur)) {
+                xpre = xcur, xcur = xblk, xblk = xpre;
+                fpre = fcur, fcur = fblk, fblk = fpre;
+            }
+            const double delta = (xtol + rtol * fabs(xcur)) / 2;
+            const double sbis = (xblk - xcur) / 2;
+            if (fcur == 0 || fabs(sbis) < delta) {
+                t_star = xcur;
+                status = GD_OK;
+                break;
+            }
+            if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+                double stry;
+                if (xpre == xblk) {
+                    stry = -fcur * (xcur - xpre) / (fcur - fpre);
+                } else {
+                    const double dpre = (fpre - fcur) / (xpre - xcur);
+                    const double dblk = (fblk - fcur) / (xblk - xcur);
+                    stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+                }
+                if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
+                    spre = scur;
+                    scur = stry;
+                } else {
+                    spre = sbis;
+                    scur = sbis;
+                }
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+            xpre = xcur;
+            fpre = fcur;
+            if (fabs(scur) > delta)
+                xcur += scur;
+            else
+                xcur += (sbis > 0 ? delta : -delta);
+            fcur = fixed_point_2d(SQ, F, N, xcur, lev, L);
+            if (fcur != fcur) break;  // NaN: scipy would wander to a convergence error
+        }
+    }
+    const bool have_fb = P.fallback_t > 0;
+    if (status == GD_OK) {
+        if (have_fb && t_star > 0.01 && t_star > 2 * P.fallback_t) t_star = P.fallback_t;  // kde_bandwidth.py:164-167
+    } else if (have_fb) {
+        t_star = P.fallback_t;  // kde_bandwidth.py:168-173
+        status = GD_OK;
+    }
+    double p02 = NAN, p20 = NAN, p11 = NAN, p00 = NAN, p13 = NAN, p31 = NAN;
+    if (status == GD_OK) {
+        func2d_levels(SQ, F, N, t_star, P.do_corr ? 0 : 2, lev, L);
+        p02 = lev[2][0], p20 = lev[2][2], p11 = lev[2][1];
+        if (P.do_corr) {
+            p00 = lev[0][0];
+            const double* PW = PW_all + (int64_t)P.pw_index * F * F;
+            double odd[4][MAXF], times[MAXF];
+            for (int q = 0; q < MAXF; ++q) times[q] = t_star;
+            psi_odd_level(PW, F, 10, 5, times, odd[3], L);  // [1,9],[3,7],[5,5],[7,3],[9,1]
+            int li = 2;
+            for (int Ls = 8; Ls >= 4; Ls -= 2, --li) {
+                const int m = Ls / 2;  // forms [1+2q, Ls-1-2q]
+                const double cst = 8.0 * (1.0 - pow(2.0, (double)(-Ls - 1))) / 3.0;
+                for (int q = 0; q < m; ++q) {
+                    const int s0 = 1 + 2 * q, s1 = Ls - s0;
+                    // func2d_odd([s0+2,s1]) + func2d_odd([s0,s1+2]) : entries q+1 and q of the level above
+                    const double sum_func = odd[li + 1][q + 1] + odd[li + 1][q];
+                    times[q] = pow(cst * p00 * k_odd(s0) * k_odd(s1) / (N * N) / (sum_func * sum_func), 1.0 / (3.0 + Ls));
+                }
+                psi_odd_level(PW, F, Ls, m, times, odd[li], L);
+            }
+            p13 = odd[0][0];  // [1,3]
+            p31 = odd[0][1];  // [3,1]
+        }
+    }
+    if (threadIdx.x == 0) {
+        double* o = out + (int64_t)b * 8;
+        o[0] = (status == GD_OK) ? t_star : NAN;
+        o[1] = p02, o[2] = p20, o[3] = p11, o[4] = p00, o[5] = p13, o[6] = p31, o[7] = (double)status;
+    }
+}
+
+extern "C" {
+
+int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* neff, const int32_t* do_corr,
+              const double* fallback_t, double* out) {
+    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 16 && F <= 1024, "KernelOptimizer2D grid size out of range (16..1024)");
+    const double* d_hist = (const double*)d_hist_v;
+    const int64_t FF = (int64_t)F * F;
+    // cached DCT matrix
+    double* D = nullptr;
+    auto it = ctx->dctmat.find(F);
+    if (it == ctx->dctmat.end()) {
+        GD_HIP(hipMalloc((void**)&D, (size_t)FF * 8));
+        k_dct_matrix<<<(unsigned)((FF + 255) / 256), 256, 0, ctx->stream>>>(F, D);
+        GD_KERNEL_CHECK();
+        ctx->dctmat[F] = D;
+    } else {
+        D = it->second;
+    }
+    std::vector<KoptPair> hp((size_t)B);
+    std::vector<int> which;
+    for (int b = 0; b < B; ++b) {
+        hp[b].N = neff[b];
+        hp[b].fallback_t = fallback_t[b];
+        hp[b].do_corr = do_corr[b] ? 1 : 0;
+        hp[b].pw_index = -1;
+        if (do_corr[b]) {
+            hp[b].pw_index = (int)which.size();
+            which.push_back(b);
+        }
+    }
+    const int nc = (int)which.size();
+    const int Fh = F / 2 + 1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_sums = take((int64_t)B * 8), o_pairs = take((int64_t)B * sizeof(KoptPair)), o_out = take((int64_t)B * 64),
+                  o_which = take((int64_t)(nc + 1) * 4), o_E = take((int64_t)B * FF * 8), o_SQ = take((int64_t)B * FF * 8),
+                  o_Z = take((int64_t)nc * F * Fh * 16), o_PW = take((int64_t)nc * FF * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_sums = (double*)(base + o_sums);
+    KoptPair* d_pairs = (KoptPair*)(base + o_pairs);
+    double* d_out = (double*)(base + o_out);
+    int* d_which = (int*)(base + o_which);
+    double* d_E = (double*)(base + o_E);
+    double* d_SQ = (double*)(base + o_SQ);
+    double2* d_Z = (double2*)(base + o_Z);
+    double* d_PW = (double*)(base + o_PW);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(KoptPair), hipMemcpyHostToDevice, ctx->stream));
+    k_hist_sums<<<B, 1024, 0, ctx->stream>>>(d_hist, (int)FF, d_sums);
+    GD_KERNEL_CHECK();
+    const dim3 ggrid((F + 63) / 64, (F + 63) / 64, B);
+    // E[l][r] = sum_c D[l][c] X[r][c]      (DCT along axis 1, transposed)
+    k_gemm_nt<0><<<ggrid, 256, 0, ctx->stream>>>(D, 0, d_hist, FF, F, d_E, FF, nullptr);
+    GD_KERNEL_CHECK();
+    // A^T[l][k] = sum_r E[l][r] D[k][r];  SQ[k][l] = (A[k][l] / sum)^2
+    k_gemm_nt<1><<<ggrid, 256, 0, ctx->stream>>>(d_E, FF, D, 0, F, d_SQ, FF, d_sums);
+    GD_KERNEL_CHECK();
+    if (nc > 0) {
+        GD_HIP(hipMemcpyAsync(d_which, which.data(), (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
+        // reuse E as the gathered, normalised input of the FFT (E is dead after the second GEMM)
+        k_gather_norm<<<dim3(64, nc), 256, 0, ctx->stream>>>(d_hist, d_which, d_sums, (int)FF, d_E);
+        GD_KERNEL_CHECK();
+        int rc = gd_fft_r2c_2d(ctx, F, F, nc, d_E, d_Z);
+        if (rc) return rc;
+        k_power_full<<<dim3(64, nc), 256, 0, ctx->stream>>>(d_Z, F, d_PW);
+        GD_KERNEL_CHECK();
+    }
+    const size_t lds = ((size_t)2 * MAXF * F + 8 + 16) * 8;
+    GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, d_out);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)B * 64, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+}  // extern "C"

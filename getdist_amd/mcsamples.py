@@ -1,0 +1,1069 @@
+"""
+``MCSamples``: the host-side mirror of GetDist's analysis object for the KDE / weighted-statistics hot
+path, driving libgdhip.so (HIP kernels on one MI355X) through the ctypes C ABI.
+
+Same method names, keyword arguments, defaults (analysis_defaults.ini) and result types as
+getdist/mcsamples.py + getdist/chains.py for that path; every O(N) step and every O(F^2) grid step runs
+on the GPU.  What stays in Python is the reference's *scalar* logic (ranges and limits, bin edges,
+bandwidth branch selection, fallbacks), evaluated in the reference's expression order so that bin edges
+are bit-identical, plus two tiny scipy scalar solvers with path-dependent results that are kept
+verbatim for parity: ``fsolve`` on the 1D Botev fixed point (one 1023-term functional per parameter,
+kde_bandwidth.py:123) and TNC on the AMISE of ~9 scalars (kde_bandwidth.py:276-299); see SURVEY.md
+A.11/A.12.
+
+Additive API (not in the reference): ``get1DDensities``, ``get2DDensities`` and ``triangleDensities``
+compute many densities in batched kernel launches; the per-name/per-pair methods are thin views over
+them.  There is no CPU fallback: without the library or a GPU, construction raises.
+"""
+
+import logging
+import warnings
+
+import numpy as np
+from scipy.optimize import brentq, fsolve, minimize
+
+from ._lib import Context
+from .densities import Density1D, Density2D, DensitiesError
+
+# analysis_defaults.ini:1-76 (the ini always overrides the class literals, mcsamples.py:491-492)
+DEFAULT_SETTINGS = dict(
+    ignore_rows=0, min_weight_ratio=1e-30, contours=[0.68, 0.95, 0.99], credible_interval_threshold=0.05,
+    range_ND_contour=-1, range_confidence=0.001, converge_test_limit=0.95, fine_bins=1024, smooth_scale_1D=-1.0,
+    boundary_correction_order=1, mult_bias_correction_order=1, smooth_scale_2D=-1.0, max_corr_2D=0.99,
+    fine_bins_2D=256, use_effective_samples_2D=False, max_scatter_points=2000, num_bins=100, num_bins_2D=40)
+
+
+class WeightedSampleError(Exception):
+    pass
+
+
+class MCSamplesError(WeightedSampleError):
+    pass
+
+
+class SettingError(MCSamplesError):
+    pass
+
+
+class BandwidthError(MCSamplesError):
+    pass
+
+
+class ParamError(MCSamplesError):
+    pass
+
+
+class ParamInfo:
+    """Per-parameter state bag; the attributes the hot path reads and writes (paramnames.py:69-154)."""
+
+    def __init__(self, name, label=None):
+        self.name = name
+        self.label = label or name
+        self.isDerived = False
+        self.limmin = self.limmax = None
+        self.has_limits_bot = self.has_limits_top = self.has_limits = False
+        self.periodic = False
+        self.N_eff_kde = None
+        self.kde_h = None
+
+    def __repr__(self):
+        return "ParamInfo(%s)" % self.name
+
+
+class ParamNames:
+    def __init__(self, names, labels=None):
+        labels = labels or [None] * len(names)
+        self.names = [ParamInfo(n, lab) for n, lab in zip(names, labels)]
+
+    def parWithName(self, name, error=False):
+        for p in self.names:
+            if p.name == name:
+                return p
+        if error:
+            raise ParamError("parameter name not found: %s" % name)
+        return None
+
+    def numberOfName(self, name):
+        for i, p in enumerate(self.names):
+            if p.name == name:
+                return i
+        return -1
+
+    def list(self):
+        return [p.name for p in self.names]
+
+    def numNonDerived(self):
+        return len([p for p in self.names if not p.isDerived])
+
+
+class ParamBounds:
+    """Hard prior ranges and periodic flags (parampriors.py:6-139, the parts the hot path uses)."""
+
+    def __init__(self):
+        self.lower, self.upper, self.periodic = {}, {}, set()
+
+    def setRange(self, name, rng):
+        lo, hi = rng[0], rng[1]
+        if len(rng) > 2 and rng[2] in (True, "periodic"):
+            self.periodic.add(name)
+        elif name in self.periodic:
+            self.periodic.discard(name)
+        for store, v in ((self.lower, lo), (self.upper, hi)):
+            if v is None or (isinstance(v, str) and v in ("N", "None")):
+                store.pop(name, None)
+            else:
+                store[name] = float(v)
+
+    def getLower(self, name):
+        return self.lower.get(name)
+
+    def getUpper(self, name):
+        return self.upper.get(name)
+
+
+_ROOTPI = np.sqrt(np.pi)
+_PISQ = np.pi**2
+_LMAX = 7
+_CONSTS_1D = np.array([(1 + 0.5 ** (j + 0.5)) / 3 * np.prod(np.arange(1, 2 * j, 2)) / (_ROOTPI / np.sqrt(2.0))
+                       for j in range(_LMAX - 1, 1, -1)])
+
+
+def _isj_fixed_point(h, N, I, logI, a2):
+    """The Botev improved-Sheather-Jones fixed point on device-computed DCT coefficients (kde_bandwidth.py:59-73)."""
+    if h <= 0:
+        return h - 1
+    f = 2 * np.pi ** (2 * _LMAX) * np.dot(a2, np.exp(_LMAX * logI - I * (_PISQ * h**2)))
+    for j, const in zip(range(_LMAX - 1, 1, -1), _CONSTS_1D):
+        t_j = (const / N / f) ** (2 / (3.0 + 2 * j))
+        f = 2 * np.pi ** (2 * j) * np.dot(a2, np.exp(j * logI - I * (_PISQ * t_j)))
+        if not f:
+            raise Exception("zero f in _bandwidth_fixed_point (non-convergence)")
+    return h - (2 * N * _ROOTPI * f) ** (-1.0 / 5)
+
+
+def _isj_solve(a, Neff):
+    """Root-find of kde_bandwidth.py:113-135 (same scipy solvers, start point and tolerances); None on failure."""
+    I = np.arange(1, a.size) ** 2
+    logI = np.log(I)
+    a2 = (a[1:] / 2) ** 2
+    try:
+        n_scaling = Neff ** (-1.0 / 5)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hfrac = 0.53 * n_scaling
+            hfrac = fsolve(_isj_fixed_point, hfrac, (Neff, I, logI, a2), xtol=hfrac / 20, factor=1)[0]
+        if hfrac < 0.019 * n_scaling:
+            try:
+                hfrac = brentq(_isj_fixed_point, 0.019 * n_scaling, 0.5, (Neff, I, logI, a2), xtol=hfrac / 20)
+            except Exception:
+                pass
+        return hfrac
+    except Exception as e:
+        logging.warning("1D auto bandwidth failed. Using fallback: %s" % e)
+        return None
+
+
+def _amise(cov, p, N, corr=None):
+    """kde_bandwidth.py:216-232 on the psi functionals p[(i,j)]"""
+    hx, hy = cov[0], cov[1]
+    c = corr if corr is not None else cov[2]
+    var = 1.0 / (4 * np.pi * hx * hy * np.sqrt(1 - c**2) * N)
+    bias = 0.25 * (hx**4 * p[4, 0] + hy**4 * p[0, 4] + 2 * hx**2 * hy**2 * p[2, 2] * (2 * c**2 + 1)
+                   + 4 * c * hx * hy * (hx**2 * p[3, 1] + hy**2 * p[1, 3]))
+    if bias < 0:
+        raise Exception("bias not positive definite")
+    return var + bias
+
+
+def _get_h(psi, N, corr_in, do_correlation):
+    """
+    KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given the device-computed functionals
+    psi = (p02, p20, p11, p00, p13, p31).  The two TNC minimisations act on these scalars only.
+    """
+    p_02, p_20, p_11, p_00, p_13, p_31 = psi
+    h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * N * p_20 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+    h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * N * p_02 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+    corr = 0
+    if not do_correlation:
+        return h_x, h_y, corr
+    p = np.zeros((5, 5))
+    p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = p_02, p_20, p_11, p_00, p_13, p_31
+    AMISE = _amise(np.array([h_x, h_y, 0]), p, N)
+    if corr_in:
+        try:
+            res = minimize(_amise, np.array([h_x, h_y]) / np.sqrt(1 - abs(corr_in)), (p, N, corr_in), method="TNC",
+                           bounds=[(0.001, 0.3), (0.001, 0.3)])
+            if res.success:
+                AMISEcorr = _amise(res.x, p, N, corr_in)
+                if AMISEcorr < AMISE:
+                    h_x, h_y = res.x
+                    corr = corr_in
+                    AMISE = AMISEcorr
+        except Exception:
+            logging.debug("AMISE fixed correlation optimization failed")
+    try:
+        res = minimize(_amise, np.array([h_x, h_y, corr_in]), (p, N, None), method="TNC",
+                       bounds=[(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)])
+        if res.success:
+            AMISEopt = _amise(res.x, p, N)
+            if AMISEopt < AMISE * 0.9:
+                h_x, h_y, corr = res.x
+    except Exception:
+        logging.debug("AMISE optimization failed")
+    return h_x, h_y, corr
+
+
+class MCSamples:
+    """
+    Weighted samples resident in HBM + the KDE hot path.  Constructor arguments follow
+    mcsamples.py:149-161 (``samples`` may be an (N, n) array or a list of per-chain arrays;
+    ``ranges`` maps name -> (lower, upper[, True|'periodic'])).  ``device`` selects the GPU.
+    """
+
+    def __init__(self, root=None, ini=None, settings=None, ranges=None, samples=None, weights=None, loglikes=None,
+                 temperature=None, names=None, labels=None, label=None, name_tag=None, sampler=None, ignore_rows=0,
+                 device=0, **kwargs):
+        if root is not None or ini is not None:
+            raise NotImplementedError("chain-file / ini loading is outside the accelerated path; pass arrays")
+        if samples is None:
+            raise MCSamplesError("samples are required")
+        self.sampler = sampler or "mcmc"
+        self.label, self.name_tag = label, name_tag
+        self.raise_on_bandwidth_errors = False
+        self.chain_offsets = None
+        if isinstance(samples, (list, tuple)) and len(samples) and np.ndim(samples[0]) == 2:
+            # list of chains (chains.py:1488-1503 makeSingle)
+            self.chain_offsets = np.cumsum(np.array([0] + [np.shape(c)[0] for c in samples]))
+            if weights is not None:
+                weights = np.hstack(list(weights))
+            if loglikes is not None:
+                loglikes = np.hstack(list(loglikes))
+            samples = np.vstack(list(samples))
+        samples = np.asarray(samples)
+        if samples.ndim == 1:
+            samples = samples.reshape(-1, 1)
+        if ignore_rows:
+            k = int(ignore_rows) if ignore_rows >= 1 else int(round(ignore_rows * samples.shape[0]))
+            samples = samples[k:]
+            weights = None if weights is None else np.asarray(weights)[k:]
+            loglikes = None if loglikes is None else np.asarray(loglikes)[k:]
+        self.samples = samples
+        self.loglikes = None if loglikes is None else np.asarray(loglikes, dtype=np.float64)
+        self.numrows, self.n = samples.shape
+        self._user_weights = weights is not None
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if names is None:
+            names = ["param%d" % (i + 1) for i in range(self.n)]
+        if len(names) != self.n:
+            raise MCSamplesError("names do not match the number of sample columns")
+        self.paramNames = ParamNames(list(names), labels)
+        self.index = {nm: i for i, nm in enumerate(names)}
+        self.ranges = ParamBounds()
+        for nm, rng in (ranges or {}).items():
+            self.ranges.setRange(nm, rng)
+        for k, v in DEFAULT_SETTINGS.items():
+            setattr(self, k, v)
+        if settings:
+            self.updateSettings(settings, doUpdate=False)
+        self.ctx = Context(device)
+        self.density1D = {}
+        self._idx_cols = {}
+        self.needs_update = True
+        self._upload()
+        self.updateBaseStatistics()
+
+    # ---- state -----------------------------------------------------------------------------------------
+    def _upload(self):
+        """(Re)build the device mirror of samples/weights (chains.py:276-323 funnel)."""
+        w = self.weights
+        if w is not None and self.min_weight_ratio is not None and self.min_weight_ratio >= 0:
+            mx, mn = np.max(w), np.min(w)  # chains.py:1017-1027
+            if mn < mx * self.min_weight_ratio:
+                keep = w > mx * self.min_weight_ratio
+                self.samples = self.samples[keep]
+                self.weights = w = w[keep]
+                if self.loglikes is not None:
+                    self.loglikes = self.loglikes[keep]
+                self.numrows = self.samples.shape[0]
+        self.ctx.upload(self.samples, w)
+        self._idx_cols = {}
+
+    def updateSettings(self, settings=None, ini=None, doUpdate=True):
+        """mcsamples.py:472-499 (settings dict only)"""
+        if ini is not None:
+            raise NotImplementedError("ini files are outside the accelerated path; pass a settings dict")
+        for k, v in (settings or {}).items():
+            if k not in DEFAULT_SETTINGS:
+                raise SettingError("unknown setting: %s" % k)
+            cur = DEFAULT_SETTINGS[k]
+            if isinstance(cur, bool):
+                v = v in (True, "T", "t", "True", "true", 1)
+            elif isinstance(cur, int) and not isinstance(v, bool):
+                v = int(v)
+            elif isinstance(cur, float):
+                v = float(v)
+            setattr(self, k, v)
+        if doUpdate:
+            self.needs_update = True
+
+    def setRanges(self, ranges):
+        """mcsamples.py:324-346"""
+        if isinstance(ranges, dict):
+            for nm, rng in ranges.items():
+                self.ranges.setRange(nm, rng)
+        else:
+            for nm, rng in zip(self.paramNames.list(), ranges):
+                self.ranges.setRange(nm, rng)
+        self.needs_update = True
+
+    def updateBaseStatistics(self):
+        """chains.py:1340-1352 + mcsamples.py:552-576, with the column scans on the GPU."""
+        ws = self.ctx.weight_stats()
+        if self.weights is not None:
+            self.norm = ws["norm"]
+        else:
+            self.norm = np.float64(self.numrows)  # chains.py:315
+        st = self.ctx.col_stats()
+        self._col_min, self._col_max = st[:, 0].copy(), st[:, 1].copy()
+        self.means = st[:, 2].copy()
+        self.vars = st[:, 3].copy()
+        self.sddev = np.sqrt(self.vars)
+        self.mean_mult = self.norm / self.numrows
+        self.max_mult = ws["max_w"]
+        self._sum_w2 = ws["sum_w2"]
+        mult_max = (self.mean_mult * self.numrows) / min(self.numrows // 2, 500)
+        if self.weights is not None:
+            outliers = self.ctx.weight_stats(thresh=mult_max)["n_above"]
+            if outliers != 0:
+                logging.warning("outlier fraction %s ", float(outliers) / self.numrows)
+        self.fullcov = None
+        self.correlationMatrix = None
+        self._setCov()
+        self.density1D = {}
+        self._initLimits()
+        for par in self.paramNames.names:
+            par.N_eff_kde = None
+            par._ranges_done = False
+        self.needs_update = False
+        return self
+
+    def _initLimits(self):
+        """mcsamples.py:442-470"""
+        for par in self.paramNames.names:
+            par.limmin = self.ranges.getLower(par.name)
+            par.limmax = self.ranges.getUpper(par.name)
+            par.has_limits_bot = par.limmin is not None
+            par.has_limits_top = par.limmax is not None
+            par.periodic = par.name in self.ranges.periodic
+
+    def _parAndNumber(self, name):
+        """chains.py:1235-1250"""
+        if isinstance(name, ParamInfo):
+            name = name.name
+        if isinstance(name, str):
+            name = self.index.get(name, None)
+            if name is None:
+                return None, None
+        if isinstance(name, (int, np.integer)):
+            return int(name), self.paramNames.names[int(name)]
+        raise ParamError("Unknown parameter type %s" % name)
+
+    # ---- moments (chains.py:339-412, 636-780) ------------------------------------------------------------
+    def get_norm(self):
+        return self.norm
+
+    def getMeans(self, pars=None):
+        return self.means if pars is None else np.array([self.means[i] for i in pars])
+
+    def getVars(self):
+        return self.vars
+
+    def _setCov(self):
+        _, cov, _ = self.ctx.cov()
+        self.fullcov = cov
+        return cov
+
+    def getCov(self, nparam=None, pars=None):
+        if self.fullcov is None:
+            self._setCov()
+        if pars is not None:
+            return self.fullcov[np.ix_(pars, pars)]
+        return self.fullcov[:nparam, :nparam]
+
+    def cov(self, pars=None):
+        cols = list(range(self.n)) if pars is None else [self._parAndNumber(p)[0] for p in pars]
+        return self.ctx.cov(cols)[1]
+
+    def corr(self, pars=None):
+        return covToCorr(self.cov(pars))
+
+    def getCorrelationMatrix(self):
+        if self.correlationMatrix is None:
+            self.correlationMatrix = covToCorr(self.getCov())
+        return self.correlationMatrix
+
+    def _col(self, par):
+        j = self._parAndNumber(par)[0]
+        if j is None:
+            raise ParamError("unknown parameter %s" % par)
+        return j
+
+    def mean(self, paramVec):
+        if isinstance(paramVec, (list, tuple)):
+            return np.array([self.means[self._col(p)] for p in paramVec])
+        return self.means[self._col(paramVec)]
+
+    def var(self, paramVec):
+        if isinstance(paramVec, (list, tuple)):
+            return np.array([self.vars[self._col(p)] for p in paramVec])
+        return self.vars[self._col(paramVec)]
+
+    def std(self, paramVec):
+        return np.sqrt(self.var(paramVec))
+
+    # ---- weighted quantiles (chains.py:782-838) ----------------------------------------------------------
+    def confidence(self, paramVec, limfrac, upper=False, start=0, end=None, weights=None):
+        if weights is not None:
+            raise NotImplementedError("alternative weights are not resident on the device")
+        j = self._col(paramVec)
+        limfrac = np.atleast_1d(np.asarray(limfrac, dtype=np.float64))
+        end = self.numrows if end is None else end
+        norm = self.norm if (start == 0 and end == self.numrows) else self.ctx.weight_stats(start, end)["norm"]
+        targets = norm * limfrac if not upper else norm * (1 - limfrac)
+        out = self.ctx.quantiles([j], targets[None, :], lo=start, hi=end)[0]
+        return out if out.size > 1 else out[0]
+
+    def twoTailLimits(self, paramVec, confidence):
+        limits = np.array([(1 - confidence) / 2, 1 - (1 - confidence) / 2])
+        return self.confidence(paramVec, limits)
+
+    # ---- autocorrelation / effective samples (chains.py:423-574) -------------------------------------------
+    def getAutocorrelation(self, paramVec, maxOff=None, weight_units=True, normalized=True):
+        j = self._col(paramVec)
+        if maxOff is None:
+            maxOff = self.n - 1
+        lags = self.ctx.autocov_lags(j, self.means[j], 0, maxOff + 1)
+        corr = lags / np.arange(self.numrows, self.numrows - (maxOff + 1), -1)
+        if normalized:
+            corr /= self.vars[j]
+        if weight_units:
+            return corr * self.numrows / self.norm
+        return corr
+
+    def getCorrelationLength(self, j, weight_units=True, min_corr=0.05, corr=None):
+        """chains.py:449-466 by direct lag sums with early exit."""
+        j = self._col(j)
+        max_off = self.numrows // 10
+        scale = (self.numrows / self.norm) if weight_units else 1.0
+        vals = []
+        k0, chunk = 0, 32
+        while k0 <= max_off:
+            nl = min(chunk, max_off + 1 - k0)
+            lags = self.ctx.autocov_lags(j, self.means[j], k0, nl)
+            c = lags / (self.numrows - np.arange(k0, k0 + nl)) / self.vars[j] * scale
+            vals.extend(c.tolist())
+            below = np.nonzero(~(np.array(vals) > min_corr * vals[0]))[0]
+            if below.size:
+                ix = int(below[0])
+                return vals[0] + 2 * float(np.sum(np.array(vals[1:ix])))
+            k0 += nl
+            chunk = min(chunk * 2, 4096)
+            if k0 > 262144:
+                raise NotImplementedError("autocorrelation longer than 2^18 samples: direct-lag kernel not suited")
+        return vals[0]  # argmin of an all-True mask is 0 (chains.py:464-465)
+
+    def getEffectiveSamples(self, j=0, min_corr=0.05):
+        return self.norm / self.getCorrelationLength(j, min_corr=min_corr)
+
+    def getEffectiveSamplesGaussianKDE(self, paramVec, h=0.2, scale=None, maxoff=None, min_corr=0.05):
+        """chains.py:477-574; the lag sums with the Gaussian kernel run on the GPU."""
+        if self.sampler in ("nested", "uncorrelated"):
+            return self.norm**2 / self._sum_w2
+        j = self._col(paramVec)
+        kernel_std = (scale or self.sddev[j]) * h
+        if maxoff is None:
+            maxoff = int(self.getCorrelationLength(j, weight_units=False) * 1.5) + 4
+        maxoff = min(maxoff, self.numrows // 10)
+        uncorr_len = self.numrows // 2
+        inv4s2 = 1.0 / (4 * kernel_std**2)
+        first = [k for k in (1, 2) if k <= maxoff]
+        lags = list(range(uncorr_len, uncorr_len + 5)) + first
+        sums = self.ctx.kde_lag_sums(j, inv4s2, lags)
+        nav = sum(self.numrows - k for k in range(uncorr_len, uncorr_len + 5))
+        uncorr_term = float(np.sum(sums[:5])) / nav
+        n = float(self.numrows)
+        cache = {k: sums[5 + i] for i, k in enumerate(first)}
+
+        def corr_k(k):
+            if k not in cache:
+                cache[k] = self.ctx.kde_lag_sums(j, inv4s2, [k])[0]
+            return cache[k] - (n - k) * uncorr_term
+
+        corr0 = self._sum_w2
+        threshold = min_corr * corr0
+        c1 = corr_k(1)
+        if c1 < threshold:
+            N = corr0
+        else:
+            c2 = corr_k(2)
+            if c2 > threshold:
+                max_k = maxoff
+                while max_k > 10:
+                    if corr_k(max_k // 3) >= threshold:
+                        break
+                    max_k //= 3
+                step_size = 1 if max_k < 20 else max_k // 10
+                cum_sum = c1 + c2
+                for k in range(3, maxoff + 1, step_size):
+                    test_val = corr_k(k)
+                    if test_val < threshold:
+                        break
+                    cum_sum += test_val * step_size if k > 3 else (test_val * step_size) / 2
+                N = corr0 + 2 * cum_sum
+            else:
+                N = corr0 + 2 * c1
+        return self.norm**2 / N
+
+    def _get1DNeff(self, par, param):
+        """mcsamples.py:1230-1235"""
+        if par.N_eff_kde is None:
+            par.N_eff_kde = self.getEffectiveSamplesGaussianKDE(param, scale=par.sigma_range)
+        return par.N_eff_kde
+
+    # ---- ranges and limits (mcsamples.py:1421-1498) --------------------------------------------------------
+    def _initParamRanges(self, j, paramConfid=None):
+        self._init_params([self._col(j)])
+        return self.paramNames.names[self._col(j)]
+
+    def _init_params(self, js):
+        """_initParam for several parameters with ONE batched quantile-select launch."""
+        todo = [j for j in dict.fromkeys(js) if not getattr(self.paramNames.names[j], "_ranges_done", False)]
+        if not todo:
+            return
+        rc = self.range_confidence
+        fracs = np.array([rc, 1 - rc] + list(np.linspace(0.1, 0.9, 9)))
+        targets = np.tile(self.norm * fracs, (len(todo), 1))
+        q = self.ctx.quantiles(todo, targets)
+        for row, j in enumerate(todo):
+            par = self.paramNames.names[j]
+            par.err = self.sddev[j]
+            par.mean = self.means[j]
+            par.param_min = self._col_min[j]
+            par.param_max = self._col_max[j]
+            confids = q[row].copy()
+            par.range_min, par.range_max = confids[0:2]
+            confids[1:-1] = confids[2:]
+            confids[0] = par.param_min
+            confids[-1] = par.param_max
+            diffs = confids[4:] - confids[:-4]
+            scale = np.min(diffs) / 1.049
+            if np.all(diffs > par.err * 1.049) and np.all(diffs < scale * 1.5):
+                par.sigma_range = scale  # very flat
+            else:
+                par.sigma_range = min(par.err, scale)
+            if self.range_ND_contour >= 0:
+                raise NotImplementedError("range_ND_contour needs likelihood statistics (outside the accelerated path)")
+            smooth_1D = par.sigma_range * 0.4
+            if par.has_limits_bot:
+                if par.range_min - par.limmin > 2 * smooth_1D and par.param_min - par.limmin > smooth_1D:
+                    par.has_limits_bot = False  # long way from limit
+                else:
+                    par.range_min = par.limmin
+            if par.has_limits_top:
+                if par.limmax - par.range_max > 2 * smooth_1D and par.limmax - par.param_max > smooth_1D:
+                    par.has_limits_top = False
+                else:
+                    par.range_max = par.limmax
+            if not par.has_limits_bot:
+                par.range_min -= smooth_1D * 2
+            if not par.has_limits_top:
+                par.range_max += smooth_1D * 2
+            par.has_limits = par.has_limits_top or par.has_limits_bot
+            par._ranges_done = True
+
+    @staticmethod
+    def _bin_edges(par, num_fine_bins, borderfrac=0.1):
+        """The scalar half of _binSamples (mcsamples.py:1486-1496); the index half runs fused in the kernels."""
+        border = (par.range_max - par.range_min) * borderfrac
+        binmin = min(par.param_min, par.range_min)
+        if not par.has_limits_bot:
+            binmin -= border
+        binmax = max(par.param_max, par.range_max)
+        if not par.has_limits_top:
+            binmax += border
+        fine_width = (binmax - binmin) / (num_fine_bins - 1)
+        return fine_width, binmin, binmax
+
+    # ---- 1D densities (mcsamples.py:1237-1283, 1500-1686) ---------------------------------------------------
+    def getAutoBandwidth1D(self, bins, par, param, mult_bias_correction_order=None, kernel_order=1, N_eff=None):
+        if N_eff is None:
+            N_eff = self._get1DNeff(par, param)
+        a = self.ctx.dct1d(np.asarray(bins, dtype=np.float64)[None, :])[0]
+        return self._bandwidth_1d_from_dct(a, par, N_eff, mult_bias_correction_order, kernel_order)
+
+    def _bandwidth_1d_from_dct(self, a, par, N_eff, mult_bias_correction_order, kernel_order):
+        h = _isj_solve(a, N_eff)
+        bin_range = max(par.param_max, par.range_max) - min(par.param_min, par.range_min)
+        if h is None or h < 0.01 * N_eff ** (-1.0 / 5) * (par.range_max - par.range_min) / bin_range:
+            hnew = 1.06 * par.sigma_range * N_eff ** (-1.0 / 5) / bin_range
+            msg = f"auto bandwidth for {par.name} very small or failed (h={h},N_eff={N_eff}). Using fallback (h={hnew})"
+            if self.raise_on_bandwidth_errors:
+                raise BandwidthError(msg)
+            logging.warning(msg)
+            h = hnew
+        par.kde_h = h
+        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
+        if kernel_order > 1:
+            m = max(m, 1)
+        if m:
+            return h * N_eff ** (1.0 / 5 - 1.0 / (4 * m + 5))
+        return h
+
+    def get1DDensity(self, name, **kwargs):
+        if self.needs_update:
+            self.updateBaseStatistics()
+        if not kwargs:
+            j, par = self._parAndNumber(name)
+            if par is not None and par.name in self.density1D:
+                return self.density1D[par.name]
+        return self.get1DDensityGridData(name, **kwargs)
+
+    def get1DDensityGridData(self, j, paramConfid=None, meanlikes=False, **kwargs):
+        if meanlikes:
+            raise NotImplementedError("meanlikes is outside the accelerated path")
+        if self.needs_update:
+            self.updateBaseStatistics()
+        j = self._parAndNumber(j)[0]
+        if j is None:
+            return None
+        return self.get1DDensities([j], **kwargs)[0]
+
+    def get1DDensities(self, params=None, **kwargs):
+        """Batched 1D KDEs (additive API): a list of Density1D, one per entry of ``params`` (default: all)."""
+        if self.needs_update:
+            self.updateBaseStatistics()
+        for k in kwargs:
+            if k not in ("smooth_scale_1D", "boundary_correction_order", "mult_bias_correction_order", "fine_bins",
+                         "num_bins"):
+                raise SettingError("unknown 1D density argument %s" % k)
+        js = list(range(self.n)) if params is None else [self._col(p) for p in params]
+        num_bins = kwargs.get("num_bins", self.num_bins)
+        smooth_scale_1D = kwargs.get("smooth_scale_1D", self.smooth_scale_1D)
+        bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
+        mbc = kwargs.get("mult_bias_correction_order", self.mult_bias_correction_order)
+        fine_bins = kwargs.get("fine_bins", self.fine_bins)
+        if bco > 2:
+            raise SettingError("Unknown boundary_correction_order (expected 0, 1, 2)")
+        self._init_params(js)
+        pars = [self.paramNames.names[j] for j in js]
+        edges = []
+        for par in pars:
+            if par.range_max - par.range_min <= 0:
+                raise MCSamplesError("Parameter range is <= 0: " + par.name)
+            edges.append(self._bin_edges(par, fine_bins))
+        hist = self.ctx.hist1d(js, [e[1] for e in edges], [e[0] for e in edges], fine_bins)
+        smooth, winw, flags = [], [], []
+        dct = None
+        if smooth_scale_1D <= 0:
+            dct = self.ctx.dct1d(hist)
+        for b, (j, par) in enumerate(zip(js, pars)):
+            fine_width, binmin, binmax = edges[b]
+            paramrange = par.range_max - par.range_min
+            width = paramrange / (num_bins - 1)
+            if smooth_scale_1D <= 0:
+                N_eff = self._get1DNeff(par, j)
+                bandwidth = self._bandwidth_1d_from_dct(dct[b], par, N_eff, mbc, bco) * (binmax - binmin)
+                bandwidth = min(bandwidth, paramrange / 4)
+                smooth_1D = bandwidth * abs(smooth_scale_1D) / fine_width
+            elif smooth_scale_1D < 1.0:
+                smooth_1D = smooth_scale_1D * par.err / fine_width
+            else:
+                smooth_1D = smooth_scale_1D * width / fine_width
+            if smooth_1D < 2:
+                logging.warning("fine_bins not large enough to well sample smoothing scale - " + par.name)
+            smooth_1D = min(max(1.0, smooth_1D), fine_bins // 2)
+            smooth.append(smooth_1D)
+            winw.append(min(int(round(2.5 * smooth_1D)), ((fine_bins - 1) if par.periodic else fine_bins) // 2 - 2))
+            flags.append((1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0))
+        P, status = self.ctx.density1d(hist, smooth, winw, flags, bco, mbc)
+        out = []
+        for b, (j, par) in enumerate(zip(js, pars)):
+            if status[b] != 0:
+                raise DensitiesError("no samples in bin")
+            fine_width, binmin, binmax = edges[b]
+            d = Density1D(np.linspace(binmin, binmax, fine_bins), P=P[b].copy(), view_ranges=[par.range_min, par.range_max])
+            d.likes = None
+            if not kwargs:
+                self.density1D[par.name] = d
+            out.append(d)
+        return out
+
+    # ---- 2D densities (mcsamples.py:1285-1419, 1730-2010) ---------------------------------------------------
+    def get2DDensity(self, x, y, normalized=False, **kwargs):
+        if self.needs_update:
+            self.updateBaseStatistics()
+        density = self.get2DDensityGridData(x, y, get_density=True, **kwargs)
+        if density is not None and normalized:
+            density.normalize(in_place=True)
+        return density
+
+    def get2DDensityGridData(self, j, j2, num_plot_contours=None, get_density=False, meanlikes=False,
+                             mask_function=None, **kwargs):
+        if meanlikes or mask_function is not None:
+            raise NotImplementedError("meanlikes / mask_function are outside the accelerated path")
+        if self.needs_update:
+            self.updateBaseStatistics()
+        j = self._parAndNumber(j)[0]
+        j2 = self._parAndNumber(j2)[0]
+        if j is None or j2 is None:
+            return None
+        return self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density, **kwargs)[0]
+
+    def triangleDensities(self, params=None, **kwargs):
+        """All lower-triangle pairs (x=params[i], y=params[i2>i]) in triangle-plot order; returns (pairs, densities)."""
+        names = list(range(self.n)) if params is None else [self._col(p) for p in params]
+        pairs = [(names[i], names[i2]) for i in range(len(names)) for i2 in range(i + 1, len(names))]
+        return pairs, self.get2DDensities(pairs, **kwargs)
+
+    def getAutoBandwidth2D(self, bins, parx, pary, paramx, paramy, corr, rangex, rangey, base_fine_bins_2D,
+                           mult_bias_correction_order=None, min_corr=0.2, N_eff=None, use_2D_Neff=False):
+        """Per-pair entry point with the reference's signature (mcsamples.py:1285-1419); ``bins`` is a host F x F grid."""
+        bins = np.ascontiguousarray(bins, dtype=np.float64)
+        F = bins.shape[0]
+        d = self.ctx.alloc(bins.nbytes)
+        d.from_host(bins)
+        plan = self._bandwidth_plan([(paramx, paramy)], [corr], [(rangex, rangey)], base_fine_bins_2D, N_eff=N_eff)
+        res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)
+        return res[0]
+
+    def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None):
+        """Branch selection per pair (mcsamples.py:1325-1409), scalars only."""
+        plan = []
+        for (jx, jy), corr, (rangex, rangey) in zip(pairs, corrs, ranges_xy):
+            parx, pary = self.paramNames.names[jx], self.paramNames.names[jy]
+            if N_eff is None:
+                if self.use_effective_samples_2D and abs(corr) < 0.999:
+                    raise NotImplementedError("use_effective_samples_2D (off by default) is not accelerated")
+                neff = min(self._get1DNeff(parx, jx), self._get1DNeff(pary, jy))
+            else:
+                neff = N_eff
+            has_limits = parx.has_limits or pary.has_limits
+            do_correlated = not parx.has_limits or not pary.has_limits
+            e = dict(jx=jx, jy=jy, parx=parx, pary=pary, corr=corr, neff=neff, has_limits=has_limits,
+                     rangex=rangex, rangey=rangey)
+            if min_corr < abs(corr) <= self.max_corr_2D and do_correlated:
+                e["branch"] = "A"
+                i, j = jx, jy
+                imax, imin = None, None
+                if parx.has_limits_bot:
+                    imin = parx.range_min
+                if parx.has_limits_top:
+                    imax = parx.range_max
+                if pary.has_limits:
+                    i, j = j, i
+                    if pary.has_limits_bot:
+                        imin = pary.range_min
+                    if pary.has_limits_top:
+                        imax = pary.range_max
+                cov = self.getCov(pars=[i, j])
+                S = np.linalg.cholesky(cov)
+                ichol = np.linalg.inv(S)
+                S *= ichol[0, 0]
+                r = ichol[1, :] / ichol[0, 0]
+                e.update(i=i, j=j, imin=imin, imax=imax, S=S, r=r)
+            elif abs(corr) > self.max_corr_2D or not do_correlated and corr > 0.8:
+                e["branch"] = "B"
+            else:
+                e["branch"] = "C"
+                e["fallback_t"] = (min(pary.sigma_range / rangey, parx.sigma_range / rangex) / neff ** (1.0 / 6)) ** 2
+            plan.append(e)
+        return plan
+
+    def _fallback_widths(self, e, ex):
+        parx, pary, corr, neff = e["parx"], e["pary"], e["corr"], e["neff"]
+        msg = f"2D kernel density bandwidth optimizer failed for {parx.name}, {pary.name}. Using fallback width: {ex}"
+        if self.raise_on_bandwidth_errors:
+            raise BandwidthError(msg)
+        logging.warning(msg)
+        _hx = parx.sigma_range / neff ** (1.0 / 6)
+        _hy = pary.sigma_range / neff ** (1.0 / 6)
+        return _hx, _hy, max(min(corr, self.max_corr_2D), -self.max_corr_2D)
+
+    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order):
+        """
+        getAutoBandwidth2D for a batch.  ``hists_by_F``: F -> (device buffer of that class's histograms,
+        list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.
+        """
+        results = [None] * len(plan)
+        ctx = self.ctx
+        # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
+        A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
+        if A:
+            mm = ctx.minmax_affine([plan[k]["i"] for k in A], [plan[k]["j"] for k in A], [plan[k]["r"][0] for k in A],
+                                   [plan[k]["r"][1] for k in A])
+            xmin, dx, ymin, dy, r1s, r2s = [], [], [], [], [], []
+            for row, k in enumerate(A):
+                e = plan[k]
+                # kde.bin_samples(p1, nbins, range_min=imin, range_max=imax) (kde_bandwidth.py:76-87)
+                mn, mx = self._col_min[e["i"]], self._col_max[e["i"]]
+                delta = mx - mn
+                rmin = e["imin"] if e["imin"] is not None else mn - delta * 0.1
+                rmax = e["imax"] if e["imax"] is not None else mx + delta * 0.1
+                R1 = rmax - rmin
+                mn2, mx2 = mm[row]
+                delta2 = mx2 - mn2
+                rmin2 = mn2 - delta2 * 0.1
+                R2 = (mx2 + delta2 * 0.1) - rmin2
+                xmin.append(rmin), dx.append(R1 / (base_F - 1)), ymin.append(rmin2), dy.append(R2 / (base_F - 1))
+                r1s.append(R1), r2s.append(R2)
+            d_rot = ctx.hist2d_sheared([plan[k]["i"] for k in A], [plan[k]["j"] for k in A],
+                                       [plan[k]["r"][0] for k in A], [plan[k]["r"][1] for k in A], xmin, dx, ymin, dy,
+                                       base_F)
+            do_corr = [0 if plan[k]["has_limits"] else 1 for k in A]
+            out = ctx.kopt2d(d_rot, len(A), base_F, [plan[k]["neff"] for k in A], do_corr, [-1.0] * len(A))
+            d_rot.free()
+            for row, k in enumerate(A):
+                e = plan[k]
+                if out[row, 7] != 0:
+                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
+                    continue
+                hx, hy, c = _get_h(out[row, 1:7], e["neff"], 0, bool(do_corr[row]))
+                hx *= r1s[row]
+                hy *= r2s[row]
+                S = e["S"]
+                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
+                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
+                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
+                if e["pary"].has_limits:
+                    hx, hy = hy, hx
+                results[k] = (hx, hy, c)
+        # -- branch B: rule of thumb
+        for k, e in enumerate(plan):
+            if e["branch"] == "B":
+                c = max(min(e["corr"], self.max_corr_2D), -self.max_corr_2D)
+                results[k] = (e["parx"].sigma_range / e["neff"] ** (1.0 / 6), e["pary"].sigma_range / e["neff"] ** (1.0 / 6), c)
+        # -- branch C: optimiser on the pair's own histogram
+        for F, (d_hist, members) in hists_by_F.items():
+            sel = [(pos, k) for pos, k in enumerate(members) if plan[k]["branch"] == "C"]
+            if not sel:
+                continue
+            if len(sel) == len(members):
+                d_sub, own = d_hist, False
+            else:
+                d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
+                self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
+            do_corr = [0 if plan[k]["has_limits"] else 1 for _, k in sel]
+            out = ctx.kopt2d(d_sub, len(sel), F, [plan[k]["neff"] for _, k in sel], do_corr,
+                             [plan[k]["fallback_t"] for _, k in sel])
+            if own:
+                d_sub.free()
+            for row, (_, k) in enumerate(sel):
+                e = plan[k]
+                if out[row, 7] != 0:
+                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
+                    continue
+                hx, hy, c = _get_h(out[row, 1:7], e["neff"], e["corr"], bool(do_corr[row]))
+                results[k] = (hx * e["rangex"], hy * e["rangey"], c)
+        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
+        if m:
+            for k, e in enumerate(plan):
+                scale = 1.1 * e["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
+                hx, hy, c = results[k]
+                results[k] = (hx * scale, hy * scale, c)
+        return results
+
+    def _gather_device(self, d_src, d_dst, positions, item_bytes):
+        """Copy selected fixed-size items of one device buffer into another (device-to-device)."""
+        for row, pos in enumerate(positions):
+            self.ctx.copy_d2d(d_dst, row * item_bytes, d_src, pos * item_bytes, item_bytes)
+
+    def _index_column(self, j, F, binmin, width):
+        key = (j, F)
+        hit = self._idx_cols.get(key)
+        if hit is None or hit[1] != (binmin, width):
+            buf = hit[0] if hit is not None else None
+            buf = self.ctx.prebin(j, binmin, width, F, buf)
+            self._idx_cols[key] = (buf, (binmin, width))
+        return self._idx_cols[key][0]
+
+    def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, **kwargs):
+        """Batched 2D KDEs (additive API): a list of Density2D, one per (x, y) entry of ``pairs``."""
+        if self.needs_update:
+            self.updateBaseStatistics()
+        for k in kwargs:
+            if k not in ("fine_bins_2D", "boundary_correction_order", "mult_bias_correction_order", "smooth_scale_2D"):
+                raise SettingError("unknown 2D density argument %s" % k)
+        pairs = [(self._col(a), self._col(b)) for a, b in pairs]
+        base_F = kwargs.get("fine_bins_2D", self.fine_bins_2D)
+        bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
+        mbc = kwargs.get("mult_bias_correction_order", self.mult_bias_correction_order)
+        smooth_scale_2D = float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D))
+        if abs(self.max_corr_2D) > 1:
+            raise SettingError("max_corr_2D cannot be >=1")
+        if bco > 1:
+            raise SettingError("unknown boundary_correction_order (expected 0 or 1)")
+        ctx = self.ctx
+        used = list(dict.fromkeys([j for p in pairs for j in p]))
+        self._init_params(used)
+        names = self.paramNames.names
+        if any(names[j].periodic for j in used):
+            raise NotImplementedError("periodic parameters are not yet supported by the 2D device pipeline")
+        corrmat = self.getCorrelationMatrix()
+        # ---- per-pair scalars (mcsamples.py:1794-1822)
+        info = []
+        for (j, j2) in pairs:
+            parx, pary = names[j], names[j2]
+            corr = corrmat[j2][j]
+            actual_corr = corr
+            if abs(abs(corr) - 1.0) <= 1e-8:
+                logging.warning("Parameters are 100%% correlated: %s, %s", parx.name, pary.name)
+                corr = np.sign(corr) * self.max_corr_2D
+            if abs(corr) < 0.1:
+                corr = 0.0
+            angle_scale = max(0.2, np.sqrt(1 - min(self.max_corr_2D, abs(corr)) ** 2))
+            nbin2D = int(round(self.num_bins_2D / angle_scale))
+            F = base_F
+            if corr:
+                scaled = 192 * int(3 / angle_scale) // 3
+                if base_F < scaled and int(1 / angle_scale) > 1:
+                    F = scaled
+            fwx, xbinmin, xbinmax = self._bin_edges(parx, F)
+            fwy, ybinmin, ybinmax = self._bin_edges(pary, F)
+            info.append(dict(j=j, j2=j2, parx=parx, pary=pary, corr=corr, actual_corr=actual_corr, F=F, nbin2D=nbin2D,
+                             fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin, ybinmax=ybinmax))
+        # ---- histograms, one batched launch per grid-size class (pre-binned u16 index columns)
+        classes = {}
+        for k, e in enumerate(info):
+            classes.setdefault(e["F"], []).append(k)
+        hists = {}
+        for F, members in classes.items():
+            ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
+            iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
+            hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
+        # ---- bandwidths
+        rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
+        if smooth_scale_2D < 0:
+            plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
+                                        [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info], base_F)
+            bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
+            for k, e in enumerate(info):
+                hx, hy, c = bw[k]
+                rx[k] = hx * abs(smooth_scale_2D) / e["fwx"]
+                ry[k] = hy * abs(smooth_scale_2D) / e["fwy"]
+                cc[k] = c
+                e["bandwidth"] = bw[k]
+        else:
+            for k, e in enumerate(info):
+                if smooth_scale_2D < 1.0:
+                    rx[k] = smooth_scale_2D * e["parx"].err / e["fwx"]
+                    ry[k] = smooth_scale_2D * e["pary"].err / e["fwy"]
+                else:
+                    rx[k] = ry[k] = smooth_scale_2D * e["F"] / e["nbin2D"]
+                cc[k] = e["corr"]
+        # ---- convolution + corrections, batched per (F, bounded?) class
+        out = [None] * len(info)
+        for F, (d_hist, members) in hists.items():
+            groups = {}
+            for pos, k in enumerate(members):
+                e = info[k]
+                flags = ((1 if e["parx"].has_limits_bot else 0) | (2 if e["parx"].has_limits_top else 0)
+                         | (4 if e["pary"].has_limits_bot else 0) | (8 if e["pary"].has_limits_top else 0))
+                e["flags"] = flags
+                smooth_scale = float(max(rx[k], ry[k]))
+                if smooth_scale < 2:
+                    logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", e["parx"].name,
+                                    e["pary"].name)
+                e["winw"] = max(1, int(round(2.5 * smooth_scale)))
+                groups.setdefault(bool(flags) and bco >= 0, []).append((pos, k))
+            max_batch = max(1, int(2.0e9 // (F * F * 8 * 30)))
+            for bounded, sel_all in groups.items():
+                for s0 in range(0, len(sel_all), max_batch):
+                    sel = sel_all[s0:s0 + max_batch]
+                    if len(sel) == len(members):
+                        d_sub, own = d_hist, False
+                    else:
+                        d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
+                        self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
+                    ks = [k for _, k in sel]
+                    d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                [cc[k] for k in ks], [info[k]["winw"] for k in ks],
+                                                [info[k]["flags"] for k in ks], bco, mbc)
+                    P = d_P.to_host((len(sel), F, F))
+                    d_P.free()
+                    if own:
+                        d_sub.free()
+                    for row, k in enumerate(ks):
+                        if status[row] != 0:
+                            raise DensitiesError("no samples in bin")
+                        e = info[k]
+                        dens = Density2D(np.linspace(e["xbinmin"], e["xbinmax"], F),
+                                         np.linspace(e["ybinmin"], e["ybinmax"], F), P[row],
+                                         view_ranges=[(e["parx"].range_min, e["parx"].range_max),
+                                                      (e["pary"].range_min, e["pary"].range_max)])
+                        dens.bandwidth = e.get("bandwidth")
+                        if not get_density:
+                            ncontours = len(self.contours)
+                            if num_plot_contours:
+                                ncontours = min(num_plot_contours, ncontours)
+                            dens.contours = dens.getContourLevels(self.contours[:ncontours])
+                        dens.likes = None
+                        out[k] = dens
+            d_hist.free()
+        return out
+
+    # ---- convergence (chains.py:1446-1527; mcsamples.py:964-1003) ------------------------------------------
+    def getSeparateChainStats(self, nparam=None):
+        """Per-chain (means, cov, norm) over the first nparam parameters, one covariance launch per chain."""
+        if self.chain_offsets is None:
+            raise WeightedSampleError("Samples were not combined from separate chains")
+        nparam = nparam or self.paramNames.numNonDerived()
+        cols = list(range(nparam))
+        return [self.ctx.cov(cols, lo=int(a), hi=int(b)) for a, b in zip(self.chain_offsets[:-1], self.chain_offsets[1:])]
+
+    def getGelmanRubinEigenvalues(self, nparam=None, chainlist=None):
+        """chains.py:1446-1474: var(mean)/mean(var) in the orthogonalised parameters"""
+        if chainlist is not None:
+            raise NotImplementedError("explicit chain lists are outside the accelerated path")
+        nparam = nparam or self.paramNames.numNonDerived()
+        stats = self.getSeparateChainStats(nparam)
+        meanscov = np.zeros((nparam, nparam))
+        means = self.getMeans()[:nparam]
+        meancov = np.zeros(meanscov.shape)
+        for cmeans, ccov, _ in stats:
+            diff = cmeans - means
+            meanscov += np.outer(diff, diff)
+            meancov += ccov
+        meanscov /= len(stats) - 1
+        meancov /= len(stats)
+        w, U = np.linalg.eigh(meancov)
+        if np.min(w) > 0:
+            U /= np.sqrt(w)
+            return np.linalg.eigvalsh(np.dot(U.T, meanscov).dot(U))
+        return None
+
+    def getGelmanRubin(self, nparam=None, chainlist=None):
+        return np.max(self.getGelmanRubinEigenvalues(nparam, chainlist))
+
+    def getMeanVarTest(self, nparam=None):
+        """The MeanVar block of getConvergeTests (mcsamples.py:964-985): sqrt(var(chain mean)/mean(chain var))."""
+        nparam = nparam or self.n
+        stats = self.getSeparateChainStats(nparam)
+        between = np.zeros(nparam)
+        within = np.zeros(nparam)
+        for cmeans, ccov, cnorm in stats:
+            between += (cmeans - self.means[:nparam]) ** 2
+            within += np.diag(ccov) * cnorm
+        between /= len(stats) - 1
+        within /= self.norm
+        return np.sqrt(between / within)
+
+
+def covToCorr(cov, copy=True):
+    """chains.py:155-169"""
+    if copy:
+        cov = cov.copy()
+    for i, di in enumerate(np.sqrt(cov.diagonal())):
+        if di:
+            cov[i, :] /= di
+            cov[:, i] /= di
+    return cov

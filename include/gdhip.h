@@ -49,6 +49,7 @@ int gd_dev_alloc(gd_ctx* ctx, int64_t bytes, void** d_out);
 int gd_dev_free(gd_ctx* ctx, void* d_ptr);
 int gd_memcpy_h2d(gd_ctx* ctx, void* d_dst, const void* src, int64_t bytes);
 int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
+int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes);
 int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
 /* HIP-event timing on the ctx stream (bench.py measures kernels with these, not torch events) */
 int gd_timer_start(gd_ctx* ctx);
