@@ -1,0 +1,222 @@
+"""
+bench.py -- BASELINE.json's metric on BASELINE.json's config: 2D KDE densities/sec on the 50-parameter,
+10M-sample triangle (1225 pairs, base fine_bins_2D=256, default settings), config "C3" of SURVEY.md 8d.
+
+One "step" = the whole hot path over the resident synthetic sample set: per-parameter preparation (ranges,
+quantiles, limits, N_eff), weighted binning, bandwidth selection (device ISJ solver + host TNC), rocFFT
+convolution, boundary / multiplicative-bias correction, normalisation, and the D2H copy of every grid.
+All per-parameter / per-pair caches are cleared before every step; the sample columns are already in HBM
+(upload time reported separately in DESIGN.md, never in `value`).
+
+    python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: every rank holds a replica of the samples; parameter preparation is split over ranks and its scalars
+all-gathered (RCCL), pairs are partitioned by cost class with no data-path collective; total work is fixed
+("strong" scaling); `value` = 1225 * K / max-over-ranks time.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nsamples", type=int, default=10_000_000)
+    ap.add_argument("--nparams", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-n", type=int, default=None, help="rows for the CPU sample (default: nsamples)")
+    return ap.parse_args()
+
+
+def pair_cost_key_factory(mc):
+    names = mc.paramNames.names
+    corr = mc.getCorrelationMatrix()
+
+    def key(p):
+        c = abs(corr[p[1]][p[0]])
+        bounded = int(names[p[0]].has_limits) + int(names[p[1]].has_limits)
+        return (c > 0.866, bounded, c > 0.2)
+
+    return key
+
+
+def reset_caches(mc):
+    for par in mc.paramNames.names:
+        par.N_eff_kde = None
+        par._ranges_done = False
+    mc._initLimits()
+    mc._idx_cols = {}
+    mc.density1D = {}
+
+
+def one_step(mc, pairs_all, dist, rank, world, torch_device):
+    """The timed unit of work.  Returns the list of Density2D this rank produced."""
+    from getdist_amd import parallel
+
+    reset_caches(mc)
+    my_params = parallel.partition_round_robin(list(range(mc.n)), world, rank)
+    mc.prepareParams(my_params)
+    parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
+    _, my_pairs = parallel.partition_pairs(pairs_all, pair_cost_key_factory(mc), world, rank)
+    return mc.get2DDensities(my_pairs)
+
+
+def binning_kernel_roofline(mc, pairs_all, reps=5):
+    """
+    Time the dominant O(N) kernel of the step -- the batched weighted 2D binning of all F=256 pairs -- with HIP
+    events on the library's stream, and price it with SURVEY.md 8d's algorithmic bytes B2 = 24 N + 8 F^2 per
+    density (x, y, w read once as fp64 + the F x F fp64 grid written).
+    """
+    names = mc.paramNames.names
+    F = mc.fine_bins_2D
+    corr = mc.getCorrelationMatrix()
+    sel = [p for p in pairs_all if abs(corr[p[1]][p[0]]) <= 0.866]
+    ix, iy = [], []
+    for (a, b) in sel:
+        fwx, bx, _ = mc._bin_edges(names[a], F)
+        fwy, by, _ = mc._bin_edges(names[b], F)
+        ix.append(mc._index_column(a, F, bx, fwx))
+        iy.append(mc._index_column(b, F, by, fwy))
+    out = mc.ctx.alloc(len(sel) * F * F * 8)
+    mc.ctx.hist2d_prebinned(ix, iy, F, out=out)
+    mc.ctx.sync()
+    ms = []
+    for _ in range(reps):
+        mc.ctx.timer_start()
+        mc.ctx.hist2d_prebinned(ix, iy, F, out=out)
+        ms.append(mc.ctx.timer_stop_ms())
+    out.free()
+    t = float(np.median(ms)) * 1e-3
+    alg_bytes = len(sel) * (24.0 * mc.numrows + 8.0 * F * F)
+    achieved = alg_bytes / t / 1e9
+    return dict(bound="hbm", kernel="k_hist2d<prebinned>", launches_pairs=len(sel), ms_per_launch=t * 1e3,
+                achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                note="algorithmic bytes 24N+8F^2 per density (SURVEY 8d); the kernel reads pre-binned u16 indices, "
+                     "so achieved may exceed the HBM peak -- see DESIGN.md and profiles/")
+
+
+def cpu_baseline(nparams, nsamples, n_rows):
+    """
+    The oracle (numpy/scipy restatement of the reference, 'port') on a bounded sample of the same workload:
+    3 of the 50 parameters and 2 of the 1225 pairs at full N, timed on this host; whole-triangle throughput
+    extrapolated as 1225 / (50 t_prep + 1225 t_pair).
+    """
+    from getdist_amd import synth
+    from oracle import kde_oracle as ko
+
+    s, w, names, ranges = synth.config_c3(n_rows, nparams)
+    cols = [5, 6, 20] if nparams > 20 else [0, 1, 2]
+    sub = np.ascontiguousarray(s[:, cols])
+    sub_names = [names[c] for c in cols]
+    orc = ko.OracleSamples(sub, w, names=sub_names, ranges={k: v for k, v in ranges.items() if k in sub_names})
+    t0 = time.perf_counter()
+    for j in range(3):
+        orc.init_param(j)
+        orc.neff_1d(j)
+    t_prep = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    orc.density_2d(0, 1)
+    orc.density_2d(0, 2)
+    t_pair = (time.perf_counter() - t0) / 2
+    npairs = nparams * (nparams - 1) // 2
+    value = npairs / (nparams * t_prep + npairs * t_pair)
+    return dict(value=value, unit="densities/s", cores=1, kind="port",
+                sample="oracle on 3 of %d parameters (prep %.2f s each) + 2 of %d pairs (%.2f s each) at N=%d; "
+                       "triangle extrapolated as npairs/(nparams*t_prep + npairs*t_pair); host has %d logical cores, "
+                       "the reference path is single-process" % (nparams, t_prep, npairs, t_pair, n_rows, os.cpu_count()))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch_device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        torch_device = torch.device("cuda", local_rank)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    t0 = time.perf_counter()
+    s, w, names, ranges = synth.config_c3(args.nsamples, args.nparams)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=local_rank)
+    t_ctor = time.perf_counter() - t0
+    pairs_all = synth.triangle_pairs(args.nparams)
+
+    def barrier():
+        mc.ctx.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(mc, pairs_all, dist, rank, world, torch_device)
+    barrier()
+    mc.timings = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    npairs = len(pairs_all)
+    value = npairs * args.steps / elapsed
+
+    if rank == 0:
+        line = {
+            "metric": "2D KDE densities/sec (triangle, %d params, %s samples)" % (args.nparams, "{:.0e}".format(args.nsamples)),
+            "value": value, "unit": "densities/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded block recipe, SURVEY.md 8d C3)",
+            "config": {"workload": "C3: 2D KDE triangle, %d params (%d pairs), N=%d unit-weight samples, base fine_bins_2D=256, "
+                                   "default settings; includes per-parameter prep, bandwidth selection and D2H of all grids"
+                                   % (args.nparams, npairs, args.nsamples),
+                       "parallelism": "pairs partitioned over %d GPU(s), samples replicated" % world,
+                       "setup_s": {"generate": round(t_gen, 2), "construct_upload_basestats": round(t_ctor, 2)}},
+        }
+        if world == 1:
+            line["roofline"] = binning_kernel_roofline(mc, pairs_all)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args.nparams, args.nsamples, args.cpu_baseline_n or args.nsamples)
+        if mc._timing:
+            line["phase_seconds_total"] = {k: round(v, 4) for k, v in sorted(mc.timings.items())}
+        assert len(dens) > 0 and all(d is not None for d in dens)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,8 @@ them.  There is no CPU fallback: without the library or a GPU, construction rais
 """
 
 import logging
+import os
+import time
 import warnings
 
 import numpy as np
@@ -213,6 +215,53 @@ def _get_h(psi, N, corr_in, do_correlation):
     return h_x, h_y, corr
 
 
+_POOL = None
+
+
+class _Phase:
+    """Wall-clock phase accounting (enabled by GETDIST_AMD_TIMING=1; syncs the stream at phase edges)."""
+
+    def __init__(self, mc, name):
+        self.mc, self.name = mc, name
+
+    def __enter__(self):
+        if self.mc._timing:
+            self.mc.ctx.sync()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *a):
+        if self.mc._timing:
+            self.mc.ctx.sync()
+            self.mc.timings[self.name] = self.mc.timings.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
+def _get_h_job(job):
+    return _get_h(*job)
+
+
+def _get_h_many(jobs, workers=None):
+    """
+    Run many independent get_h solves.  TNC costs 3-8 ms per pair on ~9 scalars; a triangle has
+    hundreds of them, so they are farmed to a persistent host process pool (pure functions of their arguments).
+    """
+    global _POOL
+    import os
+
+    if workers is None:
+        workers = int(os.environ.get("GETDIST_AMD_TNC_WORKERS", min(32, os.cpu_count() or 1)))
+    n_tnc = sum(1 for j in jobs if j[3])
+    if workers <= 1 or n_tnc < 16:
+        return [_get_h(*j) for j in jobs]
+    if _POOL is None or _POOL[1] != workers:
+        import multiprocessing as mp
+
+        if _POOL is not None:
+            _POOL[0].terminate()
+        _POOL = (mp.get_context("forkserver").Pool(workers), workers)
+    chunk = max(1, len(jobs) // (workers * 4))
+    return _POOL[0].map(_get_h_job, jobs, chunksize=chunk)
+
+
 class MCSamples:
     """
     Weighted samples resident in HBM + the KDE hot path.  Constructor arguments follow
@@ -266,6 +315,8 @@ class MCSamples:
         if settings:
             self.updateSettings(settings, doUpdate=False)
         self.ctx = Context(device)
+        self._timing = os.environ.get("GETDIST_AMD_TIMING", "0") == "1"
+        self.timings = {}
         self.density1D = {}
         self._idx_cols = {}
         self.needs_update = True
@@ -581,6 +632,24 @@ class MCSamples:
             par.has_limits = par.has_limits_top or par.has_limits_bot
             par._ranges_done = True
 
+    def prepareParams(self, params=None, neff=True):
+        """
+        Additive API: compute the per-parameter state every density needs (ranges, limits, sigma_range and, if
+        ``neff``, the KDE effective sample number) for ``params`` (default all).  The reference recomputes this inside
+        every density call (mcsamples.py:1786-1787); it is a pure function of the column, so doing it once is
+        result-preserving.
+        """
+        if self.needs_update:
+            self.updateBaseStatistics()
+        js = list(range(self.n)) if params is None else [self._col(p) for p in params]
+        with _Phase(self, "prep.ranges"):
+            self._init_params(js)
+        if neff:
+            with _Phase(self, "prep.neff"):
+                for j in js:
+                    self._get1DNeff(self.paramNames.names[j], j)
+        return js
+
     @staticmethod
     def _bin_edges(par, num_fine_bins, borderfrac=0.1):
         """The scalar half of _binSamples (mcsamples.py:1486-1496); the index half runs fused in the kernels."""
@@ -796,6 +865,9 @@ class MCSamples:
         """
         results = [None] * len(plan)
         ctx = self.ctx
+        for e in plan:
+            e["kopt"] = None
+        jobs, job_meta = [], []
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
         if A:
@@ -824,19 +896,12 @@ class MCSamples:
             d_rot.free()
             for row, k in enumerate(A):
                 e = plan[k]
+                e["kopt"] = out[row].copy()
                 if out[row, 7] != 0:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
                     continue
-                hx, hy, c = _get_h(out[row, 1:7], e["neff"], 0, bool(do_corr[row]))
-                hx *= r1s[row]
-                hy *= r2s[row]
-                S = e["S"]
-                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
-                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
-                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
-                if e["pary"].has_limits:
-                    hx, hy = hy, hx
-                results[k] = (hx, hy, c)
+                jobs.append((tuple(out[row, 1:7]), e["neff"], 0, bool(do_corr[row])))
+                job_meta.append(("A", k, r1s[row], r2s[row]))
         # -- branch B: rule of thumb
         for k, e in enumerate(plan):
             if e["branch"] == "B":
@@ -859,10 +924,28 @@ class MCSamples:
                 d_sub.free()
             for row, (_, k) in enumerate(sel):
                 e = plan[k]
+                e["kopt"] = out[row].copy()
                 if out[row, 7] != 0:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
                     continue
-                hx, hy, c = _get_h(out[row, 1:7], e["neff"], e["corr"], bool(do_corr[row]))
+                jobs.append((tuple(out[row, 1:7]), e["neff"], e["corr"], bool(do_corr[row])))
+                job_meta.append(("C", k, None, None))
+        # -- host: closed-form h_x, h_y and the TNC refinements (process pool), then map back to parameter units
+        with _Phase(self, "2d.bandwidth.host_get_h"):
+            solved = _get_h_many(jobs)
+        for (branch, k, r1, r2), (hx, hy, c) in zip(job_meta, solved):
+            e = plan[k]
+            if branch == "A":
+                hx *= r1
+                hy *= r2
+                S = e["S"]
+                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
+                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
+                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
+                if e["pary"].has_limits:
+                    hx, hy = hy, hx
+                results[k] = (hx, hy, c)
+            else:
                 results[k] = (hx * e["rangex"], hy * e["rangey"], c)
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
         if m:
@@ -886,8 +969,13 @@ class MCSamples:
             self._idx_cols[key] = (buf, (binmin, width))
         return self._idx_cols[key][0]
 
-    def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, **kwargs):
-        """Batched 2D KDEs (additive API): a list of Density2D, one per (x, y) entry of ``pairs``."""
+    def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, **kwargs):
+        """
+        Batched 2D KDEs (additive API): a list of Density2D, one per (x, y) entry of ``pairs``.
+        Each result carries ``bandwidth`` = (hx, hy, corr) in parameter units, ``bandwidth_branch`` and
+        ``kopt`` (the device optimiser's {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status}).
+        ``_bandwidths`` (tests only) injects the (hx, hy, corr) triples instead of optimising.
+        """
         if self.needs_update:
             self.updateBaseStatistics()
         for k in kwargs:
@@ -937,15 +1025,24 @@ class MCSamples:
             classes.setdefault(e["F"], []).append(k)
         hists = {}
         for F, members in classes.items():
-            ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
-            iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
-            hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
+            with _Phase(self, "2d.prebin"):
+                ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
+                iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
+            with _Phase(self, "2d.hist"):
+                hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
         # ---- bandwidths
         rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
         if smooth_scale_2D < 0:
-            plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
-                                        [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info], base_F)
-            bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
+            if _bandwidths is not None:
+                bw = list(_bandwidths)
+            else:
+                plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
+                                            [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
+                                            base_F)
+                with _Phase(self, "2d.bandwidth"):
+                    bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
+                for k, e in enumerate(info):
+                    e["branch"], e["kopt"] = plan[k]["branch"], plan[k]["kopt"]
             for k, e in enumerate(info):
                 hx, hy, c = bw[k]
                 rx[k] = hx * abs(smooth_scale_2D) / e["fwx"]
@@ -975,7 +1072,7 @@ class MCSamples:
                                     e["pary"].name)
                 e["winw"] = max(1, int(round(2.5 * smooth_scale)))
                 groups.setdefault(bool(flags) and bco >= 0, []).append((pos, k))
-            max_batch = max(1, int(2.0e9 // (F * F * 8 * 30)))
+            max_batch = max(1, int(float(os.environ.get("GETDIST_AMD_BATCH_BYTES", 24e9)) // (F * F * 8 * 30)))
             for bounded, sel_all in groups.items():
                 for s0 in range(0, len(sel_all), max_batch):
                     sel = sel_all[s0:s0 + max_batch]
@@ -985,10 +1082,12 @@ class MCSamples:
                         d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
                         self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
                     ks = [k for _, k in sel]
-                    d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                [cc[k] for k in ks], [info[k]["winw"] for k in ks],
-                                                [info[k]["flags"] for k in ks], bco, mbc)
-                    P = d_P.to_host((len(sel), F, F))
+                    with _Phase(self, "2d.convolve"):
+                        d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                    [cc[k] for k in ks], [info[k]["winw"] for k in ks],
+                                                    [info[k]["flags"] for k in ks], bco, mbc)
+                    with _Phase(self, "2d.d2h"):
+                        P = d_P.to_host((len(sel), F, F))
                     d_P.free()
                     if own:
                         d_sub.free()
@@ -1001,6 +1100,8 @@ class MCSamples:
                                          view_ranges=[(e["parx"].range_min, e["parx"].range_max),
                                                       (e["pary"].range_min, e["pary"].range_max)])
                         dens.bandwidth = e.get("bandwidth")
+                        dens.bandwidth_branch = e.get("branch")
+                        dens.kopt = e.get("kopt")
                         if not get_density:
                             ncontours = len(self.contours)
                             if num_plot_contours:

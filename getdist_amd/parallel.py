@@ -1,0 +1,76 @@
+"""
+Multi-GPU decomposition of the batched 2D-density path: one process per GPU, every rank
+holds a full replica of the sample columns, the per-parameter preparation is split round-robin over ranks and
+its ~12 scalars per parameter are all-gathered (the only collective: RCCL when the backend is "nccl", gloo in
+the CPU tests), and the independent parameter pairs are partitioned by cost class with no data-path collective.
+"""
+
+import numpy as np
+
+PARAM_STATE = ("err", "mean", "param_min", "param_max", "range_min", "range_max", "sigma_range", "has_limits_bot",
+               "has_limits_top", "has_limits", "N_eff_kde")
+
+
+def partition_round_robin(items, world, rank):
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def partition_pairs(pairs, cost_key, world, rank):
+    """
+    Deal pairs to ranks so every rank gets the same mix of cost classes: sort by class, then round-robin.
+    ``cost_key(pair)`` returns a sortable class id (e.g. (F, bounded?, branch)).  Returns (indices, pairs).
+    """
+    order = sorted(range(len(pairs)), key=lambda i: (cost_key(pairs[i]), i))
+    mine = [order[i] for i in range(len(order)) if i % world == rank]
+    mine.sort()
+    return mine, [pairs[i] for i in mine]
+
+
+def pack_param_state(mc, js):
+    """Rows of PARAM_STATE values for the parameters ``js`` this rank prepared."""
+    out = np.zeros((len(js), 1 + len(PARAM_STATE)))
+    for r, j in enumerate(js):
+        par = mc.paramNames.names[j]
+        out[r, 0] = j
+        for c, a in enumerate(PARAM_STATE):
+            v = getattr(par, a, None)
+            out[r, 1 + c] = np.nan if v is None else float(v)
+    return out
+
+
+def unpack_param_state(mc, rows):
+    for row in rows:
+        par = mc.paramNames.names[int(row[0])]
+        for c, a in enumerate(PARAM_STATE):
+            v = row[1 + c]
+            if a.startswith("has_limits"):
+                setattr(par, a, bool(v))
+            elif a == "N_eff_kde":
+                par.N_eff_kde = None if np.isnan(v) else float(v)
+            else:
+                setattr(par, a, np.float64(v))
+        par._ranges_done = True
+
+
+def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
+    """
+    All-gather the prepared per-parameter scalars so every rank knows every parameter.
+    ``dist`` is torch.distributed (initialised) or None for single-process runs.
+    """
+    mine = pack_param_state(mc, my_js)
+    if dist is None or dist.get_world_size() == 1:
+        unpack_param_state(mc, mine)
+        return
+    import torch
+
+    world = dist.get_world_size()
+    per = (n_params + world - 1) // world
+    buf = np.full((per, mine.shape[1]), -1.0)
+    buf[:len(mine)] = mine
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    rows = np.concatenate([g.cpu().numpy() for g in gathered])
+    unpack_param_state(mc, rows[rows[:, 0] >= 0])

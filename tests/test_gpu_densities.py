@@ -69,6 +69,21 @@ def test_density_1d(zoo, name):
                 assert abs(got[10] - want[10]) <= 1e-6 * want[10], (nm, "kde_h", got[10], want[10])
 
 
+def uses_tnc(d, mc, a, b):
+    """Pairs whose bandwidth passes through scipy TNC (kde_bandwidth.py:276-299): optimiser branch, no limits."""
+    px, py = mc.paramNames.names[a], mc.paramNames.names[b]
+    return d.bandwidth_branch in ("A", "C") and not (px.has_limits or py.has_limits)
+
+
+# The reference is *chaotic* through TNC: a 1e-15 relative perturbation of the psi functionals (what any other
+# BLAS / numpy build produces) moves (hx, hy, c) by ~1e-3 and the final grid by 1-3e-4 of its maximum (measured with
+# the oracle; DESIGN.md "solver-path parity").  Those pairs are therefore checked in three deterministic pieces --
+# optimiser inputs, host get_h given identical inputs (tests/test_host_solvers.py), grid given identical bandwidths --
+# and end-to-end at the reference's own reproducibility level.
+TOL_GRID_TNC = 2e-3
+TOL_BW_TNC = 1e-1  # the AMISE is nearly flat in the correlation direction
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_density_2d(zoo, name):
     fx = zoo[name]
@@ -77,17 +92,37 @@ def test_density_2d(zoo, name):
     orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
     for kw in fx["kw2"]:
         dens = mc.get2DDensities(fx["pairs"], get_density=False, **kw)
+        oracle_bw = []
         for (a, b), d in zip(fx["pairs"], dens):
             key = "p2d/%s/%s/%s" % (fx["names"][a], fx["names"][b], gu.kwkey(kw))
             tr = {}
             o = orc.density_2d(a, b, trace=tr, **kw)
+            oracle_bw.append((tr.get("hx"), tr.get("hy"), tr.get("c")))
             assert d.P.shape == o["P"].shape, key
-            if key + "/hxhyc" in g.files:
-                assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < 1e-6, (key, d.bandwidth, g[key + "/hxhyc"])
-            assert np.max(np.abs(d.P - o["P"])) < TOL_GRID, (key, "vs oracle", np.max(np.abs(d.P - o["P"])))
-            gu.check_grid_2d(g, key, d.P, TOL_GRID)
-            assert gu.relerr(d.contours, g[key + "/contours"]) < 1e-5, key
+            auto = key + "/hxhyc" in g.files
+            tnc = auto and uses_tnc(d, mc, a, b)
+            if auto:
+                assert d.bandwidth_branch == tr["branch"], key
+                if d.kopt is not None and "t_star" in tr:  # the device optimiser vs the oracle's, before any TNC
+                    assert abs(d.kopt[0] - tr["t_star"]) <= 1e-7 * tr["t_star"], (key, d.kopt[0], tr["t_star"])
+                    want = [tr["p_02"], tr["p_20"], tr["p_11"]]
+                    assert np.allclose(d.kopt[1:4], want, rtol=1e-6, atol=0), (key, d.kopt, want)
+                    if "p_13" in tr:
+                        want = [tr["p_00"], tr["p_13"], tr["p_31"]]
+                        assert np.allclose(d.kopt[4:7], want, rtol=1e-6, atol=0), (key, d.kopt, want)
+                assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < (TOL_BW_TNC if tnc else 1e-6), \
+                    (key, d.bandwidth, g[key + "/hxhyc"])
+            tol = TOL_GRID_TNC if tnc else TOL_GRID
+            assert np.max(np.abs(d.P - o["P"])) < tol, (key, "vs oracle", np.max(np.abs(d.P - o["P"])))
+            gu.check_grid_2d(g, key, d.P, tol)
+            assert gu.relerr(d.contours, g[key + "/contours"]) < (10 * tol), key
             assert np.allclose([d.x[0], d.x[-1], d.y[0], d.y[-1]], g[key + "/xy"], rtol=1e-12, atol=0), key
+        if oracle_bw[0][0] is not None:
+            # same bandwidths in -> same grids out, for every pair, at the strict tolerance
+            dens = mc.get2DDensities(fx["pairs"], _bandwidths=oracle_bw, **kw)
+            for (a, b), d in zip(fx["pairs"], dens):
+                key = "p2d/%s/%s/%s" % (fx["names"][a], fx["names"][b], gu.kwkey(kw))
+                gu.check_grid_2d(g, key, d.P, TOL_GRID)
 
 
 def test_single_pair_api_and_cache(zoo):
