@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ x, c
             }
         }
     }
-    for (int l = 0; l < AL; ++l) {
+#pragma unroll
+    for (int l = 0; l < AL; ++l) {  // unrolled: acc[] must stay in registers
         const double r = block_sum(acc[l], red);
         if (threadIdx.x == 0) part[(int64_t)blockIdx.x * AL + l] = r;
     }

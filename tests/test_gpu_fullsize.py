@@ -1,0 +1,107 @@
+"""
+GPU tests at BASELINE.json's full row count (N = 1e7) through size-independent properties, plus the property tests
+the reference itself uses (getdist/tests/getdist_test.py:144-165 mirror symmetry, :227-238 pooled mean).
+"""
+
+import numpy as np
+import pytest
+
+from getdist_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = synth.block_recipe(10, N_FULL, weighted=False, stream=31)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    return mc, s
+
+
+def test_moments_and_quantile_rank_property(big):
+    mc, s = big
+    assert np.array_equal(mc._col_min, s.min(axis=0)) and np.array_equal(mc._col_max, s.max(axis=0))
+    assert np.allclose(mc.means, s.mean(axis=0), rtol=1e-11, atol=1e-13)
+    fr = np.array([0.001, 0.1, 0.5, 0.9, 0.999])
+    for j in (0, 4, 9):
+        q = mc.confidence(j, fr)
+        x = s[:, j]
+        for f, v in zip(fr, q):
+            target = mc.norm * f
+            assert np.sum(x <= v) >= target  # cumulative weight reaches the target at v ...
+            assert np.sum(x < v) < target    # ... and not before (chains.py:836 searchsorted-left semantics)
+            assert np.any(x == v)            # a sample value, not an interpolation
+
+
+def test_histogram_properties(big):
+    mc, s = big
+    mc.prepareParams(neff=False)
+    F = 256
+    names = mc.paramNames.names
+    pairs = [(0, 1), (5, 6), (4, 9), (8, 9)]
+    e = {j: mc._bin_edges(names[j], F) for j in {p for pr in pairs for p in pr}}
+    ctx = mc.ctx
+    idx = {j: mc._index_column(j, F, e[j][1], e[j][0]) for j in e}
+    Hp = ctx.hist2d_prebinned([idx[a] for a, b in pairs], [idx[b] for a, b in pairs], F).to_host((len(pairs), F, F))
+    Hd = ctx.hist2d([a for a, b in pairs], [b for a, b in pairs], [e[a][1] for a, b in pairs], [e[a][0] for a, b in pairs],
+                    [e[b][1] for a, b in pairs], [e[b][0] for a, b in pairs], F).to_host((len(pairs), F, F))
+    assert np.array_equal(Hp, Hd)  # pre-binned and fused-fp64 kernels agree bit for bit (integer counts)
+    h1 = ctx.hist1d(sorted(e), [e[j][1] for j in sorted(e)], [e[j][0] for j in sorted(e)], F)
+    for k, (a, b) in enumerate(pairs):
+        assert Hp[k].sum() == N_FULL                       # every sample lands in the grid
+        assert np.array_equal(Hp[k].sum(axis=0), h1[sorted(e).index(a)])  # marginal over y == 1D histogram of x
+        assert np.array_equal(Hp[k].sum(axis=1), h1[sorted(e).index(b)])
+    ixs = ((s[:, 0] - e[0][1]) / e[0][0] + 0.5).astype(int)  # one column against numpy at full size
+    assert np.array_equal(h1[sorted(e).index(0)], np.bincount(ixs, minlength=F))
+
+
+def test_full_size_densities_are_sane_and_deterministic(big):
+    mc, s = big
+    pairs = [(0, 1), (5, 6), (4, 9)]
+    d1 = mc.get2DDensities(pairs)
+    d2 = mc.get2DDensities(pairs)
+    for a, b in zip(d1, d2):
+        assert a.P.max() == 1.0 and a.P.min() > -1e-12
+        assert np.allclose(a.P, b.P, rtol=0, atol=2e-3)  # TNC pairs are chaotic; the rest are bit-stable
+        assert abs(a.norm_integral() - b.norm_integral()) < 1e-2 * a.norm_integral()
+    p = mc.get1DDensities([0, 4, 9])
+    for d in p:
+        assert d.P.max() == 1.0 and d.P.shape == (1024,)
+
+
+def test_mirror_symmetry_like_reference():
+    """getdist_test.py:144-165: mirrored samples give mirrored densities, with hard bounds on both axes."""
+    from getdist_amd.mcsamples import MCSamples
+
+    r = np.random.default_rng(10)
+    n = 1_000_000
+    x = np.abs(r.normal(0.4, 0.5, n))
+    x = x[x < 1.2][:700_000]
+    y = r.normal(0.0, 1.0, len(x))
+    y = np.where(np.abs(y) > 1.5, 1.5 * np.sign(y) - (y - 1.5 * np.sign(y)), y)
+    s = np.column_stack([x, y])
+    a = MCSamples(samples=s, names=["x", "y"], ranges={"x": (0, 1.2), "y": (-1.5, 1.5)})
+    b = MCSamples(samples=np.column_stack([1.2 - x, y]), names=["x", "y"], ranges={"x": (0, 1.2), "y": (-1.5, 1.5)})
+    c = MCSamples(samples=np.column_stack([x, -y]), names=["x", "y"], ranges={"x": (0, 1.2), "y": (-1.5, 1.5)})
+    pa, pb = a.get1DDensity("x").P, b.get1DDensity("x").P
+    assert np.allclose(pa, pb[::-1], atol=1e-5)
+    da, db, dc = a.get2DDensity("x", "y").P, b.get2DDensity("x", "y").P, c.get2DDensity("x", "y").P
+    assert np.allclose(da, db[:, ::-1], atol=1e-5)
+    assert np.allclose(da, dc[::-1, :], atol=1e-5)
+
+
+def test_pooled_mean_of_chain_list():
+    """getdist_test.py:227-238"""
+    from getdist_amd.mcsamples import MCSamples
+
+    r = np.random.default_rng(3)
+    chains = [r.normal(k, 1.0, (20_000 + 1000 * k, 3)) for k in range(3)]
+    ws = [r.integers(1, 4, len(c)).astype(float) for c in chains]
+    mc = MCSamples(samples=chains, weights=ws, names=["a", "b", "c"])
+    allx, allw = np.vstack(chains), np.hstack(ws)
+    assert np.allclose(mc.getMeans(), allw.dot(allx) / allw.sum(), rtol=1e-12)
+    assert list(mc.chain_offsets) == [0, 20000, 41000, 63000]

@@ -1,0 +1,123 @@
+"""
+CPU tests (gloo, world_size 2) of the multi-GPU decomposition in getdist_amd/parallel.py: the per-parameter
+state all-gather and the cost-class pair partition.  The compute itself needs a GPU and is covered by the
+-m gpu tests; here the per-parameter state is faked.
+"""
+
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from getdist_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_pairs_covers_everything_once():
+    pairs = [(i, j) for i in range(12) for j in range(i + 1, 12)]
+    key = lambda p: (p[0] % 3, p[1] % 2)  # noqa: E731
+    for world in (1, 2, 3, 8):
+        seen = []
+        sizes = []
+        for rank in range(world):
+            idx, mine = parallel.partition_pairs(pairs, key, world, rank)
+            assert [pairs[i] for i in idx] == mine
+            seen += idx
+            sizes.append(len(idx))
+        assert sorted(seen) == list(range(len(pairs)))
+        assert max(sizes) - min(sizes) <= 1
+        # every rank gets (nearly) the same number of pairs of each cost class
+        for cls in set(map(key, pairs)):
+            per_rank = [sum(1 for p in parallel.partition_pairs(pairs, key, world, r)[1] if key(p) == cls)
+                        for r in range(world)]
+            assert max(per_rank) - min(per_rank) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from getdist_amd import parallel
+
+    class Par:  # stand-in for ParamInfo
+        pass
+
+    class FakeMC:
+        def __init__(self, n):
+            class PN: pass
+            self.paramNames = PN()
+            self.paramNames.names = [Par() for _ in range(n)]
+            self.n = n
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 7
+    mc = FakeMC(n)
+    mine = parallel.partition_round_robin(list(range(n)), world, rank)
+    for j in mine:  # "prepare" my parameters
+        p = mc.paramNames.names[j]
+        for c, a in enumerate(parallel.PARAM_STATE):
+            setattr(p, a, (j %% 2 == 0) if a.startswith("has_limits") else 100.0 * j + c)
+        if j == 3:
+            p.N_eff_kde = None
+    parallel.allgather_param_state(mc, mine, n, dist)
+    for j in range(n):
+        p = mc.paramNames.names[j]
+        assert p._ranges_done
+        for c, a in enumerate(parallel.PARAM_STATE):
+            v = getattr(p, a)
+            if a.startswith("has_limits"):
+                assert v is (j %% 2 == 0), (j, a, v)
+            elif a == "N_eff_kde" and j == 3:
+                assert v is None
+            else:
+                assert v == 100.0 * j + c, (j, a, v)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_allgather_param_state_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+
+
+def test_pack_unpack_roundtrip():
+    class Par:
+        pass
+
+    class MC:
+        pass
+
+    mc = MC()
+    mc.paramNames = MC()
+    mc.paramNames.names = [Par() for _ in range(3)]
+    for j, p in enumerate(mc.paramNames.names):
+        for c, a in enumerate(parallel.PARAM_STATE):
+            setattr(p, a, bool(j % 2) if a.startswith("has_limits") else np.float64(j + 0.25 * c))
+    rows = parallel.pack_param_state(mc, [0, 2])
+    mc2 = MC()
+    mc2.paramNames = MC()
+    mc2.paramNames.names = [Par() for _ in range(3)]
+    parallel.unpack_param_state(mc2, rows)
+    for j in (0, 2):
+        for a in parallel.PARAM_STATE:
+            assert getattr(mc2.paramNames.names[j], a) == getattr(mc.paramNames.names[j], a)
