@@ -52,8 +52,15 @@ SIGNATURES = {
     "gd_dev_free": (C.c_int, [_p, _p]),
     "gd_memcpy_h2d": (C.c_int, [_p, _p, _p, _i64]),
     "gd_memcpy_d2h": (C.c_int, [_p, _p, _p, _i64]),
+    "gd_memcpy_d2h_async": (C.c_int, [_p, _p, _p, _i64]),
+    "gd_copy_sync": (C.c_int, [_p]),
     "gd_memcpy_d2d": (C.c_int, [_p, _p, _p, _i64]),
     "gd_memset": (C.c_int, [_p, _p, C.c_int, _i64]),
+    "gd_gather_items": (C.c_int, [_p, _p, _p, _pi32, _i32, _i64]),
+    "gd_host_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "gd_host_free": (C.c_int, [_p, _p]),
+    "gd_autocov_lags_batch": (C.c_int, [_p, _pi32, _i32, _pd, _i64, _i32, _pd]),
+    "gd_kde_lag_sums_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pi64, _i32, _pd]),
     "gd_timer_start": (C.c_int, [_p]),
     "gd_timer_stop_ms": (C.c_int, [_p, _pd]),
     "gd_upload": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
@@ -134,9 +141,15 @@ class DevBuf:
         except Exception:
             pass
 
-    def to_host(self, shape, dtype=np.float64, offset_bytes=0):
-        out = np.empty(shape, dtype=dtype)
+    def to_host(self, shape, dtype=np.float64, offset_bytes=0, pinned=False):
+        out = self.ctx.pinned_array(shape, dtype) if pinned else np.empty(shape, dtype=dtype)
         self.ctx._check(self.ctx.lib.gd_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset_bytes, out.nbytes))
+        return out
+
+    def to_host_async(self, shape, dtype=np.float64):
+        """Start a D2H copy into page-locked memory on the copy stream; call ctx.copy_sync() before reading."""
+        out = self.ctx.pinned_array(shape, dtype)
+        self.ctx._check(self.ctx.lib.gd_memcpy_d2h_async(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
     def from_host(self, arr, offset_bytes=0):
@@ -160,9 +173,39 @@ class Context:
         self.device = device
         self.N = self.n = 0
         self.weighted = False
+        self._pinned = []  # (ptr, nbytes, ctypes buffer): page-locked result buffers, recycled when unreferenced
+
+    PINNED_POOL_LIMIT = 8 << 30
+
+    def pinned_array(self, shape, dtype=np.float64):
+        """
+        A numpy array in page-locked host memory (D2H at full PCIe rate).  Blocks are recycled once no array
+        view references them any more (every view keeps the block's ctypes buffer alive, so its refcount tells).
+        """
+        import sys
+
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        best = None
+        for k, (ptr, nb, buf) in enumerate(self._pinned):
+            if nb >= nbytes and sys.getrefcount(buf) <= 3 and (best is None or nb < self._pinned[best][1]):
+                best = k
+        if best is None:
+            if sum(nb for _, nb, _ in self._pinned) + nbytes > self.PINNED_POOL_LIMIT:
+                return np.empty(shape, dtype=dtype)
+            p = _p()
+            self._check(self.lib.gd_host_alloc(self.h, max(nbytes, 1 << 20), C.byref(p)))
+            nb = max(nbytes, 1 << 20)
+            buf = (C.c_ubyte * nb).from_address(p.value)
+            self._pinned.append((p.value, nb, buf))
+            best = len(self._pinned) - 1
+        buf = self._pinned[best][2]
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
         if self.h:
+            for ptr, _, _ in getattr(self, "_pinned", []):
+                self.lib.gd_host_free(self.h, ptr)
+            self._pinned = []
             self.lib.gd_destroy(self.h)
             self.h = None
 
@@ -189,6 +232,27 @@ class Context:
 
     def sync(self):
         self._check(self.lib.gd_sync(self.h))
+
+    def gather_items(self, dst, src, index, item_bytes):
+        index = _i32arr(index)
+        self._check(self.lib.gd_gather_items(self.h, dst.ptr, src.ptr, _ip(index), len(index), int(item_bytes)))
+
+    def autocov_lags_batch(self, cols, means, k0, nlags):
+        cols, means = _i32arr(cols), _f64arr(means)
+        out = np.zeros((len(cols), nlags))
+        self._check(self.lib.gd_autocov_lags_batch(self.h, _ip(cols), len(cols), _dp(means), int(k0), int(nlags), _dp(out)))
+        return out
+
+    def kde_lag_sums_batch(self, cols, inv4s2, lags):
+        cols, inv4s2 = _i32arr(cols), _f64arr(inv4s2)
+        lags = np.ascontiguousarray(lags, dtype=np.int64)
+        out = np.zeros((len(cols), len(lags)))
+        self._check(self.lib.gd_kde_lag_sums_batch(self.h, _ip(cols), len(cols), _dp(inv4s2), lags.ctypes.data_as(_pi64),
+                                                   len(lags), _dp(out)))
+        return out
+
+    def copy_sync(self):
+        self._check(self.lib.gd_copy_sync(self.h))
 
     def copy_d2d(self, dst, dst_off, src, src_off, nbytes):
         self._check(self.lib.gd_memcpy_d2d(self.h, dst.ptr + dst_off, src.ptr + src_off, int(nbytes)))

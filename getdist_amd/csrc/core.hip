@@ -54,6 +54,8 @@ int gd_create(int device, gd_ctx** out) {
     gd_ctx* ctx = new gd_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        hipStreamCreate(&ctx->copy_stream) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return GD_ERR_HIP;
@@ -76,6 +78,9 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipEventDestroy(ctx->copy_ev);
+    (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -135,9 +140,40 @@ int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes) {
     return GD_OK;
 }
 
+int gd_memcpy_d2h_async(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes) {
+    GD_REQUIRE(ctx && dst && d_src && bytes >= 0, "bad argument");
+    // order after everything queued on the compute stream so far, then copy on the copy stream
+    GD_HIP(hipEventRecord(ctx->copy_ev, ctx->stream));
+    GD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev, 0));
+    GD_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    return GD_OK;
+}
+
+int gd_copy_sync(gd_ctx* ctx) {
+    GD_REQUIRE(ctx, "null context");
+    GD_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return GD_OK;
+}
+
 int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes) {
     GD_REQUIRE(ctx && d_dst && d_src && bytes >= 0, "bad argument");
     GD_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return GD_OK;
+}
+
+int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out) {
+    GD_REQUIRE(ctx && out && bytes > 0, "bad argument");
+    *out = nullptr;
+    GD_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return GD_OK;
+}
+
+int gd_host_free(gd_ctx* ctx, void* ptr) {
+    GD_REQUIRE(ctx, "null context");
+    if (ptr) {
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_HIP(hipHostFree(ptr));
+    }
     return GD_OK;
 }
 
@@ -182,7 +218,28 @@ __global__ void transpose_rows_to_cols(const double* __restrict__ X, int64_t N, 
     }
 }
 
+__global__ void k_gather_items(double2* __restrict__ dst, const double2* __restrict__ src, const int* __restrict__ index,
+                               int64_t item16) {
+    const double2* s = src + (int64_t)index[blockIdx.y] * item16;
+    double2* d = dst + (int64_t)blockIdx.y * item16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < item16; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
 extern "C" {
+
+int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes) {
+    GD_REQUIRE(ctx && d_dst && d_src && index && count > 0 && item_bytes > 0 && item_bytes % 16 == 0, "bad argument");
+    int* d_index = (int*)gd_scratch2(ctx, (int64_t)count * 4);
+    if (!d_index) return GD_ERR_NOMEM;
+    GD_HIP(hipMemcpyAsync(d_index, index, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    int bx = (int)((item_bytes / 16 + 255) / 256);
+    if (bx > 64) bx = 64;
+    k_gather_items<<<dim3(bx, count), 256, 0, ctx->stream>>>((double2*)d_dst, (const double2*)d_src, d_index, item_bytes / 16);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
 
 int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
               const double* weights) {

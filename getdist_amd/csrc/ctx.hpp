@@ -16,6 +16,8 @@ struct FftPlanCache;  // density2d.hip
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // D2H of finished grids overlaps the next batch's kernels
+    hipEvent_t copy_ev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 256;
     std::string err;

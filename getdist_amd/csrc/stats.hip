@@ -29,6 +29,45 @@ __device__ __forceinline__ void stream_xw(const double* __restrict__ x, const do
     }
 }
 
+// Same traversal with four 16-byte loads per array in flight before any element is consumed: for kernels whose
+// per-element work (LDS atomics, branches) keeps the compiler from overlapping loop iterations by itself.
+template <bool HAS_W, class F>
+__device__ __forceinline__ void stream_xw4(const double* __restrict__ x, const double* __restrict__ w, int64_t lo,
+                                           int64_t hi, F f) {
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t a = (lo + 1) & ~(int64_t)1, b = hi & ~(int64_t)1;
+    if (b <= a) {
+        if (gtid == 0)
+            for (int64_t i = lo; i < hi; ++i) f(x[i], HAS_W ? w[i] : 1.0);
+        return;
+    }
+    if (gtid == 0) {
+        if (lo < a) f(x[lo], HAS_W ? w[lo] : 1.0);
+        if (b < hi) f(x[b], HAS_W ? w[b] : 1.0);
+    }
+    int64_t i = a + 2 * gtid;
+    for (; i + 6 * gsz < b; i += 8 * gsz) {
+        double2 xv[4], wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const double2*>(x + i + 2 * q * gsz);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            wv[q] = HAS_W ? *reinterpret_cast<const double2*>(w + i + 2 * q * gsz) : make_double2(1.0, 1.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f(xv[q].x, wv[q].x);
+            f(xv[q].y, wv[q].y);
+        }
+    }
+    for (; i < b; i += 2 * gsz) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + i);
+        const double2 wv = HAS_W ? *reinterpret_cast<const double2*>(w + i) : make_double2(1.0, 1.0);
+        f(xv.x, wv.x);
+        f(xv.y, wv.y);
+    }
+}
+
 // ---- weight statistics --------------------------------------------------------------------------------
 __global__ void k_weight_stats(const double* __restrict__ w, int64_t lo, int64_t hi, double thresh,
                                double* __restrict__ part) {
@@ -214,7 +253,15 @@ struct QState {  // per column
     unsigned long long uprefix[QK_MAX];
     int nuniq;
     int k;
+    unsigned long long bloom;  // 64-bit Bloom mask over the unique prefixes (one hash)
 };
+
+__device__ __forceinline__ int prefix_hash6(unsigned long long top) {
+    unsigned int t = (unsigned int)(top ^ (top >> 32));
+    t ^= t >> 16;
+    t ^= t >> 8;
+    return (int)((t ^ (t >> 4)) & 63u);
+}
 
 __device__ __forceinline__ unsigned long long f64_key(double v) {
     unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -223,6 +270,30 @@ __device__ __forceinline__ unsigned long long f64_key(double v) {
 __device__ __forceinline__ double key_f64(unsigned long long k) {
     unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)u);
+}
+
+// All lanes of the wave that target the same bin contribute through one LDS atomic.  In pass 0 the digit is the
+// sign + top exponent bits, so whole waves hit 1-4 bins and plain atomics would serialise 64-deep on one address.
+template <bool HAS_W>
+__device__ __forceinline__ void wave_agg_add(double* h, int bin, double wt, bool valid) {
+    // must be called by all 64 lanes of the wave (lanes without data pass valid = false)
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lb = __builtin_amdgcn_readlane(bin, leader);
+        const unsigned long long same = __ballot(bin == lb) & todo;
+        double v;
+        if (HAS_W) {
+            v = ((same >> lane) & 1ull) ? wt : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+        } else {
+            v = (double)__popcll(same);  // unit weights: the group's weight is its population count
+        }
+        if (lane == leader) atomicAdd(&h[lb], v);
+        todo &= ~same;
+    }
 }
 
 template <bool HAS_W>
@@ -241,20 +312,39 @@ __global__ void k_qsel_pass(const double* __restrict__ cols, int64_t ld, const i
     for (int i = threadIdx.x; i < nuniq * 256; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const int shift = 56 - 8 * pass;
-    stream_xw<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
-        const unsigned long long key = f64_key(v);
-        const int bin = (int)((key >> shift) & 255ull);
-        if (pass == 0) {
-            atomicAdd(&h[bin], wt);
-        } else {
-            const unsigned long long top = key >> (shift + 8);
-            for (int u = 0; u < nuniq; ++u)
-                if (top == upre[u]) {
-                    atomicAdd(&h[u * 256 + bin], wt);
-                    break;
-                }
+    if (pass == 0) {
+        // uniform trip count per wave so that every lane takes part in the wave-level aggregation
+        const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i0 = lo + (int64_t)blockIdx.x * blockDim.x; i0 < hi; i0 += 4 * gsz) {
+            double v[4], wt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = i0 + q * gsz + threadIdx.x;
+                const bool ok = i < hi;
+                v[q] = ok ? x[i] : 0.0;
+                wt[q] = ok ? (HAS_W ? w[i] : 1.0) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wave_agg_add<HAS_W>(h, (int)(f64_key(v[q]) >> 56), wt[q], i0 + q * gsz + threadIdx.x < hi);
         }
-    });
+    } else {
+        const unsigned long long bloom = st[c].bloom;
+        unsigned long long pre[QK_MAX];  // uniform per block: the compiler keeps these in scalar registers
+#pragma unroll
+        for (int u = 0; u < QK_MAX; ++u) pre[u] = st[c].uprefix[u];
+        stream_xw4<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+            const unsigned long long key = f64_key(v);
+            const unsigned long long top = key >> (shift + 8);
+            if ((bloom >> prefix_hash6(top)) & 1ull) {
+                int slot = -1;
+#pragma unroll
+                for (int u = 0; u < QK_MAX; ++u)
+                    if (u < nuniq && top == pre[u]) slot = u;
+                if (slot >= 0) atomicAdd(&h[slot * 256 + (int)((key >> shift) & 255ull)], wt);
+            }
+        });
+    }
     __syncthreads();
     double* g = ghist + (int64_t)c * QK_MAX * 256;
     for (int i = threadIdx.x; i < nuniq * 256; i += blockDim.x) {
@@ -263,13 +353,13 @@ __global__ void k_qsel_pass(const double* __restrict__ cols, int64_t ld, const i
     }
 }
 
-// one thread per column: consume the histograms, extend each target's prefix by 8 bits, dedupe prefixes.
+// one block per column: consume the histograms, extend each target's prefix by 8 bits, dedupe prefixes.
 __global__ void k_qsel_scan(QState* __restrict__ st, double* __restrict__ ghist, int ncols, int pass) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+    const int c = blockIdx.x;
     QState& s = st[c];
     double* g = ghist + (int64_t)c * QK_MAX * 256;
-    for (int t = 0; t < s.k; ++t) {
+    const int t = threadIdx.x;
+    if (t < s.k) {
         const double* h = g + (pass == 0 ? 0 : s.slot[t]) * 256;
         double cum = s.cum_below[t];
         int pick = -1, last_nonempty = -1;
@@ -293,20 +383,26 @@ __global__ void k_qsel_scan(QState* __restrict__ st, double* __restrict__ ghist,
         s.prefix[t] = (s.prefix[t] << 8) | (unsigned long long)pick;
         s.cum_below[t] = cum;
     }
-    // unique prefixes for the next pass
-    int nu = 0;
-    for (int t = 0; t < s.k; ++t) {
-        int f = -1;
-        for (int u = 0; u < nu; ++u)
-            if (s.uprefix[u] == s.prefix[t]) f = u;
-        if (f < 0) {
-            f = nu;
-            s.uprefix[nu++] = s.prefix[t];
+    __syncthreads();
+    if (t == 0) {  // unique prefixes for the next pass
+        int nu = 0;
+        for (int q = 0; q < s.k; ++q) {
+            int f = -1;
+            for (int u = 0; u < nu; ++u)
+                if (s.uprefix[u] == s.prefix[q]) f = u;
+            if (f < 0) {
+                f = nu;
+                s.uprefix[nu++] = s.prefix[q];
+            }
+            s.slot[q] = f;
         }
-        s.slot[t] = f;
+        s.nuniq = nu;
+        unsigned long long bl = 0;
+        for (int u = 0; u < nu; ++u) bl |= 1ull << prefix_hash6(s.uprefix[u]);
+        s.bloom = bl;
     }
-    s.nuniq = nu;
-    for (int i = 0; i < QK_MAX * 256; ++i) g[i] = 0;
+    __syncthreads();
+    for (int i = t; i < QK_MAX * 256; i += blockDim.x) g[i] = 0;
 }
 
 __global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, double* __restrict__ out) {
@@ -319,10 +415,14 @@ __global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, doub
 #define AL 32     // lags per launch
 #define AT 2048   // rows per tile
 template <bool HAS_W>
-__global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ x, const double* __restrict__ w,
-                                                 int64_t N, double mean, int64_t k0, double* __restrict__ part) {
+__global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ cols, int64_t ld,
+                                                 const int32_t* __restrict__ colidx, const double* __restrict__ w,
+                                                 int64_t N, const double* __restrict__ means, int64_t k0,
+                                                 double* __restrict__ part) {
     __shared__ double sB[AT + AL];
     __shared__ double red[16];
+    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
+    const double mean = means[blockIdx.y];
     double acc[AL];
 #pragma unroll
     for (int l = 0; l < AL; ++l) acc[l] = 0;
@@ -342,11 +442,22 @@ __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ x, c
             }
         }
     }
+    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * AL;
 #pragma unroll
     for (int l = 0; l < AL; ++l) {  // unrolled: acc[] must stay in registers
         const double r = block_sum(acc[l], red);
-        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * AL + l] = r;
+        if (threadIdx.x == 0) p[l] = r;
     }
+}
+
+// out[c][l] = sum_b part[c][b][l];  grid (AL, ncols)
+__global__ void k_sum_partials_batched(const double* __restrict__ part, int nblk, int stride, double* __restrict__ out) {
+    __shared__ double red[16];
+    const double* p = part + (int64_t)blockIdx.y * nblk * stride;
+    double s = 0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += p[(int64_t)i * stride + blockIdx.x];
+    const double r = block_sum(s, red);
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.y * stride + blockIdx.x] = r;
 }
 
 __global__ void k_sum_partials(const double* __restrict__ part, int nblk, int stride, double* __restrict__ out) {
@@ -359,9 +470,12 @@ __global__ void k_sum_partials(const double* __restrict__ part, int nblk, int st
 
 // ---- Gaussian-kernel lag sums: out[l] = sum_i exp(-(x_i - x_{i+k})^2 * c) w_i w_{i+k} -----------------------
 template <bool HAS_W>
-__global__ void k_kde_lag(const double* __restrict__ x, const double* __restrict__ w, int64_t N, double c,
+__global__ void k_kde_lag(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                          const double* __restrict__ w, int64_t N, const double* __restrict__ cvals,
                           const int64_t* __restrict__ lags, double* __restrict__ part) {
     __shared__ double red[16];
+    const double* x = cols + (int64_t)colidx[blockIdx.z] * ld;
+    const double c = cvals[blockIdx.z];
     const int64_t k = lags[blockIdx.y];
     const int64_t M = N - k;
     double s = 0;
@@ -372,7 +486,7 @@ __global__ void k_kde_lag(const double* __restrict__ x, const double* __restrict
         s += e;
     }
     const double r = block_sum(s, red);
-    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+    if (threadIdx.x == 0) part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = r;
 }
 
 // =============================================================================================================
@@ -533,16 +647,20 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemsetAsync(d_h, 0, (size_t)ncols * QK_MAX * 256 * 8, ctx->stream));
-    const int nblk = 2 * ctx->cu_count;
+    // few blocks per column: every block flushes its private LDS histograms with global atomics on the same
+    // per-column bins, so the flush cost (and its contention) grows with the block count
+    int nblk = (8 * ctx->cu_count + ncols - 1) / ncols;
+    if (nblk < 8) nblk = 8;
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
     for (int pass = 0; pass < 8; ++pass) {
         dim3 grid(nblk, ncols);
         if (ctx->w)
-            k_qsel_pass<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, pass, d_st, d_h);
+            k_qsel_pass<true><<<grid, 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, pass, d_st, d_h);
         else
-            k_qsel_pass<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, pass, d_st,
+            k_qsel_pass<false><<<grid, 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, pass, d_st,
                                                                d_h);
         GD_KERNEL_CHECK();
-        k_qsel_scan<<<(ncols + 63) / 64, 64, 0, ctx->stream>>>(d_st, d_h, ncols, pass);
+        k_qsel_scan<<<ncols, 256, 0, ctx->stream>>>(d_st, d_h, ncols, pass);
         GD_KERNEL_CHECK();
     }
     k_qsel_out<<<(ncols * k + 255) / 256, 256, 0, ctx->stream>>>(d_st, ncols, k, d_out);
@@ -552,59 +670,98 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     return GD_OK;
 }
 
-int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out) {
-    GD_REQUIRE(ctx && out && nlags > 0, "bad argument");
-    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n && k0 >= 0, "bad column / lag");
-    const int nblk = 2 * ctx->cu_count;
-    double* part = (double*)gd_scratch(ctx, ((int64_t)nblk * AL + AL) * 8);
-    if (!part) return GD_ERR_NOMEM;
-    double* d_out = part + (int64_t)nblk * AL;
-    const double* x = ctx->cols + (int64_t)col * ctx->ld;
+int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t k0,
+                          int32_t nlags, double* out) {
+    GD_REQUIRE(ctx && cols && means && out && nlags > 0 && ncols > 0, "bad argument");
+    GD_REQUIRE(ctx->cols && k0 >= 0, "bad lag / no samples");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    int nblk = (4 * ctx->cu_count + ncols - 1) / ncols;
+    if (nblk < 16) nblk = 16;
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_part = take((int64_t)ncols * nblk * AL * 8), o_out = take((int64_t)ncols * AL * 8),
+                  o_idx = take((int64_t)ncols * 4), o_mean = take((int64_t)ncols * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    double* part = (double*)(base + o_part);
+    double* d_out = (double*)(base + o_out);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    double* d_mean = (double*)(base + o_mean);
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_mean, means, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> h((size_t)ncols * AL);
     for (int32_t done = 0; done < nlags; done += AL) {
+        const dim3 grid(nblk, ncols);
         if (ctx->w)
-            k_autocov<true><<<nblk, 256, 0, ctx->stream>>>(x, ctx->w, ctx->N, mean, k0 + done, part);
+            k_autocov<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
         else
-            k_autocov<false><<<nblk, 256, 0, ctx->stream>>>(x, nullptr, ctx->N, mean, k0 + done, part);
+            k_autocov<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
         GD_KERNEL_CHECK();
-        k_sum_partials<<<AL, 256, 0, ctx->stream>>>(part, nblk, AL, d_out);
+        k_sum_partials_batched<<<dim3(AL, ncols), 256, 0, ctx->stream>>>(part, nblk, AL, d_out);
         GD_KERNEL_CHECK();
-        const int take = (nlags - done < AL) ? nlags - done : AL;
-        GD_HIP(hipMemcpyAsync(out + done, d_out, (size_t)take * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         GD_HIP(hipStreamSynchronize(ctx->stream));
+        const int take_n = (nlags - done < AL) ? nlags - done : AL;
+        for (int c = 0; c < ncols; ++c)
+            for (int l = 0; l < take_n; ++l) out[(size_t)c * nlags + done + l] = h[(size_t)c * AL + l];
+    }
+    return GD_OK;
+}
+
+int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out) {
+    return gd_autocov_lags_batch(ctx, &col, 1, &mean, k0, nlags, out);
+}
+
+int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* inv4s2, const int64_t* lags,
+                          int32_t nlags, double* out) {
+    GD_REQUIRE(ctx && cols && inv4s2 && lags && out && nlags > 0 && nlags <= 64 && ncols > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
+    int nblk = (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
+    if (nblk < 8) nblk = 8;
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_part = take((int64_t)ncols * nlags * nblk * 8), o_lags = take((int64_t)nlags * 8),
+                  o_idx = take((int64_t)ncols * 4), o_c = take((int64_t)ncols * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    double* part = (double*)(base + o_part);
+    int64_t* d_lags = (int64_t*)(base + o_lags);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    double* d_c = (double*)(base + o_c);
+    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_c, inv4s2, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid(nblk, nlags, ncols);
+    if (ctx->w)
+        k_kde_lag<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c, d_lags, part);
+    else
+        k_kde_lag<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_c, d_lags, part);
+    GD_KERNEL_CHECK();
+    std::vector<double> h((size_t)ncols * nlags * nblk);
+    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q < (size_t)ncols * nlags; ++q) {
+        double sum = 0;
+        for (int b = 0; b < nblk; ++b) sum += h[q * nblk + b];
+        out[q] = sum;
     }
     return GD_OK;
 }
 
 int gd_kde_lag_sums(gd_ctx* ctx, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out) {
-    GD_REQUIRE(ctx && lags && out && nlags > 0 && nlags <= 64, "bad argument");
-    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
-    for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
-    const int nblk = 2 * ctx->cu_count;
-    int64_t off_l = ((int64_t)nlags * nblk * 8 + 255) / 256 * 256;
-    char* base = (char*)gd_scratch(ctx, off_l + nlags * 8 + 256 + nlags * 8);
-    if (!base) return GD_ERR_NOMEM;
-    double* part = (double*)base;
-    int64_t* d_lags = (int64_t*)(base + off_l);
-    double* d_out = (double*)(base + off_l + ((int64_t)nlags * 8 + 255) / 256 * 256);
-    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
-    const double* x = ctx->cols + (int64_t)col * ctx->ld;
-    dim3 grid(nblk, nlags);
-    if (ctx->w)
-        k_kde_lag<true><<<grid, 256, 0, ctx->stream>>>(x, ctx->w, ctx->N, inv4s2, d_lags, part);
-    else
-        k_kde_lag<false><<<grid, 256, 0, ctx->stream>>>(x, nullptr, ctx->N, inv4s2, d_lags, part);
-    GD_KERNEL_CHECK();
-    // partials are laid out [lag][block]: reduce each row
-    std::vector<double> h((size_t)nlags * nblk);
-    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
-    (void)d_out;
-    for (int l = 0; l < nlags; ++l) {
-        double s = 0;
-        for (int b = 0; b < nblk; ++b) s += h[(size_t)l * nblk + b];
-        out[l] = s;
-    }
-    return GD_OK;
+    return gd_kde_lag_sums_batch(ctx, &col, 1, &inv4s2, lags, nlags, out);
 }
 
 }  // extern "C"

@@ -239,19 +239,35 @@ def _get_h_job(job):
     return _get_h(*job)
 
 
+def _tnc_workers():
+    env = os.environ.get("GETDIST_AMD_TNC_WORKERS")
+    if env:
+        return int(env)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return max(1, min(64, (os.cpu_count() or 1) // max(1, local_world)))
+
+
+class _Solved:
+    def __init__(self, values):
+        self.values = values
+
+    def get(self):
+        return self.values
+
+
 def _get_h_many(jobs, workers=None):
     """
-    Run many independent get_h solves.  TNC costs 3-8 ms per pair on ~9 scalars; a triangle has
-    hundreds of them, so they are farmed to a persistent host process pool (pure functions of their arguments).
+    Start many independent get_h solves; returns an object whose .get() yields the results in order.  TNC costs
+    0.5-8 ms per pair on ~9 scalars and a triangle has hundreds of them, so the jobs that need it
+    are farmed to a persistent host process pool (pure functions of their arguments) and run while the GPU works
+    on the pairs that do not.
     """
     global _POOL
-    import os
-
     if workers is None:
-        workers = int(os.environ.get("GETDIST_AMD_TNC_WORKERS", min(32, os.cpu_count() or 1)))
+        workers = _tnc_workers()
     n_tnc = sum(1 for j in jobs if j[3])
     if workers <= 1 or n_tnc < 16:
-        return [_get_h(*j) for j in jobs]
+        return _Solved([_get_h(*j) for j in jobs])
     if _POOL is None or _POOL[1] != workers:
         import multiprocessing as mp
 
@@ -259,7 +275,7 @@ def _get_h_many(jobs, workers=None):
             _POOL[0].terminate()
         _POOL = (mp.get_context("forkserver").Pool(workers), workers)
     chunk = max(1, len(jobs) // (workers * 4))
-    return _POOL[0].map(_get_h_job, jobs, chunksize=chunk)
+    return _POOL[0].map_async(_get_h_job, jobs, chunksize=chunk)
 
 
 class MCSamples:
@@ -534,16 +550,23 @@ class MCSamples:
         kernel_std = (scale or self.sddev[j]) * h
         if maxoff is None:
             maxoff = int(self.getCorrelationLength(j, weight_units=False) * 1.5) + 4
+        return self._neff_from_lags(j, kernel_std, maxoff, min_corr, None)
+
+    def _neff_lag_list(self):
+        uncorr_len = self.numrows // 2
+        return list(range(uncorr_len, uncorr_len + 5)) + [k for k in (1, 2) if k <= self.numrows // 10]
+
+    def _neff_from_lags(self, j, kernel_std, maxoff, min_corr, seed_sums):
+        """The scalar part of chains.py:509-574 given (optionally pre-computed) Gaussian-kernel lag sums."""
         maxoff = min(maxoff, self.numrows // 10)
         uncorr_len = self.numrows // 2
         inv4s2 = 1.0 / (4 * kernel_std**2)
-        first = [k for k in (1, 2) if k <= maxoff]
-        lags = list(range(uncorr_len, uncorr_len + 5)) + first
-        sums = self.ctx.kde_lag_sums(j, inv4s2, lags)
+        lags = self._neff_lag_list()
+        sums = self.ctx.kde_lag_sums(j, inv4s2, lags) if seed_sums is None else seed_sums
         nav = sum(self.numrows - k for k in range(uncorr_len, uncorr_len + 5))
         uncorr_term = float(np.sum(sums[:5])) / nav
         n = float(self.numrows)
-        cache = {k: sums[5 + i] for i, k in enumerate(first)}
+        cache = {k: sums[5 + i] for i, k in enumerate(lags[5:])}
 
         def corr_k(k):
             if k not in cache:
@@ -574,6 +597,35 @@ class MCSamples:
             else:
                 N = corr0 + 2 * c1
         return self.norm**2 / N
+
+    def _neff_batch(self, js, min_corr=0.05):
+        """_get1DNeff for many parameters with two batched launches (32 autocovariance lags, 7 kernel lag sums)."""
+        todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
+        if not todo:
+            return
+        if self.sampler in ("nested", "uncorrelated"):
+            for j in todo:
+                self.paramNames.names[j].N_eff_kde = self.norm**2 / self._sum_w2
+            return
+        max_off = self.numrows // 10
+        nl = min(32, max_off + 1)
+        lag0 = self.ctx.autocov_lags_batch(todo, self.means[todo], 0, nl)
+        kstd, maxoffs = [], []
+        for row, j in enumerate(todo):
+            par = self.paramNames.names[j]
+            c = lag0[row] / (self.numrows - np.arange(nl)) / self.vars[j]
+            below = np.nonzero(~(c > min_corr * c[0]))[0]
+            if below.size:
+                corrlen = c[0] + 2 * float(np.sum(c[1:int(below[0])]))
+            elif nl == max_off + 1:
+                corrlen = c[0]
+            else:
+                corrlen = self.getCorrelationLength(j, weight_units=False, min_corr=min_corr)
+            kstd.append((par.sigma_range or self.sddev[j]) * 0.2)
+            maxoffs.append(int(corrlen * 1.5) + 4)
+        sums = self.ctx.kde_lag_sums_batch(todo, [1.0 / (4 * k**2) for k in kstd], self._neff_lag_list())
+        for row, j in enumerate(todo):
+            self.paramNames.names[j].N_eff_kde = self._neff_from_lags(j, kstd[row], maxoffs[row], min_corr, sums[row])
 
     def _get1DNeff(self, par, param):
         """mcsamples.py:1230-1235"""
@@ -646,8 +698,7 @@ class MCSamples:
             self._init_params(js)
         if neff:
             with _Phase(self, "prep.neff"):
-                for j in js:
-                    self._get1DNeff(self.paramNames.names[j], j)
+                self._neff_batch(js)
         return js
 
     @staticmethod
@@ -734,6 +785,7 @@ class MCSamples:
         smooth, winw, flags = [], [], []
         dct = None
         if smooth_scale_1D <= 0:
+            self._neff_batch(js)
             dct = self.ctx.dct1d(hist)
         for b, (j, par) in enumerate(zip(js, pars)):
             fine_width, binmin, binmax = edges[b]
@@ -802,12 +854,14 @@ class MCSamples:
         d = self.ctx.alloc(bins.nbytes)
         d.from_host(bins)
         plan = self._bandwidth_plan([(paramx, paramy)], [corr], [(rangex, rangey)], base_fine_bins_2D, N_eff=N_eff)
-        res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)
+        res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)()
         return res[0]
 
     def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None):
         """Branch selection per pair (mcsamples.py:1325-1409), scalars only."""
         plan = []
+        if N_eff is None:
+            self._neff_batch(list(dict.fromkeys([j for p in pairs for j in p])))
         for (jx, jy), corr, (rangex, rangey) in zip(pairs, corrs, ranges_xy):
             parx, pary = self.paramNames.names[jx], self.paramNames.names[jy]
             if N_eff is None:
@@ -930,10 +984,12 @@ class MCSamples:
                     continue
                 jobs.append((tuple(out[row, 1:7]), e["neff"], e["corr"], bool(do_corr[row])))
                 job_meta.append(("C", k, None, None))
-        # -- host: closed-form h_x, h_y and the TNC refinements (process pool), then map back to parameter units
-        with _Phase(self, "2d.bandwidth.host_get_h"):
-            solved = _get_h_many(jobs)
-        for (branch, k, r1, r2), (hx, hy, c) in zip(job_meta, solved):
+        # -- host: closed-form h_x, h_y now; the TNC refinements in the process pool, asynchronously
+        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
+
+        def to_param_units(meta, solved):
+            branch, k, r1, r2 = meta
+            hx, hy, c = solved
             e = plan[k]
             if branch == "A":
                 hx *= r1
@@ -944,21 +1000,39 @@ class MCSamples:
                              kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
                 if e["pary"].has_limits:
                     hx, hy = hy, hx
-                results[k] = (hx, hy, c)
-            else:
-                results[k] = (hx * e["rangex"], hy * e["rangey"], c)
-        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
-        if m:
-            for k, e in enumerate(plan):
-                scale = 1.1 * e["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
+                return hx, hy, c
+            return hx * e["rangex"], hy * e["rangey"], c
+
+        def rescale(k):
+            if m:
+                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
                 hx, hy, c = results[k]
                 results[k] = (hx * scale, hy * scale, c)
-        return results
+
+        pooled = [(job, meta) for job, meta in zip(jobs, job_meta) if job[3]]
+        for job, meta in zip(jobs, job_meta):
+            if not job[3]:
+                results[meta[1]] = to_param_units(meta, _get_h(*job))
+        early = [k for k in range(len(plan)) if results[k] is not None]
+        for k in early:
+            rescale(k)
+        pending = _get_h_many([job for job, _ in pooled])
+
+        def finish():
+            """Collect the pooled host solves; returns the complete list of (hx, hy, corr)."""
+            with _Phase(self, "2d.bandwidth.host_get_h_wait"):
+                solved = pending.get()
+            for (_, meta), sol in zip(pooled, solved):
+                results[meta[1]] = to_param_units(meta, sol)
+                rescale(meta[1])
+            return results
+
+        finish.early = {k: results[k] for k in early}
+        return finish
 
     def _gather_device(self, d_src, d_dst, positions, item_bytes):
-        """Copy selected fixed-size items of one device buffer into another (device-to-device)."""
-        for row, pos in enumerate(positions):
-            self.ctx.copy_d2d(d_dst, row * item_bytes, d_src, pos * item_bytes, item_bytes)
+        """Copy selected fixed-size items of one device buffer into another (one gather kernel)."""
+        self.ctx.gather_items(d_dst, d_src, positions, item_bytes)
 
     def _index_column(self, j, F, binmin, width):
         key = (j, F)
@@ -1030,25 +1104,36 @@ class MCSamples:
                 iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
             with _Phase(self, "2d.hist"):
                 hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
-        # ---- bandwidths
+        # ---- bandwidths: device optimiser now, host TNC solves asynchronously in the process pool
         rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
+        finish_bw = None
+        ready = [True] * len(info)
+
+        def set_widths(k, bw_k):
+            e = info[k]
+            hx, hy, c = bw_k
+            rx[k] = hx * abs(smooth_scale_2D) / e["fwx"]
+            ry[k] = hy * abs(smooth_scale_2D) / e["fwy"]
+            cc[k] = c
+            e["bandwidth"] = bw_k
+
         if smooth_scale_2D < 0:
             if _bandwidths is not None:
-                bw = list(_bandwidths)
+                for k, b in enumerate(_bandwidths):
+                    set_widths(k, b)
             else:
                 plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
                                             [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
                                             base_F)
-                with _Phase(self, "2d.bandwidth"):
-                    bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
+                with _Phase(self, "2d.bandwidth.device"):
+                    finish_bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
                 for k, e in enumerate(info):
                     e["branch"], e["kopt"] = plan[k]["branch"], plan[k]["kopt"]
-            for k, e in enumerate(info):
-                hx, hy, c = bw[k]
-                rx[k] = hx * abs(smooth_scale_2D) / e["fwx"]
-                ry[k] = hy * abs(smooth_scale_2D) / e["fwy"]
-                cc[k] = c
-                e["bandwidth"] = bw[k]
+                    ready[k] = k in finish_bw.early  # the rest waits for the TNC pool
+                    if ready[k]:
+                        set_widths(k, finish_bw.early[k])
+                if all(ready):
+                    finish_bw = None
         else:
             for k, e in enumerate(info):
                 if smooth_scale_2D < 1.0:
@@ -1057,11 +1142,26 @@ class MCSamples:
                 else:
                     rx[k] = ry[k] = smooth_scale_2D * e["F"] / e["nbin2D"]
                 cc[k] = e["corr"]
-        # ---- convolution + corrections, batched per (F, bounded?) class
+
+        # ---- convolution + corrections, batched per (F, bounded?, FFT frame size) class
         out = [None] * len(info)
-        for F, (d_hist, members) in hists.items():
+        axes = {}
+        max_bytes = float(os.environ.get("GETDIST_AMD_BATCH_BYTES", 24e9))
+        inflight = []  # (device grid buffer, pinned host array, pair indices, status)
+
+        def axis(par, lo, hi, F):
+            key = (par.name, F)
+            if key not in axes:
+                axes[key] = np.linspace(lo, hi, F)
+            return axes[key]
+
+        def run_class(F, d_hist, members, stage):
+            """Convolve the pairs of one grid-size class that belong to ``stage`` (0: bandwidth known now,
+            1: bandwidth arrives from the host TNC pool)."""
             groups = {}
             for pos, k in enumerate(members):
+                if (0 if ready[k] else 1) != stage:
+                    continue
                 e = info[k]
                 flags = ((1 if e["parx"].has_limits_bot else 0) | (2 if e["parx"].has_limits_top else 0)
                          | (4 if e["pary"].has_limits_bot else 0) | (8 if e["pary"].has_limits_top else 0))
@@ -1072,44 +1172,70 @@ class MCSamples:
                                     e["pary"].name)
                 e["winw"] = max(1, int(round(2.5 * smooth_scale)))
                 groups.setdefault(bool(flags) and bco >= 0, []).append((pos, k))
-            max_batch = max(1, int(float(os.environ.get("GETDIST_AMD_BATCH_BYTES", 24e9)) // (F * F * 8 * 30)))
+            max_batch = max(1, int(max_bytes // (F * F * 8 * 30)))
+            batches = []
             for bounded, sel_all in groups.items():
-                for s0 in range(0, len(sel_all), max_batch):
-                    sel = sel_all[s0:s0 + max_batch]
-                    if len(sel) == len(members):
-                        d_sub, own = d_hist, False
-                    else:
-                        d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
-                        self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
-                    ks = [k for _, k in sel]
-                    with _Phase(self, "2d.convolve"):
-                        d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                    [cc[k] for k in ks], [info[k]["winw"] for k in ks],
-                                                    [info[k]["flags"] for k in ks], bco, mbc)
-                    with _Phase(self, "2d.d2h"):
-                        P = d_P.to_host((len(sel), F, F))
-                    d_P.free()
-                    if own:
-                        d_sub.free()
-                    for row, k in enumerate(ks):
-                        if status[row] != 0:
-                            raise DensitiesError("no samples in bin")
-                        e = info[k]
-                        dens = Density2D(np.linspace(e["xbinmin"], e["xbinmax"], F),
-                                         np.linspace(e["ybinmin"], e["ybinmax"], F), P[row],
-                                         view_ranges=[(e["parx"].range_min, e["parx"].range_max),
-                                                      (e["pary"].range_min, e["pary"].range_max)])
-                        dens.bandwidth = e.get("bandwidth")
-                        dens.bandwidth_branch = e.get("branch")
-                        dens.kopt = e.get("kopt")
-                        if not get_density:
-                            ncontours = len(self.contours)
-                            if num_plot_contours:
-                                ncontours = min(num_plot_contours, ncontours)
-                            dens.contours = dens.getContourLevels(self.contours[:ncontours])
-                        dens.likes = None
-                        out[k] = dens
+                by_S = {}  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
+                for item in sel_all:
+                    by_S.setdefault(next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
+                carry = []
+                sizes = sorted(by_S)
+                for q, S in enumerate(sizes):
+                    cur = carry + by_S[S]
+                    if len(cur) < 24 and q + 1 < len(sizes):
+                        carry = cur
+                        continue
+                    carry = []
+                    for s0 in range(0, len(cur), max_batch):
+                        batches.append(cur[s0:s0 + max_batch])
+            for sel in batches:
+                if [pos for pos, _ in sel] == list(range(len(members))):
+                    d_sub, own = d_hist, False
+                else:
+                    d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
+                    self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
+                ks = [k for _, k in sel]
+                with _Phase(self, "2d.convolve"):
+                    d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                [cc[k] for k in ks], [info[k]["winw"] for k in ks],
+                                                [info[k]["flags"] for k in ks], bco, mbc)
+                if own:
+                    d_sub.free()
+                # the copy runs on the copy stream while the next batch computes
+                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status))
+
+        for F, (d_hist, members) in hists.items():
+            run_class(F, d_hist, members, 0)
+        if finish_bw is not None:
+            for k, b in enumerate(finish_bw()):
+                if not ready[k]:
+                    set_widths(k, b)
+            for F, (d_hist, members) in hists.items():
+                run_class(F, d_hist, members, 1)
+        with _Phase(self, "2d.d2h_wait"):
+            ctx.copy_sync()
+        for F, (d_hist, members) in hists.items():
             d_hist.free()
+        for d_P, P, ks, status in inflight:
+            d_P.free()
+            F = P.shape[1]
+            for row, k in enumerate(ks):
+                if status[row] != 0:
+                    raise DensitiesError("no samples in bin")
+                e = info[k]
+                dens = Density2D(axis(e["parx"], e["xbinmin"], e["xbinmax"], F), axis(e["pary"], e["ybinmin"], e["ybinmax"], F),
+                                 P[row], view_ranges=[(e["parx"].range_min, e["parx"].range_max),
+                                                      (e["pary"].range_min, e["pary"].range_max)])
+                dens.bandwidth = e.get("bandwidth")
+                dens.bandwidth_branch = e.get("branch")
+                dens.kopt = e.get("kopt")
+                if not get_density:
+                    ncontours = len(self.contours)
+                    if num_plot_contours:
+                        ncontours = min(num_plot_contours, ncontours)
+                    dens.contours = dens.getContourLevels(self.contours[:ncontours])
+                dens.likes = None
+                out[k] = dens
         return out
 
     # ---- convergence (chains.py:1446-1527; mcsamples.py:964-1003) ------------------------------------------
@@ -1157,6 +1283,24 @@ class MCSamples:
         between /= len(stats) - 1
         within /= self.norm
         return np.sqrt(between / within)
+
+
+def next_fft_size(n):
+    """Smallest even 2^a 3^b 5^c >= n (the frame sizes density2d.hip plans its FFTs for)."""
+    best = None
+    p2 = 2
+    while p2 < 4 * n + 8:
+        p3 = 1
+        while p2 * p3 < 4 * n + 8:
+            p5 = 1
+            while p2 * p3 * p5 < 4 * n + 8:
+                v = p2 * p3 * p5
+                if v >= n and (best is None or v < best):
+                    best = v
+                p5 *= 5
+            p3 *= 3
+        p2 *= 2
+    return best
 
 
 def covToCorr(cov, copy=True):

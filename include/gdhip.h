@@ -49,8 +49,17 @@ int gd_dev_alloc(gd_ctx* ctx, int64_t bytes, void** d_out);
 int gd_dev_free(gd_ctx* ctx, void* d_ptr);
 int gd_memcpy_h2d(gd_ctx* ctx, void* d_dst, const void* src, int64_t bytes);
 int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
+/* D2H on a second stream, ordered after the work queued so far on the compute stream; dst should be page-locked
+ * (gd_host_alloc).  gd_copy_sync waits for all such copies. */
+int gd_memcpy_d2h_async(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
+int gd_copy_sync(gd_ctx* ctx);
 int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes);
 int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
+/* d_dst[k] = d_src[index[k]] for `count` items of item_bytes each (item_bytes % 8 == 0), one kernel launch */
+int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes);
+/* page-locked host memory for fast, asynchronous D2H of result grids */
+int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out);
+int gd_host_free(gd_ctx* ctx, void* ptr);
 /* HIP-event timing on the ctx stream (bench.py measures kernels with these, not torch events) */
 int gd_timer_start(gd_ctx* ctx);
 int gd_timer_stop_ms(gd_ctx* ctx, double* ms_out);
@@ -94,6 +103,11 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo
  *   (corr_k and the uncorrelated-term loop of getEffectiveSamplesGaussianKDE, chains.py:514-540). */
 int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out);
 int gd_kde_lag_sums(gd_ctx* ctx, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out);
+/* batched over columns in one launch: out is ncols x nlags (per-column mean / inv4s2, shared lag list) */
+int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t k0,
+                          int32_t nlags, double* out);
+int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* inv4s2, const int64_t* lags,
+                          int32_t nlags, double* out);
 
 /* ---------------------------------------------------------------- binning ----------------------
  * Index rule (mcsamples.py:1497): ix = (int)((x - binmin)/fine_width + 0.5), IEEE fp64, no FMA
