@@ -1071,8 +1071,15 @@ class MCSamples:
         if any(names[j].periodic for j in used):
             raise NotImplementedError("periodic parameters are not yet supported by the 2D device pipeline")
         corrmat = self.getCorrelationMatrix()
-        # ---- per-pair scalars (mcsamples.py:1794-1822)
+        # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         info = []
+        edge_cache = {}
+
+        def edges(jj, FF):
+            if (jj, FF) not in edge_cache:
+                edge_cache[(jj, FF)] = self._bin_edges(names[jj], FF)
+            return edge_cache[(jj, FF)]
+
         for (j, j2) in pairs:
             parx, pary = names[j], names[j2]
             corr = corrmat[j2][j]
@@ -1089,8 +1096,8 @@ class MCSamples:
                 scaled = 192 * int(3 / angle_scale) // 3
                 if base_F < scaled and int(1 / angle_scale) > 1:
                     F = scaled
-            fwx, xbinmin, xbinmax = self._bin_edges(parx, F)
-            fwy, ybinmin, ybinmax = self._bin_edges(pary, F)
+            fwx, xbinmin, xbinmax = edges(j, F)
+            fwy, ybinmin, ybinmax = edges(j2, F)
             info.append(dict(j=j, j2=j2, parx=parx, pary=pary, corr=corr, actual_corr=actual_corr, F=F, nbin2D=nbin2D,
                              fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin, ybinmax=ybinmax))
         # ---- histograms, one batched launch per grid-size class (pre-binned u16 index columns)
@@ -1251,22 +1258,10 @@ class MCSamples:
         """chains.py:1446-1474: var(mean)/mean(var) in the orthogonalised parameters"""
         if chainlist is not None:
             raise NotImplementedError("explicit chain lists are outside the accelerated path")
+        from .parallel import gelman_rubin_from_chain_stats
+
         nparam = nparam or self.paramNames.numNonDerived()
-        stats = self.getSeparateChainStats(nparam)
-        meanscov = np.zeros((nparam, nparam))
-        means = self.getMeans()[:nparam]
-        meancov = np.zeros(meanscov.shape)
-        for cmeans, ccov, _ in stats:
-            diff = cmeans - means
-            meanscov += np.outer(diff, diff)
-            meancov += ccov
-        meanscov /= len(stats) - 1
-        meancov /= len(stats)
-        w, U = np.linalg.eigh(meancov)
-        if np.min(w) > 0:
-            U /= np.sqrt(w)
-            return np.linalg.eigvalsh(np.dot(U.T, meanscov).dot(U))
-        return None
+        return gelman_rubin_from_chain_stats(self.getSeparateChainStats(nparam), self.getMeans())
 
     def getGelmanRubin(self, nparam=None, chainlist=None):
         return np.max(self.getGelmanRubinEigenvalues(nparam, chainlist))

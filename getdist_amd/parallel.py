@@ -74,3 +74,53 @@ def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
     dist.all_gather(gathered, t)
     rows = np.concatenate([g.cpu().numpy() for g in gathered])
     unpack_param_state(mc, rows[rows[:, 0] >= 0])
+
+
+# ---- convergence config: one chain per GPU ---------------------------------------------------
+def gelman_rubin_from_chain_stats(stats, total_means):
+    """
+    Brooks-Gelman var(mean)/mean(var) eigenvalues in the orthogonalised parameters (chains.py:1446-1474) from
+    per-chain (means, cov, norm) triples and the pooled weighted means.  Returns None when the mean covariance is
+    not positive definite, as the reference does.
+    """
+    nparam = len(stats[0][0])
+    means = np.asarray(total_means)[:nparam]
+    meanscov = np.zeros((nparam, nparam))
+    meancov = np.zeros((nparam, nparam))
+    for cmeans, ccov, _ in stats:
+        diff = np.asarray(cmeans) - means
+        meanscov += np.outer(diff, diff)
+        meancov += ccov
+    meanscov /= len(stats) - 1
+    meancov /= len(stats)
+    w, U = np.linalg.eigh(meancov)
+    if np.min(w) > 0:
+        U /= np.sqrt(w)
+        return np.linalg.eigvalsh(np.dot(U.T, meanscov).dot(U))
+    return None
+
+
+def allgather_chain_stats(local_means, local_cov, local_norm, dist=None, device=None):
+    """
+    Every rank holds ONE chain and has computed its weighted means / covariance / norm on its GPU (gd_cov);
+    exchange the n^2+n+1 doubles per rank (RCCL all-gather over xGMI; latency-bound, one fused buffer) and return
+    the list of per-chain (means, cov, norm) plus the pooled means  sum_c norm_c mean_c / sum_c norm_c.
+    """
+    n = len(local_means)
+    buf = np.concatenate([np.asarray(local_means, dtype=np.float64), np.asarray(local_cov, dtype=np.float64).ravel(),
+                          [float(local_norm)]])
+    if dist is None or dist.get_world_size() == 1:
+        rows = [buf]
+    else:
+        import torch
+
+        t = torch.from_numpy(buf)
+        if device is not None:
+            t = t.to(device)
+        gathered = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, t)
+        rows = [g.cpu().numpy() for g in gathered]
+    stats = [(r[:n], r[n:n + n * n].reshape(n, n), r[-1]) for r in rows]
+    tot = sum(st[2] for st in stats)
+    pooled = sum(st[2] * st[0] for st in stats) / tot
+    return stats, pooled

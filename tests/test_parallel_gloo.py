@@ -121,3 +121,25 @@ def test_pack_unpack_roundtrip():
     for j in (0, 2):
         for a in parallel.PARAM_STATE:
             assert getattr(mc2.paramNames.names[j], a) == getattr(mc.paramNames.names[j], a)
+
+
+def test_gelman_rubin_from_chain_stats_matches_golden():
+    """Host half of the C4 path: numpy per-chain moments -> eigenvalues, against the reference's golden values."""
+    import golden_util as gu
+    from getdist_amd import synth
+
+    g = np.load(gu.GOLDEN_DIR + "/convergence.npz")
+    samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
+    stats = []
+    for a, b in zip(offsets[:-1], offsets[1:]):
+        x, w = samples[a:b], weights[a:b]
+        m = w.dot(x) / w.sum()
+        d = x - m
+        stats.append((m, (d * w[:, None]).T @ d / w.sum(), w.sum()))
+    st2, pooled = parallel.allgather_chain_stats(*stats[0])  # single-process path returns the local chain only
+    assert len(st2) == 1 and np.allclose(pooled, stats[0][0])
+    tot = sum(s_[2] for s_ in stats)
+    pooled = sum(s_[2] * s_[0] for s_ in stats) / tot
+    assert np.allclose(pooled, g["means"], rtol=1e-12)
+    D = parallel.gelman_rubin_from_chain_stats(stats, pooled)
+    assert gu.relerr(D, g["gr_eigenvalues"]) < 1e-9
