@@ -1,0 +1,37 @@
+"""
+Worker process of the host TNC pool: `python -m getdist_amd._tnc_worker`.
+
+Reads length-prefixed pickled job lists from stdin, writes length-prefixed pickled result lists to stdout.  It is
+started with subprocess (NOT multiprocessing), so a user script without an `if __name__ == "__main__"` guard is
+never re-imported in the workers, and no HIP state is inherited.
+"""
+
+import pickle
+import struct
+import sys
+
+
+def main():
+    from getdist_amd.mcsamples import _get_h  # numpy/scipy only; creates no GPU context
+
+    inp, out = sys.stdin.buffer, sys.stdout.buffer
+    while True:
+        head = inp.read(8)
+        if len(head) < 8:
+            return
+        (n,) = struct.unpack("<q", head)
+        jobs = pickle.loads(inp.read(n))
+        res = []
+        for job in jobs:
+            try:
+                res.append(_get_h(*job))
+            except Exception as e:  # e.g. "bias not positive definite": re-raised in the parent
+                res.append(e)
+        blob = pickle.dumps(res, protocol=pickle.HIGHEST_PROTOCOL)
+        out.write(struct.pack("<q", len(blob)))
+        out.write(blob)
+        out.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -255,27 +255,97 @@ class _Solved:
         return self.values
 
 
+class _TncPool:
+    """
+    Persistent pool of `python -m getdist_amd._tnc_worker` subprocesses (pipes + pickle).  subprocess instead of
+    multiprocessing on purpose: spawn/forkserver re-import the user's __main__ in every worker (a script without
+    a __main__ guard would re-run itself N times), and fork would duplicate a process holding a HIP context.
+    """
+
+    def __init__(self, workers):
+        import atexit
+        import subprocess
+        import sys
+
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[k] = "1"
+        self.workers = workers
+        self.procs = [subprocess.Popen([sys.executable, "-m", "getdist_amd._tnc_worker"], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, env=env) for _ in range(workers)]
+        atexit.register(self.close)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=2)
+            except Exception:
+                p.kill()
+        self.procs = []
+
+    def submit(self, jobs):
+        import pickle
+        import struct
+
+        n = len(jobs)
+        shares = [list(range(w, n, self.workers)) for w in range(self.workers)]  # interleaved: even cost mix
+        active = []
+        for p, idx in zip(self.procs, shares):
+            if not idx:
+                continue
+            blob = pickle.dumps([jobs[i] for i in idx], protocol=pickle.HIGHEST_PROTOCOL)
+            p.stdin.write(struct.pack("<q", len(blob)))
+            p.stdin.write(blob)
+            p.stdin.flush()
+            active.append((p, idx))
+        return _PoolResult(active, n)
+
+
+class _PoolResult:
+    def __init__(self, active, n):
+        self.active, self.n = active, n
+
+    def get(self):
+        import pickle
+        import struct
+
+        out = [None] * self.n
+        for p, idx in self.active:
+            head = p.stdout.read(8)
+            if len(head) < 8:
+                raise RuntimeError("TNC worker died")
+            (m,) = struct.unpack("<q", head)
+            for i, r in zip(idx, pickle.loads(p.stdout.read(m))):
+                if isinstance(r, Exception):
+                    raise r
+                out[i] = r
+        return out
+
+
 def _get_h_many(jobs, workers=None):
     """
     Start many independent get_h solves; returns an object whose .get() yields the results in order.  TNC costs
-    0.5-8 ms per pair on ~9 scalars and a triangle has hundreds of them, so the jobs that need it
-    are farmed to a persistent host process pool (pure functions of their arguments) and run while the GPU works
-    on the pairs that do not.
+    0.5-8 ms per pair on ~9 scalars and a triangle has hundreds of them, so they are farmed to a
+    persistent pool of host worker processes (pure functions of their arguments) and run while the GPU works on
+    the pairs that do not need them.
     """
     global _POOL
     if workers is None:
         workers = _tnc_workers()
-    n_tnc = sum(1 for j in jobs if j[3])
-    if workers <= 1 or n_tnc < 16:
+    if workers <= 1 or len(jobs) < 16:
         return _Solved([_get_h(*j) for j in jobs])
-    if _POOL is None or _POOL[1] != workers:
-        import multiprocessing as mp
-
+    if _POOL is None or _POOL.workers != workers:
         if _POOL is not None:
-            _POOL[0].terminate()
-        _POOL = (mp.get_context("forkserver").Pool(workers), workers)
-    chunk = max(1, len(jobs) // (workers * 4))
-    return _POOL[0].map_async(_get_h_job, jobs, chunksize=chunk)
+            _POOL.close()
+        _POOL = _TncPool(workers)
+    return _POOL.submit(jobs)
 
 
 class MCSamples:
