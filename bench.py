@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--nsamples", type=int, default=10_000_000)
     ap.add_argument("--nparams", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="cProfile the timed steps (host side) to stderr")
     ap.add_argument("--cpu-baseline-n", type=int, default=None, help="rows for the CPU sample (default: nsamples)")
     return ap.parse_args()
 
@@ -176,15 +177,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    dens = None
     for _ in range(args.warmup):
-        one_step(mc, pairs_all, dist, rank, world, torch_device)
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device)  # held like the timed results are
+    if args.warmup > 0:
+        mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
     barrier()
     mc.timings = {}
+    prof = None
+    if args.profile:
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device)
     barrier()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(30)
     if dist is not None:
         import torch
 

@@ -121,18 +121,19 @@ def _i32arr(a):
 
 
 class DevBuf:
-    """A device allocation owned by a Context."""
+    """
+    A device allocation owned by a Context.  free() returns the block to the context's free list (hipFree
+    synchronises the device and costs ~0.25 ms; a triangle makes ~100 short-lived buffers per step).
+    """
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         self.nbytes = int(nbytes)
-        p = _p()
-        ctx._check(ctx.lib.gd_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
-        self.ptr = p.value
+        self.ptr, self.capacity = ctx._take_block(self.nbytes)
 
     def free(self):
         if self.ptr and self.ctx.h:
-            self.ctx.lib.gd_dev_free(self.ctx.h, self.ptr)
+            self.ctx._give_block(self.ptr, self.capacity)
         self.ptr = None
 
     def __del__(self):
@@ -174,6 +175,7 @@ class Context:
         self.N = self.n = 0
         self.weighted = False
         self._pinned = []  # (ptr, nbytes, ctypes buffer): page-locked result buffers, recycled when unreferenced
+        self._free_blocks = []  # (device ptr, capacity) returned by DevBuf.free(), reused by alloc()
 
     PINNED_POOL_LIMIT = 8 << 30
 
@@ -201,8 +203,17 @@ class Context:
         buf = self._pinned[best][2]
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def reserve_pinned_twin(self):
+        """Allocate a second block for every pooled page-locked block (callers that keep one result set alive while
+        computing the next need two sets; doing it up front keeps hipHostMalloc out of the steady state)."""
+        for ptr, nb, buf in list(self._pinned):
+            p = _p()
+            self._check(self.lib.gd_host_alloc(self.h, nb, C.byref(p)))
+            self._pinned.append((p.value, nb, (C.c_ubyte * nb).from_address(p.value)))
+
     def close(self):
         if self.h:
+            self.release_cached_blocks()
             for ptr, _, _ in getattr(self, "_pinned", []):
                 self.lib.gd_host_free(self.h, ptr)
             self._pinned = []
@@ -229,6 +240,34 @@ class Context:
 
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
+
+    DEVICE_CACHE_LIMIT = 16 << 30
+
+    def _take_block(self, nbytes):
+        best = None
+        for k, (ptr, cap) in enumerate(self._free_blocks):
+            if cap >= nbytes and cap <= 2 * nbytes + (1 << 20) and (best is None or cap < self._free_blocks[best][1]):
+                best = k
+        if best is not None:
+            return self._free_blocks.pop(best)
+        p = _p()
+        rc = self.lib.gd_dev_alloc(self.h, int(nbytes), C.byref(p))
+        if rc == GD_ERR_NOMEM and self._free_blocks:  # give cached blocks back and retry once
+            self.release_cached_blocks()
+            rc = self.lib.gd_dev_alloc(self.h, int(nbytes), C.byref(p))
+        self._check(rc)
+        return p.value, int(nbytes)
+
+    def _give_block(self, ptr, cap):
+        if sum(c for _, c in self._free_blocks) + cap > self.DEVICE_CACHE_LIMIT:
+            self.lib.gd_dev_free(self.h, ptr)
+        else:
+            self._free_blocks.append((ptr, cap))
+
+    def release_cached_blocks(self):
+        for ptr, _ in self._free_blocks:
+            self.lib.gd_dev_free(self.h, ptr)
+        self._free_blocks = []
 
     def sync(self):
         self._check(self.lib.gd_sync(self.h))

@@ -1350,8 +1350,18 @@ class MCSamples:
         return np.sqrt(between / within)
 
 
+_FFT_SIZE_CACHE = {}
+
+
 def next_fft_size(n):
     """Smallest even 2^a 3^b 5^c >= n (the frame sizes density2d.hip plans its FFTs for)."""
+    if n in _FFT_SIZE_CACHE:
+        return _FFT_SIZE_CACHE[n]
+    _FFT_SIZE_CACHE[n] = v = _next_fft_size(n)
+    return v
+
+
+def _next_fft_size(n):
     best = None
     p2 = 2
     while p2 < 4 * n + 8:
