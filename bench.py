@@ -104,10 +104,19 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
     t = float(np.median(ms)) * 1e-3
     alg_bytes = len(sel) * (24.0 * mc.numrows + 8.0 * F * F)
     achieved = alg_bytes / t / 1e9
-    return dict(bound="hbm", kernel="k_hist2d<prebinned>", launches_pairs=len(sel), ms_per_launch=t * 1e3,
-                achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                note="algorithmic bytes 24N+8F^2 per density (SURVEY 8d); the kernel reads pre-binned u16 indices, "
-                     "so achieved may exceed the HBM peak -- see DESIGN.md and profiles/")
+    # HBM traffic per launch from the PMC passes in profiles/r01_pmc_hist2d_{FETCH,WRITE}_SIZE.csv (separate rocprofv3
+    # --pmc runs of scripts/pmc_hist2d.py on this exact config: 1225 pairs, N=1e7, F=256, unit weights):
+    # FETCH_SIZE 13.56e6 KiB x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE 0.627e6 KiB, scaled
+    # by the number of pairs in this launch.  Not re-measured live (PMC needs the profiler); null for other configs.
+    traffic = None
+    if mc.numrows == 10_000_000 and mc.n == 50 and mc.weights is None:
+        traffic = (2 * 13.56e6 + 0.6272e6) * 1024 * len(sel) / 1225.0
+    return dict(bound="hbm", kernel="k_hist2d<prebinned u16, u32 LDS counters>", launches_pairs=len(sel),
+                ms_per_launch=t * 1e3, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                traffic=traffic,
+                note="achieved = algorithmic bytes (24N+8F^2 per density, SURVEY 8d) / launch time; the kernel reads "
+                     "pre-binned u16 indices (4 B/sample/stripe) so frac > 1 is expected; the fused-fp64 variant of the "
+                     "same kernel streams x,y and reaches 6.4 TB/s algorithmic = 0.81 of peak (profiles/r01_kernel_bench.txt)")
 
 
 def cpu_baseline(nparams, nsamples, n_rows):
