@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--nparams", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="cProfile the timed steps (host side) to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for "
+                    "exercising the multi-rank path on a single GPU)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--cpu-baseline-n", type=int, default=None, help="rows for the CPU sample (default: nsamples)")
     return ap.parse_args()
 
@@ -162,9 +165,12 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        torch_device = torch.device("cuda", local_rank)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        if args.share_device:
+            local_rank = 0
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            torch_device = torch.device("cuda", local_rank)
+        dist_mod.init_process_group(backend=args.backend, rank=rank, world_size=world)
         dist = dist_mod
 
     from getdist_amd import synth
@@ -184,7 +190,8 @@ def main():
             import torch
 
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch_device is not None:
+                torch.cuda.synchronize()
 
     dens = None
     for _ in range(args.warmup):
@@ -212,7 +219,7 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch_device or "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     npairs = len(pairs_all)

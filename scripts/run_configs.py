@@ -1,0 +1,73 @@
+"""
+Timings of the other BASELINE.json configs on one MI355X (not bench lines; recorded in DESIGN.md):
+  C2: 1D KDE, 30 params, 1e7 weighted samples, mixed hard bounds
+  C4: convergence, 8 chains x 5e6 x 100 params, weighted covariance + Gelman-Rubin (all chains on one GPU)
+Usage: python scripts/run_configs.py [c2] [c4]
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run_c2():
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = synth.config_c2()
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    t_ctor = time.perf_counter() - t0
+    mc.get1DDensities()
+    times = []
+    for _ in range(3):
+        for p in mc.paramNames.names:
+            p.N_eff_kde = None
+            p._ranges_done = False
+        mc._initLimits()
+        mc.ctx.sync()
+        t0 = time.perf_counter()
+        d = mc.get1DDensities()
+        mc.ctx.sync()
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return dict(config="C2", n=mc.n, N=mc.numrows, construct_s=round(t_ctor, 3), all_1d_densities_ms=round(t * 1e3, 2),
+                densities_per_s=round(mc.n / t, 1), bounded=[p.name for p in mc.paramNames.names if p.has_limits],
+                max_P=[float(x.P.max()) for x in d][:3])
+
+
+def run_c4():
+    import numpy as np
+
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, offsets = synth.config_c4()
+    chains = [s[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    ws = [w[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=chains, weights=ws, names=names)
+    t_ctor = time.perf_counter() - t0
+    mc.getGelmanRubinEigenvalues()
+    times = []
+    for _ in range(3):
+        mc.ctx.sync()
+        t0 = time.perf_counter()
+        D = mc.getGelmanRubinEigenvalues()
+        mv = mc.getMeanVarTest()
+        mc.ctx.sync()
+        times.append(time.perf_counter() - t0)
+    return dict(config="C4", chains=len(chains), N_per_chain=len(ws[0]), n=mc.n, construct_s=round(t_ctor, 3),
+                gr_plus_meanvar_ms=round(min(times) * 1e3, 2), GR=float(np.max(D)), meanvar_max=float(np.max(mv)))
+
+
+def main():
+    which = sys.argv[1:] or ["c2", "c4"]
+    for c in which:
+        print(json.dumps(run_c2() if c == "c2" else run_c4()), flush=True)
+
+
+if __name__ == "__main__":
+    main()

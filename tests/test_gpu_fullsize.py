@@ -105,3 +105,40 @@ def test_pooled_mean_of_chain_list():
     allx, allw = np.vstack(chains), np.hstack(ws)
     assert np.allclose(mc.getMeans(), allw.dot(allx) / allw.sum(), rtol=1e-12)
     assert list(mc.chain_offsets) == [0, 20000, 41000, 63000]
+
+
+def test_weighted_full_size_properties():
+    """N = 1e7 with real-valued weights: fp64 LDS atomics, 4 stripes; mass / marginal / variant-agreement properties."""
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = synth.block_recipe(5, N_FULL, weighted=True, stream=32)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    assert abs(mc.norm - np.sum(w)) <= 1e-12 * mc.norm
+    assert np.allclose(mc.means, w.dot(s) / np.sum(w), rtol=1e-11, atol=1e-13)
+    mc.prepareParams(neff=False)
+    F = 256
+    par = mc.paramNames.names
+    e = [mc._bin_edges(p, F) for p in par]
+    ctx = mc.ctx
+    pairs = [(0, 1), (3, 4)]
+    idx = [mc._index_column(j, F, e[j][1], e[j][0]) for j in range(5)]
+    Hp = ctx.hist2d_prebinned([idx[a] for a, b in pairs], [idx[b] for a, b in pairs], F).to_host((2, F, F))
+    Hd = ctx.hist2d([a for a, b in pairs], [b for a, b in pairs], [e[a][1] for a, b in pairs], [e[a][0] for a, b in pairs],
+                    [e[b][1] for a, b in pairs], [e[b][0] for a, b in pairs], F).to_host((2, F, F))
+    h1 = ctx.hist1d(list(range(5)), [x[1] for x in e], [x[0] for x in e], F)
+    for k, (a, b) in enumerate(pairs):
+        assert abs(Hp[k].sum() - mc.norm) <= 1e-11 * mc.norm
+        assert np.allclose(Hp[k], Hd[k], rtol=1e-11, atol=1e-9)
+        assert np.allclose(Hp[k].sum(axis=0), h1[a], rtol=1e-11, atol=1e-8)
+        assert np.allclose(Hp[k].sum(axis=1), h1[b], rtol=1e-11, atol=1e-8)
+    ixs = ((s[:, 0] - e[0][1]) / e[0][0] + 0.5).astype(int)
+    assert np.allclose(h1[0], np.bincount(ixs, weights=w, minlength=F), rtol=1e-11, atol=1e-8)
+    q = mc.confidence(2, np.array([0.05, 0.5, 0.95]))
+    for f, v in zip([0.05, 0.5, 0.95], q):
+        below = np.sum(w[s[:, 2] < v])
+        upto = np.sum(w[s[:, 2] <= v])
+        assert below < mc.norm * f * (1 + 1e-9) and upto >= mc.norm * f * (1 - 1e-9)
+    d = mc.get1DDensities([0, 4])
+    assert all(x.P.max() == 1.0 for x in d)
+    d2 = mc.get2DDensities(pairs)
+    assert all(x.P.max() == 1.0 and x.P.shape == (F, F) for x in d2)
