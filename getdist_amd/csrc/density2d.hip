@@ -11,7 +11,7 @@
 struct D2Pair {
     double c00, c11, c10;  // inverse bandwidth matrix (mcsamples.py:1864)
     int w;                 // winw
-    int flags;             // bit0/1 x bot/top, bit2/3 y bot/top
+    int flags;             // bit0/1 x bot/top, bit2/3 y bot/top, bit4/5 x/y periodic, bit6 boundary correction applies
 };
 
 __device__ __forceinline__ double win_raw(const D2Pair& p, int i1, int i2) {
@@ -87,7 +87,8 @@ __global__ void k_fill_mask(const D2Pair* __restrict__ pairs, int F, int S, int 
                yt = use_edges && (p.flags & 8);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
         const int r = e / S, c = e % S;
-        fr[e] = mask_1d(c, F, p.w, xb, xt, kind == 1) * mask_1d(r, F, p.w, yb, yt, kind == 1);
+        fr[e] = mask_1d(c, F, p.w, xb, xt, kind == 1 && !(p.flags & 16)) *
+                mask_1d(r, F, p.w, yb, yt, kind == 1 && !(p.flags & 32));
     }
 }
 
@@ -126,7 +127,7 @@ struct BcArrays {
 // linear boundary correction (mcsamples.py:1921-1961), in place on P; only pairs with a limit
 __global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF, int bco) {
     const int b = blockIdx.y;
-    if ((pairs[b].flags & 15) == 0) return;
+    if ((pairs[b].flags & 64) == 0) return;
     const double thresh = mx[b] * 1e-8;
     const int64_t o = (int64_t)b * FF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
@@ -181,6 +182,71 @@ __global__ void k_normalise(double* __restrict__ P, const double* __restrict__ m
         p[i] = (m == 0.0) ? 0.0 : p[i] / m;
 }
 
+
+// ---- periodic axes (convolve.py:215-323): circular convolution on the folded (Ny x Nx) grid ------------------
+// fold an F x F array onto the circular grid: drop the last column/row of a periodic axis and add it to the first
+__global__ void k_fill_circ(const double* __restrict__ src, int F, int Ny, int Nx, double* __restrict__ frames) {
+    const double* s = src + (int64_t)blockIdx.y * F * F;
+    double* fr = frames + (int64_t)blockIdx.y * Ny * Nx;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < Ny * Nx; e += gridDim.x * blockDim.x) {
+        const int r = e / Nx, c = e % Nx;
+        double v = s[(int64_t)r * F + c];
+        const bool wrap_c = (Nx < F) && c == 0, wrap_r = (Ny < F) && r == 0;
+        if (wrap_c) v += s[(int64_t)r * F + (F - 1)];
+        if (wrap_r) v += s[(int64_t)(F - 1) * F + c];
+        if (wrap_c && wrap_r) v += s[(int64_t)(F - 1) * F + (F - 1)];
+        fr[e] = v;
+    }
+}
+
+// window * x^px * y^py centred with wrap on the Ny x Nx circular grid (np.roll of the zero-padded kernel)
+__global__ void k_fill_window_rect(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, int Ny, int Nx,
+                                   int px, int py, double* __restrict__ frames) {
+    const D2Pair p = pairs[blockIdx.y];
+    double* fr = frames + (int64_t)blockIdx.y * Ny * Nx;
+    const double ws = wsum[blockIdx.y];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < Ny * Nx; e += gridDim.x * blockDim.x) {
+        const int r = e / Nx, c = e % Nx;
+        // hpad[:k,:k] = win then roll by -(k//2): window index i (0..2w) lands at (i - w) mod N
+        double v = 0;
+        const int i1a = r, i1b = r - Ny, i2a = c, i2b = c - Nx;  // candidates for the centred offsets
+        for (int ua = 0; ua < 2; ++ua) {
+            const int i1 = ua ? i1b : i1a;
+            if (i1 < -p.w || i1 > p.w) continue;
+            for (int ub = 0; ub < 2; ++ub) {
+                const int i2 = ub ? i2b : i2a;
+                if (i2 < -p.w || i2 > p.w) continue;
+                double t = win_raw(p, i1, i2) / ws;
+                for (int q = 0; q < px; ++q) t = t * (double)i2;
+                for (int q = 0; q < py; ++q) t = t * (double)i1;
+                v += t;
+            }
+        }
+        fr[e] = v;
+    }
+}
+
+// circular result (Ny x Nx) -> F x F with the first row/column repeated at the end of a periodic axis
+__global__ void k_expand_circ(const double* __restrict__ frames, int F, int Ny, int Nx, double* __restrict__ dst) {
+    const double* fr = frames + (int64_t)blockIdx.y * Ny * Nx;
+    double* d = dst + (int64_t)blockIdx.y * F * F;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        const int r = e / F, c = e % F;
+        d[e] = fr[(int64_t)(r % Ny) * Nx + (c % Nx)];
+    }
+}
+
+// box = hist / bins2D where bins2D > max*1e-8 else hist, as a plain F x F array
+__global__ void k_box(const double* __restrict__ hist, const double* __restrict__ P, const double* __restrict__ mx, int FF,
+                      double* __restrict__ box) {
+    const double thresh = mx[blockIdx.y] * 1e-8;
+    const int64_t o = (int64_t)blockIdx.y * FF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
+        const double h = hist[o + i], p = P[o + i];
+        box[o + i] = (p > thresh) ? h / p : h;
+    }
+}
+
 static int next_fft_size(int n) {
     // smallest even 2^a 3^b 5^c >= n
     int best = 1 << 30;
@@ -191,6 +257,148 @@ static int next_fft_size(int n) {
                 if (v >= n && v < best) best = (int)v;
             }
     return best;
+}
+
+
+// Periodic variant (one or both axes periodic, the same for the whole batch).  Histogram-side convolutions are
+// circular on the folded (Ny x Nx) grid -- including along a non-periodic axis, which the reference also wraps
+// (convolve.py:226-251 takes the FFT at the array size without zero-padding); mask-side 'valid' convolutions use the
+// ordinary zero-padded frames.  mcsamples.py:1874-1976.
+static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, const std::vector<D2Pair>& hp, int maxw,
+                              int per, int bco, int mbc, double* d_P, int32_t* status_out) {
+    const bool px = per & 16, py = per & 32, both = px && py;
+    const int Nx = px ? F - 1 : F, Ny = py ? F - 1 : F;
+    GD_REQUIRE(2 * maxw + 1 <= Nx && 2 * maxw + 1 <= Ny, "window wider than the periodic grid");
+    bool any_prior = false;
+    for (int b = 0; b < B; ++b) any_prior |= (hp[b].flags & 64) != 0;
+    const bool do_bc = any_prior && bco >= 0 && !both;
+    const bool do_mbc = mbc > 0 && !both;
+    const int S = next_fft_size(F + 2 * maxw), Sh = S / 2 + 1, Nxh = Nx / 2 + 1;
+    const int64_t FF = (int64_t)F * F, SS = (int64_t)S * S, SC = (int64_t)S * Sh, NN = (int64_t)Ny * Nx,
+                  NC = (int64_t)Ny * Nxh;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const bool need_S = do_bc || do_mbc;
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+                  o_status = take((int64_t)B * 4), o_RC = take(B * NN * 8), o_ROc = take(B * NN * 8),
+                  o_ZHc = take(B * NC * 16), o_ZWc = take(B * NC * 16), o_ZKc = take(B * NC * 16),
+                  o_ZPc = take(B * NC * 16), o_RF = take(need_S ? B * SS * 8 : 0), o_RO = take(need_S ? B * SS * 8 : 0),
+                  o_ZW = take(need_S ? B * SC * 16 : 0), o_ZM = take(need_S ? B * SC * 16 : 0),
+                  o_ZK = take(need_S ? B * SC * 16 : 0), o_ZP = take(need_S ? B * SC * 16 : 0),
+                  o_arr = take((do_bc ? (bco == 1 ? 8 : 1) : 0) * B * FF * 8), o_a00m = take(do_mbc ? B * FF * 8 : 0),
+                  o_conv = take(B * FF * 8), o_box = take(do_mbc ? B * FF * 8 : 0);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
+    double* d_wsum = (double*)(base + o_wsum);
+    double* d_mx = (double*)(base + o_mx);
+    int* d_status = (int*)(base + o_status);
+    double *RC = (double*)(base + o_RC), *ROc = (double*)(base + o_ROc), *RF = (double*)(base + o_RF),
+           *RO = (double*)(base + o_RO), *arr = (double*)(base + o_arr), *d_a00m = (double*)(base + o_a00m),
+           *d_conv = (double*)(base + o_conv), *d_box = (double*)(base + o_box);
+    double2 *ZHc = (double2*)(base + o_ZHc), *ZWc = (double2*)(base + o_ZWc), *ZKc = (double2*)(base + o_ZKc),
+            *ZPc = (double2*)(base + o_ZPc), *ZW = (double2*)(base + o_ZW), *ZM = (double2*)(base + o_ZM),
+            *ZK = (double2*)(base + o_ZK), *ZP = (double2*)(base + o_ZP);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    const dim3 gS(128, B), gF(64, B), gN(64, B);
+    const double scaleS = 1.0 / ((double)S * (double)S), scaleN = 1.0 / ((double)Ny * (double)Nx);
+    int rc;
+    // circular convolution of a folded operand spectrum with a window spectrum -> F x F
+    auto circ_conv = [&](double2* ZA, double2* ZB, double* dst) -> int {
+        k_cmul<<<1024, 256, 0, ctx->stream>>>(ZA, ZB, B * NC, scaleN, ZPc);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_cmul launch failed");
+        int r = gd_fft_c2r_2d(ctx, Ny, Nx, B, ZPc, ROc);
+        if (r) return r;
+        k_expand_circ<<<gF, 256, 0, ctx->stream>>>(ROc, F, Ny, Nx, dst);
+        return GD_OK;
+    };
+    auto mask_conv = [&](double2* ZA, double2* ZB, double* dst) -> int {
+        k_cmul<<<1024, 256, 0, ctx->stream>>>(ZA, ZB, B * SC, scaleS, ZP);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_cmul launch failed");
+        int r = gd_fft_c2r_2d(ctx, S, S, B, ZP, RO);
+        if (r) return r;
+        k_crop<<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst);
+        return GD_OK;
+    };
+    k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
+    GD_KERNEL_CHECK();
+    k_fill_window_rect<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, Ny, Nx, 0, 0, RC);
+    GD_KERNEL_CHECK();
+    if ((rc = gd_fft_r2c_2d(ctx, Ny, Nx, B, RC, ZWc))) return rc;
+    k_fill_circ<<<gN, 256, 0, ctx->stream>>>(d_hist, F, Ny, Nx, RC);
+    GD_KERNEL_CHECK();
+    if ((rc = gd_fft_r2c_2d(ctx, Ny, Nx, B, RC, ZHc))) return rc;
+    if ((rc = circ_conv(ZHc, ZWc, d_P))) return rc;
+    if (need_S) {
+        k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, RF);
+        GD_KERNEL_CHECK();
+        if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZW))) return rc;
+    }
+    if (do_bc) {
+        BcArrays A;
+        A.P = d_P;
+        A.a00 = arr;
+        A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
+        k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+        GD_KERNEL_CHECK();
+        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
+        GD_KERNEL_CHECK();
+        if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
+        if ((rc = mask_conv(ZM, ZW, A.a00))) return rc;
+        if (bco == 1) {
+            A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
+            A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
+            struct Mom {
+                int px, py;
+                double* mask_dst;
+                double* hist_dst;
+            } moms[5] = {{1, 0, A.a10, A.xP}, {0, 1, A.a01, A.yP}, {2, 0, A.a20, nullptr}, {0, 2, A.a02, nullptr},
+                         {1, 1, A.a11, nullptr}};
+            for (const Mom& m : moms) {
+                k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, m.px, m.py, RF);
+                GD_KERNEL_CHECK();
+                if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZK))) return rc;
+                if ((rc = mask_conv(ZM, ZK, m.mask_dst))) return rc;
+                if (m.hist_dst) {
+                    k_fill_window_rect<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, Ny, Nx, m.px, m.py, RC);
+                    GD_KERNEL_CHECK();
+                    if ((rc = gd_fft_r2c_2d(ctx, Ny, Nx, B, RC, ZKc))) return rc;
+                    if ((rc = circ_conv(ZHc, ZKc, m.hist_dst))) return rc;
+                }
+            }
+        }
+        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco);
+        GD_KERNEL_CHECK();
+    }
+    if (do_mbc) {
+        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 1, do_bc ? 1 : 0, RF);
+        GD_KERNEL_CHECK();
+        if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
+        if ((rc = mask_conv(ZM, ZW, d_a00m))) return rc;
+        for (int round = 0; round < mbc; ++round) {
+            k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+            GD_KERNEL_CHECK();
+            k_box<<<gF, 256, 0, ctx->stream>>>(d_hist, d_P, d_mx, (int)FF, d_box);
+            GD_KERNEL_CHECK();
+            k_fill_circ<<<gN, 256, 0, ctx->stream>>>(d_box, F, Ny, Nx, RC);
+            GD_KERNEL_CHECK();
+            if ((rc = gd_fft_r2c_2d(ctx, Ny, Nx, B, RC, ZKc))) return rc;
+            if ((rc = circ_conv(ZKc, ZWc, d_conv))) return rc;
+            k_mbc_update<<<2048, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
+            GD_KERNEL_CHECK();
+        }
+    }
+    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+    GD_KERNEL_CHECK();
+    k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
 }
 
 extern "C" {
@@ -216,10 +424,15 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
         hp[b].c11 = a / det;
         hp[b].c10 = -o / det;
         hp[b].w = winw[b];
-        hp[b].flags = flags[b] & 15;
+        hp[b].flags = flags[b] & 127;
+        // bit 6 = "has_prior" (mcsamples.py:1794): default it from the limit bits for callers that do not set it
+        if ((hp[b].flags & 15) != 0) hp[b].flags |= 64;
         if (winw[b] > maxw) maxw = winw[b];
-        if (hp[b].flags) any_limits = true;
+        if (hp[b].flags & 64) any_limits = true;
+        GD_REQUIRE((hp[b].flags & 48) == (flags[0] & 48), "a batch must not mix periodic and non-periodic pairs");
     }
+    const int per = flags[0] & 48;
+    if (per) return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out);
     const bool do_bc = any_limits && bco >= 0;
     const int S = next_fft_size(F + 2 * maxw);
     const int Sh = S / 2 + 1;

