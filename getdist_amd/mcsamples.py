@@ -72,6 +72,37 @@ class ParamInfo:
         return "ParamInfo(%s)" % self.name
 
 
+class ParamLimit:
+    """A marginalised parameter limit (types.py:652-716): lower, upper and which tails are constrained."""
+
+    def __init__(self, minmax, tag="two"):
+        self.lower, self.upper = minmax[0], minmax[1]
+        self.twotail = tag == "two"
+        self.onetail_upper = tag == ">"
+        self.onetail_lower = tag == "<"
+
+    def limitTag(self):
+        return "two" if self.twotail else (">" if self.onetail_upper else ("<" if self.onetail_lower else "none"))
+
+    def __str__(self):
+        return f"{self.lower:g} {self.upper:g} {self.limitTag()}"
+
+
+class MargeStats:
+    """The numbers of types.MargeStats (types.py:718-800): per-parameter mean, err and limits per contour."""
+
+    def __init__(self, names, limits):
+        self.names = names
+        self.limits = limits
+        self.hasBestFit = False
+
+    def parWithName(self, name):
+        for p in self.names:
+            if p.name == name:
+                return p
+        return None
+
+
 class ParamConfidenceData:
     """Handle returned by initParamConfidenceData (chains.py:176-178 namedtuple in the reference)."""
 
@@ -979,6 +1010,78 @@ class MCSamples:
                 self.density1D[par.name] = d
             out.append(d)
         return out
+
+    # ---- marginalised limits (mcsamples.py:2353-2367, 2442-2531) -----------------------------------------------
+    def _max_frac_twotail(self):
+        """mcsamples.py:427-433: how small the end bin must be relative to the maximum to use a two-tail limit"""
+        from scipy.stats import norm
+        import math
+
+        return [np.exp(-1.0 * math.pow(norm.ppf((1 - c) / 2), 2) / 2) for c in self.contours]
+
+    def _setMargeLimits(self, par, paramConfid, max_frac_twotail=None, density1D=None):
+        """mcsamples.py:2460-2531 (scalar logic on the device-computed density and quantiles)"""
+        import math
+
+        if max_frac_twotail is None:
+            max_frac_twotail = self._max_frac_twotail()
+        force_twotail = getattr(self, "force_twotail", False)
+        par.limits = []
+        density1D = density1D or self.get1DDensity(par.name)
+        interpGrid = None
+        for ix1, contour in enumerate(self.contours):
+            marge_limits_bot = par.has_limits_bot and not force_twotail and density1D.P[0] > max_frac_twotail[ix1]
+            marge_limits_top = par.has_limits_top and not force_twotail and density1D.P[-1] > max_frac_twotail[ix1]
+            if not marge_limits_bot or not marge_limits_top:
+                if not interpGrid:
+                    interpGrid = density1D.initLimitGrids()
+                tail_limit_bot, tail_limit_top, marge_limits_bot, marge_limits_top = density1D.getLimits(contour, interpGrid)
+                limfrac = 1 - contour
+                if marge_limits_bot:
+                    tail_limit_bot = par.range_min
+                    tail_confid_bot = None
+                elif marge_limits_top:
+                    tail_limit_bot = self.confidence(paramConfid, limfrac, upper=False)
+                    tail_confid_bot = None
+                else:
+                    tail_confid_bot = self.confidence(paramConfid, limfrac / 2, upper=False)
+                if marge_limits_top:
+                    tail_limit_top = par.range_max
+                    tail_confid_top = None
+                elif marge_limits_bot:
+                    tail_limit_top = self.confidence(paramConfid, limfrac, upper=True)
+                    tail_confid_top = None
+                else:
+                    tail_confid_top = self.confidence(paramConfid, limfrac / 2, upper=True)
+                if not marge_limits_bot and not marge_limits_top:
+                    if (math.fabs(density1D.Prob(tail_confid_top) - density1D.Prob(tail_confid_bot))
+                            < self.credible_interval_threshold):
+                        tail_limit_top = tail_confid_top
+                        tail_limit_bot = tail_confid_bot
+                lim = [tail_limit_bot, tail_limit_top]
+            else:
+                lim = [par.range_min, par.range_max]
+            if marge_limits_bot and marge_limits_top:
+                tag = "none"
+            elif marge_limits_bot:
+                tag = ">"
+            elif marge_limits_top:
+                tag = "<"
+            else:
+                tag = "two"
+            par.limits.append(ParamLimit(lim, tag))
+
+    def getMargeStats(self, include_bestfit=False):
+        """mcsamples.py:2353-2367: marginalised 1D constraints (numbers only; text tables are out of scope)."""
+        if include_bestfit:
+            raise NotImplementedError("best-fit files are outside the accelerated path")
+        if self.needs_update:
+            self.updateBaseStatistics()
+        dens = self.get1DDensities()  # one batched launch, cached per name
+        mft = self._max_frac_twotail()
+        for j, par in enumerate(self.paramNames.names):
+            self._setMargeLimits(par, self.initParamConfidenceData(j), mft, dens[j])
+        return MargeStats(self.paramNames.names, self.contours)
 
     # ---- 2D densities (mcsamples.py:1285-1419, 1730-2010) ---------------------------------------------------
     def get2DDensity(self, x, y, normalized=False, **kwargs):

@@ -101,6 +101,18 @@ def golden_for_fixture(name, samples, weights, names, ranges, pairs, kw1, kw2):
     return out
 
 
+def golden_margestats(fx):
+    ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    ms = ref.getMargeStats()
+    out = {}
+    for nm in fx["names"]:
+        par = ms.parWithName(nm)
+        out["lims/" + nm] = np.array([[lim.lower, lim.upper, lim.twotail, lim.onetail_upper, lim.onetail_lower]
+                                      for lim in par.limits], dtype=float)
+        out["meanerr/" + nm] = np.array([par.mean, par.err])
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -128,7 +140,10 @@ def main():
     xs = np.unique(np.concatenate([np.arange(1, 3000), np.geomspace(3000, 2.0e9, 1500).astype(np.int64)]))
     np.savez_compressed(os.path.join(HERE, "fftnumbers.npz"), x=xs, y=nearestFFTnumber(xs))
     np.savez_compressed(os.path.join(HERE, "convergence.npz"), **golden_convergence())
-    for fx in fixture_zoo():
+    zoo = {fx["name"]: fx for fx in fixture_zoo()}
+    for nm in ("shapes", "c1_bounded", "block10_weighted"):
+        np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
+    for fx in zoo.values():
         out = golden_for_fixture(**fx)
         path = os.path.join(HERE, "fixture_%s.npz" % fx["name"])
         np.savez_compressed(path, **out)

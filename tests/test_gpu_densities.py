@@ -176,3 +176,35 @@ def test_api_extras(zoo):
     m2 = MCSamples(samples=chains, weights=ws, names=names)
     txt = m2.getConvergeTests()
     assert "var(mean)/mean(var)" in txt and abs(m2.GelmanRubin - m2.getGelmanRubin()) == 0
+
+
+@pytest.mark.parametrize("name", ["shapes", "c1_bounded", "block10_weighted"])
+def test_marge_stats_golden(zoo, name):
+    """getMargeStats numbers (mcsamples.py:2353-2367, 2442-2531) against the reference's."""
+    fx = zoo[name]
+    g = np.load(gu.GOLDEN_DIR + "/margestats_%s.npz" % name)
+    mc = make(fx)
+    ms = mc.getMargeStats()
+    for nm in fx["names"]:
+        par = ms.parWithName(nm)
+        want = g["lims/" + nm]
+        got = np.array([[lim.lower, lim.upper, lim.twotail, lim.onetail_upper, lim.onetail_lower] for lim in par.limits],
+                       dtype=float)
+        assert np.array_equal(got[:, 2:], want[:, 2:]), (nm, "limit types")
+        scale = max(1e-300, float(par.err))
+        assert np.max(np.abs(got[:, :2] - want[:, :2])) < 2e-5 * scale, (nm, got, want)
+        assert np.allclose([par.mean, par.err], g["meanerr/" + nm], rtol=1e-11)
+
+
+def test_limits_analytic_like_reference():
+    """getdist_test.py:136-142: unit Gaussian with a hard upper cut at 1; limits to 2 decimal places."""
+    from getdist_amd.mcsamples import MCSamples
+
+    r = np.random.default_rng(10)
+    x = r.standard_normal(3_000_000)
+    x = x[x < 1][:1_500_000]
+    mc = MCSamples(samples=x[:, None], names=["x"], ranges={"x": (None, 1)})
+    lims = mc.getMargeStats().parWithName("x").limits
+    assert abs(lims[0].lower - (-0.78828)) < 1e-2
+    assert abs(lims[0].upper - 0.7954) < 1e-2
+    assert abs(lims[1].lower - (-1.730)) < 1e-2
