@@ -237,6 +237,66 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
     flush_stripe<BinT>(sh, row0, R, F, hist_all + (int64_t)pair * F * F, nchunks == 1);
 }
 
+
+// Unit-weight, pre-binned variant with 16-bit LDS counters packed two per word: a 256 x 256 grid fits one
+// 128 KB stripe, so every sample is visited once instead of once per stripe.  A counter can wrap if a bin receives
+// more than 65535 samples; a wrap always lowers the sum of all counters, so comparing that sum with the number of
+// samples the block accepted detects it exactly, and the host redoes flagged pairs with the 32-bit kernel.
+__global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restrict__ pairs, int B, int64_t N, int F,
+                                                     int R, int nstripes, double* __restrict__ hist_all,
+                                                     int* __restrict__ overflow) {
+    extern __shared__ double sh_raw[];
+    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
+    __shared__ double red[16];
+    int pair, chunk, stripe;
+    decode_block(nstripes, 1, pair, chunk, stripe);
+    if (pair >= B) return;
+    const Hist2DPair P = pairs[pair];
+    const int row0 = stripe * R;
+    const int nwords = (R * F + 1) / 2;
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    unsigned int nacc = 0;
+    auto visit = [&](unsigned cx, unsigned cy) {
+        const unsigned r = cy - (unsigned)row0;
+        if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F) {
+            const unsigned a = r * (unsigned)F + cx;
+            atomicAdd(&sh[a >> 1], 1u << ((a & 1u) * 16u));
+            ++nacc;
+        }
+    };
+    auto visit8 = [&](const uint4& ax, const uint4& ay) {
+        const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            visit(xs[q] & 0xFFFFu, ys[q] & 0xFFFFu);
+            visit(xs[q] >> 16, ys[q] >> 16);
+        }
+    };
+    const int64_t N16 = N & ~(int64_t)15;
+    // two 16-byte loads per index column in flight before any sample is consumed
+    for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * (int64_t)blockDim.x) {
+        const uint4 ax0 = *reinterpret_cast<const uint4*>(P.ix + i), ay0 = *reinterpret_cast<const uint4*>(P.iy + i);
+        const uint4 ax1 = *reinterpret_cast<const uint4*>(P.ix + i + 8), ay1 = *reinterpret_cast<const uint4*>(P.iy + i + 8);
+        visit8(ax0, ay0);
+        visit8(ax1, ay1);
+    }
+    if (threadIdx.x == 0)
+        for (int64_t i = N16; i < N; ++i) visit(P.ix[i], P.iy[i]);
+    __syncthreads();
+    double* hist = hist_all + (int64_t)pair * F * F;
+    unsigned int total = 0;
+    for (int i = threadIdx.x; i < R * F; i += blockDim.x) {
+        const int r = row0 + i / F;
+        if (r >= F) break;
+        const unsigned int v = (sh[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+        total += v;
+        hist[(int64_t)r * F + (i % F)] = (double)v;
+    }
+    const double t = block_sum((double)total, red), a = block_sum((double)nacc, red);
+    if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
+}
+
 // min / max of a*x + b*y over the samples; grid (nblk, B)
 __global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N, double* __restrict__ part) {
     __shared__ double red[16];
@@ -391,10 +451,38 @@ int gd_hist2d(gd_ctx* ctx, int32_t B, const int32_t* colx, const int32_t* coly, 
     return launch_hist2d<0>(ctx, B, hp, F, (double*)d_hist);
 }
 
+static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist,
+                             std::vector<int>& flagged) {
+    int R = LDS_HIST_BYTES / (F * 2);
+    if (R > F) R = F;
+    const int nstripes = (F + R - 1) / R;
+    const int units = (B + 7) / 8 * 8;
+    const int64_t nblocks = (int64_t)units * nstripes;
+    const int64_t o_flags = ((int64_t)B * sizeof(Hist2DPair) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_flags + (int64_t)B * 4);
+    if (!base) return GD_ERR_NOMEM;
+    Hist2DPair* d_pairs = (Hist2DPair*)base;
+    int* d_flags = (int*)(base + o_flags);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+    const size_t lds = ((size_t)R * F + 1) / 2 * 4;
+    k_hist2d_u16<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, d_hist, d_flags);
+    GD_KERNEL_CHECK();
+    std::vector<int> hf((size_t)B);
+    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    flagged.clear();
+    for (int b = 0; b < B; ++b)
+        if (hf[b]) flagged.push_back(b);
+    return GD_OK;
+}
+
 int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
                         void* d_hist) {
     GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins_2D out of range");
     std::vector<Hist2DPair> hp((size_t)B);
     for (int b = 0; b < B; ++b) {
         Hist2DPair& p = hp[b];
@@ -403,7 +491,27 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
         p.iy = (const unsigned short*)d_idx_y[b];
         GD_REQUIRE(p.ix && p.iy, "null index column");
     }
-    return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+    if (ctx->w || B < 16) return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+    // unit weights, batched: 16-bit packed LDS counters, exact overflow detection, 32-bit redo for flagged pairs
+    std::vector<int> flagged;
+    int rc = launch_hist2d_u16(ctx, B, hp, F, (double*)d_hist, flagged);
+    if (rc) return rc;
+    if (!flagged.empty()) {
+        const int nf = (int)flagged.size();
+        std::vector<Hist2DPair> sub((size_t)nf);
+        for (int q = 0; q < nf; ++q) sub[q] = hp[flagged[q]];
+        double* tmp = nullptr;
+        GD_HIP(hipMalloc((void**)&tmp, (size_t)nf * F * F * 8));
+        rc = launch_hist2d<2>(ctx, nf, sub, F, tmp);
+        if (rc == GD_OK)
+            for (int q = 0; q < nf && rc == GD_OK; ++q)
+                if (hipMemcpyAsync((double*)d_hist + (int64_t)flagged[q] * F * F, tmp + (int64_t)q * F * F, (size_t)F * F * 8,
+                                   hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                    rc = gd_fail(ctx, GD_ERR_HIP, "copy of redone histogram failed");
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+    }
+    return rc;
 }
 
 int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* r0,

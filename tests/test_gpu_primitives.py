@@ -189,3 +189,23 @@ def test_lag_sums(ctx, data):
     got = ctx.kde_lag_sums(2, c, lags)
     ref = [np.dot(np.exp(-((x[:-k] - x[k:]) ** 2) * c) * w[:-k], w[k:]) for k in lags]
     assert np.allclose(got, ref, rtol=1e-12)
+
+
+def test_hist2d_u16_counters_overflow_is_detected_and_redone(ctx):
+    """Batched unit-weight launches use 16-bit packed LDS counters; a bin with > 65535 samples must still be exact."""
+    r = np.random.default_rng(5)
+    N = 400_003
+    cols = [np.full(N, 0.5), np.where(r.random(N) < 0.7, 0.25, r.random(N))]  # one bin gets all / 70 % of the samples
+    cols += [r.random(N) for _ in range(5)]
+    s = np.column_stack(cols)
+    ctx.upload(s, None)
+    F = 256
+    pre = [ctx.prebin(c, -0.001, 1.002 / (F - 1), F) for c in range(s.shape[1])]
+    pairs = [(a, b) for a in range(7) for b in range(7) if a != b][:24]
+    H = ctx.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F).to_host((len(pairs), F, F))
+    for k, (a, b) in enumerate(pairs):
+        ix = ((s[:, a] + 0.001) / (1.002 / (F - 1)) + 0.5).astype(int)
+        iy = ((s[:, b] + 0.001) / (1.002 / (F - 1)) + 0.5).astype(int)
+        ref = np.bincount(ix + iy * F, minlength=F * F).reshape(F, F)
+        assert np.array_equal(H[k], ref), (a, b, H[k].max(), ref.max())
+    assert max(H[k].max() for k in range(len(pairs))) > 65535
