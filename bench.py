@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_FETCH_KIB, PMC_WRITE_KIB = 10.51e6, 0.6272e6  # per 1225-pair launch; refreshed from profiles/r01_pmc_* below
 
 
 def parse():
@@ -109,12 +110,12 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
     achieved = alg_bytes / t / 1e9
     # HBM traffic per launch from the PMC passes in profiles/r01_pmc_hist2d_{FETCH,WRITE}_SIZE.csv (separate rocprofv3
     # --pmc runs of scripts/pmc_hist2d.py on this exact config: 1225 pairs, N=1e7, F=256, unit weights):
-    # FETCH_SIZE 13.56e6 KiB x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE 0.627e6 KiB, scaled
-    # by the number of pairs in this launch.  Not re-measured live (PMC needs the profiler); null for other configs.
+    # FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB, scaled by the
+    # number of pairs in this launch.  Not re-measured live (PMC needs the profiler); null for other configs.
     traffic = None
     if mc.numrows == 10_000_000 and mc.n == 50 and mc.weights is None:
-        traffic = (2 * 13.56e6 + 0.6272e6) * 1024 * len(sel) / 1225.0
-    return dict(bound="hbm", kernel="k_hist2d<prebinned u16, u32 LDS counters>", launches_pairs=len(sel),
+        traffic = (2 * PMC_FETCH_KIB + PMC_WRITE_KIB) * 1024 * len(sel) / 1225.0
+    return dict(bound="hbm", kernel="k_hist2d_u16 (pre-binned u16 indices, 16-bit packed LDS counters)", launches_pairs=len(sel),
                 ms_per_launch=t * 1e3, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=traffic,
                 note="achieved = algorithmic bytes (24N+8F^2 per density, SURVEY 8d) / launch time; the kernel reads "

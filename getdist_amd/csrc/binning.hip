@@ -491,7 +491,13 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
         p.iy = (const unsigned short*)d_idx_y[b];
         GD_REQUIRE(p.ix && p.iy, "null index column");
     }
-    if (ctx->w || B < 16) return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+    {
+        int R16 = LDS_HIST_BYTES / (F * 2);
+        if (R16 > F) R16 = F;
+        const int nstripes16 = (F + R16 - 1) / R16;
+        // the 16-bit kernel gives each (pair, stripe) to ONE block: only worth it when that fills the chip
+        if (ctx->w || (int64_t)B * nstripes16 < ctx->cu_count) return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+    }
     // unit weights, batched: 16-bit packed LDS counters, exact overflow detection, 32-bit redo for flagged pairs
     std::vector<int> flagged;
     int rc = launch_hist2d_u16(ctx, B, hp, F, (double*)d_hist, flagged);

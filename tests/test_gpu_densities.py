@@ -168,14 +168,13 @@ def test_api_extras(zoo):
     assert "a" not in mc.density1D
     assert np.allclose(mc.means, 2.0 * fx["samples"].mean(axis=0), rtol=1e-12)
     d_after = mc.get1DDensity("a")
-    assert d_after.x[-1] > 1.5 * 0 and not np.array_equal(d_after.P, d_before) or True
     assert np.allclose(d_after.P, d_before, atol=5e-3)  # a pure rescaling of one column leaves the shape unchanged
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [samples[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
     ws = [weights[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
     m2 = MCSamples(samples=chains, weights=ws, names=names)
     txt = m2.getConvergeTests()
-    assert "var(mean)/mean(var)" in txt and abs(m2.GelmanRubin - m2.getGelmanRubin()) == 0
+    assert "var(mean)/mean(var)" in txt and abs(m2.GelmanRubin - m2.getGelmanRubin()) <= 1e-12 * m2.GelmanRubin
 
 
 @pytest.mark.parametrize("name", ["shapes", "c1_bounded", "block10_weighted"])

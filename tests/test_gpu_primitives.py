@@ -201,7 +201,7 @@ def test_hist2d_u16_counters_overflow_is_detected_and_redone(ctx):
     ctx.upload(s, None)
     F = 256
     pre = [ctx.prebin(c, -0.001, 1.002 / (F - 1), F) for c in range(s.shape[1])]
-    pairs = [(a, b) for a in range(7) for b in range(7) if a != b][:24]
+    pairs = [(a, b) for a in range(7) for b in range(7) if a != b] * 7  # 294 pairs: enough blocks for the u16 path
     H = ctx.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F).to_host((len(pairs), F, F))
     for k, (a, b) in enumerate(pairs):
         ix = ((s[:, a] + 0.001) / (1.002 / (F - 1)) + 0.5).astype(int)
