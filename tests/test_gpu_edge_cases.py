@@ -1,0 +1,109 @@
+"""GPU edge cases: tiny / ragged sizes, single column, filtered weights, degenerate ranges, odd grid sizes."""
+
+import numpy as np
+import pytest
+
+from oracle import kde_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def mcs(*a, **k):
+    from getdist_amd.mcsamples import MCSamples
+
+    return MCSamples(*a, **k)
+
+
+@pytest.mark.parametrize("N", [37, 1000, 4097])
+def test_small_and_ragged_row_counts(N):
+    r = np.random.default_rng(N)
+    s = r.standard_normal((N, 3)) * [1.0, 2.0, 0.3] + [0.0, 5.0, -1.0]
+    w = r.integers(1, 5, N).astype(float)
+    mc = mcs(samples=s, weights=w)
+    orc = ko.OracleSamples(s, w)
+    assert np.allclose(mc.means, orc.means, rtol=1e-12)
+    assert np.allclose(mc.fullcov, orc.fullcov, rtol=1e-11, atol=1e-14)
+    fr = np.array([0.05, 0.5, 0.95])
+    for j in range(3):
+        assert np.array_equal(mc.confidence(j, fr), orc.confidence(orc.confidence_data(s[:, j]), fr))
+    if N >= 1000:
+        d = mc.get1DDensities()
+        for j in range(3):
+            assert np.max(np.abs(d[j].P - orc.density_1d(j)["P"])) < 1e-6
+        d2 = mc.get2DDensity(0, 1)
+        o2 = orc.density_2d(0, 1)
+        assert np.max(np.abs(d2.P - o2["P"])) < 2e-3  # unbounded pair: TNC path
+
+
+def test_single_column_and_unknown_names():
+    r = np.random.default_rng(1)
+    x = r.standard_normal(20000)
+    mc = mcs(samples=x, names=["x"])
+    assert mc.n == 1 and mc.fullcov.shape == (1, 1)
+    assert abs(mc.fullcov[0, 0] - x.var()) < 1e-12 * x.var()
+    d = mc.get1DDensity("x")
+    o = ko.OracleSamples(x[:, None], names=["x"]).density_1d(0)
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
+    assert mc.get1DDensity("nope") is None
+    assert mc.get2DDensity("x", "nope") is None
+
+
+def test_min_weight_ratio_filter_and_zero_weights():
+    r = np.random.default_rng(2)
+    s = r.standard_normal((5000, 2))
+    w = r.random(5000)
+    w[::7] = 0.0  # removed by setMinWeightRatio (chains.py:1017-1027)
+    mc = mcs(samples=s, weights=w)
+    keep = w > 0
+    assert mc.numrows == keep.sum()
+    assert np.allclose(mc.means, w[keep].dot(s[keep]) / w[keep].sum(), rtol=1e-12)
+
+
+def test_degenerate_range_raises():
+    from getdist_amd.mcsamples import MCSamplesError
+
+    s = np.column_stack([np.full(1000, 3.0), np.random.default_rng(0).standard_normal(1000)])
+    mc = mcs(samples=s, names=["c", "x"])
+    with pytest.raises(MCSamplesError):
+        mc.get1DDensity("c")
+
+
+@pytest.mark.parametrize("kw", [dict(fine_bins=500), dict(fine_bins=257, smooth_scale_1D=0.5), dict(num_bins=50, smooth_scale_1D=1.5)])
+def test_odd_1d_grid_sizes(kw):
+    r = np.random.default_rng(3)
+    s = np.abs(r.standard_normal((30000, 1)))
+    mc = mcs(samples=s, names=["x"], ranges={"x": (0, None)})
+    orc = ko.OracleSamples(s, names=["x"], ranges={"x": (0, None)})
+    d = mc.get1DDensity("x", **kw)
+    o = orc.density_1d(0, **kw)
+    assert d.P.shape == o["P"].shape
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(fine_bins_2D=100), dict(fine_bins_2D=33, smooth_scale_2D=0.4), dict(smooth_scale_2D=2.0)])
+def test_odd_2d_grid_sizes(kw):
+    r = np.random.default_rng(4)
+    s = np.column_stack([np.abs(r.standard_normal(30000)), r.standard_normal(30000)])
+    mc = mcs(samples=s, names=["x", "y"], ranges={"x": (0, None)})
+    orc = ko.OracleSamples(s, names=["x", "y"], ranges={"x": (0, None)})
+    d = mc.get2DDensity("x", "y", **kw)
+    o = orc.density_2d(0, 1, **kw)
+    assert d.P.shape == o["P"].shape
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
+
+
+def test_settings_and_errors():
+    from getdist_amd.mcsamples import SettingError
+
+    r = np.random.default_rng(5)
+    s = r.standard_normal((20000, 2))
+    mc = mcs(samples=s, settings={"fine_bins_2D": 128, "mult_bias_correction_order": 0})
+    assert mc.get2DDensity(0, 1).P.shape == (128, 128)
+    with pytest.raises(SettingError):
+        mc.updateSettings({"no_such_setting": 1})
+    with pytest.raises(SettingError):
+        mc.get2DDensity(0, 1, boundary_correction_order=2)
+    with pytest.raises(SettingError):
+        mc.get1DDensity(0, boundary_correction_order=3)
+    mc.updateSettings({"smooth_scale_2D": 0.5})
+    assert mc.get2DDensity(0, 1).P.max() == 1.0
