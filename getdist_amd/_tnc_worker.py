@@ -10,6 +10,8 @@ import pickle
 import struct
 import sys
 
+import numpy as np
+
 
 def main():
     from getdist_amd.mcsamples import _get_h  # numpy/scipy only; creates no GPU context
@@ -22,9 +24,12 @@ def main():
         (n,) = struct.unpack("<q", head)
         jobs = pickle.loads(inp.read(n))
         res = []
-        for job in jobs:
+        for psi, neff, corr, do_corr in jobs:
             try:
-                res.append(_get_h(*job))
+                # plain floats travel over the pipe (cheap to pickle); numpy scalar semantics are restored here
+                # (np.float64 ** gives nan where a Python float would raise / go complex, as in the reference)
+                h = _get_h(tuple(np.float64(v) for v in psi), np.float64(neff), np.float64(corr) if corr else corr, do_corr)
+                res.append(tuple(float(v) for v in h))
             except Exception as e:  # e.g. "bias not positive definite": re-raised in the parent
                 res.append(e)
         blob = pickle.dumps(res, protocol=pickle.HIGHEST_PROTOCOL)

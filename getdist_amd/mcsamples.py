@@ -328,17 +328,26 @@ class _TncPool:
                 p.kill()
         self.procs = []
 
+    MAX_SHARE = 300  # jobs per worker per round: keeps every blob far below the 64 KiB pipe buffer (no deadlock)
+
     def submit(self, jobs):
         import pickle
         import struct
 
+        if len(jobs) > self.workers * self.MAX_SHARE:  # very large batches: resolve in synchronous rounds
+            out = []
+            step = self.workers * self.MAX_SHARE
+            for a in range(0, len(jobs), step):
+                out += self.submit(jobs[a:a + step]).get()
+            return _Solved(out)
         n = len(jobs)
         shares = [list(range(w, n, self.workers)) for w in range(self.workers)]  # interleaved: even cost mix
         active = []
         for p, idx in zip(self.procs, shares):
             if not idx:
                 continue
-            blob = pickle.dumps([jobs[i] for i in idx], protocol=pickle.HIGHEST_PROTOCOL)
+            blob = pickle.dumps([(tuple(map(float, jobs[i][0])), float(jobs[i][1]), float(jobs[i][2]), bool(jobs[i][3]))
+                                 for i in idx], protocol=pickle.HIGHEST_PROTOCOL)
             p.stdin.write(struct.pack("<q", len(blob)))
             p.stdin.write(blob)
             p.stdin.flush()
@@ -363,7 +372,7 @@ class _PoolResult:
             for i, r in zip(idx, pickle.loads(p.stdout.read(m))):
                 if isinstance(r, Exception):
                     raise r
-                out[i] = r
+                out[i] = tuple(np.float64(v) for v in r)
         return out
 
 
@@ -1186,6 +1195,41 @@ class MCSamples:
         for e in plan:
             e["kopt"] = None
         jobs, job_meta = [], []
+        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
+        pendings = []  # (pooled [(job, meta)], handle): TNC solves running in the host worker pool
+
+        def to_param_units(meta, solved):
+            branch, k, r1, r2 = meta
+            hx, hy, c = solved
+            e = plan[k]
+            if branch == "A":
+                hx *= r1
+                hy *= r2
+                S = e["S"]
+                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
+                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
+                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
+                if e["pary"].has_limits:
+                    hx, hy = hy, hx
+                return hx, hy, c
+            return hx * e["rangex"], hy * e["rangey"], c
+
+        def rescale(k):
+            if m:
+                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
+                hx, hy, c = results[k]
+                results[k] = (hx * scale, hy * scale, c)
+
+        def submit():
+            """Closed-form solves now; TNC solves go to the pool immediately so they overlap the next device stage."""
+            pooled = [(job, meta) for job, meta in zip(jobs, job_meta) if job[3]]
+            for job, meta in zip(jobs, job_meta):
+                if not job[3]:
+                    results[meta[1]] = to_param_units(meta, _get_h(*job))
+            if pooled:
+                pendings.append((pooled, _get_h_many([job for job, _ in pooled])))
+            del jobs[:], job_meta[:]
+
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
         if A:
@@ -1220,6 +1264,7 @@ class MCSamples:
                     continue
                 jobs.append((tuple(out[row, 1:7]), e["neff"], 0, bool(do_corr[row])))
                 job_meta.append(("A", k, r1s[row], r2s[row]))
+            submit()
         # -- branch B: rule of thumb
         for k, e in enumerate(plan):
             if e["branch"] == "B":
@@ -1248,47 +1293,18 @@ class MCSamples:
                     continue
                 jobs.append((tuple(out[row, 1:7]), e["neff"], e["corr"], bool(do_corr[row])))
                 job_meta.append(("C", k, None, None))
-        # -- host: closed-form h_x, h_y now; the TNC refinements in the process pool, asynchronously
-        m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
-
-        def to_param_units(meta, solved):
-            branch, k, r1, r2 = meta
-            hx, hy, c = solved
-            e = plan[k]
-            if branch == "A":
-                hx *= r1
-                hy *= r2
-                S = e["S"]
-                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
-                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
-                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
-                if e["pary"].has_limits:
-                    hx, hy = hy, hx
-                return hx, hy, c
-            return hx * e["rangex"], hy * e["rangey"], c
-
-        def rescale(k):
-            if m:
-                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
-                hx, hy, c = results[k]
-                results[k] = (hx * scale, hy * scale, c)
-
-        pooled = [(job, meta) for job, meta in zip(jobs, job_meta) if job[3]]
-        for job, meta in zip(jobs, job_meta):
-            if not job[3]:
-                results[meta[1]] = to_param_units(meta, _get_h(*job))
+        submit()
         early = [k for k in range(len(plan)) if results[k] is not None]
         for k in early:
             rescale(k)
-        pending = _get_h_many([job for job, _ in pooled])
 
         def finish():
             """Collect the pooled host solves; returns the complete list of (hx, hy, corr)."""
             with _Phase(self, "2d.bandwidth.host_get_h_wait"):
-                solved = pending.get()
-            for (_, meta), sol in zip(pooled, solved):
-                results[meta[1]] = to_param_units(meta, sol)
-                rescale(meta[1])
+                for pooled, handle in pendings:
+                    for (_, meta), sol in zip(pooled, handle.get()):
+                        results[meta[1]] = to_param_units(meta, sol)
+                        rescale(meta[1])
             return results
 
         finish.early = {k: results[k] for k in early}
