@@ -63,10 +63,36 @@ def run_c4():
                 gr_plus_meanvar_ms=round(min(times) * 1e3, 2), GR=float(np.max(D)), meanvar_max=float(np.max(mv)))
 
 
+def run_c5(N=2_000_000, n=200):
+    """Stress shape of C5 (200 parameters => 19 900 pairs + 200 1D densities + margestats) at a reduced row count."""
+    import numpy as np
+
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = synth.block_recipe(n, N, weighted=False, stream=7)
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    t_ctor = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ms = mc.getMargeStats()
+    t_marge = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pairs, dens = mc.triangleDensities()
+    mc.ctx.sync()
+    t_tri = time.perf_counter() - t0
+    ok = all(d is not None and d.P.max() == 1.0 for d in dens)
+    return dict(config="C5-reduced", n=n, N=N, pairs=len(pairs), construct_s=round(t_ctor, 2),
+                margestats_1d_s=round(t_marge, 2), triangle_s=round(t_tri, 2), densities_per_s=round(len(pairs) / t_tri, 1),
+                all_normalised=bool(ok), limits_p0=str(ms.parWithName("p0").limits[0]),
+                F_classes=sorted(set(int(d.P.shape[0]) for d in dens)))
+
+
 def main():
     which = sys.argv[1:] or ["c2", "c4"]
     for c in which:
-        print(json.dumps(run_c2() if c == "c2" else run_c4()), flush=True)
+        fn = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[c]
+        print(json.dumps(fn()), flush=True)
 
 
 if __name__ == "__main__":
