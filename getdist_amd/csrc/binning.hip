@@ -123,8 +123,8 @@ __device__ __forceinline__ void lds_add<double>(double* p, double w) {
     atomicAdd(p, w);
 }
 template <>
-__device__ __forceinline__ void lds_add<unsigned int>(unsigned int* p, double) {
-    atomicAdd(p, 1u);
+__device__ __forceinline__ void lds_add<unsigned int>(unsigned int* p, double w) {
+    atomicAdd(p, (unsigned int)w);  // unit weights (w = 1) or integral weights (exact)
 }
 
 // decode the 1-D grid: stripes of one unit share an XCD (block id mod 8)
@@ -177,6 +177,10 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
         for (int64_t i = lo + 8 * (int64_t)threadIdx.x; i < hi8; i += 8 * (int64_t)blockDim.x) {
             const uint4 ax = *reinterpret_cast<const uint4*>(P.ix + i);
             const uint4 ay = *reinterpret_cast<const uint4*>(P.iy + i);
+            double2 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wv[q] = HAS_W ? *reinterpret_cast<const double2*>(w + i + 2 * q) : make_double2(1.0, 1.0);
             const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
                     const unsigned cx = (xs[q] >> (16 * h)) & 0xFFFFu, cy = (ys[q] >> (16 * h)) & 0xFFFFu;
                     const unsigned r = cy - (unsigned)row0;
                     if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F)
-                        lds_add<BinT>(&sh[r * F + cx], HAS_W ? w[i + 2 * q + h] : 1.0);
+                        lds_add<BinT>(&sh[r * F + cx], h ? wv[q].y : wv[q].x);
                 }
             }
         }
@@ -328,7 +332,8 @@ template <int MODE>
 static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist) {
     GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins_2D out of range");
     const bool has_w = ctx->w != nullptr;
-    const int binbytes = has_w ? 8 : 4;
+    const bool u32bins = !has_w || ctx->w_integral;  // integral weights: exact u32 counters, twice the rows per stripe
+    const int binbytes = u32bins ? 4 : 8;
     int R = LDS_HIST_BYTES / (F * binbytes);
     GD_REQUIRE(R >= 1, "fine_bins_2D too large for the LDS stripe");
     if (R > F) R = F;
@@ -343,8 +348,12 @@ static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, 
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
     if (nchunks > 1) GD_HIP(hipMemsetAsync(d_hist, 0, (size_t)B * F * F * 8, ctx->stream));
     const size_t lds = (size_t)R * F * binbytes;
-    if (has_w) {
+    if (has_w && !u32bins) {
         auto kern = k_hist2d<MODE, true, double>;
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        kern<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->w, ctx->N, F, R, nstripes, nchunks, d_hist);
+    } else if (has_w) {
+        auto kern = k_hist2d<MODE, true, unsigned int>;
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
         kern<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->w, ctx->N, F, R, nstripes, nchunks, d_hist);
     } else {

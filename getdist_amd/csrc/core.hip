@@ -226,6 +226,20 @@ __global__ void k_gather_items(double2* __restrict__ dst, const double2* __restr
         d[i] = s[i];
 }
 
+// weights that are all non-negative integers (MCMC multiplicities) allow exact u32 LDS counters in the 2D binning
+__global__ void k_weights_integral(const double* __restrict__ w, int64_t N, int* __restrict__ bad, double* __restrict__ sum) {
+    double s = 0;
+    int b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = w[i];
+        if (!(v >= 0.0) || v != trunc(v) || v > 1048576.0) b = 1;
+        s += v;
+    }
+    if (b) atomicOr(bad, 1);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(sum, s);
+}
+
 extern "C" {
 
 int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes) {
@@ -273,9 +287,21 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
             GD_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
+    ctx->w_integral = false;
     if (weights) {
         GD_HIP(hipMalloc((void**)&ctx->w, (size_t)(ld * 8)));
         GD_HIP(hipMemcpyAsync(ctx->w, weights, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
+        char* chk = (char*)gd_scratch(ctx, 256);
+        if (!chk) return GD_ERR_NOMEM;
+        GD_HIP(hipMemsetAsync(chk, 0, 256, ctx->stream));
+        k_weights_integral<<<1024, 256, 0, ctx->stream>>>(ctx->w, N, (int*)chk, (double*)(chk + 128));
+        GD_KERNEL_CHECK();
+        int bad = 1;
+        double sum = 0;
+        GD_HIP(hipMemcpyAsync(&bad, chk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipMemcpyAsync(&sum, chk + 128, 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->w_integral = (bad == 0) && sum < 4.0e9;
     }
     GD_HIP(hipStreamSynchronize(ctx->stream));
     ctx->N = N;

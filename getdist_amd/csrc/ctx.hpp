@@ -24,6 +24,7 @@ struct gd_ctx {
     // sample set: SoA, column j at cols + j*ld, ld = N rounded up to 512 elements
     double* cols = nullptr;
     double* w = nullptr;  // nullptr => unit weights
+    bool w_integral = false;  // all weights are non-negative integers with sum < 2^32 (MCMC multiplicities)
     int64_t N = 0, n = 0, ld = 0;
     // reusable scratch (grown on demand)
     void* scratch = nullptr;

@@ -34,8 +34,12 @@ def main():
     ap.add_argument("--nsamples", type=int, default=10_000_000)
     ap.add_argument("--nparams", type=int, default=50)
     ap.add_argument("--weighted", action="store_true")
+    ap.add_argument("--intweights", action="store_true", help="integer multiplicities 1..5 as weights")
     a = ap.parse_args()
     s, w, names, ranges = synth.block_recipe(a.nparams, a.nsamples, weighted=a.weighted, stream=4)
+    if a.intweights:
+        w = np.random.default_rng(1).integers(1, 6, a.nsamples).astype(np.float64)
+        a.weighted = True
     mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
     ctx, N, n = mc.ctx, mc.numrows, mc.n
     wb = 8 if a.weighted else 0

@@ -209,3 +209,32 @@ def test_hist2d_u16_counters_overflow_is_detected_and_redone(ctx):
         ref = np.bincount(ix + iy * F, minlength=F * F).reshape(F, F)
         assert np.array_equal(H[k], ref), (a, b, H[k].max(), ref.max())
     assert max(H[k].max() for k in range(len(pairs))) > 65535
+
+
+def test_integer_weights_take_exact_u32_path(ctx):
+    """MCMC multiplicities: integral weights use u32 LDS counters (2 stripes) and must be bit-exact."""
+    r = np.random.default_rng(7)
+    N = 250_007
+    s = r.standard_normal((N, 4))
+    w = r.integers(0, 9, N).astype(float)
+    ctx.upload(s, w)
+    F = 256
+    e = [(s[:, c].min() - 0.01, (s[:, c].max() - s[:, c].min() + 0.02) / (F - 1)) for c in range(4)]
+    pairs = [(0, 1), (2, 3), (1, 3)]
+    Hd = ctx.hist2d([a for a, b in pairs], [b for a, b in pairs], [e[a][0] for a, b in pairs], [e[a][1] for a, b in pairs],
+                    [e[b][0] for a, b in pairs], [e[b][1] for a, b in pairs], F).to_host((3, F, F))
+    pre = [ctx.prebin(c, e[c][0], e[c][1], F) for c in range(4)]
+    Hp = ctx.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F).to_host((3, F, F))
+    for k, (a, b) in enumerate(pairs):
+        ix = ((s[:, a] - e[a][0]) / e[a][1] + 0.5).astype(int)
+        iy = ((s[:, b] - e[b][0]) / e[b][1] + 0.5).astype(int)
+        ref = np.bincount(ix + iy * F, weights=w, minlength=F * F).reshape(F, F)
+        assert np.array_equal(Hd[k], ref) and np.array_equal(Hp[k], ref)
+    # a non-integral weight anywhere switches back to fp64 accumulation
+    w2 = w.copy()
+    w2[12345] = 0.5
+    ctx.upload(s, w2)
+    H2 = ctx.hist2d([0], [1], [e[0][0]], [e[0][1]], [e[1][0]], [e[1][1]], F).to_host((F, F))
+    ix = ((s[:, 0] - e[0][0]) / e[0][1] + 0.5).astype(int)
+    iy = ((s[:, 1] - e[1][0]) / e[1][1] + 0.5).astype(int)
+    assert np.allclose(H2, np.bincount(ix + iy * F, weights=w2, minlength=F * F).reshape(F, F), rtol=1e-12, atol=1e-12)
