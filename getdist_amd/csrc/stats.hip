@@ -460,14 +460,6 @@ __global__ void k_sum_partials_batched(const double* __restrict__ part, int nblk
     if (threadIdx.x == 0) out[(int64_t)blockIdx.y * stride + blockIdx.x] = r;
 }
 
-__global__ void k_sum_partials(const double* __restrict__ part, int nblk, int stride, double* __restrict__ out) {
-    __shared__ double red[16];
-    double s = 0;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += part[(int64_t)i * stride + blockIdx.x];
-    const double r = block_sum(s, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = r;
-}
-
 // ---- Gaussian-kernel lag sums: out[l] = sum_i exp(-(x_i - x_{i+k})^2 * c) w_i w_{i+k} -----------------------
 template <bool HAS_W>
 __global__ void k_kde_lag(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
