@@ -341,7 +341,8 @@ class _TncPool:
                 out += self.submit(jobs[a:a + step]).get()
             return _Solved(out)
         n = len(jobs)
-        shares = [list(range(w, n, self.workers)) for w in range(self.workers)]  # interleaved: even cost mix
+        use = max(1, min(self.workers, (n + 3) // 4))  # at least ~4 jobs per worker: fewer pipe round trips
+        shares = [list(range(w, n, use)) for w in range(use)]  # interleaved: even cost mix
         active = []
         for p, idx in zip(self.procs, shares):
             if not idx:
