@@ -107,3 +107,24 @@ def test_settings_and_errors():
         mc.get1DDensity(0, boundary_correction_order=3)
     mc.updateSettings({"smooth_scale_2D": 0.5})
     assert mc.get2DDensity(0, 1).P.max() == 1.0
+
+
+def test_upscaled_grid_through_the_device_optimiser():
+    """Both parameters bounded and strongly anti-correlated: branch C of getAutoBandwidth2D on an upscaled F=576 grid
+    (mcsamples.py:1812-1819, 1396-1409) -- the only way the 2D optimiser sees F > 256."""
+    r = np.random.default_rng(11)
+    n = 60000
+    a = r.standard_normal(4 * n)
+    b = -0.95 * a + np.sqrt(1 - 0.95**2) * r.standard_normal(4 * n)
+    keep = (a > -1.0) & (b < 1.2)
+    s = np.column_stack([a[keep][:n], b[keep][:n]])
+    rng = {"x": (-1.0, None), "y": (None, 1.2)}
+    mc = mcs(samples=s, names=["x", "y"], ranges=rng)
+    orc = ko.OracleSamples(s, names=["x", "y"], ranges=rng)
+    tr = {}
+    o = orc.density_2d(0, 1, trace=tr)
+    d = mc.get2DDensities([(0, 1)])[0]
+    assert tr["branch"] == "C" and o["P"].shape[0] > 256 and d.P.shape == o["P"].shape
+    assert d.bandwidth_branch == "C"
+    assert abs(d.kopt[0] - tr["t_star"]) <= 1e-7 * tr["t_star"]
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
