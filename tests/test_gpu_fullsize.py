@@ -142,3 +142,30 @@ def test_weighted_full_size_properties():
     assert all(x.P.max() == 1.0 for x in d)
     d2 = mc.get2DDensities(pairs)
     assert all(x.P.max() == 1.0 and x.P.shape == (F, F) for x in d2)
+
+
+def test_full_size_grids_match_the_oracle(big):
+    """N = 1e7: complete 1D and 2D densities against the oracle on the same inputs (pairs whose bandwidth does not
+    pass through TNC, so the strict 1e-6 tolerance applies end to end)."""
+    from oracle import kde_oracle as ko
+
+    mc, s = big
+    names = [p.name for p in mc.paramNames.names]
+    ranges = {nm: (mc.ranges.getLower(nm), mc.ranges.getUpper(nm)) for nm in names
+              if mc.ranges.getLower(nm) is not None or mc.ranges.getUpper(nm) is not None}
+    cols = [4, 5, 9]
+    orc = ko.OracleSamples(np.ascontiguousarray(s[:, cols]), names=[names[c] for c in cols],
+                           ranges={k: v for k, v in ranges.items() if k in [names[c] for c in cols]})
+    d1 = mc.get1DDensities(cols)
+    for k in range(3):
+        o = orc.density_1d(k)
+        assert np.max(np.abs(d1[k].P - o["P"])) < 1e-6, names[cols[k]]
+        par = mc.paramNames.names[cols[k]]
+        assert abs(par.N_eff_kde - orc.pars[k].N_eff_kde) <= 1e-9 * par.N_eff_kde
+    for (a, b) in ((0, 2), (1, 2)):  # (p4,p9) both bounded, (p5,p9) one bounded
+        d = mc.get2DDensities([(cols[a], cols[b])])[0]
+        tr = {}
+        o = orc.density_2d(a, b, trace=tr)
+        assert d.bandwidth_branch == tr["branch"]
+        assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6, atol=1e-12)
+        assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[cols[a]], names[cols[b]])
