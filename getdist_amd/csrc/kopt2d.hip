@@ -121,23 +121,27 @@ __global__ void k_power_full(const double2* __restrict__ Z, int F, double* __res
 
 // ---- the per-pair solver ----------------------------------------------------------------------------------------
 struct KoptLds {
-    double* wx;   // MAXF x F
-    double* wy;   // MAXF x F
-    double* res;  // MAXF results + scratch
-    double* red;  // 16
+    double* wx;     // MAXF x F
+    double* wy;     // MAXF x F
+    double* res;    // MAXF results + scratch
+    double* red;    // 16
+    double* times;  // MAXF plug-in times of the current level (one thread computes each; pow() is expensive)
+    double* scale;  // per-level output factor: (-1)^L pi^(2L) / 4 for the even, (2 pi)^L for the odd functionals
 };
 
 // Evaluate m bilinear forms  sum_ij wy_q[i] M[i][j] wx_q[j]  for the weight sets currently in LDS.
-__device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L) {
+// Only rows / columns below kmax are visited: beyond it every weight is < 1e-30 of its form's maximum (see
+// weight_cutoff), which cannot change the fp64 result.
+__device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
     const int jx = threadIdx.x & 255, g = threadIdx.x >> 8;  // 4 row groups x 256 columns
-    const int rows_per = (F + 3) / 4;
-    const int r_lo = g * rows_per, r_hi = min(F, r_lo + rows_per);
+    const int rows_per = (kmax + 3) / 4;
+    const int r_lo = g * rows_per, r_hi = min(kmax, r_lo + rows_per);
     double val[MAXF];
 #pragma unroll
     for (int q = 0; q < MAXF; ++q) val[q] = 0;
-    for (int j0 = 0; j0 < F; j0 += 256) {
+    for (int j0 = 0; j0 < kmax; j0 += 256) {
         const int j = j0 + jx;
-        if (j < F) {
+        if (j < kmax) {
             double acc[MAXF];
 #pragma unroll
             for (int q = 0; q < MAXF; ++q) acc[q] = 0;
@@ -152,15 +156,40 @@ __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptL
                 if (q < m) val[q] = fma(acc[q], L.wx[q * F + j], val[q]);
         }
     }
-    for (int q = 0; q < m; ++q) {
-        const double r = block_sum(val[q], L.red);
-        if (threadIdx.x == 0) L.res[q] = r;
+    // all m block sums with two barriers: per-wave partials -> LDS (wx is free now) -> one thread per form adds them
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < MAXF; ++q)
+        if (q < m) {
+            const double r = wave_sum(val[q]);
+            if (lane == 0) L.wx[q * 16 + wv] = r;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < m) {
+        double r = 0;
+        for (int i = 0; i < KT / 64; ++i) r += L.wx[threadIdx.x * 16 + i];
+        L.res[threadIdx.x] = r;
     }
     __syncthreads();
 }
 
-// even functionals: psi([s0,s1], time) for the forms of one level (all with s0+s1 = Lsum)
-__device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, const double* times, double* out, KoptLds L) {
+// An index beyond which w(k) = k^(2s) exp(-k^2 pi^2 t) is below e^-69 (1e-30) of its maximum for every derivative
+// order s <= Lsum and every plug-in time of the level.  Conservative closed form: the maximum is at least
+// w(1) = exp(-c), c = pi^2 t, and ln k^2 <= ln F^2, so  k^2 >= (69 + c + s ln F^2) / c  suffices.
+__device__ __forceinline__ int weight_cutoff(int F, int Lsum, int m, const double* times) {
+    double tmin = times[0];
+    for (int q = 1; q < m; ++q) tmin = fmin(tmin, times[q]);
+    const double c = PISQ * tmin;
+    if (!(c > 0.0)) return F;  // t = 0 (Brent's left end), negative or NaN plug-in times: no truncation
+    const double k2 = (69.0 + (double)Lsum * 2.0 * log((double)F)) / c + 1.0;
+    if (!(k2 < (double)F * (double)F)) return F;
+    const int k = (int)sqrt(k2) + 2;
+    return k < F ? k : F;
+}
+
+// even functionals: psi([s0,s1], time) for the forms of one level (all with s0+s1 = Lsum); times in L.times
+__device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, double* out, KoptLds L) {
     const int m = Lsum + 1;  // forms [a, Lsum-a], a = 0..Lsum   (m <= MAXF)
     __syncthreads();
     for (int e = threadIdx.x; e < m * F; e += KT) {
@@ -169,18 +198,18 @@ __device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, const 
         if (k > 0) {
             const double I = (double)k * (double)k;
             const double logI = log(I);
-            const double w = -I * (PISQ * times[q]);
+            const double w = -I * (PISQ * L.times[q]);
             vx = exp(w + logI * (double)q);
             vy = exp(w + logI * (double)(Lsum - q));
         }
         L.wx[e] = vx;
         L.wy[e] = vy;
     }
+    const int kmax = weight_cutoff(F, Lsum, m, L.times);
     __syncthreads();
-    bilinear_forms(SQ, F, m, L);
-    const double sgn = (Lsum & 1) ? -1.0 : 1.0;
-    const double ppow = pow(PI, (double)(2 * Lsum));
-    for (int q = 0; q < m; ++q) out[q] = sgn * L.res[q] * ppow / 4.0;
+    bilinear_forms(SQ, F, m, L, kmax);
+    const double sc = L.scale[Lsum];
+    for (int q = 0; q < m; ++q) out[q] = (Lsum & 1 ? -1.0 : 1.0) * L.res[q] * sc / 4.0;
     __syncthreads();
 }
 
@@ -202,16 +231,17 @@ __device__ __forceinline__ double k_odd(int j) {
 // lev[L][a] receives func2d([a, L-a], t).
 __device__ void func2d_levels(const double* __restrict__ SQ, int F, double N, double t, int Lmin, double lev[6][MAXF],
                               KoptLds L) {
-    double times[MAXF];
-    for (int q = 0; q < MAXF; ++q) times[q] = t;
-    psi_level(SQ, F, 5, times, lev[5], L);
+    __syncthreads();
+    if (threadIdx.x < MAXF) L.times[threadIdx.x] = t;
+    psi_level(SQ, F, 5, lev[5], L);
     for (int Ls = 4; Ls >= Lmin; --Ls) {
-        const double cst = (1.0 + pow(0.5, (double)(Ls + 1))) / 3.0;
-        for (int a = 0; a <= Ls; ++a) {
+        if ((int)threadIdx.x <= Ls) {  // one thread per form evaluates its plug-in time (kde_bandwidth.py:191-193)
+            const int a = threadIdx.x;
+            const double cst = (1.0 + pow(0.5, (double)(Ls + 1))) / 3.0;
             const double sum_func = lev[Ls + 1][a + 1] + lev[Ls + 1][a];
-            times[a] = pow(-2.0 * cst * k_even(a) * k_even(Ls - a) / N / sum_func, 1.0 / (2.0 + Ls));
+            L.times[a] = pow(-2.0 * cst * k_even(a) * k_even(Ls - a) / N / sum_func, 1.0 / (2.0 + Ls));
         }
-        psi_level(SQ, F, Ls, times, lev[Ls], L);
+        psi_level(SQ, F, Ls, lev[Ls], L);
     }
 }
 
@@ -223,22 +253,21 @@ __device__ double fixed_point_2d(const double* __restrict__ SQ, int F, double N,
     return (t - time) / time;
 }
 
-// odd functionals: psi_odd for forms [1+2q, Lsum-1-2q]
-__device__ void psi_odd_level(const double* __restrict__ PW, int F, int Lsum, int m, const double* times, double* out,
-                              KoptLds L) {
+// odd functionals: psi_odd for forms [1+2q, Lsum-1-2q]; times in L.times
+__device__ void psi_odd_level(const double* __restrict__ PW, int F, int Lsum, int m, double* out, KoptLds L) {
     __syncthreads();
     for (int e = threadIdx.x; e < m * F; e += KT) {
         const int q = e / F, k = e % F;
         const double f = (k <= (F - 1) / 2) ? (double)k : (double)(k - F);
-        const double w = exp(-(f * f) * (4.0 * PISQ * times[q]));
+        const double w = exp(-(f * f) * (4.0 * PISQ * L.times[q]));
         const int s0 = 1 + 2 * q, s1 = Lsum - s0;
         L.wx[e] = w * pow(f, (double)s0);
         L.wy[e] = w * pow(f, (double)s1);
     }
     __syncthreads();
-    bilinear_forms(PW, F, m, L);
-    const double ppow = pow(2.0 * PI, (double)Lsum);
-    for (int q = 0; q < m; ++q) out[q] = L.res[q] * ppow;
+    bilinear_forms(PW, F, m, L, F);
+    const double sc = L.scale[6 + Lsum / 2];
+    for (int q = 0; q < m; ++q) out[q] = L.res[q] * sc;
     __syncthreads();
 }
 
@@ -255,6 +284,11 @@ __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all
     L.wy = lds + MAXF * F;
     L.res = L.wy + MAXF * F;
     L.red = L.res + 8;
+    L.times = L.red + 16;
+    L.scale = L.times + 8;
+    if (threadIdx.x < 6) L.scale[threadIdx.x] = pow(PI, (double)(2 * threadIdx.x));               // even: pi^(2L)
+    if (threadIdx.x >= 8 && threadIdx.x < 14) L.scale[threadIdx.x - 2] = pow(2.0 * PI, (double)(2 * (threadIdx.x - 8)));  // odd: (2pi)^L, L = 0,2,..,10
+    __syncthreads();
     const int b = blockIdx.x;
     const KoptPair P = pairs[b];
     const double* SQ = SQ_all + (int64_t)b * F * F;
@@ -347,20 +381,22 @@ __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all
         if (P.do_corr) {
             p00 = lev[0][0];
             const double* PW = PW_all + (int64_t)P.pw_index * F * F;
-            double odd[4][MAXF], times[MAXF];
-            for (int q = 0; q < MAXF; ++q) times[q] = t_star;
-            psi_odd_level(PW, F, 10, 5, times, odd[3], L);  // [1,9],[3,7],[5,5],[7,3],[9,1]
+            double odd[4][MAXF];
+            __syncthreads();
+            if (threadIdx.x < MAXF) L.times[threadIdx.x] = t_star;
+            psi_odd_level(PW, F, 10, 5, odd[3], L);  // [1,9],[3,7],[5,5],[7,3],[9,1]
             int li = 2;
             for (int Ls = 8; Ls >= 4; Ls -= 2, --li) {
                 const int m = Ls / 2;  // forms [1+2q, Ls-1-2q]
-                const double cst = 8.0 * (1.0 - pow(2.0, (double)(-Ls - 1))) / 3.0;
-                for (int q = 0; q < m; ++q) {
+                if ((int)threadIdx.x < m) {
+                    const int q = threadIdx.x;
+                    const double cst = 8.0 * (1.0 - pow(2.0, (double)(-Ls - 1))) / 3.0;
                     const int s0 = 1 + 2 * q, s1 = Ls - s0;
                     // func2d_odd([s0+2,s1]) + func2d_odd([s0,s1+2]) : entries q+1 and q of the level above
                     const double sum_func = odd[li + 1][q + 1] + odd[li + 1][q];
-                    times[q] = pow(cst * p00 * k_odd(s0) * k_odd(s1) / (N * N) / (sum_func * sum_func), 1.0 / (3.0 + Ls));
+                    L.times[q] = pow(cst * p00 * k_odd(s0) * k_odd(s1) / (N * N) / (sum_func * sum_func), 1.0 / (3.0 + Ls));
                 }
-                psi_odd_level(PW, F, Ls, m, times, odd[li], L);
+                psi_odd_level(PW, F, Ls, m, odd[li], L);
             }
             p13 = odd[0][0];  // [1,3]
             p31 = odd[0][1];  // [3,1]
@@ -445,7 +481,7 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
         k_power_full<<<dim3(64, nc), 256, 0, ctx->stream>>>(d_Z, F, d_PW);
         GD_KERNEL_CHECK();
     }
-    const size_t lds = ((size_t)2 * MAXF * F + 8 + 16) * 8;
+    const size_t lds = ((size_t)2 * MAXF * F + 8 + 16 + 8 + 16) * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, d_out);
     GD_KERNEL_CHECK();

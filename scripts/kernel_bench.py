@@ -75,6 +75,12 @@ def main():
         ms = timed(ctx, lambda: ctx.hist2d([p[0] for p in pp], [p[1] for p in pp], [e2[p[0]][1] for p in pp], [e2[p[0]][0] for p in pp],
                                            [e2[p[1]][1] for p in pp], [e2[p[1]][0] for p in pp], F, out=out), 3)
         rec("hist2d direct fp64 B=%d" % nb, ms, nb * B2, "algorithmic 24N+8F^2 per pair")
+    # 2D bandwidth optimiser on the 1225 histograms (half with the odd functionals)
+    hp = ctx.hist2d_prebinned([idx[p[0]] for p in pairs], [idx[p[1]] for p in pairs], F, out=out)
+    neff = [float(N)] * len(pairs)
+    for dc in (0, 1):
+        ms = timed(ctx, lambda: ctx.kopt2d(hp, len(pairs), F, neff, [dc] * len(pairs), [1e-4] * len(pairs)), 3)
+        rec("kopt2d B=%d do_corr=%d" % (len(pairs), dc), ms, len(pairs) * 8.0 * F * F, "DCT GEMMs + device Brent + psi functionals")
     info = ctx.device_info()
     print(json.dumps(dict(N=N, n=n, weighted=a.weighted, device=info, kernels=res)))
 
