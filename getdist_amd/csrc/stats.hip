@@ -414,21 +414,21 @@ __global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, doub
 // ---- autocovariance lag sums: out[l] = sum_i d_i d_{i+k0+l},  d = (x-mean)*w ---------------------------------
 #define AL 32     // lags per launch
 #define AT 2048   // rows per tile
-template <bool HAS_W>
+template <bool HAS_W, int NL>
 __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ cols, int64_t ld,
                                                  const int32_t* __restrict__ colidx, const double* __restrict__ w,
                                                  int64_t N, const double* __restrict__ means, int64_t k0,
                                                  double* __restrict__ part) {
-    __shared__ double sB[AT + AL];
+    __shared__ double sB[AT + NL];
     __shared__ double red[16];
     const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
     const double mean = means[blockIdx.y];
-    double acc[AL];
+    double acc[NL];
 #pragma unroll
-    for (int l = 0; l < AL; ++l) acc[l] = 0;
+    for (int l = 0; l < NL; ++l) acc[l] = 0;
     for (int64_t t0 = (int64_t)blockIdx.x * AT; t0 < N; t0 += (int64_t)gridDim.x * AT) {
         __syncthreads();
-        for (int e = threadIdx.x; e < AT + AL; e += 256) {
+        for (int e = threadIdx.x; e < AT + NL; e += 256) {
             const int64_t r = t0 + k0 + e;
             sB[e] = (r < N) ? (x[r] - mean) * (HAS_W ? w[r] : 1.0) : 0.0;
         }
@@ -438,13 +438,13 @@ __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ cols
             if (r < N) {
                 const double a = (x[r] - mean) * (HAS_W ? w[r] : 1.0);
 #pragma unroll
-                for (int l = 0; l < AL; ++l) acc[l] = fma(a, sB[e + l], acc[l]);
+                for (int l = 0; l < NL; ++l) acc[l] = fma(a, sB[e + l], acc[l]);
             }
         }
     }
-    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * AL;
+    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NL;
 #pragma unroll
-    for (int l = 0; l < AL; ++l) {  // unrolled: acc[] must stay in registers
+    for (int l = 0; l < NL; ++l) {  // unrolled: acc[] must stay in registers
         const double r = block_sum(acc[l], red);
         if (threadIdx.x == 0) p[l] = r;
     }
@@ -687,20 +687,29 @@ int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_mean, means, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
     std::vector<double> h((size_t)ncols * AL);
-    for (int32_t done = 0; done < nlags; done += AL) {
+    for (int32_t done = 0; done < nlags;) {
         const dim3 grid(nblk, ncols);
-        if (ctx->w)
-            k_autocov<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
-        else
-            k_autocov<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
+        const int NL = (nlags - done <= 8) ? 8 : AL;  // short first probe: uncorrelated chains stop at lag 1
+        if (NL == 8) {
+            if (ctx->w)
+                k_autocov<true, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
+            else
+                k_autocov<false, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
+        } else {
+            if (ctx->w)
+                k_autocov<true, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
+            else
+                k_autocov<false, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
+        }
         GD_KERNEL_CHECK();
-        k_sum_partials_batched<<<dim3(AL, ncols), 256, 0, ctx->stream>>>(part, nblk, AL, d_out);
+        k_sum_partials_batched<<<dim3(NL, ncols), 256, 0, ctx->stream>>>(part, nblk, NL, d_out);
         GD_KERNEL_CHECK();
-        GD_HIP(hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipMemcpyAsync(h.data(), d_out, (size_t)ncols * NL * 8, hipMemcpyDeviceToHost, ctx->stream));
         GD_HIP(hipStreamSynchronize(ctx->stream));
-        const int take_n = (nlags - done < AL) ? nlags - done : AL;
+        const int take_n = (nlags - done < NL) ? nlags - done : NL;
         for (int c = 0; c < ncols; ++c)
-            for (int l = 0; l < take_n; ++l) out[(size_t)c * nlags + done + l] = h[(size_t)c * AL + l];
+            for (int l = 0; l < take_n; ++l) out[(size_t)c * nlags + done + l] = h[(size_t)c * NL + l];
+        done += take_n;
     }
     return GD_OK;
 }

@@ -810,7 +810,7 @@ class MCSamples:
                 self.paramNames.names[j].N_eff_kde = self.norm**2 / self._sum_w2
             return
         max_off = self.numrows // 10
-        nl = min(32, max_off + 1)
+        nl = min(8, max_off + 1)  # short probe first; correlated chains continue in getCorrelationLength
         lag0 = self.ctx.autocov_lags_batch(todo, self.means[todo], 0, nl)
         kstd, maxoffs = [], []
         for row, j in enumerate(todo):

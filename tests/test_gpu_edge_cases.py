@@ -128,3 +128,34 @@ def test_upscaled_grid_through_the_device_optimiser():
     assert d.bandwidth_branch == "C"
     assert abs(d.kopt[0] - tr["t_star"]) <= 1e-7 * tr["t_star"]
     assert np.max(np.abs(d.P - o["P"])) < 1e-6
+
+
+@pytest.mark.parametrize("rho,weighted", [(0.9, False), (0.97, True), (0.5, False)])
+def test_correlated_chain_neff_matches_oracle(rho, weighted):
+    """AR(1) chains: the autocorrelation scan must run past the 8-lag probe (and past one 32-lag chunk for rho=0.97) and
+    the adaptive Gaussian-kernel lag scan of chains.py:541-572 must take the same path as the reference."""
+    r = np.random.default_rng(int(rho * 100))
+    N = 200_000
+    e = r.standard_normal(N)
+    x = np.empty(N)
+    x[0] = e[0]
+    for i in range(1, N):
+        x[i] = rho * x[i - 1] + np.sqrt(1 - rho * rho) * e[i]
+    y = r.standard_normal(N)
+    s = np.column_stack([x, y])
+    w = r.integers(1, 4, N).astype(float) if weighted else None
+    mc = mcs(samples=s, weights=w, names=["x", "y"])
+    orc = ko.OracleSamples(s, w, names=["x", "y"])
+    for j in range(2):
+        cl = mc.getCorrelationLength(j, weight_units=False)
+        cl_o = orc.correlation_length(s[:, j], weight_units=False)
+        assert abs(cl - cl_o) <= 1e-9 * abs(cl_o), (j, cl, cl_o)
+    mc.prepareParams()
+    for j in range(2):
+        orc.init_param(j)
+        n_o = orc.neff_1d(j)
+        n_g = mc.paramNames.names[j].N_eff_kde
+        assert abs(n_g - n_o) <= 1e-8 * n_o, (j, n_g, n_o)
+    d = mc.get1DDensity("x")
+    o = orc.density_1d(0)
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
