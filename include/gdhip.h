@@ -118,7 +118,9 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
  * gd_prebin: u16 bin-index columns kept on the device for the batched 2D path; d_idx is N u16.
  * gd_hist2d: weighted 2D histogram hist[iy*F+ix] (mcsamples.py:1724-1728) for B pairs, direct from the
  *   fp64 columns (x index from colx with rule `round`, y from coly) -> d_hist B x F x F (device).
- * gd_hist2d_prebinned: same from u16 index columns produced by gd_prebin.
+ * gd_hist2d_prebinned: same from u16 index columns produced by gd_prebin.  LDS counters: fp64 for real weights,
+ *   u32 for unit or integral weights (exact), 16-bit packed for large unit-weight batches with exact overflow
+ *   detection and a u32 redo of the affected pairs -- the result is always the exact weighted count.
  * gd_minmax_affine: min/max over samples of a*x_i + b*x_j (the sheared coordinate p2,
  *   mcsamples.py:1373 + kde_bandwidth.py:77-78); out 2*B.
  * gd_hist2d_sheared: rotated histogram of mcsamples.py:1372-1378: x index = trunc((x_i - xmin)/dx),
@@ -166,8 +168,10 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const doubl
  * gd_density2d: everything after the bandwidth for B pairs sharing F (mcsamples.py:1857-1990):
  *   window synthesis from (rx, ry, corr, winw) (:1863-1867), zero-padded linear FFT convolution via
  *   rocFFT (convolve.py:405-436), linear boundary correction of order bco (0/1) where a parameter has a
- *   limit (:1905-1961; flags[b] bit0/1 = x bot/top, bit2/3 = y bot/top), mbc rounds of multiplicative
- *   bias correction (:1963-1976), normalize("max") (:1990).
+ *   limit (:1905-1961), mbc rounds of multiplicative bias correction (:1963-1976), normalize("max") (:1990).
+ *   flags[b]: bit0/1 = x has_limits_bot/top, bit2/3 = y bot/top (non-periodic axes only, :1688-1703);
+ *   bit4/5 = x/y periodic (circular convolution on the folded grid, convolve.py:215-323; must be equal for the
+ *   whole batch); bit6 = has_prior, i.e. the boundary-correction block applies (defaults to "any of bits 0-3").
  *   d_hist: B x F x F (device, [y][x]); d_P_out: B x F x F (device).  status_out[b] as gd_density1d. */
 int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry,
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
