@@ -88,10 +88,36 @@ def run_c5(N=2_000_000, n=200):
                 F_classes=sorted(set(int(d.P.shape[0]) for d in dens)))
 
 
+def run_latency(N=10_000_000, n=10):
+    """Per-call latency of the drop-in API (what plots.py's per-pair loop would see)."""
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = synth.block_recipe(n, N, weighted=False, stream=31)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    pairs = synth.triangle_pairs(n)
+    for a, b in pairs[:5]:
+        mc.get2DDensity(a, b)
+    t0 = time.perf_counter()
+    for a, b in pairs[5:45]:
+        mc.get2DDensity(a, b)
+    t2 = (time.perf_counter() - t0) / 40
+    mc.get1DDensity(0)
+    t0 = time.perf_counter()
+    for j in range(1, n):
+        mc.get1DDensity(j)
+    t1 = (time.perf_counter() - t0) / (n - 1)
+    t0 = time.perf_counter()
+    mc.get2DDensities(pairs)
+    tb = (time.perf_counter() - t0) / len(pairs)
+    return dict(config="latency", N=N, n=n, get2DDensity_ms=round(t2 * 1e3, 3), get1DDensity_ms=round(t1 * 1e3, 3),
+                batched_2d_ms_per_pair=round(tb * 1e3, 3))
+
+
 def main():
     which = sys.argv[1:] or ["c2", "c4"]
     for c in which:
-        fn = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[c]
+        fn = {"c2": run_c2, "c4": run_c4, "c5": run_c5, "latency": run_latency}[c]
         print(json.dumps(fn()), flush=True)
 
 
