@@ -248,17 +248,17 @@ __global__ void k_box(const double* __restrict__ hist, const double* __restrict_
 }
 
 static int next_fft_size(int n) {
-    // smallest even 2^a 3^b 5^c >= n
+    // smallest 2^a * {1,3,5,9,15} (a >= 4) >= n: a coarse ladder (288, 320, 384, 480, 512, 576, 640, 768, ...) keeps
+    // the number of distinct rocFFT plans small; any zero padding gives the same linear convolution
     int best = 1 << 30;
-    for (long long p2 = 2; p2 < (1 << 28); p2 *= 2)
-        for (long long p3 = 1; p2 * p3 < (1 << 28); p3 *= 3)
-            for (long long p5 = 1; p2 * p3 * p5 < (1 << 28); p5 *= 5) {
-                const long long v = p2 * p3 * p5;
-                if (v >= n && v < best) best = (int)v;
-            }
+    const int odd[5] = {1, 3, 5, 9, 15};
+    for (int a = 4; a < 28; ++a)
+        for (int q = 0; q < 5; ++q) {
+            const long long v = (1LL << a) * odd[q];
+            if (v >= n && v < best) best = (int)v;
+        }
     return best;
 }
-
 
 // Periodic variant (one or both axes periodic, the same for the whole batch).  Histogram-side convolutions are
 // circular on the folded (Ny x Nx) grid -- including along a non-periodic axis, which the reference also wraps

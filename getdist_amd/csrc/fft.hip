@@ -50,26 +50,41 @@ static int get_plan(gd_ctx* ctx, bool forward, int n0, int n1, int batch, FftPla
     return GD_OK;
 }
 
-int gd_fft_r2c_2d(gd_ctx* ctx, int n0, int n1, int batch, const double* d_in, double2* d_out) {
+static int exec_plan(gd_ctx* ctx, bool forward, int n0, int n1, int batch, void* in, void* out) {
     FftPlan* p;
-    int rc = get_plan(ctx, true, n0, n1, batch, &p);
+    int rc = get_plan(ctx, forward, n0, n1, batch, &p);
     if (rc) return rc;
-    void* in[1] = {(void*)d_in};
-    void* out[1] = {(void*)d_out};
-    rocfft_status st = rocfft_execute(p->plan, in, out, p->info);
-    if (st != rocfft_status_success) return gd_fail(ctx, GD_ERR_FFT, "rocfft_execute(r2c) failed: %d", (int)st);
+    void* ib[1] = {in};
+    void* ob[1] = {out};
+    rocfft_status st = rocfft_execute(p->plan, ib, ob, p->info);
+    if (st != rocfft_status_success)
+        return gd_fail(ctx, GD_ERR_FFT, "rocfft_execute(%s %dx%d x%d) failed: %d", forward ? "r2c" : "c2r", n0, n1, batch, (int)st);
     return GD_OK;
 }
 
-int gd_fft_c2r_2d(gd_ctx* ctx, int n0, int n1, int batch, double2* d_in, double* d_out) {
-    FftPlan* p;
-    int rc = get_plan(ctx, false, n0, n1, batch, &p);
-    if (rc) return rc;
-    void* in[1] = {(void*)d_in};
-    void* out[1] = {(void*)d_out};
-    rocfft_status st = rocfft_execute(p->plan, in, out, p->info);
-    if (st != rocfft_status_success) return gd_fail(ctx, GD_ERR_FFT, "rocfft_execute(c2r) failed: %d", (int)st);
+// A rocFFT plan bakes in its batch count and costs 10-100 ms to build.  Small batches (interactive per-pair calls)
+// are therefore executed as power-of-two sub-batches so that only {1,2,4,...,32} plans exist per frame size; large
+// batches (the triangle) use one exact plan, amortised over the job.
+static int exec_batched(gd_ctx* ctx, bool forward, int n0, int n1, int batch, char* in, char* out) {
+    const size_t real_bytes = (size_t)n0 * n1 * 8, cplx_bytes = (size_t)n0 * (n1 / 2 + 1) * 16;
+    const size_t in_stride = forward ? real_bytes : cplx_bytes, out_stride = forward ? cplx_bytes : real_bytes;
+    if (batch >= 64) return exec_plan(ctx, forward, n0, n1, batch, in, out);
+    int done = 0;
+    for (int chunk = 32; chunk >= 1; chunk >>= 1)
+        while (batch - done >= chunk) {
+            int rc = exec_plan(ctx, forward, n0, n1, chunk, in + (size_t)done * in_stride, out + (size_t)done * out_stride);
+            if (rc) return rc;
+            done += chunk;
+        }
     return GD_OK;
+}
+
+int gd_fft_r2c_2d(gd_ctx* ctx, int n0, int n1, int batch, const double* d_in, double2* d_out) {
+    return exec_batched(ctx, true, n0, n1, batch, (char*)d_in, (char*)d_out);
+}
+
+int gd_fft_c2r_2d(gd_ctx* ctx, int n0, int n1, int batch, double2* d_in, double* d_out) {
+    return exec_batched(ctx, false, n0, n1, batch, (char*)d_in, (char*)d_out);
 }
 
 void gd_fft_cache_destroy(gd_ctx* ctx) {

@@ -1572,7 +1572,7 @@ _FFT_SIZE_CACHE = {}
 
 
 def next_fft_size(n):
-    """Smallest even 2^a 3^b 5^c >= n (the frame sizes density2d.hip plans its FFTs for)."""
+    """Smallest 2^a * {1,3,5,9,15} (a >= 4) >= n: the FFT frame ladder density2d.hip plans for."""
     if n in _FFT_SIZE_CACHE:
         return _FFT_SIZE_CACHE[n]
     _FFT_SIZE_CACHE[n] = v = _next_fft_size(n)
@@ -1581,18 +1581,11 @@ def next_fft_size(n):
 
 def _next_fft_size(n):
     best = None
-    p2 = 2
-    while p2 < 4 * n + 8:
-        p3 = 1
-        while p2 * p3 < 4 * n + 8:
-            p5 = 1
-            while p2 * p3 * p5 < 4 * n + 8:
-                v = p2 * p3 * p5
-                if v >= n and (best is None or v < best):
-                    best = v
-                p5 *= 5
-            p3 *= 3
-        p2 *= 2
+    for a in range(4, 28):
+        for odd in (1, 3, 5, 9, 15):
+            v = (1 << a) * odd
+            if v >= n and (best is None or v < best):
+                best = v
     return best
 
 
