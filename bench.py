@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for "
                     "exercising the multi-rank path on a single GPU)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--emulate-world", type=int, default=0, help="measurement aid: time rank 0's share of a W-rank "
+                    "job on one GPU (other ranks' parameter state is replayed from a cached full preparation)")
     ap.add_argument("--cpu-baseline-n", type=int, default=None, help="rows for the CPU sample (default: nsamples)")
     return ap.parse_args()
 
@@ -68,14 +70,23 @@ def reset_caches(mc):
     mc.density1D = {}
 
 
-def one_step(mc, pairs_all, dist, rank, world, torch_device):
+_REPLAY = {}
+
+
+def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     """The timed unit of work.  Returns the list of Density2D this rank produced."""
     from getdist_amd import parallel
 
     reset_caches(mc)
+    if emulate:
+        world = emulate
     my_params = parallel.partition_round_robin(list(range(mc.n)), world, rank)
     mc.prepareParams(my_params)
-    parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
+    if emulate:
+        others = [j for j in range(mc.n) if j not in my_params]
+        parallel.unpack_param_state(mc, _REPLAY["rows"][others])  # what the all-gather would deliver
+    else:
+        parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
     _, my_pairs = parallel.partition_pairs(pairs_all, pair_cost_key_factory(mc), world, rank)
     return mc.get2DDensities(my_pairs)
 
@@ -194,9 +205,14 @@ def main():
             if torch_device is not None:
                 torch.cuda.synchronize()
 
+    if args.emulate_world:
+        from getdist_amd import parallel
+
+        mc.prepareParams()
+        _REPLAY["rows"] = parallel.pack_param_state(mc, list(range(mc.n)))
     dens = None
     for _ in range(args.warmup):
-        dens = one_step(mc, pairs_all, dist, rank, world, torch_device)  # held like the timed results are
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)  # held like the timed results
     if args.warmup > 0:
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
     barrier()
@@ -209,7 +225,7 @@ def main():
         prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dens = one_step(mc, pairs_all, dist, rank, world, torch_device)
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)
     barrier()
     elapsed = time.perf_counter() - t0
     if prof is not None:
@@ -224,7 +240,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     npairs = len(pairs_all)
-    value = npairs * args.steps / elapsed
+    value = npairs * args.steps / elapsed  # with --emulate-world: what W ranks would deliver if all took this long
 
     if rank == 0:
         line = {
@@ -238,7 +254,10 @@ def main():
                        "parallelism": "pairs partitioned over %d GPU(s), samples replicated" % world,
                        "setup_s": {"generate": round(t_gen, 2), "construct_upload_basestats": round(t_ctor, 2)}},
         }
-        if world == 1:
+        if args.emulate_world:
+            line["emulated_world"] = args.emulate_world
+            line["n_gpus"] = args.emulate_world
+        if world == 1 and not args.emulate_world:
             line["roofline"] = binning_kernel_roofline(mc, pairs_all)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.nparams, args.nsamples, args.cpu_baseline_n or args.nsamples)
