@@ -387,7 +387,7 @@ def _get_h_many(jobs, workers=None):
     global _POOL
     if workers is None:
         workers = _tnc_workers()
-    if workers <= 1 or len(jobs) < 16:
+    if workers <= 1 or len(jobs) < 6:
         return _Solved([_get_h(*j) for j in jobs])
     if _POOL is None or _POOL.workers != workers:
         if _POOL is not None:
