@@ -49,16 +49,14 @@ def parse():
     return ap.parse_args()
 
 
-def pair_cost_key_factory(mc):
-    names = mc.paramNames.names
-    corr = mc.getCorrelationMatrix()
-
-    def key(p):
-        c = abs(corr[p[1]][p[0]])
-        bounded = int(names[p[0]].has_limits) + int(names[p[1]].has_limits)
-        return (c > 0.866, bounded, c > 0.2)
-
-    return key
+def pair_cost_classes(mc, pairs):
+    """Cost class per pair (upscaled grid?, #bounded parameters, optimiser vs rule-of-thumb), vectorised."""
+    corr = np.abs(mc.getCorrelationMatrix())
+    lim = np.array([bool(p.has_limits) for p in mc.paramNames.names], dtype=np.int64)
+    a = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+    b = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+    c = corr[b, a]
+    return ((c > 0.866).astype(np.int64) * 100 + (lim[a] + lim[b]) * 10 + (c > 0.2)).tolist()
 
 
 def reset_caches(mc):
@@ -87,7 +85,8 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
         parallel.unpack_param_state(mc, _REPLAY["rows"][others])  # what the all-gather would deliver
     else:
         parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
-    _, my_pairs = parallel.partition_pairs(pairs_all, pair_cost_key_factory(mc), world, rank)
+    classes = dict(zip(pairs_all, pair_cost_classes(mc, pairs_all)))
+    _, my_pairs = parallel.partition_pairs(pairs_all, classes.__getitem__, world, rank)
     return mc.get2DDensities(my_pairs)
 
 
