@@ -75,6 +75,7 @@ SIGNATURES = {
     "gd_hist1d": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, _pd]),
     "gd_bin_indices": (C.c_int, [_p, _i32, _f64, _f64, _i32, _i32, _pi32, _pi64]),
     "gd_prebin": (C.c_int, [_p, _i32, _f64, _f64, _i32, _p]),
+    "gd_prebin_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p)]),
     "gd_hist2d": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _i32, _p]),
     "gd_hist2d_prebinned": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "gd_minmax_affine": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd]),
@@ -385,6 +386,11 @@ class Context:
         buf = buf or self.alloc(self.N * 2 + 64)
         self._check(self.lib.gd_prebin(self.h, int(col), float(binmin), float(width), int(F), buf.ptr))
         return buf
+
+    def prebin_batch(self, cols, binmin, width, F, bufs):
+        cols, binmin, width = _i32arr(cols), _f64arr(binmin), _f64arr(width)
+        arr = (_p * len(cols))(*[b.ptr for b in bufs])
+        self._check(self.lib.gd_prebin_batch(self.h, _ip(cols), len(cols), _dp(binmin), _dp(width), int(F), arr))
 
     def hist2d(self, colx, coly, bx, wx, by, wy, F, out=None):
         colx, coly = _i32arr(colx), _i32arr(coly)

@@ -106,6 +106,42 @@ __global__ void __launch_bounds__(256) k_prebin(const double* __restrict__ x, in
         }
 }
 
+struct PrebinCol {
+    const double* x;
+    unsigned short* idx;
+    double binmin, width;
+};
+
+// all requested index columns in one launch; grid (blocks, ncols)
+__global__ void __launch_bounds__(256) k_prebin_batch(const PrebinCol* __restrict__ colsv, int64_t N, int F) {
+    const PrebinCol C = colsv[blockIdx.y];
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    const int64_t N8 = N & ~(int64_t)7;
+    for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
+        double2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2*>(C.x + i + 2 * q);
+        unsigned int o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = bin_round(v[q].x, C.binmin, C.width), b = bin_round(v[q].y, C.binmin, C.width);
+            o[2 * q] = (unsigned)a < (unsigned)F ? (unsigned)a : 0xFFFFu;
+            o[2 * q + 1] = (unsigned)b < (unsigned)F ? (unsigned)b : 0xFFFFu;
+        }
+        uint4 pk;
+        pk.x = o[0] | (o[1] << 16);
+        pk.y = o[2] | (o[3] << 16);
+        pk.z = o[4] | (o[5] << 16);
+        pk.w = o[6] | (o[7] << 16);
+        *reinterpret_cast<uint4*>(C.idx + i) = pk;
+    }
+    if (gtid == 0)
+        for (int64_t i = N8; i < N; ++i) {
+            const int a = bin_round(C.x[i], C.binmin, C.width);
+            C.idx[i] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
+        }
+}
+
 // ---- 2D -----------------------------------------------------------------------------------------------
 struct Hist2DPair {   // per-pair parameters, device array
     const double* x;  // column for the x index (or x_i of the shear)
@@ -441,6 +477,30 @@ int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, 
     const double* x = ctx->cols + (int64_t)col * ctx->ld;
     k_prebin<<<8 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, (unsigned short*)d_idx_u16);
     GD_KERNEL_CHECK();
+    return GD_OK;
+}
+
+int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                    void* const* d_idx_u16) {
+    GD_REQUIRE(ctx && cols && binmin && width && d_idx_u16 && ncols > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
+    std::vector<PrebinCol> hc((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) {
+        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n && d_idx_u16[c], "bad column / null index buffer");
+        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        hc[c].idx = (unsigned short*)d_idx_u16[c];
+        hc[c].binmin = binmin[c];
+        hc[c].width = width[c];
+    }
+    PrebinCol* d_c = (PrebinCol*)gd_scratch2(ctx, (int64_t)ncols * sizeof(PrebinCol));
+    if (!d_c) return GD_ERR_NOMEM;
+    GD_HIP(hipMemcpyAsync(d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol), hipMemcpyHostToDevice, ctx->stream));
+    int nblk = (8 * ctx->cu_count + ncols - 1) / ncols;
+    if (nblk < 16) nblk = 16;
+    k_prebin_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipStreamSynchronize(ctx->stream));  // hc / d_c lifetime
     return GD_OK;
 }
 

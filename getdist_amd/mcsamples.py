@@ -1315,6 +1315,19 @@ class MCSamples:
         """Copy selected fixed-size items of one device buffer into another (one gather kernel)."""
         self.ctx.gather_items(d_dst, d_src, positions, item_bytes)
 
+    def _index_columns_batch(self, F, wanted):
+        """Build every missing / stale u16 index column of grid size F in ONE launch (wanted: j -> (binmin, width))."""
+        todo = [j for j, bw in wanted.items() if self._idx_cols.get((j, F), (None, None))[1] != bw]
+        if not todo:
+            return
+        bufs = []
+        for j in todo:
+            hit = self._idx_cols.get((j, F))
+            bufs.append(hit[0] if hit is not None else self.ctx.alloc(self.numrows * 2 + 64))
+        self.ctx.prebin_batch(todo, [wanted[j][0] for j in todo], [wanted[j][1] for j in todo], F, bufs)
+        for j, buf in zip(todo, bufs):
+            self._idx_cols[(j, F)] = (buf, wanted[j])
+
     def _index_column(self, j, F, binmin, width):
         key = (j, F)
         hit = self._idx_cols.get(key)
@@ -1386,6 +1399,8 @@ class MCSamples:
         hists = {}
         for F, members in classes.items():
             with _Phase(self, "2d.prebin"):
+                self._index_columns_batch(F, {**{info[k]["j"]: (info[k]["xbinmin"], info[k]["fwx"]) for k in members},
+                                              **{info[k]["j2"]: (info[k]["ybinmin"], info[k]["fwy"]) for k in members}})
                 ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
                 iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
             with _Phase(self, "2d.hist"):
@@ -1471,8 +1486,9 @@ class MCSamples:
             batches = []
             for bounded, sel_all in groups.items():
                 by_S = {}  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
+                small = len(sel_all) < 256  # launch-bound regime: one batch (largest frame) beats several small ones
                 for item in sel_all:
-                    by_S.setdefault(next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
+                    by_S.setdefault(0 if small else next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
                 carry = []
                 sizes = sorted(by_S)
                 for q, S in enumerate(sizes):

@@ -130,6 +130,9 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
 int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
                    int32_t* idx_out, int64_t* n_out_of_range);
 int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16);
+/* several index columns in one launch (d_idx_u16[c] receives column cols[c] binned with binmin[c], width[c]) */
+int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                    void* const* d_idx_u16);
 int gd_hist2d(gd_ctx* ctx, int32_t B, const int32_t* colx, const int32_t* coly, const double* binminx,
               const double* widthx, const double* binminy, const double* widthy, int32_t F, void* d_hist);
 int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
