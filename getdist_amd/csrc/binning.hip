@@ -496,8 +496,9 @@ int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doubl
     PrebinCol* d_c = (PrebinCol*)gd_scratch2(ctx, (int64_t)ncols * sizeof(PrebinCol));
     if (!d_c) return GD_ERR_NOMEM;
     GD_HIP(hipMemcpyAsync(d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol), hipMemcpyHostToDevice, ctx->stream));
-    int nblk = (8 * ctx->cu_count + ncols - 1) / ncols;
-    if (nblk < 16) nblk = 16;
+    int nblk = (int)((ctx->N / 8 + 255) / 256);  // one 8-sample iteration per thread at most, like the single-column kernel
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+    if (nblk < 1) nblk = 1;
     k_prebin_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F);
     GD_KERNEL_CHECK();
     GD_HIP(hipStreamSynchronize(ctx->stream));  // hc / d_c lifetime

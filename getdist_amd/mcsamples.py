@@ -1486,9 +1486,8 @@ class MCSamples:
             batches = []
             for bounded, sel_all in groups.items():
                 by_S = {}  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
-                small = len(sel_all) < 256  # launch-bound regime: one batch (largest frame) beats several small ones
                 for item in sel_all:
-                    by_S.setdefault(0 if small else next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
+                    by_S.setdefault(next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
                 carry = []
                 sizes = sorted(by_S)
                 for q, S in enumerate(sizes):
