@@ -1399,8 +1399,6 @@ class MCSamples:
         hists = {}
         for F, members in classes.items():
             with _Phase(self, "2d.prebin"):
-                self._index_columns_batch(F, {**{info[k]["j"]: (info[k]["xbinmin"], info[k]["fwx"]) for k in members},
-                                              **{info[k]["j2"]: (info[k]["ybinmin"], info[k]["fwy"]) for k in members}})
                 ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
                 iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
             with _Phase(self, "2d.hist"):
