@@ -59,6 +59,7 @@ SIGNATURES = {
     "gd_gather_items": (C.c_int, [_p, _p, _p, _pi32, _i32, _i64]),
     "gd_host_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),
     "gd_host_free": (C.c_int, [_p, _p]),
+    "gd_kde_lag_sums_2d": (C.c_int, [_p, _i32, _i32, _pd, _pi64, _i32, _pd]),
     "gd_autocov_lags_batch": (C.c_int, [_p, _pi32, _i32, _pd, _i64, _i32, _pd]),
     "gd_kde_lag_sums_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pi64, _i32, _pd]),
     "gd_timer_start": (C.c_int, [_p]),
@@ -281,6 +282,14 @@ class Context:
         cols, means = _i32arr(cols), _f64arr(means)
         out = np.zeros((len(cols), nlags))
         self._check(self.lib.gd_autocov_lags_batch(self.h, _ip(cols), len(cols), _dp(means), int(k0), int(nlags), _dp(out)))
+        return out
+
+    def kde_lag_sums_2d(self, coli, colj, kinv3, lags):
+        kinv3 = _f64arr(kinv3)
+        lags = np.ascontiguousarray(lags, dtype=np.int64)
+        out = np.zeros(len(lags))
+        self._check(self.lib.gd_kde_lag_sums_2d(self.h, int(coli), int(colj), _dp(kinv3), lags.ctypes.data_as(_pi64),
+                                                len(lags), _dp(out)))
         return out
 
     def kde_lag_sums_batch(self, cols, inv4s2, lags):

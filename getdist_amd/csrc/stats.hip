@@ -481,8 +481,62 @@ __global__ void k_kde_lag(const double* __restrict__ cols, int64_t ld, const int
     if (threadIdx.x == 0) part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = r;
 }
 
+// 2D variant (chains.py:576-635): sum_i exp(-(d^T Kinv d)/4) w_i w_{i+k}, d = (x_i - x_{i+k}, y_i - y_{i+k})
+template <bool HAS_W>
+__global__ void k_kde_lag_2d(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
+                             int64_t N, double k00, double k01s, double k11, const int64_t* __restrict__ lags,
+                             double* __restrict__ part) {
+    __shared__ double red[16];
+    const int64_t k = lags[blockIdx.y];
+    const int64_t M = N - k;
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        const double dx = x[i] - x[i + k], dy = y[i] - y[i + k];
+        const double diff2 = dx * (k00 * dx) + dx * (k01s * dy) + dy * (k11 * dy);
+        double e = exp(-diff2 / 4.0);
+        if (HAS_W) e = e * w[i] * w[i + k];
+        s += e;
+    }
+    const double r = block_sum(s, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
 // =============================================================================================================
 extern "C" {
+
+int gd_kde_lag_sums_2d(gd_ctx* ctx, int32_t coli, int32_t colj, const double* kinv3, const int64_t* lags, int32_t nlags,
+                       double* out) {
+    GD_REQUIRE(ctx && kinv3 && lags && out && nlags > 0 && nlags <= 64, "bad argument");
+    GD_REQUIRE(ctx->cols && coli >= 0 && coli < ctx->n && colj >= 0 && colj < ctx->n, "bad column");
+    for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
+    int nblk = (8 * ctx->cu_count + nlags - 1) / nlags;
+    if (nblk < 8) nblk = 8;
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+    const int64_t o_l = ((int64_t)nlags * nblk * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, o_l + nlags * 8);
+    if (!base) return GD_ERR_NOMEM;
+    double* part = (double*)base;
+    int64_t* d_lags = (int64_t*)(base + o_l);
+    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
+    const double* x = ctx->cols + (int64_t)coli * ctx->ld;
+    const double* y = ctx->cols + (int64_t)colj * ctx->ld;
+    const dim3 grid(nblk, nlags);
+    // kinv3 = {K00, K01 + K10, K11} of inv(cov)/h^2
+    if (ctx->w)
+        k_kde_lag_2d<true><<<grid, 256, 0, ctx->stream>>>(x, y, ctx->w, ctx->N, kinv3[0], kinv3[1], kinv3[2], d_lags, part);
+    else
+        k_kde_lag_2d<false><<<grid, 256, 0, ctx->stream>>>(x, y, nullptr, ctx->N, kinv3[0], kinv3[1], kinv3[2], d_lags, part);
+    GD_KERNEL_CHECK();
+    std::vector<double> h((size_t)nlags * nblk);
+    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < nlags; ++l) {
+        double sum = 0;
+        for (int b = 0; b < nblk; ++b) sum += h[(size_t)l * nblk + b];
+        out[l] = sum;
+    }
+    return GD_OK;
+}
 
 int gd_weight_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double thresh, double* out4) {
     GD_REQUIRE(ctx && out4, "null argument");

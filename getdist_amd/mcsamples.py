@@ -829,6 +829,42 @@ class MCSamples:
         for row, j in enumerate(todo):
             self.paramNames.names[j].N_eff_kde = self._neff_from_lags(j, kstd[row], maxoffs[row], min_corr, sums[row])
 
+    def getEffectiveSamplesGaussianKDE_2d(self, i, j, h=0.3, maxoff=None, min_corr=0.05):
+        """chains.py:576-635 (used when use_effective_samples_2D is set); lag sums on the GPU, 8 lags per launch."""
+        if self.sampler in ("nested", "uncorrelated"):
+            return self.norm**2 / self._sum_w2
+        i, j = self._col(i), self._col(j)
+        cov = self.getCov(pars=[i, j])
+        if abs(cov[0, 1]) > np.sqrt(cov[0, 0] * cov[1, 1]) * 0.999:
+            return self.getEffectiveSamplesGaussianKDE(i, h=h, min_corr=min_corr)  # totally correlated: 1D estimate
+        kernel_inv = np.linalg.inv(cov) / h**2
+        kinv3 = [kernel_inv[0, 0], kernel_inv[0, 1] + kernel_inv[1, 0], kernel_inv[1, 1]]
+        if maxoff is None:
+            maxoff = int(max(self.getCorrelationLength(i, weight_units=False),
+                             self.getCorrelationLength(j, weight_units=False)) * 1.5) + 4
+        maxoff = min(maxoff, self.numrows // 10)
+        uncorr_len = self.numrows // 2
+        sums = self.ctx.kde_lag_sums_2d(i, j, kinv3, list(range(uncorr_len, uncorr_len + 5)))
+        nav = sum(self.numrows - k for k in range(uncorr_len, uncorr_len + 5))
+        uncorr_term = float(np.sum(sums)) / nav
+        corr0 = self._sum_w2
+        n = float(self.numrows)
+        total = 0.0
+        k = 1
+        done = False
+        while k <= maxoff and not done:
+            lags = list(range(k, min(k + 8, maxoff + 1)))
+            vals = self.ctx.kde_lag_sums_2d(i, j, kinv3, lags)
+            for kk, v in zip(lags, vals):
+                c = v - (n - kk) * uncorr_term
+                if c < min_corr * corr0:
+                    done = True
+                    break
+                total += c
+            k += len(lags)
+        N = corr0 + 2 * total
+        return self.norm**2 / N
+
     def _get1DNeff(self, par, param):
         """mcsamples.py:1230-1235"""
         if par.N_eff_kde is None:
@@ -1140,8 +1176,9 @@ class MCSamples:
             parx, pary = self.paramNames.names[jx], self.paramNames.names[jy]
             if N_eff is None:
                 if self.use_effective_samples_2D and abs(corr) < 0.999:
-                    raise NotImplementedError("use_effective_samples_2D (off by default) is not accelerated")
-                neff = min(self._get1DNeff(parx, jx), self._get1DNeff(pary, jy))
+                    neff = self.getEffectiveSamplesGaussianKDE_2d(jx, jy)  # mcsamples.py:1326-1328
+                else:
+                    neff = min(self._get1DNeff(parx, jx), self._get1DNeff(pary, jy))
             else:
                 neff = N_eff
             has_limits = parx.has_limits or pary.has_limits

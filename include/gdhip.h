@@ -103,6 +103,10 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo
  *   (corr_k and the uncorrelated-term loop of getEffectiveSamplesGaussianKDE, chains.py:514-540). */
 int gd_autocov_lags(gd_ctx* ctx, int32_t col, double mean, int64_t k0, int32_t nlags, double* out);
 int gd_kde_lag_sums(gd_ctx* ctx, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out);
+/* 2D variant (getEffectiveSamplesGaussianKDE_2d, chains.py:576-635): out[l] = sum_i exp(-(d^T K d)/4) w_i w_{i+k_l},
+ * d = (x_i - x_{i+k}, y_i - y_{i+k}), kinv3 = {K00, K01+K10, K11} with K = inv(cov)/h^2 */
+int gd_kde_lag_sums_2d(gd_ctx* ctx, int32_t coli, int32_t colj, const double* kinv3, const int64_t* lags, int32_t nlags,
+                       double* out);
 /* batched over columns in one launch: out is ncols x nlags (per-column mean / inv4s2, shared lag list) */
 int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t k0,
                           int32_t nlags, double* out);

@@ -608,6 +608,42 @@ class OracleSamples:
                 N = corr[0] + 2 * corr[1]
         return self.norm**2 / N
 
+    def neff_gaussian_kde_2d(self, i, j, h=0.3, maxoff=None, min_corr=0.05):
+        """chains.py:576-635"""
+        w = self.weights
+        if self.sampler in ("nested", "uncorrelated"):
+            return self.norm**2 / np.dot(w, w)
+        d1, d2 = self.samples[:, i], self.samples[:, j]
+        cov = self.cov([i, j])
+        if abs(cov[0, 1]) > np.sqrt(cov[0, 0] * cov[1, 1]) * 0.999:
+            return self.neff_gaussian_kde(d1, h=h, min_corr=min_corr)
+        kernel_inv = np.linalg.inv(cov) / h**2
+        if maxoff is None:
+            maxoff = int(max(self.correlation_length(d1, weight_units=False),
+                             self.correlation_length(d2, weight_units=False)) * 1.5) + 4
+        maxoff = min(maxoff, self.numrows // 10)
+        uncorr_len = self.numrows // 2
+        uncorr_term = 0
+        nav = 0
+        for k in range(uncorr_len, uncorr_len + 5):
+            nav += self.numrows - k
+            delta = np.vstack((d1[:-k] - d1[k:], d2[:-k] - d2[k:]))
+            diff2 = np.sum(delta * kernel_inv.dot(delta), 0)
+            uncorr_term += np.dot(np.exp(-diff2 / 4) * w[:-k], w[k:])
+        uncorr_term /= nav
+        corr = np.zeros(maxoff + 1)
+        corr[0] = np.dot(w, w)
+        n = float(self.numrows)
+        for k in range(1, maxoff + 1):
+            delta = np.vstack((d1[:-k] - d1[k:], d2[:-k] - d2[k:]))
+            diff2 = np.sum(delta * kernel_inv.dot(delta), 0)
+            corr[k] = np.dot(np.exp(-diff2 / 4) * w[:-k], w[k:]) - (n - k) * uncorr_term
+            if corr[k] < min_corr * corr[0]:
+                corr[k] = 0
+                break
+        N = corr[0] + 2 * np.sum(corr[1:])
+        return self.norm**2 / N
+
     def neff_1d(self, j):
         """mcsamples.py:1230-1235"""
         par = self.pars[j]
@@ -791,8 +827,9 @@ class OracleSamples:
         S = self.settings
         max_corr = S["max_corr_2D"]
         if S["use_effective_samples_2D"] and abs(corr) < 0.999:
-            raise NotImplementedError("use_effective_samples_2D (off by default) is not restated")
-        N_eff = min(self.neff_1d(jx), self.neff_1d(jy))
+            N_eff = self.neff_gaussian_kde_2d(jx, jy)  # mcsamples.py:1326-1328
+        else:
+            N_eff = min(self.neff_1d(jx), self.neff_1d(jy))
         has_limits = parx.has_limits or pary.has_limits
         do_correlated = not parx.has_limits or not pary.has_limits
 

@@ -159,3 +159,25 @@ def test_correlated_chain_neff_matches_oracle(rho, weighted):
     d = mc.get1DDensity("x")
     o = orc.density_1d(0)
     assert np.max(np.abs(d.P - o["P"])) < 1e-6
+
+
+def test_use_effective_samples_2d_setting():
+    """getEffectiveSamplesGaussianKDE_2d (chains.py:576-635) behind use_effective_samples_2D, iid and AR(1) inputs."""
+    r = np.random.default_rng(21)
+    N = 100_000
+    e = r.standard_normal((N, 2))
+    x = np.empty((N, 2))
+    x[0] = e[0]
+    for i in range(1, N):
+        x[i] = 0.8 * x[i - 1] + 0.6 * e[i]
+    x[:, 1] = 0.5 * x[:, 0] + x[:, 1]
+    iid = np.column_stack([np.abs(r.standard_normal(N)), r.standard_normal(N)])
+    for s, rng in ((x, None), (iid, {"param1": (0, None)})):
+        mc = mcs(samples=s, ranges=rng, settings={"use_effective_samples_2D": True})
+        orc = ko.OracleSamples(s, ranges=rng, settings={"use_effective_samples_2D": True})
+        n_g = mc.getEffectiveSamplesGaussianKDE_2d(0, 1)
+        n_o = orc.neff_gaussian_kde_2d(0, 1)
+        assert abs(n_g - n_o) <= 1e-8 * n_o, (n_g, n_o)
+    d = mc.get2DDensity(0, 1)  # bounded pair: no TNC, strict tolerance
+    o = orc.density_2d(0, 1)
+    assert np.max(np.abs(d.P - o["P"])) < 1e-6
