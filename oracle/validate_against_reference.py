@@ -96,6 +96,23 @@ def compare_convergence():
     return e <= 1e-13
 
 
+def compare_neff_2d():
+    """getEffectiveSamplesGaussianKDE_2d and the use_effective_samples_2D branch of getAutoBandwidth2D."""
+    zoo = {fx["name"]: fx for fx in fixture_zoo()}
+    ok = True
+    for nm, pairs in (("block10_weighted", [(0, 1), (5, 6), (8, 9)]), ("c1_bounded", [(0, 3), (2, 3)])):
+        fx = zoo[nm]
+        st = {"use_effective_samples_2D": True}
+        ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"], settings=st)
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], settings=st)
+        for a, b in pairs:
+            e1 = relerr(orc.neff_gaussian_kde_2d(a, b), ref.getEffectiveSamplesGaussianKDE_2d(a, b))
+            e2 = relerr(orc.density_2d(a, b)["P"], ref.get2DDensity(fx["names"][a], fx["names"][b]).P)
+            ok &= e1 <= 1e-12 and e2 <= 1e-10
+    print(("ok  " if ok else "FAIL") + " 2D effective sample number + densities with use_effective_samples_2D")
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -108,6 +125,7 @@ def compare_fft_numbers():
 def main():
     ok = compare_fft_numbers()
     ok &= compare_convergence()
+    ok &= compare_neff_2d()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")
