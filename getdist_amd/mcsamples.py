@@ -519,6 +519,39 @@ class MCSamples:
             raise NotImplementedError("alternative weights are not resident on the device")
         return ParamConfidenceData(self._col(paramVec), start, self.numrows if end is None else end)
 
+    def getFractionIndices(self, weights, n):
+        """mcsamples.py:668-680: row indices splitting the total weight into n equal parts"""
+        if weights is None:
+            weights = np.ones(self.numrows)
+        cumsum = np.cumsum(weights)
+        return np.append(np.searchsorted(cumsum, np.linspace(0, 1, n, endpoint=False) * self.norm), self.numrows)
+
+    def getSplitTests(self, test_confidence=0.95, max_split_tests=4):
+        """
+        The numbers of the SplitTest block of getConvergeTests (mcsamples.py:1005-1034): for n = 2..max_split_tests
+        splits of the rows, rms over the splits of the change in the upper / lower quantile, in units of the standard
+        deviation.  Returns an array (nparam, max_split_tests-1, 2) ordered [upper, lower] like the reference's table.
+        Every (row range) needs one batched quantile-select launch over all parameters.
+        """
+        if self.needs_update:
+            self.updateBaseStatistics()
+        limits = np.array([1 - (1 - test_confidence) / 2, (1 - test_confidence) / 2])
+        cols = list(range(self.n))
+
+        def conf(lo, hi):
+            norm = self.norm if (lo == 0 and hi == self.numrows) else self.ctx.weight_stats(int(lo), int(hi))["norm"]
+            return self.ctx.quantiles(cols, np.tile(norm * limits, (self.n, 1)), lo=int(lo), hi=int(hi))
+
+        confids = conf(0, self.numrows)
+        out = np.zeros((self.n, max_split_tests - 1, 2))
+        for ix in range(max_split_tests - 1):
+            split_n = 2 + ix
+            frac = self.getFractionIndices(self.weights, split_n)
+            for f1, f2 in zip(frac[:-1], frac[1:]):
+                out[:, ix, :] += (conf(f1, f2) - confids) ** 2
+            out[:, ix, :] = np.sqrt(out[:, ix, :] / split_n) / self.sddev[:, None]
+        return out
+
     def getConvergeTests(self, test_confidence=0.95, writeDataToFile=False, what=("MeanVar", "GelmanRubin"),
                          filename=None, feedback=False):
         """
@@ -528,7 +561,7 @@ class MCSamples:
         if writeDataToFile or filename:
             raise NotImplementedError("file output is outside the accelerated path")
         for w in what:
-            if w not in ("MeanVar", "GelmanRubin"):
+            if w not in ("MeanVar", "GelmanRubin", "SplitTest"):
                 raise NotImplementedError("convergence test %s is outside the accelerated path" % w)
         lines = ""
         nchains = 0 if self.chain_offsets is None else len(self.chain_offsets) - 1
@@ -551,6 +584,15 @@ class MCSamples:
                 logging.warning(summary)
             if feedback:
                 print(summary)
+            lines += "\n"
+        if "SplitTest" in what:
+            lines += "Split tests: rms_n([delta(upper/lower quantile)]/sd) n={2,3,4}, limit=%.0f%%:\n" % (
+                100 * self.converge_test_limit)
+            lines += "i.e. mean sample splitting change in the quantiles in units of the st. dev.\n\n"
+            st = self.getSplitTests(test_confidence)
+            for j, nm in enumerate(self.paramNames.list()):
+                for endb, typestr in enumerate(["upper", "lower"]):
+                    lines += "%-20s" % nm + "".join("%9.4f" % st[j, ix, endb] for ix in range(st.shape[1])) + " %s\n" % typestr
             lines += "\n"
         return lines
 

@@ -113,6 +113,21 @@ def golden_margestats(fx):
     return out
 
 
+def golden_split_tests(fx, test_confidence=0.95, max_split_tests=4):
+    """SplitTest numbers recomputed with the reference's own confidence()/getFractionIndices (mcsamples.py:1005-1034)."""
+    ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    limits = np.array([1 - (1 - test_confidence) / 2, (1 - test_confidence) / 2])
+    out = np.zeros((ref.n, max_split_tests - 1, 2))
+    fracs = [ref.getFractionIndices(ref.weights, i + 2) for i in range(max_split_tests - 1)]
+    for j in range(ref.n):
+        confids = ref.confidence(ref.samples[:, j], limits)
+        for ix, frac in enumerate(fracs):
+            for f1, f2 in zip(frac[:-1], frac[1:]):
+                out[j, ix, :] += (ref.confidence(ref.samples[:, j], limits, start=f1, end=f2) - confids) ** 2
+            out[j, ix, :] = np.sqrt(out[j, ix, :] / (2 + ix)) / ref.sddev[j]
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -143,6 +158,8 @@ def main():
     zoo = {fx["name"]: fx for fx in fixture_zoo()}
     for nm in ("shapes", "c1_bounded", "block10_weighted"):
         np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
+    np.savez_compressed(os.path.join(HERE, "splittests.npz"),
+                        **{nm: golden_split_tests(zoo[nm]) for nm in ("shapes_intweights", "c1_bounded", "block10_weighted")})
     for fx in zoo.values():
         out = golden_for_fixture(**fx)
         path = os.path.join(HERE, "fixture_%s.npz" % fx["name"])
