@@ -62,6 +62,7 @@ SIGNATURES = {
     "gd_kde_lag_sums_2d": (C.c_int, [_p, _i32, _i32, _pd, _pi64, _i32, _pd]),
     "gd_autocov_lags_batch": (C.c_int, [_p, _pi32, _i32, _pd, _i64, _i32, _pd]),
     "gd_kde_lag_sums_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pi64, _i32, _pd]),
+    "gd_autocov_lags_range_batch": (C.c_int, [_p, _pi32, _i32, _pd, _i64, _i64, _i64, _i32, _pd]),
     "gd_timer_start": (C.c_int, [_p]),
     "gd_timer_stop_ms": (C.c_int, [_p, _pd]),
     "gd_upload": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
@@ -282,6 +283,13 @@ class Context:
         cols, means = _i32arr(cols), _f64arr(means)
         out = np.zeros((len(cols), nlags))
         self._check(self.lib.gd_autocov_lags_batch(self.h, _ip(cols), len(cols), _dp(means), int(k0), int(nlags), _dp(out)))
+        return out
+
+    def autocov_lags_range_batch(self, cols, means, lo, hi, k0, nlags):
+        cols, means = _i32arr(cols), _f64arr(means)
+        out = np.zeros((len(cols), nlags))
+        self._check(self.lib.gd_autocov_lags_range_batch(self.h, _ip(cols), len(cols), _dp(means), int(lo), int(hi), int(k0),
+                                                         int(nlags), _dp(out)))
         return out
 
     def kde_lag_sums_2d(self, coli, colj, kinv3, lags):

@@ -416,12 +416,13 @@ __global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, doub
 #define AT 2048   // rows per tile
 template <bool HAS_W, int NL>
 __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ cols, int64_t ld,
-                                                 const int32_t* __restrict__ colidx, const double* __restrict__ w,
-                                                 int64_t N, const double* __restrict__ means, int64_t k0,
+                                                 const int32_t* __restrict__ colidx, const double* __restrict__ w_all,
+                                                 int64_t row0, int64_t N, const double* __restrict__ means, int64_t k0,
                                                  double* __restrict__ part) {
     __shared__ double sB[AT + NL];
     __shared__ double red[16];
-    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
+    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld + row0;  // rows [row0, row0+N) of the column
+    const double* w = HAS_W ? w_all + row0 : nullptr;
     const double mean = means[blockIdx.y];
     double acc[NL];
 #pragma unroll
@@ -718,8 +719,16 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
 
 int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t k0,
                           int32_t nlags, double* out) {
+    GD_REQUIRE(ctx, "null context");
+    return gd_autocov_lags_range_batch(ctx, cols, ncols, means, 0, ctx->N, k0, nlags, out);
+}
+
+int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t row_lo,
+                                int64_t row_hi, int64_t k0, int32_t nlags, double* out) {
     GD_REQUIRE(ctx && cols && means && out && nlags > 0 && ncols > 0, "bad argument");
     GD_REQUIRE(ctx->cols && k0 >= 0, "bad lag / no samples");
+    GD_REQUIRE(row_lo >= 0 && row_hi <= ctx->N && row_lo < row_hi, "bad row range");
+    const int64_t NR = row_hi - row_lo;
     for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
     int nblk = (4 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk < 16) nblk = 16;
@@ -746,14 +755,14 @@ int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
         const int NL = (nlags - done <= 8) ? 8 : AL;  // short first probe: uncorrelated chains stop at lag 1
         if (NL == 8) {
             if (ctx->w)
-                k_autocov<true, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
+                k_autocov<true, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, row_lo, NR, d_mean, k0 + done, part);
             else
-                k_autocov<false, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
+                k_autocov<false, 8><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, row_lo, NR, d_mean, k0 + done, part);
         } else {
             if (ctx->w)
-                k_autocov<true, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_mean, k0 + done, part);
+                k_autocov<true, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, row_lo, NR, d_mean, k0 + done, part);
             else
-                k_autocov<false, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_mean, k0 + done, part);
+                k_autocov<false, AL><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, row_lo, NR, d_mean, k0 + done, part);
         }
         GD_KERNEL_CHECK();
         k_sum_partials_batched<<<dim3(NL, ncols), 256, 0, ctx->stream>>>(part, nblk, NL, d_out);

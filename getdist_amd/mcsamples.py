@@ -526,6 +526,46 @@ class MCSamples:
         cumsum = np.cumsum(weights)
         return np.append(np.searchsorted(cumsum, np.linspace(0, 1, n, endpoint=False) * self.norm), self.numrows)
 
+    def getCorrLengths(self, min_corr=0.05):
+        """
+        The numbers of the CorrLengths block of getConvergeTests (mcsamples.py:941-962): per parameter, the weight-unit
+        autocorrelation length from the chain-averaged autocovariance (each chain about its own mean), summed up to the
+        first lag at or below 5 %.  Lag sums per chain run on the GPU in 32-lag chunks with early exit.
+        """
+        if self.chain_offsets is None:
+            raise WeightedSampleError("Samples were not combined from separate chains")
+        if self.needs_update:
+            self.updateBaseStatistics()
+        ranges = list(zip(self.chain_offsets[:-1], self.chain_offsets[1:]))
+        stats = self.getSeparateChainStats(self.n)
+        maxoff = int(min((b - a) // 10 for a, b in ranges))
+        cols = list(range(self.n))
+        corr_rows = [[] for _ in cols]
+        result = [None] * self.n
+        k0 = 0
+        while k0 <= maxoff and any(r is None for r in result):
+            nl = min(32, maxoff + 1 - k0)
+            chunk = np.zeros((self.n, nl))
+            for (a, b), (cmeans, _, _) in zip(ranges, stats):
+                nc = int(b - a)
+                lags = self.ctx.autocov_lags_range_batch(cols, cmeans, int(a), int(b), k0, nl)
+                chunk += lags / (nc - np.arange(k0, k0 + nl)) * nc  # normalize=True, weight_units, times chain.norm
+            chunk /= (self.norm * self.vars)[:, None]
+            for j in cols:
+                if result[j] is not None:
+                    continue
+                corr_rows[j].extend(chunk[j].tolist())
+                c = np.array(corr_rows[j])
+                below = np.nonzero(~(c > min_corr * c[0]))[0]
+                if below.size:
+                    result[j] = c[0] + 2 * float(np.sum(c[1:int(below[0])]))
+            k0 += nl
+        for j in cols:
+            if result[j] is None:
+                result[j] = corr_rows[j][0]  # argmin of an all-True mask is 0
+        self.indep_thin = max(result)
+        return np.array(result)
+
     def getSplitTests(self, test_confidence=0.95, max_split_tests=4):
         """
         The numbers of the SplitTest block of getConvergeTests (mcsamples.py:1005-1034): for n = 2..max_split_tests
@@ -561,10 +601,17 @@ class MCSamples:
         if writeDataToFile or filename:
             raise NotImplementedError("file output is outside the accelerated path")
         for w in what:
-            if w not in ("MeanVar", "GelmanRubin", "SplitTest"):
+            if w not in ("MeanVar", "GelmanRubin", "SplitTest", "CorrLengths"):
                 raise NotImplementedError("convergence test %s is outside the accelerated path" % w)
         lines = ""
         nchains = 0 if self.chain_offsets is None else len(self.chain_offsets) - 1
+        if "CorrLengths" in what:
+            lines += ("Parameter autocorrelation lengths (effective number of samples N_eff = tot weight/weight length)\n\n"
+                      + "%-20s%15s %15s %15s\n" % ("", "Weight Length", "Sample length", "N_eff"))
+            for nm, Nw in zip(self.paramNames.list(), self.getCorrLengths()):
+                form = "%15.2f" if self.mean_mult > 1 else "%15.2E"
+                lines += "%-20s" % nm + form % Nw + " %15.2f %15i\n" % (Nw / self.mean_mult, self.norm / Nw)
+            lines += "\n"
         if nchains > 1 and "MeanVar" in what:
             lines += "\nmean convergence stats using remaining chains\nparam sqrt(var(chain mean)/mean(chain var))\n\n"
             for nm, v in zip(self.paramNames.list(), self.getMeanVarTest()):

@@ -112,6 +112,9 @@ int gd_autocov_lags_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
                           int32_t nlags, double* out);
 int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* inv4s2, const int64_t* lags,
                           int32_t nlags, double* out);
+/* the same lag sums restricted to rows [row_lo,row_hi) (one chain of a multi-chain set, mcsamples.py:941-962) */
+int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, int64_t row_lo,
+                                int64_t row_hi, int64_t k0, int32_t nlags, double* out);
 
 /* ---------------------------------------------------------------- binning ----------------------
  * Index rule (mcsamples.py:1497): ix = (int)((x - binmin)/fine_width + 0.5), IEEE fp64, no FMA

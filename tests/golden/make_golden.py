@@ -148,6 +148,17 @@ def golden_convergence():
             within[j] += np.dot(ch.weights, ch.diffs[j] ** 2)
         within[j] /= ref.norm
     out["meanvar"] = np.sqrt(between / within)
+    # CorrLengths block (mcsamples.py:941-962)
+    maxoff = np.min([chain.weights.size // 10 for chain in chainlist])
+    lens = []
+    for j in range(ref.n):
+        corr = np.zeros(maxoff + 1)
+        for chain in chainlist:
+            corr += chain.getAutocorrelation(j, maxoff, normalized=False) * chain.norm
+        corr /= ref.norm * ref.vars[j]
+        ix = np.argmin(corr > 0.05 * corr[0])
+        lens.append(corr[0] + 2 * np.sum(corr[1:ix]))
+    out["corr_lengths"] = np.array(lens)
     return out
 
 

@@ -151,6 +151,8 @@ def test_gelman_rubin_golden():
     assert gu.relerr(D, g["gr_eigenvalues"]) < 1e-9
     assert abs(mc.getGelmanRubin() - float(g["gr"])) < 1e-9 * float(g["gr"])
     assert gu.relerr(mc.getMeanVarTest(), g["meanvar"]) < 1e-9
+    assert gu.relerr(mc.getCorrLengths(), g["corr_lengths"]) < 1e-9
+    assert "autocorrelation lengths" in mc.getConvergeTests(what=("CorrLengths",))
 
 
 def test_api_extras(zoo):
