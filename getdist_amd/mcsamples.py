@@ -405,7 +405,7 @@ class MCSamples:
 
     def __init__(self, root=None, ini=None, settings=None, ranges=None, samples=None, weights=None, loglikes=None,
                  temperature=None, names=None, labels=None, label=None, name_tag=None, sampler=None, ignore_rows=0,
-                 device=0, **kwargs):
+                 device=0, _context_factory=None, **kwargs):
         if root is not None or ini is not None:
             raise NotImplementedError("chain-file / ini loading is outside the accelerated path; pass arrays")
         if samples is None:
@@ -448,7 +448,9 @@ class MCSamples:
             setattr(self, k, v)
         if settings:
             self.updateSettings(settings, doUpdate=False)
-        self.ctx = Context(device)
+        # _context_factory is a TEST hook (tests/fake_ctx.py drives the host logic on CPU); the product always uses
+        # the HIP library and raises if it or a GPU is missing
+        self.ctx = (_context_factory or Context)(device)
         self._timing = os.environ.get("GETDIST_AMD_TIMING", "0") == "1"
         self.timings = {}
         self.density1D = {}

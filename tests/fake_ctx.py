@@ -1,0 +1,346 @@
+"""
+TEST DOUBLE of getdist_amd._lib.Context for the CPU (`-m "not gpu"`) tier.
+
+It answers every Context call the host layer makes (getdist_amd/mcsamples.py, bench.one_step) with numpy / the
+oracle, so the host logic -- ranges and limits, branch selection, batching, grouping by grid/frame class, the
+asynchronous TNC pool, result assembly, the multi-rank partition -- can be exercised without a GPU.  It is test
+infrastructure only: nothing in the product imports it, and it is NOT a fallback (MCSamples only uses it when a test
+passes `_context_factory=`).
+"""
+
+import numpy as np
+from scipy import fftpack
+
+from oracle import kde_oracle as ko
+
+
+class FakeBuf:
+    def __init__(self, arr=None, nbytes=0):
+        self.a = arr
+        self.nbytes = nbytes
+        self.ptr = id(self)
+
+    def free(self):
+        self.a = None
+
+    def to_host(self, shape, dtype=np.float64, offset_bytes=0, pinned=False):
+        return np.array(self.a, dtype=dtype).reshape(shape).copy()
+
+    def to_host_async(self, shape, dtype=np.float64):
+        return self.to_host(shape, dtype)
+
+    def from_host(self, arr, offset_bytes=0):
+        self.a = np.array(arr)
+
+
+class FakeContext:
+    calls = None  # class-level call log for tests that count launches
+
+    def __init__(self, device=0):
+        self.device = device
+        self.N = self.n = 0
+        self.log = []
+
+    # ---- plumbing
+    def close(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def copy_sync(self):
+        pass
+
+    def reserve_pinned_twin(self):
+        pass
+
+    def timer_start(self):
+        pass
+
+    def timer_stop_ms(self):
+        return 0.0
+
+    def alloc(self, nbytes):
+        return FakeBuf(None, nbytes)
+
+    def device_info(self):
+        return dict(cu_count=1, lds_bytes=0, hbm_total=0, hbm_free=0, clock_khz=0, wave=64)
+
+    def gather_items(self, dst, src, index, item_bytes):
+        dst.a = np.array(src.a)[np.asarray(index)]
+
+    # ---- sample set
+    def upload(self, samples, weights=None):
+        self.s = np.asarray(samples, dtype=np.float64)
+        if self.s.ndim == 1:
+            self.s = self.s.reshape(-1, 1)
+        self.N, self.n = self.s.shape
+        self.w = None if weights is None else np.asarray(weights, dtype=np.float64)
+        self.weighted = self.w is not None
+
+    def _w(self, lo=0, hi=None):
+        hi = self.N if hi is None else hi
+        return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
+
+    # ---- moments
+    def weight_stats(self, lo=0, hi=None, thresh=np.inf):
+        w = self._w(lo, hi)
+        return dict(norm=float(np.sum(w)), max_w=float(np.max(w)), sum_w2=float(np.dot(w, w)), n_above=float(np.sum(w > thresh)))
+
+    def col_stats(self, lo=0, hi=None):
+        hi = self.N if hi is None else hi
+        s, w = self.s[lo:hi], self._w(lo, hi)
+        norm = np.sum(w)
+        means = w.dot(s) / norm
+        var = np.array([w.dot((s[:, i] - means[i]) ** 2) / norm for i in range(self.n)])
+        return np.column_stack([s.min(axis=0), s.max(axis=0), means, var])
+
+    def cov(self, cols=None, lo=0, hi=None):
+        hi = self.N if hi is None else hi
+        cols = list(range(self.n)) if cols is None else list(cols)
+        s, w = self.s[lo:hi][:, cols], self._w(lo, hi)
+        norm = np.sum(w)
+        means = w.dot(s) / norm
+        d = s - means
+        return means, (d * w[:, None]).T @ d / norm, float(norm)
+
+    def quantiles(self, cols, targets, lo=0, hi=None):
+        hi = self.N if hi is None else hi
+        targets = np.asarray(targets, dtype=float).reshape(len(cols), -1)
+        out = np.zeros_like(targets)
+        w = self._w(lo, hi)
+        for r, c in enumerate(cols):
+            x = self.s[lo:hi, c]
+            idx = x.argsort()
+            cum = np.cumsum(w[idx])
+            out[r] = x[idx[np.minimum(np.searchsorted(cum, targets[r]), len(idx) - 1)]]
+        return out
+
+    # ---- lag sums
+    def autocov_lags_range_batch(self, cols, means, lo, hi, k0, nlags):
+        out = np.zeros((len(cols), nlags))
+        w = self._w(lo, hi)
+        for r, (c, m) in enumerate(zip(cols, means)):
+            d = (self.s[lo:hi, c] - m) * w
+            for l in range(nlags):
+                k = k0 + l
+                out[r, l] = np.dot(d[:len(d) - k], d[k:]) if k < len(d) else 0.0
+        return out
+
+    def autocov_lags_batch(self, cols, means, k0, nlags):
+        return self.autocov_lags_range_batch(cols, means, 0, self.N, k0, nlags)
+
+    def autocov_lags(self, col, mean, k0, nlags):
+        return self.autocov_lags_batch([col], [mean], k0, nlags)[0]
+
+    def kde_lag_sums_batch(self, cols, inv4s2, lags):
+        w = self._w()
+        out = np.zeros((len(cols), len(lags)))
+        for r, (c, cc) in enumerate(zip(cols, inv4s2)):
+            x = self.s[:, c]
+            for q, k in enumerate(lags):
+                out[r, q] = np.dot(np.exp(-((x[:-k] - x[k:]) ** 2) * cc) * w[:-k], w[k:])
+        return out
+
+    def kde_lag_sums(self, col, inv4s2, lags):
+        return self.kde_lag_sums_batch([col], [inv4s2], lags)[0]
+
+    def kde_lag_sums_2d(self, coli, colj, kinv3, lags):
+        w = self._w()
+        x, y = self.s[:, coli], self.s[:, colj]
+        out = np.zeros(len(lags))
+        for q, k in enumerate(lags):
+            dx, dy = x[:-k] - x[k:], y[:-k] - y[k:]
+            out[q] = np.dot(np.exp(-(kinv3[0] * dx * dx + kinv3[1] * dx * dy + kinv3[2] * dy * dy) / 4) * w[:-k], w[k:])
+        return out
+
+    # ---- binning
+    def hist1d(self, cols, binmin, width, F):
+        w = self._w()
+        return np.array([np.bincount(((self.s[:, c] - b) / wd + 0.5).astype(int), weights=w, minlength=F)[:F]
+                         for c, b, wd in zip(cols, binmin, width)])
+
+    def prebin(self, col, binmin, width, F, buf=None):
+        self.log.append(("prebin", col, F))
+        return FakeBuf(((self.s[:, col] - binmin) / width + 0.5).astype(np.int64))
+
+    def prebin_batch(self, cols, binmin, width, F, bufs):
+        for c, b, wd, buf in zip(cols, binmin, width, bufs):
+            buf.a = ((self.s[:, c] - b) / wd + 0.5).astype(np.int64)
+
+    def hist2d_prebinned(self, idx_x, idx_y, F, out=None):
+        self.log.append(("hist2d_prebinned", len(idx_x), F))
+        w = self._w()
+        H = np.array([np.bincount(bx.a + by.a * F, weights=w, minlength=F * F).reshape(F, F) for bx, by in zip(idx_x, idx_y)])
+        return FakeBuf(H)
+
+    def minmax_affine(self, coli, colj, a, b):
+        return np.array([[np.min(aa * self.s[:, i] + bb * self.s[:, j]), np.max(aa * self.s[:, i] + bb * self.s[:, j])]
+                         for i, j, aa, bb in zip(coli, colj, a, b)])
+
+    def hist2d_sheared(self, coli, colj, r0, r1, xmin, dx, ymin, dy, F, out=None):
+        w = self._w()
+        H = []
+        for i, j, a, b, x0, ddx, y0, ddy in zip(coli, colj, r0, r1, xmin, dx, ymin, dy):
+            b1 = ((self.s[:, i] - x0) / ddx).astype(int)
+            b2 = (((a * self.s[:, i] + b * self.s[:, j]) - y0) / ddy).astype(int)
+            H.append(np.bincount(b1 + b2 * F, weights=w, minlength=F * F).reshape(F, F))
+        return FakeBuf(np.array(H))
+
+    # ---- 1D density
+    def dct1d(self, hist):
+        hist = np.asarray(hist, dtype=float)
+        return np.array([fftpack.dct(h / np.sum(h)) for h in hist])
+
+    def density1d(self, hist, smooth, winw, flags, bco, mbc):
+        hist = np.asarray(hist, dtype=float)
+        B, F = hist.shape
+        P_out = np.zeros_like(hist)
+        status = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            bins = hist[b]
+            bot, top, periodic = bool(flags[b] & 1), bool(flags[b] & 2), bool(flags[b] & 4)
+            kernel = ko.Kernel1D(int(winw[b]), smooth[b])
+            w_ = int(winw[b])
+            mode = "periodic" if periodic else "same"
+            P = ko.conv1d(bins, kernel.Win, mode)
+            if (bot or top) and not periodic and bco >= 0:
+                mask = np.ones(F + 2 * w_)
+                if bot:
+                    mask[w_] = 0.5
+                    mask[:w_] = 0
+                if top:
+                    mask[-(w_ + 1)] = 0.5
+                    mask[-w_:] = 0
+                a0 = ko.conv1d(mask, kernel.Win, "valid")
+                ix = np.nonzero(a0 * P)
+                a0 = a0[ix]
+                normed = P[ix] / a0
+                if bco == 0:
+                    P[ix] = normed
+                else:
+                    xWin = kernel.Win * kernel.x
+                    a1 = ko.conv1d(mask, xWin, "valid")[ix]
+                    a2 = ko.conv1d(mask, xWin * kernel.x, "valid")[ix]
+                    xP = ko.conv1d(bins, xWin, "same")[ix]
+                    if bco == 1:
+                        corrected = (P[ix] * a2 - xP * a1) / (a0 * a2 - a1**2)
+                    else:
+                        a3 = ko.conv1d(mask, xWin * kernel.x**2, "valid")[ix]
+                        a4 = ko.conv1d(mask, xWin * kernel.x**3, "valid")[ix]
+                        x2P = ko.conv1d(bins, xWin * kernel.x, "same")[ix]
+                        denom = a4 * a2 * a0 - a4 * a1**2 - a2**3 - a3**2 * a0 + 2 * a1 * a2 * a3
+                        corrected = (P[ix] * (a4 * a2 - a3**2) + xP * (a2 * a3 - a4 * a1) + x2P * (a3 * a1 - a2**2)) / denom
+                    P[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+            elif not periodic and bco == 2:
+                xWin2 = kernel.Win * kernel.x**2
+                x2P = ko.conv1d(bins, xWin2, "same")
+                a2 = np.sum(xWin2)
+                a4 = np.dot(xWin2, kernel.x**2)
+                corrected = (P * a4 - a2 * x2P) / (a4 - a2**2)
+                ix = P > 0
+                P[ix] *= np.exp(np.minimum(corrected[ix] / P[ix], 2) - 1)
+            if mbc:
+                if not periodic:
+                    m2 = np.ones(F)
+                    if bot:
+                        m2[0] *= 0.5
+                    if top:
+                        m2[-1] *= 0.5
+                    a0 = ko.conv1d(m2, kernel.Win, "same")
+                for _ in range(mbc):
+                    p1 = P.copy()
+                    p1[p1 == 0] = 1
+                    P = P * ko.conv1d(bins / p1, kernel.Win, mode)
+                    if not periodic:
+                        P /= a0
+            mx = np.max(P)
+            if mx == 0:
+                status[b] = -4
+            else:
+                P_out[b] = P / mx
+        return P_out, status
+
+    # ---- 2D
+    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t):
+        self.log.append(("kopt2d", B, F))
+        H = np.asarray(d_hist.a).reshape(B, F, F)
+        out = np.full((B, 8), np.nan)
+        for b in range(B):
+            tr = {}
+            try:
+                opt = ko.Optimizer2D(H[b], neff[b], 0.0, do_correlation=bool(do_corr[b]),
+                                     fallback_t=(fallback_t[b] if fallback_t[b] > 0 else None), trace=tr)
+                opt.get_h()
+                out[b, 0] = tr["t_star"]
+                out[b, 1:4] = tr["p_02"], tr["p_20"], tr["p_11"]
+                if do_corr[b]:
+                    out[b, 4:7] = tr["p_00"], tr["p_13"], tr["p_31"]
+                out[b, 7] = 0
+            except ValueError:
+                out[b, 7] = -5
+        return out
+
+    def density2d(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, out=None):
+        self.log.append(("density2d", B, F))
+        H = np.asarray(d_hist.a).reshape(B, F, F)
+        P_out = np.zeros((B, F, F))
+        status = np.zeros(B, dtype=np.int32)
+
+        class _P:  # stand-in for ParamState in the oracle's mask helpers
+            def __init__(self, bot, top, periodic):
+                self.has_limits_bot, self.has_limits_top, self.periodic = bot, top, periodic
+
+        for b in range(B):
+            fl, w_ = int(flags[b]), int(winw[b])
+            parx = _P(bool(fl & 1), bool(fl & 2), bool(fl & 16))
+            pary = _P(bool(fl & 4), bool(fl & 8), bool(fl & 32))
+            has_prior = bool(fl & 64) or bool(fl & 15)
+            Cinv = np.linalg.inv(np.array([[ry[b] ** 2, rx[b] * ry[b] * corr[b]], [rx[b] * ry[b] * corr[b], rx[b] ** 2]]))
+            i1, i2 = np.mgrid[-w_:w_ + 1, -w_:w_ + 1]
+            Win = np.exp(-(i1**2 * Cinv[0, 0] + i2**2 * Cinv[1, 1] + 2 * Cinv[1, 0] * i1 * i2) / 2)
+            Win /= np.sum(Win)
+            mode = ("periodic_both" if parx.periodic and pary.periodic else "periodic_x" if parx.periodic
+                    else "periodic_y" if pary.periodic else "same")
+            hist = H[b]
+            big = F + 4 * w_ + 1
+            bins2D = ko.conv2d(hist, Win, mode, largest_size=big)
+            both = parx.periodic and pary.periodic
+            mask = np.ones((F + 2 * w_, F + 2 * w_))
+            if has_prior and bco >= 0 and not both:
+                ko._set_edge_mask_2d(parx, pary, mask, w_)
+                a00 = ko.conv2d(mask, Win, "valid", largest_size=big)
+                ix = a00 * bins2D > np.max(bins2D) * 1e-8
+                a00 = a00[ix]
+                normed = bins2D[ix] / a00
+                if bco == 0:
+                    bins2D[ix] = normed
+                else:
+                    idx = np.arange(-w_, w_ + 1)
+                    y = np.repeat(idx[:, None], Win.shape[1], axis=1)
+                    winx, winy = Win * idx, Win * y
+                    a10 = ko.conv2d(mask, winx, "valid", largest_size=big)[ix]
+                    a01 = ko.conv2d(mask, winy, "valid", largest_size=big)[ix]
+                    a20 = ko.conv2d(mask, winx * idx, "valid", largest_size=big)[ix]
+                    a02 = ko.conv2d(mask, winy * y, "valid", largest_size=big)[ix]
+                    a11 = ko.conv2d(mask, winy * idx, "valid", largest_size=big)[ix]
+                    xP = ko.conv2d(hist, winx, mode, largest_size=big)[ix]
+                    yP = ko.conv2d(hist, winy, mode, largest_size=big)[ix]
+                    denom = a20 * a01**2 + a10**2 * a02 - a00 * a02 * a20 + a11**2 * a00 - 2 * a01 * a10 * a11
+                    corrected = (bins2D[ix] * (a11**2 - a02 * a20) + xP * (a10 * a02 - a01 * a11) + yP * (a01 * a20 - a10 * a11)) / denom
+                    bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+            if mbc and not both:
+                ko._set_all_edge_mask_2d(mask, w_, parx.periodic, pary.periodic)
+                a00 = ko.conv2d(mask, Win, "valid", largest_size=big)
+                for _ in range(mbc):
+                    box = hist.copy()
+                    ix2 = bins2D > np.max(bins2D) * 1e-8
+                    box[ix2] /= bins2D[ix2]
+                    bins2D *= ko.conv2d(box, Win, mode, largest_size=big)
+                    bins2D /= a00
+            mx = np.max(bins2D)
+            if mx == 0:
+                status[b] = -4
+            else:
+                P_out[b] = bins2D / mx
+        return FakeBuf(P_out), status

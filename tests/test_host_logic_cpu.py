@@ -1,0 +1,131 @@
+"""
+CPU tests of the HOST layer (getdist_amd/mcsamples.py, bench.one_step, parallel.py) with the C ABI replaced by the
+numpy test double in tests/fake_ctx.py: ranges/limits, branch selection, batching by grid and frame class, the
+asynchronous TNC pool, result assembly and the 2-rank partition are exercised without a GPU.  (The kernels themselves
+are covered by the -m gpu tests.)
+"""
+
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+import golden_util as gu
+from fake_ctx import FakeContext
+from oracle import kde_oracle as ko
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make(fx, **kw):
+    from getdist_amd.mcsamples import MCSamples
+
+    return MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"],
+                     _context_factory=FakeContext, **kw)
+
+
+def test_host_logic_matches_oracle_1d_and_2d(zoo):
+    fx = zoo["c1_bounded"]
+    mc = make(fx)
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    assert np.allclose(mc.fullcov, orc.fullcov, rtol=1e-12)
+    for j, d in enumerate(mc.get1DDensities()):
+        o = orc.density_1d(j)
+        assert np.max(np.abs(d.P - o["P"])) < 1e-9
+        assert np.allclose([d.x[0], d.x[-1]], [o["x"][0], o["x"][-1]], rtol=0, atol=0)
+    dens = mc.get2DDensities(fx["pairs"])
+    for (a, b), d in zip(fx["pairs"], dens):
+        tr = {}
+        o = orc.density_2d(a, b, trace=tr)
+        assert d.bandwidth_branch == tr["branch"]
+        assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-9)  # bounded pairs: no TNC
+        assert np.max(np.abs(d.P - o["P"])) < 1e-9
+
+
+def test_host_logic_branches_and_grid_classes(zoo):
+    """block50: all three bandwidth branches, four grid sizes, bounded and unbounded pairs through the batched path."""
+    fx = zoo["block50"]
+    g = gu.load("block50")
+    mc = make(fx)
+    dens = mc.get2DDensities(fx["pairs"])
+    branches = set()
+    for (a, b), d in zip(fx["pairs"], dens):
+        key = "p2d/%s/%s/default" % (fx["names"][a], fx["names"][b])
+        assert d.P.shape[0] == int(g[key + "/F"]), key
+        branches.add(d.bandwidth_branch)
+        px, py = mc.paramNames.names[a], mc.paramNames.names[b]
+        tnc = d.bandwidth_branch in ("A", "C") and not (px.has_limits or py.has_limits)
+        gu.check_grid_2d(g, key, d.P, 2e-3 if tnc else 1e-8)
+    assert branches == {"A", "B", "C"}
+    # one batched histogram launch per grid-size class, not one per pair
+    n_hist = [c for c in mc.ctx.log if c[0] == "hist2d_prebinned"]
+    assert len(n_hist) == len({c[2] for c in n_hist}) == 4
+    ms = mc.getMargeStats()
+    assert len(ms.parWithName("p4").limits) == 3
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    import bench
+    from fake_ctx import FakeContext
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, w, names, ranges = synth.block_recipe(10, 6000, weighted=False, stream=41)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=FakeContext)
+    pairs = synth.triangle_pairs(10)
+    dens = bench.one_step(mc, pairs, dist, rank, world, None)
+    # which pairs did this rank take, and what did it get?
+    from getdist_amd import parallel
+    classes = dict(zip(pairs, bench.pair_cost_classes(mc, pairs)))
+    idx, mine = parallel.partition_pairs(pairs, classes.__getitem__, world, rank)
+    assert len(mine) == len(dens)
+    np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), idx=np.array(idx), P=np.array([d.P for d in dens]),
+             neff=np.array([p.N_eff_kde for p in mc.paramNames.names]))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    """bench.one_step under gloo world_size 2: every pair computed exactly once, grids equal to the 1-rank run."""
+    import bench
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT, out=str(tmp_path)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GETDIST_AMD_TNC_WORKERS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0 and "rank %d ok" % rank in out, out
+    s, w, names, ranges = synth.block_recipe(10, 6000, weighted=False, stream=41)
+    os.environ["GETDIST_AMD_TNC_WORKERS"] = "1"
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=FakeContext)
+    pairs = synth.triangle_pairs(10)
+    ref = bench.one_step(mc, pairs, None, 0, 1, None)
+    seen = []
+    for rank in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert np.allclose(z["neff"], [p.N_eff_kde for p in mc.paramNames.names], rtol=1e-12)  # all-gathered state
+        for i, P in zip(z["idx"], z["P"]):
+            seen.append(int(i))
+            assert np.array_equal(P, ref[int(i)].P), pairs[int(i)]  # same inputs, same solver path => identical
+    assert sorted(seen) == list(range(len(pairs)))
