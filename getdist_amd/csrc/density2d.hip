@@ -92,6 +92,108 @@ __global__ void k_fill_mask(const D2Pair* __restrict__ pairs, int F, int S, int 
     }
 }
 
+// ---- prior-mask moments without FFTs -------------------------------------------------------------------------
+// The prior masks of mcsamples.py:1688-1712 are axis-aligned boxes (1 inside, 1/2 on a limit edge, 0 beyond), so
+// a_pq = conv(mask, Win * x^p y^q) at a pixel is a rectangle sum of the window moment: four look-ups in its
+// summed-area table, minus half of the edge row / column, plus a quarter of the corner cell.  This replaces the
+// mask FFT and one inverse FFT per moment (mcsamples.py:1905-1919, 1964-1966) with (2w+2)^2 table entries per pair.
+struct MomSpec {
+    int px, py, kind;  // kind 0: edge mask, kind 1: all-edge mask
+    double* dst;       // B x F x F
+};
+struct MomList {
+    int n, edge_applied;
+    MomSpec m[7];
+};
+
+// grid (n moments, B), block 256: sat[(a+1)*(M+1) + (b+1)] = sum_{a'<=a, b'<=b} K[a'-w][b'-w]
+__global__ void k_window_sat(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, MomList L,
+                             int64_t sat_stride, double* __restrict__ sat) {
+    const D2Pair p = pairs[blockIdx.y];
+    const MomSpec sp = L.m[blockIdx.x];
+    if (sp.kind == 0 && !(p.flags & 64)) return;
+    const int w = p.w, M = 2 * w + 1, M1 = M + 1;
+    const double ws = wsum[blockIdx.y];
+    double* s = sat + ((int64_t)blockIdx.y * L.n + blockIdx.x) * sat_stride;
+    for (int t = threadIdx.x; t < M1; t += blockDim.x) s[t] = 0.0, s[(int64_t)t * M1] = 0.0;
+    // column prefixes (thread per column: coalesced)
+    for (int c = threadIdx.x; c < M; c += blockDim.x) {
+        const int i2 = c - w;
+        double run = 0;
+        for (int r = 0; r < M; ++r) {
+            const int i1 = r - w;
+            double v = win_raw(p, i1, i2) / ws;
+            for (int q = 0; q < sp.px; ++q) v = v * (double)i2;
+            for (int q = 0; q < sp.py; ++q) v = v * (double)i1;
+            run += v;
+            s[(int64_t)(r + 1) * M1 + c + 1] = run;
+        }
+    }
+    __syncthreads();
+    // row prefixes
+    for (int r = threadIdx.x; r < M; r += blockDim.x) {
+        double* row = s + (int64_t)(r + 1) * M1 + 1;
+        double run = 0;
+        for (int c = 0; c < M; ++c) {
+            run += row[c];
+            row[c] = run;
+        }
+    }
+}
+
+__device__ __forceinline__ double sat_rect(const double* __restrict__ s, int M1, int a0, int a1, int b0, int b1) {
+    return ((s[(a1 + 1) * M1 + b1 + 1] - s[a0 * M1 + b1 + 1]) - s[(a1 + 1) * M1 + b0]) + s[a0 * M1 + b0];
+}
+
+// one axis of a mask: support [lo, hi] in padded coordinates, half weight on lo / hi when a limit sits there
+struct MaskIv {
+    int lo, hi;
+    bool hlo, hhi;
+};
+__device__ __forceinline__ MaskIv mask_interval(int F, int w, bool bot, bool top, int kind, bool use_edges) {
+    MaskIv iv;
+    iv.lo = (kind == 1 || (use_edges && bot)) ? w : 0;
+    iv.hi = (kind == 1 || (use_edges && top)) ? F + w - 1 : F + 2 * w - 1;
+    iv.hlo = use_edges && bot;
+    iv.hhi = use_edges && top;
+    return iv;
+}
+
+// grid (blocks, n moments, B)
+__global__ void k_mask_eval(const D2Pair* __restrict__ pairs, MomList L, int F, int64_t sat_stride,
+                            const double* __restrict__ sat) {
+    const D2Pair p = pairs[blockIdx.z];
+    const MomSpec sp = L.m[blockIdx.y];
+    if (sp.kind == 0 && !(p.flags & 64)) return;
+    const int w = p.w, M1 = 2 * w + 2;
+    const double* s = sat + ((int64_t)blockIdx.z * L.n + blockIdx.y) * sat_stride;
+    double* dst = sp.dst + (int64_t)blockIdx.z * F * F;
+    const bool use_edges = (sp.kind == 0) || L.edge_applied;
+    const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, sp.kind, use_edges);
+    const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, sp.kind, use_edges);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        const int y = e / F, x = e % F;
+        // window offset i covers padded position  (pixel + w - i)
+        const int i_lo = max(-w, y + w - iy.hi), i_hi = min(w, y + w - iy.lo);
+        const int j_lo = max(-w, x + w - ix.hi), j_hi = min(w, x + w - ix.lo);
+        double v = 0.0;
+        if (i_lo <= i_hi && j_lo <= j_hi) {
+            const int a0 = i_lo + w, a1 = i_hi + w, b0 = j_lo + w, b1 = j_hi + w;
+            v = sat_rect(s, M1, a0, a1, b0, b1);
+            int er[2], ec[2], ner = 0, nec = 0;
+            if (iy.hlo && y + w - iy.lo <= w) er[ner++] = y + 2 * w - iy.lo;
+            if (iy.hhi && y + w - iy.hi >= -w) er[ner++] = y + 2 * w - iy.hi;
+            if (ix.hlo && x + w - ix.lo <= w) ec[nec++] = x + 2 * w - ix.lo;
+            if (ix.hhi && x + w - ix.hi >= -w) ec[nec++] = x + 2 * w - ix.hi;
+            for (int k = 0; k < ner; ++k) v -= 0.5 * sat_rect(s, M1, er[k], er[k], b0, b1);
+            for (int k = 0; k < nec; ++k) v -= 0.5 * sat_rect(s, M1, a0, a1, ec[k], ec[k]);
+            for (int k = 0; k < ner; ++k)
+                for (int l = 0; l < nec; ++l) v += 0.25 * sat_rect(s, M1, er[k], er[k], ec[l], ec[l]);
+        }
+        dst[e] = v;
+    }
+}
+
 // out = a * b * scale (complex), n elements per batch entry
 __global__ void k_cmul(const double2* __restrict__ a, const double2* __restrict__ b, int64_t n, double scale,
                        double2* __restrict__ out) {
@@ -437,6 +539,9 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
     const int S = next_fft_size(F + 2 * maxw);
     const int Sh = S / 2 + 1;
     const int64_t FF = (int64_t)F * F, SS = (int64_t)S * S, SC = (int64_t)S * Sh;
+    // prior-mask moments come from summed-area tables of the window (k_window_sat / k_mask_eval)
+    const int n_mom = (do_bc ? (bco == 1 ? 6 : 1) : 0) + (mbc ? 1 : 0);
+    const int64_t sat_stride = (int64_t)(2 * maxw + 2) * (2 * maxw + 2);
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
         int64_t o = off;
@@ -445,10 +550,10 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
     };
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
                   o_status = take((int64_t)B * 4), o_RF = take(B * SS * 8), o_RO = take(B * SS * 8),
-                  o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16), o_ZM = take(do_bc || mbc ? B * SC * 16 : 0),
+                  o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16),
                   o_ZK = take(do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(B * SC * 16),
                   o_arr = take((do_bc ? (bco == 1 ? 8 : 1) : 0) * B * FF * 8), o_a00m = take(mbc ? B * FF * 8 : 0),
-                  o_conv = take(mbc ? B * FF * 8 : 0);
+                  o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
@@ -459,12 +564,12 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
     double* RO = (double*)(base + o_RO);
     double2* ZH = (double2*)(base + o_ZH);
     double2* ZW = (double2*)(base + o_ZW);
-    double2* ZM = (double2*)(base + o_ZM);
     double2* ZK = (double2*)(base + o_ZK);
     double2* ZP = (double2*)(base + o_ZP);
     double* arr = (double*)(base + o_arr);
     double* d_a00m = (double*)(base + o_a00m);
     double* d_conv = (double*)(base + o_conv);
+    double* d_sat = (double*)(base + o_sat);
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
     const dim3 gS(128, B), gF(64, B);
     const double scale = 1.0 / ((double)S * (double)S);
@@ -496,42 +601,51 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
     GD_KERNEL_CHECK();
     FWD(RF, ZH);
     CONV_TO(ZH, ZW, d_P);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884)
+    BcArrays A;
+    A.P = d_P;
+    A.a00 = arr;
+    A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
+    if (do_bc && bco == 1)
+        A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
+        A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
+    if (n_mom) {
+        MomList L;
+        L.n = 0;
+        L.edge_applied = do_bc ? 1 : 0;
+        if (do_bc) {
+            L.m[L.n++] = {0, 0, 0, A.a00};
+            if (bco == 1) {
+                L.m[L.n++] = {1, 0, 0, A.a10};
+                L.m[L.n++] = {0, 1, 0, A.a01};
+                L.m[L.n++] = {2, 0, 0, A.a20};
+                L.m[L.n++] = {0, 2, 0, A.a02};
+                L.m[L.n++] = {1, 1, 0, A.a11};
+            }
+        }
+        if (mbc) L.m[L.n++] = {0, 0, 1, d_a00m};
+        k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
+        GD_KERNEL_CHECK();
+        k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
+        GD_KERNEL_CHECK();
+    }
     if (do_bc) {
-        BcArrays A;
-        A.P = d_P;
-        A.a00 = arr;
-        A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
         k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
         GD_KERNEL_CHECK();
-        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
-        GD_KERNEL_CHECK();
-        FWD(RF, ZM);
-        CONV_TO(ZM, ZW, A.a00);
         if (bco == 1) {
-            A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
-            A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
-            struct Mom {
-                int px, py;
-                double* mask_dst;
-                double* hist_dst;
-            } moms[5] = {{1, 0, A.a10, A.xP}, {0, 1, A.a01, A.yP}, {2, 0, A.a20, nullptr}, {0, 2, A.a02, nullptr},
-                         {1, 1, A.a11, nullptr}};
-            for (const Mom& m : moms) {
-                k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, m.px, m.py, RF);
-                GD_KERNEL_CHECK();
-                FWD(RF, ZK);
-                CONV_TO(ZM, ZK, m.mask_dst);
-                if (m.hist_dst) CONV_TO(ZH, ZK, m.hist_dst);
-            }
+            // x*P and y*P still need the histogram: conv(histbins, Win*x), conv(histbins, Win*y)  (mcsamples.py:1940-1941)
+            k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 1, 0, RF);
+            GD_KERNEL_CHECK();
+            FWD(RF, ZK);
+            CONV_TO(ZH, ZK, A.xP);
+            k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 1, RF);
+            GD_KERNEL_CHECK();
+            FWD(RF, ZK);
+            CONV_TO(ZH, ZK, A.yP);
         }
         k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco);
         GD_KERNEL_CHECK();
     }
     if (mbc > 0) {
-        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 1, do_bc ? 1 : 0, RF);
-        GD_KERNEL_CHECK();
-        FWD(RF, ZM);
-        CONV_TO(ZM, ZW, d_a00m);
         for (int round = 0; round < mbc; ++round) {
             k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
             GD_KERNEL_CHECK();
