@@ -61,6 +61,18 @@ def periodic_fixture(N=4000):
     return np.column_stack([angle, radius]), ["angle", "radius"], {"angle": (0, 2 * np.pi, True), "radius": (0, 5)}
 
 
+def loglikes_for(samples, k=7):
+    """-log(posterior) column for the mean-likelihood tests: a quadratic in the first parameters plus seeded noise."""
+    s = np.asarray(samples, dtype=np.float64)
+    m = min(3, s.shape[1])
+    z = (s[:, :m] - s[:, :m].mean(axis=0)) / s[:, :m].std(axis=0)
+    return 0.5 * np.sum(z * z, axis=1) + 0.3 * _rng(k).standard_normal(len(s)) + 11.0
+
+
+MEANLIKES_CASES = (("c1_bounded", ({}, dict(mult_bias_correction_order=0), dict(mult_bias_correction_order=2))),
+                   ("block10_weighted", ({},)), ("shapes", ({},)), ("periodic", (dict(fine_bins=64, fine_bins_2D=32),)))
+
+
 def fixture_zoo():
     """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
     zoo = []

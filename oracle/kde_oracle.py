@@ -460,7 +460,8 @@ class OracleSamples:
     restated over plain arrays.  ``samples`` is (N, n) row-major like the reference's.
     """
 
-    def __init__(self, samples, weights=None, names=None, ranges=None, settings=None, sampler="mcmc", periodic=()):
+    def __init__(self, samples, weights=None, names=None, ranges=None, settings=None, sampler="mcmc", periodic=(),
+                 loglikes=None):
         samples = np.asarray(samples, dtype=np.float64)
         if samples.ndim == 1:
             samples = samples.reshape(-1, 1)
@@ -474,6 +475,8 @@ class OracleSamples:
             self.weights = np.ones(self.numrows)
             self.norm = np.float64(self.numrows)
         self.sampler = sampler
+        self.loglikes = None if loglikes is None else np.asarray(loglikes, dtype=np.float64)
+        self.shade_likes_is_mean_loglikes = False  # mcsamples.py:233
         self.settings = dict(DEFAULT_SETTINGS)
         if settings:
             self.settings.update(settings)
@@ -493,6 +496,7 @@ class OracleSamples:
         """chains.py:1340-1352 + mcsamples.py:552-576"""
         w = self.weights
         self.means = w.dot(self.samples) / self.norm  # chains.py:379
+        self.mean_loglike = None if self.loglikes is None else w.dot(self.loglikes) / self.norm  # chains.py:380-383
         self.vars = np.empty(self.n)
         for i in range(self.n):  # chains.py:409-410
             self.vars[i] = w.dot((self.samples[:, i] - self.means[i]) ** 2) / self.norm
@@ -721,8 +725,8 @@ class OracleSamples:
             return h * N_eff ** (1.0 / 5 - 1.0 / (4 * m + 5))
         return h
 
-    def density_1d(self, j, trace=None, **kwargs):
-        """Returns dict(x, P, view_ranges, + intermediates).  mcsamples.py:1517-1686 (no meanlikes)."""
+    def density_1d(self, j, trace=None, meanlikes=False, **kwargs):
+        """Returns dict(x, P, view_ranges, likes, + intermediates).  mcsamples.py:1517-1686."""
         if isinstance(j, str):
             j = self.index[j]
         S = self.settings
@@ -738,6 +742,12 @@ class OracleSamples:
         width = paramrange / (num_bins - 1)
         ix_, fine_width, binmin, binmax = self.bin_samples(self.samples[:, j], par, fine_bins)
         bins = np.bincount(ix_, weights=self.weights, minlength=fine_bins)
+        if meanlikes:  # mcsamples.py:1556-1561
+            if self.shade_likes_is_mean_loglikes:
+                lw = self.weights * self.loglikes
+            else:
+                lw = self.weights * np.exp(self.mean_loglike - self.loglikes)
+            finebinlikes = np.bincount(ix_, weights=lw, minlength=fine_bins)
         if smooth_scale_1D <= 0:
             bandwidth = self.auto_bandwidth_1d(bins, j, mbc, bco, trace=trace) * (binmax - binmin)
             bandwidth = min(bandwidth, paramrange / 4)
@@ -751,6 +761,7 @@ class OracleSamples:
         kernel = Kernel1D(winw, smooth_1D)
         mode = "periodic" if par.periodic else "same"
         P = conv1d(bins, kernel.Win, mode)
+        rawbins = P.copy()  # mcsamples.py:1597-1598
         fine_x = np.linspace(binmin, binmax, fine_bins)
         if par.has_limits and not par.periodic and bco >= 0:
             prior_mask = np.ones(fine_bins + 2 * winw)
@@ -813,8 +824,20 @@ class OracleSamples:
         if mx == 0:
             raise ValueError("no samples in bin")
         P /= mx
+        likes = None
+        if meanlikes:  # mcsamples.py:1672-1682
+            ixp = P > 0
+            finebinlikes[ixp] /= P[ixp]
+            binlikes = conv1d(finebinlikes, kernel.Win, mode)
+            binlikes[ixp] *= P[ixp] / rawbins[ixp]
+            if self.shade_likes_is_mean_loglikes:
+                maxbin = np.min(binlikes)
+                binlikes = np.where((binlikes - maxbin) < 30, np.exp(-(binlikes - maxbin)), 0)
+                binlikes[rawbins == 0] = 0
+            binlikes /= np.max(binlikes)
+            likes = binlikes
         return dict(x=fine_x, P=P, view_ranges=[par.range_min, par.range_max], bins=bins, ix=ix_, binmin=binmin,
-                    binmax=binmax, fine_width=fine_width, winw=winw, smooth_1D=smooth_1D)
+                    binmax=binmax, fine_width=fine_width, winw=winw, smooth_1D=smooth_1D, likes=likes)
 
     # ---- 2D density (mcsamples.py:1285-1419, 1748-2010) ---------------------------------------
     def make_2d_hist(self, ixs, iys, xsize, ysize):
@@ -901,8 +924,8 @@ class OracleSamples:
             trace.update(branch=branch, N_eff=N_eff, hx=hx, hy=hy, c=c)
         return hx, hy, c
 
-    def density_2d(self, j, j2, trace=None, **kwargs):
-        """Returns dict(x, y, P[y,x], view_ranges, ...).  mcsamples.py:1748-2010 (no meanlikes/mask_function)."""
+    def density_2d(self, j, j2, trace=None, meanlikes=False, **kwargs):
+        """Returns dict(x, y, P[y,x], view_ranges, likes, ...).  mcsamples.py:1748-2010 (no mask_function)."""
         if isinstance(j, str):
             j = self.index[j]
         if isinstance(j2, str):
@@ -933,6 +956,9 @@ class OracleSamples:
         iys, finewidthy, ybinmin, ybinmax = self.bin_samples(self.samples[:, j2], pary, fine_bins_2D)
         xsize = ysize = fine_bins_2D
         histbins, flatix = self.make_2d_hist(ixs, iys, xsize, ysize)
+        if meanlikes:  # mcsamples.py:1829-1831
+            likeweights = self.weights * np.exp(self.mean_loglike - self.loglikes)
+            finebinlikes = np.bincount(flatix, weights=likeweights, minlength=xsize * ysize).reshape((ysize, xsize))
         if smooth_scale_2D < 0:
             rx, ry, corr = self.auto_bandwidth_2d(histbins, j, j2, actual_corr, xbinmax - xbinmin, ybinmax - ybinmin,
                                                   base_fine_bins_2D, mbc, trace=trace)
@@ -960,6 +986,18 @@ class OracleSamples:
         else:
             mode = "same"
         bins2D = conv2d(histbins, Win, mode, largest_size=convolvesize)
+        bin2Dlikes = None
+        if meanlikes:  # mcsamples.py:1886-1901
+            bin2Dlikes = conv2d(finebinlikes, Win, mode, largest_size=convolvesize)
+            if mbc:
+                ixl = bin2Dlikes > 0
+                finebinlikes[ixl] /= bin2Dlikes[ixl]
+                likes2 = conv2d(finebinlikes, Win, mode, largest_size=convolvesize)
+                likes2[ixl] *= bin2Dlikes[ixl]
+                bin2Dlikes = likes2
+            mxl = 1e-4 * np.max(bins2D)
+            bin2Dlikes[bins2D > mxl] /= bins2D[bins2D > mxl]
+            bin2Dlikes[bins2D <= mxl] = 0
         if has_prior and bco >= 0 or mbc:
             prior_mask = np.ones((ysize + 2 * winw, xsize + 2 * winw))
         if has_prior and bco >= 0 and not (parx.periodic and pary.periodic):
@@ -1007,10 +1045,13 @@ class OracleSamples:
         if mx == 0:
             raise ValueError("no samples in bin")
         bins2D /= mx
+        if meanlikes:  # mcsamples.py:2004-2006
+            bin2Dlikes /= np.max(bin2Dlikes)
         if trace is not None:
             trace.update(fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr_used=corr, actual_corr=actual_corr)
         return dict(x=x, y=y, P=bins2D, view_ranges=[(parx.range_min, parx.range_max), (pary.range_min, pary.range_max)],
-                    histbins=histbins, flatix=flatix, fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr=corr)
+                    histbins=histbins, flatix=flatix, fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr=corr,
+                    likes=bin2Dlikes)
 
     # ---- convergence (chains.py:1446-1486; mcsamples.py:964-985) --------------------------------
     def gelman_rubin_eigenvalues(self, chain_offsets, nparam=None):

@@ -21,7 +21,7 @@ from getdist import MCSamples  # noqa: E402  (the reference)
 
 from getdist_amd import synth  # noqa: E402
 from oracle import kde_oracle as ko  # noqa: E402
-from oracle.fixtures import fixture_zoo  # noqa: E402
+from oracle.fixtures import MEANLIKES_CASES, fixture_zoo, loglikes_for  # noqa: E402
 
 logging.getLogger().setLevel(logging.ERROR)
 
@@ -113,6 +113,38 @@ def compare_neff_2d():
     return ok
 
 
+def compare_meanlikes():
+    """The mean-likelihood branches of get1DDensityGridData / get2DDensityGridData (mcsamples.py:1556-1561,
+    1672-1684, 1829-1831, 1886-1903, 2004-2006), including shade_likes_is_mean_loglikes for 1D."""
+    zoo = {fx["name"]: fx for fx in fixture_zoo()}
+    ok = True
+    worst = 0.0
+    for nm, kws in MEANLIKES_CASES:
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"], loglikes=ll)
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+        for kw in kws:
+            kw1 = {k: v for k, v in kw.items() if k != "fine_bins_2D"}
+            kw2 = {k: v for k, v in kw.items() if k != "fine_bins"}
+            for shade in (False, True):
+                ref.shade_likes_is_mean_loglikes = orc.shade_likes_is_mean_loglikes = shade
+                for j, name in enumerate(fx["names"][:6]):
+                    e = relerr(orc.density_1d(j, meanlikes=True, **kw1)["likes"],
+                               ref.get1DDensityGridData(name, meanlikes=True, **kw1).likes)
+                    worst = max(worst, e)
+                    ok &= e <= 1e-10
+            ref.shade_likes_is_mean_loglikes = orc.shade_likes_is_mean_loglikes = False
+            for a, b in fx["pairs"][:4]:
+                d_ref = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], meanlikes=True, **kw2)
+                d_orc = orc.density_2d(a, b, meanlikes=True, **kw2)
+                e = max(relerr(d_orc["likes"], d_ref.likes), relerr(d_orc["P"], d_ref.P))
+                worst = max(worst, e)
+                ok &= e <= 1e-10
+    print(("ok  " if ok else "FAIL") + " mean likelihoods 1D/2D (worst %.1e)" % worst)
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -126,6 +158,7 @@ def main():
     ok = compare_fft_numbers()
     ok &= compare_convergence()
     ok &= compare_neff_2d()
+    ok &= compare_meanlikes()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")

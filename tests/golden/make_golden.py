@@ -128,6 +128,33 @@ def golden_split_tests(fx, test_confidence=0.95, max_split_tests=4):
     return out
 
 
+def golden_meanlikes(zoo):
+    """Mean-likelihood grids of the reference (mcsamples.py:1556-1561,1672-1684,1829-1831,1886-1903,2004-2006)."""
+    from oracle.fixtures import MEANLIKES_CASES, loglikes_for
+
+    out = {}
+    for nm, kws in MEANLIKES_CASES:
+        fx = zoo[nm]
+        ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"],
+                        ranges=fx["ranges"], loglikes=loglikes_for(fx["samples"]))
+        for kw in kws:
+            kw1 = {k: v for k, v in kw.items() if k != "fine_bins_2D"}
+            kw2 = {k: v for k, v in kw.items() if k != "fine_bins"}
+            for shade in (False, True):
+                ref.shade_likes_is_mean_loglikes = shade
+                for j, name in enumerate(fx["names"][:6]):
+                    out["%s/%s/1d/%d/shade%d" % (nm, kwkey(kw), j, shade)] = ref.get1DDensityGridData(
+                        name, meanlikes=True, **kw1).likes
+            ref.shade_likes_is_mean_loglikes = False
+            for a, b in fx["pairs"][:3]:
+                d = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], meanlikes=True, **kw2)
+                st = max(1, d.likes.shape[0] // 64)
+                out["%s/%s/2d/%d_%d/stride" % (nm, kwkey(kw), a, b)] = np.int32(st)
+                out["%s/%s/2d/%d_%d/likes" % (nm, kwkey(kw), a, b)] = d.likes[::st, ::st].copy()
+                out["%s/%s/2d/%d_%d/sum" % (nm, kwkey(kw), a, b)] = np.float64(np.sum(d.likes))
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -171,6 +198,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
     np.savez_compressed(os.path.join(HERE, "splittests.npz"),
                         **{nm: golden_split_tests(zoo[nm]) for nm in ("shapes_intweights", "c1_bounded", "block10_weighted")})
+    np.savez_compressed(os.path.join(HERE, "meanlikes.npz"), **golden_meanlikes(zoo))
+    if "--only-new" in sys.argv:
+        return
     for fx in zoo.values():
         out = golden_for_fixture(**fx)
         path = os.path.join(HERE, "fixture_%s.npz" % fx["name"])

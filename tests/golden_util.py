@@ -38,3 +38,15 @@ def check_grid_2d(gold, key, P, tol):
     else:
         assert relerr(P[::st, ::st], gold[key + "/Pstrided"]) <= tol, key
     assert abs(np.sum(P) - float(gold[key + "/Psum"])) <= tol * float(gold[key + "/Psum"]) * 10, key
+
+
+def meanlikes_cases(zoo, g):
+    """Yields (case, kw1, kw2, fixture, loglikes) for the mean-likelihood goldens (tests/golden/meanlikes.npz)."""
+    from oracle.fixtures import MEANLIKES_CASES, loglikes_for
+
+    for nm, kws in MEANLIKES_CASES:
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        for kw in kws:
+            yield ("%s/%s" % (nm, kwkey(kw)), {k: v for k, v in kw.items() if k != "fine_bins_2D"},
+                   {k: v for k, v in kw.items() if k != "fine_bins"}, fx, ll)

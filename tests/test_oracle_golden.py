@@ -72,3 +72,20 @@ def test_oracle_matches_golden(zoo, name):
             assert gu.relerr(lev, g[key + "/contours"]) < TOL_GRID, key
             if not kw:
                 assert gu.crc(d["flatix"].astype(np.int32)) == g[key + "/flatix_crc"], key
+
+
+def test_oracle_meanlikes_golden(zoo):
+    g = np.load(gu.GOLDEN_DIR + "/meanlikes.npz")
+    for case, kw1, kw2, fx, ll in gu.meanlikes_cases(zoo, g):
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+        for shade in (False, True):
+            orc.shade_likes_is_mean_loglikes = shade
+            for j in range(min(6, len(fx["names"]))):
+                likes = orc.density_1d(j, meanlikes=True, **kw1)["likes"]
+                assert gu.relerr(likes, g["%s/1d/%d/shade%d" % (case, j, shade)]) <= TOL_GRID, (case, j, shade)
+        orc.shade_likes_is_mean_loglikes = False
+        for a, b in fx["pairs"][:3]:
+            likes = orc.density_2d(a, b, meanlikes=True, **kw2)["likes"]
+            st = int(g["%s/2d/%d_%d/stride" % (case, a, b)])
+            assert gu.relerr(likes[::st, ::st], g["%s/2d/%d_%d/likes" % (case, a, b)]) <= TOL_GRID, (case, a, b)
+            assert abs(np.sum(likes) - float(g["%s/2d/%d_%d/sum" % (case, a, b)])) <= 1e-9 * np.sum(likes)
