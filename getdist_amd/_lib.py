@@ -86,6 +86,10 @@ SIGNATURES = {
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_like_weights": (C.c_int, [_p, _pd, _i32, C.c_double, _pd]),
+    "gd_select_weights": (C.c_int, [_p, _i32]),
+    "gd_likes1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _pi32, _pi32, _i32, _pd, _pi32]),
+    "gd_likes2d": (C.c_int, [_p, _i32, _i32, _p, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _p, _pi32]),
 }
 
 _lib = None
@@ -458,6 +462,40 @@ class Context:
         self._check(self.lib.gd_density1d(self.h, B, F, _dp(hist), _dp(smooth), _ip(winw), _ip(flags), int(bco),
                                           int(mbc), _dp(P), _ip(status)))
         return P, status
+
+    # ---- mean likelihoods
+    def like_weights(self, loglikes, mode, mean_loglike):
+        """Build (or with loglikes=None drop) the device vector w*exp(mean_loglike-loglikes) / w*loglikes."""
+        if loglikes is None:
+            self._check(self.lib.gd_like_weights(self.h, None, 0, 0.0, None))
+            return None
+        ll = _f64arr(loglikes)
+        if ll.shape != (self.N,):
+            raise ValueError("loglikes must have one entry per sample row")
+        tot = C.c_double()
+        self._check(self.lib.gd_like_weights(self.h, _dp(ll), int(mode), float(mean_loglike), C.byref(tot)))
+        return tot.value
+
+    def select_weights(self, which):
+        self._check(self.lib.gd_select_weights(self.h, int(which)))
+
+    def likes1d(self, hist, likehist, P, smooth, winw, flags, shade_mean_loglikes):
+        hist, likehist, P = _f64arr(hist), _f64arr(likehist), _f64arr(P)
+        B, F = hist.shape
+        smooth, winw, flags = _f64arr(smooth), _i32arr(winw), _i32arr(flags)
+        out = np.zeros_like(hist)
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_likes1d(self.h, B, F, _dp(hist), _dp(likehist), _dp(P), _dp(smooth), _ip(winw),
+                                        _ip(flags), int(bool(shade_mean_loglikes)), _dp(out), _ip(status)))
+        return out, status
+
+    def likes2d(self, d_hist, d_likehist, B, F, rx, ry, corr, winw, flags, mbc):
+        out = self.alloc(B * F * F * 8)
+        rx, ry, corr, winw, flags = _f64arr(rx), _f64arr(ry), _f64arr(corr), _i32arr(winw), _i32arr(flags)
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_likes2d(self.h, B, F, d_hist.ptr, d_likehist.ptr, _dp(rx), _dp(ry), _dp(corr),
+                                        _ip(winw), _ip(flags), int(mbc), out.ptr, _ip(status)))
+        return out, status
 
     def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t):
         neff, do_corr, fallback_t = _f64arr(neff), _i32arr(do_corr), _f64arr(fallback_t)

@@ -73,7 +73,9 @@ void gd_destroy(gd_ctx* ctx) {
     gd_fft_cache_destroy(ctx);
     for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
     if (ctx->cols) (void)hipFree(ctx->cols);
+    if (ctx->w_sel) ctx->w = ctx->w_main;
     if (ctx->w) (void)hipFree(ctx->w);
+    if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     (void)hipEventDestroy(ctx->ev0);
@@ -261,8 +263,11 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     GD_HIP(hipSetDevice(ctx->device));
     GD_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->cols) (void)hipFree(ctx->cols);
+    if (ctx->w_sel) ctx->w = ctx->w_main;
     if (ctx->w) (void)hipFree(ctx->w);
-    ctx->cols = ctx->w = nullptr;
+    if (ctx->like_w) (void)hipFree(ctx->like_w);
+    ctx->cols = ctx->w = ctx->like_w = ctx->w_main = nullptr;
+    ctx->w_sel = 0;
     ctx->N = ctx->n = ctx->ld = 0;
     const int64_t ld = (N + 511) / 512 * 512;
     GD_HIP(hipMalloc((void**)&ctx->cols, (size_t)(ld * n * 8)));
@@ -326,6 +331,74 @@ int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out) {
     }
     GD_REQUIRE(j >= 0 && j < ctx->n, "column out of range");
     *d_out = ctx->cols + j * ctx->ld;
+    return GD_OK;
+}
+
+// like weights = w * exp(mean_loglike - loglikes)  (mode 0; mcsamples.py:1560,1830)  or  w * loglikes  (mode 1; :1558)
+__global__ void k_like_weights(const double* __restrict__ w, const double* __restrict__ loglikes, int64_t N, int mode,
+                               double mean_loglike, double* __restrict__ out, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double wi = w ? w[i] : 1.0, l = loglikes[i];
+        const double v = (mode == 1) ? wi * l : wi * exp(mean_loglike - l);
+        out[i] = v;
+        s += v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+int gd_like_weights(gd_ctx* ctx, const double* loglikes, int32_t mode, double mean_loglike, double* sum_out) {
+    GD_REQUIRE(ctx, "null context");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(ctx->w_sel == 0, "like weights are selected; call gd_select_weights(ctx, 0) first");
+    if (!loglikes) {
+        if (ctx->like_w) (void)hipFree(ctx->like_w);
+        ctx->like_w = nullptr;
+        return GD_OK;
+    }
+    GD_REQUIRE(mode == 0 || mode == 1, "unknown like-weight mode");
+    if (!ctx->like_w) {
+        GD_HIP(hipMalloc((void**)&ctx->like_w, (size_t)(ctx->ld * 8)));
+        GD_HIP(hipMemsetAsync(ctx->like_w, 0, (size_t)(ctx->ld * 8), ctx->stream));
+    }
+    const int nblk = 2048;
+    const int64_t stage_bytes = (ctx->N * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, stage_bytes + nblk * 8);
+    if (!base) return GD_ERR_NOMEM;
+    double* stage = (double*)base;
+    double* d_part = (double*)(base + stage_bytes);
+    GD_HIP(hipMemcpyAsync(stage, loglikes, (size_t)(ctx->N * 8), hipMemcpyHostToDevice, ctx->stream));
+    k_like_weights<<<nblk, 256, 0, ctx->stream>>>(ctx->w, stage, ctx->N, mode, mean_loglike, ctx->like_w, d_part);
+    GD_KERNEL_CHECK();
+    std::vector<double> part((size_t)nblk);
+    GD_HIP(hipMemcpyAsync(part.data(), d_part, (size_t)nblk * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (sum_out) {
+        double tot = 0;
+        for (double v : part) tot += v;
+        *sum_out = tot;
+    }
+    return GD_OK;
+}
+
+int gd_select_weights(gd_ctx* ctx, int32_t which) {
+    GD_REQUIRE(ctx, "null context");
+    GD_REQUIRE(which == 0 || which == 1, "which must be 0 (sample weights) or 1 (like weights)");
+    if (which == ctx->w_sel) return GD_OK;
+    if (which == 1) {
+        GD_REQUIRE(ctx->like_w, "no like weights: call gd_like_weights first");
+        ctx->w_main = ctx->w;
+        ctx->w_main_integral = ctx->w_integral;
+        ctx->w = ctx->like_w;
+        ctx->w_integral = false;
+    } else {
+        ctx->w = ctx->w_main;
+        ctx->w_integral = ctx->w_main_integral;
+        ctx->w_main = nullptr;
+    }
+    ctx->w_sel = which;
     return GD_OK;
 }
 

@@ -25,6 +25,12 @@ struct gd_ctx {
     double* cols = nullptr;
     double* w = nullptr;  // nullptr => unit weights
     bool w_integral = false;  // all weights are non-negative integers with sum < 2^32 (MCMC multiplicities)
+    // mean-likelihood weights (gd_like_weights / gd_select_weights): while selected, `w` points at like_w and the
+    // sample weights wait in w_main
+    double* like_w = nullptr;
+    double* w_main = nullptr;
+    bool w_main_integral = false;
+    int w_sel = 0;
     int64_t N = 0, n = 0, ld = 0;
     // reusable scratch (grown on demand)
     void* scratch = nullptr;

@@ -230,6 +230,95 @@ __global__ void __launch_bounds__(256) k_density1d(const double* __restrict__ hi
     for (int n = tid; n < F; n += 256) Pout[(int64_t)b * F + n] = (mx == 0.0) ? 0.0 : P[n] / mx;
 }
 
+// ---- mean likelihoods (mcsamples.py:1672-1682): one block per parameter -------------------------------------
+__global__ void __launch_bounds__(256) k_likes1d(const double* __restrict__ hist, const double* __restrict__ likehist,
+                                                 const double* __restrict__ Pfinal, const double* __restrict__ smooth,
+                                                 const int* __restrict__ winw, const int* __restrict__ flags, int F,
+                                                 int shade_mean_loglikes, double* __restrict__ out, int* __restrict__ status) {
+    extern __shared__ double sh[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double* src = sh;        // F: operand of the current convolution (circular copy in periodic mode)
+    double* raw = src + F;   // F: rawbins = conv(bins, Win)
+    double* lk = raw + F;    // F: binlikes
+    double* Win = lk + F;    // 2w+1 <= F
+    __shared__ double red[16];
+    __shared__ double bc;
+    const int w = winw[b], M = 2 * w + 1, Fc = F - 1;
+    const double hh = smooth[b];
+    const bool periodic = flags[b] & 4;
+    const double* bins = hist + (int64_t)b * F;
+    const double* lh = likehist + (int64_t)b * F;
+    const double* P = Pfinal + (int64_t)b * F;
+    double s = 0;
+    for (int j = tid; j < M; j += 256) {
+        const double x = (double)(j - w) / hh;
+        const double v = exp(-(x * x) / 2.0);
+        Win[j] = v;
+        s += v;
+    }
+    s = block_sum(s, red);
+    if (tid == 0) bc = s;
+    __syncthreads();
+    const double wsum = bc;
+    for (int j = tid; j < M; j += 256) Win[j] = Win[j] / wsum;
+    // dst = convolve1D(v, Win, mode) for v given element-wise by `get`
+    auto conv = [&](auto get, double* dst) {
+        __syncthreads();
+        if (periodic) {
+            for (int i = tid; i < Fc; i += 256) src[i] = get(i) + (i == 0 ? get(F - 1) : 0.0);
+        } else {
+            for (int i = tid; i < F; i += 256) src[i] = get(i);
+        }
+        __syncthreads();
+        for (int n = tid; n < F; n += 256) {
+            double acc = 0;
+            if (periodic) {
+                const int nn = (n == F - 1) ? 0 : n;
+                for (int i = -w; i <= w; ++i) {
+                    int idx = (nn - i) % Fc;
+                    if (idx < 0) idx += Fc;
+                    acc = fma(Win[i + w], src[idx], acc);
+                }
+            } else {
+                for (int i = -w; i <= w; ++i) {
+                    const int idx = n - i;
+                    if (idx >= 0 && idx < F) acc = fma(Win[i + w], src[idx], acc);
+                }
+            }
+            dst[n] = acc;
+        }
+        __syncthreads();
+    };
+    conv([&](int i) { return bins[i]; }, raw);
+    conv([&](int i) { return (P[i] > 0) ? lh[i] / P[i] : lh[i]; }, lk);
+    for (int n = tid; n < F; n += 256)
+        if (P[n] > 0) lk[n] = lk[n] * (P[n] / raw[n]);
+    __syncthreads();
+    if (shade_mean_loglikes) {
+        double mn = INFINITY;
+        for (int n = tid; n < F; n += 256) mn = fmin(mn, lk[n]);
+        mn = block_min(mn, red);
+        if (tid == 0) bc = mn;
+        __syncthreads();
+        mn = bc;
+        for (int n = tid; n < F; n += 256) {
+            const double d = lk[n] - mn;
+            lk[n] = (raw[n] == 0.0) ? 0.0 : ((d < 30) ? exp(-d) : 0.0);
+        }
+        __syncthreads();
+    }
+    double mx = -INFINITY;
+    for (int n = tid; n < F; n += 256) mx = fmax(mx, lk[n]);
+    mx = block_max(mx, red);
+    if (tid == 0) {
+        bc = mx;
+        status[b] = (mx == 0.0) ? GD_ERR_EMPTY : GD_OK;
+    }
+    __syncthreads();
+    mx = bc;
+    for (int n = tid; n < F; n += 256) out[(int64_t)b * F + n] = (mx == 0.0) ? 0.0 : lk[n] / mx;
+}
+
 extern "C" {
 
 int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_out) {
@@ -280,6 +369,39 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
     k_density1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_smooth, d_winw, d_flags, A, d_P, d_status);
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(P_out, d_P, (size_t)B * F * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* likehist, const double* P,
+               const double* smooth, const int32_t* winw, const int32_t* flags, int32_t shade_mean_loglikes,
+               double* likes_out, int32_t* status_out) {
+    GD_REQUIRE(ctx && hist && likehist && P && smooth && winw && flags && likes_out && status_out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins out of range (8..4096)");
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(winw[b] >= 0 && 2 * winw[b] + 1 <= F, "window wider than the grid");
+        GD_REQUIRE(smooth[b] > 0, "smoothing scale must be positive");
+    }
+    const int64_t nb = ((int64_t)B * F * 8 + 255) / 256 * 256, ns = ((int64_t)B * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, 4 * nb + 4 * ns);
+    if (!base) return GD_ERR_NOMEM;
+    double *d_hist = (double*)base, *d_lh = (double*)(base + nb), *d_P = (double*)(base + 2 * nb),
+           *d_out = (double*)(base + 3 * nb), *d_smooth = (double*)(base + 4 * nb);
+    int *d_winw = (int*)(base + 4 * nb + ns), *d_flags = (int*)(base + 4 * nb + 2 * ns),
+        *d_status = (int*)(base + 4 * nb + 3 * ns);
+    GD_HIP(hipMemcpyAsync(d_hist, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_lh, likehist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_P, P, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_smooth, smooth, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_winw, winw, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_flags, flags, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = (size_t)4 * F * 8;
+    GD_HIP(hipFuncSetAttribute((const void*)k_likes1d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
+    k_likes1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_lh, d_P, d_smooth, d_winw, d_flags, F, shade_mean_loglikes, d_out,
+                                            d_status);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(likes_out, d_out, (size_t)B * F * 8, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;

@@ -285,6 +285,26 @@ __global__ void k_normalise(double* __restrict__ P, const double* __restrict__ m
 }
 
 
+// ---- mean likelihoods (mcsamples.py:1886-1903, 2004-2006) ----------------------------------------------------
+// t = likehist / L where L > 0 (else likehist)
+__global__ void k_likes_div(const double* __restrict__ likehist, const double* __restrict__ L, int64_t n,
+                            double* __restrict__ t) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        t[i] = (L[i] > 0) ? likehist[i] / L[i] : likehist[i];
+}
+// L = (L > 0) ? L2 * L : L2
+__global__ void k_likes_mul(const double* __restrict__ L2, int64_t n, double* __restrict__ L) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        L[i] = (L[i] > 0) ? L2[i] * L[i] : L2[i];
+}
+// L = L / P0 where P0 > 1e-4 max(P0), else 0.  grid (blocks, B)
+__global__ void k_likes_ratio(const double* __restrict__ P0, const double* __restrict__ mx, int FF, double* __restrict__ L) {
+    const double thresh = 1e-4 * mx[blockIdx.y];
+    const int64_t o = (int64_t)blockIdx.y * FF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x)
+        L[o + i] = (P0[o + i] > thresh) ? L[o + i] / P0[o + i] : 0.0;
+}
+
 // ---- periodic axes (convolve.py:215-323): circular convolution on the folded (Ny x Nx) grid ------------------
 // fold an F x F array onto the circular grid: drop the last column/row of a periodic axis and add it to the first
 __global__ void k_fill_circ(const double* __restrict__ src, int F, int Ny, int Nx, double* __restrict__ frames) {
@@ -665,6 +685,110 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
     GD_HIP(hipStreamSynchronize(ctx->stream));
 #undef FWD
 #undef CONV_TO
+    return GD_OK;
+}
+
+int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const void* d_likehist_v, const double* rx,
+               const double* ry, const double* corr, const int32_t* winw, const int32_t* flags, int32_t mbc,
+               void* d_likes_out, int32_t* status_out) {
+    GD_REQUIRE(ctx && d_hist_v && d_likehist_v && rx && ry && corr && winw && flags && d_likes_out && status_out && B > 0,
+               "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins_2D out of range");
+    const double* d_hist = (const double*)d_hist_v;
+    const double* d_likehist = (const double*)d_likehist_v;
+    double* d_L = (double*)d_likes_out;
+    std::vector<D2Pair> hp((size_t)B);
+    int maxw = 1;
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(winw[b] >= 1 && winw[b] <= 2 * F, "bad window half-width");
+        GD_REQUIRE(rx[b] > 0 && ry[b] > 0 && fabs(corr[b]) < 1, "bad bandwidth matrix");
+        const double a = ry[b] * ry[b], d = rx[b] * rx[b], o = rx[b] * ry[b] * corr[b];
+        const double det = a * d - o * o;
+        hp[b].c00 = d / det;
+        hp[b].c11 = a / det;
+        hp[b].c10 = -o / det;
+        hp[b].w = winw[b];
+        hp[b].flags = flags[b] & 127;
+        if (winw[b] > maxw) maxw = winw[b];
+        GD_REQUIRE((hp[b].flags & 48) == (flags[0] & 48), "a batch must not mix periodic and non-periodic pairs");
+    }
+    const int per = flags[0] & 48;
+    const bool px = per & 16, py = per & 32;
+    // operand frames: zero-padded S x S for 'same', the folded (Ny x Nx) circular grid for periodic axes
+    const int S = next_fft_size(F + 2 * maxw);
+    const int n0 = per ? (py ? F - 1 : F) : S, n1 = per ? (px ? F - 1 : F) : S, n1h = n1 / 2 + 1;
+    if (per) GD_REQUIRE(2 * maxw + 1 <= n1 && 2 * maxw + 1 <= n0, "window wider than the periodic grid");
+    const int64_t FF = (int64_t)F * F, NN = (int64_t)n0 * n1, NC = (int64_t)n0 * n1h;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+                  o_status = take((int64_t)B * 4), o_R = take(B * NN * 8), o_RO = take(B * NN * 8),
+                  o_ZW = take(B * NC * 16), o_ZA = take(B * NC * 16), o_ZP = take(B * NC * 16), o_P0 = take(B * FF * 8),
+                  o_T = take(B * FF * 8), o_L2 = take(B * FF * 8);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
+    double* d_wsum = (double*)(base + o_wsum);
+    double* d_mx = (double*)(base + o_mx);
+    int* d_status = (int*)(base + o_status);
+    double *R = (double*)(base + o_R), *RO = (double*)(base + o_RO), *d_P0 = (double*)(base + o_P0),
+           *d_T = (double*)(base + o_T), *d_L2 = (double*)(base + o_L2);
+    double2 *ZW = (double2*)(base + o_ZW), *ZA = (double2*)(base + o_ZA), *ZP = (double2*)(base + o_ZP);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    const dim3 gN(128, B), gF(64, B);
+    const double scale = 1.0 / ((double)n0 * (double)n1);
+    k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
+    GD_KERNEL_CHECK();
+    if (per)
+        k_fill_window_rect<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, n0, n1, 0, 0, R);
+    else
+        k_fill_window<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, R);
+    GD_KERNEL_CHECK();
+    int rc = gd_fft_r2c_2d(ctx, n0, n1, B, R, ZW);
+    if (rc) return rc;
+    // dst = convolve2D(src, Win, convolution_mode)
+    auto smooth = [&](const double* src, double* dst) -> int {
+        if (per)
+            k_fill_circ<<<gN, 256, 0, ctx->stream>>>(src, F, n0, n1, R);
+        else
+            k_fill_embed<<<gN, 256, 0, ctx->stream>>>(d_pairs, src, F, S, R);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "operand fill launch failed");
+        int r = gd_fft_r2c_2d(ctx, n0, n1, B, R, ZA);
+        if (r) return r;
+        k_cmul<<<2048, 256, 0, ctx->stream>>>(ZA, ZW, B * NC, scale, ZP);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_cmul launch failed");
+        r = gd_fft_c2r_2d(ctx, n0, n1, B, ZP, RO);
+        if (r) return r;
+        if (per)
+            k_expand_circ<<<gF, 256, 0, ctx->stream>>>(RO, F, n0, n1, dst);
+        else
+            k_crop<<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "crop launch failed");
+        return GD_OK;
+    };
+    if ((rc = smooth(d_hist, d_P0))) return rc;       // bins2D before any correction (mcsamples.py:1884)
+    if ((rc = smooth(d_likehist, d_L))) return rc;    // bin2Dlikes (:1887)
+    if (mbc) {                                        // :1890-1897
+        k_likes_div<<<2048, 256, 0, ctx->stream>>>(d_likehist, d_L, B * FF, d_T);
+        GD_KERNEL_CHECK();
+        if ((rc = smooth(d_T, d_L2))) return rc;
+        k_likes_mul<<<2048, 256, 0, ctx->stream>>>(d_L2, B * FF, d_L);
+        GD_KERNEL_CHECK();
+    }
+    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P0, (int)FF, d_mx);
+    GD_KERNEL_CHECK();
+    k_likes_ratio<<<gF, 256, 0, ctx->stream>>>(d_P0, d_mx, (int)FF, d_L);  // :1899-1901
+    GD_KERNEL_CHECK();
+    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_L, (int)FF, d_mx);
+    GD_KERNEL_CHECK();
+    k_normalise<<<gF, 256, 0, ctx->stream>>>(d_L, d_mx, (int)FF, d_status);  // bin2Dlikes /= max (:2005)
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;
 }
 

@@ -455,6 +455,7 @@ class MCSamples:
         self.timings = {}
         self.density1D = {}
         self._idx_cols = {}
+        self.shade_likes_is_mean_loglikes = False  # mcsamples.py:233
         self.needs_update = True
         self._upload()
         self.updateBaseStatistics()
@@ -474,6 +475,8 @@ class MCSamples:
                 self.numrows = self.samples.shape[0]
         self.ctx.upload(self.samples, w)
         self._idx_cols = {}
+        self.mean_loglike = None  # chains.py:317; recomputed on the device when a mean-likelihood is asked for
+        self._like_mode = None
 
     def setSamples(self, samples, weights=None, loglikes=None, min_weight_ratio=None):
         """chains.py:276-300: replace samples / weights; drops the device mirror and every derived cache."""
@@ -501,6 +504,30 @@ class MCSamples:
         self._upload()
         self.needs_update = True
         self.updateBaseStatistics()
+
+    def _use_like_weights(self, mode):
+        """
+        Make the mean-likelihood weights resident on the device: mode 0 = weights*exp(mean_loglike - loglikes)
+        (mcsamples.py:1560,1830), mode 1 = weights*loglikes (:1558).  mean_loglike (chains.py:380-383) falls out of
+        the mode-1 pass as sum/norm.
+        """
+        if self.loglikes is None:
+            raise MCSamplesError("mean likelihoods need the loglikes column")
+        if self.mean_loglike is None:
+            self.mean_loglike = self.ctx.like_weights(self.loglikes, 1, 0.0) / self.norm
+            self._like_mode = 1
+        if self._like_mode != mode:
+            self.ctx.like_weights(self.loglikes, mode, self.mean_loglike)
+            self._like_mode = mode
+
+    def _like_histograms(self, mode, fn):
+        """Run the histogram call ``fn`` with the like weights selected (np.bincount(..., weights=w) of :1561,1831)."""
+        self._use_like_weights(mode)
+        self.ctx.select_weights(1)
+        try:
+            return fn()
+        finally:
+            self.ctx.select_weights(0)
 
     def mean_diff(self, paramVec):
         """chains.py:744-761 (host vector p_i - mean; the device path never materialises it)"""
@@ -1078,17 +1105,18 @@ class MCSamples:
         return self.get1DDensityGridData(name, **kwargs)
 
     def get1DDensityGridData(self, j, paramConfid=None, meanlikes=False, **kwargs):
-        if meanlikes:
-            raise NotImplementedError("meanlikes is outside the accelerated path")
         if self.needs_update:
             self.updateBaseStatistics()
         j = self._parAndNumber(j)[0]
         if j is None:
             return None
-        return self.get1DDensities([j], **kwargs)[0]
+        return self.get1DDensities([j], meanlikes=meanlikes, **kwargs)[0]
 
-    def get1DDensities(self, params=None, **kwargs):
-        """Batched 1D KDEs (additive API): a list of Density1D, one per entry of ``params`` (default: all)."""
+    def get1DDensities(self, params=None, meanlikes=False, **kwargs):
+        """
+        Batched 1D KDEs (additive API): a list of Density1D, one per entry of ``params`` (default: all); with
+        ``meanlikes`` each carries the mean-likelihood profile ``likes`` (mcsamples.py:1556-1561,1672-1682).
+        """
         if self.needs_update:
             self.updateBaseStatistics()
         for k in kwargs:
@@ -1136,13 +1164,19 @@ class MCSamples:
             winw.append(min(int(round(2.5 * smooth_1D)), ((fine_bins - 1) if par.periodic else fine_bins) // 2 - 2))
             flags.append((1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0))
         P, status = self.ctx.density1d(hist, smooth, winw, flags, bco, mbc)
+        if np.any(status != 0):
+            raise DensitiesError("no samples in bin")
+        likes = None
+        if meanlikes:
+            shade = bool(self.shade_likes_is_mean_loglikes)
+            likehist = self._like_histograms(1 if shade else 0, lambda: self.ctx.hist1d(
+                js, [e[1] for e in edges], [e[0] for e in edges], fine_bins))
+            likes, _ = self.ctx.likes1d(hist, likehist, P, smooth, winw, flags, shade)
         out = []
         for b, (j, par) in enumerate(zip(js, pars)):
-            if status[b] != 0:
-                raise DensitiesError("no samples in bin")
             fine_width, binmin, binmax = edges[b]
             d = Density1D(np.linspace(binmin, binmax, fine_bins), P=P[b].copy(), view_ranges=[par.range_min, par.range_max])
-            d.likes = None
+            d.likes = None if likes is None else likes[b].copy()
             if not kwargs:
                 self.density1D[par.name] = d
             out.append(d)
@@ -1231,15 +1265,16 @@ class MCSamples:
 
     def get2DDensityGridData(self, j, j2, num_plot_contours=None, get_density=False, meanlikes=False,
                              mask_function=None, **kwargs):
-        if meanlikes or mask_function is not None:
-            raise NotImplementedError("meanlikes / mask_function are outside the accelerated path")
+        if mask_function is not None:
+            raise NotImplementedError("mask_function is outside the accelerated path")
         if self.needs_update:
             self.updateBaseStatistics()
         j = self._parAndNumber(j)[0]
         j2 = self._parAndNumber(j2)[0]
         if j is None or j2 is None:
             return None
-        return self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density, **kwargs)[0]
+        return self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density,
+                                   meanlikes=meanlikes, **kwargs)[0]
 
     def triangleDensities(self, params=None, **kwargs):
         """All lower-triangle pairs (x=params[i], y=params[i2>i]) in triangle-plot order; returns (pairs, densities)."""
@@ -1465,9 +1500,11 @@ class MCSamples:
             self._idx_cols[key] = (buf, (binmin, width))
         return self._idx_cols[key][0]
 
-    def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, **kwargs):
+    def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, meanlikes=False,
+                       **kwargs):
         """
         Batched 2D KDEs (additive API): a list of Density2D, one per (x, y) entry of ``pairs``.
+        With ``meanlikes`` each result carries the mean-likelihood grid ``likes`` (mcsamples.py:1829-1831,1886-1903).
         Each result carries ``bandwidth`` = (hx, hy, corr) in parameter units, ``bandwidth_branch`` and
         ``kopt`` (the device optimiser's {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status}).
         ``_bandwidths`` (tests only) injects the (hx, hy, corr) triples instead of optimising.
@@ -1524,13 +1561,15 @@ class MCSamples:
         classes = {}
         for k, e in enumerate(info):
             classes.setdefault(e["F"], []).append(k)
-        hists = {}
+        hists, likehists = {}, {}
         for F, members in classes.items():
             with _Phase(self, "2d.prebin"):
                 ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
                 iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
             with _Phase(self, "2d.hist"):
                 hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
+                if meanlikes:
+                    likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
         # ---- bandwidths: device optimiser now, host TNC solves asynchronously in the process pool
         rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
         finish_bw = None
@@ -1635,10 +1674,25 @@ class MCSamples:
                     d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
                                                 [cc[k] for k in ks], [info[k]["winw"] for k in ks],
                                                 [info[k]["flags"] for k in ks], bco, mbc)
+                d_L = L = None
+                if meanlikes:
+                    if own:
+                        d_lsub = ctx.alloc(len(sel) * F * F * 8)
+                        self._gather_device(likehists[F], d_lsub, [pos for pos, _ in sel], F * F * 8)
+                    else:
+                        d_lsub = likehists[F]
+                    d_L, lstatus = ctx.likes2d(d_sub, d_lsub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                               [cc[k] for k in ks], [info[k]["winw"] for k in ks],
+                                               [info[k]["flags"] for k in ks], mbc)
+                    if own:
+                        d_lsub.free()
+                    if np.any(lstatus != 0):
+                        raise DensitiesError("no likelihood weight in any bin")
+                    L = d_L.to_host_async((len(sel), F, F))
                 if own:
                     d_sub.free()
                 # the copy runs on the copy stream while the next batch computes
-                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status))
+                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L))
 
         for F, (d_hist, members) in hists.items():
             run_class(F, d_hist, members, 0)
@@ -1652,8 +1706,12 @@ class MCSamples:
             ctx.copy_sync()
         for F, (d_hist, members) in hists.items():
             d_hist.free()
-        for d_P, P, ks, status in inflight:
+        for d_lh in likehists.values():
+            d_lh.free()
+        for d_P, P, ks, status, d_L, L in inflight:
             d_P.free()
+            if d_L is not None:
+                d_L.free()
             F = P.shape[1]
             for row, k in enumerate(ks):
                 if status[row] != 0:
@@ -1670,7 +1728,7 @@ class MCSamples:
                     if num_plot_contours:
                         ncontours = min(num_plot_contours, ncontours)
                     dens.contours = dens.getContourLevels(self.contours[:ncontours])
-                dens.likes = None
+                dens.likes = None if L is None else L[row]
                 out[k] = dens
         return out
 

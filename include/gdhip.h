@@ -187,6 +187,32 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const do
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                  void* d_P_out, int32_t* status_out);
 
+/* ---------------------------------------------------------------- mean likelihoods -------------
+ * The optional `meanlikes` branches of get1DDensityGridData / get2DDensityGridData.
+ * gd_like_weights: build the device vector  weights*exp(mean_loglike - loglikes)  (mode 0; mcsamples.py:1560,
+ *   1830)  or  weights*loglikes  (mode 1, shade_likes_is_mean_loglikes; :1558) from the host column
+ *   loglikes (N rows); *sum_out (optional) = the sum of the vector, so that mode 1 with sum_out gives
+ *   mean_loglike = sum/norm (chains.py:380-383).  loglikes == NULL drops the vector.
+ * gd_select_weights: which = 1 makes every histogram entry point (gd_hist1d, gd_hist2d, gd_hist2d_prebinned)
+ *   accumulate the like weights instead of the sample weights (the `np.bincount(..., weights=w)` of
+ *   :1561,1831); which = 0 restores the sample weights.  Must be 0 for everything else.
+ * gd_likes1d: mcsamples.py:1672-1682 for B parameters: rawbins = conv(hist, Win); likehist/P where P>0,
+ *   smoothed, times P/rawbins; the exp(-(l - min l)) transform when shade_mean_loglikes; / max.
+ *   hist, likehist, P (the finished density of gd_density1d), likes_out: host B x F; smooth/winw/flags as
+ *   gd_density1d.
+ * gd_likes2d: mcsamples.py:1886-1903,2004-2006 for B pairs: bin2Dlikes = conv(likehist, Win) [with the
+ *   mbc re-smoothing of :1890-1897 when mbc != 0], divided by the uncorrected conv(hist, Win) where that
+ *   exceeds 1e-4 of its maximum (0 elsewhere), / max.  d_hist, d_likehist, d_likes_out: device B x F x F;
+ *   rx/ry/corr/winw/flags as gd_density2d (only the periodic bits matter). */
+int gd_like_weights(gd_ctx* ctx, const double* loglikes, int32_t mode, double mean_loglike, double* sum_out);
+int gd_select_weights(gd_ctx* ctx, int32_t which);
+int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* likehist, const double* P,
+               const double* smooth, const int32_t* winw, const int32_t* flags, int32_t shade_mean_loglikes,
+               double* likes_out, int32_t* status_out);
+int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const void* d_likehist, const double* rx,
+               const double* ry, const double* corr, const int32_t* winw, const int32_t* flags, int32_t mbc,
+               void* d_likes_out, int32_t* status_out);
+
 #ifdef __cplusplus
 }
 #endif

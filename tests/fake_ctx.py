@@ -80,7 +80,83 @@ class FakeContext:
 
     def _w(self, lo=0, hi=None):
         hi = self.N if hi is None else hi
+        if getattr(self, "_w_sel", 0):
+            return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
+
+    # ---- mean likelihoods
+    def like_weights(self, loglikes, mode, mean_loglike):
+        assert not getattr(self, "_w_sel", 0)
+        if loglikes is None:
+            self._like_w = None
+            return None
+        w = self._w()
+        ll = np.asarray(loglikes, dtype=np.float64)
+        self._like_w = w * ll if mode == 1 else w * np.exp(mean_loglike - ll)
+        return float(np.sum(self._like_w))
+
+    def select_weights(self, which):
+        assert which in (0, 1) and (which == 0 or self._like_w is not None)
+        self._w_sel = which
+
+    def likes1d(self, hist, likehist, P, smooth, winw, flags, shade_mean_loglikes):
+        hist, likehist, P = (np.asarray(a, dtype=float) for a in (hist, likehist, P))
+        out = np.zeros_like(hist)
+        status = np.zeros(len(hist), dtype=np.int32)
+        for b in range(len(hist)):
+            w_ = int(winw[b])
+            x = np.arange(-w_, w_ + 1)
+            Win = np.exp(-((x / smooth[b]) ** 2) / 2)
+            Win /= np.sum(Win)
+            mode = "periodic" if flags[b] & 4 else "same"
+            raw = ko.conv1d(hist[b], Win, mode)
+            ix = P[b] > 0
+            fine = likehist[b].copy()
+            fine[ix] /= P[b][ix]
+            lk = ko.conv1d(fine, Win, mode)
+            lk[ix] *= P[b][ix] / raw[ix]
+            if shade_mean_loglikes:
+                mn = np.min(lk)
+                lk = np.where((lk - mn) < 30, np.exp(-(lk - mn)), 0)
+                lk[raw == 0] = 0
+            mx = np.max(lk)
+            if mx == 0:
+                status[b] = -4
+            else:
+                out[b] = lk / mx
+        return out, status
+
+    def likes2d(self, d_hist, d_likehist, B, F, rx, ry, corr, winw, flags, mbc):
+        H = np.asarray(d_hist.a).reshape(B, F, F)
+        LH = np.asarray(d_likehist.a).reshape(B, F, F)
+        out = np.zeros((B, F, F))
+        status = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            fl, w_ = int(flags[b]), int(winw[b])
+            Cinv = np.linalg.inv(np.array([[ry[b] ** 2, rx[b] * ry[b] * corr[b]], [rx[b] * ry[b] * corr[b], rx[b] ** 2]]))
+            i1, i2 = np.mgrid[-w_:w_ + 1, -w_:w_ + 1]
+            Win = np.exp(-(i1**2 * Cinv[0, 0] + i2**2 * Cinv[1, 1] + 2 * Cinv[1, 0] * i1 * i2) / 2)
+            Win /= np.sum(Win)
+            px, py = bool(fl & 16), bool(fl & 32)
+            mode = "periodic_both" if px and py else "periodic_x" if px else "periodic_y" if py else "same"
+            big = F + 4 * w_ + 1
+            P0 = ko.conv2d(H[b], Win, mode, largest_size=big)
+            L = ko.conv2d(LH[b], Win, mode, largest_size=big)
+            if mbc:
+                ix = L > 0
+                fine = LH[b].copy()
+                fine[ix] /= L[ix]
+                L2 = ko.conv2d(fine, Win, mode, largest_size=big)
+                L2[ix] *= L[ix]
+                L = L2
+            mx = 1e-4 * np.max(P0)
+            L[P0 > mx] /= P0[P0 > mx]
+            L[P0 <= mx] = 0
+            if np.max(L) == 0:
+                status[b] = -4
+            else:
+                out[b] = L / np.max(L)
+        return FakeBuf(out), status
 
     # ---- moments
     def weight_stats(self, lo=0, hi=None, thresh=np.inf):

@@ -228,3 +228,45 @@ def test_split_tests_golden(zoo, name):
     else:  # real weights: a knife-edge quantile pick may move by one sample
         assert np.allclose(st, g, rtol=0, atol=2e-3)
     assert "Split tests" in mc.getConvergeTests(what=("SplitTest",))
+
+
+def test_meanlikes_golden(zoo):
+    """Mean-likelihood profiles / grids (gd_like_weights, gd_select_weights, gd_likes1d, gd_likes2d) against the
+    reference outputs and the oracle, including shade_likes_is_mean_loglikes, periodic axes and mbc 0/1/2."""
+    from getdist_amd.mcsamples import MCSamples
+
+    g = np.load(gu.GOLDEN_DIR + "/meanlikes.npz")
+    for case, kw1, kw2, fx, ll in gu.meanlikes_cases(zoo, g):
+        mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+        mc._use_like_weights(0)
+        assert abs(mc.mean_loglike - orc.mean_loglike) < 1e-12 * abs(orc.mean_loglike)
+        nj = min(6, len(fx["names"]))
+        for shade in (False, True):
+            mc.shade_likes_is_mean_loglikes = shade
+            for j, d in enumerate(mc.get1DDensities(list(range(nj)), meanlikes=True, **kw1)):
+                err = gu.relerr(d.likes, g["%s/1d/%d/shade%d" % (case, j, shade)])
+                assert err < TOL_GRID, (case, j, shade, err)
+        mc.shade_likes_is_mean_loglikes = False
+        pairs = fx["pairs"][:3]
+        dens = mc.get2DDensities(pairs, meanlikes=True, **kw2)
+        oracle_bw = []
+        for (a, b), d in zip(pairs, dens):
+            tr = {}
+            o = orc.density_2d(a, b, trace=tr, meanlikes=True, **kw2)
+            oracle_bw.append((tr["hx"], tr["hy"], tr["c"]))
+            bw_agrees = gu.relerr(d.bandwidth, oracle_bw[-1]) < 1e-6
+            assert bw_agrees or uses_tnc(d, mc, a, b), (case, a, b)
+            tol = TOL_GRID if bw_agrees else TOL_GRID_TNC
+            assert np.max(np.abs(d.likes - o["likes"])) < tol, (case, a, b, np.max(np.abs(d.likes - o["likes"])))
+            assert np.max(np.abs(d.P - o["P"])) < tol, (case, a, b)
+        # identical bandwidths in -> the reference's likes grids out, strictly
+        dens = mc.get2DDensities(pairs, meanlikes=True, _bandwidths=oracle_bw, **kw2)
+        for (a, b), d in zip(pairs, dens):
+            st = int(g["%s/2d/%d_%d/stride" % (case, a, b)])
+            err = gu.relerr(d.likes[::st, ::st], g["%s/2d/%d_%d/likes" % (case, a, b)])
+            assert err < TOL_GRID, (case, a, b, err)
+            assert abs(np.sum(d.likes) - float(g["%s/2d/%d_%d/sum" % (case, a, b)])) < 1e-5 * np.sum(d.likes)
+        # the sample weights are back: plain densities unchanged by the excursion
+        d0 = mc.get1DDensityGridData(0)
+        assert d0.likes is None and np.max(np.abs(d0.P - orc.density_1d(0)["P"])) < TOL_GRID

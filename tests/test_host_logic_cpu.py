@@ -45,6 +45,30 @@ def test_host_logic_matches_oracle_1d_and_2d(zoo):
         assert np.max(np.abs(d.P - o["P"])) < 1e-9
 
 
+def test_host_logic_meanlikes(zoo):
+    """The meanlikes branches of the 1D/2D host path (weights swap, likes kernels' call order) against the goldens."""
+    from getdist_amd.mcsamples import MCSamples
+
+    g = np.load(gu.GOLDEN_DIR + "/meanlikes.npz")
+    for case, kw1, kw2, fx, ll in gu.meanlikes_cases(zoo, g):
+        if not case.startswith(("c1_bounded/default", "periodic")):
+            continue
+        mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"],
+                       loglikes=ll, _context_factory=FakeContext)
+        for shade in (False, True):
+            mc.shade_likes_is_mean_loglikes = shade
+            for j in range(min(6, len(fx["names"]))):
+                d = mc.get1DDensityGridData(j, meanlikes=True, **kw1)
+                assert gu.relerr(d.likes, g["%s/1d/%d/shade%d" % (case, j, shade)]) < 1e-9, (case, j, shade)
+        mc.shade_likes_is_mean_loglikes = False
+        for a, b in fx["pairs"][:3]:
+            d = mc.get2DDensityGridData(a, b, meanlikes=True, **kw2)
+            st = int(g["%s/2d/%d_%d/stride" % (case, a, b)])
+            assert gu.relerr(d.likes[::st, ::st], g["%s/2d/%d_%d/likes" % (case, a, b)]) < 1e-9, (case, a, b)
+        assert mc.ctx._w_sel == 0  # the sample weights are selected again
+        assert mc.get1DDensityGridData(0).likes is None
+
+
 def test_host_logic_branches_and_grid_classes(zoo):
     """block50: all three bandwidth branches, four grid sizes, bounded and unbounded pairs through the batched path."""
     fx = zoo["block50"]
