@@ -305,6 +305,72 @@ __global__ void k_likes_ratio(const double* __restrict__ P0, const double* __res
         L[o + i] = (P0[o + i] > thresh) ? L[o + i] / P0[o + i] : 0.0;
 }
 
+// Direct (summation) 2D convolution with the Gaussian window, used by the mean-likelihood path: a sum of non-negative
+// terms has no cancellation noise, so exact zeros stay zero and tiny likelihood weights keep their relative accuracy
+// (the reference's FFT route makes its `bin2Dlikes > 0` mask depend on the sign of rounding noise).
+// src, dst: B x n0 x n1.  wrap != 0: circular over both axes (convolve.py:262-294), else zero outside ('same').
+// Block = 64 columns x 4 row groups; each thread accumulates RY consecutive rows so one operand load feeds RY taps.
+// The window is synthesised into LDS in column chunks.  grid (tiles, B)
+#define CONV_RY 4
+#define CONV_WIN_DOUBLES 4096
+__global__ void __launch_bounds__(256) k_conv2d_direct(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum,
+                                                       const double* __restrict__ src, int n0, int n1, int wrap,
+                                                       double* __restrict__ dst) {
+    __shared__ double win[CONV_WIN_DOUBLES];
+    const D2Pair p = pairs[blockIdx.y];
+    const double ws = wsum[blockIdx.y];
+    const int w = p.w, M = 2 * w + 1;
+    const int C = max(1, min(M, CONV_WIN_DOUBLES / M));  // window columns per chunk
+    const int tiles_x = (n1 + 63) / 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = (blockIdx.x % tiles_x) * 64 + tx;
+    const int y0 = (blockIdx.x / tiles_x) * (4 * CONV_RY) + ty * CONV_RY;
+    const double* s = src + (int64_t)blockIdx.y * n0 * n1;
+    double acc[CONV_RY];
+#pragma unroll
+    for (int k = 0; k < CONV_RY; ++k) acc[k] = 0.0;
+    const bool live = x < n1 && y0 < n0;
+    for (int c0 = 0; c0 < M; c0 += C) {
+        const int nc = min(C, M - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < M * nc; e += 256) {
+            const int r = e / nc, cc = e % nc;
+            win[r * C + cc] = win_raw(p, r - w, c0 + cc - w) / ws;
+        }
+        __syncthreads();
+        if (!live) continue;
+        for (int cc = 0; cc < nc; ++cc) {
+            int xs = x - (c0 + cc - w);
+            if (wrap) {
+                xs %= n1;
+                if (xs < 0) xs += n1;
+            } else if (xs < 0 || xs >= n1) {
+                continue;
+            }
+            for (int r = y0 - w; r <= y0 + CONV_RY - 1 + w; ++r) {
+                int rr = r;
+                if (wrap) {
+                    rr %= n0;
+                    if (rr < 0) rr += n0;
+                } else if (rr < 0 || rr >= n0) {
+                    continue;
+                }
+                const double v = s[(int64_t)rr * n1 + xs];
+#pragma unroll
+                for (int k = 0; k < CONV_RY; ++k) {
+                    const int i1 = y0 + k - r;
+                    if (i1 >= -w && i1 <= w) acc[k] = fma(win[(i1 + w) * C + cc], v, acc[k]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+    double* d = dst + (int64_t)blockIdx.y * n0 * n1;
+#pragma unroll
+    for (int k = 0; k < CONV_RY; ++k)
+        if (y0 + k < n0) d[(int64_t)(y0 + k) * n1 + x] = acc[k];
+}
+
 // ---- periodic axes (convolve.py:215-323): circular convolution on the folded (Ny x Nx) grid ------------------
 // fold an F x F array onto the circular grid: drop the last column/row of a periodic axis and add it to the first
 __global__ void k_fill_circ(const double* __restrict__ src, int F, int Ny, int Nx, double* __restrict__ frames) {
@@ -712,13 +778,13 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
         if (winw[b] > maxw) maxw = winw[b];
         GD_REQUIRE((hp[b].flags & 48) == (flags[0] & 48), "a batch must not mix periodic and non-periodic pairs");
     }
+    GD_REQUIRE(2 * maxw + 1 <= CONV_WIN_DOUBLES, "window too wide for the direct convolution");
     const int per = flags[0] & 48;
     const bool px = per & 16, py = per & 32;
-    // operand frames: zero-padded S x S for 'same', the folded (Ny x Nx) circular grid for periodic axes
-    const int S = next_fft_size(F + 2 * maxw);
-    const int n0 = per ? (py ? F - 1 : F) : S, n1 = per ? (px ? F - 1 : F) : S, n1h = n1 / 2 + 1;
+    // operands: the F x F grid itself for 'same', the folded circular (n0 x n1) grid for periodic axes
+    const int n0 = py ? F - 1 : F, n1 = px ? F - 1 : F;
     if (per) GD_REQUIRE(2 * maxw + 1 <= n1 && 2 * maxw + 1 <= n0, "window wider than the periodic grid");
-    const int64_t FF = (int64_t)F * F, NN = (int64_t)n0 * n1, NC = (int64_t)n0 * n1h;
+    const int64_t FF = (int64_t)F * F, NN = (int64_t)n0 * n1;
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
         int64_t o = off;
@@ -726,50 +792,34 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
         return o;
     };
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
-                  o_status = take((int64_t)B * 4), o_R = take(B * NN * 8), o_RO = take(B * NN * 8),
-                  o_ZW = take(B * NC * 16), o_ZA = take(B * NC * 16), o_ZP = take(B * NC * 16), o_P0 = take(B * FF * 8),
-                  o_T = take(B * FF * 8), o_L2 = take(B * FF * 8);
+                  o_status = take((int64_t)B * 4), o_C1 = take(per ? B * NN * 8 : 0), o_C2 = take(per ? B * NN * 8 : 0),
+                  o_P0 = take(B * FF * 8), o_T = take(B * FF * 8), o_L2 = take(B * FF * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
     double* d_wsum = (double*)(base + o_wsum);
     double* d_mx = (double*)(base + o_mx);
     int* d_status = (int*)(base + o_status);
-    double *R = (double*)(base + o_R), *RO = (double*)(base + o_RO), *d_P0 = (double*)(base + o_P0),
+    double *C1 = (double*)(base + o_C1), *C2 = (double*)(base + o_C2), *d_P0 = (double*)(base + o_P0),
            *d_T = (double*)(base + o_T), *d_L2 = (double*)(base + o_L2);
-    double2 *ZW = (double2*)(base + o_ZW), *ZA = (double2*)(base + o_ZA), *ZP = (double2*)(base + o_ZP);
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
-    const dim3 gN(128, B), gF(64, B);
-    const double scale = 1.0 / ((double)n0 * (double)n1);
+    const dim3 gN(64, B), gF(64, B);
+    const dim3 gC((unsigned)(((n1 + 63) / 64) * ((n0 + 4 * CONV_RY - 1) / (4 * CONV_RY))), B);
     k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
     GD_KERNEL_CHECK();
-    if (per)
-        k_fill_window_rect<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, n0, n1, 0, 0, R);
-    else
-        k_fill_window<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, R);
-    GD_KERNEL_CHECK();
-    int rc = gd_fft_r2c_2d(ctx, n0, n1, B, R, ZW);
-    if (rc) return rc;
-    // dst = convolve2D(src, Win, convolution_mode)
+    // dst = convolve2D(src, Win, convolution_mode), by direct summation
     auto smooth = [&](const double* src, double* dst) -> int {
-        if (per)
-            k_fill_circ<<<gN, 256, 0, ctx->stream>>>(src, F, n0, n1, R);
-        else
-            k_fill_embed<<<gN, 256, 0, ctx->stream>>>(d_pairs, src, F, S, R);
-        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "operand fill launch failed");
-        int r = gd_fft_r2c_2d(ctx, n0, n1, B, R, ZA);
-        if (r) return r;
-        k_cmul<<<2048, 256, 0, ctx->stream>>>(ZA, ZW, B * NC, scale, ZP);
-        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_cmul launch failed");
-        r = gd_fft_c2r_2d(ctx, n0, n1, B, ZP, RO);
-        if (r) return r;
-        if (per)
-            k_expand_circ<<<gF, 256, 0, ctx->stream>>>(RO, F, n0, n1, dst);
-        else
-            k_crop<<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst);
-        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "crop launch failed");
+        if (per) {
+            k_fill_circ<<<gN, 256, 0, ctx->stream>>>(src, F, n0, n1, C1);
+            k_conv2d_direct<<<gC, 256, 0, ctx->stream>>>(d_pairs, d_wsum, C1, n0, n1, 1, C2);
+            k_expand_circ<<<gF, 256, 0, ctx->stream>>>(C2, F, n0, n1, dst);
+        } else {
+            k_conv2d_direct<<<gC, 256, 0, ctx->stream>>>(d_pairs, d_wsum, src, n0, n1, 0, dst);
+        }
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "convolution launch failed");
         return GD_OK;
     };
+    int rc;
     if ((rc = smooth(d_hist, d_P0))) return rc;       // bins2D before any correction (mcsamples.py:1884)
     if ((rc = smooth(d_likehist, d_L))) return rc;    // bin2Dlikes (:1887)
     if (mbc) {                                        // :1890-1897

@@ -203,7 +203,9 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const do
  * gd_likes2d: mcsamples.py:1886-1903,2004-2006 for B pairs: bin2Dlikes = conv(likehist, Win) [with the
  *   mbc re-smoothing of :1890-1897 when mbc != 0], divided by the uncorrected conv(hist, Win) where that
  *   exceeds 1e-4 of its maximum (0 elsewhere), / max.  d_hist, d_likehist, d_likes_out: device B x F x F;
- *   rx/ry/corr/winw/flags as gd_density2d (only the periodic bits matter). */
+ *   rx/ry/corr/winw/flags as gd_density2d (only the periodic bits matter).  The convolutions are evaluated
+ *   by direct summation, not FFTs: the same linear maps, but free of the cancellation noise whose sign decides
+ *   the reference's `bin2Dlikes > 0` mask at low-likelihood pixels ("mean likelihoods"). */
 int gd_like_weights(gd_ctx* ctx, const double* loglikes, int32_t mode, double mean_loglike, double* sum_out);
 int gd_select_weights(gd_ctx* ctx, int32_t which);
 int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* likehist, const double* P,

@@ -173,6 +173,59 @@ def conv2d(x, y, mode, largest_size=0):
     return conv2d_fft(x, y, mode, largest_size)
 
 
+def conv2d_direct(x, y, mode):
+    """
+    The same linear maps as conv2d(x, y, mode) for mode in same / periodic_*, evaluated by direct summation
+    (scipy.signal.convolve2d) instead of FFTs: identical in exact arithmetic, but a sum of non-negative terms has no
+    cancellation noise, so zeros stay exactly zero and tiny values keep their relative accuracy.
+    """
+    from scipy.signal import convolve2d
+
+    px = mode in ("periodic", "periodic_both", "periodic_x")
+    py = mode in ("periodic", "periodic_both", "periodic_y")
+    if not (px or py):
+        return convolve2d(x, y, mode="same")
+    ny, nx = x.shape
+    xc = x[:ny - 1 if py else ny, :nx - 1 if px else nx].copy()  # fold exactly as conv2d_periodic does
+    if px:
+        xc[:, 0] += x[:xc.shape[0], -1]
+    if py:
+        xc[0, :] += x[-1, :xc.shape[1]]
+    if px and py:
+        xc[0, 0] += x[-1, -1]
+    # convolve.py:262-294: the transform is circular over BOTH axes of the folded grid (the non-periodic axis of a
+    # single-axis periodic pair wraps too; that is the reference's behaviour and the device path's)
+    ky, kx = y.shape
+    padded = np.pad(xc, ((ky // 2, ky // 2), (kx // 2, kx // 2)), mode="wrap")
+    res = convolve2d(padded, y, mode="valid")
+    out = np.empty((ny, nx))
+    out[:res.shape[0], :res.shape[1]] = res
+    if px:
+        out[:res.shape[0], -1] = res[:, 0]
+    if py:
+        out[-1, :res.shape[1]] = res[0, :]
+    if px and py:
+        out[-1, -1] = res[0, 0]
+    return out
+
+
+def mean_likes_2d(histbins, finebinlikes, Win, mode, mbc, conv):
+    """mcsamples.py:1884-1901 + 2005 with the convolution routine as a parameter (conv2d or conv2d_direct)."""
+    bins2D = conv(histbins, Win, mode)
+    finebinlikes = finebinlikes.copy()
+    bin2Dlikes = conv(finebinlikes, Win, mode)
+    if mbc:
+        ix = bin2Dlikes > 0
+        finebinlikes[ix] /= bin2Dlikes[ix]
+        likes2 = conv(finebinlikes, Win, mode)
+        likes2[ix] *= bin2Dlikes[ix]
+        bin2Dlikes = likes2
+    mx = 1e-4 * np.max(bins2D)
+    bin2Dlikes[bins2D > mx] /= bins2D[bins2D > mx]
+    bin2Dlikes[bins2D <= mx] = 0
+    return bin2Dlikes / np.max(bin2Dlikes)
+
+
 def auto_convolve(x, n=None, normalize=True):
     """convolve.py:458-478: lag sums sum_i x_i x_{i+k}, k=0..n-1 (optionally / number of terms)"""
     s = nearest_fft_number(2 * x.size)
@@ -986,8 +1039,10 @@ class OracleSamples:
         else:
             mode = "same"
         bins2D = conv2d(histbins, Win, mode, largest_size=convolvesize)
-        bin2Dlikes = None
+        bin2Dlikes = likes_exact = None
         if meanlikes:  # mcsamples.py:1886-1901
+            if kwargs.get("likes_exact"):  # the same algorithm free of FFT cancellation noise (see conv2d_direct)
+                likes_exact = mean_likes_2d(histbins, finebinlikes, Win, mode, mbc, conv2d_direct)
             bin2Dlikes = conv2d(finebinlikes, Win, mode, largest_size=convolvesize)
             if mbc:
                 ixl = bin2Dlikes > 0
@@ -1051,7 +1106,7 @@ class OracleSamples:
             trace.update(fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr_used=corr, actual_corr=actual_corr)
         return dict(x=x, y=y, P=bins2D, view_ranges=[(parx.range_min, parx.range_max), (pary.range_min, pary.range_max)],
                     histbins=histbins, flatix=flatix, fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr=corr,
-                    likes=bin2Dlikes)
+                    likes=bin2Dlikes, likes_exact=likes_exact)
 
     # ---- convergence (chains.py:1446-1486; mcsamples.py:964-985) --------------------------------
     def gelman_rubin_eigenvalues(self, chain_offsets, nparam=None):

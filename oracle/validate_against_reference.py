@@ -119,6 +119,7 @@ def compare_meanlikes():
     zoo = {fx["name"]: fx for fx in fixture_zoo()}
     ok = True
     worst = 0.0
+    worst_bad = 0
     for nm, kws in MEANLIKES_CASES:
         fx = zoo[nm]
         ll = loglikes_for(fx["samples"])
@@ -137,11 +138,19 @@ def compare_meanlikes():
             ref.shade_likes_is_mean_loglikes = orc.shade_likes_is_mean_loglikes = False
             for a, b in fx["pairs"][:4]:
                 d_ref = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], meanlikes=True, **kw2)
-                d_orc = orc.density_2d(a, b, meanlikes=True, **kw2)
+                exact = d_ref.P.shape[0] <= 384
+                d_orc = orc.density_2d(a, b, meanlikes=True, likes_exact=exact, **kw2)
                 e = max(relerr(d_orc["likes"], d_ref.likes), relerr(d_orc["P"], d_ref.P))
                 worst = max(worst, e)
                 ok &= e <= 1e-10
-    print(("ok  " if ok else "FAIL") + " mean likelihoods 1D/2D (worst %.1e)" % worst)
+                if exact:
+                    # the direct-summation evaluation of the same formulas equals the reference except at the
+                    # isolated pixels where the reference's FFT rounding noise decides its `bin2Dlikes > 0` mask
+                    bad = int(np.sum(np.abs(d_orc["likes_exact"] - d_ref.likes) > 1e-6))
+                    worst_bad = max(worst_bad, bad)
+                    ok &= bad <= 8
+    print(("ok  " if ok else "FAIL") + " mean likelihoods 1D/2D (worst %.1e; direct-summation variant differs from "
+          "the reference at <= %d noise-decided pixels per grid)" % (worst, worst_bad))
     return ok
 
 

@@ -139,23 +139,11 @@ class FakeContext:
             Win /= np.sum(Win)
             px, py = bool(fl & 16), bool(fl & 32)
             mode = "periodic_both" if px and py else "periodic_x" if px else "periodic_y" if py else "same"
-            big = F + 4 * w_ + 1
-            P0 = ko.conv2d(H[b], Win, mode, largest_size=big)
-            L = ko.conv2d(LH[b], Win, mode, largest_size=big)
-            if mbc:
-                ix = L > 0
-                fine = LH[b].copy()
-                fine[ix] /= L[ix]
-                L2 = ko.conv2d(fine, Win, mode, largest_size=big)
-                L2[ix] *= L[ix]
-                L = L2
-            mx = 1e-4 * np.max(P0)
-            L[P0 > mx] /= P0[P0 > mx]
-            L[P0 <= mx] = 0
-            if np.max(L) == 0:
+            L = ko.mean_likes_2d(H[b], LH[b], Win, mode, mbc, ko.conv2d_direct)  # direct summation, like the kernel
+            if not np.max(L) > 0:
                 status[b] = -4
             else:
-                out[b] = L / np.max(L)
+                out[b] = L
         return FakeBuf(out), status
 
     # ---- moments
