@@ -86,6 +86,9 @@ SIGNATURES = {
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_set_extra_column": (C.c_int, [_p, _i32, _pd]),
+    "gd_aux_weights": (C.c_int, [_p, _pd]),
+    "gd_col_minmax": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _i32, C.c_double, _pd]),
     "gd_like_weights": (C.c_int, [_p, _pd, _i32, C.c_double, _pd]),
     "gd_select_weights": (C.c_int, [_p, _i32]),
     "gd_likes1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _pi32, _pi32, _i32, _pd, _pi32]),
@@ -462,6 +465,31 @@ class Context:
         self._check(self.lib.gd_density1d(self.h, B, F, _dp(hist), _dp(smooth), _ip(winw), _ip(flags), int(bco),
                                           int(mbc), _dp(P), _ip(status)))
         return P, status
+
+    # ---- auxiliary vectors
+    EXTRA_COLS = 4
+
+    def set_extra_column(self, slot, x):
+        """Copy a host vector into spare column ``slot``; returns the column index (n + slot) it is addressed by."""
+        x = _f64arr(x)
+        if x.shape != (self.N,):
+            raise ValueError("vector must have one entry per sample row")
+        self._check(self.lib.gd_set_extra_column(self.h, int(slot), _dp(x)))
+        return self.n + int(slot)
+
+    def aux_weights(self, w):
+        w = _f64arr(w)
+        if w.shape != (self.N,):
+            raise ValueError("weights must have one entry per sample row")
+        self._check(self.lib.gd_aux_weights(self.h, _dp(w)))
+
+    def col_minmax(self, cols, lo=0, hi=None, cond_col=-1, cond_below=0.0):
+        """min / max per column over the rows whose ``cond_col`` value is < ``cond_below`` (cond_col < 0: all rows)."""
+        cols = _i32arr(cols)
+        out = np.zeros((len(cols), 2))
+        self._check(self.lib.gd_col_minmax(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi,
+                                           int(cond_col), float(cond_below), _dp(out)))
+        return out
 
     # ---- mean likelihoods
     def like_weights(self, loglikes, mode, mean_loglike):

@@ -410,7 +410,7 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
     GD_REQUIRE(ctx && cols && binmin && width && out && ncols > 0, "bad argument");
     GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins out of range (2..4096)");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
-    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     const int nblk = ctx->cu_count;
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
@@ -450,7 +450,7 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
 int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
                    int32_t* idx_out, int64_t* n_out_of_range) {
     GD_REQUIRE(ctx && idx_out, "bad argument");
-    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n + GD_EXTRA_COLS, "bad column");
     char* base = (char*)gd_scratch(ctx, ctx->N * 4 + 256);
     if (!base) return GD_ERR_NOMEM;
     unsigned long long* d_bad = (unsigned long long*)base;
@@ -472,7 +472,7 @@ int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_
 
 int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16) {
     GD_REQUIRE(ctx && d_idx_u16, "bad argument");
-    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n, "bad column");
+    GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n + GD_EXTRA_COLS, "bad column");
     GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
     const double* x = ctx->cols + (int64_t)col * ctx->ld;
     k_prebin<<<8 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, (unsigned short*)d_idx_u16);
@@ -487,7 +487,7 @@ int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doubl
     GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
     std::vector<PrebinCol> hc((size_t)ncols);
     for (int c = 0; c < ncols; ++c) {
-        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n && d_idx_u16[c], "bad column / null index buffer");
+        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_u16[c], "bad column / null index buffer");
         hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
         hc[c].idx = (unsigned short*)d_idx_u16[c];
         hc[c].binmin = binmin[c];
@@ -511,7 +511,7 @@ int gd_hist2d(gd_ctx* ctx, int32_t B, const int32_t* colx, const int32_t* coly, 
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     std::vector<Hist2DPair> hp((size_t)B);
     for (int b = 0; b < B; ++b) {
-        GD_REQUIRE(colx[b] >= 0 && colx[b] < ctx->n && coly[b] >= 0 && coly[b] < ctx->n, "column out of range");
+        GD_REQUIRE(colx[b] >= 0 && colx[b] < ctx->n + GD_EXTRA_COLS && coly[b] >= 0 && coly[b] < ctx->n + GD_EXTRA_COLS, "column out of range");
         Hist2DPair& p = hp[b];
         memset(&p, 0, sizeof p);
         p.x = ctx->cols + (int64_t)colx[b] * ctx->ld;
@@ -597,7 +597,7 @@ int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     std::vector<Hist2DPair> hp((size_t)B);
     for (int b = 0; b < B; ++b) {
-        GD_REQUIRE(coli[b] >= 0 && coli[b] < ctx->n && colj[b] >= 0 && colj[b] < ctx->n, "column out of range");
+        GD_REQUIRE(coli[b] >= 0 && coli[b] < ctx->n + GD_EXTRA_COLS && colj[b] >= 0 && colj[b] < ctx->n + GD_EXTRA_COLS, "column out of range");
         Hist2DPair& p = hp[b];
         memset(&p, 0, sizeof p);
         p.x = ctx->cols + (int64_t)coli[b] * ctx->ld;
@@ -613,7 +613,7 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     std::vector<Hist2DPair> hp((size_t)B);
     for (int q = 0; q < B; ++q) {
-        GD_REQUIRE(coli[q] >= 0 && coli[q] < ctx->n && colj[q] >= 0 && colj[q] < ctx->n, "column out of range");
+        GD_REQUIRE(coli[q] >= 0 && coli[q] < ctx->n + GD_EXTRA_COLS && colj[q] >= 0 && colj[q] < ctx->n + GD_EXTRA_COLS, "column out of range");
         Hist2DPair& p = hp[q];
         memset(&p, 0, sizeof p);
         p.x = ctx->cols + (int64_t)coli[q] * ctx->ld;

@@ -270,7 +270,8 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     ctx->w_sel = 0;
     ctx->N = ctx->n = ctx->ld = 0;
     const int64_t ld = (N + 511) / 512 * 512;
-    GD_HIP(hipMalloc((void**)&ctx->cols, (size_t)(ld * n * 8)));
+    GD_HIP(hipMalloc((void**)&ctx->cols, (size_t)(ld * (n + GD_EXTRA_COLS) * 8)));
+    GD_HIP(hipMemsetAsync(ctx->cols + ld * n, 0, (size_t)(ld * GD_EXTRA_COLS * 8), ctx->stream));
     if (row_stride == 1) {
         // column-major host input: one contiguous copy per column
         for (int64_t j = 0; j < n; ++j)
@@ -329,7 +330,7 @@ int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out) {
         *d_out = ctx->w;
         return GD_OK;
     }
-    GD_REQUIRE(j >= 0 && j < ctx->n, "column out of range");
+    GD_REQUIRE(j >= 0 && j < ctx->n + GD_EXTRA_COLS, "column out of range");
     *d_out = ctx->cols + j * ctx->ld;
     return GD_OK;
 }
@@ -399,6 +400,29 @@ int gd_select_weights(gd_ctx* ctx, int32_t which) {
         ctx->w_main = nullptr;
     }
     ctx->w_sel = which;
+    return GD_OK;
+}
+
+int gd_set_extra_column(gd_ctx* ctx, int32_t slot, const double* x) {
+    GD_REQUIRE(ctx && x, "null argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(slot >= 0 && slot < GD_EXTRA_COLS, "extra column slot out of range");
+    GD_HIP(hipMemcpyAsync(ctx->cols + (ctx->n + slot) * ctx->ld, x, (size_t)(ctx->N * 8), hipMemcpyHostToDevice,
+                          ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_aux_weights(gd_ctx* ctx, const double* w) {
+    GD_REQUIRE(ctx && w, "null argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(ctx->w_sel == 0, "auxiliary weights are selected; call gd_select_weights(ctx, 0) first");
+    if (!ctx->like_w) {
+        GD_HIP(hipMalloc((void**)&ctx->like_w, (size_t)(ctx->ld * 8)));
+        GD_HIP(hipMemsetAsync(ctx->like_w, 0, (size_t)(ctx->ld * 8), ctx->stream));
+    }
+    GD_HIP(hipMemcpyAsync(ctx->like_w, w, (size_t)(ctx->N * 8), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;
 }
 

@@ -13,6 +13,8 @@
 
 struct FftPlanCache;  // density2d.hip
 
+#define GD_EXTRA_COLS 4  // spare columns behind the sample columns (gd_set_extra_column): loglikes, derived vectors
+
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

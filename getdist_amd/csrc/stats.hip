@@ -87,6 +87,28 @@ __global__ void k_weight_stats(const double* __restrict__ w, int64_t lo, int64_t
 }
 
 // ---- column statistics ----------------------------------------------------------------------------------
+// min / max of each column over the rows of [lo,hi) whose condition-column value is < below (cond == nullptr: all
+// rows).  grid (blocks, ncols)
+template <bool HAS_COND>
+__global__ void k_col_minmax(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                             const double* __restrict__ cond, double below, int64_t lo, int64_t hi,
+                             double* __restrict__ part) {
+    __shared__ double red[16];
+    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
+    double mn = INFINITY, mx = -INFINITY;
+    stream_xw<HAS_COND>(x, cond, lo, hi, [&](double v, double c) {
+        if (!HAS_COND || c < below) {
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    });
+    double r0 = block_min(mn, red), r1 = block_max(mx, red);
+    if (threadIdx.x == 0) {
+        double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        p[0] = r0, p[1] = r1;
+    }
+}
+
 // pass 1: min, max, sum w, sum w x      pass 2: sum w (x-mean)^2
 template <bool HAS_W>
 __global__ void k_col_pass1(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
@@ -508,7 +530,7 @@ extern "C" {
 int gd_kde_lag_sums_2d(gd_ctx* ctx, int32_t coli, int32_t colj, const double* kinv3, const int64_t* lags, int32_t nlags,
                        double* out) {
     GD_REQUIRE(ctx && kinv3 && lags && out && nlags > 0 && nlags <= 64, "bad argument");
-    GD_REQUIRE(ctx->cols && coli >= 0 && coli < ctx->n && colj >= 0 && colj < ctx->n, "bad column");
+    GD_REQUIRE(ctx->cols && coli >= 0 && coli < ctx->n + GD_EXTRA_COLS && colj >= 0 && colj < ctx->n + GD_EXTRA_COLS, "bad column");
     for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
     int nblk = (8 * ctx->cu_count + nlags - 1) / nlags;
     if (nblk < 8) nblk = 8;
@@ -606,11 +628,45 @@ int gd_col_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double* out) {
     return GD_OK;
 }
 
+int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, int32_t cond_col,
+                  double cond_below, double* out) {
+    GD_REQUIRE(ctx && cols && out && ncols > 0, "bad argument");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    GD_REQUIRE(cond_col < ctx->n + GD_EXTRA_COLS, "condition column out of range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
+    const int nblk = NBLK_STREAM;
+    const int64_t idx_bytes = ((int64_t)ncols * 4 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, idx_bytes + (int64_t)ncols * nblk * 2 * 8);
+    if (!base) return GD_ERR_NOMEM;
+    int32_t* d_idx = (int32_t*)base;
+    double* d_part = (double*)(base + idx_bytes);
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid(nblk, ncols);
+    if (cond_col >= 0)
+        k_col_minmax<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->cols + (int64_t)cond_col * ctx->ld,
+                                                          cond_below, lo, hi, d_part);
+    else
+        k_col_minmax<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, 0.0, lo, hi, d_part);
+    GD_KERNEL_CHECK();
+    std::vector<double> h((size_t)ncols * nblk * 2);
+    GD_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ncols; ++c) {
+        double mn = INFINITY, mx = -INFINITY;
+        for (int b = 0; b < nblk; ++b) {
+            mn = fmin(mn, h[((size_t)c * nblk + b) * 2]);
+            mx = fmax(mx, h[((size_t)c * nblk + b) * 2 + 1]);
+        }
+        out[2 * c] = mn, out[2 * c + 1] = mx;
+    }
+    return GD_OK;
+}
+
 int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, double* means_out, double* cov_out,
            double* norm_out) {
     GD_REQUIRE(ctx && cols && means_out && cov_out && norm_out && m > 0, "bad argument");
     GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
-    for (int i = 0; i < m; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < m; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     const int nt = (m + CT - 1) / CT;
     std::vector<int2> tiles;
     for (int a = 0; a < nt; ++a)
@@ -669,7 +725,7 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     GD_REQUIRE(ctx && cols && targets && out && ncols > 0, "bad argument");
     GD_REQUIRE(k > 0 && k <= QK_MAX, "at most 16 quantiles per call");
     GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
-    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     std::vector<QState> hst((size_t)ncols);
     memset(hst.data(), 0, hst.size() * sizeof(QState));
     for (int c = 0; c < ncols; ++c) {
@@ -729,7 +785,7 @@ int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols,
     GD_REQUIRE(ctx->cols && k0 >= 0, "bad lag / no samples");
     GD_REQUIRE(row_lo >= 0 && row_hi <= ctx->N && row_lo < row_hi, "bad row range");
     const int64_t NR = row_hi - row_lo;
-    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     int nblk = (4 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk < 16) nblk = 16;
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
@@ -785,7 +841,7 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
                           int32_t nlags, double* out) {
     GD_REQUIRE(ctx && cols && inv4s2 && lags && out && nlags > 0 && nlags <= 64 && ncols > 0, "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
-    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n, "column out of range");
+    for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
     int nblk = (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
     if (nblk < 8) nblk = 8;

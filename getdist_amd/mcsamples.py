@@ -106,8 +106,10 @@ class MargeStats:
 class ParamConfidenceData:
     """Handle returned by initParamConfidenceData (chains.py:176-178 namedtuple in the reference)."""
 
-    def __init__(self, col, start, end):
+    def __init__(self, col, start, end, weights=None, vec=None):
         self.col, self.start, self.end = col, start, end
+        self.weights = weights  # alternative weights (host, full length) or None
+        self.vec = vec          # host vector the handle refers to when it is not a resident column
 
 
 class ParamNames:
@@ -529,24 +531,28 @@ class MCSamples:
         finally:
             self.ctx.select_weights(0)
 
-    def mean_diff(self, paramVec):
+    def mean_diff(self, paramVec, where=None):
         """chains.py:744-761 (host vector p_i - mean; the device path never materialises it)"""
-        j = self._col(paramVec)
-        return self.samples[:, j] - self.means[j]
+        vec = self._host_vector(paramVec)
+        if vec is None:
+            vec = self.samples[:, self._col(paramVec)]
+        if where is None:
+            return vec - self.mean(paramVec)
+        return vec[where] - self.mean(paramVec, where)
 
-    def mean_diffs(self, pars=None):
+    def mean_diffs(self, pars=None, where=None):
         """chains.py:763-780"""
         cols = range(self.n) if pars is None else (range(pars) if isinstance(pars, (int, np.integer)) else pars)
-        return [self.mean_diff(j) for j in cols]
+        return [self.mean_diff(j, where) for j in cols]
 
     def initParamConfidenceData(self, paramVec, start=0, end=None, weights=None):
         """
         chains.py:793-812.  The reference caches argsort + cumulative weights here; the device path selects
         quantiles without sorting, so the "cache" is just the (column, row range) handle confidence() accepts.
         """
-        if weights is not None:
-            raise NotImplementedError("alternative weights are not resident on the device")
-        return ParamConfidenceData(self._col(paramVec), start, self.numrows if end is None else end)
+        vec = self._host_vector(paramVec)
+        return ParamConfidenceData(None if vec is not None else self._col(paramVec), start,
+                                   self.numrows if end is None else end, weights=weights, vec=vec)
 
     def getFractionIndices(self, weights, n):
         """mcsamples.py:668-680: row indices splitting the total weight into n equal parts"""
@@ -728,6 +734,7 @@ class MCSamples:
         for par in self.paramNames.names:
             par.N_eff_kde = None
             par._ranges_done = False
+        self._nd_limits_done = False
         self.needs_update = False
         return self
 
@@ -753,8 +760,63 @@ class MCSamples:
         raise ParamError("Unknown parameter type %s" % name)
 
     # ---- moments (chains.py:339-412, 636-780) ------------------------------------------------------------
-    def get_norm(self):
-        return self.norm
+    # Vectors, row filters and alternative weights (chains.py:325-337, 636-780): a host vector goes into one of the
+    # device's spare columns; `where=` / `weights=` become an auxiliary weight vector (weights*mask) that is swapped in
+    # for the duration of the call, which gives exactly the reference's x[where], w[where] sums.
+    def _host_vector(self, par):
+        """The host vector behind a non-column argument of _makeParamvec (chains.py:325-337), else None."""
+        if isinstance(par, np.ndarray):
+            if par.shape != (self.numrows,):
+                raise WeightedSampleError("parameter vector must have one entry per sample")
+            return par
+        if isinstance(par, (int, np.integer)) and not isinstance(par, bool):
+            if par == -1:
+                if self.loglikes is None:
+                    raise WeightedSampleError("Samples do not have logLikes (par=-1)")
+                return self.loglikes
+            if par == -2:
+                return self.weights if self.weights is not None else np.ones(self.numrows)
+            if not 0 <= par < self.n:
+                raise WeightedSampleError("Parameter %i does not exist" % par)
+        return None
+
+    def _vec_col(self, par, slot=0):
+        """Device column index for a parameter reference or a host vector (uploaded into spare column ``slot``)."""
+        vec = par.vec if isinstance(par, ParamConfidenceData) else self._host_vector(par)
+        if vec is not None:
+            if slot >= self.ctx.EXTRA_COLS:
+                raise WeightedSampleError("at most %d vector arguments per call" % self.ctx.EXTRA_COLS)
+            return self.ctx.set_extra_column(slot, vec)
+        return par.col if isinstance(par, ParamConfidenceData) else self._col(par)
+
+    def _where_weights(self, where):
+        """weights*mask for a boolean mask or an index array (numpy semantics of x[where])."""
+        where = np.asarray(where)
+        w = self.weights if self.weights is not None else np.ones(self.numrows)
+        if where.dtype == bool:
+            if where.shape != (self.numrows,):
+                raise WeightedSampleError("where must have one entry per sample")
+            return w * where
+        return w * np.bincount(where.astype(np.int64) % self.numrows, minlength=self.numrows)
+
+    def _with_weights(self, w_host, fn):
+        """Run ``fn`` with the auxiliary weight vector ``w_host`` selected on the device."""
+        self.ctx.aux_weights(w_host)
+        self._like_mode = None  # the auxiliary buffer is shared with the like weights
+        self.ctx.select_weights(1)
+        try:
+            return fn()
+        finally:
+            self.ctx.select_weights(0)
+
+    def get_norm(self, where=None):
+        if where is None:
+            return self.norm
+        return self._with_weights(self._where_weights(where), lambda: self.ctx.weight_stats()["norm"])
+
+    def weighted_sum(self, paramVec, where=None):
+        """chains.py:636-649"""
+        return self.mean(paramVec, where) * self.get_norm(where)
 
     def getMeans(self, pars=None):
         return self.means if pars is None else np.array([self.means[i] for i in pars])
@@ -774,9 +836,25 @@ class MCSamples:
             return self.fullcov[np.ix_(pars, pars)]
         return self.fullcov[:nparam, :nparam]
 
-    def cov(self, pars=None):
-        cols = list(range(self.n)) if pars is None else [self._parAndNumber(p)[0] for p in pars]
-        return self.ctx.cov(cols)[1]
+    def _moments(self, pars, where):
+        """(means, cov, norm) of parameter references / vectors, optionally over a row filter: one gd_cov call."""
+        slot = 0
+        cols = []
+        for p in pars:
+            if self._host_vector(p) is not None:
+                cols.append(self._vec_col(p, slot))
+                slot += 1
+            else:
+                cols.append(self._col(p))
+        if where is None:
+            return self.ctx.cov(cols)
+        return self._with_weights(self._where_weights(where), lambda: self.ctx.cov(cols))
+
+    def cov(self, pars=None, where=None):
+        """chains.py:709-733"""
+        if isinstance(pars, (int, np.integer)):
+            pars = range(pars)
+        return self._moments(list(range(self.n)) if pars is None else list(pars), where)[1]
 
     def corr(self, pars=None):
         return covToCorr(self.cov(pars))
@@ -792,32 +870,53 @@ class MCSamples:
             raise ParamError("unknown parameter %s" % par)
         return j
 
-    def mean(self, paramVec):
-        if isinstance(paramVec, (list, tuple)):
-            return np.array([self.means[self._col(p)] for p in paramVec])
-        return self.means[self._col(paramVec)]
+    def _is_plain_column(self, par):
+        return self._host_vector(par) is None
 
-    def var(self, paramVec):
+    def mean(self, paramVec, where=None):
+        """chains.py:665-677"""
         if isinstance(paramVec, (list, tuple)):
-            return np.array([self.vars[self._col(p)] for p in paramVec])
-        return self.vars[self._col(paramVec)]
+            if where is None and all(self._is_plain_column(p) for p in paramVec):
+                return np.array([self.means[self._col(p)] for p in paramVec])
+            return np.array([self.mean(p, where) for p in paramVec])
+        if where is None and self._is_plain_column(paramVec):
+            return self.means[self._col(paramVec)]
+        return self._moments([paramVec], where)[0][0]
 
-    def std(self, paramVec):
-        return np.sqrt(self.var(paramVec))
+    def var(self, paramVec, where=None):
+        """chains.py:679-693 (like the reference, a list ignores ``where``)"""
+        if isinstance(paramVec, (list, tuple)):
+            return np.array([self.var(p) for p in paramVec])
+        if where is None and self._is_plain_column(paramVec):
+            return self.vars[self._col(paramVec)]
+        return self._moments([paramVec], where)[1][0, 0]
+
+    def std(self, paramVec, where=None):
+        return np.sqrt(self.var(paramVec, where))
 
     # ---- weighted quantiles (chains.py:782-838) ----------------------------------------------------------
     def confidence(self, paramVec, limfrac, upper=False, start=0, end=None, weights=None):
-        if weights is not None:
-            raise NotImplementedError("alternative weights are not resident on the device")
+        """chains.py:814-838: sort-free weighted quantile selection on the device (gd_quantiles)."""
         if isinstance(paramVec, ParamConfidenceData):
-            j, start, end = paramVec.col, paramVec.start, paramVec.end
-        else:
-            j = self._col(paramVec)
+            start, end = paramVec.start, paramVec.end
+            weights = paramVec.weights if weights is None else weights
+        j = self._vec_col(paramVec)
         limfrac = np.atleast_1d(np.asarray(limfrac, dtype=np.float64))
         end = self.numrows if end is None else end
-        norm = self.norm if (start == 0 and end == self.numrows) else self.ctx.weight_stats(start, end)["norm"]
-        targets = norm * limfrac if not upper else norm * (1 - limfrac)
-        out = self.ctx.quantiles([j], targets[None, :], lo=start, hi=end)[0]
+
+        def select():
+            full = start == 0 and end == self.numrows and weights is None
+            norm = self.norm if full else self.ctx.weight_stats(start, end)["norm"]
+            targets = norm * limfrac if not upper else norm * (1 - limfrac)
+            return self.ctx.quantiles([j], targets[None, :], lo=start, hi=end)[0]
+
+        if weights is None:
+            out = select()
+        else:
+            weights = np.asarray(weights, dtype=np.float64)
+            if weights.shape != (self.numrows,):
+                raise WeightedSampleError("weights must have one entry per sample")
+            out = self._with_weights(weights, select)
         return out if out.size > 1 else out[0]
 
     def twoTailLimits(self, paramVec, confidence):
@@ -994,6 +1093,28 @@ class MCSamples:
         self._init_params([self._col(j)])
         return self.paramNames.names[self._col(j)]
 
+    def _setNDLimits(self):
+        """
+        The N-dimensional confidence-region limits of _setLikeStats (mcsamples.py:2263-2274): per contour, min / max of
+        every parameter over the best-likelihood samples holding that fraction of the weight.  The reference argsorts
+        loglikes; here the weighted quantile of the loglikes column (gd_quantiles) is the likelihood of the first
+        sample outside the region, and one conditional min/max pass per contour (gd_col_minmax) does the rest.  Rows
+        tied with that threshold are all excluded (the reference keeps an arbitrary subset of them).
+        """
+        if self._nd_limits_done:
+            return
+        ctx = self.ctx
+        col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
+        contours = np.asarray(self.contours, dtype=np.float64)
+        thr = ctx.quantiles([col], (self.norm * contours)[None, :])[0]
+        lims = np.empty((len(contours), self.n, 2))
+        for i, (c, t) in enumerate(zip(contours, thr)):
+            lims[i] = ctx.col_minmax(list(range(self.n)), cond_col=-1 if c >= 1 else col, cond_below=t)
+        for j, par in enumerate(self.paramNames.names):
+            par.ND_limit_bot = lims[:, j, 0].copy()
+            par.ND_limit_top = lims[:, j, 1].copy()
+        self._nd_limits_done = True
+
     def _init_params(self, js):
         """_initParam for several parameters with ONE batched quantile-select launch."""
         todo = [j for j in dict.fromkeys(js) if not getattr(self.paramNames.names[j], "_ranges_done", False)]
@@ -1020,8 +1141,12 @@ class MCSamples:
                 par.sigma_range = scale  # very flat
             else:
                 par.sigma_range = min(par.err, scale)
-            if self.range_ND_contour >= 0:
-                raise NotImplementedError("range_ND_contour needs likelihood statistics (outside the accelerated path)")
+            if self.range_ND_contour >= 0 and self.loglikes is not None:  # mcsamples.py:1455-1459
+                self._setNDLimits()
+                if self.range_ND_contour >= par.ND_limit_bot.size:
+                    raise SettingError("range_ND_contour should be -1 (off), or an index into the computed contour levels")
+                par.range_min = min(max(par.range_min - par.err, par.ND_limit_bot[self.range_ND_contour]), par.range_min)
+                par.range_max = max(max(par.range_max + par.err, par.ND_limit_top[self.range_ND_contour]), par.range_max)
             smooth_1D = par.sigma_range * 0.4
             if par.has_limits_bot:
                 if par.range_min - par.limmin > 2 * smooth_1D and par.param_min - par.limmin > smooth_1D:

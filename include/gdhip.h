@@ -187,6 +187,22 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const do
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                  void* d_P_out, int32_t* status_out);
 
+/* ---------------------------------------------------------------- auxiliary vectors ------------
+ * The reference lets most statistics take an arbitrary vector instead of a column index (`_makeParamvec`,
+ * chains.py:325-337), a row filter `where=` (chains.py:666-780) or alternative weights (chains.py:793-838).
+ * gd_set_extra_column: copy a host vector (N rows) into spare column `slot` (0..3); it is then addressed as
+ *   column index  n + slot  by every entry point that takes column indices.
+ * gd_aux_weights: copy a host weight vector (N rows, e.g. weights*where) into the auxiliary weight buffer
+ *   (shared with gd_like_weights); gd_select_weights(ctx, 1) makes every weighted entry point use it.
+ * gd_col_minmax: out[2c], out[2c+1] = min, max of column cols[c] over the rows of [lo,hi) whose value in
+ *   column cond_col is < cond_below (cond_col < 0: all rows; +inf / -inf when no row qualifies) -- the
+ *   N-dimensional confidence-region limits of _setLikeStats (mcsamples.py:2263-2274) with cond_col = the
+ *   loglikes column and cond_below = its weighted quantile from gd_quantiles. */
+int gd_set_extra_column(gd_ctx* ctx, int32_t slot, const double* x);
+int gd_aux_weights(gd_ctx* ctx, const double* w);
+int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, int32_t cond_col,
+                  double cond_below, double* out);
+
 /* ---------------------------------------------------------------- mean likelihoods -------------
  * The optional `meanlikes` branches of get1DDensityGridData / get2DDensityGridData.
  * gd_like_weights: build the device vector  weights*exp(mean_loglike - loglikes)  (mode 0; mcsamples.py:1560,

@@ -709,6 +709,20 @@ class OracleSamples:
         return par.N_eff_kde
 
     # ---- ranges and limits (mcsamples.py:1421-1484) -------------------------------------------
+    def nd_limits(self):
+        """mcsamples.py:2263-2274: per contour, min / max of each parameter over the best-likelihood region."""
+        indexes = self.loglikes.argsort()
+        cumsum = np.cumsum(self.weights[indexes])
+        contours = np.asarray(self.settings["contours"])
+        n_d = np.searchsorted(cumsum, self.norm * contours)
+        bot = np.empty((len(contours), self.n))
+        top = np.empty((len(contours), self.n))
+        for i, cont in enumerate(n_d):
+            region = self.samples[indexes[:cont]]
+            bot[i] = region.min(axis=0)
+            top[i] = region.max(axis=0)
+        return bot, top
+
     def init_param(self, j):
         par = self.pars[j]
         vec = self.samples[:, j]
@@ -729,6 +743,13 @@ class OracleSamples:
             par.sigma_range = scale
         else:
             par.sigma_range = min(par.err, scale)
+        k = self.settings["range_ND_contour"]
+        if k >= 0 and self.loglikes is not None:  # mcsamples.py:1455-1459
+            bot, top = self.nd_limits()
+            if k >= bot.shape[0]:
+                raise ValueError("range_ND_contour should be -1 (off), or an index into the computed contour levels")
+            par.range_min = min(max(par.range_min - par.err, bot[k, j]), par.range_min)
+            par.range_max = max(max(par.range_max + par.err, top[k, j]), par.range_max)
         smooth = par.sigma_range * 0.4
         if par.has_limits_bot:
             if par.range_min - par.limmin > 2 * smooth and par.param_min - par.limmin > smooth:

@@ -154,6 +154,34 @@ def compare_meanlikes():
     return ok
 
 
+def compare_nd_ranges():
+    """range_ND_contour >= 0: ND confidence-region limits (mcsamples.py:2263-2274) widen the ranges (:1455-1459)."""
+    zoo = {fx["name"]: fx for fx in fixture_zoo()}
+    ok = True
+    changed = 0
+    for nm in ("block10_weighted", "shapes", "c1_bounded"):
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        for k in (0, 1, 2):
+            st = {"range_ND_contour": k}
+            ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"], settings=st, loglikes=ll)
+            orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], settings=st,
+                                   loglikes=ll)
+            off = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+            bot, top = orc.nd_limits()
+            for j, name in enumerate(fx["names"]):
+                rp = ref._initParamRanges(j)
+                op = orc.init_param(j)
+                ok &= np.array_equal(bot[:, j], rp.ND_limit_bot) and np.array_equal(top[:, j], rp.ND_limit_top)
+                ok &= op.range_min == rp.range_min and op.range_max == rp.range_max
+                po = off.init_param(j)
+                changed += (op.range_min != po.range_min) or (op.range_max != po.range_max)
+            a, b = fx["pairs"][0]
+            ok &= relerr(orc.density_2d(a, b)["P"], ref.get2DDensity(fx["names"][a], fx["names"][b]).P) <= 1e-10
+    print(("ok  " if ok else "FAIL") + " range_ND_contour ranges and ND limits (%d parameter ranges actually widened)" % changed)
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -168,6 +196,7 @@ def main():
     ok &= compare_convergence()
     ok &= compare_neff_2d()
     ok &= compare_meanlikes()
+    ok &= compare_nd_ranges()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")

@@ -75,14 +75,34 @@ class FakeContext:
         if self.s.ndim == 1:
             self.s = self.s.reshape(-1, 1)
         self.N, self.n = self.s.shape
+        self.s = np.hstack([self.s, np.zeros((self.N, self.EXTRA_COLS))])  # spare columns (gd_set_extra_column)
         self.w = None if weights is None else np.asarray(weights, dtype=np.float64)
         self.weighted = self.w is not None
+        self._like_w, self._w_sel = None, 0
 
     def _w(self, lo=0, hi=None):
         hi = self.N if hi is None else hi
         if getattr(self, "_w_sel", 0):
             return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
+
+    # ---- auxiliary vectors
+    EXTRA_COLS = 4
+
+    def set_extra_column(self, slot, x):
+        assert 0 <= slot < self.EXTRA_COLS
+        self.s[:, self.n + slot] = np.asarray(x, dtype=np.float64)
+        return self.n + slot
+
+    def aux_weights(self, w):
+        assert not self._w_sel
+        self._like_w = np.array(w, dtype=np.float64)
+
+    def col_minmax(self, cols, lo=0, hi=None, cond_col=-1, cond_below=0.0):
+        hi = self.N if hi is None else hi
+        keep = self.s[lo:hi, cond_col] < cond_below if cond_col >= 0 else np.ones(hi - lo, dtype=bool)
+        return np.array([[self.s[lo:hi, c][keep].min(), self.s[lo:hi, c][keep].max()] if keep.any()
+                         else [np.inf, -np.inf] for c in cols])
 
     # ---- mean likelihoods
     def like_weights(self, loglikes, mode, mean_loglike):
@@ -153,7 +173,7 @@ class FakeContext:
 
     def col_stats(self, lo=0, hi=None):
         hi = self.N if hi is None else hi
-        s, w = self.s[lo:hi], self._w(lo, hi)
+        s, w = self.s[lo:hi, :self.n], self._w(lo, hi)
         norm = np.sum(w)
         means = w.dot(s) / norm
         var = np.array([w.dot((s[:, i] - means[i]) ** 2) / norm for i in range(self.n)])

@@ -155,6 +155,26 @@ def golden_meanlikes(zoo):
     return out
 
 
+def golden_nd_ranges(zoo):
+    """ND confidence-region limits (mcsamples.py:2263-2274) and the ranges they widen with range_ND_contour = k."""
+    from oracle.fixtures import loglikes_for
+
+    out = {}
+    for nm in ("block10_weighted", "shapes", "c1_bounded"):
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        for k in (0, 1, 2):
+            ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"],
+                            ranges=fx["ranges"], loglikes=ll, settings={"range_ND_contour": k})
+            pars = [ref._initParamRanges(j) for j in range(len(fx["names"]))]
+            out["%s/%d/range_min" % (nm, k)] = np.array([p.range_min for p in pars], dtype=float)
+            out["%s/%d/range_max" % (nm, k)] = np.array([p.range_max for p in pars], dtype=float)
+            if k == 0:
+                out["%s/ND_limit_bot" % nm] = np.array([p.ND_limit_bot for p in pars])
+                out["%s/ND_limit_top" % nm] = np.array([p.ND_limit_top for p in pars])
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -198,6 +218,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
     np.savez_compressed(os.path.join(HERE, "splittests.npz"),
                         **{nm: golden_split_tests(zoo[nm]) for nm in ("shapes_intweights", "c1_bounded", "block10_weighted")})
+    np.savez_compressed(os.path.join(HERE, "nd_ranges.npz"), **golden_nd_ranges(zoo))
+    if "--only-nd" in sys.argv:
+        return
     np.savez_compressed(os.path.join(HERE, "meanlikes.npz"), **golden_meanlikes(zoo))
     if "--only-new" in sys.argv:
         return

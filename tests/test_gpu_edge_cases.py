@@ -181,3 +181,53 @@ def test_use_effective_samples_2d_setting():
     d = mc.get2DDensity(0, 1)  # bounded pair: no TNC, strict tolerance
     o = orc.density_2d(0, 1)
     assert np.max(np.abs(d.P - o["P"])) < 1e-6
+
+
+def test_where_filters_alternative_weights_and_vector_arguments(zoo):
+    """chains.py:325-337,636-838 through gd_set_extra_column / gd_aux_weights / gd_select_weights, against numpy."""
+    fx = zoo["block10_weighted"]
+    mc = mcs(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    s, w = np.asarray(fx["samples"]), np.asarray(fx["weights"])
+    where = s[:, 0] > 0.5
+    ww = w[where]
+    assert np.isclose(mc.get_norm(where), ww.sum(), rtol=1e-12)
+    assert np.isclose(mc.mean(2, where), ww.dot(s[where, 2]) / ww.sum(), rtol=1e-11)
+    sub = s[where][:, [1, 3, 4]]
+    dm = sub - ww.dot(sub) / ww.sum()
+    assert np.allclose(mc.cov([1, 3, 4], where), (dm * ww[:, None]).T @ dm / ww.sum(), rtol=1e-10)
+    assert np.isclose(mc.var(3, where), (ww.dot(dm[:, 1] ** 2) / ww.sum()), rtol=1e-10)
+    vec = s[:, 0] ** 2 + s[:, 1]
+    dv = np.column_stack([vec, s[:, 1]])
+    dv = dv - w.dot(dv) / w.sum()
+    assert np.isclose(mc.mean(vec), w.dot(vec) / w.sum(), rtol=1e-11)
+    assert np.allclose(mc.cov([vec, 1]), (dv * w[:, None]).T @ dv / w.sum(), rtol=1e-10)
+    alt = np.abs(np.sin(np.arange(len(w)))) + 0.1
+    f = np.array([0.025, 0.5, 0.9])
+    for args in (dict(), dict(start=100, end=15000), dict(weights=alt), dict(start=7, end=9000, weights=alt)):
+        a, b = args.get("start", 0), args.get("end", len(w))
+        wt = args.get("weights", w)[a:b]
+        x = vec[a:b]
+        order = x.argsort()
+        cum = np.cumsum(wt[order])
+        for upper in (False, True):
+            tgt = cum[-1] * ((1 - f) if upper else f)
+            want_pos = np.minimum(np.searchsorted(cum, tgt), len(x) - 1)
+            got = mc.confidence(mc.initParamConfidenceData(vec, **args), f, upper=upper)
+            got_pos = np.searchsorted(x[order], got)
+            assert np.all(np.abs(got_pos - want_pos) <= 1), (args, upper)  # summation order: knife-edge picks
+            assert np.all(np.isin(got, x)), args
+    # the sample weights are selected again afterwards
+    assert np.isclose(mc.mean(2), w.dot(s[:, 2]) / w.sum(), rtol=1e-12)
+    cov_again = mc.cov([1, 3])
+    assert np.allclose(cov_again, mc.getCov(pars=[1, 3]), rtol=1e-12)
+
+
+def test_range_nd_contour_widening(zoo):
+    """gd_set_extra_column (loglikes) + gd_quantiles + gd_col_minmax behind range_ND_contour, vs the reference goldens."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic_cpu import nd_ranges_check
+
+    nd_ranges_check(zoo)

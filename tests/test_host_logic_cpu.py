@@ -70,6 +70,87 @@ def test_host_logic_meanlikes(zoo):
         assert mc.get1DDensityGridData(0).likes is None
 
 
+def test_host_logic_where_weights_and_vectors(zoo):
+    """chains.py:325-337,636-838: vector arguments, `where=` filters and alternative weights, against plain numpy."""
+    fx = zoo["block10_weighted"]
+    mc = make(fx)
+    s, w = np.asarray(fx["samples"]), np.asarray(fx["weights"])
+    where = s[:, 0] > 0.5
+    ww = w[where]
+    assert np.isclose(mc.get_norm(where), ww.sum(), rtol=1e-13)
+    assert np.isclose(mc.mean(2, where), ww.dot(s[where, 2]) / ww.sum(), rtol=1e-12)
+    d = s[where, 2] - ww.dot(s[where, 2]) / ww.sum()
+    assert np.isclose(mc.var(2, where), ww.dot(d * d) / ww.sum(), rtol=1e-12)
+    sub = s[where][:, [1, 3, 4]]
+    dm = sub - ww.dot(sub) / ww.sum()
+    assert np.allclose(mc.cov([1, 3, 4], where), (dm * ww[:, None]).T @ dm / ww.sum(), rtol=1e-11)
+    idx = np.nonzero(where)[0][::3]  # an index array filters like x[idx]
+    assert np.isclose(mc.mean(2, idx), w[idx].dot(s[idx, 2]) / w[idx].sum(), rtol=1e-12)
+    vec = s[:, 0] ** 2 + s[:, 1]
+    assert np.isclose(mc.mean(vec), w.dot(vec) / w.sum(), rtol=1e-12)
+    assert np.isclose(mc.std(vec), np.sqrt(w.dot((vec - w.dot(vec) / w.sum()) ** 2) / w.sum()), rtol=1e-12)
+    c = mc.cov([vec, 1])
+    dv = np.column_stack([vec, s[:, 1]])
+    dv = dv - w.dot(dv) / w.sum()
+    assert np.allclose(c, (dv * w[:, None]).T @ dv / w.sum(), rtol=1e-11)
+    assert np.isclose(mc.mean(-2), w.dot(w) / w.sum(), rtol=1e-12)  # par=-2: the weights vector
+    # quantiles of a vector, over a row range, with alternative weights (chains.py:793-838)
+    alt = np.abs(np.sin(np.arange(len(w)))) + 0.1
+    for args in (dict(), dict(start=100, end=15000), dict(weights=alt), dict(start=7, end=9000, weights=alt)):
+        a, b = args.get("start", 0), args.get("end", len(w))
+        wt = args.get("weights", w)[a:b]
+        x = vec[a:b]
+        order = x.argsort()
+        cum = np.cumsum(wt[order])
+        for upper in (False, True):
+            f = np.array([0.025, 0.5, 0.9])
+            tgt = cum[-1] * ((1 - f) if upper else f)
+            want = x[order[np.minimum(np.searchsorted(cum, tgt), len(x) - 1)]]
+            assert np.array_equal(mc.confidence(vec, f, upper=upper, **args), want), args
+            h = mc.initParamConfidenceData(vec, **args)
+            assert np.array_equal(mc.confidence(h, f, upper=upper), want), args
+    assert mc.ctx._w_sel == 0 and np.isclose(mc.mean(2), w.dot(s[:, 2]) / w.sum(), rtol=1e-12)
+
+
+def nd_ranges_check(zoo, factory=None):
+    """range_ND_contour = k: ND confidence-region limits and the widened ranges against the reference goldens."""
+    from getdist_amd.mcsamples import MCSamples, SettingError
+    from oracle.fixtures import loglikes_for
+
+    g = np.load(gu.GOLDEN_DIR + "/nd_ranges.npz")
+    kw = {} if factory is None else dict(_context_factory=factory)
+    for nm in ("block10_weighted", "shapes", "c1_bounded"):
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        for k in (0, 1, 2):
+            mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"],
+                           loglikes=ll, settings={"range_ND_contour": k}, **kw)
+            mc._init_params(list(range(mc.n)))
+            pars = mc.paramNames.names
+            assert np.array_equal([p.range_min for p in pars], g["%s/%d/range_min" % (nm, k)]), (nm, k)
+            assert np.array_equal([p.range_max for p in pars], g["%s/%d/range_max" % (nm, k)]), (nm, k)
+        assert np.array_equal([p.ND_limit_bot for p in pars], g["%s/ND_limit_bot" % nm])
+        assert np.array_equal([p.ND_limit_top for p in pars], g["%s/ND_limit_top" % nm])
+    # without loglikes the setting is inert (`self.likeStats` is None in the reference), and the index is checked
+    fx = zoo["c1_bounded"]
+    a = MCSamples(samples=fx["samples"], names=fx["names"], ranges=fx["ranges"], settings={"range_ND_contour": 1}, **kw)
+    b = MCSamples(samples=fx["samples"], names=fx["names"], ranges=fx["ranges"], **kw)
+    a._init_params([0, 1]), b._init_params([0, 1])
+    assert a.paramNames.names[1].range_min == b.paramNames.names[1].range_min
+    c = MCSamples(samples=fx["samples"], names=fx["names"], ranges=fx["ranges"], loglikes=loglikes_for(fx["samples"]),
+                  settings={"range_ND_contour": 7}, **kw)
+    try:
+        c._init_params([0])
+    except SettingError:
+        pass
+    else:
+        raise AssertionError("range_ND_contour beyond the contour list must raise SettingError")
+
+
+def test_host_logic_nd_ranges(zoo):
+    nd_ranges_check(zoo, FakeContext)
+
+
 def test_host_logic_branches_and_grid_classes(zoo):
     """block50: all three bandwidth branches, four grid sizes, bounded and unbounded pairs through the batched path."""
     fx = zoo["block50"]

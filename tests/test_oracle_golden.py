@@ -89,3 +89,20 @@ def test_oracle_meanlikes_golden(zoo):
             st = int(g["%s/2d/%d_%d/stride" % (case, a, b)])
             assert gu.relerr(likes[::st, ::st], g["%s/2d/%d_%d/likes" % (case, a, b)]) <= TOL_GRID, (case, a, b)
             assert abs(np.sum(likes) - float(g["%s/2d/%d_%d/sum" % (case, a, b)])) <= 1e-9 * np.sum(likes)
+
+
+def test_oracle_nd_ranges_golden(zoo):
+    from oracle.fixtures import loglikes_for
+
+    g = np.load(gu.GOLDEN_DIR + "/nd_ranges.npz")
+    for nm in ("block10_weighted", "shapes", "c1_bounded"):
+        fx = zoo[nm]
+        ll = loglikes_for(fx["samples"])
+        for k in (0, 1, 2):
+            orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll,
+                                   settings={"range_ND_contour": k})
+            pars = [orc.init_param(j) for j in range(orc.n)]
+            assert np.array_equal([p.range_min for p in pars], g["%s/%d/range_min" % (nm, k)])
+            assert np.array_equal([p.range_max for p in pars], g["%s/%d/range_max" % (nm, k)])
+        bot, top = orc.nd_limits()
+        assert np.array_equal(bot.T, g["%s/ND_limit_bot" % nm]) and np.array_equal(top.T, g["%s/ND_limit_top" % nm])
