@@ -119,6 +119,10 @@ def nd_ranges_check(zoo, factory=None):
 
     g = np.load(gu.GOLDEN_DIR + "/nd_ranges.npz")
     kw = {} if factory is None else dict(_context_factory=factory)
+
+    def same(a, b):  # the device's moments differ from numpy's in the last bits (summation order), so err does too
+        return np.array_equal(a, b) if factory is not None else np.allclose(a, b, rtol=1e-12, atol=0)
+
     for nm in ("block10_weighted", "shapes", "c1_bounded"):
         fx = zoo[nm]
         ll = loglikes_for(fx["samples"])
@@ -127,8 +131,8 @@ def nd_ranges_check(zoo, factory=None):
                            loglikes=ll, settings={"range_ND_contour": k}, **kw)
             mc._init_params(list(range(mc.n)))
             pars = mc.paramNames.names
-            assert np.array_equal([p.range_min for p in pars], g["%s/%d/range_min" % (nm, k)]), (nm, k)
-            assert np.array_equal([p.range_max for p in pars], g["%s/%d/range_max" % (nm, k)]), (nm, k)
+            assert same([p.range_min for p in pars], g["%s/%d/range_min" % (nm, k)]), (nm, k)
+            assert same([p.range_max for p in pars], g["%s/%d/range_max" % (nm, k)]), (nm, k)
         assert np.array_equal([p.ND_limit_bot for p in pars], g["%s/ND_limit_bot" % nm])
         assert np.array_equal([p.ND_limit_top for p in pars], g["%s/ND_limit_top" % nm])
     # without loglikes the setting is inert (`self.likeStats` is None in the reference), and the index is checked
