@@ -73,6 +73,31 @@ MEANLIKES_CASES = (("c1_bounded", ({}, dict(mult_bias_correction_order=0), dict(
                    ("block10_weighted", ({},)), ("shapes", ({},)), ("periodic", (dict(fine_bins=64, fine_bins_2D=32),)))
 
 
+def mcmc_chains_fixture(nchains=3, N=6000, n=5):
+    """
+    Integer-weight (MCMC multiplicity) chains with AR(1) correlation that differs per parameter, plus a loglikes
+    column: what the Raftery-Lewis / CorrSteps tests need (mcsamples.py:1039: integer weights only).
+    Returns (samples, weights, loglikes, names, chain_offsets).
+    """
+    r = _rng(21)
+    rhos = np.linspace(0.0, 0.85, n)
+    chains, ws = [], []
+    for c in range(nchains):
+        rows = N + 500 * c
+        x = np.empty((rows, n))
+        e = r.standard_normal((rows, n))
+        x[0] = e[0]
+        for t in range(1, rows):
+            x[t] = rhos * x[t - 1] + np.sqrt(1 - rhos**2) * e[t]
+        chains.append(x + 0.05 * c)
+        ws.append(r.geometric(0.45, rows).astype(np.float64))
+    samples = np.vstack(chains)
+    weights = np.concatenate(ws)
+    offsets = np.concatenate([[0], np.cumsum([len(c) for c in chains])])
+    loglikes = 0.5 * np.sum(samples**2, axis=1)
+    return samples, weights, loglikes, ["m%d" % i for i in range(n)], offsets
+
+
 def fixture_zoo():
     """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
     zoo = []

@@ -21,7 +21,8 @@ from getdist import MCSamples  # noqa: E402  (the reference)
 
 from getdist_amd import synth  # noqa: E402
 from oracle import kde_oracle as ko  # noqa: E402
-from oracle.fixtures import MEANLIKES_CASES, fixture_zoo, loglikes_for  # noqa: E402
+from oracle import convergence_oracle as co  # noqa: E402
+from oracle.fixtures import MEANLIKES_CASES, fixture_zoo, loglikes_for, mcmc_chains_fixture  # noqa: E402
 
 logging.getLogger().setLevel(logging.ERROR)
 
@@ -182,6 +183,63 @@ def compare_nd_ranges():
     return ok
 
 
+def reference_chain_set():
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture()
+    chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
+    ref = MCSamples(samples=chains, weights=[weights[a:b] for a, b in zip(offsets[:-1], offsets[1:])],
+                    loglikes=[loglikes[a:b] for a, b in zip(offsets[:-1], offsets[1:])], names=names)
+    return ref, samples, weights, loglikes, names, offsets
+
+
+def parse_raftery_lewis(text):
+    """The 'chain  markov_thin  indep_thin  nburn' table of getConvergeTests' text output."""
+    rows = []
+    lines = text.split("\n")
+    start = [i for i, ln in enumerate(lines) if ln.startswith("chain  markov_thin")][0]
+    for ln in lines[start + 1:]:
+        if not ln.strip():
+            break
+        f = ln.split()
+        rows.append([int(v) for v in f[1:4]] if len(f) == 4 else [0, 0, 0])
+    return np.array(rows)
+
+
+def compare_raftery_lewis():
+    """thin indices, the Raftery-Lewis table and the CorrSteps numbers (mcsamples.py:1039-1221; chains.py:878-916)."""
+    from getdist.chains import WeightedSamples
+
+    ok = True
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        w = rng.geometric(rng.uniform(0.2, 0.9), rng.integers(1, 400)).astype(float)
+        for factor in (1, 2, 3, int(np.max(w)), int(np.max(w)) + 1, 11):
+            ok &= np.array_equal(co.thin_indices(factor, w), WeightedSamples.thin_indices_single_samples(factor, w))
+    ref, samples, weights, loglikes, names, offsets = reference_chain_set()
+    for tc in (0.95, 0.8):
+        text = ref.getConvergeTests(test_confidence=tc, what=("RafteryLewis",))
+        table = parse_raftery_lewis(text)
+        rl = co.raftery_lewis(samples, weights, offsets, len(names), tc)
+        mine = np.column_stack([rl["markov_thin"], rl["thin_fac"], rl["nburn"]])
+        mine[rl["thin_fac"] == 0] = 0
+        ok &= np.array_equal(table, mine)
+        ok &= int(ref.RL_indep_thin) == int(np.max(rl["thin_fac"]))
+    # CorrSteps prints %8.3f: compare the formatted numbers
+    for thin in (0, 3):
+        ref.corr_length_thin = thin
+        ref.indep_thin = 0
+        text = ref.getConvergeTests(what=("CorrSteps",))
+        lines = [ln for ln in text.split("\n") if ln.strip()]
+        header = lines[1].split()
+        autocorr_thin = thin if thin else 20
+        corrs = co.corr_steps(samples, weights, offsets, ref.vars, autocorr_thin, ref.corr_length_steps)
+        ok &= [int(h) for h in header] == [(i + 1) * autocorr_thin for i in range(corrs.shape[0])]
+        for j, ln in enumerate(lines[2:2 + len(names)]):
+            got = [float(v) for v in ln.split()[1:1 + corrs.shape[0]]]
+            ok &= np.allclose(got, np.round(corrs[:, j], 3), atol=1.1e-3)
+    print(("ok  " if ok else "FAIL") + " thin indices, Raftery-Lewis table, CorrSteps")
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -197,6 +255,7 @@ def main():
     ok &= compare_neff_2d()
     ok &= compare_meanlikes()
     ok &= compare_nd_ranges()
+    ok &= compare_raftery_lewis()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")

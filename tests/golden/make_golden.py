@@ -175,6 +175,46 @@ def golden_nd_ranges(zoo):
     return out
 
 
+def golden_raftery_lewis():
+    """
+    Raftery-Lewis table parsed from the reference's getConvergeTests text (mcsamples.py:1039-1165) and the CorrSteps
+    numbers recomputed to full precision with the reference's own thin_indices / chain diffs (:1183-1210; the text
+    only carries three decimals).
+    """
+    from oracle.validate_against_reference import parse_raftery_lewis, reference_chain_set
+
+    ref, samples, weights, loglikes, names, offsets = reference_chain_set()
+    out = {}
+    for tc in (0.95, 0.8):
+        out["table/%g" % tc] = parse_raftery_lewis(ref.getConvergeTests(test_confidence=tc, what=("RafteryLewis",)))
+        out["indep_thin/%g" % tc] = np.int64(ref.RL_indep_thin)
+    chainlist = ref.getSeparateChains()
+    for ch in chainlist:
+        ch.setDiffs()
+    for autocorr_thin in (20, 3):
+        thin_rows = len(ref.thin_indices(autocorr_thin))
+        maxoff = int(min(ref.corr_length_steps, thin_rows // (2 * len(chainlist))))
+        corrs = np.zeros([maxoff, ref.n])
+        for chain in chainlist:
+            thin_ix = chain.thin_indices(autocorr_thin)
+            thin_rows = len(thin_ix)
+            maxoff = min(maxoff, thin_rows // autocorr_thin)
+            for j in range(ref.n):
+                diff = chain.diffs[j][thin_ix]
+                for off in range(1, maxoff + 1):
+                    corrs[off - 1][j] += np.dot(diff[off:], diff[:-off]) / (thin_rows - off) / ref.vars[j]
+        corrs /= len(chainlist)
+        out["corrsteps/%d" % autocorr_thin] = corrs[:maxoff]
+    rng = np.random.default_rng(9)
+    for k in range(6):  # thin indices of the reference on random multiplicities
+        w = rng.geometric(0.35, 3000 + 17 * k).astype(float)
+        f = [1, 2, 5, int(w.max()), int(w.max()) + 3, 40][k]
+        out["thin/%d/w" % k] = w
+        out["thin/%d/factor" % k] = np.int64(f)
+        out["thin/%d/ix" % k] = ref.thin_indices(f, w)
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -218,6 +258,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
     np.savez_compressed(os.path.join(HERE, "splittests.npz"),
                         **{nm: golden_split_tests(zoo[nm]) for nm in ("shapes_intweights", "c1_bounded", "block10_weighted")})
+    np.savez_compressed(os.path.join(HERE, "raftery_lewis.npz"), **golden_raftery_lewis())
+    if "--only-rl" in sys.argv:
+        return
     np.savez_compressed(os.path.join(HERE, "nd_ranges.npz"), **golden_nd_ranges(zoo))
     if "--only-nd" in sys.argv:
         return

@@ -106,3 +106,21 @@ def test_oracle_nd_ranges_golden(zoo):
             assert np.array_equal([p.range_max for p in pars], g["%s/%d/range_max" % (nm, k)])
         bot, top = orc.nd_limits()
         assert np.array_equal(bot.T, g["%s/ND_limit_bot" % nm]) and np.array_equal(top.T, g["%s/ND_limit_top" % nm])
+
+
+def test_convergence_oracle_golden():
+    """Raftery-Lewis / CorrSteps / thinning restatement against the reference outputs."""
+    from oracle import convergence_oracle as co
+    from oracle.fixtures import mcmc_chains_fixture
+
+    g = np.load(gu.GOLDEN_DIR + "/raftery_lewis.npz")
+    for k in range(6):
+        assert np.array_equal(co.thin_indices(int(g["thin/%d/factor" % k]), g["thin/%d/w" % k]), g["thin/%d/ix" % k])
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture()
+    for tc in (0.95, 0.8):
+        rl = co.raftery_lewis(samples, weights, offsets, len(names), tc)
+        assert np.array_equal(np.column_stack([rl["markov_thin"], rl["thin_fac"], rl["nburn"]]), g["table/%g" % tc])
+    orc = ko.OracleSamples(samples, weights, names=names)
+    for thin in (20, 3):
+        corrs = co.corr_steps(samples, weights, offsets, orc.vars, thin)
+        assert gu.relerr(corrs, g["corrsteps/%d" % thin]) < 1e-11
