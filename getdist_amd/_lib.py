@@ -89,6 +89,10 @@ SIGNATURES = {
     "gd_set_extra_column": (C.c_int, [_p, _i32, _pd]),
     "gd_aux_weights": (C.c_int, [_p, _pd]),
     "gd_col_minmax": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _i32, C.c_double, _pd]),
+    "gd_weights_integral": (C.c_int, [_p, _pi32]),
+    "gd_thin_rows": (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _i64, C.POINTER(C.c_int64)]),
+    "gd_binary_transitions": (C.c_int, [_p, _pi32, _i32, _p, _i64, _pd, _i32, C.POINTER(C.c_int64)]),
+    "gd_thinned_lag_sums": (C.c_int, [_p, _pi32, _i32, _pd, _p, _i64, _i32, _pd]),
     "gd_like_weights": (C.c_int, [_p, _pd, _i32, C.c_double, _pd]),
     "gd_select_weights": (C.c_int, [_p, _i32]),
     "gd_likes1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _pi32, _pi32, _i32, _pd, _pi32]),
@@ -489,6 +493,35 @@ class Context:
         out = np.zeros((len(cols), 2))
         self._check(self.lib.gd_col_minmax(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi,
                                            int(cond_col), float(cond_below), _dp(out)))
+        return out
+
+    # ---- thinned chains
+    def weights_integral(self):
+        out = C.c_int32()
+        self._check(self.lib.gd_weights_integral(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def thin_rows(self, lo, hi, factor, unique_mode, capacity):
+        """Thinned row list (device int32 buffer, count) of chain rows [lo,hi); see gd_thin_rows."""
+        buf = self.alloc(max(int(capacity), 1) * 4)
+        n = C.c_int64()
+        self._check(self.lib.gd_thin_rows(self.h, int(lo), int(hi), int(factor), int(bool(unique_mode)), buf.ptr,
+                                          int(capacity), C.byref(n)))
+        return buf, n.value
+
+    def binary_transitions(self, cols, rows, K, thresholds):
+        cols = _i32arr(cols)
+        thresholds = _f64arr(thresholds).reshape(len(cols), -1)
+        out = np.zeros((len(cols), thresholds.shape[1], 12), dtype=np.int64)
+        self._check(self.lib.gd_binary_transitions(self.h, _ip(cols), len(cols), rows.ptr, int(K), _dp(thresholds),
+                                                   thresholds.shape[1], out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def thinned_lag_sums(self, cols, means, rows, K, maxoff):
+        cols, means = _i32arr(cols), _f64arr(means)
+        out = np.zeros((len(cols), int(maxoff)))
+        self._check(self.lib.gd_thinned_lag_sums(self.h, _ip(cols), len(cols), _dp(means), rows.ptr, int(K), int(maxoff),
+                                                 _dp(out)))
         return out
 
     # ---- mean likelihoods

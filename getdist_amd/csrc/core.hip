@@ -76,6 +76,7 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->w_sel) ctx->w = ctx->w_main;
     if (ctx->w) (void)hipFree(ctx->w);
     if (ctx->like_w) (void)hipFree(ctx->like_w);
+    if (ctx->wcum) (void)hipFree(ctx->wcum);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     (void)hipEventDestroy(ctx->ev0);
@@ -266,6 +267,8 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     if (ctx->w_sel) ctx->w = ctx->w_main;
     if (ctx->w) (void)hipFree(ctx->w);
     if (ctx->like_w) (void)hipFree(ctx->like_w);
+    if (ctx->wcum) (void)hipFree(ctx->wcum);
+    ctx->wcum = nullptr;
     ctx->cols = ctx->w = ctx->like_w = ctx->w_main = nullptr;
     ctx->w_sel = 0;
     ctx->N = ctx->n = ctx->ld = 0;

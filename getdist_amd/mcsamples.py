@@ -30,7 +30,7 @@ from .densities import Density1D, Density2D, DensitiesError
 # analysis_defaults.ini:1-76 (the ini always overrides the class literals, mcsamples.py:491-492)
 DEFAULT_SETTINGS = dict(
     ignore_rows=0, min_weight_ratio=1e-30, contours=[0.68, 0.95, 0.99], credible_interval_threshold=0.05,
-    range_ND_contour=-1, range_confidence=0.001, converge_test_limit=0.95, fine_bins=1024, smooth_scale_1D=-1.0,
+    range_ND_contour=-1, range_confidence=0.001, corr_length_thin=0, corr_length_steps=15, converge_test_limit=0.95, fine_bins=1024, smooth_scale_1D=-1.0,
     boundary_correction_order=1, mult_bias_correction_order=1, smooth_scale_2D=-1.0, max_corr_2D=0.99,
     fine_bins_2D=256, use_effective_samples_2D=False, max_scatter_points=2000, num_bins=100, num_bins_2D=40)
 
@@ -636,7 +636,7 @@ class MCSamples:
         if writeDataToFile or filename:
             raise NotImplementedError("file output is outside the accelerated path")
         for w in what:
-            if w not in ("MeanVar", "GelmanRubin", "SplitTest", "CorrLengths"):
+            if w not in ("MeanVar", "GelmanRubin", "SplitTest", "CorrLengths", "RafteryLewis", "CorrSteps"):
                 raise NotImplementedError("convergence test %s is outside the accelerated path" % w)
         lines = ""
         nchains = 0 if self.chain_offsets is None else len(self.chain_offsets) - 1
@@ -676,7 +676,208 @@ class MCSamples:
                 for endb, typestr in enumerate(["upper", "lower"]):
                     lines += "%-20s" % nm + "".join("%9.4f" % st[j, ix, endb] for ix in range(st.shape[1])) + " %s\n" % typestr
             lines += "\n"
+        # mcsamples.py:1039: the remaining two tests need integer weights (raw MCMC multiplicities)
+        if ("RafteryLewis" in what or "CorrSteps" in what) and self.ctx.weights_integral():
+            if "RafteryLewis" in what:
+                rl = self.getRafteryLewis(test_confidence)
+                if rl is None:
+                    print("Raftery and Lewis estimator had problems")
+                    return None
+                lines += "Raftery&Lewis statistics\n\nchain  markov_thin  indep_thin    nburn\n"
+                for ix in range(len(rl["thin_fac"])):
+                    if rl["thin_fac"][ix] == 0:
+                        lines += "%4i      Failed/not enough samples\n" % ix
+                    else:
+                        lines += "%4i%12i%12i%12i\n" % (ix, rl["markov_thin"][ix], rl["thin_fac"][ix], rl["nburn"][ix])
+                if feedback:
+                    if not np.all(rl["thin_fac"] != 0):
+                        print("RL: Not enough samples to estimate convergence stats")
+                    else:
+                        print("RL: Thin for Markov: ", np.max(rl["markov_thin"]))
+                        print("RL: Thin for indep samples:  ", str(self.RL_indep_thin))
+                        print("RL: Estimated burn in steps: ", np.max(rl["nburn"]), " (",
+                              int(round(np.max(rl["nburn"]) / self.mean_mult)), " rows)")
+                lines += "\n"
+            if "CorrSteps" in what:
+                lines += "Parameter auto-correlations as function of step separation\n\n"
+                thin, corrs = self.getCorrSteps()
+                if corrs is not None:
+                    lines += "%-20s" % "" + "".join("%8i" % ((i + 1) * thin) for i in range(corrs.shape[0])) + "\n"
+                    for j, nm in enumerate(self.paramNames.list()):
+                        lines += "%-20s" % nm + "".join("%8.3f" % corrs[i][j] for i in range(corrs.shape[0])) + " \n"
         return lines
+
+    # ---- thinned-chain diagnostics (mcsamples.py:1039-1221; chains.py:853-916) ---------------------------------
+    def _chain_ranges(self):
+        if self.chain_offsets is None:
+            raise WeightedSampleError("Samples were not combined from separate chains")
+        return [(int(a), int(b)) for a, b in zip(self.chain_offsets[:-1], self.chain_offsets[1:])]
+
+    def _thin_rows(self, factor, lo=0, hi=None):
+        """
+        Device row list of the weight-one thinning of rows [lo,hi) (chains.py:878-916): (buffer, count).  Which of the
+        reference's two branches applies is decided by factor >= max weight of that chain, as there.
+        """
+        hi = self.numrows if hi is None else hi
+        if factor != int(factor):
+            raise WeightedSampleError("Thin factor must be integer")
+        ws = self.ctx.weight_stats(lo, hi)
+        unique_mode = int(factor) >= ws["max_w"]
+        capacity = int(ws["norm"]) // int(factor) + 2
+        return self.ctx.thin_rows(lo, hi, int(factor), unique_mode, capacity)
+
+    def thin_indices(self, factor, weights=None):
+        """chains.py:853-863: indices that make single-weight samples (the device list copied to the host)."""
+        if weights is not None:
+            raise NotImplementedError("thinning of weights that are not resident on the device")
+        buf, K = self._thin_rows(factor)
+        out = buf.to_host((K,), dtype=np.int32).astype(np.int64) if K else np.zeros(0, dtype=np.int64)
+        buf.free()
+        return out
+
+    def getRafteryLewis(self, test_confidence=0.95, nparam=None):
+        """
+        The Raftery-Lewis block of getConvergeTests (mcsamples.py:1039-1165): per chain the thinning needed for the
+        thinned binary chains (parameter above/below a tail quantile) to be first-order Markov, then independent, and
+        the burn-in estimate.  Returns dict(markov_thin, thin_fac, nburn) (arrays over chains; thin_fac = indep_thin,
+        0 = failed) or None where the reference gives up.  The quantiles, the thinning and the transition counts of
+        every (parameter, tail) at the current thin factor come from the GPU in one launch each; only the BIC logic
+        on 8 / 4 integers runs here.
+        """
+        import math
+
+        if not self.ctx.weights_integral():
+            raise WeightedSampleError("Raftery-Lewis needs integer weights")
+        ctx = self.ctx
+        ranges = self._chain_ranges()
+        nparamMC = nparam or self.paramNames.numNonDerived()
+        cols = list(range(nparamMC))
+        limits = np.array([1 - (1 - test_confidence) / 2, (1 - test_confidence) / 2])
+        nc = len(ranges)
+        thin_fac = np.zeros(nc, dtype=int)
+        nburn = np.zeros(nc, dtype=int)
+        markov_thin = np.zeros(nc, dtype=int)
+        epsilon = 0.001
+        hardest, hardestend = -1, 0  # carried over from chain to chain, as in the reference
+
+        class Failed(Exception):
+            pass
+
+        for ix, (lo, hi) in enumerate(ranges):
+            ws = ctx.weight_stats(lo, hi)
+            thin_fac[ix] = int(round(ws["max_w"]))
+            targets = np.tile(ws["norm"] * limits, (nparamMC, 1))
+            confids = ctx.quantiles(cols, targets, lo=lo, hi=hi)  # (param, upper/lower)
+            cache = {}
+
+            def counts(f, columns=cols, thr=confids, key="all"):
+                """(thin_rows, transition counts of every column/threshold) at thin factor f, cached per factor."""
+                if (key, f) not in cache:
+                    rows, K = self._thin_rows(f, lo, hi)
+                    cache[(key, f)] = (K, ctx.binary_transitions(columns, rows, K, thr) if K >= 2 else None)
+                    rows.free()
+                return cache[(key, f)]
+
+            thin_rows = None
+            try:
+                for j in range(nparamMC):
+                    for endb in (0, 1):
+                        tran = None
+                        while True:
+                            thin_rows, c = counts(int(thin_fac[ix]))
+                            if thin_rows < 2:
+                                break
+                            tran = c[j, endb, :8].reshape(2, 2, 2)
+                            g2 = 0.0
+                            for i1 in (0, 1):
+                                for i2 in (0, 1):
+                                    for i3 in (0, 1):
+                                        if tran[i1][i2][i3] != 0:
+                                            fitted = float((tran[i1][i2][0] + tran[i1][i2][1]) * (tran[0][i2][i3] + tran[1][i2][i3])) \
+                                                / float(tran[0][i2][0] + tran[0][i2][1] + tran[1][i2][0] + tran[1][i2][1])
+                                            focus = float(tran[i1][i2][i3])
+                                            g2 += math.log(focus / fitted) * focus
+                            g2 *= 2
+                            if g2 - math.log(float(thin_rows - 2)) * 2 < 0:
+                                break
+                            thin_fac[ix] += 1
+                        if tran is None:
+                            raise ValueError("not enough thinned samples")  # the reference's NameError -> bare except
+                        if np.sum(tran[:, 0, 1]) == 0 or np.sum(tran[:, 1, 0]) == 0:
+                            thin_fac[ix] = 0
+                            raise Failed()
+                        alpha = np.sum(tran[:, 0, 1]) / float(np.sum(tran[:, 0, 0]) + np.sum(tran[:, 0, 1]))
+                        beta = np.sum(tran[:, 1, 0]) / float(np.sum(tran[:, 1, 0]) + np.sum(tran[:, 1, 1]))
+                        probsum = alpha + beta
+                        tmp1 = math.log(probsum * epsilon / max(alpha, beta)) / math.log(abs(1.0 - probsum))
+                        if int(tmp1 + 1) * thin_fac[ix] > nburn[ix]:
+                            nburn[ix] = int(tmp1 + 1) * thin_fac[ix]
+                            hardest, hardestend = j, endb
+                markov_thin[ix] = thin_fac[ix]
+                hardest = max(hardest, 0)
+                u = self.confidence(hardest, (1 - test_confidence) / 2, hardestend == 0)  # over ALL samples (:1113)
+                while True:
+                    thin_rows, c = counts(int(thin_fac[ix]), [hardest], [[u]], key=("indep", hardest, hardestend))
+                    if thin_rows < 2:
+                        break
+                    tran2 = c[0, 0, 8:].reshape(2, 2)
+                    g2 = 0.0
+                    for i1 in (0, 1):
+                        for i2 in (0, 1):
+                            if tran2[i1][i2] != 0:
+                                fitted = float((tran2[i1][0] + tran2[i1][1]) * (tran2[0][i2] + tran2[1][i2])) / float(thin_rows - 1)
+                                focus = float(tran2[i1][i2])
+                                if fitted <= 0 or focus <= 0:
+                                    return None
+                                g2 += np.log(focus / fitted) * focus
+                    g2 *= 2
+                    if g2 - np.log(float(thin_rows - 1)) < 0:
+                        break
+                    thin_fac[ix] += 1
+            except Failed:
+                pass
+            except (ValueError, ZeroDivisionError, OverflowError, FloatingPointError):
+                thin_fac[ix] = 0  # the arithmetic failures the reference's bare `except:` swallows (:1146-1147)
+            if thin_fac[ix] and thin_rows is not None and thin_rows < 2:
+                thin_fac[ix] = 0
+        self.RL_indep_thin = np.max(thin_fac)
+        return dict(markov_thin=markov_thin, thin_fac=thin_fac, nburn=nburn)
+
+    def getCorrSteps(self):
+        """
+        The CorrSteps block (mcsamples.py:1183-1210): auto-correlation of every parameter in the thinned chains
+        (each about its own mean) at step separations 1..maxoff thinned rows.  Returns (autocorr_thin, corrs[maxoff, n])
+        or (autocorr_thin, None).  Thinning and the gathered lag sums run on the GPU.
+        """
+        if self.needs_update:
+            self.updateBaseStatistics()
+        ranges = self._chain_ranges()
+        if self.corr_length_thin != 0:
+            autocorr_thin = self.corr_length_thin
+        else:
+            indep_thin = getattr(self, "indep_thin", 0)
+            if indep_thin == 0:
+                autocorr_thin = 20
+            elif indep_thin <= 30:
+                autocorr_thin = 5
+            else:
+                autocorr_thin = int(5 * (indep_thin / 30))
+        rows, K = self._thin_rows(autocorr_thin)
+        rows.free()
+        maxoff = int(min(self.corr_length_steps, K // (2 * len(ranges))))
+        if maxoff <= 0:
+            return autocorr_thin, None
+        cols = list(range(self.n))
+        corrs = np.zeros((maxoff, self.n))
+        for (lo, hi), (cmeans, _, _) in zip(ranges, self.getSeparateChainStats(self.n)):
+            rows, K = self._thin_rows(autocorr_thin, lo, hi)
+            maxoff = min(maxoff, K // autocorr_thin)
+            if maxoff > 0:
+                lags = self.ctx.thinned_lag_sums(cols, cmeans, rows, K, maxoff)  # (n, maxoff)
+                corrs[:maxoff] += (lags / (K - np.arange(1, maxoff + 1))).T / self.vars
+            rows.free()
+        corrs /= len(ranges)
+        return autocorr_thin, corrs[:maxoff]
 
     def updateSettings(self, settings=None, ini=None, doUpdate=True):
         """mcsamples.py:472-499 (settings dict only)"""

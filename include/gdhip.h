@@ -203,6 +203,26 @@ int gd_aux_weights(gd_ctx* ctx, const double* w);
 int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, int32_t cond_col,
                   double cond_below, double* out);
 
+/* ---------------------------------------------------------------- thinned chains ---------------
+ * Raftery-Lewis and CorrSteps (mcsamples.py:1039-1221) work on weight-one thinnings of integer-weight chains
+ * (chains.py:878-916 thin_indices_single_samples).
+ * gd_weights_integral: *out = 1 when every sample weight is a non-negative integer (or weights are absent).
+ * gd_thin_rows: the thinned row list of chain rows [lo,hi) for `factor`, as int32 global row indices into
+ *   d_rows (device, `capacity` entries).  unique_mode = 1 is the reference's branch for factor >= max weight
+ *   (np.unique(cumsum // factor) first indices, :889-892), 0 its sequential loop (:894-914: row i once per
+ *   multiple of factor in (C_{i-1}, C_i]).  Both come from one cached prefix sum of the weights.
+ * gd_binary_transitions: for each column c and threshold t (thresholds: ncols x nthr, nthr <= 4), with
+ *   b[k] = (x[rows[k]] >= u ? 0 : 1): counts_out[(c*nthr+t)*12 + 0..7] = np.bincount(4 b[k-2] + 2 b[k-1] + b[k])
+ *   (:1065-1066) and [8..11] = np.bincount(2 b[k-1] + b[k]) (:1120-1122).
+ * gd_thinned_lag_sums: out[c*maxoff + off-1] = sum_k (x[rows[k+off]]-means[c]) (x[rows[k]]-means[c])  (:1204-1206). */
+int gd_weights_integral(gd_ctx* ctx, int32_t* out);
+int gd_thin_rows(gd_ctx* ctx, int64_t lo, int64_t hi, int64_t factor, int32_t unique_mode, void* d_rows, int64_t capacity,
+                 int64_t* count_out);
+int gd_binary_transitions(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const void* d_rows, int64_t K,
+                          const double* thresholds, int32_t nthr, int64_t* counts_out);
+int gd_thinned_lag_sums(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* means, const void* d_rows, int64_t K,
+                        int32_t maxoff, double* out);
+
 /* ---------------------------------------------------------------- mean likelihoods -------------
  * The optional `meanlikes` branches of get1DDensityGridData / get2DDensityGridData.
  * gd_like_weights: build the device vector  weights*exp(mean_loglike - loglikes)  (mode 0; mcsamples.py:1560,

@@ -86,6 +86,41 @@ class FakeContext:
             return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
 
+    # ---- thinned chains
+    def weights_integral(self):
+        w = self.w
+        return w is None or bool(np.all(w == np.floor(w)) and np.all(w >= 0))
+
+    def thin_rows(self, lo, hi, factor, unique_mode, capacity):
+        from oracle import convergence_oracle as co
+
+        w = np.ones(hi - lo) if self.w is None else self.w[lo:hi]
+        assert bool(unique_mode) == (factor >= np.max(w))
+        ix = co.thin_indices(factor, w) + lo
+        assert len(ix) <= capacity
+        return FakeBuf(ix.astype(np.int64)), len(ix)
+
+    def binary_transitions(self, cols, rows, K, thresholds):
+        thresholds = np.asarray(thresholds, dtype=float).reshape(len(cols), -1)
+        out = np.zeros((len(cols), thresholds.shape[1], 12), dtype=np.int64)
+        r = rows.a[:K]
+        for ci, c in enumerate(cols):
+            x = self.s[r, c]
+            for t in range(thresholds.shape[1]):
+                b = np.where(x >= thresholds[ci, t], 0, 1)
+                out[ci, t, :8] = np.bincount(b[:-2] * 4 + b[1:-1] * 2 + b[2:], minlength=8)
+                out[ci, t, 8:] = np.bincount(b[:-1] * 2 + b[1:], minlength=4)
+        return out
+
+    def thinned_lag_sums(self, cols, means, rows, K, maxoff):
+        r = rows.a[:K]
+        out = np.zeros((len(cols), maxoff))
+        for ci, c in enumerate(cols):
+            d = self.s[r, c] - means[ci]
+            for off in range(1, maxoff + 1):
+                out[ci, off - 1] = np.dot(d[off:], d[:-off])
+        return out
+
     # ---- auxiliary vectors
     EXTRA_COLS = 4
 

@@ -231,3 +231,14 @@ def test_range_nd_contour_widening(zoo):
     from test_host_logic_cpu import nd_ranges_check
 
     nd_ranges_check(zoo)
+
+
+def test_raftery_lewis_corr_steps_and_thinning():
+    """gd_thin_rows / gd_binary_transitions / gd_thinned_lag_sums behind getRafteryLewis, getCorrSteps, thin_indices."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic_cpu import raftery_lewis_check
+
+    raftery_lewis_check()

@@ -155,6 +155,45 @@ def test_host_logic_nd_ranges(zoo):
     nd_ranges_check(zoo, FakeContext)
 
 
+def raftery_lewis_check(factory=None):
+    """RafteryLewis / CorrSteps / thin_indices of the product against the reference goldens (integer-weight chains)."""
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import mcmc_chains_fixture
+
+    g = np.load(gu.GOLDEN_DIR + "/raftery_lewis.npz")
+    kw = {} if factory is None else dict(_context_factory=factory)
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture()
+    parts = list(zip(offsets[:-1], offsets[1:]))
+    mc = MCSamples(samples=[samples[a:b] for a, b in parts], weights=[weights[a:b] for a, b in parts],
+                   loglikes=[loglikes[a:b] for a, b in parts], names=names, **kw)
+    for tc in (0.95, 0.8):
+        rl = mc.getRafteryLewis(tc)
+        assert np.array_equal(np.column_stack([rl["markov_thin"], rl["thin_fac"], rl["nburn"]]), g["table/%g" % tc]), tc
+        assert int(mc.RL_indep_thin) == int(g["indep_thin/%g" % tc])
+    for thin in (20, 3):
+        mc.corr_length_thin = 0 if thin == 20 else thin
+        mc.indep_thin = 0
+        got_thin, corrs = mc.getCorrSteps()
+        assert got_thin == thin
+        assert gu.relerr(corrs, g["corrsteps/%d" % thin]) < 1e-10, thin
+    text = mc.getConvergeTests(what=("RafteryLewis", "CorrSteps"))
+    assert "chain  markov_thin  indep_thin    nburn" in text and "%4i%12i%12i%12i" % (0, *g["table/0.95"][0]) in text
+    assert "Parameter auto-correlations as function of step separation" in text
+    # thin_indices on the reference's random multiplicities, both branches
+    for k in range(6):
+        w = g["thin/%d/w" % k]
+        one = MCSamples(samples=np.arange(len(w), dtype=float)[:, None], weights=w, names=["x"], **kw)
+        assert np.array_equal(one.thin_indices(int(g["thin/%d/factor" % k])), g["thin/%d/ix" % k]), k
+    # non-integer weights: the two tests are skipped like in the reference (mcsamples.py:1039)
+    frac = MCSamples(samples=[samples[a:b] for a, b in parts], weights=[weights[a:b] + 0.25 for a, b in parts],
+                     names=names, **kw)
+    assert frac.getConvergeTests(what=("RafteryLewis", "CorrSteps")) == ""
+
+
+def test_host_logic_raftery_lewis():
+    raftery_lewis_check(FakeContext)
+
+
 def test_host_logic_branches_and_grid_classes(zoo):
     """block50: all three bandwidth branches, four grid sizes, bounded and unbounded pairs through the batched path."""
     fx = zoo["block50"]
