@@ -627,11 +627,14 @@ class MCSamples:
             out[:, ix, :] = np.sqrt(out[:, ix, :] / split_n) / self.sddev[:, None]
         return out
 
-    def getConvergeTests(self, test_confidence=0.95, writeDataToFile=False, what=("MeanVar", "GelmanRubin"),
-                         filename=None, feedback=False):
+    def getConvergeTests(self, test_confidence=0.95, writeDataToFile=False,
+                         what=("MeanVar", "GelmanRubin", "SplitTest", "RafteryLewis", "CorrLengths"), filename=None,
+                         feedback=False):
         """
-        The MeanVar and GelmanRubin blocks of mcsamples.py:904-1003 (the other diagnostics are outside the
-        accelerated path).  Returns the report text and sets self.GelmanRubin like the reference.
+        mcsamples.py:904-1221: the report text of the convergence tests (same defaults as the reference; "CorrSteps" is
+        opt-in there too).  Sets self.GelmanRubin, self.indep_thin, self.RL_indep_thin like the reference.  Every
+        N-sized pass behind the numbers (chain covariances, quantiles on row sub-ranges, lag sums, thinning, transition
+        counts) runs on the GPU; this function only formats.
         """
         if writeDataToFile or filename:
             raise NotImplementedError("file output is outside the accelerated path")
