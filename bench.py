@@ -75,6 +75,7 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     """The timed unit of work.  Returns the list of Density2D this rank produced."""
     from getdist_amd import parallel
 
+    t_step0 = time.perf_counter()
     reset_caches(mc)
     if emulate:
         world = emulate
@@ -85,9 +86,15 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
         parallel.unpack_param_state(mc, _REPLAY["rows"][others])  # what the all-gather would deliver
     else:
         parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
+    t_part0 = time.perf_counter()
     classes = dict(zip(pairs_all, pair_cost_classes(mc, pairs_all)))
     _, my_pairs = parallel.partition_pairs(pairs_all, classes.__getitem__, world, rank)
-    return mc.get2DDensities(my_pairs)
+    if mc._timing:
+        mc.timings["step.partition"] = mc.timings.get("step.partition", 0.0) + time.perf_counter() - t_part0
+    out = mc.get2DDensities(my_pairs)
+    if mc._timing:
+        mc.timings["step.total"] = mc.timings.get("step.total", 0.0) + time.perf_counter() - t_step0
+    return out
 
 
 def binning_kernel_roofline(mc, pairs_all, reps=5):

@@ -433,6 +433,110 @@ __global__ void k_qsel_out(const QState* __restrict__ st, int ncols, int k, doub
     out[i] = key_f64(st[i / k].prefix[i % k]);
 }
 
+// ---- early finish of the radix select ------------------------------------------------------------------------
+// After P passes (8P key bits known) the selected buckets of continuous data hold a handful of rows (N = 1e7
+// Gaussian columns: <~1000 after 24 bits, <~10 after 32).  Instead of five more streaming passes, ONE pass collects
+// the (key, weight) pairs of every live bucket and a per-column block sorts each short list and walks its cumulative
+// weight exactly like np.cumsum on the argsorted column does (chains.py:807-811, 834-838).  A bucket that overflows
+// the list (heavily tied data) sets a flag and the caller falls back to the remaining radix passes.
+#define QCAP 4096
+template <bool HAS_W>
+__global__ void k_qsel_collect(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                               const double* __restrict__ w, int64_t lo, int64_t hi, int passes_done,
+                               const QState* __restrict__ st, unsigned long long* __restrict__ lkeys,
+                               double* __restrict__ lw, int* __restrict__ counts) {
+    const int c = blockIdx.y;
+    const double* x = cols + (int64_t)colidx[c] * ld;
+    const int nuniq = st[c].nuniq;
+    const int shift = 64 - 8 * passes_done;
+    const unsigned long long bloom = st[c].bloom;
+    unsigned long long pre[QK_MAX];
+#pragma unroll
+    for (int u = 0; u < QK_MAX; ++u) pre[u] = st[c].uprefix[u];
+    stream_xw4<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        const unsigned long long key = f64_key(v);
+        const unsigned long long top = key >> shift;
+        if ((bloom >> prefix_hash6(top)) & 1ull) {
+            int slot = -1;
+#pragma unroll
+            for (int u = 0; u < QK_MAX; ++u)
+                if (u < nuniq && top == pre[u]) slot = u;
+            if (slot >= 0) {
+                const int pos = atomicAdd(&counts[c * QK_MAX + slot], 1);
+                if (pos < QCAP) {
+                    const int64_t o = ((int64_t)c * QK_MAX + slot) * QCAP + pos;
+                    lkeys[o] = key;
+                    lw[o] = wt;
+                }
+            }
+        }
+    });
+}
+
+// one block per column: sort each live bucket's list (bitonic, LDS) and pick every target's row
+__global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__ st, const unsigned long long* __restrict__ lkeys,
+                                                      const double* __restrict__ lw, const int* __restrict__ counts, int k,
+                                                      int passes_done, double* __restrict__ out, int* __restrict__ overflow) {
+    __shared__ unsigned long long sk[QCAP];
+    __shared__ double sw[QCAP];
+    const int c = blockIdx.x;
+    const QState& s = st[c];
+    for (int u = 0; u < s.nuniq; ++u) {
+        const int n = counts[c * QK_MAX + u];
+        if (n > QCAP) {
+            if (threadIdx.x == 0) atomicOr(overflow, 1);
+            return;
+        }
+    }
+    for (int u = 0; u < s.nuniq; ++u) {
+        const int n = counts[c * QK_MAX + u];
+        int m = 1;
+        while (m < n) m <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const int64_t o = ((int64_t)c * QK_MAX + u) * QCAP + i;
+            sk[i] = (i < n) ? lkeys[o] : ~0ull;
+            sw[i] = (i < n) ? lw[o] : 0.0;
+        }
+        __syncthreads();
+        for (int size = 2; size <= m; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < m; i += blockDim.x) {
+                    const int j = i ^ stride;
+                    if (j > i) {
+                        const bool up = (i & size) == 0;
+                        const unsigned long long a = sk[i], b = sk[j];
+                        if ((a > b) == up) {
+                            sk[i] = b, sk[j] = a;
+                            const double t = sw[i];
+                            sw[i] = sw[j], sw[j] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        // every target that lives in this bucket walks the sorted list (thread q <-> target q)
+        if (threadIdx.x < k && s.slot[threadIdx.x] == u) {
+            const int q = threadIdx.x;
+            double cum = s.cum_below[q];
+            int pick = -1, last = -1;
+            for (int i = 0; i < n; ++i) {
+                const double wv = sw[i];
+                if (wv != 0) {
+                    last = i;
+                    if (cum + wv >= s.target[q]) {
+                        pick = i;
+                        break;
+                    }
+                }
+                cum += wv;
+            }
+            if (pick < 0) pick = last < 0 ? 0 : last;  // beyond the total weight: clamp to the last row
+            out[(int64_t)c * k + q] = key_f64(n > 0 ? sk[pick] : (s.prefix[q] << (64 - 8 * passes_done)));
+        }
+    }
+}
+
 // ---- autocovariance lag sums: out[l] = sum_i d_i d_{i+k0+l},  d = (x-mean)*w ---------------------------------
 #define AL 32     // lags per launch
 #define AT 2048   // rows per tile
@@ -740,13 +844,18 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
         return o;
     };
     const int64_t o_st = take((int64_t)ncols * sizeof(QState)), o_h = take((int64_t)ncols * QK_MAX * 256 * 8),
-                  o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8);
+                  o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8),
+                  o_cnt = take((int64_t)ncols * QK_MAX * 4 + 256), o_lk = take((int64_t)ncols * QK_MAX * QCAP * 8),
+                  o_lw = take((int64_t)ncols * QK_MAX * QCAP * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     QState* d_st = (QState*)(base + o_st);
     double* d_h = (double*)(base + o_h);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_out = (double*)(base + o_out);
+    int* d_cnt = (int*)(base + o_cnt);
+    unsigned long long* d_lk = (unsigned long long*)(base + o_lk);
+    double* d_lw = (double*)(base + o_lw);
     GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemsetAsync(d_h, 0, (size_t)ncols * QK_MAX * 256 * 8, ctx->stream));
@@ -755,7 +864,7 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     int nblk = (8 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk < 8) nblk = 8;
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
-    for (int pass = 0; pass < 8; ++pass) {
+    auto radix_pass = [&](int pass) -> int {
         dim3 grid(nblk, ncols);
         if (ctx->w)
             k_qsel_pass<true><<<grid, 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, pass, d_st, d_h);
@@ -765,7 +874,33 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
         GD_KERNEL_CHECK();
         k_qsel_scan<<<ncols, 256, 0, ctx->stream>>>(d_st, d_h, ncols, pass);
         GD_KERNEL_CHECK();
+        return GD_OK;
+    };
+    // radix passes until the live buckets are short, then collect + sort them (k_qsel_collect / k_qsel_finish)
+    const int P = (hi - lo) <= 15000000 ? 3 : 4;
+    int rc;
+    for (int pass = 0; pass < P; ++pass)
+        if ((rc = radix_pass(pass))) return rc;
+    GD_HIP(hipMemsetAsync(d_cnt, 0, (size_t)ncols * QK_MAX * 4 + 256, ctx->stream));
+    {
+        dim3 grid(nblk, ncols);
+        if (ctx->w)
+            k_qsel_collect<true><<<grid, 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, P, d_st, d_lk, d_lw,
+                                                                  d_cnt);
+        else
+            k_qsel_collect<false><<<grid, 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, P, d_st, d_lk,
+                                                                   d_lw, d_cnt);
+        GD_KERNEL_CHECK();
     }
+    k_qsel_finish<<<ncols, 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    GD_KERNEL_CHECK();
+    int overflow = 0;
+    GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (!overflow) return GD_OK;
+    for (int pass = P; pass < 8; ++pass)  // heavily tied data: finish with the plain radix passes
+        if ((rc = radix_pass(pass))) return rc;
     k_qsel_out<<<(ncols * k + 255) / 256, 256, 0, ctx->stream>>>(d_st, ncols, k, d_out);
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -275,6 +275,20 @@ class _Phase:
             self.mc.timings[self.name] = self.mc.timings.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
+_HELPER = None
+
+
+def _helper_thread():
+    """One background thread for C-ABI calls that can run while the main thread does host-only scalar work (ctypes
+    releases the GIL for the duration of a call)."""
+    global _HELPER
+    if _HELPER is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gdhip-helper")
+    return _HELPER
+
+
 def _get_h_job(job):
     return _get_h(*job)
 
@@ -1857,6 +1871,8 @@ class MCSamples:
         self._init_params(used)
         names = self.paramNames.names
         corrmat = self.getCorrelationMatrix()
+        _ph_info = _Phase(self, "2d.host_pair_scalars")
+        _ph_info.__enter__()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         info = []
         edge_cache = {}
@@ -1886,19 +1902,38 @@ class MCSamples:
             fwy, ybinmin, ybinmax = edges(j2, F)
             info.append(dict(j=j, j2=j2, parx=parx, pary=pary, corr=corr, actual_corr=actual_corr, F=F, nbin2D=nbin2D,
                              fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin, ybinmax=ybinmax))
+        _ph_info.__exit__()
         # ---- histograms, one batched launch per grid-size class (pre-binned u16 index columns)
         classes = {}
         for k, e in enumerate(info):
             classes.setdefault(e["F"], []).append(k)
         hists, likehists = {}, {}
-        for F, members in classes.items():
-            with _Phase(self, "2d.prebin"):
-                ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
-                iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
-            with _Phase(self, "2d.hist"):
-                hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
-                if meanlikes:
-                    likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
+
+        def binning():
+            for F, members in classes.items():
+                with _Phase(self, "2d.prebin"):
+                    ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
+                    iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
+                with _Phase(self, "2d.hist"):
+                    hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
+                    if meanlikes:
+                        likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
+
+        auto_bw = smooth_scale_2D < 0 and _bandwidths is None
+        plan = None
+        if auto_bw and not self._timing and not self.use_effective_samples_2D:
+            # the branch selection is host-only scalar work once every N_eff is known: run it here while a helper thread
+            # sits in the (GIL-free) binning calls
+            self._neff_batch(used)
+            pending = _helper_thread().submit(binning)
+            try:
+                plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
+                                            [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
+                                            base_F)
+            finally:
+                pending.result()
+        else:
+            binning()
         # ---- bandwidths: device optimiser now, host TNC solves asynchronously in the process pool
         rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
         finish_bw = None
@@ -1917,9 +1952,11 @@ class MCSamples:
                 for k, b in enumerate(_bandwidths):
                     set_widths(k, b)
             else:
-                plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
-                                            [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
-                                            base_F)
+                if plan is None:
+                    with _Phase(self, "2d.host_bandwidth_plan"):
+                        plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
+                                                    [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
+                                                    base_F)
                 with _Phase(self, "2d.bandwidth.device"):
                     finish_bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
                 for k, e in enumerate(info):
@@ -2031,16 +2068,17 @@ class MCSamples:
                     set_widths(k, b)
             for F, (d_hist, members) in hists.items():
                 run_class(F, d_hist, members, 1)
-        with _Phase(self, "2d.d2h_wait"):
-            ctx.copy_sync()
         for F, (d_hist, members) in hists.items():
             d_hist.free()
         for d_lh in likehists.values():
             d_lh.free()
+        if not get_density:  # contour levels read the grids
+            with _Phase(self, "2d.d2h_wait"):
+                ctx.copy_sync()
+        _ph_asm = _Phase(self, "2d.host_assemble_results")
+        _ph_asm.__enter__()
+        # the result objects only hold views of the page-locked arrays, so they are built while the last copies land
         for d_P, P, ks, status, d_L, L in inflight:
-            d_P.free()
-            if d_L is not None:
-                d_L.free()
             F = P.shape[1]
             for row, k in enumerate(ks):
                 if status[row] != 0:
@@ -2059,6 +2097,14 @@ class MCSamples:
                     dens.contours = dens.getContourLevels(self.contours[:ncontours])
                 dens.likes = None if L is None else L[row]
                 out[k] = dens
+        _ph_asm.__exit__()
+        if get_density:
+            with _Phase(self, "2d.d2h_wait"):
+                ctx.copy_sync()
+        for d_P, P, ks, status, d_L, L in inflight:
+            d_P.free()
+            if d_L is not None:
+                d_L.free()
         return out
 
     # ---- convergence (chains.py:1446-1527; mcsamples.py:964-1003) ------------------------------------------

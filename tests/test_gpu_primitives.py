@@ -238,3 +238,43 @@ def test_integer_weights_take_exact_u32_path(ctx):
     ix = ((s[:, 0] - e[0][0]) / e[0][1] + 0.5).astype(int)
     iy = ((s[:, 1] - e[1][0]) / e[1][1] + 0.5).astype(int)
     assert np.allclose(H2, np.bincount(ix + iy * F, weights=w2, minlength=F * F).reshape(F, F), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("weights", ["unit", "integer"])
+def test_quantiles_with_ties_take_the_radix_fallback(weights):
+    """
+    Heavily tied columns overflow the collect list of the early-finish quantile select (k_qsel_collect, 4096 rows per
+    bucket) and must fall back to the plain radix passes; short-bucket and tied columns share one call.  Unit and
+    integer weights make the reference's pick unambiguous, so the comparison is exact.
+    """
+    from getdist_amd._lib import Context
+
+    rng = np.random.default_rng(77)
+    N = 250_003
+    tied = rng.choice([-1.5, 0.25, 0.2500000001, 7.0], size=N, p=[0.2, 0.3, 0.3, 0.2])
+    cont = rng.standard_normal(N)
+    const = np.full(N, 3.25)
+    few = np.round(rng.standard_normal(N), 1)  # ~80 distinct values
+    s = np.column_stack([cont, tied, const, few, np.abs(cont)])
+    w = None if weights == "unit" else rng.integers(0, 4, N).astype(float)
+    c = Context(0)
+    try:
+        c.upload(s, w)
+        wv = np.ones(N) if w is None else w
+        fracs = np.array([0.0, 0.001, 0.2, 0.25, 0.5, 0.5000001, 0.8, 0.999, 1.0, 1.5])
+        cols = [0, 1, 2, 3, 4]
+        for lo, hi in ((0, N), (1001, 200_000)):
+            norm = wv[lo:hi].sum()
+            got = c.quantiles(cols, np.tile(norm * fracs, (len(cols), 1)), lo=lo, hi=hi)
+            for ci, col in enumerate(cols):
+                x = s[lo:hi, col]
+                idx = x.argsort(kind="stable")
+                cum = np.cumsum(wv[lo:hi][idx])
+                want = x[idx[np.minimum(np.searchsorted(cum, norm * fracs), len(idx) - 1)]]
+                ok = got[ci] == want
+                # target 0 / rows of zero weight at the very start: the reference returns the smallest row whatever its
+                # weight, the device the smallest row of positive weight
+                assert np.all(ok[1:]), (weights, col, lo, got[ci], want)
+                assert ok[0] or w is not None
+    finally:
+        c.close()
