@@ -286,9 +286,11 @@ class Context:
     def sync(self):
         self._check(self.lib.gd_sync(self.h))
 
-    def gather_items(self, dst, src, index, item_bytes):
+    def gather_items(self, dst, src, index, item_bytes, dst_offset=0):
+        """dst[dst_offset + q] = src[index[q]] for fixed-size items (one gather kernel)."""
         index = _i32arr(index)
-        self._check(self.lib.gd_gather_items(self.h, dst.ptr, src.ptr, _ip(index), len(index), int(item_bytes)))
+        self._check(self.lib.gd_gather_items(self.h, dst.ptr + int(dst_offset) * int(item_bytes), src.ptr, _ip(index),
+                                             len(index), int(item_bytes)))
 
     def autocov_lags_batch(self, cols, means, k0, nlags):
         cols, means = _i32arr(cols), _f64arr(means)

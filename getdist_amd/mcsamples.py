@@ -1760,26 +1760,46 @@ class MCSamples:
             d_rot = ctx.hist2d_sheared([plan[k]["i"] for k in A], [plan[k]["j"] for k in A],
                                        [plan[k]["r"][0] for k in A], [plan[k]["r"][1] for k in A], xmin, dx, ymin, dy,
                                        base_F)
-            do_corr = [0 if plan[k]["has_limits"] else 1 for k in A]
-            out = ctx.kopt2d(d_rot, len(A), base_F, [plan[k]["neff"] for k in A], do_corr, [-1.0] * len(A))
-            d_rot.free()
-            for row, k in enumerate(A):
-                e = plan[k]
-                e["kopt"] = out[row].copy()
-                if out[row, 7] != 0:
-                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                    continue
-                jobs.append((tuple(out[row, 1:7]), e["neff"], 0, bool(do_corr[row])))
-                job_meta.append(("A", k, r1s[row], r2s[row]))
-            submit()
+            shear = dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
+        else:
+            shear = None
         # -- branch B: rule of thumb
         for k, e in enumerate(plan):
             if e["branch"] == "B":
                 c = max(min(e["corr"], self.max_corr_2D), -self.max_corr_2D)
                 results[k] = (e["parx"].sigma_range / e["neff"] ** (1.0 / 6), e["pary"].sigma_range / e["neff"] ** (1.0 / 6), c)
-        # -- branch C: optimiser on the pair's own histogram
+
+        def optimise(F, d_batch, rows):
+            """One device-optimiser launch; rows = [(branch, plan index, r1, r2)] in batch order."""
+            ks = [k for _, k, _, _ in rows]
+            do_corr = [0 if plan[k]["has_limits"] else 1 for k in ks]
+            fb = [-1.0 if br == "A" else plan[k]["fallback_t"] for br, k, _, _ in rows]
+            out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb)
+            for row, (br, k, r1, r2) in enumerate(rows):
+                e = plan[k]
+                e["kopt"] = out[row].copy()
+                if out[row, 7] != 0:
+                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
+                    continue
+                jobs.append((tuple(out[row, 1:7]), e["neff"], 0 if br == "A" else e["corr"], bool(do_corr[row])))
+                job_meta.append((br, k, r1, r2))
+
+        # -- branches A and C share the device optimiser: the sheared histograms ride in the same launch as the
+        #    base-grid pairs' own histograms (one block per pair; a short extra launch would cost a full block latency)
+        item = base_F * base_F * 8
+        rows_A = [("A", k, shear["r1s"][row], shear["r2s"][row]) for row, k in enumerate(A)] if A else []
+        merged = False
         for F, (d_hist, members) in hists_by_F.items():
             sel = [(pos, k) for pos, k in enumerate(members) if plan[k]["branch"] == "C"]
+            rows_C = [("C", k, None, None) for _, k in sel]
+            if F == base_F and rows_A and sel:
+                d_all = ctx.alloc((len(rows_A) + len(sel)) * item)
+                ctx.gather_items(d_all, shear["d_rot"], list(range(len(rows_A))), item)
+                ctx.gather_items(d_all, d_hist, [pos for pos, _ in sel], item, dst_offset=len(rows_A))
+                optimise(F, d_all, rows_A + rows_C)
+                d_all.free()
+                merged = True
+                continue
             if not sel:
                 continue
             if len(sel) == len(members):
@@ -1787,19 +1807,13 @@ class MCSamples:
             else:
                 d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
                 self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
-            do_corr = [0 if plan[k]["has_limits"] else 1 for _, k in sel]
-            out = ctx.kopt2d(d_sub, len(sel), F, [plan[k]["neff"] for _, k in sel], do_corr,
-                             [plan[k]["fallback_t"] for _, k in sel])
+            optimise(F, d_sub, rows_C)
             if own:
                 d_sub.free()
-            for row, (_, k) in enumerate(sel):
-                e = plan[k]
-                e["kopt"] = out[row].copy()
-                if out[row, 7] != 0:
-                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                    continue
-                jobs.append((tuple(out[row, 1:7]), e["neff"], e["corr"], bool(do_corr[row])))
-                job_meta.append(("C", k, None, None))
+        if rows_A and not merged:
+            optimise(base_F, shear["d_rot"], rows_A)
+        if shear is not None:
+            shear["d_rot"].free()
         submit()
         early = [k for k in range(len(plan)) if results[k] is not None]
         for k in early:

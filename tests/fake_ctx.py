@@ -66,8 +66,17 @@ class FakeContext:
     def device_info(self):
         return dict(cu_count=1, lds_bytes=0, hbm_total=0, hbm_free=0, clock_khz=0, wave=64)
 
-    def gather_items(self, dst, src, index, item_bytes):
-        dst.a = np.array(src.a)[np.asarray(index)]
+    def gather_items(self, dst, src, index, item_bytes, dst_offset=0):
+        picked = np.array(src.a)[np.asarray(index, dtype=int)]
+        if dst_offset == 0 and (dst.a is None or dst.nbytes <= len(index) * item_bytes):
+            dst.a = picked
+            return
+        if dst.a is None or len(dst.a) < dst.nbytes // item_bytes:
+            grown = np.zeros((dst.nbytes // item_bytes,) + picked.shape[1:])
+            if dst.a is not None:
+                grown[:len(dst.a)] = dst.a
+            dst.a = grown
+        dst.a[dst_offset:dst_offset + len(index)] = picked
 
     # ---- sample set
     def upload(self, samples, weights=None):
