@@ -195,6 +195,15 @@ class Density2D(GridDensity):
         self.contours = None
         self.setP(P)
 
+    @classmethod
+    def _wrap(cls, x, y, P, view_ranges, spacing):
+        """Constructor without the shape checks, for batches of grids whose axes were built with them."""
+        d = cls.__new__(cls)
+        d.x, d.y, d.axes, d.view_ranges, d.mask, d.spacing = x, y, [y, x], view_ranges, None, spacing
+        d.likes = d.contours = d.spl = None
+        d.P = P
+        return d
+
     def integrate(self, P):
         inner = np.sum(P[1:-1, 1:-1])
         corners = (P[0, 0] + P[0, -1] + P[-1, 0] + P[-1, -1]) / 4.0

@@ -393,6 +393,16 @@ class _PoolResult:
         return out
 
 
+class _Deferred:
+    """A pool handle that is itself still being created in the helper thread."""
+
+    def __init__(self, future):
+        self.future = future
+
+    def get(self):
+        return self.future.result().get()
+
+
 def _get_h_many(jobs, workers=None):
     """
     Start many independent get_h solves; returns an object whose .get() yields the results in order.  TNC costs
@@ -1730,11 +1740,13 @@ class MCSamples:
         def submit():
             """Closed-form solves now; TNC solves go to the pool immediately so they overlap the next device stage."""
             pooled = [(job, meta) for job, meta in zip(jobs, job_meta) if job[3]]
+            if pooled:
+                # the pipe writes to the workers go through the helper thread: the workers start at once and the
+                # closed-form solves below run meanwhile
+                pendings.append((pooled, _Deferred(_helper_thread().submit(_get_h_many, [job for job, _ in pooled]))))
             for job, meta in zip(jobs, job_meta):
                 if not job[3]:
                     results[meta[1]] = to_param_units(meta, _get_h(*job))
-            if pooled:
-                pendings.append((pooled, _get_h_many([job for job, _ in pooled])))
             del jobs[:], job_meta[:]
 
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
@@ -1896,26 +1908,27 @@ class MCSamples:
                 edge_cache[(jj, FF)] = self._bin_edges(names[jj], FF)
             return edge_cache[(jj, FF)]
 
-        for (j, j2) in pairs:
-            parx, pary = names[j], names[j2]
-            corr = corrmat[j2][j]
-            actual_corr = corr
-            if abs(abs(corr) - 1.0) <= 1e-8:
-                logging.warning("Parameters are 100%% correlated: %s, %s", parx.name, pary.name)
-                corr = np.sign(corr) * self.max_corr_2D
-            if abs(corr) < 0.1:
-                corr = 0.0
-            angle_scale = max(0.2, np.sqrt(1 - min(self.max_corr_2D, abs(corr)) ** 2))
-            nbin2D = int(round(self.num_bins_2D / angle_scale))
-            F = base_F
-            if corr:
-                scaled = 192 * int(3 / angle_scale) // 3
-                if base_F < scaled and int(1 / angle_scale) > 1:
-                    F = scaled
+        # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
+        jx = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+        jy = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+        actual = np.asarray(corrmat)[jy, jx]
+        corr_v = actual.copy()
+        full = np.abs(np.abs(corr_v) - 1.0) <= 1e-8
+        for q in np.nonzero(full)[0]:
+            logging.warning("Parameters are 100%% correlated: %s, %s", names[jx[q]].name, names[jy[q]].name)
+        corr_v[full] = np.sign(corr_v[full]) * self.max_corr_2D
+        corr_v[np.abs(corr_v) < 0.1] = 0.0
+        angle_scale = np.maximum(0.2, np.sqrt(1 - np.minimum(self.max_corr_2D, np.abs(corr_v)) ** 2))
+        nbin2D_v = np.round(self.num_bins_2D / angle_scale).astype(np.int64)
+        scaled = 192 * (3 / angle_scale).astype(np.int64) // 3
+        F_v = np.where((corr_v != 0) & (base_F < scaled) & ((1 / angle_scale).astype(np.int64) > 1), scaled, base_F)
+        for q, (j, j2) in enumerate(pairs):
+            F = int(F_v[q])
             fwx, xbinmin, xbinmax = edges(j, F)
             fwy, ybinmin, ybinmax = edges(j2, F)
-            info.append(dict(j=j, j2=j2, parx=parx, pary=pary, corr=corr, actual_corr=actual_corr, F=F, nbin2D=nbin2D,
-                             fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin, ybinmax=ybinmax))
+            info.append(dict(j=j, j2=j2, parx=names[j], pary=names[j2], corr=corr_v[q], actual_corr=actual[q], F=F,
+                             nbin2D=int(nbin2D_v[q]), fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin,
+                             ybinmax=ybinmax))
         _ph_info.__exit__()
         # ---- histograms, one batched launch per grid-size class (pre-binned u16 index columns)
         classes = {}
@@ -1998,7 +2011,8 @@ class MCSamples:
         def axis(par, lo, hi, F):
             key = (par.name, F)
             if key not in axes:
-                axes[key] = np.linspace(lo, hi, F)
+                a = np.linspace(lo, hi, F)
+                axes[key] = (a, a[1] - a[0])
             return axes[key]
 
         def run_class(F, d_hist, members, stage):
@@ -2098,9 +2112,9 @@ class MCSamples:
                 if status[row] != 0:
                     raise DensitiesError("no samples in bin")
                 e = info[k]
-                dens = Density2D(axis(e["parx"], e["xbinmin"], e["xbinmax"], F), axis(e["pary"], e["ybinmin"], e["ybinmax"], F),
-                                 P[row], view_ranges=[(e["parx"].range_min, e["parx"].range_max),
-                                                      (e["pary"].range_min, e["pary"].range_max)])
+                (ax, sx), (ay, sy) = axis(e["parx"], e["xbinmin"], e["xbinmax"], F), axis(e["pary"], e["ybinmin"], e["ybinmax"], F)
+                dens = Density2D._wrap(ax, ay, P[row], [(e["parx"].range_min, e["parx"].range_max),
+                                                        (e["pary"].range_min, e["pary"].range_max)], sx * sy)
                 dens.bandwidth = e.get("bandwidth")
                 dens.bandwidth_branch = e.get("branch")
                 dens.kopt = e.get("kopt")
