@@ -2041,9 +2041,9 @@ class MCSamples:
                                     e["pary"].name)
                 e["winw"] = max(1, int(round(2.5 * smooth_scale)))
                 groups.setdefault((flags & 48, has_prior and bco >= 0), []).append((pos, k))
-            # batches of a few hundred grids keep the FFTs efficient and the D2H copy of batch k hidden behind the
+            # batches of a few hundred grids (default cap 320) keep the FFTs efficient and the D2H copy of batch k hidden behind the
             # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
-            max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 192))))
+            max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 320))))
             batches = []
             for bounded, sel_all in groups.items():
                 by_S = {}  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
