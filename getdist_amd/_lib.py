@@ -86,6 +86,7 @@ SIGNATURES = {
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_contour_levels": (C.c_int, [_p, _i32, _i32, _p, _pd, _i32, _pd, _pi32]),
     "gd_set_extra_column": (C.c_int, [_p, _i32, _pd]),
     "gd_aux_weights": (C.c_int, [_p, _pd]),
     "gd_col_minmax": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _i32, C.c_double, _pd]),
@@ -496,6 +497,15 @@ class Context:
         self._check(self.lib.gd_col_minmax(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi,
                                            int(cond_col), float(cond_below), _dp(out)))
         return out
+
+    # ---- contour levels
+    def contour_levels(self, d_P, B, F, contours):
+        contours = _f64arr(contours)
+        out = np.zeros((B, len(contours)))
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_contour_levels(self.h, int(B), int(F), d_P.ptr, _dp(contours), len(contours), _dp(out),
+                                               _ip(status)))
+        return out, status
 
     # ---- thinned chains
     def weights_integral(self):

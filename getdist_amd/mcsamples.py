@@ -2070,6 +2070,12 @@ class MCSamples:
                     d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
                                                 [cc[k] for k in ks], [info[k]["winw"] for k in ks],
                                                 [info[k]["flags"] for k in ks], bco, mbc)
+                levels = None
+                if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
+                    ncontours = len(self.contours)
+                    if num_plot_contours:
+                        ncontours = min(num_plot_contours, ncontours)
+                    levels = ctx.contour_levels(d_P, len(sel), F, self.contours[:ncontours])
                 d_L = L = None
                 if meanlikes:
                     if own:
@@ -2088,7 +2094,7 @@ class MCSamples:
                 if own:
                     d_sub.free()
                 # the copy runs on the copy stream while the next batch computes
-                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L))
+                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
 
         for F, (d_hist, members) in hists.items():
             run_class(F, d_hist, members, 0)
@@ -2102,13 +2108,14 @@ class MCSamples:
             d_hist.free()
         for d_lh in likehists.values():
             d_lh.free()
-        if not get_density:  # contour levels read the grids
-            with _Phase(self, "2d.d2h_wait"):
-                ctx.copy_sync()
+        synced = False
+        if any(lv is not None and np.any(lv[1] == -5) for *_, lv in inflight):  # a grid left to the host reads P
+            ctx.copy_sync()
+            synced = True
         _ph_asm = _Phase(self, "2d.host_assemble_results")
         _ph_asm.__enter__()
         # the result objects only hold views of the page-locked arrays, so they are built while the last copies land
-        for d_P, P, ks, status, d_L, L in inflight:
+        for d_P, P, ks, status, d_L, L, levels in inflight:
             F = P.shape[1]
             for row, k in enumerate(ks):
                 if status[row] != 0:
@@ -2120,18 +2127,20 @@ class MCSamples:
                 dens.bandwidth = e.get("bandwidth")
                 dens.bandwidth_branch = e.get("branch")
                 dens.kopt = e.get("kopt")
-                if not get_density:
-                    ncontours = len(self.contours)
-                    if num_plot_contours:
-                        ncontours = min(num_plot_contours, ncontours)
-                    dens.contours = dens.getContourLevels(self.contours[:ncontours])
+                if levels is not None:
+                    if levels[1][row] == 0:
+                        dens.contours = levels[0][row].copy()
+                    elif levels[1][row] == -4:
+                        raise DensitiesError("Contour level outside plotted ranges")
+                    else:  # more exactly equal grid values at the level than the kernel's tie list holds
+                        dens.contours = dens.getContourLevels(self.contours[:levels[0].shape[1]])
                 dens.likes = None if L is None else L[row]
                 out[k] = dens
         _ph_asm.__exit__()
-        if get_density:
+        if not synced:
             with _Phase(self, "2d.d2h_wait"):
                 ctx.copy_sync()
-        for d_P, P, ks, status, d_L, L in inflight:
+        for d_P, P, ks, status, d_L, L, levels in inflight:
             d_P.free()
             if d_L is not None:
                 d_L.free()

@@ -187,6 +187,15 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const do
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                  void* d_P_out, int32_t* status_out);
 
+/* ---------------------------------------------------------------- contour levels ---------------
+ * gd_contour_levels: densities.py:19-56 getContourLevels(P, contours, half_edge=True) for B grids
+ *   (device, B x F x F): out[b*nc + c] = the density level enclosing contours[c] of the half-edge-weighted
+ *   mass (argsort of the un-halved grid, cumulative half-weighted mass, linear interpolation between the two
+ *   bracketing sorted entries).  status_out[b]: GD_OK; GD_ERR_EMPTY = "Contour level outside plotted ranges"
+ *   (:51-52); GD_ERR_SOLVER = more than 1024 exactly equal values at the level (do that grid on the host). */
+int gd_contour_levels(gd_ctx* ctx, int32_t B, int32_t F, const void* d_P, const double* contours, int32_t nc, double* out,
+                      int32_t* status_out);
+
 /* ---------------------------------------------------------------- auxiliary vectors ------------
  * The reference lets most statistics take an arbitrary vector instead of a column index (`_makeParamvec`,
  * chains.py:325-337), a row filter `where=` (chains.py:666-780) or alternative weights (chains.py:793-838).

@@ -95,6 +95,11 @@ class FakeContext:
             return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
 
+    # ---- contour levels
+    def contour_levels(self, d_P, B, F, contours):
+        P = np.asarray(d_P.a).reshape(B, F, F)
+        return np.array([ko.contour_levels(P[b], tuple(contours)) for b in range(B)]), np.zeros(B, dtype=np.int32)
+
     # ---- thinned chains
     def weights_integral(self):
         w = self.w

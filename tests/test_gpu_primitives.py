@@ -274,3 +274,31 @@ def test_quantiles_with_ties_take_the_radix_fallback(weights):
                 assert np.array_equal(got[ci], want), (weights, col, lo, got[ci], want)
     finally:
         c.close()
+
+
+def test_contour_levels_batch(ctx):
+    """gd_contour_levels against the oracle's restatement of densities.py:19-56 on smooth, flat-topped and tied grids."""
+    from oracle import kde_oracle as ko
+
+    rng = np.random.default_rng(3)
+    F = 96
+    y, x = np.mgrid[0:F, 0:F] / (F - 1.0)
+    grids = [np.exp(-((x - 0.4) ** 2 / 0.02 + (y - 0.6) ** 2 / 0.05)),
+             np.exp(-((x - 0.5) ** 2 + (y - 0.5) ** 2) / 0.5),  # mass on the edges: half-edge weights matter
+             np.minimum(1.0, 3 * np.exp(-((x - 0.5) ** 2 + (y - 0.5) ** 2) / 0.03)),  # flat top: thousands of exact ties at 1
+             rng.random((F, F)) ** 3,
+             np.round(rng.random((F, F)), 2)]  # ~100 distinct values: ties at every level
+    grids[0][grids[0] < 1e-12] = 0.0
+    P = np.array([g / g.max() for g in grids])
+    contours = (0.68, 0.95, 0.99)
+    d = ctx.alloc(P.nbytes)
+    d.from_host(P)
+    got, status = ctx.contour_levels(d, len(P), F, contours)
+    d.free()
+    for b in range(len(P)):
+        want = ko.contour_levels(P[b], contours)
+        if status[b] == 0:
+            assert np.allclose(got[b], want, rtol=1e-9, atol=1e-12), (b, got[b], want)
+        else:
+            assert status[b] == -5 and b in (2, 4)  # tie list overflow: the host path takes that grid
+    assert status[0] == 0 and status[1] == 0 and status[3] == 0

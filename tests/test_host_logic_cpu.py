@@ -36,8 +36,9 @@ def test_host_logic_matches_oracle_1d_and_2d(zoo):
         o = orc.density_1d(j)
         assert np.max(np.abs(d.P - o["P"])) < 1e-9
         assert np.allclose([d.x[0], d.x[-1]], [o["x"][0], o["x"][-1]], rtol=0, atol=0)
-    dens = mc.get2DDensities(fx["pairs"])
+    dens = mc.get2DDensities(fx["pairs"], get_density=False)
     for (a, b), d in zip(fx["pairs"], dens):
+        assert np.allclose(d.contours, ko.contour_levels(d.P, tuple(mc.contours)), rtol=1e-12)
         tr = {}
         o = orc.density_2d(a, b, trace=tr)
         assert d.bandwidth_branch == tr["branch"]
