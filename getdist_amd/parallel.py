@@ -124,3 +124,22 @@ def allgather_chain_stats(local_means, local_cov, local_norm, dist=None, device=
     tot = sum(st[2] for st in stats)
     pooled = sum(st[2] * st[0] for st in stats) / tot
     return stats, pooled
+
+
+def convergence_chain_per_rank(mc, dist=None, device=None, nparam=None):
+    """
+    SURVEY.md 8e, convergence configuration: every rank holds ONE chain in ``mc`` (an MCSamples on that rank's GPU).
+    The local weighted means / covariance / norm come from one gd_cov launch, the n^2+n+1 doubles per rank are
+    all-gathered (RCCL over xGMI with backend "nccl"), and every rank evaluates the Gelman-Rubin eigenvalues
+    (chains.py:1446-1474) and the per-parameter MeanVar statistic (mcsamples.py:964-985) of the pooled set.
+    Returns dict(D, R_minus_1, meanvar, pooled_means, total_norm).
+    """
+    nparam = nparam or mc.paramNames.numNonDerived()
+    means, cov, norm = mc.ctx.cov(list(range(nparam)))
+    stats, pooled = allgather_chain_stats(means, cov, norm, dist, device)
+    D = gelman_rubin_from_chain_stats(stats, pooled)
+    total = sum(st[2] for st in stats)
+    between = sum((st[0] - pooled) ** 2 for st in stats) / (len(stats) - 1) if len(stats) > 1 else np.zeros(nparam)
+    within = sum(np.diag(st[1]) * st[2] for st in stats) / total
+    return dict(D=D, R_minus_1=None if D is None else float(np.max(D)), meanvar=np.sqrt(between / within),
+                pooled_means=pooled, total_norm=total)

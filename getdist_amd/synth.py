@@ -144,6 +144,22 @@ def config_c4(nchains=8, N=5_000_000, n=100):
     return cols.T, weights, ["p%d" % i for i in range(n)], offsets
 
 
+def config_c4_chain(chain, N=5_000_000, n=100):
+    """One chain of the C4 recipe, generated independently of the others (chain-per-GPU runs: each rank makes its own)."""
+    rng0 = np.random.default_rng(np.random.SeedSequence([BASE_SEED, 5]))
+    A = rng0.standard_normal((n, n))
+    L = np.linalg.cholesky(A @ A.T / n + 0.1 * np.eye(n))
+    cols = np.empty((n, N))
+    weights = np.empty(N)
+
+    def fill(a, b, rng):
+        cols[:, a:b] = L @ rng.standard_normal((n, b - a))
+        weights[a:b] = rng.exponential(1.0, b - a)
+
+    _run_chunks(fill, N, stream=600 + chain)
+    return cols.T, weights, ["p%d" % i for i in range(n)]
+
+
 def triangle_pairs(n):
     """Lower-triangle (x, y) index pairs in the order the reference's triangle plot visits them
     (plots.py:2845-2878: for each row i2>i, x=param i, y=param i2)."""

@@ -143,3 +143,50 @@ def test_gelman_rubin_from_chain_stats_matches_golden():
     assert np.allclose(pooled, g["means"], rtol=1e-12)
     D = parallel.gelman_rubin_from_chain_stats(stats, pooled)
     assert gu.relerr(D, g["gr_eigenvalues"]) < 1e-9
+
+
+CHAIN_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    from fake_ctx import FakeContext
+    from getdist_amd import parallel, synth
+    from getdist_amd.mcsamples import MCSamples
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, w, names = synth.config_c4_chain(rank, 6000, 6)
+    mc = MCSamples(samples=s, weights=w, names=names, _context_factory=FakeContext)   # this rank's chain only
+    res = parallel.convergence_chain_per_rank(mc, dist)
+    # single-process comparator: all chains in one sample set, through the list-of-chains API
+    chains = [synth.config_c4_chain(c, 6000, 6) for c in range(world)]
+    allmc = MCSamples(samples=[c[0] for c in chains], weights=[c[1] for c in chains], names=names,
+                      _context_factory=FakeContext)
+    D = allmc.getGelmanRubinEigenvalues()
+    assert np.allclose(res["D"], D, rtol=1e-10), (res["D"], D)
+    assert np.allclose(res["meanvar"], allmc.getMeanVarTest(), rtol=1e-10)
+    assert np.allclose(res["pooled_means"], allmc.means, rtol=1e-12)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_chain_per_rank_convergence_gloo_world2(tmp_path):
+    """one chain per rank, all-gather of the chain moments, Gelman-Rubin + MeanVar on every rank."""
+    script = tmp_path / "chain_worker.py"
+    script.write_text(CHAIN_WORKER % dict(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
