@@ -83,6 +83,8 @@ def gelman_rubin_from_chain_stats(stats, total_means):
     per-chain (means, cov, norm) triples and the pooled weighted means.  Returns None when the mean covariance is
     not positive definite, as the reference does.
     """
+    if len(stats) < 2:
+        return None  # the between-chain variance needs at least two chains
     nparam = len(stats[0][0])
     means = np.asarray(total_means)[:nparam]
     meanscov = np.zeros((nparam, nparam))
