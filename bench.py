@@ -66,6 +66,8 @@ def reset_caches(mc):
     mc._initLimits()
     mc._idx_cols = {}
     mc.density1D = {}
+    if getattr(mc, "_twin", None) is not None:  # the second lane's index columns are per-step work too
+        mc._twin._idx_cols = {}
 
 
 _REPLAY = {}

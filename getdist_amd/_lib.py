@@ -86,6 +86,8 @@ SIGNATURES = {
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_attach_samples": (C.c_int, [_p, _p]),
+    "gd_bind_thread": (C.c_int, [_p]),
     "gd_contour_levels": (C.c_int, [_p, _i32, _i32, _p, _pd, _i32, _pd, _pi32]),
     "gd_set_extra_column": (C.c_int, [_p, _i32, _pd]),
     "gd_aux_weights": (C.c_int, [_p, _pd]),
@@ -354,6 +356,14 @@ class Context:
         self._check(self.lib.gd_upload(self.h, s.ctypes.data, N, n, rs, cs, None if w is None else w.ctypes.data))
         self._keep = None
         self.N, self.n, self.weighted = N, n, w is not None
+
+    def attach(self, owner):
+        """Borrow ``owner``'s resident sample set (same device, no copy): this context becomes a second lane."""
+        self._check(self.lib.gd_attach_samples(self.h, owner.h))
+        self.N, self.n, self.weighted = owner.N, owner.n, owner.weighted
+
+    def bind_thread(self):
+        self._check(self.lib.gd_bind_thread(self.h))
 
     def column_ptr(self, j):
         p = _p()

@@ -72,9 +72,11 @@ void gd_destroy(gd_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gd_fft_cache_destroy(ctx);
     for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
-    if (ctx->cols) (void)hipFree(ctx->cols);
     if (ctx->w_sel) ctx->w = ctx->w_main;
-    if (ctx->w) (void)hipFree(ctx->w);
+    if (!ctx->borrowed) {
+        if (ctx->cols) (void)hipFree(ctx->cols);
+        if (ctx->w) (void)hipFree(ctx->w);
+    }
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -263,9 +265,12 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
     GD_HIP(hipSetDevice(ctx->device));
     GD_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->cols) (void)hipFree(ctx->cols);
     if (ctx->w_sel) ctx->w = ctx->w_main;
-    if (ctx->w) (void)hipFree(ctx->w);
+    if (!ctx->borrowed) {
+        if (ctx->cols) (void)hipFree(ctx->cols);
+        if (ctx->w) (void)hipFree(ctx->w);
+    }
+    ctx->borrowed = false;
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     ctx->wcum = nullptr;
@@ -426,6 +431,39 @@ int gd_aux_weights(gd_ctx* ctx, const double* w) {
     }
     GD_HIP(hipMemcpyAsync(ctx->like_w, w, (size_t)(ctx->N * 8), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_bind_thread(gd_ctx* ctx) {
+    GD_REQUIRE(ctx, "null context");
+    GD_HIP(hipSetDevice(ctx->device));  // the current device is per host thread in HIP
+    return GD_OK;
+}
+
+int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner) {
+    GD_REQUIRE(ctx && owner && ctx != owner, "bad argument");
+    GD_REQUIRE(owner->cols && !owner->borrowed, "the owner has no resident sample set of its own");
+    GD_REQUIRE(ctx->device == owner->device, "contexts must live on the same device");
+    GD_REQUIRE(owner->w_sel == 0, "owner has auxiliary weights selected");
+    GD_HIP(hipSetDevice(ctx->device));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_HIP(hipStreamSynchronize(owner->stream));
+    if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w_sel = 0;
+    if (!ctx->borrowed) {
+        if (ctx->cols) (void)hipFree(ctx->cols);
+        if (ctx->w) (void)hipFree(ctx->w);
+    }
+    if (ctx->like_w) (void)hipFree(ctx->like_w);
+    if (ctx->wcum) (void)hipFree(ctx->wcum);
+    ctx->like_w = ctx->w_main = nullptr;
+    ctx->wcum = nullptr;
+    ctx->cols = owner->cols;
+    ctx->w = owner->w;
+    ctx->w_integral = owner->w_integral;
+    ctx->N = owner->N;
+    ctx->n = owner->n;
+    ctx->ld = owner->ld;
+    ctx->borrowed = true;
     return GD_OK;
 }
 

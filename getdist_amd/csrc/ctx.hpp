@@ -33,6 +33,7 @@ struct gd_ctx {
     double* w_main = nullptr;
     bool w_main_integral = false;
     int w_sel = 0;
+    bool borrowed = false;  // cols / w belong to another context of this process (gd_attach_samples)
     long long* wcum = nullptr;  // inclusive cumulative integer sample weights (thin.hip), built on first use
     int64_t N = 0, n = 0, ld = 0;
     // reusable scratch (grown on demand)

@@ -18,6 +18,7 @@ them.  There is no CPU fallback: without the library or a GPU, construction rais
 
 import logging
 import os
+import threading
 import time
 import warnings
 
@@ -275,18 +276,7 @@ class _Phase:
             self.mc.timings[self.name] = self.mc.timings.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
-_HELPER = None
-
-
-def _helper_thread():
-    """One background thread for C-ABI calls that can run while the main thread does host-only scalar work (ctypes
-    releases the GIL for the duration of a call)."""
-    global _HELPER
-    if _HELPER is None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gdhip-helper")
-    return _HELPER
+_POOL_LOCK = threading.Lock()
 
 
 def _get_h_job(job):
@@ -346,21 +336,24 @@ class _TncPool:
 
     MAX_SHARE = 300  # jobs per worker per round: keeps every blob far below the 64 KiB pipe buffer (no deadlock)
 
-    def submit(self, jobs):
+    def submit(self, jobs, lane=0, nlanes=1):
+        """``lane`` of ``nlanes``: concurrent callers (the two lanes of a triangle) own disjoint worker processes, so
+        their length-prefixed request / reply streams never interleave on a pipe."""
         import pickle
         import struct
 
-        if len(jobs) > self.workers * self.MAX_SHARE:  # very large batches: resolve in synchronous rounds
+        procs = self.procs[lane::nlanes] if nlanes > 1 and len(self.procs) >= nlanes else self.procs
+        if len(jobs) > len(procs) * self.MAX_SHARE:  # very large batches: resolve in synchronous rounds
             out = []
-            step = self.workers * self.MAX_SHARE
+            step = len(procs) * self.MAX_SHARE
             for a in range(0, len(jobs), step):
-                out += self.submit(jobs[a:a + step]).get()
+                out += self.submit(jobs[a:a + step], lane, nlanes).get()
             return _Solved(out)
         n = len(jobs)
-        use = max(1, min(self.workers, (n + 3) // 4))  # at least ~4 jobs per worker: fewer pipe round trips
+        use = max(1, min(len(procs), (n + 3) // 4))  # at least ~4 jobs per worker: fewer pipe round trips
         shares = [list(range(w, n, use)) for w in range(use)]  # interleaved: even cost mix
         active = []
-        for p, idx in zip(self.procs, shares):
+        for p, idx in zip(procs, shares):
             if not idx:
                 continue
             blob = pickle.dumps([(tuple(map(float, jobs[i][0])), float(jobs[i][1]), float(jobs[i][2]), bool(jobs[i][3]))
@@ -403,7 +396,7 @@ class _Deferred:
         return self.future.result().get()
 
 
-def _get_h_many(jobs, workers=None):
+def _get_h_many(jobs, workers=None, lane=0, nlanes=1):
     """
     Start many independent get_h solves; returns an object whose .get() yields the results in order.  TNC costs
     0.5-8 ms per pair on ~9 scalars and a triangle has hundreds of them, so they are farmed to a
@@ -415,11 +408,13 @@ def _get_h_many(jobs, workers=None):
         workers = _tnc_workers()
     if workers <= 1 or len(jobs) < 6:
         return _Solved([_get_h(*j) for j in jobs])
-    if _POOL is None or _POOL.workers != workers:
-        if _POOL is not None:
-            _POOL.close()
-        _POOL = _TncPool(workers)
-    return _POOL.submit(jobs)
+    with _POOL_LOCK:
+        if _POOL is None or _POOL.workers != workers:
+            if _POOL is not None:
+                _POOL.close()
+            _POOL = _TncPool(workers)
+        pool = _POOL
+    return pool.submit(jobs, lane, nlanes)
 
 
 class MCSamples:
@@ -482,13 +477,72 @@ class MCSamples:
         self.density1D = {}
         self._idx_cols = {}
         self.shade_likes_is_mean_loglikes = False  # mcsamples.py:233
+        self._context_factory = _context_factory or Context
+        self._device = device
+        self._lane, self._nlanes = 0, 1
+        self._helper_exec = None
+        self._lane_exec = None
+        self._twin = None
         self.needs_update = True
         self._upload()
         self.updateBaseStatistics()
 
     # ---- state -----------------------------------------------------------------------------------------
+    def _helper(self):
+        """One background thread per lane for C-ABI calls that can run while this thread does host-only scalar work
+        (ctypes releases the GIL for the duration of a call).  The thread binds the context's device first."""
+        if self._helper_exec is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._helper_exec = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gdhip-helper",
+                                                   initializer=self.ctx.bind_thread)
+        return self._helper_exec
+
+    def _second_lane(self):
+        """
+        A shallow twin of this object on a second context (= second stream) that borrows the resident sample set:
+        independent pairs dealt to the two lanes overlap one lane's host-side scalar work, launch gaps and result
+        copies with the other lane's kernels.  Parameter state is shared (read-only while densities are made).
+        """
+        own = ("ctx", "_idx_cols", "density1D", "timings", "_helper_exec", "_lane_exec", "_twin", "_lane")
+        if self._twin is None:
+            import copy
+
+            twin = copy.copy(self)
+            twin.ctx = self._context_factory(self._device)
+            twin.ctx.attach(self.ctx)
+            twin._idx_cols, twin.density1D, twin.timings = {}, {}, {}
+            twin._helper_exec = twin._lane_exec = twin._twin = None
+            twin._lane = 1
+            self._twin = twin
+        self._nlanes = 2
+        # settings and statistics may have changed since the twin was made: everything but the lane's own state follows
+        self._twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in own})
+        return self._twin
+
+    def _lane_thread(self, twin):
+        """The thread that drives the second lane (its own helper thread stays free for the lane's inner overlap)."""
+        if self._lane_exec is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._lane_exec = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gdhip-lane",
+                                                 initializer=twin.ctx.bind_thread)
+        return self._lane_exec
+
+    def _drop_second_lane(self):
+        if getattr(self, "_lane_exec", None) is not None:
+            self._lane_exec.shutdown(wait=True)
+        self._lane_exec = None
+        if self._twin is not None:
+            if self._twin._helper_exec is not None:
+                self._twin._helper_exec.shutdown(wait=True)
+            self._twin.ctx.close()
+            self._twin = None
+        self._nlanes = 1
+
     def _upload(self):
         """(Re)build the device mirror of samples/weights (chains.py:276-323 funnel)."""
+        self._drop_second_lane()
         w = self.weights
         if w is not None and self.min_weight_ratio is not None and self.min_weight_ratio >= 0:
             mx, mn = np.max(w), np.min(w)  # chains.py:1017-1027
@@ -1743,7 +1797,7 @@ class MCSamples:
             if pooled:
                 # the pipe writes to the workers go through the helper thread: the workers start at once and the
                 # closed-form solves below run meanwhile
-                pendings.append((pooled, _Deferred(_helper_thread().submit(_get_h_many, [job for job, _ in pooled]))))
+                pendings.append((pooled, _Deferred(self._helper().submit(_get_h_many, [job for job, _ in pooled], None, self._lane, self._nlanes))))
             for job, meta in zip(jobs, job_meta):
                 if not job[3]:
                     results[meta[1]] = to_param_units(meta, _get_h(*job))
@@ -1877,6 +1931,10 @@ class MCSamples:
         Each result carries ``bandwidth`` = (hx, hy, corr) in parameter units, ``bandwidth_branch`` and
         ``kopt`` (the device optimiser's {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status}).
         ``_bandwidths`` (tests only) injects the (hx, hy, corr) triples instead of optimising.
+
+        Large batches are dealt to two lanes (two contexts = two streams over the same resident samples, the second
+        driven from a helper thread): the pairs are independent, so one lane's host-side scalar work, launch gaps and
+        result copies hide behind the other lane's kernels.  GETDIST_AMD_LANES=1 turns this off.
         """
         if self.needs_update:
             self.updateBaseStatistics()
@@ -1884,6 +1942,41 @@ class MCSamples:
             if k not in ("fine_bins_2D", "boundary_correction_order", "mult_bias_correction_order", "smooth_scale_2D"):
                 raise SettingError("unknown 2D density argument %s" % k)
         pairs = [(self._col(a), self._col(b)) for a, b in pairs]
+        lanes = int(os.environ.get("GETDIST_AMD_LANES", "2"))
+        if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
+                or self.use_effective_samples_2D):
+            return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes, **kwargs)
+        # everything per-parameter is settled here, on this lane, before the pairs are dealt
+        used = list(dict.fromkeys([j for p in pairs for j in p]))
+        self._init_params(used)
+        if float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D)) < 0:
+            self._neff_batch(used)
+        self.getCorrelationMatrix()
+        names = self.paramNames.names
+        # deal by cost class (grid up-scaling follows the correlation; bounded pairs carry the boundary correction)
+        corr = np.abs(np.asarray(self.correlationMatrix)[[p[1] for p in pairs], [p[0] for p in pairs]])
+        key = [(round(float(c), 1) if c > 0.8 else 0.0, bool(names[a].has_limits or names[b].has_limits))
+               for c, (a, b) in zip(corr, pairs)]
+        order = sorted(range(len(pairs)), key=lambda q: (key[q], q))
+        mine = sorted(order[0::2])
+        theirs = sorted(order[1::2])
+        twin = self._second_lane()
+        pending = self._lane_thread(twin).submit(twin._get2DDensities_lane, [pairs[q] for q in theirs], num_plot_contours,
+                                                 get_density, None, False, **kwargs)
+        try:
+            first = self._get2DDensities_lane([pairs[q] for q in mine], num_plot_contours, get_density, None, False, **kwargs)
+        finally:
+            second = pending.result()
+        out = [None] * len(pairs)
+        for q, d in zip(mine, first):
+            out[q] = d
+        for q, d in zip(theirs, second):
+            out[q] = d
+        return out
+
+    def _get2DDensities_lane(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, meanlikes=False,
+                             **kwargs):
+        """One lane of get2DDensities: the whole batched pipeline on this object's context."""
         base_F = kwargs.get("fine_bins_2D", self.fine_bins_2D)
         bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
         mbc = kwargs.get("mult_bias_correction_order", self.mult_bias_correction_order)
@@ -1952,7 +2045,7 @@ class MCSamples:
             # the branch selection is host-only scalar work once every N_eff is known: run it here while a helper thread
             # sits in the (GIL-free) binning calls
             self._neff_batch(used)
-            pending = _helper_thread().submit(binning)
+            pending = self._helper().submit(binning)
             try:
                 plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
                                             [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],

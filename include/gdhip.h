@@ -187,6 +187,17 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const do
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                  void* d_P_out, int32_t* status_out);
 
+/* ---------------------------------------------------------------- second lane -----------------
+ * A context is one stream; a second context on the same device gives a second, concurrent lane of work over the
+ * SAME resident sample set (independent pairs of a triangle are dealt to two lanes so that one lane's host-side
+ * scalar work and result copies hide behind the other lane's kernels).
+ * gd_attach_samples: ctx borrows owner's device columns / weights (no copy); owner must outlive ctx or be
+ *   re-uploaded only after ctx is destroyed or re-attached.  The extra columns (gd_set_extra_column) are shared too.
+ * gd_bind_thread: make ctx's device current for the calling host thread (HIP's current device is per thread);
+ *   call once from every additional thread that uses ctx. */
+int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner);
+int gd_bind_thread(gd_ctx* ctx);
+
 /* ---------------------------------------------------------------- contour levels ---------------
  * gd_contour_levels: densities.py:19-56 getContourLevels(P, contours, half_edge=True) for B grids
  *   (device, B x F x F): out[b*nc + c] = the density level enclosing contours[c] of the half-edge-weighted

@@ -95,6 +95,14 @@ class FakeContext:
             return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
 
+    # ---- second lane
+    def attach(self, owner):
+        self.s, self.w, self.N, self.n, self.weighted = owner.s, owner.w, owner.N, owner.n, owner.weighted
+        self._like_w, self._w_sel = None, 0
+
+    def bind_thread(self):
+        pass
+
     # ---- contour levels
     def contour_levels(self, d_P, B, F, contours):
         P = np.asarray(d_P.a).reshape(B, F, F)

@@ -195,6 +195,31 @@ def test_host_logic_raftery_lewis():
     raftery_lewis_check(FakeContext)
 
 
+def test_two_lanes_equal_one_lane(zoo, monkeypatch):
+    """A batch of >= 64 pairs is dealt to two lanes (two contexts, second one driven from a helper thread): same grids,
+    same order, same bandwidths as the single-lane run; settings changed afterwards reach the second lane too."""
+    fx = zoo["block50"]
+    pairs = [(i, j) for i in range(13) for j in range(i + 1, 13)] + [(20, 21), (38, 39)]
+    assert len(pairs) >= 64
+    mc = make(fx)
+    two = mc.get2DDensities(pairs)
+    assert mc._twin is not None and mc._nlanes == 2
+    monkeypatch.setenv("GETDIST_AMD_LANES", "1")
+    ref = make(fx)
+    one = ref.get2DDensities(pairs)
+    assert ref._twin is None
+    for a, b in zip(two, one):
+        assert np.array_equal(a.P, b.P) and np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
+        assert a.bandwidth_branch == b.bandwidth_branch and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
+    monkeypatch.delenv("GETDIST_AMD_LANES")
+    mc.updateSettings({"fine_bins_2D": 128})
+    mc.updateBaseStatistics()
+    again = mc.get2DDensities(pairs)
+    assert all(d.P.shape[0] in (128, 192, 384, 576, 768, 960) for d in again) and again[0].P.shape == (128, 128)
+    mc.setSamples(np.asarray(fx["samples"]) * 1.0)  # re-upload drops the second lane
+    assert mc._twin is None
+
+
 def test_host_logic_branches_and_grid_classes(zoo):
     """block50: all three bandwidth branches, four grid sizes, bounded and unbounded pairs through the batched path."""
     fx = zoo["block50"]
