@@ -1932,9 +1932,11 @@ class MCSamples:
         ``kopt`` (the device optimiser's {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status}).
         ``_bandwidths`` (tests only) injects the (hx, hy, corr) triples instead of optimising.
 
-        Large batches are dealt to two lanes (two contexts = two streams over the same resident samples, the second
-        driven from a helper thread): the pairs are independent, so one lane's host-side scalar work, launch gaps and
-        result copies hide behind the other lane's kernels.  GETDIST_AMD_LANES=1 turns this off.
+        With GETDIST_AMD_LANES=2 large batches are dealt to two lanes (two contexts = two streams over the same resident
+        samples, the second driven from its own thread).  Off by default: measured on MI355X the two in-process lanes
+        are slower than one (96 vs 87 ms per C3 triangle) although two PROCESSES sharing the GPU reach 61 ms -- the HIP
+        runtime serialises the API calls of one process, so hiding the host gaps needs fewer, asynchronous entry points
+        rather than threads.
         """
         if self.needs_update:
             self.updateBaseStatistics()
@@ -1942,7 +1944,7 @@ class MCSamples:
             if k not in ("fine_bins_2D", "boundary_correction_order", "mult_bias_correction_order", "smooth_scale_2D"):
                 raise SettingError("unknown 2D density argument %s" % k)
         pairs = [(self._col(a), self._col(b)) for a, b in pairs]
-        lanes = int(os.environ.get("GETDIST_AMD_LANES", "2"))
+        lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
                 or self.use_effective_samples_2D):
             return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes, **kwargs)

@@ -201,6 +201,7 @@ def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     fx = zoo["block50"]
     pairs = [(i, j) for i in range(13) for j in range(i + 1, 13)] + [(20, 21), (38, 39)]
     assert len(pairs) >= 64
+    monkeypatch.setenv("GETDIST_AMD_LANES", "2")
     mc = make(fx)
     two = mc.get2DDensities(pairs)
     assert mc._twin is not None and mc._nlanes == 2
@@ -211,7 +212,7 @@ def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     for a, b in zip(two, one):
         assert np.array_equal(a.P, b.P) and np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
         assert a.bandwidth_branch == b.bandwidth_branch and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
-    monkeypatch.delenv("GETDIST_AMD_LANES")
+    monkeypatch.setenv("GETDIST_AMD_LANES", "2")
     mc.updateSettings({"fine_bins_2D": 128})
     mc.updateBaseStatistics()
     again = mc.get2DDensities(pairs)
