@@ -195,6 +195,30 @@ def test_host_logic_raftery_lewis():
     raftery_lewis_check(FakeContext)
 
 
+def test_prefill_plot_caches(zoo):
+    """plots.MCSampleAnalysis cache layout (plots.py:594-645): keys, contour counts, one batched call per dimension."""
+    from getdist_amd.plotting import prefill_plot_caches
+
+    class Analysis:  # the two dicts of getdist.plots.MCSampleAnalysis
+        def __init__(self):
+            self.densities_1D, self.densities_2D = {}, {}
+
+    fx = zoo["c1_bounded"]
+    mc = make(fx)
+    an = Analysis()
+    n1, n2 = prefill_plot_caches(an, "chain", mc, params=fx["names"][:3], conts=2)
+    assert (n1, n2) == (3, 3)
+    assert set(an.densities_1D["chain"]) == {(nm, False) for nm in fx["names"][:3]}
+    a, b, c = fx["names"][:3]
+    assert set(an.densities_2D["chain"]) == {(a, b, False, 2), (a, c, False, 2), (b, c, False, 2)}
+    d = an.densities_2D["chain"][(a, c, False, 2)]
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    o = orc.density_2d(0, 2)
+    assert np.max(np.abs(d.P - o["P"])) < 1e-9 and len(d.contours) == 2
+    assert np.allclose(d.contours, ko.contour_levels(o["P"], (0.68, 0.95)), rtol=1e-9)
+    assert np.max(np.abs(an.densities_1D["chain"][(b, False)].P - orc.density_1d(1)["P"])) < 1e-9
+
+
 def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     """A batch of >= 64 pairs is dealt to two lanes (two contexts, second one driven from a helper thread): same grids,
     same order, same bandwidths as the single-lane run; settings changed afterwards reach the second lane too."""
