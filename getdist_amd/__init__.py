@@ -16,6 +16,7 @@ _EXPORTS = {
     "ParamError": "mcsamples", "WeightedSampleError": "mcsamples", "MargeStats": "mcsamples", "ParamLimit": "mcsamples",
     "covToCorr": "mcsamples", "Density1D": "densities", "Density2D": "densities", "GridDensity": "densities",
     "DensitiesError": "densities", "getContourLevels": "densities", "nearestFFTnumber": "convolve",
+    "loadMCSamples": "chainfiles", "chainFiles": "chainfiles", "prefill_plot_caches": "plotting",
 }
 
 

@@ -240,6 +240,40 @@ def compare_raftery_lewis():
     return ok
 
 
+def compare_chain_loader():
+    """getdist_amd.chainfiles.loadMCSamples against the reference's loadMCSamples on the same text chains."""
+    import tempfile
+
+    from getdist import loadMCSamples as ref_load
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_ctx import FakeContext
+    from getdist_amd import chainfiles
+
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=3, N=900, n=4)
+    ok = True
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "run")
+        for c, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
+            block = np.column_stack([weights[a:b], loglikes[a:b], samples[a:b, :2], np.full(b - a, 0.7), samples[a:b, 2:]])
+            np.savetxt("%s_%d.txt" % (root, c + 1), block, fmt="%.16e")
+        with open(root + ".paramnames", "w") as f:
+            f.write("m0  \\mu_0\nm1\nfixedpar  f\nm2*  derived_2\nm3*\n")
+        with open(root + ".ranges", "w") as f:
+            f.write("m0  N  N\nm1  -5.5  N\nm3  N  9\nfixedpar 0.7 0.7\n")
+        for ign in (0, 0.25, 10):
+            ref = ref_load(root, settings={"ignore_rows": ign}, no_cache=True)
+            mine = chainfiles.loadMCSamples(root, settings={"ignore_rows": ign}, _context_factory=FakeContext)
+            ok &= ref.paramNames.list() == mine.paramNames.list()
+            ok &= [p.isDerived for p in ref.paramNames.names] == [p.isDerived for p in mine.paramNames.names]
+            ok &= np.array_equal(ref.samples, mine.samples) and np.array_equal(ref.weights, mine.weights)
+            ok &= np.array_equal(ref.loglikes, mine.loglikes) and list(ref.chain_offsets) == list(mine.chain_offsets)
+            for nm in mine.paramNames.list():
+                ok &= ref.ranges.getLower(nm) == mine.ranges.getLower(nm) and ref.ranges.getUpper(nm) == mine.ranges.getUpper(nm)
+    print(("ok  " if ok else "FAIL") + " chain-file loader (text chains, paramnames, ranges, burn-in, fixed parameters)")
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -256,6 +290,7 @@ def main():
     ok &= compare_meanlikes()
     ok &= compare_nd_ranges()
     ok &= compare_raftery_lewis()
+    ok &= compare_chain_loader()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")

@@ -329,3 +329,31 @@ def test_two_rank_step_equals_single_process(tmp_path):
             seen.append(int(i))
             assert np.array_equal(P, ref[int(i)].P), pairs[int(i)]  # same inputs, same solver path => identical
     assert sorted(seen) == list(range(len(pairs)))
+
+
+def test_chain_file_loader(tmp_path, zoo):
+    """GetDist text chains + .paramnames + .ranges -> MCSamples: burn-in, fixed-parameter deletion, derived flags."""
+    from getdist_amd import chainfiles
+    from oracle.fixtures import mcmc_chains_fixture
+
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=3, N=900, n=4)
+    root = str(tmp_path / "run")
+    for c, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
+        block = np.column_stack([weights[a:b], loglikes[a:b], samples[a:b, :2], np.full(b - a, 0.7), samples[a:b, 2:]])
+        np.savetxt("%s_%d.txt" % (root, c + 1), block, fmt="%.16e")
+    (tmp_path / "run.paramnames").write_text("m0  \\mu_0\nm1\nfixedpar  f\nm2*  derived_2\nm3*\n")
+    (tmp_path / "run.ranges").write_text("m0  N  N\nm1  -5.5  N\nm3  N  9\nfixedpar 0.7 0.7\n")
+    (tmp_path / "other_1.txt").write_text("1 0 0\n")
+    assert [os.path.basename(f) for f in chainfiles.chainFiles(root)] == ["run_1.txt", "run_2.txt", "run_3.txt"]
+    mc = chainfiles.loadMCSamples(root, settings={"ignore_rows": 0.25}, _context_factory=FakeContext)
+    assert mc.paramNames.list() == ["m0", "m1", "m2", "m3"]  # the fixed column is gone
+    assert [p.isDerived for p in mc.paramNames.names] == [False, False, True, True]
+    assert mc.paramNames.numNonDerived() == 2 and mc.paramNames.names[0].label == "\\mu_0"
+    keep = np.concatenate([np.arange(a + int(round((b - a) * 0.25)), b) for a, b in zip(offsets[:-1], offsets[1:])])
+    assert mc.numrows == len(keep) and len(mc.chain_offsets) == 4
+    assert np.allclose(mc.samples, samples[keep], rtol=1e-15) and np.allclose(mc.weights, weights[keep])
+    assert np.allclose(mc.loglikes, loglikes[keep])
+    assert mc.ranges.getLower("m1") == -5.5 and mc.ranges.getUpper("m3") == 9.0 and mc.ranges.getLower("m0") is None
+    assert np.isclose(mc.getGelmanRubin(), mc.getGelmanRubin()) and mc.get1DDensity("m1").P.shape == (1024,)
+    full = chainfiles.loadMCSamples(root, ignore_rows=10, _context_factory=FakeContext)
+    assert full.numrows == len(weights) - 30
