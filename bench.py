@@ -82,7 +82,9 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     if emulate:
         world = emulate
     my_params = parallel.partition_round_robin(list(range(mc.n)), world, rank)
-    mc.prepareParams(my_params)
+    # single rank: N_eff is left to get2DDensities, which overlaps it with the 2D binning on a second stream; with
+    # several ranks it must be known before the parameter state is exchanged
+    mc.prepareParams(my_params, neff=(world > 1))
     if emulate:
         others = [j for j in range(mc.n) if j not in my_params]
         parallel.unpack_param_state(mc, _REPLAY["rows"][others])  # what the all-gather would deliver

@@ -2031,24 +2031,35 @@ class MCSamples:
             classes.setdefault(e["F"], []).append(k)
         hists, likehists = {}, {}
 
-        def binning():
+        def binning(owner=self):
+            """prebin + batched 2D histograms on ``owner``'s context (this object, or its second-lane twin)."""
             for F, members in classes.items():
                 with _Phase(self, "2d.prebin"):
-                    ix = [self._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
-                    iy = [self._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
+                    ix = [owner._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
+                    iy = [owner._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
                 with _Phase(self, "2d.hist"):
-                    hists[F] = (ctx.hist2d_prebinned(ix, iy, F), members)
+                    hists[F] = (owner.ctx.hist2d_prebinned(ix, iy, F), members)
                     if meanlikes:
                         likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
 
         auto_bw = smooth_scale_2D < 0 and _bandwidths is None
         plan = None
         if auto_bw and not self._timing and not self.use_effective_samples_2D:
-            # the branch selection is host-only scalar work once every N_eff is known: run it here while a helper thread
-            # sits in the (GIL-free) binning calls
-            self._neff_batch(used)
-            pending = self._helper().submit(binning)
+            # the branch selection is host-only scalar work once every N_eff is known: it runs here while another
+            # thread sits in the (GIL-free) binning calls.  When the effective sample numbers are still missing, the
+            # binning goes to the second context (own stream and scratch over the same resident samples) so that the
+            # N_eff kernels -- exp-bound -- and the LDS-bound histograms share the GPU.
+            need_neff = any(names[j].N_eff_kde is None for j in used)
+            if (need_neff and self._lane == 0 and not meanlikes and len(pairs) >= 64
+                    and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
+                twin = self._second_lane()
+                self._nlanes = 1  # only the binning is shared out; the TNC pool stays whole
+                pending = self._lane_thread(twin).submit(binning, twin)
+            else:
+                self._neff_batch(used)
+                pending = self._helper().submit(binning)
             try:
+                self._neff_batch(used)
                 plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
                                             [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
                                             base_F)

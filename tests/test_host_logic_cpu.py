@@ -230,9 +230,15 @@ def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     two = mc.get2DDensities(pairs)
     assert mc._twin is not None and mc._nlanes == 2
     monkeypatch.setenv("GETDIST_AMD_LANES", "1")
+    monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "0")
     ref = make(fx)
     one = ref.get2DDensities(pairs)
     assert ref._twin is None
+    monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "1")  # default: only the binning runs on the second context
+    ovl = make(fx)
+    for a, b in zip(ovl.get2DDensities(pairs), one):
+        assert np.array_equal(a.P, b.P) and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
+    assert ovl._twin is not None and ovl._nlanes == 1
     for a, b in zip(two, one):
         assert np.array_equal(a.P, b.P) and np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
         assert a.bandwidth_branch == b.bandwidth_branch and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
