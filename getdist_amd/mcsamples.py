@@ -1962,13 +1962,23 @@ class MCSamples:
         order = sorted(range(len(pairs)), key=lambda q: (key[q], q))
         mine = sorted(order[0::2])
         theirs = sorted(order[1::2])
+        import sys
+
         twin = self._second_lane()
-        pending = self._lane_thread(twin).submit(twin._get2DDensities_lane, [pairs[q] for q in theirs], num_plot_contours,
-                                                 get_density, None, False, **kwargs)
+        # a thread returning from a C call waits for the GIL up to the interpreter's switch interval (5 ms by default)
+        # while the other lane runs Python scalars: far too coarse for lanes whose C calls last 0.1-5 ms
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get("GETDIST_AMD_SWITCH_INTERVAL", 1e-4)))
         try:
-            first = self._get2DDensities_lane([pairs[q] for q in mine], num_plot_contours, get_density, None, False, **kwargs)
+            pending = self._lane_thread(twin).submit(twin._get2DDensities_lane, [pairs[q] for q in theirs],
+                                                     num_plot_contours, get_density, None, False, **kwargs)
+            try:
+                first = self._get2DDensities_lane([pairs[q] for q in mine], num_plot_contours, get_density, None, False,
+                                                  **kwargs)
+            finally:
+                second = pending.result()
         finally:
-            second = pending.result()
+            sys.setswitchinterval(old_interval)
         out = [None] * len(pairs)
         for q, d in zip(mine, first):
             out[q] = d
