@@ -169,3 +169,25 @@ def test_full_size_grids_match_the_oracle(big):
         assert d.bandwidth_branch == tr["branch"]
         assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6, atol=1e-12)
         assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[cols[a]], names[cols[b]])
+
+
+def test_thinning_at_scale_matches_the_oracle():
+    """gd_thin_rows with more scan tiles than one pass of the tile-sum scan holds (carry path), on sub-ranges, both
+    branches of chains.py:878-916, against the oracle's cumsum restatement."""
+    from getdist_amd.mcsamples import MCSamples
+    from oracle import convergence_oracle as co
+
+    rng = np.random.default_rng(11)
+    N = 2_600_000  # 1270 tiles of 2048 rows
+    w = rng.geometric(0.3, N).astype(np.float64)
+    x = rng.standard_normal((N, 1))
+    offs = [0, 900_001, N]
+    mc = MCSamples(samples=[x[a:b] for a, b in zip(offs[:-1], offs[1:])], weights=[w[a:b] for a, b in zip(offs[:-1], offs[1:])],
+                   names=["x"])
+    for factor in (3, int(w.max()), int(w.max()) + 5):
+        for lo, hi in ((0, N), (offs[1], N), (0, offs[1])):
+            buf, K = mc._thin_rows(factor, lo, hi)
+            got = buf.to_host((K,), dtype=np.int32).astype(np.int64)
+            buf.free()
+            want = co.thin_indices(factor, w[lo:hi]) + lo
+            assert K == len(want) and np.array_equal(got, want), (factor, lo, hi)
