@@ -1798,9 +1798,18 @@ class MCSamples:
                 # the pipe writes to the workers go through the helper thread: the workers start at once and the
                 # closed-form solves below run meanwhile
                 pendings.append((pooled, _Deferred(self._helper().submit(_get_h_many, [job for job, _ in pooled], None, self._lane, self._nlanes))))
-            for job, meta in zip(jobs, job_meta):
-                if not job[3]:
-                    results[meta[1]] = to_param_units(meta, _get_h(*job))
+            closed = [(job, meta) for job, meta in zip(jobs, job_meta) if not job[3]]
+            if closed:
+                # get_h without the correlation search is the closed form of kde_bandwidth.py:245-252: all pairs at once
+                psi = np.array([job[0][:3] for job, _ in closed], dtype=np.float64)
+                neff_v = np.array([job[1] for job, _ in closed], dtype=np.float64)
+                p_02, p_20, p_11 = psi[:, 0], psi[:, 1], psi[:, 2]
+                cross = p_11 + np.sqrt(p_20 * p_02)
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * neff_v * p_20 ** (3.0 / 4) * cross)) ** (1.0 / 6)
+                    h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * neff_v * p_02 ** (3.0 / 4) * cross)) ** (1.0 / 6)
+                for (_, meta), a, b in zip(closed, h_x, h_y):
+                    results[meta[1]] = to_param_units(meta, (a, b, 0))
             del jobs[:], job_meta[:]
 
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
@@ -1843,7 +1852,7 @@ class MCSamples:
             out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb)
             for row, (br, k, r1, r2) in enumerate(rows):
                 e = plan[k]
-                e["kopt"] = out[row].copy()
+                e["kopt"] = out[row]
                 if out[row, 7] != 0:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
                     continue
