@@ -15,6 +15,13 @@
 
 // ---- small fp64 GEMM: C[i][j] = sum_p A[i][p] B[j][p]  (NT), M=N=K=F, batched ---------------------------------
 // EPI 0: plain store.  EPI 1: v = acc / sums[b]; out[j][i] = v*v (transposed, squared).
+// 64 x 64 output tile per block, 32 x 32 per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles; K is staged through LDS in
+// chunks of 16 (k-major rows padded to 65 doubles: the 16 lanes of a k-group read consecutive doubles).  fp64 MFMA
+// runs at the fp64 vector rate, but one instruction carries 1024 FMAs per wave against two LDS reads per lane, where
+// the scalar-FMA tile needed eight -- the old kernel was LDS-bound at a quarter of the fp64 peak.
+// Operand / result lanes (CDNA4): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[row = (lane >> 4) + 4 r][col = lane & 15] for result register r.
+typedef double gd_f64x4 __attribute__((ext_vector_type(4)));
 template <int EPI>
 __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, int64_t strideA,
                                                  const double* __restrict__ Bm, int64_t strideB, int F,
@@ -26,12 +33,14 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, i
     const double* Ab = A + (int64_t)b * strideA;
     const double* Bb = Bm + (int64_t)b * strideB;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    double acc[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int l15 = lane & 15, lk = lane >> 4;
+    gd_f64x4 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+        for (int v = 0; v < 2; ++v) acc[u][v] = (gd_f64x4){0.0, 0.0, 0.0, 0.0};
     for (int p0 = 0; p0 < F; p0 += 16) {
         __syncthreads();
         for (int e = threadIdx.x; e < 64 * 16; e += 256) {
@@ -42,33 +51,34 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, i
         }
         __syncthreads();
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            double a[4], bb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = As[pp][ty * 4 + u];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) bb[v] = Bs[pp][tx * 4 + v];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], bb[v], acc[u][v]);
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = kk * 4 + lk;
+            const double a0 = As[k][wi + l15], a1 = As[k][wi + 16 + l15];
+            const double b0 = Bs[k][wj + l15], b1 = Bs[k][wj + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
     double* Cb = Cm + (int64_t)b * strideC;
+    const double inv = (EPI == 1) ? sums[b] : 1.0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
-            if (i < F && j < F) {
-                if (EPI == 0) {
-                    Cb[(int64_t)i * F + j] = acc[u][v];
-                } else {
-                    const double val = acc[u][v] / sums[b];
-                    Cb[(int64_t)j * F + i] = val * val;
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi + u * 16 + lk + 4 * r, j = j0 + wj + v * 16 + l15;
+                if (i < F && j < F) {
+                    if (EPI == 0) {
+                        Cb[(int64_t)i * F + j] = acc[u][v][r];
+                    } else {
+                        const double val = acc[u][v][r] / inv;
+                        Cb[(int64_t)j * F + i] = val * val;
+                    }
                 }
             }
-        }
 }
 
 // DCT-II matrix: D[k][n] = 2 cos(pi k (2n+1) / (2F))   (scipy.fftpack.dct type 2, unnormalised)
