@@ -16,7 +16,7 @@
 // ---- small fp64 GEMM: C[i][j] = sum_p A[i][p] B[j][p]  (NT), M=N=K=F, batched ---------------------------------
 // EPI 0: plain store.  EPI 1: v = acc / sums[b]; out[j][i] = v*v (transposed, squared).
 // 64 x 64 output tile per block, 32 x 32 per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles; K is staged through LDS in
-// chunks of 16 (k-major rows padded to 65 doubles: the 16 lanes of a k-group read consecutive doubles).  fp64 MFMA
+// chunks of 32, register-prefetched one step ahead (k-major rows padded to 65 doubles: the 16 lanes of a k-group read consecutive doubles).  fp64 MFMA
 // runs at the fp64 vector rate, but one instruction carries 1024 FMAs per wave against two LDS reads per lane, where
 // the scalar-FMA tile needed eight -- the old kernel was LDS-bound at a quarter of the fp64 peak.
 // Operand / result lanes (CDNA4): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
@@ -27,8 +27,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, i
                                                  const double* __restrict__ Bm, int64_t strideB, int F,
                                                  double* __restrict__ Cm, int64_t strideC,
                                                  const double* __restrict__ sums) {
-    __shared__ double As[16][65];
-    __shared__ double Bs[16][65];
+    constexpr int KC = 32;  // K rows staged per step
+    __shared__ double As[KC][65];
+    __shared__ double Bs[KC][65];
     const int b = blockIdx.z;
     const double* Ab = A + (int64_t)b * strideA;
     const double* Bb = Bm + (int64_t)b * strideB;
@@ -41,17 +42,33 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, i
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) acc[u][v] = (gd_f64x4){0.0, 0.0, 0.0, 0.0};
-    for (int p0 = 0; p0 < F; p0 += 16) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-            const int pp = e & 15, ii = e >> 4;
+    // each thread stages 8 elements of each operand per step: element q -> (row ii = e >> 5, k = e & 31), e = tid + 256 q;
+    // the next step's global loads are issued before this step's MFMAs so that they overlap
+    constexpr int NQ = 64 * KC / 256;
+    double ra[NQ], rb[NQ];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int pp = e & (KC - 1), ii = e / KC;
             const int p = p0 + pp;
-            As[pp][ii] = (i0 + ii < F && p < F) ? Ab[(int64_t)(i0 + ii) * F + p] : 0.0;
-            Bs[pp][ii] = (j0 + ii < F && p < F) ? Bb[(int64_t)(j0 + ii) * F + p] : 0.0;
+            ra[q] = (i0 + ii < F && p < F) ? Ab[(int64_t)(i0 + ii) * F + p] : 0.0;
+            rb[q] = (j0 + ii < F && p < F) ? Bb[(int64_t)(j0 + ii) * F + p] : 0.0;
         }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < F; p0 += KC) {
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            As[e & (KC - 1)][e / KC] = ra[q];
+            Bs[e & (KC - 1)][e / KC] = rb[q];
+        }
+        __syncthreads();
+        if (p0 + KC < F) fetch(p0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; ++kk) {
             const int k = kk * 4 + lk;
             const double a0 = As[k][wi + l15], a1 = As[k][wi + 16 + l15];
             const double b0 = Bs[k][wj + l15], b1 = Bs[k][wj + 16 + l15];
