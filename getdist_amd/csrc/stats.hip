@@ -181,7 +181,8 @@ __global__ void k_col_fin2(const double* __restrict__ part, int nblk, const doub
 }
 
 // ---- weighted covariance (two-pass) -----------------------------------------------------------------------
-// One block = one 64x64 tile of column pairs over one chunk of rows; 256 threads, 4x4 outputs per thread.
+// One block = one 64x64 tile of column pairs over one chunk of rows; 256 threads = 4 waves of 32x32 outputs on the
+// fp64 matrix cores.
 #define CT 64
 #define CRB 64
 template <bool HAS_W>
@@ -195,12 +196,17 @@ __global__ void __launch_bounds__(256) k_cov_tile(const double* __restrict__ col
     const int2 tl = tiles[blockIdx.y];
     const int ci0 = tl.x * CT, cj0 = tl.y * CT;
     const bool diag = (tl.x == tl.y);
-    const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
-    double acc[4][4];
+    // 32 x 32 outputs per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles (A[i = lane&15][k = lane>>4] = sI[k][i],
+    // B[k][j = lane&15] = sJ[k][j], D[row = (lane>>4) + 4 r][col = lane&15]): two LDS reads per lane feed 1024 FMAs
+    // per wave and instruction, where the scalar-FMA register tile needed eight reads for sixteen
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32, l15 = lane & 15, lk = lane >> 4;
+    f64x4 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+        for (int v = 0; v < 2; ++v) acc[u][v] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
     int64_t c_hi = c_lo + rows_per_chunk;
     if (c_hi > hi) c_hi = hi;
@@ -230,23 +236,23 @@ __global__ void __launch_bounds__(256) k_cov_tile(const double* __restrict__ col
         }
         __syncthreads();
 #pragma unroll 4
-        for (int r = 0; r < CRB; ++r) {
-            double a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = sI[r][ti * 4 + u];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) b[v] = sJ[r][tj * 4 + v];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+        for (int kk = 0; kk < CRB / 4; ++kk) {
+            const int k = kk * 4 + lk;
+            const double a0 = sI[k][wi + l15], a1 = sI[k][wi + 16 + l15];
+            const double b0 = sJ[k][wj + l15], b1 = sJ[k][wj + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
     double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (CT * CT);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) p[(ti * 4 + u) * CT + tj * 4 + v] = acc[u][v];
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(wi + u * 16 + lk + 4 * r) * CT + wj + v * 16 + l15] = acc[u][v][r];
 }
 
 // cov[i][j] = sum over chunks / norm, mirrored
