@@ -96,6 +96,8 @@ SIGNATURES = {
     "gd_thin_rows": (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _i64, C.POINTER(C.c_int64)]),
     "gd_binary_transitions": (C.c_int, [_p, _pi32, _i32, _p, _i64, _pd, _i32, C.POINTER(C.c_int64)]),
     "gd_thinned_lag_sums": (C.c_int, [_p, _pi32, _i32, _pd, _p, _i64, _i32, _pd]),
+    "gd_density2d_masked": (C.c_int, [_p, _i32, _p, C.c_double, C.c_double, C.c_double, _i32, _i32, _i32, _i32, _pd, _pd,
+                                      C.POINTER(C.c_ubyte), _p, _pi32]),
     "gd_like_weights": (C.c_int, [_p, _pd, _i32, C.c_double, _pd]),
     "gd_select_weights": (C.c_int, [_p, _i32]),
     "gd_likes1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _pi32, _pi32, _i32, _pd, _pi32]),
@@ -482,6 +484,20 @@ class Context:
         self._check(self.lib.gd_density1d(self.h, B, F, _dp(hist), _dp(smooth), _ip(winw), _ip(flags), int(bco),
                                           int(mbc), _dp(P), _ip(status)))
         return P, status
+
+    def density2d_masked(self, d_hist, pos, F, rx, ry, corr, winw, flags, bco, mbc, mask_bc, mask_mbc, zero_mask):
+        """Pair ``pos`` of the histogram batch ``d_hist`` with an explicit prior mask (mask_function);
+        returns (device grid, status)."""
+        out = self.alloc(F * F * 8)
+        status = np.zeros(1, dtype=np.int32)
+        mb = None if mask_bc is None else _f64arr(mask_bc)
+        mm = None if mask_mbc is None else _f64arr(mask_mbc)
+        zm = None if zero_mask is None else np.ascontiguousarray(zero_mask, dtype=np.uint8)
+        self._check(self.lib.gd_density2d_masked(
+            self.h, int(F), d_hist.ptr + int(pos) * F * F * 8, float(rx), float(ry), float(corr),
+            int(winw), int(flags), int(bco), int(mbc), None if mb is None else _dp(mb), None if mm is None else _dp(mm),
+            None if zm is None else zm.ctypes.data_as(C.POINTER(C.c_ubyte)), out.ptr, _ip(status)))
+        return out, status
 
     # ---- auxiliary vectors
     EXTRA_COLS = 4

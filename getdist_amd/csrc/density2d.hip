@@ -285,6 +285,58 @@ __global__ void k_normalise(double* __restrict__ P, const double* __restrict__ m
 }
 
 
+// ---- explicit prior masks (mask_function, mcsamples.py:1907-1919) --------------------------------------------
+// A user callback may carve any shape out of the (F+2w)^2 prior mask, so the box shortcut of k_mask_eval does not
+// apply: the moments  a_pq = conv(mask, Win x^p y^q, 'valid')  are summed directly for the one pair concerned.
+struct MaskOv {
+    const double* d_mask_bc;      // (F+2w)^2 mask after _setEdgeMask2D (boundary-correction moments), or nullptr
+    const double* d_mask_mbc;     // (F+2w)^2 mask after _setAllEdgeMask2D (bias-correction a00), or nullptr
+    const unsigned char* d_zero;  // F^2 flags: 1 where the mask excludes the pixel (bool_mask, :1919), or nullptr
+};
+
+// kwin[(i1+w)*(2w+1) + (i2+w)] = Win[i1][i2] * i2^px * i1^py
+__global__ void k_moment_window(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, int px, int py,
+                                double* __restrict__ kwin) {
+    const D2Pair p = pairs[0];
+    const int M = 2 * p.w + 1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M * M; e += gridDim.x * blockDim.x) {
+        const int i1 = e / M - p.w, i2 = e % M - p.w;
+        double v = win_raw(p, i1, i2) / wsum[0];
+        for (int q = 0; q < px; ++q) v = v * (double)i2;
+        for (int q = 0; q < py; ++q) v = v * (double)i1;
+        kwin[e] = v;
+    }
+}
+
+// dst[y][x] = sum_{i1,i2} kwin[i1][i2] * mask[y + w - i1][x + w - i2]   (one pair)
+__global__ void k_mask_moment_direct(const double* __restrict__ kwin, const double* __restrict__ mask, int F, int w,
+                                     double* __restrict__ dst) {
+    const int M = 2 * w + 1, Mp = F + 2 * w;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        const int y = e / F, x = e % F;
+        double acc = 0;
+        for (int a = 0; a < M; ++a) {
+            const double* mrow = mask + (int64_t)(y + 2 * w - a) * Mp + (x + 2 * w);
+            const double* krow = kwin + a * M;
+            for (int b = 0; b < M; ++b) acc = fma(krow[b], mrow[-b], acc);
+        }
+        dst[e] = acc;
+    }
+}
+
+// bins2D = bins2D * conv / a00 outside the excluded region only (mcsamples.py:1973-1974)
+__global__ void k_mbc_update_masked(double* __restrict__ P, const double* __restrict__ conv, const double* __restrict__ a00,
+                                    const unsigned char* __restrict__ zero, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = P[i] * conv[i];
+        P[i] = zero[i] ? v : v / a00[i];
+    }
+}
+__global__ void k_zero_masked(double* __restrict__ P, const unsigned char* __restrict__ zero, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (zero[i]) P[i] = 0.0;
+}
+
 // ---- mean likelihoods (mcsamples.py:1886-1903, 2004-2006) ----------------------------------------------------
 // t = likehist / L where L > 0 (else likehist)
 __global__ void k_likes_div(const double* __restrict__ likehist, const double* __restrict__ L, int64_t n,
@@ -591,9 +643,9 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
 
 extern "C" {
 
-int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
-                 const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P_out,
-                 int32_t* status_out) {
+static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
+                          const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
+                          void* d_P_out, int32_t* status_out, const MaskOv* ov) {
     GD_REQUIRE(ctx && d_hist_v && rx && ry && corr && winw && flags && d_P_out && status_out && B > 0, "bad argument");
     GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins_2D out of range");
     GD_REQUIRE(bco >= -1 && bco <= 1, "unknown boundary_correction_order (expected 0 or 1)");
@@ -620,7 +672,10 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
         GD_REQUIRE((hp[b].flags & 48) == (flags[0] & 48), "a batch must not mix periodic and non-periodic pairs");
     }
     const int per = flags[0] & 48;
-    if (per) return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out);
+    if (per) {
+        GD_REQUIRE(!ov, "explicit prior masks are not supported on periodic axes");
+        return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out);
+    }
     const bool do_bc = any_limits && bco >= 0;
     const int S = next_fft_size(F + 2 * maxw);
     const int Sh = S / 2 + 1;
@@ -709,10 +764,21 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
             }
         }
         if (mbc) L.m[L.n++] = {0, 0, 1, d_a00m};
-        k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
-        GD_KERNEL_CHECK();
-        k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
-        GD_KERNEL_CHECK();
+        if (!ov) {
+            k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
+            GD_KERNEL_CHECK();
+            k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
+            GD_KERNEL_CHECK();
+        } else {
+            for (int q = 0; q < L.n; ++q) {  // d_sat doubles as the window-moment buffer ((2w+1)^2 <= sat_stride)
+                const double* mask = L.m[q].kind == 0 ? ov->d_mask_bc : ov->d_mask_mbc;
+                GD_REQUIRE(mask, "explicit mask missing for a requested correction");
+                k_moment_window<<<64, 256, 0, ctx->stream>>>(d_pairs, d_wsum, L.m[q].px, L.m[q].py, d_sat);
+                GD_KERNEL_CHECK();
+                k_mask_moment_direct<<<1024, 256, 0, ctx->stream>>>(d_sat, mask, F, maxw, L.m[q].dst);
+                GD_KERNEL_CHECK();
+            }
+        }
     }
     if (do_bc) {
         k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
@@ -739,9 +805,16 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
             GD_KERNEL_CHECK();
             FWD(RF, ZH);  // ZH is free to reuse: the histogram spectrum is no longer needed
             CONV_TO(ZH, ZW, d_conv);
-            k_mbc_update<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
+            if (ov && ov->d_zero)
+                k_mbc_update_masked<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, ov->d_zero, B * FF);
+            else
+                k_mbc_update<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
             GD_KERNEL_CHECK();
         }
+    }
+    if (ov && ov->d_zero) {  // bins2D[bool_mask] = 0  (mcsamples.py:1978-1979)
+        k_zero_masked<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, ov->d_zero, B * FF);
+        GD_KERNEL_CHECK();
     }
     k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
     GD_KERNEL_CHECK();
@@ -752,6 +825,37 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
 #undef FWD
 #undef CONV_TO
     return GD_OK;
+}
+
+int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
+                 const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P_out,
+                 int32_t* status_out) {
+    return density2d_main(ctx, B, F, d_hist_v, rx, ry, corr, winw, flags, bco, mbc, d_P_out, status_out, nullptr);
+}
+
+int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, double ry, double corr, int32_t winw,
+                        int32_t flags, int32_t bco, int32_t mbc, const double* mask_bc, const double* mask_mbc,
+                        const unsigned char* zero_mask, void* d_P_out, int32_t* status_out) {
+    GD_REQUIRE(ctx && d_hist && d_P_out && status_out, "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096 && winw >= 1 && winw <= 2 * F, "bad grid size / window half-width");
+    const int64_t Mp = (int64_t)F + 2 * winw, nb = (Mp * Mp * 8 + 255) / 256 * 256, nz = ((int64_t)F * F + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, 2 * nb + nz);
+    if (!base) return GD_ERR_NOMEM;
+    MaskOv ov{nullptr, nullptr, nullptr};
+    if (mask_bc) {
+        GD_HIP(hipMemcpyAsync(base, mask_bc, (size_t)(Mp * Mp * 8), hipMemcpyHostToDevice, ctx->stream));
+        ov.d_mask_bc = (const double*)base;
+    }
+    if (mask_mbc) {
+        GD_HIP(hipMemcpyAsync(base + nb, mask_mbc, (size_t)(Mp * Mp * 8), hipMemcpyHostToDevice, ctx->stream));
+        ov.d_mask_mbc = (const double*)(base + nb);
+    }
+    if (zero_mask) {
+        GD_HIP(hipMemcpyAsync(base + 2 * nb, zero_mask, (size_t)F * F, hipMemcpyHostToDevice, ctx->stream));
+        ov.d_zero = (const unsigned char*)(base + 2 * nb);
+    }
+    const int32_t fl = flags | 64;  // a mask function always counts as a prior (mcsamples.py:1794)
+    return density2d_main(ctx, 1, F, d_hist, &rx, &ry, &corr, &winw, &fl, bco, mbc, d_P_out, status_out, &ov);
 }
 
 int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const void* d_likehist_v, const double* rx,

@@ -386,6 +386,30 @@ class _PoolResult:
         return out
 
 
+def _set_edge_mask_2d(parx, pary, prior_mask, winw):
+    """mcsamples.py:1688-1703 (non-periodic axes): half weight on a limit's edge bins, zero beyond"""
+    if parx.has_limits_bot:
+        prior_mask[:, winw] /= 2
+        prior_mask[:, :winw] = 0
+    if parx.has_limits_top:
+        prior_mask[:, -(winw + 1)] /= 2
+        prior_mask[:, -winw:] = 0
+    if pary.has_limits_bot:
+        prior_mask[winw, :] /= 2
+        prior_mask[:winw] = 0
+    if pary.has_limits_top:
+        prior_mask[-(winw + 1), :] /= 2
+        prior_mask[-winw:, :] = 0
+
+
+def _set_all_edge_mask_2d(prior_mask, winw):
+    """mcsamples.py:1705-1712 (non-periodic axes): zero the padding margins"""
+    prior_mask[:, :winw] = 0
+    prior_mask[:, -winw:] = 0
+    prior_mask[:winw] = 0
+    prior_mask[-winw:, :] = 0
+
+
 class _Deferred:
     """A pool handle that is itself still being created in the helper thread."""
 
@@ -1672,8 +1696,8 @@ class MCSamples:
 
     def get2DDensityGridData(self, j, j2, num_plot_contours=None, get_density=False, meanlikes=False,
                              mask_function=None, **kwargs):
-        if mask_function is not None:
-            raise NotImplementedError("mask_function is outside the accelerated path")
+        if mask_function is not None and meanlikes:
+            raise NotImplementedError("mask_function together with meanlikes")
         if self.needs_update:
             self.updateBaseStatistics()
         j = self._parAndNumber(j)[0]
@@ -1681,7 +1705,7 @@ class MCSamples:
         if j is None or j2 is None:
             return None
         return self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density,
-                                   meanlikes=meanlikes, **kwargs)[0]
+                                   meanlikes=meanlikes, mask_function=mask_function, **kwargs)[0]
 
     def triangleDensities(self, params=None, **kwargs):
         """All lower-triangle pairs (x=params[i], y=params[i2>i]) in triangle-plot order; returns (pairs, densities)."""
@@ -1933,9 +1957,11 @@ class MCSamples:
         return self._idx_cols[key][0]
 
     def get2DDensities(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, meanlikes=False,
-                       **kwargs):
+                       mask_function=None, **kwargs):
         """
         Batched 2D KDEs (additive API): a list of Density2D, one per (x, y) entry of ``pairs``.
+        ``mask_function(minx, miny, stepx, stepy, mask)`` may zero parts of each pair's prior mask in place
+        (mcsamples.py:1767-1770); those pairs take the explicit-mask entry point one at a time.
         With ``meanlikes`` each result carries the mean-likelihood grid ``likes`` (mcsamples.py:1829-1831,1886-1903).
         Each result carries ``bandwidth`` = (hx, hy, corr) in parameter units, ``bandwidth_branch`` and
         ``kopt`` (the device optimiser's {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status}).
@@ -1955,8 +1981,9 @@ class MCSamples:
         pairs = [(self._col(a), self._col(b)) for a, b in pairs]
         lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
-                or self.use_effective_samples_2D):
-            return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes, **kwargs)
+                or self.use_effective_samples_2D or mask_function is not None):
+            return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes,
+                                             mask_function=mask_function, **kwargs)
         # everything per-parameter is settled here, on this lane, before the pairs are dealt
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
@@ -1996,7 +2023,7 @@ class MCSamples:
         return out
 
     def _get2DDensities_lane(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, meanlikes=False,
-                             **kwargs):
+                             mask_function=None, **kwargs):
         """One lane of get2DDensities: the whole batched pipeline on this object's context."""
         base_F = kwargs.get("fine_bins_2D", self.fine_bins_2D)
         bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
@@ -2156,7 +2183,7 @@ class MCSamples:
                 if not pary.periodic:
                     flags |= (4 if pary.has_limits_bot else 0) | (8 if pary.has_limits_top else 0)
                 flags |= (16 if parx.periodic else 0) | (32 if pary.periodic else 0)
-                has_prior = bool(parx.has_limits or pary.has_limits)
+                has_prior = bool(parx.has_limits or pary.has_limits or mask_function is not None)  # mcsamples.py:1794
                 if has_prior:
                     flags |= 64
                 e["flags"] = flags
@@ -2184,7 +2211,36 @@ class MCSamples:
                     carry = []
                     for s0 in range(0, len(cur), max_batch):
                         batches.append(cur[s0:s0 + max_batch])
+            if mask_function is not None:
+                batches = [[item] for b in batches for item in b]  # the callback edits one pair's mask at a time
             for sel in batches:
+                if mask_function is not None:
+                    (pos, k), = sel
+                    e = info[k]
+                    if e["flags"] & 48:
+                        raise NotImplementedError("mask_function on periodic parameters")
+                    w_ = e["winw"]
+                    prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
+                    mask_function(e["xbinmin"] - w_ * e["fwx"], e["ybinmin"] - w_ * e["fwy"], e["fwx"], e["fwy"], prior_mask)
+                    e["mask"] = bool_mask = prior_mask[w_:-w_, w_:-w_] < 1e-8
+                    mask_bc = mask_mbc = None
+                    if bco >= 0:
+                        _set_edge_mask_2d(e["parx"], e["pary"], prior_mask, w_)
+                        mask_bc = prior_mask.copy()
+                    if mbc:
+                        _set_all_edge_mask_2d(prior_mask, w_)
+                        mask_mbc = prior_mask
+                    with _Phase(self, "2d.convolve"):
+                        d_P, status = ctx.density2d_masked(d_hist, pos, F, rx[k], ry[k], cc[k], w_,
+                                                           e["flags"], bco, mbc, mask_bc, mask_mbc, bool_mask)
+                    levels = None
+                    if not get_density:
+                        ncontours = len(self.contours)
+                        if num_plot_contours:
+                            ncontours = min(num_plot_contours, ncontours)
+                        levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
+                    inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
+                    continue
                 if [pos for pos, _ in sel] == list(range(len(members))):
                     d_sub, own = d_hist, False
                 else:
@@ -2249,6 +2305,7 @@ class MCSamples:
                 (ax, sx), (ay, sy) = axis(e["parx"], e["xbinmin"], e["xbinmax"], F), axis(e["pary"], e["ybinmin"], e["ybinmax"], F)
                 dens = Density2D._wrap(ax, ay, P[row], [(e["parx"].range_min, e["parx"].range_max),
                                                         (e["pary"].range_min, e["pary"].range_max)], sx * sy)
+                dens.mask = e.get("mask")
                 dens.bandwidth = e.get("bandwidth")
                 dens.bandwidth_branch = e.get("branch")
                 dens.kopt = e.get("kopt")

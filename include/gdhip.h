@@ -271,6 +271,15 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const void
                const double* ry, const double* corr, const int32_t* winw, const int32_t* flags, int32_t mbc,
                void* d_likes_out, int32_t* status_out);
 
+/* gd_density2d_masked: gd_density2d for ONE pair whose prior mask was edited by a user callback
+ *   (mask_function, mcsamples.py:1767-1770,1907-1919): mask_bc = the (F+2 winw)^2 mask after _setEdgeMask2D
+ *   (host, row-major; NULL when no boundary correction), mask_mbc = the same after _setAllEdgeMask2D (NULL when
+ *   mbc == 0), zero_mask = F^2 bytes, 1 where mask < 1e-8 (bool_mask: the bias correction does not divide there and
+ *   the density is zeroed at the end, :1973-1979).  The mask moments are summed directly.  Non-periodic axes only. */
+int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, double ry, double corr, int32_t winw,
+                        int32_t flags, int32_t bco, int32_t mbc, const double* mask_bc, const double* mask_mbc,
+                        const unsigned char* zero_mask, void* d_P_out, int32_t* status_out);
+
 #ifdef __cplusplus
 }
 #endif

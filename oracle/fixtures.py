@@ -73,6 +73,15 @@ MEANLIKES_CASES = (("c1_bounded", ({}, dict(mult_bias_correction_order=0), dict(
                    ("block10_weighted", ({},)), ("shapes", ({},)), ("periodic", (dict(fine_bins=64, fine_bins_2D=32),)))
 
 
+def example_mask_function(minx, miny, stepx, stepy, mask):
+    """A prior cut for the mask_function tests: the region  y > 0.6 x + 0.2  is excluded (mask set to 0 there), in the
+    calling convention of mcsamples.py:1767-1770 (mask[iy, ix] <-> point (minx + ix stepx, miny + iy stepy))."""
+    ny, nx = mask.shape
+    x = minx + np.arange(nx) * stepx
+    y = miny + np.arange(ny) * stepy
+    mask[y[:, None] > 0.6 * x[None, :] + 0.2] = 0
+
+
 def mcmc_chains_fixture(nchains=3, N=6000, n=5):
     """
     Integer-weight (MCMC multiplicity) chains with AR(1) correlation that differs per parameter, plus a loglikes

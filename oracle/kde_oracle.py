@@ -998,8 +998,8 @@ class OracleSamples:
             trace.update(branch=branch, N_eff=N_eff, hx=hx, hy=hy, c=c)
         return hx, hy, c
 
-    def density_2d(self, j, j2, trace=None, meanlikes=False, **kwargs):
-        """Returns dict(x, y, P[y,x], view_ranges, likes, ...).  mcsamples.py:1748-2010 (no mask_function)."""
+    def density_2d(self, j, j2, trace=None, meanlikes=False, mask_function=None, **kwargs):
+        """Returns dict(x, y, P[y,x], view_ranges, likes, mask, ...).  mcsamples.py:1748-2010."""
         if isinstance(j, str):
             j = self.index[j]
         if isinstance(j2, str):
@@ -1012,7 +1012,7 @@ class OracleSamples:
         mbc = kwargs.get("mult_bias_correction_order", S["mult_bias_correction_order"])
         smooth_scale_2D = float(kwargs.get("smooth_scale_2D", S["smooth_scale_2D"]))
         max_corr = S["max_corr_2D"]
-        has_prior = parx.has_limits or pary.has_limits
+        has_prior = bool(parx.has_limits or pary.has_limits or mask_function)  # mcsamples.py:1794
         corr = self.corrmat[j2][j]
         actual_corr = corr
         if abs(abs(corr) - 1.0) <= 1e-8:
@@ -1074,8 +1074,12 @@ class OracleSamples:
             mxl = 1e-4 * np.max(bins2D)
             bin2Dlikes[bins2D > mxl] /= bins2D[bins2D > mxl]
             bin2Dlikes[bins2D <= mxl] = 0
-        if has_prior and bco >= 0 or mbc:
+        bool_mask = None
+        if has_prior and bco >= 0 or mbc or mask_function:
             prior_mask = np.ones((ysize + 2 * winw, xsize + 2 * winw))
+            if mask_function:  # mcsamples.py:1911-1919
+                mask_function(xbinmin - winw * finewidthx, ybinmin - winw * finewidthy, finewidthx, finewidthy, prior_mask)
+                bool_mask = prior_mask[winw:-winw, winw:-winw] < 1e-8
         if has_prior and bco >= 0 and not (parx.periodic and pary.periodic):
             _set_edge_mask_2d(parx, pary, prior_mask, winw)
             a00 = conv2d(prior_mask, Win, "valid", largest_size=convolvesize)
@@ -1114,7 +1118,12 @@ class OracleSamples:
                 ix2_ = bins2D > np.max(bins2D) * 1e-8
                 box[ix2_] /= bins2D[ix2_]
                 bins2D *= conv2d(box, Win, mode, largest_size=convolvesize)
-                bins2D /= a00
+                if mask_function:
+                    bins2D[~bool_mask] /= a00[~bool_mask]
+                else:
+                    bins2D /= a00
+        if mask_function:
+            bins2D[bool_mask] = 0
         x = np.linspace(xbinmin, xbinmax, xsize)
         y = np.linspace(ybinmin, ybinmax, ysize)
         mx = np.max(bins2D)
@@ -1127,7 +1136,7 @@ class OracleSamples:
             trace.update(fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr_used=corr, actual_corr=actual_corr)
         return dict(x=x, y=y, P=bins2D, view_ranges=[(parx.range_min, parx.range_max), (pary.range_min, pary.range_max)],
                     histbins=histbins, flatix=flatix, fine_bins_2D=fine_bins_2D, winw=winw, rx=rx, ry=ry, corr=corr,
-                    likes=bin2Dlikes, likes_exact=likes_exact)
+                    likes=bin2Dlikes, likes_exact=likes_exact, mask=bool_mask)
 
     # ---- convergence (chains.py:1446-1486; mcsamples.py:964-985) --------------------------------
     def gelman_rubin_eigenvalues(self, chain_offsets, nparam=None):

@@ -22,7 +22,8 @@ from getdist import MCSamples  # noqa: E402  (the reference)
 from getdist_amd import synth  # noqa: E402
 from oracle import kde_oracle as ko  # noqa: E402
 from oracle import convergence_oracle as co  # noqa: E402
-from oracle.fixtures import MEANLIKES_CASES, fixture_zoo, loglikes_for, mcmc_chains_fixture  # noqa: E402
+from oracle.fixtures import (MEANLIKES_CASES, example_mask_function, fixture_zoo, loglikes_for,  # noqa: E402
+                             mcmc_chains_fixture)
 
 logging.getLogger().setLevel(logging.ERROR)
 
@@ -274,6 +275,25 @@ def compare_chain_loader():
     return ok
 
 
+def compare_mask_function():
+    """get2DDensityGridData(mask_function=...) (mcsamples.py:1794,1907-1919,1973-1979,1987)."""
+    zoo = {fx["name"]: fx for fx in fixture_zoo()}
+    ok = True
+    for nm, pairs in (("c1_100k", [(0, 1), (2, 3)]), ("c1_bounded", [(0, 3), (2, 3)]), ("shapes", [(0, 1), (6, 7)])):
+        fx = zoo[nm]
+        ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"])
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+        for a, b in pairs:
+            for kw in ({}, dict(mult_bias_correction_order=0), dict(boundary_correction_order=0, mult_bias_correction_order=2)):
+                d_ref = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], get_density=True,
+                                                 mask_function=example_mask_function, **kw)
+                d_orc = orc.density_2d(a, b, mask_function=example_mask_function, **kw)
+                ok &= relerr(d_orc["P"], d_ref.P) <= 1e-10 and np.array_equal(d_orc["mask"], d_ref.mask)
+                ok &= bool(np.any(d_ref.mask)) and not bool(np.all(d_ref.mask))
+    print(("ok  " if ok else "FAIL") + " mask_function densities and masks")
+    return ok
+
+
 def compare_fft_numbers():
     from getdist.convolve import nearestFFTnumber
 
@@ -291,6 +311,7 @@ def main():
     ok &= compare_nd_ranges()
     ok &= compare_raftery_lewis()
     ok &= compare_chain_loader()
+    ok &= compare_mask_function()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)
     print("ALL OK" if ok else "SOME FAILED")

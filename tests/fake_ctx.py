@@ -95,6 +95,54 @@ class FakeContext:
             return self._like_w[lo:hi]
         return np.ones(hi - lo) if self.w is None else self.w[lo:hi]
 
+    def density2d_masked(self, d_hist, pos, F, rx, ry, corr, winw, flags, bco, mbc, mask_bc, mask_mbc, zero_mask):
+        """mcsamples.py:1884-1979 for one pair with explicit (already edge-masked) prior masks."""
+        hist = np.asarray(d_hist.a)[pos]
+        w_ = int(winw)
+        Cinv = np.linalg.inv(np.array([[ry ** 2, rx * ry * corr], [rx * ry * corr, rx ** 2]]))
+        i1, i2 = np.mgrid[-w_:w_ + 1, -w_:w_ + 1]
+        Win = np.exp(-(i1**2 * Cinv[0, 0] + i2**2 * Cinv[1, 1] + 2 * Cinv[1, 0] * i1 * i2) / 2)
+        Win /= np.sum(Win)
+        big = F + 4 * w_ + 1
+        bins2D = ko.conv2d(hist, Win, "same", largest_size=big)
+        if bco >= 0:
+            a00 = ko.conv2d(mask_bc, Win, "valid", largest_size=big)
+            ix = a00 * bins2D > np.max(bins2D) * 1e-8
+            a00 = a00[ix]
+            normed = bins2D[ix] / a00
+            if bco == 0:
+                bins2D[ix] = normed
+            else:
+                idx = np.arange(-w_, w_ + 1)
+                y = np.repeat(idx[:, None], Win.shape[1], axis=1)
+                winx, winy = Win * idx, Win * y
+                a10 = ko.conv2d(mask_bc, winx, "valid", largest_size=big)[ix]
+                a01 = ko.conv2d(mask_bc, winy, "valid", largest_size=big)[ix]
+                a20 = ko.conv2d(mask_bc, winx * idx, "valid", largest_size=big)[ix]
+                a02 = ko.conv2d(mask_bc, winy * y, "valid", largest_size=big)[ix]
+                a11 = ko.conv2d(mask_bc, winy * idx, "valid", largest_size=big)[ix]
+                xP = ko.conv2d(hist, winx, "same", largest_size=big)[ix]
+                yP = ko.conv2d(hist, winy, "same", largest_size=big)[ix]
+                denom = a20 * a01**2 + a10**2 * a02 - a00 * a02 * a20 + a11**2 * a00 - 2 * a01 * a10 * a11
+                corrected = (bins2D[ix] * (a11**2 - a02 * a20) + xP * (a10 * a02 - a01 * a11) + yP * (a01 * a20 - a10 * a11)) / denom
+                bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+        zero = np.asarray(zero_mask, dtype=bool)
+        if mbc:
+            a00 = ko.conv2d(mask_mbc, Win, "valid", largest_size=big)
+            for _ in range(mbc):
+                box = hist.copy()
+                ix2 = bins2D > np.max(bins2D) * 1e-8
+                box[ix2] /= bins2D[ix2]
+                bins2D *= ko.conv2d(box, Win, "same", largest_size=big)
+                bins2D[~zero] /= a00[~zero]
+        bins2D[zero] = 0
+        mx = np.max(bins2D)
+        status = np.zeros(1, dtype=np.int32)
+        if mx == 0:
+            status[0] = -4
+            return FakeBuf(np.zeros((1, F, F))), status
+        return FakeBuf((bins2D / mx)[None]), status
+
     # ---- second lane
     def attach(self, owner):
         self.s, self.w, self.N, self.n, self.weighted = owner.s, owner.w, owner.N, owner.n, owner.weighted

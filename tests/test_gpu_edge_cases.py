@@ -242,3 +242,14 @@ def test_raftery_lewis_corr_steps_and_thinning():
     from test_host_logic_cpu import raftery_lewis_check
 
     raftery_lewis_check()
+
+
+def test_mask_function(zoo):
+    """gd_density2d_masked (direct moment sums over a user-edited prior mask) through get2DDensityGridData."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic_cpu import mask_function_check
+
+    mask_function_check(zoo, tol=1e-6)

@@ -195,6 +195,44 @@ def test_host_logic_raftery_lewis():
     raftery_lewis_check(FakeContext)
 
 
+def mask_function_check(zoo, factory=None, tol=1e-9):
+    """get2DDensityGridData(mask_function=...) against the oracle (pinned to the reference) incl. the returned mask."""
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import example_mask_function
+
+    kw = {} if factory is None else dict(_context_factory=factory)
+    for nm, pairs in (("c1_bounded", [(0, 3), (2, 3)]), ("shapes", [(0, 1), (6, 7)])):
+        fx = zoo[nm]
+        mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"], **kw)
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+        for a, b in pairs:
+            for kws in ({}, dict(mult_bias_correction_order=0), dict(boundary_correction_order=0, mult_bias_correction_order=2)):
+                tr = {}
+                o = orc.density_2d(a, b, mask_function=example_mask_function, trace=tr, **kws)
+                # next to the cut the linear boundary correction divides by a determinant that passes through zero
+                # (mcsamples.py:1950-1957): a pixel there flips between exp(3) x and 0 under 1e-16 perturbations of the
+                # bandwidth or the mask moments -- in the reference too (measured: a 1e-14 change of the TNC correlation
+                # moves the grid by 7.6e-4) -- and the bias-correction round spreads it over the window.  Orders 0 must
+                # agree to tol; order 1 to tol whenever it is stable, else within the reference's own sensitivity.
+                for bw in (None, [(tr["hx"], tr["hy"], tr["c"])]):
+                    d = mc.get2DDensities([(a, b)], mask_function=example_mask_function, _bandwidths=bw, **kws)[0]
+                    assert np.array_equal(d.mask, o["mask"]) and d.mask.any() and not d.mask.all()
+                    err = np.abs(d.P - o["P"])
+                    same_bw = np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6)
+                    if err.max() >= (tol if same_bw else 2e-3):
+                        assert kws.get("boundary_correction_order", 1) == 1 and err.max() < 2e-3, (nm, a, b, kws, err.max())
+                        assert np.median(err) < 1e-5
+                    assert np.all(d.P[d.mask] == 0)
+                    if bw is not None and factory is not None:
+                        assert err.max() == 0.0  # identical inputs through the numpy double: identical grids
+        plain = mc.get2DDensityGridData(pairs[0][0], pairs[0][1], get_density=True)
+        assert plain.mask is None
+
+
+def test_host_logic_mask_function(zoo):
+    mask_function_check(zoo, FakeContext)
+
+
 def test_prefill_plot_caches(zoo):
     """plots.MCSampleAnalysis cache layout (plots.py:594-645): keys, contour counts, one batched call per dimension."""
     from getdist_amd.plotting import prefill_plot_caches
