@@ -1106,8 +1106,9 @@ class OracleSamples:
                 A = a11**2 - a02 * a20
                 Ax = a10 * a02 - a01 * a11
                 Ay = a01 * a20 - a10 * a11
-                corrected = (bins2D[ix] * A + xP * Ax + yP * Ay) / denom
-                bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+                with np.errstate(divide="ignore", invalid="ignore"):  # denom passes through 0 next to a mask_function cut
+                    corrected = (bins2D[ix] * A + xP * Ax + yP * Ay) / denom
+                    bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
             else:
                 raise ValueError("unknown boundary_correction_order (expected 0 or 1)")
         if mbc and not (parx.periodic and pary.periodic):

@@ -124,8 +124,9 @@ class FakeContext:
                 xP = ko.conv2d(hist, winx, "same", largest_size=big)[ix]
                 yP = ko.conv2d(hist, winy, "same", largest_size=big)[ix]
                 denom = a20 * a01**2 + a10**2 * a02 - a00 * a02 * a20 + a11**2 * a00 - 2 * a01 * a10 * a11
-                corrected = (bins2D[ix] * (a11**2 - a02 * a20) + xP * (a10 * a02 - a01 * a11) + yP * (a01 * a20 - a10 * a11)) / denom
-                bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    corrected = (bins2D[ix] * (a11**2 - a02 * a20) + xP * (a10 * a02 - a01 * a11) + yP * (a01 * a20 - a10 * a11)) / denom
+                    bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
         zero = np.asarray(zero_mask, dtype=bool)
         if mbc:
             a00 = ko.conv2d(mask_mbc, Win, "valid", largest_size=big)
