@@ -215,6 +215,25 @@ def golden_raftery_lewis():
     return out
 
 
+def golden_mask_function(zoo):
+    """get2DDensityGridData(mask_function=example_mask_function) of the reference (mcsamples.py:1907-1919,1973-1979)."""
+    from oracle.fixtures import example_mask_function
+
+    out = {}
+    for nm, pairs in (("c1_bounded", [(0, 3), (2, 3)]), ("shapes", [(0, 1), (6, 7)])):
+        fx = zoo[nm]
+        ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+        for a, b in pairs:
+            for kw in ({}, dict(mult_bias_correction_order=0), dict(boundary_correction_order=0, mult_bias_correction_order=2)):
+                d = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], get_density=True,
+                                             mask_function=example_mask_function, **kw)
+                key = "%s/%d_%d/%s" % (nm, a, b, kwkey(kw))
+                out[key + "/P"] = d.P[::4, ::4].copy()
+                out[key + "/Psum"] = np.float64(np.sum(d.P))
+                out[key + "/mask_crc"] = crc(np.asarray(d.mask, dtype=np.uint8))
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -258,6 +277,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
     np.savez_compressed(os.path.join(HERE, "splittests.npz"),
                         **{nm: golden_split_tests(zoo[nm]) for nm in ("shapes_intweights", "c1_bounded", "block10_weighted")})
+    np.savez_compressed(os.path.join(HERE, "mask_function.npz"), **golden_mask_function(zoo))
+    if "--only-mask" in sys.argv:
+        return
     np.savez_compressed(os.path.join(HERE, "raftery_lewis.npz"), **golden_raftery_lewis())
     if "--only-rl" in sys.argv:
         return

@@ -124,3 +124,18 @@ def test_convergence_oracle_golden():
     for thin in (20, 3):
         corrs = co.corr_steps(samples, weights, offsets, orc.vars, thin)
         assert gu.relerr(corrs, g["corrsteps/%d" % thin]) < 1e-11
+
+
+def test_oracle_mask_function_golden(zoo):
+    from oracle.fixtures import example_mask_function
+
+    g = np.load(gu.GOLDEN_DIR + "/mask_function.npz")
+    for nm, pairs in (("c1_bounded", [(0, 3), (2, 3)]), ("shapes", [(0, 1), (6, 7)])):
+        fx = zoo[nm]
+        orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+        for a, b in pairs:
+            for kw in ({}, dict(mult_bias_correction_order=0), dict(boundary_correction_order=0, mult_bias_correction_order=2)):
+                o = orc.density_2d(a, b, mask_function=example_mask_function, **kw)
+                key = "%s/%d_%d/%s" % (nm, a, b, gu.kwkey(kw))
+                assert gu.relerr(o["P"][::4, ::4], g[key + "/P"]) <= TOL_GRID, key
+                assert gu.crc(np.asarray(o["mask"], dtype=np.uint8)) == g[key + "/mask_crc"], key
