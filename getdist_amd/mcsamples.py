@@ -386,6 +386,39 @@ class _PoolResult:
         return out
 
 
+def _g2_markov_vs_second_order(tran):
+    """
+    Likelihood-ratio statistic G^2 of the first-order Markov model against the second-order one for the transition
+    counts tran[a, b, c] of a binary chain (mcsamples.py:1072-1089): the Markov fit of cell (a, b, c) is
+    n(a,b,.) n(.,b,c) / n(.,b,.); empty cells drop out.  Terms are added in C order, like the reference's loops.
+    """
+    import math
+
+    n_ab = tran.sum(axis=2)
+    n_bc = tran.sum(axis=0)
+    n_b = tran.sum(axis=(0, 2))
+    g2 = 0.0
+    for (a, b, c), focus in np.ndenumerate(tran):
+        if focus != 0:
+            fitted = float(n_ab[a, b] * n_bc[b, c]) / float(n_b[b])
+            g2 += math.log(float(focus) / fitted) * float(focus)
+    return 2 * g2
+
+
+def _g2_independence_vs_markov(tran2, thin_rows):
+    """G^2 of independence against first-order Markov for pair counts tran2[a, b] (mcsamples.py:1124-1139); None where the
+    reference gives up ("Raftery and Lewis estimator had problems")."""
+    rows, cols = tran2.sum(axis=1), tran2.sum(axis=0)
+    g2 = 0
+    for (a, b), focus in np.ndenumerate(tran2):
+        if focus != 0:
+            fitted = float(rows[a] * cols[b]) / float(thin_rows - 1)
+            if fitted <= 0 or focus <= 0:
+                return None
+            g2 += np.log(float(focus) / fitted) * float(focus)
+    return 2 * g2
+
+
 def _set_edge_mask_2d(parx, pary, prior_mask, winw):
     """mcsamples.py:1688-1703 (non-periodic axes): half weight on a limit's edge bins, zero beyond"""
     if parx.has_limits_bot:
@@ -893,16 +926,7 @@ class MCSamples:
                             if thin_rows < 2:
                                 break
                             tran = c[j, endb, :8].reshape(2, 2, 2)
-                            g2 = 0.0
-                            for i1 in (0, 1):
-                                for i2 in (0, 1):
-                                    for i3 in (0, 1):
-                                        if tran[i1][i2][i3] != 0:
-                                            fitted = float((tran[i1][i2][0] + tran[i1][i2][1]) * (tran[0][i2][i3] + tran[1][i2][i3])) \
-                                                / float(tran[0][i2][0] + tran[0][i2][1] + tran[1][i2][0] + tran[1][i2][1])
-                                            focus = float(tran[i1][i2][i3])
-                                            g2 += math.log(focus / fitted) * focus
-                            g2 *= 2
+                            g2 = _g2_markov_vs_second_order(tran)
                             if g2 - math.log(float(thin_rows - 2)) * 2 < 0:
                                 break
                             thin_fac[ix] += 1
@@ -926,16 +950,9 @@ class MCSamples:
                     if thin_rows < 2:
                         break
                     tran2 = c[0, 0, 8:].reshape(2, 2)
-                    g2 = 0.0
-                    for i1 in (0, 1):
-                        for i2 in (0, 1):
-                            if tran2[i1][i2] != 0:
-                                fitted = float((tran2[i1][0] + tran2[i1][1]) * (tran2[0][i2] + tran2[1][i2])) / float(thin_rows - 1)
-                                focus = float(tran2[i1][i2])
-                                if fitted <= 0 or focus <= 0:
-                                    return None
-                                g2 += np.log(focus / fitted) * focus
-                    g2 *= 2
+                    g2 = _g2_independence_vs_markov(tran2, thin_rows)
+                    if g2 is None:
+                        return None
                     if g2 - np.log(float(thin_rows - 1)) < 0:
                         break
                     thin_fac[ix] += 1
