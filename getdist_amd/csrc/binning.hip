@@ -282,9 +282,12 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
 // 128 KB stripe, so every sample is visited once instead of once per stripe.  A counter can wrap if a bin receives
 // more than 65535 samples; a wrap always lowers the sum of all counters, so comparing that sum with the number of
 // samples the block accepted detects it exactly, and the host redoes flagged pairs with the 32-bit kernel.
+// HAS_W8: integer multiplicities <= 255 ride along as one byte per sample (exact: the counters add integers; the
+// wrap test compares against the accepted WEIGHT instead of the accepted count).
+template <bool HAS_W8>
 __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restrict__ pairs, int B, int64_t N, int F,
-                                                     int R, int nstripes, double* __restrict__ hist_all,
-                                                     int* __restrict__ overflow) {
+                                                     int R, int nstripes, const unsigned char* __restrict__ w8,
+                                                     double* __restrict__ hist_all, int* __restrict__ overflow) {
     extern __shared__ double sh_raw[];
     unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
     __shared__ double red[16];
@@ -297,20 +300,22 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restric
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) sh[i] = 0;
     __syncthreads();
     unsigned int nacc = 0;
-    auto visit = [&](unsigned cx, unsigned cy) {
+    auto visit = [&](unsigned cx, unsigned cy, unsigned wt) {
         const unsigned r = cy - (unsigned)row0;
-        if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F) {
+        if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F && (!HAS_W8 || wt != 0u)) {
             const unsigned a = r * (unsigned)F + cx;
-            atomicAdd(&sh[a >> 1], 1u << ((a & 1u) * 16u));
-            ++nacc;
+            atomicAdd(&sh[a >> 1], wt << ((a & 1u) * 16u));
+            nacc += wt;
         }
     };
-    auto visit8 = [&](const uint4& ax, const uint4& ay) {
+    // 8 samples: two u16 per word of the index columns, one byte per sample of weights (wlo = samples 0-3, whi = 4-7)
+    auto visit8 = [&](const uint4& ax, const uint4& ay, unsigned wlo, unsigned whi) {
         const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            visit(xs[q] & 0xFFFFu, ys[q] & 0xFFFFu);
-            visit(xs[q] >> 16, ys[q] >> 16);
+            const unsigned ww = (q < 2 ? wlo : whi) >> ((q & 1) * 16);
+            visit(xs[q] & 0xFFFFu, ys[q] & 0xFFFFu, HAS_W8 ? (ww & 0xFFu) : 1u);
+            visit(xs[q] >> 16, ys[q] >> 16, HAS_W8 ? ((ww >> 8) & 0xFFu) : 1u);
         }
     };
     const int64_t N16 = N & ~(int64_t)15;
@@ -318,11 +323,13 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restric
     for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * (int64_t)blockDim.x) {
         const uint4 ax0 = *reinterpret_cast<const uint4*>(P.ix + i), ay0 = *reinterpret_cast<const uint4*>(P.iy + i);
         const uint4 ax1 = *reinterpret_cast<const uint4*>(P.ix + i + 8), ay1 = *reinterpret_cast<const uint4*>(P.iy + i + 8);
-        visit8(ax0, ay0);
-        visit8(ax1, ay1);
+        uint4 wv = make_uint4(0, 0, 0, 0);
+        if (HAS_W8) wv = *reinterpret_cast<const uint4*>(w8 + i);
+        visit8(ax0, ay0, wv.x, wv.y);
+        visit8(ax1, ay1, wv.z, wv.w);
     }
     if (threadIdx.x == 0)
-        for (int64_t i = N16; i < N; ++i) visit(P.ix[i], P.iy[i]);
+        for (int64_t i = N16; i < N; ++i) visit(P.ix[i], P.iy[i], HAS_W8 ? (unsigned)w8[i] : 1u);
     __syncthreads();
     double* hist = hist_all + (int64_t)pair * F * F;
     unsigned int total = 0;
@@ -535,9 +542,16 @@ static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     int* d_flags = (int*)(base + o_flags);
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
-    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
     const size_t lds = ((size_t)R * F + 1) / 2 * 4;
-    k_hist2d_u16<<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, d_hist, d_flags);
+    if (ctx->w8) {
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        k_hist2d_u16<true><<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, ctx->w8, d_hist,
+                                                                         d_flags);
+    } else {
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        k_hist2d_u16<false><<<(unsigned)nblocks, 1024, lds, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, nullptr, d_hist,
+                                                                          d_flags);
+    }
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
     GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -566,9 +580,11 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
         if (R16 > F) R16 = F;
         const int nstripes16 = (F + R16 - 1) / R16;
         // the 16-bit kernel gives each (pair, stripe) to ONE block: only worth it when that fills the chip
-        if (ctx->w || (int64_t)B * nstripes16 < ctx->cu_count) return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
+        if ((ctx->w && !ctx->w8) || (int64_t)B * nstripes16 < ctx->cu_count)
+            return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
     }
-    // unit weights, batched: 16-bit packed LDS counters, exact overflow detection, 32-bit redo for flagged pairs
+    // unit weights or byte multiplicities, batched: 16-bit packed LDS counters, exact overflow detection, 32-bit redo
+    // for flagged pairs
     std::vector<int> flagged;
     int rc = launch_hist2d_u16(ctx, B, hp, F, (double*)d_hist, flagged);
     if (rc) return rc;

@@ -72,10 +72,11 @@ void gd_destroy(gd_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gd_fft_cache_destroy(ctx);
     for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
-    if (ctx->w_sel) ctx->w = ctx->w_main;
+    if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);
         if (ctx->w) (void)hipFree(ctx->w);
+        if (ctx->w8) (void)hipFree(ctx->w8);
     }
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
@@ -237,12 +238,18 @@ __global__ void k_weights_integral(const double* __restrict__ w, int64_t N, int*
     int b = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const double v = w[i];
-        if (!(v >= 0.0) || v != trunc(v) || v > 1048576.0) b = 1;
+        if (!(v >= 0.0) || v != trunc(v) || v > 1048576.0) b |= 1;
+        if (v > 255.0) b |= 2;  // too large for the byte copy
         s += v;
     }
-    if (b) atomicOr(bad, 1);
+    if (b) atomicOr(bad, b);
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(sum, s);
+}
+
+__global__ void k_weights_to_u8(const double* __restrict__ w, int64_t N, unsigned char* __restrict__ w8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        w8[i] = (unsigned char)w[i];
 }
 
 extern "C" {
@@ -265,11 +272,13 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
     GD_HIP(hipSetDevice(ctx->device));
     GD_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->w_sel) ctx->w = ctx->w_main;
+    if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);
         if (ctx->w) (void)hipFree(ctx->w);
+        if (ctx->w8) (void)hipFree(ctx->w8);
     }
+    ctx->w8 = ctx->w8_main = nullptr;
     ctx->borrowed = false;
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
@@ -315,7 +324,13 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
         GD_HIP(hipMemcpyAsync(&bad, chk, 4, hipMemcpyDeviceToHost, ctx->stream));
         GD_HIP(hipMemcpyAsync(&sum, chk + 128, 8, hipMemcpyDeviceToHost, ctx->stream));
         GD_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->w_integral = (bad == 0) && sum < 4.0e9;
+        ctx->w_integral = ((bad & 1) == 0) && sum < 4.0e9;
+        if (ctx->w_integral && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
+            GD_HIP(hipMalloc((void**)&ctx->w8, (size_t)ld));
+            GD_HIP(hipMemsetAsync(ctx->w8, 0, (size_t)ld, ctx->stream));
+            k_weights_to_u8<<<1024, 256, 0, ctx->stream>>>(ctx->w, N, ctx->w8);
+            GD_KERNEL_CHECK();
+        }
     }
     GD_HIP(hipStreamSynchronize(ctx->stream));
     ctx->N = N;
@@ -400,12 +415,16 @@ int gd_select_weights(gd_ctx* ctx, int32_t which) {
         GD_REQUIRE(ctx->like_w, "no like weights: call gd_like_weights first");
         ctx->w_main = ctx->w;
         ctx->w_main_integral = ctx->w_integral;
+        ctx->w8_main = ctx->w8;
         ctx->w = ctx->like_w;
         ctx->w_integral = false;
+        ctx->w8 = nullptr;
     } else {
         ctx->w = ctx->w_main;
         ctx->w_integral = ctx->w_main_integral;
+        ctx->w8 = ctx->w8_main;
         ctx->w_main = nullptr;
+        ctx->w8_main = nullptr;
     }
     ctx->w_sel = which;
     return GD_OK;
@@ -448,17 +467,20 @@ int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner) {
     GD_HIP(hipSetDevice(ctx->device));
     GD_HIP(hipStreamSynchronize(ctx->stream));
     GD_HIP(hipStreamSynchronize(owner->stream));
-    if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w_sel = 0;
+    if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main, ctx->w_sel = 0;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);
         if (ctx->w) (void)hipFree(ctx->w);
+        if (ctx->w8) (void)hipFree(ctx->w8);
     }
+    ctx->w8_main = nullptr;
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     ctx->like_w = ctx->w_main = nullptr;
     ctx->wcum = nullptr;
     ctx->cols = owner->cols;
     ctx->w = owner->w;
+    ctx->w8 = owner->w8;
     ctx->w_integral = owner->w_integral;
     ctx->N = owner->N;
     ctx->n = owner->n;

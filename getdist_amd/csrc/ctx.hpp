@@ -27,6 +27,8 @@ struct gd_ctx {
     double* cols = nullptr;
     double* w = nullptr;  // nullptr => unit weights
     bool w_integral = false;  // all weights are non-negative integers with sum < 2^32 (MCMC multiplicities)
+    unsigned char* w8 = nullptr;       // the same multiplicities as bytes when none exceeds 255 (k_hist2d_u16)
+    unsigned char* w8_main = nullptr;  // parked while auxiliary weights are selected
     // mean-likelihood weights (gd_like_weights / gd_select_weights): while selected, `w` points at like_w and the
     // sample weights wait in w_main
     double* like_w = nullptr;

@@ -240,6 +240,32 @@ def test_integer_weights_take_exact_u32_path(ctx):
     assert np.allclose(H2, np.bincount(ix + iy * F, weights=w2, minlength=F * F).reshape(F, F), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("wmax", [6, 200, 300])
+def test_byte_multiplicities_in_the_packed_binning(ctx, wmax):
+    """
+    Integer weights <= 255 ride through the batched 16-bit packed binning as one byte per sample (wmax 6, 200: the
+    second overflows counters and must be detected against the accepted WEIGHT and redone); anything larger (300) keeps
+    the u32 path.  All exact.
+    """
+    r = np.random.default_rng(13)
+    N = 300_011
+    cols = [np.where(r.random(N) < 0.5, 0.25, r.random(N))] + [r.random(N) for _ in range(6)]
+    s = np.column_stack(cols)
+    w = r.integers(0, wmax + 1, N).astype(float)
+    ctx.upload(s, w)
+    F = 256
+    pre = [ctx.prebin(c, -0.001, 1.002 / (F - 1), F) for c in range(s.shape[1])]
+    pairs = [(a, b) for a in range(7) for b in range(7) if a != b] * 7  # 294 pairs: the batched path
+    H = ctx.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F).to_host((len(pairs), F, F))
+    idx = [((s[:, c] + 0.001) / (1.002 / (F - 1)) + 0.5).astype(int) for c in range(s.shape[1])]
+    for k, (a, b) in enumerate(pairs[:42]):
+        ref = np.bincount(idx[a] + idx[b] * F, weights=w, minlength=F * F).reshape(F, F)
+        assert np.array_equal(H[k], ref), (wmax, a, b, H[k].max(), ref.max())
+    assert np.array_equal(H[:42], H[42:84])
+    if wmax == 200:
+        assert H.max() > 65535  # a counter did wrap and was redone
+
+
 @pytest.mark.parametrize("weights", ["unit", "integer"])
 def test_quantiles_with_ties_take_the_radix_fallback(weights):
     """
