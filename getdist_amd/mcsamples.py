@@ -2184,6 +2184,17 @@ class MCSamples:
                 axes[key] = (a, a[1] - a[0])
             return axes[key]
 
+        bits_cache = {}
+
+        def par_bits(j):
+            """(flag bits as the x parameter, as the y parameter, has_limits): edge masks only on non-periodic axes
+            (mcsamples.py:1688-1703); bits 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic."""
+            if j not in bits_cache:
+                p = names[j]
+                lim = 0 if p.periodic else (1 if p.has_limits_bot else 0) | (2 if p.has_limits_top else 0)
+                bits_cache[j] = (lim | (16 if p.periodic else 0), (lim << 2) | (32 if p.periodic else 0), bool(p.has_limits))
+            return bits_cache[j]
+
         def run_class(F, d_hist, members, stage):
             """Convolve the pairs of one grid-size class that belong to ``stage`` (0: bandwidth known now,
             1: bandwidth arrives from the host TNC pool)."""
@@ -2192,18 +2203,9 @@ class MCSamples:
                 if (0 if ready[k] else 1) != stage:
                     continue
                 e = info[k]
-                parx, pary = e["parx"], e["pary"]
-                # edge masks only on non-periodic axes (mcsamples.py:1688-1703); bit 6 = has_prior (:1794)
-                flags = 0
-                if not parx.periodic:
-                    flags |= (1 if parx.has_limits_bot else 0) | (2 if parx.has_limits_top else 0)
-                if not pary.periodic:
-                    flags |= (4 if pary.has_limits_bot else 0) | (8 if pary.has_limits_top else 0)
-                flags |= (16 if parx.periodic else 0) | (32 if pary.periodic else 0)
-                has_prior = bool(parx.has_limits or pary.has_limits or mask_function is not None)  # mcsamples.py:1794
-                if has_prior:
-                    flags |= 64
-                e["flags"] = flags
+                bx, by = par_bits(e["j"]), par_bits(e["j2"])
+                has_prior = bx[2] or by[2] or mask_function is not None  # mcsamples.py:1794
+                e["flags"] = flags = bx[0] | by[1] | (64 if has_prior else 0)
                 smooth_scale = float(max(rx[k], ry[k]))
                 if smooth_scale < 2:
                     logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", e["parx"].name,
