@@ -195,6 +195,7 @@ class Context:
         self.weighted = False
         self._pinned = []  # (ptr, nbytes, ctypes buffer): page-locked result buffers, recycled when unreferenced
         self._free_blocks = []  # (device ptr, capacity) returned by DevBuf.free(), reused by alloc()
+        self._pinned_blocks = []
 
     PINNED_POOL_LIMIT = 8 << 30
 
@@ -222,6 +223,16 @@ class Context:
         buf = self._pinned[best][2]
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def pinned_block(self, shape, dtype=np.float64):
+        """A page-locked array outside the recycling pool (freed with the context): the landing buffer of the binary
+        chain cache, from which the sample columns are DMA'd to the device."""
+        nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 8)
+        p = _p()
+        self._check(self.lib.gd_host_alloc(self.h, nbytes, C.byref(p)))
+        buf = (C.c_ubyte * nbytes).from_address(p.value)
+        self._pinned_blocks.append(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def reserve_pinned_twin(self):
         """Allocate a second block for every pooled page-locked block (callers that keep one result set alive while
         computing the next need two sets; doing it up front keeps hipHostMalloc out of the steady state)."""
@@ -236,6 +247,9 @@ class Context:
             for ptr, _, _ in getattr(self, "_pinned", []):
                 self.lib.gd_host_free(self.h, ptr)
             self._pinned = []
+            for ptr in getattr(self, "_pinned_blocks", []):
+                self.lib.gd_host_free(self.h, ptr)
+            self._pinned_blocks = []
             self.lib.gd_destroy(self.h)
             self.h = None
 

@@ -34,6 +34,8 @@ def chainFiles(root, chain_indices=None, ext=".txt", separator="_", first_chain=
 
 def loadNumpyTxt(fname, skiprows=None):
     """chains.py:115-125: a 2D float array from a whitespace-separated text file (``#`` comments allowed)."""
+    if os.path.getsize(fname) == 0:
+        return np.zeros((0, 0))
     try:
         import pandas as pd
 
@@ -77,55 +79,119 @@ def readRanges(fname):
     return ranges
 
 
-def loadMCSamples(file_root, settings=None, ignore_rows=None, chain_exclude=None, device=0, **kwargs):
+CACHE_MAGIC = b"GDAMDSOA1\n"
+CACHE_ALIGN = 4096
+
+
+def cache_path(file_root):
+    return file_root + ".gdamd_soa"
+
+
+def write_soa_cache(path, chains):
     """
-    mcsamples.py:47-146 for the plain-text format: read every chain file of ``file_root``, drop ``ignore_rows`` rows
-    (a count if >= 1, else a fraction of each chain) as burn-in, delete the parameters that never move
-    (chains.py:1029-1045), name / bound the rest from the side files and return an MCSamples holding the chains.
+    Binary chain cache (the role of the reference's ``.py_mcsamples`` pickle, mcsamples.py:83-126, in a layout made for
+    the device): magic, one JSON header line (rows per chain, columns), zero padding to a 4096-byte boundary, then the
+    stacked chain rows as ONE column-major fp64 block -- column 0 = weight, 1 = -log(posterior), 2.. = parameters --
+    i.e. exactly the SoA layout of the device (ctx.hpp), so a load is one sequential read into page-locked memory
+    followed by per-column DMA with no transpose and no text parse.
     """
-    from .mcsamples import MCSamples, WeightedSampleError
+    import json
+
+    rows = [int(c.shape[0]) for c in chains]
+    ncol = int(chains[0].shape[1])
+    head = json.dumps(dict(rows=rows, ncol=ncol, dtype="<f8")).encode() + b"\n"
+    pad = (-(len(CACHE_MAGIC) + len(head))) % CACHE_ALIGN
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(CACHE_MAGIC + head + b"\0" * pad)
+        for j in range(ncol):
+            for c in chains:
+                np.ascontiguousarray(c[:, j], dtype="<f8").tofile(f)
+    os.replace(tmp, path)
+
+
+def read_soa_cache(path, alloc=None):
+    """(column-major (N, ncol) array, rows per chain) from a cache file.  ``alloc(shape, dtype)`` supplies the host
+    buffer (page-locked memory from the device context); the file is read straight into it."""
+    import json
+
+    with open(path, "rb") as f:
+        if f.read(len(CACHE_MAGIC)) != CACHE_MAGIC:
+            raise ValueError("not a getdist_amd chain cache: " + path)
+        head = json.loads(f.readline().decode())
+        pos = f.tell()
+        f.seek(pos + (-pos) % CACHE_ALIGN)
+        N, ncol = int(sum(head["rows"])), int(head["ncol"])
+        flat = alloc((N * ncol,), np.float64) if alloc is not None else np.empty(N * ncol)
+        got = f.readinto(memoryview(flat).cast("B"))
+        if got != N * ncol * 8:
+            raise ValueError("truncated chain cache: " + path)
+    return flat.reshape((ncol, N)).T, head["rows"]
+
+
+def read_root(file_root, chain_exclude=None, no_cache=False, alloc=None):
+    """
+    Everything ``MCSamples(root=...)`` / ``loadMCSamples`` read from disk (mcsamples.py:47-146, chains.py:1368-1405):
+    the chain files (or the binary cache when it is newer than all of them), ``.paramnames`` and ``.ranges``.
+    Returns dict(samples=[per-chain (rows, n)], weights=[...], loglikes=[...], names, labels, derived, ranges,
+    from_cache).  No burn-in is removed here.
+    """
+    from .mcsamples import WeightedSampleError
 
     files = chainFiles(file_root, chain_exclude=chain_exclude) or chainFiles(file_root, separator=".", chain_exclude=chain_exclude)
     if not files:
-        raise WeightedSampleError("loadChains - no chains found for " + file_root)
-    if ignore_rows is None:
-        ignore_rows = float((settings or {}).get("ignore_rows", 0))
-    chains = []
-    for fname in files:
-        cols = loadNumpyTxt(fname, skiprows=int(ignore_rows) if ignore_rows >= 1 else None)
-        if cols.shape[0] == 0 or cols.shape[1] < 3:
-            continue  # "Ignored file (likely empty)" (chains.py:1400-1403)
-        if 0 < ignore_rows < 1:
-            cols = cols[int(round(cols.shape[0] * ignore_rows)):]
-        chains.append(cols)
-    if not chains:
-        raise WeightedSampleError("loadChains - no chains found for " + file_root)
+        raise OSError("No chains found: " + file_root)
+    if chain_exclude:
+        no_cache = True  # mcsamples.py:73-74
+    cpath = cache_path(file_root)
+    chains = None
+    from_cache = False
+    if not no_cache and os.path.isfile(cpath) and max(os.path.getmtime(f) for f in files) < os.path.getmtime(cpath):
+        try:
+            block, rows = read_soa_cache(cpath, alloc)
+            offs = np.cumsum([0] + list(rows))
+            chains = [block[a:b] for a, b in zip(offs[:-1], offs[1:])]
+            from_cache = True
+        except (ValueError, OSError, KeyError):
+            chains = None
+    if chains is None:
+        chains = []
+        for fname in files:
+            cols = loadNumpyTxt(fname)
+            if cols.shape[0] == 0 or cols.shape[1] < 3:
+                continue  # "Ignored file (likely empty)" (chains.py:1400-1403)
+            chains.append(cols)
+        if not chains:
+            raise WeightedSampleError("loadChains - no chains found for " + file_root)
+        if not no_cache:
+            try:
+                write_soa_cache(cpath, chains)
+            except OSError:
+                pass  # read-only chain directory: the cache is an optimisation only
     n = chains[0].shape[1] - 2
-    names = labels = derived = None
+    labels = derived = None
     if os.path.isfile(file_root + ".paramnames"):
         names, labels, derived = readParamNames(file_root + ".paramnames")
         if len(names) != n:
             raise WeightedSampleError("paramnames file does not match the number of chain columns")
     else:
         names = ["param%d" % (i + 1) for i in range(n)]
-    # deleteFixedParams over the combined set (chains.py:1029-1045)
-    allrows = np.vstack([c[:, 2:] for c in chains]) if len(chains) > 1 else chains[0][:, 2:]
-    keep = []
-    for i in range(n):
-        col = allrows[:, i]
-        fixed = np.isclose(col[0], col[-1], equal_nan=True) and np.allclose(col, np.average(col), rtol=1e-12, atol=0, equal_nan=True)
-        if not fixed:
-            keep.append(i)
-    kept_names = [names[i] for i in keep]
     ranges = readRanges(file_root + ".ranges") if os.path.isfile(file_root + ".ranges") else {}
-    s = {k: v for k, v in (settings or {}).items() if k != "ignore_rows"}
-    mc = MCSamples(samples=[np.asfortranarray(c[:, 2:][:, keep]) for c in chains], weights=[c[:, 0] for c in chains],
-                   loglikes=[c[:, 1] for c in chains], names=kept_names,
-                   labels=None if labels is None else [labels[i] for i in keep],
-                   ranges={k: v for k, v in ranges.items() if k in kept_names}, settings=s or None, device=device,
-                   name_tag=os.path.basename(file_root), **kwargs)
-    if derived is not None:
-        for par, i in zip(mc.paramNames.names, keep):
-            par.isDerived = derived[i]
-    mc.root = file_root
-    return mc
+    return dict(samples=[c[:, 2:] for c in chains], weights=[c[:, 0] for c in chains], loglikes=[c[:, 1] for c in chains],
+                names=names, labels=labels, derived=derived, ranges={k: v for k, v in ranges.items() if k in names},
+                from_cache=from_cache)
+
+
+def loadMCSamples(file_root, ini=None, jobItem=None, no_cache=False, settings=None, chain_exclude=None, **kwargs):
+    """
+    mcsamples.py:47-126: an MCSamples from the chain files of ``file_root`` (``ignore_rows`` burn-in per chain --
+    a row count if >= 1, else a fraction --, per-chain minimum-weight filter, deletion of the parameters that do not
+    move, names / labels / derived flags and hard bounds from the side files).  The first load writes the binary
+    column cache next to the chains; later loads stream it (``no_cache`` or ``chain_exclude`` bypass it, as in the
+    reference).
+    """
+    from .mcsamples import MCSamples
+
+    if jobItem is not None:
+        raise NotImplementedError("grid job items are outside the accelerated path")
+    return MCSamples(root=file_root, ini=ini, settings=settings, _chain_exclude=chain_exclude, _no_cache=no_cache, **kwargs)

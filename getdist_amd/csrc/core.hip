@@ -267,6 +267,62 @@ int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* 
     return GD_OK;
 }
 
+// Builds the new sample set in locals; the context is only touched once everything has succeeded, so a failed upload
+// leaves it EMPTY (cols == nullptr, N == 0), never half-initialised.
+static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
+                        const double* weights, int64_t ld, double** cols_out, double** w_out, unsigned char** w8_out,
+                        bool* integral_out) {
+    double*& cols = *cols_out;
+    double*& w = *w_out;
+    unsigned char*& w8 = *w8_out;
+    GD_HIP(hipMalloc((void**)&cols, (size_t)(ld * (n + GD_EXTRA_COLS) * 8)));
+    GD_HIP(hipMemsetAsync(cols + ld * n, 0, (size_t)(ld * GD_EXTRA_COLS * 8), ctx->stream));
+    if (row_stride == 1) {
+        // column-major host input: one contiguous copy per column
+        for (int64_t j = 0; j < n; ++j)
+            GD_HIP(hipMemcpyAsync(cols + j * ld, X + j * col_stride, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        GD_REQUIRE(col_stride == 1 && row_stride >= n, "samples must be C- or Fortran-contiguous");
+        // stage row blocks through scratch and transpose on the device
+        const int64_t rows_per = 4 << 20;  // 4M rows x n x 8 B per staged block
+        for (int64_t r0 = 0; r0 < N; r0 += rows_per) {
+            int64_t nr = (N - r0 < rows_per) ? N - r0 : rows_per;
+            double* stage = (double*)gd_scratch(ctx, nr * row_stride * 8);
+            if (!stage) return GD_ERR_NOMEM;
+            GD_HIP(hipMemcpyAsync(stage, X + r0 * row_stride, (size_t)(nr * row_stride * 8), hipMemcpyHostToDevice,
+                                  ctx->stream));
+            dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((n + 31) / 32)), block(32, 8);
+            transpose_rows_to_cols<<<grid, block, 0, ctx->stream>>>(stage, nr, n, row_stride, cols + r0, ld);
+            GD_KERNEL_CHECK();
+            GD_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    *integral_out = false;
+    if (weights) {
+        GD_HIP(hipMalloc((void**)&w, (size_t)(ld * 8)));
+        GD_HIP(hipMemcpyAsync(w, weights, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
+        char* chk = (char*)gd_scratch(ctx, 256);
+        if (!chk) return GD_ERR_NOMEM;
+        GD_HIP(hipMemsetAsync(chk, 0, 256, ctx->stream));
+        k_weights_integral<<<1024, 256, 0, ctx->stream>>>(w, N, (int*)chk, (double*)(chk + 128));
+        GD_KERNEL_CHECK();
+        int bad = 1;
+        double sum = 0;
+        GD_HIP(hipMemcpyAsync(&bad, chk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipMemcpyAsync(&sum, chk + 128, 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        *integral_out = ((bad & 1) == 0) && sum < 4.0e9;
+        if (*integral_out && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
+            GD_HIP(hipMalloc((void**)&w8, (size_t)ld));
+            GD_HIP(hipMemsetAsync(w8, 0, (size_t)ld, ctx->stream));
+            k_weights_to_u8<<<1024, 256, 0, ctx->stream>>>(w, N, w8);
+            GD_KERNEL_CHECK();
+        }
+    }
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
 int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
               const double* weights) {
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
@@ -285,54 +341,24 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     ctx->wcum = nullptr;
     ctx->cols = ctx->w = ctx->like_w = ctx->w_main = nullptr;
     ctx->w_sel = 0;
+    ctx->w_integral = false;
     ctx->N = ctx->n = ctx->ld = 0;
     const int64_t ld = (N + 511) / 512 * 512;
-    GD_HIP(hipMalloc((void**)&ctx->cols, (size_t)(ld * (n + GD_EXTRA_COLS) * 8)));
-    GD_HIP(hipMemsetAsync(ctx->cols + ld * n, 0, (size_t)(ld * GD_EXTRA_COLS * 8), ctx->stream));
-    if (row_stride == 1) {
-        // column-major host input: one contiguous copy per column
-        for (int64_t j = 0; j < n; ++j)
-            GD_HIP(hipMemcpyAsync(ctx->cols + j * ld, X + j * col_stride, (size_t)(N * 8), hipMemcpyHostToDevice,
-                                  ctx->stream));
-    } else {
-        GD_REQUIRE(col_stride == 1 && row_stride >= n, "samples must be C- or Fortran-contiguous");
-        // stage row blocks through scratch and transpose on the device
-        const int64_t rows_per = 4 << 20;  // 4M rows x n x 8 B per staged block
-        for (int64_t r0 = 0; r0 < N; r0 += rows_per) {
-            int64_t nr = (N - r0 < rows_per) ? N - r0 : rows_per;
-            double* stage = (double*)gd_scratch(ctx, nr * row_stride * 8);
-            if (!stage) return GD_ERR_NOMEM;
-            GD_HIP(hipMemcpyAsync(stage, X + r0 * row_stride, (size_t)(nr * row_stride * 8), hipMemcpyHostToDevice,
-                                  ctx->stream));
-            dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((n + 31) / 32)), block(32, 8);
-            transpose_rows_to_cols<<<grid, block, 0, ctx->stream>>>(stage, nr, n, row_stride, ctx->cols + r0, ld);
-            GD_KERNEL_CHECK();
-            GD_HIP(hipStreamSynchronize(ctx->stream));
-        }
+    double *cols = nullptr, *w = nullptr;
+    unsigned char* w8 = nullptr;
+    bool integral = false;
+    const int rc = upload_build(ctx, X, N, n, row_stride, col_stride, weights, ld, &cols, &w, &w8, &integral);
+    if (rc != GD_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (cols) (void)hipFree(cols);
+        if (w) (void)hipFree(w);
+        if (w8) (void)hipFree(w8);
+        return rc;
     }
-    ctx->w_integral = false;
-    if (weights) {
-        GD_HIP(hipMalloc((void**)&ctx->w, (size_t)(ld * 8)));
-        GD_HIP(hipMemcpyAsync(ctx->w, weights, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
-        char* chk = (char*)gd_scratch(ctx, 256);
-        if (!chk) return GD_ERR_NOMEM;
-        GD_HIP(hipMemsetAsync(chk, 0, 256, ctx->stream));
-        k_weights_integral<<<1024, 256, 0, ctx->stream>>>(ctx->w, N, (int*)chk, (double*)(chk + 128));
-        GD_KERNEL_CHECK();
-        int bad = 1;
-        double sum = 0;
-        GD_HIP(hipMemcpyAsync(&bad, chk, 4, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipMemcpyAsync(&sum, chk + 128, 8, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->w_integral = ((bad & 1) == 0) && sum < 4.0e9;
-        if (ctx->w_integral && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
-            GD_HIP(hipMalloc((void**)&ctx->w8, (size_t)ld));
-            GD_HIP(hipMemsetAsync(ctx->w8, 0, (size_t)ld, ctx->stream));
-            k_weights_to_u8<<<1024, 256, 0, ctx->stream>>>(ctx->w, N, ctx->w8);
-            GD_KERNEL_CHECK();
-        }
-    }
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->cols = cols;
+    ctx->w = w;
+    ctx->w8 = w8;
+    ctx->w_integral = integral;
     ctx->N = N;
     ctx->n = n;
     ctx->ld = ld;

@@ -30,7 +30,7 @@ from .densities import Density1D, Density2D, DensitiesError
 
 # analysis_defaults.ini:1-76 (the ini always overrides the class literals, mcsamples.py:491-492)
 DEFAULT_SETTINGS = dict(
-    ignore_rows=0, min_weight_ratio=1e-30, contours=[0.68, 0.95, 0.99], credible_interval_threshold=0.05,
+    ignore_rows=0.0, min_weight_ratio=1e-30, contours=[0.68, 0.95, 0.99], credible_interval_threshold=0.05,
     range_ND_contour=-1, range_confidence=0.001, corr_length_thin=0, corr_length_steps=15, converge_test_limit=0.95, fine_bins=1024, smooth_scale_1D=-1.0,
     boundary_correction_order=1, mult_bias_correction_order=1, smooth_scale_2D=-1.0, max_corr_2D=0.99,
     fine_bins_2D=256, use_effective_samples_2D=False, max_scatter_points=2000, num_bins=100, num_bins_2D=40)
@@ -138,6 +138,10 @@ class ParamNames:
     def numNonDerived(self):
         return len([p for p in self.names if not p.isDerived])
 
+    def deleteIndices(self, indices):
+        gone = set(indices)
+        self.names = [p for i, p in enumerate(self.names) if i not in gone]
+
 
 class ParamBounds:
     """Hard prior ranges and periodic flags (parampriors.py:6-139, the parts the hot path uses)."""
@@ -156,6 +160,14 @@ class ParamBounds:
                 store.pop(name, None)
             else:
                 store[name] = float(v)
+
+    def setFixed(self, name, value):
+        """parampriors.py:78-79: a fixed parameter is a zero-width range"""
+        self.lower[name] = self.upper[name] = float(value)
+
+    def fixedValue(self, name):
+        lo, hi = self.lower.get(name), self.upper.get(name)
+        return lo if lo is not None and lo == hi else None
 
     def getLower(self, name):
         return self.lower.get(name)
@@ -254,6 +266,56 @@ def _get_h(psi, N, corr_in, do_correlation):
     except Exception:
         logging.debug("AMISE optimization failed")
     return h_x, h_y, corr
+
+
+def _read_ini_settings(ini):
+    """
+    The analysis settings of a GetDist .ini file (``key = value`` lines, ``#`` comments; inifile.py:100-180) that this
+    path knows; other keys (plot options, file lists) are ignored like the reference ignores what it does not read.
+    A dict is passed through.
+    """
+    if isinstance(ini, dict):
+        return {k: v for k, v in ini.items() if k in DEFAULT_SETTINGS}
+    out = {}
+    with open(ini, encoding="utf-8-sig") as f:
+        for line in f:
+            line = line.split("#", 1)[0].strip()
+            if "=" not in line:
+                continue
+            key, value = (t.strip() for t in line.split("=", 1))
+            if key in DEFAULT_SETTINGS and value != "":
+                out[key] = [float(v) for v in value.split()] if key == "contours" else value
+    return out
+
+
+def _stack_rows(parts):
+    """
+    np.vstack / np.hstack of per-chain arrays.  Chains that are consecutive row ranges of one column-major block (the
+    binary chain cache, chainfiles.read_soa_cache) are returned as a view of that block -- no host copy, and the
+    page-locked columns go to the device as they are; anything else is copied into a new column-major array.
+    """
+    first = parts[0]
+    if len(parts) == 1:
+        return first
+    adjacent = all(p.dtype == np.float64 and p.strides == first.strides and p.shape[1:] == first.shape[1:] for p in parts)
+    if adjacent:
+        addr = first.ctypes.data
+        for p in parts:
+            if p.ctypes.data != addr:
+                adjacent = False
+                break
+            addr += p.shape[0] * p.strides[0]
+        adjacent = adjacent and first.strides[0] == 8
+    total = sum(p.shape[0] for p in parts)
+    if adjacent:
+        shape = (total,) + first.shape[1:]
+        return np.lib.stride_tricks.as_strided(first, shape=shape, strides=first.strides, writeable=False)
+    out = np.empty((total,) + first.shape[1:], dtype=np.float64, order="F")
+    a = 0
+    for p in parts:
+        out[a:a + p.shape[0]] = p
+        a += p.shape[0]
+    return out
 
 
 _POOL = None
@@ -482,53 +544,73 @@ class MCSamples:
     """
 
     def __init__(self, root=None, ini=None, settings=None, ranges=None, samples=None, weights=None, loglikes=None,
-                 temperature=None, names=None, labels=None, label=None, name_tag=None, sampler=None, ignore_rows=0,
-                 device=0, _context_factory=None, **kwargs):
-        if root is not None or ini is not None:
-            raise NotImplementedError("chain-file / ini loading is outside the accelerated path; pass arrays")
-        if samples is None:
-            raise MCSamplesError("samples are required")
+                 temperature=None, names=None, labels=None, label=None, name_tag=None, sampler=None, device=0,
+                 _context_factory=None, **kwargs):
         self.sampler = sampler or "mcmc"
         self.label, self.name_tag = label, name_tag
+        self.root = root
         self.raise_on_bandwidth_errors = False
         self.chain_offsets = None
-        if isinstance(samples, (list, tuple)) and len(samples) and np.ndim(samples[0]) == 2:
-            # list of chains (chains.py:1488-1503 makeSingle)
-            self.chain_offsets = np.cumsum(np.array([0] + [np.shape(c)[0] for c in samples]))
-            if weights is not None:
-                weights = np.hstack(list(weights))
-            if loglikes is not None:
-                loglikes = np.hstack(list(loglikes))
-            samples = np.vstack(list(samples))
-        samples = np.asarray(samples)
-        if samples.ndim == 1:
-            samples = samples.reshape(-1, 1)
-        if ignore_rows:
-            k = int(ignore_rows) if ignore_rows >= 1 else int(round(ignore_rows * samples.shape[0]))
-            samples = samples[k:]
-            weights = None if weights is None else np.asarray(weights)[k:]
-            loglikes = None if loglikes is None else np.asarray(loglikes)[k:]
-        self.samples = samples
-        self.loglikes = None if loglikes is None else np.asarray(loglikes, dtype=np.float64)
-        self.numrows, self.n = samples.shape
-        self._user_weights = weights is not None
-        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
-        if names is None:
-            names = ["param%d" % (i + 1) for i in range(self.n)]
-        if len(names) != self.n:
-            raise MCSamplesError("names do not match the number of sample columns")
-        self.paramNames = ParamNames(list(names), labels)
-        self.index = {nm: i for i, nm in enumerate(names)}
-        self.ranges = ParamBounds()
-        for nm, rng in (ranges or {}).items():
-            self.ranges.setRange(nm, rng)
+        self.chains = None
+        self.ctx = None
         for k, v in DEFAULT_SETTINGS.items():
             setattr(self, k, v)
+        if "ignore_rows" in kwargs:  # mcsamples.py:246-250: the keyword is a setting
+            settings = dict(settings or {})
+            settings["ignore_rows"] = kwargs.pop("ignore_rows")
+        chain_exclude, no_cache = kwargs.pop("_chain_exclude", None), kwargs.pop("_no_cache", False)
+        if kwargs:
+            raise TypeError("unexpected keyword arguments: %s" % ", ".join(kwargs))
+        if ini is not None:
+            settings = dict(_read_ini_settings(ini), **(settings or {}))  # the dict takes preference (:472-499)
         if settings:
             self.updateSettings(settings, doUpdate=False)
+        if self.sampler == "nested" and not np.isclose(self.ignore_rows, 0):
+            raise ValueError("Should not remove burn-in from Nested Sampler samples.")
+        self.ranges = ParamBounds()
+        derived = None
+        if root is not None and samples is None:
+            # mcsamples.py:47-146, chains.py:1368-1405: the chain files, side files and (when fresh) the binary cache
+            from . import chainfiles
+
+            self.ctx = (_context_factory or Context)(device)  # page-locked landing buffer for the binary cache
+            loaded = chainfiles.read_root(root, chain_exclude, no_cache,
+                                          alloc=getattr(self.ctx, "pinned_block", None))
+            samples, weights, loglikes = loaded["samples"], loaded["weights"], loaded["loglikes"]
+            names = names or loaded["names"]
+            labels = labels or loaded["labels"]
+            derived = loaded["derived"]
+            for nm, rng in loaded["ranges"].items():
+                self.ranges.setRange(nm, rng)
+            self.name_tag = self.name_tag or os.path.basename(root)
+        ignore_lines = int(self.ignore_rows)
+        if samples is None:
+            raise MCSamplesError("samples are required")
+        for nm, rng in (ranges or {}).items():
+            self.ranges.setRange(nm, rng)
+        samples, weights, loglikes, fixed = self._read_chains(samples, weights, loglikes, ignore_lines)
+        self.samples = samples
+        self.loglikes = loglikes
+        self.numrows, n_all = samples.shape[0], samples.shape[1] + len(fixed)
+        self._user_weights = weights is not None
+        self.weights = weights
+        if names is None:
+            names = ["param%d" % (i + 1) for i in range(n_all)]
+        if len(names) != n_all:
+            raise MCSamplesError("names do not match the number of sample columns")
+        self.paramNames = ParamNames(list(names), labels)
+        if derived is not None:
+            for par, d in zip(self.paramNames.names, derived):
+                par.isDerived = bool(d)
+        for ix, value in fixed:  # chains.py:1555-1559: a parameter that never moves becomes a zero-width range
+            self.ranges.setFixed(self.paramNames.names[ix].name, value)
+        self.paramNames.deleteIndices([ix for ix, _ in fixed])
+        self.n = samples.shape[1]
+        self.index = {p.name: i for i, p in enumerate(self.paramNames.names)}
         # _context_factory is a TEST hook (tests/fake_ctx.py drives the host logic on CPU); the product always uses
         # the HIP library and raises if it or a GPU is missing
-        self.ctx = (_context_factory or Context)(device)
+        if getattr(self, "ctx", None) is None:
+            self.ctx = (_context_factory or Context)(device)
         self._timing = os.environ.get("GETDIST_AMD_TIMING", "0") == "1"
         self.timings = {}
         self.density1D = {}
@@ -540,9 +622,67 @@ class MCSamples:
         self._helper_exec = None
         self._lane_exec = None
         self._twin = None
+        self._chain_stats_cache = {}
         self.needs_update = True
-        self._upload()
+        self._upload(filter_weights=False)  # the per-chain filter already ran (makeSingle passes min_weight_ratio=-1)
         self.updateBaseStatistics()
+
+    def _read_chains(self, samples, weights, loglikes, ignore_lines):
+        """
+        loadChains + readChains for array input (chains.py:1405-1443, mcsamples.py:501-528): per chain, drop
+        ``ignore_lines`` leading rows, drop rows below min_weight_ratio of THAT chain's maximum weight
+        (chains.py:1017-1027), drop the burn-in fraction (chains.py:1047-1061); delete the parameters that do not move
+        (decided on the first chain, chains.py:1029-1045,1548-1555); stack the chains and record their offsets
+        (makeSingle, chains.py:1488-1503).  Returns (samples, weights, loglikes, [(fixed column, value)]).
+        """
+        is_list = isinstance(samples, (list, tuple)) and len(samples) and np.ndim(samples[0]) == 2
+        if is_list:
+            chains = [[np.asarray(c), None if weights is None else np.asarray(weights[i], dtype=np.float64),
+                       None if loglikes is None else np.asarray(loglikes[i], dtype=np.float64)]
+                      for i, c in enumerate(samples)]
+        else:
+            if isinstance(samples, (list, tuple)):  # a list of parameter vectors (chains.py:287-288)
+                samples = np.hstack([np.asarray(x).reshape(-1, 1) for x in samples])
+            samples = np.asarray(samples)
+            if samples.ndim == 1:
+                samples = samples.reshape(-1, 1)
+            chains = [[samples, None if weights is None else np.asarray(weights, dtype=np.float64),
+                       None if loglikes is None else np.asarray(loglikes, dtype=np.float64)]]
+        ignore_frac = 0 if int(self.ignore_rows) else self.ignore_rows
+        mwr = self.min_weight_ratio
+        for ch in chains:
+            if ignore_lines:
+                ch[:] = [None if v is None else v[ignore_lines:] for v in ch]
+            w = ch[1]
+            if w is not None and mwr is not None and mwr >= 0 and w.size:
+                mx = np.max(w)
+                if np.min(w) < mx * mwr:
+                    keep = w > mx * mwr
+                    ch[:] = [None if v is None else v[keep] for v in ch]
+            if ignore_frac:
+                ix = int(ignore_frac) if ignore_frac >= 1 else int(round(ch[0].shape[0] * ignore_frac))
+                ch[:] = [None if v is None else v[ix:] for v in ch]
+        first = chains[0][0]
+        fixed = []
+        if first.shape[0]:
+            for i in range(first.shape[1]):
+                if np.isclose(first[0, i], first[-1, i], equal_nan=True):
+                    mean = np.average(first[:, i])
+                    if np.allclose(first[:, i], mean, rtol=1e-12, atol=0, equal_nan=True):
+                        fixed.append((i, mean))
+        if fixed:
+            gone = [i for i, _ in fixed]
+            for ch in chains:
+                ch[0] = np.delete(ch[0], gone, 1)
+        if is_list:
+            self.chain_offsets = np.cumsum(np.array([0] + [ch[0].shape[0] for ch in chains]))
+            samples = _stack_rows([ch[0] for ch in chains])
+            weights = None if chains[0][1] is None else _stack_rows([ch[1] for ch in chains])
+            loglikes = None if chains[0][2] is None else _stack_rows([ch[2] for ch in chains])
+        else:
+            samples, weights, loglikes = chains[0]
+        weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        return samples, weights, loglikes, fixed
 
     # ---- state -----------------------------------------------------------------------------------------
     def _helper(self):
@@ -597,11 +737,14 @@ class MCSamples:
             self._twin = None
         self._nlanes = 1
 
-    def _upload(self):
-        """(Re)build the device mirror of samples/weights (chains.py:276-323 funnel)."""
+    def _upload(self, filter_weights=True):
+        """(Re)build the device mirror of samples/weights (chains.py:276-323 funnel).  The min-weight filter of
+        setSamples applies to a single sample array only: chain lists are filtered per chain before they are stacked."""
         self._drop_second_lane()
+        self._chain_stats_cache = {}
         w = self.weights
-        if w is not None and self.min_weight_ratio is not None and self.min_weight_ratio >= 0:
+        if (filter_weights and self.chain_offsets is None and w is not None and self.min_weight_ratio is not None
+                and self.min_weight_ratio >= 0):
             mx, mn = np.max(w), np.min(w)  # chains.py:1017-1027
             if mn < mx * self.min_weight_ratio:
                 keep = w > mx * self.min_weight_ratio
@@ -1002,9 +1145,9 @@ class MCSamples:
         return autocorr_thin, corrs[:maxoff]
 
     def updateSettings(self, settings=None, ini=None, doUpdate=True):
-        """mcsamples.py:472-499 (settings dict only)"""
+        """mcsamples.py:472-499: analysis settings from a dict and / or a .ini file (the dict takes preference)"""
         if ini is not None:
-            raise NotImplementedError("ini files are outside the accelerated path; pass a settings dict")
+            settings = dict(_read_ini_settings(ini), **(settings or {}))
         for k, v in (settings or {}).items():
             if k not in DEFAULT_SETTINGS:
                 raise SettingError("unknown setting: %s" % k)
@@ -2349,21 +2492,45 @@ class MCSamples:
 
     # ---- convergence (chains.py:1446-1527; mcsamples.py:964-1003) ------------------------------------------
     def getSeparateChainStats(self, nparam=None):
-        """Per-chain (means, cov, norm) over the first nparam parameters, one covariance launch per chain."""
+        """Per-chain (means, cov, norm) over the first nparam parameters: one covariance launch per chain over ALL
+        columns, cached until the samples change, so Gelman-Rubin, MeanVar, CorrLengths and CorrSteps share one pass."""
         if self.chain_offsets is None:
             raise WeightedSampleError("Samples were not combined from separate chains")
         nparam = nparam or self.paramNames.numNonDerived()
-        cols = list(range(nparam))
-        return [self.ctx.cov(cols, lo=int(a), hi=int(b)) for a, b in zip(self.chain_offsets[:-1], self.chain_offsets[1:])]
+        if "all" not in self._chain_stats_cache:
+            cols = list(range(self.n))
+            self._chain_stats_cache["all"] = [self.ctx.cov(cols, lo=int(a), hi=int(b))
+                                              for a, b in zip(self.chain_offsets[:-1], self.chain_offsets[1:])]
+        return [(m[:nparam], c[:nparam, :nparam], nrm) for m, c, nrm in self._chain_stats_cache["all"]]
+
+    def getSeparateChains(self):
+        """
+        chains.py:1505-1527: one object per chain.  The reference slices the host arrays into WeightedSamples; here each
+        is a ChainView -- a row range [lo, hi) of the resident device columns with the WeightedSamples statistics API
+        (getMeans / getVars / getCov / mean / var / std / cov / corr / confidence / twoTailLimits / norm), no copy.
+        """
+        if self.chain_offsets is None:
+            raise WeightedSampleError("Samples were not combined from separate chains")
+        return [ChainView(self, int(a), int(b)) for a, b in zip(self.chain_offsets[:-1], self.chain_offsets[1:])]
+
+    def makeSingle(self):
+        """chains.py:1488-1503.  The constructor already stacks a list of chains into one resident array (recording
+        chain_offsets), after which the reference's ``chains`` attribute is None and this call raises there too."""
+        if not self.chains:
+            raise ValueError("There are no separated chains for makeSingle()")
+        return self
 
     def getGelmanRubinEigenvalues(self, nparam=None, chainlist=None):
-        """chains.py:1446-1474: var(mean)/mean(var) in the orthogonalised parameters"""
-        if chainlist is not None:
-            raise NotImplementedError("explicit chain lists are outside the accelerated path")
+        """chains.py:1446-1474: var(mean)/mean(var) in the orthogonalised parameters; ``chainlist`` may be any
+        sub-list of getSeparateChains() (or objects with getMeans() / getCov(nparam))."""
         from .parallel import gelman_rubin_from_chain_stats
 
         nparam = nparam or self.paramNames.numNonDerived()
-        return gelman_rubin_from_chain_stats(self.getSeparateChainStats(nparam), self.getMeans())
+        if chainlist is None:
+            stats = self.getSeparateChainStats(nparam)
+        else:
+            stats = [(np.asarray(ch.getMeans())[:nparam], np.asarray(ch.getCov(nparam)), None) for ch in chainlist]
+        return gelman_rubin_from_chain_stats(stats, self.getMeans())
 
     def getGelmanRubin(self, nparam=None, chainlist=None):
         return np.max(self.getGelmanRubinEigenvalues(nparam, chainlist))
@@ -2380,6 +2547,97 @@ class MCSamples:
         between /= len(stats) - 1
         within /= self.norm
         return np.sqrt(between / within)
+
+
+class ChainView:
+    """
+    One chain of a combined sample set: rows [lo, hi) of the parent's device-resident columns, with the statistics
+    interface of chains.WeightedSamples (chains.py:339-412, 636-838) evaluated on that row range by the same kernels
+    (every entry point of the C ABI takes a row range).  ``samples`` / ``weights`` / ``loglikes`` are host views.
+    """
+
+    def __init__(self, parent, lo, hi):
+        self.parent, self.lo, self.hi = parent, lo, hi
+        self.numrows = hi - lo
+        self.n = parent.n
+        self.paramNames = parent.paramNames
+        self._stats = self._cov = self._ws = None
+
+    samples = property(lambda self: self.parent.samples[self.lo:self.hi])
+    weights = property(lambda self: (np.ones(self.numrows) if self.parent.weights is None
+                                     else self.parent.weights[self.lo:self.hi]))
+    loglikes = property(lambda self: None if self.parent.loglikes is None else self.parent.loglikes[self.lo:self.hi])
+
+    def _weight_stats(self):
+        if self._ws is None:
+            self._ws = self.parent.ctx.weight_stats(self.lo, self.hi)
+        return self._ws
+
+    @property
+    def norm(self):
+        return self._weight_stats()["norm"] if self.parent.weights is not None else np.float64(self.numrows)
+
+    def get_norm(self, where=None):
+        if where is not None:
+            raise NotImplementedError("row filters on a chain view")
+        return self.norm
+
+    def _col_stats(self):
+        if self._stats is None:
+            self._stats = self.parent.ctx.col_stats(self.lo, self.hi)
+        return self._stats
+
+    def getMeans(self, pars=None):
+        means = self._col_stats()[:, 2]
+        return means.copy() if pars is None else np.array([means[self.parent._col(p)] for p in pars])
+
+    def getVars(self):
+        return self._col_stats()[:, 3].copy()
+
+    def getCov(self, nparam=None, pars=None):
+        if self._cov is None:
+            self._cov = self.parent.ctx.cov(list(range(self.n)), lo=self.lo, hi=self.hi)[1]
+        if pars is not None:
+            return self._cov[np.ix_(pars, pars)]
+        return self._cov[:nparam, :nparam]
+
+    def getCorrelationMatrix(self):
+        return covToCorr(self.getCov())
+
+    def cov(self, pars=None, where=None):
+        if where is not None:
+            raise NotImplementedError("row filters on a chain view")
+        if isinstance(pars, (int, np.integer)):
+            pars = range(pars)
+        cols = list(range(self.n)) if pars is None else [self.parent._col(p) for p in pars]
+        return self.parent.ctx.cov(cols, lo=self.lo, hi=self.hi)[1]
+
+    def corr(self, pars=None):
+        return covToCorr(self.cov(pars))
+
+    def mean(self, paramVec, where=None):
+        if where is not None:
+            raise NotImplementedError("row filters on a chain view")
+        if isinstance(paramVec, (list, tuple)):
+            return np.array([self.mean(p) for p in paramVec])
+        return self._col_stats()[self.parent._col(paramVec), 2]
+
+    def var(self, paramVec, where=None):
+        if where is not None:
+            raise NotImplementedError("row filters on a chain view")
+        if isinstance(paramVec, (list, tuple)):
+            return np.array([self.var(p) for p in paramVec])
+        return self._col_stats()[self.parent._col(paramVec), 3]
+
+    def std(self, paramVec, where=None):
+        return np.sqrt(self.var(paramVec, where))
+
+    def confidence(self, paramVec, limfrac, upper=False):
+        return self.parent.confidence(paramVec, limfrac, upper, start=self.lo, end=self.hi)
+
+    def twoTailLimits(self, paramVec, confidence):
+        limits = np.array([(1 - confidence) / 2, 1 - (1 - confidence) / 2])
+        return self.confidence(paramVec, limits)
 
 
 _FFT_SIZE_CACHE = {}

@@ -107,6 +107,28 @@ def mcmc_chains_fixture(nchains=3, N=6000, n=5):
     return samples, weights, loglikes, ["m%d" % i for i in range(n)], offsets
 
 
+def ingestion_cases():
+    """Array-input cases for the per-chain ingestion pipeline: (label, kwargs for MCSamples) -- shared with the tests."""
+    rng = np.random.default_rng(4242)
+    chains = [rng.standard_normal((n, 4)) * [1, 2, 0.5, 1] + [0, 1, -1, 3] for n in (1000, 1300, 700)]
+    for c in chains:
+        c[:, 2] = 0.25  # never moves in any chain: deleted, recorded as a fixed range
+    chains[1][:, 3] = 3.0  # constant in chain 2 only: decided on chain 1, so it stays
+    w = [rng.integers(0, 5, size=c.shape[0]).astype(float) for c in chains]  # zeros included
+    w[0][:10] = 0.0
+    L = [rng.random(c.shape[0]) * 10 for c in chains]
+    names = ["a", "b", "c", "d"]
+    cases = []
+    for ign in (0, 0.3, 25):
+        cases.append(("chains ignore_rows=%s" % ign, dict(samples=chains, weights=w, loglikes=L, names=names, ignore_rows=ign)))
+        cases.append(("chains settings ignore_rows=%s" % ign, dict(samples=chains, weights=w, loglikes=L, names=names,
+                                                                   settings={"ignore_rows": ign})))
+        cases.append(("single ignore_rows=%s" % ign, dict(samples=chains[0], weights=w[0], loglikes=L[0], names=names,
+                                                          ignore_rows=ign)))
+    cases.append(("chains unweighted", dict(samples=chains, loglikes=L, names=names, ignore_rows=0.2)))
+    return cases
+
+
 def fixture_zoo():
     """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
     zoo = []

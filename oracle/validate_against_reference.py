@@ -22,7 +22,7 @@ from getdist import MCSamples  # noqa: E402  (the reference)
 from getdist_amd import synth  # noqa: E402
 from oracle import kde_oracle as ko  # noqa: E402
 from oracle import convergence_oracle as co  # noqa: E402
-from oracle.fixtures import (MEANLIKES_CASES, example_mask_function, fixture_zoo, loglikes_for,  # noqa: E402
+from oracle.fixtures import (MEANLIKES_CASES, ingestion_cases, example_mask_function, fixture_zoo, loglikes_for,  # noqa: E402
                              mcmc_chains_fixture)
 
 logging.getLogger().setLevel(logging.ERROR)
@@ -275,6 +275,36 @@ def compare_chain_loader():
     return ok
 
 
+def compare_array_ingestion():
+    """MCSamples(samples=[chains...]) burn-in / min-weight / fixed-parameter handling against the reference
+    (chains.py:1017-1061,1405-1443,1488-1503,1548-1559; mcsamples.py:501-528)."""
+    from getdist import MCSamples as RefMCSamples
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_ctx import FakeContext
+    from getdist_amd.mcsamples import MCSamples
+
+    ok = True
+    for label, kw in ingestion_cases():
+        ref = RefMCSamples(**{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        mine = MCSamples(_context_factory=FakeContext, **kw)
+        good = ref.paramNames.list() == mine.paramNames.list()
+        good &= np.array_equal(ref.samples, mine.samples)
+        good &= np.array_equal(ref.weights, np.ones(mine.numrows) if mine.weights is None else mine.weights)
+        good &= np.array_equal(ref.loglikes, mine.loglikes)
+        good &= (ref.chain_offsets is None and mine.chain_offsets is None) or \
+            list(ref.chain_offsets) == list(mine.chain_offsets)
+        for nm in ("a", "b", "c", "d"):
+            good &= ref.ranges.getLower(nm) == mine.ranges.getLower(nm) and ref.ranges.getUpper(nm) == mine.ranges.getUpper(nm)
+        if mine.chain_offsets is not None:
+            good &= bool(np.allclose(ref.getGelmanRubinEigenvalues(), mine.getGelmanRubinEigenvalues(), rtol=1e-9, atol=1e-14))
+        if not good:
+            print("   mismatch in case:", label)
+        ok &= bool(good)
+    print(("ok  " if ok else "FAIL") + " array ingestion (per-chain burn-in, min-weight filter, fixed parameters, offsets)")
+    return ok
+
+
 def compare_mask_function():
     """get2DDensityGridData(mask_function=...) (mcsamples.py:1794,1907-1919,1973-1979,1987)."""
     zoo = {fx["name"]: fx for fx in fixture_zoo()}
@@ -311,6 +341,7 @@ def main():
     ok &= compare_nd_ranges()
     ok &= compare_raftery_lewis()
     ok &= compare_chain_loader()
+    ok &= compare_array_ingestion()
     ok &= compare_mask_function()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)

@@ -401,3 +401,134 @@ def test_chain_file_loader(tmp_path, zoo):
     assert np.isclose(mc.getGelmanRubin(), mc.getGelmanRubin()) and mc.get1DDensity("m1").P.shape == (1024,)
     full = chainfiles.loadMCSamples(root, ignore_rows=10, _context_factory=FakeContext)
     assert full.numrows == len(weights) - 30
+
+
+def _expected_ingestion(kw, min_weight_ratio=1e-30):
+    """Independent statement of chains.py:1017-1061,1405-1443,1488-1503 for the cases of oracle.ingestion_cases()."""
+    ign = kw.get("ignore_rows", (kw.get("settings") or {}).get("ignore_rows", 0))
+    lines = int(ign)
+    frac = 0 if lines else ign
+    is_list = isinstance(kw["samples"], list)
+    chains = kw["samples"] if is_list else [kw["samples"]]
+    ws = kw.get("weights") if is_list else [kw.get("weights")]
+    Ls = kw.get("loglikes") if is_list else [kw.get("loglikes")]
+    out = []
+    for i, c in enumerate(chains):
+        w = None if ws is None or ws[i] is None else ws[i]
+        L = Ls[i]
+        c, L = c[lines:], L[lines:]
+        if w is not None:
+            w = w[lines:]
+            keep = w > w.max() * min_weight_ratio
+            c, L, w = c[keep], L[keep], w[keep]
+        k = int(round(c.shape[0] * frac))
+        out.append((c[k:], None if w is None else w[k:], L[k:]))
+    offsets = np.cumsum([0] + [c.shape[0] for c, _, _ in out])
+    samples = np.vstack([c for c, _, _ in out])[:, [0, 1, 3]]  # column 2 never moves in chain 1 -> deleted
+    weights = None if out[0][1] is None else np.hstack([w for _, w, _ in out])
+    return samples, weights, np.hstack([L for _, _, L in out]), (offsets if is_list else None)
+
+
+def test_array_ingestion_follows_the_reference_per_chain():
+    """burn-in, the minimum-weight filter and chain offsets are per chain; fixed parameters are decided on
+    the first chain and recorded as zero-width ranges; the ignore_rows setting is honoured as a fraction.  The same
+    cases are compared with the imported reference in oracle/validate_against_reference.py::compare_array_ingestion."""
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import ingestion_cases
+
+    for label, kw in ingestion_cases():
+        mc = MCSamples(_context_factory=FakeContext, **kw)
+        samples, weights, loglikes, offsets = _expected_ingestion(kw)
+        assert mc.paramNames.list() == ["a", "b", "d"], label
+        assert np.array_equal(mc.samples, samples), label
+        assert (weights is None and mc.weights is None) or np.array_equal(mc.weights, weights), label
+        assert np.array_equal(mc.loglikes, loglikes), label
+        assert mc.ranges.getLower("c") == 0.25 and mc.ranges.getUpper("c") == 0.25, label
+        if offsets is None:
+            assert mc.chain_offsets is None
+        else:
+            assert list(mc.chain_offsets) == list(offsets), label
+            assert mc.chain_offsets[-1] == mc.numrows
+            D = mc.getGelmanRubinEigenvalues()  # per-chain statistics read the right row ranges
+            st = mc.getSeparateChainStats(3)
+            for (a, b), (cm, _, _) in zip(zip(offsets[:-1], offsets[1:]), st):
+                w = np.ones(b - a) if weights is None else weights[a:b]
+                assert np.allclose(cm, w @ samples[a:b] / w.sum(), rtol=1e-12)
+            assert D is not None and D.shape == (3,)
+
+
+def test_root_constructor_binary_cache_and_ini(tmp_path):
+    """MCSamples(root=...) / loadMCSamples: text chains on the first load, the column-major binary cache afterwards
+    (same arrays bit for bit, returned as views of one block), cache invalidation by mtime, ini settings."""
+    from getdist_amd import chainfiles
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import mcmc_chains_fixture
+
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=3, N=500, n=3)
+    root = str(tmp_path / "run")
+    for c, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
+        np.savetxt("%s_%d.txt" % (root, c + 1), np.column_stack([weights[a:b], loglikes[a:b], samples[a:b]]), fmt="%.17g")
+    (tmp_path / "run.paramnames").write_text("x\ny\nz*\n")
+    (tmp_path / "my.ini").write_text("# analysis settings\nignore_rows = 0.1\nfine_bins_2D = 128\nplot_ext = pdf\ncontours = 0.5 0.9\n")
+    first = MCSamples(root=root, _context_factory=FakeContext)
+    assert os.path.isfile(chainfiles.cache_path(root))
+    assert np.array_equal(first.samples, samples) and np.array_equal(first.weights, weights)
+    again = MCSamples(root=root, _context_factory=FakeContext)
+    assert np.array_equal(again.samples, samples) and np.array_equal(again.weights, weights)
+    assert np.array_equal(again.loglikes, loglikes) and list(again.chain_offsets) == list(offsets)
+    assert again.samples.flags.f_contiguous  # a view of the cache block: no host-side copy or transpose
+    assert again.paramNames.numNonDerived() == 2 and again.name_tag == "run"
+    loaded = chainfiles.read_root(root)
+    assert loaded["from_cache"]
+    # a newer chain file invalidates the cache
+    os.utime(chainfiles.cache_path(root), (1, 1))
+    assert not chainfiles.read_root(root, no_cache=True)["from_cache"]
+    assert not chainfiles.read_root(root)["from_cache"] and chainfiles.read_root(root)["from_cache"]
+    burnt = chainfiles.loadMCSamples(root, ini=str(tmp_path / "my.ini"), _context_factory=FakeContext)
+    keep = np.concatenate([np.arange(a + int(round((b - a) * 0.1)), b) for a, b in zip(offsets[:-1], offsets[1:])])
+    assert np.array_equal(burnt.samples, samples[keep]) and burnt.fine_bins_2D == 128 and burnt.contours == [0.5, 0.9]
+    excl = chainfiles.loadMCSamples(root, chain_exclude=[2], _context_factory=FakeContext)
+    assert excl.numrows == len(weights) - (offsets[2] - offsets[1]) and len(excl.chain_offsets) == 3
+
+
+def test_separate_chains_chainlist_and_make_single():
+    """chains.py:1446-1527: getSeparateChains() views, chainlist= sub-lists, makeSingle() on combined samples."""
+    import pytest
+
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import mcmc_chains_fixture
+
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=4, N=800, n=4)
+    parts = [(samples[a:b], weights[a:b], loglikes[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
+    mc = MCSamples(samples=[p[0] for p in parts], weights=[p[1] for p in parts], loglikes=[p[2] for p in parts],
+                   names=names, _context_factory=FakeContext)
+    chains = mc.getSeparateChains()
+    assert len(chains) == 4
+    for ch, (s, w, L) in zip(chains, parts):
+        assert np.array_equal(ch.samples, s) and np.array_equal(ch.weights, w) and np.array_equal(ch.loglikes, L)
+        m = w @ s / w.sum()
+        assert np.allclose(ch.getMeans(), m, rtol=1e-12) and np.isclose(ch.norm, w.sum())
+        d = s - m
+        assert np.allclose(ch.getCov(3), ((d * w[:, None]).T @ d / w.sum())[:3, :3], rtol=1e-10, atol=1e-14)
+        assert np.allclose(ch.getVars(), np.diag((d * w[:, None]).T @ d / w.sum()), rtol=1e-10)
+        order = np.argsort(s[:, 1])
+        cum = np.cumsum(w[order])
+        assert ch.confidence(1, 0.3) == s[order[np.searchsorted(cum, 0.3 * w.sum())], 1]
+    full = mc.getGelmanRubinEigenvalues()
+    assert np.allclose(mc.getGelmanRubinEigenvalues(chainlist=chains), full, rtol=1e-10, atol=1e-15)
+    sub = mc.getGelmanRubinEigenvalues(chainlist=chains[1:])
+    # the reference formula on chains 1..3 with the POOLED means of all four (chains.py:1456-1466)
+    from getdist_amd.parallel import gelman_rubin_from_chain_stats
+    stats = []
+    for s, w, _ in parts[1:]:
+        m = w @ s / w.sum()
+        d = s - m
+        stats.append((m, (d * w[:, None]).T @ d / w.sum(), w.sum()))
+    want = gelman_rubin_from_chain_stats(stats, weights @ samples / weights.sum())
+    assert np.allclose(sub, want, rtol=1e-9, atol=1e-15) and not np.allclose(sub, full)
+    assert np.isclose(mc.getGelmanRubin(chainlist=chains[:2]), np.max(mc.getGelmanRubinEigenvalues(chainlist=chains[:2])))
+    with pytest.raises(ValueError):
+        mc.makeSingle()
+    single = MCSamples(samples=samples, weights=weights, names=names, _context_factory=FakeContext)
+    with pytest.raises(Exception):
+        single.getSeparateChains()
