@@ -89,6 +89,7 @@ SIGNATURES = {
     "gd_attach_samples": (C.c_int, [_p, _p]),
     "gd_bind_thread": (C.c_int, [_p]),
     "gd_contour_levels": (C.c_int, [_p, _i32, _i32, _p, _pd, _i32, _pd, _pi32]),
+    "gd_limits1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _i32, _i32, _pd, _pi32]),
     "gd_set_extra_column": (C.c_int, [_p, _i32, _pd]),
     "gd_aux_weights": (C.c_int, [_p, _pd]),
     "gd_col_minmax": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _i32, C.c_double, _pd]),
@@ -545,6 +546,17 @@ class Context:
         status = np.zeros(B, dtype=np.int32)
         self._check(self.lib.gd_contour_levels(self.h, int(B), int(F), d_P.ptr, _dp(contours), len(contours), _dp(out),
                                                _ip(status)))
+        return out, status
+
+    # ---- credible limits
+    def limits1d(self, P, x0, spacing, contours, factor=0):
+        """(limits[B, nc, 4] = lower, upper, has_min, has_top; status[B]) of B densities P[B, F] on regular grids."""
+        P, x0, spacing, contours = _f64arr(P), _f64arr(x0), _f64arr(spacing), _f64arr(contours)
+        B, F = P.shape
+        out = np.zeros((B, len(contours), 4))
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_limits1d(self.h, B, F, _dp(P), _dp(x0), _dp(spacing), _dp(contours), len(contours),
+                                         int(factor), _dp(out), _ip(status)))
         return out, status
 
     # ---- thinned chains

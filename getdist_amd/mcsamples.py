@@ -1781,68 +1781,85 @@ class MCSamples:
 
         return [np.exp(-1.0 * math.pow(norm.ppf((1 - c) / 2), 2) / 2) for c in self.contours]
 
-    def _setMargeLimits(self, par, paramConfid, max_frac_twotail=None, density1D=None):
-        """mcsamples.py:2460-2531 (scalar logic on the device-computed density and quantiles)"""
-        import math
+    def _marge_limit_inputs(self, js, densities):
+        """
+        Everything the marginalised limits of parameters ``js`` need from the device, in three batched calls:
+        equal-density credible intervals of every (density, contour) (gd_limits1d), and the one- and two-tail sample
+        quantiles of every (column, contour) (gd_quantiles; targets per contour: f, 1-f, f/2, 1-f/2 with f = 1-contour).
+        Returns (credible[len(js), nc, 4], tails[len(js), nc, 4]).
+        """
+        contours = np.asarray(self.contours, dtype=np.float64)
+        nc = len(contours)
+        credible = np.zeros((len(js), nc, 4))
+        by_F = {}
+        for b, d in enumerate(densities):
+            by_F.setdefault(d.P.size, []).append(b)
+        for F, members in by_F.items():
+            for c0 in range(0, nc, 8):
+                lims, status = self.ctx.limits1d(np.stack([densities[b].P for b in members]),
+                                                 [densities[b].x[0] for b in members],
+                                                 [densities[b].spacing for b in members], contours[c0:c0 + 8])
+                if np.any(status != 0):
+                    raise DensitiesError("credible limit outside the refined density grid")
+                credible[members, c0:c0 + 8] = lims
+        tails = np.zeros((len(js), nc, 4))
+        f = 1 - contours
+        for c0 in range(0, nc, 4):
+            fr = f[c0:c0 + 4]
+            fracs = np.stack([fr, 1 - fr, fr / 2, 1 - fr / 2], axis=1).reshape(-1)
+            q = self.ctx.quantiles(js, np.tile(self.norm * fracs, (len(js), 1)))
+            tails[:, c0:c0 + 4] = q.reshape(len(js), -1, 4)
+        return credible, tails
 
-        if max_frac_twotail is None:
-            max_frac_twotail = self._max_frac_twotail()
+    def _assign_marge_limits(self, par, density, credible, tails, max_frac_twotail):
+        """
+        The limit type and values per contour (contract of mcsamples.py:2460-2531).  A hard prior edge where the
+        density is still high (above max_frac_twotail of the peak) makes that side unconstrained; otherwise the
+        equal-density interval of the smoothed density decides which sides are open, open sides take the prior range,
+        a single closed side takes the one-tail sample quantile, and two closed sides take the equal-density interval
+        -- or the two-tail quantiles when the density is nearly equal at them (credible_interval_threshold).
+        """
         force_twotail = getattr(self, "force_twotail", False)
         par.limits = []
+        for c in range(len(self.contours)):
+            open_bot = bool(par.has_limits_bot and not force_twotail and density.P[0] > max_frac_twotail[c])
+            open_top = bool(par.has_limits_top and not force_twotail and density.P[-1] > max_frac_twotail[c])
+            lower, upper = par.range_min, par.range_max
+            if not (open_bot and open_top):
+                cred_lo, cred_hi, open_bot, open_top = credible[c]
+                open_bot, open_top = bool(open_bot), bool(open_top)
+                one_lo, one_hi, two_lo, two_hi = tails[c]
+                if not open_bot and not open_top:
+                    lower, upper = cred_lo, cred_hi
+                    if abs(density.Prob(two_hi) - density.Prob(two_lo)) < self.credible_interval_threshold:
+                        lower, upper = two_lo, two_hi
+                elif not open_bot:
+                    lower = one_lo
+                elif not open_top:
+                    upper = one_hi
+            tag = {(True, True): "none", (True, False): ">", (False, True): "<", (False, False): "two"}[(open_bot, open_top)]
+            par.limits.append(ParamLimit([lower, upper], tag))
+
+    def _setMargeLimits(self, par, paramConfid=None, max_frac_twotail=None, density1D=None):
+        """Marginalised limits of ONE parameter (the reference's per-parameter entry point, mcsamples.py:2460)."""
+        j = self._col(par.name)
         density1D = density1D or self.get1DDensity(par.name)
-        interpGrid = None
-        for ix1, contour in enumerate(self.contours):
-            marge_limits_bot = par.has_limits_bot and not force_twotail and density1D.P[0] > max_frac_twotail[ix1]
-            marge_limits_top = par.has_limits_top and not force_twotail and density1D.P[-1] > max_frac_twotail[ix1]
-            if not marge_limits_bot or not marge_limits_top:
-                if not interpGrid:
-                    interpGrid = density1D.initLimitGrids()
-                tail_limit_bot, tail_limit_top, marge_limits_bot, marge_limits_top = density1D.getLimits(contour, interpGrid)
-                limfrac = 1 - contour
-                if marge_limits_bot:
-                    tail_limit_bot = par.range_min
-                    tail_confid_bot = None
-                elif marge_limits_top:
-                    tail_limit_bot = self.confidence(paramConfid, limfrac, upper=False)
-                    tail_confid_bot = None
-                else:
-                    tail_confid_bot = self.confidence(paramConfid, limfrac / 2, upper=False)
-                if marge_limits_top:
-                    tail_limit_top = par.range_max
-                    tail_confid_top = None
-                elif marge_limits_bot:
-                    tail_limit_top = self.confidence(paramConfid, limfrac, upper=True)
-                    tail_confid_top = None
-                else:
-                    tail_confid_top = self.confidence(paramConfid, limfrac / 2, upper=True)
-                if not marge_limits_bot and not marge_limits_top:
-                    if (math.fabs(density1D.Prob(tail_confid_top) - density1D.Prob(tail_confid_bot))
-                            < self.credible_interval_threshold):
-                        tail_limit_top = tail_confid_top
-                        tail_limit_bot = tail_confid_bot
-                lim = [tail_limit_bot, tail_limit_top]
-            else:
-                lim = [par.range_min, par.range_max]
-            if marge_limits_bot and marge_limits_top:
-                tag = "none"
-            elif marge_limits_bot:
-                tag = ">"
-            elif marge_limits_top:
-                tag = "<"
-            else:
-                tag = "two"
-            par.limits.append(ParamLimit(lim, tag))
+        credible, tails = self._marge_limit_inputs([j], [density1D])
+        self._assign_marge_limits(par, density1D, credible[0], tails[0], max_frac_twotail or self._max_frac_twotail())
 
     def getMargeStats(self, include_bestfit=False):
-        """mcsamples.py:2353-2367: marginalised 1D constraints (numbers only; text tables are out of scope)."""
+        """mcsamples.py:2353-2367: marginalised 1D constraints (numbers only; text tables are out of scope).  All
+        densities, all equal-density intervals and all tail quantiles come from batched device calls."""
         if include_bestfit:
             raise NotImplementedError("best-fit files are outside the accelerated path")
         if self.needs_update:
             self.updateBaseStatistics()
         dens = self.get1DDensities()  # one batched launch, cached per name
         mft = self._max_frac_twotail()
+        js = list(range(self.n))
+        credible, tails = self._marge_limit_inputs(js, dens)
         for j, par in enumerate(self.paramNames.names):
-            self._setMargeLimits(par, self.initParamConfidenceData(j), mft, dens[j])
+            self._assign_marge_limits(par, dens[j], credible[j], tails[j], mft)
         return MargeStats(self.paramNames.names, self.contours)
 
     # ---- 2D densities (mcsamples.py:1285-1419, 1730-2010) ---------------------------------------------------

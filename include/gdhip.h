@@ -207,6 +207,18 @@ int gd_bind_thread(gd_ctx* ctx);
 int gd_contour_levels(gd_ctx* ctx, int32_t B, int32_t F, const void* d_P, const double* contours, int32_t nc, double* out,
                       int32_t* status_out);
 
+/* ---------------------------------------------------------------- credible limits 1D -----------
+ * gd_limits1d: densities.py:186-248 Density1D.initLimitGrids + getLimits for B densities on regular grids
+ *   (host arrays: P is B x F, x0[b] the first grid abscissa, spacing[b] the grid step).  Each density is refined
+ *   `factor` times (<= 0: the reference default max(2, 20000 / F)) with the not-a-knot cubic spline through its F
+ *   values; per contour c the density level below which (1 - contours[c]) of the refined mass lies is read off the
+ *   ranked refined values (interpolating towards the NEXT ranked value, :227), and the outermost crossings of that
+ *   level are located.  out[(b*nc + c)*4 ..] = {lower, upper, has_min, has_top} with has_* = 1.0 where the density at
+ *   that end of the grid is still >= the level (no crossing: the limit is the grid end).  status_out[b]: GD_OK or
+ *   GD_ERR_SOLVER (level beyond the ranked values / no crossing found, where the reference raises IndexError). */
+int gd_limits1d(gd_ctx* ctx, int32_t B, int32_t F, const double* P, const double* x0, const double* spacing,
+                const double* contours, int32_t nc, int32_t factor, double* out, int32_t* status_out);
+
 /* ---------------------------------------------------------------- auxiliary vectors ------------
  * The reference lets most statistics take an arbitrary vector instead of a column index (`_makeParamvec`,
  * chains.py:325-337), a row filter `where=` (chains.py:666-780) or alternative weights (chains.py:793-838).

@@ -480,6 +480,53 @@ def contour_levels(inbins, contours=(0.68, 0.95), missing_norm=0, half_edge=True
 # ----------------------------------------------------------------------------------------------
 # per-parameter state (paramnames.py:69-154 attributes written by the hot path)
 # ----------------------------------------------------------------------------------------------
+def density_limits_1d(x, P, contours, factor=None):
+    """
+    Density1D.initLimitGrids + getLimits (densities.py:186-248) for a density P on the regular grid x:
+    array (len(contours), 4) of (lower, upper, has_min, has_top).  scipy's FITPACK spline, np.sort, np.cumsum and
+    np.searchsorted exactly as the reference calls them.
+    """
+    from scipy.interpolate import splev, splrep
+
+    x, P = np.asarray(x, dtype=np.float64), np.asarray(P, dtype=np.float64)
+    n = x.size
+    spacing = x[1] - x[0]
+    spl = splrep(x, P, s=0)
+    if factor is None:
+        factor = max(2, 20000 // n)
+    bign = (n - 1) * factor + 1
+    grid = splev(x[0] + np.arange(bign) * spacing / factor, spl)
+    norm = np.sum(grid) - (0.5 * P[-1]) - (0.5 * P[0])
+    sortgrid = np.sort(grid)
+    cumsum = np.cumsum(sortgrid)
+    out = np.zeros((len(contours), 4))
+    for row, p in enumerate(contours):
+        target = (1 - p) * norm
+        ix = np.searchsorted(cumsum, target)
+        trial = sortgrid[ix]
+        if ix > 0:
+            d = cumsum[ix] - cumsum[ix - 1]
+            frac = (cumsum[ix] - target) / d
+            trial = (1 - frac) * trial + frac * sortgrid[ix + 1]
+        finespace = spacing / factor
+        lim_bot = grid[0] >= trial
+        if lim_bot:
+            mn = x[0]
+        else:
+            i = np.argmax(grid > trial)
+            d = (grid[i] - trial) / (grid[i] - grid[i - 1])
+            mn = x[0] + (i - d) * finespace
+        lim_top = grid[-1] >= trial
+        if lim_top:
+            mx = x[-1]
+        else:
+            i = bign - np.argmax(grid[::-1] > trial) - 1
+            d = (grid[i] - trial) / (grid[i] - grid[i + 1])
+            mx = x[0] + (i + d) * finespace
+        out[row] = (mn, mx, lim_bot, lim_top)
+    return out
+
+
 class ParamState:
     def __init__(self, name, limmin=None, limmax=None, periodic=False):
         self.name = name

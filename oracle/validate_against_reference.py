@@ -305,6 +305,53 @@ def compare_array_ingestion():
     return ok
 
 
+def compare_density_containers():
+    """getdist_amd.densities (own implementation of the container contract) against getdist.densities on random grids:
+    spline values and derivatives, integrals, normalisation, credible limits, contour levels in 2 and 3 dimensions."""
+    from getdist import densities as R
+    from getdist_amd import densities as M
+
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    ok = True
+    for trial in range(40):
+        n = int(rng.choice([64, 257, 1024, 2048]))
+        x = np.linspace(-3 + rng.random(), 4 + rng.random(), n)
+        P = np.exp(-0.5 * ((x - 0.3) / 0.7) ** 2) + 0.4 * np.exp(-0.5 * ((x - 2.5) / 0.3) ** 2) * (trial % 2)
+        if trial % 3 == 0:
+            P = P * (x > -1.0)
+        if trial % 5 == 0:
+            P += 0.01 * rng.random(n)
+        P /= P.max()
+        r, m = R.Density1D(x, P.copy()), M.Density1D(x, P.copy())
+        xq = rng.uniform(x[0] - 0.5, x[-1] + 0.5, 300)
+        for d, tol in ((0, 1e-13), (1, 1e-10), (2, 1e-7)):
+            worst = max(worst, np.max(np.abs(r.Prob(xq, d) - m.Prob(xq, d))) / max(1.0, np.max(np.abs(r.Prob(xq, d)))) / tol)
+        worst = max(worst, abs(r.Prob(0.2) - m.Prob(0.2)) / 1e-13, abs(r.norm_integral() - m.norm_integral()) / 1e-13)
+        for p in (0.68, 0.95, 0.99):
+            a, b = r.getLimits(p), m.getLimits(p)
+            ok &= bool(a[2]) == bool(b[2]) and bool(a[3]) == bool(b[3])
+            worst = max(worst, max(abs(a[0] - b[0]), abs(a[1] - b[1])) / (x[-1] - x[0]) / 1e-12)
+        for a, b in zip(r.getLimits(np.array([0.68, 0.95])), m.getLimits(np.array([0.68, 0.95]))):
+            worst = max(worst, (abs(a[0] - b[0]) + abs(a[1] - b[1])) / 1e-11)
+        g, g3 = rng.random((40, 50)) ** 3, rng.random((8, 9, 7))
+        worst = max(worst, np.max(np.abs(R.getContourLevels(g, (0.5, 0.9, 0.99)) - M.getContourLevels(g, (0.5, 0.9, 0.99)))) / 1e-13)
+        worst = max(worst, np.max(np.abs(R.getContourLevels(g3, (0.5, 0.8)) - M.getContourLevels(g3, (0.5, 0.8)))) / 1e-13)
+        worst = max(worst, np.max(np.abs(R.getContourLevels(g, (0.5,), half_edge=False, missing_norm=0.1)
+                                         - M.getContourLevels(g, (0.5,), half_edge=False, missing_norm=0.1))) / 1e-13)
+        xx, yy = np.linspace(0, 1, 50), np.linspace(-1, 1, 40)
+        r2, m2 = R.Density2D(xx, yy, g.copy()), M.Density2D(xx, yy, g.copy())
+        worst = max(worst, abs(r2.norm_integral() - m2.norm_integral()) / 1e-13)
+        worst = max(worst, np.max(np.abs(r2.Prob(xx[3:9] + 0.01, yy[3:9]) - m2.Prob(xx[3:9] + 0.01, yy[3:9]))) / 1e-13)
+        ok &= r2.bounds() == m2.bounds()
+        r2.normalize("max", in_place=True), m2.normalize("max", in_place=True)
+        r2.normalize(), m2.normalize()
+        worst = max(worst, np.max(np.abs(r2.P - m2.P)) / 1e-13)
+    ok &= worst <= 1.0
+    print(("ok  " if ok else "FAIL") + " density containers (spline, limits, contour levels, integrals): worst error / tolerance = %.2g" % worst)
+    return bool(ok)
+
+
 def compare_mask_function():
     """get2DDensityGridData(mask_function=...) (mcsamples.py:1794,1907-1919,1973-1979,1987)."""
     zoo = {fx["name"]: fx for fx in fixture_zoo()}
@@ -342,6 +389,7 @@ def main():
     ok &= compare_raftery_lewis()
     ok &= compare_chain_loader()
     ok &= compare_array_ingestion()
+    ok &= compare_density_containers()
     ok &= compare_mask_function()
     for fx in fixture_zoo():
         ok &= compare_fixture(**fx)

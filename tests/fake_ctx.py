@@ -157,6 +157,15 @@ class FakeContext:
         P = np.asarray(d_P.a).reshape(B, F, F)
         return np.array([ko.contour_levels(P[b], tuple(contours)) for b in range(B)]), np.zeros(B, dtype=np.int32)
 
+    def limits1d(self, P, x0, spacing, contours, factor=0):
+        P = np.asarray(P, dtype=float)
+        B, F = P.shape
+        out = np.zeros((B, len(contours), 4))
+        for b in range(B):
+            x = x0[b] + spacing[b] * np.arange(F)
+            out[b] = ko.density_limits_1d(x, P[b], contours, factor or None)
+        return out, np.zeros(B, dtype=np.int32)
+
     # ---- thinned chains
     def weights_integral(self):
         w = self.w

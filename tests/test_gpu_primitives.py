@@ -328,3 +328,39 @@ def test_contour_levels_batch(ctx):
         else:
             assert status[b] == -5 and b in (2, 4)  # tie list overflow: the host path takes that grid
     assert status[0] == 0 and status[1] == 0 and status[3] == 0
+
+
+@pytest.mark.parametrize("F", [1024, 257, 4096, 64])
+def test_limits1d_batch_matches_the_reference_algorithm(ctx, F):
+    """gd_limits1d (device spline refinement + radix select + crossing search) against the oracle's restatement of
+    Density1D.initLimitGrids/getLimits (densities.py:186-248: FITPACK spline, np.sort, np.cumsum) on shapes with two
+    modes, a hard cut-off, a plateau of exact ties and noise; flags exact, positions to 1e-9 of the grid range."""
+    from oracle import kde_oracle as ko
+
+    r = np.random.default_rng(F)
+    x = np.linspace(-3.1, 4.2, F)
+    shapes = []
+    for k in range(12):
+        P = np.exp(-0.5 * ((x - 0.3 * k / 4) / (0.4 + 0.05 * k)) ** 2)
+        if k % 2:
+            P += 0.4 * np.exp(-0.5 * ((x - 2.5) / 0.3) ** 2)
+        if k % 3 == 0:
+            P = P * (x > -1.0)          # hard lower edge: one-tail limits
+        if k % 4 == 1:
+            P = np.minimum(P, 0.8)      # flat top: exactly tied values
+        if k % 5 == 0:
+            P = P + 0.01 * r.random(F)
+        if k == 7:
+            P = np.exp(-0.5 * (x / 5.0) ** 2)  # wider than the grid: both ends open
+        shapes.append(P / P.max())
+    P = np.array(shapes)
+    contours = [0.68, 0.95, 0.99]
+    x0 = np.full(len(P), x[0])
+    sp = np.full(len(P), x[1] - x[0])
+    for factor in (0, 3):
+        got, status = ctx.limits1d(P, x0, sp, contours, factor)
+        assert np.all(status == 0)
+        for b in range(len(P)):
+            want = ko.density_limits_1d(x, P[b], contours, factor or None)
+            assert np.array_equal(got[b][:, 2:], want[:, 2:]), (F, b, got[b], want)
+            assert np.max(np.abs(got[b][:, :2] - want[:, :2])) < 1e-9 * (x[-1] - x[0]), (F, b, got[b], want)

@@ -532,3 +532,32 @@ def test_separate_chains_chainlist_and_make_single():
     single = MCSamples(samples=samples, weights=weights, names=names, _context_factory=FakeContext)
     with pytest.raises(Exception):
         single.getSeparateChains()
+
+
+def test_marge_stats_host_logic_against_goldens(zoo):
+    """getMargeStats: the batched limit inputs + the per-contour decision against the reference's numbers
+    (tests/golden/margestats_*.npz), with the device calls played by the oracle; and the oracle's limits routine against
+    the package's own spline implementation."""
+    from getdist_amd.densities import Density1D
+
+    for name in ("c1_bounded", "shapes", "block10_weighted"):
+        fx = zoo[name]
+        g = np.load(gu.GOLDEN_DIR + "/margestats_%s.npz" % name)
+        mc = make(fx)
+        ms = mc.getMargeStats()
+        for nm in fx["names"]:
+            par = ms.parWithName(nm)
+            want = g["lims/" + nm]
+            got = np.array([[lim.lower, lim.upper, lim.twotail, lim.onetail_upper, lim.onetail_lower] for lim in par.limits],
+                           dtype=float)
+            assert np.array_equal(got[:, 2:], want[:, 2:]), (name, nm, "limit types")
+            assert np.max(np.abs(got[:, :2] - want[:, :2])) < 1e-9 * max(1e-300, float(par.err)), (name, nm, got, want)
+            d = mc.get1DDensity(nm)
+            host = np.array(Density1D(d.x, d.P).getLimits(np.array(mc.contours)), dtype=float)
+            orc = ko.density_limits_1d(d.x, d.P, mc.contours)
+            assert np.array_equal(host[:, 2:], orc[:, 2:]) and np.max(np.abs(host[:, :2] - orc[:, :2])) < 1e-11 * (d.x[-1] - d.x[0])
+        # the per-parameter entry point gives the same limits as the batch
+        par = mc.paramNames.names[0]
+        before = [(lim.lower, lim.upper, lim.limitTag()) for lim in par.limits]
+        mc._setMargeLimits(par, mc.initParamConfidenceData(0))
+        assert before == [(lim.lower, lim.upper, lim.limitTag()) for lim in par.limits]
