@@ -83,6 +83,7 @@ SIGNATURES = {
     "gd_minmax_affine": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd]),
     "gd_hist2d_sheared": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _i32, _p]),
     "gd_dct1d": (C.c_int, [_p, _i32, _i32, _pd, _pd]),
+    "gd_isj1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pi32]),
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
@@ -489,6 +490,15 @@ class Context:
         out = np.zeros_like(hist)
         self._check(self.lib.gd_dct1d(self.h, B, F, _dp(hist), _dp(out)))
         return out
+
+    def isj1d(self, hist, neff):
+        """(hfrac[B], status[B]): the 1D ISJ bandwidths of B histograms, solved on the device."""
+        hist, neff = _f64arr(hist), _f64arr(neff)
+        B, F = hist.shape
+        h = np.zeros(B)
+        status = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.gd_isj1d(self.h, B, F, _dp(hist), _dp(neff), _dp(h), _ip(status)))
+        return h, status
 
     def density1d(self, hist, smooth, winw, flags, bco, mbc):
         hist = _f64arr(hist)

@@ -2,6 +2,7 @@
 // boundary correction (orders 0/1/2), multiplicative bias correction, max-normalisation.
 // One workgroup per parameter; everything (F <= 4096 bins, <= F taps) lives in LDS.
 #include "ctx.hpp"
+#include "solvers.hpp"
 
 // ---- DCT-II (scipy.fftpack.dct type 2, unnormalised): a[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2F)) ----------
 // tab[m] = cos(pi m / (2F)), m in [0,4F), built with exact octant reduction.
@@ -52,6 +53,95 @@ __global__ void __launch_bounds__(256) k_dct1d(const double* __restrict__ hist, 
     }
     if (n < F) a0 = fma(xs[n], tab[m], a0);
     out[(int64_t)blockIdx.y * F + k] = 2.0 * (a0 + a1);
+}
+
+// ---- Botev improved-Sheather-Jones bandwidth, solved on the device (kde_bandwidth.py:59-73,102-135) ---------------
+// One block per parameter.  The fixed-point functional is a chain of six 1023-term sums (block reductions over
+// coefficients held in LDS); the root finder is MINPACK's hybrd for one unknown exactly as scipy's fsolve drives it
+// (solvers.hpp, checked against scipy evaluation by evaluation), followed by the reference's brentq re-check.  All
+// threads run the scalar control flow redundantly on identical values, so every branch is block-uniform.
+struct IsjConsts {
+    double two_pi_pow[8];  // 2 * pi^(2 l), l = 2..7
+    double kde_const[8];   // _kde_consts_1d for j = 6..2, indexed by j
+    double rootpi, pisq;
+};
+
+__device__ __forceinline__ double block_sum_all(double v, double* red, double* slot) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0;
+        for (int i = 0; i < nw; ++i) r += red[i];
+        *slot = r;
+    }
+    __syncthreads();
+    return *slot;
+}
+
+// grid B; a_all = DCT-II coefficients (B x F); out[b] = {hfrac, status}
+__global__ void __launch_bounds__(256) k_isj1d(const double* __restrict__ a_all, int F, const double* __restrict__ neff,
+                                               const double* __restrict__ nscale, IsjConsts C, double* __restrict__ out) {
+    extern __shared__ double sh[];
+    double* a2 = sh;            // F-1
+    double* logI = sh + F;      // F-1
+    __shared__ double red[8];
+    __shared__ double slot;
+    const int b = blockIdx.x, tid = threadIdx.x, K = F - 1;
+    const double* a = a_all + (int64_t)b * F;
+    for (int k = tid; k < K; k += 256) {
+        const double v = a[k + 1] / 2.0;
+        a2[k] = v * v;
+        const double I = (double)(k + 1) * (double)(k + 1);
+        logI[k] = log(I);
+    }
+    __syncthreads();
+    const double N = neff[b];
+    auto functional = [&](int l, double t) {  // 2 pi^(2l) sum_k a2_k exp(l logI_k - I_k pi^2 t)
+        const double pt = C.pisq * t;
+        double s = 0;
+        for (int k = tid; k < K; k += 256) {
+            const double I = (double)(k + 1) * (double)(k + 1);
+            s += a2[k] * exp((double)l * logI[k] - I * pt);
+        }
+        return C.two_pi_pow[l] * block_sum_all(s, red, &slot);
+    };
+    auto fixed_point = [&](double h, bool* fail) -> double {
+        if (h <= 0) return h - 1;
+        double f = functional(7, h * h);
+        for (int j = 6; j >= 2; --j) {
+            const double t_j = pow(C.kde_const[j] / N / f, 2 / (3.0 + 2 * j));
+            f = functional(j, t_j);
+            if (f == 0.0) {  // "zero f in _bandwidth_fixed_point (non-convergence)"
+                *fail = true;
+                return 0.0;
+            }
+        }
+        return h - pow(2 * N * C.rootpi * f, -1.0 / 5);
+    };
+    const double n_scaling = nscale[b];
+    double hfrac = 0.53 * n_scaling;
+    const gdsolve::HybrdResult hr = gdsolve::hybrd1(fixed_point, hfrac, hfrac / 20, 400, 1.0);
+    int status = GD_OK;
+    if (hr.info < 0) {
+        status = GD_ERR_SOLVER;  // an exception inside fsolve: the reference logs and returns None
+    } else {
+        hfrac = hr.x;
+        if (hfrac < 0.019 * n_scaling) {  // may be the second solution: re-check with Brent (kde_bandwidth.py:124-131)
+            const double xtol = hfrac / 20;
+            if (xtol > 0) {
+                const gdsolve::BrentResult br = gdsolve::brentq(fixed_point, 0.019 * n_scaling, 0.5, xtol,
+                                                                4.0 * gdsolve::EPSMCH, 100);
+                if (br.status == 0) hfrac = br.x;
+            }
+        }
+    }
+    if (tid == 0) {
+        out[2 * b] = hfrac;
+        out[2 * b + 1] = (double)status;
+    }
 }
 
 // ---- density assembly -------------------------------------------------------------------------------------
@@ -337,6 +427,55 @@ int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_ou
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(a_out, d_out, (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
+    return GD_OK;
+}
+
+int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* neff, double* hfrac_out,
+             int32_t* status_out) {
+    GD_REQUIRE(ctx && hist && neff && hfrac_out && status_out && B > 0, "bad argument");
+    GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins out of range (8..4096)");
+    const int64_t nb = ((int64_t)B * F * 8 + 255) / 256 * 256, ns = ((int64_t)B * 16 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch(ctx, 2 * nb + 3 * ns + (int64_t)4 * F * 8 + 512);
+    if (!base) return GD_ERR_NOMEM;
+    double* d_in = (double*)base;
+    double* d_a = (double*)(base + nb);
+    double* d_neff = (double*)(base + 2 * nb);
+    double* d_nscale = (double*)(base + 2 * nb + ns);
+    double* d_out = (double*)(base + 2 * nb + 2 * ns);
+    double* d_tab = (double*)(base + 2 * nb + 3 * ns);
+    // host-side constants with the reference's expressions (kde_bandwidth.py:47-56,63,69,73) in libm arithmetic
+    IsjConsts C;
+    const double pi = 3.141592653589793;
+    C.rootpi = sqrt(pi);
+    C.pisq = pi * pi;
+    for (int l = 0; l < 8; ++l) {
+        C.two_pi_pow[l] = 2 * pow(pi, (double)(2 * l));
+        double prod = 1;
+        for (int q = 1; q < 2 * l; q += 2) prod *= q;
+        C.kde_const[l] = (1 + pow(0.5, l + 0.5)) / 3 * prod / (C.rootpi / sqrt(2.0));
+    }
+    std::vector<double> nscale((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        GD_REQUIRE(neff[b] > 0, "effective sample number must be positive");
+        nscale[b] = pow(neff[b], -1.0 / 5);
+    }
+    GD_HIP(hipMemcpyAsync(d_in, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_neff, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_nscale, nscale.data(), (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    k_cos_table<<<(4 * F + 255) / 256, 256, 0, ctx->stream>>>(F, d_tab);
+    GD_KERNEL_CHECK();
+    k_dct1d<<<dim3((F + 255) / 256, B), 256, (size_t)F * 8, ctx->stream>>>(d_in, F, d_tab, d_a);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipFuncSetAttribute((const void*)k_isj1d, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8));
+    k_isj1d<<<B, 256, (size_t)2 * F * 8, ctx->stream>>>(d_a, F, d_neff, d_nscale, C, d_out);
+    GD_KERNEL_CHECK();
+    std::vector<double> res((size_t)2 * B);
+    GD_HIP(hipMemcpyAsync(res.data(), d_out, (size_t)B * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) {
+        hfrac_out[b] = res[2 * b];
+        status_out[b] = (int32_t)res[2 * b + 1];
+    }
     return GD_OK;
 }
 

@@ -4,12 +4,10 @@ path, driving libgdhip.so (HIP kernels on one MI355X) through the ctypes C ABI.
 
 Same method names, keyword arguments, defaults (analysis_defaults.ini) and result types as
 getdist/mcsamples.py + getdist/chains.py for that path; every O(N) step and every O(F^2) grid step runs
-on the GPU.  What stays in Python is the reference's *scalar* logic (ranges and limits, bin edges,
-bandwidth branch selection, fallbacks), evaluated in the reference's expression order so that bin edges
-are bit-identical, plus two tiny scipy scalar solvers with path-dependent results that are kept
-verbatim for parity: ``fsolve`` on the 1D Botev fixed point (one 1023-term functional per parameter,
-kde_bandwidth.py:123) and TNC on the AMISE of ~9 scalars (kde_bandwidth.py:276-299); see SURVEY.md
-A.11/A.12.
+on the GPU, including the root finders of the bandwidth selection (MINPACK hybrd as scipy's fsolve runs it for the
+1D Botev fixed point, Brent's method for the 2D one: csrc/solvers.hpp).  What stays in Python is the reference's
+*scalar* logic (ranges and limits, bin edges, bandwidth branch selection, fallbacks), evaluated in the reference's
+expression order so that bin edges are bit-identical.
 
 Additive API (not in the reference): ``get1DDensities``, ``get2DDensities`` and ``triangleDensities``
 compute many densities in batched kernel launches; the per-name/per-pair methods are thin views over
@@ -23,7 +21,7 @@ import time
 import warnings
 
 import numpy as np
-from scipy.optimize import brentq, fsolve, minimize
+from scipy.optimize import minimize
 
 from ._lib import Context
 from .densities import Density1D, Density2D, DensitiesError
@@ -174,48 +172,6 @@ class ParamBounds:
 
     def getUpper(self, name):
         return self.upper.get(name)
-
-
-_ROOTPI = np.sqrt(np.pi)
-_PISQ = np.pi**2
-_LMAX = 7
-_CONSTS_1D = np.array([(1 + 0.5 ** (j + 0.5)) / 3 * np.prod(np.arange(1, 2 * j, 2)) / (_ROOTPI / np.sqrt(2.0))
-                       for j in range(_LMAX - 1, 1, -1)])
-
-
-def _isj_fixed_point(h, N, I, logI, a2):
-    """The Botev improved-Sheather-Jones fixed point on device-computed DCT coefficients (kde_bandwidth.py:59-73)."""
-    if h <= 0:
-        return h - 1
-    f = 2 * np.pi ** (2 * _LMAX) * np.dot(a2, np.exp(_LMAX * logI - I * (_PISQ * h**2)))
-    for j, const in zip(range(_LMAX - 1, 1, -1), _CONSTS_1D):
-        t_j = (const / N / f) ** (2 / (3.0 + 2 * j))
-        f = 2 * np.pi ** (2 * j) * np.dot(a2, np.exp(j * logI - I * (_PISQ * t_j)))
-        if not f:
-            raise Exception("zero f in _bandwidth_fixed_point (non-convergence)")
-    return h - (2 * N * _ROOTPI * f) ** (-1.0 / 5)
-
-
-def _isj_solve(a, Neff):
-    """Root-find of kde_bandwidth.py:113-135 (same scipy solvers, start point and tolerances); None on failure."""
-    I = np.arange(1, a.size) ** 2
-    logI = np.log(I)
-    a2 = (a[1:] / 2) ** 2
-    try:
-        n_scaling = Neff ** (-1.0 / 5)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            hfrac = 0.53 * n_scaling
-            hfrac = fsolve(_isj_fixed_point, hfrac, (Neff, I, logI, a2), xtol=hfrac / 20, factor=1)[0]
-        if hfrac < 0.019 * n_scaling:
-            try:
-                hfrac = brentq(_isj_fixed_point, 0.019 * n_scaling, 0.5, (Neff, I, logI, a2), xtol=hfrac / 20)
-            except Exception:
-                pass
-        return hfrac
-    except Exception as e:
-        logging.warning("1D auto bandwidth failed. Using fallback: %s" % e)
-        return None
 
 
 def _amise(cov, p, N, corr=None):
@@ -1665,11 +1621,14 @@ class MCSamples:
     def getAutoBandwidth1D(self, bins, par, param, mult_bias_correction_order=None, kernel_order=1, N_eff=None):
         if N_eff is None:
             N_eff = self._get1DNeff(par, param)
-        a = self.ctx.dct1d(np.asarray(bins, dtype=np.float64)[None, :])[0]
-        return self._bandwidth_1d_from_dct(a, par, N_eff, mult_bias_correction_order, kernel_order)
+        h, status = self.ctx.isj1d(np.asarray(bins, dtype=np.float64)[None, :], [N_eff])
+        return self._bandwidth_1d(None if status[0] else h[0], par, N_eff, mult_bias_correction_order, kernel_order)
 
-    def _bandwidth_1d_from_dct(self, a, par, N_eff, mult_bias_correction_order, kernel_order):
-        h = _isj_solve(a, N_eff)
+    def _bandwidth_1d(self, h, par, N_eff, mult_bias_correction_order, kernel_order):
+        """The scalar tail of getAutoBandwidth1D (mcsamples.py:1256-1283) given the device's ISJ solution ``h`` (None
+        where the solver failed): rule-of-thumb fallback when it failed or is very small, higher-order rescaling."""
+        if h is None:
+            logging.warning("1D auto bandwidth failed. Using fallback: zero f in _bandwidth_fixed_point (non-convergence)")
         bin_range = max(par.param_max, par.range_max) - min(par.param_min, par.range_min)
         if h is None or h < 0.01 * N_eff ** (-1.0 / 5) * (par.range_max - par.range_min) / bin_range:
             hnew = 1.06 * par.sigma_range * N_eff ** (-1.0 / 5) / bin_range
@@ -1731,17 +1690,17 @@ class MCSamples:
             edges.append(self._bin_edges(par, fine_bins))
         hist = self.ctx.hist1d(js, [e[1] for e in edges], [e[0] for e in edges], fine_bins)
         smooth, winw, flags = [], [], []
-        dct = None
+        isj_h = isj_status = None
         if smooth_scale_1D <= 0:
             self._neff_batch(js)
-            dct = self.ctx.dct1d(hist)
+            isj_h, isj_status = self.ctx.isj1d(hist, [self._get1DNeff(par, j) for j, par in zip(js, pars)])
         for b, (j, par) in enumerate(zip(js, pars)):
             fine_width, binmin, binmax = edges[b]
             paramrange = par.range_max - par.range_min
             width = paramrange / (num_bins - 1)
             if smooth_scale_1D <= 0:
                 N_eff = self._get1DNeff(par, j)
-                bandwidth = self._bandwidth_1d_from_dct(dct[b], par, N_eff, mbc, bco) * (binmax - binmin)
+                bandwidth = self._bandwidth_1d(None if isj_status[b] else isj_h[b], par, N_eff, mbc, bco) * (binmax - binmin)
                 bandwidth = min(bandwidth, paramrange / 4)
                 smooth_1D = bandwidth * abs(smooth_scale_1D) / fine_width
             elif smooth_scale_1D < 1.0:

@@ -150,6 +150,15 @@ int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t
                       const double* r1, const double* xmin, const double* dx, const double* ymin, const double* dy,
                       int32_t F, void* d_hist);
 
+/* gd_isj1d: kde_bandwidth.py:102-135 gaussian_kde_bandwidth_binned for B histograms (host, B x F) with effective
+ *   sample numbers neff[b]: DCT-II of hist/sum, the Botev improved-Sheather-Jones fixed point (:59-73) solved by
+ *   MINPACK hybrd for one unknown as scipy.optimize.fsolve(x0 = 0.53 N^-1/5, xtol = x0/20, factor = 1) runs it, then
+ *   the brentq re-check on [0.019 N^-1/5, 0.5] when the root is below 0.019 N^-1/5 -- all inside one kernel.
+ *   hfrac_out[b] = bandwidth in units of the bin range; status_out[b] = GD_OK, or GD_ERR_SOLVER where the
+ *   reference returns None ("1D auto bandwidth failed": zero functional). */
+int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* neff, double* hfrac_out,
+             int32_t* status_out);
+
 /* ---------------------------------------------------------------- 1D density -------------------
  * gd_dct1d: a = DCT-II(data/sum(data)) (scipy.fftpack.dct type 2, unnormalised), for the Botev ISJ
  *   fixed point (kde_bandwidth.py:113-117).  in/out host arrays B x F.

@@ -129,6 +129,35 @@ def ingestion_cases():
     return cases
 
 
+def histogram_shape_zoo(n_cases, seed=5, F=1024):
+    """Histograms of Gaussian, bimodal, half-Gaussian at an edge, FLAT (uniform between bounds / over the whole range:
+    the cases where fsolve wanders to h <= 0 and leaves through MINPACK's slow-progress exits), exponential, mixed and
+    U-shaped samples, with random sizes and effective sample numbers."""
+    rng = np.random.default_rng(seed)
+    for k in range(n_cases):
+        kind = k % 8
+        N = int(10 ** rng.uniform(3, 6))
+        if kind == 0:
+            s = rng.normal(0.5, 0.08, N)
+        elif kind == 1:
+            s = np.concatenate([rng.normal(0.3, 0.05, N // 2), rng.normal(0.7, 0.07, N - N // 2)])
+        elif kind == 2:
+            s = np.abs(rng.normal(0, 0.2, N)) + 0.1
+        elif kind == 3:
+            s = rng.uniform(0.1, 0.9, N)
+        elif kind == 4:
+            s = rng.uniform(0.0, 1.0, N)
+        elif kind == 5:
+            s = rng.exponential(0.1, N) + 0.05
+        elif kind == 6:
+            s = np.concatenate([rng.uniform(0.2, 0.4, N // 2), rng.normal(0.7, 0.02, N - N // 2)])
+        else:
+            s = rng.beta(0.5, 0.5, N)
+        s = s[(s >= 0) & (s <= 1)]
+        hist = np.bincount((s * (F - 1) + 0.5).astype(int), minlength=F).astype(float)
+        yield kind, hist, len(s) / rng.uniform(1, 30)
+
+
 def fixture_zoo():
     """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
     zoo = []

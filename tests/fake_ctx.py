@@ -157,6 +157,18 @@ class FakeContext:
         P = np.asarray(d_P.a).reshape(B, F, F)
         return np.array([ko.contour_levels(P[b], tuple(contours)) for b in range(B)]), np.zeros(B, dtype=np.int32)
 
+    def isj1d(self, hist, neff):
+        hist = np.asarray(hist, dtype=float)
+        h = np.zeros(len(hist))
+        status = np.zeros(len(hist), dtype=np.int32)
+        for b in range(len(hist)):
+            v = ko.isj_bandwidth_binned(hist[b], neff[b])
+            if v is None:
+                status[b] = -5
+            else:
+                h[b] = v
+        return h, status
+
     def limits1d(self, P, x0, spacing, contours, factor=0):
         P = np.asarray(P, dtype=float)
         B, F = P.shape

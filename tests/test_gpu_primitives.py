@@ -364,3 +364,31 @@ def test_limits1d_batch_matches_the_reference_algorithm(ctx, F):
             want = ko.density_limits_1d(x, P[b], contours, factor or None)
             assert np.array_equal(got[b][:, 2:], want[:, 2:]), (F, b, got[b], want)
             assert np.max(np.abs(got[b][:, :2] - want[:, :2])) < 1e-9 * (x[-1] - x[0]), (F, b, got[b], want)
+
+
+@pytest.mark.parametrize("F", [1024, 256])
+def test_isj1d_device_solver_matches_scipy_path(ctx, F):
+    """gd_isj1d (DCT + MINPACK hybrd n=1 + brentq re-check inside one kernel) against the oracle, which runs scipy's
+    fsolve / brentq on the same histograms: the iteration paths coincide (tests/test_native_solvers.py pins the port
+    bit for bit on the CPU), so the stopping points agree to the rounding of the functional (device exp / summation
+    order), also for the flat shapes that leave through MINPACK's slow-progress exits and for failures (None)."""
+    from oracle import kde_oracle as ko
+    from oracle.fixtures import histogram_shape_zoo
+
+    cases = list(histogram_shape_zoo(72, seed=23, F=F))
+    hist = np.array([c[1] for c in cases])
+    neff = np.array([c[2] for c in cases])
+    h, status = ctx.isj1d(hist, neff)
+    n_none = n_recheck = 0
+    worst = 0.0
+    for b, (kind, hb, nb) in enumerate(cases):
+        want = ko.isj_bandwidth_binned(hb, nb)
+        if want is None:
+            n_none += 1
+            assert status[b] != 0, (b, kind)
+            continue
+        assert status[b] == 0, (b, kind)
+        n_recheck += want < 0.019 * nb ** (-0.2) * 1.0000001
+        worst = max(worst, abs(h[b] - want) / abs(want))
+        assert abs(h[b] - want) <= 1e-9 * abs(want), (b, kind, h[b], want)
+    print("isj1d worst relative deviation %.2e, %d failures, %d near the re-check threshold" % (worst, n_none, n_recheck))

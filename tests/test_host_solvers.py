@@ -5,20 +5,9 @@ solver-path parity argument (the chaotic half is documented in DESIGN.md).
 """
 
 import numpy as np
-from scipy import fftpack
 
 from getdist_amd import mcsamples as hm
 from oracle import kde_oracle as ko
-
-
-def test_isj_solve_matches_oracle(zoo):
-    fx = zoo["shapes"]
-    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
-    for j in range(orc.n):
-        d = orc.density_1d(j)
-        neff = orc.pars[j].N_eff_kde
-        a = fftpack.dct(d["bins"] / np.sum(d["bins"]))
-        assert hm._isj_solve(a, neff) == ko.isj_bandwidth_binned(d["bins"], neff)
 
 
 def test_get_h_matches_oracle(zoo):
