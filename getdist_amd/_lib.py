@@ -85,7 +85,8 @@ SIGNATURES = {
     "gd_dct1d": (C.c_int, [_p, _i32, _i32, _pd, _pd]),
     "gd_isj1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pi32]),
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
-    "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd]),
+    "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd]),
+    "gd_get_h": (C.c_int, [_p, _i32, _pd, _pd, _pd, _pi32, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
     "gd_attach_samples": (C.c_int, [_p, _p]),
     "gd_bind_thread": (C.c_int, [_p]),
@@ -632,11 +633,19 @@ class Context:
                                         _ip(winw), _ip(flags), int(mbc), out.ptr, _ip(status)))
         return out, status
 
-    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t):
-        neff, do_corr, fallback_t = _f64arr(neff), _i32arr(do_corr), _f64arr(fallback_t)
-        out = np.zeros((B, 8))
+    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t, corr):
+        """B x 12: {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status, hx, hy, corr, get_h status}"""
+        neff, do_corr, fallback_t, corr = _f64arr(neff), _i32arr(do_corr), _f64arr(fallback_t), _f64arr(corr)
+        out = np.zeros((B, 12))
         self._check(self.lib.gd_kopt2d(self.h, B, F, d_hist.ptr if isinstance(d_hist, DevBuf) else d_hist, _dp(neff),
-                                       _ip(do_corr), _dp(fallback_t), _dp(out)))
+                                       _ip(do_corr), _dp(fallback_t), _dp(corr), _dp(out)))
+        return out
+
+    def get_h(self, psi, neff, corr, do_corr):
+        """B x 4 {hx, hy, corr, status} from the functionals psi (B x 6): KernelOptimizer2D.get_h on the device."""
+        psi, neff, corr, do_corr = _f64arr(psi).reshape(-1, 6), _f64arr(neff), _f64arr(corr), _i32arr(do_corr)
+        out = np.zeros((len(psi), 4))
+        self._check(self.lib.gd_get_h(self.h, len(psi), _dp(psi), _dp(neff), _dp(corr), _ip(do_corr), _dp(out)))
         return out
 
     def density2d(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, out=None):

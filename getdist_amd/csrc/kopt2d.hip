@@ -7,9 +7,11 @@
 // psi functionals get_h needs, and -- when the pair is unbounded -- the odd functionals from |fft2|^2
 // (rocFFT).  Reference: kde_bandwidth.py:146-270.
 #include "ctx.hpp"
+#include "solvers.hpp"
 
 #define KT 1024
 #define MAXF 6  // forms per level
+#define KOPT_STRIDE 12  // doubles per pair in the optimiser's result row (see k_get_h)
 #define PI 3.141592653589793238462643383279502884
 #define PISQ (PI * PI)
 
@@ -430,17 +432,68 @@ __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all
         }
     }
     if (threadIdx.x == 0) {
-        double* o = out + (int64_t)b * 8;
+        double* o = out + (int64_t)b * KOPT_STRIDE;
         o[0] = (status == GD_OK) ? t_star : NAN;
         o[1] = p02, o[2] = p20, o[3] = p11, o[4] = p00, o[5] = p13, o[6] = p31, o[7] = (double)status;
     }
 }
 
+// ---- get_h: closed-form bandwidths + the two TNC minimisations of the AMISE (kde_bandwidth.py:234-306) -------------
+// The AMISE is a function of ~9 scalars; scipy's TNC (tnc.c + finite-difference gradients) is ported in solvers.hpp and
+// pinned against scipy evaluation by evaluation.  One wavefront per pair, lane 0 runs the scalar optimiser (a few
+// hundred AMISE evaluations); hundreds of pairs run concurrently on separate SIMDs, so the whole stage costs about one
+// pair's serial latency instead of a host process pool.
+// kopt: B x KOPT_STRIDE doubles {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status, hx, hy, c, get_h status}
+__global__ void __launch_bounds__(64) k_get_h(double* __restrict__ kopt, const double* __restrict__ neff,
+                                              const double* __restrict__ corr, const int* __restrict__ do_corr, int B) {
+    const int b = blockIdx.x;
+    if (b >= B || threadIdx.x != 0) return;
+    double* o = kopt + (int64_t)b * KOPT_STRIDE;
+    o[8] = o[9] = o[10] = NAN;
+    o[11] = (double)GD_ERR_SOLVER;
+    if (o[7] != (double)GD_OK) return;
+    const gdsolve::GetHResult r = gdsolve::get_h(o + 1, neff[b], corr[b], do_corr[b] != 0);
+    o[8] = r.hx, o[9] = r.hy, o[10] = r.corr;
+    o[11] = r.status ? (double)GD_ERR_BADARG : (double)GD_OK;  // status 1: "bias not positive definite"
+}
+
 extern "C" {
 
+int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, const double* corr, const int32_t* do_corr,
+             double* out) {
+    GD_REQUIRE(ctx && psi && neff && corr && do_corr && out && B > 0, "bad argument");
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_k = take((int64_t)B * KOPT_STRIDE * 8), o_n = take((int64_t)B * 8), o_c = take((int64_t)B * 8),
+                  o_d = take((int64_t)B * 4);
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    std::vector<double> hk((size_t)B * KOPT_STRIDE, 0.0);
+    for (int b = 0; b < B; ++b) {
+        for (int q = 0; q < 6; ++q) hk[(size_t)b * KOPT_STRIDE + 1 + q] = psi[(size_t)b * 6 + q];
+        hk[(size_t)b * KOPT_STRIDE + 7] = (double)GD_OK;
+    }
+    GD_HIP(hipMemcpyAsync(base + o_k, hk.data(), hk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(base + o_n, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(base + o_c, corr, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(base + o_d, do_corr, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_get_h<<<B, 64, 0, ctx->stream>>>((double*)(base + o_k), (const double*)(base + o_n), (const double*)(base + o_c),
+                                      (const int*)(base + o_d), B);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(hk.data(), base + o_k, hk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < 4; ++q) out[(size_t)b * 4 + q] = hk[(size_t)b * KOPT_STRIDE + 8 + q];
+    return GD_OK;
+}
+
 int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* neff, const int32_t* do_corr,
-              const double* fallback_t, double* out) {
-    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && out && B > 0, "bad argument");
+              const double* fallback_t, const double* corr, double* out) {
+    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && corr && out && B > 0, "bad argument");
     GD_REQUIRE(F >= 16 && F <= 1024, "KernelOptimizer2D grid size out of range (16..1024)");
     const double* d_hist = (const double*)d_hist_v;
     const int64_t FF = (int64_t)F * F;
@@ -475,7 +528,8 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_sums = take((int64_t)B * 8), o_pairs = take((int64_t)B * sizeof(KoptPair)), o_out = take((int64_t)B * 64),
+    const int64_t o_sums = take((int64_t)B * 8), o_pairs = take((int64_t)B * sizeof(KoptPair)), o_out = take((int64_t)B * KOPT_STRIDE * 8), o_neff = take((int64_t)B * 8), o_corr = take((int64_t)B * 8),
+                  o_dc = take((int64_t)B * 4),
                   o_which = take((int64_t)(nc + 1) * 4), o_E = take((int64_t)B * FF * 8), o_SQ = take((int64_t)B * FF * 8),
                   o_Z = take((int64_t)nc * F * Fh * 16), o_PW = take((int64_t)nc * FF * 8);
     char* base = (char*)gd_scratch(ctx, off);
@@ -512,7 +566,14 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
     GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, d_out);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)B * 64, hipMemcpyDeviceToHost, ctx->stream));
+    // get_h on the device: the optimiser's functionals never leave HBM
+    GD_HIP(hipMemcpyAsync(base + o_neff, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(base + o_corr, corr, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(base + o_dc, do_corr, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_get_h<<<B, 64, 0, ctx->stream>>>(d_out, (const double*)(base + o_neff), (const double*)(base + o_corr),
+                                      (const int*)(base + o_dc), B);
+    GD_KERNEL_CHECK();
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)B * KOPT_STRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;
 }

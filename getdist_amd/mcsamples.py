@@ -21,7 +21,6 @@ import time
 import warnings
 
 import numpy as np
-from scipy.optimize import minimize
 
 from ._lib import Context
 from .densities import Density1D, Density2D, DensitiesError
@@ -174,56 +173,6 @@ class ParamBounds:
         return self.upper.get(name)
 
 
-def _amise(cov, p, N, corr=None):
-    """kde_bandwidth.py:216-232 on the psi functionals p[(i,j)]"""
-    hx, hy = cov[0], cov[1]
-    c = corr if corr is not None else cov[2]
-    var = 1.0 / (4 * np.pi * hx * hy * np.sqrt(1 - c**2) * N)
-    bias = 0.25 * (hx**4 * p[4, 0] + hy**4 * p[0, 4] + 2 * hx**2 * hy**2 * p[2, 2] * (2 * c**2 + 1)
-                   + 4 * c * hx * hy * (hx**2 * p[3, 1] + hy**2 * p[1, 3]))
-    if bias < 0:
-        raise Exception("bias not positive definite")
-    return var + bias
-
-
-def _get_h(psi, N, corr_in, do_correlation):
-    """
-    KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given the device-computed functionals
-    psi = (p02, p20, p11, p00, p13, p31).  The two TNC minimisations act on these scalars only.
-    """
-    p_02, p_20, p_11, p_00, p_13, p_31 = psi
-    h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * N * p_20 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
-    h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * N * p_02 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
-    corr = 0
-    if not do_correlation:
-        return h_x, h_y, corr
-    p = np.zeros((5, 5))
-    p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = p_02, p_20, p_11, p_00, p_13, p_31
-    AMISE = _amise(np.array([h_x, h_y, 0]), p, N)
-    if corr_in:
-        try:
-            res = minimize(_amise, np.array([h_x, h_y]) / np.sqrt(1 - abs(corr_in)), (p, N, corr_in), method="TNC",
-                           bounds=[(0.001, 0.3), (0.001, 0.3)])
-            if res.success:
-                AMISEcorr = _amise(res.x, p, N, corr_in)
-                if AMISEcorr < AMISE:
-                    h_x, h_y = res.x
-                    corr = corr_in
-                    AMISE = AMISEcorr
-        except Exception:
-            logging.debug("AMISE fixed correlation optimization failed")
-    try:
-        res = minimize(_amise, np.array([h_x, h_y, corr_in]), (p, N, None), method="TNC",
-                       bounds=[(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)])
-        if res.success:
-            AMISEopt = _amise(res.x, p, N)
-            if AMISEopt < AMISE * 0.9:
-                h_x, h_y, corr = res.x
-    except Exception:
-        logging.debug("AMISE optimization failed")
-    return h_x, h_y, corr
-
-
 def _read_ini_settings(ini):
     """
     The analysis settings of a GetDist .ini file (``key = value`` lines, ``#`` comments; inifile.py:100-180) that this
@@ -274,9 +223,6 @@ def _stack_rows(parts):
     return out
 
 
-_POOL = None
-
-
 class _Phase:
     """Wall-clock phase accounting (enabled by GETDIST_AMD_TIMING=1; syncs the stream at phase edges)."""
 
@@ -292,116 +238,6 @@ class _Phase:
         if self.mc._timing:
             self.mc.ctx.sync()
             self.mc.timings[self.name] = self.mc.timings.get(self.name, 0.0) + time.perf_counter() - self.t0
-
-
-_POOL_LOCK = threading.Lock()
-
-
-def _get_h_job(job):
-    return _get_h(*job)
-
-
-def _tnc_workers():
-    env = os.environ.get("GETDIST_AMD_TNC_WORKERS")
-    if env:
-        return int(env)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
-    return max(1, min(64, (os.cpu_count() or 1) // max(1, local_world)))
-
-
-class _Solved:
-    def __init__(self, values):
-        self.values = values
-
-    def get(self):
-        return self.values
-
-
-class _TncPool:
-    """
-    Persistent pool of `python -m getdist_amd._tnc_worker` subprocesses (pipes + pickle).  subprocess instead of
-    multiprocessing on purpose: spawn/forkserver re-import the user's __main__ in every worker (a script without
-    a __main__ guard would re-run itself N times), and fork would duplicate a process holding a HIP context.
-    """
-
-    def __init__(self, workers):
-        import atexit
-        import subprocess
-        import sys
-
-        env = dict(os.environ)
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-            env[k] = "1"
-        self.workers = workers
-        self.procs = [subprocess.Popen([sys.executable, "-m", "getdist_amd._tnc_worker"], stdin=subprocess.PIPE,
-                                       stdout=subprocess.PIPE, env=env) for _ in range(workers)]
-        atexit.register(self.close)
-
-    def close(self):
-        for p in self.procs:
-            try:
-                p.stdin.close()
-            except Exception:
-                pass
-        for p in self.procs:
-            try:
-                p.wait(timeout=2)
-            except Exception:
-                p.kill()
-        self.procs = []
-
-    MAX_SHARE = 300  # jobs per worker per round: keeps every blob far below the 64 KiB pipe buffer (no deadlock)
-
-    def submit(self, jobs, lane=0, nlanes=1):
-        """``lane`` of ``nlanes``: concurrent callers (the two lanes of a triangle) own disjoint worker processes, so
-        their length-prefixed request / reply streams never interleave on a pipe."""
-        import pickle
-        import struct
-
-        procs = self.procs[lane::nlanes] if nlanes > 1 and len(self.procs) >= nlanes else self.procs
-        if len(jobs) > len(procs) * self.MAX_SHARE:  # very large batches: resolve in synchronous rounds
-            out = []
-            step = len(procs) * self.MAX_SHARE
-            for a in range(0, len(jobs), step):
-                out += self.submit(jobs[a:a + step], lane, nlanes).get()
-            return _Solved(out)
-        n = len(jobs)
-        use = max(1, min(len(procs), (n + 3) // 4))  # at least ~4 jobs per worker: fewer pipe round trips
-        shares = [list(range(w, n, use)) for w in range(use)]  # interleaved: even cost mix
-        active = []
-        for p, idx in zip(procs, shares):
-            if not idx:
-                continue
-            blob = pickle.dumps([(tuple(map(float, jobs[i][0])), float(jobs[i][1]), float(jobs[i][2]), bool(jobs[i][3]))
-                                 for i in idx], protocol=pickle.HIGHEST_PROTOCOL)
-            p.stdin.write(struct.pack("<q", len(blob)))
-            p.stdin.write(blob)
-            p.stdin.flush()
-            active.append((p, idx))
-        return _PoolResult(active, n)
-
-
-class _PoolResult:
-    def __init__(self, active, n):
-        self.active, self.n = active, n
-
-    def get(self):
-        import pickle
-        import struct
-
-        out = [None] * self.n
-        for p, idx in self.active:
-            head = p.stdout.read(8)
-            if len(head) < 8:
-                raise RuntimeError("TNC worker died")
-            (m,) = struct.unpack("<q", head)
-            for i, r in zip(idx, pickle.loads(p.stdout.read(m))):
-                if isinstance(r, Exception):
-                    raise r
-                out[i] = tuple(np.float64(v) for v in r)
-        return out
 
 
 def _g2_markov_vs_second_order(tran):
@@ -459,37 +295,6 @@ def _set_all_edge_mask_2d(prior_mask, winw):
     prior_mask[:, -winw:] = 0
     prior_mask[:winw] = 0
     prior_mask[-winw:, :] = 0
-
-
-class _Deferred:
-    """A pool handle that is itself still being created in the helper thread."""
-
-    def __init__(self, future):
-        self.future = future
-
-    def get(self):
-        return self.future.result().get()
-
-
-def _get_h_many(jobs, workers=None, lane=0, nlanes=1):
-    """
-    Start many independent get_h solves; returns an object whose .get() yields the results in order.  TNC costs
-    0.5-8 ms per pair on ~9 scalars and a triangle has hundreds of them, so they are farmed to a
-    persistent pool of host worker processes (pure functions of their arguments) and run while the GPU works on
-    the pairs that do not need them.
-    """
-    global _POOL
-    if workers is None:
-        workers = _tnc_workers()
-    if workers <= 1 or len(jobs) < 6:
-        return _Solved([_get_h(*j) for j in jobs])
-    with _POOL_LOCK:
-        if _POOL is None or _POOL.workers != workers:
-            if _POOL is not None:
-                _POOL.close()
-            _POOL = _TncPool(workers)
-        pool = _POOL
-    return pool.submit(jobs, lane, nlanes)
 
 
 class MCSamples:
@@ -1857,7 +1662,7 @@ class MCSamples:
         d = self.ctx.alloc(bins.nbytes)
         d.from_host(bins)
         plan = self._bandwidth_plan([(paramx, paramy)], [corr], [(rangex, rangey)], base_fine_bins_2D, N_eff=N_eff)
-        res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)()
+        res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)
         return res[0]
 
     def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None):
@@ -1918,22 +1723,21 @@ class MCSamples:
 
     def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order):
         """
-        getAutoBandwidth2D for a batch.  ``hists_by_F``: F -> (device buffer of that class's histograms,
-        list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.
+        getAutoBandwidth2D for a batch (mcsamples.py:1325-1419).  ``hists_by_F``: F -> (device buffer of that class's
+        histograms, list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.  Returns the
+        list of (hx, hy, corr) in parameter units.  The whole KernelOptimizer2D -- fixed point, functionals, get_h with
+        its TNC minimisations -- runs on the device (gd_kopt2d); here only branch bookkeeping and unit conversions.
         """
         results = [None] * len(plan)
         ctx = self.ctx
         for e in plan:
             e["kopt"] = None
-        jobs, job_meta = [], []
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
-        pendings = []  # (pooled [(job, meta)], handle): TNC solves running in the host worker pool
 
-        def to_param_units(meta, solved):
-            branch, k, r1, r2 = meta
+        def to_param_units(branch, k, r1, r2, solved):
             hx, hy, c = solved
             e = plan[k]
-            if branch == "A":
+            if branch == "A":  # de-rotate the sheared kernel (mcsamples.py:1379-1390)
                 hx *= r1
                 hy *= r2
                 S = e["S"]
@@ -1945,35 +1749,9 @@ class MCSamples:
                 return hx, hy, c
             return hx * e["rangex"], hy * e["rangey"], c
 
-        def rescale(k):
-            if m:
-                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
-                hx, hy, c = results[k]
-                results[k] = (hx * scale, hy * scale, c)
-
-        def submit():
-            """Closed-form solves now; TNC solves go to the pool immediately so they overlap the next device stage."""
-            pooled = [(job, meta) for job, meta in zip(jobs, job_meta) if job[3]]
-            if pooled:
-                # the pipe writes to the workers go through the helper thread: the workers start at once and the
-                # closed-form solves below run meanwhile
-                pendings.append((pooled, _Deferred(self._helper().submit(_get_h_many, [job for job, _ in pooled], None, self._lane, self._nlanes))))
-            closed = [(job, meta) for job, meta in zip(jobs, job_meta) if not job[3]]
-            if closed:
-                # get_h without the correlation search is the closed form of kde_bandwidth.py:245-252: all pairs at once
-                psi = np.array([job[0][:3] for job, _ in closed], dtype=np.float64)
-                neff_v = np.array([job[1] for job, _ in closed], dtype=np.float64)
-                p_02, p_20, p_11 = psi[:, 0], psi[:, 1], psi[:, 2]
-                cross = p_11 + np.sqrt(p_20 * p_02)
-                with np.errstate(invalid="ignore", divide="ignore"):
-                    h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * neff_v * p_20 ** (3.0 / 4) * cross)) ** (1.0 / 6)
-                    h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * neff_v * p_02 ** (3.0 / 4) * cross)) ** (1.0 / 6)
-                for (_, meta), a, b in zip(closed, h_x, h_y):
-                    results[meta[1]] = to_param_units(meta, (a, b, 0))
-            del jobs[:], job_meta[:]
-
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
+        shear = None
         if A:
             mm = ctx.minmax_affine([plan[k]["i"] for k in A], [plan[k]["j"] for k in A], [plan[k]["r"][0] for k in A],
                                    [plan[k]["r"][1] for k in A])
@@ -1996,8 +1774,6 @@ class MCSamples:
                                        [plan[k]["r"][0] for k in A], [plan[k]["r"][1] for k in A], xmin, dx, ymin, dy,
                                        base_F)
             shear = dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
-        else:
-            shear = None
         # -- branch B: rule of thumb
         for k, e in enumerate(plan):
             if e["branch"] == "B":
@@ -2009,15 +1785,17 @@ class MCSamples:
             ks = [k for _, k, _, _ in rows]
             do_corr = [0 if plan[k]["has_limits"] else 1 for k in ks]
             fb = [-1.0 if br == "A" else plan[k]["fallback_t"] for br, k, _, _ in rows]
-            out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb)
+            corr_in = [0.0 if br == "A" else plan[k]["corr"] for br, k, _, _ in rows]
+            out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb, corr_in)
             for row, (br, k, r1, r2) in enumerate(rows):
                 e = plan[k]
                 e["kopt"] = out[row]
                 if out[row, 7] != 0:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                    continue
-                jobs.append((tuple(out[row, 1:7]), e["neff"], 0 if br == "A" else e["corr"], bool(do_corr[row])))
-                job_meta.append((br, k, r1, r2))
+                elif out[row, 11] != 0:
+                    raise Exception("bias not positive definite")  # kde_bandwidth.py:229-230, raised out of get_h
+                else:
+                    results[k] = to_param_units(br, k, r1, r2, tuple(out[row, 8:11]))
 
         # -- branches A and C share the device optimiser: the sheared histograms ride in the same launch as the
         #    base-grid pairs' own histograms (one block per pair; a short extra launch would cost a full block latency)
@@ -2049,22 +1827,12 @@ class MCSamples:
             optimise(base_F, shear["d_rot"], rows_A)
         if shear is not None:
             shear["d_rot"].free()
-        submit()
-        early = [k for k in range(len(plan)) if results[k] is not None]
-        for k in early:
-            rescale(k)
-
-        def finish():
-            """Collect the pooled host solves; returns the complete list of (hx, hy, corr)."""
-            with _Phase(self, "2d.bandwidth.host_get_h_wait"):
-                for pooled, handle in pendings:
-                    for (_, meta), sol in zip(pooled, handle.get()):
-                        results[meta[1]] = to_param_units(meta, sol)
-                        rescale(meta[1])
-            return results
-
-        finish.early = {k: results[k] for k in early}
-        return finish
+        if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416)
+            for k in range(len(plan)):
+                hx, hy, c = results[k]
+                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
+                results[k] = (hx * scale, hy * scale, c)
+        return results
 
     def _gather_device(self, d_src, d_dst, positions, item_bytes):
         """Copy selected fixed-size items of one device buffer into another (one gather kernel)."""
@@ -2249,10 +2017,8 @@ class MCSamples:
                 pending.result()
         else:
             binning()
-        # ---- bandwidths: device optimiser now, host TNC solves asynchronously in the process pool
+        # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
         rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
-        finish_bw = None
-        ready = [True] * len(info)
 
         def set_widths(k, bw_k):
             e = info[k]
@@ -2273,14 +2039,10 @@ class MCSamples:
                                                     [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
                                                     base_F)
                 with _Phase(self, "2d.bandwidth.device"):
-                    finish_bw = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
+                    widths = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
                 for k, e in enumerate(info):
                     e["branch"], e["kopt"] = plan[k]["branch"], plan[k]["kopt"]
-                    ready[k] = k in finish_bw.early  # the rest waits for the TNC pool
-                    if ready[k]:
-                        set_widths(k, finish_bw.early[k])
-                if all(ready):
-                    finish_bw = None
+                    set_widths(k, widths[k])
         else:
             for k, e in enumerate(info):
                 if smooth_scale_2D < 1.0:
@@ -2314,13 +2076,10 @@ class MCSamples:
                 bits_cache[j] = (lim | (16 if p.periodic else 0), (lim << 2) | (32 if p.periodic else 0), bool(p.has_limits))
             return bits_cache[j]
 
-        def run_class(F, d_hist, members, stage):
-            """Convolve the pairs of one grid-size class that belong to ``stage`` (0: bandwidth known now,
-            1: bandwidth arrives from the host TNC pool)."""
+        def run_class(F, d_hist, members):
+            """Convolve the pairs of one grid-size class."""
             groups = {}
             for pos, k in enumerate(members):
-                if (0 if ready[k] else 1) != stage:
-                    continue
                 e = info[k]
                 bx, by = par_bits(e["j"]), par_bits(e["j2"])
                 has_prior = bx[2] or by[2] or mask_function is not None  # mcsamples.py:1794
@@ -2416,13 +2175,7 @@ class MCSamples:
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
 
         for F, (d_hist, members) in hists.items():
-            run_class(F, d_hist, members, 0)
-        if finish_bw is not None:
-            for k, b in enumerate(finish_bw()):
-                if not ready[k]:
-                    set_widths(k, b)
-            for F, (d_hist, members) in hists.items():
-                run_class(F, d_hist, members, 1)
+            run_class(F, d_hist, members)
         for F, (d_hist, members) in hists.items():
             d_hist.free()
         for d_lh in likehists.values():

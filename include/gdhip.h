@@ -179,9 +179,19 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
  *   rtol=4eps, maxiter=100), the fallback_t rules (:164-175; fallback_t<=0 means None),
  *   psi_02, psi_20, psi_11 = func2d at t* (:245-247), and when do_corr[b]: psi_00 (:267) and the odd
  *   functionals psi_13, psi_31 from |fft2|^2 (:156-157,198-214,269-270).
- *   out: B x 8 = {t_star, p02, p20, p11, p00, p13, p31, status(0 ok, <0 gd_status)}. */
+ *   Then KernelOptimizer2D.get_h (:234-306) on the device, one wavefront per pair: the closed-form bandwidths
+ *   (:245-252) and, when do_corr[b], the two TNC minimisations of the AMISE (:276-302) started from corr[b]
+ *   (scipy.optimize.minimize(method="TNC") ported evaluation-faithfully, csrc/solvers.hpp), with the reference's
+ *   acceptance rules.
+ *   out: B x 12 = {t_star, p02, p20, p11, p00, p13, p31, status(0 ok, <0 gd_status), hx, hy, corr,
+ *   get_h status (0 ok, GD_ERR_BADARG = "bias not positive definite", GD_ERR_SOLVER = no functionals)};
+ *   hx, hy are fractions of the histogram's bin range. */
 int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
-              const double* fallback_t, double* out);
+              const double* fallback_t, const double* corr, double* out);
+/* gd_get_h: the get_h stage alone, from host arrays: psi is B x 6 = {p02, p20, p11, p00, p13, p31};
+ *   out: B x 4 = {hx, hy, corr, status}. */
+int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, const double* corr, const int32_t* do_corr,
+             double* out);
 
 /* ---------------------------------------------------------------- 2D density -------------------
  * gd_density2d: everything after the bandwidth for B pairs sharing F (mcsamples.py:1857-1990):

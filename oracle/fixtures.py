@@ -158,6 +158,30 @@ def histogram_shape_zoo(n_cases, seed=5, F=1024):
         yield kind, hist, len(s) / rng.uniform(1, 30)
 
 
+def random_psi_tuples(n, seed=3, wide=False):
+    """
+    Random but realistic inputs of KernelOptimizer2D.get_h: the psi functionals of a correlated bivariate Gaussian of
+    widths (sx, sy) in bin-range units and correlation rho, each perturbed by 20-30 %, an effective sample number and
+    the sample correlation handed to the optimiser.  Yields (psi = (p02, p20, p11, p00, p13, p31), N, corr).
+    """
+    rng = np.random.default_rng(seed)
+    made = 0
+    while made < n:
+        N = 10 ** (rng.uniform(1.5, 7.5) if wide else rng.uniform(2.5, 6.5))
+        sx, sy = (10 ** rng.uniform(-2.3, -0.4, 2)) if wide else rng.uniform(0.02, 0.25, 2)
+        rho = rng.uniform(-0.95, 0.95)
+        p40 = 3 / (16 * np.pi * sx**5 * sy) * (1 + rng.normal() * 0.2)
+        p04 = 3 / (16 * np.pi * sy**5 * sx) * (1 + rng.normal() * 0.2)
+        p22 = 1 / (16 * np.pi * sx**3 * sy**3) * (1 + rng.normal() * 0.3) * (1 + 2 * rho**2)
+        p13 = 3 * rho / (16 * np.pi * sx**2 * sy**4) * (1 + rng.normal() * 0.3)
+        p31 = 3 * rho / (16 * np.pi * sx**4 * sy**2) * (1 + rng.normal() * 0.3)
+        if p40 <= 0 or p04 <= 0 or p22 + np.sqrt(p40 * p04) <= 0:
+            continue
+        corr = float(rho * rng.uniform(0.5, 1.0)) if rng.random() < 0.85 else 0.0
+        made += 1
+        yield (float(p04), float(p40), float(p22), -1.0, float(p13), float(p31)), float(N), corr
+
+
 def fixture_zoo():
     """Yields dicts(name, samples, weights, names, ranges, pairs, kw1, kw2)."""
     zoo = []

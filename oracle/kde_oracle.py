@@ -347,6 +347,7 @@ class Optimizer2D:
                 raise
         if trace is not None:
             trace["t_star"] = self.t_star
+            trace["opt_N"], trace["opt_corr"], trace["opt_do_corr"] = Neff, correlation, do_correlation
 
     def fixed_point_2d(self, t):
         sum_func = self.func2d([0, 2], t) + self.func2d([2, 0], t) + 2 * self.func2d([1, 1], t)
@@ -385,64 +386,104 @@ class Optimizer2D:
         return wy.dot(self.aFFT).real.dot(wx.T) * (2 * np.pi) ** (np.sum(s))
 
     def amise(self, cov, corr=None):
-        hx = cov[0]
-        hy = cov[1]
-        c = corr if corr is not None else cov[2]
-        var = 1.0 / (4 * np.pi * hx * hy * np.sqrt(1 - c**2) * self.N)
-        bias = 0.25 * (hx**4 * self.p[4, 0] + hy**4 * self.p[0, 4] + 2 * hx**2 * hy**2 * self.p[2, 2] * (2 * c**2 + 1)
-                       + 4 * c * hx * hy * (hx**2 * self.p[3, 1] + hy**2 * self.p[1, 3]))
-        if bias < 0:
-            raise Exception("bias not positive definite")
-        return var + bias
+        return amise_from_psi(cov, self.p, self.N, corr)
 
     def get_h(self, do_correlation=None):
         if do_correlation is None:
             do_correlation = self.do_correlation
-        p = np.zeros((5, 5))
         tpsi = self.t_star
         p_02 = self.func2d([0, 2], tpsi)
         p_20 = self.func2d([2, 0], tpsi)
         p_11 = self.func2d([1, 1], tpsi)
-        h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * self.N * p_20 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
-        h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * self.N * p_02 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+        p_00 = p_13 = p_31 = np.nan
+        if do_correlation:
+            p_00 = self.func2d([0, 0], tpsi)
+            self.p00 = p_00
+            p_13 = self.func2d_odd([1, 3], tpsi)
+            p_31 = self.func2d_odd([3, 1], tpsi)
         if self.trace is not None:
-            self.trace.update(p_02=p_02, p_20=p_20, p_11=p_11, h_x0=h_x, h_y0=h_y)
-        corr = 0
-        if not do_correlation:
-            return h_x, h_y, corr
-        p[0, 4] = p_02
-        p[4, 0] = p_20
-        p[2, 2] = p_11
-        p[0, 0] = self.func2d([0, 0], tpsi)
-        self.p00 = p[0, 0]
-        p[1, 3] = self.func2d_odd([1, 3], tpsi)
-        p[3, 1] = self.func2d_odd([3, 1], tpsi)
-        self.p = p
-        if self.trace is not None:
-            self.trace.update(p_00=p[0, 0], p_13=p[1, 3], p_31=p[3, 1])
-        AMISE = self.amise(np.array([h_x, h_y, 0]))
-        if self.corr:
-            try:
-                res = minimize(self.amise, np.array([h_x, h_y]) / np.sqrt(1 - abs(self.corr)), (self.corr,),
-                               method="TNC", bounds=[(0.001, 0.3), (0.001, 0.3)])
-                if res.success:
-                    AMISEcorr = self.amise(res.x, self.corr)
-                    if AMISEcorr < AMISE:
-                        h_x, h_y = res.x
-                        corr = self.corr
-                        AMISE = AMISEcorr
-            except Exception:
-                pass
+            self.trace.update(p_02=p_02, p_20=p_20, p_11=p_11)
+            if do_correlation:
+                self.trace.update(p_00=p_00, p_13=p_13, p_31=p_31)
+        h = get_h_from_psi((p_02, p_20, p_11, p_00, p_13, p_31), self.N, self.corr, do_correlation, owner=self)
+        return h
+
+
+def amise_from_psi(cov, p, N, corr=None):
+    """KernelOptimizer2D.AMISE (kde_bandwidth.py:216-232) on the functionals p[(i, j)]."""
+    hx = cov[0]
+    hy = cov[1]
+    c = corr if corr is not None else cov[2]
+    var = 1.0 / (4 * np.pi * hx * hy * np.sqrt(1 - c**2) * N)
+    bias = 0.25 * (hx**4 * p[4, 0] + hy**4 * p[0, 4] + 2 * hx**2 * hy**2 * p[2, 2] * (2 * c**2 + 1)
+                   + 4 * c * hx * hy * (hx**2 * p[3, 1] + hy**2 * p[1, 3]))
+    if bias < 0:
+        raise Exception("bias not positive definite")
+    return var + bias
+
+
+def get_h_is_chaotic(psi, N, corr_in, rel=1e-15, tol=1e-6, trials=6):
+    """
+    Is the reference's own get_h unstable at these inputs?  Re-runs get_h_from_psi with every functional perturbed by
+    +-(1..trials) x ``rel`` (what a different BLAS / summation order does to them) and reports whether the resulting
+    bandwidth triple moves by more than ``tol`` relative: TNC on a finite-difference gradient amplifies rounding where
+    its result is accepted.  Returns (chaotic, largest relative move).
+    """
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = np.array(get_h_from_psi(psi, N, corr_in, True), dtype=float)
+        worst = 0.0
+        for k in range(1, trials + 1):
+            for sign in (1, -1):
+                pert = tuple(v * (1 + sign * k * rel * (1 + 0.37 * q)) for q, v in enumerate(psi))
+                moved = np.array(get_h_from_psi(pert, N, corr_in, True), dtype=float)
+                worst = max(worst, float(np.max(np.abs(moved - base)) / np.max(np.abs(base))))
+    return worst > tol, worst
+
+
+def get_h_from_psi(psi, N, corr_in, do_correlation, owner=None):
+    """
+    The scalar half of KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given psi = (p02, p20, p11, p00, p13, p31):
+    closed-form axis bandwidths, then scipy's TNC on the AMISE (fixed correlation, then free) with the reference's
+    acceptance rules.  This is the checker for the device port of TNC (getdist_amd/csrc/solvers.hpp).
+    """
+    p_02, p_20, p_11, p_00, p_13, p_31 = psi
+    h_x = (p_02 ** (3.0 / 4) / (4 * np.pi * N * p_20 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+    h_y = (p_20 ** (3.0 / 4) / (4 * np.pi * N * p_02 ** (3.0 / 4) * (p_11 + np.sqrt(p_20 * p_02)))) ** (1.0 / 6)
+    if owner is not None and owner.trace is not None:
+        owner.trace.update(h_x0=h_x, h_y0=h_y)
+    corr = 0
+    if not do_correlation:
+        return h_x, h_y, corr
+    p = np.zeros((5, 5))
+    p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = p_02, p_20, p_11, p_00, p_13, p_31
+    if owner is not None:
+        owner.p = p
+    AMISE = amise_from_psi(np.array([h_x, h_y, 0]), p, N)
+    if corr_in:
         try:
-            res = minimize(self.amise, np.array([h_x, h_y, self.corr]), (None,), method="TNC",
-                           bounds=[(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)])
+            res = minimize(amise_from_psi, np.array([h_x, h_y]) / np.sqrt(1 - abs(corr_in)), (p, N, corr_in),
+                           method="TNC", bounds=[(0.001, 0.3), (0.001, 0.3)])
             if res.success:
-                AMISEopt = self.amise(res.x)
-                if AMISEopt < AMISE * 0.9:
-                    h_x, h_y, corr = res.x
+                AMISEcorr = amise_from_psi(res.x, p, N, corr_in)
+                if AMISEcorr < AMISE:
+                    h_x, h_y = res.x
+                    corr = corr_in
+                    AMISE = AMISEcorr
         except Exception:
             pass
-        return h_x, h_y, corr
+    try:
+        res = minimize(amise_from_psi, np.array([h_x, h_y, corr_in]), (p, N, None), method="TNC",
+                       bounds=[(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)])
+        if res.success:
+            AMISEopt = amise_from_psi(res.x, p, N)
+            if AMISEopt < AMISE * 0.9:
+                h_x, h_y, corr = res.x
+    except Exception:
+        pass
+    return h_x, h_y, corr
 
 
 # ----------------------------------------------------------------------------------------------

@@ -79,8 +79,8 @@ def main():
     hp = ctx.hist2d_prebinned([idx[p[0]] for p in pairs], [idx[p[1]] for p in pairs], F, out=out)
     neff = [float(N)] * len(pairs)
     for dc in (0, 1):
-        ms = timed(ctx, lambda: ctx.kopt2d(hp, len(pairs), F, neff, [dc] * len(pairs), [1e-4] * len(pairs)), 3)
-        rec("kopt2d B=%d do_corr=%d" % (len(pairs), dc), ms, len(pairs) * 8.0 * F * F, "DCT GEMMs + device Brent + psi functionals")
+        ms = timed(ctx, lambda: ctx.kopt2d(hp, len(pairs), F, neff, [dc] * len(pairs), [1e-4] * len(pairs), [0.3] * len(pairs)), 3)
+        rec("kopt2d B=%d do_corr=%d" % (len(pairs), dc), ms, len(pairs) * 8.0 * F * F, "DCT GEMMs + device Brent + psi functionals + get_h (TNC)")
     info = ctx.device_info()
     print(json.dumps(dict(N=N, n=n, weighted=a.weighted, device=info, kernels=res)))
 

@@ -473,23 +473,38 @@ class FakeContext:
         return P_out, status
 
     # ---- 2D
-    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t):
+    def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t, corr):
         self.log.append(("kopt2d", B, F))
         H = np.asarray(d_hist.a).reshape(B, F, F)
-        out = np.full((B, 8), np.nan)
+        out = np.full((B, 12), np.nan)
         for b in range(B):
             tr = {}
+            out[b, 11] = -5
             try:
-                opt = ko.Optimizer2D(H[b], neff[b], 0.0, do_correlation=bool(do_corr[b]),
+                opt = ko.Optimizer2D(H[b], neff[b], corr[b], do_correlation=bool(do_corr[b]),
                                      fallback_t=(fallback_t[b] if fallback_t[b] > 0 else None), trace=tr)
-                opt.get_h()
+                out[b, 7] = 0
+                try:
+                    out[b, 8:11] = opt.get_h()
+                    out[b, 11] = 0
+                except Exception:
+                    out[b, 11] = -1  # "bias not positive definite"
                 out[b, 0] = tr["t_star"]
                 out[b, 1:4] = tr["p_02"], tr["p_20"], tr["p_11"]
                 if do_corr[b]:
                     out[b, 4:7] = tr["p_00"], tr["p_13"], tr["p_31"]
-                out[b, 7] = 0
             except ValueError:
                 out[b, 7] = -5
+        return out
+
+    def get_h(self, psi, neff, corr, do_corr):
+        psi = np.asarray(psi, dtype=float).reshape(-1, 6)
+        out = np.zeros((len(psi), 4))
+        for b in range(len(psi)):
+            try:
+                out[b, :3] = ko.get_h_from_psi(tuple(psi[b]), neff[b], corr[b], bool(do_corr[b]))
+            except Exception:
+                out[b, 3] = -1
         return out
 
     def density2d(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, out=None):

@@ -70,18 +70,33 @@ def test_density_1d(zoo, name):
 
 
 def uses_tnc(d, mc, a, b):
-    """Pairs whose bandwidth passes through scipy TNC (kde_bandwidth.py:276-299): optimiser branch, no limits."""
+    """Pairs whose bandwidth passes through TNC (kde_bandwidth.py:276-299): optimiser branch, no limits."""
     px, py = mc.paramNames.names[a], mc.paramNames.names[b]
     return d.bandwidth_branch in ("A", "C") and not (px.has_limits or py.has_limits)
 
 
-# The reference is *chaotic* through TNC: a 1e-15 relative perturbation of the psi functionals (what any other
-# BLAS / numpy build produces) moves (hx, hy, c) by ~1e-3 and the final grid by 1-3e-4 of its maximum (measured with
-# the oracle; DESIGN.md "solver-path parity").  Those pairs are therefore checked in three deterministic pieces --
-# optimiser inputs, host get_h given identical inputs (tests/test_host_solvers.py), grid given identical bandwidths --
-# and end-to-end at the reference's own reproducibility level.
+# Gates of the 2D optimiser, at the level measured on MI355X (profiles/r02_parity_2d.json):
+TOL_TSTAR = 1e-10   # Brent stops at the same iterate: t* differs only by the rounding of the fixed-point functional
+TOL_PSI = 1e-10     # psi functionals at t* (fp64 bilinear forms, different summation order than numpy)
+# The reference is *chaotic* through TNC for some pairs: a 1e-15 relative perturbation of the psi functionals (what any
+# other BLAS / numpy build produces) moves (hx, hy, c) by up to ~1e-3 and the grid by 1-3e-4 of its maximum.  The device
+# runs the same TNC (csrc/solvers.hpp, pinned evaluation by evaluation against scipy on the CPU), so wherever the
+# reference is stable the strict 1e-6 gate applies end to end; the loose gate below is granted ONLY to pairs for which
+# the oracle itself is shown to move by more than 1e-6 under such a perturbation (get_h_is_chaotic), and each use is
+# recorded in the parity report.
 TOL_GRID_TNC = 2e-3
 TOL_BW_TNC = 0.25  # the AMISE is nearly flat in the correlation direction; the grid tolerance is the real gate
+PARITY_REPORT = {}
+
+
+def _write_parity_report():
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r02_parity_2d.json"), "w") as f:
+        json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
 
 
 @pytest.mark.parametrize("name", FIXTURES + ["periodic"])
@@ -90,6 +105,8 @@ def test_density_2d(zoo, name):
     g = gu.load(name)
     mc = make(fx)
     orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    report = PARITY_REPORT.setdefault(name, dict(pairs=0, tnc_pairs=0, loose=[], worst_tstar=0.0, worst_psi=0.0,
+                                                 worst_grid_strict=0.0, worst_grid_loose=0.0, worst_bw_strict=0.0))
     for kw in fx["kw2"]:
         dens = mc.get2DDensities(fx["pairs"], get_density=False, **kw)
         oracle_bw = []
@@ -101,25 +118,44 @@ def test_density_2d(zoo, name):
             assert d.P.shape == o["P"].shape, key
             auto = key + "/hxhyc" in g.files
             tnc = auto and uses_tnc(d, mc, a, b)
+            report["pairs"] += 1
+            report["tnc_pairs"] += bool(tnc)
             if auto:
                 assert d.bandwidth_branch == tr["branch"], key
-                if d.kopt is not None and "t_star" in tr:  # the device optimiser vs the oracle's, before any TNC
-                    assert abs(d.kopt[0] - tr["t_star"]) <= 1e-7 * tr["t_star"], (key, d.kopt[0], tr["t_star"])
-                    want = [tr["p_02"], tr["p_20"], tr["p_11"]]
-                    assert np.allclose(d.kopt[1:4], want, rtol=1e-6, atol=0), (key, d.kopt, want)
-                    if "p_13" in tr:
-                        want = [tr["p_00"], tr["p_13"], tr["p_31"]]
-                        assert np.allclose(d.kopt[4:7], want, rtol=1e-6, atol=0), (key, d.kopt, want)
-                assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < (TOL_BW_TNC if tnc else 1e-6), \
-                    (key, d.bandwidth, g[key + "/hxhyc"])
-            # TNC only matters where its result is accepted (AMISE improves); everywhere else, and whenever the two
-            # bandwidth triples agree, the strict tolerance applies end to end
-            bw_agrees = (not auto) or gu.relerr(d.bandwidth, (tr["hx"], tr["hy"], tr["c"])) < 1e-6
-            assert bw_agrees or tnc, (key, d.bandwidth, (tr["hx"], tr["hy"], tr["c"]))
+                if d.kopt is not None and "t_star" in tr:  # the device optimiser vs the oracle's
+                    e_t = abs(d.kopt[0] - tr["t_star"]) / tr["t_star"]
+                    want = np.array([tr["p_02"], tr["p_20"], tr["p_11"]] + ([tr["p_00"], tr["p_13"], tr["p_31"]] if "p_13" in tr else []))
+                    e_p = float(np.max(np.abs(d.kopt[1:1 + len(want)] - want) / np.abs(want)))
+                    report["worst_tstar"] = max(report["worst_tstar"], float(e_t))
+                    report["worst_psi"] = max(report["worst_psi"], e_p)
+                    assert e_t <= TOL_TSTAR, (key, d.kopt[0], tr["t_star"])
+                    assert e_p <= TOL_PSI, (key, d.kopt, want)
+            bw_err = gu.relerr(d.bandwidth, (tr["hx"], tr["hy"], tr["c"])) if auto else 0.0
+            bw_agrees = bw_err < 1e-6
+            if not bw_agrees:
+                # the loose gate must be earned: a TNC pair whose bandwidth the ORACLE cannot reproduce under a 1e-15
+                # perturbation of its own inputs
+                assert tnc, (key, d.bandwidth, (tr["hx"], tr["hy"], tr["c"]))
+                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+                chaotic, moved = ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])
+                report["loose"].append(dict(pair=key, bandwidth_error=float(bw_err), oracle_moves_by=float(moved)))
+                assert chaotic, (key, "device and oracle bandwidths differ by %.2e but the oracle is stable (moves %.2e)"
+                                 % (bw_err, moved))
+                assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < TOL_BW_TNC, (key, d.bandwidth, g[key + "/hxhyc"])
+            elif auto:
+                report["worst_bw_strict"] = max(report["worst_bw_strict"], float(bw_err))
+                if not tnc:
+                    assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < 1e-6, (key, d.bandwidth, g[key + "/hxhyc"])
             tol = TOL_GRID if bw_agrees else TOL_GRID_TNC
-            assert np.max(np.abs(d.P - o["P"])) < tol, (key, "vs oracle", np.max(np.abs(d.P - o["P"])))
-            gu.check_grid_2d(g, key, d.P, tol)
-            assert gu.relerr(d.contours, g[key + "/contours"]) < (10 * tol), key
+            e_grid = float(np.max(np.abs(d.P - o["P"])))
+            report["worst_grid_strict" if bw_agrees else "worst_grid_loose"] = max(
+                report["worst_grid_strict" if bw_agrees else "worst_grid_loose"], e_grid)
+            assert e_grid < tol, (key, "vs oracle", e_grid)
+            if bw_agrees and not tnc:
+                gu.check_grid_2d(g, key, d.P, tol)
+                assert gu.relerr(d.contours, g[key + "/contours"]) < (10 * tol), key
+            else:  # the committed reference grid of a TNC pair is itself one sample of the chaotic map
+                gu.check_grid_2d(g, key, d.P, TOL_GRID_TNC)
             assert np.allclose([d.x[0], d.x[-1], d.y[0], d.y[-1]], g[key + "/xy"], rtol=1e-12, atol=0), key
         if oracle_bw[0][0] is not None:
             # same bandwidths in -> same grids out, for every pair, at the strict tolerance
@@ -127,6 +163,45 @@ def test_density_2d(zoo, name):
             for (a, b), d in zip(fx["pairs"], dens):
                 key = "p2d/%s/%s/%s" % (fx["names"][a], fx["names"][b], gu.kwkey(kw))
                 gu.check_grid_2d(g, key, d.P, TOL_GRID)
+    _write_parity_report()
+
+
+def test_get_h_on_the_device_against_scipy(zoo):
+    """gd_get_h (closed forms + the two TNC minimisations, one wavefront per pair) on random psi tuples against the
+    oracle's scipy version.  The CPU build of the same source is bit-identical to scipy (tests/test_native_solvers.py);
+    on the device only libm differs (pow / sqrt rounding), so the results agree to rounding wherever the reference's map
+    is stable, and every disagreement above 1e-6 must be a tuple on which the oracle is chaotic itself."""
+    import warnings
+
+    from getdist_amd._lib import Context
+    from oracle.fixtures import random_psi_tuples
+
+    ctx = Context(0)
+    cases = list(random_psi_tuples(1500, seed=31))
+    out = ctx.get_h([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], [1] * len(cases))
+    closed = ctx.get_h([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], [0] * len(cases))
+    tight = loose = 0
+    worst_tight = 0.0
+    for (psi, N, corr), got, got0 in zip(cases, out, closed):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.array(ko.get_h_from_psi(psi, N, corr, True), dtype=float)
+            want0 = np.array(ko.get_h_from_psi(psi, N, corr, False), dtype=float)
+        assert got[3] == 0 and got0[3] == 0
+        assert np.allclose(got0[:3], want0, rtol=1e-13, atol=0)
+        err = float(np.max(np.abs(got[:3] - want)) / np.max(np.abs(want)))
+        if err < 1e-6:
+            tight += 1
+            worst_tight = max(worst_tight, err)
+        else:
+            loose += 1
+            chaotic, moved = ko.get_h_is_chaotic(psi, N, corr)
+            assert chaotic, (psi, N, corr, got[:3], want, moved)
+    PARITY_REPORT["get_h_random_tuples"] = dict(n=len(cases), within_1e_6=tight, chaotic_in_the_oracle=loose,
+                                                worst_relative_error_of_the_stable_ones=worst_tight)
+    _write_parity_report()
+    assert tight >= 0.9 * len(cases)
+    ctx.close()
 
 
 def test_single_pair_api_and_cache(zoo):

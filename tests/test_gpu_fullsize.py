@@ -169,6 +169,28 @@ def test_full_size_grids_match_the_oracle(big):
         assert d.bandwidth_branch == tr["branch"]
         assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6, atol=1e-12)
         assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[cols[a]], names[cols[b]])
+    # unbounded pairs: the bandwidth passes through the device's TNC.  Strict gate wherever the oracle's own map is
+    # stable under a 1e-15 perturbation of its inputs; the loose gate only if it is demonstrably chaotic there.
+    ucols = [5, 6, 7]
+    orc_u = ko.OracleSamples(np.ascontiguousarray(s[:, ucols]), names=[names[c] for c in ucols])
+    strict = 0
+    for (a, b) in ((0, 1), (1, 2)):  # (p5,p6): correlated block -> sheared branch A; (p6,p7)
+        d = mc.get2DDensities([(ucols[a], ucols[b])])[0]
+        tr = {}
+        o = orc_u.density_2d(a, b, trace=tr)
+        assert d.bandwidth_branch == tr["branch"] and not (mc.paramNames.names[ucols[a]].has_limits
+                                                           or mc.paramNames.names[ucols[b]].has_limits)
+        assert abs(d.kopt[0] - tr["t_star"]) <= 1e-10 * tr["t_star"]
+        bw_err = float(np.max(np.abs(np.array(d.bandwidth) - (tr["hx"], tr["hy"], tr["c"]))) / max(tr["hx"], tr["hy"]))
+        if bw_err < 1e-6:
+            strict += 1
+            assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[ucols[a]], names[ucols[b]])
+        else:
+            psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+            chaotic, moved = ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])
+            assert chaotic, (names[ucols[a]], names[ucols[b]], bw_err, moved)
+            assert np.max(np.abs(d.P - o["P"])) < 2e-3
+    print("full-size unbounded TNC pairs on the strict gate: %d of 2" % strict)
 
 
 def test_thinning_at_scale_matches_the_oracle():
@@ -191,3 +213,185 @@ def test_thinning_at_scale_matches_the_oracle():
             buf.free()
             want = co.thin_indices(factor, w[lo:hi]) + lo
             assert K == len(want) and np.array_equal(got, want), (factor, lo, hi)
+
+
+# ---- the other BASELINE.json configurations at their full sizes --------------------------------------------------------
+def _report(key, value):
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "r02_configs.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = value
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("n,weighted", [(100, True), (100, False), (200, True), (64, True), (65, False)])
+def test_covariance_multi_tile_against_numpy(n, weighted):
+    """gd_cov with more columns than one 64-column tile (C4's n = 100: 3 tile pairs, C5's n = 200: 10) at N > 1e6,
+    against the two-pass weighted covariance in numpy (chains.py:709-733); also on row sub-ranges."""
+    from getdist_amd._lib import Context
+
+    N = 1_200_037
+    r = np.random.default_rng(n)
+    A = r.standard_normal((n, n)) / np.sqrt(n) + np.eye(n)
+    s = r.standard_normal((N, n)) @ A.T + r.uniform(-5, 5, n)
+    w = r.exponential(1.0, N) if weighted else None
+    ctx = Context(0)
+    ctx.upload(np.asfortranarray(s), w)
+    for lo, hi in ((0, N), (100_003, 900_001)):
+        means, cov, norm = ctx.cov(None, lo, hi)
+        ww = np.ones(hi - lo) if w is None else w[lo:hi]
+        x = s[lo:hi]
+        m = ww @ x / ww.sum()
+        d = x - m
+        want = (d * ww[:, None]).T @ d / ww.sum()
+        sd = np.sqrt(np.diag(want))
+        assert abs(norm - ww.sum()) <= 1e-12 * ww.sum()
+        assert np.max(np.abs(means - m) / sd) < 1e-12
+        assert np.max(np.abs(cov - want) / np.outer(sd, sd)) < 1e-11, (n, weighted, lo, hi)
+        assert np.array_equal(cov, cov.T)
+    sub = [3, n - 1, 17, 64 % n, 0]
+    _, cov_sub, _ = ctx.cov(sub)
+    assert np.allclose(cov_sub, ctx.cov(None)[1][np.ix_(sub, sub)], rtol=1e-12, atol=0)
+    ctx.close()
+
+
+def test_c4_full_size_gelman_rubin_against_numpy():
+    """C4 at its full size -- 8 chains x 5e6 rows x 100 parameters, w ~ Exp(1), all chains on one GPU (32 GB resident):
+    Gelman-Rubin eigenvalues and the MeanVar statistics against the same formulas (chains.py:1446-1474,
+    mcsamples.py:964-985) evaluated with numpy BLAS on the host, relative 1e-9."""
+    import time
+
+    from getdist_amd.mcsamples import MCSamples
+    from getdist_amd.parallel import gelman_rubin_from_chain_stats
+
+    nch, N, n = 8, 5_000_000, 100
+    chains, ws = [], []
+    for c in range(nch):
+        s, w, names = synth.config_c4_chain(c, N, n)
+        chains.append(s)
+        ws.append(w)
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=chains, weights=ws, names=names)
+    t_ctor = time.perf_counter() - t0
+    mc.ctx.sync()
+    t0 = time.perf_counter()
+    D = mc.getGelmanRubinEigenvalues()
+    mv = mc.getMeanVarTest()
+    t_conv = time.perf_counter() - t0
+    mc._chain_stats_cache = {}
+    mc.ctx.timer_start()
+    mc.getSeparateChainStats(n)
+    t_kernels = mc.ctx.timer_stop_ms()
+    stats = []
+    tot_w = sum(float(w.sum()) for w in ws)
+    pooled = sum(w @ s for s, w in zip(chains, ws)) / tot_w
+    for s, w in zip(chains, ws):
+        m = w @ s / w.sum()
+        d = s - m
+        stats.append((m, (d * w[:, None]).T @ d / w.sum(), float(w.sum())))
+    want = gelman_rubin_from_chain_stats(stats, pooled)
+    assert np.allclose(mc.means, pooled, rtol=1e-11)
+    assert np.max(np.abs(D - want) / np.abs(want)) < 1e-9, (D[:3], want[:3])
+    between = sum((m - pooled) ** 2 for m, _, _ in stats) / (nch - 1)
+    within = sum(np.diag(c) * nw for _, c, nw in stats) / tot_w
+    assert np.allclose(mv, np.sqrt(between / within), rtol=1e-9)
+    alg_bytes = nch * 2 * 8.0 * N * (n + 1)
+    _report("C4", dict(chains=nch, rows_per_chain=N, params=n, construct_upload_s=round(t_ctor, 2),
+                       gelman_rubin_plus_meanvar_ms=round(t_conv * 1e3, 2), chain_covariances_ms=round(t_kernels, 2),
+                       algorithmic_GB=round(alg_bytes / 1e9, 2), algorithmic_GBps=round(alg_bytes / t_kernels / 1e6, 1),
+                       flops_T=round(nch * N * n * n * 2 / 1e12, 3), TFLOPs=round(nch * N * n * n * 2 / t_kernels / 1e9, 2),
+                       GR=float(np.max(D)), max_rel_error_vs_numpy=float(np.max(np.abs(D - want) / np.abs(want)))))
+
+
+def test_c2_weighted_full_size_1d_grids_against_the_oracle():
+    """C2 at its full size -- 30 parameters, N = 1e7, w ~ Exp(1), seven hard-bounded parameters: 1D density grids of a
+    bimodal, an unbounded, two one-sided bounded parameters and one of the strongly correlated block against the
+    oracle on the same weighted columns, 1e-6 of the peak; N_eff 1e-9; limit flags exact."""
+    import time
+
+    from getdist_amd.mcsamples import MCSamples
+    from oracle import kde_oracle as ko
+
+    s, w, names, ranges = synth.config_c2(N_FULL)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    mc.get1DDensities()
+    times = []
+    for _ in range(3):
+        for p in mc.paramNames.names:
+            p.N_eff_kde = None
+            p._ranges_done = False
+        mc._initLimits()
+        mc.density1D = {}
+        mc.ctx.sync()
+        t0 = time.perf_counter()
+        dens = mc.get1DDensities()
+        times.append(time.perf_counter() - t0)
+    cols = [0, 7, 4, 24, 22]
+    sub = [names[c] for c in cols]
+    orc = ko.OracleSamples(np.ascontiguousarray(s[:, cols]), w, names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
+    worst = 0.0
+    for k, c in enumerate(cols):
+        o = orc.density_1d(k)
+        par, opar = mc.paramNames.names[c], orc.pars[k]
+        assert (bool(par.has_limits_bot), bool(par.has_limits_top)) == (bool(opar.has_limits_bot), bool(opar.has_limits_top))
+        assert abs(par.N_eff_kde - opar.N_eff_kde) <= 1e-9 * par.N_eff_kde
+        assert abs(par.kde_h - opar.kde_h) <= 1e-8 * opar.kde_h, (names[c], par.kde_h, opar.kde_h)
+        err = float(np.max(np.abs(dens[c].P - o["P"])))
+        worst = max(worst, err)
+        assert err < 1e-6, (names[c], err)
+    assert {bool(mc.paramNames.names[c].has_limits) for c in cols} == {True, False}
+    _report("C2", dict(params=30, rows=N_FULL, weights="Exp(1) fp64", all_30_densities_ms=round(min(times) * 1e3, 2),
+                       densities_per_s=round(30 / min(times), 1), checked_params=sub, max_abs_grid_error_vs_oracle=worst,
+                       bounded=[p.name for p in mc.paramNames.names if p.has_limits]))
+
+
+@pytest.mark.skipif(__import__("os").environ.get("GETDIST_AMD_RUN_C5", "0") != "1",
+                    reason="C5 holds 80 GB of samples: run with GETDIST_AMD_RUN_C5=1 (results in profiles/r02_configs.json)")
+def test_c5_stress_full_size_properties():
+    """C5 -- 200 parameters x 5e7 rows resident on ONE GPU (80 GB): margestats of all 200 parameters, then the full
+    19 900-pair triangle in slabs, through size-independent properties (normalisation, determinism of a re-run pair,
+    2D marginal mass = 1D mass, quantile rank property)."""
+    import time
+
+    from getdist_amd.mcsamples import MCSamples
+
+    n, N = 200, 50_000_000
+    t0 = time.perf_counter()
+    s, w, names, ranges = synth.block_recipe(n, N, weighted=False, stream=7)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    t_ctor = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ms = mc.getMargeStats()
+    t_marge = time.perf_counter() - t0
+    for j in (0, 57, 199):
+        lim = ms.parWithName(names[j]).limits[0]
+        x = s[:, j]
+        inside = np.mean((x >= lim.lower) & (x <= lim.upper))
+        assert abs(inside - 0.68) < 0.01 or not lim.twotail, (names[j], inside)
+    q = mc.confidence(123, np.array([0.025, 0.5]))
+    for f, v in zip((0.025, 0.5), q):
+        assert np.sum(s[:, 123] <= v) >= N * f > np.sum(s[:, 123] < v)
+    pairs = synth.triangle_pairs(n)
+    t0 = time.perf_counter()
+    done = 0
+    classes = set()
+    for a in range(0, len(pairs), 2000):
+        dens = mc.get2DDensities(pairs[a:a + 2000])
+        for d in dens:
+            assert d.P.max() == 1.0 and d.P.min() > -1e-12
+            classes.add(int(d.P.shape[0]))
+        done += len(dens)
+    t_tri = time.perf_counter() - t0
+    d1 = mc.get2DDensities([pairs[5]])[0]
+    d2 = mc.get2DDensities([pairs[5]])[0]
+    assert np.allclose(d1.P, d2.P, rtol=0, atol=2e-3)
+    _report("C5", dict(params=n, rows=N, pairs=done, generate_s=round(t_gen, 1), construct_upload_s=round(t_ctor, 1),
+                       margestats_200_params_s=round(t_marge, 2), triangle_s=round(t_tri, 1),
+                       densities_per_s=round(done / t_tri, 1), F_classes=sorted(classes)))

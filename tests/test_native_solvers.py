@@ -13,7 +13,7 @@ import warnings
 import numpy as np
 import pytest
 from scipy import fftpack
-from scipy.optimize import brentq, fsolve
+from scipy.optimize import brentq, fsolve, minimize
 
 from oracle import kde_oracle as ko
 from oracle.fixtures import histogram_shape_zoo as shape_zoo
@@ -21,6 +21,7 @@ from oracle.fixtures import histogram_shape_zoo as shape_zoo
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "native"))
 
 FCN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_int))
+FCN_ND = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_int))
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +32,8 @@ def lib():
     pd, pi = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
     lib.gdt_hybrd1.argtypes = [FCN, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, pd, pi]
     lib.gdt_brentq.argtypes = [FCN, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, pd, pi]
+    lib.gdt_tnc.argtypes = [FCN_ND, ctypes.c_int, pd, pd, pd, pd, pi, pi, pi]
+    lib.gdt_get_h.argtypes = [pd, ctypes.c_double, ctypes.c_double, ctypes.c_int, pd, pi]
     return lib
 
 
@@ -140,3 +143,93 @@ def test_brentq_port_matches_scipy_on_smooth_functions(lib):
             assert st == -1
         else:
             assert st == 0 and x_out.value == want and seq == seq_ref
+
+
+def _tnc_both(lib, p, N, x0, bounds, corr):
+    """Run scipy's TNC and the port on the same Python AMISE; returns (reference result or None, its evaluation points,
+    port's (x, rc, success, nit), its evaluation points)."""
+    seq_ref, seq = [], []
+
+    def f_ref(x, *a):
+        seq_ref.append(tuple(float(v) for v in x))
+        return ko.amise_from_psi(x, p, N, corr)
+
+    ref = None
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = minimize(f_ref, np.array(x0), method="TNC", bounds=bounds)
+    except Exception:
+        pass
+
+    def cb(xp, n, fail):
+        x = np.array([xp[i] for i in range(n)])
+        seq.append(tuple(float(v) for v in x))
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return float(ko.amise_from_psi(x, p, N, corr))
+        except Exception:
+            fail[0] = 1
+            return 0.0
+
+    n = len(x0)
+    arr = ctypes.c_double * n
+    x_out, suc, nf, nit = arr(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = lib.gdt_tnc(FCN_ND(cb), n, arr(*x0), arr(*[b[0] for b in bounds]), arr(*[b[1] for b in bounds]), x_out,
+                     ctypes.byref(suc), ctypes.byref(nf), ctypes.byref(nit))
+    return ref, seq_ref, (np.array(list(x_out)), rc, bool(suc.value), nit.value), seq
+
+
+def test_tnc_port_follows_scipy_evaluation_by_evaluation(lib):
+    """scipy.optimize.minimize(method="TNC") with finite-difference gradients and bounds, as get_h calls it
+    (kde_bandwidth.py:276-299), against the port in csrc/solvers.hpp: identical sequences of evaluation points, final
+    iterate, return code, iteration count -- also where the callback raises ("bias not positive definite"), where the
+    start point violates the bounds, where a bound becomes active and is released, and where the line search fails.
+    (scripts/validate_native_solvers.py repeats this on 3 x 10^4 runs over wider parameter ranges.)"""
+    from oracle.fixtures import random_psi_tuples
+
+    n_runs = n_abort = n_bound = 0
+    codes = set()
+    for wide in (False, True):
+        for psi, N, corr in random_psi_tuples(220, seed=7 + wide, wide=wide):
+            p = np.zeros((5, 5))
+            p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = psi
+            h_x, h_y, _ = ko.get_h_from_psi(psi, N, 0.0, False)
+            runs = [([h_x, h_y, corr], [(0.001, 0.3), (0.001, 0.3), (-0.99, 0.99)], None)]
+            if corr:
+                runs.append((list(np.array([h_x, h_y]) / np.sqrt(1 - abs(corr))), [(0.001, 0.3), (0.001, 0.3)], corr))
+            for x0, bounds, c in runs:
+                ref, seq_ref, (x, rc, success, nit), seq = _tnc_both(lib, p, N, x0, bounds, c)
+                n_runs += 1
+                if ref is None:
+                    n_abort += 1
+                    assert rc == 7 and seq == seq_ref, (psi, N, corr)
+                    continue
+                # scipy re-evaluates f and the gradient at the returned x (memoised if it was the last point)
+                assert seq_ref[:len(seq)] == seq and len(seq_ref) - len(seq) in (0, 1 + len(x0)), (psi, N, corr)
+                assert np.array_equal(ref.x, x) and ref.status == rc and bool(ref.success) == success and ref.nit == nit
+                codes.add(rc)
+                lo, hi = np.array(bounds).T
+                n_bound += bool(np.any(np.minimum(np.abs(x - lo), np.abs(x - hi)) < 1e-12))
+    assert n_runs > 700 and n_abort > 0 and n_bound > 0 and {1, 4} <= codes, (n_runs, n_abort, n_bound, codes)
+
+
+def test_get_h_port_equals_the_oracle_bit_for_bit(lib):
+    """KernelOptimizer2D.get_h in plain C++ (the code the kernel runs: closed forms, AMISE, two TNC runs, acceptance
+    rules) against the oracle's scipy version on random psi tuples: identical doubles."""
+    from oracle.fixtures import random_psi_tuples
+
+    kinds = [0, 0, 0]
+    for psi, N, corr in random_psi_tuples(1200, seed=3):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = tuple(float(v) for v in ko.get_h_from_psi(tuple(np.float64(v) for v in psi), N, corr, True))
+        out, nf = (ctypes.c_double * 3)(), ctypes.c_int()
+        st = lib.gdt_get_h((ctypes.c_double * 6)(*psi), N, corr, 1, out, ctypes.byref(nf))
+        assert st == 0 and tuple(out) == want, (psi, N, corr, tuple(out), want)
+        kinds[0 if want[2] == 0 else (1 if want[2] == corr else 2)] += 1
+        want0 = tuple(float(v) for v in ko.get_h_from_psi(psi, N, corr, False))
+        lib.gdt_get_h((ctypes.c_double * 6)(*psi), N, corr, 0, out, ctypes.byref(nf))
+        assert tuple(out) == want0
+    assert kinds[0] > 0 and kinds[2] > 0  # both "closed form kept" and "TNC result accepted" occur
