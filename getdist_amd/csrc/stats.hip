@@ -263,12 +263,135 @@ __global__ void k_cov_fin(const double* __restrict__ part, int nchunks, const in
     if (e >= CT * CT) return;
     const int i = tl.x * CT + e / CT, j = tl.y * CT + e % CT;
     if (i >= m || j >= m) return;
+    if (tl.x == tl.y && j < i) return;  // diagonal tiles: the upper triangle decides, so the result is exactly symmetric
     const double* p = part + (int64_t)blockIdx.y * nchunks * (CT * CT) + e;
     double s = 0;
     for (int c = 0; c < nchunks; ++c) s += p[(int64_t)c * (CT * CT)];
     const double norm = res[2];
     cov[(int64_t)i * m + j] = s / norm;
     cov[(int64_t)j * m + i] = s / norm;
+}
+
+// ---- weighted covariance, slab form: every column of a row slab is read from HBM exactly once -------------------------
+// A block walks its chunk of rows in slabs of KS rows.  The slab of ALL m columns (d = x - mean, and w d when weighted)
+// is staged in LDS once and every 16 x 16 tile pair (ti <= tj) of the covariance is accumulated from it on the fp64
+// matrix cores; the tile pairs are dealt round-robin to the waves of the block (accumulators stay in registers for the
+// whole chunk).  The next slab's global loads are issued before the MFMAs of the current one.
+//   LDS layout s[col][KS + 2] (row index fastest): staging writes are contiguous per column, and the MFMA operand reads
+//   (lane: col = 16 t + (lane & 15), row = k0 + (lane >> 4)) hit 64 distinct banks per half-wave because the column
+//   stride KS + 2 = 34 doubles is 4 dwords modulo 64 (MI355X_MICROARCH.md, ds_read_b64 lane groups).
+// Templates: MCAP = column capacity (multiple of 16), NW waves per block, MAXP tile pairs per wave, KS rows per slab.
+template <bool HAS_W, int MCAP, int NW, int MAXP, int KS>
+__global__ void __launch_bounds__(NW * 64) k_cov_slab(const double* __restrict__ cols, int64_t ld,
+                                                      const int32_t* __restrict__ colidx, int m,
+                                                      const double* __restrict__ res, const double* __restrict__ w,
+                                                      int64_t lo, int64_t hi, int64_t rows_per_chunk,
+                                                      double* __restrict__ part) {
+    constexpr int NT = NW * 64, KSP = KS + 2, CPT = NT / KS;  // CPT columns staged per pass of the block
+    constexpr int NQ = (MCAP + CPT - 1) / CPT;
+    extern __shared__ double lds[];
+    double* sB = lds;                               // d
+    double* sA = HAS_W ? lds + MCAP * KSP : lds;    // w d (same array for unit weights)
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int nt = (m + 15) / 16, T = nt * (nt + 1) / 2;
+    int ti[MAXP], tj[MAXP];
+    bool live[MAXP];
+    f64x4 acc[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+        int pq = wv + q * NW, a = 0, len = nt;
+        live[q] = pq < T;  // wave-uniform
+        if (!live[q]) pq = 0;
+        while (pq >= len) {
+            pq -= len;
+            ++a;
+            --len;
+        }
+        ti[q] = a * 16;
+        tj[q] = (a + pq) * 16;
+        acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int e = tid; e < (HAS_W ? 2 : 1) * MCAP * KSP; e += NT) lds[e] = 0.0;  // padding columns stay zero
+    // this thread stages row r of columns c0 + CPT q
+    const int r = tid % KS, c0 = tid / KS;
+    const double* src[NQ];
+    double mean[NQ], pre[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = c0 + CPT * q;
+        const bool has = c < m;
+        src[q] = has ? cols + (int64_t)colidx[c] * ld : nullptr;
+        mean[q] = has ? res[(int64_t)c * 4 + 3] : 0.0;
+    }
+    const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
+    int64_t c_hi = c_lo + rows_per_chunk;
+    if (c_hi > hi) c_hi = hi;
+    double wpre = 1.0;
+    auto fetch = [&](int64_t r0) {
+        const int64_t row = r0 + r;
+        const bool in = row < c_hi;
+        if (HAS_W) wpre = in ? w[row] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pre[q] = (in && src[q]) ? src[q][row] - mean[q] : 0.0;
+    };
+    if (c_lo < c_hi) fetch(c_lo);
+    for (int64_t r0 = c_lo; r0 < c_hi; r0 += KS) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = c0 + CPT * q;
+            if (c < MCAP && src[q]) {
+                sB[c * KSP + r] = pre[q];
+                if (HAS_W) sA[c * KSP + r] = pre[q] * wpre;
+            }
+        }
+        __syncthreads();
+        if (r0 + KS < c_hi) fetch(r0 + KS);
+#pragma unroll 2
+        for (int kk = 0; kk < KS / 4; ++kk) {
+            const int k = kk * 4 + lk;
+#pragma unroll
+            for (int q = 0; q < MAXP; ++q) {
+                if (live[q]) {
+                    const double a = sA[(ti[q] + l15) * KSP + k];
+                    const double b = sB[(tj[q] + l15) * KSP + k];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial tiles of this block: part[block][pair][16 x 16], D[row = lk + 4 reg][col = l15]
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+        const int pq = wv + q * NW;
+        if (pq < T) {
+            double* p = part + ((int64_t)blockIdx.x * T + pq) * 256;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) p[(lk + 4 * rg) * 16 + l15] = acc[q][rg];
+        }
+    }
+}
+
+// cov[i][j] = sum over blocks / norm, mirrored; grid (pairs), 256 threads
+__global__ void __launch_bounds__(256) k_cov_slab_fin(const double* __restrict__ part, int nblocks, int m,
+                                                      const double* __restrict__ res, double* __restrict__ cov) {
+    const int nt = (m + 15) / 16, T = nt * (nt + 1) / 2;
+    int pq = blockIdx.x, a = 0, len = nt;
+    while (pq >= len) {
+        pq -= len;
+        ++a;
+        --len;
+    }
+    const int i = a * 16 + threadIdx.x / 16, j = (a + pq) * 16 + threadIdx.x % 16;
+    if (i >= m || j >= m) return;
+    const double* p = part + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += p[(int64_t)b * T * 256];
+    const double v = s / res[2];
+    if (a == a + pq && j < i) return;  // diagonal tiles: the upper triangle decides, so the result is exactly symmetric
+    cov[(int64_t)i * m + j] = v;
+    cov[(int64_t)j * m + i] = v;
 }
 
 // ---- sort-free weighted quantiles: MSB radix select, 8 bits per pass ---------------------------------------
@@ -777,12 +900,65 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     GD_REQUIRE(ctx && cols && means_out && cov_out && norm_out && m > 0, "bad argument");
     GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
     for (int i = 0; i < m; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
+    const int64_t rows = hi - lo;
+    auto take_init = [](int64_t& off, int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    double* d_res = nullptr;
+    double* d_cov = nullptr;
+    const bool slab = (m <= 208) && !getenv("GDHIP_COV_TILE");
+    if (slab) {
+        // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
+        constexpr int KS = 32;
+        const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2;
+        int nblk = 2 * ctx->cu_count;
+        if (nblk > (rows + 4 * KS - 1) / (4 * KS)) nblk = (int)((rows + 4 * KS - 1) / (4 * KS));
+        if (nblk < 1) nblk = 1;
+        int64_t rows_per_chunk = (rows + nblk - 1) / nblk;
+        rows_per_chunk = (rows_per_chunk + KS - 1) / KS * KS;
+        nblk = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
+        int64_t off = 0;
+        const int64_t o_part1 = take_init(off, (int64_t)m * NBLK_STREAM * 4 * 8), o_res = take_init(off, (int64_t)m * 4 * 8),
+                      o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * T * 256 * 8),
+                      o_cov = take_init(off, (int64_t)m * m * 8);
+        char* base = (char*)gd_scratch(ctx, off);
+        if (!base) return GD_ERR_NOMEM;
+        double* d_part1 = (double*)(base + o_part1);
+        d_res = (double*)(base + o_res);
+        int32_t* d_idx = (int32_t*)(base + o_idx);
+        double* d_cpart = (double*)(base + o_cpart);
+        d_cov = (double*)(base + o_cov);
+        GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
+        if (rc) return rc;
+        const bool hw = ctx->w != nullptr;
+#define GD_COV_LAUNCH(HW, MCAP, NW, MAXP)                                                                              \
+    do {                                                                                                               \
+        const size_t lds = (size_t)((HW) ? 2 : 1) * (MCAP) * (KS + 2) * 8;                                             \
+        GD_HIP(hipFuncSetAttribute((const void*)k_cov_slab<HW, MCAP, NW, MAXP, KS>,                                    \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+        k_cov_slab<HW, MCAP, NW, MAXP, KS><<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res,  \
+                                                                               ctx->w, lo, hi, rows_per_chunk, d_cpart); \
+    } while (0)
+        if (m <= 64) {
+            if (hw) GD_COV_LAUNCH(true, 64, 4, 3); else GD_COV_LAUNCH(false, 64, 4, 3);
+        } else if (m <= 112) {
+            if (hw) GD_COV_LAUNCH(true, 112, 4, 7); else GD_COV_LAUNCH(false, 112, 4, 7);
+        } else {
+            if (hw) GD_COV_LAUNCH(true, 208, 8, 12); else GD_COV_LAUNCH(false, 208, 8, 12);
+        }
+#undef GD_COV_LAUNCH
+        GD_KERNEL_CHECK();
+        k_cov_slab_fin<<<T, 256, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
+        GD_KERNEL_CHECK();
+    } else {
     const int nt = (m + CT - 1) / CT;
     std::vector<int2> tiles;
     for (int a = 0; a < nt; ++a)
         for (int b = a; b < nt; ++b) tiles.push_back(make_int2(a, b));
     const int ntp = (int)tiles.size();
-    const int64_t rows = hi - lo;
     int nchunks = (2 * ctx->cu_count + ntp - 1) / ntp;
     if (nchunks > (rows + CRB - 1) / CRB) nchunks = (int)((rows + CRB - 1) / CRB);
     if (nchunks < 1) nchunks = 1;
@@ -791,22 +967,18 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     nchunks = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
     // scratch layout
     int64_t off = 0;
-    auto take = [&](int64_t bytes) {
-        int64_t o = off;
-        off += (bytes + 255) / 256 * 256;
-        return o;
-    };
+    auto take = [&](int64_t bytes) { return take_init(off, bytes); };
     const int64_t o_part1 = take((int64_t)m * NBLK_STREAM * 4 * 8), o_res = take((int64_t)m * 4 * 8),
                   o_idx = take((int64_t)m * 4), o_tiles = take((int64_t)ntp * 8),
                   o_cpart = take((int64_t)ntp * nchunks * CT * CT * 8), o_cov = take((int64_t)m * m * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     double* d_part1 = (double*)(base + o_part1);
-    double* d_res = (double*)(base + o_res);
+    d_res = (double*)(base + o_res);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     int2* d_tiles = (int2*)(base + o_tiles);
     double* d_cpart = (double*)(base + o_cpart);
-    double* d_cov = (double*)(base + o_cov);
+    d_cov = (double*)(base + o_cov);
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntp * 8, hipMemcpyHostToDevice, ctx->stream));
     int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
@@ -821,6 +993,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     GD_KERNEL_CHECK();
     k_cov_fin<<<dim3((CT * CT + 255) / 256, ntp), 256, 0, ctx->stream>>>(d_cpart, nchunks, d_tiles, m, d_res, d_cov);
     GD_KERNEL_CHECK();
+    }
     std::vector<double> hres((size_t)m * 4);
     GD_HIP(hipMemcpyAsync(hres.data(), d_res, hres.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipMemcpyAsync(cov_out, d_cov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -59,13 +59,15 @@ def test_min_weight_ratio_filter_and_zero_weights():
     assert np.allclose(mc.means, w[keep].dot(s[keep]) / w[keep].sum(), rtol=1e-12)
 
 
-def test_degenerate_range_raises():
-    from getdist_amd.mcsamples import MCSamplesError
-
+def test_fixed_parameter_is_removed_like_the_reference():
+    """chains.py:1029-1045,1548-1559: a column that never moves is deleted at construction and recorded as a fixed
+    (zero-width) range; asking for its density gives None like any unknown name."""
     s = np.column_stack([np.full(1000, 3.0), np.random.default_rng(0).standard_normal(1000)])
     mc = mcs(samples=s, names=["c", "x"])
-    with pytest.raises(MCSamplesError):
-        mc.get1DDensity("c")
+    assert mc.paramNames.list() == ["x"] and mc.n == 1
+    assert mc.ranges.fixedValue("c") == 3.0
+    assert mc.get1DDensity("c") is None
+    assert mc.get1DDensity("x").P.shape == (1024,)
 
 
 @pytest.mark.parametrize("kw", [dict(fine_bins=500), dict(fine_bins=257, smooth_scale_1D=0.5), dict(num_bins=50, smooth_scale_1D=1.5)])

@@ -229,7 +229,7 @@ def _report(key, value):
         json.dump(data, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("n,weighted", [(100, True), (100, False), (200, True), (64, True), (65, False)])
+@pytest.mark.parametrize("n,weighted", [(100, True), (100, False), (200, True), (64, True), (65, False), (230, True), (3, True)])
 def test_covariance_multi_tile_against_numpy(n, weighted):
     """gd_cov with more columns than one 64-column tile (C4's n = 100: 3 tile pairs, C5's n = 200: 10) at N > 1e6,
     against the two-pass weighted covariance in numpy (chains.py:709-733); also on row sub-ranges."""
@@ -254,7 +254,7 @@ def test_covariance_multi_tile_against_numpy(n, weighted):
         assert np.max(np.abs(means - m) / sd) < 1e-12
         assert np.max(np.abs(cov - want) / np.outer(sd, sd)) < 1e-11, (n, weighted, lo, hi)
         assert np.array_equal(cov, cov.T)
-    sub = [3, n - 1, 17, 64 % n, 0]
+    sub = [3 % n, n - 1, 17 % n, 64 % n, 0] if n > 4 else [2, 0]
     _, cov_sub, _ = ctx.cov(sub)
     assert np.allclose(cov_sub, ctx.cov(None)[1][np.ix_(sub, sub)], rtol=1e-12, atol=0)
     ctx.close()
@@ -296,7 +296,11 @@ def test_c4_full_size_gelman_rubin_against_numpy():
         stats.append((m, (d * w[:, None]).T @ d / w.sum(), float(w.sum())))
     want = gelman_rubin_from_chain_stats(stats, pooled)
     assert np.allclose(mc.means, pooled, rtol=1e-11)
-    assert np.max(np.abs(D - want) / np.abs(want)) < 1e-9, (D[:3], want[:3])
+    # 8 chains give a between-chain matrix of rank 7: the other 93 eigenvalues are rounding noise around zero
+    big = np.abs(want) > 1e-9 * np.max(want)
+    assert np.sum(big) == nch - 1
+    assert np.max(np.abs(D - want)[big] / np.abs(want)[big]) < 1e-9, (D[big], want[big])
+    assert np.max(np.abs(D - want)[~big]) < 1e-12 * np.max(want)
     between = sum((m - pooled) ** 2 for m, _, _ in stats) / (nch - 1)
     within = sum(np.diag(c) * nw for _, c, nw in stats) / tot_w
     assert np.allclose(mv, np.sqrt(between / within), rtol=1e-9)
@@ -305,7 +309,7 @@ def test_c4_full_size_gelman_rubin_against_numpy():
                        gelman_rubin_plus_meanvar_ms=round(t_conv * 1e3, 2), chain_covariances_ms=round(t_kernels, 2),
                        algorithmic_GB=round(alg_bytes / 1e9, 2), algorithmic_GBps=round(alg_bytes / t_kernels / 1e6, 1),
                        flops_T=round(nch * N * n * n * 2 / 1e12, 3), TFLOPs=round(nch * N * n * n * 2 / t_kernels / 1e9, 2),
-                       GR=float(np.max(D)), max_rel_error_vs_numpy=float(np.max(np.abs(D - want) / np.abs(want)))))
+                       GR=float(np.max(D)), max_rel_error_vs_numpy=float(np.max(np.abs(D - want)[big] / np.abs(want)[big]))))
 
 
 def test_c2_weighted_full_size_1d_grids_against_the_oracle():
