@@ -2,13 +2,22 @@
 bench.py -- BASELINE.json's metric on BASELINE.json's config: 2D KDE densities/sec on the 50-parameter,
 10M-sample triangle (1225 pairs, base fine_bins_2D=256, default settings), config "C3" of SURVEY.md 8d.
 
-One "step" = the whole hot path over the resident synthetic sample set: per-parameter preparation (ranges,
-quantiles, limits, N_eff), weighted binning, bandwidth selection (device ISJ solver + host TNC), rocFFT
-convolution, boundary / multiplicative-bias correction, normalisation, and the D2H copy of every grid.
-All per-parameter / per-pair caches are cleared before every step; the sample columns are already in HBM
-(upload time reported separately in DESIGN.md, never in `value`).
+One "step" = the whole hot path over the resident synthetic sample set: base statistics (means, variances, covariance),
+per-parameter preparation (ranges, quantiles, limits, N_eff), weighted binning, bandwidth selection (2D Botev fixed
+point, psi functionals and the TNC refinement, all on the device), rocFFT convolution, boundary / multiplicative-bias
+correction, normalisation, and the D2H copy of every grid.  All per-parameter / per-pair caches are cleared before every
+step; the sample columns are already in HBM (upload time reported separately, never in `value`).
 
     python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run, one rank per GPU)
+
+After the timed region rank 0 adds, on one GPU only (SURVEY.md 8d protocol):
+  * roofline: the batched 2D binning kernel timed with HIP events on the library's stream, priced by its HBM counter
+    traffic (profiles/r02_pmc_hist2d.json, separate rocprofv3 --pmc passes) and by the unit-weight streaming model;
+  * cpu_baseline: the oracle (numpy/scipy restatement of the reference) on the GPU box's host cores -- all 50
+    per-parameter preparations plus up to 3 pairs of every (bandwidth branch, #bounded, grid size) class at N = 1e7,
+    timed in a pool of min(cores, 32) single-threaded workers and extrapolated over the class census, a short
+    single-process sample of the same tasks, and the UN-extrapolated full triangle at N = 1e6 on CPU and GPU;
+  * parity: the GPU grids of those stratified pairs against the oracle's at full size.
 
 Multi-GPU: every rank holds a replica of the samples; parameter preparation is split over ranks and its scalars
 all-gathered (RCCL), pairs are partitioned by cost class with no data-path collective; total work is fixed
@@ -27,8 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FETCH_KIB, PMC_WRITE_KIB = 10.51e6, 0.6272e6  # per 1225-pair launch; refreshed from profiles/r01_pmc_* below
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hist2d.json")
 
 
 def parse():
@@ -45,7 +54,8 @@ def parse():
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--emulate-world", type=int, default=0, help="measurement aid: time rank 0's share of a W-rank "
                     "job on one GPU (other ranks' parameter state is replayed from a cached full preparation)")
-    ap.add_argument("--cpu-baseline-n", type=int, default=None, help="rows for the CPU sample (default: nsamples)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline pool size (default min(cores, 32))")
+    ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
     return ap.parse_args()
 
 
@@ -78,6 +88,7 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     from getdist_amd import parallel
 
     t_step0 = time.perf_counter()
+    mc.updateBaseStatistics()  # means, variances, covariance, weight statistics; clears every per-parameter cache
     reset_caches(mc)
     if emulate:
         world = emulate
@@ -96,16 +107,20 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     if mc._timing:
         mc.timings["step.partition"] = mc.timings.get("step.partition", 0.0) + time.perf_counter() - t_part0
     out = mc.get2DDensities(my_pairs)
+    _REPLAY["last_pairs"] = my_pairs  # the order of `out`
     if mc._timing:
         mc.timings["step.total"] = mc.timings.get("step.total", 0.0) + time.perf_counter() - t_step0
     return out
 
 
+# ---- roofline of the batched 2D binning kernel ------------------------------------------------------------------------
 def binning_kernel_roofline(mc, pairs_all, reps=5):
     """
-    Time the dominant O(N) kernel of the step -- the batched weighted 2D binning of all F=256 pairs -- with HIP
-    events on the library's stream, and price it with SURVEY.md 8d's algorithmic bytes B2 = 24 N + 8 F^2 per
-    density (x, y, w read once as fp64 + the F x F fp64 grid written).
+    The O(N) kernel the path is built around -- the batched 2D binning of every base-grid pair (k_hist2d_u16) -- timed
+    with HIP events on the library's stream.  `achieved` is its HBM traffic per launch (rocprofv3 PMC counters of this
+    very launch shape, profiles/r02_pmc_hist2d.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) over the
+    measured time; when no counter file matches the configuration the unit-weight streaming model 16 N + 8 F^2 per
+    density is used instead and says so.  The kernel is bound by LDS atomics (profiles/), not by HBM.
     """
     names = mc.paramNames.names
     F = mc.fine_bins_2D
@@ -127,52 +142,210 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
         ms.append(mc.ctx.timer_stop_ms())
     out.free()
     t = float(np.median(ms)) * 1e-3
-    alg_bytes = len(sel) * (24.0 * mc.numrows + 8.0 * F * F)
-    achieved = alg_bytes / t / 1e9
-    # HBM traffic per launch from the PMC passes in profiles/r01_pmc_hist2d_{FETCH,WRITE}_SIZE.csv (separate rocprofv3
-    # --pmc runs of scripts/pmc_hist2d.py on this exact config: 1225 pairs, N=1e7, F=256, unit weights):
-    # FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB, scaled by the
-    # number of pairs in this launch.  Not re-measured live (PMC needs the profiler); null for other configs.
+    weighted = mc.weights is not None
+    model_bytes = len(sel) * ((24.0 if weighted else 16.0) * mc.numrows + 8.0 * F * F)
     traffic = None
-    if mc.numrows == 10_000_000 and mc.n == 50 and mc.weights is None:
-        traffic = (2 * PMC_FETCH_KIB + PMC_WRITE_KIB) * 1024 * len(sel) / 1225.0
-    return dict(bound="hbm", kernel="k_hist2d_u16 (pre-binned u16 indices, 16-bit packed LDS counters)", launches_pairs=len(sel),
-                ms_per_launch=t * 1e3, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                traffic=traffic,
-                note="achieved = algorithmic bytes (24N+8F^2 per density, SURVEY 8d) / launch time; the kernel reads "
-                     "pre-binned u16 indices (4 B/sample/stripe) so frac > 1 is expected; the fused-fp64 variant of the "
-                     "same kernel streams x,y and reaches 6.4 TB/s algorithmic = 0.81 of peak (profiles/r01_kernel_bench.txt)")
+    source = "none"
+    if os.path.exists(PMC_FILE):
+        pmc = json.load(open(PMC_FILE))
+        if (pmc.get("N") == mc.numrows and pmc.get("n") == mc.n and pmc.get("F") == F and bool(pmc.get("weighted")) == weighted
+                and pmc.get("pairs")):
+            traffic = float(pmc["hbm_bytes_per_launch"]) * len(sel) / pmc["pairs"]
+            source = "profiles/r02_pmc_hist2d.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled by pairs)"
+    frac_model = model_bytes / t / 1e9 / HBM_PEAK_GBS
+    if traffic is not None:
+        achieved = traffic / t / 1e9
+    else:
+        achieved = model_bytes / t / 1e9
+    return dict(kernel="k_hist2d_u16 (batched 2D binning of pre-binned index columns, 16-bit packed LDS counters)",
+                bound="lds-atomic", priced_against="hbm", launches_pairs=len(sel), ms_per_launch=t * 1e3,
+                achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                traffic_source=source, frac_counter=(None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS),
+                frac_model_unit_weight=frac_model, model_bytes=model_bytes,
+                note="achieved = HBM counter bytes of this launch shape / HIP-event time (falls back to the streaming "
+                     "model when no counter file matches). frac_model_unit_weight prices the same launch with the "
+                     "streaming model of SURVEY 8d for unit weights (x, y read once as fp64 + the F x F grid = 16N + 8F^2 "
+                     "per density); it exceeds 1 because the kernel reads 2-byte pre-binned indices shared by 49 pairs "
+                     "each instead of the fp64 columns.")
 
 
-def cpu_baseline(nparams, nsamples, n_rows):
-    """
-    The oracle (numpy/scipy restatement of the reference, 'port') on a bounded sample of the same workload:
-    3 of the 50 parameters and 2 of the 1225 pairs at full N, timed on this host; whole-triangle throughput
-    extrapolated as 1225 / (50 t_prep + 1225 t_pair).
-    """
-    from getdist_amd import synth
+# ---- CPU baseline ----------------------------------------------------------------------------------------
+def _cpu_task(task):
+    """Worker: one oracle task on memory-mapped sample columns.  kinds: 'prep' (ranges + N_eff of one parameter),
+    'pair' (one 2D density with its parameters' N_eff prepared beforehand, as in a triangle) and 'triangle' (a share of
+    the full triangle at small N, parameter state cached in the worker)."""
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    import warnings
+
     from oracle import kde_oracle as ko
 
-    s, w, names, ranges = synth.config_c3(n_rows, nparams)
-    cols = [5, 6, 20] if nparams > 20 else [0, 1, 2]
-    sub = np.ascontiguousarray(s[:, cols])
-    sub_names = [names[c] for c in cols]
-    orc = ko.OracleSamples(sub, w, names=sub_names, ranges={k: v for k, v in ranges.items() if k in sub_names})
+    warnings.simplefilter("ignore")
+    import logging
+
+    logging.disable(logging.WARNING)
+    kind = task["kind"]
+    s = np.load(task["path"], mmap_mode="r")
+    names, ranges = task["names"], task["ranges"]
+    if kind == "prep":
+        j = task["j"]
+        orc = ko.OracleSamples(np.array(s[:, [j]]), names=[names[j]], ranges={k: v for k, v in ranges.items() if k == names[j]})
+        t0 = time.perf_counter()
+        orc.init_param(0)
+        orc.neff_1d(0)
+        return dict(kind=kind, j=j, seconds=time.perf_counter() - t0)
+    if kind == "pair":
+        a, b = task["pair"]
+        sub = [names[a], names[b]]
+        orc = ko.OracleSamples(np.array(s[:, [a, b]]), names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
+        for k in (0, 1):
+            orc.init_param(k)
+            orc.neff_1d(k)
+        tr = {}
+        t0 = time.perf_counter()
+        o = orc.density_2d(0, 1, trace=tr)
+        dt = time.perf_counter() - t0
+        out = dict(kind=kind, pair=(a, b), seconds=dt, branch=tr.get("branch"), bw=(tr.get("hx"), tr.get("hy"), tr.get("c")),
+                   F=int(o["P"].shape[0]))
+        if task.get("want_grid"):
+            out["P"] = o["P"]
+            if "p_13" in tr:
+                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+                out["chaotic"] = ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])
+        return out
+    # share of a full triangle: this worker's pairs, parameter state cached across them
+    orc = ko.OracleSamples(np.array(s), names=names, ranges=ranges)
     t0 = time.perf_counter()
-    for j in range(3):
-        orc.init_param(j)
-        orc.neff_1d(j)
-    t_prep = (time.perf_counter() - t0) / 3
+    sums = []
+    for a, b in task["pairs"]:
+        for k in (a, b):
+            if orc.pars[k].N_eff_kde is None:
+                orc.init_param(k)
+                orc.neff_1d(k)
+        sums.append(float(np.sum(orc.density_2d(a, b)["P"])))
+    return dict(kind=kind, seconds=time.perf_counter() - t0, sums=sums, pairs=task["pairs"])
+
+
+def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
+    """the oracle on this host's cores next to the GPU numbers, and full-size parity of the sample."""
+    import multiprocessing as mp
+    import tempfile
+
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    cores = os.cpu_count() or 1
+    workers = args.cpu_workers or min(cores, 32)
+    N, n = s.shape
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="gdamd_bench_", dir=shm)
+    path_full = os.path.join(tmp, "full.npy")
+    np.save(path_full, np.asfortranarray(s))
+    # class census from the GPU run: (bandwidth branch, #bounded parameters, grid size)
+    par = mc.paramNames.names
+    klass = {}
+    for (a, b), d in zip(pairs_all, dens):
+        key = "%s/%d/%d" % (d.bandwidth_branch, int(bool(par[a].has_limits)) + int(bool(par[b].has_limits)), d.P.shape[0])
+        klass.setdefault(key, []).append((a, b))
+    sample = [(key, pr) for key, members in sorted(klass.items()) for pr in members[:3]]
+    base = dict(path=path_full, names=list(names), ranges=dict(ranges))
+    tasks = [dict(base, kind="prep", j=j) for j in range(n)] + \
+            [dict(base, kind="pair", pair=pr, want_grid=True) for _, pr in sample]
+    ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
-    orc.density_2d(0, 1)
-    orc.density_2d(0, 2)
-    t_pair = (time.perf_counter() - t0) / 2
-    npairs = nparams * (nparams - 1) // 2
-    value = npairs / (nparams * t_prep + npairs * t_pair)
-    return dict(value=value, unit="densities/s", cores=1, kind="port",
-                sample="oracle on 3 of %d parameters (prep %.2f s each) + 2 of %d pairs (%.2f s each) at N=%d; "
-                       "triangle extrapolated as npairs/(nparams*t_prep + npairs*t_pair); host has %d logical cores, "
-                       "the reference path is single-process" % (nparams, t_prep, npairs, t_pair, n_rows, os.cpu_count()))
+    with ctx.Pool(workers) as pool:
+        # longest tasks first keeps the pool busy to the end
+        res = pool.map(_cpu_task, sorted(tasks, key=lambda t: 0 if t["kind"] == "pair" else 1), chunksize=1)
+        wall_sample = time.perf_counter() - t0
+        prep = {r["j"]: r["seconds"] for r in res if r["kind"] == "prep"}
+        pair_res = {tuple(r["pair"]): r for r in res if r["kind"] == "pair"}
+        by_class = {}
+        for key, pr in sample:
+            by_class.setdefault(key, []).append(pair_res[pr]["seconds"])
+        t_preps = sum(prep.values())
+        t_pairs = sum(len(klass[key]) * float(np.mean(v)) for key, v in by_class.items())
+        cpu_seconds_triangle = t_preps + t_pairs  # one core doing everything
+        task_seconds = t_preps + sum(sum(v) for v in by_class.values())
+        pool_efficiency = task_seconds / (wall_sample * workers)
+        value_pool = len(pairs_all) / (cpu_seconds_triangle / (workers * min(1.0, pool_efficiency)))
+        # ---- parity of the stratified sample at full size
+        dens_by_pair = dict(zip(pairs_all, dens))
+        parity = {}
+        loose = []
+        for key, pr in sample:
+            r, d = pair_res[pr], dens_by_pair[pr]
+            err = float(np.max(np.abs(d.P - r["P"]))) if d.P.shape == r["P"].shape else float("inf")
+            bw_err = float(np.max(np.abs(np.array(d.bandwidth) - np.array(r["bw"], dtype=float)))
+                           / max(abs(r["bw"][0]), abs(r["bw"][1])))
+            ent = parity.setdefault(key, dict(pairs_in_class=len(klass[key]), checked=0, max_abs_dP=0.0, max_bandwidth_rel_err=0.0))
+            ent["checked"] += 1
+            ent["max_abs_dP"] = max(ent["max_abs_dP"], err)
+            ent["max_bandwidth_rel_err"] = max(ent["max_bandwidth_rel_err"], bw_err)
+            if err > 1e-6:
+                chaotic = r.get("chaotic", (False, 0.0))
+                loose.append(dict(pair=[names[pr[0]], names[pr[1]]], klass=key, max_abs_dP=err, bandwidth_rel_err=bw_err,
+                                  oracle_chaotic=bool(chaotic[0]), oracle_moves_by=float(chaotic[1])))
+        parity_block = dict(N=int(N), tolerance=1e-6, classes=parity, n_pairs_checked=len(sample), n_pairs_on_loose_gate=len(loose),
+                            loose_pairs=loose,
+                            note="max|dP| of the GPU grid against the oracle grid (both max-normalised); a pair is on the "
+                                 "loose gate only if the oracle's own TNC result moves under a 1e-15 perturbation of its inputs")
+        # ---- single-process sample (the reference as shipped is one process): two preparations + two pairs
+        t0 = time.perf_counter()
+        single = [_cpu_task(dict(base, kind="prep", j=j)) for j in (5, 20) if j < n]
+        single += [_cpu_task(dict(base, kind="pair", pair=pr)) for _, pr in sample[:2]]
+        wall_single = time.perf_counter() - t0
+        sp_prep = float(np.mean([r["seconds"] for r in single if r["kind"] == "prep"]))
+        sp_ratio = float(np.mean([r["seconds"] / pair_res[tuple(r["pair"])]["seconds"] for r in single if r["kind"] == "pair"]))
+        value_single = len(pairs_all) / (n * sp_prep + t_pairs * sp_ratio)
+        # ---- un-extrapolated cross-check: the full triangle at small N on the same cores and on the GPU
+        small = None
+        if args.cpu_small_n and args.cpu_small_n < N:
+            s2, w2, names2, ranges2 = synth.config_c3(args.cpu_small_n, n)
+            path_small = os.path.join(tmp, "small.npy")
+            np.save(path_small, np.asfortranarray(s2))
+            shares = [pairs_all[k::workers] for k in range(workers)]
+            t0 = time.perf_counter()
+            tri = pool.map(_cpu_task, [dict(kind="triangle", path=path_small, names=list(names2), ranges=dict(ranges2), pairs=sh)
+                                       for sh in shares if sh], chunksize=1)
+            wall_cpu = time.perf_counter() - t0
+            mc2 = MCSamples(samples=s2, weights=w2, names=names2, ranges=ranges2, device=mc._device)
+            mc2.get2DDensities(pairs_all)
+            reset_caches(mc2)
+            mc2.ctx.sync()
+            t0 = time.perf_counter()
+            mc2.updateBaseStatistics()
+            d2 = mc2.get2DDensities(pairs_all)
+            mc2.ctx.sync()
+            wall_gpu = time.perf_counter() - t0
+            gpu_sums = {pr: float(np.sum(d.P)) for pr, d in zip(pairs_all, d2)}
+            rel = [abs(gpu_sums[tuple(pr)] - sm) / sm for r in tri for pr, sm in zip(r["pairs"], r["sums"])]
+            small = dict(N=int(args.cpu_small_n), pairs=len(pairs_all), cpu_wall_s=round(wall_cpu, 2), cpu_workers=workers,
+                         cpu_densities_per_s=round(len(pairs_all) / wall_cpu, 2), cpu_core_seconds=round(sum(r["seconds"] for r in tri), 1),
+                         gpu_wall_s=round(wall_gpu, 4), gpu_densities_per_s=round(len(pairs_all) / wall_gpu, 1),
+                         gpu_over_cpu_pool=round(wall_cpu / wall_gpu, 1),
+                         median_rel_diff_of_grid_sums=float(np.median(rel)), pairs_with_grid_sum_within_1e_5=int(np.sum(np.array(rel) < 1e-5)))
+            mc2.ctx.close()
+    try:
+        import shutil
+
+        shutil.rmtree(tmp)
+    except OSError:
+        pass
+    cpu = dict(value=value_pool, unit="densities/s", cores=workers, kind="port",
+               sample="oracle (numpy/scipy restatement of the reference, validated against it) at N=%d: all %d per-parameter "
+                      "preparations (%.1f core-s) + %d pairs stratified over the %d (branch/#bounded/F) classes of the census "
+                      "(%.1f core-s), in a pool of %d single-threaded workers (%.1f s wall, %.0f %% busy); triangle extrapolated "
+                      "with the per-class pair counts as core-seconds / (workers x busy fraction); host has %d logical cores"
+                      % (N, n, t_preps, len(sample), len(by_class), task_seconds - t_preps, workers, wall_sample,
+                         100 * pool_efficiency, cores),
+               single_process_value=value_single,
+               single_process_sample="%d preparations + 2 pairs run alone in one process (%.1f s); the reference as shipped is "
+                                     "single-process" % (len([r for r in single if r["kind"] == "prep"]), wall_single),
+               cpu_core_seconds_per_triangle=round(cpu_seconds_triangle, 1),
+               per_class_pair_seconds={k: round(float(np.mean(v)), 3) for k, v in by_class.items()},
+               class_census={k: len(v) for k, v in sorted(klass.items())},
+               full_triangle_small_n=small)
+    return cpu, parity_block
 
 
 def main():
@@ -195,6 +368,9 @@ def main():
         dist_mod.init_process_group(backend=args.backend, rank=rank, world_size=world)
         dist = dist_mod
 
+    import logging
+
+    logging.getLogger().setLevel(logging.ERROR)  # the reference's "fine_bins_2D not large enough" warnings, 170 per step
     from getdist_amd import synth
     from getdist_amd.mcsamples import MCSamples
 
@@ -259,7 +435,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded block recipe, SURVEY.md 8d C3)",
             "config": {"workload": "C3: 2D KDE triangle, %d params (%d pairs), N=%d unit-weight samples, base fine_bins_2D=256, "
-                                   "default settings; includes per-parameter prep, bandwidth selection and D2H of all grids"
+                                   "default settings; every step includes base statistics (means, variances, covariance), "
+                                   "per-parameter prep, bandwidth selection (fixed point + TNC on the device) and D2H of all grids"
                                    % (args.nparams, npairs, args.nsamples),
                        "parallelism": "pairs partitioned over %d GPU(s), samples replicated" % world,
                        "setup_s": {"generate": round(t_gen, 2), "construct_upload_basestats": round(t_ctor, 2)}},
@@ -270,7 +447,10 @@ def main():
         if world == 1 and not args.emulate_world:
             line["roofline"] = binning_kernel_roofline(mc, pairs_all)
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(args.nparams, args.nsamples, args.cpu_baseline_n or args.nsamples)
+                order = {pr: k for k, pr in enumerate(_REPLAY["last_pairs"])}
+                cpu, parity = cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, [dens[order[pr]] for pr in pairs_all])
+                line["cpu_baseline"] = cpu
+                line["parity"] = parity
         if mc._timing:
             line["phase_seconds_total"] = {k: round(v, 4) for k, v in sorted(mc.timings.items())}
         assert len(dens) > 0 and all(d is not None for d in dens)
