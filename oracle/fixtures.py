@@ -107,6 +107,140 @@ def mcmc_chains_fixture(nchains=3, N=6000, n=5):
     return samples, weights, loglikes, ["m%d" % i for i in range(n)], offsets
 
 
+# ---- the shape zoo of the reference's own test suite (getdist/tests/test_distributions.py:129-257), from its SPECS -----
+def _mixture_2d(r, N, means, shapes, weights=None, xmin=None, xmax=None, ymin=None, ymax=None):
+    """N draws of a 2D Gaussian mixture; components given as (sigma_x, sigma_y, correlation) or as a 2 x 2 covariance;
+    hard cuts by rejection."""
+    k = len(means)
+    wts = np.ones(k) / k if weights is None else np.asarray(weights, dtype=float) / np.sum(weights)
+    chol = []
+    for sh in shapes:
+        cov = np.asarray(sh, dtype=float)
+        if cov.shape != (2, 2):
+            sx, sy, c = sh
+            cov = np.array([[sx * sx, sx * sy * c], [sx * sy * c, sy * sy]])
+        chol.append(np.linalg.cholesky(cov))
+    xs, ys = [], []
+    need = N
+    while need > 0:
+        m = 2 * need + 64
+        comp = r.choice(k, size=m, p=wts)
+        z = r.standard_normal((m, 2))
+        pts = np.empty((m, 2))
+        for q in range(k):
+            sel = comp == q
+            pts[sel] = z[sel] @ chol[q].T + np.asarray(means[q], dtype=float)
+        keep = np.ones(m, dtype=bool)
+        if xmin is not None:
+            keep &= pts[:, 0] > xmin
+        if xmax is not None:
+            keep &= pts[:, 0] < xmax
+        if ymin is not None:
+            keep &= pts[:, 1] > ymin
+        if ymax is not None:
+            keep &= pts[:, 1] < ymax
+        xs.append(pts[keep, 0][:need])
+        ys.append(pts[keep, 1][:need])
+        need -= len(xs[-1])
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def _cov2(sx, sy, c):
+    return np.array([[sx * sx, sx * sy * c], [sx * sy * c, sy * sy]])
+
+
+def wj_zoo_2d(N=10000):
+    """
+    The 23 two-dimensional shapes of Test2DDistributions (test_distributions.py:154-257) -- Gaussian, bending with a hard
+    edge, hammer, skew, broad tail, rotating, tight (rho 0.99 / 0.98), cut correlated, flat between four cuts, the
+    Wand & Jones bi-, tri- and quadrimodal mixtures, seven half-plane-cut Gaussians -- as ONE sample set of 46 mutually
+    independent columns (x_k, y_k); the pairs of interest are (2k, 2k+1).  Returns (samples, names, ranges, pairs, labels).
+    """
+    r = _rng(40)
+    rt = np.sqrt(0.5)
+    specs = [
+        ("gauss", dict(means=[[0, 0]], shapes=[(0.7, 1, 0.3)])),
+        ("bending", dict(means=[[0, 0], [2, 1.8]], shapes=[(rt, 1, 0.9), (1, 1, 0.8)], weights=[0.6, 0.4], xmin=-1)),
+        ("hammer", dict(means=[[0, 0], [1, 1.8]], shapes=[(rt, 1, 0.9), (0.3, 1, -0.7)], weights=[0.5, 0.5])),
+        ("skew", dict(means=[[0, 0], [0, 1.2]], shapes=[_cov2(rt, 1, 0.1), _cov2(rt, 1, 0.1) / 4], weights=[0.5, 0.5])),
+        ("broadtail", dict(means=[[0, 0], [0, 0.2]], shapes=[_cov2(rt, 1, 0.1), _cov2(rt, 1, 0.1) * 8], weights=[0.9, 0.1])),
+        ("rotating", dict(means=[[0, 0], [0, 0.2]], shapes=[(1, 1, 0.5), (2, 2, -0.5)], weights=[0.6, 0.4])),
+        ("tight", dict(means=[[0, 0], [2.5, 3.5]], shapes=[(1, 1, 0.99), (1, 1.5, 0.98)], weights=[0.6, 0.4])),
+        ("cutcorr", dict(means=[[0, 0]], shapes=[(0.7, 1, 0.95)], ymin=0.3, xmax=1.2)),
+        ("flat", dict(means=[[0, 0]], shapes=[(1, 2, 0)], ymin=-1, ymax=2.1, xmin=-1, xmax=0.2)),
+        ("bimodal1", dict(means=[[-1, 0], [1, 0]], shapes=[(2 / 3, 2 / 3, 0)] * 2)),
+        ("bimodal2", dict(means=[[-1.5, 0], [1.5, 0]], shapes=[(0.25, 1, 0)] * 2)),
+        ("bimodal3", dict(means=[[-1, 1], [1, -1]], shapes=[(2 / 3, 2 / 3, 0.6)] * 2)),
+        ("bimodal4", dict(means=[[1, -1], [-1, 1]], shapes=[(2 / 3, 2 / 3, 0.7), (2 / 3, 2 / 3, 0)])),
+        ("trimodal1", dict(means=[[-1.2, 1.2], [1.2, -1.2], [0, 0]], shapes=[(0.6, 0.6, 0.3), (0.6, 0.6, -0.6), (0.25, 0.25, 0.2)],
+                           weights=[9, 9, 2])),
+        ("trimodal2", dict(means=[[-1.2, 0], [1.2, 0], [0, 0]], shapes=[(0.6, 0.6, 0.7), (0.6, 0.6, 0.7), (0.25, 0.25, -0.7)])),
+        ("trimodal3", dict(means=[[-1, 0], [1, 2 * np.sqrt(3) / 3], [1, -2 * np.sqrt(3) / 3]],
+                           shapes=[(0.6, 0.7, 0.6), (0.6, 0.7, 0), (0.4, 0.7, 0)], weights=[3, 3, 1])),
+        ("quadrimodal", dict(means=[[-1, 1], [-1, -1], [1, -1], [1, 1]],
+                             shapes=[(2 / 3, 2 / 3, 0.4), (2 / 3, 2 / 3, 0.6), (2 / 3, 2 / 3, -0.7), (2 / 3, 2 / 3, -0.5)],
+                             weights=[1, 3, 1, 3])),
+    ]
+    for cut in (-2, -1, -0.5, 0, 1, 1.5, 2):
+        specs.append(("cutx%g" % cut, dict(means=[[0, 0]], shapes=[(0.7, 1, 0.3)], xmin=cut)))
+    cols, names, ranges, labels = [], [], {}, []
+    for k, (label, sp) in enumerate(specs):
+        x, y = _mixture_2d(r, N, **sp)
+        cols += [x, y]
+        nx, ny = "x%d" % k, "y%d" % k
+        names += [nx, ny]
+        labels.append(label)
+        if sp.get("xmin") is not None or sp.get("xmax") is not None:
+            ranges[nx] = (sp.get("xmin"), sp.get("xmax"))
+        if sp.get("ymin") is not None or sp.get("ymax") is not None:
+            ranges[ny] = (sp.get("ymin"), sp.get("ymax"))
+    pairs = [(2 * k, 2 * k + 1) for k in range(len(specs))]
+    return np.column_stack(cols), names, ranges, pairs, labels
+
+
+def wj_zoo_1d(N=10000):
+    """The 17 one-dimensional shapes of Test1DDistributions (test_distributions.py:129-151): Gaussian, skew, tailed, broad,
+    flat between two cuts, flat top, two bimodal, one trimodal, six half-line-cut Gaussians -- one column each."""
+    r = _rng(41)
+
+    def mix(means, sigmas, weights=None, xmin=None, xmax=None):
+        k = len(means)
+        wts = np.ones(k) / k if weights is None else np.asarray(weights, dtype=float) / np.sum(weights)
+        out = []
+        need = N
+        while need > 0:
+            m = 2 * need + 64
+            comp = r.choice(k, size=m, p=wts)
+            v = r.standard_normal(m) * np.asarray(sigmas, dtype=float)[comp] + np.asarray(means, dtype=float)[comp]
+            keep = np.ones(m, dtype=bool)
+            if xmin is not None:
+                keep &= v > xmin
+            if xmax is not None:
+                keep &= v < xmax
+            out.append(v[keep][:need])
+            need -= len(out[-1])
+        return np.concatenate(out)
+
+    specs = [("gauss", dict(means=[0], sigmas=[0.5])), ("skew", dict(means=[0, 1], sigmas=[1, 0.4], weights=[0.6, 0.4])),
+             ("tailed", dict(means=[0, 0], sigmas=[1, 3], weights=[0.8, 0.2])),
+             ("broad", dict(means=[0, 0.3], sigmas=[1, 2], weights=[0.6, 0.4])),
+             ("flat", dict(means=[0], sigmas=[3], xmin=-1, xmax=2)),
+             ("flattop", dict(means=[0, 1.5, 3], sigmas=[1, 1, 1], weights=[0.4, 0.2, 0.4])),
+             ("bimodal1", dict(means=[0, 2], sigmas=[0.5, 0.5], weights=[0.6, 0.4])),
+             ("bimodal2", dict(means=[0, 2], sigmas=[0.2, 0.5], weights=[0.5, 0.5])),
+             ("trimodal", dict(means=[0, 2, 5], sigmas=[0.2, 0.7, 0.4]))]
+    for cut in (-1.5, -1, -0.5, 0, 1, 1.5):
+        specs.append(("cut%g" % cut, dict(means=[0], sigmas=[1], xmin=cut)))
+    specs += [("gauss_b", dict(means=[1], sigmas=[2])), ("twocut", dict(means=[0], sigmas=[1], xmin=-0.7, xmax=1.1))]
+    cols, names, ranges = [], [], {}
+    for label, sp in specs:
+        cols.append(mix(**sp))
+        names.append("u_" + label)
+        if sp.get("xmin") is not None or sp.get("xmax") is not None:
+            ranges[names[-1]] = (sp.get("xmin"), sp.get("xmax"))
+    return np.column_stack(cols), names, ranges
+
+
 def ingestion_cases():
     """Array-input cases for the per-chain ingestion pipeline: (label, kwargs for MCSamples) -- shared with the tests."""
     rng = np.random.default_rng(4242)
@@ -204,6 +338,17 @@ def fixture_zoo():
     r = _rng(3)
     zoo.append(dict(name="shapes_intweights", samples=s, weights=r.integers(1, 6, len(s)).astype(float), names=names,
                     ranges=ranges, pairs=[(0, 1), (4, 5)], kw1=({},), kw2=({},)))
+    s, names, ranges, pairs, _ = wj_zoo_2d()
+    zoo.append(dict(name="wj2d", samples=s, weights=None, names=names, ranges=ranges, pairs=pairs, kw1=({},), kw2=({},)))
+    r = _rng(42)
+    sel = [0, 1, 4, 5, 12, 13, 14, 15, 16, 17, 26, 27, 32, 33, 36, 37]  # gauss, hammer, tight, cutcorr, flat, trimodal1, quadrimodal, cutx-0.5
+    zoo.append(dict(name="wj2d_weighted", samples=s[:, sel], weights=r.exponential(1.0, len(s)), names=[names[c] for c in sel],
+                    ranges={k: v for k, v in ranges.items() if k in [names[c] for c in sel]},
+                    pairs=[(2 * k, 2 * k + 1) for k in range(len(sel) // 2)], kw1=({},), kw2=({},)))
+    s, names, ranges = wj_zoo_1d()
+    zoo.append(dict(name="wj1d", samples=s, weights=None, names=names, ranges=ranges, pairs=[],
+                    kw1=({}, dict(boundary_correction_order=2, mult_bias_correction_order=1), dict(mult_bias_correction_order=0)),
+                    kw2=({},)))
     s, names, ranges = periodic_fixture()
     zoo.append(dict(name="periodic", samples=s, weights=None, names=names, ranges=ranges,
                     pairs=[(0, 1), (1, 0)], kw1=({}, dict(fine_bins=64)), kw2=(dict(fine_bins_2D=32), dict(fine_bins_2D=64))))

@@ -269,6 +269,17 @@ def golden_convergence():
 
 
 def main():
+    if "--fixtures" in sys.argv:  # only the named fixture files (e.g. when the zoo grows)
+        wanted = sys.argv[sys.argv.index("--fixtures") + 1].split(",")
+        zoo = {fx["name"]: fx for fx in fixture_zoo()}
+        for nm in wanted:
+            out = golden_for_fixture(**zoo[nm])
+            path = os.path.join(HERE, "fixture_%s.npz" % nm)
+            np.savez_compressed(path, **out)
+            print(nm, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+            if "--margestats" in sys.argv:
+                np.savez_compressed(os.path.join(HERE, "margestats_%s.npz" % nm), **golden_margestats(zoo[nm]))
+        return
     xs = np.unique(np.concatenate([np.arange(1, 3000), np.geomspace(3000, 2.0e9, 1500).astype(np.int64)]))
     np.savez_compressed(os.path.join(HERE, "fftnumbers.npz"), x=xs, y=nearestFFTnumber(xs))
     np.savez_compressed(os.path.join(HERE, "convergence.npz"), **golden_convergence())

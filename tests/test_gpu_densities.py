@@ -16,7 +16,7 @@ from oracle import kde_oracle as ko
 pytestmark = pytest.mark.gpu
 
 TOL_GRID = 1e-6
-FIXTURES = ["c1_100k", "c1_bounded", "block10_weighted", "block50", "shapes", "shapes_intweights"]
+FIXTURES = ["c1_100k", "c1_bounded", "block10_weighted", "block50", "shapes", "shapes_intweights", "wj2d", "wj2d_weighted", "wj1d"]
 
 
 def make(fx):
@@ -266,7 +266,7 @@ def test_api_extras(zoo):
     assert "var(mean)/mean(var)" in txt and abs(m2.GelmanRubin - m2.getGelmanRubin()) <= 1e-12 * m2.GelmanRubin
 
 
-@pytest.mark.parametrize("name", ["shapes", "c1_bounded", "block10_weighted"])
+@pytest.mark.parametrize("name", ["shapes", "c1_bounded", "block10_weighted", "wj1d", "wj2d", "wj2d_weighted"])
 def test_marge_stats_golden(zoo, name):
     """getMargeStats numbers (mcsamples.py:2353-2367, 2442-2531) against the reference's."""
     fx = zoo[name]

@@ -540,7 +540,7 @@ def test_marge_stats_host_logic_against_goldens(zoo):
     the package's own spline implementation."""
     from getdist_amd.densities import Density1D
 
-    for name in ("c1_bounded", "shapes", "block10_weighted"):
+    for name in ("c1_bounded", "shapes", "block10_weighted", "wj1d", "wj2d_weighted"):
         fx = zoo[name]
         g = np.load(gu.GOLDEN_DIR + "/margestats_%s.npz" % name)
         mc = make(fx)

@@ -9,7 +9,7 @@ import pytest
 import golden_util as gu
 from oracle import kde_oracle as ko
 
-FIXTURES = ["c1_100k", "c1_bounded", "block10_weighted", "block50", "shapes", "shapes_intweights", "periodic"]
+FIXTURES = ["c1_100k", "c1_bounded", "block10_weighted", "block50", "shapes", "shapes_intweights", "wj2d", "wj2d_weighted", "wj1d", "periodic"]
 TOL_MOMENT = 1e-13  # BLAS summation order differs with memory layout
 TOL_GRID = 1e-10
 
@@ -51,7 +51,9 @@ def test_oracle_matches_golden(zoo, name):
             d = orc.density_1d(j, **kw)
             key = "p1d/%s/%s" % (nm, gu.kwkey(kw))
             assert gu.relerr(d["P"], g[key + "/P"]) < TOL_GRID, key
-            assert np.array_equal([d["x"][0], d["x"][-1]], g[key + "/x0x1"]), key
+            # bit-equal in general; where numpy's BLAS rounds a mean / variance differently from the run that made the
+            # goldens (summation order follows the memory layout) the edge moves by an ulp
+            assert np.allclose([d["x"][0], d["x"][-1]], g[key + "/x0x1"], rtol=4e-16, atol=0), key
             if not kw:
                 par = orc.pars[j]
                 got = np.array([float(getattr(par, a)) for a in gu.PAR_ATTS])
