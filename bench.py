@@ -56,6 +56,8 @@ def parse():
                     "job on one GPU (other ranks' parameter state is replayed from a cached full preparation)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline pool size (default min(cores, 32))")
     ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock cap of each CPU-baseline pool stage; "
+                    "a stage that exceeds it is abandoned and reported as such (the GPU numbers are printed regardless)")
     return ap.parse_args()
 
 
@@ -126,19 +128,35 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
     F = mc.fine_bins_2D
     corr = mc.getCorrelationMatrix()
     sel = [p for p in pairs_all if abs(corr[p[1]][p[0]]) <= 0.866]
-    ix, iy = [], []
-    for (a, b) in sel:
-        fwx, bx, _ = mc._bin_edges(names[a], F)
-        fwy, by, _ = mc._bin_edges(names[b], F)
-        ix.append(mc._index_column(a, F, bx, fwx))
-        iy.append(mc._index_column(b, F, by, fwy))
+    use_u8 = mc.weights is None and F == 256 and hasattr(mc.ctx, "hist2d_prebinned8")
+    if use_u8:
+        wanted = {}
+        for (a, b) in sel:
+            for j in (a, b):
+                fw, b0, _ = mc._bin_edges(names[j], F)
+                wanted[j] = (b0, fw)
+        use_u8 = mc._index_columns8(wanted)
+    if use_u8:
+        ix = [mc._idx_cols[(a, 256, "u8")][0] for a, b in sel]
+        iy = [mc._idx_cols[(b, 256, "u8")][0] for a, b in sel]
+        launch = lambda out: mc.ctx.hist2d_prebinned8(ix, iy, out=out)  # noqa: E731
+        kernel = "k_hist2d_u8 (batched 2D binning of byte index columns, F=256, 16-bit packed LDS counters, v_perm addressing)"
+    else:
+        ix, iy = [], []
+        for (a, b) in sel:
+            fwx, bx, _ = mc._bin_edges(names[a], F)
+            fwy, by, _ = mc._bin_edges(names[b], F)
+            ix.append(mc._index_column(a, F, bx, fwx))
+            iy.append(mc._index_column(b, F, by, fwy))
+        launch = lambda out: mc.ctx.hist2d_prebinned(ix, iy, F, out=out)  # noqa: E731
+        kernel = "k_hist2d_u16 (batched 2D binning of pre-binned u16 index columns, 16-bit packed LDS counters)"
     out = mc.ctx.alloc(len(sel) * F * F * 8)
-    mc.ctx.hist2d_prebinned(ix, iy, F, out=out)
+    launch(out)
     mc.ctx.sync()
     ms = []
     for _ in range(reps):
         mc.ctx.timer_start()
-        mc.ctx.hist2d_prebinned(ix, iy, F, out=out)
+        launch(out)
         ms.append(mc.ctx.timer_stop_ms())
     out.free()
     t = float(np.median(ms)) * 1e-3
@@ -149,7 +167,7 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
     if os.path.exists(PMC_FILE):
         pmc = json.load(open(PMC_FILE))
         if (pmc.get("N") == mc.numrows and pmc.get("n") == mc.n and pmc.get("F") == F and bool(pmc.get("weighted")) == weighted
-                and pmc.get("pairs")):
+                and pmc.get("pairs") and pmc.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]):
             traffic = float(pmc["hbm_bytes_per_launch"]) * len(sel) / pmc["pairs"]
             source = "profiles/r02_pmc_hist2d.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled by pairs)"
     frac_model = model_bytes / t / 1e9 / HBM_PEAK_GBS
@@ -157,8 +175,7 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
         achieved = traffic / t / 1e9
     else:
         achieved = model_bytes / t / 1e9
-    return dict(kernel="k_hist2d_u16 (batched 2D binning of pre-binned index columns, 16-bit packed LDS counters)",
-                bound="lds-atomic", priced_against="hbm", launches_pairs=len(sel), ms_per_launch=t * 1e3,
+    return dict(kernel=kernel, bound="lds-atomic", priced_against="hbm", launches_pairs=len(sel), ms_per_launch=t * 1e3,
                 achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                 traffic_source=source, frac_counter=(None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS),
                 frac_model_unit_weight=frac_model, model_bytes=model_bytes,
@@ -170,12 +187,14 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
 
 
 # ---- CPU baseline ----------------------------------------------------------------------------------------
+def _cpu_noop(k):
+    return k
+
+
 def _cpu_task(task):
     """Worker: one oracle task on memory-mapped sample columns.  kinds: 'prep' (ranges + N_eff of one parameter),
     'pair' (one 2D density with its parameters' N_eff prepared beforehand, as in a triangle) and 'triangle' (a share of
     the full triangle at small N, parameter state cached in the worker)."""
-    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ[k] = "1"
     import warnings
 
     from oracle import kde_oracle as ko
@@ -252,10 +271,24 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
     tasks = [dict(base, kind="prep", j=j) for j in range(n)] + \
             [dict(base, kind="pair", pair=pr, want_grid=True) for _, pr in sample]
     ctx = mp.get_context("spawn")
+    # the workers are single-threaded: the BLAS / OpenMP pools read these variables when numpy is first imported in
+    # the child, so they must be in the environment the children are spawned with
+    saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved_env:
+        os.environ[k] = "1"
     t0 = time.perf_counter()
-    with ctx.Pool(workers) as pool:
+    pool_cm = ctx.Pool(workers)
+    for k, v in saved_env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    with pool_cm as pool:
+        pool.map(_cpu_noop, range(workers * 2), chunksize=1)  # start-up (interpreter + numpy import) is not CPU-baseline time
+        t0 = time.perf_counter()
         # longest tasks first keeps the pool busy to the end
-        res = pool.map(_cpu_task, sorted(tasks, key=lambda t: 0 if t["kind"] == "pair" else 1), chunksize=1)
+        res = pool.map_async(_cpu_task, sorted(tasks, key=lambda t: 0 if t["kind"] == "pair" else 1),
+                             chunksize=1).get(timeout=args.cpu_budget_s)
         wall_sample = time.perf_counter() - t0
         prep = {r["j"]: r["seconds"] for r in res if r["kind"] == "prep"}
         pair_res = {tuple(r["pair"]): r for r in res if r["kind"] == "pair"}
@@ -291,8 +324,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                                  "loose gate only if the oracle's own TNC result moves under a 1e-15 perturbation of its inputs")
         # ---- single-process sample (the reference as shipped is one process): two preparations + two pairs
         t0 = time.perf_counter()
-        single = [_cpu_task(dict(base, kind="prep", j=j)) for j in (5, 20) if j < n]
-        single += [_cpu_task(dict(base, kind="pair", pair=pr)) for _, pr in sample[:2]]
+        single = [_cpu_task(dict(base, kind="prep", j=min(5, n - 1))), _cpu_task(dict(base, kind="pair", pair=sample[0][1]))]
         wall_single = time.perf_counter() - t0
         sp_prep = float(np.mean([r["seconds"] for r in single if r["kind"] == "prep"]))
         sp_ratio = float(np.mean([r["seconds"] / pair_res[tuple(r["pair"])]["seconds"] for r in single if r["kind"] == "pair"]))
@@ -305,8 +337,8 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
             np.save(path_small, np.asfortranarray(s2))
             shares = [pairs_all[k::workers] for k in range(workers)]
             t0 = time.perf_counter()
-            tri = pool.map(_cpu_task, [dict(kind="triangle", path=path_small, names=list(names2), ranges=dict(ranges2), pairs=sh)
-                                       for sh in shares if sh], chunksize=1)
+            tri = pool.map_async(_cpu_task, [dict(kind="triangle", path=path_small, names=list(names2), ranges=dict(ranges2),
+                                                  pairs=sh) for sh in shares if sh], chunksize=1).get(timeout=args.cpu_budget_s)
             wall_cpu = time.perf_counter() - t0
             mc2 = MCSamples(samples=s2, weights=w2, names=names2, ranges=ranges2, device=mc._device)
             mc2.get2DDensities(pairs_all)
@@ -339,8 +371,8 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                       % (N, n, t_preps, len(sample), len(by_class), task_seconds - t_preps, workers, wall_sample,
                          100 * pool_efficiency, cores),
                single_process_value=value_single,
-               single_process_sample="%d preparations + 2 pairs run alone in one process (%.1f s); the reference as shipped is "
-                                     "single-process" % (len([r for r in single if r["kind"] == "prep"]), wall_single),
+               single_process_sample="one preparation + one pair (with its two preparations) run alone in this process with the "
+                                     "default BLAS threads (%.1f s); the reference as shipped is single-process" % wall_single,
                cpu_core_seconds_per_triangle=round(cpu_seconds_triangle, 1),
                per_class_pair_seconds={k: round(float(np.mean(v)), 3) for k, v in by_class.items()},
                class_census={k: len(v) for k, v in sorted(klass.items())},
@@ -448,9 +480,14 @@ def main():
             line["roofline"] = binning_kernel_roofline(mc, pairs_all)
             if not args.no_cpu_baseline:
                 order = {pr: k for k, pr in enumerate(_REPLAY["last_pairs"])}
-                cpu, parity = cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, [dens[order[pr]] for pr in pairs_all])
-                line["cpu_baseline"] = cpu
-                line["parity"] = parity
+                try:
+                    cpu, parity = cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all,
+                                                          [dens[order[pr]] for pr in pairs_all])
+                    line["cpu_baseline"] = cpu
+                    line["parity"] = parity
+                except Exception as exc:  # never lose the measured GPU line to a host-side problem
+                    line["cpu_baseline"] = dict(value=None, unit="densities/s", cores=0, kind="port",
+                                                sample="CPU baseline failed: %r" % (exc,))
         if mc._timing:
             line["phase_seconds_total"] = {k: round(v, 4) for k, v in sorted(mc.timings.items())}
         assert len(dens) > 0 and all(d is not None for d in dens)

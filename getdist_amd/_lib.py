@@ -78,6 +78,8 @@ SIGNATURES = {
     "gd_bin_indices": (C.c_int, [_p, _i32, _f64, _f64, _i32, _i32, _pi32, _pi64]),
     "gd_prebin": (C.c_int, [_p, _i32, _f64, _f64, _i32, _p]),
     "gd_prebin_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p)]),
+    "gd_prebin8_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p), _pi64]),
+    "gd_hist2d_prebinned8": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _p]),
     "gd_hist2d": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _i32, _p]),
     "gd_hist2d_prebinned": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "gd_minmax_affine": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd]),
@@ -451,6 +453,24 @@ class Context:
         cols, binmin, width = _i32arr(cols), _f64arr(binmin), _f64arr(width)
         arr = (_p * len(cols))(*[b.ptr for b in bufs])
         self._check(self.lib.gd_prebin_batch(self.h, _ip(cols), len(cols), _dp(binmin), _dp(width), int(F), arr))
+
+    def prebin8_batch(self, cols, binmin, width, F, bufs):
+        """Byte index columns (F <= 256) for several sample columns in one launch; returns the out-of-range counts."""
+        cols, binmin, width = _i32arr(cols), _f64arr(binmin), _f64arr(width)
+        arr = (_p * len(cols))(*[b.ptr for b in bufs])
+        bad = np.zeros(len(cols), dtype=np.int64)
+        self._check(self.lib.gd_prebin8_batch(self.h, _ip(cols), len(cols), _dp(binmin), _dp(width), int(F), arr,
+                                              bad.ctypes.data_as(_pi64)))
+        return bad
+
+    def hist2d_prebinned8(self, idx_x, idx_y, out=None):
+        """B histograms of 256 x 256 bins from byte index columns (unit weights); raises GdhipError(-5) on counter wrap."""
+        B = len(idx_x)
+        out = out or self.alloc(B * 65536 * 8)
+        ax = (_p * B)(*[b.ptr for b in idx_x])
+        ay = (_p * B)(*[b.ptr for b in idx_y])
+        self._check(self.lib.gd_hist2d_prebinned8(self.h, B, ax, ay, out.ptr))
+        return out
 
     def hist2d(self, colx, coly, bx, wx, by, wy, F, out=None):
         colx, coly = _i32arr(colx), _i32arr(coly)

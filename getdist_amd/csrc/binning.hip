@@ -344,6 +344,180 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restric
     if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
 }
 
+// ---- F = 256, unit weights, byte indices: the batched triangle kernel ------------------------------------------------
+// One block per pair; the 256 x 256 grid is 65536 16-bit counters packed two per LDS word (128 KB).  Bin a = (y << 8) | x
+// lives in word (a & 0x7fff), half (a >> 15): neighbouring x bins fall in neighbouring banks, and the byte-interleave
+// v_perm_b32 builds two bin addresses per instruction from four x bytes and four y bytes, so a sample costs about half
+// the VALU instructions of the u16 kernel (which is issue-bound as much as LDS-bound: profiles/).  Every sample is
+// inside the grid by construction of the bin range (the pre-bin kernel verifies it), so the accepted count is N and
+// a counter wrap -- which always changes the sum of all counters -- is detected by comparing that sum with N.
+struct Hist2DPair8 {
+    const unsigned char* ix;
+    const unsigned char* iy;
+};
+
+__global__ void __launch_bounds__(1024) k_hist2d_u8(const Hist2DPair8* __restrict__ pairs, int B, int64_t N,
+                                                    double* __restrict__ hist_all, int* __restrict__ overflow) {
+    extern __shared__ double sh_raw[];
+    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
+    __shared__ double red[16];
+    // consecutive pairs share their x column: give each XCD (block id mod 8) a contiguous run of pairs
+    const int per_xcd = (B + 7) / 8;
+    const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pair >= B || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    const Hist2DPair8 P = pairs[pair];
+    for (int i = threadIdx.x; i < 32768; i += 1024) sh[i] = 0;
+    __syncthreads();
+    auto add = [&](unsigned a) { atomicAdd(&sh[a & 0x7fffu], 1u << ((a >> 11) & 16u)); };
+    auto visit4 = [&](unsigned x4, unsigned y4) {
+        const unsigned lo = __builtin_amdgcn_perm(y4, x4, 0x05010400u);  // (y1 x1 y0 x0)
+        const unsigned hi = __builtin_amdgcn_perm(y4, x4, 0x07030602u);  // (y3 x3 y2 x2)
+        add(lo & 0xffffu);
+        add(lo >> 16);
+        add(hi & 0xffffu);
+        add(hi >> 16);
+    };
+    const int64_t N16 = N & ~(int64_t)15;
+    for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * 1024) {
+        const uint4 ax = *reinterpret_cast<const uint4*>(P.ix + i), ay = *reinterpret_cast<const uint4*>(P.iy + i);
+        visit4(ax.x, ay.x);
+        visit4(ax.y, ay.y);
+        visit4(ax.z, ay.z);
+        visit4(ax.w, ay.w);
+    }
+    if (threadIdx.x == 0)
+        for (int64_t i = N16; i < N; ++i) add(((unsigned)P.iy[i] << 8) | (unsigned)P.ix[i]);
+    __syncthreads();
+    double* hist = hist_all + (int64_t)pair * 65536;
+    unsigned int total = 0;
+    for (int i = threadIdx.x; i < 32768; i += 1024) {
+        const unsigned int v = sh[i];
+        total += (v & 0xffffu) + (v >> 16);
+        hist[i] = (double)(v & 0xffffu);
+        hist[i + 32768] = (double)(v >> 16);
+    }
+    const double t = block_sum((double)total, red);
+    if (threadIdx.x == 0 && t != (double)N) atomicOr(&overflow[pair], 1);
+}
+
+struct PrebinCol8 {
+    const double* x;
+    unsigned char* idx;
+    double binmin, width;
+};
+
+// byte bin indices of several columns in one launch (grid (blocks, ncols)); bad[c] counts samples outside [0, F)
+__global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restrict__ colsv, int64_t N, int F,
+                                                       unsigned long long* __restrict__ bad) {
+    const PrebinCol8 C = colsv[blockIdx.y];
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    const int64_t N8 = N & ~(int64_t)7;
+    unsigned nbad = 0;
+    for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
+        double2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2*>(C.x + i + 2 * q);
+        unsigned o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = bin_round(v[q].x, C.binmin, C.width), b = bin_round(v[q].y, C.binmin, C.width);
+            nbad += ((unsigned)a >= (unsigned)F) + ((unsigned)b >= (unsigned)F);
+            o[2 * q] = (unsigned)a & 0xffu;
+            o[2 * q + 1] = (unsigned)b & 0xffu;
+        }
+        uint2 pk;
+        pk.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        pk.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+        *reinterpret_cast<uint2*>(C.idx + i) = pk;
+    }
+    if (gtid == 0)
+        for (int64_t i = N8; i < N; ++i) {
+            const int a = bin_round(C.x[i], C.binmin, C.width);
+            nbad += ((unsigned)a >= (unsigned)F);
+            C.idx[i] = (unsigned char)a;
+        }
+    if (nbad) atomicAdd(&bad[blockIdx.y], (unsigned long long)nbad);
+}
+
+// ---- fused fp64 index + binning with packed 16-bit counters (unit weights): one stripe at F <= 256 --------------------
+// MODE 0: rounded indices of two columns; MODE 1: the sheared, truncating indices of kde.bin_samples.  A block owns a
+// (pair, chunk of rows, stripe of R rows); its packed counters go to scratch and k_p16_reduce adds the chunks, so no
+// global atomics and every sample's two divisions are done once per stripe (ONE stripe at F <= 256; the 32-bit kernel
+// needs two and therefore reads and divides twice).
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __restrict__ pairs, int B, int64_t N, int F, int R,
+                                                         int nstripes, int nchunks, unsigned int* __restrict__ part,
+                                                         int* __restrict__ overflow) {
+    extern __shared__ double sh_raw[];
+    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
+    __shared__ double red[16];
+    int pair, chunk, stripe;
+    decode_block(nstripes, nchunks, pair, chunk, stripe);
+    if (pair >= B) return;
+    const Hist2DPair P = pairs[pair];
+    const int row0 = stripe * R;
+    const int nwords = (R * F + 1) / 2;
+    for (int i = threadIdx.x; i < nwords; i += 1024) sh[i] = 0;
+    __syncthreads();
+    int64_t per = (N + nchunks - 1) / nchunks;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t lo = (int64_t)chunk * per;
+    int64_t hi = lo + per;
+    if (hi > N) hi = N;
+    unsigned int nacc = 0;
+    auto visit = [&](double xv, double yv) {
+        int cx, cy;
+        if (MODE == 0) {
+            cx = bin_round(xv, P.bx, P.wx), cy = bin_round(yv, P.by, P.wy);
+        } else {
+            cx = bin_trunc(xv, P.bx, P.wx);
+            cy = bin_trunc(P.r0 * xv + P.r1 * yv, P.by, P.wy);
+        }
+        const unsigned r = (unsigned)cy - (unsigned)row0;
+        if (r < (unsigned)R && (unsigned)cx < (unsigned)F && (unsigned)cy < (unsigned)F) {
+            const unsigned a = r * (unsigned)F + (unsigned)cx;
+            atomicAdd(&sh[a >> 1], 1u << ((a & 1u) * 16u));
+            nacc += 1;
+        }
+    };
+    const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
+    for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * 1024) {
+        const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
+        const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+        visit(xv.x, yv.x);
+        visit(xv.y, yv.y);
+    }
+    if (threadIdx.x == 0 && hi2 < hi) visit(P.x[hi2], P.y[hi2]);
+    __syncthreads();
+    unsigned int* dst = part + (((int64_t)pair * nchunks + chunk) * nstripes + stripe) * (int64_t)nwords;
+    unsigned int total = 0;
+    for (int i = threadIdx.x; i < nwords; i += 1024) {
+        const unsigned int v = sh[i];
+        total += (v & 0xffffu) + (v >> 16);
+        dst[i] = v;
+    }
+    const double t = block_sum((double)total, red), a = block_sum((double)nacc, red);
+    if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
+}
+
+// hist[pair][row][col] = sum over chunks of the packed partial counters; grid (blocks, B)
+__global__ void k_p16_reduce(const unsigned int* __restrict__ part, int F, int R, int nstripes, int nchunks,
+                             double* __restrict__ hist_all) {
+    const int pair = blockIdx.y;
+    const int nwords = (R * F + 1) / 2;
+    double* hist = hist_all + (int64_t)pair * F * F;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        const int row = e / F, col = e % F;
+        const int stripe = row / R, a = (row - stripe * R) * F + col;
+        unsigned int s = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const unsigned int v = part[(((int64_t)pair * nchunks + c) * nstripes + stripe) * (int64_t)nwords + (a >> 1)];
+            s += (v >> ((a & 1) * 16)) & 0xffffu;
+        }
+        hist[e] = (double)s;
+    }
+}
+
 // min / max of a*x + b*y over the samples; grid (nblk, B)
 __global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N, double* __restrict__ part) {
     __shared__ double red[16];
@@ -372,9 +546,71 @@ __global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N,
 
 // =============================================================================================================
 template <int MODE>
-static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist) {
+static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist, bool allow_p16 = true);
+
+// unit weights, fp64 columns: packed 16-bit counters, partial grids per chunk reduced without atomics; pairs whose
+// counters wrapped are redone with the 32-bit kernel
+template <int MODE>
+static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist) {
+    int R = LDS_HIST_BYTES / (F * 2);
+    if (R > F) R = F;
+    const int nstripes = (F + R - 1) / R;
+    int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
+    if (nchunks < 1) nchunks = 1;
+    if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+    const int units = (B * nchunks + 7) / 8 * 8;
+    const int64_t nblocks = (int64_t)units * nstripes;
+    const int nwords = (R * F + 1) / 2;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_pairs = take((int64_t)B * sizeof(Hist2DPair)), o_flags = take((int64_t)B * 4),
+                  o_part = take((int64_t)B * nchunks * nstripes * nwords * 4);
+    char* base = (char*)gd_scratch2(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    Hist2DPair* d_pairs = (Hist2DPair*)(base + o_pairs);
+    int* d_flags = (int*)(base + o_flags);
+    unsigned int* d_part = (unsigned int*)(base + o_part);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_f64_p16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+    k_hist2d_f64_p16<MODE><<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes,
+                                                                                      nchunks, d_part, d_flags);
+    GD_KERNEL_CHECK();
+    k_p16_reduce<<<dim3(16, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
+    GD_KERNEL_CHECK();
+    std::vector<int> hf((size_t)B);
+    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> flagged;
+    for (int b = 0; b < B; ++b)
+        if (hf[b]) flagged.push_back(b);
+    int rc = GD_OK;
+    if (!flagged.empty()) {
+        const int nf = (int)flagged.size();
+        std::vector<Hist2DPair> sub((size_t)nf);
+        for (int q = 0; q < nf; ++q) sub[q] = hp[flagged[q]];
+        double* tmp = nullptr;
+        GD_HIP(hipMalloc((void**)&tmp, (size_t)nf * F * F * 8));
+        rc = launch_hist2d<MODE>(ctx, nf, sub, F, tmp, false);
+        for (int q = 0; q < nf && rc == GD_OK; ++q)
+            if (hipMemcpyAsync(d_hist + (int64_t)flagged[q] * F * F, tmp + (int64_t)q * F * F, (size_t)F * F * 8,
+                               hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                rc = gd_fail(ctx, GD_ERR_HIP, "copy of redone histogram failed");
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+    }
+    return rc;
+}
+
+template <int MODE>
+static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist, bool allow_p16) {
     GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins_2D out of range");
     const bool has_w = ctx->w != nullptr;
+    if (MODE != 2 && !has_w && allow_p16 && !getenv("GDHIP_NO_P16")) return launch_hist2d_p16<(MODE == 2 ? 0 : MODE)>(ctx, B, hp, F, d_hist);
     const bool u32bins = !has_w || ctx->w_integral;  // integral weights: exact u32 counters, twice the rows per stripe
     const int binbytes = u32bins ? 4 : 8;
     int R = LDS_HIST_BYTES / (F * binbytes);
@@ -603,6 +839,69 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(tmp);
     }
+    return rc;
+}
+
+int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                     void* const* d_idx_out, int64_t* bad_out) {
+    GD_REQUIRE(ctx && cols && binmin && width && d_idx_out && bad_out && ncols > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(F >= 2 && F <= 256, "byte indices need fine_bins_2D <= 256");
+    std::vector<PrebinCol8> hc((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) {
+        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
+        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        hc[c].idx = (unsigned char*)d_idx_out[c];
+        hc[c].binmin = binmin[c];
+        hc[c].width = width[c];
+    }
+    const int64_t o_bad = ((int64_t)ncols * sizeof(PrebinCol8) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_bad + (int64_t)ncols * 8);
+    if (!base) return GD_ERR_NOMEM;
+    PrebinCol8* d_c = (PrebinCol8*)base;
+    unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
+    GD_HIP(hipMemcpyAsync(d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol8), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_bad, 0, (size_t)ncols * 8, ctx->stream));
+    int nblk = (int)((ctx->N / 8 + 255) / 256);
+    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+    if (nblk < 1) nblk = 1;
+    k_prebin8_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F, d_bad);
+    GD_KERNEL_CHECK();
+    std::vector<unsigned long long> hb((size_t)ncols);
+    GD_HIP(hipMemcpyAsync(hb.data(), d_bad, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)hb[c];
+    return GD_OK;
+}
+
+int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, void* d_hist) {
+    GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(!ctx->w, "byte-index binning is for unit weights");
+    const int F = 256;
+    std::vector<Hist2DPair8> hp((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        hp[b].ix = (const unsigned char*)d_idx_x[b];
+        hp[b].iy = (const unsigned char*)d_idx_y[b];
+        GD_REQUIRE(hp[b].ix && hp[b].iy, "null index column");
+    }
+    const int64_t o_flags = ((int64_t)B * sizeof(Hist2DPair8) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_flags + (int64_t)B * 4);
+    if (!base) return GD_ERR_NOMEM;
+    Hist2DPair8* d_pairs = (Hist2DPair8*)base;
+    int* d_flags = (int*)(base + o_flags);
+    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+    const int nblocks = (B + 7) / 8 * 8;
+    k_hist2d_u8<<<nblocks, 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
+    GD_KERNEL_CHECK();
+    std::vector<int> hf((size_t)B);
+    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = GD_OK;
+    for (int b = 0; b < B && rc == GD_OK; ++b)
+        if (hf[b]) rc = gd_fail(ctx, GD_ERR_SOLVER, "16-bit bin counter wrapped in pair %d: redo with gd_hist2d_prebinned", b);
     return rc;
 }
 

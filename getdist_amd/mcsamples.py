@@ -22,7 +22,7 @@ import warnings
 
 import numpy as np
 
-from ._lib import Context
+from ._lib import Context, GdhipError
 from .densities import Density1D, Density2D, DensitiesError
 
 # analysis_defaults.ini:1-76 (the ini always overrides the class literals, mcsamples.py:491-492)
@@ -1851,6 +1851,20 @@ class MCSamples:
         for j, buf in zip(todo, bufs):
             self._idx_cols[(j, F)] = (buf, wanted[j])
 
+    def _index_columns8(self, wanted):
+        """Byte index columns of the 256-bin grid (wanted: j -> (binmin, width)) in ONE launch; False if any sample of
+        any column falls outside the grid (then the u16 path, which marks such samples, must be used)."""
+        todo = [j for j, bw in wanted.items() if self._idx_cols.get((j, 256, "u8"), (None, None))[1] != bw]
+        if todo:
+            bufs = []
+            for j in todo:
+                hit = self._idx_cols.get((j, 256, "u8"))
+                bufs.append(hit[0] if hit is not None else self.ctx.alloc(self.numrows + 64))
+            bad = self.ctx.prebin8_batch(todo, [wanted[j][0] for j in todo], [wanted[j][1] for j in todo], 256, bufs)
+            for j, buf, nb in zip(todo, bufs, bad):
+                self._idx_cols[(j, 256, "u8")] = (buf, wanted[j] if nb == 0 else None)
+        return all(self._idx_cols[(j, 256, "u8")][1] == bw for j, bw in wanted.items())
+
     def _index_column(self, j, F, binmin, width):
         key = (j, F)
         hit = self._idx_cols.get(key)
@@ -1984,6 +1998,25 @@ class MCSamples:
         def binning(owner=self):
             """prebin + batched 2D histograms on ``owner``'s context (this object, or its second-lane twin)."""
             for F, members in classes.items():
+                if (F == 256 and owner.weights is None and not meanlikes and len(members) >= 64
+                        and hasattr(owner.ctx, "hist2d_prebinned8") and os.environ.get("GETDIST_AMD_U8", "1") == "1"):
+                    # the base grid of a unit-weight triangle: byte indices, packed 16-bit counters, one block per pair
+                    with _Phase(self, "2d.prebin"):
+                        wanted = {}
+                        for k in members:
+                            wanted[info[k]["j"]] = (info[k]["xbinmin"], info[k]["fwx"])
+                            wanted[info[k]["j2"]] = (info[k]["ybinmin"], info[k]["fwy"])
+                        ok = owner._index_columns8(wanted)
+                    if ok:
+                        try:
+                            with _Phase(self, "2d.hist"):
+                                hists[F] = (owner.ctx.hist2d_prebinned8([owner._idx_cols[(info[k]["j"], 256, "u8")][0] for k in members],
+                                                                        [owner._idx_cols[(info[k]["j2"], 256, "u8")][0] for k in members]),
+                                            members)
+                            continue
+                        except GdhipError as e:
+                            if e.code != -5:  # a 16-bit counter wrapped: the u16 / u32 path below redoes the class
+                                raise
                 with _Phase(self, "2d.prebin"):
                     ix = [owner._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
                     iy = [owner._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]

@@ -137,6 +137,18 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
 int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
                    int32_t* idx_out, int64_t* n_out_of_range);
 int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16);
+/* Byte-index variant of the batched triangle binning (unit weights, fine_bins_2D = 256, the base grid of 98 % of a
+ * triangle's pairs): gd_prebin8_batch writes (unsigned char)((x - binmin)/width + 0.5) for ncols columns in one launch
+ * (d_idx_out[c]: device buffers of N bytes, 16-byte aligned) and reports in bad_out[c] how many samples fell outside
+ * [0, F) -- zero by construction of the bin range (mcsamples.py:1486-1498), and required to be zero by
+ * gd_hist2d_prebinned8, which builds B 256 x 256 histograms (device, B x 256 x 256 fp64, [y][x]) from pairs of those
+ * columns: one block per pair, 16-bit counters packed two per LDS word, two bin addresses per v_perm_b32.  A wrapped
+ * counter (more than 65535 samples in one bin) is detected exactly and reported as GD_ERR_SOLVER; the caller then uses
+ * gd_prebin_batch + gd_hist2d_prebinned for that batch. */
+int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                     void* const* d_idx_out, int64_t* bad_out);
+int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, void* d_hist);
+
 /* several index columns in one launch (d_idx_u16[c] receives column cols[c] binned with binmin[c], width[c]) */
 int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
                     void* const* d_idx_u16);

@@ -398,3 +398,71 @@ def test_isj1d_device_solver_matches_scipy_path(ctx, F):
             assert err <= 1e-9, (b, kind, h[b], want)
     print("isj1d worst relative deviation %.2e (flat shapes %.2e), %d failures, %d near the re-check threshold"
           % (worst, worst_flat, n_none, n_recheck))
+
+
+def test_byte_index_binning_matches_numpy_and_detects_wraps():
+    """gd_prebin8_batch + gd_hist2d_prebinned8 (byte indices, F = 256, unit weights, packed 16-bit counters addressed
+    through v_perm_b32): bit-exact histograms against numpy's bincount on the reference's index expression, the
+    out-of-range report, and the exact wrap detection (one bin receiving more than 65535 samples)."""
+    from getdist_amd._lib import Context, GdhipError
+
+    N, F = 300_007, 256
+    r = np.random.default_rng(5)
+    s = np.column_stack([r.standard_normal(N), r.standard_normal(N) * 2 + 1, r.exponential(1.0, N), r.uniform(-1, 1, N)])
+    c = Context(0)
+    c.upload(np.asfortranarray(s), None)
+    lo, hi = s.min(axis=0), s.max(axis=0)
+    binmin = lo - 0.05 * (hi - lo)
+    width = (hi + 0.05 * (hi - lo) - binmin) / (F - 1)
+    bufs = [c.alloc(N + 64) for _ in range(4)]
+    bad = c.prebin8_batch([0, 1, 2, 3], binmin, width, F, bufs)
+    assert np.all(bad == 0)
+    ix = [((s[:, j] - binmin[j]) / width[j] + 0.5).astype(int) for j in range(4)]
+    for j in range(4):
+        assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint8), ix[j].astype(np.uint8))
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3), (3, 0), (2, 1), (1, 1)]
+    H = c.hist2d_prebinned8([bufs[a] for a, b in pairs], [bufs[b] for a, b in pairs]).to_host((len(pairs), F, F))
+    for k, (a, b) in enumerate(pairs):
+        want = np.bincount(ix[a] + ix[b] * F, minlength=F * F).reshape(F, F)
+        assert np.array_equal(H[k], want), (a, b)
+    # a narrower grid leaves samples outside: reported per column
+    bad = c.prebin8_batch([0], [binmin[0] + 40 * width[0]], [width[0]], F, [bufs[0]])
+    assert bad[0] == np.sum(((s[:, 0] - (binmin[0] + 40 * width[0])) / width[0] + 0.5).astype(int) < 0) > 0
+    # every sample in one bin: the 16-bit counter wraps and the call says so
+    t = np.zeros((70_000, 2))
+    c.upload(np.asfortranarray(t), None)
+    b2 = [c.alloc(70_000 + 64) for _ in range(2)]
+    assert np.all(c.prebin8_batch([0, 1], [-1.0, -1.0], [2.0 / 255, 2.0 / 255], F, b2) == 0)
+    with pytest.raises(GdhipError) as err:
+        c.hist2d_prebinned8([b2[0]], [b2[1]])
+    assert err.value.code == -5
+    c.close()
+
+
+def test_fused_fp64_binning_packed_counters_match_the_32_bit_kernel(monkeypatch):
+    """Unit weights: gd_hist2d / gd_hist2d_sheared take the packed-16-bit, chunk-reduced kernel; with GDHIP_NO_P16 the
+    32-bit stripe kernel.  Same histograms bit for bit, also when a counter wraps (redo) and for F > 256 (two stripes)."""
+    from getdist_amd._lib import Context
+
+    N = 400_003
+    r = np.random.default_rng(8)
+    x = r.standard_normal(N)
+    y = 0.8 * x + 0.6 * r.standard_normal(N)
+    z = np.zeros(N)  # all in one bin: wraps
+    c = Context(0)
+    c.upload(np.asfortranarray(np.column_stack([x, y, z])), None)
+    for F in (256, 384, 64):
+        args = ([0, 0, 2], [1, 2, 2], [-6.0] * 3, [12.0 / (F - 1)] * 3, [-6.0] * 3, [12.0 / (F - 1)] * 3, F)
+        sh = ([0, 1], [1, 0], [1.0, -0.3], [-0.5, 0.7], [-6.0, -6.0], [12.0 / (F - 1)] * 2, [-8.0, -8.0], [16.0 / (F - 1)] * 2, F)
+        monkeypatch.delenv("GDHIP_NO_P16", raising=False)
+        a0 = c.hist2d(*args).to_host((3, F, F))
+        a1 = c.hist2d_sheared(*sh).to_host((2, F, F))
+        monkeypatch.setenv("GDHIP_NO_P16", "1")
+        b0 = c.hist2d(*args).to_host((3, F, F))
+        b1 = c.hist2d_sheared(*sh).to_host((2, F, F))
+        assert np.array_equal(a0, b0) and np.array_equal(a1, b1), F
+        assert a0[2].max() == N and a0.sum() == 3 * N
+        ixs = ((x + 6.0) / (12.0 / (F - 1)) + 0.5).astype(int)
+        iys = ((y + 6.0) / (12.0 / (F - 1)) + 0.5).astype(int)
+        assert np.array_equal(a0[0], np.bincount(ixs + iys * F, minlength=F * F).reshape(F, F))
+    c.close()
