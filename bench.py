@@ -90,10 +90,17 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     from getdist_amd import parallel
 
     t_step0 = time.perf_counter()
-    mc.updateBaseStatistics()  # means, variances, covariance, weight statistics; clears every per-parameter cache
-    reset_caches(mc)
     if emulate:
         world = emulate
+    if world > 1:
+        # rows split over the ranks for the base statistics; the shares are pooled by one small all-gather
+        if emulate:
+            mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: [mine] + _REPLAY["moments"][world][1:])
+        else:
+            mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: parallel.allgather_vector(mine, dist, torch_device))
+    else:
+        mc.updateBaseStatistics()  # means, variances, covariance, weight statistics; clears every per-parameter cache
+    reset_caches(mc)
     my_params = parallel.partition_round_robin(list(range(mc.n)), world, rank)
     # single rank: N_eff is left to get2DDensities, which overlaps it with the 2D binning on a second stream; with
     # several ranks it must be known before the parameter state is exchanged
@@ -428,6 +435,9 @@ def main():
 
         mc.prepareParams()
         _REPLAY["rows"] = parallel.pack_param_state(mc, list(range(mc.n)))
+        W = args.emulate_world
+        per = (mc.numrows + W - 1) // W
+        _REPLAY["moments"] = {W: [mc._partial_moments(min(r * per, mc.numrows), min((r + 1) * per, mc.numrows)) for r in range(W)]}
     dens = None
     for _ in range(args.warmup):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)  # held like the timed results

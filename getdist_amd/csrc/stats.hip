@@ -282,7 +282,7 @@ __global__ void k_cov_fin(const double* __restrict__ part, int nchunks, const in
 //   stride KS + 2 = 34 doubles is 4 dwords modulo 64 (MI355X_MICROARCH.md, ds_read_b64 lane groups).
 // Templates: MCAP = column capacity (multiple of 16), NW waves per block, MAXP tile pairs per wave, KS rows per slab.
 template <bool HAS_W, int MCAP, int NW, int MAXP, int KS>
-__global__ void __launch_bounds__(NW * 64) k_cov_slab(const double* __restrict__ cols, int64_t ld,
+__global__ void __launch_bounds__(NW * 64, (MCAP == 112 ? 4 : 1)) k_cov_slab(const double* __restrict__ cols, int64_t ld,
                                                       const int32_t* __restrict__ colidx, int m,
                                                       const double* __restrict__ res, const double* __restrict__ w,
                                                       int64_t lo, int64_t hi, int64_t rows_per_chunk,
@@ -913,7 +913,9 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
         constexpr int KS = 32;
         const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2;
-        int nblk = 2 * ctx->cu_count;
+        // enough resident blocks per CU that the next slab's loads (HBM latency ~2 us) hide behind other blocks' MFMAs:
+        // the 64-column variant fits four blocks per CU, the 112-column one two, the 208-column one one (8 waves)
+        int nblk = (m <= 64 ? 4 : 2) * ctx->cu_count;
         if (nblk > (rows + 4 * KS - 1) / (4 * KS)) nblk = (int)((rows + 4 * KS - 1) / (4 * KS));
         if (nblk < 1) nblk = 1;
         int64_t rows_per_chunk = (rows + nblk - 1) / nblk;
@@ -945,7 +947,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         if (m <= 64) {
             if (hw) GD_COV_LAUNCH(true, 64, 4, 3); else GD_COV_LAUNCH(false, 64, 4, 3);
         } else if (m <= 112) {
-            if (hw) GD_COV_LAUNCH(true, 112, 4, 7); else GD_COV_LAUNCH(false, 112, 4, 7);
+            if (hw) GD_COV_LAUNCH(true, 112, 8, 4); else GD_COV_LAUNCH(false, 112, 8, 4);
         } else {
             if (hw) GD_COV_LAUNCH(true, 208, 8, 12); else GD_COV_LAUNCH(false, 208, 8, 12);
         }

@@ -933,8 +933,59 @@ class MCSamples:
                 self.ranges.setRange(nm, rng)
         self.needs_update = True
 
-    def updateBaseStatistics(self):
-        """chains.py:1340-1352 + mcsamples.py:552-576, with the column scans on the GPU."""
+    def _partial_moments(self, lo, hi):
+        """One packed vector of the base statistics of rows [lo, hi): [norm, max_w, sum_w2, min(n), max(n), mean(n),
+        cov(n x n)] -- what a rank contributes when the rows are split over ranks (three launches over its share)."""
+        ws = self.ctx.weight_stats(lo, hi)
+        means, cov, norm = self.ctx.cov(list(range(self.n)), lo=lo, hi=hi)
+        mm = self.ctx.col_minmax(list(range(self.n)), lo=lo, hi=hi)
+        nrm = norm if self.weights is not None else float(hi - lo)
+        return np.concatenate([[nrm, ws["max_w"], ws["sum_w2"]], mm[:, 0], mm[:, 1], means, cov.reshape(-1)])
+
+    def _combine_moments(self, parts):
+        """Pool per-share moments: means by weight, covariance as the weighted mean of the shares' covariances plus the
+        spread of their means (the identity behind chains.py:1456-1466), minima / maxima / sums directly."""
+        n = self.n
+        parts = np.asarray(parts, dtype=np.float64)
+        norms = parts[:, 0]
+        norm = float(np.sum(norms))
+        means = norms @ parts[:, 3 + 2 * n:3 + 3 * n] / norm
+        cov = np.zeros((n, n))
+        for p in parts:
+            d = p[3 + 2 * n:3 + 3 * n] - means
+            cov += p[0] * (p[3 + 3 * n:].reshape(n, n) + np.outer(d, d))
+        cov /= norm
+        return dict(norm=norm, max_w=float(np.max(parts[:, 1])), sum_w2=float(np.sum(parts[:, 2])),
+                    col_min=np.min(parts[:, 3:3 + n], axis=0), col_max=np.max(parts[:, 3 + n:3 + 2 * n], axis=0),
+                    means=means, cov=cov)
+
+    def updateBaseStatistics(self, row_share=None, exchange=None):
+        """
+        chains.py:1340-1352 + mcsamples.py:552-576, with the column scans on the GPU.
+
+        Multi-GPU (samples replicated): ``row_share=(rank, world)`` makes this process reduce only its
+        contiguous share of the rows; ``exchange(vector) -> (world, len)`` (an all-gather of n^2 + 3n + 3 doubles over
+        RCCL) pools the shares, so the O(N n^2) covariance pass costs 1/world per rank instead of being repeated.
+        """
+        if row_share is not None:
+            rank, world = row_share
+            per = (self.numrows + world - 1) // world
+            lo, hi = min(rank * per, self.numrows), min((rank + 1) * per, self.numrows)
+            mine = self._partial_moments(lo, hi) if hi > lo else None
+            parts = exchange(mine)
+            pooled = self._combine_moments([p for p in parts if p is not None and p[0] > 0])
+            self.norm = np.float64(pooled["norm"]) if self.weights is not None else np.float64(self.numrows)
+            self._col_min, self._col_max = pooled["col_min"], pooled["col_max"]
+            self.means = pooled["means"]
+            self.fullcov = pooled["cov"]
+            self.vars = np.diag(self.fullcov).copy()
+            self.sddev = np.sqrt(self.vars)
+            self.mean_mult = self.norm / self.numrows
+            self.max_mult = pooled["max_w"]
+            self._sum_w2 = pooled["sum_w2"]
+            self.correlationMatrix = None
+            self._after_base_statistics()
+            return self
         ws = self.ctx.weight_stats()
         if self.weights is not None:
             self.norm = ws["norm"]
@@ -956,6 +1007,10 @@ class MCSamples:
         self.fullcov = None
         self.correlationMatrix = None
         self._setCov()
+        self._after_base_statistics()
+        return self
+
+    def _after_base_statistics(self):
         self.density1D = {}
         self._initLimits()
         for par in self.paramNames.names:
@@ -963,7 +1018,6 @@ class MCSamples:
             par._ranges_done = False
         self._nd_limits_done = False
         self.needs_update = False
-        return self
 
     def _initLimits(self):
         """mcsamples.py:442-470"""

@@ -76,6 +76,20 @@ def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
     unpack_param_state(mc, rows[rows[:, 0] >= 0])
 
 
+def allgather_vector(vec, dist=None, device=None):
+    """All-gather one equal-length fp64 vector per rank -> list of numpy vectors (None stays None on every rank)."""
+    if dist is None or dist.get_world_size() == 1:
+        return [vec]
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, t)
+    return [g.cpu().numpy() for g in gathered]
+
+
 # ---- convergence config (SURVEY.md 8e, C4): one chain per GPU ---------------------------------------------------
 def gelman_rubin_from_chain_stats(stats, total_means):
     """

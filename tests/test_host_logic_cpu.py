@@ -366,13 +366,19 @@ def test_two_rank_step_equals_single_process(tmp_path):
     pairs = synth.triangle_pairs(10)
     ref = bench.one_step(mc, pairs, None, 0, 1, None)
     seen = []
+    tight = 0
     for rank in range(2):
         z = np.load(tmp_path / ("rank%d.npz" % rank))
-        assert np.allclose(z["neff"], [p.N_eff_kde for p in mc.paramNames.names], rtol=1e-12)  # all-gathered state
+        assert np.allclose(z["neff"], [p.N_eff_kde for p in mc.paramNames.names], rtol=1e-9)  # all-gathered state
         for i, P in zip(z["idx"], z["P"]):
             seen.append(int(i))
-            assert np.array_equal(P, ref[int(i)].P), pairs[int(i)]  # same inputs, same solver path => identical
+            # the base statistics are pooled from the two ranks' row shares, so means / edges agree with the one-process
+            # run to rounding, not bit for bit; pairs whose bandwidth goes through TNC may amplify that
+            err = float(np.max(np.abs(P - ref[int(i)].P)))
+            assert err < 2e-3, (pairs[int(i)], err)
+            tight += err < 1e-8
     assert sorted(seen) == list(range(len(pairs)))
+    assert tight >= 0.8 * len(pairs)
 
 
 def test_chain_file_loader(tmp_path, zoo):
@@ -561,3 +567,27 @@ def test_marge_stats_host_logic_against_goldens(zoo):
         before = [(lim.lower, lim.upper, lim.limitTag()) for lim in par.limits]
         mc._setMargeLimits(par, mc.initParamConfidenceData(0))
         assert before == [(lim.lower, lim.upper, lim.limitTag()) for lim in par.limits]
+
+
+def test_row_partitioned_base_statistics_pool_to_the_single_process_values():
+    """updateBaseStatistics(row_share=...): per-rank moments of a row share pooled by an all-gather equal the one-process
+    statistics (weighted and unit weights, uneven shares, a rank with no rows)."""
+    from getdist_amd import synth
+    from getdist_amd.mcsamples import MCSamples
+
+    for weighted in (True, False):
+        s, w, names, ranges = synth.block_recipe(10, 10_007, weighted=weighted, stream=51)
+        ref = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=FakeContext)
+        for world in (2, 3, 8):
+            mcs = [MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=FakeContext) for _ in range(world)]
+            per = (ref.numrows + world - 1) // world
+            shares = [m._partial_moments(min(r * per, ref.numrows), min((r + 1) * per, ref.numrows)) for r, m in enumerate(mcs)]
+            for r, m in enumerate(mcs):
+                m.updateBaseStatistics(row_share=(r, world), exchange=lambda mine: shares)
+                assert np.allclose(m.means, ref.means, rtol=1e-12, atol=1e-14)
+                assert np.allclose(m.fullcov, ref.fullcov, rtol=1e-10, atol=1e-13)
+                assert np.allclose(m.vars, ref.vars, rtol=1e-10) and np.isclose(m.norm, ref.norm, rtol=1e-13)
+                assert np.array_equal(m._col_min, ref._col_min) and np.array_equal(m._col_max, ref._col_max)
+                assert np.isclose(m._sum_w2, ref._sum_w2, rtol=1e-13) and m.max_mult == ref.max_mult
+                d = m.get1DDensity(names[3])
+                assert np.max(np.abs(d.P - ref.get1DDensity(names[3]).P)) < 1e-9
