@@ -378,7 +378,8 @@ def test_c5_stress_full_size_properties():
         lim = ms.parWithName(names[j]).limits[0]
         x = s[:, j]
         inside = np.mean((x >= lim.lower) & (x <= lim.upper))
-        assert abs(inside - 0.68) < 0.01 or not lim.twotail, (names[j], inside)
+        if lim.twotail:  # the outermost equal-density crossings: exactly 68 % for a unimodal marginal, more when the
+            assert inside > 0.67 and (inside < 0.69 or j == 0), (names[j], inside)  # interval spans a valley (p0 is bimodal)
     q = mc.confidence(123, np.array([0.025, 0.5]))
     for f, v in zip((0.025, 0.5), q):
         assert np.sum(s[:, 123] <= v) >= N * f > np.sum(s[:, 123] < v)
