@@ -70,7 +70,7 @@ SIGNATURES = {
     "gd_column_ptr": (C.c_int, [_p, _i64, C.POINTER(_p)]),
     "gd_weight_stats": (C.c_int, [_p, _i64, _i64, _f64, _pd]),
     "gd_col_stats": (C.c_int, [_p, _i64, _i64, _pd]),
-    "gd_cov": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _pd, _pd]),
+    "gd_cov": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _pd, _pd, _pd]),
     "gd_quantiles": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd]),
     "gd_autocov_lags": (C.c_int, [_p, _i32, _f64, _i64, _i32, _pd]),
     "gd_kde_lag_sums": (C.c_int, [_p, _i32, _f64, _pi64, _i32, _pd]),
@@ -402,13 +402,15 @@ class Context:
         self._check(self.lib.gd_col_stats(self.h, lo, self.N if hi is None else hi, _dp(out)))
         return out
 
-    def cov(self, cols=None, lo=0, hi=None):
+    def cov(self, cols=None, lo=0, hi=None, minmax=False):
+        """(means, cov, norm) of the columns over rows [lo, hi); with ``minmax`` also the (m, 2) column extrema."""
         cols = _i32arr(np.arange(self.n) if cols is None else cols)
         m = len(cols)
         means, cov, norm = np.zeros(m), np.zeros((m, m)), C.c_double()
+        mm = np.zeros((m, 2)) if minmax else None
         self._check(self.lib.gd_cov(self.h, _ip(cols), m, lo, self.N if hi is None else hi, _dp(means), _dp(cov),
-                                    C.byref(norm)))
-        return means, cov, norm.value
+                                    C.byref(norm), None if mm is None else _dp(mm)))
+        return (means, cov, norm.value, mm) if minmax else (means, cov, norm.value)
 
     def quantiles(self, cols, targets, lo=0, hi=None):
         cols = _i32arr(cols)

@@ -213,13 +213,23 @@ __global__ void k_crop(const D2Pair* __restrict__ pairs, const double* __restric
         d[e] = fr[(int64_t)(e / F + w) * S + (e % F + w)];
 }
 
+// per-grid maximum in PM_PARTS partial maxima (grid (PM_PARTS, B): one block per grid left most of the chip idle for the
+// 20-odd max reductions of a triangle step); consumers fold the parts with pair_max()
+#define PM_PARTS 8
 __global__ void k_pair_max(const double* __restrict__ a, int FF, double* __restrict__ mx) {
     __shared__ double red[16];
-    const double* p = a + (int64_t)blockIdx.x * FF;
+    const double* p = a + (int64_t)blockIdx.y * FF;
+    const int per = (FF + PM_PARTS - 1) / PM_PARTS, lo = blockIdx.x * per, hi = min(FF, lo + per);
     double m = -INFINITY;
-    for (int i = threadIdx.x; i < FF; i += blockDim.x) m = fmax(m, p[i]);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) m = fmax(m, p[i]);
     m = block_max(m, red);
-    if (threadIdx.x == 0) mx[blockIdx.x] = m;
+    if (threadIdx.x == 0) mx[(int64_t)blockIdx.y * PM_PARTS + blockIdx.x] = m;
+}
+__device__ __forceinline__ double pair_max(const double* __restrict__ mx, int b) {
+    double m = mx[(int64_t)b * PM_PARTS];
+#pragma unroll
+    for (int k = 1; k < PM_PARTS; ++k) m = fmax(m, mx[(int64_t)b * PM_PARTS + k]);
+    return m;
 }
 
 struct BcArrays {
@@ -230,7 +240,7 @@ struct BcArrays {
 __global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF, int bco) {
     const int b = blockIdx.y;
     if ((pairs[b].flags & 64) == 0) return;
-    const double thresh = mx[b] * 1e-8;
+    const double thresh = pair_max(mx, b) * 1e-8;
     const int64_t o = (int64_t)b * FF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
         const double P = A.P[o + i], a00 = A.a00[o + i];
@@ -255,7 +265,7 @@ __global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const d
 __global__ void k_fill_box(const D2Pair* __restrict__ pairs, const double* __restrict__ hist, const double* __restrict__ P,
                            const double* __restrict__ mx, int F, int S, double* __restrict__ frames) {
     const int w = pairs[blockIdx.y].w;
-    const double thresh = mx[blockIdx.y] * 1e-8;
+    const double thresh = pair_max(mx, blockIdx.y) * 1e-8;
     const int64_t o = (int64_t)blockIdx.y * F * F;
     double* fr = frames + (int64_t)blockIdx.y * S * S;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
@@ -277,7 +287,7 @@ __global__ void k_mbc_update(double* __restrict__ P, const double* __restrict__ 
 }
 
 __global__ void k_normalise(double* __restrict__ P, const double* __restrict__ mx, int FF, int* __restrict__ status) {
-    const double m = mx[blockIdx.y];
+    const double m = pair_max(mx, blockIdx.y);
     if (blockIdx.x == 0 && threadIdx.x == 0) status[blockIdx.y] = (m == 0.0) ? GD_ERR_EMPTY : GD_OK;
     double* p = P + (int64_t)blockIdx.y * FF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x)
@@ -351,7 +361,7 @@ __global__ void k_likes_mul(const double* __restrict__ L2, int64_t n, double* __
 }
 // L = L / P0 where P0 > 1e-4 max(P0), else 0.  grid (blocks, B)
 __global__ void k_likes_ratio(const double* __restrict__ P0, const double* __restrict__ mx, int FF, double* __restrict__ L) {
-    const double thresh = 1e-4 * mx[blockIdx.y];
+    const double thresh = 1e-4 * pair_max(mx, blockIdx.y);
     const int64_t o = (int64_t)blockIdx.y * FF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x)
         L[o + i] = (P0[o + i] > thresh) ? L[o + i] / P0[o + i] : 0.0;
@@ -479,7 +489,7 @@ __global__ void k_expand_circ(const double* __restrict__ frames, int F, int Ny, 
 // box = hist / bins2D where bins2D > max*1e-8 else hist, as a plain F x F array
 __global__ void k_box(const double* __restrict__ hist, const double* __restrict__ P, const double* __restrict__ mx, int FF,
                       double* __restrict__ box) {
-    const double thresh = mx[blockIdx.y] * 1e-8;
+    const double thresh = pair_max(mx, blockIdx.y) * 1e-8;
     const int64_t o = (int64_t)blockIdx.y * FF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
         const double h = hist[o + i], p = P[o + i];
@@ -523,7 +533,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         return o;
     };
     const bool need_S = do_bc || do_mbc;
-    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_RC = take(B * NN * 8), o_ROc = take(B * NN * 8),
                   o_ZHc = take(B * NC * 16), o_ZWc = take(B * NC * 16), o_ZKc = take(B * NC * 16),
                   o_ZPc = take(B * NC * 16), o_RF = take(need_S ? B * SS * 8 : 0), o_RO = take(need_S ? B * SS * 8 : 0),
@@ -583,7 +593,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         A.P = d_P;
         A.a00 = arr;
         A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
-        k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+        k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
         GD_KERNEL_CHECK();
         k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
         GD_KERNEL_CHECK();
@@ -620,7 +630,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
         if ((rc = mask_conv(ZM, ZW, d_a00m))) return rc;
         for (int round = 0; round < mbc; ++round) {
-            k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+            k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
             GD_KERNEL_CHECK();
             k_box<<<gF, 256, 0, ctx->stream>>>(d_hist, d_P, d_mx, (int)FF, d_box);
             GD_KERNEL_CHECK();
@@ -632,7 +642,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
             GD_KERNEL_CHECK();
         }
     }
-    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+    k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
     GD_KERNEL_CHECK();
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
     GD_KERNEL_CHECK();
@@ -689,7 +699,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_RF = take(B * SS * 8), o_RO = take(B * SS * 8),
                   o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16),
                   o_ZK = take(do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(B * SC * 16),
@@ -781,7 +791,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         }
     }
     if (do_bc) {
-        k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+        k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
         GD_KERNEL_CHECK();
         if (bco == 1) {
             // x*P and y*P still need the histogram: conv(histbins, Win*x), conv(histbins, Win*y)  (mcsamples.py:1940-1941)
@@ -799,7 +809,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
     if (mbc > 0) {
         for (int round = 0; round < mbc; ++round) {
-            k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+            k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
             GD_KERNEL_CHECK();
             k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, d_mx, F, S, RF);
             GD_KERNEL_CHECK();
@@ -816,7 +826,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         k_zero_masked<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, ov->d_zero, B * FF);
         GD_KERNEL_CHECK();
     }
-    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
+    k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
     GD_KERNEL_CHECK();
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
     GD_KERNEL_CHECK();
@@ -895,7 +905,7 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8),
+    const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_C1 = take(per ? B * NN * 8 : 0), o_C2 = take(per ? B * NN * 8 : 0),
                   o_P0 = take(B * FF * 8), o_T = take(B * FF * 8), o_L2 = take(B * FF * 8);
     char* base = (char*)gd_scratch(ctx, off);
@@ -933,11 +943,11 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
         k_likes_mul<<<2048, 256, 0, ctx->stream>>>(d_L2, B * FF, d_L);
         GD_KERNEL_CHECK();
     }
-    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_P0, (int)FF, d_mx);
+    k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P0, (int)FF, d_mx);
     GD_KERNEL_CHECK();
     k_likes_ratio<<<gF, 256, 0, ctx->stream>>>(d_P0, d_mx, (int)FF, d_L);  // :1899-1901
     GD_KERNEL_CHECK();
-    k_pair_max<<<B, 1024, 0, ctx->stream>>>(d_L, (int)FF, d_mx);
+    k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_L, (int)FF, d_mx);
     GD_KERNEL_CHECK();
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_L, d_mx, (int)FF, d_status);  // bin2Dlikes /= max (:2005)
     GD_KERNEL_CHECK();

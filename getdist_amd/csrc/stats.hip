@@ -896,7 +896,7 @@ int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, i
 }
 
 int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, double* means_out, double* cov_out,
-           double* norm_out) {
+           double* norm_out, double* minmax_out) {
     GD_REQUIRE(ctx && cols && means_out && cov_out && norm_out && m > 0, "bad argument");
     GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
     for (int i = 0; i < m; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
@@ -1001,6 +1001,8 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     GD_HIP(hipMemcpyAsync(cov_out, d_cov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->stream));
     GD_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < m; ++i) means_out[i] = hres[(size_t)i * 4 + 3];
+    if (minmax_out)
+        for (int i = 0; i < m; ++i) minmax_out[2 * i] = hres[(size_t)i * 4], minmax_out[2 * i + 1] = hres[(size_t)i * 4 + 1];
     *norm_out = hres[2];
     return GD_OK;
 }

@@ -937,8 +937,7 @@ class MCSamples:
         """One packed vector of the base statistics of rows [lo, hi): [norm, max_w, sum_w2, min(n), max(n), mean(n),
         cov(n x n)] -- what a rank contributes when the rows are split over ranks (three launches over its share)."""
         ws = self.ctx.weight_stats(lo, hi)
-        means, cov, norm = self.ctx.cov(list(range(self.n)), lo=lo, hi=hi)
-        mm = self.ctx.col_minmax(list(range(self.n)), lo=lo, hi=hi)
+        means, cov, norm, mm = self.ctx.cov(list(range(self.n)), lo=lo, hi=hi, minmax=True)
         nrm = norm if self.weights is not None else float(hi - lo)
         return np.concatenate([[nrm, ws["max_w"], ws["sum_w2"]], mm[:, 0], mm[:, 1], means, cov.reshape(-1)])
 
@@ -991,10 +990,12 @@ class MCSamples:
             self.norm = ws["norm"]
         else:
             self.norm = np.float64(self.numrows)  # chains.py:315
-        st = self.ctx.col_stats()
-        self._col_min, self._col_max = st[:, 0].copy(), st[:, 1].copy()
-        self.means = st[:, 2].copy()
-        self.vars = st[:, 3].copy()
+        # one statistics pass (min, max, weighted mean) + one covariance pass; the variances are its diagonal
+        # (chains.py:409-410 and :729 are the same sum)
+        means, cov, _, mm = self.ctx.cov(list(range(self.n)), minmax=True)
+        self._col_min, self._col_max = mm[:, 0].copy(), mm[:, 1].copy()
+        self.means = means
+        self.vars = np.diag(cov).copy()
         self.sddev = np.sqrt(self.vars)
         self.mean_mult = self.norm / self.numrows
         self.max_mult = ws["max_w"]
@@ -1004,9 +1005,8 @@ class MCSamples:
             outliers = self.ctx.weight_stats(thresh=mult_max)["n_above"]
             if outliers != 0:
                 logging.warning("outlier fraction %s ", float(outliers) / self.numrows)
-        self.fullcov = None
+        self.fullcov = cov
         self.correlationMatrix = None
-        self._setCov()
         self._after_base_statistics()
         return self
 
@@ -1298,6 +1298,23 @@ class MCSamples:
                 N = corr0 + 2 * c1
         return self.norm**2 / N
 
+    def _probe_lags(self, todo, nl):
+        """The first ``nl`` autocovariance lag sums of columns ``todo``: taken from the prefetch started by
+        prepareParams on the second context (they need the means only, so they ran beside the quantile select), else
+        computed now."""
+        pre = getattr(self, "_lag_prefetch", None)
+        self._lag_prefetch = None
+        if pre is not None:
+            cols, pnl, fut = pre
+            try:
+                lags = fut.result()
+            except Exception:
+                lags = None
+            if lags is not None and pnl == nl and set(todo) <= set(cols):
+                row = {c: k for k, c in enumerate(cols)}
+                return lags[[row[c] for c in todo]]
+        return self.ctx.autocov_lags_batch(todo, self.means[todo], 0, nl)
+
     def _neff_batch(self, js, min_corr=0.05):
         """_get1DNeff for many parameters with two batched launches (32 autocovariance lags, 7 kernel lag sums)."""
         todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
@@ -1309,7 +1326,7 @@ class MCSamples:
             return
         max_off = self.numrows // 10
         nl = min(8, max_off + 1)  # short probe first; correlated chains continue in getCorrelationLength
-        lag0 = self.ctx.autocov_lags_batch(todo, self.means[todo], 0, nl)
+        lag0 = self._probe_lags(todo, nl)
         kstd, maxoffs = [], []
         for row, j in enumerate(todo):
             par = self.paramNames.names[j]
@@ -1456,6 +1473,16 @@ class MCSamples:
         if self.needs_update:
             self.updateBaseStatistics()
         js = list(range(self.n)) if params is None else [self._col(p) for p in params]
+        todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
+        if (todo and self._lane == 0 and not self._timing and self.sampler not in ("nested", "uncorrelated")
+                and len(todo) >= 8 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
+            # the autocovariance probe of the N_eff estimate depends on the means only: start it on the second context
+            # (own stream) while this one runs the quantile select
+            twin = self._second_lane()
+            self._nlanes = 1
+            nl = min(8, self.numrows // 10 + 1)
+            self._lag_prefetch = (todo, nl, self._lane_thread(twin).submit(
+                twin.ctx.autocov_lags_batch, todo, self.means[todo], 0, nl))
         with _Phase(self, "prep.ranges"):
             self._init_params(js)
         if neff:

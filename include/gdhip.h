@@ -81,11 +81,13 @@ int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out);
  * gd_col_stats: per column over rows [row_lo,row_hi): min, max (mcsamples.py:1434-1435), weighted mean
  *   (chains.py:379), weighted variance about that mean (chains.py:409-410). out = n x 4 {min,max,mean,var}
  * gd_cov: two-pass weighted covariance of the listed columns over rows [row_lo,row_hi)
- *   (chains.py:709-733 + mean_diffs :763-780); means_out m, cov_out m x m, norm_out 1. */
+ *   (chains.py:709-733 + mean_diffs :763-780); means_out m, cov_out m x m, norm_out 1; minmax_out (may be NULL)
+ *   m x 2 = the columns' min / max over the range, which the first pass sees anyway -- updateBaseStatistics then needs
+ *   no separate gd_col_stats call (the variances are the diagonal). */
 int gd_weight_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double thresh, double* out4);
 int gd_col_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double* out);
 int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t row_lo, int64_t row_hi, double* means_out,
-           double* cov_out, double* norm_out);
+           double* cov_out, double* norm_out, double* minmax_out);
 
 /* ---------------------------------------------------------------- weighted quantiles -----------
  * Replaces initParamConfidenceData + confidence (chains.py:793-838: argsort, cumsum(w[idx]),

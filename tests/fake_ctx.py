@@ -306,14 +306,15 @@ class FakeContext:
         var = np.array([w.dot((s[:, i] - means[i]) ** 2) / norm for i in range(self.n)])
         return np.column_stack([s.min(axis=0), s.max(axis=0), means, var])
 
-    def cov(self, cols=None, lo=0, hi=None):
+    def cov(self, cols=None, lo=0, hi=None, minmax=False):
         hi = self.N if hi is None else hi
         cols = list(range(self.n)) if cols is None else list(cols)
         s, w = self.s[lo:hi][:, cols], self._w(lo, hi)
         norm = np.sum(w)
         means = w.dot(s) / norm
         d = s - means
-        return means, (d * w[:, None]).T @ d / norm, float(norm)
+        out = (means, (d * w[:, None]).T @ d / norm, float(norm))
+        return out + (np.column_stack([s.min(axis=0), s.max(axis=0)]),) if minmax else out
 
     def quantiles(self, cols, targets, lo=0, hi=None):
         hi = self.N if hi is None else hi
