@@ -11,6 +11,9 @@
 
 #define KT 1024
 #define MAXF 6  // forms per level
+#ifndef KOPT_U
+#define KOPT_U 8  // rows requested ahead in the bilinear forms
+#endif
 #define KOPT_STRIDE 12  // doubles per pair in the optimiser's result row (see k_get_h)
 #define PI 3.141592653589793238462643383279502884
 #define PISQ (PI * PI)
@@ -162,27 +165,45 @@ struct KoptLds {
 // Only rows / columns below kmax are visited: beyond it every weight is < 1e-30 of its form's maximum (see
 // weight_cutoff), which cannot change the fp64 result.
 __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
-    const int jx = threadIdx.x & 255, g = threadIdx.x >> 8;  // 4 row groups x 256 columns
-    const int rows_per = (kmax + 3) / 4;
+    // 8 row groups x 128 column pairs; the matrix comes from L2 / MALL with ~1 us latency, so what matters is the number
+    // of independent loads in flight: 8 rows (16-B loads) are requested before the first is consumed.
+    constexpr int U = KOPT_U;
+    const int jx = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int rows_per = (kmax + 7) / 8;
     const int r_lo = g * rows_per, r_hi = min(kmax, r_lo + rows_per);
     double val[MAXF];
 #pragma unroll
     for (int q = 0; q < MAXF; ++q) val[q] = 0;
     for (int j0 = 0; j0 < kmax; j0 += 256) {
-        const int j = j0 + jx;
+        const int j = j0 + 2 * jx;  // F is even and rows are 16-B aligned
         if (j < kmax) {
-            double acc[MAXF];
+            double ax[MAXF], ay[MAXF];
 #pragma unroll
-            for (int q = 0; q < MAXF; ++q) acc[q] = 0;
-            for (int i = r_lo; i < r_hi; ++i) {
-                const double a = M[(int64_t)i * F + j];
+            for (int q = 0; q < MAXF; ++q) ax[q] = ay[q] = 0;
+            for (int i = r_lo; i < r_hi; i += U) {
+                double2 a[U];
 #pragma unroll
-                for (int q = 0; q < MAXF; ++q)
-                    if (q < m) acc[q] = fma(L.wy[q * F + i], a, acc[q]);
+                for (int u = 0; u < U; ++u)
+                    a[u] = (i + u < r_hi) ? *reinterpret_cast<const double2*>(M + (int64_t)(i + u) * F + j)
+                                          : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int iu = min(i + u, r_hi - 1);  // the padded rows carry a = 0
+#pragma unroll
+                    for (int q = 0; q < MAXF; ++q)
+                        if (q < m) {
+                            const double wyq = L.wy[q * F + iu];
+                            ax[q] = fma(wyq, a[u].x, ax[q]);
+                            ay[q] = fma(wyq, a[u].y, ay[q]);
+                        }
+                }
             }
 #pragma unroll
             for (int q = 0; q < MAXF; ++q)
-                if (q < m) val[q] = fma(acc[q], L.wx[q * F + j], val[q]);
+                if (q < m) {
+                    val[q] = fma(ax[q], L.wx[q * F + j], val[q]);
+                    if (j + 1 < kmax) val[q] = fma(ay[q], L.wx[q * F + j + 1], val[q]);
+                }
         }
     }
     // all m block sums with two barriers: per-wave partials -> LDS (wx is free now) -> one thread per form adds them

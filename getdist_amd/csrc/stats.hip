@@ -682,19 +682,43 @@ __global__ void __launch_bounds__(256) k_autocov(const double* __restrict__ cols
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0;
+    static_assert(AT % 256 == 0 && NL <= 256, "tile shape");
+    constexpr int Q = AT / 256;
     for (int64_t t0 = (int64_t)blockIdx.x * AT; t0 < N; t0 += (int64_t)gridDim.x * AT) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < AT + NL; e += 256) {
-            const int64_t r = t0 + k0 + e;
-            sB[e] = (r < N) ? (x[r] - mean) * (HAS_W ? w[r] : 1.0) : 0.0;
+        // the whole tile is requested before anything is consumed: Q independent loads in flight per lane
+        double v[Q], vw[Q], hv = 0, hw = 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int64_t r = t0 + k0 + threadIdx.x + 256 * q;
+            v[q] = (r < N) ? x[r] : mean;
+            vw[q] = (HAS_W && r < N) ? w[r] : 1.0;
+        }
+        if (threadIdx.x < NL) {
+            const int64_t r = t0 + k0 + AT + threadIdx.x;
+            hv = (r < N) ? x[r] : mean;
+            hw = (HAS_W && r < N) ? w[r] : 1.0;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < AT; e += 256) {
-            const int64_t r = t0 + e;
-            if (r < N) {
-                const double a = (x[r] - mean) * (HAS_W ? w[r] : 1.0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) sB[threadIdx.x + 256 * q] = (v[q] - mean) * vw[q];
+        if (threadIdx.x < NL) sB[AT + threadIdx.x] = (hv - mean) * hw;
+        __syncthreads();
+        if (k0 == 0) {  // the leading factor is the tile itself
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int e = threadIdx.x + 256 * q;
+                const double a = sB[e];  // rows beyond N were stored as 0
 #pragma unroll
                 for (int l = 0; l < NL; ++l) acc[l] = fma(a, sB[e + l], acc[l]);
+            }
+        } else {
+            for (int e = threadIdx.x; e < AT; e += 256) {
+                const int64_t r = t0 + e;
+                if (r < N) {
+                    const double a = (x[r] - mean) * (HAS_W ? w[r] : 1.0);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) acc[l] = fma(a, sB[e + l], acc[l]);
+                }
             }
         }
     }
@@ -717,6 +741,75 @@ __global__ void k_sum_partials_batched(const double* __restrict__ part, int nblk
 }
 
 // ---- Gaussian-kernel lag sums: out[l] = sum_i exp(-(x_i - x_{i+k})^2 * c) w_i w_{i+k} -----------------------
+// exp(-t) for t >= 0 (the only argument range of these sums), ~2e-16 relative: t = (64 q + j) ln2/64 - r with
+// |r| <= ln2/128, exp(-t) = 2^-q' * T[j'] * exp(r); T = 2^(j/64) from a 64-entry LDS table, exp(r) by a degree-5
+// polynomial (next term 3.5e-17).  About half the instructions of the library exp, which these kernels are bound by.
+__device__ __forceinline__ double exp_neg(double t, const double* __restrict__ tab) {
+    const double n = __builtin_rint(t * 92.332482616893656756);  // 64 / ln 2
+    // ln2/64 split so that n * hi is exact for n < 2^17
+    double r = __builtin_fma(n, 1.0830424696223417413e-02, -t);
+    r = __builtin_fma(n, 2.5728046223276688287e-14, r);
+    double p = __builtin_fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const int m = -(int)n;  // exp(-t) = 2^(m/64) exp(r)
+    const double v = __builtin_ldexp(tab[m & 63] * p, m >> 6);
+    return t < 708.0 ? v : 0.0;  // beyond: below 1e-307, and the int conversion above would wrap for huge t
+}
+
+#define KDE_LAG_MAX 8
+// All lags of a column in one read: grid (blocks, columns); x_i stays in a register for the <= 8 lags.
+template <bool HAS_W>
+__global__ void __launch_bounds__(256) k_kde_lag_multi(const double* __restrict__ cols, int64_t ld,
+                                                       const int32_t* __restrict__ colidx, const double* __restrict__ w,
+                                                       int64_t N, const double* __restrict__ cvals,
+                                                       const int64_t* __restrict__ lags, int nl,
+                                                       double* __restrict__ part) {
+    __shared__ double red[16];
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64));
+    __syncthreads();
+    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
+    const double c = cvals[blockIdx.y];
+    int64_t k[KDE_LAG_MAX];
+#pragma unroll
+    for (int l = 0; l < KDE_LAG_MAX; ++l) k[l] = l < nl ? lags[l] : N;  // N: never in range
+    double s[KDE_LAG_MAX];
+#pragma unroll
+    for (int l = 0; l < KDE_LAG_MAX; ++l) s[l] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        // every load of the row is requested before the first exponential: with a load inside each lag's branch the
+        // loop pays eight memory latencies in sequence (measured: no faster than one lag per thread)
+        const double xi = x[i];
+        const double wi = HAS_W ? w[i] : 1.0;
+        double xk[KDE_LAG_MAX], wk[KDE_LAG_MAX];
+#pragma unroll
+        for (int l = 0; l < KDE_LAG_MAX; ++l) {
+            const int64_t r = i + k[l];
+            const int64_t rc = r < N ? r : N - 1;
+            xk[l] = x[rc];
+            wk[l] = HAS_W ? w[rc] : 1.0;
+        }
+#pragma unroll
+        for (int l = 0; l < KDE_LAG_MAX; ++l) {
+            if (l < nl) {  // uniform
+                const double d = xi - xk[l];
+                double e = exp_neg((d * d) * c, tab);
+                if (HAS_W) e = e * wi * wk[l];
+                s[l] += (i + k[l] < N) ? e : 0.0;
+            }
+        }
+    }
+    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * KDE_LAG_MAX;
+#pragma unroll
+    for (int l = 0; l < KDE_LAG_MAX; ++l) {
+        const double r = block_sum(s[l], red);
+        if (threadIdx.x == 0) p[l] = r;
+    }
+}
+
 template <bool HAS_W>
 __global__ void k_kde_lag(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
                           const double* __restrict__ w, int64_t N, const double* __restrict__ cvals,
@@ -1104,7 +1197,7 @@ int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols,
     GD_REQUIRE(row_lo >= 0 && row_hi <= ctx->N && row_lo < row_hi, "bad row range");
     const int64_t NR = row_hi - row_lo;
     for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
-    int nblk = (4 * ctx->cu_count + ncols - 1) / ncols;
+    int nblk = (8 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk < 16) nblk = 16;
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
     int64_t off = 0;
@@ -1161,7 +1254,8 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
-    int nblk = (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
+    const bool multi = nlags <= KDE_LAG_MAX && getenv("GDHIP_KDE_LAG_SINGLE") == nullptr;
+    int nblk = multi ? (8 * ctx->cu_count + ncols - 1) / ncols : (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
     if (nblk < 8) nblk = 8;
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
     int64_t off = 0;
@@ -1170,7 +1264,7 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_part = take((int64_t)ncols * nlags * nblk * 8), o_lags = take((int64_t)nlags * 8),
+    const int64_t o_part = take((int64_t)ncols * (multi ? KDE_LAG_MAX : nlags) * nblk * 8), o_lags = take((int64_t)nlags * 8),
                   o_idx = take((int64_t)ncols * 4), o_c = take((int64_t)ncols * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
@@ -1181,6 +1275,26 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_c, inv4s2, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (multi) {
+        const dim3 grid(nblk, ncols);
+        if (ctx->w)
+            k_kde_lag_multi<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c, d_lags,
+                                                                  nlags, part);
+        else
+            k_kde_lag_multi<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_c, d_lags,
+                                                                   nlags, part);
+        GD_KERNEL_CHECK();
+        std::vector<double> h((size_t)ncols * nblk * KDE_LAG_MAX);
+        GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        for (int c = 0; c < ncols; ++c)
+            for (int l = 0; l < nlags; ++l) {
+                double sum = 0;
+                for (int b = 0; b < nblk; ++b) sum += h[((size_t)c * nblk + b) * KDE_LAG_MAX + l];
+                out[(size_t)c * nlags + l] = sum;
+            }
+        return GD_OK;
+    }
     const dim3 grid(nblk, nlags, ncols);
     if (ctx->w)
         k_kde_lag<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c, d_lags, part);

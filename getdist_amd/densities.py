@@ -282,6 +282,14 @@ class Density2D(GridDensity):
         d.P = P
         return d
 
+    @classmethod
+    def _from_fields(cls, fields):
+        """Batch constructor used for whole triangles: ``fields`` becomes the instance dictionary (the caller supplies
+        every attribute _set_axes / setP would)."""
+        d = cls.__new__(cls)
+        d.__dict__ = fields
+        return d
+
     def _initSpline(self):
         from scipy.interpolate import RectBivariateSpline
 

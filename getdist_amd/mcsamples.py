@@ -223,6 +223,30 @@ def _stack_rows(parts):
     return out
 
 
+class _FastThreadSwitch:
+    """While a helper thread drives a second stream, a thread returning from a C call would wait for the GIL up to the
+    interpreter's switch interval (5 ms by default) whenever the other thread is in Python scalar code -- longer than
+    most kernels here.  100 us for the duration of a batched call; restored on exit."""
+
+    def __init__(self, active=True):
+        self.active = active
+
+    def __enter__(self):
+        if self.active:
+            import sys
+
+            self.old = sys.getswitchinterval()
+            sys.setswitchinterval(float(os.environ.get("GETDIST_AMD_SWITCH_INTERVAL", 1e-4)))
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            import sys
+
+            sys.setswitchinterval(self.old)
+        return False
+
+
 class _Phase:
     """Wall-clock phase accounting (enabled by GETDIST_AMD_TIMING=1; syncs the stream at phase edges)."""
 
@@ -1146,6 +1170,8 @@ class MCSamples:
         return self.correlationMatrix
 
     def _col(self, par):
+        if type(par) is int and 0 <= par < self.n:
+            return par
         j = self._parAndNumber(par)[0]
         if j is None:
             raise ParamError("unknown parameter %s" % par)
@@ -1483,7 +1509,7 @@ class MCSamples:
             nl = min(8, self.numrows // 10 + 1)
             self._lag_prefetch = (todo, nl, self._lane_thread(twin).submit(
                 twin.ctx.autocov_lags_batch, todo, self.means[todo], 0, nl))
-        with _Phase(self, "prep.ranges"):
+        with _Phase(self, "prep.ranges"), _FastThreadSwitch(getattr(self, "_lag_prefetch", None) is not None):
             self._init_params(js)
         if neff:
             with _Phase(self, "prep.neff"):
@@ -1747,49 +1773,73 @@ class MCSamples:
         return res[0]
 
     def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None):
-        """Branch selection per pair (mcsamples.py:1325-1409), scalars only."""
-        plan = []
+        """Branch selection per pair (mcsamples.py:1325-1409), scalars only.  The classification is evaluated on arrays
+        over the pairs (a triangle has thousands); powers stay Python-float operations so that every scalar is the one the
+        reference computes."""
+        names = self.paramNames.names
+        npairs = len(pairs)
+        if npairs == 0:
+            return []
         if N_eff is None:
             self._neff_batch(list(dict.fromkeys([j for p in pairs for j in p])))
-        for (jx, jy), corr, (rangex, rangey) in zip(pairs, corrs, ranges_xy):
-            parx, pary = self.paramNames.names[jx], self.paramNames.names[jy]
-            if N_eff is None:
-                if self.use_effective_samples_2D and abs(corr) < 0.999:
-                    neff = self.getEffectiveSamplesGaussianKDE_2d(jx, jy)  # mcsamples.py:1326-1328
-                else:
-                    neff = min(self._get1DNeff(parx, jx), self._get1DNeff(pary, jy))
+        jx = [p[0] for p in pairs]
+        jy = [p[1] for p in pairs]
+        used = sorted(set(jx) | set(jy))
+        at = np.full(max(used) + 1, -1, dtype=np.int64)
+        at[used] = np.arange(len(used))
+        ix, iy = at[jx], at[jy]
+        upar = [names[j] for j in used]
+        lim_u = np.array([bool(p.has_limits) for p in upar])
+        sig_u = np.array([np.nan if p.sigma_range is None else p.sigma_range for p in upar], dtype=np.float64)
+        corr_v = np.asarray(corrs, dtype=np.float64)
+        if N_eff is None:
+            if self.use_effective_samples_2D:
+                neff_v = np.array([self.getEffectiveSamplesGaussianKDE_2d(a, b) if abs(c) < 0.999  # mcsamples.py:1326-1328
+                                   else min(self._get1DNeff(names[a], a), self._get1DNeff(names[b], b))
+                                   for a, b, c in zip(jx, jy, corr_v.tolist())], dtype=np.float64)
             else:
-                neff = N_eff
-            has_limits = parx.has_limits or pary.has_limits
-            do_correlated = not parx.has_limits or not pary.has_limits
-            e = dict(jx=jx, jy=jy, parx=parx, pary=pary, corr=corr, neff=neff, has_limits=has_limits,
-                     rangex=rangex, rangey=rangey)
-            if min_corr < abs(corr) <= self.max_corr_2D and do_correlated:
-                e["branch"] = "A"
-                i, j = jx, jy
-                imax, imin = None, None
-                if parx.has_limits_bot:
-                    imin = parx.range_min
-                if parx.has_limits_top:
-                    imax = parx.range_max
-                if pary.has_limits:
-                    i, j = j, i
-                    if pary.has_limits_bot:
-                        imin = pary.range_min
-                    if pary.has_limits_top:
-                        imax = pary.range_max
-                cov = self.getCov(pars=[i, j])
-                S = np.linalg.cholesky(cov)
-                ichol = np.linalg.inv(S)
-                S *= ichol[0, 0]
-                r = ichol[1, :] / ichol[0, 0]
-                e.update(i=i, j=j, imin=imin, imax=imax, S=S, r=r)
-            elif abs(corr) > self.max_corr_2D or not do_correlated and corr > 0.8:
-                e["branch"] = "B"
-            else:
-                e["branch"] = "C"
-                e["fallback_t"] = (min(pary.sigma_range / rangey, parx.sigma_range / rangex) / neff ** (1.0 / 6)) ** 2
-            plan.append(e)
+                neff_u = np.array([self._get1DNeff(p, j) for p, j in zip(upar, used)], dtype=np.float64)
+                neff_v = np.minimum(neff_u[ix], neff_u[iy])
+        else:
+            neff_v = np.full(npairs, float(N_eff))
+        limx, limy = lim_u[ix], lim_u[iy]
+        has_limits = limx | limy
+        do_correlated = ~limx | ~limy
+        absc = np.abs(corr_v)
+        is_A = (min_corr < absc) & (absc <= self.max_corr_2D) & do_correlated
+        is_B = ~is_A & ((absc > self.max_corr_2D) | (~do_correlated & (corr_v > 0.8)))
+        rng = np.asarray(ranges_xy, dtype=np.float64).reshape(npairs, 2)
+        with np.errstate(all="ignore"):
+            ratio = np.minimum(sig_u[iy] / rng[:, 1], sig_u[ix] / rng[:, 0]).tolist()
+        neff_l = neff_v.tolist()
+        branch = np.where(is_A, "A", np.where(is_B, "B", "C")).tolist()
+        plan = [dict(jx=a, jy=b, parx=names[a], pary=names[b], corr=c, neff=ne, has_limits=hl, rangex=rx_, rangey=ry_,
+                     branch=br)
+                for a, b, c, ne, hl, rx_, ry_, br in zip(jx, jy, corr_v.tolist(), neff_l, has_limits.tolist(),
+                                                         rng[:, 0].tolist(), rng[:, 1].tolist(), branch)]
+        for k in np.nonzero(~is_A & ~is_B)[0].tolist():
+            plan[k]["fallback_t"] = (ratio[k] / neff_l[k] ** (1.0 / 6)) ** 2
+        for k in np.nonzero(is_A)[0].tolist():
+            e = plan[k]
+            parx, pary = e["parx"], e["pary"]
+            i, j = e["jx"], e["jy"]
+            imax, imin = None, None
+            if parx.has_limits_bot:
+                imin = parx.range_min
+            if parx.has_limits_top:
+                imax = parx.range_max
+            if pary.has_limits:
+                i, j = j, i
+                if pary.has_limits_bot:
+                    imin = pary.range_min
+                if pary.has_limits_top:
+                    imax = pary.range_max
+            cov = self.getCov(pars=[i, j])
+            S = np.linalg.cholesky(cov)
+            ichol = np.linalg.inv(S)
+            S *= ichol[0, 0]
+            r = ichol[1, :] / ichol[0, 0]
+            e.update(i=i, j=j, imin=imin, imax=imax, S=S, r=r)
         return plan
 
     def _fallback_widths(self, e, ex):
@@ -1802,7 +1852,37 @@ class MCSamples:
         _hy = pary.sigma_range / neff ** (1.0 / 6)
         return _hx, _hy, max(min(corr, self.max_corr_2D), -self.max_corr_2D)
 
-    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order):
+    def _shear_histograms(self, plan, base_F):
+        """Branch A of getAutoBandwidth2D (mcsamples.py:1347-1378): min/max of the sheared coordinate and the re-binned
+        base_F x base_F histograms of every sheared pair, two batched launches.  Independent of the pairs' own histograms,
+        so the caller may run it while those are still being made on the second stream.  None if there is no such pair."""
+        A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
+        if not A:
+            return None
+        ctx = self.ctx
+        mm = ctx.minmax_affine([plan[k]["i"] for k in A], [plan[k]["j"] for k in A], [plan[k]["r"][0] for k in A],
+                               [plan[k]["r"][1] for k in A])
+        xmin, dx, ymin, dy, r1s, r2s = [], [], [], [], [], []
+        for row, k in enumerate(A):
+            e = plan[k]
+            # kde.bin_samples(p1, nbins, range_min=imin, range_max=imax) (kde_bandwidth.py:76-87)
+            mn, mx = self._col_min[e["i"]], self._col_max[e["i"]]
+            delta = mx - mn
+            rmin = e["imin"] if e["imin"] is not None else mn - delta * 0.1
+            rmax = e["imax"] if e["imax"] is not None else mx + delta * 0.1
+            R1 = rmax - rmin
+            mn2, mx2 = mm[row]
+            delta2 = mx2 - mn2
+            rmin2 = mn2 - delta2 * 0.1
+            R2 = (mx2 + delta2 * 0.1) - rmin2
+            xmin.append(rmin), dx.append(R1 / (base_F - 1)), ymin.append(rmin2), dy.append(R2 / (base_F - 1))
+            r1s.append(R1), r2s.append(R2)
+        d_rot = ctx.hist2d_sheared([plan[k]["i"] for k in A], [plan[k]["j"] for k in A],
+                                   [plan[k]["r"][0] for k in A], [plan[k]["r"][1] for k in A], xmin, dx, ymin, dy,
+                                   base_F)
+        return dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
+
+    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order, shear=None):
         """
         getAutoBandwidth2D for a batch (mcsamples.py:1325-1419).  ``hists_by_F``: F -> (device buffer of that class's
         histograms, list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.  Returns the
@@ -1832,29 +1912,8 @@ class MCSamples:
 
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
-        shear = None
-        if A:
-            mm = ctx.minmax_affine([plan[k]["i"] for k in A], [plan[k]["j"] for k in A], [plan[k]["r"][0] for k in A],
-                                   [plan[k]["r"][1] for k in A])
-            xmin, dx, ymin, dy, r1s, r2s = [], [], [], [], [], []
-            for row, k in enumerate(A):
-                e = plan[k]
-                # kde.bin_samples(p1, nbins, range_min=imin, range_max=imax) (kde_bandwidth.py:76-87)
-                mn, mx = self._col_min[e["i"]], self._col_max[e["i"]]
-                delta = mx - mn
-                rmin = e["imin"] if e["imin"] is not None else mn - delta * 0.1
-                rmax = e["imax"] if e["imax"] is not None else mx + delta * 0.1
-                R1 = rmax - rmin
-                mn2, mx2 = mm[row]
-                delta2 = mx2 - mn2
-                rmin2 = mn2 - delta2 * 0.1
-                R2 = (mx2 + delta2 * 0.1) - rmin2
-                xmin.append(rmin), dx.append(R1 / (base_F - 1)), ymin.append(rmin2), dy.append(R2 / (base_F - 1))
-                r1s.append(R1), r2s.append(R2)
-            d_rot = ctx.hist2d_sheared([plan[k]["i"] for k in A], [plan[k]["j"] for k in A],
-                                       [plan[k]["r"][0] for k in A], [plan[k]["r"][1] for k in A], xmin, dx, ymin, dy,
-                                       base_F)
-            shear = dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
+        if shear is None:
+            shear = self._shear_histograms(plan, base_F)
         # -- branch B: rule of thumb
         for k, e in enumerate(plan):
             if e["branch"] == "B":
@@ -1868,13 +1927,21 @@ class MCSamples:
             fb = [-1.0 if br == "A" else plan[k]["fallback_t"] for br, k, _, _ in rows]
             corr_in = [0.0 if br == "A" else plan[k]["corr"] for br, k, _, _ in rows]
             out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb, corr_in)
-            for row, (br, k, r1, r2) in enumerate(rows):
+            no_root = out[:, 7] != 0
+            if np.any(~no_root & (out[:, 11] != 0)):
+                raise Exception("bias not positive definite")  # kde_bandwidth.py:229-230, raised out of get_h
+            # branch C (the bulk): parameter units = the fractions times the ranges, evaluated on the whole batch
+            hx_l = (out[:, 8] * np.array([plan[k]["rangex"] for k in ks])).tolist()
+            hy_l = (out[:, 9] * np.array([plan[k]["rangey"] for k in ks])).tolist()
+            c_l = out[:, 10].tolist()
+            bad = no_root.tolist()
+            for row, ((br, k, r1, r2), kopt_row) in enumerate(zip(rows, out)):
                 e = plan[k]
-                e["kopt"] = out[row]
-                if out[row, 7] != 0:
+                e["kopt"] = kopt_row
+                if bad[row]:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                elif out[row, 11] != 0:
-                    raise Exception("bias not positive definite")  # kde_bandwidth.py:229-230, raised out of get_h
+                elif br == "C":
+                    results[k] = (hx_l[row], hy_l[row], c_l[row])
                 else:
                     results[k] = to_param_units(br, k, r1, r2, tuple(out[row, 8:11]))
 
@@ -1981,8 +2048,9 @@ class MCSamples:
         lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
                 or self.use_effective_samples_2D or mask_function is not None):
-            return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes,
-                                             mask_function=mask_function, **kwargs)
+            with _FastThreadSwitch(len(pairs) >= 64):
+                return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes,
+                                                 mask_function=mask_function, **kwargs)
         # everything per-parameter is settled here, on this lane, before the pairs are dealt
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
@@ -2107,7 +2175,7 @@ class MCSamples:
                         likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
 
         auto_bw = smooth_scale_2D < 0 and _bandwidths is None
-        plan = None
+        plan = shear = None
         if auto_bw and not self._timing and not self.use_effective_samples_2D:
             # the branch selection is host-only scalar work once every N_eff is known: it runs here while another
             # thread sits in the (GIL-free) binning calls.  When the effective sample numbers are still missing, the
@@ -2127,25 +2195,19 @@ class MCSamples:
                 plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
                                             [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
                                             base_F)
+                # the sheared re-binning (HBM-bound) shares the GPU with the byte-index binning (LDS-bound) of the other stream
+                shear = self._shear_histograms(plan, base_F)
             finally:
                 pending.result()
         else:
             binning()
         # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
-        rx, ry, cc = [0.0] * len(info), [0.0] * len(info), [0.0] * len(info)
-
-        def set_widths(k, bw_k):
-            e = info[k]
-            hx, hy, c = bw_k
-            rx[k] = hx * abs(smooth_scale_2D) / e["fwx"]
-            ry[k] = hy * abs(smooth_scale_2D) / e["fwy"]
-            cc[k] = c
-            e["bandwidth"] = bw_k
-
+        npair = len(info)
+        fwx_v = np.array([e["fwx"] for e in info], dtype=np.float64)
+        fwy_v = np.array([e["fwy"] for e in info], dtype=np.float64)
         if smooth_scale_2D < 0:
             if _bandwidths is not None:
-                for k, b in enumerate(_bandwidths):
-                    set_widths(k, b)
+                widths = list(_bandwidths)
             else:
                 if plan is None:
                     with _Phase(self, "2d.host_bandwidth_plan"):
@@ -2153,18 +2215,23 @@ class MCSamples:
                                                     [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
                                                     base_F)
                 with _Phase(self, "2d.bandwidth.device"):
-                    widths = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc)
-                for k, e in enumerate(info):
-                    e["branch"], e["kopt"] = plan[k]["branch"], plan[k]["kopt"]
-                    set_widths(k, widths[k])
+                    widths = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc, shear=shear)
+                for e, pl in zip(info, plan):
+                    e["branch"], e["kopt"] = pl["branch"], pl["kopt"]
+            wv = np.array(widths, dtype=np.float64).reshape(npair, 3)
+            rx_v = wv[:, 0] * abs(smooth_scale_2D) / fwx_v
+            ry_v = wv[:, 1] * abs(smooth_scale_2D) / fwy_v
+            cc_v = wv[:, 2]
+            for e, bw_k in zip(info, widths):
+                e["bandwidth"] = bw_k
+        elif smooth_scale_2D < 1.0:
+            rx_v = smooth_scale_2D * np.array([e["parx"].err for e in info]) / fwx_v
+            ry_v = smooth_scale_2D * np.array([e["pary"].err for e in info]) / fwy_v
+            cc_v = np.array([e["corr"] for e in info], dtype=np.float64)
         else:
-            for k, e in enumerate(info):
-                if smooth_scale_2D < 1.0:
-                    rx[k] = smooth_scale_2D * e["parx"].err / e["fwx"]
-                    ry[k] = smooth_scale_2D * e["pary"].err / e["fwy"]
-                else:
-                    rx[k] = ry[k] = smooth_scale_2D * e["F"] / e["nbin2D"]
-                cc[k] = e["corr"]
+            rx_v = ry_v = np.array([smooth_scale_2D * e["F"] / e["nbin2D"] for e in info], dtype=np.float64)
+            cc_v = np.array([e["corr"] for e in info], dtype=np.float64)
+        rx, ry, cc = rx_v.tolist(), ry_v.tolist(), cc_v.tolist()
 
         # ---- convolution + corrections, batched per (F, bounded?, FFT frame size) class
         out = [None] * len(info)
@@ -2179,43 +2246,42 @@ class MCSamples:
                 axes[key] = (a, a[1] - a[0])
             return axes[key]
 
-        bits_cache = {}
-
-        def par_bits(j):
-            """(flag bits as the x parameter, as the y parameter, has_limits): edge masks only on non-periodic axes
-            (mcsamples.py:1688-1703); bits 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic."""
-            if j not in bits_cache:
-                p = names[j]
-                lim = 0 if p.periodic else (1 if p.has_limits_bot else 0) | (2 if p.has_limits_top else 0)
-                bits_cache[j] = (lim | (16 if p.periodic else 0), (lim << 2) | (32 if p.periodic else 0), bool(p.has_limits))
-            return bits_cache[j]
+        # per-pair flag bits, window half-widths and FFT frame sizes for all pairs at once.  Edge masks only on
+        # non-periodic axes (mcsamples.py:1688-1703); bits 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic.
+        nmax = max(used) + 1
+        lim_bits, per_bit, has_lim = np.zeros(nmax, np.int64), np.zeros(nmax, np.int64), np.zeros(nmax, bool)
+        for j in used:
+            p_ = names[j]
+            lim_bits[j] = 0 if p_.periodic else (1 if p_.has_limits_bot else 0) | (2 if p_.has_limits_top else 0)
+            per_bit[j] = 1 if p_.periodic else 0
+            has_lim[j] = bool(p_.has_limits)
+        has_prior_v = has_lim[jx] | has_lim[jy] | (mask_function is not None)  # mcsamples.py:1794
+        flags_v = lim_bits[jx] | (per_bit[jx] << 4) | (lim_bits[jy] << 2) | (per_bit[jy] << 5) | (has_prior_v.astype(np.int64) << 6)
+        smooth_v = np.maximum(rx_v, ry_v)
+        for k in np.nonzero(smooth_v < 2)[0].tolist():
+            logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", info[k]["parx"].name,
+                            info[k]["pary"].name)
+        winw_v = np.maximum(1, np.rint(2.5 * smooth_v).astype(np.int64))  # max(1, int(round(2.5 * smooth_scale)))
+        group_v = (flags_v & 48) * 2 + (has_prior_v & (bco >= 0))
+        flags_l, winw_l = flags_v.tolist(), winw_v.tolist()
 
         def run_class(F, d_hist, members):
             """Convolve the pairs of one grid-size class."""
-            groups = {}
-            for pos, k in enumerate(members):
-                e = info[k]
-                bx, by = par_bits(e["j"]), par_bits(e["j2"])
-                has_prior = bx[2] or by[2] or mask_function is not None  # mcsamples.py:1794
-                e["flags"] = flags = bx[0] | by[1] | (64 if has_prior else 0)
-                smooth_scale = float(max(rx[k], ry[k]))
-                if smooth_scale < 2:
-                    logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", e["parx"].name,
-                                    e["pary"].name)
-                e["winw"] = max(1, int(round(2.5 * smooth_scale)))
-                groups.setdefault((flags & 48, has_prior and bco >= 0), []).append((pos, k))
+            mem = np.asarray(members, dtype=np.int64)
             # batches of a few hundred grids (default cap 320) keep the FFTs efficient and the D2H copy of batch k hidden behind the
             # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
             max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 320))))
             batches = []
-            for bounded, sel_all in groups.items():
-                by_S = {}  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
-                for item in sel_all:
-                    by_S.setdefault(next_fft_size(F + 2 * info[item[1]]["winw"]), []).append(item)
+            gk = group_v[mem]
+            frame = {w_: next_fft_size(F + 2 * w_) for w_ in np.unique(winw_v[mem]).tolist()}
+            S_v = np.array([frame[w_] for w_ in winw_v[mem].tolist()], dtype=np.int64)
+            for g_ in dict.fromkeys(gk.tolist()):  # groups in order of first appearance
+                in_g = np.nonzero(gk == g_)[0]
                 carry = []
-                sizes = sorted(by_S)
+                sizes = np.unique(S_v[in_g]).tolist()  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
                 for q, S in enumerate(sizes):
-                    cur = carry + by_S[S]
+                    pos_S = in_g[S_v[in_g] == S]
+                    cur = carry + [(int(pos), members[pos]) for pos in pos_S.tolist()]
                     if len(cur) < 24 and q + 1 < len(sizes):
                         carry = cur
                         continue
@@ -2228,9 +2294,9 @@ class MCSamples:
                 if mask_function is not None:
                     (pos, k), = sel
                     e = info[k]
-                    if e["flags"] & 48:
+                    if flags_l[k] & 48:
                         raise NotImplementedError("mask_function on periodic parameters")
-                    w_ = e["winw"]
+                    w_ = winw_l[k]
                     prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
                     mask_function(e["xbinmin"] - w_ * e["fwx"], e["ybinmin"] - w_ * e["fwy"], e["fwx"], e["fwy"], prior_mask)
                     e["mask"] = bool_mask = prior_mask[w_:-w_, w_:-w_] < 1e-8
@@ -2243,7 +2309,7 @@ class MCSamples:
                         mask_mbc = prior_mask
                     with _Phase(self, "2d.convolve"):
                         d_P, status = ctx.density2d_masked(d_hist, pos, F, rx[k], ry[k], cc[k], w_,
-                                                           e["flags"], bco, mbc, mask_bc, mask_mbc, bool_mask)
+                                                           flags_l[k], bco, mbc, mask_bc, mask_mbc, bool_mask)
                     levels = None
                     if not get_density:
                         ncontours = len(self.contours)
@@ -2260,8 +2326,8 @@ class MCSamples:
                 ks = [k for _, k in sel]
                 with _Phase(self, "2d.convolve"):
                     d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                [cc[k] for k in ks], [info[k]["winw"] for k in ks],
-                                                [info[k]["flags"] for k in ks], bco, mbc)
+                                                [cc[k] for k in ks], [winw_l[k] for k in ks],
+                                                [flags_l[k] for k in ks], bco, mbc)
                 levels = None
                 if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
                     ncontours = len(self.contours)
@@ -2276,8 +2342,8 @@ class MCSamples:
                     else:
                         d_lsub = likehists[F]
                     d_L, lstatus = ctx.likes2d(d_sub, d_lsub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                               [cc[k] for k in ks], [info[k]["winw"] for k in ks],
-                                               [info[k]["flags"] for k in ks], mbc)
+                                               [cc[k] for k in ks], [winw_l[k] for k in ks],
+                                               [flags_l[k] for k in ks], mbc)
                     if own:
                         d_lsub.free()
                     if np.any(lstatus != 0):
@@ -2301,27 +2367,40 @@ class MCSamples:
         _ph_asm = _Phase(self, "2d.host_assemble_results")
         _ph_asm.__enter__()
         # the result objects only hold views of the page-locked arrays, so they are built while the last copies land
+        ax_cache = {}
+
+        def axis_of(j, par, lo, hi, F):
+            key = (j, F)
+            if key not in ax_cache:
+                a = np.linspace(lo, hi, F)
+                ax_cache[key] = (a, a[1] - a[0], (par.range_min, par.range_max))
+            return ax_cache[key]
+
+        ncont = None
         for d_P, P, ks, status, d_L, L, levels in inflight:
             F = P.shape[1]
+            if np.any(np.asarray(status) != 0):
+                raise DensitiesError("no samples in bin")
+            lev_state = None if levels is None else np.asarray(levels[1]).tolist()
             for row, k in enumerate(ks):
-                if status[row] != 0:
-                    raise DensitiesError("no samples in bin")
                 e = info[k]
-                (ax, sx), (ay, sy) = axis(e["parx"], e["xbinmin"], e["xbinmax"], F), axis(e["pary"], e["ybinmin"], e["ybinmax"], F)
-                dens = Density2D._wrap(ax, ay, P[row], [(e["parx"].range_min, e["parx"].range_max),
-                                                        (e["pary"].range_min, e["pary"].range_max)], sx * sy)
-                dens.mask = e.get("mask")
-                dens.bandwidth = e.get("bandwidth")
-                dens.bandwidth_branch = e.get("branch")
-                dens.kopt = e.get("kopt")
-                if levels is not None:
-                    if levels[1][row] == 0:
-                        dens.contours = levels[0][row].copy()
-                    elif levels[1][row] == -4:
+                ax, sx, vrx = axis_of(e["j"], e["parx"], e["xbinmin"], e["xbinmax"], F)
+                ay, sy, vry = axis_of(e["j2"], e["pary"], e["ybinmin"], e["ybinmax"], F)
+                contours = None
+                if lev_state is not None:
+                    if lev_state[row] == 0:
+                        contours = levels[0][row].copy()
+                    elif lev_state[row] == -4:
                         raise DensitiesError("Contour level outside plotted ranges")
-                    else:  # more exactly equal grid values at the level than the kernel's tie list holds
-                        dens.contours = dens.getContourLevels(self.contours[:levels[0].shape[1]])
-                dens.likes = None if L is None else L[row]
+                    else:
+                        ncont = levels[0].shape[1]
+                dens = Density2D._from_fields(dict(
+                    x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=e.get("mask"),
+                    likes=None if L is None else L[row], contours=contours, spl=None, P=P[row],
+                    bandwidth=e.get("bandwidth"), bandwidth_branch=e.get("branch"), kopt=e.get("kopt")))
+                if contours is None and lev_state is not None:
+                    # more exactly equal grid values at the level than the kernel's tie list holds
+                    dens.contours = dens.getContourLevels(self.contours[:ncont])
                 out[k] = dens
         _ph_asm.__exit__()
         if not synced:

@@ -342,13 +342,19 @@ def test_meanlikes_golden(zoo):
             o = orc.density_2d(a, b, trace=tr, meanlikes=True, likes_exact=exact, **kw2)
             oracle_bw.append((tr["hx"], tr["hy"], tr["c"]))
             bw_agrees = gu.relerr(d.bandwidth, oracle_bw[-1]) < 1e-6
-            assert bw_agrees or uses_tnc(d, mc, a, b), (case, a, b)
-            tol = TOL_GRID if bw_agrees else TOL_GRID_TNC
-            assert np.max(np.abs(d.P - o["P"])) < tol, (case, a, b)
+            if not bw_agrees:
+                # only where the oracle's own TNC result moves under a 1e-15 perturbation of its inputs; the grids are
+                # then checked at the strict tolerance against the oracle run with the device's bandwidth triple
+                assert uses_tnc(d, mc, a, b), (case, a, b)
+                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+                assert ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])[0], (case, a, b)
+                assert np.max(np.abs(d.P - o["P"])) < TOL_GRID_TNC, (case, a, b)
+                o = orc.density_2d(a, b, meanlikes=True, likes_exact=exact, _bandwidths=tuple(d.bandwidth), **kw2)
+            assert np.max(np.abs(d.P - o["P"])) < TOL_GRID, (case, a, b)
             if exact:  # the same algorithm by direct summation: no noise-decided pixels on either side
                 err = np.max(np.abs(d.likes - o["likes_exact"]))
-                assert err < tol, (case, a, b, err)
-            bad = gu.likes_outliers(d.likes, o["likes"], tol)
+                assert err < TOL_GRID, (case, a, b, err)
+            bad = gu.likes_outliers(d.likes, o["likes"], TOL_GRID)
             assert bad <= gu.MAX_LIKES_OUTLIERS, (case, a, b, bad)
         # identical bandwidths in -> the reference's likes grids out (up to its own noise-decided pixels)
         dens = mc.get2DDensities(pairs, meanlikes=True, _bandwidths=oracle_bw, **kw2)
