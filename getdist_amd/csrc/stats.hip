@@ -745,6 +745,7 @@ __global__ void k_sum_partials_batched(const double* __restrict__ part, int nblk
 // |r| <= ln2/128, exp(-t) = 2^-q' * T[j'] * exp(r); T = 2^(j/64) from a 64-entry LDS table, exp(r) by a degree-5
 // polynomial (next term 3.5e-17).  About half the instructions of the library exp, which these kernels are bound by.
 __device__ __forceinline__ double exp_neg(double t, const double* __restrict__ tab) {
+    t = __builtin_fmin(t, 708.0);  // beyond: below 1e-307 anyway, and the int conversion below would wrap for huge t
     const double n = __builtin_rint(t * 92.332482616893656756);  // 64 / ln 2
     // ln2/64 split so that n * hi is exact for n < 2^17
     double r = __builtin_fma(n, 1.0830424696223417413e-02, -t);
@@ -755,56 +756,73 @@ __device__ __forceinline__ double exp_neg(double t, const double* __restrict__ t
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     const int m = -(int)n;  // exp(-t) = 2^(m/64) exp(r)
-    const double v = __builtin_ldexp(tab[m & 63] * p, m >> 6);
-    return t < 708.0 ? v : 0.0;  // beyond: below 1e-307, and the int conversion above would wrap for huge t
+    return __builtin_ldexp(tab[m & 63] * p, m >> 6);
 }
 
 #define KDE_LAG_MAX 8
-// All lags of a column in one read: grid (blocks, columns); x_i stays in a register for the <= 8 lags.
-template <bool HAS_W>
+// All NL lags of a column in one read: grid (blocks, columns), rows in chunks of 256.  Chunks below min(N - k) need no
+// bounds handling at all (straight-line code: NL loads in flight, NL interleaved exponentials); the others skip a lag
+// whose range has ended for the whole chunk (with lags near N/2 that is most of the second half) and mask the rest.
+template <bool HAS_W, int NL>
 __global__ void __launch_bounds__(256) k_kde_lag_multi(const double* __restrict__ cols, int64_t ld,
                                                        const int32_t* __restrict__ colidx, const double* __restrict__ w,
                                                        int64_t N, const double* __restrict__ cvals,
-                                                       const int64_t* __restrict__ lags, int nl,
-                                                       double* __restrict__ part) {
+                                                       const int64_t* __restrict__ lags, double* __restrict__ part) {
     __shared__ double red[16];
     __shared__ double tab[64];
     if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64));
     __syncthreads();
     const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
     const double c = cvals[blockIdx.y];
-    int64_t k[KDE_LAG_MAX];
+    int64_t k[NL], M[NL];
+    int64_t Mmin = N;
 #pragma unroll
-    for (int l = 0; l < KDE_LAG_MAX; ++l) k[l] = l < nl ? lags[l] : N;  // N: never in range
-    double s[KDE_LAG_MAX];
+    for (int l = 0; l < NL; ++l) {
+        k[l] = lags[l];
+        M[l] = N - k[l];
+        Mmin = M[l] < Mmin ? M[l] : Mmin;
+    }
+    double s[NL];
 #pragma unroll
-    for (int l = 0; l < KDE_LAG_MAX; ++l) s[l] = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        // every load of the row is requested before the first exponential: with a load inside each lag's branch the
-        // loop pays eight memory latencies in sequence (measured: no faster than one lag per thread)
+    for (int l = 0; l < NL; ++l) s[l] = 0;
+    const int64_t nA = Mmin / 256, nT = (N + 255) / 256;
+    for (int64_t ch = blockIdx.x; ch < nA; ch += gridDim.x) {
+        const int64_t i = ch * 256 + threadIdx.x;
         const double xi = x[i];
         const double wi = HAS_W ? w[i] : 1.0;
-        double xk[KDE_LAG_MAX], wk[KDE_LAG_MAX];
+        double xk[NL], wk[NL];
 #pragma unroll
-        for (int l = 0; l < KDE_LAG_MAX; ++l) {
-            const int64_t r = i + k[l];
-            const int64_t rc = r < N ? r : N - 1;
-            xk[l] = x[rc];
-            wk[l] = HAS_W ? w[rc] : 1.0;
+        for (int l = 0; l < NL; ++l) {
+            xk[l] = (x + k[l])[i];
+            wk[l] = HAS_W ? (w + k[l])[i] : 1.0;
         }
 #pragma unroll
-        for (int l = 0; l < KDE_LAG_MAX; ++l) {
-            if (l < nl) {  // uniform
-                const double d = xi - xk[l];
+        for (int l = 0; l < NL; ++l) {
+            const double d = xi - xk[l];
+            double e = exp_neg((d * d) * c, tab);
+            if (HAS_W) e = e * wi * wk[l];
+            s[l] += e;
+        }
+    }
+    for (int64_t ch = nA + blockIdx.x; ch < nT; ch += gridDim.x) {
+        const int64_t i0 = ch * 256, i = i0 + threadIdx.x;
+        const double xi = i < N ? x[i] : 0.0;
+        const double wi = (HAS_W && i < N) ? w[i] : 1.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (i0 < M[l]) {  // uniform: this lag still has rows in the chunk
+                const bool valid = i < M[l];
+                const int64_t r = valid ? i + k[l] : N - 1;
+                const double d = xi - x[r];
                 double e = exp_neg((d * d) * c, tab);
-                if (HAS_W) e = e * wi * wk[l];
-                s[l] += (i + k[l] < N) ? e : 0.0;
+                if (HAS_W) e = e * wi * w[r];
+                s[l] += valid ? e : 0.0;
             }
         }
     }
     double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * KDE_LAG_MAX;
 #pragma unroll
-    for (int l = 0; l < KDE_LAG_MAX; ++l) {
+    for (int l = 0; l < NL; ++l) {
         const double r = block_sum(s[l], red);
         if (threadIdx.x == 0) p[l] = r;
     }
@@ -1277,12 +1295,19 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     GD_HIP(hipMemcpyAsync(d_c, inv4s2, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
     if (multi) {
         const dim3 grid(nblk, ncols);
-        if (ctx->w)
-            k_kde_lag_multi<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c, d_lags,
-                                                                  nlags, part);
-        else
-            k_kde_lag_multi<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_c, d_lags,
-                                                                   nlags, part);
+#define KDE_LAUNCH(NLV)                                                                                                 \
+    case NLV:                                                                                                           \
+        if (ctx->w)                                                                                                     \
+            k_kde_lag_multi<true, NLV><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c,   \
+                                                                      d_lags, part);                                    \
+        else                                                                                                            \
+            k_kde_lag_multi<false, NLV><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_c, \
+                                                                       d_lags, part);                                   \
+        break;
+        switch (nlags) {
+            KDE_LAUNCH(1) KDE_LAUNCH(2) KDE_LAUNCH(3) KDE_LAUNCH(4) KDE_LAUNCH(5) KDE_LAUNCH(6) KDE_LAUNCH(7) KDE_LAUNCH(8)
+        }
+#undef KDE_LAUNCH
         GD_KERNEL_CHECK();
         std::vector<double> h((size_t)ncols * nblk * KDE_LAG_MAX);
         GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -1772,15 +1772,16 @@ class MCSamples:
         res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)
         return res[0]
 
-    def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None):
+    def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None, defer_neff=False):
         """Branch selection per pair (mcsamples.py:1325-1409), scalars only.  The classification is evaluated on arrays
         over the pairs (a triangle has thousands); powers stay Python-float operations so that every scalar is the one the
-        reference computes."""
+        reference computes.  With ``defer_neff`` the effective sample numbers are not touched yet (their kernels may
+        still be running on a helper thread): returns (plan, fill) and ``fill()`` completes the entries later."""
         names = self.paramNames.names
         npairs = len(pairs)
         if npairs == 0:
-            return []
-        if N_eff is None:
+            return ([], lambda: None) if defer_neff else []
+        if N_eff is None and not defer_neff:
             self._neff_batch(list(dict.fromkeys([j for p in pairs for j in p])))
         jx = [p[0] for p in pairs]
         jy = [p[1] for p in pairs]
@@ -1792,16 +1793,17 @@ class MCSamples:
         lim_u = np.array([bool(p.has_limits) for p in upar])
         sig_u = np.array([np.nan if p.sigma_range is None else p.sigma_range for p in upar], dtype=np.float64)
         corr_v = np.asarray(corrs, dtype=np.float64)
-        if N_eff is None:
+
+        def effective_samples():
+            if N_eff is not None:
+                return np.full(npairs, float(N_eff))
             if self.use_effective_samples_2D:
-                neff_v = np.array([self.getEffectiveSamplesGaussianKDE_2d(a, b) if abs(c) < 0.999  # mcsamples.py:1326-1328
-                                   else min(self._get1DNeff(names[a], a), self._get1DNeff(names[b], b))
-                                   for a, b, c in zip(jx, jy, corr_v.tolist())], dtype=np.float64)
-            else:
-                neff_u = np.array([self._get1DNeff(p, j) for p, j in zip(upar, used)], dtype=np.float64)
-                neff_v = np.minimum(neff_u[ix], neff_u[iy])
-        else:
-            neff_v = np.full(npairs, float(N_eff))
+                return np.array([self.getEffectiveSamplesGaussianKDE_2d(a, b) if abs(c) < 0.999  # mcsamples.py:1326-1328
+                                 else min(self._get1DNeff(names[a], a), self._get1DNeff(names[b], b))
+                                 for a, b, c in zip(jx, jy, corr_v.tolist())], dtype=np.float64)
+            neff_u = np.array([self._get1DNeff(p, j) for p, j in zip(upar, used)], dtype=np.float64)
+            return np.minimum(neff_u[ix], neff_u[iy])
+
         limx, limy = lim_u[ix], lim_u[iy]
         has_limits = limx | limy
         do_correlated = ~limx | ~limy
@@ -1811,14 +1813,22 @@ class MCSamples:
         rng = np.asarray(ranges_xy, dtype=np.float64).reshape(npairs, 2)
         with np.errstate(all="ignore"):
             ratio = np.minimum(sig_u[iy] / rng[:, 1], sig_u[ix] / rng[:, 0]).tolist()
-        neff_l = neff_v.tolist()
         branch = np.where(is_A, "A", np.where(is_B, "B", "C")).tolist()
-        plan = [dict(jx=a, jy=b, parx=names[a], pary=names[b], corr=c, neff=ne, has_limits=hl, rangex=rx_, rangey=ry_,
+        plan = [dict(jx=a, jy=b, parx=names[a], pary=names[b], corr=c, neff=None, has_limits=hl, rangex=rx_, rangey=ry_,
                      branch=br)
-                for a, b, c, ne, hl, rx_, ry_, br in zip(jx, jy, corr_v.tolist(), neff_l, has_limits.tolist(),
-                                                         rng[:, 0].tolist(), rng[:, 1].tolist(), branch)]
-        for k in np.nonzero(~is_A & ~is_B)[0].tolist():
-            plan[k]["fallback_t"] = (ratio[k] / neff_l[k] ** (1.0 / 6)) ** 2
+                for a, b, c, hl, rx_, ry_, br in zip(jx, jy, corr_v.tolist(), has_limits.tolist(),
+                                                     rng[:, 0].tolist(), rng[:, 1].tolist(), branch)]
+        is_C = np.nonzero(~is_A & ~is_B)[0].tolist()
+
+        def fill():
+            neff_l = effective_samples().tolist()
+            for e, ne in zip(plan, neff_l):
+                e["neff"] = ne
+            for k in is_C:
+                plan[k]["fallback_t"] = (ratio[k] / neff_l[k] ** (1.0 / 6)) ** 2
+
+        if not defer_neff:
+            fill()
         for k in np.nonzero(is_A)[0].tolist():
             e = plan[k]
             parx, pary = e["parx"], e["pary"]
@@ -1840,7 +1850,7 @@ class MCSamples:
             S *= ichol[0, 0]
             r = ichol[1, :] / ichol[0, 0]
             e.update(i=i, j=j, imin=imin, imax=imax, S=S, r=r)
-        return plan
+        return (plan, fill) if defer_neff else plan
 
     def _fallback_widths(self, e, ex):
         parx, pary, corr, neff = e["parx"], e["pary"], e["corr"], e["neff"]
@@ -2105,17 +2115,7 @@ class MCSamples:
         self._init_params(used)
         names = self.paramNames.names
         corrmat = self.getCorrelationMatrix()
-        _ph_info = _Phase(self, "2d.host_pair_scalars")
-        _ph_info.__enter__()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
-        info = []
-        edge_cache = {}
-
-        def edges(jj, FF):
-            if (jj, FF) not in edge_cache:
-                edge_cache[(jj, FF)] = self._bin_edges(names[jj], FF)
-            return edge_cache[(jj, FF)]
-
         # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
         jx = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
         jy = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
@@ -2130,18 +2130,26 @@ class MCSamples:
         nbin2D_v = np.round(self.num_bins_2D / angle_scale).astype(np.int64)
         scaled = 192 * (3 / angle_scale).astype(np.int64) // 3
         F_v = np.where((corr_v != 0) & (base_F < scaled) & ((1 / angle_scale).astype(np.int64) > 1), scaled, base_F)
-        for q, (j, j2) in enumerate(pairs):
-            F = int(F_v[q])
-            fwx, xbinmin, xbinmax = edges(j, F)
-            fwy, ybinmin, ybinmax = edges(j2, F)
-            info.append(dict(j=j, j2=j2, parx=names[j], pary=names[j2], corr=corr_v[q], actual_corr=actual[q], F=F,
-                             nbin2D=int(nbin2D_v[q]), fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy, ybinmin=ybinmin,
-                             ybinmax=ybinmax))
-        _ph_info.__exit__()
-        # ---- histograms, one batched launch per grid-size class (pre-binned u16 index columns)
+        pj, pj2, pF = jx.tolist(), jy.tolist(), [int(f) for f in F_v.tolist()]
+        edge_of = {key: self._bin_edges(names[key[0]], key[1])  # (fine width, binmin, binmax) per (parameter, F)
+                   for key in dict.fromkeys(list(zip(pj, pF)) + list(zip(pj2, pF)))}
+        info = []
+
+        def build_info():
+            """The per-pair records; nothing here is needed to start the binning."""
+            corr_l, actual_l, nbin_l = corr_v.tolist(), actual.tolist(), nbin2D_v.tolist()
+            with _Phase(self, "2d.host_pair_scalars"):
+                for q, (j, j2, F) in enumerate(zip(pj, pj2, pF)):
+                    fwx, xbinmin, xbinmax = edge_of[(j, F)]
+                    fwy, ybinmin, ybinmax = edge_of[(j2, F)]
+                    info.append(dict(j=j, j2=j2, parx=names[j], pary=names[j2], corr=corr_l[q], actual_corr=actual_l[q],
+                                     F=F, nbin2D=nbin_l[q], fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy,
+                                     ybinmin=ybinmin, ybinmax=ybinmax))
+
+        # ---- histograms, one batched launch per grid-size class (pre-binned index columns)
         classes = {}
-        for k, e in enumerate(info):
-            classes.setdefault(e["F"], []).append(k)
+        for k, F in enumerate(pF):
+            classes.setdefault(F, []).append(k)
         hists, likehists = {}, {}
 
         def binning(owner=self):
@@ -2152,54 +2160,70 @@ class MCSamples:
                     # the base grid of a unit-weight triangle: byte indices, packed 16-bit counters, one block per pair
                     with _Phase(self, "2d.prebin"):
                         wanted = {}
-                        for k in members:
-                            wanted[info[k]["j"]] = (info[k]["xbinmin"], info[k]["fwx"])
-                            wanted[info[k]["j2"]] = (info[k]["ybinmin"], info[k]["fwy"])
+                        for j in dict.fromkeys([pj[k] for k in members] + [pj2[k] for k in members]):
+                            fw, bmin, _ = edge_of[(j, 256)]
+                            wanted[j] = (bmin, fw)
                         ok = owner._index_columns8(wanted)
                     if ok:
                         try:
                             with _Phase(self, "2d.hist"):
-                                hists[F] = (owner.ctx.hist2d_prebinned8([owner._idx_cols[(info[k]["j"], 256, "u8")][0] for k in members],
-                                                                        [owner._idx_cols[(info[k]["j2"], 256, "u8")][0] for k in members]),
+                                hists[F] = (owner.ctx.hist2d_prebinned8([owner._idx_cols[(pj[k], 256, "u8")][0] for k in members],
+                                                                        [owner._idx_cols[(pj2[k], 256, "u8")][0] for k in members]),
                                             members)
                             continue
                         except GdhipError as e:
                             if e.code != -5:  # a 16-bit counter wrapped: the u16 / u32 path below redoes the class
                                 raise
                 with _Phase(self, "2d.prebin"):
-                    ix = [owner._index_column(info[k]["j"], F, info[k]["xbinmin"], info[k]["fwx"]) for k in members]
-                    iy = [owner._index_column(info[k]["j2"], F, info[k]["ybinmin"], info[k]["fwy"]) for k in members]
+                    ix = [owner._index_column(pj[k], F, edge_of[(pj[k], F)][1], edge_of[(pj[k], F)][0]) for k in members]
+                    iy = [owner._index_column(pj2[k], F, edge_of[(pj2[k], F)][1], edge_of[(pj2[k], F)][0]) for k in members]
                 with _Phase(self, "2d.hist"):
                     hists[F] = (owner.ctx.hist2d_prebinned(ix, iy, F), members)
                     if meanlikes:
                         likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
 
+        def plan_args():
+            return ([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
+                    [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info], base_F)
+
         auto_bw = smooth_scale_2D < 0 and _bandwidths is None
         plan = shear = None
         if auto_bw and not self._timing and not self.use_effective_samples_2D:
-            # the branch selection is host-only scalar work once every N_eff is known: it runs here while another
-            # thread sits in the (GIL-free) binning calls.  When the effective sample numbers are still missing, the
-            # binning goes to the second context (own stream and scratch over the same resident samples) so that the
-            # N_eff kernels -- exp-bound -- and the LDS-bound histograms share the GPU.
+            # Everything that needs no device result runs on this thread while helper threads sit in the (GIL-free)
+            # entry points: the N_eff kernels (exp-bound) on this context, the byte-index binning (LDS-bound) on the
+            # second context (own stream and scratch over the same resident samples), then the sheared re-binning
+            # (HBM-bound) on this context again; the per-pair records and the branch selection are built meanwhile.
             need_neff = any(names[j].N_eff_kde is None for j in used)
             if (need_neff and self._lane == 0 and not meanlikes and len(pairs) >= 64
                     and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
+                neff_f = self._helper().submit(self._neff_batch, used)
                 twin = self._second_lane()
-                self._nlanes = 1  # only the binning is shared out; the TNC pool stays whole
+                self._nlanes = 1  # only the binning is shared out
                 pending = self._lane_thread(twin).submit(binning, twin)
+                try:
+                    try:
+                        build_info()
+                        plan, fill_plan = self._bandwidth_plan(*plan_args(), defer_neff=True)
+                    finally:
+                        neff_f.result()
+                    # a context is not re-entrant: the shear launches start once the N_eff call has returned
+                    shear_f = self._helper().submit(self._shear_histograms, plan, base_F)
+                    try:
+                        fill_plan()
+                    finally:
+                        shear = shear_f.result()
+                finally:
+                    pending.result()
             else:
                 self._neff_batch(used)
-                pending = self._helper().submit(binning)
-            try:
-                self._neff_batch(used)
-                plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
-                                            [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
-                                            base_F)
-                # the sheared re-binning (HBM-bound) shares the GPU with the byte-index binning (LDS-bound) of the other stream
-                shear = self._shear_histograms(plan, base_F)
-            finally:
-                pending.result()
+                pending = self._helper().submit(binning)  # the helper thread is inside this context's entry points
+                try:
+                    build_info()
+                    plan = self._bandwidth_plan(*plan_args())
+                finally:
+                    pending.result()
         else:
+            build_info()
             binning()
         # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
         npair = len(info)
@@ -2211,9 +2235,7 @@ class MCSamples:
             else:
                 if plan is None:
                     with _Phase(self, "2d.host_bandwidth_plan"):
-                        plan = self._bandwidth_plan([(e["j"], e["j2"]) for e in info], [e["actual_corr"] for e in info],
-                                                    [(e["xbinmax"] - e["xbinmin"], e["ybinmax"] - e["ybinmin"]) for e in info],
-                                                    base_F)
+                        plan = self._bandwidth_plan(*plan_args())
                 with _Phase(self, "2d.bandwidth.device"):
                     widths = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc, shear=shear)
                 for e, pl in zip(info, plan):

@@ -1,16 +1,9 @@
 mkdir -p gpurun_out; cd /root/repo
 timeout 600 python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r02_pytest_gpu.log
-echo "== U=8"; timeout 200 python scripts/tune_kopt.py 2>&1 | tail -3
-for U in 4 2; do touch getdist_amd/csrc/kopt2d.hip; GDHIP_EXTRA_FLAGS=-DKOPT_U=$U bash getdist_amd/csrc/build.sh >/dev/null 2>&1; echo "== U=$U"; timeout 200 python scripts/tune_kopt.py 2>&1 | tail -3; done
-touch getdist_amd/csrc/kopt2d.hip; bash getdist_amd/csrc/build.sh > /dev/null 2>&1
+timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | cut -c1-330
 export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/r02_prof_bench.json 2> gpurun_out/r02_prof_bench.err; echo "prof rc=$?"
 find /tmp/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r02_bench_kernel_stats.csv \;
 find /tmp/prof -name "*kernel_trace.csv" -exec cp {} gpurun_out/r02_bench_kernel_trace.csv \;
-ls -la gpurun_out/ | head -30
-cat gpurun_out/r02_prof_bench.json | cut -c1-400
-GETDIST_AMD_TIMING=1 timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --emulate-world 8 > gpurun_out/r02_emu8_timing.json 2>/dev/null; python -c "
-import json;d=json.load(open('gpurun_out/r02_emu8_timing.json'));print(d['ms_per_step'], d.get('phase_seconds_total'))"
-for W in 8 4 2; do timeout 200 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --emulate-world $W > gpurun_out/r02_emu$W.json 2>/dev/null; python -c "
+for W in 8 2; do timeout 200 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --emulate-world $W > gpurun_out/r02_emu$W.json 2>/dev/null; python -c "
 import json;d=json.load(open('gpurun_out/r02_emu$W.json'));print($W, d['ms_per_step'])"; done
-timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | cut -c1-300
