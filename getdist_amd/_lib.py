@@ -90,6 +90,7 @@ SIGNATURES = {
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd]),
     "gd_get_h": (C.c_int, [_p, _i32, _pd, _pd, _pd, _pi32, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_density2d_enqueue": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _p]),
     "gd_attach_samples": (C.c_int, [_p, _p]),
     "gd_bind_thread": (C.c_int, [_p]),
     "gd_contour_levels": (C.c_int, [_p, _i32, _i32, _p, _pd, _i32, _pd, _pi32]),
@@ -580,6 +581,17 @@ class Context:
         self._check(self.lib.gd_contour_levels(self.h, int(B), int(F), d_P.ptr, _dp(contours), len(contours), _dp(out),
                                                _ip(status)))
         return out, status
+
+    def density2d_enqueue(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, status):
+        """density2d without the final wait: ``status`` is a page-locked int32 array of length B (pinned_array) that is
+        valid after sync() / copy_sync() of a later to_host_async; the returned grids likewise."""
+        out = self.alloc(B * F * F * 8)
+        rx, ry, corr, winw, flags = _f64arr(rx), _f64arr(ry), _f64arr(corr), _i32arr(winw), _i32arr(flags)
+        assert status.dtype == np.int32 and status.size == B and status.flags.c_contiguous
+        self._check(self.lib.gd_density2d_enqueue(self.h, B, F, d_hist.ptr if isinstance(d_hist, DevBuf) else d_hist,
+                                                  _dp(rx), _dp(ry), _dp(corr), _ip(winw), _ip(flags), int(bco), int(mbc),
+                                                  out.ptr, status.ctypes.data))
+        return out
 
     # ---- credible limits
     def limits1d(self, P, x0, spacing, contours, factor=0):

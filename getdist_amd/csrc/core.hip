@@ -13,6 +13,24 @@ int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    gd_ctx::StageSlot& sl = ctx->stage[ctx->stage_next];
+    ctx->stage_next = (ctx->stage_next + 1) % gd_ctx::kStageSlots;
+    if (sl.used) GD_HIP(hipEventSynchronize(sl.ev));  // the copy that last read this slot has executed
+    if (sl.cap < bytes) {
+        if (sl.host) GD_HIP(hipHostFree(sl.host));
+        sl.host = nullptr;
+        sl.cap = bytes < (64u << 10) ? (64u << 10) : bytes;
+        GD_HIP(hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault));
+    }
+    if (!sl.ev) GD_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    memcpy(sl.host, src, bytes);
+    GD_HIP(hipMemcpyAsync(d_dst, sl.host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipEventRecord(sl.ev, ctx->stream));
+    sl.used = true;
+    return GD_OK;
+}
+
 static int grow(gd_ctx* ctx, void** p, int64_t* have, int64_t bytes) {
     if (bytes <= *have) return 0;
     if (*p) (void)hipFree(*p);
@@ -82,6 +100,10 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    for (auto& sl : ctx->stage) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamSynchronize(ctx->copy_stream);
@@ -258,12 +280,13 @@ int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* 
     GD_REQUIRE(ctx && d_dst && d_src && index && count > 0 && item_bytes > 0 && item_bytes % 16 == 0, "bad argument");
     int* d_index = (int*)gd_scratch2(ctx, (int64_t)count * 4);
     if (!d_index) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(d_index, index, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    // stream-ordered: returns once enqueued (every consumer of d_dst is an entry point of this context)
+    int rc = gd_stage_h2d(ctx, d_index, index, (size_t)count * 4);
+    if (rc) return rc;
     int bx = (int)((item_bytes / 16 + 255) / 256);
     if (bx > 64) bx = 64;
     k_gather_items<<<dim3(bx, count), 256, 0, ctx->stream>>>((double2*)d_dst, (const double2*)d_src, d_index, item_bytes / 16);
     GD_KERNEL_CHECK();
-    GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;
 }
 

@@ -45,7 +45,21 @@ struct gd_ctx {
     int64_t scratch2_bytes = 0;
     FftPlanCache* fft = nullptr;
     std::map<int, double*> dctmat;  // F -> F x F DCT-II matrix 2cos(pi k (2n+1) / 2F) (kopt2d.hip)
+    // page-locked staging ring for the small per-call tables of the entry points that return before their kernels
+    // have run (gd_stage_h2d): a slot is reused only after the copy that read it has executed
+    struct StageSlot {
+        void* host = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool used = false;
+    };
+    static constexpr int kStageSlots = 32;
+    StageSlot stage[kStageSlots];
+    int stage_next = 0;
 };
+
+// Stream-ordered H2D copy of a small host table whose storage the caller may release as soon as this returns.
+int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 
 // fft.hip: batched 2D real FFTs through rocFFT (plans cached per ctx); n0 = slow axis, n1 = fast axis.
 // r2c: in batch x n0 x n1 doubles -> out batch x n0 x (n1/2+1) complex.  c2r is unnormalised and

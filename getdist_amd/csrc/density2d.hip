@@ -515,7 +515,7 @@ static int next_fft_size(int n) {
 // (convolve.py:226-251 takes the FFT at the array size without zero-padding); mask-side 'valid' convolutions use the
 // ordinary zero-padded frames.  mcsamples.py:1874-1976.
 static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, const std::vector<D2Pair>& hp, int maxw,
-                              int per, int bco, int mbc, double* d_P, int32_t* status_out) {
+                              int per, int bco, int mbc, double* d_P, int32_t* status_out, bool wait) {
     const bool px = per & 16, py = per & 32, both = px && py;
     const int Nx = px ? F - 1 : F, Ny = py ? F - 1 : F;
     GD_REQUIRE(2 * maxw + 1 <= Nx && 2 * maxw + 1 <= Ny, "window wider than the periodic grid");
@@ -553,7 +553,12 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
     double2 *ZHc = (double2*)(base + o_ZHc), *ZWc = (double2*)(base + o_ZWc), *ZKc = (double2*)(base + o_ZKc),
             *ZPc = (double2*)(base + o_ZPc), *ZW = (double2*)(base + o_ZW), *ZM = (double2*)(base + o_ZM),
             *ZK = (double2*)(base + o_ZK), *ZP = (double2*)(base + o_ZP);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    if (wait) {
+        GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    } else {  // hp dies with this frame before the copy executes
+        const int rc_stage = gd_stage_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair));
+        if (rc_stage) return rc_stage;
+    }
     const dim3 gS(128, B), gF(64, B), gN(64, B);
     const double scaleS = 1.0 / ((double)S * (double)S), scaleN = 1.0 / ((double)Ny * (double)Nx);
     int rc;
@@ -647,7 +652,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait) GD_HIP(hipStreamSynchronize(ctx->stream));
     return GD_OK;
 }
 
@@ -655,7 +660,7 @@ extern "C" {
 
 static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
                           const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
-                          void* d_P_out, int32_t* status_out, const MaskOv* ov) {
+                          void* d_P_out, int32_t* status_out, const MaskOv* ov, bool wait = true) {
     GD_REQUIRE(ctx && d_hist_v && rx && ry && corr && winw && flags && d_P_out && status_out && B > 0, "bad argument");
     GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins_2D out of range");
     GD_REQUIRE(bco >= -1 && bco <= 1, "unknown boundary_correction_order (expected 0 or 1)");
@@ -684,7 +689,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     const int per = flags[0] & 48;
     if (per) {
         GD_REQUIRE(!ov, "explicit prior masks are not supported on periodic axes");
-        return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out);
+        return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out, wait);
     }
     const bool do_bc = any_limits && bco >= 0;
     const int S = next_fft_size(F + 2 * maxw);
@@ -721,7 +726,12 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     double* d_a00m = (double*)(base + o_a00m);
     double* d_conv = (double*)(base + o_conv);
     double* d_sat = (double*)(base + o_sat);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    if (wait) {
+        GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    } else {  // hp dies with this frame before the copy executes
+        const int rc_stage = gd_stage_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair));
+        if (rc_stage) return rc_stage;
+    }
     const dim3 gS(128, B), gF(64, B);
     const double scale = 1.0 / ((double)S * (double)S);
     const int cm_blocks = 2048;
@@ -831,7 +841,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait) GD_HIP(hipStreamSynchronize(ctx->stream));
 #undef FWD
 #undef CONV_TO
     return GD_OK;
@@ -841,6 +851,12 @@ int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const 
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P_out,
                  int32_t* status_out) {
     return density2d_main(ctx, B, F, d_hist_v, rx, ry, corr, winw, flags, bco, mbc, d_P_out, status_out, nullptr);
+}
+
+int gd_density2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
+                         const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
+                         void* d_P_out, int32_t* status_pinned) {
+    return density2d_main(ctx, B, F, d_hist_v, rx, ry, corr, winw, flags, bco, mbc, d_P_out, status_pinned, nullptr, false);
 }
 
 int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, double ry, double corr, int32_t winw,

@@ -1354,12 +1354,15 @@ class MCSamples:
         nl = min(8, max_off + 1)  # short probe first; correlated chains continue in getCorrelationLength
         lag0 = self._probe_lags(todo, nl)
         kstd, maxoffs = [], []
+        # the probe of all columns at once: c[row, k] = autocovariance at lag k over the variance (chains.py:449-466)
+        C_all = np.asarray(lag0) / (self.numrows - np.arange(nl)) / np.asarray(self.vars)[todo][:, None]
+        below_all = ~(C_all > min_corr * C_all[:, :1])
+        first_below = np.where(below_all.any(axis=1), below_all.argmax(axis=1), -1).tolist()
         for row, j in enumerate(todo):
             par = self.paramNames.names[j]
-            c = lag0[row] / (self.numrows - np.arange(nl)) / self.vars[j]
-            below = np.nonzero(~(c > min_corr * c[0]))[0]
-            if below.size:
-                corrlen = c[0] + 2 * float(np.sum(c[1:int(below[0])]))
+            c = C_all[row]
+            if first_below[row] >= 0:
+                corrlen = c[0] + 2 * float(np.sum(c[1:first_below[row]]))
             elif nl == max_off + 1:
                 corrlen = c[0]
             else:
@@ -2347,9 +2350,18 @@ class MCSamples:
                     self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
                 ks = [k for _, k in sel]
                 with _Phase(self, "2d.convolve"):
-                    d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                [cc[k] for k in ks], [winw_l[k] for k in ks],
-                                                [flags_l[k] for k in ks], bco, mbc)
+                    if enqueue_only:
+                        # returns once enqueued: the next batch is prepared, and at the end the result objects are
+                        # built, while this one computes; its status words land in page-locked memory
+                        status = status_all[status_at[0]:status_at[0] + len(sel)]
+                        status_at[0] += len(sel)
+                        d_P = ctx.density2d_enqueue(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                    [cc[k] for k in ks], [winw_l[k] for k in ks],
+                                                    [flags_l[k] for k in ks], bco, mbc, status)
+                    else:
+                        d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                    [cc[k] for k in ks], [winw_l[k] for k in ks],
+                                                    [flags_l[k] for k in ks], bco, mbc)
                 levels = None
                 if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
                     ncontours = len(self.contours)
@@ -2372,16 +2384,17 @@ class MCSamples:
                         raise DensitiesError("no likelihood weight in any bin")
                     L = d_L.to_host_async((len(sel), F, F))
                 if own:
-                    d_sub.free()
+                    release.append(d_sub)  # freeing waits for the stream: after the last batch
                 # the copy runs on the copy stream while the next batch computes
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
 
+        enqueue_only = (hasattr(ctx, "density2d_enqueue") and not self._timing and not meanlikes and mask_function is None
+                        and os.environ.get("GETDIST_AMD_ASYNC_CONVOLVE", "1") == "1")
+        release = []
+        status_all, status_at = (ctx.pinned_array((npair,), np.int32) if enqueue_only else None), [0]
         for F, (d_hist, members) in hists.items():
             run_class(F, d_hist, members)
-        for F, (d_hist, members) in hists.items():
-            d_hist.free()
-        for d_lh in likehists.values():
-            d_lh.free()
+        release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
         synced = False
         if any(lv is not None and np.any(lv[1] == -5) for *_, lv in inflight):  # a grid left to the host reads P
             ctx.copy_sync()
@@ -2401,8 +2414,6 @@ class MCSamples:
         ncont = None
         for d_P, P, ks, status, d_L, L, levels in inflight:
             F = P.shape[1]
-            if np.any(np.asarray(status) != 0):
-                raise DensitiesError("no samples in bin")
             lev_state = None if levels is None else np.asarray(levels[1]).tolist()
             for row, k in enumerate(ks):
                 e = info[k]
@@ -2428,10 +2439,15 @@ class MCSamples:
         if not synced:
             with _Phase(self, "2d.d2h_wait"):
                 ctx.copy_sync()
+        failed = any(np.any(np.asarray(status) != 0) for _, _, _, status, _, _, _ in inflight)
         for d_P, P, ks, status, d_L, L, levels in inflight:
             d_P.free()
             if d_L is not None:
                 d_L.free()
+        for buf in release:
+            buf.free()
+        if failed:
+            raise DensitiesError("no samples in bin")
         return out
 
     # ---- convergence (chains.py:1446-1527; mcsamples.py:964-1003) ------------------------------------------

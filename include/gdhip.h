@@ -55,7 +55,8 @@ int gd_memcpy_d2h_async(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes
 int gd_copy_sync(gd_ctx* ctx);
 int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes);
 int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
-/* d_dst[k] = d_src[index[k]] for `count` items of item_bytes each (item_bytes % 8 == 0), one kernel launch */
+/* d_dst[k] = d_src[index[k]] for `count` items of item_bytes each (item_bytes % 16 == 0), one kernel launch;
+ * stream-ordered (returns once enqueued; `index` may be released on return) */
 int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes);
 /* page-locked host memory for fast, asynchronous D2H of result grids */
 int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out);
@@ -219,6 +220,14 @@ int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, cons
 int gd_density2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry,
                  const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                  void* d_P_out, int32_t* status_out);
+/* gd_density2d_enqueue: the same work, but the call returns as soon as it is enqueued on the context's stream, so
+ *   the host prepares the next batch (and builds result objects) while this one computes.  The per-pair table is
+ *   staged through page-locked memory owned by the context; `status_pinned` must be page-locked (gd_host_alloc) and
+ *   is valid after gd_sync, or after gd_copy_sync of a gd_memcpy_d2h_async issued after this call.  d_hist and
+ *   d_P_out must stay allocated until then. */
+int gd_density2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry,
+                         const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
+                         void* d_P_out, int32_t* status_pinned);
 
 /* ---------------------------------------------------------------- second lane -----------------
  * A context is one stream; a second context on the same device gives a second, concurrent lane of work over the

@@ -508,6 +508,14 @@ class FakeContext:
                 out[b, 3] = -1
         return out
 
+    def pinned_array(self, shape, dtype=np.float64):
+        return np.zeros(shape, dtype=dtype)
+
+    def density2d_enqueue(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, status):
+        out, st = self.density2d(d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc)
+        status[:] = st
+        return out
+
     def density2d(self, d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc, out=None):
         self.log.append(("density2d", B, F))
         H = np.asarray(d_hist.a).reshape(B, F, F)
