@@ -90,6 +90,8 @@ SIGNATURES = {
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd]),
     "gd_get_h": (C.c_int, [_p, _i32, _pd, _pd, _pd, _pi32, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
+    "gd_copy_mark": (C.c_int, [_p, _pi32]),
+    "gd_copy_wait": (C.c_int, [_p, _i32]),
     "gd_density2d_enqueue": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _p]),
     "gd_attach_samples": (C.c_int, [_p, _p]),
     "gd_bind_thread": (C.c_int, [_p]),
@@ -348,6 +350,15 @@ class Context:
 
     def copy_sync(self):
         self._check(self.lib.gd_copy_sync(self.h))
+
+    def copy_mark(self):
+        """A token for 'every result copy issued so far'; copy_wait(token) blocks until those have landed."""
+        tok = C.c_int32(0)
+        self._check(self.lib.gd_copy_mark(self.h, C.byref(tok)))
+        return int(tok.value)
+
+    def copy_wait(self, token):
+        self._check(self.lib.gd_copy_wait(self.h, int(token)))
 
     def copy_d2d(self, dst, dst_off, src, src_off, nbytes):
         self._check(self.lib.gd_memcpy_d2d(self.h, dst.ptr + dst_off, src.ptr + src_off, int(nbytes)))

@@ -100,6 +100,8 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    for (auto& ev : ctx->copy_marks)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->stage) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
@@ -180,6 +182,26 @@ int gd_memcpy_d2h_async(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes
 int gd_copy_sync(gd_ctx* ctx) {
     GD_REQUIRE(ctx, "null context");
     GD_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return GD_OK;
+}
+
+int gd_copy_mark(gd_ctx* ctx, int32_t* token_out) {
+    GD_REQUIRE(ctx && token_out, "null argument");
+    const int slot = ctx->copy_mark_next;
+    ctx->copy_mark_next = (slot + 1) % gd_ctx::kCopyMarks;
+    if (!ctx->copy_marks[slot]) GD_HIP(hipEventCreateWithFlags(&ctx->copy_marks[slot], hipEventDisableTiming));
+    // also order the mark after the compute stream's work so far (status words are copied on that stream)
+    GD_HIP(hipEventRecord(ctx->copy_ev, ctx->stream));
+    GD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev, 0));
+    GD_HIP(hipEventRecord(ctx->copy_marks[slot], ctx->copy_stream));
+    *token_out = slot;
+    return GD_OK;
+}
+
+int gd_copy_wait(gd_ctx* ctx, int32_t token) {
+    GD_REQUIRE(ctx && token >= 0 && token < gd_ctx::kCopyMarks && ctx->copy_marks[token], "bad copy mark");
+    // a slot re-used by a later mark waits for that later point: the copy stream is FIFO, so that covers this one
+    GD_HIP(hipEventSynchronize(ctx->copy_marks[token]));
     return GD_OK;
 }
 

@@ -53,6 +53,10 @@ struct gd_ctx {
         hipEvent_t ev = nullptr;
         bool used = false;
     };
+    // marks on the copy stream (gd_copy_mark / gd_copy_wait): a caller waits for ITS result copies only
+    static constexpr int kCopyMarks = 16;
+    hipEvent_t copy_marks[kCopyMarks] = {};
+    int copy_mark_next = 0;
     static constexpr int kStageSlots = 32;
     StageSlot stage[kStageSlots];
     int stage_next = 0;

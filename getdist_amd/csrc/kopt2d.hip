@@ -11,8 +11,21 @@
 
 #define KT 1024
 #define MAXF 6  // forms per level
+#ifdef KOPT_PROFILE
+__device__ long long g_prof[8];  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
+#define PROF_T0 long long prof_t0 = clock64()
+#define PROF_ADD(slot)                                                        \
+    do {                                                                      \
+        const long long prof_t1 = clock64();                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += prof_t1 - prof_t0; \
+        prof_t0 = prof_t1;                                                    \
+    } while (0)
+#else
+#define PROF_T0
+#define PROF_ADD(slot)
+#endif
 #ifndef KOPT_U
-#define KOPT_U 8  // rows requested ahead in the bilinear forms
+#define KOPT_U 1  // rows (16-B loads) requested ahead in the bilinear forms; more only spills registers (measured 8: 8.3, 4: 7.2, 2: 6.9, 1: 6.6 ms)
 #endif
 #define KOPT_STRIDE 12  // doubles per pair in the optimiser's result row (see k_get_h)
 #define PI 3.141592653589793238462643383279502884
@@ -159,12 +172,88 @@ struct KoptLds {
     double* red;    // 16
     double* times;  // MAXF plug-in times of the current level (one thread computes each; pow() is expensive)
     double* scale;  // per-level output factor: (-1)^L pi^(2L) / 4 for the even, (2 pi)^L for the odd functionals
+    double* tile;   // staging area for rows of the matrix (LDS-DMA target), nullptr when F is not a multiple of 128
+    int tile_doubles;
 };
 
 // Evaluate m bilinear forms  sum_ij wy_q[i] M[i][j] wx_q[j]  for the weight sets currently in LDS.
 // Only rows / columns below kmax are visited: beyond it every weight is < 1e-30 of its form's maximum (see
 // weight_cutoff), which cannot change the fp64 result.
+__device__ void bilinear_forms_reg(const double* __restrict__ M, int F, int m, KoptLds L, int kmax);
+
+// The matrix (512 KB at F = 256) is re-read ~25 times per pair and 256 pairs are in flight, so it comes from MALL / HBM
+// at ~2 us per access: with register loads a block has 16 KB in flight and the launch crawls at 1.8 TB/s (PMC: 89 % L2
+// misses, 15.5 GB per 1200 pairs).  Here whole rows go straight into LDS (global_load_lds_dwordx4: one 1-KB row segment
+// per wave instruction, no VGPRs), up to 128 KB per tile in flight; the forms are then accumulated from LDS.
 __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
+    if (L.tile == nullptr) {
+        bilinear_forms_reg(M, F, m, L, kmax);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = (kmax + 127) >> 7;  // 128-column (1 KB) segments of a row that carry weight
+    const int rows_fit = L.tile_doubles / (nseg * 128);
+    const int jx = threadIdx.x & 127, g = threadIdx.x >> 7;  // 128 column pairs x 8 row groups
+    double val[MAXF];
+#pragma unroll
+    for (int q = 0; q < MAXF; ++q) val[q] = 0;
+    PROF_T0;
+    for (int r0 = 0; r0 < kmax; r0 += rows_fit) {
+        const int nr = min(rows_fit, kmax - r0);
+        for (int idx = wave; idx < nr * nseg; idx += KT / 64) {
+            const int row = idx / nseg, seg = idx - row * nseg;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(M + (int64_t)(r0 + row) * F + seg * 128 + lane * 2),
+                (__attribute__((address_space(3))) void*)(L.tile + idx * 128), 16, 0, 0);
+        }
+        __syncthreads();  // carries the vmcnt(0) that lands the tile
+        PROF_ADD(1);
+        for (int j0 = 0; j0 < nseg * 128; j0 += 256) {
+            const int j = j0 + 2 * jx;
+            if (j < kmax) {
+                double ax[MAXF], ay[MAXF];
+#pragma unroll
+                for (int q = 0; q < MAXF; ++q) ax[q] = ay[q] = 0;
+                const double* col = L.tile + (j >> 7) * 128 + (j & 127);
+                for (int r = g; r < nr; r += 8) {
+                    const double2 a = *reinterpret_cast<const double2*>(col + r * nseg * 128);
+#pragma unroll
+                    for (int q = 0; q < MAXF; ++q)
+                        if (q < m) {
+                            const double wyq = L.wy[q * F + r0 + r];
+                            ax[q] = fma(wyq, a.x, ax[q]);
+                            ay[q] = fma(wyq, a.y, ay[q]);
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < MAXF; ++q)
+                    if (q < m) {
+                        val[q] = fma(ax[q], L.wx[q * F + j], val[q]);
+                        if (j + 1 < kmax) val[q] = fma(ay[q], L.wx[q * F + j + 1], val[q]);
+                    }
+            }
+        }
+        __syncthreads();  // the tile is consumed before the next one overwrites it
+        PROF_ADD(2);
+    }
+    const int wv = wave;
+#pragma unroll
+    for (int q = 0; q < MAXF; ++q)
+        if (q < m) {
+            const double r = wave_sum(val[q]);
+            if (lane == 0) L.wx[q * 16 + wv] = r;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < m) {
+        double r = 0;
+        for (int i = 0; i < KT / 64; ++i) r += L.wx[threadIdx.x * 16 + i];
+        L.res[threadIdx.x] = r;
+    }
+    __syncthreads();
+    PROF_ADD(3);
+}
+
+__device__ void bilinear_forms_reg(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
     // 8 row groups x 128 column pairs; the matrix comes from L2 / MALL with ~1 us latency, so what matters is the number
     // of independent loads in flight: 8 rows (16-B loads) are requested before the first is consumed.
     constexpr int U = KOPT_U;
@@ -241,7 +330,9 @@ __device__ __forceinline__ int weight_cutoff(int F, int Lsum, int m, const doubl
 // even functionals: psi([s0,s1], time) for the forms of one level (all with s0+s1 = Lsum); times in L.times
 __device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, double* out, KoptLds L) {
     const int m = Lsum + 1;  // forms [a, Lsum-a], a = 0..Lsum   (m <= MAXF)
+    PROF_T0;
     __syncthreads();
+    PROF_ADD(4);
     for (int e = threadIdx.x; e < m * F; e += KT) {
         const int q = e / F, k = e % F;
         double vx = 0, vy = 0;
@@ -257,6 +348,10 @@ __device__ void psi_level(const double* __restrict__ SQ, int F, int Lsum, double
     }
     const int kmax = weight_cutoff(F, Lsum, m, L.times);
     __syncthreads();
+    PROF_ADD(0);
+#ifdef KOPT_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[5] += 1, g_prof[6] += kmax;
+#endif
     bilinear_forms(SQ, F, m, L, kmax);
     const double sc = L.scale[Lsum];
     for (int q = 0; q < m; ++q) out[q] = (Lsum & 1 ? -1.0 : 1.0) * L.res[q] * sc / 4.0;
@@ -285,12 +380,14 @@ __device__ void func2d_levels(const double* __restrict__ SQ, int F, double N, do
     if (threadIdx.x < MAXF) L.times[threadIdx.x] = t;
     psi_level(SQ, F, 5, lev[5], L);
     for (int Ls = 4; Ls >= Lmin; --Ls) {
+        PROF_T0;
         if ((int)threadIdx.x <= Ls) {  // one thread per form evaluates its plug-in time (kde_bandwidth.py:191-193)
             const int a = threadIdx.x;
             const double cst = (1.0 + pow(0.5, (double)(Ls + 1))) / 3.0;
             const double sum_func = lev[Ls + 1][a + 1] + lev[Ls + 1][a];
             L.times[a] = pow(-2.0 * cst * k_even(a) * k_even(Ls - a) / N / sum_func, 1.0 / (2.0 + Ls));
         }
+        PROF_ADD(7);
         psi_level(SQ, F, Ls, lev[Ls], L);
     }
 }
@@ -327,7 +424,8 @@ struct KoptPair {
 };
 
 __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all, const double* __restrict__ PW_all,
-                                               const KoptPair* __restrict__ pairs, int F, double* __restrict__ out) {
+                                               const KoptPair* __restrict__ pairs, int F, int tile_doubles,
+                                               double* __restrict__ out) {
     extern __shared__ double lds[];
     KoptLds L;
     L.wx = lds;
@@ -336,6 +434,8 @@ __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all
     L.red = L.res + 8;
     L.times = L.red + 16;
     L.scale = L.times + 8;
+    L.tile = tile_doubles > 0 ? L.scale + 16 : nullptr;
+    L.tile_doubles = tile_doubles;
     if (threadIdx.x < 6) L.scale[threadIdx.x] = pow(PI, (double)(2 * threadIdx.x));               // even: pi^(2L)
     if (threadIdx.x >= 8 && threadIdx.x < 14) L.scale[threadIdx.x - 2] = pow(2.0 * PI, (double)(2 * (threadIdx.x - 8)));  // odd: (2pi)^L, L = 0,2,..,10
     __syncthreads();
@@ -583,10 +683,30 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
         k_power_full<<<dim3(64, nc), 256, 0, ctx->stream>>>(d_Z, F, d_PW);
         GD_KERNEL_CHECK();
     }
-    const size_t lds = ((size_t)2 * MAXF * F + 8 + 16 + 8 + 16) * 8;
+    const size_t lds_base = ((size_t)2 * MAXF * F + 8 + 16 + 8 + 16) * 8;
+    // row staging area for the bilinear forms: as much of the 160 KB as is left (at most 128 KB), whole 1-KB segments
+    size_t tile_bytes = 0;
+    if (F % 128 == 0 && getenv("GDHIP_KOPT_NO_LDS_TILE") == nullptr) {
+        const size_t room = (size_t)160 * 1024 - 1024 - lds_base;
+        tile_bytes = room < (size_t)128 * 1024 ? room : (size_t)128 * 1024;
+        tile_bytes = tile_bytes / ((size_t)F * 8) * ((size_t)F * 8);  // whole rows even when every segment is needed
+    }
+    const size_t lds = lds_base + tile_bytes;
     GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, d_out);
+    k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, (int)(tile_bytes / 8), d_out);
     GD_KERNEL_CHECK();
+#ifdef KOPT_PROFILE
+    {
+        long long hp[8];
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp)));
+        fprintf(stderr, "kopt block 0 cycles (100 MHz clock): weights %lld  tile-load %lld  tile-fma %lld  reduce %lld  "
+                        "entry-barrier %lld  times/pow %lld | levels %lld  mean kmax %.1f\n",
+                hp[0], hp[1], hp[2], hp[3], hp[4], hp[7], hp[5], hp[5] ? (double)hp[6] / hp[5] : 0.0);
+        memset(hp, 0, sizeof(hp));
+        GD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), hp, sizeof(hp)));
+    }
+#endif
     // get_h on the device: the optimiser's functionals never leave HBM
     GD_HIP(hipMemcpyAsync(base + o_neff, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(base + o_corr, corr, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -282,6 +282,22 @@ class Density2D(GridDensity):
         d.P = P
         return d
 
+    # ``P`` may still be in flight from the device when a batched call returns (the copy of one triangle's grids
+    # overlaps whatever the caller does next): the first read waits for the copies of that call and surfaces its
+    # per-grid status.  Grids set by the user or by the synchronous paths have no waiter.
+    @property
+    def P(self):
+        d = self.__dict__
+        waiter = d.get("_wait")
+        if waiter is not None:
+            d["_wait"] = None
+            waiter()
+        return d.get("_P")
+
+    @P.setter
+    def P(self, value):
+        self.__dict__["_P"] = value
+
     @classmethod
     def _from_fields(cls, fields):
         """Batch constructor used for whole triangles: ``fields`` becomes the instance dictionary (the caller supplies

@@ -223,6 +223,44 @@ def _stack_rows(parts):
     return out
 
 
+class _PendingResults:
+    """
+    The tail of a batched 2D call whose result copies are still in flight: the device grids, the inputs that must not
+    be recycled before the kernels reading them have run, and the page-locked status words.  wait() blocks until THIS
+    call's copies have landed (a mark on the copy stream, so a later call's copies are not waited for), releases the
+    device blocks and raises if any grid was empty.  Idempotent; also runs when the results are collected.
+    """
+
+    def __init__(self, ctx, inflight, release):
+        self.ctx, self.inflight, self.release = ctx, inflight, release
+        self.token = ctx.copy_mark()
+        self.done = False
+
+    def wait(self):
+        if self.done:
+            return
+        self.done = True
+        if self.ctx.h is None:
+            return
+        self.ctx.copy_wait(self.token)
+        failed = any(np.any(np.asarray(status) != 0) for _, _, _, status, _, _, _ in self.inflight)
+        for d_P, _, _, _, d_L, _, _ in self.inflight:
+            d_P.free()
+            if d_L is not None:
+                d_L.free()
+        for buf in self.release:
+            buf.free()
+        self.inflight = self.release = ()
+        if failed:
+            raise DensitiesError("no samples in bin")
+
+    def __del__(self):
+        try:
+            self.wait()
+        except Exception:
+            pass
+
+
 class _FastThreadSwitch:
     """While a helper thread drives a second stream, a thread returning from a C call would wait for the GIL up to the
     interpreter's switch interval (5 ms by default) whenever the other thread is in Python scalar code -- longer than
@@ -1450,21 +1488,25 @@ class MCSamples:
         rc = self.range_confidence
         fracs = np.array([rc, 1 - rc] + list(np.linspace(0.1, 0.9, 9)))
         targets = np.tile(self.norm * fracs, (len(todo), 1))
-        q = self.ctx.quantiles(todo, targets)
+        q = np.asarray(self.ctx.quantiles(todo, targets))
+        # mcsamples.py:1440-1452 for all parameters at once: [param_min, deciles 0.1..0.9, param_max], spans of four
+        err_v = np.asarray(self.sddev)[todo]
+        confids = np.empty_like(q)
+        confids[:, 0] = np.asarray(self._col_min)[todo]
+        confids[:, 1:-1] = q[:, 2:]
+        confids[:, -1] = np.asarray(self._col_max)[todo]
+        diffs = confids[:, 4:] - confids[:, :-4]
+        scale_v = np.min(diffs, axis=1) / 1.049
+        flat_v = (np.all(diffs > (err_v * 1.049)[:, None], axis=1) & np.all(diffs < (scale_v * 1.5)[:, None], axis=1)).tolist()
         for row, j in enumerate(todo):
             par = self.paramNames.names[j]
             par.err = self.sddev[j]
             par.mean = self.means[j]
             par.param_min = self._col_min[j]
             par.param_max = self._col_max[j]
-            confids = q[row].copy()
-            par.range_min, par.range_max = confids[0:2]
-            confids[1:-1] = confids[2:]
-            confids[0] = par.param_min
-            confids[-1] = par.param_max
-            diffs = confids[4:] - confids[:-4]
-            scale = np.min(diffs) / 1.049
-            if np.all(diffs > par.err * 1.049) and np.all(diffs < scale * 1.5):
+            par.range_min, par.range_max = q[row, 0], q[row, 1]
+            scale = scale_v[row]
+            if flat_v[row]:
                 par.sigma_range = scale  # very flat
             else:
                 par.sigma_range = min(par.err, scale)
@@ -2297,6 +2339,7 @@ class MCSamples:
             # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
             max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 320))))
             batches = []
+            first_batch = int(os.environ.get("GETDIST_AMD_FIRST_BATCH", 128))
             gk = group_v[mem]
             frame = {w_: next_fft_size(F + 2 * w_) for w_ in np.unique(winw_v[mem]).tolist()}
             S_v = np.array([frame[w_] for w_ in winw_v[mem].tolist()], dtype=np.int64)
@@ -2311,8 +2354,14 @@ class MCSamples:
                         carry = cur
                         continue
                     carry = []
-                    for s0 in range(0, len(cur), max_batch):
-                        batches.append(cur[s0:s0 + max_batch])
+                    # a short first batch starts the result copies early; from then on a batch's copy (PCIe) is shorter
+                    # than the next batch's kernels, so only the last batch's copy is exposed
+                    s0 = 0
+                    if not batches and len(cur) > first_batch:
+                        batches.append(cur[:first_batch])
+                        s0 = first_batch
+                    for s1 in range(s0, len(cur), max_batch):
+                        batches.append(cur[s1:s1 + max_batch])
             if mask_function is not None:
                 batches = [[item] for b in batches for item in b]  # the callback edits one pair's mask at a time
             for sel in batches:
@@ -2392,7 +2441,8 @@ class MCSamples:
                         and os.environ.get("GETDIST_AMD_ASYNC_CONVOLVE", "1") == "1")
         release = []
         status_all, status_at = (ctx.pinned_array((npair,), np.int32) if enqueue_only else None), [0]
-        for F, (d_hist, members) in hists.items():
+        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
+        for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
             run_class(F, d_hist, members)
         release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
         synced = False
@@ -2412,6 +2462,12 @@ class MCSamples:
             return ax_cache[key]
 
         ncont = None
+        # With every batch enqueued without waiting, the call may return while the last result copies are still in
+        # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
+        lazy = (enqueue_only and not synced and get_density and hasattr(ctx, "copy_mark")
+                and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
+        completion = _PendingResults(ctx, inflight, release) if lazy else None
+        waiter = completion.wait if lazy else None
         for d_P, P, ks, status, d_L, L, levels in inflight:
             F = P.shape[1]
             lev_state = None if levels is None else np.asarray(levels[1]).tolist()
@@ -2429,13 +2485,16 @@ class MCSamples:
                         ncont = levels[0].shape[1]
                 dens = Density2D._from_fields(dict(
                     x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=e.get("mask"),
-                    likes=None if L is None else L[row], contours=contours, spl=None, P=P[row],
+                    likes=None if L is None else L[row], contours=contours, spl=None, _P=P[row], _wait=waiter,
                     bandwidth=e.get("bandwidth"), bandwidth_branch=e.get("branch"), kopt=e.get("kopt")))
                 if contours is None and lev_state is not None:
                     # more exactly equal grid values at the level than the kernel's tie list holds
                     dens.contours = dens.getContourLevels(self.contours[:ncont])
                 out[k] = dens
         _ph_asm.__exit__()
+        if lazy:
+            self._pending_results = completion  # finished by the next batched call at the latest
+            return out
         if not synced:
             with _Phase(self, "2d.d2h_wait"):
                 ctx.copy_sync()

@@ -53,6 +53,12 @@ int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
  * (gd_host_alloc).  gd_copy_sync waits for all such copies. */
 int gd_memcpy_d2h_async(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
 int gd_copy_sync(gd_ctx* ctx);
+/* gd_copy_mark: a point on the copy stream after every copy (and all compute-stream work) issued so far;
+ * gd_copy_wait blocks until that point has been reached -- the caller's own result copies, not later ones (a batch
+ * of results can be delivered while the next batch already computes).  16 marks are kept; an older token waits for
+ * the newer mark that replaced it. */
+int gd_copy_mark(gd_ctx* ctx, int32_t* token_out);
+int gd_copy_wait(gd_ctx* ctx, int32_t token);
 int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes);
 int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
 /* d_dst[k] = d_src[index[k]] for `count` items of item_bytes each (item_bytes % 16 == 0), one kernel launch;

@@ -1,9 +1,7 @@
 mkdir -p gpurun_out; cd /root/repo
-timeout 600 python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r02_pytest_gpu.log
-timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | cut -c1-330
-export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/r02_prof_bench.json 2> gpurun_out/r02_prof_bench.err; echo "prof rc=$?"
-find /tmp/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r02_bench_kernel_stats.csv \;
-find /tmp/prof -name "*kernel_trace.csv" -exec cp {} gpurun_out/r02_bench_kernel_trace.csv \;
-for W in 8 2; do timeout 200 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --emulate-world $W > gpurun_out/r02_emu$W.json 2>/dev/null; python -c "
-import json;d=json.load(open('gpurun_out/r02_emu$W.json'));print($W, d['ms_per_step'])"; done
+timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | cut -c1-420
+GETDIST_AMD_LAZY_RESULTS=0 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | python -c "
+import sys,json;d=json.loads(sys.stdin.read());print('eager', d['ms_per_step'], d['ms_single_triangle_latency'])"
+timeout 700 python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02_pytest_gpu.log
+python -c "
+import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
