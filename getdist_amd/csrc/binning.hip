@@ -544,6 +544,64 @@ __global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N,
     }
 }
 
+// Several sheared pairs share their columns (a correlated block of 5 parameters gives 10 pairs over 5 columns): a group
+// of <= 16 pairs over <= 8 distinct columns reads each column ONCE.  Every thread parks its 16-B loads in its own LDS
+// slots (LDS as indexable per-thread storage: no barrier) and evaluates the pairs from there.
+#define MMG_COLS 8
+#define MMG_PAIRS 16
+struct MinmaxGroup {
+    const double* col[MMG_COLS];
+    double r0[MMG_PAIRS], r1[MMG_PAIRS];
+    int a[MMG_PAIRS], b[MMG_PAIRS];
+    int ncols, npairs;
+};
+
+__global__ void __launch_bounds__(256) k_minmax_affine_grouped(const MinmaxGroup* __restrict__ groups, int64_t N,
+                                                               double* __restrict__ part) {
+    __shared__ double2 slot[MMG_COLS][256];
+    __shared__ double red[16];
+    const MinmaxGroup& G = groups[blockIdx.y];
+    const int ncols = G.ncols, npairs = G.npairs;
+    double mn[MMG_PAIRS], mx[MMG_PAIRS];
+#pragma unroll
+    for (int p = 0; p < MMG_PAIRS; ++p) mn[p] = INFINITY, mx[p] = -INFINITY;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t Ne = N & ~(int64_t)1;
+    for (int64_t i = 2 * gtid; i < Ne; i += 2 * gsz) {
+        double2 v[MMG_COLS];
+#pragma unroll
+        for (int c = 0; c < MMG_COLS; ++c)
+            v[c] = (c < ncols) ? *reinterpret_cast<const double2*>(G.col[c] + i) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int c = 0; c < MMG_COLS; ++c)
+            if (c < ncols) slot[c][threadIdx.x] = v[c];
+#pragma unroll
+        for (int p = 0; p < MMG_PAIRS; ++p)
+            if (p < npairs) {
+                const double2 xv = slot[G.a[p]][threadIdx.x], yv = slot[G.b[p]][threadIdx.x];
+                const double p0 = G.r0[p] * xv.x + G.r1[p] * yv.x, p1 = G.r0[p] * xv.y + G.r1[p] * yv.y;
+                mn[p] = fmin(mn[p], fmin(p0, p1));
+                mx[p] = fmax(mx[p], fmax(p0, p1));
+            }
+    }
+    if (gtid == 0 && Ne < N) {
+#pragma unroll
+        for (int p = 0; p < MMG_PAIRS; ++p)
+            if (p < npairs) {
+                const double p0 = G.r0[p] * G.col[G.a[p]][Ne] + G.r1[p] * G.col[G.b[p]][Ne];
+                mn[p] = fmin(mn[p], p0);
+                mx[p] = fmax(mx[p], p0);
+            }
+    }
+    double* out = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * MMG_PAIRS * 2;
+#pragma unroll
+    for (int p = 0; p < MMG_PAIRS; ++p)
+        if (p < npairs) {
+            const double r0 = block_min(mn[p], red), r1 = block_max(mx[p], red);
+            if (threadIdx.x == 0) out[2 * p] = r0, out[2 * p + 1] = r1;
+        }
+}
+
 // =============================================================================================================
 template <int MODE>
 static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist, bool allow_p16 = true);
@@ -934,6 +992,76 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
         p.x = ctx->cols + (int64_t)coli[q] * ctx->ld;
         p.y = ctx->cols + (int64_t)colj[q] * ctx->ld;
         p.r0 = a[q], p.r1 = b[q];
+    }
+    if (B >= 4 && getenv("GDHIP_MINMAX_UNGROUPED") == nullptr) {
+        // groups of pairs over shared columns: each column of a group is read once
+        std::vector<int> order((size_t)B);
+        for (int q = 0; q < B; ++q) order[q] = q;
+        std::sort(order.begin(), order.end(), [&](int u, int v) {
+            const int ul = std::min(coli[u], colj[u]), uh = std::max(coli[u], colj[u]);
+            const int vl = std::min(coli[v], colj[v]), vh = std::max(coli[v], colj[v]);
+            return ul != vl ? ul < vl : (uh != vh ? uh < vh : u < v);
+        });
+        std::vector<MinmaxGroup> groups;
+        std::vector<std::vector<int>> members;  // original pair index per slot
+        std::vector<int> gcols;                 // column ids of the open group
+        auto slot_of = [&](int c) {
+            for (size_t k = 0; k < gcols.size(); ++k)
+                if (gcols[k] == c) return (int)k;
+            return -1;
+        };
+        for (int q : order) {
+            const int ci = coli[q], cj = colj[q];
+            bool open = !groups.empty();
+            if (open) {
+                const int need = (slot_of(ci) < 0) + (cj != ci && slot_of(cj) < 0);
+                open = (int)gcols.size() + need <= MMG_COLS && groups.back().npairs < MMG_PAIRS;
+            }
+            if (!open) {
+                MinmaxGroup g;
+                memset(&g, 0, sizeof g);
+                groups.push_back(g);
+                members.emplace_back();
+                gcols.clear();
+            }
+            MinmaxGroup& g = groups.back();
+            for (int c : {ci, cj})
+                if (slot_of(c) < 0) {
+                    g.col[gcols.size()] = ctx->cols + (int64_t)c * ctx->ld;
+                    gcols.push_back(c);
+                }
+            g.ncols = (int)gcols.size();
+            g.a[g.npairs] = slot_of(ci), g.b[g.npairs] = slot_of(cj);
+            g.r0[g.npairs] = a[q], g.r1[g.npairs] = b[q];
+            members.back().push_back(q);
+            ++g.npairs;
+        }
+        const int ng = (int)groups.size();
+        int nblk = (6 * ctx->cu_count + ng - 1) / ng;
+        if (nblk < 8) nblk = 8;
+        if (nblk > 1024) nblk = 1024;
+        const int64_t o_part = ((int64_t)ng * sizeof(MinmaxGroup) + 255) / 256 * 256;
+        const int64_t part_doubles = (int64_t)ng * nblk * MMG_PAIRS * 2;
+        char* base = (char*)gd_scratch(ctx, o_part + part_doubles * 8);
+        if (!base) return GD_ERR_NOMEM;
+        GD_HIP(hipMemcpyAsync(base, groups.data(), (size_t)ng * sizeof(MinmaxGroup), hipMemcpyHostToDevice, ctx->stream));
+        k_minmax_affine_grouped<<<dim3(nblk, ng), 256, 0, ctx->stream>>>((const MinmaxGroup*)base, ctx->N,
+                                                                        (double*)(base + o_part));
+        GD_KERNEL_CHECK();
+        std::vector<double> h((size_t)part_doubles);
+        GD_HIP(hipMemcpyAsync(h.data(), base + o_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GD_HIP(hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < ng; ++g)
+            for (int p = 0; p < groups[g].npairs; ++p) {
+                double mn = INFINITY, mx = -INFINITY;
+                for (int k = 0; k < nblk; ++k) {
+                    const double* v = &h[(((size_t)g * nblk + k) * MMG_PAIRS + p) * 2];
+                    if (v[0] < mn) mn = v[0];
+                    if (v[1] > mx) mx = v[1];
+                }
+                out[2 * members[g][p]] = mn, out[2 * members[g][p] + 1] = mx;
+            }
+        return GD_OK;
     }
     int nblk = (4 * ctx->cu_count + B - 1) / B;
     if (nblk < 8) nblk = 8;

@@ -215,14 +215,23 @@ __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptL
 #pragma unroll
                 for (int q = 0; q < MAXF; ++q) ax[q] = ay[q] = 0;
                 const double* col = L.tile + (j >> 7) * 128 + (j & 127);
-                for (int r = g; r < nr; r += 8) {
-                    const double2 a = *reinterpret_cast<const double2*>(col + r * nseg * 128);
+                // two rows per step: the row weights of a form are adjacent, so one 16-B broadcast read serves both
+                // (with one row per step the phase was bound by the LDS issue rate, not by the FMAs)
+                for (int r = 2 * g; r < nr; r += 16) {
+                    const double2 a0 = *reinterpret_cast<const double2*>(col + r * nseg * 128);
+                    const bool two = r + 1 < nr;
+                    const double2 a1 = two ? *reinterpret_cast<const double2*>(col + (r + 1) * nseg * 128)
+                                           : make_double2(0.0, 0.0);
 #pragma unroll
                     for (int q = 0; q < MAXF; ++q)
                         if (q < m) {
-                            const double wyq = L.wy[q * F + r0 + r];
-                            ax[q] = fma(wyq, a.x, ax[q]);
-                            ay[q] = fma(wyq, a.y, ay[q]);
+                            // r0 + r is even and F is even: 16-B aligned
+                            const double2 wyq = *reinterpret_cast<const double2*>(L.wy + q * F + r0 + r);
+                            ax[q] = fma(wyq.x, a0.x, ax[q]);
+                            ay[q] = fma(wyq.x, a0.y, ay[q]);
+                            const double wy1 = two ? wyq.y : 0.0;  // never 0 x NaN from the neighbouring words
+                            ax[q] = fma(wy1, a1.x, ax[q]);
+                            ay[q] = fma(wy1, a1.y, ay[q]);
                         }
                 }
 #pragma unroll

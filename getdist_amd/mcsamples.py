@@ -1950,21 +1950,6 @@ class MCSamples:
             e["kopt"] = None
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
 
-        def to_param_units(branch, k, r1, r2, solved):
-            hx, hy, c = solved
-            e = plan[k]
-            if branch == "A":  # de-rotate the sheared kernel (mcsamples.py:1379-1390)
-                hx *= r1
-                hy *= r2
-                S = e["S"]
-                kernelC = S.dot(np.array([[hx**2, hx * hy * c], [hx * hy * c, hy**2]])).dot(S.T)
-                hx, hy, c = (np.sqrt(kernelC[0, 0]), np.sqrt(kernelC[1, 1]),
-                             kernelC[0, 1] / np.sqrt(kernelC[0, 0] * kernelC[1, 1]))
-                if e["pary"].has_limits:
-                    hx, hy = hy, hx
-                return hx, hy, c
-            return hx * e["rangex"], hy * e["rangey"], c
-
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
         if shear is None:
@@ -1990,15 +1975,36 @@ class MCSamples:
             hy_l = (out[:, 9] * np.array([plan[k]["rangey"] for k in ks])).tolist()
             c_l = out[:, 10].tolist()
             bad = no_root.tolist()
+            # branch A: de-rotate the sheared kernels (mcsamples.py:1379-1390), kernelC = S K S^T written out for the
+            # 2x2 case and evaluated on all sheared pairs at once
+            rows_A = [row for row, (br, _, _, _) in enumerate(rows) if br == "A"]
+            if rows_A:
+                ra = np.array(rows_A)
+                hxa = out[ra, 8] * np.array([rows[r][2] for r in rows_A])
+                hya = out[ra, 9] * np.array([rows[r][3] for r in rows_A])
+                ca = out[ra, 10]
+                S = np.array([plan[rows[r][1]]["S"] for r in rows_A])  # (nA, 2, 2)
+                k00, k01, k11 = hxa**2, hxa * hya * ca, hya**2
+                t00 = S[:, 0, 0] * k00 + S[:, 0, 1] * k01
+                t01 = S[:, 0, 0] * k01 + S[:, 0, 1] * k11
+                t10 = S[:, 1, 0] * k00 + S[:, 1, 1] * k01
+                t11 = S[:, 1, 0] * k01 + S[:, 1, 1] * k11
+                c00 = t00 * S[:, 0, 0] + t01 * S[:, 0, 1]
+                c01 = t00 * S[:, 1, 0] + t01 * S[:, 1, 1]
+                c11 = t10 * S[:, 1, 0] + t11 * S[:, 1, 1]
+                sx, sy = np.sqrt(c00), np.sqrt(c11)
+                cc_a = (c01 / np.sqrt(c00 * c11)).tolist()
+                swap = [bool(plan[rows[r][1]]["pary"].has_limits) for r in rows_A]
+                for pos, row in enumerate(rows_A):
+                    a_, b_ = (sy[pos], sx[pos]) if swap[pos] else (sx[pos], sy[pos])
+                    hx_l[row], hy_l[row], c_l[row] = float(a_), float(b_), cc_a[pos]
             for row, ((br, k, r1, r2), kopt_row) in enumerate(zip(rows, out)):
                 e = plan[k]
                 e["kopt"] = kopt_row
                 if bad[row]:
                     results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                elif br == "C":
-                    results[k] = (hx_l[row], hy_l[row], c_l[row])
                 else:
-                    results[k] = to_param_units(br, k, r1, r2, tuple(out[row, 8:11]))
+                    results[k] = (hx_l[row], hy_l[row], c_l[row])
 
         # -- branches A and C share the device optimiser: the sheared histograms ride in the same launch as the
         #    base-grid pairs' own histograms (one block per pair; a short extra launch would cost a full block latency)
@@ -2159,6 +2165,14 @@ class MCSamples:
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
         names = self.paramNames.names
+        # the N_eff kernels need nothing but the parameter ranges: they are started first, from the helper thread, and
+        # run while the per-pair scalars below are worked out
+        neff_f = None
+        if (smooth_scale_2D < 0 and _bandwidths is None and not self._timing and not self.use_effective_samples_2D
+                and self._lane == 0 and not meanlikes and len(pairs) >= 64
+                and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"
+                and any(names[j].N_eff_kde is None for j in used)):
+            neff_f = self._helper().submit(self._neff_batch, used)
         corrmat = self.getCorrelationMatrix()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
@@ -2238,10 +2252,7 @@ class MCSamples:
             # entry points: the N_eff kernels (exp-bound) on this context, the byte-index binning (LDS-bound) on the
             # second context (own stream and scratch over the same resident samples), then the sheared re-binning
             # (HBM-bound) on this context again; the per-pair records and the branch selection are built meanwhile.
-            need_neff = any(names[j].N_eff_kde is None for j in used)
-            if (need_neff and self._lane == 0 and not meanlikes and len(pairs) >= 64
-                    and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
-                neff_f = self._helper().submit(self._neff_batch, used)
+            if neff_f is not None:
                 twin = self._second_lane()
                 self._nlanes = 1  # only the binning is shared out
                 pending = self._lane_thread(twin).submit(binning, twin)

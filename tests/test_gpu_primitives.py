@@ -174,6 +174,22 @@ def test_sheared_hist_and_minmax(ctx, data):
     assert np.allclose(H, ref, rtol=1e-12, atol=1e-12)
 
 
+def test_minmax_affine_groups_of_pairs_over_shared_columns(ctx, data):
+    """Batches of >= 4 sheared pairs are evaluated in groups that read each shared column once: every pair's min / max
+    must still be the exact min / max of r0*x_i + r1*x_j (same fp64 operations, no contraction), whatever the grouping."""
+    s, w, _ = data
+    n = s.shape[1]
+    rng = np.random.default_rng(11)
+    # correlated-block pattern (many pairs over few columns), a long random tail (forces several groups), a repeated pair
+    pairs = [(i, j) for i in range(min(n, 5)) for j in range(i)] + [tuple(rng.choice(n, 2, replace=False)) for _ in range(37)]
+    pairs += [pairs[0], (1, 1)]
+    r = rng.normal(size=(len(pairs), 2))
+    mm = ctx.minmax_affine([p[0] for p in pairs], [p[1] for p in pairs], r[:, 0], r[:, 1])
+    for k, (i, j) in enumerate(pairs):
+        p2 = r[k, 0] * s[:, i] + r[k, 1] * s[:, j]
+        assert mm[k, 0] == p2.min() and mm[k, 1] == p2.max(), (k, i, j)
+
+
 def test_lag_sums(ctx, data):
     s, w, _ = data
     x = s[:, 2]
