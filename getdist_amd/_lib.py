@@ -481,8 +481,12 @@ class Context:
         """B histograms of 256 x 256 bins from byte index columns (unit weights); raises GdhipError(-5) on counter wrap."""
         B = len(idx_x)
         out = out or self.alloc(B * 65536 * 8)
-        ax = (_p * B)(*[b.ptr for b in idx_x])
-        ay = (_p * B)(*[b.ptr for b in idx_y])
+        if isinstance(idx_x, np.ndarray):  # device addresses already gathered (uint64), e.g. from a per-column table
+            px, py = np.ascontiguousarray(idx_x, dtype=np.uint64), np.ascontiguousarray(idx_y, dtype=np.uint64)
+            ax, ay = px.ctypes.data_as(C.POINTER(_p)), py.ctypes.data_as(C.POINTER(_p))
+        else:
+            ax = (_p * B)(*[b.ptr for b in idx_x])
+            ay = (_p * B)(*[b.ptr for b in idx_y])
         self._check(self.lib.gd_hist2d_prebinned8(self.h, B, ax, ay, out.ptr))
         return out
 

@@ -223,6 +223,17 @@ def _stack_rows(parts):
     return out
 
 
+_HOSTLOG = [] if os.environ.get("GETDIST_AMD_HOSTLOG") else None
+
+
+def _hostlog(what):
+    """Host-side timeline of a batched call (GETDIST_AMD_HOSTLOG=1; read by scripts and tests only)."""
+    if _HOSTLOG is not None:
+        import time
+
+        _HOSTLOG.append((time.perf_counter(), what))
+
+
 class _PendingResults:
     """
     The tail of a batched 2D call whose result copies are still in flight: the device grids, the inputs that must not
@@ -2037,9 +2048,13 @@ class MCSamples:
         if shear is not None:
             shear["d_rot"].free()
         if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416)
+            scale_of = {}  # few distinct N_eff values (one per parameter)
             for k in range(len(plan)):
                 hx, hy, c = results[k]
-                scale = 1.1 * plan[k]["neff"] ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
+                ne = plan[k]["neff"]
+                scale = scale_of.get(ne)
+                if scale is None:
+                    scale = scale_of[ne] = 1.1 * ne ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
                 results[k] = (hx * scale, hy * scale, c)
         return results
 
@@ -2162,6 +2177,7 @@ class MCSamples:
         if bco > 1:
             raise SettingError("unknown boundary_correction_order (expected 0 or 1)")
         ctx = self.ctx
+        _hostlog("lane start")
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
         names = self.paramNames.names
@@ -2226,9 +2242,13 @@ class MCSamples:
                     if ok:
                         try:
                             with _Phase(self, "2d.hist"):
-                                hists[F] = (owner.ctx.hist2d_prebinned8([owner._idx_cols[(pj[k], 256, "u8")][0] for k in members],
-                                                                        [owner._idx_cols[(pj2[k], 256, "u8")][0] for k in members]),
-                                            members)
+                                # device addresses per pair from a per-column table (this runs on a helper thread
+                                # while the main thread is in Python: as little interpreter work here as possible)
+                                table = np.zeros(max(wanted) + 1, dtype=np.uint64)
+                                for j in wanted:
+                                    table[j] = owner._idx_cols[(j, 256, "u8")][0].ptr
+                                mem = np.asarray(members, dtype=np.int64)
+                                hists[F] = (owner.ctx.hist2d_prebinned8(table[jx[mem]], table[jy[mem]]), members)
                             continue
                         except GdhipError as e:
                             if e.code != -5:  # a 16-bit counter wrapped: the u16 / u32 path below redoes the class
@@ -2282,6 +2302,7 @@ class MCSamples:
             build_info()
             binning()
         # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
+        _hostlog("binning / N_eff / plan joined")
         npair = len(info)
         fwx_v = np.array([e["fwx"] for e in info], dtype=np.float64)
         fwy_v = np.array([e["fwy"] for e in info], dtype=np.float64)
@@ -2448,6 +2469,7 @@ class MCSamples:
                 # the copy runs on the copy stream while the next batch computes
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
 
+        _hostlog("bandwidths done")
         enqueue_only = (hasattr(ctx, "density2d_enqueue") and not self._timing and not meanlikes and mask_function is None
                         and os.environ.get("GETDIST_AMD_ASYNC_CONVOLVE", "1") == "1")
         release = []
@@ -2456,6 +2478,7 @@ class MCSamples:
         for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
             run_class(F, d_hist, members)
         release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
+        _hostlog("all batches enqueued")
         synced = False
         if any(lv is not None and np.any(lv[1] == -5) for *_, lv in inflight):  # a grid left to the host reads P
             ctx.copy_sync()
@@ -2503,6 +2526,7 @@ class MCSamples:
                     dens.contours = dens.getContourLevels(self.contours[:ncont])
                 out[k] = dens
         _ph_asm.__exit__()
+        _hostlog("results assembled")
         if lazy:
             self._pending_results = completion  # finished by the next batched call at the latest
             return out
