@@ -351,12 +351,15 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                                                   pairs=sh) for sh in shares if sh], chunksize=1).get(timeout=args.cpu_budget_s)
             wall_cpu = time.perf_counter() - t0
             mc2 = MCSamples(samples=s2, weights=w2, names=names2, ranges=ranges2, device=mc._device)
-            mc2.get2DDensities(pairs_all)
-            reset_caches(mc2)
+            for _ in range(3):  # plans, page-locked result blocks and the second set of device blocks exist afterwards
+                mc2.get2DDensities(pairs_all)
+                reset_caches(mc2)
             mc2.ctx.sync()
+            mc2.ctx.copy_sync()
             t0 = time.perf_counter()
             mc2.updateBaseStatistics()
             d2 = mc2.get2DDensities(pairs_all)
+            d2[-1].P  # waits for the result copies of this call
             mc2.ctx.sync()
             wall_gpu = time.perf_counter() - t0
             gpu_sums = {pr: float(np.sum(d.P)) for pr, d in zip(pairs_all, d2)}

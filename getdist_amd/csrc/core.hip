@@ -17,13 +17,20 @@ int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     gd_ctx::StageSlot& sl = ctx->stage[ctx->stage_next];
     ctx->stage_next = (ctx->stage_next + 1) % gd_ctx::kStageSlots;
     if (sl.used) GD_HIP(hipEventSynchronize(sl.ev));  // the copy that last read this slot has executed
-    if (sl.cap < bytes) {
-        if (sl.host) GD_HIP(hipHostFree(sl.host));
-        sl.host = nullptr;
-        sl.cap = bytes < (64u << 10) ? (64u << 10) : bytes;
-        GD_HIP(hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault));
+    if (!ctx->stage_block) {  // one page-locked block serves the usual small tables of all slots (one hipHostMalloc)
+        GD_HIP(hipHostMalloc(&ctx->stage_block, (size_t)gd_ctx::kStageSlots * gd_ctx::kStageBytes, hipHostMallocDefault));
+        for (int k = 0; k < gd_ctx::kStageSlots; ++k) {
+            ctx->stage[k].host = (char*)ctx->stage_block + (size_t)k * gd_ctx::kStageBytes;
+            ctx->stage[k].cap = gd_ctx::kStageBytes;
+            GD_HIP(hipEventCreateWithFlags(&ctx->stage[k].ev, hipEventDisableTiming));
+        }
     }
-    if (!sl.ev) GD_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.cap < bytes) {  // an unusually large table: a private block for this slot
+        if (sl.own) GD_HIP(hipHostFree(sl.host));
+        sl.host = nullptr, sl.own = false;
+        GD_HIP(hipHostMalloc(&sl.host, bytes, hipHostMallocDefault));
+        sl.cap = bytes, sl.own = true;
+    }
     memcpy(sl.host, src, bytes);
     GD_HIP(hipMemcpyAsync(d_dst, sl.host, bytes, hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipEventRecord(sl.ev, ctx->stream));
@@ -103,9 +110,10 @@ void gd_destroy(gd_ctx* ctx) {
     for (auto& ev : ctx->copy_marks)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->stage) {
-        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.own && sl.host) (void)hipHostFree(sl.host);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
+    if (ctx->stage_block) (void)hipHostFree(ctx->stage_block);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamSynchronize(ctx->copy_stream);

@@ -52,7 +52,10 @@ struct gd_ctx {
         size_t cap = 0;
         hipEvent_t ev = nullptr;
         bool used = false;
+        bool own = false;  // host is a private allocation (table larger than kStageBytes), not a slice of stage_block
     };
+    static constexpr size_t kStageBytes = 64u << 10;
+    void* stage_block = nullptr;
     // marks on the copy stream (gd_copy_mark / gd_copy_wait): a caller waits for ITS result copies only
     static constexpr int kCopyMarks = 16;
     hipEvent_t copy_marks[kCopyMarks] = {};
