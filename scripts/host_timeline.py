@@ -1,3 +1,4 @@
+"""Host-side timeline of one bench step on the GPU box (GETDIST_AMD_HOSTLOG hooks in getdist_amd/mcsamples.py)."""
 import os, sys, time
 os.environ["GETDIST_AMD_HOSTLOG"] = "1"
 sys.path.insert(0, ".")
