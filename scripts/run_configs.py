@@ -79,6 +79,7 @@ def run_c5(N=2_000_000, n=200):
     t_marge = time.perf_counter() - t0
     t0 = time.perf_counter()
     pairs, dens = mc.triangleDensities()
+    dens[-1].P  # results are delivered lazily: the first read waits for this call's copies
     mc.ctx.sync()
     t_tri = time.perf_counter() - t0
     ok = all(d is not None and d.P.max() == 1.0 for d in dens)
@@ -100,7 +101,7 @@ def run_latency(N=10_000_000, n=10):
         mc.get2DDensity(a, b)
     t0 = time.perf_counter()
     for a, b in pairs[5:45]:
-        mc.get2DDensity(a, b)
+        mc.get2DDensity(a, b).P
     t2 = (time.perf_counter() - t0) / 40
     mc.get1DDensity(0)
     t0 = time.perf_counter()
@@ -108,7 +109,7 @@ def run_latency(N=10_000_000, n=10):
         mc.get1DDensity(j)
     t1 = (time.perf_counter() - t0) / (n - 1)
     t0 = time.perf_counter()
-    mc.get2DDensities(pairs)
+    mc.get2DDensities(pairs)[-1].P
     tb = (time.perf_counter() - t0) / len(pairs)
     return dict(config="latency", N=N, n=n, get2DDensity_ms=round(t2 * 1e3, 3), get1DDensity_ms=round(t1 * 1e3, 3),
                 batched_2d_ms_per_pair=round(tb * 1e3, 3))
