@@ -1022,7 +1022,10 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     const bool slab = (m <= 208) && !getenv("GDHIP_COV_TILE");
     if (slab) {
         // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
-        constexpr int KS = 32;
+        // rows per slab: 32.  (64 for the narrow variant -- 512-B runs per column, 16 loads in flight per lane -- was
+        // measured slower, 4.5 vs 3.1 ms at m = 50: 142 VGPRs leave three blocks per CU instead of four; GDHIP_COV_KS64
+        // selects it.)
+        const int KS = (m <= 64 && getenv("GDHIP_COV_KS64")) ? 64 : 32;
         const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2;
         // enough resident blocks per CU that the next slab's loads (HBM latency ~2 us) hide behind other blocks' MFMAs:
         // the 64-column variant fits four blocks per CU, the 112-column one two, the 208-column one one (8 waves)
@@ -1047,20 +1050,22 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
         if (rc) return rc;
         const bool hw = ctx->w != nullptr;
-#define GD_COV_LAUNCH(HW, MCAP, NW, MAXP)                                                                              \
+#define GD_COV_LAUNCH(HW, MCAP, NW, MAXP, KSV)                                                                         \
     do {                                                                                                               \
-        const size_t lds = (size_t)((HW) ? 2 : 1) * (MCAP) * (KS + 2) * 8;                                             \
-        GD_HIP(hipFuncSetAttribute((const void*)k_cov_slab<HW, MCAP, NW, MAXP, KS>,                                    \
+        const size_t lds = (size_t)((HW) ? 2 : 1) * (MCAP) * ((KSV) + 2) * 8;                                          \
+        GD_HIP(hipFuncSetAttribute((const void*)k_cov_slab<HW, MCAP, NW, MAXP, KSV>,                                   \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-        k_cov_slab<HW, MCAP, NW, MAXP, KS><<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res,  \
-                                                                               ctx->w, lo, hi, rows_per_chunk, d_cpart); \
+        k_cov_slab<HW, MCAP, NW, MAXP, KSV><<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, \
+                                                                                ctx->w, lo, hi, rows_per_chunk, d_cpart); \
     } while (0)
-        if (m <= 64) {
-            if (hw) GD_COV_LAUNCH(true, 64, 4, 3); else GD_COV_LAUNCH(false, 64, 4, 3);
+        if (m <= 64 && KS == 64) {
+            if (hw) GD_COV_LAUNCH(true, 64, 4, 3, 64); else GD_COV_LAUNCH(false, 64, 4, 3, 64);
+        } else if (m <= 64) {
+            if (hw) GD_COV_LAUNCH(true, 64, 4, 3, 32); else GD_COV_LAUNCH(false, 64, 4, 3, 32);
         } else if (m <= 112) {
-            if (hw) GD_COV_LAUNCH(true, 112, 8, 4); else GD_COV_LAUNCH(false, 112, 8, 4);
+            if (hw) GD_COV_LAUNCH(true, 112, 8, 4, 32); else GD_COV_LAUNCH(false, 112, 8, 4, 32);
         } else {
-            if (hw) GD_COV_LAUNCH(true, 208, 8, 12); else GD_COV_LAUNCH(false, 208, 8, 12);
+            if (hw) GD_COV_LAUNCH(true, 208, 8, 12, 32); else GD_COV_LAUNCH(false, 208, 8, 12, 32);
         }
 #undef GD_COV_LAUNCH
         GD_KERNEL_CHECK();
