@@ -606,7 +606,10 @@ class OracleSamples:
         samples = np.asarray(samples, dtype=np.float64)
         if samples.ndim == 1:
             samples = samples.reshape(-1, 1)
-        self.samples = samples
+        # The reference always ends up holding the samples column-major: deleteFixedParams (chains.py:1544-1560) goes
+        # through np.delete(samples, fixed, 1), whose fancy indexing along axis 1 returns a Fortran-ordered copy.  BLAS
+        # sums in a layout-dependent order, so the moments are bit-identical only in the same layout.
+        self.samples = np.asfortranarray(samples)
         self.numrows, self.n = samples.shape
         # chains.py:310-316
         if weights is not None:
