@@ -185,6 +185,9 @@ __device__ void bilinear_forms_reg(const double* __restrict__ M, int F, int m, K
 // at ~2 us per access: with register loads a block has 16 KB in flight and the launch crawls at 1.8 TB/s (PMC: 89 % L2
 // misses, 15.5 GB per 1200 pairs).  Here whole rows go straight into LDS (global_load_lds_dwordx4: one 1-KB row segment
 // per wave instruction, no VGPRs), up to 128 KB per tile in flight; the forms are then accumulated from LDS.
+// (Tried and measured slower: two 64-KB buffers with asm-issued loads and hand-placed s_waitcnt vmcnt(4) so that tile
+// t+1 streams in while tile t is accumulated -- 11.4 vs 5.8 ms for 1200 pairs: twice the barriers per pass cost more
+// than the overlap gains; and the fallbacks as noinline calls -- 8.4 ms.)
 __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
     if (L.tile == nullptr) {
         bilinear_forms_reg(M, F, m, L, kmax);
