@@ -187,7 +187,11 @@ __device__ void bilinear_forms_reg(const double* __restrict__ M, int F, int m, K
 // per wave instruction, no VGPRs), up to 128 KB per tile in flight; the forms are then accumulated from LDS.
 // (Tried and measured slower: two 64-KB buffers with asm-issued loads and hand-placed s_waitcnt vmcnt(4) so that tile
 // t+1 streams in while tile t is accumulated -- 11.4 vs 5.8 ms for 1200 pairs: twice the barriers per pass cost more
-// than the overlap gains; and the fallbacks as noinline calls -- 8.4 ms.)
+// than the overlap gains; the fallbacks as noinline calls -- 8.4 ms; and barrier-free wave-private row rings (each wave
+// streams its own rows with counted vmcnt waits) -- 7.6 ms, while merely carrying that extra code path slowed THIS one
+// from 5.8 to 7.8 ms: the kernel sits at the 128-VGPR limit with ~650 B of scratch per lane, and every variant that adds
+// live state or code pays for it in spills.  The next step is to split the solver into smaller kernels, not to tune
+// this loop further.)
 __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptLds L, int kmax) {
     if (L.tile == nullptr) {
         bilinear_forms_reg(M, F, m, L, kmax);
