@@ -9,7 +9,9 @@
 #include "ctx.hpp"
 #include "solvers.hpp"
 
-#define KT 1024
+#ifndef KT
+#define KT 512  // threads per pair: 512 leave 176 VGPRs and no spills (1024: 128 VGPRs, ~170 B spilled per lane; measured 5.8 -> 5.4 ms)
+#endif
 #define MAXF 6  // forms per level
 #ifdef KOPT_PROFILE
 __device__ long long g_prof[8];  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
@@ -224,7 +226,7 @@ __device__ void bilinear_forms(const double* __restrict__ M, int F, int m, KoptL
                 const double* col = L.tile + (j >> 7) * 128 + (j & 127);
                 // two rows per step: the row weights of a form are adjacent, so one 16-B broadcast read serves both
                 // (with one row per step the phase was bound by the LDS issue rate, not by the FMAs)
-                for (int r = 2 * g; r < nr; r += 16) {
+                for (int r = 2 * g; r < nr; r += 2 * (KT / 128)) {
                     const double2 a0 = *reinterpret_cast<const double2*>(col + r * nseg * 128);
                     const bool two = r + 1 < nr;
                     const double2 a1 = two ? *reinterpret_cast<const double2*>(col + (r + 1) * nseg * 128)
@@ -274,7 +276,7 @@ __device__ void bilinear_forms_reg(const double* __restrict__ M, int F, int m, K
     // of independent loads in flight: 8 rows (16-B loads) are requested before the first is consumed.
     constexpr int U = KOPT_U;
     const int jx = threadIdx.x & 127, g = threadIdx.x >> 7;
-    const int rows_per = (kmax + 7) / 8;
+    const int rows_per = (kmax + KT / 128 - 1) / (KT / 128);
     const int r_lo = g * rows_per, r_hi = min(kmax, r_lo + rows_per);
     double val[MAXF];
 #pragma unroll
@@ -704,7 +706,9 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
     size_t tile_bytes = 0;
     if (F % 128 == 0 && getenv("GDHIP_KOPT_NO_LDS_TILE") == nullptr) {
         const size_t room = (size_t)160 * 1024 - 1024 - lds_base;
-        tile_bytes = room < (size_t)128 * 1024 ? room : (size_t)128 * 1024;
+        size_t cap = (size_t)128 * 1024;
+        if (const char* e = getenv("GDHIP_KOPT_TILE_KB")) cap = (size_t)atoi(e) * 1024;  // tuning knob
+        tile_bytes = room < cap ? room : cap;
         tile_bytes = tile_bytes / ((size_t)F * 8) * ((size_t)F * 8);  // whole rows even when every segment is needed
     }
     const size_t lds = lds_base + tile_bytes;
