@@ -2486,14 +2486,20 @@ class MCSamples:
         _ph_asm = _Phase(self, "2d.host_assemble_results")
         _ph_asm.__enter__()
         # the result objects only hold views of the page-locked arrays, so they are built while the last copies land
+        # the grid axes of every (parameter, F) in use, all at once: np.linspace(lo, hi, F) written out
+        # (k * step + start, last point = stop) on one 2D array per F
         ax_cache = {}
+        for F_ in set(pF):
+            js_ = sorted({j for j, f in zip(pj, pF) if f == F_} | {j for j, f in zip(pj2, pF) if f == F_})
+            lo_ = np.array([edge_of[(j, F_)][1] for j in js_], dtype=np.float64)
+            hi_ = np.array([edge_of[(j, F_)][2] for j in js_], dtype=np.float64)
+            A = np.arange(F_, dtype=np.float64)[None, :] * ((hi_ - lo_) / (F_ - 1))[:, None] + lo_[:, None]
+            A[:, -1] = hi_
+            for row, j in enumerate(js_):
+                ax_cache[(j, F_)] = (A[row], A[row, 1] - A[row, 0], (names[j].range_min, names[j].range_max))
 
         def axis_of(j, par, lo, hi, F):
-            key = (j, F)
-            if key not in ax_cache:
-                a = np.linspace(lo, hi, F)
-                ax_cache[key] = (a, a[1] - a[0], (par.range_min, par.range_max))
-            return ax_cache[key]
+            return ax_cache[(j, F)]
 
         ncont = None
         # With every batch enqueued without waiting, the call may return while the last result copies are still in
