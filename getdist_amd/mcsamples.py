@@ -251,7 +251,7 @@ class _PendingResults:
         if self.done:
             return
         self.done = True
-        if self.ctx.h is None:
+        if getattr(self.ctx, "h", True) is None:  # the context was closed: its memory is gone with it
             return
         self.ctx.copy_wait(self.token)
         failed = any(np.any(np.asarray(status) != 0) for _, _, _, status, _, _, _ in self.inflight)

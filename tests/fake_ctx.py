@@ -51,6 +51,12 @@ class FakeContext:
     def copy_sync(self):
         pass
 
+    def copy_mark(self):  # the double completes every copy at once, so the lazy-delivery code runs on it unchanged
+        return 0
+
+    def copy_wait(self, token):
+        pass
+
     def reserve_pinned_twin(self):
         pass
 
