@@ -298,6 +298,14 @@ class Density2D(GridDensity):
     def P(self, value):
         self.__dict__["_P"] = value
 
+    def __getstate__(self):
+        """Pickling / copying completes the grid first; the waiter (bound to a device context) is not part of the state."""
+        self.P
+        state = dict(self.__dict__)
+        state.pop("_wait", None)
+        state["spl"] = None
+        return state
+
     @classmethod
     def _from_fields(cls, fields):
         """Batch constructor used for whole triangles: ``fields`` becomes the instance dictionary (the caller supplies

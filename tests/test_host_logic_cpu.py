@@ -611,3 +611,21 @@ def test_row_partitioned_base_statistics_pool_to_the_single_process_values():
                 assert np.isclose(m._sum_w2, ref._sum_w2, rtol=1e-13) and m.max_mult == ref.max_mult
                 d = m.get1DDensity(names[3])
                 assert np.max(np.abs(d.P - ref.get1DDensity(names[3]).P)) < 1e-9
+
+
+def test_lazy_results_pickle_and_copy(zoo):
+    """Results of the batched call carry a waiter until their grid is first read; pickling and deep-copying complete
+    the grid and leave the waiter (and the device context behind it) out of the state."""
+    import copy
+    import pickle
+
+    fx = zoo["c1_bounded"]
+    mc = make(fx)
+    d = mc.get2DDensities([(0, 1), (2, 3)])
+    assert d[0].__dict__.get("_wait") is not None
+    clone = pickle.loads(pickle.dumps(d[0]))
+    assert d[0].__dict__.get("_wait") is None and "_wait" not in clone.__dict__
+    assert np.array_equal(clone.P, d[0].P) and np.array_equal(clone.x, d[0].x)
+    deep = copy.deepcopy(d[1])
+    assert np.array_equal(deep.P, d[1].P) and deep.P is not d[1].P
+    assert abs(float(np.ravel(clone.Prob(clone.x[10], clone.y[20]))[0]) - clone.P[20, 10]) < 1e-9  # spline rebuilt on demand
