@@ -268,7 +268,57 @@ def golden_convergence():
     return out
 
 
+def golden_reference_unit_tests():
+    """The inputs and the asserted numbers of the reference's OWN unit tests for this path (getdist/tests/getdist_test.py):
+    testFileLoadPlot (three 4000-sample text chains of `bimodal[0]`, seed 10, reloaded with ignore_rows = 0.1:
+    GelmanRubin = 0.00052997 to 4 places) and testLimits (cut_correlated, 12000 samples, seed 10: limits 0.2077 /
+    0.0574 to 3 places, third limit one-tailed).  Stored: the chains exactly as loadMCSamples returns them (the text
+    round trip is part of the test), the sample array of testLimits, and the numbers the reference computes from them."""
+    import shutil
+    import tempfile
+
+    from getdist import loadMCSamples
+    from getdist.tests.test_distributions import Test2DDistributions
+
+    out = {}
+    rng = np.random.default_rng(10)
+    prob = Test2DDistributions().bimodal[0]
+    tmp = tempfile.mkdtemp()
+    try:
+        root = os.path.join(tmp, "testchain")
+        for n in range(3):
+            prob.MCSamples(4000, logLikes=True, random_state=rng).saveAsText(root, chain_index=n)
+        raw = loadMCSamples(root, no_cache=True)  # before the burn-in: what a loader has to deliver
+        out["fileload/samples"], out["fileload/loglikes"] = raw.samples, raw.loglikes
+        out["fileload/weights"] = raw.weights
+        out["fileload/chain_offsets"] = np.asarray(raw.chain_offsets)
+        samples = loadMCSamples(root, settings={"ignore_rows": 0.1}, no_cache=True)
+        samples.getConvergeTests(0.95)
+        out["fileload/numrows_after_burn"] = np.int64(samples.numrows)
+        out["fileload/GelmanRubin"] = np.float64(samples.GelmanRubin)
+        out["fileload/asserted"] = np.float64(0.00052997)
+    finally:
+        shutil.rmtree(tmp)
+    tl = Test2DDistributions().cut_correlated.MCSamples(12000, logLikes=False, random_state=10)
+    out["limits/samples"] = tl.samples
+    out["limits/names"] = np.array([p.name for p in tl.paramNames.names])
+    out["limits/range_lo"] = np.array([np.nan if tl.ranges.getLower(n) is None else tl.ranges.getLower(n) for n in out["limits/names"]])
+    out["limits/range_hi"] = np.array([np.nan if tl.ranges.getUpper(n) is None else tl.ranges.getUpper(n) for n in out["limits/names"]])
+    lims = tl.getMargeStats().parWithName("x").limits
+    out["limits/x_lower"] = np.array([lims[0].lower, lims[1].lower])
+    out["limits/x_onetail_lower_2"] = np.bool_(lims[2].onetail_lower)
+    out["limits/asserted"] = np.array([0.2077, 0.0574])
+    return out
+
+
 def main():
+    if "--reference-unit-tests" in sys.argv:
+        out = golden_reference_unit_tests()
+        path = os.path.join(HERE, "reference_unit_tests.npz")
+        np.savez_compressed(path, **out)
+        print("reference unit tests:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()},
+              os.path.getsize(path) // 1024, "KiB")
+        return
     if "--fixtures" in sys.argv:  # only the named fixture files (e.g. when the zoo grows)
         wanted = sys.argv[sys.argv.index("--fixtures") + 1].split(",")
         zoo = {fx["name"]: fx for fx in fixture_zoo()}

@@ -63,3 +63,32 @@ def likes_outliers(a, ref, tol=1e-6):
 
 
 MAX_LIKES_OUTLIERS = 8  # measured: at most 5 per grid in the fixture zoo (oracle/validate_against_reference.py)
+
+
+def reference_unit_test_checks(factory=None):
+    """The reference's OWN unit tests for this path (getdist/tests/getdist_test.py: testFileLoadPlot, testLimits) on its
+    own inputs (tests/golden/reference_unit_tests.npz, made by make_golden.py --reference-unit-tests): the asserted
+    numbers to the reference's assertAlmostEqual places, and the reference's actual outputs to 1e-9."""
+    import numpy as np
+
+    from getdist_amd.mcsamples import MCSamples
+
+    g = np.load(GOLDEN_DIR + "/reference_unit_tests.npz")
+    kw = {} if factory is None else dict(_context_factory=factory)
+    off = g["fileload/chain_offsets"]
+    cut = lambda a: [a[lo:hi] for lo, hi in zip(off[:-1], off[1:])]  # noqa: E731
+    mc = MCSamples(samples=cut(g["fileload/samples"]), weights=cut(g["fileload/weights"]),
+                   loglikes=cut(g["fileload/loglikes"]), names=["x", "y"], settings={"ignore_rows": 0.1}, **kw)
+    assert mc.numrows == int(g["fileload/numrows_after_burn"])
+    mc.getConvergeTests(0.95)
+    assert round(abs(mc.GelmanRubin - float(g["fileload/asserted"])), 4) == 0  # assertAlmostEqual(..., 4)
+    assert abs(mc.GelmanRubin - float(g["fileload/GelmanRubin"])) < 1e-9 * float(g["fileload/GelmanRubin"])
+    names = [str(n) for n in g["limits/names"]]
+    ranges = {n: (None if np.isnan(lo) else float(lo), None if np.isnan(hi) else float(hi))
+              for n, lo, hi in zip(names, g["limits/range_lo"], g["limits/range_hi"])}
+    tl = MCSamples(samples=g["limits/samples"], names=names, ranges=ranges, **kw)
+    lims = tl.getMargeStats().parWithName("x").limits
+    for k in (0, 1):
+        assert round(abs(lims[k].lower - float(g["limits/asserted"][k])), 3) == 0  # assertAlmostEqual(..., 3)
+        assert abs(lims[k].lower - float(g["limits/x_lower"][k])) < 1e-6
+    assert bool(lims[2].onetail_lower) == bool(g["limits/x_onetail_lower_2"])

@@ -365,3 +365,9 @@ def test_meanlikes_golden(zoo):
         # the sample weights are back: plain densities unchanged by the excursion
         d0 = mc.get1DDensityGridData(0)
         assert d0.likes is None and np.max(np.abs(d0.P - orc.density_1d(0)["P"])) < TOL_GRID
+
+
+def test_reference_unit_tests_on_the_device():
+    """The reference's own unit tests for this path on its own inputs, through the HIP library: GelmanRubin to 4 places,
+    the cut-correlated limits to 3, and the reference's actual outputs to 1e-9 / 1e-6."""
+    gu.reference_unit_test_checks()

@@ -629,3 +629,8 @@ def test_lazy_results_pickle_and_copy(zoo):
     deep = copy.deepcopy(d[1])
     assert np.array_equal(deep.P, d[1].P) and deep.P is not d[1].P
     assert abs(float(np.ravel(clone.Prob(clone.x[10], clone.y[20]))[0]) - clone.P[20, 10]) < 1e-9  # spline rebuilt on demand
+
+
+def test_reference_unit_tests_host_logic():
+    """getdist_test.py's testFileLoadPlot / testLimits numbers with the device calls played by the numpy double."""
+    gu.reference_unit_test_checks(FakeContext)
