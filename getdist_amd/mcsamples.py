@@ -453,6 +453,8 @@ class MCSamples:
         self._context_factory = _context_factory or Context
         self._device = device
         self._lane, self._nlanes = 0, 1
+        # set up front: helper threads assign these while another thread may be iterating this object's __dict__
+        self._lag_prefetch = self._pending_results = None
         self._helper_exec = None
         self._lane_exec = None
         self._twin = None
