@@ -550,7 +550,8 @@ class MCSamples:
             self._twin = twin
         self._nlanes = 2
         # settings and statistics may have changed since the twin was made: everything but the lane's own state follows
-        self._twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in own})
+        # (a snapshot: a helper thread may be adding attributes to this object at the same time)
+        self._twin.__dict__.update({k: v for k, v in list(self.__dict__.items()) if k not in own})
         return self._twin
 
     def _lane_thread(self, twin):
