@@ -58,7 +58,30 @@ def parse():
     ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
     ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock cap of each CPU-baseline pool stage; "
                     "a stage that exceeds it is abandoned and reported as such (the GPU numbers are printed regardless)")
+    ap.add_argument("--context-factory", default="", help="testing only: 'module:attr' of a Context stand-in (the CPU "
+                    "suite runs the launcher and the multi-rank step with tests/fake_ctx.py); the product path never sets it")
     return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """
+    `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-launch this very command line
+    under torch.distributed.run with one rank per GPU and hand its exit code back.  Under a launcher (the driver's
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) this is a no-op; main() then checks that the
+    communicator really has --gpus ranks.
+    """
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or args.emulate_world:
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def pair_cost_classes(mc, pairs):
@@ -395,6 +418,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
 
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -412,6 +436,10 @@ def main():
             torch_device = torch.device("cuda", local_rank)
         dist_mod.init_process_group(backend=args.backend, rank=rank, world_size=world)
         dist = dist_mod
+        world = dist.get_world_size()  # from the communicator, not from an environment default
+    if world != max(args.gpus, 1) and not args.emulate_world:
+        raise SystemExit("bench.py: --gpus %d but the communicator has %d rank(s): launch with "
+                         "`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N" % (args.gpus, world))
 
     import logging
 
@@ -423,7 +451,13 @@ def main():
     s, w, names, ranges = synth.config_c3(args.nsamples, args.nparams)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=local_rank)
+    extra = {}
+    if args.context_factory:  # CPU suite only (tests/fake_ctx.py); see parse()
+        import importlib
+
+        mod, attr = args.context_factory.split(":")
+        extra["_context_factory"] = getattr(importlib.import_module(mod), attr)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=local_rank, **extra)
     t_ctor = time.perf_counter() - t0
     pairs_all = synth.triangle_pairs(args.nparams)
 
@@ -484,6 +518,9 @@ def main():
         import torch
 
         tt = torch.tensor([elapsed], dtype=torch.float64, device=torch_device or "cpu")
+        every = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     npairs = len(pairs_all)
@@ -506,6 +543,10 @@ def main():
                                      "ms_single_triangle_latency = the same step with its grids read before the next starts",
                        "setup_s": {"generate": round(t_gen, 2), "construct_upload_basestats": round(t_ctor, 2)}},
         }
+        if dist is not None:
+            line["ranks"] = world
+            line["backend"] = "%s%s" % (args.backend, " (RCCL)" if args.backend == "nccl" else "")
+            line["ms_per_step_by_rank"] = [round(v, 3) for v in per_rank_ms]
         if args.emulate_world:
             line["emulated_world"] = args.emulate_world
             line["n_gpus"] = args.emulate_world

@@ -1046,7 +1046,14 @@ class MCSamples:
             rank, world = row_share
             per = (self.numrows + world - 1) // world
             lo, hi = min(rank * per, self.numrows), min((rank + 1) * per, self.numrows)
-            mine = self._partial_moments(lo, hi) if hi > lo else None
+            if hi > lo:
+                mine = self._partial_moments(lo, hi)
+            else:
+                # a rank without rows (N < world, or the last rank after the ceiling division) still contributes a
+                # vector of the full length, so the all-gather's shapes agree: zero norm, +inf / -inf extrema
+                n = self.n
+                mine = np.zeros(3 + 3 * n + n * n)
+                mine[3:3 + n], mine[3 + n:3 + 2 * n] = np.inf, -np.inf
             parts = exchange(mine)
             pooled = self._combine_moments([p for p in parts if p is not None and p[0] > 0])
             self.norm = np.float64(pooled["norm"]) if self.weights is not None else np.float64(self.numrows)
@@ -1058,6 +1065,12 @@ class MCSamples:
             self.mean_mult = self.norm / self.numrows
             self.max_mult = pooled["max_w"]
             self._sum_w2 = pooled["sum_w2"]
+            if self.weights is not None:  # mcsamples.py:559-562, from the pooled sums (each rank counts its own rows)
+                mult_max = (self.mean_mult * self.numrows) / min(self.numrows // 2, 500)
+                if self.max_mult > mult_max:
+                    outliers = self.ctx.weight_stats(thresh=mult_max)["n_above"]
+                    if outliers != 0:
+                        logging.warning("outlier fraction %s ", float(outliers) / self.numrows)
             self.correlationMatrix = None
             self._after_base_statistics()
             return self

@@ -77,7 +77,10 @@ def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
 
 
 def allgather_vector(vec, dist=None, device=None):
-    """All-gather one equal-length fp64 vector per rank -> list of numpy vectors (None stays None on every rank)."""
+    """All-gather one equal-length fp64 vector per rank -> list of numpy vectors.  Every rank must pass a vector of the
+    same length (a rank with nothing to contribute passes its neutral element, see updateBaseStatistics)."""
+    if vec is None:
+        raise ValueError("allgather_vector: every rank contributes a vector of the common length")
     if dist is None or dist.get_world_size() == 1:
         return [vec]
     import torch

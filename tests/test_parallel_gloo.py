@@ -190,3 +190,27 @@ def test_chain_per_rank_convergence_gloo_world2(tmp_path):
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out
         assert "rank %d ok" % rank in out
+
+
+def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
+    """`python bench.py --gpus 2` without a launcher around it re-launches itself under torch.distributed.run: the
+    JSON line reports two ranks from the communicator (gloo and the numpy context double here, RCCL on the GPU box)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "tests"), root, env.get("PYTHONPATH", "")])
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nsamples", "6000",
+           "--nparams", "10", "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--context-factory",
+           "fake_ctx:FakeContext"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and len(line["ms_per_step_by_rank"]) == 2
+    assert line["value"] > 0 and line["scaling"] == "strong"
+    # a communicator that does not have --gpus ranks is refused, not silently measured
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    bad = subprocess.run(cmd, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
