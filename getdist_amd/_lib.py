@@ -110,6 +110,10 @@ SIGNATURES = {
     "gd_select_weights": (C.c_int, [_p, _i32]),
     "gd_likes1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pd, _pi32, _pi32, _i32, _pd, _pi32]),
     "gd_likes2d": (C.c_int, [_p, _i32, _i32, _p, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _p, _pi32]),
+    "gd_circ_convolve": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd]),
+    "gd_convolve1d_direct": (C.c_int, [_p, _pd, _i64, _pd, _i64, _pd]),
+    "gd_autoconvolve": (C.c_int, [_p, _i32, _f64, _i32, _pd, _i64, _i64, _i64, _i32, _pd]),
+    "gd_like_stats": (C.c_int, [_p, _i32, _pd]),
 }
 
 _lib = None
@@ -681,6 +685,38 @@ class Context:
         self._check(self.lib.gd_likes2d(self.h, B, F, d_hist.ptr, d_likehist.ptr, _dp(rx), _dp(ry), _dp(corr),
                                         _ip(winw), _ip(flags), int(mbc), out.ptr, _ip(status)))
         return out, status
+
+    # ---- stand-alone convolutions / likelihood statistics
+    def circ_convolve(self, a, b):
+        """irfft(rfft(a) * rfft(b)) of two equal-shape real arrays (1-D or 2-D) through rocFFT."""
+        a, b = _f64arr(a), _f64arr(b)
+        if a.shape != b.shape or a.ndim not in (1, 2):
+            raise ValueError("circ_convolve needs two arrays of one shape, one- or two-dimensional")
+        n0, n1 = (1, a.shape[0]) if a.ndim == 1 else a.shape
+        out = np.empty_like(a)
+        self._check(self.lib.gd_circ_convolve(self.h, int(n0), int(n1), _dp(a), _dp(b), _dp(out)))
+        return out
+
+    def convolve1d_direct(self, x, y):
+        x, y = _f64arr(x), _f64arr(y)
+        out = np.empty(x.size + y.size - 1)
+        self._check(self.lib.gd_convolve1d_direct(self.h, _dp(x), x.size, _dp(y), y.size, _dp(out)))
+        return out
+
+    def autoconvolve(self, s, n, normalize=True, x=None, col=-1, mean=0.0, use_weights=False):
+        """autoConvolve of a host vector ``x`` or of (column - mean) * weights; ``s`` = nearestFFTnumber(2 N)."""
+        out = np.empty(int(n))
+        xx = None if x is None else _f64arr(x)
+        self._check(self.lib.gd_autoconvolve(self.h, int(col), float(mean), int(bool(use_weights)),
+                                             None if xx is None else _dp(xx), 0 if xx is None else xx.size, int(s), int(n),
+                                             int(bool(normalize)), _dp(out)))
+        return out
+
+    def like_stats(self, col):
+        out = np.zeros(8)
+        self._check(self.lib.gd_like_stats(self.h, int(col), _dp(out)))
+        return dict(min=out[0], max=out[1], norm=out[2], sum_wl=out[3], sum_wl2=out[4], sum_w_exp_plus=out[5],
+                    sum_w_exp_minus=out[6], argmin=int(out[7]))
 
     def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t, corr):
         """B x 12: {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status, hx, hy, corr, get_h status}"""

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_prebin_batch(const PrebinCol* __restric
     for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
         double2 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2*>(C.x + i + 2 * q);
+        for (int q = 0; q < 4; ++q) v[q] = gload_d2(C.x + i + 2 * q);
         unsigned int o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
     if (MODE == 2) {
         const int64_t hi8 = lo + ((hi - lo) & ~(int64_t)7);
         for (int64_t i = lo + 8 * (int64_t)threadIdx.x; i < hi8; i += 8 * (int64_t)blockDim.x) {
-            const uint4 ax = *reinterpret_cast<const uint4*>(P.ix + i);
-            const uint4 ay = *reinterpret_cast<const uint4*>(P.iy + i);
+            const uint4 ax = gload_u4(P.ix + i);
+            const uint4 ay = gload_u4(P.iy + i);
             double2 wv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
     } else {
         const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
         for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * (int64_t)blockDim.x) {
-            const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
-            const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+            const double2 xv = gload_d2(P.x + i);
+            const double2 yv = gload_d2(P.y + i);
             double2 wv = make_double2(1.0, 1.0);
             if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
             int cx0, cy0, cx1, cy1;
@@ -321,8 +321,8 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restric
     const int64_t N16 = N & ~(int64_t)15;
     // two 16-byte loads per index column in flight before any sample is consumed
     for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * (int64_t)blockDim.x) {
-        const uint4 ax0 = *reinterpret_cast<const uint4*>(P.ix + i), ay0 = *reinterpret_cast<const uint4*>(P.iy + i);
-        const uint4 ax1 = *reinterpret_cast<const uint4*>(P.ix + i + 8), ay1 = *reinterpret_cast<const uint4*>(P.iy + i + 8);
+        const uint4 ax0 = gload_u4(P.ix + i), ay0 = gload_u4(P.iy + i);
+        const uint4 ax1 = gload_u4(P.ix + i + 8), ay1 = gload_u4(P.iy + i + 8);
         uint4 wv = make_uint4(0, 0, 0, 0);
         if (HAS_W8) wv = *reinterpret_cast<const uint4*>(w8 + i);
         visit8(ax0, ay0, wv.x, wv.y);
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_u8(const Hist2DPair8* __restric
     };
     const int64_t N16 = N & ~(int64_t)15;
     for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * 1024) {
-        const uint4 ax = *reinterpret_cast<const uint4*>(P.ix + i), ay = *reinterpret_cast<const uint4*>(P.iy + i);
+        const uint4 ax = gload_u4(P.ix + i), ay = gload_u4(P.iy + i);
         visit4(ax.x, ay.x);
         visit4(ax.y, ay.y);
         visit4(ax.z, ay.z);
@@ -395,6 +395,77 @@ __global__ void __launch_bounds__(1024) k_hist2d_u8(const Hist2DPair8* __restric
         total += (v & 0xffffu) + (v >> 16);
         hist[i] = (double)(v & 0xffffu);
         hist[i + 32768] = (double)(v >> 16);
+    }
+    const double t = block_sum((double)total, red);
+    if (threadIdx.x == 0 && t != (double)N) atomicOr(&overflow[pair], 1);
+}
+
+// The same kernel with (i) global_load instead of flat_load for the index bytes -- the per-pair table holds generic
+// pointers, and a flat load also counts on lgkmcnt, so waiting for it drained all 16 LDS atomics of the previous
+// iteration before the next byte could be unpacked; (ii) DEPTH iterations of loads in flight per lane (register ring),
+// so a wave always has adds to issue while its next bytes travel; (iii) the packed counters at LDS address 0 and the
+// increment as 1 + 0xffff * (top bit of y): 4.5 VALU operations per sample instead of 6.
+template <int DEPTH>
+__global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __restrict__ pairs, int B, int64_t N,
+                                                       double* __restrict__ hist_all, int* __restrict__ overflow) {
+    extern __shared__ double sh_raw[];  // 32768 words of counters, then 16 doubles for the block reduction
+    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
+    double* red = sh_raw + 16384;
+    const int per_xcd = (B + 7) / 8;
+    const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pair >= B || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    const Hist2DPair8 P = pairs[pair];
+    const uint4* gx = reinterpret_cast<const uint4*>(P.ix);
+    const uint4* gy = reinterpret_cast<const uint4*>(P.iy);
+    for (int i = threadIdx.x; i < 32768; i += 1024) sh[i] = 0;
+    __syncthreads();
+    auto visit2 = [&](unsigned v) {  // v = (y1 x1 y0 x0): two samples
+        atomicAdd(&sh[v & 0x7fffu], __builtin_amdgcn_ubfe(v, 15, 1) * 0xffffu + 1u);
+        atomicAdd(&sh[__builtin_amdgcn_ubfe(v, 16, 15)], (v >> 31) * 0xffffu + 1u);
+    };
+    auto visit16 = [&](const uint4& ax, const uint4& ay) {
+        const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            visit2(__builtin_amdgcn_perm(ys[q], xs[q], 0x05010400u));
+            visit2(__builtin_amdgcn_perm(ys[q], xs[q], 0x07030602u));
+        }
+    };
+    const int64_t nvec = N >> 4;  // 16-byte vectors per column
+    const int64_t K = (nvec >> 10) / DEPTH * DEPTH;  // rounds in which every lane has a vector, a multiple of the ring depth
+    if (K > 0) {
+        uint4 rx[DEPTH], ry[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            rx[d] = gload_u4(gx + d * 1024 + threadIdx.x), ry[d] = gload_u4(gy + d * 1024 + threadIdx.x);
+            __builtin_amdgcn_sched_barrier(0);  // in slot order, or the loop head must wait for the youngest load
+        }
+        for (int64_t k = 0; k < K; k += DEPTH) {
+            // the rounds these slots serve next; past the end: a harmless re-read of the last ring
+            const int64_t kn = (k + DEPTH < K ? k + DEPTH : K - DEPTH) * 1024 + threadIdx.x;
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                visit16(rx[d], ry[d]);  // consumed first: the reload lands in the same registers, no copies at the back edge
+                rx[d] = gload_u4(gx + kn + d * 1024), ry[d] = gload_u4(gy + kn + d * 1024);
+                // keep the slots apart: merged by the scheduler, all DEPTH loads would be waited for at the loop head
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    for (int64_t u = K * 1024 + threadIdx.x; u < nvec; u += 1024) visit16(gload_u4(gx + u), gload_u4(gy + u));
+    if (threadIdx.x == 0)
+        for (int64_t i = nvec << 4; i < N; ++i) {
+            const unsigned a = ((unsigned)P.iy[i] << 8) | (unsigned)P.ix[i];
+            atomicAdd(&sh[a & 0x7fffu], (a >> 15) * 0xffffu + 1u);
+        }
+    __syncthreads();
+    double* hist = hist_all + (int64_t)pair * 65536;
+    unsigned int total = 0;
+    for (int i = 2 * threadIdx.x; i < 32768; i += 2048) {  // two words per lane: 16-byte stores (the tail is store-issue bound)
+        const uint2 c = *reinterpret_cast<const uint2*>(&sh[i]);
+        total += (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu) + (c.y >> 16);
+        *reinterpret_cast<double2*>(&hist[i]) = make_double2((double)(c.x & 0xffffu), (double)(c.y & 0xffffu));
+        *reinterpret_cast<double2*>(&hist[i + 32768]) = make_double2((double)(c.x >> 16), (double)(c.y >> 16));
     }
     const double t = block_sum((double)total, red);
     if (threadIdx.x == 0 && t != (double)N) atomicOr(&overflow[pair], 1);
@@ -416,7 +487,7 @@ __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restr
     for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
         double2 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2*>(C.x + i + 2 * q);
+        for (int q = 0; q < 4; ++q) v[q] = gload_d2(C.x + i + 2 * q);
         unsigned o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -482,8 +553,8 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
     };
     const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
     for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * 1024) {
-        const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
-        const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+        const double2 xv = gload_d2(P.x + i);
+        const double2 yv = gload_d2(P.y + i);
         visit(xv.x, yv.x);
         visit(xv.y, yv.y);
     }
@@ -526,8 +597,8 @@ __global__ void k_minmax_affine(const Hist2DPair* __restrict__ pairs, int64_t N,
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     const int64_t Ne = N & ~(int64_t)1;
     for (int64_t i = 2 * gtid; i < Ne; i += 2 * gsz) {
-        const double2 xv = *reinterpret_cast<const double2*>(P.x + i);
-        const double2 yv = *reinterpret_cast<const double2*>(P.y + i);
+        const double2 xv = gload_d2(P.x + i);
+        const double2 yv = gload_d2(P.y + i);
         const double p0 = P.r0 * xv.x + P.r1 * yv.x, p1 = P.r0 * xv.y + P.r1 * yv.y;
         mn = fmin(mn, fmin(p0, p1));
         mx = fmax(mx, fmax(p0, p1));
@@ -571,7 +642,7 @@ __global__ void __launch_bounds__(256) k_minmax_affine_grouped(const MinmaxGroup
         double2 v[MMG_COLS];
 #pragma unroll
         for (int c = 0; c < MMG_COLS; ++c)
-            v[c] = (c < ncols) ? *reinterpret_cast<const double2*>(G.col[c] + i) : make_double2(0.0, 0.0);
+            v[c] = (c < ncols) ? gload_d2(G.col[c] + i) : make_double2(0.0, 0.0);
 #pragma unroll
         for (int c = 0; c < MMG_COLS; ++c)
             if (c < ncols) slot[c][threadIdx.x] = v[c];
@@ -950,9 +1021,16 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
     int* d_flags = (int*)(base + o_flags);
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
-    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
     const int nblocks = (B + 7) / 8 * 8;
-    k_hist2d_u8<<<nblocks, 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
+    const int variant = getenv("GDHIP_U8_VARIANT") ? atoi(getenv("GDHIP_U8_VARIANT")) : 3;
+    if (variant == 0) {  // the round-2 kernel, kept for A/B timing
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        k_hist2d_u8<<<nblocks, 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
+    } else {
+        auto kern = variant == 1 ? k_hist2d_u8_pf<1> : variant == 2 ? k_hist2d_u8_pf<2> : variant == 4 ? k_hist2d_u8_pf<4> : k_hist2d_u8_pf<3>;
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
+        kern<<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
+    }
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
     GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));

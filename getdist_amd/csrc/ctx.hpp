@@ -97,6 +97,21 @@ void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
 // ---- device helpers -------------------------------------------------------------------------------
 #define WAVE 64
 
+// A pointer that a kernel reads out of a per-pair table in memory is "generic" to the compiler: it emits flat_load,
+// which also counts on lgkmcnt, so the wait for the loaded data drains every LDS atomic the wave has in flight.
+// Every such pointer here is device memory: say so, and the loads become global_load (vmcnt only).
+typedef double gd_f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gd_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte loads from device memory (p 16-byte aligned)
+__device__ __forceinline__ double2 gload_d2(const double* p) {
+    const gd_f64x2 v = *(const __attribute__((address_space(1))) gd_f64x2*)p;
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 gload_u4(const void* p) {
+    const gd_u32x4 v = *(const __attribute__((address_space(1))) gd_u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);

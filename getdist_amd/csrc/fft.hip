@@ -31,10 +31,10 @@ static int get_plan(gd_ctx* ctx, bool forward, int n0, int n1, int batch, FftPla
         return GD_OK;
     }
     FftPlan p;
-    const size_t lengths[2] = {(size_t)n1, (size_t)n0};  // rocFFT: fastest dimension first
+    const size_t lengths[2] = {(size_t)n1, (size_t)n0};  // rocFFT: fastest dimension first; n0 == 1 is a 1-D transform
     rocfft_status st = rocfft_plan_create(&p.plan, rocfft_placement_notinplace,
                                           forward ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
-                                          rocfft_precision_double, 2, lengths, (size_t)batch, nullptr);
+                                          rocfft_precision_double, n0 == 1 ? 1 : 2, lengths, (size_t)batch, nullptr);
     if (st != rocfft_status_success) return gd_fail(ctx, GD_ERR_FFT, "rocfft_plan_create(%dx%d x%d) failed: %d", n0, n1, batch, (int)st);
     st = rocfft_execution_info_create(&p.info);
     if (st != rocfft_status_success) return gd_fail(ctx, GD_ERR_FFT, "rocfft_execution_info_create failed: %d", (int)st);

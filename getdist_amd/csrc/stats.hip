@@ -373,6 +373,170 @@ __global__ void __launch_bounds__(NW * 64, (MCAP == 112 ? 4 : 1)) k_cov_slab(con
     }
 }
 
+// ---- slab covariance, second form --------------------------------------------------------------------------------
+// Same data flow (a slab of KS rows of ALL columns staged once in LDS as d = x - mean [and w d], every upper-triangle
+// 16 x 16 tile pair accumulated from it by v_mfma_f64_16x16x4_f64), rebuilt around what the first form's ISA showed:
+//   * staging loads were 8-byte, one branch each, and each waited for (vmcnt(0)) before the next was issued; here a
+//     thread owns two consecutive rows of NQ columns: unconditional 16-byte global loads (column index clamped, the
+//     store predicated instead), all NQ (+ the weights) in flight while the previous slab is multiplied.  Ragged
+//     ends of a chunk (an odd first row, the last partial slab) go through a guarded slow path once per block;
+//   * every MFMA sat in its own basic block behind `if (live[q])`, so each one waited for its own two LDS reads.  Now
+//     the waves are an NG x NH arrangement: group g owns P consecutive tile pairs (dead slots alias pair 0 and are not
+//     written), row-split h owns KS/4/NH of the slab's k-steps; the loop over (k-step, slot) is straight-line code
+//     and the compiler keeps several operand reads in flight ahead of the matrix pipe;
+//   * tile-pair bases are wave-uniform (readfirstlane): one VGPR holds the lane part of every operand address.
+// Partials: part[(block * NH + h) * T + pair][16 x 16]; k_cov_slab_fin sums nblocks * NH of them.
+template <bool HAS_W, int MCAP, int NW, int NH, int P, int KS, int DEPTH>
+__global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict__ cols, int64_t ld,
+                                                       const int32_t* __restrict__ colidx, int m,
+                                                       const double* __restrict__ res, const double* __restrict__ w,
+                                                       int64_t lo, int64_t hi, int64_t rows_per_chunk,
+                                                       double* __restrict__ part) {
+    constexpr int NT = NW * 64, KSP = KS + 2, TPC = KS / 2, CPP = NT / TPC, NG = NW / NH;
+    constexpr int NQ = (MCAP + CPP - 1) / CPP, KPW = KS / 4 / NH;
+    static_assert(NW % NH == 0 && (KS / 4) % NH == 0 && NT % TPC == 0, "wave arrangement");
+    extern __shared__ double lds[];
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int nt = (m + 15) / 16, mc = nt * 16, T = nt * (nt + 1) / 2;
+    double* sB = lds;                            // d
+    double* sA = HAS_W ? lds + mc * KSP : lds;   // w d (the same array for unit weights)
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wv % NG, h = wv / NG;
+    int offA[P], offB[P];  // wave-uniform element offsets of the slots' tiles
+    f64x4 acc[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        int pq = g * P + q, a = 0, len = nt;
+        if (pq >= T) pq = 0;
+        while (pq >= len) {
+            pq -= len;
+            ++a;
+            --len;
+        }
+        offA[q] = a * 16 * KSP;
+        offB[q] = (a + pq) * 16 * KSP;
+        acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+    const int lbase = l15 * KSP + lk + h * KPW * 4;  // lane part: column l15 of the tile, row lk of the wave's k-steps
+    for (int e = tid; e < (HAS_W ? 2 : 1) * mc * KSP; e += NT) lds[e] = 0.0;  // padding columns / rows stay zero
+    // staging: this thread owns rows 2 rp, 2 rp + 1 of columns c0 + CPP q
+    const int rp = tid % TPC, c0 = tid / TPC;
+    const double* src[NQ];
+    double mean[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = c0 + CPP * q, cc = c < m ? c : m - 1;
+        src[q] = cols + (int64_t)colidx[cc] * ld;
+        mean[q] = res[(int64_t)cc * 4 + 3];
+    }
+    const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
+    int64_t c_hi = c_lo + rows_per_chunk;
+    if (c_hi > hi) c_hi = hi;
+
+    // the (k-step, slot) sequence as straight-line code with the NEXT product's two operand reads issued before each
+    // MFMA (two register pairs alternate): the matrix pipe never waits for a read it has just asked for, and the
+    // operand registers stay at eight whatever P is
+    // the (k-step, slot) products of one k-step as straight-line code; the schedule groups ask for the NEXT product's
+    // two operand reads to be issued before each MFMA, so the matrix pipe never waits for a read it has just requested
+    constexpr int UNRK = KPW * P <= 28 ? KPW : 2;
+    auto multiply = [&]() {
+#pragma unroll UNRK
+        for (int kk = 0; kk < KPW; ++kk) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const double a = sA[offA[q] + lbase + kk * 4], b = sB[offB[q] + lbase + kk * 4];
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+            }
+            if (P >= 2) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS reads of the first two products
+#pragma unroll
+                for (int q = 0; q < P - 2; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // ... then the reads of the product after next
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+    };
+    // guarded slab: rows [rb, re), re - rb <= KS, any alignment (once or twice per block)
+    auto slab_guarded = [&](int64_t rb, int64_t re) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = c0 + CPP * q;
+            if (c < m) {
+                const double* x = cols + (int64_t)colidx[c] * ld;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int64_t row = rb + 2 * rp + e;
+                    const bool in = row < re;
+                    const double d = in ? x[row] - mean[q] : 0.0;
+                    sB[c * KSP + 2 * rp + e] = d;
+                    if (HAS_W) sA[c * KSP + 2 * rp + e] = in ? d * w[row] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        multiply();
+    };
+    if (c_lo < c_hi) {
+        const int64_t a_lo = (c_lo + 1) & ~(int64_t)1;  // first 16-byte aligned row of the chunk
+        const int64_t nfull = c_hi > a_lo ? (c_hi - a_lo) / KS : 0;
+        if (a_lo > c_lo) slab_guarded(c_lo, a_lo < c_hi ? a_lo : c_hi);
+        // DEPTH slabs of loads in flight per lane (a register ring): narrow matrices have so little matrix work per
+        // slab that one slab ahead does not cover the HBM latency
+        double2 pre[DEPTH][NQ], wpre[DEPTH];
+        auto fetch = [&](int d, int64_t slab) {
+            const int64_t v = a_lo + slab * KS + 2 * rp;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) pre[d][q] = gload_d2(src[q] + v);
+            wpre[d] = HAS_W ? gload_d2(w + v) : make_double2(1.0, 1.0);
+        };
+        const int64_t nring = nfull / DEPTH * DEPTH;  // slabs taken by the ring: whole rounds only, no inner branches
+        if (nring > 0) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                fetch(d, d);
+                __builtin_amdgcn_sched_barrier(0);  // in ring order
+            }
+        }
+        for (int64_t s = 0; s < nring; s += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                __syncthreads();  // the previous slab's operand reads are done
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = c0 + CPP * q;
+                    if (c < m) {
+                        const double2 dd = make_double2(pre[d][q].x - mean[q], pre[d][q].y - mean[q]);
+                        *reinterpret_cast<double2*>(&sB[c * KSP + 2 * rp]) = dd;
+                        if (HAS_W)
+                            *reinterpret_cast<double2*>(&sA[c * KSP + 2 * rp]) = make_double2(dd.x * wpre[d].x, dd.y * wpre[d].y);
+                    }
+                }
+                __syncthreads();
+                // in flight while DEPTH slabs are multiplied; unconditional (past the end: a harmless re-read of the
+                // last slab) so that the number of loads in flight is the same on every path and the wait before the
+                // LDS stores can leave the other ring slots' loads outstanding
+                fetch(d, s + d + DEPTH < nring ? s + d + DEPTH : nring - 1);
+                multiply();
+            }
+        }
+        // what the ring left: fewer than DEPTH whole slabs and the ragged end
+        for (int64_t t_lo = a_lo + nring * KS; t_lo < c_hi; t_lo += KS) slab_guarded(t_lo, t_lo + KS < c_hi ? t_lo + KS : c_hi);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int pq = g * P + q;
+        if (pq < T) {
+            double* p = part + (((int64_t)blockIdx.x * NH + h) * T + pq) * 256;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) p[(lk + 4 * rg) * 16 + l15] = acc[q][rg];
+        }
+    }
+}
+
 // cov[i][j] = sum over blocks / norm, mirrored; grid (pairs), 256 threads
 __global__ void __launch_bounds__(256) k_cov_slab_fin(const double* __restrict__ part, int nblocks, int m,
                                                       const double* __restrict__ res, double* __restrict__ cov) {
@@ -1020,7 +1184,76 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     double* d_res = nullptr;
     double* d_cov = nullptr;
     const bool slab = (m <= 208) && !getenv("GDHIP_COV_TILE");
-    if (slab) {
+    if (slab && !getenv("GDHIP_COV_OLD")) {
+        // ---- slab kernel, second form: pick the wave arrangement with the fewest tile-pair slots >= T
+        const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2, mc = nt16 * 16;
+        const int KS = mc <= 64 ? 64 : 32;  // narrow matrices: more rows per barrier pair
+        struct Cfg { int mcap, nw, nh, p, bpc; };
+        static const Cfg cfgs[] = {{64, 8, 8, 3, 4},  {64, 8, 4, 3, 4},   {64, 8, 4, 5, 4},   {112, 8, 2, 4, 2}, {112, 8, 2, 6, 2},
+                                   {112, 8, 2, 7, 2}, {208, 16, 2, 6, 1}, {208, 16, 1, 5, 1}, {208, 16, 1, 6, 1}};
+        int pick = -1;
+        for (int k = 0; k < (int)(sizeof(cfgs) / sizeof(cfgs[0])); ++k)
+            if (cfgs[k].mcap >= mc && (cfgs[k].nw / cfgs[k].nh) * cfgs[k].p >= T) {
+                pick = k;
+                break;
+            }
+        GD_REQUIRE(pick >= 0, "covariance: no slab configuration");
+        const Cfg cf = cfgs[pick];
+        const bool hw = ctx->w != nullptr;
+        const size_t lds = (size_t)(hw ? 2 : 1) * mc * (KS + 2) * 8;
+        int bpc = cf.bpc;
+        while (bpc > 1 && (size_t)bpc * lds > 150u * 1024u) --bpc;
+        int nblk = bpc * ctx->cu_count;
+        if (nblk > (rows + 4 * KS - 1) / (4 * KS)) nblk = (int)((rows + 4 * KS - 1) / (4 * KS));
+        if (nblk < 1) nblk = 1;
+        int64_t rows_per_chunk = (rows + nblk - 1) / nblk;
+        rows_per_chunk = (rows_per_chunk + KS - 1) / KS * KS;
+        nblk = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
+        int64_t off = 0;
+        const int64_t o_part1 = take_init(off, (int64_t)m * NBLK_STREAM * 4 * 8), o_res = take_init(off, (int64_t)m * 4 * 8),
+                      o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * cf.nh * T * 256 * 8),
+                      o_cov = take_init(off, (int64_t)m * m * 8);
+        char* base = (char*)gd_scratch(ctx, off);
+        if (!base) return GD_ERR_NOMEM;
+        double* d_part1 = (double*)(base + o_part1);
+        d_res = (double*)(base + o_res);
+        int32_t* d_idx = (int32_t*)(base + o_idx);
+        double* d_cpart = (double*)(base + o_cpart);
+        d_cov = (double*)(base + o_cov);
+        GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
+        if (rc) return rc;
+#define GD_COV2(HW, MCAP, NW, NH, PP)                                                                                     \
+    do {                                                                                                                  \
+        auto kern = k_cov_slab2<HW, MCAP, NW, NH, PP, ((MCAP) <= 64 ? 64 : 32), ((MCAP) <= 64 ? 2 : 1)>;                                                             \
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        kern<<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, ctx->w, lo, hi, rows_per_chunk,  \
+                                                    d_cpart);                                                             \
+    } while (0)
+#define GD_COV2_HW(MCAP, NW, NH, PP) \
+    do {                              \
+        if (hw)                       \
+            GD_COV2(true, MCAP, NW, NH, PP);  \
+        else                          \
+            GD_COV2(false, MCAP, NW, NH, PP); \
+    } while (0)
+        switch (pick) {
+            case 0: GD_COV2_HW(64, 8, 8, 3); break;
+            case 1: GD_COV2_HW(64, 8, 4, 3); break;
+            case 2: GD_COV2_HW(64, 8, 4, 5); break;
+            case 3: GD_COV2_HW(112, 8, 2, 4); break;
+            case 4: GD_COV2_HW(112, 8, 2, 6); break;
+            case 5: GD_COV2_HW(112, 8, 2, 7); break;
+            case 6: GD_COV2_HW(208, 16, 2, 6); break;
+            case 7: GD_COV2_HW(208, 16, 1, 5); break;
+            default: GD_COV2_HW(208, 16, 1, 6); break;
+        }
+#undef GD_COV2_HW
+#undef GD_COV2
+        GD_KERNEL_CHECK();
+        k_cov_slab_fin<<<T, 256, 0, ctx->stream>>>(d_cpart, nblk * cf.nh, m, d_res, d_cov);
+        GD_KERNEL_CHECK();
+    } else if (slab) {
         // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
         // rows per slab: 32.  (64 for the narrow variant -- 512-B runs per column, 16 loads in flight per lane -- was
         // measured slower, 4.5 vs 3.1 ms at m = 50: 142 VGPRs leave three blocks per CU instead of four; GDHIP_COV_KS64

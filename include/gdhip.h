@@ -340,6 +340,29 @@ int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, d
                         int32_t flags, int32_t bco, int32_t mbc, const double* mask_bc, const double* mask_mbc,
                         const unsigned char* zero_mask, void* d_P_out, int32_t* status_out);
 
+/* ---------------------------------------------------------------- stand-alone convolutions -------
+ * The device-backed forms of getdist/convolve.py's public functions (host arrays in and out; the Python module
+ * getdist_amd/convolve.py does the padding, the centring roll and the mode slices exactly as convolve.py:196-444).
+ * gd_circ_convolve: out = irfft(rfft(a) * rfft(b)) for two real frames of n0 x n1 doubles (n0 == 1: one dimension,
+ *   any n1 >= 2) -- the transform pair behind convolveFFT / convolveFFTn / convolve1D_periodic / convolve2D_periodic
+ *   (convolve.py:371-436, 215-367), through rocFFT.
+ * gd_convolve1d_direct: out_full[i] = sum_j x[j] y[i-j], i < nx + ny - 1: what np.convolve evaluates when an operand
+ *   is shorter than 1000 samples (convolve.py:199-202).
+ * gd_autoconvolve: autoConvolve(x, n, normalize) (convolve.py:458-478): result[k] = sum_i x_i x_{i+k} [/ (N - k)],
+ *   k < n, through a real FFT of length s = nearestFFTnumber(2 N) (passed in: the table lives in the Python module).
+ *   x_host != NULL: that vector of nx values; else the resident column `col` as (x - mean) * w (use_weights != 0) --
+ *   the vector getAutocorrelation builds (chains.py:439-441) -- without it ever existing on the host. */
+int gd_circ_convolve(gd_ctx* ctx, int32_t n0, int32_t n1, const double* a, const double* b, double* out);
+int gd_convolve1d_direct(gd_ctx* ctx, const double* x, int64_t nx, const double* y, int64_t ny, double* out_full);
+int gd_autoconvolve(gd_ctx* ctx, int32_t col, double mean, int32_t use_weights, const double* x_host, int64_t nx, int64_t s,
+                    int64_t n, int32_t normalize, double* out);
+
+/* gd_like_stats: the sample-likelihood numbers of MCSamples._setLikeStats (mcsamples.py:2216-2243) from the column
+ *   `col` holding loglikes (an extra column, gd_set_extra_column) and the selected weights, in two passes:
+ *   out8 = {min L, max L, sum w, sum w L, sum w L^2, sum w exp(L - min L), sum w exp(-(L - min L)),
+ *           first row index attaining min L (np.argmin)}. */
+int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,136 @@
+"""
+Round-3 kernel A/B on the MI355X (run on the GPU box):  python scripts/r03_kernels.py [--quick]
+  * k_hist2d_u8 (round 2) against k_hist2d_u8_pf<DEPTH> (global loads + register ring), 1200 base pairs of C3, HIP events,
+    results compared bit for bit;
+  * k_cov_slab (round 2) against k_cov_slab2 at C3's shape (50 columns x 1e7, unit weights), C4's (100 x 5e6, weighted)
+    and C5's width (200 columns, 2e6 rows, unit and weighted), against each other and against numpy on a row sample.
+Writes gpurun_out/r03_kernels.json.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from getdist_amd import synth  # noqa: E402
+from getdist_amd.mcsamples import MCSamples  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def timed(ctx, fn, reps=5):
+    fn()
+    ctx.sync()
+    ms = []
+    for _ in range(reps):
+        ctx.timer_start()
+        fn()
+        ms.append(ctx.timer_stop_ms())
+    return float(np.median(ms)), float(np.min(ms))
+
+
+def main():
+    quick = "--quick" in sys.argv
+    res = {}
+    N, n, F = (2_000_000 if quick else 10_000_000), 50, 256
+    s, w, names, ranges = synth.config_c3(N, n)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    mc.prepareParams(neff=False)
+    ctx = mc.ctx
+    par = mc.paramNames.names
+    e = [mc._bin_edges(p, F) for p in par]
+    corr = mc.getCorrelationMatrix()
+    pairs = [p for p in synth.triangle_pairs(n) if abs(corr[p[1]][p[0]]) <= 0.866]
+    assert mc._index_columns8({j: (e[j][1], e[j][0]) for j in range(n)})
+    i8 = [mc._idx_cols[(j, 256, "u8")][0] for j in range(n)]
+    out = ctx.alloc(len(pairs) * F * F * 8)
+    ix, iy = [i8[a] for a, b in pairs], [i8[b] for a, b in pairs]
+    ref = None
+    hist = {}
+    for variant in (0, 1, 2, 3, 4):
+        os.environ["GDHIP_U8_VARIANT"] = str(variant)
+        med, mn = timed(ctx, lambda: ctx.hist2d_prebinned8(ix, iy, out=out))
+        got = out.to_host((64, F, F))  # the first 64 grids
+        tot = float(np.sum(got))
+        if ref is None:
+            ref = got
+        hist["variant%d" % variant] = dict(ms_median=med, ms_min=mn, equal_to_round2=bool(np.array_equal(got, ref)),
+                                           mass_first64=tot)
+        print("u8 variant", variant, hist["variant%d" % variant], flush=True)
+    os.environ.pop("GDHIP_U8_VARIANT")
+    res["hist2d_u8"] = dict(pairs=len(pairs), N=N, variants=hist,
+                            note="variant 0 = round-2 kernel (flat loads, lgkmcnt drain); 1..4 = k_hist2d_u8_pf<DEPTH>")
+    out.free()
+    # sheared + upscaled classes through the (now global-load) generic kernels: timing only, parity is in pytest
+    # ---- covariance
+    cov = {}
+
+    def cov_ab(tag, ctx_, m, rows, flops_note=""):
+        r = {}
+        outs = {}
+        for name, env in (("round2", "1"), ("slab2", None)):
+            if env:
+                os.environ["GDHIP_COV_OLD"] = env
+            else:
+                os.environ.pop("GDHIP_COV_OLD", None)
+            med, mn = timed(ctx_, lambda: ctx_.cov(list(range(m))), reps=3)
+            outs[name] = ctx_.cov(list(range(m)))
+            r[name] = dict(ms_median=med, ms_min=mn)
+        os.environ.pop("GDHIP_COV_OLD", None)
+        c0, c1 = outs["round2"][1], outs["slab2"][1]
+        scale = np.sqrt(np.outer(np.diag(c0), np.diag(c0)))
+        r["max_rel_diff_new_vs_round2"] = float(np.max(np.abs(c0 - c1) / scale))
+        r["symmetric"] = bool(np.array_equal(c1, c1.T))
+        nt = (m + 15) // 16
+        r["executed_TFLOPs_slab2"] = nt * (nt + 1) / 2 * 512.0 * rows / (r["slab2"]["ms_median"] * 1e-3) / 1e12
+        r["GBps_slab2_incl_means_pass"] = 2.0 * rows * m * 8 / (r["slab2"]["ms_median"] * 1e-3) / 1e9
+        cov[tag] = r
+        print("cov", tag, r, flush=True)
+        return outs["slab2"]
+
+    got = cov_ab("C3_50x%g_unit" % N, ctx, n, N)
+    sub = slice(0, 200_000)
+    # numpy check on the full set is slow; the pooled statistics of a row sample bound gross errors, pytest does the rest
+    ctx.close()
+    del mc, s
+    rng = np.random.default_rng(5)
+    for tag, m, rows, weighted in (("C4_100x5e6_weighted", 100, 1_000_000 if quick else 5_000_000, True),
+                                   ("C5w_200x2e6_unit", 200, 500_000 if quick else 2_000_000, False),
+                                   ("C5w_200x2e6_weighted", 200, 500_000 if quick else 2_000_000, True),
+                                   ("m130_x2e6_unit", 130, 500_000 if quick else 2_000_000, False),
+                                   ("m30_x4e6_unit", 30, 1_000_000 if quick else 4_000_000, False)):
+        A = rng.standard_normal((m, m)) / np.sqrt(m)
+        x = np.asfortranarray(rng.standard_normal((rows, m)) @ (A + 0.3 * np.eye(m)))
+        ww = rng.exponential(1.0, rows) if weighted else None
+        mc = MCSamples(samples=x, weights=ww, names=["p%d" % i for i in range(m)])
+        means, c, norm = cov_ab(tag, mc.ctx, m, rows)
+        wn = np.ones(rows) if ww is None else ww
+        mu = (wn @ x) / wn.sum()
+        d = x[:300_000] - mu
+        # exact check on a prefix is not the full covariance: compare the device's own prefix call instead
+        mp, cp, _ = mc.ctx.cov(list(range(m)), lo=0, hi=300_000)
+        mu_p = (wn[:300_000] @ x[:300_000]) / wn[:300_000].sum()
+        dp = x[:300_000] - mu_p
+        ref_c = (dp * wn[:300_000, None]).T @ dp / wn[:300_000].sum()
+        cov[tag]["max_rel_err_vs_numpy_prefix_300k"] = float(np.max(np.abs(cp - ref_c)) / np.max(np.abs(ref_c)))
+        # odd row range: exercises the guarded head / tail slabs
+        mp2, cp2, _ = mc.ctx.cov(list(range(m)), lo=12_345, hi=212_350)
+        sl = slice(12_345, 212_350)
+        mu2 = (wn[sl] @ x[sl]) / wn[sl].sum()
+        d2 = x[sl] - mu2
+        ref2 = (d2 * wn[sl, None]).T @ d2 / wn[sl].sum()
+        cov[tag]["max_rel_err_vs_numpy_odd_range"] = float(np.max(np.abs(cp2 - ref2)) / np.max(np.abs(ref2)))
+        print("   numpy checks", cov[tag]["max_rel_err_vs_numpy_prefix_300k"], cov[tag]["max_rel_err_vs_numpy_odd_range"], flush=True)
+        mc.ctx.close()
+        del mc, x
+    res["covariance"] = cov
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(res, open(os.path.join(OUT, "r03_kernels.json"), "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
