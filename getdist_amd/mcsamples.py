@@ -101,6 +101,25 @@ class MargeStats:
         return None
 
 
+class LikeStats:
+    """The numbers of types.LikeStats (types.py:900-939): posterior statistics of the sample log-likelihoods; the N-D
+    confidence-region limits and the best-fit sample live on ``names[i]`` (ND_limit_bot / ND_limit_top / bestfit_sample)."""
+
+    def __init__(self):
+        self.logLike_sample = self.logMeanInvLike = self.meanLogLike = self.logMeanLike = None
+        self.complexity = self.varLogLike = None
+        self.names = []
+
+    def likeSummary(self):
+        text = "Best fit sample -log(Like) = %f\n" % self.logLike_sample
+        if self.logMeanInvLike:
+            text += "Ln(mean 1/like) = %f\n" % self.logMeanInvLike
+        text += "mean(-Ln(like)) = %f\n" % self.meanLogLike
+        text += "-Ln(mean like)  = %f\n" % self.logMeanLike
+        text += "2*Var(Ln(like)) = %f\n" % (self.varLogLike * 2.0)
+        return text
+
+
 class ParamConfidenceData:
     """Handle returned by initParamConfidenceData (chains.py:176-178 namedtuple in the reference)."""
 
@@ -381,6 +400,8 @@ class MCSamples:
                  temperature=None, names=None, labels=None, label=None, name_tag=None, sampler=None, device=0,
                  _context_factory=None, **kwargs):
         self.sampler = sampler or "mcmc"
+        self.temperature, self.cooled = temperature, 1
+        self.likeStats = None
         self.label, self.name_tag = label, name_tag
         self.root = root
         self.raise_on_bandwidth_errors = False
@@ -615,12 +636,202 @@ class MCSamples:
         """chains.py:302-308"""
         self.setSamples(samples, self.weights, self.loglikes)
 
-    def _weightsChanged(self):
-        """chains.py:310-323: everything derived from samples/weights is stale; re-upload and recompute lazily."""
+    def _weightsChanged(self, filter_weights=True):
+        """chains.py:310-323: everything derived from samples/weights is stale; re-upload and recompute.  The
+        min-weight filter belongs to setSamples (chains.py:296-299), not to the reference's _weightsChanged: mutators
+        that call that directly (reweightAddingLogLikes, cool) pass filter_weights=False."""
         self.means = self.vars = self.sddev = self.fullcov = self.correlationMatrix = None
-        self._upload()
+        self._upload(filter_weights=filter_weights)
         self.needs_update = True
         self.updateBaseStatistics()
+
+    # ---- mutators of the sample set (SURVEY.md 8b, state invalidation): every one funnels into a re-upload -------
+    def _replace_samples(self, samples, weights, loglikes, chain_offsets=None):
+        """setSamples(..., min_weight_ratio=-1) of the reference's mutators (no weight filter), for a sample array whose
+        row AND column counts may have changed; the device mirror and every derived cache are rebuilt."""
+        samples = np.asarray(samples)
+        if samples.ndim == 1:
+            samples = samples.reshape(-1, 1)
+        if samples.shape[1] != len(self.paramNames.names):
+            raise WeightedSampleError("number of sample columns does not match the parameter names")
+        self.samples = samples
+        self.numrows, self.n = samples.shape
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self.loglikes = None if loglikes is None else np.ascontiguousarray(loglikes, dtype=np.float64)
+        self.chain_offsets = None if chain_offsets is None else np.asarray(chain_offsets, dtype=np.int64)
+        self.index = {p.name: i for i, p in enumerate(self.paramNames.names)}
+        self._weightsChanged(filter_weights=False)
+
+    def _host_weights(self):
+        return self.weights if self.weights is not None else np.ones(self.numrows)
+
+    def thin(self, factor):
+        """chains.py:941-952: thin by ``factor`` to unit-weight samples (integer weights).  The thinned row list comes
+        from the device (gd_thin_rows); chain boundaries follow the rows that survive."""
+        thin_ix = self.thin_indices(factor)
+        offsets = None if self.chain_offsets is None else np.searchsorted(thin_ix, self.chain_offsets)
+        self._replace_samples(self.samples[thin_ix, :], None,
+                              None if self.loglikes is None else self.loglikes[thin_ix], offsets)
+
+    def weighted_thin(self, factor):
+        """chains.py:954-966,1188-1206: thin by ``factor`` keeping integer multiplicities; separate chains are thinned
+        one by one (the cumulative weight restarts with every chain), as the reference does."""
+        if not self.ctx.weights_integral():
+            raise WeightedSampleError("Can only thin with integer weights")
+        ranges = [(0, self.numrows)] if self.chain_offsets is None else self._chain_ranges()
+        rows, counts, lens = [], [], [0]
+        for lo, hi in ranges:
+            buf, K = self._thin_rows(factor, lo, hi)
+            ix = buf.to_host((K,), dtype=np.int32).astype(np.int64) if K else np.zeros(0, dtype=np.int64)
+            buf.free()
+            u, c = np.unique(ix, return_counts=True)
+            rows.append(u), counts.append(c), lens.append(len(u))
+        rows, counts = np.concatenate(rows), np.concatenate(counts)
+        offsets = None if self.chain_offsets is None else np.cumsum(lens)
+        self._replace_samples(self.samples[rows, :], counts.astype(np.float64),
+                              None if self.loglikes is None else self.loglikes[rows], offsets)
+
+    def filter(self, where):
+        """chains.py:968-979,1174-1186: keep the rows ``where`` (boolean mask or row indices)"""
+        where = np.asarray(where)
+        offsets = None
+        if self.chain_offsets is not None:
+            if where.dtype == bool:
+                offsets = np.cumsum([0] + [int(np.count_nonzero(where[a:b])) for a, b in self._chain_ranges()])
+            elif where.size == 0 or np.all(np.diff(where) > 0):
+                offsets = np.searchsorted(where, self.chain_offsets)
+        self._replace_samples(self.samples[where, :], None if self.weights is None else self.weights[where],
+                              None if self.loglikes is None else self.loglikes[where], offsets)
+
+    def deleteZeros(self):
+        """chains.py:1010-1015"""
+        self.filter(self._host_weights() > 0)
+
+    def setMinWeightRatio(self, min_weight_ratio=1e-30):
+        """chains.py:1017-1027"""
+        if self.weights is not None and min_weight_ratio >= 0:
+            mx, mn = np.max(self.weights), np.min(self.weights)
+            if mn < mx * min_weight_ratio:
+                self.filter(self.weights > mx * min_weight_ratio)
+
+    def reweightAddingLogLikes(self, logLikes):
+        """chains.py:981-993: importance-sample by adding ``logLikes`` (-log likelihood per sample)"""
+        logLikes = np.asarray(logLikes, dtype=np.float64)
+        if logLikes.shape != (self.numrows,):
+            raise WeightedSampleError("logLikes must have one entry per sample")
+        scale = np.min(logLikes)
+        if self.loglikes is not None:
+            self.loglikes = self.loglikes + logLikes
+        self.weights = self._host_weights() * np.exp(-(logLikes - scale))
+        self._weightsChanged(filter_weights=False)
+
+    def cool(self, cool=None):
+        """mcsamples.py:533-550 + chains.py:995-1008: multiply the log-likelihoods by ``cool`` and re-weight"""
+        if cool is None:
+            if self.temperature is None:
+                raise ValueError("Pass a cooling temperature, since the sample does not have one specified")
+            cool = float(self.temperature)
+        if cool == 1:
+            return
+        if self.cooled != 1:
+            logging.warning("Chain has already been cooled by %s", self.cooled)
+        if self.loglikes is None:
+            raise WeightedSampleError("Samples have no likelihood values, required to cool")
+        MaxL = np.min(self.loglikes)
+        newL = self.loglikes * cool
+        self.weights = self._host_weights() * np.exp(-(newL - self.loglikes) - (MaxL * (1 - cool)))
+        self.loglikes = newL
+        self._weightsChanged(filter_weights=False)
+        self.cooled = cool
+        if self.temperature is not None:
+            self.temperature = float(self.temperature) / cool
+
+    def removeBurn(self, remove=0.3):
+        """chains.py:1047-1061: drop the first ``remove`` fraction of the rows (or that many rows if >= 1)"""
+        ix = int(remove) if remove >= 1 else int(round(self.numrows * remove))
+        offsets = None if self.chain_offsets is None else np.maximum(self.chain_offsets - ix, 0)
+        self._replace_samples(self.samples[ix:, :], None if self.weights is None else self.weights[ix:],
+                              None if self.loglikes is None else self.loglikes[ix:], offsets)
+
+    def deleteFixedParams(self):
+        """chains.py:1029-1045,1544-1559: remove the parameters that do not vary (they become zero-width ranges).
+        Returns (indices removed, their values)."""
+        fixed, values = [], []
+        for i in range(self.samples.shape[1]):
+            if np.isclose(self.samples[0, i], self.samples[-1, i], equal_nan=True):
+                mean = np.average(self.samples[:, i])
+                if np.allclose(self.samples[:, i], mean, rtol=1e-12, atol=0, equal_nan=True):
+                    fixed.append(i)
+                    values.append(mean)
+        if fixed:
+            for ix, value in zip(fixed, values):
+                self.ranges.setFixed(self.paramNames.names[ix].name, value)
+            self.paramNames.deleteIndices(fixed)
+            self._replace_samples(np.delete(self.samples, fixed, 1), self.weights, self.loglikes, self.chain_offsets)
+        return fixed, values
+
+    def addDerived(self, paramVec, name, label="", comment="", range=None):
+        """mcsamples.py:2560-2575 + chains.py:1354-1366: append a derived parameter column.  Returns its ParamInfo."""
+        if self.paramNames.parWithName(name):
+            raise ValueError("Parameter with name %s already exists" % name)
+        vec = np.asarray(paramVec, dtype=np.float64).reshape(-1)
+        if vec.shape != (self.numrows,):
+            raise WeightedSampleError("derived parameter vector must have one entry per sample")
+        if range is not None:
+            self.ranges.setRange(name, range)
+        new = np.empty((self.numrows, self.n + 1), dtype=np.float64, order="F")  # the device layout: no transpose
+        new[:, :self.n] = self.samples
+        new[:, self.n] = vec
+        par = ParamInfo(name, label or None)
+        par.isDerived, par.comment = True, comment
+        self.paramNames.names.append(par)
+        self._replace_samples(new, self.weights, self.loglikes, self.chain_offsets)
+        return par
+
+    def getParams(self):
+        """chains.py:1252-1268 in spirit: an object with one attribute per parameter name holding its sample vector"""
+
+        class ParSamples:
+            pass
+
+        out = ParSamples()
+        for j, par in enumerate(self.paramNames.names):
+            setattr(out, par.name, self.samples[:, j])
+        return out
+
+    # ---- likelihood statistics (mcsamples.py:2216-2261, 2369-2378) ----------------------------------------------
+    def _setLikeStats(self):
+        """Best-fit sample, posterior likelihood statistics and the N-D confidence-region limits.  Two passes over the
+        loglikes column on the device (gd_like_stats) give every weighted mean the reference forms from exp / square
+        of that vector; the N-D limits come from _setNDLimits (weighted quantile + conditional min / max)."""
+        if self.loglikes is None:
+            self.likeStats = None
+            return None
+        ctx = self.ctx
+        col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
+        st = ctx.like_stats(col)
+        norm = self.norm
+        maxlike = st["min"]
+        m = LikeStats()
+        m.logLike_sample = maxlike
+        m.logMeanInvLike = (np.log(st["sum_w_exp_plus"] / norm) + maxlike) if st["max"] - maxlike < 30 else None
+        self.mean_loglike = st["sum_wl"] / norm  # chains.py:380-383
+        m.meanLogLike = self.mean_loglike
+        m.logMeanLike = -np.log(st["sum_w_exp_minus"] / norm) + maxlike
+        m.complexity = 2 * (self.mean_loglike - maxlike)
+        m.varLogLike = st["sum_wl2"] / norm - self.mean_loglike**2
+        m.names = self.paramNames.names
+        self._setNDLimits()
+        best = self.samples[st["argmin"]]
+        for j, par in enumerate(self.paramNames.names):
+            par.bestfit_sample = best[j]
+        self.likeStats = m
+        return m
+
+    def getLikeStats(self):
+        """mcsamples.py:2369-2378 (computed on first use after a change of the samples, not inside every
+        updateBaseStatistics: it costs three passes over the sample set)"""
+        return self.likeStats or self._setLikeStats()
 
     def _use_like_weights(self, mode):
         """
@@ -848,6 +1059,8 @@ class MCSamples:
         """chains.py:853-863: indices that make single-weight samples (the device list copied to the host)."""
         if weights is not None:
             raise NotImplementedError("thinning of weights that are not resident on the device")
+        if not self.ctx.weights_integral():
+            raise WeightedSampleError("Can only thin with integer weights")
         buf, K = self._thin_rows(factor)
         out = buf.to_host((K,), dtype=np.int32).astype(np.int64) if K else np.zeros(0, dtype=np.int64)
         buf.free()
@@ -1106,6 +1319,7 @@ class MCSamples:
             par.N_eff_kde = None
             par._ranges_done = False
         self._nd_limits_done = False
+        self.likeStats = None
         self.needs_update = False
 
     def _initLimits(self):
@@ -1296,38 +1510,57 @@ class MCSamples:
         return self.confidence(paramVec, limits)
 
     # ---- autocorrelation / effective samples (chains.py:423-574) -------------------------------------------
+    DIRECT_LAGS_MAX = 512  # beyond this many lags the length-2N FFT (gd_autoconvolve) is cheaper than lag sums
+
+    def _autocov(self, col, mean, k0, nlags):
+        """Un-normalised autocovariance lag sums sum_i d_i d_{i+k}, d = (x - mean) w, for k0 <= k < k0 + nlags: direct
+        lag sums for a few lags, the reference's FFT route (convolve.py:458-478 on the device) for many."""
+        if nlags <= self.DIRECT_LAGS_MAX:
+            return self.ctx.autocov_lags(col, mean, k0, nlags)
+        from .convolve import nearestFFTnumber
+
+        s = int(nearestFFTnumber(2 * self.numrows))
+        return self.ctx.autoconvolve(s, k0 + nlags, False, col=col, mean=mean, use_weights=self.weights is not None)[k0:]
+
     def getAutocorrelation(self, paramVec, maxOff=None, weight_units=True, normalized=True):
-        j = self._col(paramVec)
+        """chains.py:423-447; ``paramVec`` may be a parameter or a vector of one value per sample"""
+        j = self._vec_col(paramVec)
         if maxOff is None:
             maxOff = self.n - 1
-        lags = self.ctx.autocov_lags(j, self.means[j], 0, maxOff + 1)
+        lags = self._autocov(j, self.mean(paramVec), 0, maxOff + 1)
         corr = lags / np.arange(self.numrows, self.numrows - (maxOff + 1), -1)
         if normalized:
-            corr /= self.vars[j]
+            corr /= self.var(paramVec)
         if weight_units:
             return corr * self.numrows / self.norm
         return corr
 
     def getCorrelationLength(self, j, weight_units=True, min_corr=0.05, corr=None):
-        """chains.py:449-466 by direct lag sums with early exit."""
-        j = self._col(j)
+        """chains.py:449-466.  Without ``corr``: direct lag sums in growing chunks with early exit; a
+        chain whose correlation has not dropped below ``min_corr`` within DIRECT_LAGS_MAX lags takes the FFT route for
+        all N/10 lags at once."""
+        if corr is not None:
+            corr = np.asarray(corr)
+            ix = int(np.argmin(corr > min_corr * corr[0]))
+            return corr[0] + 2 * np.sum(corr[1:ix])
+        col = self._vec_col(j)
+        mean, var = self.mean(j), self.var(j)
         max_off = self.numrows // 10
         scale = (self.numrows / self.norm) if weight_units else 1.0
-        vals = []
+        vals = np.zeros(0)
         k0, chunk = 0, 32
         while k0 <= max_off:
             nl = min(chunk, max_off + 1 - k0)
-            lags = self.ctx.autocov_lags(j, self.means[j], k0, nl)
-            c = lags / (self.numrows - np.arange(k0, k0 + nl)) / self.vars[j] * scale
-            vals.extend(c.tolist())
-            below = np.nonzero(~(np.array(vals) > min_corr * vals[0]))[0]
+            if k0 + nl > self.DIRECT_LAGS_MAX:
+                nl = max_off + 1 - k0  # everything that is left, in one transform
+            lags = self._autocov(col, mean, k0, nl)
+            c = lags / (self.numrows - np.arange(k0, k0 + nl)) / var * scale
+            vals = np.concatenate([vals, c])
+            below = np.nonzero(~(vals > min_corr * vals[0]))[0]
             if below.size:
-                ix = int(below[0])
-                return vals[0] + 2 * float(np.sum(np.array(vals[1:ix])))
+                return vals[0] + 2 * float(np.sum(vals[1:int(below[0])]))
             k0 += nl
-            chunk = min(chunk * 2, 4096)
-            if k0 > 262144:
-                raise NotImplementedError("autocorrelation longer than 2^18 samples: direct-lag kernel not suited")
+            chunk *= 2
         return vals[0]  # argmin of an all-True mask is 0 (chains.py:464-465)
 
     def getEffectiveSamples(self, j=0, min_corr=0.05):

@@ -335,6 +335,31 @@ class FakeContext:
         return out
 
     # ---- lag sums
+    # ---- stand-alone convolutions / likelihood statistics (numpy statements of the four entry points)
+    def circ_convolve(self, a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        if a.ndim == 1:
+            return np.fft.irfft(np.fft.rfft(a) * np.fft.rfft(b), n=a.size)
+        return np.fft.irfftn(np.fft.rfftn(a) * np.fft.rfftn(b), a.shape, axes=(0, 1))
+
+    def convolve1d_direct(self, x, y):
+        return np.convolve(x, y, "full")
+
+    def autoconvolve(self, s, n, normalize=True, x=None, col=-1, mean=0.0, use_weights=False):
+        if x is None:
+            x = (self.s[:, col] - mean) * (self._w() if use_weights else 1.0)
+        x = np.asarray(x, dtype=np.float64)
+        f = np.fft.rfft(x, s)
+        r = np.fft.irfft((f * f.conj()).real, s)[:n]
+        return r / np.arange(x.size, x.size - n, -1) if normalize else r
+
+    def like_stats(self, col):
+        L, w = self.s[:, col], self._w()
+        mn = float(np.min(L))
+        return dict(min=mn, max=float(np.max(L)), norm=float(np.sum(w)), sum_wl=float(np.dot(w, L)),
+                    sum_wl2=float(np.dot(w, L * L)), sum_w_exp_plus=float(np.dot(w, np.exp(L - mn))),
+                    sum_w_exp_minus=float(np.dot(w, np.exp(-(L - mn)))), argmin=int(np.argmin(L)))
+
     def autocov_lags_range_batch(self, cols, means, lo, hi, k0, nlags):
         out = np.zeros((len(cols), nlags))
         w = self._w(lo, hi)

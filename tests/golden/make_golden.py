@@ -311,7 +311,102 @@ def golden_reference_unit_tests():
     return out
 
 
+def golden_mutators():
+    """Reference outputs after every mutator of the sample set named in SURVEY.md 8b (chains.py:941-1061,1354,
+    mcsamples.py:533,2560), of getLikeStats (mcsamples.py:2216-2261,2369), of getAutocorrelation / getCorrelationLength
+    with many lags, vectors and corr= (chains.py:423-466), and of the public functions of convolve.py on seeded inputs."""
+    from getdist import convolve as rconv
+
+    from make_golden_inputs import mutator_inputs
+
+    samples, weights, loglikes, names, offsets, extra = mutator_inputs()
+    cut = lambda a: [a[lo:hi] for lo, hi in zip(offsets[:-1], offsets[1:])]  # noqa: E731
+
+    def fresh():
+        return MCSamples(samples=[c.copy() for c in cut(samples)], weights=[c.copy() for c in cut(weights)],
+                         loglikes=[c.copy() for c in cut(loglikes)], names=names, ranges={"m3": (-3.0, None)})
+
+    def state(mc, tag, out):
+        mc.updateBaseStatistics()
+        out[tag + "/numrows"] = np.int64(mc.numrows)
+        out[tag + "/norm"] = np.float64(mc.norm)
+        out[tag + "/means"] = mc.means.copy()
+        out[tag + "/cov"] = mc.fullcov.copy()
+        out[tag + "/max_mult"] = np.float64(mc.max_mult)
+        if mc.loglikes is not None:
+            out[tag + "/loglike_sum"] = np.float64(np.dot(mc.weights, mc.loglikes))
+        if getattr(mc, "chain_offsets", None) is not None:
+            out[tag + "/chain_offsets"] = np.asarray(mc.chain_offsets, dtype=np.int64)
+
+    out = {}
+    mc = fresh()
+    state(mc, "base", out)
+    ls = mc.getLikeStats()
+    out["likestats/scalars"] = np.array([ls.logLike_sample, ls.logMeanInvLike if ls.logMeanInvLike is not None else np.nan,
+                                         ls.meanLogLike, ls.logMeanLike, ls.complexity, ls.varLogLike])
+    out["likestats/ND_bot"] = np.array([p.ND_limit_bot for p in mc.paramNames.names])
+    out["likestats/ND_top"] = np.array([p.ND_limit_top for p in mc.paramNames.names])
+    out["likestats/bestfit"] = np.array([p.bestfit_sample for p in mc.paramNames.names])
+    # autocorrelation: many lags (the FFT route), both units, a vector argument, the length with and without corr=
+    for j in (0, 3):
+        for wu in (True, False):
+            out["autocorr/%d/%d" % (j, wu)] = mc.getAutocorrelation(j, maxOff=700, weight_units=wu)
+        out["corrlen/%d" % j] = np.float64(mc.getCorrelationLength(j))
+    vec = mc.samples[:, 1] * mc.samples[:, 2]
+    out["autocorr/vec"] = mc.getAutocorrelation(vec, maxOff=40, normalized=False)
+    out["corrlen/given"] = np.float64(mc.getCorrelationLength(0, corr=out["autocorr/3/1"]))
+    # a slowly mixing single chain: the 5 % crossing lies beyond a thousand lags
+    rng = np.random.default_rng(5)
+    n_ar = 60000
+    e = rng.standard_normal(n_ar)
+    ar = np.empty(n_ar)
+    ar[0] = e[0]
+    for t in range(1, n_ar):
+        ar[t] = 0.9985 * ar[t - 1] + e[t]
+    slow = MCSamples(samples=ar.reshape(-1, 1), names=["s"])
+    out["slow/corrlen"] = np.float64(slow.getCorrelationLength(0))
+    out["slow/corrlen_rows"] = np.float64(slow.getCorrelationLength(0, weight_units=False))
+    mc = fresh(); mc.thin(3); state(mc, "thin3", out)
+    mc = fresh(); mc.weighted_thin(2); state(mc, "wthin2", out)
+    mc = fresh(); mc.filter(mc.samples[:, 0] > -0.4); state(mc, "filter", out)
+    mc = fresh(); mc.reweightAddingLogLikes(extra.copy()); state(mc, "reweight", out)
+    mc = fresh(); mc.cool(1.7); state(mc, "cool", out)
+    mc = fresh(); mc.removeBurn(0.2); state(mc, "burn", out)
+    mc = fresh()
+    mc.addDerived(mc.samples[:, 0] * mc.samples[:, 1] + 0.2 * mc.samples[:, 3], "d01", label="d_{01}", range=(None, 6.0))
+    state(mc, "derived", out)
+    out["derived/P1d"] = mc.get1DDensity("d01").P
+    out["derived/P2d_sum"] = np.float64(np.sum(mc.get2DDensity("m0", "d01").P))
+    out["derived/isDerived"] = np.bool_(mc.paramNames.parWithName("d01").isDerived)
+    fx = np.column_stack([samples[:, 0], np.full(len(samples), 0.25), samples[:, 1]])
+    mc = MCSamples(samples=fx, weights=weights.copy(), names=["a", "fixed", "b"])
+    out["fixed/names_after"] = np.array([p.name for p in mc.paramNames.names])
+    out["fixed/value"] = np.float64(mc.ranges.getLower("fixed"))
+    # ---- convolve.py on seeded inputs
+    rng = np.random.default_rng(123)
+    x1, y1, ys, x2, y2 = rng.random(1024), rng.random(141), rng.random(1203), rng.random((128, 128)), rng.random((31, 31))
+    xl = rng.random(1500)
+    for mode in ("same", "valid", "full"):
+        out["conv1d/direct/" + mode] = rconv.convolve1D(x1, y1, mode)
+        out["conv1d/fft/" + mode] = rconv.convolve1D(xl, ys, mode, largest_size=3000)
+        out["conv2d/" + mode] = rconv.convolve2D(x2, y2, mode, largest_size=128 + 2 * 15 + 31)
+    out["conv1d/periodic"] = rconv.convolve1D(x1, y1, "periodic")
+    for mode in ("periodic", "periodic_x", "periodic_y"):
+        out["conv2d/" + mode] = rconv.convolve2D(x2[:96, :80], y2[:21, :17], mode)
+    z = rng.standard_normal(20000)
+    out["autoconv/norm"] = rconv.autoConvolve(z, 300)
+    out["autoconv/raw"] = rconv.autoConvolve(z, 300, normalize=False)
+    out["autocorrfn"] = rconv.autoCorrelation(z, 200)
+    return out
+
+
 def main():
+    if "--mutators" in sys.argv:
+        out = golden_mutators()
+        path = os.path.join(HERE, "mutators.npz")
+        np.savez_compressed(path, **out)
+        print("mutators:", len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+        return
     if "--reference-unit-tests" in sys.argv:
         out = golden_reference_unit_tests()
         path = os.path.join(HERE, "reference_unit_tests.npz")

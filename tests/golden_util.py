@@ -92,3 +92,122 @@ def reference_unit_test_checks(factory=None):
         assert round(abs(lims[k].lower - float(g["limits/asserted"][k])), 3) == 0  # assertAlmostEqual(..., 3)
         assert abs(lims[k].lower - float(g["limits/x_lower"][k])) < 1e-6
     assert bool(lims[2].onetail_lower) == bool(g["limits/x_onetail_lower_2"])
+
+
+def mutator_checks(factory=None, tol=1e-9):
+    """
+    Every mutator of the sample set the reference offers on this path (thin, weighted_thin, filter,
+    reweightAddingLogLikes, cool, removeBurn, addDerived, deleteFixedParams), getLikeStats, the autocorrelation entry
+    points with many lags / vectors / corr=, and the public functions of getdist_amd.convolve, against what the imported
+    reference returned for the same seeded inputs (tests/golden/mutators.npz, made by make_golden.py --mutators).
+    ``factory`` = a Context stand-in for the CPU tier (None: the HIP library).
+    """
+    import sys
+
+    from getdist_amd import convolve as conv
+    from getdist_amd.mcsamples import MCSamples
+
+    sys.path.insert(0, GOLDEN_DIR)
+    from make_golden_inputs import mutator_inputs
+
+    g = np.load(GOLDEN_DIR + "/mutators.npz")
+    samples, weights, loglikes, names, offsets, extra = mutator_inputs()
+    kw = {} if factory is None else dict(_context_factory=factory)
+    cut = lambda a: [a[lo:hi] for lo, hi in zip(offsets[:-1], offsets[1:])]  # noqa: E731
+
+    def fresh():
+        return MCSamples(samples=[c.copy() for c in cut(samples)], weights=[c.copy() for c in cut(weights)],
+                         loglikes=[c.copy() for c in cut(loglikes)], names=names, ranges={"m3": (-3.0, None)}, **kw)
+
+    def check_state(mc, tag):
+        assert mc.numrows == int(g[tag + "/numrows"]), tag
+        assert abs(mc.norm - float(g[tag + "/norm"])) <= tol * float(g[tag + "/norm"]), tag
+        assert relerr(mc.means, g[tag + "/means"]) < tol, tag
+        assert relerr(mc.fullcov, g[tag + "/cov"]) < tol, tag
+        assert abs(mc.max_mult - float(g[tag + "/max_mult"])) <= tol * float(g[tag + "/max_mult"]), tag
+        if tag + "/loglike_sum" in g.files:
+            w = mc.weights if mc.weights is not None else np.ones(mc.numrows)
+            assert abs(np.dot(w, mc.loglikes) - float(g[tag + "/loglike_sum"])) <= tol * abs(float(g[tag + "/loglike_sum"])), tag
+        if tag + "/chain_offsets" in g.files and tag not in ("thin3", "burn"):  # the reference leaves those two stale
+            assert np.array_equal(np.asarray(mc.chain_offsets), g[tag + "/chain_offsets"]), tag
+
+    mc = fresh()
+    check_state(mc, "base")
+    ls = mc.getLikeStats()
+    got = np.array([ls.logLike_sample, np.nan if ls.logMeanInvLike is None else ls.logMeanInvLike, ls.meanLogLike,
+                    ls.logMeanLike, ls.complexity, ls.varLogLike])
+    want = g["likestats/scalars"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=tol, atol=0)
+    assert np.array_equal(np.array([p.bestfit_sample for p in mc.paramNames.names]), g["likestats/bestfit"])
+    # the N-D region: the reference keeps an arbitrary subset of the rows tied with the threshold likelihood, the device
+    # excludes them all; without ties (this fixture) the limits are the same sample values
+    assert np.array_equal(np.array([p.ND_limit_bot for p in mc.paramNames.names]), g["likestats/ND_bot"])
+    assert np.array_equal(np.array([p.ND_limit_top for p in mc.paramNames.names]), g["likestats/ND_top"])
+    assert mc.getLikeStats() is ls  # cached until the samples change
+    for j in (0, 3):
+        for wu in (True, False):
+            assert relerr(mc.getAutocorrelation(j, maxOff=700, weight_units=wu), g["autocorr/%d/%d" % (j, wu)]) < tol
+        assert abs(mc.getCorrelationLength(j) - float(g["corrlen/%d" % j])) < tol * float(g["corrlen/%d" % j])
+    vec = mc.samples[:, 1] * mc.samples[:, 2]
+    assert relerr(mc.getAutocorrelation(vec, maxOff=40, normalized=False), g["autocorr/vec"]) < tol
+    assert abs(mc.getCorrelationLength(0, corr=g["autocorr/3/1"]) - float(g["corrlen/given"])) < 1e-12 * float(g["corrlen/given"])
+    rng = np.random.default_rng(5)
+    n_ar = 60000
+    e = rng.standard_normal(n_ar)
+    ar = np.empty(n_ar)
+    ar[0] = e[0]
+    for t in range(1, n_ar):
+        ar[t] = 0.9985 * ar[t - 1] + e[t]
+    slow = MCSamples(samples=ar.reshape(-1, 1), names=["s"], **kw)
+    assert float(g["slow/corrlen"]) > 1000  # far beyond the direct-lag window: the FFT route
+    assert abs(slow.getCorrelationLength(0) - float(g["slow/corrlen"])) < tol * float(g["slow/corrlen"])
+    assert abs(slow.getCorrelationLength(0, weight_units=False) - float(g["slow/corrlen_rows"])) < tol * float(g["slow/corrlen_rows"])
+    mc = fresh(); mc.thin(3); check_state(mc, "thin3")  # noqa: E702
+    assert mc.weights is None and mc.chain_offsets[-1] == mc.numrows
+    mc = fresh(); mc.weighted_thin(2); check_state(mc, "wthin2")  # noqa: E702
+    mc = fresh(); mc.filter(mc.samples[:, 0] > -0.4); check_state(mc, "filter")  # noqa: E702
+    mc = fresh(); mc.reweightAddingLogLikes(extra.copy()); check_state(mc, "reweight")  # noqa: E702
+    mc = fresh(); mc.cool(1.7); check_state(mc, "cool")  # noqa: E702
+    assert mc.cooled == 1.7
+    mc = fresh(); mc.removeBurn(0.2); check_state(mc, "burn")  # noqa: E702
+    mc = fresh()
+    par = mc.addDerived(mc.samples[:, 0] * mc.samples[:, 1] + 0.2 * mc.samples[:, 3], "d01", label="d_{01}", range=(None, 6.0))
+    check_state(mc, "derived")
+    assert par.isDerived == bool(g["derived/isDerived"]) and mc.n == len(names) + 1 and mc.index["d01"] == len(names)
+    assert relerr(mc.get1DDensity("d01").P, g["derived/P1d"]) < 1e-6
+    p2 = mc.get2DDensity("m0", "d01").P
+    assert abs(np.sum(p2) - float(g["derived/P2d_sum"])) < 2e-3 * float(g["derived/P2d_sum"])  # TNC pair: see DESIGN.md
+    try:
+        mc.addDerived(mc.samples[:, 0], "d01")
+        raise AssertionError("duplicate derived name accepted")
+    except ValueError:
+        pass
+    fx = np.column_stack([samples[:, 0], np.full(len(samples), 0.25), samples[:, 1]])
+    mc = MCSamples(samples=fx, weights=weights.copy(), names=["a", "fixed", "b"], **kw)
+    assert [p.name for p in mc.paramNames.names] == [str(v) for v in g["fixed/names_after"]]
+    assert mc.ranges.getLower("fixed") == float(g["fixed/value"])
+    mc2 = MCSamples(samples=samples[:, :3].copy(), weights=weights.copy(), names=["a", "b", "c"], **kw)
+    mc2.samples = np.column_stack([samples[:, 0], np.full(len(samples), 0.25), samples[:, 1]])  # edited in place, then:
+    fixed, values = mc2.deleteFixedParams()
+    assert fixed == [1] and values == [0.25] and mc2.n == 2 and [p.name for p in mc2.paramNames.names] == ["a", "c"]
+    assert relerr(mc2.means, [np.average(samples[:, 0], weights=weights), np.average(samples[:, 1], weights=weights)]) < 1e-12
+    # ---- getdist_amd.convolve against getdist.convolve
+    conv.set_context(mc.ctx)
+    try:
+        rng = np.random.default_rng(123)
+        x1, y1, ys, x2, y2 = rng.random(1024), rng.random(141), rng.random(1203), rng.random((128, 128)), rng.random((31, 31))
+        xl = rng.random(1500)
+        for mode in ("same", "valid", "full"):
+            assert relerr(conv.convolve1D(x1, y1, mode), g["conv1d/direct/" + mode]) < 1e-13, mode
+            assert relerr(conv.convolve1D(xl, ys, mode, largest_size=3000), g["conv1d/fft/" + mode]) < 1e-12, mode
+            assert relerr(conv.convolve2D(x2, y2, mode, largest_size=128 + 2 * 15 + 31), g["conv2d/" + mode]) < 1e-12, mode
+        assert relerr(conv.convolve1D(x1, y1, "periodic"), g["conv1d/periodic"]) < 1e-12
+        for mode in ("periodic", "periodic_x", "periodic_y"):
+            assert relerr(conv.convolve2D(x2[:96, :80], y2[:21, :17], mode), g["conv2d/" + mode]) < 1e-12, mode
+        z = rng.standard_normal(20000)
+        assert relerr(conv.autoConvolve(z, 300), g["autoconv/norm"]) < 1e-11
+        assert relerr(conv.autoConvolve(z, 300, normalize=False), g["autoconv/raw"]) < 1e-11
+        assert relerr(conv.autoCorrelation(z, 200), g["autocorrfn"]) < 1e-11
+    finally:
+        conv.set_context(None)

@@ -634,3 +634,9 @@ def test_lazy_results_pickle_and_copy(zoo):
 def test_reference_unit_tests_host_logic():
     """getdist_test.py's testFileLoadPlot / testLimits numbers with the device calls played by the numpy double."""
     gu.reference_unit_test_checks(FakeContext)
+
+
+def test_mutators_like_stats_autocorrelation_and_convolve_host_logic():
+    """SURVEY.md 8b state invalidation: every mutator, getLikeStats, the long-lag autocorrelation route and the
+    convolve module against the reference's outputs, with the device calls played by the numpy double."""
+    gu.mutator_checks(FakeContext)
