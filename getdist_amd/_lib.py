@@ -242,7 +242,7 @@ class Context:
         p = _p()
         self._check(self.lib.gd_host_alloc(self.h, nbytes, C.byref(p)))
         buf = (C.c_ubyte * nbytes).from_address(p.value)
-        self._pinned_blocks.append(p.value)
+        self._pinned_blocks.append((p.value, buf))
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def reserve_pinned_twin(self):
@@ -254,13 +254,21 @@ class Context:
             self._pinned.append((p.value, nb, (C.c_ubyte * nb).from_address(p.value)))
 
     def close(self):
+        """Free the device side.  Page-locked host blocks that some numpy array still views (mc.samples loaded from the
+        binary cache, a Density2D.P the user kept) are NOT freed: every view holds the block's ctypes buffer, so its
+        reference count tells; such a block stays valid for the life of the process instead of dangling."""
+        import sys
+
         if self.h:
+            self.lib.gd_copy_sync(self.h)  # result copies in flight land before their targets could go away
             self.release_cached_blocks()
-            for ptr, _, _ in getattr(self, "_pinned", []):
-                self.lib.gd_host_free(self.h, ptr)
+            for ptr, _, buf in getattr(self, "_pinned", []):
+                if sys.getrefcount(buf) <= 3:
+                    self.lib.gd_host_free(self.h, ptr)
             self._pinned = []
-            for ptr in getattr(self, "_pinned_blocks", []):
-                self.lib.gd_host_free(self.h, ptr)
+            for ptr, buf in getattr(self, "_pinned_blocks", []):
+                if sys.getrefcount(buf) <= 3:
+                    self.lib.gd_host_free(self.h, ptr)
             self._pinned_blocks = []
             self.lib.gd_destroy(self.h)
             self.h = None

@@ -42,7 +42,14 @@ def loadNumpyTxt(fname, skiprows=None):
         # round_trip: correctly rounded decimal -> double, bit-equal to np.loadtxt (the default fast parser is not)
         df = pd.read_csv(fname, sep=r"\s+", header=None, comment="#", skiprows=skiprows or 0, dtype=np.float64,
                          engine="c", float_precision="round_trip")
-        return np.atleast_2d(df.to_numpy())
+        arr = np.atleast_2d(df.to_numpy())
+        if np.isnan(arr).any():
+            # pandas pads a short row with NaN where np.loadtxt -- the reference -- raises: a chain file that is still
+            # being written must fail loudly, not yield a NaN sample (and poison the binary cache).  NaN written in the
+            # file itself parses identically in np.loadtxt, which then decides.
+            print("Error reading %s" % fname)
+            return np.atleast_2d(np.loadtxt(fname, skiprows=skiprows or 0))
+        return arr
     except ImportError:
         return np.atleast_2d(np.loadtxt(fname, skiprows=skiprows or 0))
     except ValueError:

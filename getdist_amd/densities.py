@@ -290,8 +290,8 @@ class Density2D(GridDensity):
         d = self.__dict__
         waiter = d.get("_wait")
         if waiter is not None:
+            waiter()  # raises DensitiesError for an empty grid -- on every read of it: the waiter stays in place
             d["_wait"] = None
-            waiter()
         return d.get("_P")
 
     @P.setter

@@ -192,23 +192,42 @@ class ParamBounds:
         return self.upper.get(name)
 
 
+# keys of a reference analysis .ini that are settings of this path although they are not in analysis_defaults.ini by
+# that name: the contour list in its numbered form and the limit-type overrides (mcsamples.py:417-433)
+_INI_EXTRA = ("num_contours", "force_twotail")
+
+
 def _read_ini_settings(ini):
     """
     The analysis settings of a GetDist .ini file (``key = value`` lines, ``#`` comments; inifile.py:100-180) that this
     path knows; other keys (plot options, file lists) are ignored like the reference ignores what it does not read.
-    A dict is passed through.
+    ``num_contours`` + ``contour1..N`` become ``contours`` (unless ``contours`` itself is given, mcsamples.py:420-424),
+    ``force_twotail`` and ``max_frac_twotailN`` are kept (mcsamples.py:417,426-431).  A dict is passed through.
     """
     if isinstance(ini, dict):
-        return {k: v for k, v in ini.items() if k in DEFAULT_SETTINGS}
+        raw = {str(k): v for k, v in ini.items()}
+    else:
+        raw = {}
+        with open(ini, encoding="utf-8-sig") as f:
+            for line in f:
+                line = line.split("#", 1)[0].strip()
+                if "=" not in line:
+                    continue
+                key, value = (t.strip() for t in line.split("=", 1))
+                if value != "":
+                    raw[key] = value
     out = {}
-    with open(ini, encoding="utf-8-sig") as f:
-        for line in f:
-            line = line.split("#", 1)[0].strip()
-            if "=" not in line:
-                continue
-            key, value = (t.strip() for t in line.split("=", 1))
-            if key in DEFAULT_SETTINGS and value != "":
-                out[key] = [float(v) for v in value.split()] if key == "contours" else value
+    for key, value in raw.items():
+        if key in DEFAULT_SETTINGS:
+            out[key] = [float(v) for v in value.split()] if (key == "contours" and isinstance(value, str)) else value
+        elif key == "force_twotail" or key.startswith("max_frac_twotail"):
+            out[key] = value
+    if "contours" not in out and "num_contours" in raw:
+        n = int(raw["num_contours"])
+        missing = [i + 1 for i in range(n) if "contour%d" % (i + 1) not in raw]
+        if missing:
+            raise SettingError("num_contours = %d but contour%d is not set" % (n, missing[0]))
+        out["contours"] = [float(raw["contour%d" % (i + 1)]) for i in range(n)]
     return out
 
 
@@ -256,32 +275,48 @@ def _hostlog(what):
 class _PendingResults:
     """
     The tail of a batched 2D call whose result copies are still in flight: the device grids, the inputs that must not
-    be recycled before the kernels reading them have run, and the page-locked status words.  wait() blocks until THIS
-    call's copies have landed (a mark on the copy stream, so a later call's copies are not waited for), releases the
-    device blocks and raises if any grid was empty.  Idempotent; also runs when the results are collected.
+    be recycled before the kernels reading them have run, and the page-locked status words.
+
+    wait() blocks until THIS call's copies have landed (a mark on the copy stream, so a later call's copies are not
+    waited for), releases the device blocks and records which grids came back empty; it is idempotent, serialised by a
+    lock (a second reader thread returns only after the copies have landed), and marks itself done only after the wait
+    succeeded.  wait_grid(k) -- what a grid's first read calls -- completes the call and raises DensitiesError every
+    time the grid of pair ``k`` is read if THAT grid had no samples; its siblings are unaffected.  The next batched
+    call on the same object completes this one before it takes its place, so an unread triangle never pins its device
+    blocks beyond one further call.
     """
 
     def __init__(self, ctx, inflight, release):
         self.ctx, self.inflight, self.release = ctx, inflight, release
         self.token = ctx.copy_mark()
         self.done = False
+        self.failed = frozenset()
+        self.lock = threading.Lock()
 
     def wait(self):
-        if self.done:
-            return
-        self.done = True
-        if getattr(self.ctx, "h", True) is None:  # the context was closed: its memory is gone with it
-            return
-        self.ctx.copy_wait(self.token)
-        failed = any(np.any(np.asarray(status) != 0) for _, _, _, status, _, _, _ in self.inflight)
-        for d_P, _, _, _, d_L, _, _ in self.inflight:
-            d_P.free()
-            if d_L is not None:
-                d_L.free()
-        for buf in self.release:
-            buf.free()
-        self.inflight = self.release = ()
-        if failed:
+        with self.lock:
+            if self.done:
+                return
+            if getattr(self.ctx, "h", True) is not None:  # a closed context has synchronised its streams on the way out
+                self.ctx.copy_wait(self.token)
+            failed = set()
+            for _, _, ks, status, _, _, _ in self.inflight:
+                bad = np.nonzero(np.asarray(status) != 0)[0]
+                failed.update(ks[int(r)] for r in bad)
+            self.failed = frozenset(failed)
+            if getattr(self.ctx, "h", True) is not None:
+                for d_P, _, _, _, d_L, _, _ in self.inflight:
+                    d_P.free()
+                    if d_L is not None:
+                        d_L.free()
+                for buf in self.release:
+                    buf.free()
+            self.inflight = self.release = ()
+            self.done = True
+
+    def wait_grid(self, k):
+        self.wait()
+        if k in self.failed:
             raise DensitiesError("no samples in bin")
 
     def __del__(self):
@@ -584,7 +619,18 @@ class MCSamples:
                                                  initializer=twin.ctx.bind_thread)
         return self._lane_exec
 
+    def _finish_pending(self):
+        """Complete a lazily delivered batched call (its grids view page-locked memory of this object's contexts)."""
+        pend, self._pending_results = getattr(self, "_pending_results", None), None
+        if pend is not None:
+            pend.wait()
+        twin = getattr(self, "_twin", None)
+        if twin is not None and getattr(twin, "_pending_results", None) is not None:
+            pend, twin._pending_results = twin._pending_results, None
+            pend.wait()
+
     def _drop_second_lane(self):
+        self._finish_pending()
         if getattr(self, "_lane_exec", None) is not None:
             self._lane_exec.shutdown(wait=True)
         self._lane_exec = None
@@ -1199,6 +1245,15 @@ class MCSamples:
         if ini is not None:
             settings = dict(_read_ini_settings(ini), **(settings or {}))
         for k, v in (settings or {}).items():
+            if k == "force_twotail":
+                self.force_twotail = v in (True, "T", "t", "True", "true", 1)
+                if self.force_twotail:
+                    logging.warning("Computing two tail limits")
+                continue
+            if k.startswith("max_frac_twotail") and k[len("max_frac_twotail"):].isdigit():
+                self._max_frac_overrides = dict(getattr(self, "_max_frac_overrides", {}))
+                self._max_frac_overrides[int(k[len("max_frac_twotail"):]) - 1] = float(v)
+                continue
             if k not in DEFAULT_SETTINGS:
                 raise SettingError("unknown setting: %s" % k)
             cur = DEFAULT_SETTINGS[k]
@@ -1955,7 +2010,8 @@ class MCSamples:
         from scipy.stats import norm
         import math
 
-        return [np.exp(-1.0 * math.pow(norm.ppf((1 - c) / 2), 2) / 2) for c in self.contours]
+        over = getattr(self, "_max_frac_overrides", {})  # max_frac_twotailN of the .ini (mcsamples.py:429-430)
+        return [over.get(i, np.exp(-1.0 * math.pow(norm.ppf((1 - c) / 2), 2) / 2)) for i, c in enumerate(self.contours)]
 
     def _marge_limit_inputs(self, js, densities):
         """
@@ -2057,8 +2113,10 @@ class MCSamples:
         j2 = self._parAndNumber(j2)[0]
         if j is None or j2 is None:
             return None
-        return self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density,
-                                   meanlikes=meanlikes, mask_function=mask_function, **kwargs)[0]
+        density = self.get2DDensities([(j, j2)], num_plot_contours=num_plot_contours, get_density=get_density,
+                                      meanlikes=meanlikes, mask_function=mask_function, **kwargs)[0]
+        density.P  # a single-pair call delivers (and raises "no samples in bin") here, like the reference
+        return density
 
     def triangleDensities(self, params=None, **kwargs):
         """All lower-triangle pairs (x=params[i], y=params[i2>i]) in triangle-plot order; returns (pairs, densities)."""
@@ -2756,7 +2814,8 @@ class MCSamples:
         lazy = (enqueue_only and not synced and get_density and hasattr(ctx, "copy_mark")
                 and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
         completion = _PendingResults(ctx, inflight, release) if lazy else None
-        waiter = completion.wait if lazy else None
+        import functools
+
         for d_P, P, ks, status, d_L, L, levels in inflight:
             F = P.shape[1]
             lev_state = None if levels is None else np.asarray(levels[1]).tolist()
@@ -2774,7 +2833,8 @@ class MCSamples:
                         ncont = levels[0].shape[1]
                 dens = Density2D._from_fields(dict(
                     x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=e.get("mask"),
-                    likes=None if L is None else L[row], contours=contours, spl=None, _P=P[row], _wait=waiter,
+                    likes=None if L is None else L[row], contours=contours, spl=None, _P=P[row],
+                    _wait=functools.partial(completion.wait_grid, k) if lazy else None,
                     bandwidth=e.get("bandwidth"), bandwidth_branch=e.get("branch"), kopt=e.get("kopt")))
                 if contours is None and lev_state is not None:
                     # more exactly equal grid values at the level than the kernel's tie list holds
@@ -2783,7 +2843,11 @@ class MCSamples:
         _ph_asm.__exit__()
         _hostlog("results assembled")
         if lazy:
-            self._pending_results = completion  # finished by the next batched call at the latest
+            previous, self._pending_results = self._pending_results, completion
+            if previous is not None:
+                # the previous call's copies are ahead of this call's on the copy stream: completing it here costs no
+                # waiting, and its device blocks are released even if nobody ever read its grids
+                previous.wait()
             return out
         if not synced:
             with _Phase(self, "2d.d2h_wait"):

@@ -631,6 +631,48 @@ def test_lazy_results_pickle_and_copy(zoo):
     assert abs(float(np.ravel(clone.Prob(clone.x[10], clone.y[20]))[0]) - clone.P[20, 10]) < 1e-9  # spline rebuilt on demand
 
 
+def test_lazy_results_empty_grid_raises_at_every_read_of_that_grid_only(zoo, monkeypatch):
+    """'no samples in bin' belongs to the grid that is empty -- every read of it raises, its siblings of the
+    same call deliver, the single-pair entry points raise at the call site like the reference, and a later batched
+    call completes (and releases) the previous one."""
+    import pytest
+
+    from getdist_amd.densities import DensitiesError
+
+    fx = zoo["c1_bounded"]
+    mc = make(fx)
+    real = FakeContext.density2d
+
+    def one_empty(self, d_hist, B, F, *a, **k):
+        out, st = real(self, d_hist, B, F, *a, **k)
+        st[0] = -4  # the first grid of every batch comes back empty
+        return out, st
+
+    monkeypatch.setattr(FakeContext, "density2d", one_empty)
+    d = mc.get2DDensities([(0, 1), (0, 2), (1, 2)])
+    first_pending = mc._pending_results
+    empty = [q for q in range(3) if q in [ks[0] for _, _, ks, _, _, _, _ in first_pending.inflight]]
+    assert 0 < len(empty) < 3
+    for q in range(3):
+        if q in empty:
+            with pytest.raises(DensitiesError):
+                d[q].P
+            with pytest.raises(DensitiesError):  # again: not only the first reader learns about it
+                d[q].P
+        else:
+            assert d[q].P.shape == (256, 256) and d[q].P.max() == 1.0
+    with pytest.raises(DensitiesError):
+        mc.get2DDensity(0, 1)
+    with pytest.raises(DensitiesError):
+        mc.get2DDensityGridData(0, 1, get_density=True)
+    monkeypatch.setattr(FakeContext, "density2d", real)
+    d2 = mc.get2DDensities([(0, 1), (2, 3)])
+    assert first_pending.done and mc._pending_results is not first_pending  # completed by the later call
+    assert d2[0].P.max() == 1.0
+    mc._drop_second_lane()  # contexts going away complete what is pending first
+    assert mc._pending_results is None
+
+
 def test_reference_unit_tests_host_logic():
     """getdist_test.py's testFileLoadPlot / testLimits numbers with the device calls played by the numpy double."""
     gu.reference_unit_test_checks(FakeContext)
@@ -640,3 +682,34 @@ def test_mutators_like_stats_autocorrelation_and_convolve_host_logic():
     """SURVEY.md 8b state invalidation: every mutator, getLikeStats, the long-lag autocorrelation route and the
     convolve module against the reference's outputs, with the device calls played by the numpy double."""
     gu.mutator_checks(FakeContext)
+
+
+def test_truncated_chain_file_is_rejected_and_ini_contour_keys_are_honoured(tmp_path, zoo):
+    """a chain file whose last row is short raises like np.loadtxt (no NaN row reaches the samples or the
+    binary cache); num_contours / contourN / force_twotail / max_frac_twotailN of a reference .ini are applied."""
+    import pytest
+
+    from getdist_amd import chainfiles
+    from getdist_amd.mcsamples import MCSamples, _read_ini_settings
+
+    good = tmp_path / "ok_1.txt"
+    good.write_text("1 0.5 0.1 0.2\n2 0.6 0.3 0.4\n1 0.7 0.5 0.6\n")
+    assert chainfiles.loadNumpyTxt(str(good)).shape == (3, 4)
+    bad = tmp_path / "bad_1.txt"
+    bad.write_text("1 0.5 0.1 0.2\n2 0.6 0.3 0.4\n1 0.7 0.5\n")
+    with pytest.raises(ValueError):
+        chainfiles.loadNumpyTxt(str(bad))
+    ini = tmp_path / "a.ini"
+    ini.write_text("num_contours = 2\ncontour1 = 0.5\ncontour2 = 0.9\nforce_twotail = T\nmax_frac_twotail2 = 0.02\n"
+                   "fine_bins = 512\nplot_meanlikes = F\n")
+    st = _read_ini_settings(str(ini))
+    assert st["contours"] == [0.5, 0.9] and st["fine_bins"] == "512" and "plot_meanlikes" not in st
+    fx = zoo["c1_bounded"]
+    mc = MCSamples(samples=fx["samples"], names=fx["names"], ranges=fx["ranges"], ini=str(ini), _context_factory=FakeContext)
+    assert list(mc.contours) == [0.5, 0.9] and mc.force_twotail is True and mc.fine_bins == 512
+    mft = mc._max_frac_twotail()
+    assert mft[1] == 0.02 and abs(mft[0] - np.exp(-0.5 * 0.6744897501960817**2)) < 1e-12
+    ms = mc.getMargeStats()
+    assert len(ms.names[0].limits) == 2 and len(ms.names[3].limits) == 2  # one limit per contour of the .ini
+    with pytest.raises(Exception):
+        _read_ini_settings({"num_contours": 2, "contour1": 0.5})
