@@ -443,6 +443,41 @@ def get_h_is_chaotic(psi, N, corr_in, rel=1e-15, tol=1e-6, trials=6):
     return worst > tol, worst
 
 
+def get_h_ensemble(psi, N, corr_in, rel=1e-15, trials=12):
+    """
+    The reference's get_h on its own inputs and on 2 x ``trials`` copies perturbed by +-(1..trials) x ``rel`` (relative,
+    a different factor per functional): the set of bandwidth triples the reference's map produces for inputs that are
+    equal to rounding.  Returns an array (1 + 2 trials, 3); row 0 is the unperturbed result.
+    """
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rows = [get_h_from_psi(psi, N, corr_in, True)]
+        for k in range(1, trials + 1):
+            for sign in (1, -1):
+                pert = tuple(v * (1 + sign * k * rel * (1 + 0.37 * q)) for q, v in enumerate(psi))
+                rows.append(get_h_from_psi(pert, N, corr_in, True))
+    return np.array(rows, dtype=float)
+
+
+def within_oracle_spread(triple, ensemble, slack=1.0, floor=1e-6):
+    """
+    Does a bandwidth triple (hx, hy, c) lie inside what the reference itself produces for rounding-equal inputs?
+    Component by component: between the ensemble's minimum and maximum, widened on both sides by ``slack`` times the
+    ensemble's own spread (and by ``floor`` of the largest bandwidth, the strict tolerance).  Returns (ok, the largest
+    excess over the ensemble's range in units of that component's spread).
+    """
+    t = np.asarray(triple, dtype=float)
+    lo, hi = ensemble.min(axis=0), ensemble.max(axis=0)
+    spread = hi - lo
+    pad = slack * spread + floor * np.max(np.abs(ensemble[:, :2]))
+    ok = bool(np.all(t >= lo - pad) and np.all(t <= hi + pad))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        excess = np.where(spread > 0, np.maximum(np.maximum(lo - t, t - hi), 0) / spread, 0.0)
+    return ok, float(np.max(excess))
+
+
 def get_h_from_psi(psi, N, corr_in, do_correlation, owner=None):
     """
     The scalar half of KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given psi = (p02, p20, p11, p00, p13, p31):

@@ -40,6 +40,14 @@ def test_stats_and_ranges(zoo, name):
         if fx["weights"] is None or name == "shapes_intweights":
             assert np.array_equal(q, g["quantiles"][j])
         else:
+            # real weights: the cumulative weight is summed in another order than np.cumsum, so a target that lies
+            # within rounding of a step may pick the neighbouring sample -- per quantile: the reference's sample, or
+            # the one next to it in sort order
+            col = np.sort(np.asarray(fx["samples"])[:, j])
+            for got, want in zip(q, g["quantiles"][j]):
+                if got != want:
+                    k = int(np.searchsorted(col, want))
+                    assert got in col[max(k - 1, 0):k + 2], (name, j, got, want)
             assert np.mean(q == g["quantiles"][j]) >= 0.8
 
 
@@ -75,7 +83,7 @@ def uses_tnc(d, mc, a, b):
     return d.bandwidth_branch in ("A", "C") and not (px.has_limits or py.has_limits)
 
 
-# Gates of the 2D optimiser, at the level measured on MI355X (profiles/r02_parity_2d.json):
+# Gates of the 2D optimiser, at the level measured on MI355X (profiles/r03_parity_2d.json):
 TOL_TSTAR = 1e-10   # Brent stops at the same iterate: t* differs only by the rounding of the fixed-point functional
 TOL_PSI = 1e-10     # psi functionals at t* (fp64 bilinear forms, different summation order than numpy)
 # The reference is *chaotic* through TNC for some pairs: a 1e-15 relative perturbation of the psi functionals (what any
@@ -84,7 +92,12 @@ TOL_PSI = 1e-10     # psi functionals at t* (fp64 bilinear forms, different summ
 # reference is stable the strict 1e-6 gate applies end to end; the loose gate below is granted ONLY to pairs for which
 # the oracle itself is shown to move by more than 1e-6 under such a perturbation (get_h_is_chaotic), and each use is
 # recorded in the parity report.
-TOL_GRID_TNC = 2e-3
+# Round 3: the loose gate is 5e-4 of the grid maximum (nothing measured exceeds 3.2e-4), AND the device's raw bandwidth
+# triple must lie inside the set the oracle itself produces for rounding-equal inputs (get_h_ensemble: +-1..12e-15
+# perturbations of the functionals; within_oracle_spread), AND per fixture there may not be more loose pairs than pairs
+# on which the oracle is chaotic.  The report also counts the pairs on which the ORACLE's TNC, fed the DEVICE's
+# functionals, leaves its own result: the part of the looseness that is nothing but psi rounding.
+TOL_GRID_TNC = 5e-4
 TOL_BW_TNC = 0.25  # the AMISE is nearly flat in the correlation direction; the grid tolerance is the real gate
 PARITY_REPORT = {}
 
@@ -95,7 +108,7 @@ def _write_parity_report():
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r02_parity_2d.json"), "w") as f:
+    with open(os.path.join(out, "r03_parity_2d.json"), "w") as f:
         json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -108,7 +121,9 @@ def test_density_2d(zoo, name):
     mc = make(fx)
     orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
     report = PARITY_REPORT.setdefault(name, dict(pairs=0, tnc_pairs=0, loose=[], worst_tstar=0.0, worst_psi=0.0,
-                                                 worst_grid_strict=0.0, worst_grid_loose=0.0, worst_bw_strict=0.0))
+                                                 worst_grid_strict=0.0, worst_grid_loose=0.0, worst_bw_strict=0.0,
+                                                 tnc_pairs_chaotic_in_the_oracle=0, oracle_on_device_psi_leaves_its_result=0,
+                                                 worst_excess_over_oracle_spread=0.0))
     for kw in fx["kw2"]:
         dens = mc.get2DDensities(fx["pairs"], get_density=False, **kw)
         oracle_bw = []
@@ -134,15 +149,26 @@ def test_density_2d(zoo, name):
                     assert e_p <= TOL_PSI, (key, d.kopt, want)
             bw_err = gu.relerr(d.bandwidth, (tr["hx"], tr["hy"], tr["c"])) if auto else 0.0
             bw_agrees = bw_err < 1e-6
+            ens = None
+            if tnc and "p_13" in tr and d.kopt is not None:
+                # every TNC pair: what the oracle does for rounding-equal inputs, and for the device's own functionals
+                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+                ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
+                moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
+                report["tnc_pairs_chaotic_in_the_oracle"] += moved > 1e-6
+                on_dev = np.array(ko.get_h_from_psi(tuple(d.kopt[1:7]), tr["opt_N"], tr["opt_corr"], True), dtype=float)
+                report["oracle_on_device_psi_leaves_its_result"] += bool(np.max(np.abs(on_dev - ens[0])) > 1e-6 * np.max(np.abs(ens[0])))
             if not bw_agrees:
                 # the loose gate must be earned: a TNC pair whose bandwidth the ORACLE cannot reproduce under a 1e-15
-                # perturbation of its own inputs
-                assert tnc, (key, d.bandwidth, (tr["hx"], tr["hy"], tr["c"]))
-                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-                chaotic, moved = ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])
-                report["loose"].append(dict(pair=key, bandwidth_error=float(bw_err), oracle_moves_by=float(moved)))
-                assert chaotic, (key, "device and oracle bandwidths differ by %.2e but the oracle is stable (moves %.2e)"
-                                 % (bw_err, moved))
+                # perturbation of its own inputs, and a device result inside the oracle's own spread
+                assert tnc and ens is not None, (key, d.bandwidth, (tr["hx"], tr["hy"], tr["c"]))
+                inside, excess = ko.within_oracle_spread(d.kopt[8:11], ens)
+                report["loose"].append(dict(pair=key, bandwidth_error=float(bw_err), oracle_moves_by=moved,
+                                            excess_over_oracle_spread=excess))
+                report["worst_excess_over_oracle_spread"] = max(report["worst_excess_over_oracle_spread"], excess)
+                assert moved > 1e-6, (key, "device and oracle bandwidths differ by %.2e but the oracle is stable (moves %.2e)"
+                                      % (bw_err, moved))
+                assert inside, (key, "device triple outside the oracle's own spread", d.kopt[8:11], ens.min(axis=0), ens.max(axis=0))
                 assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < TOL_BW_TNC, (key, d.bandwidth, g[key + "/hxhyc"])
             elif auto:
                 report["worst_bw_strict"] = max(report["worst_bw_strict"], float(bw_err))
@@ -159,6 +185,8 @@ def test_density_2d(zoo, name):
             else:  # the committed reference grid of a TNC pair is itself one sample of the chaotic map
                 gu.check_grid_2d(g, key, d.P, TOL_GRID_TNC)
             assert np.allclose([d.x[0], d.x[-1], d.y[0], d.y[-1]], g[key + "/xy"], rtol=1e-12, atol=0), key
+        # no more loose pairs than pairs on which the oracle itself is chaotic
+        assert len(report["loose"]) <= report["tnc_pairs_chaotic_in_the_oracle"], (name, report)
         if oracle_bw[0][0] is not None:
             # same bandwidths in -> same grids out, for every pair, at the strict tolerance
             dens = mc.get2DDensities(fx["pairs"], _bandwidths=oracle_bw, **kw)

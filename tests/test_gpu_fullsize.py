@@ -66,11 +66,74 @@ def test_full_size_densities_are_sane_and_deterministic(big):
     d2 = mc.get2DDensities(pairs)
     for a, b in zip(d1, d2):
         assert a.P.max() == 1.0 and a.P.min() > -1e-12
-        assert np.allclose(a.P, b.P, rtol=0, atol=2e-3)  # TNC pairs are chaotic; the rest are bit-stable
-        assert abs(a.norm_integral() - b.norm_integral()) < 1e-2 * a.norm_integral()
+        assert np.array_equal(a.P, b.P)  # the same call twice on one device: every reduction has a fixed order
     p = mc.get1DDensities([0, 4, 9])
     for d in p:
         assert d.P.max() == 1.0 and d.P.shape == (1024,)
+
+
+def test_c3_full_shape_determinism_and_one_pair_per_census_class_against_the_oracle(tmp_path):
+    """C3 as BASELINE.json states it -- 50 parameters x 1e7 rows, all 1225 pairs: two identical calls on one device give
+    bit-identical grids (every reduction has a fixed order), and one pair of each (bandwidth branch, #bounded, grid size)
+    class is compared with the oracle at full size (strict 1e-6 gate; a TNC pair above it must be chaotic in the oracle
+    and inside the oracle's own spread)."""
+    import multiprocessing as mp
+    import os
+    import shutil
+    import tempfile
+
+    from getdist_amd.mcsamples import MCSamples
+    from parity_workers import oracle_pair
+
+    s, w, names, ranges = synth.config_c3(N_FULL, 50)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+    pairs = synth.triangle_pairs(50)
+    dens = mc.get2DDensities(pairs)
+    par = mc.paramNames.names
+    again = mc.get2DDensities(pairs)
+    differing = [pr for pr, d1, d2 in zip(pairs, dens, again) if not np.array_equal(d1.P, d2.P)]
+    assert not differing, ("same call, same device, different grids", len(differing), differing[:5])
+    klass = {}
+    for (a, b), d in zip(pairs, dens):
+        assert d.P.max() == 1.0 and d.P.min() > -1e-12
+        key = "%s/%d/%d" % (d.bandwidth_branch, int(bool(par[a].has_limits)) + int(bool(par[b].has_limits)), d.P.shape[0])
+        klass.setdefault(key, []).append((a, b))
+    assert len(klass) >= 8 and {256, 384, 768, 960} <= {int(k.split("/")[2]) for k in klass}  # SURVEY 8d census
+    picks = [members[len(members) // 2] for _, members in sorted(klass.items())]
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="gdamd_c3_", dir=shm)
+    try:
+        tasks = []
+        for (a, b) in picks:
+            path = os.path.join(tmp, "p%d_%d.npy" % (a, b))
+            np.save(path, np.ascontiguousarray(s[:, [a, b]]))
+            sub = [names[a], names[b]]
+            tasks.append(dict(pair=(a, b), path=path, names=sub, ranges={k: v for k, v in ranges.items() if k in sub}))
+        with mp.get_context("spawn").Pool(min(len(tasks), os.cpu_count() or 1)) as pool:
+            results = pool.map(oracle_pair, tasks, chunksize=1)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    by_pair = dict(zip(pairs, dens))
+    from oracle import kde_oracle as ko
+
+    report = {}
+    for r in results:
+        d = by_pair[tuple(r["pair"])]
+        assert d.bandwidth_branch == r["branch"] and d.P.shape == r["P"].shape, r["pair"]
+        err = float(np.max(np.abs(d.P - r["P"])))
+        report["%s-%s" % (names[r["pair"][0]], names[r["pair"][1]])] = dict(branch=r["branch"], F=int(d.P.shape[0]), max_abs_dP=err)
+        if r["tnc"]:
+            assert abs(d.kopt[0] - r["t_star"]) <= 1e-10 * r["t_star"]
+            assert np.max(np.abs(np.asarray(d.kopt[1:7]) - r["psi"]) / np.abs(r["psi"])) <= 1e-10
+        if err >= 1e-6:
+            assert r["tnc"], (r["pair"], err)
+            ens = r["ensemble"]
+            assert np.max(np.abs(ens - ens[0])) > 1e-6 * np.max(np.abs(ens[0])), (r["pair"], "oracle stable, device off", err)
+            assert ko.within_oracle_spread(d.kopt[8:11], ens)[0], (r["pair"], d.kopt[8:11], ens.min(axis=0), ens.max(axis=0))
+            assert err < 5e-4, (r["pair"], err)
+    _report("C3_census_parity", dict(classes=len(klass), pairs_checked=len(results), per_pair=report,
+                                     identical_reruns=len(pairs)))
+    mc.ctx.close()
 
 
 def test_mirror_symmetry_like_reference():
@@ -187,9 +250,11 @@ def test_full_size_grids_match_the_oracle(big):
             assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[ucols[a]], names[ucols[b]])
         else:
             psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-            chaotic, moved = ko.get_h_is_chaotic(psi, tr["opt_N"], tr["opt_corr"])
-            assert chaotic, (names[ucols[a]], names[ucols[b]], bw_err, moved)
-            assert np.max(np.abs(d.P - o["P"])) < 2e-3
+            ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
+            moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
+            assert moved > 1e-6, (names[ucols[a]], names[ucols[b]], bw_err, moved)
+            assert ko.within_oracle_spread(d.kopt[8:11], ens)[0], (d.kopt[8:11], ens.min(axis=0), ens.max(axis=0))
+            assert np.max(np.abs(d.P - o["P"])) < 5e-4
     print("full-size unbounded TNC pairs on the strict gate: %d of 2" % strict)
 
 
@@ -222,7 +287,7 @@ def _report(key, value):
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "r02_configs.json")
+    path = os.path.join(out, "r03_configs.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[key] = value
     with open(path, "w") as f:
@@ -354,16 +419,31 @@ def test_c2_weighted_full_size_1d_grids_against_the_oracle():
                        bounded=[p.name for p in mc.paramNames.names if p.has_limits]))
 
 
-@pytest.mark.skipif(__import__("os").environ.get("GETDIST_AMD_RUN_C5", "0") != "1",
-                    reason="C5 holds 80 GB of samples: run with GETDIST_AMD_RUN_C5=1 (results in profiles/r02_configs.json)")
+def _c5_fits():
+    """C5 keeps 80 GB of samples on the host and on the device: needs 100 GB of free HBM and 130 GB of free host RAM."""
+    try:
+        import psutil
+
+        from getdist_amd._lib import Context
+
+        ctx = Context(0)
+        free = ctx.device_info()["hbm_free"]
+        ctx.close()
+        return free > 100e9 and psutil.virtual_memory().available > 130e9
+    except Exception:
+        return False
+
+
 def test_c5_stress_full_size_properties():
     """C5 -- 200 parameters x 5e7 rows resident on ONE GPU (80 GB): margestats of all 200 parameters, then the full
     19 900-pair triangle in slabs, through size-independent properties (normalisation, determinism of a re-run pair,
-    2D marginal mass = 1D mass, quantile rank property)."""
+    2D marginal mass = 1D mass, quantile rank property), and one pair against the oracle at full size."""
     import time
 
     from getdist_amd.mcsamples import MCSamples
 
+    if __import__("os").environ.get("GETDIST_AMD_SKIP_C5", "0") == "1" or not _c5_fits():
+        pytest.skip("C5 needs 100 GB of free HBM and 130 GB of free host memory")
     n, N = 200, 50_000_000
     t0 = time.perf_counter()
     s, w, names, ranges = synth.block_recipe(n, N, weighted=False, stream=7)
@@ -396,7 +476,23 @@ def test_c5_stress_full_size_properties():
     t_tri = time.perf_counter() - t0
     d1 = mc.get2DDensities([pairs[5]])[0]
     d2 = mc.get2DDensities([pairs[5]])[0]
-    assert np.allclose(d1.P, d2.P, rtol=0, atol=2e-3)
-    _report("C5", dict(params=n, rows=N, pairs=done, generate_s=round(t_gen, 1), construct_upload_s=round(t_ctor, 1),
+    assert np.array_equal(d1.P, d2.P)  # the same call twice on one device: bit for bit
+    # one pair against the oracle at C5's full row count (a bounded pair: no TNC in its bandwidth)
+    from oracle import kde_oracle as ko
+
+    bounded = [j for j, p in enumerate(mc.paramNames.names) if p.has_limits]
+    a, b = bounded[0], bounded[1]
+    sub = [names[a], names[b]]
+    t0 = time.perf_counter()
+    orc = ko.OracleSamples(np.ascontiguousarray(s[:, [a, b]]), names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
+    tr = {}
+    o = orc.density_2d(0, 1, trace=tr)
+    t_oracle = time.perf_counter() - t0
+    d = mc.get2DDensities([(a, b)])[0]
+    assert d.bandwidth_branch == tr["branch"]
+    assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6, atol=1e-12)
+    c5_err = float(np.max(np.abs(d.P - o["P"])))
+    assert c5_err < 1e-6, (sub, c5_err)
+    _report("C5", dict(oracle_pair=sub, oracle_pair_max_abs_dP=c5_err, oracle_pair_cpu_s=round(t_oracle, 1), params=n, rows=N, pairs=done, generate_s=round(t_gen, 1), construct_upload_s=round(t_ctor, 1),
                        margestats_200_params_s=round(t_marge, 2), triangle_s=round(t_tri, 1),
                        densities_per_s=round(done / t_tri, 1), F_classes=sorted(classes)))
