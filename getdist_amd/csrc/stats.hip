@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(NW * 64, (MCAP == 112 ? 4 : 1)) k_cov_slab(con
 //     written), row-split h owns KS/4/NH of the slab's k-steps; the loop over (k-step, slot) is straight-line code
 //     and the compiler keeps several operand reads in flight ahead of the matrix pipe;
 //   * tile-pair bases are wave-uniform (readfirstlane): one VGPR holds the lane part of every operand address.
-// Partials: part[(block * NH + h) * T + pair][16 x 16]; k_cov_slab_fin sums nblocks * NH of them.
+// Partials: part[block * T + pair][16 x 16] (the NH row-splits are added inside the block); k_cov_slab_fin sums the blocks.
 template <bool HAS_W, int MCAP, int NW, int NH, int P, int KS, int DEPTH>
 __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict__ cols, int64_t ld,
                                                        const int32_t* __restrict__ colidx, int m,
@@ -526,20 +526,46 @@ __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict_
         // what the ring left: fewer than DEPTH whole slabs and the ragged end
         for (int64_t t_lo = a_lo + nring * KS; t_lo < c_hi; t_lo += KS) slab_guarded(t_lo, t_lo + KS < c_hi ? t_lo + KS : c_hi);
     }
+    if (NH == 1) {
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const int pq = g * P + q;
-        if (pq < T) {
-            double* p = part + (((int64_t)blockIdx.x * NH + h) * T + pq) * 256;
+        for (int q = 0; q < P; ++q) {
+            const int pq = g * P + q;
+            if (pq < T) {
+                double* p = part + ((int64_t)blockIdx.x * T + pq) * 256;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) p[(lk + 4 * rg) * 16 + l15] = acc[q][rg];
+                for (int rg = 0; rg < 4; ++rg) p[(lk + 4 * rg) * 16 + l15] = acc[q][rg];
+            }
+        }
+    } else {
+        // the NH row-splits of a tile pair are added up here, in the fixed order h = 0, 1, ..., through LDS (the staging
+        // area is free now): one partial per (block, pair) leaves the kernel, and the sum is the same in every run
+        __syncthreads();
+        double* red = lds;  // NG * P * 256 doubles (the launch sizes the dynamic LDS for it)
+#pragma unroll 1
+        for (int hh = 0; hh < NH; ++hh) {
+            if (h == hh) {
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int idx = (g * P + q) * 256 + (lk + 4 * rg) * 16 + l15;
+                        red[idx] = hh == 0 ? acc[q][rg] : red[idx] + acc[q][rg];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < NG * P * 256; e += NT) {
+            const int pq = e >> 8;
+            if (pq < T) part[((int64_t)blockIdx.x * T + pq) * 256 + (e & 255)] = red[e];
         }
     }
 }
 
-// cov[i][j] = sum over blocks / norm, mirrored; grid (pairs), 256 threads
-__global__ void __launch_bounds__(256) k_cov_slab_fin(const double* __restrict__ part, int nblocks, int m,
-                                                      const double* __restrict__ res, double* __restrict__ cov) {
+// cov[i][j] = sum over blocks / norm, mirrored; grid (pairs), 1024 threads: four interleaved partial sums per element
+// (four times the loads in flight), combined in a fixed order
+__global__ void __launch_bounds__(1024) k_cov_slab_fin(const double* __restrict__ part, int nblocks, int m,
+                                                       const double* __restrict__ res, double* __restrict__ cov) {
+    __shared__ double sh[4][256];
     const int nt = (m + 15) / 16, T = nt * (nt + 1) / 2;
     int pq = blockIdx.x, a = 0, len = nt;
     while (pq >= len) {
@@ -547,13 +573,22 @@ __global__ void __launch_bounds__(256) k_cov_slab_fin(const double* __restrict__
         ++a;
         --len;
     }
-    const int i = a * 16 + threadIdx.x / 16, j = (a + pq) * 16 + threadIdx.x % 16;
+    const int e = threadIdx.x & 255, lane4 = threadIdx.x >> 8;
+    const double* p = part + (int64_t)blockIdx.x * 256 + e;
+    double s0 = 0, s1 = 0;
+    int b = lane4;
+    for (; b + 4 < nblocks; b += 8) {
+        s0 += p[(int64_t)b * T * 256];
+        s1 += p[(int64_t)(b + 4) * T * 256];
+    }
+    if (b < nblocks) s0 += p[(int64_t)b * T * 256];
+    sh[lane4][e] = s0 + s1;
+    __syncthreads();
+    if (lane4 != 0) return;
+    const double v = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) / res[2];
+    const int i = a * 16 + e / 16, j = (a + pq) * 16 + e % 16;
     if (i >= m || j >= m) return;
-    const double* p = part + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += p[(int64_t)b * T * 256];
-    const double v = s / res[2];
-    if (a == a + pq && j < i) return;  // diagonal tiles: the upper triangle decides, so the result is exactly symmetric
+    if (pq == 0 && j < i) return;  // diagonal tiles: the upper triangle decides, so the result is exactly symmetric
     cov[(int64_t)i * m + j] = v;
     cov[(int64_t)j * m + i] = v;
 }
@@ -1200,7 +1235,8 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         GD_REQUIRE(pick >= 0, "covariance: no slab configuration");
         const Cfg cf = cfgs[pick];
         const bool hw = ctx->w != nullptr;
-        const size_t lds = (size_t)(hw ? 2 : 1) * mc * (KS + 2) * 8;
+        size_t lds = (size_t)(hw ? 2 : 1) * mc * (KS + 2) * 8;
+        if (cf.nh > 1) lds = std::max(lds, (size_t)(cf.nw / cf.nh) * cf.p * 256 * 8);  // the in-block sum over the row-splits
         int bpc = cf.bpc;
         while (bpc > 1 && (size_t)bpc * lds > 150u * 1024u) --bpc;
         int nblk = bpc * ctx->cu_count;
@@ -1211,7 +1247,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         nblk = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
         int64_t off = 0;
         const int64_t o_part1 = take_init(off, (int64_t)m * NBLK_STREAM * 4 * 8), o_res = take_init(off, (int64_t)m * 4 * 8),
-                      o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * cf.nh * T * 256 * 8),
+                      o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * T * 256 * 8),
                       o_cov = take_init(off, (int64_t)m * m * 8);
         char* base = (char*)gd_scratch(ctx, off);
         if (!base) return GD_ERR_NOMEM;
@@ -1251,7 +1287,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
 #undef GD_COV2_HW
 #undef GD_COV2
         GD_KERNEL_CHECK();
-        k_cov_slab_fin<<<T, 256, 0, ctx->stream>>>(d_cpart, nblk * cf.nh, m, d_res, d_cov);
+        k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
         GD_KERNEL_CHECK();
     } else if (slab) {
         // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
@@ -1302,7 +1338,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         }
 #undef GD_COV_LAUNCH
         GD_KERNEL_CHECK();
-        k_cov_slab_fin<<<T, 256, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
+        k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
         GD_KERNEL_CHECK();
     } else {
     const int nt = (m + CT - 1) / CT;
