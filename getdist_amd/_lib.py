@@ -72,6 +72,7 @@ SIGNATURES = {
     "gd_col_stats": (C.c_int, [_p, _i64, _i64, _pd]),
     "gd_cov": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _pd, _pd, _pd]),
     "gd_quantiles": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd]),
+    "gd_quantiles_mm": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd, _pd]),
     "gd_autocov_lags": (C.c_int, [_p, _i32, _f64, _i64, _i32, _pd]),
     "gd_kde_lag_sums": (C.c_int, [_p, _i32, _f64, _pi64, _i32, _pd]),
     "gd_hist1d": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, _pd]),
@@ -436,12 +437,15 @@ class Context:
                                     C.byref(norm), None if mm is None else _dp(mm)))
         return (means, cov, norm.value, mm) if minmax else (means, cov, norm.value)
 
-    def quantiles(self, cols, targets, lo=0, hi=None):
+    def quantiles(self, cols, targets, lo=0, hi=None, minmax=None):
+        """Weighted quantile selection; ``minmax`` (len(cols) x 2: each column's min and max over the rows, or over a
+        superset of them) enables the two-pass linear-bucket path."""
         cols = _i32arr(cols)
         targets = _f64arr(targets).reshape(len(cols), -1)
         out = np.zeros_like(targets)
-        self._check(self.lib.gd_quantiles(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi, _dp(targets),
-                                          targets.shape[1], _dp(out)))
+        mm = None if minmax is None else _f64arr(minmax).reshape(len(cols), 2)
+        self._check(self.lib.gd_quantiles_mm(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi, _dp(targets),
+                                             targets.shape[1], None if mm is None else _dp(mm), _dp(out)))
         return out
 
     def autocov_lags(self, col, mean, k0, nlags):

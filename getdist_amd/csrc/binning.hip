@@ -14,11 +14,38 @@
 
 #define LDS_HIST_BYTES (128 * 1024)
 
-__device__ __forceinline__ int bin_round(double x, double binmin, double width) {
-    return (int)((x - binmin) / width + 0.5);
+// The quotient (x - binmin) / width must be the correctly rounded IEEE quotient (bin indices are bit-exact against
+// numpy), but the divisor is the same for every sample of a column: with y = RN(1 / width) taken once per thread by a
+// true division, q <- RN(n y), then twice  r = n - q width (one exact FMA), q <- RN(q + r y)  yields RN(n / width) for
+// every n (Markstein's correction step: exact unless the divisor's significand is all ones, which takes the true
+// division below).  5 fp64 operations per sample instead of the ~30 of the division sequence (v_rcp_f64 at quarter
+// rate, three Newton steps, scale / fixup); checked against n / d on 4e8 random and near-half-integer cases on the host.
+struct BinDiv {
+    double binmin, width, rcp;
+};
+__device__ __forceinline__ BinDiv make_bindiv(double binmin, double width) {
+    BinDiv d;
+    d.binmin = binmin, d.width = width;
+    const unsigned long long mant = (unsigned long long)__double_as_longlong(width) & 0xFFFFFFFFFFFFFull;
+    d.rcp = (mant == 0xFFFFFFFFFFFFFull) ? 0.0 : 1.0 / width;  // 0: use the true division
+    return d;
 }
-__device__ __forceinline__ int bin_trunc(double x, double binmin, double width) {
-    return (int)((x - binmin) / width);
+__device__ __forceinline__ double bin_quotient(double x, const BinDiv& d) {
+    const double n = x - d.binmin;
+    double q = n * d.rcp;
+    double r = fma(-q, d.width, n);
+    q = fma(r, d.rcp, q);
+    r = fma(-q, d.width, n);
+    q = fma(r, d.rcp, q);
+    // infinities / NaN (r is NaN then) and the all-ones divisor: the division itself
+    if (!(fabs(q) < 1e300) || d.rcp == 0.0) q = n / d.width;
+    return q;
+}
+__device__ __forceinline__ int bin_round(double x, const BinDiv& d) {
+    return (int)(bin_quotient(x, d) + 0.5);
+}
+__device__ __forceinline__ int bin_trunc(double x, const BinDiv& d) {
+    return (int)bin_quotient(x, d);
 }
 
 // ---- 1D -----------------------------------------------------------------------------------------------
@@ -31,7 +58,7 @@ __global__ void __launch_bounds__(256) k_hist1d(const double* __restrict__ cols,
     extern __shared__ double sh[];  // 4 * F
     const int c = blockIdx.y;
     const double* x = cols + (int64_t)colidx[c] * ld;
-    const double b0 = binmin[c], wd = width[c];
+    const BinDiv bd = make_bindiv(binmin[c], width[c]);
     for (int i = threadIdx.x; i < 4 * F; i += 256) sh[i] = 0;
     __syncthreads();
     double* mine = sh + (threadIdx.x >> 6) * F;
@@ -41,12 +68,12 @@ __global__ void __launch_bounds__(256) k_hist1d(const double* __restrict__ cols,
         const double2 xv = *reinterpret_cast<const double2*>(x + i);
         double2 wv = make_double2(1.0, 1.0);
         if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
-        const int i0 = bin_round(xv.x, b0, wd), i1 = bin_round(xv.y, b0, wd);
+        const int i0 = bin_round(xv.x, bd), i1 = bin_round(xv.y, bd);
         if ((unsigned)i0 < (unsigned)F) atomicAdd(&mine[i0], wv.x);
         if ((unsigned)i1 < (unsigned)F) atomicAdd(&mine[i1], wv.y);
     }
     if (gtid == 0 && Ne < N) {
-        const int i0 = bin_round(x[Ne], b0, wd);
+        const int i0 = bin_round(x[Ne], bd);
         if ((unsigned)i0 < (unsigned)F) atomicAdd(&mine[i0], HAS_W ? w[Ne] : 1.0);
     }
     __syncthreads();
@@ -68,8 +95,9 @@ template <bool ROUND, typename T>
 __global__ void k_bin_indices(const double* __restrict__ x, int64_t N, double binmin, double width, int F,
                               T* __restrict__ idx, unsigned long long* __restrict__ n_bad) {
     unsigned long long bad = 0;
+    const BinDiv bd = make_bindiv(binmin, width);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const int v = ROUND ? bin_round(x[i], binmin, width) : bin_trunc(x[i], binmin, width);
+        const int v = ROUND ? bin_round(x[i], bd) : bin_trunc(x[i], bd);
         idx[i] = (T)v;
         bad += ((unsigned)v >= (unsigned)F);
     }
@@ -81,6 +109,7 @@ __global__ void __launch_bounds__(256) k_prebin(const double* __restrict__ x, in
                                                 int F, unsigned short* __restrict__ idx) {
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
     const int64_t N8 = N & ~(int64_t)7;
+    const BinDiv bd = make_bindiv(binmin, width);
     for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
         double2 v[4];
 #pragma unroll
@@ -88,7 +117,7 @@ __global__ void __launch_bounds__(256) k_prebin(const double* __restrict__ x, in
         unsigned short o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int a = bin_round(v[q].x, binmin, width), b = bin_round(v[q].y, binmin, width);
+            const int a = bin_round(v[q].x, bd), b = bin_round(v[q].y, bd);
             o[2 * q] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
             o[2 * q + 1] = (unsigned)b < (unsigned)F ? (unsigned short)b : (unsigned short)0xFFFF;
         }
@@ -101,7 +130,7 @@ __global__ void __launch_bounds__(256) k_prebin(const double* __restrict__ x, in
     }
     if (gtid == 0)
         for (int64_t i = N8; i < N; ++i) {
-            const int a = bin_round(x[i], binmin, width);
+            const int a = bin_round(x[i], bd);
             idx[i] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
         }
 }
@@ -115,6 +144,7 @@ struct PrebinCol {
 // all requested index columns in one launch; grid (blocks, ncols)
 __global__ void __launch_bounds__(256) k_prebin_batch(const PrebinCol* __restrict__ colsv, int64_t N, int F) {
     const PrebinCol C = colsv[blockIdx.y];
+    const BinDiv bd = make_bindiv(C.binmin, C.width);
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
     const int64_t N8 = N & ~(int64_t)7;
     for (int64_t i = 8 * gtid; i < N8; i += 8 * gsz) {
@@ -124,7 +154,7 @@ __global__ void __launch_bounds__(256) k_prebin_batch(const PrebinCol* __restric
         unsigned int o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int a = bin_round(v[q].x, C.binmin, C.width), b = bin_round(v[q].y, C.binmin, C.width);
+            const int a = bin_round(v[q].x, bd), b = bin_round(v[q].y, bd);
             o[2 * q] = (unsigned)a < (unsigned)F ? (unsigned)a : 0xFFFFu;
             o[2 * q + 1] = (unsigned)b < (unsigned)F ? (unsigned)b : 0xFFFFu;
         }
@@ -137,7 +167,7 @@ __global__ void __launch_bounds__(256) k_prebin_batch(const PrebinCol* __restric
     }
     if (gtid == 0)
         for (int64_t i = N8; i < N; ++i) {
-            const int a = bin_round(C.x[i], C.binmin, C.width);
+            const int a = bin_round(C.x[i], bd);
             C.idx[i] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
         }
 }
@@ -199,6 +229,7 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
     decode_block(nstripes, nchunks, pair, chunk, stripe);
     if (pair >= B) return;
     const Hist2DPair P = pairs[pair];
+    const BinDiv bdx = make_bindiv(P.bx, P.wx), bdy = make_bindiv(P.by, P.wy);
     const int row0 = stripe * R;
     for (int i = threadIdx.x; i < R * F; i += blockDim.x) sh[i] = 0;
     __syncthreads();
@@ -245,12 +276,12 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
             if (HAS_W) wv = *reinterpret_cast<const double2*>(w + i);
             int cx0, cy0, cx1, cy1;
             if (MODE == 0) {
-                cx0 = bin_round(xv.x, P.bx, P.wx), cy0 = bin_round(yv.x, P.by, P.wy);
-                cx1 = bin_round(xv.y, P.bx, P.wx), cy1 = bin_round(yv.y, P.by, P.wy);
+                cx0 = bin_round(xv.x, bdx), cy0 = bin_round(yv.x, bdy);
+                cx1 = bin_round(xv.y, bdx), cy1 = bin_round(yv.y, bdy);
             } else {
-                cx0 = bin_trunc(xv.x, P.bx, P.wx), cx1 = bin_trunc(xv.y, P.bx, P.wx);
+                cx0 = bin_trunc(xv.x, bdx), cx1 = bin_trunc(xv.y, bdx);
                 const double p0 = P.r0 * xv.x + P.r1 * yv.x, p1 = P.r0 * xv.y + P.r1 * yv.y;
-                cy0 = bin_trunc(p0, P.by, P.wy), cy1 = bin_trunc(p1, P.by, P.wy);
+                cy0 = bin_trunc(p0, bdy), cy1 = bin_trunc(p1, bdy);
             }
             unsigned r = (unsigned)cy0 - (unsigned)row0;
             if (r < (unsigned)R && (unsigned)cx0 < (unsigned)F && (unsigned)cy0 < (unsigned)F)
@@ -263,10 +294,10 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
             const double xv = P.x[hi2], yv = P.y[hi2];
             int cx, cy;
             if (MODE == 0) {
-                cx = bin_round(xv, P.bx, P.wx), cy = bin_round(yv, P.by, P.wy);
+                cx = bin_round(xv, bdx), cy = bin_round(yv, bdy);
             } else {
-                cx = bin_trunc(xv, P.bx, P.wx);
-                cy = bin_trunc(P.r0 * xv + P.r1 * yv, P.by, P.wy);
+                cx = bin_trunc(xv, bdx);
+                cy = bin_trunc(P.r0 * xv + P.r1 * yv, bdy);
             }
             const unsigned r = (unsigned)cy - (unsigned)row0;
             if (r < (unsigned)R && (unsigned)cx < (unsigned)F && (unsigned)cy < (unsigned)F)
@@ -295,6 +326,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16(const Hist2DPair* __restric
     decode_block(nstripes, 1, pair, chunk, stripe);
     if (pair >= B) return;
     const Hist2DPair P = pairs[pair];
+    const BinDiv bdx = make_bindiv(P.bx, P.wx), bdy = make_bindiv(P.by, P.wy);
     const int row0 = stripe * R;
     const int nwords = (R * F + 1) / 2;
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) sh[i] = 0;
@@ -481,6 +513,7 @@ struct PrebinCol8 {
 __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restrict__ colsv, int64_t N, int F,
                                                        unsigned long long* __restrict__ bad) {
     const PrebinCol8 C = colsv[blockIdx.y];
+    const BinDiv bd = make_bindiv(C.binmin, C.width);
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
     const int64_t N8 = N & ~(int64_t)7;
     unsigned nbad = 0;
@@ -491,7 +524,7 @@ __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restr
         unsigned o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int a = bin_round(v[q].x, C.binmin, C.width), b = bin_round(v[q].y, C.binmin, C.width);
+            const int a = bin_round(v[q].x, bd), b = bin_round(v[q].y, bd);
             nbad += ((unsigned)a >= (unsigned)F) + ((unsigned)b >= (unsigned)F);
             o[2 * q] = (unsigned)a & 0xffu;
             o[2 * q + 1] = (unsigned)b & 0xffu;
@@ -503,7 +536,7 @@ __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restr
     }
     if (gtid == 0)
         for (int64_t i = N8; i < N; ++i) {
-            const int a = bin_round(C.x[i], C.binmin, C.width);
+            const int a = bin_round(C.x[i], bd);
             nbad += ((unsigned)a >= (unsigned)F);
             C.idx[i] = (unsigned char)a;
         }
@@ -526,6 +559,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
     decode_block(nstripes, nchunks, pair, chunk, stripe);
     if (pair >= B) return;
     const Hist2DPair P = pairs[pair];
+    const BinDiv bdx = make_bindiv(P.bx, P.wx), bdy = make_bindiv(P.by, P.wy);
     const int row0 = stripe * R;
     const int nwords = (R * F + 1) / 2;
     for (int i = threadIdx.x; i < nwords; i += 1024) sh[i] = 0;
@@ -539,10 +573,10 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
     auto visit = [&](double xv, double yv) {
         int cx, cy;
         if (MODE == 0) {
-            cx = bin_round(xv, P.bx, P.wx), cy = bin_round(yv, P.by, P.wy);
+            cx = bin_round(xv, bdx), cy = bin_round(yv, bdy);
         } else {
-            cx = bin_trunc(xv, P.bx, P.wx);
-            cy = bin_trunc(P.r0 * xv + P.r1 * yv, P.by, P.wy);
+            cx = bin_trunc(xv, bdx);
+            cy = bin_trunc(P.r0 * xv + P.r1 * yv, bdy);
         }
         const unsigned r = (unsigned)cy - (unsigned)row0;
         if (r < (unsigned)R && (unsigned)cx < (unsigned)F && (unsigned)cy < (unsigned)F) {

@@ -2,6 +2,9 @@
 // All streaming kernels read the SoA columns with 16-byte (double2) loads, coalesced across the wave.
 #include "ctx.hpp"
 
+#include <algorithm>
+#include <cmath>
+
 #define NBLK_STREAM 1024  // blocks per column for streaming reductions (x 256 threads): >> 256 CUs
 
 // Stream rows [lo,hi) of x (and w) with double2 loads; f(xval, wval) per element.
@@ -865,6 +868,180 @@ __global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__
     }
 }
 
+// ---- linear-bucket select: two reads of the columns instead of four -----------------------------------------------
+// When the column's minimum and maximum are known (the base statistics have them), ONE counting pass over
+// b = (int)((x - min) * scale) -- monotone in x, so buckets partition the sort order exactly like radix digits do --
+// with 32768 (unit weights, u32 counters) or 16384 (fp64 weight sums) buckets held in LDS narrows every target to a
+// bucket of a few hundred to a few thousand rows; the collect pass and k_qsel_finish (sorted walk of the cumulative
+// weight, chains.py:807-838) are those of the radix path.  The radix path's first digit is sign + exponent, which
+// separates nothing for data of one magnitude: that is why it needs three passes before the collect.
+#define QLIN_NB_U 32768
+#define QLIN_NB_W 16384
+struct QLin {  // per column, next to its QState
+    double mn, scale;
+    int nb, pad;
+    int ubucket[QK_MAX];
+};
+__device__ __forceinline__ int qlin_bucket(double v, double mn, double scale, int nb) {
+    int b = (int)((v - mn) * scale);
+    b = b < 0 ? 0 : b;
+    return b < nb ? b : nb - 1;
+}
+
+template <bool HAS_W>
+__global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                                                     const double* __restrict__ w, int64_t lo, int64_t hi,
+                                                     const QLin* __restrict__ ql, void* __restrict__ part) {
+    extern __shared__ double qsh[];
+    const int c = blockIdx.y;
+    const double* x = cols + (int64_t)colidx[c] * ld;
+    const double mn = ql[c].mn, scale = ql[c].scale;
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
+    unsigned int* hu = reinterpret_cast<unsigned int*>(qsh);
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+        if (HAS_W)
+            qsh[i] = 0.0;
+        else
+            hu[i] = 0u;
+    }
+    __syncthreads();
+    stream_xw4<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        const int b = qlin_bucket(v, mn, scale, nb);
+        if (HAS_W)
+            atomicAdd(&qsh[b], wt);
+        else
+            atomicAdd(&hu[b], 1u);
+    });
+    __syncthreads();
+    if (HAS_W) {
+        double* p = (double*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
+        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = qsh[i];
+    } else {
+        unsigned int* p = (unsigned int*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
+        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = hu[i];
+    }
+}
+
+// per column: bucket totals (the blocks' partials added in block order), then every target's bucket -- the first
+// non-empty one at which the cumulative weight reaches the target -- and the weight below it; fills the QState the
+// collect / finish kernels read.  One block of 1024 threads per column; thread t owns PER consecutive buckets.
+template <bool HAS_W>
+__global__ void __launch_bounds__(1024) k_qlin_scan(QState* __restrict__ st, QLin* __restrict__ ql, const void* __restrict__ part,
+                                                    int nblk) {
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U, PER = nb / 1024;
+    __shared__ double tsum[1024];
+    __shared__ int pick[QK_MAX];
+    __shared__ double cumb[QK_MAX];
+    __shared__ int lastne;
+    const int c = blockIdx.x, t = threadIdx.x;
+    QState& s = st[c];
+    double tot[PER];
+    double mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        double v = 0;
+        if (HAS_W) {
+            const double* p = (const double*)part + (int64_t)c * nblk * nb + b;
+            for (int k = 0; k < nblk; ++k) v += p[(int64_t)k * nb];
+        } else {
+            const unsigned int* p = (const unsigned int*)part + (int64_t)c * nblk * nb + b;
+            unsigned long long u = 0;
+            for (int k = 0; k < nblk; ++k) u += p[(int64_t)k * nb];
+            v = (double)u;
+        }
+        tot[j] = v;
+        mine += v;
+    }
+    tsum[t] = mine;
+    if (t < QK_MAX) pick[t] = 0x7fffffff;
+    if (t == 0) lastne = -1;
+    __syncthreads();
+    double below = 0;  // weight of every bucket before this thread's first, added in bucket order
+    for (int k = 0; k < t; ++k) below += tsum[k];
+    int my_last = -1;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (tot[j] != 0) my_last = t * PER + j;
+    if (my_last >= 0) atomicMax(&lastne, my_last);
+    for (int q = 0; q < s.k; ++q) {
+        const double target = s.target[q];
+        double cum = below;
+        int found = -1;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const double hv = tot[j];
+            if (found < 0 && hv != 0 && cum + hv >= target) found = t * PER + j;
+            cum += hv;
+        }
+        if (found >= 0) atomicMin(&pick[q], found);
+    }
+    __syncthreads();
+    for (int q = 0; q < s.k; ++q) {
+        int p = pick[q];
+        if (p == 0x7fffffff) p = lastne < 0 ? 0 : lastne;  // target beyond the total weight: the last row (chains.py:836)
+        if (p / PER == t) {
+            double cum = below;
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (t * PER + j < p) cum += tot[j];
+            cumb[q] = cum;
+            pick[q] = p;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        int nu = 0;
+        for (int q = 0; q < s.k; ++q) {
+            s.cum_below[q] = cumb[q];
+            s.prefix[q] = 0;
+            int f = -1;
+            for (int u = 0; u < nu; ++u)
+                if (ql[c].ubucket[u] == pick[q]) f = u;
+            if (f < 0) {
+                f = nu;
+                ql[c].ubucket[nu++] = pick[q];
+            }
+            s.slot[q] = f;
+        }
+        s.nuniq = nu;
+    }
+}
+
+// the (key, weight) pairs of every live bucket, appended to that bucket's list
+template <bool HAS_W>
+__global__ void k_qlin_collect(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                               const double* __restrict__ w, int64_t lo, int64_t hi, const QState* __restrict__ st,
+                               const QLin* __restrict__ ql, unsigned long long* __restrict__ lkeys, double* __restrict__ lw,
+                               int* __restrict__ counts) {
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
+    __shared__ unsigned int live[nb / 32];  // one bit per bucket
+    __shared__ int ub[QK_MAX];
+    const int c = blockIdx.y;
+    const double* x = cols + (int64_t)colidx[c] * ld;
+    const int nuniq = st[c].nuniq;
+    const double mn = ql[c].mn, scale = ql[c].scale;
+    for (int i = threadIdx.x; i < nb / 32; i += blockDim.x) live[i] = 0u;
+    if (threadIdx.x < QK_MAX) ub[threadIdx.x] = threadIdx.x < nuniq ? ql[c].ubucket[threadIdx.x] : -1;
+    __syncthreads();
+    if ((int)threadIdx.x < nuniq) atomicOr(&live[ub[threadIdx.x] >> 5], 1u << (ub[threadIdx.x] & 31));
+    __syncthreads();
+    stream_xw4<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+        const int b = qlin_bucket(v, mn, scale, nb);
+        if ((live[b >> 5] >> (b & 31)) & 1u) {
+            int slot = 0;
+            for (int u = 1; u < nuniq; ++u)
+                if (ub[u] == b) slot = u;
+            const int pos = atomicAdd(&counts[c * QK_MAX + slot], 1);
+            if (pos < QCAP) {
+                const int64_t o = ((int64_t)c * QK_MAX + slot) * QCAP + pos;
+                lkeys[o] = f64_key(v);
+                lw[o] = wt;
+            }
+        }
+    });
+}
+
 // ---- autocovariance lag sums: out[l] = sum_i d_i d_{i+k0+l},  d = (x-mean)*w ---------------------------------
 #define AL 32     // lags per launch
 #define AT 2048   // rows per tile
@@ -1390,6 +1567,105 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         for (int i = 0; i < m; ++i) minmax_out[2 * i] = hres[(size_t)i * 4], minmax_out[2 * i + 1] = hres[(size_t)i * 4 + 1];
     *norm_out = hres[2];
     return GD_OK;
+}
+
+// the linear-bucket path of gd_quantiles_mm; returns 1 when a bucket list overflowed (the caller takes the radix path)
+static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets,
+                            int32_t k, const double* minmax, double* out, int* overflowed) {
+    const bool hw = ctx->w != nullptr;
+    const int nb = hw ? QLIN_NB_W : QLIN_NB_U;
+    std::vector<QState> hst((size_t)ncols);
+    std::vector<QLin> hql((size_t)ncols);
+    memset(hst.data(), 0, hst.size() * sizeof(QState));
+    memset(hql.data(), 0, hql.size() * sizeof(QLin));
+    for (int c = 0; c < ncols; ++c) {
+        hst[c].k = k;
+        hst[c].nuniq = 1;
+        for (int t = 0; t < k; ++t) hst[c].target[t] = targets[(size_t)c * k + t];
+        hql[c].mn = minmax[2 * c];
+        hql[c].scale = (double)nb / (minmax[2 * c + 1] - minmax[2 * c]);
+        hql[c].nb = nb;
+    }
+    int nblk = (2 * ctx->cu_count + ncols - 1) / ncols;
+    if (nblk > 64) nblk = 64;
+    if ((int64_t)nblk * 65536 > hi - lo) nblk = (int)((hi - lo + 65535) / 65536);
+    if (nblk < 1) nblk = 1;
+    int nblk2 = (8 * ctx->cu_count + ncols - 1) / ncols;
+    if (nblk2 < 8) nblk2 = 8;
+    if (nblk2 > 2 * ctx->cu_count) nblk2 = 2 * ctx->cu_count;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_st = take((int64_t)ncols * sizeof(QState)), o_ql = take((int64_t)ncols * sizeof(QLin)),
+                  o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8),
+                  o_cnt = take((int64_t)ncols * QK_MAX * 4 + 256), o_lk = take((int64_t)ncols * QK_MAX * QCAP * 8),
+                  o_lw = take((int64_t)ncols * QK_MAX * QCAP * 8), o_part = take((int64_t)ncols * nblk * nb * (hw ? 8 : 4));
+    char* base = (char*)gd_scratch(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    QState* d_st = (QState*)(base + o_st);
+    QLin* d_ql = (QLin*)(base + o_ql);
+    int32_t* d_idx = (int32_t*)(base + o_idx);
+    double* d_out = (double*)(base + o_out);
+    int* d_cnt = (int*)(base + o_cnt);
+    unsigned long long* d_lk = (unsigned long long*)(base + o_lk);
+    double* d_lw = (double*)(base + o_lw);
+    void* d_part = base + o_part;
+    GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_ql, hql.data(), hql.size() * sizeof(QLin), hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_HIP(hipMemsetAsync(d_cnt, 0, (size_t)ncols * QK_MAX * 4 + 256, ctx->stream));
+    const size_t lds = (size_t)nb * (hw ? 8 : 4);
+    if (hw) {
+        GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_qlin_count<true><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part);
+        GD_KERNEL_CHECK();
+        k_qlin_scan<true><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_part, nblk);
+        GD_KERNEL_CHECK();
+        k_qlin_collect<true><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_st, d_ql, d_lk,
+                                                                          d_lw, d_cnt);
+    } else {
+        GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_qlin_count<false><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_ql, d_part);
+        GD_KERNEL_CHECK();
+        k_qlin_scan<false><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_part, nblk);
+        GD_KERNEL_CHECK();
+        k_qlin_collect<false><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_st, d_ql,
+                                                                           d_lk, d_lw, d_cnt);
+    }
+    GD_KERNEL_CHECK();
+    k_qsel_finish<<<ncols, 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    GD_KERNEL_CHECK();
+    int overflow = 0;
+    GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    *overflowed = overflow;
+    return GD_OK;
+}
+
+int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets, int32_t k,
+                    const double* minmax, double* out) {
+    GD_REQUIRE(ctx && cols && targets && out && ncols > 0, "bad argument");
+    GD_REQUIRE(k > 0 && k <= QK_MAX, "at most 16 quantiles per call");
+    GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
+    bool linear = minmax != nullptr && getenv("GDHIP_QSEL_RADIX") == nullptr;
+    // the expected length of a live bucket's list is rows / buckets times the peak-to-mean density ratio (about 4 for a
+    // Gaussian over its sampled range); beyond these row counts the lists would overflow QCAP
+    if (linear && (hi - lo) > (ctx->w ? 12000000 : 25000000)) linear = false;
+    for (int c = 0; linear && c < ncols; ++c) {
+        const double a = minmax[2 * c], b = minmax[2 * c + 1];
+        if (!(b > a) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite((double)QLIN_NB_U / (b - a))) linear = false;
+    }
+    if (linear) {
+        for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
+        int overflowed = 0;
+        const int rc = quantiles_linear(ctx, cols, ncols, lo, hi, targets, k, minmax, out, &overflowed);
+        if (rc || !overflowed) return rc;  // heavily tied or very peaked data: the radix path below redoes the call
+    }
+    return gd_quantiles(ctx, cols, ncols, lo, hi, targets, k, out);
 }
 
 int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets,

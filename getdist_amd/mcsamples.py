@@ -1541,6 +1541,7 @@ class MCSamples:
         if isinstance(paramVec, ParamConfidenceData):
             start, end = paramVec.start, paramVec.end
             weights = paramVec.weights if weights is None else weights
+        vec_arg = paramVec.vec if isinstance(paramVec, ParamConfidenceData) else self._host_vector(paramVec)
         j = self._vec_col(paramVec)
         limfrac = np.atleast_1d(np.asarray(limfrac, dtype=np.float64))
         end = self.numrows if end is None else end
@@ -1549,7 +1550,8 @@ class MCSamples:
             full = start == 0 and end == self.numrows and weights is None
             norm = self.norm if full else self.ctx.weight_stats(start, end)["norm"]
             targets = norm * limfrac if not upper else norm * (1 - limfrac)
-            return self.ctx.quantiles([j], targets[None, :], lo=start, hi=end)[0]
+            mm = self._minmax_of([j]) if (vec_arg is None and j < self.n) else None
+            return self.ctx.quantiles([j], targets[None, :], lo=start, hi=end, minmax=mm)[0]
 
         if weights is None:
             out = select()
@@ -1795,6 +1797,14 @@ class MCSamples:
             par.ND_limit_top = lims[:, j, 1].copy()
         self._nd_limits_done = True
 
+    def _minmax_of(self, js):
+        """(len(js), 2) minima / maxima of resident columns from the base statistics: with them the quantile select
+        needs two reads of a column instead of four (gd_quantiles_mm)."""
+        if getattr(self, "_col_min", None) is None:
+            return None
+        js = np.asarray(js, dtype=np.int64)
+        return np.stack([np.asarray(self._col_min)[js], np.asarray(self._col_max)[js]], axis=1)
+
     def _init_params(self, js):
         """_initParam for several parameters with ONE batched quantile-select launch."""
         todo = [j for j in dict.fromkeys(js) if not getattr(self.paramNames.names[j], "_ranges_done", False)]
@@ -1803,7 +1813,7 @@ class MCSamples:
         rc = self.range_confidence
         fracs = np.array([rc, 1 - rc] + list(np.linspace(0.1, 0.9, 9)))
         targets = np.tile(self.norm * fracs, (len(todo), 1))
-        q = np.asarray(self.ctx.quantiles(todo, targets))
+        q = np.asarray(self.ctx.quantiles(todo, targets, minmax=self._minmax_of(todo)))
         # mcsamples.py:1440-1452 for all parameters at once: [param_min, deciles 0.1..0.9, param_max], spans of four
         err_v = np.asarray(self.sddev)[todo]
         confids = np.empty_like(q)
@@ -2039,7 +2049,7 @@ class MCSamples:
         for c0 in range(0, nc, 4):
             fr = f[c0:c0 + 4]
             fracs = np.stack([fr, 1 - fr, fr / 2, 1 - fr / 2], axis=1).reshape(-1)
-            q = self.ctx.quantiles(js, np.tile(self.norm * fracs, (len(js), 1)))
+            q = self.ctx.quantiles(js, np.tile(self.norm * fracs, (len(js), 1)), minmax=self._minmax_of(js))
             tails[:, c0:c0 + 4] = q.reshape(len(js), -1, 4)
         return credible, tails
 

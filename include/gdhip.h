@@ -105,6 +105,16 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t row_lo, int64_t 
 int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
                  const double* targets, int32_t k, double* out);
 
+/* gd_quantiles_mm: the same selection when the caller knows each column's minimum and maximum over (a superset of) the
+ * row range -- minmax[2c], minmax[2c+1]; the base statistics have them (gd_cov's minmax_out).  Then ONE counting pass
+ * over the monotone linear bucket index (int)((x - min) * nbuckets / (max - min)) in 32768 (unit weights) or 16384
+ * (fp64 weights) LDS buckets narrows every target to a few hundred rows, which one collect pass gathers and a sorted walk
+ * of the cumulative weight finishes exactly as above: two reads of the columns instead of four.  minmax == NULL, a
+ * degenerate range, more rows than the bucket lists can hold, or a list overflow (heavily tied data) take the radix
+ * path of gd_quantiles; the result is the same sample value either way. */
+int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
+                    const double* targets, int32_t k, const double* minmax, double* out);
+
 /* ---------------------------------------------------------------- autocorrelation / N_eff ------
  * gd_autocov_lags: out[l] = sum_{i} d_i d_{i+k0+l}, d=(x-mean)*w, l<nlags -- the un-normalised lag
  *   sums convolve.autoConvolve (convolve.py:458-478) obtains by FFT for chains.py:441.

@@ -322,7 +322,7 @@ class FakeContext:
         out = (means, (d * w[:, None]).T @ d / norm, float(norm))
         return out + (np.column_stack([s.min(axis=0), s.max(axis=0)]),) if minmax else out
 
-    def quantiles(self, cols, targets, lo=0, hi=None):
+    def quantiles(self, cols, targets, lo=0, hi=None, minmax=None):
         hi = self.N if hi is None else hi
         targets = np.asarray(targets, dtype=float).reshape(len(cols), -1)
         out = np.zeros_like(targets)

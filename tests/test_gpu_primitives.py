@@ -318,6 +318,53 @@ def test_quantiles_with_ties_take_the_radix_fallback(weights):
         c.close()
 
 
+@pytest.mark.parametrize("weights", ["unit", "integer", "real"])
+def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
+    """gd_quantiles_mm (one linear-bucket counting pass + collect, given the columns' min / max) against the radix path
+    and against argsort semantics: continuous, bounded, heavily tied (list overflow -> radix fallback inside the call),
+    constant (degenerate range -> radix) columns in ONE call, full range and a sub-range with the full range's extrema,
+    targets at 0, beyond the total weight and on the extreme rows."""
+    from getdist_amd._lib import Context
+
+    rng = np.random.default_rng(5)
+    N = 2_000_003
+    cont = rng.standard_normal(N)
+    s = np.column_stack([cont, np.abs(cont), rng.uniform(-3, 9, N), np.round(cont, 1), np.full(N, 3.25),
+                         np.where(rng.random(N) < 0.5, cont * 1e-9, cont * 1e6)])
+    w = None if weights == "unit" else (rng.integers(1, 5, N).astype(float) if weights == "integer" else rng.exponential(1.0, N))
+    wv = np.ones(N) if w is None else w
+    c = Context(0)
+    try:
+        c.upload(s, w)
+        cols = list(range(s.shape[1]))
+        mm = np.stack([s.min(axis=0), s.max(axis=0)], axis=1)
+        fracs = np.array([0.0, 1e-7, 0.001, 0.1, 0.25, 0.5, 0.5000001, 0.9, 0.999, 1.0 - 1e-9, 1.0, 1.5])
+        for lo, hi in ((0, N), (12_345, 1_500_001)):
+            norm = wv[lo:hi].sum()
+            targets = np.tile(norm * fracs, (len(cols), 1))
+            lin = c.quantiles(cols, targets, lo=lo, hi=hi, minmax=mm)
+            monkeypatch.setenv("GDHIP_QSEL_RADIX", "1")
+            rad = c.quantiles(cols, targets, lo=lo, hi=hi, minmax=mm)
+            monkeypatch.delenv("GDHIP_QSEL_RADIX")
+            plain = c.quantiles(cols, targets, lo=lo, hi=hi)
+            assert np.array_equal(rad, plain)
+            for ci, col in enumerate(cols):
+                x = s[lo:hi, col]
+                idx = x.argsort(kind="stable")
+                xs = x[idx]
+                cum = np.cumsum(wv[lo:hi][idx])
+                want = xs[np.minimum(np.searchsorted(cum, norm * fracs), len(idx) - 1)]
+                if weights == "real":  # the weight below a bucket is summed in another order: a knife-edge target may
+                    for got in (lin[ci], rad[ci]):  # pick the neighbouring sample; both paths within one row of numpy
+                        assert np.all(np.abs(np.searchsorted(xs, got) - np.searchsorted(xs, want)) <= 1), (col, lo)
+                        assert np.mean(got == want) >= 0.75, (col, lo, got, want)
+                else:
+                    assert np.array_equal(lin[ci], want), (weights, col, lo, lin[ci], want)
+                    assert np.array_equal(rad[ci], want), (weights, col, lo)
+    finally:
+        c.close()
+
+
 def test_contour_levels_batch(ctx):
     """gd_contour_levels against the oracle's restatement of densities.py:19-56 on smooth, flat-topped and tied grids."""
     from oracle import kde_oracle as ko
