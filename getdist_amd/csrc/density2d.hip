@@ -203,6 +203,35 @@ __global__ void k_cmul(const double2* __restrict__ a, const double2* __restrict_
     }
 }
 
+// per-grid maximum in PM_PARTS partial maxima, one per block of the (PM_PARTS, B) grids the F x F passes run on: the
+// passes that produce a grid (crop, bias-correction update, boundary correction) leave their block maxima behind, so no
+// separate reduction pass reads the grid again; consumers fold the parts with pair_max()
+#define PM_PARTS 64
+// crop frame positions [w, F+w)^2 into an F x F array; MODE 1: as the multiplicative bias-correction update
+// dst = dst * crop / a00 (mcsamples.py:1972-1973) without materialising the cropped convolution; mx != nullptr: the
+// block's maximum of what it wrote goes to mx[b * PM_PARTS + blockIdx.x] (grid (PM_PARTS, B))
+template <int MODE>
+__global__ void __launch_bounds__(256) k_crop_fused(const D2Pair* __restrict__ pairs, const double* __restrict__ frames, int F, int S,
+                                                    double* __restrict__ dst, const double* __restrict__ a00,
+                                                    double* __restrict__ mx) {
+    __shared__ double red[16];
+    const int w = pairs[blockIdx.y].w;
+    const double* fr = frames + (int64_t)blockIdx.y * S * S;
+    const int64_t o = (int64_t)blockIdx.y * F * F;
+    double* d = dst + o;
+    double m = -INFINITY;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
+        double v = fr[(int64_t)(e / F + w) * S + (e % F + w)];
+        if (MODE == 1) v = (d[e] * v) / a00[o + e];
+        d[e] = v;
+        m = fmax(m, v);
+    }
+    if (mx) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) mx[(int64_t)blockIdx.y * PM_PARTS + blockIdx.x] = m;
+    }
+}
+
 // crop frame positions [w, F+w)^2 into an F x F array
 __global__ void k_crop(const D2Pair* __restrict__ pairs, const double* __restrict__ frames, int F, int S,
                        double* __restrict__ dst) {
@@ -213,9 +242,6 @@ __global__ void k_crop(const D2Pair* __restrict__ pairs, const double* __restric
         d[e] = fr[(int64_t)(e / F + w) * S + (e % F + w)];
 }
 
-// per-grid maximum in PM_PARTS partial maxima (grid (PM_PARTS, B): one block per grid left most of the chip idle for the
-// 20-odd max reductions of a triangle step); consumers fold the parts with pair_max()
-#define PM_PARTS 8
 __global__ void k_pair_max(const double* __restrict__ a, int FF, double* __restrict__ mx) {
     __shared__ double red[16];
     const double* p = a + (int64_t)blockIdx.y * FF;
@@ -237,17 +263,29 @@ struct BcArrays {
 };
 
 // linear boundary correction (mcsamples.py:1921-1961), in place on P; only pairs with a limit
-__global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF, int bco) {
+// mx_out (may be nullptr; must not alias mx: other blocks of the pair are still folding mx): the block maxima of the
+// grid after the correction (grid (PM_PARTS, B))
+__global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF,
+                                                  int bco, double* __restrict__ mx_out) {
+    __shared__ double red[16];
     const int b = blockIdx.y;
-    if ((pairs[b].flags & 64) == 0) return;
+    if ((pairs[b].flags & 64) == 0) {  // untouched grid: its maxima move to the output set unchanged
+        if (mx_out && threadIdx.x == 0) mx_out[(int64_t)b * PM_PARTS + blockIdx.x] = mx[(int64_t)b * PM_PARTS + blockIdx.x];
+        return;
+    }
     const double thresh = pair_max(mx, b) * 1e-8;
     const int64_t o = (int64_t)b * FF;
+    double m = -INFINITY;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
         const double P = A.P[o + i], a00 = A.a00[o + i];
-        if (!(a00 * P > thresh)) continue;
+        if (!(a00 * P > thresh)) {
+            m = fmax(m, P);
+            continue;
+        }
         const double normed = P / a00;
         if (bco == 0) {
             A.P[o + i] = normed;
+            m = fmax(m, normed);
             continue;
         }
         const double a10 = A.a10[o + i], a01 = A.a01[o + i], a20 = A.a20[o + i], a02 = A.a02[o + i],
@@ -257,7 +295,13 @@ __global__ void k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const d
         const double Ax = a10 * a02 - a01 * a11;
         const double Ay = a01 * a20 - a10 * a11;
         const double corrected = (P * Aq + xP * Ax + yP * Ay) / denom;
-        A.P[o + i] = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
+        const double out = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
+        A.P[o + i] = out;
+        m = fmax(m, out);
+    }
+    if (mx_out) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) mx_out[(int64_t)b * PM_PARTS + blockIdx.x] = m;
     }
 }
 
@@ -626,7 +670,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
                 }
             }
         }
-        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco);
+        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, nullptr);
         GD_KERNEL_CHECK();
     }
     if (do_mbc) {
@@ -705,6 +749,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         return o;
     };
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
+                  o_mx2 = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_RF = take(B * SS * 8), o_RO = take(B * SS * 8),
                   o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16),
                   o_ZK = take(do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(B * SC * 16),
@@ -714,7 +759,8 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     if (!base) return GD_ERR_NOMEM;
     D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
     double* d_wsum = (double*)(base + o_wsum);
-    double* d_mx = (double*)(base + o_mx);
+    double* d_mx = (double*)(base + o_mx);    // block maxima of the current grid ...
+    double* d_mx2 = (double*)(base + o_mx2);  // ... and the set the boundary correction writes while it reads the other
     int* d_status = (int*)(base + o_status);
     double* RF = (double*)(base + o_RF);
     double* RO = (double*)(base + o_RO);
@@ -732,7 +778,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         const int rc_stage = gd_stage_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair));
         if (rc_stage) return rc_stage;
     }
-    const dim3 gS(128, B), gF(64, B);
+    const dim3 gS(128, B), gF(PM_PARTS, B);
     const double scale = 1.0 / ((double)S * (double)S);
     const int cm_blocks = 2048;
     int rc;
@@ -741,15 +787,16 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         rc = gd_fft_r2c_2d(ctx, S, S, B, frames, Z);          \
         if (rc) return rc;                                    \
     } while (0)
-    // product of two spectra -> inverse -> crop into dst (B x F x F)
-#define CONV_TO(ZA, ZB, dst)                                                              \
-    do {                                                                                  \
-        k_cmul<<<cm_blocks, 256, 0, ctx->stream>>>(ZA, ZB, B * SC, scale, ZP);            \
-        GD_KERNEL_CHECK();                                                                \
-        rc = gd_fft_c2r_2d(ctx, S, S, B, ZP, RO);                                         \
-        if (rc) return rc;                                                                \
-        k_crop<<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst);                      \
-        GD_KERNEL_CHECK();                                                                \
+    // product of two spectra -> inverse -> crop into dst (B x F x F), the crop leaving its block maxima in `mxp`
+    // (nullptr: not wanted)
+#define CONV_TO(ZA, ZB, dst, mxp)                                                                        \
+    do {                                                                                                 \
+        k_cmul<<<cm_blocks, 256, 0, ctx->stream>>>(ZA, ZB, B * SC, scale, ZP);                           \
+        GD_KERNEL_CHECK();                                                                               \
+        rc = gd_fft_c2r_2d(ctx, S, S, B, ZP, RO);                                                        \
+        if (rc) return rc;                                                                               \
+        k_crop_fused<0><<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, dst, nullptr, mxp);              \
+        GD_KERNEL_CHECK();                                                                               \
     } while (0)
 
     k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
@@ -761,7 +808,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     k_fill_embed<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, F, S, RF);
     GD_KERNEL_CHECK();
     FWD(RF, ZH);
-    CONV_TO(ZH, ZW, d_P);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884)
+    CONV_TO(ZH, ZW, d_P, d_mx);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884), with its maxima
     BcArrays A;
     A.P = d_P;
     A.a00 = arr;
@@ -800,45 +847,52 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             }
         }
     }
+    double* mx_cur = d_mx;
     if (do_bc) {
-        k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
-        GD_KERNEL_CHECK();
         if (bco == 1) {
             // x*P and y*P still need the histogram: conv(histbins, Win*x), conv(histbins, Win*y)  (mcsamples.py:1940-1941)
             k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 1, 0, RF);
             GD_KERNEL_CHECK();
             FWD(RF, ZK);
-            CONV_TO(ZH, ZK, A.xP);
+            CONV_TO(ZH, ZK, A.xP, (double*)nullptr);
             k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 1, RF);
             GD_KERNEL_CHECK();
             FWD(RF, ZK);
-            CONV_TO(ZH, ZK, A.yP);
+            CONV_TO(ZH, ZK, A.yP, (double*)nullptr);
         }
-        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco);
+        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2);
         GD_KERNEL_CHECK();
+        mx_cur = d_mx2;
     }
     if (mbc > 0) {
         for (int round = 0; round < mbc; ++round) {
-            k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
-            GD_KERNEL_CHECK();
-            k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, d_mx, F, S, RF);
+            k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, mx_cur, F, S, RF);
             GD_KERNEL_CHECK();
             FWD(RF, ZH);  // ZH is free to reuse: the histogram spectrum is no longer needed
-            CONV_TO(ZH, ZW, d_conv);
-            if (ov && ov->d_zero)
+            if (ov && ov->d_zero) {
+                CONV_TO(ZH, ZW, d_conv, (double*)nullptr);
                 k_mbc_update_masked<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, ov->d_zero, B * FF);
-            else
-                k_mbc_update<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
-            GD_KERNEL_CHECK();
+                GD_KERNEL_CHECK();
+                k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, mx_cur);
+                GD_KERNEL_CHECK();
+            } else {
+                // bins2D *= conv(box, Win) / a00 straight out of the inverse transform's frame, maxima included
+                k_cmul<<<cm_blocks, 256, 0, ctx->stream>>>(ZH, ZW, B * SC, scale, ZP);
+                GD_KERNEL_CHECK();
+                rc = gd_fft_c2r_2d(ctx, S, S, B, ZP, RO);
+                if (rc) return rc;
+                k_crop_fused<1><<<gF, 256, 0, ctx->stream>>>(d_pairs, RO, F, S, d_P, d_a00m, mx_cur);
+                GD_KERNEL_CHECK();
+            }
         }
     }
     if (ov && ov->d_zero) {  // bins2D[bool_mask] = 0  (mcsamples.py:1978-1979)
         k_zero_masked<<<cm_blocks, 256, 0, ctx->stream>>>(d_P, ov->d_zero, B * FF);
         GD_KERNEL_CHECK();
+        k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, mx_cur);
+        GD_KERNEL_CHECK();
     }
-    k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
-    GD_KERNEL_CHECK();
-    k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
+    k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, mx_cur, (int)FF, d_status);
     GD_KERNEL_CHECK();
     GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (wait) GD_HIP(hipStreamSynchronize(ctx->stream));
