@@ -2960,9 +2960,30 @@ class ChainView:
     def norm(self):
         return self._weight_stats()["norm"] if self.parent.weights is not None else np.float64(self.numrows)
 
+    def _where_global(self, where):
+        """A chain-relative ``where`` (boolean mask or row indices of THIS chain) as full-length weights*mask of the
+        parent: the kernels then see x[where], w[where] of the chain inside its row range."""
+        where = np.asarray(where)
+        p = self.parent
+        w = np.zeros(p.numrows)
+        base = p.weights[self.lo:self.hi] if p.weights is not None else np.ones(self.numrows)
+        if where.dtype == bool:
+            if where.shape != (self.numrows,):
+                raise WeightedSampleError("where must have one entry per sample of the chain")
+            w[self.lo:self.hi] = base * where
+        else:
+            w[self.lo:self.hi] = base * np.bincount(where.astype(np.int64) % self.numrows, minlength=self.numrows)
+        return w
+
+    def _moments(self, pars, where):
+        p = self.parent
+        cols = [p._col(q) for q in pars]
+        return p._with_weights(self._where_global(where), lambda: p.ctx.cov(cols, lo=self.lo, hi=self.hi))
+
     def get_norm(self, where=None):
         if where is not None:
-            raise NotImplementedError("row filters on a chain view")
+            p = self.parent
+            return p._with_weights(self._where_global(where), lambda: p.ctx.weight_stats(self.lo, self.hi)["norm"])
         return self.norm
 
     def _col_stats(self):
@@ -2988,28 +3009,28 @@ class ChainView:
         return covToCorr(self.getCov())
 
     def cov(self, pars=None, where=None):
-        if where is not None:
-            raise NotImplementedError("row filters on a chain view")
         if isinstance(pars, (int, np.integer)):
             pars = range(pars)
         cols = list(range(self.n)) if pars is None else [self.parent._col(p) for p in pars]
+        if where is not None:
+            return self._moments(cols, where)[1]
         return self.parent.ctx.cov(cols, lo=self.lo, hi=self.hi)[1]
 
     def corr(self, pars=None):
         return covToCorr(self.cov(pars))
 
     def mean(self, paramVec, where=None):
-        if where is not None:
-            raise NotImplementedError("row filters on a chain view")
         if isinstance(paramVec, (list, tuple)):
-            return np.array([self.mean(p) for p in paramVec])
+            return np.array([self.mean(p, where) for p in paramVec])
+        if where is not None:
+            return self._moments([paramVec], where)[0][0]
         return self._col_stats()[self.parent._col(paramVec), 2]
 
     def var(self, paramVec, where=None):
-        if where is not None:
-            raise NotImplementedError("row filters on a chain view")
         if isinstance(paramVec, (list, tuple)):
-            return np.array([self.var(p) for p in paramVec])
+            return np.array([self.var(p) for p in paramVec])  # like the reference, a list ignores ``where``
+        if where is not None:
+            return self._moments([paramVec], where)[1][0, 0]
         return self._col_stats()[self.parent._col(paramVec), 3]
 
     def std(self, paramVec, where=None):

@@ -211,3 +211,84 @@ def mutator_checks(factory=None, tol=1e-9):
         assert relerr(conv.autoCorrelation(z, 200), g["autocorrfn"]) < 1e-11
     finally:
         conv.set_context(None)
+
+
+def prefill_plot_caches_checks(zoo, factory=None, tol=1e-9):
+    """getdist_amd.plotting.prefill_plot_caches: plots.MCSampleAnalysis cache layout (plots.py:594-645), keys, contour
+    counts, grids and device contour levels against the oracle (CPU tier: numpy double; -m gpu: the HIP path)."""
+    from getdist_amd.mcsamples import MCSamples
+    from getdist_amd.plotting import prefill_plot_caches
+    from oracle import kde_oracle as ko
+
+    class Analysis:  # the two dicts of getdist.plots.MCSampleAnalysis
+        def __init__(self):
+            self.densities_1D, self.densities_2D = {}, {}
+
+    fx = zoo["c1_bounded"]
+    kw = {} if factory is None else dict(_context_factory=factory)
+    mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"], **kw)
+    an = Analysis()
+    n1, n2 = prefill_plot_caches(an, "chain", mc, params=fx["names"][:3], conts=2)
+    assert (n1, n2) == (3, 3)
+    assert set(an.densities_1D["chain"]) == {(nm, False) for nm in fx["names"][:3]}
+    a, b, c = fx["names"][:3]
+    assert set(an.densities_2D["chain"]) == {(a, b, False, 2), (a, c, False, 2), (b, c, False, 2)}
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    d1 = an.densities_1D["chain"][(b, False)]
+    assert np.max(np.abs(d1.P - orc.density_1d(1)["P"])) < max(tol, 1e-9)
+    # (a, c) of this fixture: both unbounded -> the bandwidth passes through TNC; on the device the grid is compared
+    # at the device's own bandwidth (the chaotic map is covered by test_density_2d), the layout checks are exact
+    d = an.densities_2D["chain"][(a, c, False, 2)]
+    assert len(d.contours) == 2 and d.P.shape == (256, 256) and d.P.max() == 1.0
+    tr = {}
+    o = orc.density_2d(0, 2, trace=tr)
+    if relerr(d.bandwidth, (tr["hx"], tr["hy"], tr["c"])) < 1e-6:
+        assert np.max(np.abs(d.P - o["P"])) < 1e-6
+        assert np.allclose(d.contours, ko.contour_levels(o["P"], (0.68, 0.95)), rtol=1e-6)
+    assert np.allclose(d.contours, ko.contour_levels(d.P, (0.68, 0.95)), rtol=1e-9)  # device levels of the device grid
+    # a second fill replaces nothing it should not and returns the cached objects to the plotting layer
+    assert prefill_plot_caches(an, "chain", mc, params=fx["names"][:2], conts=1) == (2, 1)
+    assert (a, b, False, 1) in an.densities_2D["chain"] and (a, b, False, 2) in an.densities_2D["chain"]
+
+
+def root_constructor_checks(tmp_path, factory=None):
+    """MCSamples(root=...) / loadMCSamples: text chains on the first load, the column-major binary cache afterwards
+    (same arrays bit for bit, views of one page-locked block on the HIP path), invalidation by mtime, ini settings,
+    and statistics / a density from the reloaded object."""
+    from getdist_amd import chainfiles
+    from getdist_amd.mcsamples import MCSamples
+    from oracle.fixtures import mcmc_chains_fixture
+
+    kw = {} if factory is None else dict(_context_factory=factory)
+    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=3, N=500, n=3)
+    root = str(tmp_path / "run")
+    for c, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
+        np.savetxt("%s_%d.txt" % (root, c + 1), np.column_stack([weights[a:b], loglikes[a:b], samples[a:b]]), fmt="%.17g")
+    (tmp_path / "run.paramnames").write_text("x\ny\nz*\n")
+    (tmp_path / "my.ini").write_text("# analysis settings\nignore_rows = 0.1\nfine_bins_2D = 128\nplot_ext = pdf\ncontours = 0.5 0.9\n")
+    first = MCSamples(root=root, **kw)
+    assert os.path.isfile(chainfiles.cache_path(root))
+    assert np.array_equal(first.samples, samples) and np.array_equal(first.weights, weights)
+    again = MCSamples(root=root, **kw)
+    assert np.array_equal(again.samples, samples) and np.array_equal(again.weights, weights)
+    assert np.array_equal(again.loglikes, loglikes) and list(again.chain_offsets) == list(offsets)
+    assert again.samples.flags.f_contiguous  # a view of the cache block: no host-side copy or transpose
+    assert again.paramNames.numNonDerived() == 2 and again.name_tag == "run"
+    # the reloaded object computes: pooled moments, Gelman-Rubin over the three chains, a density
+    assert np.allclose(again.means, weights.dot(samples) / weights.sum(), rtol=1e-12)
+    assert np.array_equal(again.means, first.means) and np.array_equal(again.fullcov, first.fullcov)
+    assert again.getGelmanRubin() > 0 and again.get1DDensity("x").P.max() == 1.0
+    keep_alive = again.samples  # page-locked on the HIP path: must stay readable after the object is gone
+    del again
+    assert np.array_equal(keep_alive, samples)
+    loaded = chainfiles.read_root(root)
+    assert loaded["from_cache"]
+    # a newer chain file invalidates the cache
+    os.utime(chainfiles.cache_path(root), (1, 1))
+    assert not chainfiles.read_root(root, no_cache=True)["from_cache"]
+    assert not chainfiles.read_root(root)["from_cache"] and chainfiles.read_root(root)["from_cache"]
+    burnt = chainfiles.loadMCSamples(root, ini=str(tmp_path / "my.ini"), **kw)
+    keep = np.concatenate([np.arange(a + int(round((b - a) * 0.1)), b) for a, b in zip(offsets[:-1], offsets[1:])])
+    assert np.array_equal(burnt.samples, samples[keep]) and burnt.fine_bins_2D == 128 and list(burnt.contours) == [0.5, 0.9]
+    excl = chainfiles.loadMCSamples(root, chain_exclude=[2], **kw)
+    assert excl.numrows == len(weights) - (offsets[2] - offsets[1]) and len(excl.chain_offsets) == 3

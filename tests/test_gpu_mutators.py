@@ -42,3 +42,14 @@ def test_autoconvolve_fft_route_equals_direct_lag_sums_at_full_size():
         b = mc.getCorrelationLength(0)
         assert abs(a - b) < 1e-8 * a
         mc.ctx.close()
+
+
+def test_prefill_plot_caches_on_the_device(zoo):
+    """SURVEY.md 8f rank 3 on the HIP path: the plot-cache glue over the batched calls and gd_contour_levels."""
+    gu.prefill_plot_caches_checks(zoo, None)
+
+
+def test_root_constructor_and_binary_cache_on_the_device(tmp_path):
+    """SURVEY.md 8f rank 4 on the HIP path: text chains -> MCSamples(root=), the .gdamd_soa cache read into page-locked
+    memory and uploaded from there, reload equality, statistics from the reloaded object."""
+    gu.root_constructor_checks(tmp_path, None)

@@ -255,26 +255,7 @@ def test_host_logic_mask_function(zoo):
 
 def test_prefill_plot_caches(zoo):
     """plots.MCSampleAnalysis cache layout (plots.py:594-645): keys, contour counts, one batched call per dimension."""
-    from getdist_amd.plotting import prefill_plot_caches
-
-    class Analysis:  # the two dicts of getdist.plots.MCSampleAnalysis
-        def __init__(self):
-            self.densities_1D, self.densities_2D = {}, {}
-
-    fx = zoo["c1_bounded"]
-    mc = make(fx)
-    an = Analysis()
-    n1, n2 = prefill_plot_caches(an, "chain", mc, params=fx["names"][:3], conts=2)
-    assert (n1, n2) == (3, 3)
-    assert set(an.densities_1D["chain"]) == {(nm, False) for nm in fx["names"][:3]}
-    a, b, c = fx["names"][:3]
-    assert set(an.densities_2D["chain"]) == {(a, b, False, 2), (a, c, False, 2), (b, c, False, 2)}
-    d = an.densities_2D["chain"][(a, c, False, 2)]
-    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
-    o = orc.density_2d(0, 2)
-    assert np.max(np.abs(d.P - o["P"])) < 1e-9 and len(d.contours) == 2
-    assert np.allclose(d.contours, ko.contour_levels(o["P"], (0.68, 0.95)), rtol=1e-9)
-    assert np.max(np.abs(an.densities_1D["chain"][(b, False)].P - orc.density_1d(1)["P"])) < 1e-9
+    gu.prefill_plot_caches_checks(zoo, FakeContext)
 
 
 def test_two_lanes_equal_one_lane(zoo, monkeypatch):
@@ -486,35 +467,7 @@ def test_array_ingestion_follows_the_reference_per_chain():
 def test_root_constructor_binary_cache_and_ini(tmp_path):
     """MCSamples(root=...) / loadMCSamples: text chains on the first load, the column-major binary cache afterwards
     (same arrays bit for bit, returned as views of one block), cache invalidation by mtime, ini settings."""
-    from getdist_amd import chainfiles
-    from getdist_amd.mcsamples import MCSamples
-    from oracle.fixtures import mcmc_chains_fixture
-
-    samples, weights, loglikes, names, offsets = mcmc_chains_fixture(nchains=3, N=500, n=3)
-    root = str(tmp_path / "run")
-    for c, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
-        np.savetxt("%s_%d.txt" % (root, c + 1), np.column_stack([weights[a:b], loglikes[a:b], samples[a:b]]), fmt="%.17g")
-    (tmp_path / "run.paramnames").write_text("x\ny\nz*\n")
-    (tmp_path / "my.ini").write_text("# analysis settings\nignore_rows = 0.1\nfine_bins_2D = 128\nplot_ext = pdf\ncontours = 0.5 0.9\n")
-    first = MCSamples(root=root, _context_factory=FakeContext)
-    assert os.path.isfile(chainfiles.cache_path(root))
-    assert np.array_equal(first.samples, samples) and np.array_equal(first.weights, weights)
-    again = MCSamples(root=root, _context_factory=FakeContext)
-    assert np.array_equal(again.samples, samples) and np.array_equal(again.weights, weights)
-    assert np.array_equal(again.loglikes, loglikes) and list(again.chain_offsets) == list(offsets)
-    assert again.samples.flags.f_contiguous  # a view of the cache block: no host-side copy or transpose
-    assert again.paramNames.numNonDerived() == 2 and again.name_tag == "run"
-    loaded = chainfiles.read_root(root)
-    assert loaded["from_cache"]
-    # a newer chain file invalidates the cache
-    os.utime(chainfiles.cache_path(root), (1, 1))
-    assert not chainfiles.read_root(root, no_cache=True)["from_cache"]
-    assert not chainfiles.read_root(root)["from_cache"] and chainfiles.read_root(root)["from_cache"]
-    burnt = chainfiles.loadMCSamples(root, ini=str(tmp_path / "my.ini"), _context_factory=FakeContext)
-    keep = np.concatenate([np.arange(a + int(round((b - a) * 0.1)), b) for a, b in zip(offsets[:-1], offsets[1:])])
-    assert np.array_equal(burnt.samples, samples[keep]) and burnt.fine_bins_2D == 128 and burnt.contours == [0.5, 0.9]
-    excl = chainfiles.loadMCSamples(root, chain_exclude=[2], _context_factory=FakeContext)
-    assert excl.numrows == len(weights) - (offsets[2] - offsets[1]) and len(excl.chain_offsets) == 3
+    gu.root_constructor_checks(tmp_path, FakeContext)
 
 
 def test_separate_chains_chainlist_and_make_single():
@@ -553,6 +506,18 @@ def test_separate_chains_chainlist_and_make_single():
     want = gelman_rubin_from_chain_stats(stats, weights @ samples / weights.sum())
     assert np.allclose(sub, want, rtol=1e-9, atol=1e-15) and not np.allclose(sub, full)
     assert np.isclose(mc.getGelmanRubin(chainlist=chains[:2]), np.max(mc.getGelmanRubinEigenvalues(chainlist=chains[:2])))
+    # row filters on a chain (chains.py:665-733 with where=): x[where], w[where] of that chain
+    s1, w1, _ = parts[1]
+    keep = s1[:, 0] > 0.1
+    ch = chains[1]
+    assert np.isclose(ch.get_norm(keep), w1[keep].sum(), rtol=1e-12)
+    mu = w1[keep] @ s1[keep] / w1[keep].sum()
+    assert np.allclose(ch.mean([0, 2], keep), mu[[0, 2]], rtol=1e-11)
+    dk = s1[keep] - mu
+    assert np.allclose(ch.cov(where=keep), (dk * w1[keep, None]).T @ dk / w1[keep].sum(), rtol=1e-10, atol=1e-14)
+    assert np.isclose(ch.var(1, keep), (w1[keep] * dk[:, 1] ** 2).sum() / w1[keep].sum(), rtol=1e-10)
+    idx = np.array([3, 5, 5, 11])
+    assert np.isclose(ch.mean(0, idx), (w1[idx] * s1[idx, 0]).sum() / w1[idx].sum(), rtol=1e-11)
     with pytest.raises(ValueError):
         mc.makeSingle()
     single = MCSamples(samples=samples, weights=weights, names=names, _context_factory=FakeContext)
