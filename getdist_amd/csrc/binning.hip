@@ -605,6 +605,62 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
     if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
 }
 
+// The same packed-counter partials from pre-binned u16 index columns: the few pairs of an up-scaled grid class (F = 384,
+// 768, 960; a dozen pairs each) cannot fill the chip with one block per (pair, stripe), so the rows are cut into chunks
+// as well; packed 16-bit counters need half the stripes (= half the passes over the samples) of the 32-bit kernel these
+// classes used to take.  Partials are added by k_p16_reduce: no atomics, the same sum in every run.
+__global__ void __launch_bounds__(1024) k_hist2d_u16_chunks(const Hist2DPair* __restrict__ pairs, int B, int64_t N, int F, int R,
+                                                            int nstripes, int nchunks, unsigned int* __restrict__ part,
+                                                            int* __restrict__ overflow) {
+    extern __shared__ double sh_raw[];
+    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
+    __shared__ double red[16];
+    int pair, chunk, stripe;
+    decode_block(nstripes, nchunks, pair, chunk, stripe);
+    if (pair >= B) return;
+    const Hist2DPair P = pairs[pair];
+    const int row0 = stripe * R;
+    const int nwords = (R * F + 1) / 2;
+    for (int i = threadIdx.x; i < nwords; i += 1024) sh[i] = 0;
+    __syncthreads();
+    int64_t per = (N + nchunks - 1) / nchunks;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t lo = (int64_t)chunk * per;
+    int64_t hi = lo + per;
+    if (hi > N) hi = N;
+    unsigned int nacc = 0;
+    auto visit = [&](unsigned cx, unsigned cy) {
+        const unsigned r = cy - (unsigned)row0;
+        if (r < (unsigned)R && cx < (unsigned)F && cy < (unsigned)F) {
+            const unsigned a = r * (unsigned)F + cx;
+            atomicAdd(&sh[a >> 1], 1u << ((a & 1u) * 16u));
+            nacc += 1;
+        }
+    };
+    const int64_t hi8 = lo < hi ? lo + ((hi - lo) & ~(int64_t)7) : lo;
+    for (int64_t i = lo + 8 * (int64_t)threadIdx.x; i < hi8; i += 8 * 1024) {
+        const uint4 ax = gload_u4(P.ix + i), ay = gload_u4(P.iy + i);
+        const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            visit(xs[q] & 0xFFFFu, ys[q] & 0xFFFFu);
+            visit(xs[q] >> 16, ys[q] >> 16);
+        }
+    }
+    if (threadIdx.x == 0)
+        for (int64_t i = hi8; i < hi; ++i) visit(P.ix[i], P.iy[i]);
+    __syncthreads();
+    unsigned int* dst = part + (((int64_t)pair * nchunks + chunk) * nstripes + stripe) * (int64_t)nwords;
+    unsigned int total = 0;
+    for (int i = threadIdx.x; i < nwords; i += 1024) {
+        const unsigned int v = sh[i];
+        total += (v & 0xffffu) + (v >> 16);
+        dst[i] = v;
+    }
+    const double t = block_sum((double)total, red), a = block_sum((double)nacc, red);
+    if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
+}
+
 // hist[pair][row][col] = sum over chunks of the packed partial counters; grid (blocks, B)
 __global__ void k_p16_reduce(const unsigned int* __restrict__ part, int F, int R, int nstripes, int nchunks,
                              double* __restrict__ hist_all) {
@@ -978,6 +1034,53 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
         int R16 = LDS_HIST_BYTES / (F * 2);
         if (R16 > F) R16 = F;
         const int nstripes16 = (F + R16 - 1) / R16;
+        if (!ctx->w && (int64_t)B * nstripes16 < ctx->cu_count && !getenv("GDHIP_NO_U16_CHUNKS")) {
+            // few pairs (the up-scaled grid classes): packed counters over (pair, chunk of rows, stripe) blocks, partials
+            // reduced without atomics; pairs whose counters wrapped are redone with the 32-bit kernel
+            const int R = R16, nstripes = nstripes16;
+            int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
+            if (nchunks < 1) nchunks = 1;
+            if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+            const int units = (B * nchunks + 7) / 8 * 8;
+            const int64_t nblocks = (int64_t)units * nstripes;
+            const int nwords = (R * F + 1) / 2;
+            const int64_t o_flags = ((int64_t)B * sizeof(Hist2DPair) + 255) / 256 * 256, o_part = o_flags + ((int64_t)B * 4 + 255) / 256 * 256;
+            char* base = (char*)gd_scratch2(ctx, o_part + (int64_t)B * nchunks * nstripes * nwords * 4);
+            if (!base) return GD_ERR_NOMEM;
+            Hist2DPair* d_pairs = (Hist2DPair*)base;
+            int* d_flags = (int*)(base + o_flags);
+            unsigned int* d_part = (unsigned int*)(base + o_part);
+            GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+            GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
+            GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+            k_hist2d_u16_chunks<<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, nchunks,
+                                                                                              d_part, d_flags);
+            GD_KERNEL_CHECK();
+            k_p16_reduce<<<dim3(16, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
+            GD_KERNEL_CHECK();
+            std::vector<int> hf((size_t)B);
+            GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+            GD_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<int> flagged;
+            for (int b = 0; b < B; ++b)
+                if (hf[b]) flagged.push_back(b);
+            int rc = GD_OK;
+            if (!flagged.empty()) {
+                const int nf = (int)flagged.size();
+                std::vector<Hist2DPair> sub((size_t)nf);
+                for (int q = 0; q < nf; ++q) sub[q] = hp[flagged[q]];
+                double* tmp = nullptr;
+                GD_HIP(hipMalloc((void**)&tmp, (size_t)nf * F * F * 8));
+                rc = launch_hist2d<2>(ctx, nf, sub, F, tmp);
+                for (int q = 0; q < nf && rc == GD_OK; ++q)
+                    if (hipMemcpyAsync((double*)d_hist + (int64_t)flagged[q] * F * F, tmp + (int64_t)q * F * F, (size_t)F * F * 8,
+                                       hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                        rc = gd_fail(ctx, GD_ERR_HIP, "copy of redone histogram failed");
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(tmp);
+            }
+            return rc;
+        }
         // the 16-bit kernel gives each (pair, stripe) to ONE block: only worth it when that fills the chip
         if ((ctx->w && !ctx->w8) || (int64_t)B * nstripes16 < ctx->cu_count)
             return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);

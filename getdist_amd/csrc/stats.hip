@@ -804,7 +804,8 @@ __global__ void k_qsel_collect(const double* __restrict__ cols, int64_t ld, cons
     });
 }
 
-// one block per column: sort each live bucket's list (bitonic, LDS) and pick every target's row
+// one block per (column, live bucket) -- grid (ncols, QK_MAX): sort the bucket's list (bitonic, LDS) and pick the row of
+// every target that lives in it.  (One block per column sorting its up to 11 lists in turn took 1.1 ms of a 45-ms step.)
 __global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__ st, const unsigned long long* __restrict__ lkeys,
                                                       const double* __restrict__ lw, const int* __restrict__ counts, int k,
                                                       int passes_done, double* __restrict__ out, int* __restrict__ overflow) {
@@ -812,14 +813,13 @@ __global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__
     __shared__ double sw[QCAP];
     const int c = blockIdx.x;
     const QState& s = st[c];
-    for (int u = 0; u < s.nuniq; ++u) {
-        const int n = counts[c * QK_MAX + u];
-        if (n > QCAP) {
-            if (threadIdx.x == 0) atomicOr(overflow, 1);
-            return;
-        }
+    if ((int)blockIdx.y >= s.nuniq) return;
+    if (counts[c * QK_MAX + blockIdx.y] > QCAP) {
+        if (threadIdx.x == 0) atomicOr(overflow, 1);
+        return;
     }
-    for (int u = 0; u < s.nuniq; ++u) {
+    {
+        const int u = blockIdx.y;
         const int n = counts[c * QK_MAX + u];
         int m = 1;
         while (m < n) m <<= 1;
@@ -905,13 +905,47 @@ __global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ 
             hu[i] = 0u;
     }
     __syncthreads();
-    stream_xw4<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
+    auto add = [&](double v, double wt) {
         const int b = qlin_bucket(v, mn, scale, nb);
         if (HAS_W)
             atomicAdd(&qsh[b], wt);
         else
             atomicAdd(&hu[b], 1u);
-    });
+    };
+    {
+        // the 128-KB table leaves one block per CU: eight 16-byte loads per lane in flight (the 4 of stream_xw4 left
+        // the pass at 2.9 TB/s), ragged ends by the generic walker
+        const int64_t gtid = (int64_t)blockIdx.x * 1024 + threadIdx.x, gsz = (int64_t)gridDim.x * 1024;
+        const int64_t a = (lo + 1) & ~(int64_t)1, b = hi & ~(int64_t)1;
+        constexpr int U = HAS_W ? 4 : 8;
+        int64_t i = a + 2 * gtid;
+        for (; i + 2 * (U - 1) * gsz < b; i += 2 * U * gsz) {
+            double2 xv[U], wv[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) xv[q] = gload_d2(x + i + 2 * q * gsz);
+#pragma unroll
+            for (int q = 0; q < U; ++q) wv[q] = HAS_W ? gload_d2(w + i + 2 * q * gsz) : make_double2(1.0, 1.0);
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                add(xv[q].x, wv[q].x);
+                add(xv[q].y, wv[q].y);
+            }
+        }
+        for (; i < b; i += 2 * gsz) {
+            const double2 xv = gload_d2(x + i);
+            const double2 wv = HAS_W ? gload_d2(w + i) : make_double2(1.0, 1.0);
+            add(xv.x, wv.x);
+            add(xv.y, wv.y);
+        }
+        if (gtid == 0) {
+            if (b <= a) {
+                for (int64_t r = lo; r < hi; ++r) add(x[r], HAS_W ? w[r] : 1.0);
+            } else {
+                if (lo < a) add(x[lo], HAS_W ? w[lo] : 1.0);
+                if (b < hi) add(x[b], HAS_W ? w[b] : 1.0);
+            }
+        }
+    }
     __syncthreads();
     if (HAS_W) {
         double* p = (double*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
@@ -957,8 +991,24 @@ __global__ void __launch_bounds__(1024) k_qlin_scan(QState* __restrict__ st, QLi
     if (t < QK_MAX) pick[t] = 0x7fffffff;
     if (t == 0) lastne = -1;
     __syncthreads();
-    double below = 0;  // weight of every bucket before this thread's first, added in bucket order
-    for (int k = 0; k < t; ++k) below += tsum[k];
+    // weight of every bucket before this thread's first: exclusive prefix of the thread sums in three fixed steps
+    // (lane prefix by shuffles, the 16 wave totals serially, then the add) -- the same association in every run
+    double below;
+    {
+        const int lane = t & 63, wv = t >> 6;
+        double incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        __shared__ double wtot[16];
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        double base = 0;
+        for (int k = 0; k < wv; ++k) base += wtot[k];
+        below = base + (incl - mine);
+    }
     int my_last = -1;
 #pragma unroll
     for (int j = 0; j < PER; ++j)
@@ -1636,7 +1686,7 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
                                                                            d_lk, d_lw, d_cnt);
     }
     GD_KERNEL_CHECK();
-    k_qsel_finish<<<ncols, 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
     GD_KERNEL_CHECK();
     int overflow = 0;
     GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1736,7 +1786,7 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
                                                                    d_lw, d_cnt);
         GD_KERNEL_CHECK();
     }
-    k_qsel_finish<<<ncols, 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX);
     GD_KERNEL_CHECK();
     int overflow = 0;
     GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -61,6 +61,42 @@ def main():
                                            mass_first64=tot)
         print("u8 variant", variant, hist["variant%d" % variant], flush=True)
     os.environ.pop("GDHIP_U8_VARIANT")
+    # the other O(N) kernels of a step, isolated (HIP events): pre-binning, quantile select (linear buckets vs radix),
+    # the sheared re-binning of 79 pairs, the up-scaled classes (packed chunks vs the 32-bit kernel)
+    iso = {}
+    bufs = [ctx.alloc(N + 64) for _ in range(n)]
+    med, mn = timed(ctx, lambda: ctx.prebin8_batch(list(range(n)), [e[j][1] for j in range(n)], [e[j][0] for j in range(n)], 256, bufs))
+    iso["prebin8_batch_50_columns"] = dict(ms_median=med, ms_min=mn, GBps=n * N * 9 / med / 1e6)
+    fr = np.array([0.001, 0.999] + list(np.linspace(0.1, 0.9, 9)))
+    tg = np.tile(mc.norm * fr, (n, 1))
+    mm = mc._minmax_of(list(range(n)))
+    med, mn = timed(ctx, lambda: ctx.quantiles(list(range(n)), tg, minmax=mm), reps=3)
+    q_lin = ctx.quantiles(list(range(n)), tg, minmax=mm)
+    iso["quantiles_linear_50x11"] = dict(ms_median=med, ms_min=mn)
+    med, mn = timed(ctx, lambda: ctx.quantiles(list(range(n)), tg), reps=3)
+    iso["quantiles_radix_50x11"] = dict(ms_median=med, ms_min=mn, equal_to_linear=bool(np.array_equal(q_lin, ctx.quantiles(list(range(n)), tg))))
+    sh = pairs[:79]
+    shear_args = ([a for a, b in sh], [b for a, b in sh], [1.0] * 79, [-0.4] * 79, [e[a][1] for a, b in sh], [e[a][0] for a, b in sh],
+                  [-12.0] * 79, [24.0 / 255] * 79, F)
+    o2 = ctx.alloc(79 * F * F * 8)
+    med, mn = timed(ctx, lambda: ctx.hist2d_sheared(*shear_args, out=o2))
+    iso["hist2d_sheared_79_pairs"] = dict(ms_median=med, ms_min=mn)
+    for Fu, npair in ((384, 13), (768, 6), (960, 6)):
+        eu = [mc._bin_edges(p, Fu) for p in par]
+        ixu = [mc._index_column(j, Fu, eu[j][1], eu[j][0]) for j in range(npair + 1)]
+        o3 = ctx.alloc(npair * Fu * Fu * 8)
+        xs, ys = [ixu[0]] * npair, ixu[1:npair + 1]
+        med, mn = timed(ctx, lambda: ctx.hist2d_prebinned(xs, ys, Fu, out=o3))
+        h_new = o3.to_host((npair, Fu, Fu)).copy()
+        os.environ["GDHIP_NO_U16_CHUNKS"] = "1"
+        med0, mn0 = timed(ctx, lambda: ctx.hist2d_prebinned(xs, ys, Fu, out=o3))
+        os.environ.pop("GDHIP_NO_U16_CHUNKS")
+        iso["hist2d_upscaled_F%d_%dpairs" % (Fu, npair)] = dict(ms_median_chunks=med, ms_median_u32=med0,
+                                                                equal=bool(np.array_equal(h_new, o3.to_host((npair, Fu, Fu)))),
+                                                                mass_ok=bool(np.all(h_new.sum(axis=(1, 2)) == N)))
+        o3.free()
+    print("isolated", json.dumps(iso), flush=True)
+    res["isolated_kernels"] = iso
     res["hist2d_u8"] = dict(pairs=len(pairs), N=N, variants=hist,
                             note="variant 0 = round-2 kernel (flat loads, lgkmcnt drain); 1..4 = k_hist2d_u8_pf<DEPTH>")
     out.free()
