@@ -2746,6 +2746,7 @@ class MCSamples:
                             ncontours = min(num_plot_contours, ncontours)
                         levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
                     inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
+                    assemble_new()
                     continue
                 if [pos for pos, _ in sel] == list(range(len(members))):
                     d_sub, own = d_hist, False
@@ -2791,25 +2792,21 @@ class MCSamples:
                     release.append(d_sub)  # freeing waits for the stream: after the last batch
                 # the copy runs on the copy stream while the next batch computes
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
+                if not self._timing:
+                    assemble_new()
 
         _hostlog("bandwidths done")
         enqueue_only = (hasattr(ctx, "density2d_enqueue") and not self._timing and not meanlikes and mask_function is None
                         and os.environ.get("GETDIST_AMD_ASYNC_CONVOLVE", "1") == "1")
         release = []
         status_all, status_at = (ctx.pinned_array((npair,), np.int32) if enqueue_only else None), [0]
-        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
-        for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
-            run_class(F, d_hist, members)
-            _hostlog("class F=%d enqueued (%d pairs)" % (F, len(members)))
-        release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
-        _hostlog("all batches enqueued")
-        synced = False
-        if any(lv is not None and np.any(lv[1] == -5) for *_, lv in inflight):  # a grid left to the host reads P
-            ctx.copy_sync()
-            synced = True
-        _ph_asm = _Phase(self, "2d.host_assemble_results")
-        _ph_asm.__enter__()
-        # the result objects only hold views of the page-locked arrays, so they are built while the last copies land
+        # With every batch enqueued without waiting, the call may return while the last result copies are still in
+        # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
+        lazy = (enqueue_only and get_density and hasattr(ctx, "copy_mark")
+                and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
+        completion = _PendingResults(ctx, inflight, release) if lazy else None  # shares the two lists filled below
+        import functools
+
         # the grid axes of every (parameter, F) in use, all at once: np.linspace(lo, hi, F) written out
         # (k * step + start, last point = stop) on one 2D array per F
         ax_cache = {}
@@ -2821,42 +2818,55 @@ class MCSamples:
             A[:, -1] = hi_
             for row, j in enumerate(js_):
                 ax_cache[(j, F_)] = (A[row], A[row, 1] - A[row, 0], (names[j].range_min, names[j].range_max))
+        assembled = [0]
+        sync_state = [False]
 
-        def axis_of(j, par, lo, hi, F):
-            return ax_cache[(j, F)]
+        def assemble_new():
+            """Result objects of the batches enqueued since the last call: they only hold views of the page-locked
+            arrays, so they are built while those batches compute and copy -- batch by batch, not after the last
+            enqueue, where the host work would sit between this call's kernels and the caller's next ones."""
+            for d_P, P, ks, status, d_L, L, levels in inflight[assembled[0]:]:
+                F = P.shape[1]
+                lev_state = None if levels is None else np.asarray(levels[1]).tolist()
+                if lev_state is not None and -5 in lev_state and not sync_state[0]:  # a grid left to the host reads P
+                    ctx.copy_sync()
+                    sync_state[0] = True
+                ncont = None
+                for row, k in enumerate(ks):
+                    e = info[k]
+                    ax, sx, vrx = ax_cache[(e["j"], F)]
+                    ay, sy, vry = ax_cache[(e["j2"], F)]
+                    contours = None
+                    if lev_state is not None:
+                        if lev_state[row] == 0:
+                            contours = levels[0][row].copy()
+                        elif lev_state[row] == -4:
+                            raise DensitiesError("Contour level outside plotted ranges")
+                        else:
+                            ncont = levels[0].shape[1]
+                    dens = Density2D._from_fields(dict(
+                        x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=e.get("mask"),
+                        likes=None if L is None else L[row], contours=contours, spl=None, _P=P[row],
+                        _wait=functools.partial(completion.wait_grid, k) if lazy else None,
+                        bandwidth=e.get("bandwidth"), bandwidth_branch=e.get("branch"), kopt=e.get("kopt")))
+                    if contours is None and lev_state is not None:
+                        # more exactly equal grid values at the level than the kernel's tie list holds
+                        dens.contours = dens.getContourLevels(self.contours[:ncont])
+                    out[k] = dens
+            assembled[0] = len(inflight)
 
-        ncont = None
-        # With every batch enqueued without waiting, the call may return while the last result copies are still in
-        # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
-        lazy = (enqueue_only and not synced and get_density and hasattr(ctx, "copy_mark")
-                and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
-        completion = _PendingResults(ctx, inflight, release) if lazy else None
-        import functools
-
-        for d_P, P, ks, status, d_L, L, levels in inflight:
-            F = P.shape[1]
-            lev_state = None if levels is None else np.asarray(levels[1]).tolist()
-            for row, k in enumerate(ks):
-                e = info[k]
-                ax, sx, vrx = axis_of(e["j"], e["parx"], e["xbinmin"], e["xbinmax"], F)
-                ay, sy, vry = axis_of(e["j2"], e["pary"], e["ybinmin"], e["ybinmax"], F)
-                contours = None
-                if lev_state is not None:
-                    if lev_state[row] == 0:
-                        contours = levels[0][row].copy()
-                    elif lev_state[row] == -4:
-                        raise DensitiesError("Contour level outside plotted ranges")
-                    else:
-                        ncont = levels[0].shape[1]
-                dens = Density2D._from_fields(dict(
-                    x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=e.get("mask"),
-                    likes=None if L is None else L[row], contours=contours, spl=None, _P=P[row],
-                    _wait=functools.partial(completion.wait_grid, k) if lazy else None,
-                    bandwidth=e.get("bandwidth"), bandwidth_branch=e.get("branch"), kopt=e.get("kopt")))
-                if contours is None and lev_state is not None:
-                    # more exactly equal grid values at the level than the kernel's tie list holds
-                    dens.contours = dens.getContourLevels(self.contours[:ncont])
-                out[k] = dens
+        _ph_asm = _Phase(self, "2d.host_assemble_results")
+        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
+        for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
+            run_class(F, d_hist, members)
+            _hostlog("class F=%d enqueued (%d pairs)" % (F, len(members)))
+        release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
+        _hostlog("all batches enqueued")
+        _ph_asm.__enter__()
+        assemble_new()
+        synced = sync_state[0]
+        if lazy:
+            completion.token = ctx.copy_mark()  # after the last copy of this call
         _ph_asm.__exit__()
         _hostlog("results assembled")
         if lazy:
