@@ -764,6 +764,24 @@ __global__ void __launch_bounds__(256) k_minmax_affine_grouped(const MinmaxGroup
 }
 
 // =============================================================================================================
+// How many row chunks to cut every (pair, stripe) unit into.  The 128-KB counter table leaves one block per CU, so a
+// launch runs in ceil(blocks / CUs) rounds of one block time each, and a block's time is proportional to its rows:
+// the cost of c chunks is rounds(c) / c.  (The old rule, "at least two blocks per CU", gave 79 sheared pairs 553
+// blocks = 2.16 -> three rounds of N/7 rows; three chunks give one round of N/3.)  A small penalty per chunk accounts
+// for the zero-fill, flush and reduction of its partial table; at most 16 chunks.
+static int pick_chunks(const gd_ctx* ctx, int64_t units, int64_t rows) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int c = 1; c <= 16; ++c) {
+        if ((int64_t)c * 65536 > rows && c > 1) break;
+        const int64_t blocks = units * c;
+        const double rounds = (double)((blocks + ctx->cu_count - 1) / ctx->cu_count);
+        const double cost = rounds / c + 0.004 * c;
+        if (cost < best_cost - 1e-12) best_cost = cost, best = c;
+    }
+    return best;
+}
+
 template <int MODE>
 static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, int F, double* d_hist, bool allow_p16 = true);
 
@@ -774,9 +792,7 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     int R = LDS_HIST_BYTES / (F * 2);
     if (R > F) R = F;
     const int nstripes = (F + R - 1) / R;
-    int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
-    if (nchunks < 1) nchunks = 1;
-    if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+    const int nchunks = pick_chunks(ctx, (int64_t)B * nstripes, ctx->N);
     const int units = (B * nchunks + 7) / 8 * 8;
     const int64_t nblocks = (int64_t)units * nstripes;
     const int nwords = (R * F + 1) / 2;
@@ -836,9 +852,7 @@ static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, 
     GD_REQUIRE(R >= 1, "fine_bins_2D too large for the LDS stripe");
     if (R > F) R = F;
     const int nstripes = (F + R - 1) / R;
-    int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
-    if (nchunks < 1) nchunks = 1;
-    if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+    const int nchunks = pick_chunks(ctx, (int64_t)B * nstripes, ctx->N);
     const int units = (B * nchunks + 7) / 8 * 8;
     const int64_t nblocks = (int64_t)units * nstripes;
     Hist2DPair* d_pairs = (Hist2DPair*)gd_scratch2(ctx, (int64_t)B * sizeof(Hist2DPair));
@@ -1038,9 +1052,7 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             // few pairs (the up-scaled grid classes): packed counters over (pair, chunk of rows, stripe) blocks, partials
             // reduced without atomics; pairs whose counters wrapped are redone with the 32-bit kernel
             const int R = R16, nstripes = nstripes16;
-            int nchunks = (2 * ctx->cu_count + B * nstripes - 1) / (B * nstripes);
-            if (nchunks < 1) nchunks = 1;
-            if ((int64_t)nchunks * 8192 > ctx->N) nchunks = (int)((ctx->N + 8191) / 8192);
+            const int nchunks = pick_chunks(ctx, (int64_t)B * nstripes, ctx->N);
             const int units = (B * nchunks + 7) / 8 * 8;
             const int64_t nblocks = (int64_t)units * nstripes;
             const int nwords = (R * F + 1) / 2;

@@ -956,12 +956,29 @@ __global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ 
     }
 }
 
-// per column: bucket totals (the blocks' partials added in block order), then every target's bucket -- the first
-// non-empty one at which the cumulative weight reaches the target -- and the weight below it; fills the QState the
-// collect / finish kernels read.  One block of 1024 threads per column; thread t owns PER consecutive buckets.
+// bucket totals: the blocks' partial tables added in block order; grid (nb / 256, ncols)
 template <bool HAS_W>
-__global__ void __launch_bounds__(1024) k_qlin_scan(QState* __restrict__ st, QLin* __restrict__ ql, const void* __restrict__ part,
-                                                    int nblk) {
+__global__ void __launch_bounds__(256) k_qlin_reduce(const void* __restrict__ part, int nblk, double* __restrict__ tot) {
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
+    const int c = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    double v = 0;
+    if (HAS_W) {
+        const double* p = (const double*)part + (int64_t)c * nblk * nb + b;
+        for (int k = 0; k < nblk; ++k) v += p[(int64_t)k * nb];
+    } else {
+        const unsigned int* p = (const unsigned int*)part + (int64_t)c * nblk * nb + b;
+        unsigned long long u = 0;
+        for (int k = 0; k < nblk; ++k) u += p[(int64_t)k * nb];
+        v = (double)u;
+    }
+    tot[(int64_t)c * nb + b] = v;
+}
+
+// per column, from the bucket totals: every target's bucket -- the first non-empty one at which the cumulative weight
+// reaches the target -- and the weight below it; fills the QState the collect / finish kernels read.  One block of
+// 1024 threads per column; thread t owns PER consecutive buckets.
+template <bool HAS_W>
+__global__ void __launch_bounds__(1024) k_qlin_scan(QState* __restrict__ st, QLin* __restrict__ ql, const double* __restrict__ totals) {
     constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U, PER = nb / 1024;
     __shared__ double tsum[1024];
     __shared__ int pick[QK_MAX];
@@ -973,17 +990,7 @@ __global__ void __launch_bounds__(1024) k_qlin_scan(QState* __restrict__ st, QLi
     double mine = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int b = t * PER + j;
-        double v = 0;
-        if (HAS_W) {
-            const double* p = (const double*)part + (int64_t)c * nblk * nb + b;
-            for (int k = 0; k < nblk; ++k) v += p[(int64_t)k * nb];
-        } else {
-            const unsigned int* p = (const unsigned int*)part + (int64_t)c * nblk * nb + b;
-            unsigned long long u = 0;
-            for (int k = 0; k < nblk; ++k) u += p[(int64_t)k * nb];
-            v = (double)u;
-        }
+        const double v = totals[(int64_t)c * nb + t * PER + j];
         tot[j] = v;
         mine += v;
     }
@@ -1636,9 +1643,12 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
         hql[c].scale = (double)nb / (minmax[2 * c + 1] - minmax[2 * c]);
         hql[c].nb = nb;
     }
+    // blocks per column: the chip filled about twice over, but every block keeps at least 256K rows to spread its 128-KB
+    // table's zero-fill and flush over (few columns -- one rank's share of the parameters -- would otherwise get 64
+    // blocks of 150K rows each)
     int nblk = (2 * ctx->cu_count + ncols - 1) / ncols;
-    if (nblk > 64) nblk = 64;
-    if ((int64_t)nblk * 65536 > hi - lo) nblk = (int)((hi - lo + 65535) / 65536);
+    if (nblk > 32) nblk = 32;
+    if ((int64_t)nblk * 262144 > hi - lo) nblk = (int)((hi - lo + 262143) / 262144);
     if (nblk < 1) nblk = 1;
     int nblk2 = (8 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk2 < 8) nblk2 = 8;
@@ -1652,7 +1662,8 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     const int64_t o_st = take((int64_t)ncols * sizeof(QState)), o_ql = take((int64_t)ncols * sizeof(QLin)),
                   o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8),
                   o_cnt = take((int64_t)ncols * QK_MAX * 4 + 256), o_lk = take((int64_t)ncols * QK_MAX * QCAP * 8),
-                  o_lw = take((int64_t)ncols * QK_MAX * QCAP * 8), o_part = take((int64_t)ncols * nblk * nb * (hw ? 8 : 4));
+                  o_lw = take((int64_t)ncols * QK_MAX * QCAP * 8), o_part = take((int64_t)ncols * nblk * nb * (hw ? 8 : 4)),
+                  o_tot = take((int64_t)ncols * nb * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     QState* d_st = (QState*)(base + o_st);
@@ -1663,6 +1674,7 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     unsigned long long* d_lk = (unsigned long long*)(base + o_lk);
     double* d_lw = (double*)(base + o_lw);
     void* d_part = base + o_part;
+    double* d_tot = (double*)(base + o_tot);
     GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_ql, hql.data(), hql.size() * sizeof(QLin), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1672,7 +1684,9 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
         GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_qlin_count<true><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part);
         GD_KERNEL_CHECK();
-        k_qlin_scan<true><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_part, nblk);
+        k_qlin_reduce<true><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot);
+        GD_KERNEL_CHECK();
+        k_qlin_scan<true><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
         GD_KERNEL_CHECK();
         k_qlin_collect<true><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_st, d_ql, d_lk,
                                                                           d_lw, d_cnt);
@@ -1680,7 +1694,9 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
         GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_qlin_count<false><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_ql, d_part);
         GD_KERNEL_CHECK();
-        k_qlin_scan<false><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_part, nblk);
+        k_qlin_reduce<false><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot);
+        GD_KERNEL_CHECK();
+        k_qlin_scan<false><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
         GD_KERNEL_CHECK();
         k_qlin_collect<false><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_st, d_ql,
                                                                            d_lk, d_lw, d_cnt);
