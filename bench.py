@@ -280,7 +280,9 @@ def _cpu_task(task):
                 moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
                 out["chaotic"] = (moved > 1e-6, moved)
                 if task.get("gpu_kopt") is not None:
-                    out["inside_oracle_spread"], out["excess"] = ko.within_oracle_spread(np.asarray(task["gpu_kopt"])[8:11], ens)
+                    trip = np.asarray(task["gpu_kopt"])[8:11]
+                    out["inside_oracle_spread"], out["excess"] = ko.within_oracle_spread(trip, ens)
+                    out["amise_ok"] = ko.amise_within_oracle_range(trip, ens, psi, tr["opt_N"])[0]
         return out
     # share of a full triangle: this worker's pairs, parameter state cached across them.  The CPU time is the oracle's
     # alone; afterwards (outside the timed span) every grid is compared with the GPU's grid of the same pair, read from
@@ -310,6 +312,7 @@ def _cpu_task(task):
                 ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
                 row["oracle_moves_by"] = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
                 row["inside_oracle_spread"], row["excess"] = ko.within_oracle_spread(kopt[8:11], ens)
+                row["amise_ok"] = ko.amise_within_oracle_range(kopt[8:11], ens, psi, tr["opt_N"])[0]
         rows.append(row)
     return dict(kind=kind, seconds=seconds, rows=rows)
 
@@ -394,6 +397,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                 loose.append(dict(pair=[names[pr[0]], names[pr[1]]], klass=key, max_abs_dP=err, bandwidth_rel_err=bw_err,
                                   oracle_chaotic=bool(chaotic[0]), oracle_moves_by=float(chaotic[1]),
                                   inside_oracle_spread=bool(r.get("inside_oracle_spread", False)),
+                                  as_good_in_amise=bool(r.get("amise_ok", False)),
                                   excess_over_oracle_spread=float(r.get("excess", 0.0))))
         parity_block = dict(N=int(N), tolerance=1e-6, classes=parity, n_pairs_checked=len(sample), n_pairs_on_loose_gate=len(loose),
                             loose_pairs=loose,
@@ -470,6 +474,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                              loose_pairs_that_use_tnc=int(sum(bool(r["tnc"]) for r in loose_rows)),
                              loose_pairs_chaotic_in_the_oracle=int(sum(r.get("oracle_moves_by", 0.0) > 1e-6 for r in loose_rows)),
                              loose_pairs_inside_the_oracle_spread=int(sum(bool(r.get("inside_oracle_spread")) for r in loose_rows)),
+                             loose_pairs_inside_spread_or_as_good_in_amise=int(sum(bool(r.get("inside_oracle_spread") or r.get("amise_ok")) for r in loose_rows)),
                              worst_excess_over_oracle_spread=float(max([r.get("excess", 0.0) for r in loose_rows] or [0.0])),
                              per_class={k: dict(pairs=v["pairs"], above_1e_6=int(v["loose"]), max_abs_dP=float(np.max(v["errs"])),
                                                 median_abs_dP=float(np.median(v["errs"]))) for k, v in sorted(census.items())}))

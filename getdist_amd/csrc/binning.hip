@@ -815,7 +815,7 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     k_hist2d_f64_p16<MODE><<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes,
                                                                                       nchunks, d_part, d_flags);
     GD_KERNEL_CHECK();
-    k_p16_reduce<<<dim3(16, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
+    k_p16_reduce<<<dim3((unsigned)(((int64_t)F * F + 1023) / 1024), B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
     GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1068,7 +1068,7 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             k_hist2d_u16_chunks<<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, nchunks,
                                                                                               d_part, d_flags);
             GD_KERNEL_CHECK();
-            k_p16_reduce<<<dim3(16, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
+            k_p16_reduce<<<dim3((unsigned)(((int64_t)F * F + 1023) / 1024), B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
             GD_KERNEL_CHECK();
             std::vector<int> hf((size_t)B);
             GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));

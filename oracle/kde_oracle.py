@@ -478,6 +478,23 @@ def within_oracle_spread(triple, ensemble, slack=1.0, floor=1e-6):
     return ok, float(np.max(excess))
 
 
+def amise_within_oracle_range(triple, ensemble, psi, N, margin=10.0, floor=1e-7):
+    """
+    The reference's own objective as the judge of a bandwidth triple: TNC stops somewhere on the flat floor of the AMISE
+    (kde_bandwidth.py:216-232), and where exactly depends on rounding.  A triple is as good as the reference's if its
+    AMISE does not exceed the smallest AMISE of the oracle ensemble by more than ``margin`` times the ensemble's own
+    AMISE range (at least ``floor`` relative).  Returns (ok, relative excess over the ensemble minimum, ensemble range).
+    """
+    p = np.zeros((5, 5))
+    p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = psi
+    vals = np.array([amise_from_psi(np.asarray(row, dtype=float), p, N) for row in ensemble])
+    mine = amise_from_psi(np.asarray(triple, dtype=float), p, N)
+    lo, hi = float(vals.min()), float(vals.max())
+    rng = (hi - lo) / lo
+    excess = (mine - lo) / lo
+    return bool(excess <= max(margin * rng, floor)), float(excess), float(rng)
+
+
 def get_h_from_psi(psi, N, corr_in, do_correlation, owner=None):
     """
     The scalar half of KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given psi = (p02, p20, p11, p00, p13, p31):

@@ -25,6 +25,6 @@ def oracle_pair(task):
                seconds=time.perf_counter() - t0, tnc="p_13" in tr)
     if out["tnc"]:
         psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-        out["t_star"], out["psi"] = tr["t_star"], psi
+        out["t_star"], out["psi"], out["opt_N"] = tr["t_star"], psi, tr["opt_N"]
         out["ensemble"] = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
     return out
