@@ -388,55 +388,12 @@ struct Hist2DPair8 {
     const unsigned char* iy;
 };
 
-__global__ void __launch_bounds__(1024) k_hist2d_u8(const Hist2DPair8* __restrict__ pairs, int B, int64_t N,
-                                                    double* __restrict__ hist_all, int* __restrict__ overflow) {
-    extern __shared__ double sh_raw[];
-    unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
-    __shared__ double red[16];
-    // consecutive pairs share their x column: give each XCD (block id mod 8) a contiguous run of pairs
-    const int per_xcd = (B + 7) / 8;
-    const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (pair >= B || (int)(blockIdx.x >> 3) >= per_xcd) return;
-    const Hist2DPair8 P = pairs[pair];
-    for (int i = threadIdx.x; i < 32768; i += 1024) sh[i] = 0;
-    __syncthreads();
-    auto add = [&](unsigned a) { atomicAdd(&sh[a & 0x7fffu], 1u << ((a >> 11) & 16u)); };
-    auto visit4 = [&](unsigned x4, unsigned y4) {
-        const unsigned lo = __builtin_amdgcn_perm(y4, x4, 0x05010400u);  // (y1 x1 y0 x0)
-        const unsigned hi = __builtin_amdgcn_perm(y4, x4, 0x07030602u);  // (y3 x3 y2 x2)
-        add(lo & 0xffffu);
-        add(lo >> 16);
-        add(hi & 0xffffu);
-        add(hi >> 16);
-    };
-    const int64_t N16 = N & ~(int64_t)15;
-    for (int64_t i = 16 * (int64_t)threadIdx.x; i < N16; i += 16 * 1024) {
-        const uint4 ax = gload_u4(P.ix + i), ay = gload_u4(P.iy + i);
-        visit4(ax.x, ay.x);
-        visit4(ax.y, ay.y);
-        visit4(ax.z, ay.z);
-        visit4(ax.w, ay.w);
-    }
-    if (threadIdx.x == 0)
-        for (int64_t i = N16; i < N; ++i) add(((unsigned)P.iy[i] << 8) | (unsigned)P.ix[i]);
-    __syncthreads();
-    double* hist = hist_all + (int64_t)pair * 65536;
-    unsigned int total = 0;
-    for (int i = threadIdx.x; i < 32768; i += 1024) {
-        const unsigned int v = sh[i];
-        total += (v & 0xffffu) + (v >> 16);
-        hist[i] = (double)(v & 0xffffu);
-        hist[i + 32768] = (double)(v >> 16);
-    }
-    const double t = block_sum((double)total, red);
-    if (threadIdx.x == 0 && t != (double)N) atomicOr(&overflow[pair], 1);
-}
-
-// The same kernel with (i) global_load instead of flat_load for the index bytes -- the per-pair table holds generic
-// pointers, and a flat load also counts on lgkmcnt, so waiting for it drained all 16 LDS atomics of the previous
-// iteration before the next byte could be unpacked; (ii) DEPTH iterations of loads in flight per lane (register ring),
-// so a wave always has adds to issue while its next bytes travel; (iii) the packed counters at LDS address 0 and the
-// increment as 1 + 0xffff * (top bit of y): 4.5 VALU operations per sample instead of 6.
+// Memory side: the index bytes come in by global_load (the per-pair table holds generic pointers, and a flat load also
+// counts on lgkmcnt -- waiting for one drains all 16 LDS atomics of the previous iteration), DEPTH iterations of loads in
+// flight per lane (register ring: a wave always has adds to issue while its next bytes travel); the packed counters sit
+// at LDS address 0 and the increment is 1 + 0xffff * (top bit of y): 4.5 VALU operations per sample.
+// (profiles/r03_kernels_ab.json: 3.43 ms for the flat-load, no-ring form of round 2 -> 2.88 ms at DEPTH 3; 1, 2, 4: 3.19,
+// 3.00, 2.89 ms.)
 template <int DEPTH>
 __global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __restrict__ pairs, int B, int64_t N,
                                                        double* __restrict__ hist_all, int* __restrict__ overflow) {
@@ -1171,15 +1128,8 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
     GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8), hipMemcpyHostToDevice, ctx->stream));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
     const int nblocks = (B + 7) / 8 * 8;
-    const int variant = getenv("GDHIP_U8_VARIANT") ? atoi(getenv("GDHIP_U8_VARIANT")) : 3;
-    if (variant == 0) {  // the round-2 kernel, kept for A/B timing
-        GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
-        k_hist2d_u8<<<nblocks, 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
-    } else {
-        auto kern = variant == 1 ? k_hist2d_u8_pf<1> : variant == 2 ? k_hist2d_u8_pf<2> : variant == 4 ? k_hist2d_u8_pf<4> : k_hist2d_u8_pf<3>;
-        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
-        kern<<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
-    }
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
+    k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
     GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -277,118 +277,21 @@ __global__ void k_cov_fin(const double* __restrict__ part, int nchunks, const in
 
 // ---- weighted covariance, slab form: every column of a row slab is read from HBM exactly once -------------------------
 // A block walks its chunk of rows in slabs of KS rows.  The slab of ALL m columns (d = x - mean, and w d when weighted)
-// is staged in LDS once and every 16 x 16 tile pair (ti <= tj) of the covariance is accumulated from it on the fp64
-// matrix cores; the tile pairs are dealt round-robin to the waves of the block (accumulators stay in registers for the
-// whole chunk).  The next slab's global loads are issued before the MFMAs of the current one.
+// is staged in LDS once and every upper-triangle 16 x 16 tile pair (ti <= tj) of the covariance is accumulated from it
+// by v_mfma_f64_16x16x4_f64; accumulators stay in registers for the whole chunk.
 //   LDS layout s[col][KS + 2] (row index fastest): staging writes are contiguous per column, and the MFMA operand reads
 //   (lane: col = 16 t + (lane & 15), row = k0 + (lane >> 4)) hit 64 distinct banks per half-wave because the column
-//   stride KS + 2 = 34 doubles is 4 dwords modulo 64 (MI355X_MICROARCH.md, ds_read_b64 lane groups).
-// Templates: MCAP = column capacity (multiple of 16), NW waves per block, MAXP tile pairs per wave, KS rows per slab.
-template <bool HAS_W, int MCAP, int NW, int MAXP, int KS>
-__global__ void __launch_bounds__(NW * 64, (MCAP == 112 ? 4 : 1)) k_cov_slab(const double* __restrict__ cols, int64_t ld,
-                                                      const int32_t* __restrict__ colidx, int m,
-                                                      const double* __restrict__ res, const double* __restrict__ w,
-                                                      int64_t lo, int64_t hi, int64_t rows_per_chunk,
-                                                      double* __restrict__ part) {
-    constexpr int NT = NW * 64, KSP = KS + 2, CPT = NT / KS;  // CPT columns staged per pass of the block
-    constexpr int NQ = (MCAP + CPT - 1) / CPT;
-    extern __shared__ double lds[];
-    double* sB = lds;                               // d
-    double* sA = HAS_W ? lds + MCAP * KSP : lds;    // w d (same array for unit weights)
-    typedef double f64x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
-    const int nt = (m + 15) / 16, T = nt * (nt + 1) / 2;
-    int ti[MAXP], tj[MAXP];
-    bool live[MAXP];
-    f64x4 acc[MAXP];
-#pragma unroll
-    for (int q = 0; q < MAXP; ++q) {
-        int pq = wv + q * NW, a = 0, len = nt;
-        live[q] = pq < T;  // wave-uniform
-        if (!live[q]) pq = 0;
-        while (pq >= len) {
-            pq -= len;
-            ++a;
-            --len;
-        }
-        ti[q] = a * 16;
-        tj[q] = (a + pq) * 16;
-        acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    }
-    for (int e = tid; e < (HAS_W ? 2 : 1) * MCAP * KSP; e += NT) lds[e] = 0.0;  // padding columns stay zero
-    // this thread stages row r of columns c0 + CPT q
-    const int r = tid % KS, c0 = tid / KS;
-    const double* src[NQ];
-    double mean[NQ], pre[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int c = c0 + CPT * q;
-        const bool has = c < m;
-        src[q] = has ? cols + (int64_t)colidx[c] * ld : nullptr;
-        mean[q] = has ? res[(int64_t)c * 4 + 3] : 0.0;
-    }
-    const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
-    int64_t c_hi = c_lo + rows_per_chunk;
-    if (c_hi > hi) c_hi = hi;
-    double wpre = 1.0;
-    auto fetch = [&](int64_t r0) {
-        const int64_t row = r0 + r;
-        const bool in = row < c_hi;
-        if (HAS_W) wpre = in ? w[row] : 0.0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) pre[q] = (in && src[q]) ? src[q][row] - mean[q] : 0.0;
-    };
-    if (c_lo < c_hi) fetch(c_lo);
-    for (int64_t r0 = c_lo; r0 < c_hi; r0 += KS) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int c = c0 + CPT * q;
-            if (c < MCAP && src[q]) {
-                sB[c * KSP + r] = pre[q];
-                if (HAS_W) sA[c * KSP + r] = pre[q] * wpre;
-            }
-        }
-        __syncthreads();
-        if (r0 + KS < c_hi) fetch(r0 + KS);
-#pragma unroll 2
-        for (int kk = 0; kk < KS / 4; ++kk) {
-            const int k = kk * 4 + lk;
-#pragma unroll
-            for (int q = 0; q < MAXP; ++q) {
-                if (live[q]) {
-                    const double a = sA[(ti[q] + l15) * KSP + k];
-                    const double b = sB[(tj[q] + l15) * KSP + k];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // partial tiles of this block: part[block][pair][16 x 16], D[row = lk + 4 reg][col = l15]
-#pragma unroll
-    for (int q = 0; q < MAXP; ++q) {
-        const int pq = wv + q * NW;
-        if (pq < T) {
-            double* p = part + ((int64_t)blockIdx.x * T + pq) * 256;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) p[(lk + 4 * rg) * 16 + l15] = acc[q][rg];
-        }
-    }
-}
-
-// ---- slab covariance, second form --------------------------------------------------------------------------------
-// Same data flow (a slab of KS rows of ALL columns staged once in LDS as d = x - mean [and w d], every upper-triangle
-// 16 x 16 tile pair accumulated from it by v_mfma_f64_16x16x4_f64), rebuilt around what the first form's ISA showed:
-//   * staging loads were 8-byte, one branch each, and each waited for (vmcnt(0)) before the next was issued; here a
-//     thread owns two consecutive rows of NQ columns: unconditional 16-byte global loads (column index clamped, the
-//     store predicated instead), all NQ (+ the weights) in flight while the previous slab is multiplied.  Ragged
-//     ends of a chunk (an odd first row, the last partial slab) go through a guarded slow path once per block;
-//   * every MFMA sat in its own basic block behind `if (live[q])`, so each one waited for its own two LDS reads.  Now
-//     the waves are an NG x NH arrangement: group g owns P consecutive tile pairs (dead slots alias pair 0 and are not
+//   stride KS + 2 doubles is 4 dwords modulo 64 (MI355X_MICROARCH.md, ds_read_b64 lane groups).
+//   * staging: a thread owns two consecutive rows of NQ columns: unconditional 16-byte global loads (column index
+//     clamped, the store predicated instead), a ring of DEPTH slabs in flight while the previous slab is multiplied.
+//     Ragged ends of a chunk (an odd first row, the last partial slab) go through a guarded slow path once per block;
+//   * the waves are an NG x NH arrangement: group g owns P consecutive tile pairs (dead slots alias pair 0 and are not
 //     written), row-split h owns KS/4/NH of the slab's k-steps; the loop over (k-step, slot) is straight-line code
-//     and the compiler keeps several operand reads in flight ahead of the matrix pipe;
+//     and sched_group_barrier keeps several operand reads in flight ahead of the matrix pipe;
 //   * tile-pair bases are wave-uniform (readfirstlane): one VGPR holds the lane part of every operand address.
 // Partials: part[block * T + pair][16 x 16] (the NH row-splits are added inside the block); k_cov_slab_fin sums the blocks.
+// Templates: MCAP = column capacity (multiple of 16), NW = NG * NH waves per block, P tile pairs per wave, KS rows per
+// slab, DEPTH slabs of global loads in flight.
 template <bool HAS_W, int MCAP, int NW, int NH, int P, int KS, int DEPTH>
 __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict__ cols, int64_t ld,
                                                        const int32_t* __restrict__ colidx, int m,
@@ -1453,8 +1356,8 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     double* d_res = nullptr;
     double* d_cov = nullptr;
     const bool slab = (m <= 208) && !getenv("GDHIP_COV_TILE");
-    if (slab && !getenv("GDHIP_COV_OLD")) {
-        // ---- slab kernel, second form: pick the wave arrangement with the fewest tile-pair slots >= T
+    if (slab) {
+        // ---- slab kernel: pick the wave arrangement with the fewest tile-pair slots >= T
         const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2, mc = nt16 * 16;
         const int KS = mc <= 64 ? 64 : 32;  // narrow matrices: more rows per barrier pair
         struct Cfg { int mcap, nw, nh, p, bpc; };
@@ -1520,57 +1423,6 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         }
 #undef GD_COV2_HW
 #undef GD_COV2
-        GD_KERNEL_CHECK();
-        k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
-        GD_KERNEL_CHECK();
-    } else if (slab) {
-        // ---- slab kernel: all columns of a row slab staged once, every tile pair from LDS
-        // rows per slab: 32.  (64 for the narrow variant -- 512-B runs per column, 16 loads in flight per lane -- was
-        // measured slower, 4.5 vs 3.1 ms at m = 50: 142 VGPRs leave three blocks per CU instead of four; GDHIP_COV_KS64
-        // selects it.)
-        const int KS = (m <= 64 && getenv("GDHIP_COV_KS64")) ? 64 : 32;
-        const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2;
-        // enough resident blocks per CU that the next slab's loads (HBM latency ~2 us) hide behind other blocks' MFMAs:
-        // the 64-column variant fits four blocks per CU, the 112-column one two, the 208-column one one (8 waves)
-        int nblk = (m <= 64 ? 4 : 2) * ctx->cu_count;
-        if (nblk > (rows + 4 * KS - 1) / (4 * KS)) nblk = (int)((rows + 4 * KS - 1) / (4 * KS));
-        if (nblk < 1) nblk = 1;
-        int64_t rows_per_chunk = (rows + nblk - 1) / nblk;
-        rows_per_chunk = (rows_per_chunk + KS - 1) / KS * KS;
-        nblk = (int)((rows + rows_per_chunk - 1) / rows_per_chunk);
-        int64_t off = 0;
-        const int64_t o_part1 = take_init(off, (int64_t)m * NBLK_STREAM * 4 * 8), o_res = take_init(off, (int64_t)m * 4 * 8),
-                      o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * T * 256 * 8),
-                      o_cov = take_init(off, (int64_t)m * m * 8);
-        char* base = (char*)gd_scratch(ctx, off);
-        if (!base) return GD_ERR_NOMEM;
-        double* d_part1 = (double*)(base + o_part1);
-        d_res = (double*)(base + o_res);
-        int32_t* d_idx = (int32_t*)(base + o_idx);
-        double* d_cpart = (double*)(base + o_cpart);
-        d_cov = (double*)(base + o_cov);
-        GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-        int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
-        if (rc) return rc;
-        const bool hw = ctx->w != nullptr;
-#define GD_COV_LAUNCH(HW, MCAP, NW, MAXP, KSV)                                                                         \
-    do {                                                                                                               \
-        const size_t lds = (size_t)((HW) ? 2 : 1) * (MCAP) * ((KSV) + 2) * 8;                                          \
-        GD_HIP(hipFuncSetAttribute((const void*)k_cov_slab<HW, MCAP, NW, MAXP, KSV>,                                   \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
-        k_cov_slab<HW, MCAP, NW, MAXP, KSV><<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, \
-                                                                                ctx->w, lo, hi, rows_per_chunk, d_cpart); \
-    } while (0)
-        if (m <= 64 && KS == 64) {
-            if (hw) GD_COV_LAUNCH(true, 64, 4, 3, 64); else GD_COV_LAUNCH(false, 64, 4, 3, 64);
-        } else if (m <= 64) {
-            if (hw) GD_COV_LAUNCH(true, 64, 4, 3, 32); else GD_COV_LAUNCH(false, 64, 4, 3, 32);
-        } else if (m <= 112) {
-            if (hw) GD_COV_LAUNCH(true, 112, 8, 4, 32); else GD_COV_LAUNCH(false, 112, 8, 4, 32);
-        } else {
-            if (hw) GD_COV_LAUNCH(true, 208, 8, 12, 32); else GD_COV_LAUNCH(false, 208, 8, 12, 32);
-        }
-#undef GD_COV_LAUNCH
         GD_KERNEL_CHECK();
         k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
         GD_KERNEL_CHECK();

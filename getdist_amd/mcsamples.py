@@ -2505,10 +2505,7 @@ class MCSamples:
                 and self._lane == 0 and not meanlikes and len(pairs) >= 64
                 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"
                 and any(names[j].N_eff_kde is None for j in used)):
-            if os.environ.get("GETDIST_AMD_BIN_FIRST", "0") == "1":
-                neff_f = "later"  # experiment: the binning is launched first, the N_eff kernels right behind it
-            else:
-                neff_f = self._helper().submit(self._neff_batch, used)
+            neff_f = self._helper().submit(self._neff_batch, used)
         corrmat = self.getCorrelationMatrix()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
@@ -2596,8 +2593,6 @@ class MCSamples:
                 twin = self._second_lane()
                 self._nlanes = 1  # only the binning is shared out
                 pending = self._lane_thread(twin).submit(binning, twin)
-                if neff_f == "later":
-                    neff_f = self._helper().submit(self._neff_batch, used)
                 _hostlog("binning and N_eff submitted")
                 try:
                     try:

@@ -1,10 +1,13 @@
 """
-Round-3 kernel A/B on the MI355X (run on the GPU box):  python scripts/r03_kernels.py [--quick]
-  * k_hist2d_u8 (round 2) against k_hist2d_u8_pf<DEPTH> (global loads + register ring), 1200 base pairs of C3, HIP events,
-    results compared bit for bit;
-  * k_cov_slab (round 2) against k_cov_slab2 at C3's shape (50 columns x 1e7, unit weights), C4's (100 x 5e6, weighted)
-    and C5's width (200 columns, 2e6 rows, unit and weighted), against each other and against numpy on a row sample.
+Isolated kernel timings on the MI355X (run on the GPU box):  python scripts/r03_kernels.py [--quick]
+  * k_hist2d_u8_pf over the base pairs of C3 (HIP events), the other O(N) kernels of a step one by one;
+  * k_cov_slab2 at C3's shape (50 columns x 1e7, unit weights), C4's (100 x 5e6, weighted), C5's width (200 columns,
+    2e6 rows, unit and weighted) and two odd widths, against numpy on a row prefix and on an odd row range.
 Writes gpurun_out/r03_kernels.json.
+
+profiles/r03_kernels_ab.json is this script's output at commit e7ee704, when the round-2 kernels (k_hist2d_u8 with flat
+loads, k_cov_slab) were still in the library behind GDHIP_U8_VARIANT / GDHIP_COV_OLD and were timed side by side and
+compared bit for bit with the present ones; they have been removed since, the switches with them.
 """
 import json
 import os
@@ -48,19 +51,10 @@ def main():
     i8 = [mc._idx_cols[(j, 256, "u8")][0] for j in range(n)]
     out = ctx.alloc(len(pairs) * F * F * 8)
     ix, iy = [i8[a] for a, b in pairs], [i8[b] for a, b in pairs]
-    ref = None
-    hist = {}
-    for variant in (0, 1, 2, 3, 4):
-        os.environ["GDHIP_U8_VARIANT"] = str(variant)
-        med, mn = timed(ctx, lambda: ctx.hist2d_prebinned8(ix, iy, out=out))
-        got = out.to_host((64, F, F))  # the first 64 grids
-        tot = float(np.sum(got))
-        if ref is None:
-            ref = got
-        hist["variant%d" % variant] = dict(ms_median=med, ms_min=mn, equal_to_round2=bool(np.array_equal(got, ref)),
-                                           mass_first64=tot)
-        print("u8 variant", variant, hist["variant%d" % variant], flush=True)
-    os.environ.pop("GDHIP_U8_VARIANT")
+    med, mn = timed(ctx, lambda: ctx.hist2d_prebinned8(ix, iy, out=out))
+    got = out.to_host((64, F, F))  # the first 64 grids
+    hist = dict(ms_median=med, ms_min=mn, mass_first64=float(np.sum(got)), mass_ok=bool(np.all(got.sum(axis=(1, 2)) == N)))
+    print("k_hist2d_u8_pf", hist, flush=True)
     # the other O(N) kernels of a step, isolated (HIP events): pre-binning, quantile select (linear buckets vs radix),
     # the sheared re-binning of 79 pairs, the up-scaled classes (packed chunks vs the 32-bit kernel)
     iso = {}
@@ -97,8 +91,7 @@ def main():
         o3.free()
     print("isolated", json.dumps(iso), flush=True)
     res["isolated_kernels"] = iso
-    res["hist2d_u8"] = dict(pairs=len(pairs), N=N, variants=hist,
-                            note="variant 0 = round-2 kernel (flat loads, lgkmcnt drain); 1..4 = k_hist2d_u8_pf<DEPTH>")
+    res["hist2d_u8"] = dict(pairs=len(pairs), N=N, **hist)
     out.free()
     # sheared + upscaled classes through the (now global-load) generic kernels: timing only, parity is in pytest
     # ---- covariance
@@ -106,26 +99,16 @@ def main():
 
     def cov_ab(tag, ctx_, m, rows, flops_note=""):
         r = {}
-        outs = {}
-        for name, env in (("round2", "1"), ("slab2", None)):
-            if env:
-                os.environ["GDHIP_COV_OLD"] = env
-            else:
-                os.environ.pop("GDHIP_COV_OLD", None)
-            med, mn = timed(ctx_, lambda: ctx_.cov(list(range(m))), reps=3)
-            outs[name] = ctx_.cov(list(range(m)))
-            r[name] = dict(ms_median=med, ms_min=mn)
-        os.environ.pop("GDHIP_COV_OLD", None)
-        c0, c1 = outs["round2"][1], outs["slab2"][1]
-        scale = np.sqrt(np.outer(np.diag(c0), np.diag(c0)))
-        r["max_rel_diff_new_vs_round2"] = float(np.max(np.abs(c0 - c1) / scale))
-        r["symmetric"] = bool(np.array_equal(c1, c1.T))
+        med, mn = timed(ctx_, lambda: ctx_.cov(list(range(m))), reps=3)
+        out_ = ctx_.cov(list(range(m)))
+        r["slab2"] = dict(ms_median=med, ms_min=mn)
+        r["symmetric"] = bool(np.array_equal(out_[1], out_[1].T))
         nt = (m + 15) // 16
         r["executed_TFLOPs_slab2"] = nt * (nt + 1) / 2 * 512.0 * rows / (r["slab2"]["ms_median"] * 1e-3) / 1e12
         r["GBps_slab2_incl_means_pass"] = 2.0 * rows * m * 8 / (r["slab2"]["ms_median"] * 1e-3) / 1e9
         cov[tag] = r
         print("cov", tag, r, flush=True)
-        return outs["slab2"]
+        return out_
 
     got = cov_ab("C3_50x%g_unit" % N, ctx, n, N)
     sub = slice(0, 200_000)
