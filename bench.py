@@ -87,14 +87,19 @@ def spawn_ranks_if_needed(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+_PAIR_INDEX = {}
+
+
 def pair_cost_classes(mc, pairs):
     """Cost class per pair (upscaled grid?, #bounded parameters, optimiser vs rule-of-thumb), vectorised."""
     corr = np.abs(mc.getCorrelationMatrix())
     lim = np.array([bool(p.has_limits) for p in mc.paramNames.names], dtype=np.int64)
-    a = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
-    b = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+    if _PAIR_INDEX.get("of") is not pairs:  # the pair list of a run never changes: its index arrays are made once
+        _PAIR_INDEX.update(of=pairs, a=np.array([p[0] for p in pairs], dtype=np.int64),
+                           b=np.array([p[1] for p in pairs], dtype=np.int64))
+    a, b = _PAIR_INDEX["a"], _PAIR_INDEX["b"]
     c = corr[b, a]
-    return ((c > 0.866).astype(np.int64) * 100 + (lim[a] + lim[b]) * 10 + (c > 0.2)).tolist()
+    return (c > 0.866).astype(np.int64) * 100 + (lim[a] + lim[b]) * 10 + (c > 0.2)
 
 
 def reset_caches(mc):
@@ -102,13 +107,30 @@ def reset_caches(mc):
         par.N_eff_kde = None
         par._ranges_done = False
     mc._initLimits()
-    mc._idx_cols = {}
+    # the index columns are per-step work: every entry is marked stale (its device block is kept for the rewrite)
+    mc._idx_cols = {k: (buf, None) for k, (buf, _) in mc._idx_cols.items()}
     mc.density1D = {}
-    if getattr(mc, "_twin", None) is not None:  # the second lane's index columns are per-step work too
-        mc._twin._idx_cols = {}
+    if getattr(mc, "_twin", None) is not None:  # the second lane's as well
+        mc._twin._idx_cols = {k: (buf, None) for k, (buf, _) in mc._twin._idx_cols.items()}
 
 
 _REPLAY = {}
+
+
+def _hostlog(what):
+    from getdist_amd import mcsamples
+
+    mcsamples._hostlog(what)
+
+
+def prepare_replay(mc, W):
+    """--emulate-world: what the other W - 1 ranks would contribute to the two all-gathers of a step."""
+    from getdist_amd import parallel
+
+    mc.prepareParams()
+    _REPLAY["rows"] = parallel.pack_param_state(mc, list(range(mc.n)))
+    per = (mc.numrows + W - 1) // W
+    _REPLAY["moments"] = {W: [mc._partial_moments(min(r * per, mc.numrows), min((r + 1) * per, mc.numrows)) for r in range(W)]}
 
 
 def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
@@ -126,25 +148,42 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
             mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: parallel.allgather_vector(mine, dist, torch_device))
     else:
         mc.updateBaseStatistics()  # means, variances, covariance, weight statistics; clears every per-parameter cache
+    _hostlog("step: base statistics done")
     reset_caches(mc)
     my_params = parallel.partition_round_robin(list(range(mc.n)), world, rank)
-    # single rank: N_eff is left to get2DDensities, which overlaps it with the 2D binning on a second stream; with
-    # several ranks it must be known before the parameter state is exchanged
-    mc.prepareParams(my_params, neff=(world > 1))
+    # N_eff is left to get2DDensities, which overlaps it with the 2D binning on a second stream; with several ranks the
+    # ranges are exchanged first (the bin edges of every parameter are needed to start the binning) and each rank's
+    # share of the N_eff values in a second, smaller all-gather once its kernels are through (parallel.NeffShare)
+    mc.prepareParams(my_params, neff=False)
     if emulate:
         others = [j for j in range(mc.n) if j not in my_params]
-        parallel.unpack_param_state(mc, _REPLAY["rows"][others])  # what the all-gather would deliver
+        state = _REPLAY["rows"][others].copy()
+        state[:, 1 + parallel.PARAM_STATE.index("N_eff_kde")] = np.nan
+        parallel.unpack_param_state(mc, state)  # what the first all-gather would deliver
+
+        def exchange(mc_):
+            neff = _REPLAY["rows"][others][:, 1 + parallel.PARAM_STATE.index("N_eff_kde")]
+            for j, v in zip(others, neff.tolist()):
+                mc_.paramNames.names[j].N_eff_kde = v
     else:
         parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
+
+        def exchange(mc_):
+            parallel.allgather_neff(mc_, my_params, mc_.n, dist, torch_device)
+    _hostlog("step: parameter state exchanged")
     t_part0 = time.perf_counter()
     if world == 1:
         my_pairs = pairs_all  # nothing to deal out
     else:
-        classes = dict(zip(pairs_all, pair_cost_classes(mc, pairs_all)))
-        _, my_pairs = parallel.partition_pairs(pairs_all, classes.__getitem__, world, rank)
+        _, my_pairs = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
+        mc._neff_share = parallel.NeffShare(my_params, exchange)
     if mc._timing:
         mc.timings["step.partition"] = mc.timings.get("step.partition", 0.0) + time.perf_counter() - t_part0
-    out = mc.get2DDensities(my_pairs)
+    _hostlog("step: pairs dealt")
+    try:
+        out = mc.get2DDensities(my_pairs)
+    finally:
+        mc._neff_share = None
     _REPLAY["last_pairs"] = my_pairs  # the order of `out`
     if mc._timing:
         mc.timings["step.total"] = mc.timings.get("step.total", 0.0) + time.perf_counter() - t_step0
@@ -558,18 +597,14 @@ def main():
                 torch.cuda.synchronize()
 
     if args.emulate_world:
-        from getdist_amd import parallel
-
-        mc.prepareParams()
-        _REPLAY["rows"] = parallel.pack_param_state(mc, list(range(mc.n)))
-        W = args.emulate_world
-        per = (mc.numrows + W - 1) // W
-        _REPLAY["moments"] = {W: [mc._partial_moments(min(r * per, mc.numrows), min((r + 1) * per, mc.numrows)) for r in range(W)]}
+        prepare_replay(mc, args.emulate_world)
     dens = None
     for _ in range(args.warmup):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)  # held like the timed results
     if args.warmup > 0:
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
+        if getattr(mc, "_twin", None) is not None:
+            mc._twin.ctx.reserve_pinned_twin()  # a rank's share is convolved on both contexts' streams
     barrier()
     mc.timings = {}
     prof = None

@@ -618,22 +618,34 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16_chunks(const Hist2DPair* __
     if (threadIdx.x == 0 && t != a) atomicOr(&overflow[pair], 1);
 }
 
-// hist[pair][row][col] = sum over chunks of the packed partial counters; grid (blocks, B)
-__global__ void k_p16_reduce(const unsigned int* __restrict__ part, int F, int R, int nstripes, int nchunks,
-                             double* __restrict__ hist_all) {
-    const int pair = blockIdx.y;
+// hist[pair][row][col] = sum over chunks of the packed partial counters; grid (word blocks, stripes, B).  A thread owns
+// one packed word of a stripe (two neighbouring bins) and keeps eight chunks' loads in flight: the chunks of a word lie
+// megabytes apart, so a serial walk (one load latency per chunk) had left this at 50 GB/s on a single up-scaled pair.
+__global__ void __launch_bounds__(256) k_p16_reduce(const unsigned int* __restrict__ part, int F, int R, int nstripes, int nchunks,
+                                                    double* __restrict__ hist_all) {
+    const int pair = blockIdx.z, stripe = blockIdx.y;
     const int nwords = (R * F + 1) / 2;
-    double* hist = hist_all + (int64_t)pair * F * F;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
-        const int row = e / F, col = e % F;
-        const int stripe = row / R, a = (row - stripe * R) * F + col;
-        unsigned int s = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            const unsigned int v = part[(((int64_t)pair * nchunks + c) * nstripes + stripe) * (int64_t)nwords + (a >> 1)];
-            s += (v >> ((a & 1) * 16)) & 0xffffu;
-        }
-        hist[e] = (double)s;
+    const int rows = min(R, F - stripe * R);
+    const int wd = blockIdx.x * 256 + threadIdx.x;
+    if (2 * wd >= rows * F) return;
+    const int64_t step = (int64_t)nstripes * nwords;
+    const unsigned int* p = part + ((int64_t)pair * nchunks * nstripes + stripe) * (int64_t)nwords + wd;
+    unsigned int lo = 0, hi = 0;
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+        unsigned int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(p + (c + q) * step);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lo += v[q] & 0xffffu, hi += v[q] >> 16;
     }
+    for (; c < nchunks; ++c) {
+        const unsigned int v = p[c * step];
+        lo += v & 0xffffu, hi += v >> 16;
+    }
+    double* hist = hist_all + (int64_t)pair * F * F + (int64_t)stripe * R * F;
+    hist[2 * wd] = (double)lo;  // index in the stripe = row * F + col: the stripe's rows are contiguous in the grid
+    if (2 * wd + 1 < rows * F) hist[2 * wd + 1] = (double)hi;
 }
 
 // min / max of a*x + b*y over the samples; grid (nblk, B)
@@ -772,7 +784,7 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     k_hist2d_f64_p16<MODE><<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes,
                                                                                       nchunks, d_part, d_flags);
     GD_KERNEL_CHECK();
-    k_p16_reduce<<<dim3((unsigned)(((int64_t)F * F + 1023) / 1024), B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
+    k_p16_reduce<<<dim3((unsigned)((nwords + 255) / 256), nstripes, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
     GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1025,7 +1037,7 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             k_hist2d_u16_chunks<<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, nchunks,
                                                                                               d_part, d_flags);
             GD_KERNEL_CHECK();
-            k_p16_reduce<<<dim3((unsigned)(((int64_t)F * F + 1023) / 1024), B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
+            k_p16_reduce<<<dim3((unsigned)((nwords + 255) / 256), nstripes, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
             GD_KERNEL_CHECK();
             std::vector<int> hf((size_t)B);
             GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));

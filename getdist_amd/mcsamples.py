@@ -286,19 +286,26 @@ class _PendingResults:
     blocks beyond one further call.
     """
 
-    def __init__(self, ctx, inflight, release):
+    def __init__(self, ctx, inflight, release, more_ctxs=()):
         self.ctx, self.inflight, self.release = ctx, inflight, release
-        self.token = ctx.copy_mark()
+        self.ctxs = [ctx] + list(more_ctxs)  # a small call spreads its batches over the streams of two contexts
+        self.mark()
         self.done = False
         self.failed = frozenset()
         self.lock = threading.Lock()
+
+    def mark(self):
+        """'Every result copy issued so far' on each context's copy stream."""
+        self.tokens = [c.copy_mark() for c in self.ctxs]
+        self.token = self.tokens[0]
 
     def wait(self):
         with self.lock:
             if self.done:
                 return
-            if getattr(self.ctx, "h", True) is not None:  # a closed context has synchronised its streams on the way out
-                self.ctx.copy_wait(self.token)
+            for c, tok in zip(self.ctxs, self.tokens):
+                if getattr(c, "h", True) is not None:  # a closed context has synchronised its streams on the way out
+                    c.copy_wait(tok)
             failed = set()
             for _, _, ks, status, _, _, _ in self.inflight:
                 bad = np.nonzero(np.asarray(status) != 0)[0]
@@ -1567,6 +1574,9 @@ class MCSamples:
         return self.confidence(paramVec, limits)
 
     # ---- autocorrelation / effective samples (chains.py:423-574) -------------------------------------------
+    # batched 2D calls of this many pairs convolve their batches on two streams (below: not worth a second context's
+    # plans and scratch; above: one batch fills the chip)
+    CONV_TWO_STREAMS_PAIRS = (64, 400)
     DIRECT_LAGS_MAX = 512  # beyond this many lags the length-2N FFT (gd_autoconvolve) is cheaper than lag sums
 
     def _autocov(self, col, mean, k0, nlags):
@@ -1701,6 +1711,18 @@ class MCSamples:
         todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
         if not todo:
             return
+        share = getattr(self, "_neff_share", None)
+        if share is not None:
+            # multi-rank runs (parallel.NeffShare): this rank computes the parameters it owns, the others arrive by exchange
+            self._neff_share = None
+            try:
+                self._neff_batch([j for j in todo if j in share.params], min_corr)
+                share.exchange(self)
+            finally:
+                self._neff_share = share
+            todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]  # owned by nobody: computed here
+            if not todo:
+                return
         if self.sampler in ("nested", "uncorrelated"):
             for j in todo:
                 self.paramNames.names[j].N_eff_kde = self.norm**2 / self._sum_w2
@@ -1881,9 +1903,11 @@ class MCSamples:
                 twin.ctx.autocov_lags_batch, todo, self.means[todo], 0, nl))
         with _Phase(self, "prep.ranges"), _FastThreadSwitch(getattr(self, "_lag_prefetch", None) is not None):
             self._init_params(js)
+        _hostlog("prep: ranges done")
         if neff:
             with _Phase(self, "prep.neff"):
                 self._neff_batch(js)
+            _hostlog("prep: N_eff done")
         return js
 
     @staticmethod
@@ -2375,9 +2399,9 @@ class MCSamples:
                 results[k] = (hx * scale, hy * scale, c)
         return results
 
-    def _gather_device(self, d_src, d_dst, positions, item_bytes):
+    def _gather_device(self, d_src, d_dst, positions, item_bytes, ctx=None):
         """Copy selected fixed-size items of one device buffer into another (one gather kernel)."""
-        self.ctx.gather_items(d_dst, d_src, positions, item_bytes)
+        (ctx or self.ctx).gather_items(d_dst, d_src, positions, item_bytes)
 
     def _index_columns_batch(self, F, wanted):
         """Build every missing / stale u16 index column of grid size F in ONE launch (wanted: j -> (binmin, width))."""
@@ -2556,6 +2580,7 @@ class MCSamples:
                             fw, bmin, _ = edge_of[(j, 256)]
                             wanted[j] = (bmin, fw)
                         ok = owner._index_columns8(wanted)
+                        _hostlog("binning: byte index columns launched")
                     if ok:
                         try:
                             with _Phase(self, "2d.hist"):
@@ -2575,6 +2600,7 @@ class MCSamples:
                     iy = [owner._index_column(pj2[k], F, edge_of[(pj2[k], F)][1], edge_of[(pj2[k], F)][0]) for k in members]
                 with _Phase(self, "2d.hist"):
                     hists[F] = (owner.ctx.hist2d_prebinned(ix, iy, F), members)
+                    _hostlog("binning: class F=%d done" % F)
                     if meanlikes:
                         likehists[F] = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F))
 
@@ -2611,6 +2637,7 @@ class MCSamples:
             else:
                 self._neff_batch(used)
                 pending = self._helper().submit(binning)  # the helper thread is inside this context's entry points
+                _hostlog("binning submitted")
                 try:
                     build_info()
                     plan = self._bandwidth_plan(*plan_args())
@@ -2743,11 +2770,15 @@ class MCSamples:
                     inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
                     assemble_new()
                     continue
+                # a small call (one rank's share of a triangle, a handful of pairs) cannot fill the chip with one
+                # batch's kernels: its batches go alternately to the streams of the two contexts and run side by side
+                bctx = conv_ctxs[batch_no[0] % len(conv_ctxs)]
+                batch_no[0] += 1
                 if [pos for pos, _ in sel] == list(range(len(members))):
                     d_sub, own = d_hist, False
                 else:
-                    d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
-                    self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
+                    d_sub, own = bctx.alloc(len(sel) * F * F * 8), True
+                    self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8, ctx=bctx)
                 ks = [k for _, k in sel]
                 with _Phase(self, "2d.convolve"):
                     if enqueue_only:
@@ -2755,9 +2786,9 @@ class MCSamples:
                         # built, while this one computes; its status words land in page-locked memory
                         status = status_all[status_at[0]:status_at[0] + len(sel)]
                         status_at[0] += len(sel)
-                        d_P = ctx.density2d_enqueue(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                    [cc[k] for k in ks], [winw_l[k] for k in ks],
-                                                    [flags_l[k] for k in ks], bco, mbc, status)
+                        d_P = bctx.density2d_enqueue(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
+                                                     [cc[k] for k in ks], [winw_l[k] for k in ks],
+                                                     [flags_l[k] for k in ks], bco, mbc, status)
                     else:
                         d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
                                                     [cc[k] for k in ks], [winw_l[k] for k in ks],
@@ -2767,7 +2798,7 @@ class MCSamples:
                     ncontours = len(self.contours)
                     if num_plot_contours:
                         ncontours = min(num_plot_contours, ncontours)
-                    levels = ctx.contour_levels(d_P, len(sel), F, self.contours[:ncontours])
+                    levels = bctx.contour_levels(d_P, len(sel), F, self.contours[:ncontours])
                 d_L = L = None
                 if meanlikes:
                     if own:
@@ -2799,7 +2830,13 @@ class MCSamples:
         # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
         lazy = (enqueue_only and get_density and hasattr(ctx, "copy_mark")
                 and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
-        completion = _PendingResults(ctx, inflight, release) if lazy else None  # shares the two lists filled below
+        conv_ctxs, batch_no = [ctx], [0]
+        if (lazy and self._lane == 0 and self.CONV_TWO_STREAMS_PAIRS[0] <= npair <= self.CONV_TWO_STREAMS_PAIRS[1] and not self._timing
+                and self._context_factory is not None):
+            nlanes = self._nlanes
+            conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
+            self._nlanes = nlanes
+        completion = _PendingResults(ctx, inflight, release, conv_ctxs[1:]) if lazy else None  # shares the two lists filled below
         import functools
 
         # the grid axes of every (parameter, F) in use, all at once: np.linspace(lo, hi, F) written out
@@ -2824,7 +2861,8 @@ class MCSamples:
                 F = P.shape[1]
                 lev_state = None if levels is None else np.asarray(levels[1]).tolist()
                 if lev_state is not None and -5 in lev_state and not sync_state[0]:  # a grid left to the host reads P
-                    ctx.copy_sync()
+                    for c in conv_ctxs:
+                        c.copy_sync()
                     sync_state[0] = True
                 ncont = None
                 for row, k in enumerate(ks):
@@ -2861,7 +2899,7 @@ class MCSamples:
         assemble_new()
         synced = sync_state[0]
         if lazy:
-            completion.token = ctx.copy_mark()  # after the last copy of this call
+            completion.mark()  # after the last copy of this call
         _ph_asm.__exit__()
         _hostlog("results assembled")
         if lazy:
@@ -2873,7 +2911,8 @@ class MCSamples:
             return out
         if not synced:
             with _Phase(self, "2d.d2h_wait"):
-                ctx.copy_sync()
+                for c in conv_ctxs:
+                    c.copy_sync()
         failed = any(np.any(np.asarray(status) != 0) for _, _, _, status, _, _, _ in inflight)
         for d_P, P, ks, status, d_L, L, levels in inflight:
             d_P.free()

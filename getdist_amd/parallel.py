@@ -26,6 +26,51 @@ def partition_pairs(pairs, cost_key, world, rank):
     return mine, [pairs[i] for i in mine]
 
 
+def partition_pairs_by_class(pairs, class_ids, world, rank):
+    """partition_pairs for integer class ids given as an array (one per pair): the same deal, without a Python call per
+    pair -- at 8 ranks the dealing of a 1225-pair triangle is otherwise a visible part of a rank's step."""
+    class_ids = np.asarray(class_ids)
+    order = np.argsort(class_ids, kind="stable")
+    mine = np.sort(order[rank::world]).tolist()
+    return mine, [pairs[i] for i in mine]
+
+
+class NeffShare:
+    """
+    Who computes which parameter's KDE effective sample number in a multi-rank run.  Set as ``mc._neff_share``:
+    ``MCSamples._neff_batch`` then computes only the parameters in ``params`` (this rank's share) and calls
+    ``exchange(mc)``, which must leave ``N_eff_kde`` of every other parameter filled in (an all-gather of one double per
+    parameter).  This lets the N_eff kernels of a rank run beside its 2D binning exactly as in the single-GPU pipeline,
+    instead of before the parameter state is exchanged.
+    """
+
+    def __init__(self, params, exchange):
+        self.params = set(params)
+        self.exchange = exchange
+
+
+def allgather_neff(mc, my_js, n_params, dist=None, device=None):
+    """The second, small exchange of a step: N_eff_kde of the parameters each rank owns (one (index, value) row each)."""
+    names = mc.paramNames.names
+    mine = np.array([[j, np.nan if names[j].N_eff_kde is None else float(names[j].N_eff_kde)] for j in my_js]).reshape(-1, 2)
+    if dist is None or dist.get_world_size() == 1:
+        return
+    import torch
+
+    world = dist.get_world_size()
+    per = (n_params + world - 1) // world
+    buf = np.full((per, 2), -1.0)
+    buf[:len(mine)] = mine
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    rows = np.concatenate([g.cpu().numpy() for g in gathered])
+    for j, v in rows[rows[:, 0] >= 0]:
+        names[int(j)].N_eff_kde = None if np.isnan(v) else float(v)
+
+
 def pack_param_state(mc, js):
     """Rows of PARAM_STATE values for the parameters ``js`` this rank prepared."""
     out = np.zeros((len(js), 1 + len(PARAM_STATE)))

@@ -93,6 +93,15 @@ def test_c3_full_shape_determinism_and_one_pair_per_census_class_against_the_ora
     again = mc.get2DDensities(pairs)
     differing = [pr for pr, d1, d2 in zip(pairs, dens, again) if not np.array_equal(d1.P, d2.P)]
     assert not differing, ("same call, same device, different grids", len(differing), differing[:5])
+    # one rank's share of an 8-rank job (153 pairs, dealt like bench.py does): its batches are convolved alternately on
+    # the streams of two contexts, in other batch compositions than above -- the grids must not notice
+    share = pairs[3::8]
+    lo, hi = mc.CONV_TWO_STREAMS_PAIRS
+    assert lo <= len(share) <= hi
+    part = mc.get2DDensities(share)
+    full = dict(zip(pairs, dens))
+    differing = [pr for pr, d in zip(share, part) if not np.array_equal(d.P, full[pr].P)]
+    assert not differing, ("a share of the triangle differs from the same pairs of the full call", len(differing), differing[:5])
     klass = {}
     for (a, b), d in zip(pairs, dens):
         assert d.P.max() == 1.0 and d.P.min() > -1e-12

@@ -260,7 +260,8 @@ def test_prefill_plot_caches(zoo):
 
 def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     """A batch of >= 64 pairs is dealt to two lanes (two contexts, second one driven from a helper thread): same grids,
-    same order, same bandwidths as the single-lane run; settings changed afterwards reach the second lane too."""
+    same order, same bandwidths as the single-lane run; settings changed afterwards reach the second lane too.  The
+    default (one lane, binning and alternate convolution batches on the second context) equals it as well."""
     fx = zoo["block50"]
     pairs = [(i, j) for i in range(13) for j in range(i + 1, 13)] + [(20, 21), (38, 39)]
     assert len(pairs) >= 64
@@ -271,6 +272,7 @@ def test_two_lanes_equal_one_lane(zoo, monkeypatch):
     monkeypatch.setenv("GETDIST_AMD_LANES", "1")
     monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "0")
     ref = make(fx)
+    ref.CONV_TWO_STREAMS_PAIRS = (1 << 30, 0)  # and every batch convolved on this context's stream
     one = ref.get2DDensities(pairs)
     assert ref._twin is None
     monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "1")  # default: only the binning runs on the second context

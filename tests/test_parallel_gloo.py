@@ -194,7 +194,9 @@ def test_chain_per_rank_convergence_gloo_world2(tmp_path):
 
 def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     """`python bench.py --gpus 2` without a launcher around it re-launches itself under torch.distributed.run: the
-    JSON line reports two ranks from the communicator (gloo and the numpy context double here, RCCL on the GPU box)."""
+    JSON line reports two ranks from the communicator (gloo and the numpy context double here, RCCL on the GPU box).
+    17 parameters = 68 pairs per rank: enough for the overlapped pipeline, whose N_eff exchange is a collective issued
+    from the helper thread."""
     import json
     import subprocess
     import sys
@@ -203,7 +205,7 @@ def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "tests"), root, env.get("PYTHONPATH", "")])
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nsamples", "6000",
-           "--nparams", "10", "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--context-factory",
+           "--nparams", "17", "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--context-factory",
            "fake_ctx:FakeContext"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
