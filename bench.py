@@ -90,13 +90,18 @@ def spawn_ranks_if_needed(args):
 _PAIR_INDEX = {}
 
 
+def _pair_index(pairs):
+    """The pair list of a run never changes: its index arrays are made once."""
+    if _PAIR_INDEX.get("of") is not pairs:
+        arr = np.array(pairs, dtype=np.int64).reshape(-1, 2)
+        _PAIR_INDEX.update(of=pairs, array=arr, a=np.ascontiguousarray(arr[:, 0]), b=np.ascontiguousarray(arr[:, 1]))
+
+
 def pair_cost_classes(mc, pairs):
     """Cost class per pair (upscaled grid?, #bounded parameters, optimiser vs rule-of-thumb), vectorised."""
     corr = np.abs(mc.getCorrelationMatrix())
     lim = np.array([bool(p.has_limits) for p in mc.paramNames.names], dtype=np.int64)
-    if _PAIR_INDEX.get("of") is not pairs:  # the pair list of a run never changes: its index arrays are made once
-        _PAIR_INDEX.update(of=pairs, a=np.array([p[0] for p in pairs], dtype=np.int64),
-                           b=np.array([p[1] for p in pairs], dtype=np.int64))
+    _pair_index(pairs)
     a, b = _PAIR_INDEX["a"], _PAIR_INDEX["b"]
     c = corr[b, a]
     return (c > 0.866).astype(np.int64) * 100 + (lim[a] + lim[b]) * 10 + (c > 0.2)
@@ -172,10 +177,12 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
             parallel.allgather_neff(mc_, my_params, mc_.n, dist, torch_device)
     _hostlog("step: parameter state exchanged")
     t_part0 = time.perf_counter()
+    _pair_index(pairs_all)
     if world == 1:
-        my_pairs = pairs_all  # nothing to deal out
+        my_pairs = _PAIR_INDEX["array"]  # nothing to deal out; the (npairs, 2) index array of the list, made once
     else:
-        _, my_pairs = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
+        mine, _ = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
+        my_pairs = _PAIR_INDEX["array"][mine]
         mc._neff_share = parallel.NeffShare(my_params, exchange)
     if mc._timing:
         mc.timings["step.partition"] = mc.timings.get("step.partition", 0.0) + time.perf_counter() - t_part0
@@ -605,6 +612,13 @@ def main():
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
         if getattr(mc, "_twin", None) is not None:
             mc._twin.ctx.reserve_pinned_twin()  # a rank's share is convolved on both contexts' streams
+    # The cyclic collector's full passes walk every object the interpreter holds (modules, the sample-set object, ...):
+    # 5-10 ms every eighth step on this host, all of it in front of a kernel launch.  Objects alive after the warm-up are
+    # moved to the permanent generation; the per-step garbage (closures of the batched call) is still collected.
+    import gc
+
+    gc.collect()
+    gc.freeze()
     barrier()
     mc.timings = {}
     prof = None
@@ -614,8 +628,10 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
+    step_returned = []
     for _ in range(args.steps):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)
+        step_returned.append(time.perf_counter())
     if dens:
         dens[-1].P  # first read of a grid: waits for this step's copies and checks every grid's status
     barrier()
@@ -652,6 +668,9 @@ def main():
             "metric": "2D KDE densities/sec (triangle, %d params, %s samples)" % (args.nparams, "{:.0e}".format(args.nsamples)),
             "value": value, "unit": "densities/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_single_triangle_latency": serial_ms,
+            # host time between the returns of consecutive steps (a step returns once its last batch is enqueued, so in
+            # steady state this is the GPU's pace); the last entry is the wait for the final step's grids
+            "ms_between_step_returns": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_returned, step_returned + [t0 + elapsed])],
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded block recipe, SURVEY.md 8d C3)",
             "config": {"workload": "C3: 2D KDE triangle, %d params (%d pairs), N=%d unit-weight samples, base fine_bins_2D=256, "
@@ -674,7 +693,7 @@ def main():
         if world == 1 and not args.emulate_world:
             line["roofline"] = binning_kernel_roofline(mc, pairs_all)
             if not args.no_cpu_baseline:
-                order = {pr: k for k, pr in enumerate(_REPLAY["last_pairs"])}
+                order = {tuple(pr): k for k, pr in enumerate(np.asarray(_REPLAY["last_pairs"]).tolist())}
                 try:
                     cpu, parity = cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all,
                                                           [dens[order[pr]] for pr in pairs_all])

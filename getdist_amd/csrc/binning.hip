@@ -787,8 +787,8 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     k_p16_reduce<<<dim3((unsigned)((nwords + 255) / 256), nstripes, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
-    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hf.data(), d_flags, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     std::vector<int> flagged;
     for (int b = 0; b < B; ++b)
         if (hf[b]) flagged.push_back(b);
@@ -844,7 +844,7 @@ static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, 
                                                             d_hist);
     }
     GD_KERNEL_CHECK();
-    GD_HIP(hipStreamSynchronize(ctx->stream));  // hp / d_pairs lifetime
+    GD_TRY(gd_stream_sync(ctx));  // hp / d_pairs lifetime
     return GD_OK;
 }
 
@@ -887,8 +887,8 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
     GD_KERNEL_CHECK();
     k_hist1d_reduce<<<dim3((F + 255) / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, F, d_out);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * F * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * F * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -908,9 +908,9 @@ int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_
         k_bin_indices<false, int32_t><<<4 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, d_idx, d_bad);
     GD_KERNEL_CHECK();
     unsigned long long bad = 0;
-    GD_HIP(hipMemcpyAsync(idx_out, d_idx, (size_t)ctx->N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, idx_out, d_idx, (size_t)ctx->N * 4));
+    GD_TRY(gd_fetch(ctx, &bad, d_bad, 8));
+    GD_TRY(gd_stream_sync(ctx));
     if (n_out_of_range) *n_out_of_range = (int64_t)bad;
     return GD_OK;
 }
@@ -946,7 +946,7 @@ int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doubl
     if (nblk < 1) nblk = 1;
     k_prebin_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F);
     GD_KERNEL_CHECK();
-    GD_HIP(hipStreamSynchronize(ctx->stream));  // hc / d_c lifetime
+    GD_TRY(gd_stream_sync(ctx));  // hc / d_c lifetime
     return GD_OK;
 }
 
@@ -992,8 +992,8 @@ static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     }
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
-    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hf.data(), d_flags, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     flagged.clear();
     for (int b = 0; b < B; ++b)
         if (hf[b]) flagged.push_back(b);
@@ -1040,8 +1040,8 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             k_p16_reduce<<<dim3((unsigned)((nwords + 255) / 256), nstripes, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, (double*)d_hist);
             GD_KERNEL_CHECK();
             std::vector<int> hf((size_t)B);
-            GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-            GD_HIP(hipStreamSynchronize(ctx->stream));
+            GD_TRY(gd_fetch(ctx, hf.data(), d_flags, (size_t)B * 4));
+            GD_TRY(gd_stream_sync(ctx));
             std::vector<int> flagged;
             for (int b = 0; b < B; ++b)
                 if (hf[b]) flagged.push_back(b);
@@ -1115,8 +1115,8 @@ int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doub
     k_prebin8_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F, d_bad);
     GD_KERNEL_CHECK();
     std::vector<unsigned long long> hb((size_t)ncols);
-    GD_HIP(hipMemcpyAsync(hb.data(), d_bad, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hb.data(), d_bad, (size_t)ncols * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)hb[c];
     return GD_OK;
 }
@@ -1144,8 +1144,8 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
     k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
     GD_KERNEL_CHECK();
     std::vector<int> hf((size_t)B);
-    GD_HIP(hipMemcpyAsync(hf.data(), d_flags, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hf.data(), d_flags, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     int rc = GD_OK;
     for (int b = 0; b < B && rc == GD_OK; ++b)
         if (hf[b]) rc = gd_fail(ctx, GD_ERR_SOLVER, "16-bit bin counter wrapped in pair %d: redo with gd_hist2d_prebinned", b);
@@ -1238,8 +1238,8 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
                                                                         (double*)(base + o_part));
         GD_KERNEL_CHECK();
         std::vector<double> h((size_t)part_doubles);
-        GD_HIP(hipMemcpyAsync(h.data(), base + o_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_fetch(ctx, h.data(), base + o_part, h.size() * 8));
+        GD_TRY(gd_stream_sync(ctx));
         for (int g = 0; g < ng; ++g)
             for (int p = 0; p < groups[g].npairs; ++p) {
                 double mn = INFINITY, mx = -INFINITY;
@@ -1264,8 +1264,8 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
     k_minmax_affine<<<dim3(nblk, B), 256, 0, ctx->stream>>>(d_pairs, ctx->N, d_part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)B * nblk * 2);
-    GD_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), d_part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int q = 0; q < B; ++q) {
         double mn = INFINITY, mx = -INFINITY;
         for (int k = 0; k < nblk; ++k) {

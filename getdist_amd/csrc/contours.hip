@@ -167,9 +167,9 @@ int gd_contour_levels(gd_ctx* ctx, int32_t B, int32_t F, const void* d_P, const 
     k_contour_levels<<<B, 1024, 0, ctx->stream>>>((const double*)d_P, F, (const double*)(base + o_c), nc,
                                                   (double*)(base + o_out), (int*)(base + o_st));
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, base + o_out, (size_t)B * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(status_out, base + o_st, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, base + o_out, (size_t)B * nc * 8));
+    GD_TRY(gd_fetch(ctx, status_out, base + o_st, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 

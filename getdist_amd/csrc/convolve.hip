@@ -107,8 +107,8 @@ int gd_circ_convolve(gd_ctx* ctx, int32_t n0, int32_t n1, const double* a, const
     k_cmul_scale<<<(unsigned)((nc + 255) / 256 > 4096 ? 4096 : (nc + 255) / 256), 256, 0, ctx->stream>>>(za, zb, nc, 1.0 / (double)nr);
     GD_KERNEL_CHECK();
     if ((rc = gd_fft_c2r_2d(ctx, n0, n1, 1, za, d_a))) return rc;
-    GD_HIP(hipMemcpyAsync(out, d_a, (size_t)nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_a, (size_t)nr * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -123,8 +123,8 @@ int gd_convolve1d_direct(gd_ctx* ctx, const double* x, int64_t nx, const double*
     GD_HIP(hipMemcpyAsync(d_y, y, (size_t)ny * 8, hipMemcpyHostToDevice, ctx->stream));
     k_conv1d_direct<<<(unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256), 256, 0, ctx->stream>>>(d_x, nx, d_y, ny, d_o);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out_full, d_o, (size_t)nout * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out_full, d_o, (size_t)nout * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -160,8 +160,8 @@ int gd_autoconvolve(gd_ctx* ctx, int32_t col, double mean, int32_t use_weights, 
     k_autoconv_out<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, ctx->stream>>>(frame, n, (double)s, N, normalize,
                                                                                                       d_out);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)n * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -177,8 +177,8 @@ int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8) {
     k_like_pass1<<<nblk, 256, 0, ctx->stream>>>(L, ctx->w, ctx->N, d_part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)nblk * 5);
-    GD_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), d_part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     double mn = INFINITY, mx = -INFINITY, sw = 0, swl = 0, swl2 = 0;
     for (int b = 0; b < nblk; ++b) {
         mn = fmin(mn, h[(size_t)b * 5]), mx = fmax(mx, h[(size_t)b * 5 + 1]);
@@ -189,9 +189,9 @@ int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8) {
     k_like_pass2<<<nblk, 256, 0, ctx->stream>>>(L, ctx->w, ctx->N, mn, d_part, d_first);
     GD_KERNEL_CHECK();
     unsigned long long first = 0;
-    GD_HIP(hipMemcpyAsync(h.data(), d_part, (size_t)nblk * 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(&first, d_first, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), d_part, (size_t)nblk * 2 * 8));
+    GD_TRY(gd_fetch(ctx, &first, d_first, 8));
+    GD_TRY(gd_stream_sync(ctx));
     double sp = 0, sm = 0;
     for (int b = 0; b < nblk; ++b) sp += h[(size_t)b * 2], sm += h[(size_t)b * 2 + 1];
     out8[0] = mn, out8[1] = mx, out8[2] = sw, out8[3] = swl, out8[4] = swl2, out8[5] = sp, out8[6] = sm, out8[7] = (double)first;

@@ -9,8 +9,75 @@ int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        ctx->err = buf;
+        ctx->fetch_pending.clear();  // their destinations may be locals of the entry point that is failing
+        ctx->fetch_off = 0;
+    }
     return code;
+}
+
+__global__ void k_fetch_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+__global__ void k_fetch_copy4(const unsigned int* __restrict__ src, unsigned int* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+__global__ void k_fetch_copy1(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+
+static int fetch_kernel(gd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return GD_OK;
+    const uintptr_t a = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    if ((a & 15) == 0) {
+        const size_t n = bytes / 16;
+        k_fetch_copy16<<<(unsigned)std::min<size_t>((n + 255) / 256, 1024), 256, 0, ctx->stream>>>((const uint4*)src, (uint4*)dst, n);
+    } else if ((a & 3) == 0) {
+        const size_t n = bytes / 4;
+        k_fetch_copy4<<<(unsigned)std::min<size_t>((n + 255) / 256, 1024), 256, 0, ctx->stream>>>((const unsigned int*)src,
+                                                                                             (unsigned int*)dst, n);
+    } else {
+        k_fetch_copy1<<<(unsigned)std::min<size_t>((bytes + 255) / 256, 1024), 256, 0, ctx->stream>>>((const unsigned char*)src,
+                                                                                                (unsigned char*)dst, bytes);
+    }
+    GD_KERNEL_CHECK();
+    return GD_OK;
+}
+
+int gd_fetch(gd_ctx* ctx, void* host_dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return GD_OK;
+    if (!ctx->fetch_block) GD_HIP(hipHostMalloc(&ctx->fetch_block, gd_ctx::kFetchBytes, hipHostMallocDefault));
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (bytes > gd_ctx::kFetchMax || ctx->fetch_off + need > gd_ctx::kFetchBytes) {
+        GD_HIP(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, (ctx->stream)));
+        return GD_OK;
+    }
+    const size_t off = ctx->fetch_off;
+    ctx->fetch_off += need;
+    const int rc = fetch_kernel(ctx, (char*)ctx->fetch_block + off, d_src, bytes);
+    if (rc) return rc;
+    ctx->fetch_pending.push_back({host_dst, off, bytes});
+    return GD_OK;
+}
+
+int gd_fetch_pinned(gd_ctx* ctx, void* pinned_dst, const void* d_src, size_t bytes) {
+    if (bytes > gd_ctx::kFetchMax) {
+        GD_HIP(hipMemcpyAsync(pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, (ctx->stream)));
+        return GD_OK;
+    }
+    return fetch_kernel(ctx, pinned_dst, d_src, bytes);
+}
+
+int gd_stream_sync(gd_ctx* ctx) {
+    GD_HIP(hipStreamSynchronize((ctx->stream)));
+    for (const gd_ctx::Fetch& f : ctx->fetch_pending) memcpy(f.dst, (const char*)ctx->fetch_block + f.off, f.bytes);
+    ctx->fetch_pending.clear();
+    ctx->fetch_off = 0;
+    return GD_OK;
 }
 
 int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
@@ -143,7 +210,7 @@ int gd_device_info(gd_ctx* ctx, int64_t* info) {
 
 int gd_sync(gd_ctx* ctx) {
     GD_REQUIRE(ctx, "null context");
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -158,7 +225,7 @@ int gd_dev_alloc(gd_ctx* ctx, int64_t bytes, void** d_out) {
 int gd_dev_free(gd_ctx* ctx, void* d_ptr) {
     GD_REQUIRE(ctx, "null context");
     if (d_ptr) {
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_stream_sync(ctx));
         GD_HIP(hipFree(d_ptr));
     }
     return GD_OK;
@@ -167,14 +234,14 @@ int gd_dev_free(gd_ctx* ctx, void* d_ptr) {
 int gd_memcpy_h2d(gd_ctx* ctx, void* d_dst, const void* src, int64_t bytes) {
     GD_REQUIRE(ctx && d_dst && src && bytes >= 0, "bad argument");
     GD_HIP(hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
 int gd_memcpy_d2h(gd_ctx* ctx, void* dst, const void* d_src, int64_t bytes) {
     GD_REQUIRE(ctx && dst && d_src && bytes >= 0, "bad argument");
-    GD_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, dst, d_src, (size_t)bytes));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -229,7 +296,7 @@ int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out) {
 int gd_host_free(gd_ctx* ctx, void* ptr) {
     GD_REQUIRE(ctx, "null context");
     if (ptr) {
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_stream_sync(ctx));
         GD_HIP(hipHostFree(ptr));
     }
     return GD_OK;
@@ -347,7 +414,7 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
             dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((n + 31) / 32)), block(32, 8);
             transpose_rows_to_cols<<<grid, block, 0, ctx->stream>>>(stage, nr, n, row_stride, cols + r0, ld);
             GD_KERNEL_CHECK();
-            GD_HIP(hipStreamSynchronize(ctx->stream));
+            GD_TRY(gd_stream_sync(ctx));
         }
     }
     *integral_out = false;
@@ -361,9 +428,9 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
         GD_KERNEL_CHECK();
         int bad = 1;
         double sum = 0;
-        GD_HIP(hipMemcpyAsync(&bad, chk, 4, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipMemcpyAsync(&sum, chk + 128, 8, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_fetch(ctx, &bad, chk, 4));
+        GD_TRY(gd_fetch(ctx, &sum, chk + 128, 8));
+        GD_TRY(gd_stream_sync(ctx));
         *integral_out = ((bad & 1) == 0) && sum < 4.0e9;
         if (*integral_out && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
             GD_HIP(hipMalloc((void**)&w8, (size_t)ld));
@@ -372,7 +439,7 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
             GD_KERNEL_CHECK();
         }
     }
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -380,7 +447,7 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
               const double* weights) {
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
     GD_HIP(hipSetDevice(ctx->device));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);
@@ -476,8 +543,8 @@ int gd_like_weights(gd_ctx* ctx, const double* loglikes, int32_t mode, double me
     k_like_weights<<<nblk, 256, 0, ctx->stream>>>(ctx->w, stage, ctx->N, mode, mean_loglike, ctx->like_w, d_part);
     GD_KERNEL_CHECK();
     std::vector<double> part((size_t)nblk);
-    GD_HIP(hipMemcpyAsync(part.data(), d_part, (size_t)nblk * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, part.data(), d_part, (size_t)nblk * 8));
+    GD_TRY(gd_stream_sync(ctx));
     if (sum_out) {
         double tot = 0;
         for (double v : part) tot += v;
@@ -515,7 +582,7 @@ int gd_set_extra_column(gd_ctx* ctx, int32_t slot, const double* x) {
     GD_REQUIRE(slot >= 0 && slot < GD_EXTRA_COLS, "extra column slot out of range");
     GD_HIP(hipMemcpyAsync(ctx->cols + (ctx->n + slot) * ctx->ld, x, (size_t)(ctx->N * 8), hipMemcpyHostToDevice,
                           ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -528,7 +595,7 @@ int gd_aux_weights(gd_ctx* ctx, const double* w) {
         GD_HIP(hipMemsetAsync(ctx->like_w, 0, (size_t)(ctx->ld * 8), ctx->stream));
     }
     GD_HIP(hipMemcpyAsync(ctx->like_w, w, (size_t)(ctx->N * 8), hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -544,7 +611,7 @@ int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner) {
     GD_REQUIRE(ctx->device == owner->device, "contexts must live on the same device");
     GD_REQUIRE(owner->w_sel == 0, "owner has auxiliary weights selected");
     GD_HIP(hipSetDevice(ctx->device));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     GD_HIP(hipStreamSynchronize(owner->stream));
     if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main, ctx->w_sel = 0;
     if (!ctx->borrowed) {

@@ -63,6 +63,15 @@ struct gd_ctx {
     static constexpr int kStageSlots = 32;
     StageSlot stage[kStageSlots];
     int stage_next = 0;
+    // page-locked bounce block for small results (gd_fetch / gd_stream_sync)
+    struct Fetch {
+        void* dst;
+        size_t off, bytes;
+    };
+    static constexpr size_t kFetchBytes = 4u << 20, kFetchMax = 1u << 20;
+    void* fetch_block = nullptr;
+    size_t fetch_off = 0;
+    std::vector<Fetch> fetch_pending;
 };
 
 // Stream-ordered H2D copy of a small host table whose storage the caller may release as soon as this returns.
@@ -74,6 +83,16 @@ int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int gd_fft_r2c_2d(gd_ctx* ctx, int n0, int n1, int batch, const double* d_in, double2* d_out);
 int gd_fft_c2r_2d(gd_ctx* ctx, int n0, int n1, int batch, double2* d_in, double* d_out);
 void gd_fft_cache_destroy(gd_ctx* ctx);
+
+// Small results come back through a page-locked bounce block that a copy KERNEL fills: a pageable destination turns
+// hipMemcpyAsync into a blocking staged copy per call, and any DMA copy queues behind the 100-MB result copies of the
+// previous batched call on the copy engines (measured: 0.1-2 ms per small copy while those are in flight).  gd_fetch
+// enqueues the copy on ctx->stream; gd_stream_sync waits for the stream and delivers every pending fetch to its
+// destination.  Results above kFetchMax (or when the block is full) take the DMA path.  gd_fetch_pinned writes straight
+// into a page-locked destination (no delivery step: for entry points that return before their kernels have run).
+int gd_fetch(gd_ctx* ctx, void* host_dst, const void* d_src, size_t bytes);
+int gd_fetch_pinned(gd_ctx* ctx, void* pinned_dst, const void* d_src, size_t bytes);
+int gd_stream_sync(gd_ctx* ctx);
 
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure
@@ -88,6 +107,12 @@ void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
     } while (0)
 
 #define GD_KERNEL_CHECK() GD_HIP(hipGetLastError())
+
+#define GD_TRY(call)              \
+    do {                          \
+        const int rc__ = (call);  \
+        if (rc__) return rc__;    \
+    } while (0)
 
 #define GD_REQUIRE(cond, msg)                                   \
     do {                                                        \

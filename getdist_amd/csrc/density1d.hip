@@ -425,8 +425,8 @@ int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_ou
     GD_KERNEL_CHECK();
     k_dct1d<<<dim3((F + 255) / 256, B), 256, (size_t)F * 8, ctx->stream>>>(d_in, F, d_tab, d_out);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(a_out, d_out, (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, a_out, d_out, (size_t)nb));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -470,8 +470,8 @@ int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double
     k_isj1d<<<B, 256, (size_t)2 * F * 8, ctx->stream>>>(d_a, F, d_neff, d_nscale, C, d_out);
     GD_KERNEL_CHECK();
     std::vector<double> res((size_t)2 * B);
-    GD_HIP(hipMemcpyAsync(res.data(), d_out, (size_t)B * 16, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, res.data(), d_out, (size_t)B * 16));
+    GD_TRY(gd_stream_sync(ctx));
     for (int b = 0; b < B; ++b) {
         hfrac_out[b] = res[2 * b];
         status_out[b] = (int32_t)res[2 * b + 1];
@@ -507,9 +507,9 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
     GD_HIP(hipFuncSetAttribute((const void*)k_density1d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
     k_density1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_smooth, d_winw, d_flags, A, d_P, d_status);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(P_out, d_P, (size_t)B * F * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, P_out, d_P, (size_t)B * F * 8));
+    GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -540,9 +540,9 @@ int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const doub
     k_likes1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_lh, d_P, d_smooth, d_winw, d_flags, F, shade_mean_loglikes, d_out,
                                             d_status);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(likes_out, d_out, (size_t)B * F * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, likes_out, d_out, (size_t)B * F * 8));
+    GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 

@@ -695,8 +695,12 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
     GD_KERNEL_CHECK();
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, d_mx, (int)FF, d_status);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (wait) GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait) {
+        GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
+        GD_TRY(gd_stream_sync(ctx));
+    } else {
+        GD_TRY(gd_fetch_pinned(ctx, status_out, d_status, (size_t)B * 4));  // page-locked by the entry point's contract
+    }
     return GD_OK;
 }
 
@@ -894,8 +898,12 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_P, mx_cur, (int)FF, d_status);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (wait) GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait) {
+        GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
+        GD_TRY(gd_stream_sync(ctx));
+    } else {
+        GD_TRY(gd_fetch_pinned(ctx, status_out, d_status, (size_t)B * 4));  // page-locked by the entry point's contract
+    }
 #undef FWD
 #undef CONV_TO
     return GD_OK;
@@ -1021,8 +1029,8 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
     GD_KERNEL_CHECK();
     k_normalise<<<gF, 256, 0, ctx->stream>>>(d_L, d_mx, (int)FF, d_status);  // bin2Dlikes /= max (:2005)
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(status_out, d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 

@@ -623,8 +623,8 @@ int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, cons
     k_get_h<<<B, 64, 0, ctx->stream>>>((double*)(base + o_k), (const double*)(base + o_n), (const double*)(base + o_c),
                                       (const int*)(base + o_d), B);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(hk.data(), base + o_k, hk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hk.data(), base + o_k, hk.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int b = 0; b < B; ++b)
         for (int q = 0; q < 4; ++q) out[(size_t)b * 4 + q] = hk[(size_t)b * KOPT_STRIDE + 8 + q];
     return GD_OK;
@@ -718,7 +718,7 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
 #ifdef KOPT_PROFILE
     {
         long long hp[8];
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_stream_sync(ctx));
         GD_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp)));
         fprintf(stderr, "kopt block 0 cycles (100 MHz clock): weights %lld  tile-load %lld  tile-fma %lld  reduce %lld  "
                         "entry-barrier %lld  times/pow %lld | levels %lld  mean kmax %.1f\n",
@@ -734,8 +734,8 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
     k_get_h<<<B, 64, 0, ctx->stream>>>(d_out, (const double*)(base + o_neff), (const double*)(base + o_corr),
                                       (const int*)(base + o_dc), B);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)B * KOPT_STRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)B * KOPT_STRIDE * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 

@@ -257,9 +257,9 @@ int gd_limits1d(gd_ctx* ctx, int32_t B, int32_t F, const double* P, const double
                                                            (const double*)(base + o_s), (const double*)(base + o_c), A,
                                                            (double*)(base + o_G), (double*)(base + o_out), (int*)(base + o_st));
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, base + o_out, (size_t)B * nc * 32, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(status_out, base + o_st, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, base + o_out, (size_t)B * nc * 32));
+    GD_TRY(gd_fetch(ctx, status_out, base + o_st, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 

@@ -1231,8 +1231,8 @@ int gd_kde_lag_sums_2d(gd_ctx* ctx, int32_t coli, int32_t colj, const double* ki
         k_kde_lag_2d<false><<<grid, 256, 0, ctx->stream>>>(x, y, nullptr, ctx->N, kinv3[0], kinv3[1], kinv3[2], d_lags, part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)nlags * nblk);
-    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int l = 0; l < nlags; ++l) {
         double sum = 0;
         for (int b = 0; b < nblk; ++b) sum += h[(size_t)l * nblk + b];
@@ -1255,8 +1255,8 @@ int gd_weight_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double thresh, double* 
     k_weight_stats<<<nblk, 256, 0, ctx->stream>>>(ctx->w, lo, hi, thresh, part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)nblk * 4);
-    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     double s = 0, mx = -INFINITY, s2 = 0, cnt = 0;
     for (int i = 0; i < nblk; ++i) {
         s += h[i * 4], s2 += h[i * 4 + 2], cnt += h[i * 4 + 3];
@@ -1303,8 +1303,8 @@ int gd_col_stats(gd_ctx* ctx, int64_t lo, int64_t hi, double* out) {
     double* d_out = d_res + (int64_t)n * 4;
     int rc = col_stats_device(ctx, nullptr, n, lo, hi, d_res, d_part, d_out);
     if (rc) return rc;
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)n * 4 * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -1329,8 +1329,8 @@ int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, i
         k_col_minmax<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, 0.0, lo, hi, d_part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)ncols * nblk * 2);
-    GD_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), d_part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int c = 0; c < ncols; ++c) {
         double mn = INFINITY, mx = -INFINITY;
         for (int b = 0; b < nblk; ++b) {
@@ -1468,9 +1468,9 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     GD_KERNEL_CHECK();
     }
     std::vector<double> hres((size_t)m * 4);
-    GD_HIP(hipMemcpyAsync(hres.data(), d_res, hres.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(cov_out, d_cov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, hres.data(), d_res, hres.size() * 8));
+    GD_TRY(gd_fetch(ctx, cov_out, d_cov, (size_t)m * m * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int i = 0; i < m; ++i) means_out[i] = hres[(size_t)i * 4 + 3];
     if (minmax_out)
         for (int i = 0; i < m; ++i) minmax_out[2 * i] = hres[(size_t)i * 4], minmax_out[2 * i + 1] = hres[(size_t)i * 4 + 1];
@@ -1557,9 +1557,9 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
     GD_KERNEL_CHECK();
     int overflow = 0;
-    GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, &overflow, d_cnt + (int64_t)ncols * QK_MAX, 4));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * k * 8));
+    GD_TRY(gd_stream_sync(ctx));
     *overflowed = overflow;
     return GD_OK;
 }
@@ -1657,16 +1657,16 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX);
     GD_KERNEL_CHECK();
     int overflow = 0;
-    GD_HIP(hipMemcpyAsync(&overflow, d_cnt + (int64_t)ncols * QK_MAX, 4, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, &overflow, d_cnt + (int64_t)ncols * QK_MAX, 4));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * k * 8));
+    GD_TRY(gd_stream_sync(ctx));
     if (!overflow) return GD_OK;
     for (int pass = P; pass < 8; ++pass)  // heavily tied data: finish with the plain radix passes
         if ((rc = radix_pass(pass))) return rc;
     k_qsel_out<<<(ncols * k + 255) / 256, 256, 0, ctx->stream>>>(d_st, ncols, k, d_out);
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(out, d_out, (size_t)ncols * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * k * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -1720,8 +1720,8 @@ int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols,
         GD_KERNEL_CHECK();
         k_sum_partials_batched<<<dim3(NL, ncols), 256, 0, ctx->stream>>>(part, nblk, NL, d_out);
         GD_KERNEL_CHECK();
-        GD_HIP(hipMemcpyAsync(h.data(), d_out, (size_t)ncols * NL * 8, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_fetch(ctx, h.data(), d_out, (size_t)ncols * NL * 8));
+        GD_TRY(gd_stream_sync(ctx));
         const int take_n = (nlags - done < NL) ? nlags - done : NL;
         for (int c = 0; c < ncols; ++c)
             for (int l = 0; l < take_n; ++l) out[(size_t)c * nlags + done + l] = h[(size_t)c * NL + l];
@@ -1778,8 +1778,8 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
 #undef KDE_LAUNCH
         GD_KERNEL_CHECK();
         std::vector<double> h((size_t)ncols * nblk * KDE_LAG_MAX);
-        GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        GD_HIP(hipStreamSynchronize(ctx->stream));
+        GD_TRY(gd_fetch(ctx, h.data(), part, h.size() * 8));
+        GD_TRY(gd_stream_sync(ctx));
         for (int c = 0; c < ncols; ++c)
             for (int l = 0; l < nlags; ++l) {
                 double sum = 0;
@@ -1795,8 +1795,8 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
         k_kde_lag<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, ctx->N, d_c, d_lags, part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)ncols * nlags * nblk);
-    GD_HIP(hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), part, h.size() * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (size_t q = 0; q < (size_t)ncols * nlags; ++q) {
         double sum = 0;
         for (int b = 0; b < nblk; ++b) sum += h[q * nblk + b];

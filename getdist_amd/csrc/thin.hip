@@ -203,10 +203,10 @@ int gd_thin_rows(gd_ctx* ctx, int64_t lo, int64_t hi, int64_t factor, int32_t un
     int rc = ensure_weight_cumsum(ctx);
     if (rc) return rc;
     long long ends[3] = {0, 0, 0};  // C[lo-1], C[lo], C[hi-1]
-    if (lo > 0) GD_HIP(hipMemcpyAsync(&ends[0], ctx->wcum + lo - 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(&ends[1], ctx->wcum + lo, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipMemcpyAsync(&ends[2], ctx->wcum + hi - 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    if (lo > 0) GD_TRY(gd_fetch(ctx, &ends[0], ctx->wcum + lo - 1, 8));
+    GD_TRY(gd_fetch(ctx, &ends[1], ctx->wcum + lo, 8));
+    GD_TRY(gd_fetch(ctx, &ends[2], ctx->wcum + hi - 1, 8));
+    GD_TRY(gd_stream_sync(ctx));
     const long long vlast = (ends[2] - ends[0]) / factor, v0 = (ends[1] - ends[0]) / factor;
     const int64_t K = unique_mode ? 1 + vlast - v0 : vlast;
     *count_out = K;
@@ -214,7 +214,7 @@ int gd_thin_rows(gd_ctx* ctx, int64_t lo, int64_t hi, int64_t factor, int32_t un
     if (K == 0) return GD_OK;
     k_thin_rows<<<2048, 256, 0, ctx->stream>>>(ctx->wcum, lo, hi, factor, unique_mode, (int32_t*)d_rows);
     GD_KERNEL_CHECK();
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -245,8 +245,8 @@ int gd_binary_transitions(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
                                                                     (const int32_t*)d_rows, K, (const double*)(base + o_thr),
                                                                     nthr, (unsigned long long*)(base + o_cnt));
     GD_KERNEL_CHECK();
-    GD_HIP(hipMemcpyAsync(counts_out, base + o_cnt, (size_t)nc * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, counts_out, base + o_cnt, (size_t)nc * 8));
+    GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
 }
 
@@ -274,8 +274,8 @@ int gd_thinned_lag_sums(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const d
                                                                      (double*)(base + o_part));
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)np);
-    GD_HIP(hipMemcpyAsync(h.data(), base + o_part, (size_t)np * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GD_HIP(hipStreamSynchronize(ctx->stream));
+    GD_TRY(gd_fetch(ctx, h.data(), base + o_part, (size_t)np * 8));
+    GD_TRY(gd_stream_sync(ctx));
     for (int64_t e = 0; e < (int64_t)ncols * maxoff; ++e) {
         double s = 0;
         for (int b = 0; b < nblk; ++b) s += h[(size_t)(e * nblk + b)];

@@ -333,6 +333,14 @@ class _PendingResults:
             pass
 
 
+class _Plan(list):
+    """The per-pair bandwidth records (dicts) of _bandwidth_plan plus the same fields as arrays over the pairs
+    (``arr``: branch code 0/1/2 = A/B/C, has_limits, corr, rangex, rangey and -- once the effective sample numbers are
+    known -- neff, fallback_t): what sits between two kernels of a batched call is evaluated on the arrays."""
+
+    arr = None
+
+
 class _FastThreadSwitch:
     """While a helper thread drives a second stream, a thread returning from a C call would wait for the GIL up to the
     interpreter's switch interval (5 ms by default) whenever the other thread is in Python scalar code -- longer than
@@ -1893,7 +1901,7 @@ class MCSamples:
         js = list(range(self.n)) if params is None else [self._col(p) for p in params]
         todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
         if (todo and self._lane == 0 and not self._timing and self.sampler not in ("nested", "uncorrelated")
-                and len(todo) >= 8 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
+                and len(todo) >= 2 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
             # the autocovariance probe of the N_eff estimate depends on the means only: start it on the second context
             # (own stream) while this one runs the quantile select
             twin = self._second_lane()
@@ -1909,6 +1917,24 @@ class MCSamples:
                 self._neff_batch(js)
             _hostlog("prep: N_eff done")
         return js
+
+    def _bin_edge_arrays(self, js, borderfrac=0.1):
+        """binmin, binmax of _bin_edges for the parameters ``js``, as arrays indexed by parameter number (the same
+        fp64 operations, element by element)."""
+        names = self.paramNames.names
+        n = max(js) + 1
+        rmin, rmax, pmin, pmax = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+        lim_b, lim_t = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)
+        for j in js:
+            p = names[j]
+            rmin[j], rmax[j], pmin[j], pmax[j] = p.range_min, p.range_max, p.param_min, p.param_max
+            lim_b[j], lim_t[j] = bool(p.has_limits_bot), bool(p.has_limits_top)
+        border = (rmax - rmin) * borderfrac
+        binmin = np.minimum(pmin, rmin)
+        binmin = np.where(lim_b, binmin, binmin - border)
+        binmax = np.maximum(pmax, rmax)
+        binmax = np.where(lim_t, binmax, binmax + border)
+        return binmin, binmax
 
     @staticmethod
     def _bin_edges(par, num_fine_bins, borderfrac=0.1):
@@ -2167,7 +2193,7 @@ class MCSamples:
         d.from_host(bins)
         plan = self._bandwidth_plan([(paramx, paramy)], [corr], [(rangex, rangey)], base_fine_bins_2D, N_eff=N_eff)
         res = self._bandwidth_2d(plan, {F: (d, [0])}, [F], base_fine_bins_2D, mult_bias_correction_order)
-        return res[0]
+        return tuple(res[0].tolist())
 
     def _bandwidth_plan(self, pairs, corrs, ranges_xy, base_F, min_corr=0.2, N_eff=None, defer_neff=False):
         """Branch selection per pair (mcsamples.py:1325-1409), scalars only.  The classification is evaluated on arrays
@@ -2177,7 +2203,7 @@ class MCSamples:
         names = self.paramNames.names
         npairs = len(pairs)
         if npairs == 0:
-            return ([], lambda: None) if defer_neff else []
+            return (_Plan(), lambda: None) if defer_neff else _Plan()
         if N_eff is None and not defer_neff:
             self._neff_batch(list(dict.fromkeys([j for p in pairs for j in p])))
         jx = [p[0] for p in pairs]
@@ -2211,18 +2237,23 @@ class MCSamples:
         with np.errstate(all="ignore"):
             ratio = np.minimum(sig_u[iy] / rng[:, 1], sig_u[ix] / rng[:, 0]).tolist()
         branch = np.where(is_A, "A", np.where(is_B, "B", "C")).tolist()
-        plan = [dict(jx=a, jy=b, parx=names[a], pary=names[b], corr=c, neff=None, has_limits=hl, rangex=rx_, rangey=ry_,
-                     branch=br)
-                for a, b, c, hl, rx_, ry_, br in zip(jx, jy, corr_v.tolist(), has_limits.tolist(),
-                                                     rng[:, 0].tolist(), rng[:, 1].tolist(), branch)]
+        plan = _Plan(dict(jx=a, jy=b, parx=names[a], pary=names[b], corr=c, neff=None, has_limits=hl, rangex=rx_, rangey=ry_,
+                          branch=br)
+                     for a, b, c, hl, rx_, ry_, br in zip(jx, jy, corr_v.tolist(), has_limits.tolist(),
+                                                          rng[:, 0].tolist(), rng[:, 1].tolist(), branch))
+        plan.arr = dict(branch=np.where(is_A, 0, np.where(is_B, 1, 2)).astype(np.int8), has_limits=has_limits, corr=corr_v,
+                        rangex=rng[:, 0].copy(), rangey=rng[:, 1].copy(), neff=None, fallback_t=None)
         is_C = np.nonzero(~is_A & ~is_B)[0].tolist()
 
         def fill():
-            neff_l = effective_samples().tolist()
+            neff_v = effective_samples()
+            neff_l = neff_v.tolist()
             for e, ne in zip(plan, neff_l):
                 e["neff"] = ne
+            fb = np.full(npairs, np.nan)
             for k in is_C:
-                plan[k]["fallback_t"] = (ratio[k] / neff_l[k] ** (1.0 / 6)) ** 2
+                fb[k] = plan[k]["fallback_t"] = (ratio[k] / neff_l[k] ** (1.0 / 6)) ** 2
+            plan.arr["neff"], plan.arr["fallback_t"] = neff_v, fb
 
         if not defer_neff:
             fill()
@@ -2289,53 +2320,55 @@ class MCSamples:
                                    base_F)
         return dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
 
-    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order, shear=None):
+    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order, shear=None, deferred=None):
         """
         getAutoBandwidth2D for a batch (mcsamples.py:1325-1419).  ``hists_by_F``: F -> (device buffer of that class's
         histograms, list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.  Returns the
-        list of (hx, hy, corr) in parameter units.  The whole KernelOptimizer2D -- fixed point, functionals, get_h with
-        its TNC minimisations -- runs on the device (gd_kopt2d); here only branch bookkeeping and unit conversions.
+        (hx, hy, corr) triples in parameter units as an (npair, 3) array.  The whole KernelOptimizer2D -- fixed point,
+        functionals, get_h with its TNC minimisations -- runs on the device (gd_kopt2d); here only branch bookkeeping and
+        unit conversions, on arrays over the pairs: this code sits between the optimiser's kernels and the convolution's.
+        The per-pair records (``plan[k]["kopt"]``) are written by a callable appended to ``deferred`` (the caller runs it
+        once the next kernels are enqueued), or at once when ``deferred`` is None.
         """
-        results = [None] * len(plan)
+        npair = len(plan)
         ctx = self.ctx
-        for e in plan:
-            e["kopt"] = None
+        arr = plan.arr
+        W = np.full((npair, 3), np.nan)
+        kopt_rows = []  # (plan indices, optimiser output rows) per launch
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
+        branch = arr["branch"]
 
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
-        A = [k for k, e in enumerate(plan) if e["branch"] == "A"]
+        A = np.nonzero(branch == 0)[0]
         if shear is None:
             shear = self._shear_histograms(plan, base_F)
         # -- branch B: rule of thumb
-        for k, e in enumerate(plan):
-            if e["branch"] == "B":
-                c = max(min(e["corr"], self.max_corr_2D), -self.max_corr_2D)
-                results[k] = (e["parx"].sigma_range / e["neff"] ** (1.0 / 6), e["pary"].sigma_range / e["neff"] ** (1.0 / 6), c)
+        for k in np.nonzero(branch == 1)[0].tolist():
+            e = plan[k]
+            c = max(min(e["corr"], self.max_corr_2D), -self.max_corr_2D)
+            W[k] = (e["parx"].sigma_range / e["neff"] ** (1.0 / 6), e["pary"].sigma_range / e["neff"] ** (1.0 / 6), c)
 
-        def optimise(F, d_batch, rows):
-            """One device-optimiser launch; rows = [(branch, plan index, r1, r2)] in batch order."""
-            ks = [k for _, k, _, _ in rows]
-            do_corr = [0 if plan[k]["has_limits"] else 1 for k in ks]
-            fb = [-1.0 if br == "A" else plan[k]["fallback_t"] for br, k, _, _ in rows]
-            corr_in = [0.0 if br == "A" else plan[k]["corr"] for br, k, _, _ in rows]
-            out = ctx.kopt2d(d_batch, len(rows), F, [plan[k]["neff"] for k in ks], do_corr, fb, corr_in)
+        def optimise(F, d_batch, ks, row_A, r1, r2):
+            """One device-optimiser launch over plan entries ``ks`` (batch order); ``row_A`` marks the sheared rows,
+            whose sheared ranges are r1, r2."""
+            fb = np.where(row_A, -1.0, arr["fallback_t"][ks])
+            corr_in = np.where(row_A, 0.0, arr["corr"][ks])
+            out = ctx.kopt2d(d_batch, len(ks), F, arr["neff"][ks], (~arr["has_limits"][ks]).astype(np.int32), fb, corr_in)
             no_root = out[:, 7] != 0
             if np.any(~no_root & (out[:, 11] != 0)):
                 raise Exception("bias not positive definite")  # kde_bandwidth.py:229-230, raised out of get_h
             # branch C (the bulk): parameter units = the fractions times the ranges, evaluated on the whole batch
-            hx_l = (out[:, 8] * np.array([plan[k]["rangex"] for k in ks])).tolist()
-            hy_l = (out[:, 9] * np.array([plan[k]["rangey"] for k in ks])).tolist()
-            c_l = out[:, 10].tolist()
-            bad = no_root.tolist()
+            hx = out[:, 8] * arr["rangex"][ks]
+            hy = out[:, 9] * arr["rangey"][ks]
+            c = out[:, 10].copy()
             # branch A: de-rotate the sheared kernels (mcsamples.py:1379-1390), kernelC = S K S^T written out for the
             # 2x2 case and evaluated on all sheared pairs at once
-            rows_A = [row for row, (br, _, _, _) in enumerate(rows) if br == "A"]
-            if rows_A:
-                ra = np.array(rows_A)
-                hxa = out[ra, 8] * np.array([rows[r][2] for r in rows_A])
-                hya = out[ra, 9] * np.array([rows[r][3] for r in rows_A])
+            if np.any(row_A):
+                ra = np.nonzero(row_A)[0]
+                hxa = out[ra, 8] * r1
+                hya = out[ra, 9] * r2
                 ca = out[ra, 10]
-                S = np.array([plan[rows[r][1]]["S"] for r in rows_A])  # (nA, 2, 2)
+                S = np.array([plan[k]["S"] for k in ks[ra].tolist()])  # (nA, 2, 2)
                 k00, k01, k11 = hxa**2, hxa * hya * ca, hya**2
                 t00 = S[:, 0, 0] * k00 + S[:, 0, 1] * k01
                 t01 = S[:, 0, 0] * k01 + S[:, 0, 1] * k11
@@ -2345,59 +2378,66 @@ class MCSamples:
                 c01 = t00 * S[:, 1, 0] + t01 * S[:, 1, 1]
                 c11 = t10 * S[:, 1, 0] + t11 * S[:, 1, 1]
                 sx, sy = np.sqrt(c00), np.sqrt(c11)
-                cc_a = (c01 / np.sqrt(c00 * c11)).tolist()
-                swap = [bool(plan[rows[r][1]]["pary"].has_limits) for r in rows_A]
-                for pos, row in enumerate(rows_A):
-                    a_, b_ = (sy[pos], sx[pos]) if swap[pos] else (sx[pos], sy[pos])
-                    hx_l[row], hy_l[row], c_l[row] = float(a_), float(b_), cc_a[pos]
-            for row, ((br, k, r1, r2), kopt_row) in enumerate(zip(rows, out)):
-                e = plan[k]
-                e["kopt"] = kopt_row
-                if bad[row]:
-                    results[k] = self._fallback_widths(e, "2D fixed point: no root in [0, 0.1]")
-                else:
-                    results[k] = (hx_l[row], hy_l[row], c_l[row])
+                swap = np.array([bool(plan[k]["pary"].has_limits) for k in ks[ra].tolist()])
+                hx[ra], hy[ra], c[ra] = np.where(swap, sy, sx), np.where(swap, sx, sy), c01 / np.sqrt(c00 * c11)
+            W[ks, 0], W[ks, 1], W[ks, 2] = hx, hy, c
+            for row in np.nonzero(no_root)[0].tolist():
+                k = int(ks[row])
+                plan[k]["kopt"] = out[row]
+                W[k] = self._fallback_widths(plan[k], "2D fixed point: no root in [0, 0.1]")
+            kopt_rows.append((ks, out))
 
         # -- branches A and C share the device optimiser: the sheared histograms ride in the same launch as the
         #    base-grid pairs' own histograms (one block per pair; a short extra launch would cost a full block latency)
         item = base_F * base_F * 8
-        rows_A = [("A", k, shear["r1s"][row], shear["r2s"][row]) for row, k in enumerate(A)] if A else []
+        nA = len(A)
+        r1s = np.asarray(shear["r1s"], dtype=np.float64) if nA else None
+        r2s = np.asarray(shear["r2s"], dtype=np.float64) if nA else None
         merged = False
         for F, (d_hist, members) in hists_by_F.items():
-            sel = [(pos, k) for pos, k in enumerate(members) if plan[k]["branch"] == "C"]
-            rows_C = [("C", k, None, None) for _, k in sel]
-            if F == base_F and rows_A and sel:
-                d_all = ctx.alloc((len(rows_A) + len(sel)) * item)
-                ctx.gather_items(d_all, shear["d_rot"], list(range(len(rows_A))), item)
-                ctx.gather_items(d_all, d_hist, [pos for pos, _ in sel], item, dst_offset=len(rows_A))
-                optimise(F, d_all, rows_A + rows_C)
+            mem = np.asarray(members, dtype=np.int64)
+            pos_C = np.nonzero(branch[mem] == 2)[0]
+            if F == base_F and nA and len(pos_C):
+                d_all = ctx.alloc((nA + len(pos_C)) * item)
+                ctx.gather_items(d_all, shear["d_rot"], np.arange(nA, dtype=np.int32), item)
+                ctx.gather_items(d_all, d_hist, pos_C, item, dst_offset=nA)
+                optimise(F, d_all, np.concatenate([A, mem[pos_C]]), np.arange(nA + len(pos_C)) < nA, r1s, r2s)
                 d_all.free()
                 merged = True
                 continue
-            if not sel:
+            if not len(pos_C):
                 continue
-            if len(sel) == len(members):
+            if len(pos_C) == len(mem):
                 d_sub, own = d_hist, False
             else:
-                d_sub, own = ctx.alloc(len(sel) * F * F * 8), True
-                self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8)
-            optimise(F, d_sub, rows_C)
+                d_sub, own = ctx.alloc(len(pos_C) * F * F * 8), True
+                self._gather_device(d_hist, d_sub, pos_C, F * F * 8)
+            optimise(F, d_sub, mem[pos_C], np.zeros(len(pos_C), dtype=bool), None, None)
             if own:
                 d_sub.free()
-        if rows_A and not merged:
-            optimise(base_F, shear["d_rot"], rows_A)
+        if nA and not merged:
+            optimise(base_F, shear["d_rot"], A, np.ones(nA, dtype=bool), r1s, r2s)
         if shear is not None:
             shear["d_rot"].free()
-        if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416)
-            scale_of = {}  # few distinct N_eff values (one per parameter)
-            for k in range(len(plan)):
-                hx, hy, c = results[k]
-                ne = plan[k]["neff"]
-                scale = scale_of.get(ne)
-                if scale is None:
-                    scale = scale_of[ne] = 1.1 * ne ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m)))
-                results[k] = (hx * scale, hy * scale, c)
-        return results
+        if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416); few distinct N_eff values, each
+            # scale a Python-float power as before
+            uniq, inv = np.unique(arr["neff"], return_inverse=True)
+            scale = np.array([1.1 * ne ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m))) for ne in uniq.tolist()])[inv]
+            W[:, 0] *= scale
+            W[:, 1] *= scale
+
+        def book():
+            for e in plan:
+                e["kopt"] = None
+            for ks, out in kopt_rows:
+                for k, row in zip(ks.tolist(), out):
+                    plan[k]["kopt"] = row
+
+        if deferred is None:
+            book()
+        else:
+            deferred.append(book)
+        return W
 
     def _gather_device(self, d_src, d_dst, positions, item_bytes, ctx=None):
         """Copy selected fixed-size items of one device buffer into another (one gather kernel)."""
@@ -2461,7 +2501,15 @@ class MCSamples:
         for k in kwargs:
             if k not in ("fine_bins_2D", "boundary_correction_order", "mult_bias_correction_order", "smooth_scale_2D"):
                 raise SettingError("unknown 2D density argument %s" % k)
-        pairs = [(self._col(a), self._col(b)) for a, b in pairs]
+        pa = None
+        if len(pairs) > 8:
+            try:  # a triangle's worth of integer indices: one conversion instead of a name lookup per entry
+                pa = np.asarray(pairs)
+                if pa.ndim != 2 or pa.shape[1] != 2 or pa.dtype.kind != "i" or pa.min() < 0 or pa.max() >= self.n:
+                    pa = None
+            except (ValueError, TypeError):
+                pa = None
+        pairs = pa.astype(np.int64, copy=False) if pa is not None else [(self._col(a), self._col(b)) for a, b in pairs]
         lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
                 or self.use_effective_samples_2D or mask_function is not None):
@@ -2469,6 +2517,7 @@ class MCSamples:
                 return self._get2DDensities_lane(pairs, num_plot_contours, get_density, _bandwidths, meanlikes,
                                                  mask_function=mask_function, **kwargs)
         # everything per-parameter is settled here, on this lane, before the pairs are dealt
+        pairs = [(int(a), int(b)) for a, b in pairs]
         used = list(dict.fromkeys([j for p in pairs for j in p]))
         self._init_params(used)
         if float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D)) < 0:
@@ -2519,22 +2568,24 @@ class MCSamples:
             raise SettingError("unknown boundary_correction_order (expected 0 or 1)")
         ctx = self.ctx
         _hostlog("lane start")
-        used = list(dict.fromkeys([j for p in pairs for j in p]))
+        pa = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        jx, jy = np.ascontiguousarray(pa[:, 0]), np.ascontiguousarray(pa[:, 1])
+        flat = pa.ravel()
+        used = flat[np.sort(np.unique(flat, return_index=True)[1])].tolist()  # in order of first appearance
         self._init_params(used)
         names = self.paramNames.names
         # the N_eff kernels need nothing but the parameter ranges: they are started first, from the helper thread, and
         # run while the per-pair scalars below are worked out
         neff_f = None
         if (smooth_scale_2D < 0 and _bandwidths is None and not self._timing and not self.use_effective_samples_2D
-                and self._lane == 0 and not meanlikes and len(pairs) >= 64
+                and self._lane == 0 and not meanlikes and len(pa) >= 64
                 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"
                 and any(names[j].N_eff_kde is None for j in used)):
             neff_f = self._helper().submit(self._neff_batch, used)
+        _hostlog("lane: pairs indexed, N_eff submitted")
         corrmat = self.getCorrelationMatrix()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
-        jx = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
-        jy = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
         actual = np.asarray(corrmat)[jy, jx]
         corr_v = actual.copy()
         full = np.abs(np.abs(corr_v) - 1.0) <= 1e-8
@@ -2547,8 +2598,19 @@ class MCSamples:
         scaled = 192 * (3 / angle_scale).astype(np.int64) // 3
         F_v = np.where((corr_v != 0) & (base_F < scaled) & ((1 / angle_scale).astype(np.int64) > 1), scaled, base_F)
         pj, pj2, pF = jx.tolist(), jy.tolist(), [int(f) for f in F_v.tolist()]
-        edge_of = {key: self._bin_edges(names[key[0]], key[1])  # (fine width, binmin, binmax) per (parameter, F)
-                   for key in dict.fromkeys(list(zip(pj, pF)) + list(zip(pj2, pF)))}
+        _hostlog("lane: grid sizes")
+        # (fine width, binmin, binmax) per (parameter, F): _bin_edges for all parameters at once -- binmin / binmax do
+        # not depend on F -- and the table of widths per grid size
+        bmin_t, bmax_t = self._bin_edge_arrays(used)
+        F_list = list(dict.fromkeys(pF))
+        fw_t = {F: (bmax_t - bmin_t) / (F - 1) for F in F_list}
+        edge_of = {(j, F): (fw_t[F][j], bmin_t[j], bmax_t[j])
+                   for F in F_list for j in np.unique(np.concatenate([jx[F_v == F], jy[F_v == F]])).tolist()}
+        fwx_v = np.empty(len(pa))
+        fwy_v = np.empty(len(pa))
+        for F in F_list:
+            sel_F = F_v == F
+            fwx_v[sel_F], fwy_v[sel_F] = fw_t[F][jx[sel_F]], fw_t[F][jy[sel_F]]
         info = []
 
         def build_info():
@@ -2562,10 +2624,9 @@ class MCSamples:
                                      F=F, nbin2D=nbin_l[q], fwx=fwx, xbinmin=xbinmin, xbinmax=xbinmax, fwy=fwy,
                                      ybinmin=ybinmin, ybinmax=ybinmax))
 
+        _hostlog("lane: bin edges")
         # ---- histograms, one batched launch per grid-size class (pre-binned index columns)
-        classes = {}
-        for k, F in enumerate(pF):
-            classes.setdefault(F, []).append(k)
+        classes = {F: np.nonzero(F_v == F)[0].tolist() for F in F_list}
         hists, likehists = {}, {}
 
         def binning(owner=self):
@@ -2649,25 +2710,34 @@ class MCSamples:
         # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
         _hostlog("binning / N_eff / plan joined")
         npair = len(info)
-        fwx_v = np.array([e["fwx"] for e in info], dtype=np.float64)
-        fwy_v = np.array([e["fwy"] for e in info], dtype=np.float64)
+        # Bookkeeping that no kernel waits for (per-pair records, log messages) is collected here and run once the first
+        # convolution batch has been enqueued: between the optimiser's last kernel and the convolution's first one the
+        # GPU is idle, so only what decides the window sizes is evaluated there, on arrays.
+        deferred = []
         if smooth_scale_2D < 0:
             if _bandwidths is not None:
-                widths = list(_bandwidths)
+                wv = np.array(list(_bandwidths), dtype=np.float64).reshape(npair, 3)
             else:
                 if plan is None:
                     with _Phase(self, "2d.host_bandwidth_plan"):
                         plan = self._bandwidth_plan(*plan_args())
                 with _Phase(self, "2d.bandwidth.device"):
-                    widths = self._bandwidth_2d(plan, hists, [e["F"] for e in info], base_F, mbc, shear=shear)
-                for e, pl in zip(info, plan):
-                    e["branch"], e["kopt"] = pl["branch"], pl["kopt"]
-            wv = np.array(widths, dtype=np.float64).reshape(npair, 3)
+                    wv = self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred)
+
+                def book_plan(plan=plan):
+                    for e, pl in zip(info, plan):
+                        e["branch"], e["kopt"] = pl["branch"], pl["kopt"]
+
+                deferred.append(book_plan)
             rx_v = wv[:, 0] * abs(smooth_scale_2D) / fwx_v
             ry_v = wv[:, 1] * abs(smooth_scale_2D) / fwy_v
             cc_v = wv[:, 2]
-            for e, bw_k in zip(info, widths):
-                e["bandwidth"] = bw_k
+
+            def book_widths():
+                for e, bw_k in zip(info, wv.tolist()):
+                    e["bandwidth"] = tuple(bw_k)
+
+            deferred.append(book_widths)
         elif smooth_scale_2D < 1.0:
             rx_v = smooth_scale_2D * np.array([e["parx"].err for e in info]) / fwx_v
             ry_v = smooth_scale_2D * np.array([e["pary"].err for e in info]) / fwy_v
@@ -2702,12 +2772,19 @@ class MCSamples:
         has_prior_v = has_lim[jx] | has_lim[jy] | (mask_function is not None)  # mcsamples.py:1794
         flags_v = lim_bits[jx] | (per_bit[jx] << 4) | (lim_bits[jy] << 2) | (per_bit[jy] << 5) | (has_prior_v.astype(np.int64) << 6)
         smooth_v = np.maximum(rx_v, ry_v)
-        for k in np.nonzero(smooth_v < 2)[0].tolist():
-            logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", info[k]["parx"].name,
-                            info[k]["pary"].name)
+        def warn_coarse():
+            for k in np.nonzero(smooth_v < 2)[0].tolist():
+                logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", info[k]["parx"].name,
+                                info[k]["pary"].name)
+
+        deferred.append(warn_coarse)
         winw_v = np.maximum(1, np.rint(2.5 * smooth_v).astype(np.int64))  # max(1, int(round(2.5 * smooth_scale)))
         group_v = (flags_v & 48) * 2 + (has_prior_v & (bco >= 0))
         flags_l, winw_l = flags_v.tolist(), winw_v.tolist()
+
+        def run_deferred():
+            while deferred:
+                deferred.pop(0)()
 
         def run_class(F, d_hist, members):
             """Convolve the pairs of one grid-size class."""
@@ -2758,6 +2835,7 @@ class MCSamples:
                     if mbc:
                         _set_all_edge_mask_2d(prior_mask, w_)
                         mask_mbc = prior_mask
+                    run_deferred()
                     with _Phase(self, "2d.convolve"):
                         d_P, status = ctx.density2d_masked(d_hist, pos, F, rx[k], ry[k], cc[k], w_,
                                                            flags_l[k], bco, mbc, mask_bc, mask_mbc, bool_mask)
@@ -2793,6 +2871,10 @@ class MCSamples:
                         d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
                                                     [cc[k] for k in ks], [winw_l[k] for k in ks],
                                                     [flags_l[k] for k in ks], bco, mbc)
+                # the first batch is short (it starts the result copies early) and would be through before the
+                # bookkeeping: that runs once the second batch is queued behind it
+                if batch_no[0] >= 2:
+                    run_deferred()
                 levels = None
                 if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
                     ncontours = len(self.contours)
@@ -2818,7 +2900,7 @@ class MCSamples:
                     release.append(d_sub)  # freeing waits for the stream: after the last batch
                 # the copy runs on the copy stream while the next batch computes
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
-                if not self._timing:
+                if not self._timing and not deferred:
                     assemble_new()
 
         _hostlog("bandwidths done")
@@ -2837,19 +2919,27 @@ class MCSamples:
             conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
             self._nlanes = nlanes
         completion = _PendingResults(ctx, inflight, release, conv_ctxs[1:]) if lazy else None  # shares the two lists filled below
+        if lazy and self._pending_results is not None:
+            # the previous call's copies landed long ago: its device blocks are handed back while this call's first
+            # batches compute, not between the last enqueue and the caller's next launch
+            deferred.append(self._pending_results.wait)
         import functools
 
         # the grid axes of every (parameter, F) in use, all at once: np.linspace(lo, hi, F) written out
         # (k * step + start, last point = stop) on one 2D array per F
         ax_cache = {}
-        for F_ in set(pF):
-            js_ = sorted({j for j, f in zip(pj, pF) if f == F_} | {j for j, f in zip(pj2, pF) if f == F_})
-            lo_ = np.array([edge_of[(j, F_)][1] for j in js_], dtype=np.float64)
-            hi_ = np.array([edge_of[(j, F_)][2] for j in js_], dtype=np.float64)
-            A = np.arange(F_, dtype=np.float64)[None, :] * ((hi_ - lo_) / (F_ - 1))[:, None] + lo_[:, None]
-            A[:, -1] = hi_
-            for row, j in enumerate(js_):
-                ax_cache[(j, F_)] = (A[row], A[row, 1] - A[row, 0], (names[j].range_min, names[j].range_max))
+
+        def make_axes():
+            for F_ in F_list:
+                js_ = np.unique(np.concatenate([jx[F_v == F_], jy[F_v == F_]])).tolist()
+                lo_ = np.array([edge_of[(j, F_)][1] for j in js_], dtype=np.float64)
+                hi_ = np.array([edge_of[(j, F_)][2] for j in js_], dtype=np.float64)
+                A = np.arange(F_, dtype=np.float64)[None, :] * ((hi_ - lo_) / (F_ - 1))[:, None] + lo_[:, None]
+                A[:, -1] = hi_
+                for row, j in enumerate(js_):
+                    ax_cache[(j, F_)] = (A[row], A[row, 1] - A[row, 0], (names[j].range_min, names[j].range_max))
+
+        deferred.append(make_axes)  # needed by the result objects only
         assembled = [0]
         sync_state = [False]
 
@@ -2893,6 +2983,7 @@ class MCSamples:
         for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
             run_class(F, d_hist, members)
             _hostlog("class F=%d enqueued (%d pairs)" % (F, len(members)))
+        run_deferred()  # (nothing was enqueued: no pairs)
         release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
         _hostlog("all batches enqueued")
         _ph_asm.__enter__()

@@ -102,10 +102,9 @@ def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
     All-gather the prepared per-parameter scalars so every rank knows every parameter.
     ``dist`` is torch.distributed (initialised) or None for single-process runs.
     """
-    mine = pack_param_state(mc, my_js)
     if dist is None or dist.get_world_size() == 1:
-        unpack_param_state(mc, mine)
-        return
+        return  # one rank prepared every parameter: nothing to exchange
+    mine = pack_param_state(mc, my_js)
     import torch
 
     world = dist.get_world_size()

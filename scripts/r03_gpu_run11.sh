@@ -1,0 +1,15 @@
+#!/bin/bash
+# small results through a kernel-filled page-locked bounce block; bookkeeping behind the second batch
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r03_pytest11.log 2>&1; echo "pytest rc=$?"
+tail -5 gpurun_out/r03_pytest11.log | cut -c1-300
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r03_bench11.log 2>&1
+grep "^{" gpurun_out/r03_bench11.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('W1', d['ms_per_step'], d['ms_single_triangle_latency'], d['roofline']['ms_per_launch'])"
+for W in 8 4 2; do
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --emulate-world $W > gpurun_out/r03_emu11_$W.log 2>&1
+  grep "^{" gpurun_out/r03_emu11_$W.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('W', d['n_gpus'], d['ms_per_step'])"
+done
+(cd /tmp && timeout 400 rocprofv3 --hip-runtime-trace --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/api11_w1 -o w1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/api11_w1.log 2>&1); echo "api w1 rc=$?"
+(cd /tmp && timeout 400 rocprofv3 --hip-runtime-trace --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/api11_w8 -o w8 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --emulate-world 8 > $GRAFT_REPO_ROOT/gpurun_out/api11_w8.log 2>&1); echo "api w8 rc=$?"
