@@ -612,13 +612,16 @@ def main():
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
         if getattr(mc, "_twin", None) is not None:
             mc._twin.ctx.reserve_pinned_twin()  # a rank's share is convolved on both contexts' streams
-    # The cyclic collector's full passes walk every object the interpreter holds (modules, the sample-set object, ...):
-    # 5-10 ms every eighth step on this host, all of it in front of a kernel launch.  Objects alive after the warm-up are
-    # moved to the permanent generation; the per-step garbage (closures of the batched call) is still collected.
+    # The cyclic collector's passes walk the live objects (a step's 1225 result objects, the interpreter's modules):
+    # 5-10 ms every eighth step on this host, all of it in front of a kernel launch, and they find nothing -- the path
+    # creates no reference cycles (every per-step object is freed by its reference count; checked with
+    # gc.DEBUG_SAVEALL).  A caller that loops over batched calls does what this does: collect once, freeze what is
+    # alive, and keep the collector off while it loops.
     import gc
 
     gc.collect()
     gc.freeze()
+    gc.disable()
     barrier()
     mc.timings = {}
     prof = None
@@ -646,6 +649,7 @@ def main():
             dens[-1].P
         barrier()
         serial_ms = (time.perf_counter() - ts) / 3 * 1e3
+    gc.enable()
     if prof is not None:
         import pstats
 

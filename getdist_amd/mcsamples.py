@@ -525,7 +525,7 @@ class MCSamples:
         self._device = device
         self._lane, self._nlanes = 0, 1
         # set up front: helper threads assign these while another thread may be iterating this object's __dict__
-        self._lag_prefetch = self._pending_results = None
+        self._lag_prefetch = self._pending_results = self._parked = None
         self._helper_exec = None
         self._lane_exec = None
         self._twin = None
@@ -2923,6 +2923,8 @@ class MCSamples:
             # the previous call's copies landed long ago: its device blocks are handed back while this call's first
             # batches compute, not between the last enqueue and the caller's next launch
             deferred.append(self._pending_results.wait)
+        parked, self._parked = [getattr(self, "_parked", None)], None
+        deferred.append(parked.clear)  # the previous call's per-pair records (see the end of this function)
         import functools
 
         # the grid axes of every (parameter, F) in use, all at once: np.linspace(lo, hi, F) written out
@@ -2999,6 +3001,10 @@ class MCSamples:
                 # the previous call's copies are ahead of this call's on the copy stream: completing it here costs no
                 # waiting, and its device blocks are released even if nobody ever read its grids
                 previous.wait()
+            # The per-pair records of a triangle are a few thousand small objects: tearing them down on return would
+            # sit between this call's last enqueue and the caller's next launch.  They are parked and dropped by the
+            # next batched call while its first batches compute (or with this object).
+            self._parked = (info, plan)
             return out
         if not synced:
             with _Phase(self, "2d.d2h_wait"):

@@ -680,3 +680,33 @@ def test_truncated_chain_file_is_rejected_and_ini_contour_keys_are_honoured(tmp_
     assert len(ms.names[0].limits) == 2 and len(ms.names[3].limits) == 2  # one limit per contour of the .ini
     with pytest.raises(Exception):
         _read_ini_settings({"num_contours": 2, "contour1": 0.5})
+
+
+def test_batched_call_leaves_no_reference_cycles_of_its_own(zoo):
+    """A looping caller keeps the cyclic collector off (bench.py): everything a batched call creates must
+    then be freed by reference counts.  With the collector off, two calls may leave unreachable objects only from the
+    test double's scipy optimiser, none defined in getdist_amd."""
+    import gc
+
+    fx = zoo["block10_weighted"]
+    mc = make(fx)
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    mc.get2DDensities(pairs)
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    old_flags = gc.get_debug()
+    gc.set_debug(gc.DEBUG_SAVEALL)
+    try:
+        first = mc.get2DDensities(pairs)
+        second = mc.get2DDensities(pairs)
+        del first, second
+        gc.collect()
+        mine = [o for o in gc.garbage
+                if (getattr(o, "__module__", None) or type(o).__module__ or "").startswith("getdist_amd")]
+        assert not mine, [type(o).__name__ + ":" + getattr(o, "__qualname__", "") for o in mine][:10]
+    finally:
+        gc.set_debug(old_flags)
+        gc.garbage.clear()
+        if was:
+            gc.enable()
