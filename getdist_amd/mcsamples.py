@@ -1721,16 +1721,17 @@ class MCSamples:
             return
         share = getattr(self, "_neff_share", None)
         if share is not None:
-            # multi-rank runs (parallel.NeffShare): this rank computes the parameters it owns, the others arrive by exchange
+            # multi-rank runs (parallel.NeffShare): this rank computes the parameters it owns; the others arrive by an
+            # exchange that is always issued from the main thread (collectives of a process stay on one thread), i.e.
+            # here, or -- when this runs on the helper thread beside the binning -- by the caller's _neff_complete
             self._neff_share = None
             try:
                 self._neff_batch([j for j in todo if j in share.params], min_corr)
-                share.exchange(self)
             finally:
                 self._neff_share = share
-            todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]  # owned by nobody: computed here
-            if not todo:
-                return
+            if threading.current_thread() is threading.main_thread():
+                self._neff_complete(js, min_corr)
+            return
         if self.sampler in ("nested", "uncorrelated"):
             for j in todo:
                 self.paramNames.names[j].N_eff_kde = self.norm**2 / self._sum_w2
@@ -1757,6 +1758,20 @@ class MCSamples:
         sums = self.ctx.kde_lag_sums_batch(todo, [1.0 / (4 * k**2) for k in kstd], self._neff_lag_list())
         for row, j in enumerate(todo):
             self.paramNames.names[j].N_eff_kde = self._neff_from_lags(j, kstd[row], maxoffs[row], min_corr, sums[row])
+
+    def _neff_complete(self, js, min_corr=0.05):
+        """Multi-rank runs: fetch the N_eff values of the parameters other ranks own (parallel.NeffShare.exchange), then
+        compute whatever nobody owned.  Main thread only."""
+        share = getattr(self, "_neff_share", None)
+        if share is None:
+            return
+        if any(self.paramNames.names[j].N_eff_kde is None for j in js):
+            share.exchange(self)
+        self._neff_share = None
+        try:
+            self._neff_batch(js, min_corr)  # owned by nobody: computed here
+        finally:
+            self._neff_share = share
 
     def getEffectiveSamplesGaussianKDE_2d(self, i, j, h=0.3, maxoff=None, min_corr=0.05):
         """chains.py:576-635 (used when use_effective_samples_2D is set); lag sums on the GPU, 8 lags per launch."""
@@ -2687,6 +2702,7 @@ class MCSamples:
                         plan, fill_plan = self._bandwidth_plan(*plan_args(), defer_neff=True)
                     finally:
                         neff_f.result()
+                    self._neff_complete(used)  # (multi-rank runs: the other ranks' values, from this thread)
                     # a context is not re-entrant: the shear launches start once the N_eff call has returned
                     shear_f = self._helper().submit(self._shear_histograms, plan, base_F)
                     try:

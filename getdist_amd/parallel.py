@@ -38,10 +38,10 @@ def partition_pairs_by_class(pairs, class_ids, world, rank):
 class NeffShare:
     """
     Who computes which parameter's KDE effective sample number in a multi-rank run.  Set as ``mc._neff_share``:
-    ``MCSamples._neff_batch`` then computes only the parameters in ``params`` (this rank's share) and calls
-    ``exchange(mc)``, which must leave ``N_eff_kde`` of every other parameter filled in (an all-gather of one double per
-    parameter).  This lets the N_eff kernels of a rank run beside its 2D binning exactly as in the single-GPU pipeline,
-    instead of before the parameter state is exchanged.
+    ``MCSamples._neff_batch`` then computes only the parameters in ``params`` (this rank's share) -- on the helper thread,
+    beside the 2D binning, exactly as in the single-GPU pipeline -- and ``exchange(mc)``, called from the main thread once
+    that has finished (``_neff_complete``), must leave ``N_eff_kde`` of every other parameter filled in (an all-gather of
+    one double per parameter).  Every collective of a process is issued from its main thread.
     """
 
     def __init__(self, params, exchange):

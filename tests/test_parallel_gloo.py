@@ -195,8 +195,8 @@ def test_chain_per_rank_convergence_gloo_world2(tmp_path):
 def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     """`python bench.py --gpus 2` without a launcher around it re-launches itself under torch.distributed.run: the
     JSON line reports two ranks from the communicator (gloo and the numpy context double here, RCCL on the GPU box).
-    17 parameters = 68 pairs per rank: enough for the overlapped pipeline, whose N_eff exchange is a collective issued
-    from the helper thread."""
+    17 parameters = 68 pairs per rank: enough for the overlapped pipeline (N_eff kernels on the helper thread beside the
+    binning, their exchange from the main thread once they are through)."""
     import json
     import subprocess
     import sys
