@@ -1,0 +1,39 @@
+"""One-GPU smoke of what a multi-rank bench process does besides the densities: torch's HIP runtime, RCCL (backend "nccl")
+and libgdhip.so in ONE process -- a single-rank communicator, the all-gathers of parallel.py on GPU tensors, a batched call
+between them.  (The multi-rank logic itself is covered by the gloo tests; 8-GPU runs are the driver's.)"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+import torch
+import torch.distributed as dist
+
+from getdist_amd import synth
+from getdist_amd.mcsamples import MCSamples
+
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+s, w, names, ranges = synth.config_c3(200_000, 12)
+mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=0)
+t = torch.from_numpy(np.arange(8, dtype=np.float64)).to(dev)
+out = [torch.empty_like(t)]
+dist.all_gather(out, t)
+assert np.array_equal(out[0].cpu().numpy(), np.arange(8.0))
+d1 = mc.get2DDensities(synth.triangle_pairs(12))
+from concurrent.futures import ThreadPoolExecutor
+
+with ThreadPoolExecutor(1) as ex:  # a collective while another thread of the process is inside the library
+    f = ex.submit(mc.getMargeStats)
+    dist.all_gather(out, t)
+    f.result()
+dist.barrier()
+torch.cuda.synchronize()
+d2 = mc.get2DDensities(synth.triangle_pairs(12))
+assert all(np.array_equal(a.P, b.P) for a, b in zip(d1, d2))
+dist.destroy_process_group()
+print("nccl smoke ok: torch %s, %d densities twice, bit-equal" % (torch.__version__, len(d1)))
