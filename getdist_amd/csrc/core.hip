@@ -164,6 +164,7 @@ void gd_destroy(gd_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gd_fft_cache_destroy(ctx);
     for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
+    for (auto& kv : ctx->fft_tw) (void)hipFree(kv.second);
     if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);

@@ -45,6 +45,7 @@ struct gd_ctx {
     int64_t scratch2_bytes = 0;
     FftPlanCache* fft = nullptr;
     std::map<int, double*> dctmat;  // F -> F x F DCT-II matrix 2cos(pi k (2n+1) / 2F) (kopt2d.hip)
+    std::map<int, void*> fft_tw;    // S -> the S twiddles e^{-2 pi i k / S} of the LDS transforms (density2d.hip)
     // page-locked staging ring for the small per-call tables of the entry points that return before their kernels
     // have run (gd_stage_h2d): a slot is reused only after the copy that read it has executed
     struct StageSlot {

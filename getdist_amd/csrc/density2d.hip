@@ -541,6 +541,324 @@ __global__ void k_box(const double* __restrict__ hist, const double* __restrict_
     }
 }
 
+// ---- convolution in LDS: row transforms, column transform x window spectrum x inverse column transform, row transforms ----
+// The rocFFT route moves every S x S frame through HBM about eight times per convolution (embed, two transform passes,
+// spectral product, two inverse passes, crop: ~10.6 MB per pair at S = 288).  Here a convolution is three kernels and
+// ~4 MB per pair:
+//   k_rows_fwd   reads the F x F source (the histogram, or the bias-correction box formed on the fly), transforms each of
+//                its F non-zero rows in LDS and writes the half spectrum transposed, Xt[b][kx][y]  (y < F only: the other
+//                rows of the frame are zero);
+//   k_col_conv   per column kx: transform along y, multiply by the window's spectrum -- built in the block from the
+//                (2w+1)^2 window values: a direct sum over x for each window row, then the same column transform -- inverse
+//                transform, keep the F rows of the crop: Yt[b][kx][y];
+//   k_rows_inv   per output row: Hermitian-extend, inverse transform, crop, and the epilogue of k_crop_fused (bias update,
+//                block maxima).
+// A transform is a sequence of Stockham auto-sort passes of radix 3 / 5 / 4 / 2 done IN PLACE in one LDS buffer by
+// FT = 32 lanes (two transforms per wavefront): every lane reads the inputs of all its butterflies of a pass into
+// registers, the group synchronises, and the outputs go back to their auto-sorted places.  One buffer per transform is
+// what lets ~30 transforms be resident per CU -- their number, not the arithmetic, bounds these kernels.  Any frame size of
+// the ladder up to 512 is handled (larger grids keep the rocFFT route).
+#define FT 32
+struct FftDev {
+    int S, nst;
+    int radix[12];
+};
+
+// The FT lanes of a transform sit inside one wavefront, whose LDS operations execute in order: passes are separated by a
+// compiler-level fence, not by a block barrier, so the waves of a block run their transforms independently.
+__device__ __forceinline__ void group_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One in-place Stockham pass of radix R over the length-S sequence in `buf`; MAXIT >= ceil(S / R / FT) butterflies per
+// lane.  `emit(pos, value)` receives the outputs after the group has read all its inputs (default: store to buf).
+template <int R, int MAXIT, class Emit>
+__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int S, int Ns, int t, bool inv,
+                                         bool active, Emit emit) {
+    const int nb = S / R, step = S / (Ns * R);
+    double2 o[MAXIT][R];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int j = t + it * FT;
+        if (active && j < nb) {
+            const int k = j % Ns;
+            double2 v[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double2 x = buf[j + q * nb];
+                if (q > 0 && k > 0) {
+                    double2 w = tw[q * k * step];
+                    if (inv) w.y = -w.y;
+                    x = cmulf(x, w);
+                }
+                v[q] = x;
+            }
+            if (R == 2) {
+                o[it][0] = make_double2(v[0].x + v[1].x, v[0].y + v[1].y);
+                o[it][1] = make_double2(v[0].x - v[1].x, v[0].y - v[1].y);
+            } else if (R == 4) {
+                const double2 t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+                const double2 t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y);
+                const double2 d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
+                const double2 t3 = inv ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) : d * (-i)
+                o[it][0] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                o[it][1] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                o[it][2] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                o[it][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
+            } else {  // small DFT by its definition; cos / sin of 2 pi m / R as literals (R = 3, 5)
+                constexpr double C3[3] = {1.0, -0.5, -0.5};
+                constexpr double S3[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+                constexpr double C5[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410,
+                                          0.30901699437494742410};
+                constexpr double S5[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917,
+                                          -0.95105651629515357212};
+#pragma unroll
+                for (int p = 0; p < R; ++p) {
+                    double2 acc = v[0];
+#pragma unroll
+                    for (int q = 1; q < R; ++q) {
+                        const int m = (p * q) % R;
+                        const double c = R == 3 ? C3[m] : C5[m];
+                        const double sn = (R == 3 ? S3[m] : S5[m]) * (inv ? 1.0 : -1.0);  // e^{-+ 2 pi i m / R}
+                        acc.x += v[q].x * c - v[q].y * sn;
+                        acc.y += v[q].x * sn + v[q].y * c;
+                    }
+                    o[it][p] = acc;
+                }
+            }
+        }
+    }
+    group_sync();
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int j = t + it * FT;
+        if (active && j < nb) {
+            const int j0 = (j / Ns) * Ns * R + j % Ns;
+#pragma unroll
+            for (int q = 0; q < R; ++q) emit(j0 + q * Ns, o[it][q]);
+        }
+    }
+    group_sync();
+}
+
+// butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
+template <bool BIG, class Emit>
+__device__ __forceinline__ void fft_pass_any(int R, double2* buf, const double2* tw, int S, int Ns, int t, bool inv, bool active,
+                                             Emit emit) {
+    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, S, Ns, t, inv, active, emit);
+    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, S, Ns, t, inv, active, emit);
+    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, S, Ns, t, inv, active, emit);
+    else fft_pass<5, BIG ? 4 : 2>(buf, tw, S, Ns, t, inv, active, emit);
+}
+
+// all passes but the last; returns the sub-transform length the last pass starts from
+template <bool BIG>
+__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, const FftDev& pl, int t, bool inv, bool active) {
+    int Ns = 1;
+    for (int st = 0; st + 1 < pl.nst; ++st) {
+        const int R = pl.radix[st];
+        fft_pass_any<BIG>(R, buf, tw, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+        Ns *= R;
+    }
+    return Ns;
+}
+
+template <bool BIG>
+__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, const FftDev& pl, int t, bool inv, bool active) {
+    const int Ns = fft_head<BIG>(buf, tw, pl, t, inv, active);
+    fft_pass_any<BIG>(pl.radix[pl.nst - 1], buf, tw, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+}
+
+// grid (ceil(F / 8), B), 256 threads = 8 rows of pair b per block.
+// MODE 0: rows of src (B x F x F); MODE 1: rows of the bias-correction box src / P where P > max * 1e-8 (k_fill_box).
+template <int MODE, bool BIG>
+__global__ void __launch_bounds__(256) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
+                                                  const double* __restrict__ P, const double* __restrict__ mx, int F, FftDev pl,
+                                                  const double2* __restrict__ twg, double2* __restrict__ Xt) {
+    extern __shared__ double2 sh2[];
+    __shared__ double thresh_sh;
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    double2* tw = sh2;
+    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    double2* buf = sh2 + S + (size_t)g * S;
+    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
+    __syncthreads();
+    const int w = pairs[b].w;
+    const int y = blockIdx.x * 8 + g;
+    const bool active = y < F;
+    if (active) {
+        const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
+        for (int x = t; x < S; x += FT) {
+            const int c = x - w;
+            double v = 0.0;
+            if (c >= 0 && c < F) {
+                v = src[o + c];
+                if (MODE == 1) {
+                    const double p = P[o + c];
+                    if (p > thresh_sh) v = v / p;
+                }
+            }
+            buf[x] = make_double2(v, 0.0);
+        }
+    }
+    group_sync();
+    fft_full<BIG>(buf, tw, pl, t, false, active);
+    if (active)
+        for (int kx = t; kx < Sh; kx += FT) Xt[((int64_t)b * Sh + kx) * F + y] = buf[kx];
+}
+
+// grid (ceil(Sh / 8), B), 256 threads = 8 columns per block.  The spectrum of the window moment Win * x^px * y^py, by
+// columns: Wt[b][kx][ky].  Built from the (2w+1)^2 window values: a direct sum over x for each window row, then the column
+// transform.  Once per pair and moment (the plain window serves the first convolution and the bias-correction round).
+template <bool BIG>
+__global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, FftDev pl,
+                                                  const double2* __restrict__ twg, int px, int py, int maxw,
+                                                  double2* __restrict__ Wt) {
+    extern __shared__ double2 sh2[];
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    const D2Pair p = pairs[b];
+    const int w = p.w, M = 2 * w + 1, Mmax = 2 * maxw + 1;
+    double2* tw = sh2;
+    double* wn = reinterpret_cast<double*>(sh2 + S);  // (2w+1)^2 window values, row stride M
+    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    double2* bw = sh2 + S + (Mmax * Mmax + 1) / 2 + (size_t)g * S;
+    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    {
+        const double ws = wsum[b];
+        for (int e = threadIdx.x; e < M * M; e += 256) {
+            const int i1 = e / M - w, i2 = e % M - w;
+            double v = win_raw(p, i1, i2) / ws;
+            for (int q = 0; q < px; ++q) v = v * (double)i2;
+            for (int q = 0; q < py; ++q) v = v * (double)i1;
+            wn[e] = v;
+        }
+    }
+    __syncthreads();
+    const int kx = blockIdx.x * 8 + g;
+    const bool active = kx < Sh;
+    // rows wrapped into the frame; two lanes per row (the halves of its x range, added lower + upper on both lanes), so
+    // that the group's lanes share the (2w+1)^2 terms instead of 2w+1 of them doing a row each
+    for (int idx = t; idx < S; idx += FT) bw[idx] = make_double2(0.0, 0.0);
+    group_sync();
+    {
+        const int half = (M + 1) / 2;
+        for (int task0 = 0; task0 < 2 * M; task0 += FT) {
+            const int task = task0 + t, row_i = task >> 1, part = task & 1;
+            double2 acc = make_double2(0.0, 0.0);
+            if (active && row_i < M) {
+                const double* row = wn + row_i * M;
+                const int c0 = part ? half : 0, c1 = part ? M : half;
+                int ph = (int)(((int64_t)kx * (S - w + c0)) % S);  // x offset c0 - w: e^{-2 pi i kx (c0 - w) / S}
+                for (int c = c0; c < c1; ++c) {
+                    const double2 e = tw[ph];
+                    acc.x += row[c] * e.x, acc.y += row[c] * e.y;
+                    ph += kx;
+                    if (ph >= S) ph -= S;
+                }
+            }
+            const double ox = __shfl_xor(acc.x, 1), oy = __shfl_xor(acc.y, 1);
+            if (active && row_i < M && part == 0) {
+                const int i1 = row_i - w;
+                bw[i1 >= 0 ? i1 : i1 + S] = make_double2(acc.x + ox, acc.y + oy);
+            }
+        }
+    }
+    group_sync();
+    fft_full<BIG>(bw, tw, pl, t, false, active);
+    if (active) {
+        double2* col = Wt + ((int64_t)b * Sh + kx) * S;
+        for (int idx = t; idx < S; idx += FT) col[idx] = bw[idx];
+    }
+}
+
+// grid (ceil(Sh / 8), B), 256 threads = 8 columns per block, one LDS buffer per column: transform the source's column,
+// multiply by the window's spectrum in the last pass (scaled), inverse transform, keep the F rows of the crop.
+template <bool BIG>
+__global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pairs, int F, FftDev pl, const double2* __restrict__ twg,
+                                                  const double2* __restrict__ Wt, const double2* __restrict__ Xt,
+                                                  double2* __restrict__ Yt) {
+    extern __shared__ double2 sh2[];
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    const int w = pairs[b].w;
+    double2* tw = sh2;
+    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    double2* bh = sh2 + S + (size_t)g * S;
+    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    __syncthreads();
+    const int kx = blockIdx.x * 8 + g;
+    const bool active = kx < Sh;
+    if (active) {
+        const double2* col = Xt + ((int64_t)b * Sh + kx) * F;
+        for (int idx = t; idx < S; idx += FT) {
+            const int r = idx - w;
+            bh[idx] = (r >= 0 && r < F) ? col[r] : make_double2(0.0, 0.0);
+        }
+    }
+    group_sync();
+    const int Ns = fft_head<BIG>(bh, tw, pl, t, false, active);
+    const double scale = 1.0 / ((double)S * (double)S);
+    const double2* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;
+    fft_pass_any<BIG>(pl.radix[pl.nst - 1], bh, tw, S, Ns, t, false, active, [&](int pos, double2 v) {
+        const double2 m = cmulf(v, wcol[pos]);
+        bh[pos] = make_double2(m.x * scale, m.y * scale);
+    });
+    fft_full<BIG>(bh, tw, pl, t, true, active);
+    if (active) {
+        double2* col = Yt + ((int64_t)b * Sh + kx) * F;
+        for (int r = t; r < F; r += FT) col[r] = bh[r + w];
+    }
+}
+
+// grid (ceil(F / 8), B), 256 threads = 8 rows per block.  MODE 0: dst = crop; MODE 1: dst = dst * crop / a00 (the
+// multiplicative bias-correction update); mx (may be nullptr): block maxima of what was written, parts the grid does not
+// cover set to -inf.
+template <int MODE, bool BIG>
+__global__ void __launch_bounds__(256) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev pl,
+                                                  const double2* __restrict__ twg, double* __restrict__ dst,
+                                                  const double* __restrict__ a00, double* __restrict__ mx) {
+    extern __shared__ double2 sh2[];
+    __shared__ double red[16];
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    double2* tw = sh2;
+    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    double2* buf = sh2 + S + (size_t)g * S;
+    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    __syncthreads();
+    const int w = pairs[b].w;
+    const int y = blockIdx.x * 8 + g;
+    const bool active = y < F;
+    if (active)
+        for (int kx = t; kx < Sh; kx += FT) {
+            const double2 v = Yt[((int64_t)b * Sh + kx) * F + y];
+            buf[kx] = v;
+            if (kx > 0 && 2 * kx < S) buf[S - kx] = make_double2(v.x, -v.y);
+        }
+    group_sync();
+    fft_full<BIG>(buf, tw, pl, t, true, active);
+    double m = -INFINITY;
+    if (active) {
+        const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
+        for (int x = t; x < F; x += FT) {
+            double v = buf[x + w].x;
+            if (MODE == 1) v = (dst[o + x] * v) / a00[o + x];
+            dst[o + x] = v;
+            m = fmax(m, v);
+        }
+    }
+    if (mx) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) mx[(int64_t)b * PM_PARTS + blockIdx.x] = m;
+        if (blockIdx.x == 0)
+            for (int part = gridDim.x + threadIdx.x; part < PM_PARTS; part += 256) mx[(int64_t)b * PM_PARTS + part] = -INFINITY;
+    }
+}
+
 static int next_fft_size(int n) {
     // smallest 2^a * {1,3,5,9,15} (a >= 4) >= n: a coarse ladder (288, 320, 384, 480, 512, 576, 640, 768, ...) keeps
     // the number of distinct rocFFT plans small; any zero padding gives the same linear convolution
@@ -552,6 +870,36 @@ static int next_fft_size(int n) {
             if (v >= n && v < best) best = (int)v;
         }
     return best;
+}
+
+// The LDS route's plan for frame size S (radices 4, 2, 3, 5) and its twiddle table on the device (cached per context).
+// false: S has another prime factor (not on the ladder) -- the caller keeps the rocFFT route.
+static bool lds_fft_plan(gd_ctx* ctx, int S, FftDev* pl, const double2** tw) {
+    pl->S = S, pl->nst = 0;
+    int n = S;
+    // odd radices first: a pass writes its outputs R * (length of the finished sub-transforms) apart, and a power-of-two
+    // stride in the first pass (sub-transform length 1) would put every lane's 16-byte store on a few LDS banks
+    const int order[4] = {3, 5, 4, 2};
+    for (int q = 0; q < 4; ++q)
+        while (n % order[q] == 0 && pl->nst < 12) pl->radix[pl->nst++] = order[q], n /= order[q];
+    if (n != 1 || pl->nst == 0) return false;
+    auto it = ctx->fft_tw.find(S);
+    if (it == ctx->fft_tw.end()) {
+        std::vector<double2> h((size_t)S);
+        for (int k = 0; k < S; ++k) {
+            const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)S;
+            h[k] = make_double2((double)cosl(a), (double)sinl(a));
+        }
+        void* d = nullptr;
+        if (hipMalloc(&d, (size_t)S * 16) != hipSuccess) return false;
+        if (hipMemcpy(d, h.data(), (size_t)S * 16, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return false;
+        }
+        it = ctx->fft_tw.emplace(S, d).first;
+    }
+    *tw = (const double2*)it->second;
+    return true;
 }
 
 // Periodic variant (one or both axes periodic, the same for the whole batch).  Histogram-side convolutions are
@@ -752,11 +1100,21 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         off += (bytes + 255) / 256 * 256;
         return o;
     };
+    // ---- route: transforms in LDS (three kernels per convolution) where the frame, the window table and the grid fit
+    FftDev pl;
+    const double2* d_tw = nullptr;
+    const int Mmax = 2 * maxw + 1;
+    const size_t lds_rows = ((size_t)S + (size_t)8 * S) * 16;  // twiddles + one buffer for each of the block's 8 transforms
+    const size_t lds_win = ((size_t)S + (size_t)(Mmax * Mmax + 1) / 2 + (size_t)8 * S) * 16;  // + the window table
+    const bool lds_conv = !ov && S <= 512 && (F + 7) / 8 <= PM_PARTS && lds_win <= 150u * 1024u &&
+                          getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw);
+    const int64_t XT = (int64_t)B * Sh * F * 16;  // transposed half spectra of the LDS route
+    const int64_t WT = (int64_t)B * Sh * S * 16;  // a window moment's spectrum by columns
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_mx2 = take((int64_t)B * 8 * PM_PARTS),
-                  o_status = take((int64_t)B * 4), o_RF = take(B * SS * 8), o_RO = take(B * SS * 8),
-                  o_ZH = take(B * SC * 16), o_ZW = take(B * SC * 16),
-                  o_ZK = take(do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(B * SC * 16),
+                  o_status = take((int64_t)B * 4), o_RF = take(lds_conv ? XT : B * SS * 8), o_RO = take(lds_conv ? XT : B * SS * 8),
+                  o_ZH = take(lds_conv ? WT : B * SC * 16), o_ZW = take(lds_conv ? WT : B * SC * 16),
+                  o_ZK = take(!lds_conv && do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(lds_conv ? 0 : B * SC * 16),
                   o_arr = take((do_bc ? (bco == 1 ? 8 : 1) : 0) * B * FF * 8), o_a00m = take(mbc ? B * FF * 8 : 0),
                   o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8);
     char* base = (char*)gd_scratch(ctx, off);
@@ -805,14 +1163,57 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
 
     k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);
     GD_KERNEL_CHECK();
-    // spectra of the window and of the histogram
-    k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, RF);
-    GD_KERNEL_CHECK();
-    FWD(RF, ZW);
-    k_fill_embed<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, F, S, RF);
-    GD_KERNEL_CHECK();
-    FWD(RF, ZH);
-    CONV_TO(ZH, ZW, d_P, d_mx);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884), with its maxima
+    // LDS route: Xt = row spectra of the source (RF's block), Yt = columns after the convolution (RO's block)
+    double2* Xt = (double2*)RF;
+    double2* Yt = (double2*)RO;
+    const dim3 gR((F + 7) / 8, B), gC((Sh + 7) / 8, B);
+    // ---- LDS route: launches.  ZW's block holds the plain window's spectrum by columns (kept for the bias-correction
+    //      round), ZH's block the moment windows' one after the other.
+    const bool big = S > 320;  // size class of the transforms (butterflies per lane)
+    double2* Wt0 = (double2*)ZW;
+    double2* Wt1 = (double2*)ZH;
+    // the window moment's spectrum
+    auto lds_win_spec = [&](int px_, int py_, double2* WT_) -> int {
+        auto kern = big ? k_win_spec<true> : k_win_spec<false>;
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        kern<<<gC, 256, lds_win, ctx->stream>>>(d_pairs, d_wsum, pl, d_tw, px_, py_, maxw, WT_);
+        GD_KERNEL_CHECK();
+        return GD_OK;
+    };
+    // row spectra of a source into Xt (box: the bias-correction box of src and P)
+    auto lds_rows_fwd = [&](bool box, const double* P_, const double* mx_) -> int {
+        auto kern = box ? (big ? k_rows_fwd<1, true> : k_rows_fwd<1, false>) : (big ? k_rows_fwd<0, true> : k_rows_fwd<0, false>);
+        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        kern<<<gR, 256, lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, pl, d_tw, Xt);
+        GD_KERNEL_CHECK();
+        return GD_OK;
+    };
+    // convolution of the source in Xt with the window spectrum WT_, cropped into dst (update: dst *= crop / a00)
+    auto lds_conv_to = [&](const double2* WT_, bool update, double* dst, const double* a00_, double* mxp) -> int {
+        auto kc = big ? k_col_conv<true> : k_col_conv<false>;
+        GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        kc<<<gC, 256, lds_rows, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, Xt, Yt);
+        GD_KERNEL_CHECK();
+        auto kr = update ? (big ? k_rows_inv<1, true> : k_rows_inv<1, false>) : (big ? k_rows_inv<0, true> : k_rows_inv<0, false>);
+        GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        kr<<<gR, 256, lds_rows, ctx->stream>>>(d_pairs, Yt, F, pl, d_tw, dst, a00_, mxp);
+        GD_KERNEL_CHECK();
+        return GD_OK;
+    };
+    if (lds_conv) {
+        GD_TRY(lds_rows_fwd(false, nullptr, nullptr));
+        GD_TRY(lds_win_spec(0, 0, Wt0));
+        GD_TRY(lds_conv_to(Wt0, false, d_P, nullptr, d_mx));
+    } else {
+        // spectra of the window and of the histogram
+        k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, RF);
+        GD_KERNEL_CHECK();
+        FWD(RF, ZW);
+        k_fill_embed<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, F, S, RF);
+        GD_KERNEL_CHECK();
+        FWD(RF, ZH);
+        CONV_TO(ZH, ZW, d_P, d_mx);  // bins2D = conv(histbins, Win, 'same')   (mcsamples.py:1884), with its maxima
+    }
     BcArrays A;
     A.P = d_P;
     A.a00 = arr;
@@ -853,8 +1254,13 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
     double* mx_cur = d_mx;
     if (do_bc) {
-        if (bco == 1) {
+        if (bco == 1 && lds_conv) {
             // x*P and y*P still need the histogram: conv(histbins, Win*x), conv(histbins, Win*y)  (mcsamples.py:1940-1941)
+            GD_TRY(lds_win_spec(1, 0, Wt1));
+            GD_TRY(lds_conv_to(Wt1, false, A.xP, nullptr, nullptr));
+            GD_TRY(lds_win_spec(0, 1, Wt1));
+            GD_TRY(lds_conv_to(Wt1, false, A.yP, nullptr, nullptr));
+        } else if (bco == 1) {
             k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 1, 0, RF);
             GD_KERNEL_CHECK();
             FWD(RF, ZK);
@@ -870,6 +1276,12 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
     if (mbc > 0) {
         for (int round = 0; round < mbc; ++round) {
+            if (lds_conv) {
+                // bins2D *= conv(box, Win) / a00: the box is formed in the row pass, the update in the inverse row pass
+                GD_TRY(lds_rows_fwd(true, d_P, mx_cur));
+                GD_TRY(lds_conv_to(Wt0, true, d_P, d_a00m, mx_cur));
+                continue;
+            }
             k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, mx_cur, F, S, RF);
             GD_KERNEL_CHECK();
             FWD(RF, ZH);  // ZH is free to reuse: the histogram spectrum is no longer needed
@@ -906,6 +1318,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
 #undef FWD
 #undef CONV_TO
+
     return GD_OK;
 }
 

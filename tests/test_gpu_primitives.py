@@ -529,3 +529,56 @@ def test_fused_fp64_binning_packed_counters_match_the_32_bit_kernel(monkeypatch)
         iys = ((y + 6.0) / (12.0 / (F - 1)) + 0.5).astype(int)
         assert np.array_equal(a0[0], np.bincount(ixs + iys * F, minlength=F * F).reshape(F, F))
     c.close()
+
+
+@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (384, 40), (100, 9)])
+def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
+    """gd_density2d: the convolutions through LDS transforms (k_rows_fwd / k_col_conv / k_rows_inv) against the same call
+    through rocFFT frames (GDHIP_CONV_ROCFFT=1), on random histograms with bounded and unbounded pairs, linear boundary
+    correction and the multiplicative bias correction: both are exact transforms of the same sums, so the normalised
+    grids agree to rounding."""
+    from getdist_amd._lib import Context
+
+    r = np.random.default_rng(F + wmax)
+    B = 21
+    yy, xx = np.mgrid[0:F, 0:F]
+    hists = np.empty((B, F, F))
+    for b in range(B):
+        cx, cy = r.uniform(0.2, 0.8, 2) * F
+        sx, sy = r.uniform(0.05, 0.2, 2) * F
+        lam = 3000.0 * np.exp(-0.5 * (((xx - cx) / sx) ** 2 + ((yy - cy) / sy) ** 2))
+        hists[b] = r.poisson(lam).astype(np.float64)
+    smooth = r.uniform(2.0, wmax / 2.5, B)
+    rx = smooth * r.uniform(0.6, 1.0, B)
+    ry = smooth * r.uniform(0.6, 1.0, B)
+    rx[0] = ry[0] = wmax / 2.5  # one pair at the widest window of the class
+    corr = r.uniform(-0.7, 0.7, B)
+    winw = np.maximum(1, np.rint(2.5 * np.maximum(rx, ry))).astype(np.int32)
+    flags = np.array([0, 1 | 64, 2 | 64, 4 | 64, 8 | 64, 5 | 64, 10 | 64, 15 | 64, 0, 0, 3 | 64] * 2, dtype=np.int32)[:B]
+    ctx = Context(0)
+    try:
+        ctx.upload(r.standard_normal((1000, 2)), None)
+        d_hist = ctx.alloc(hists.nbytes)
+        d_hist.from_host(hists)
+        out = {}
+        for route in ("lds", "rocfft"):
+            if route == "rocfft":
+                monkeypatch.setenv("GDHIP_CONV_ROCFFT", "1")
+            else:
+                monkeypatch.delenv("GDHIP_CONV_ROCFFT", raising=False)
+            res = []
+            for bco, mbc in ((1, 1), (0, 0), (1, 2)):
+                d_P, status = ctx.density2d(d_hist, B, F, rx, ry, corr, winw, flags, bco, mbc)
+                assert not np.any(status)
+                res.append(d_P.to_host((B, F, F)).copy())
+                d_P.free()
+            out[route] = res
+        for a, b_ in zip(out["lds"], out["rocfft"]):
+            assert np.all(a.max(axis=(1, 2)) == 1.0)
+            assert float(np.max(np.abs(a - b_))) < 1e-11, float(np.max(np.abs(a - b_)))
+        # the same call twice: bit-equal
+        monkeypatch.delenv("GDHIP_CONV_ROCFFT", raising=False)
+        d_P, _ = ctx.density2d(d_hist, B, F, rx, ry, corr, winw, flags, 1, 1)
+        assert np.array_equal(d_P.to_host((B, F, F)), out["lds"][0])
+    finally:
+        ctx.close()
