@@ -577,9 +577,10 @@ __device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
 
 // One in-place Stockham pass of radix R over the length-S sequence in `buf`; MAXIT >= ceil(S / R / FT) butterflies per
 // lane.  `emit(pos, value)` receives the outputs after the group has read all its inputs (default: store to buf).
+// tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its stride.
 template <int R, int MAXIT, class Emit>
-__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int S, int Ns, int t, bool inv,
-                                         bool active, Emit emit) {
+__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns, int t,
+                                         bool inv, bool active, Emit emit) {
     const int nb = S / R, step = S / (Ns * R);
     double2 o[MAXIT][R];
 #pragma unroll
@@ -592,7 +593,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
             for (int q = 0; q < R; ++q) {
                 double2 x = buf[j + q * nb];
                 if (q > 0 && k > 0) {
-                    double2 w = tw[q * k * step];
+                    double2 w = tw[q * k * step * tws];
                     if (inv) w.y = -w.y;
                     x = cmulf(x, w);
                 }
@@ -648,53 +649,55 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
 
 // butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
 template <bool BIG, class Emit>
-__device__ __forceinline__ void fft_pass_any(int R, double2* buf, const double2* tw, int S, int Ns, int t, bool inv, bool active,
-                                             Emit emit) {
-    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, S, Ns, t, inv, active, emit);
-    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, S, Ns, t, inv, active, emit);
-    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, S, Ns, t, inv, active, emit);
-    else fft_pass<5, BIG ? 4 : 2>(buf, tw, S, Ns, t, inv, active, emit);
+__device__ __forceinline__ void fft_pass_any(int R, double2* buf, const double2* tw, int tws, int S, int Ns, int t, bool inv,
+                                             bool active, Emit emit) {
+    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, tws, S, Ns, t, inv, active, emit);
+    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, tws, S, Ns, t, inv, active, emit);
+    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, tws, S, Ns, t, inv, active, emit);
+    else fft_pass<5, BIG ? 4 : 2>(buf, tw, tws, S, Ns, t, inv, active, emit);
 }
 
 // all passes but the last; returns the sub-transform length the last pass starts from
 template <bool BIG>
-__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, const FftDev& pl, int t, bool inv, bool active) {
+__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
     int Ns = 1;
     for (int st = 0; st + 1 < pl.nst; ++st) {
         const int R = pl.radix[st];
-        fft_pass_any<BIG>(R, buf, tw, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+        fft_pass_any<BIG>(R, buf, tw, tws, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
         Ns *= R;
     }
     return Ns;
 }
 
 template <bool BIG>
-__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, const FftDev& pl, int t, bool inv, bool active) {
-    const int Ns = fft_head<BIG>(buf, tw, pl, t, inv, active);
-    fft_pass_any<BIG>(pl.radix[pl.nst - 1], buf, tw, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
+    const int Ns = fft_head<BIG>(buf, tw, tws, pl, t, inv, active);
+    fft_pass_any<BIG>(pl.radix[pl.nst - 1], buf, tw, tws, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
 }
 
-// grid (ceil(F / 8), B), 256 threads = 8 rows of pair b per block.
+// grid (ceil(F / RPB), B), RPB * 32 threads = RPB (16) rows of pair b per block: the transposed store then writes 256-byte
+// runs.  A row is real: its even and odd samples are packed into one complex sequence of half the frame length H = S / 2
+// (plH), transformed, and un-mixed into the S / 2 + 1 spectrum values (twg: the S twiddles, stride 2 for the transform).
 // MODE 0: rows of src (B x F x F); MODE 1: rows of the bias-correction box src / P where P > max * 1e-8 (k_fill_box).
-template <int MODE, bool BIG>
-__global__ void __launch_bounds__(256) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
-                                                  const double* __restrict__ P, const double* __restrict__ mx, int F, FftDev pl,
+template <int MODE>
+__global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
+                                                  const double* __restrict__ P, const double* __restrict__ mx, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double2* __restrict__ Xt) {
     extern __shared__ double2 sh2[];
     __shared__ double thresh_sh;
-    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
     double2* tw = sh2;
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
-    double2* buf = sh2 + S + (size_t)g * S;
-    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    double2* buf = sh2 + S + (size_t)g * H;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
     __syncthreads();
     const int w = pairs[b].w;
-    const int y = blockIdx.x * 8 + g;
+    const int y = blockIdx.x * (blockDim.x / FT) + g;
     const bool active = y < F;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
-        for (int x = t; x < S; x += FT) {
+        auto value = [&](int x) {  // the frame's row at position x: the source row embedded at offset w
             const int c = x - w;
             double v = 0.0;
             if (c >= 0 && c < F) {
@@ -704,13 +707,34 @@ __global__ void __launch_bounds__(256) k_rows_fwd(const D2Pair* __restrict__ pai
                     if (p > thresh_sh) v = v / p;
                 }
             }
-            buf[x] = make_double2(v, 0.0);
-        }
+            return v;
+        };
+        for (int n = t; n < H; n += FT) buf[n] = make_double2(value(2 * n), value(2 * n + 1));
     }
     group_sync();
-    fft_full<BIG>(buf, tw, pl, t, false, active);
-    if (active)
-        for (int kx = t; kx < Sh; kx += FT) Xt[((int64_t)b * Sh + kx) * F + y] = buf[kx];
+    fft_full<false>(buf, tw, 2, plH, t, false, active);
+    if (active) {
+        double2* out = Xt + (int64_t)b * Sh * F + y;  // out[kx * F]
+        for (int k = t; 2 * k <= H; k += FT) {
+            if (k == 0) {
+                const double2 z = buf[0];
+                out[0] = make_double2(z.x + z.y, 0.0);
+                out[(int64_t)H * F] = make_double2(z.x - z.y, 0.0);
+                continue;
+            }
+            const double2 zk = buf[k], zm = buf[H - k];
+            // X[k] = ((zk + conj zm) - i w^k (zk - conj zm)) / 2,  w = e^{-2 pi i / S}
+            const double ax = zk.x + zm.x, ay = zk.y - zm.y, bx = zk.x - zm.x, by = zk.y + zm.y;
+            const double2 e = tw[k];
+            const double u = e.x * bx - e.y * by, v = e.x * by + e.y * bx;
+            out[(int64_t)k * F] = make_double2(0.5 * (ax + v), 0.5 * (ay - u));
+            if (2 * k < H) {  // X[H - k] from the same two values (roles exchanged, w^(H - k))
+                const double2 f = tw[H - k];
+                const double u2 = f.x * (-bx) - f.y * by, v2 = f.x * by + f.y * (-bx);
+                out[(int64_t)(H - k) * F] = make_double2(0.5 * (ax + v2), 0.5 * (-ay - u2));
+            }
+        }
+    }
 }
 
 // grid (ceil(Sh / 8), B), 256 threads = 8 columns per block.  The spectrum of the window moment Win * x^px * y^py, by
@@ -770,7 +794,7 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    fft_full<BIG>(bw, tw, pl, t, false, active);
+    fft_full<BIG>(bw, tw, 1, pl, t, false, active);
     if (active) {
         double2* col = Wt + ((int64_t)b * Sh + kx) * S;
         for (int idx = t; idx < S; idx += FT) col[idx] = bw[idx];
@@ -801,51 +825,70 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    const int Ns = fft_head<BIG>(bh, tw, pl, t, false, active);
+    const int Ns = fft_head<BIG>(bh, tw, 1, pl, t, false, active);
     const double scale = 1.0 / ((double)S * (double)S);
     const double2* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;
-    fft_pass_any<BIG>(pl.radix[pl.nst - 1], bh, tw, S, Ns, t, false, active, [&](int pos, double2 v) {
+    fft_pass_any<BIG>(pl.radix[pl.nst - 1], bh, tw, 1, S, Ns, t, false, active, [&](int pos, double2 v) {
         const double2 m = cmulf(v, wcol[pos]);
         bh[pos] = make_double2(m.x * scale, m.y * scale);
     });
-    fft_full<BIG>(bh, tw, pl, t, true, active);
+    fft_full<BIG>(bh, tw, 1, pl, t, true, active);
     if (active) {
         double2* col = Yt + ((int64_t)b * Sh + kx) * F;
         for (int r = t; r < F; r += FT) col[r] = bh[r + w];
     }
 }
 
-// grid (ceil(F / 8), B), 256 threads = 8 rows per block.  MODE 0: dst = crop; MODE 1: dst = dst * crop / a00 (the
-// multiplicative bias-correction update); mx (may be nullptr): block maxima of what was written, parts the grid does not
-// cover set to -inf.
-template <int MODE, bool BIG>
-__global__ void __launch_bounds__(256) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev pl,
+// grid (ceil(F / RPB), B), RPB * 32 threads.  The inverse of k_rows_fwd's packing: the S / 2 + 1 spectrum values of a real
+// row are mixed into the half-length complex sequence whose inverse transform carries the row's even samples in its real
+// and the odd ones in its imaginary part (unnormalised like a length-S inverse).  MODE 0: dst = crop; MODE 1: dst = dst *
+// crop / a00 (the multiplicative bias-correction update); mx (may be nullptr): block maxima of what was written, parts the
+// grid does not cover set to -inf.
+template <int MODE>
+__global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
                                                   const double* __restrict__ a00, double* __restrict__ mx) {
     extern __shared__ double2 sh2[];
     __shared__ double red[16];
-    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
     double2* tw = sh2;
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
-    double2* buf = sh2 + S + (size_t)g * S;
-    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    double2* buf = sh2 + S + (size_t)g * H;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     __syncthreads();
     const int w = pairs[b].w;
-    const int y = blockIdx.x * 8 + g;
+    const int y = blockIdx.x * (blockDim.x / FT) + g;
     const bool active = y < F;
-    if (active)
-        for (int kx = t; kx < Sh; kx += FT) {
-            const double2 v = Yt[((int64_t)b * Sh + kx) * F + y];
-            buf[kx] = v;
-            if (kx > 0 && 2 * kx < S) buf[S - kx] = make_double2(v.x, -v.y);
+    if (active) {
+        const double2* in = Yt + (int64_t)b * Sh * F + y;  // in[kx * F]
+        for (int k = t; 2 * k <= H; k += FT) {
+            if (k == 0) {
+                const double x0 = in[0].x, xh = in[(int64_t)H * F].x;  // the imaginary parts of X[0], X[H] do not enter
+                buf[0] = make_double2(x0 + xh, x0 - xh);
+                continue;
+            }
+            const double2 xk = in[(int64_t)k * F], xm = in[(int64_t)(H - k) * F];
+            // Z[k] = (xk + conj xm) + i conj(w^k) (xk - conj xm)
+            const double ax = xk.x + xm.x, ay = xk.y - xm.y, bx = xk.x - xm.x, by = xk.y + xm.y;
+            const double2 e = tw[k];  // w^k = (e.x, e.y); conj: (e.x, -e.y)
+            const double u = e.x * bx + e.y * by, v = e.x * by - e.y * bx;  // conj(w^k) * (bx, by)
+            buf[k] = make_double2(ax - v, ay + u);
+            if (2 * k < H) {
+                const double2 f = tw[H - k];
+                const double u2 = f.x * (-bx) + f.y * by, v2 = f.x * by - f.y * (-bx);
+                buf[H - k] = make_double2(ax - v2, -ay + u2);
+            }
         }
+    }
     group_sync();
-    fft_full<BIG>(buf, tw, pl, t, true, active);
+    fft_full<false>(buf, tw, 2, plH, t, true, active);
     double m = -INFINITY;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
         for (int x = t; x < F; x += FT) {
-            double v = buf[x + w].x;
+            const int pos = x + w;
+            const double2 z = buf[pos >> 1];
+            double v = (pos & 1) ? z.y : z.x;
             if (MODE == 1) v = (dst[o + x] * v) / a00[o + x];
             dst[o + x] = v;
             m = fmax(m, v);
@@ -855,13 +898,13 @@ __global__ void __launch_bounds__(256) k_rows_inv(const D2Pair* __restrict__ pai
         m = block_max(m, red);
         if (threadIdx.x == 0) mx[(int64_t)b * PM_PARTS + blockIdx.x] = m;
         if (blockIdx.x == 0)
-            for (int part = gridDim.x + threadIdx.x; part < PM_PARTS; part += 256) mx[(int64_t)b * PM_PARTS + part] = -INFINITY;
+            for (int part = gridDim.x + threadIdx.x; part < PM_PARTS; part += blockDim.x) mx[(int64_t)b * PM_PARTS + part] = -INFINITY;
     }
 }
 
 static int next_fft_size(int n) {
     // smallest 2^a * {1,3,5,9,15} (a >= 4) >= n: a coarse ladder (288, 320, 384, 480, 512, 576, 640, 768, ...) keeps
-    // the number of distinct rocFFT plans small; any zero padding gives the same linear convolution
+    // the number of distinct plans small; any zero padding gives the same linear convolution
     int best = 1 << 30;
     const int odd[5] = {1, 3, 5, 9, 15};
     for (int a = 4; a < 28; ++a)
@@ -883,6 +926,7 @@ static bool lds_fft_plan(gd_ctx* ctx, int S, FftDev* pl, const double2** tw) {
     for (int q = 0; q < 4; ++q)
         while (n % order[q] == 0 && pl->nst < 12) pl->radix[pl->nst++] = order[q], n /= order[q];
     if (n != 1 || pl->nst == 0) return false;
+    if (!tw) return true;  // plan only (the rows' half-length transforms use the frame's table with stride 2)
     auto it = ctx->fft_tw.find(S);
     if (it == ctx->fft_tw.end()) {
         std::vector<double2> h((size_t)S);
@@ -1101,13 +1145,16 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         return o;
     };
     // ---- route: transforms in LDS (three kernels per convolution) where the frame, the window table and the grid fit
-    FftDev pl;
+    FftDev pl, plH;  // plans of the frame length (columns) and of half of it (the real rows, packed)
     const double2* d_tw = nullptr;
     const int Mmax = 2 * maxw + 1;
-    const size_t lds_rows = ((size_t)S + (size_t)8 * S) * 16;  // twiddles + one buffer for each of the block's 8 transforms
+    const int RPB = 16;  // rows per block of the row passes
+    const size_t lds_rows = ((size_t)S + (size_t)RPB * (S / 2)) * 16;  // twiddles + a half-length buffer per row
+    const size_t lds_cols = ((size_t)S + (size_t)8 * S) * 16;
     const size_t lds_win = ((size_t)S + (size_t)(Mmax * Mmax + 1) / 2 + (size_t)8 * S) * 16;  // + the window table
-    const bool lds_conv = !ov && S <= 512 && (F + 7) / 8 <= PM_PARTS && lds_win <= 150u * 1024u &&
-                          getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw);
+    const bool lds_conv = !ov && S <= 512 && (F + RPB - 1) / RPB <= PM_PARTS && lds_win <= 150u * 1024u &&
+                          getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw) &&
+                          lds_fft_plan(ctx, S / 2, &plH, nullptr);
     const int64_t XT = (int64_t)B * Sh * F * 16;  // transposed half spectra of the LDS route
     const int64_t WT = (int64_t)B * Sh * S * 16;  // a window moment's spectrum by columns
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
@@ -1166,7 +1213,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     // LDS route: Xt = row spectra of the source (RF's block), Yt = columns after the convolution (RO's block)
     double2* Xt = (double2*)RF;
     double2* Yt = (double2*)RO;
-    const dim3 gR((F + 7) / 8, B), gC((Sh + 7) / 8, B);
+    const dim3 gR((F + RPB - 1) / RPB, B), gC((Sh + 7) / 8, B);
     // ---- LDS route: launches.  ZW's block holds the plain window's spectrum by columns (kept for the bias-correction
     //      round), ZH's block the moment windows' one after the other.
     const bool big = S > 320;  // size class of the transforms (butterflies per lane)
@@ -1182,21 +1229,21 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     };
     // row spectra of a source into Xt (box: the bias-correction box of src and P)
     auto lds_rows_fwd = [&](bool box, const double* P_, const double* mx_) -> int {
-        auto kern = box ? (big ? k_rows_fwd<1, true> : k_rows_fwd<1, false>) : (big ? k_rows_fwd<0, true> : k_rows_fwd<0, false>);
+        auto kern = box ? k_rows_fwd<1> : k_rows_fwd<0>;
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kern<<<gR, 256, lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, pl, d_tw, Xt);
+        kern<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, plH, d_tw, Xt);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
     // convolution of the source in Xt with the window spectrum WT_, cropped into dst (update: dst *= crop / a00)
     auto lds_conv_to = [&](const double2* WT_, bool update, double* dst, const double* a00_, double* mxp) -> int {
         auto kc = big ? k_col_conv<true> : k_col_conv<false>;
-        GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kc<<<gC, 256, lds_rows, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, Xt, Yt);
+        GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
+        kc<<<gC, 256, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, Xt, Yt);
         GD_KERNEL_CHECK();
-        auto kr = update ? (big ? k_rows_inv<1, true> : k_rows_inv<1, false>) : (big ? k_rows_inv<0, true> : k_rows_inv<0, false>);
+        auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
         GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kr<<<gR, 256, lds_rows, ctx->stream>>>(d_pairs, Yt, F, pl, d_tw, dst, a00_, mxp);
+        kr<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
