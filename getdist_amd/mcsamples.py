@@ -2803,7 +2803,8 @@ class MCSamples:
                 deferred.pop(0)()
 
         def run_class(F, d_hist, members):
-            """Convolve the pairs of one grid-size class."""
+            """Convolve the pairs of one grid-size class: a generator that returns control after every batch it has
+            enqueued, so that the caller can interleave the classes' batches."""
             mem = np.asarray(members, dtype=np.int64)
             # batches of a few hundred grids (default cap 320) keep the FFTs efficient and the D2H copy of batch k hidden behind the
             # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
@@ -2863,11 +2864,17 @@ class MCSamples:
                         levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
                     inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
                     assemble_new()
+                    yield
                     continue
                 # a small call (one rank's share of a triangle, a handful of pairs) cannot fill the chip with one
                 # batch's kernels: its batches go alternately to the streams of the two contexts and run side by side
-                bctx = conv_ctxs[batch_no[0] % len(conv_ctxs)]
+                if side_classes:
+                    bctx = conv_ctxs[1 if F in side_classes else 0]
+                else:
+                    bctx = conv_ctxs[batch_no[0] % len(conv_ctxs)]
                 batch_no[0] += 1
+                if bctx is ctx:
+                    main_no[0] += 1
                 if [pos for pos, _ in sel] == list(range(len(members))):
                     d_sub, own = d_hist, False
                 else:
@@ -2889,7 +2896,7 @@ class MCSamples:
                                                     [flags_l[k] for k in ks], bco, mbc)
                 # the first batch is short (it starts the result copies early) and would be through before the
                 # bookkeeping: that runs once the second batch is queued behind it
-                if batch_no[0] >= 2:
+                if main_no[0] >= 2:
                     run_deferred()
                 levels = None
                 if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
@@ -2918,6 +2925,7 @@ class MCSamples:
                 inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
                 if not self._timing and not deferred:
                     assemble_new()
+                yield
 
         _hostlog("bandwidths done")
         enqueue_only = (hasattr(ctx, "density2d_enqueue") and not self._timing and not meanlikes and mask_function is None
@@ -2928,12 +2936,21 @@ class MCSamples:
         # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
         lazy = (enqueue_only and get_density and hasattr(ctx, "copy_mark")
                 and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
-        conv_ctxs, batch_no = [ctx], [0]
-        if (lazy and self._lane == 0 and self.CONV_TWO_STREAMS_PAIRS[0] <= npair <= self.CONV_TWO_STREAMS_PAIRS[1] and not self._timing
-                and self._context_factory is not None):
-            nlanes = self._nlanes
-            conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
-            self._nlanes = nlanes
+        conv_ctxs, batch_no, main_no = [ctx], [0], [0]
+        # Second stream for the convolution.  A small call (one rank's share of a triangle) cannot fill the chip with one
+        # batch's kernels: its batches alternate between the streams of the two contexts.  A large call keeps its main
+        # grid class on this context and sends the few pairs of the up-scaled classes (large frames, a handful of grids
+        # per launch) to the second one, where they run beside the main class instead of after it.
+        side_classes = set()
+        if lazy and self._lane == 0 and not self._timing and self._context_factory is not None and npair >= self.CONV_TWO_STREAMS_PAIRS[0]:
+            if npair > self.CONV_TWO_STREAMS_PAIRS[1]:
+                side_classes = {F_ for F_, (_, mem_) in hists.items() if len(mem_) < 64}
+                if len(side_classes) == len(hists):
+                    side_classes = set()
+            if npair <= self.CONV_TWO_STREAMS_PAIRS[1] or side_classes:
+                nlanes = self._nlanes
+                conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
+                self._nlanes = nlanes
         completion = _PendingResults(ctx, inflight, release, conv_ctxs[1:]) if lazy else None  # shares the two lists filled below
         if lazy and self._pending_results is not None:
             # the previous call's copies landed long ago: its device blocks are handed back while this call's first
@@ -2997,10 +3014,17 @@ class MCSamples:
             assembled[0] = len(inflight)
 
         _ph_asm = _Phase(self, "2d.host_assemble_results")
-        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
-        for F, (d_hist, members) in sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0]):
-            run_class(F, d_hist, members)
-            _hostlog("class F=%d enqueued (%d pairs)" % (F, len(members)))
+        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one; classes that go to
+        # the second stream are queued there right after the main class's first batch
+        order = sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0])
+        main = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F not in side_classes]
+        side = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F in side_classes]
+        if side and main:
+            next(main[0], None)  # the main class's short first batch goes out before the second stream is fed
+        for gen in side + main:
+            for _ in gen:
+                pass
+        _hostlog("classes enqueued (%s)" % ", ".join("F=%d: %d pairs" % (F, len(m_)) for F, (_, m_) in order))
         run_deferred()  # (nothing was enqueued: no pairs)
         release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())
         _hostlog("all batches enqueued")
