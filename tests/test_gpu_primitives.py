@@ -531,7 +531,7 @@ def test_fused_fp64_binning_packed_counters_match_the_32_bit_kernel(monkeypatch)
     c.close()
 
 
-@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (384, 40), (100, 9)])
+@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (384, 40), (100, 9), (24, 3), (101, 5), (450, 30)])
 def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
     """gd_density2d: the convolutions through LDS transforms (k_rows_fwd / k_col_conv / k_rows_inv) against the same call
     through rocFFT frames (GDHIP_CONV_ROCFFT=1), on random histograms with bounded and unbounded pairs, linear boundary
@@ -548,7 +548,7 @@ def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
         sx, sy = r.uniform(0.05, 0.2, 2) * F
         lam = 3000.0 * np.exp(-0.5 * (((xx - cx) / sx) ** 2 + ((yy - cy) / sy) ** 2))
         hists[b] = r.poisson(lam).astype(np.float64)
-    smooth = r.uniform(2.0, wmax / 2.5, B)
+    smooth = r.uniform(min(2.0, 0.5 * wmax / 2.5), wmax / 2.5, B)
     rx = smooth * r.uniform(0.6, 1.0, B)
     ry = smooth * r.uniform(0.6, 1.0, B)
     rx[0] = ry[0] = wmax / 2.5  # one pair at the widest window of the class
