@@ -1,10 +1,12 @@
 // 2D density assembly on the device for a batch of pairs sharing the fine grid size F
-// (mcsamples.py:1857-1990): Gaussian window synthesis, zero-padded linear convolution through rocFFT,
-// linear boundary correction, multiplicative bias correction, max-normalisation.
+// (mcsamples.py:1857-1990): Gaussian window synthesis, zero-padded linear convolution, linear boundary correction,
+// multiplicative bias correction, max-normalisation.  The convolutions run through hand-written transforms in LDS
+// (k_rows_fwd / k_win_spec / k_col_conv / k_rows_inv below); frames above 512, explicit prior masks and periodic axes
+// take the older route through rocFFT frames (fft.hip).
 //
-// Frame convention: every operand lives in an S x S real frame (S >= F + 2*winw, FFT-friendly).  The
-// (F+2w)^2 prior mask sits at the frame origin, the F^2 histogram at offset (w,w), and each window is
-// stored centred-with-wrap, so that one circular convolution gives the reference's 'same' result for
+// Frame convention (both routes): every operand lives in an S x S real frame (S >= F + 2*winw on a ladder of
+// transform-friendly sizes).  The (F+2w)^2 prior mask sits at the frame origin, the F^2 histogram at offset (w,w), and
+// each window is stored centred-with-wrap, so that one circular convolution gives the reference's 'same' result for
 // the histogram and its 'valid' result for the mask at frame positions [w, F+w)^2 (convolve.py:405-444).
 #include "ctx.hpp"
 

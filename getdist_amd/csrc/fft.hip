@@ -1,6 +1,7 @@
 // rocFFT plumbing: cached batched 2D real<->hermitian plans on the ctx stream.
-// rocFFT is used for the convolution step (and the 256^2 power spectrum of the 2D bandwidth optimiser)
-// only; everything around it is hand-written HIP.
+// rocFFT serves the 256^2 power spectrum of the 2D bandwidth optimiser, the public getdist.convolve functions
+// (convolve.hip) and the frame route of the 2D convolution (frames above 512, explicit masks, periodic axes); the
+// batched triangle's convolutions run through the LDS transforms of density2d.hip.
 #include <rocfft/rocfft.h>
 
 #include <mutex>
