@@ -182,6 +182,7 @@ void gd_destroy(gd_ctx* ctx) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
     if (ctx->stage_block) (void)hipHostFree(ctx->stage_block);
+    if (ctx->fetch_block) (void)hipHostFree(ctx->fetch_block);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamSynchronize(ctx->copy_stream);
