@@ -2598,6 +2598,17 @@ class MCSamples:
                 and any(names[j].N_eff_kde is None for j in used)):
             neff_f = self._helper().submit(self._neff_batch, used)
         _hostlog("lane: pairs indexed, N_eff submitted")
+        # (binmin, binmax) per parameter: _bin_edges for all parameters at once (they do not depend on the grid size)
+        bmin_t, bmax_t = self._bin_edge_arrays(used)
+        early_prebin = None
+        if (neff_f is not None and base_F == 256 and self.weights is None and len(pa) >= 128
+                and hasattr(ctx, "hist2d_prebinned8") and os.environ.get("GETDIST_AMD_U8", "1") == "1"):
+            # the byte index columns of the base grid need nothing but these edges: their launch goes out on the second
+            # context before the per-pair scalars below are worked out (binning() finds them made)
+            twin = self._second_lane()
+            self._nlanes = 1
+            fw256 = (bmax_t - bmin_t) / 255
+            early_prebin = self._lane_thread(twin).submit(twin._index_columns8, {j: (bmin_t[j], fw256[j]) for j in used})
         corrmat = self.getCorrelationMatrix()
         # ---- per-pair scalars (mcsamples.py:1794-1822); bin edges depend on (parameter, F) only
         # vectorised over the pairs: the correlation handling, angle_scale and the grid up-scaling (mcsamples.py:1796-1816)
@@ -2614,9 +2625,7 @@ class MCSamples:
         F_v = np.where((corr_v != 0) & (base_F < scaled) & ((1 / angle_scale).astype(np.int64) > 1), scaled, base_F)
         pj, pj2, pF = jx.tolist(), jy.tolist(), [int(f) for f in F_v.tolist()]
         _hostlog("lane: grid sizes")
-        # (fine width, binmin, binmax) per (parameter, F): _bin_edges for all parameters at once -- binmin / binmax do
-        # not depend on F -- and the table of widths per grid size
-        bmin_t, bmax_t = self._bin_edge_arrays(used)
+        # (fine width, binmin, binmax) per (parameter, F): the table of widths per grid size
         F_list = list(dict.fromkeys(pF))
         fw_t = {F: (bmax_t - bmin_t) / (F - 1) for F in F_list}
         edge_of = {(j, F): (fw_t[F][j], bmin_t[j], bmax_t[j])
@@ -2711,6 +2720,8 @@ class MCSamples:
                         shear = shear_f.result()
                 finally:
                     pending.result()
+                    if early_prebin is not None:
+                        early_prebin.result()
             else:
                 self._neff_batch(used)
                 pending = self._helper().submit(binning)  # the helper thread is inside this context's entry points
