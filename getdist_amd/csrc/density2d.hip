@@ -564,6 +564,8 @@ __global__ void k_box(const double* __restrict__ hist, const double* __restrict_
 struct FftDev {
     int S, nst;
     int radix[12];
+    unsigned int magic[12];  // ceil(2^20 / Ns) of pass st (Ns = product of the earlier radices): j / Ns = (j * magic) >> 20
+                             // exactly for j < 512 -- the passes are VALU-bound and a runtime division costs ~40 instructions
 };
 
 // The FT lanes of a transform sit inside one wavefront, whose LDS operations execute in order: passes are separated by a
@@ -573,29 +575,31 @@ __device__ __forceinline__ void group_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// complex product with explicit fused multiply-adds (the library is built with -ffp-contract=off for the kernels whose
+// results must match numpy's operation by operation; these transforms are VALU-bound and have no such twin)
 __device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
 
 // One in-place Stockham pass of radix R over the length-S sequence in `buf`; MAXIT >= ceil(S / R / FT) butterflies per
 // lane.  `emit(pos, value)` receives the outputs after the group has read all its inputs (default: store to buf).
 // tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its stride.
 template <int R, int MAXIT, class Emit>
-__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns, int t,
-                                         bool inv, bool active, Emit emit) {
-    const int nb = S / R, step = S / (Ns * R);
+__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns,
+                                         unsigned int magic, int nb, int t, bool inv, bool active, Emit emit) {
+    const int step = (nb / Ns) * tws;  // S / (Ns R) twiddle-table entries per unit of q k
     double2 o[MAXIT][R];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int j = t + it * FT;
         if (active && j < nb) {
-            const int k = j % Ns;
+            const int k = j - (int)(((unsigned int)j * magic) >> 20) * Ns;  // j % Ns
             double2 v[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 double2 x = buf[j + q * nb];
                 if (q > 0 && k > 0) {
-                    double2 w = tw[q * k * step * tws];
+                    double2 w = tw[q * k * step];
                     if (inv) w.y = -w.y;
                     x = cmulf(x, w);
                 }
@@ -628,8 +632,8 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
                         const int m = (p * q) % R;
                         const double c = R == 3 ? C3[m] : C5[m];
                         const double sn = (R == 3 ? S3[m] : S5[m]) * (inv ? 1.0 : -1.0);  // e^{-+ 2 pi i m / R}
-                        acc.x += v[q].x * c - v[q].y * sn;
-                        acc.y += v[q].x * sn + v[q].y * c;
+                        acc.x = fma(v[q].x, c, fma(-v[q].y, sn, acc.x));
+                        acc.y = fma(v[q].x, sn, fma(v[q].y, c, acc.y));
                     }
                     o[it][p] = acc;
                 }
@@ -641,7 +645,8 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
     for (int it = 0; it < MAXIT; ++it) {
         const int j = t + it * FT;
         if (active && j < nb) {
-            const int j0 = (j / Ns) * Ns * R + j % Ns;
+            const int jq = (int)(((unsigned int)j * magic) >> 20);  // j / Ns
+            const int j0 = jq * Ns * (R - 1) + j;                   // (j / Ns) Ns R + j % Ns
 #pragma unroll
             for (int q = 0; q < R; ++q) emit(j0 + q * Ns, o[it][q]);
         }
@@ -651,12 +656,14 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
 
 // butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
 template <bool BIG, class Emit>
-__device__ __forceinline__ void fft_pass_any(int R, double2* buf, const double2* tw, int tws, int S, int Ns, int t, bool inv,
-                                             bool active, Emit emit) {
-    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, tws, S, Ns, t, inv, active, emit);
-    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, tws, S, Ns, t, inv, active, emit);
-    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, tws, S, Ns, t, inv, active, emit);
-    else fft_pass<5, BIG ? 4 : 2>(buf, tw, tws, S, Ns, t, inv, active, emit);
+__device__ __forceinline__ void fft_pass_any(const FftDev& pl, int st, double2* buf, const double2* tw, int tws, int Ns, int t,
+                                             bool inv, bool active, Emit emit) {
+    const int R = pl.radix[st], S = pl.S;
+    const unsigned int mg = pl.magic[st];
+    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, tws, S, Ns, mg, S >> 2, t, inv, active, emit);
+    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, tws, S, Ns, mg, S >> 1, t, inv, active, emit);
+    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, tws, S, Ns, mg, S / 3, t, inv, active, emit);
+    else fft_pass<5, BIG ? 4 : 2>(buf, tw, tws, S, Ns, mg, S / 5, t, inv, active, emit);
 }
 
 // all passes but the last; returns the sub-transform length the last pass starts from
@@ -664,9 +671,8 @@ template <bool BIG>
 __device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
     int Ns = 1;
     for (int st = 0; st + 1 < pl.nst; ++st) {
-        const int R = pl.radix[st];
-        fft_pass_any<BIG>(R, buf, tw, tws, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
-        Ns *= R;
+        fft_pass_any<BIG>(pl, st, buf, tw, tws, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+        Ns *= pl.radix[st];
     }
     return Ns;
 }
@@ -674,7 +680,7 @@ __device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws
 template <bool BIG>
 __device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
     const int Ns = fft_head<BIG>(buf, tw, tws, pl, t, inv, active);
-    fft_pass_any<BIG>(pl.radix[pl.nst - 1], buf, tw, tws, pl.S, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+    fft_pass_any<BIG>(pl, pl.nst - 1, buf, tw, tws, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
 }
 
 // grid (ceil(F / RPB), B), RPB * 32 threads = RPB (16) rows of pair b per block: the transposed store then writes 256-byte
@@ -728,11 +734,11 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
             // X[k] = ((zk + conj zm) - i w^k (zk - conj zm)) / 2,  w = e^{-2 pi i / S}
             const double ax = zk.x + zm.x, ay = zk.y - zm.y, bx = zk.x - zm.x, by = zk.y + zm.y;
             const double2 e = tw[k];
-            const double u = e.x * bx - e.y * by, v = e.x * by + e.y * bx;
+            const double u = fma(e.x, bx, -(e.y * by)), v = fma(e.x, by, e.y * bx);
             out[(int64_t)k * F] = make_double2(0.5 * (ax + v), 0.5 * (ay - u));
             if (2 * k < H) {  // X[H - k] from the same two values (roles exchanged, w^(H - k))
                 const double2 f = tw[H - k];
-                const double u2 = f.x * (-bx) - f.y * by, v2 = f.x * by + f.y * (-bx);
+                const double u2 = -fma(f.x, bx, f.y * by), v2 = fma(f.x, by, -(f.y * bx));
                 out[(int64_t)(H - k) * F] = make_double2(0.5 * (ax + v2), 0.5 * (-ay - u2));
             }
         }
@@ -745,7 +751,7 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
 template <bool BIG>
 __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, FftDev pl,
                                                   const double2* __restrict__ twg, int px, int py, int maxw,
-                                                  double2* __restrict__ Wt) {
+                                                  double* __restrict__ Wt) {
     extern __shared__ double2 sh2[];
     const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
     const D2Pair p = pairs[b];
@@ -783,7 +789,7 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
                 int ph = (int)(((int64_t)kx * (S - w + c0)) % S);  // x offset c0 - w: e^{-2 pi i kx (c0 - w) / S}
                 for (int c = c0; c < c1; ++c) {
                     const double2 e = tw[ph];
-                    acc.x += row[c] * e.x, acc.y += row[c] * e.y;
+                    acc.x = fma(row[c], e.x, acc.x), acc.y = fma(row[c], e.y, acc.y);
                     ph += kx;
                     if (ph >= S) ph -= S;
                 }
@@ -798,8 +804,11 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
     group_sync();
     fft_full<BIG>(bw, tw, 1, pl, t, false, active);
     if (active) {
-        double2* col = Wt + ((int64_t)b * Sh + kx) * S;
-        for (int idx = t; idx < S; idx += FT) col[idx] = bw[idx];
+        // the window is even, so the spectrum of an even moment (px + py even) is real and that of an odd one imaginary:
+        // one double per entry, the other part is rounding noise of the sums
+        double* col = Wt + ((int64_t)b * Sh + kx) * S;
+        const bool odd = (px + py) & 1;
+        for (int idx = t; idx < S; idx += FT) col[idx] = odd ? bw[idx].y : bw[idx].x;
     }
 }
 
@@ -807,7 +816,7 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
 // multiply by the window's spectrum in the last pass (scaled), inverse transform, keep the F rows of the crop.
 template <bool BIG>
 __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pairs, int F, FftDev pl, const double2* __restrict__ twg,
-                                                  const double2* __restrict__ Wt, const double2* __restrict__ Xt,
+                                                  const double* __restrict__ Wt, int w_odd, const double2* __restrict__ Xt,
                                                   double2* __restrict__ Yt) {
     extern __shared__ double2 sh2[];
     const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
@@ -829,10 +838,10 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
     group_sync();
     const int Ns = fft_head<BIG>(bh, tw, 1, pl, t, false, active);
     const double scale = 1.0 / ((double)S * (double)S);
-    const double2* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;
-    fft_pass_any<BIG>(pl.radix[pl.nst - 1], bh, tw, 1, S, Ns, t, false, active, [&](int pos, double2 v) {
-        const double2 m = cmulf(v, wcol[pos]);
-        bh[pos] = make_double2(m.x * scale, m.y * scale);
+    const double* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;  // real part (even moment) or imaginary part (odd)
+    fft_pass_any<BIG>(pl, pl.nst - 1, bh, tw, 1, Ns, t, false, active, [&](int pos, double2 v) {
+        const double ws = wcol[pos] * scale;
+        bh[pos] = w_odd ? make_double2(-v.y * ws, v.x * ws) : make_double2(v.x * ws, v.y * ws);
     });
     fft_full<BIG>(bh, tw, 1, pl, t, true, active);
     if (active) {
@@ -873,11 +882,11 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
             // Z[k] = (xk + conj xm) + i conj(w^k) (xk - conj xm)
             const double ax = xk.x + xm.x, ay = xk.y - xm.y, bx = xk.x - xm.x, by = xk.y + xm.y;
             const double2 e = tw[k];  // w^k = (e.x, e.y); conj: (e.x, -e.y)
-            const double u = e.x * bx + e.y * by, v = e.x * by - e.y * bx;  // conj(w^k) * (bx, by)
+            const double u = fma(e.x, bx, e.y * by), v = fma(e.x, by, -(e.y * bx));  // conj(w^k) * (bx, by)
             buf[k] = make_double2(ax - v, ay + u);
             if (2 * k < H) {
                 const double2 f = tw[H - k];
-                const double u2 = f.x * (-bx) + f.y * by, v2 = f.x * by - f.y * (-bx);
+                const double u2 = fma(f.y, by, -(f.x * bx)), v2 = fma(f.x, by, f.y * bx);
                 buf[H - k] = make_double2(ax - v2, -ay + u2);
             }
         }
@@ -928,6 +937,7 @@ static bool lds_fft_plan(gd_ctx* ctx, int S, FftDev* pl, const double2** tw) {
     for (int q = 0; q < 4; ++q)
         while (n % order[q] == 0 && pl->nst < 12) pl->radix[pl->nst++] = order[q], n /= order[q];
     if (n != 1 || pl->nst == 0) return false;
+    for (int st = 0, Ns = 1; st < pl->nst; Ns *= pl->radix[st], ++st) pl->magic[st] = (unsigned int)(((1u << 20) + Ns - 1) / Ns);
     if (!tw) return true;  // plan only (the rows' half-length transforms use the frame's table with stride 2)
     auto it = ctx->fft_tw.find(S);
     if (it == ctx->fft_tw.end()) {
@@ -1158,7 +1168,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
                           getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw) &&
                           lds_fft_plan(ctx, S / 2, &plH, nullptr);
     const int64_t XT = (int64_t)B * Sh * F * 16;  // transposed half spectra of the LDS route
-    const int64_t WT = (int64_t)B * Sh * S * 16;  // a window moment's spectrum by columns
+    const int64_t WT = (int64_t)B * Sh * S * 8;  // a window moment's spectrum by columns (its real or its imaginary part)
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_mx2 = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_RF = take(lds_conv ? XT : B * SS * 8), o_RO = take(lds_conv ? XT : B * SS * 8),
@@ -1219,10 +1229,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     // ---- LDS route: launches.  ZW's block holds the plain window's spectrum by columns (kept for the bias-correction
     //      round), ZH's block the moment windows' one after the other.
     const bool big = S > 320;  // size class of the transforms (butterflies per lane)
-    double2* Wt0 = (double2*)ZW;
-    double2* Wt1 = (double2*)ZH;
+    double* Wt0 = (double*)ZW;
+    double* Wt1 = (double*)ZH;
     // the window moment's spectrum
-    auto lds_win_spec = [&](int px_, int py_, double2* WT_) -> int {
+    auto lds_win_spec = [&](int px_, int py_, double* WT_) -> int {
         auto kern = big ? k_win_spec<true> : k_win_spec<false>;
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         kern<<<gC, 256, lds_win, ctx->stream>>>(d_pairs, d_wsum, pl, d_tw, px_, py_, maxw, WT_);
@@ -1238,10 +1248,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         return GD_OK;
     };
     // convolution of the source in Xt with the window spectrum WT_, cropped into dst (update: dst *= crop / a00)
-    auto lds_conv_to = [&](const double2* WT_, bool update, double* dst, const double* a00_, double* mxp) -> int {
+    auto lds_conv_to = [&](const double* WT_, int w_odd, bool update, double* dst, const double* a00_, double* mxp) -> int {
         auto kc = big ? k_col_conv<true> : k_col_conv<false>;
         GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
-        kc<<<gC, 256, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, Xt, Yt);
+        kc<<<gC, 256, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, w_odd, Xt, Yt);
         GD_KERNEL_CHECK();
         auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
         GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
@@ -1252,7 +1262,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     if (lds_conv) {
         GD_TRY(lds_rows_fwd(false, nullptr, nullptr));
         GD_TRY(lds_win_spec(0, 0, Wt0));
-        GD_TRY(lds_conv_to(Wt0, false, d_P, nullptr, d_mx));
+        GD_TRY(lds_conv_to(Wt0, 0, false, d_P, nullptr, d_mx));
     } else {
         // spectra of the window and of the histogram
         k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 0, 0, RF);
@@ -1306,9 +1316,9 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         if (bco == 1 && lds_conv) {
             // x*P and y*P still need the histogram: conv(histbins, Win*x), conv(histbins, Win*y)  (mcsamples.py:1940-1941)
             GD_TRY(lds_win_spec(1, 0, Wt1));
-            GD_TRY(lds_conv_to(Wt1, false, A.xP, nullptr, nullptr));
+            GD_TRY(lds_conv_to(Wt1, 1, false, A.xP, nullptr, nullptr));
             GD_TRY(lds_win_spec(0, 1, Wt1));
-            GD_TRY(lds_conv_to(Wt1, false, A.yP, nullptr, nullptr));
+            GD_TRY(lds_conv_to(Wt1, 1, false, A.yP, nullptr, nullptr));
         } else if (bco == 1) {
             k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, 1, 0, RF);
             GD_KERNEL_CHECK();
@@ -1328,7 +1338,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             if (lds_conv) {
                 // bins2D *= conv(box, Win) / a00: the box is formed in the row pass, the update in the inverse row pass
                 GD_TRY(lds_rows_fwd(true, d_P, mx_cur));
-                GD_TRY(lds_conv_to(Wt0, true, d_P, d_a00m, mx_cur));
+                GD_TRY(lds_conv_to(Wt0, 0, true, d_P, d_a00m, mx_cur));
                 continue;
             }
             k_fill_box<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_hist, d_P, mx_cur, F, S, RF);
