@@ -582,25 +582,28 @@ __device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
 }
 
 // One in-place Stockham pass of radix R over the length-S sequence in `buf`; MAXIT >= ceil(S / R / FT) butterflies per
-// lane.  `emit(pos, value)` receives the outputs after the group has read all its inputs (default: store to buf).
-// tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its stride.
-template <int R, int MAXIT, class Emit>
+// lane; INV: inverse transform (conjugate twiddles).  `emit(pos, value)` receives the outputs after the group has read all
+// its inputs (default: store to buf).  tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its
+// stride.  Groups without work run the passes on their (unused) buffer like the others -- the passes are VALU-bound and a
+// per-lane `active` test in every butterfly costs more than the idle arithmetic of the last block of a grid.
+template <int R, int MAXIT, bool INV, class Emit>
 __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns,
-                                         unsigned int magic, int nb, int t, bool inv, bool active, Emit emit) {
+                                         unsigned int magic, int nb, int t, Emit emit) {
     const int step = (nb / Ns) * tws;  // S / (Ns R) twiddle-table entries per unit of q k
+    const bool twiddles = Ns > 1;      // (wave-uniform) the first pass has none
     double2 o[MAXIT][R];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int j = t + it * FT;
-        if (active && j < nb) {
+        if (j < nb) {
             const int k = j - (int)(((unsigned int)j * magic) >> 20) * Ns;  // j % Ns
             double2 v[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 double2 x = buf[j + q * nb];
-                if (q > 0 && k > 0) {
+                if (q > 0 && twiddles) {
                     double2 w = tw[q * k * step];
-                    if (inv) w.y = -w.y;
+                    if (INV) w.y = -w.y;
                     x = cmulf(x, w);
                 }
                 v[q] = x;
@@ -612,12 +615,22 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
                 const double2 t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
                 const double2 t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y);
                 const double2 d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
-                const double2 t3 = inv ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) : d * (-i)
+                const double2 t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) : d * (-i)
                 o[it][0] = make_double2(t0.x + t2.x, t0.y + t2.y);
                 o[it][1] = make_double2(t1.x + t3.x, t1.y + t3.y);
                 o[it][2] = make_double2(t0.x - t2.x, t0.y - t2.y);
                 o[it][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
-            } else {  // small DFT by its definition; cos / sin of 2 pi m / R as literals (R = 3, 5)
+            } else if (R == 3) {
+                // o0 = v0 + (v1 + v2);  o1, o2 = v0 - (v1 + v2) / 2  -+ i sin(60) (v1 - v2)   (forward; + - for the inverse)
+                constexpr double SIN60 = 0.86602540378443864676;
+                const double2 sm = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), df = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
+                const double2 md = make_double2(fma(-0.5, sm.x, v[0].x), fma(-0.5, sm.y, v[0].y));
+                // -i s df = (s df.y, -s df.x) forward;  +i s df = (-s df.y, s df.x) inverse
+                const double rx = (INV ? -SIN60 : SIN60) * df.y, ry = (INV ? SIN60 : -SIN60) * df.x;
+                o[it][0] = make_double2(v[0].x + sm.x, v[0].y + sm.y);
+                o[it][1] = make_double2(md.x + rx, md.y + ry);
+                o[it][2] = make_double2(md.x - rx, md.y - ry);
+            } else {  // small DFT by its definition; cos / sin of 2 pi m / R as literals (R = 5)
                 constexpr double C3[3] = {1.0, -0.5, -0.5};
                 constexpr double S3[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
                 constexpr double C5[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410,
@@ -631,7 +644,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
                     for (int q = 1; q < R; ++q) {
                         const int m = (p * q) % R;
                         const double c = R == 3 ? C3[m] : C5[m];
-                        const double sn = (R == 3 ? S3[m] : S5[m]) * (inv ? 1.0 : -1.0);  // e^{-+ 2 pi i m / R}
+                        const double sn = (R == 3 ? S3[m] : S5[m]) * (INV ? 1.0 : -1.0);  // e^{-+ 2 pi i m / R}
                         acc.x = fma(v[q].x, c, fma(-v[q].y, sn, acc.x));
                         acc.y = fma(v[q].x, sn, fma(v[q].y, c, acc.y));
                     }
@@ -644,7 +657,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int j = t + it * FT;
-        if (active && j < nb) {
+        if (j < nb) {
             const int jq = (int)(((unsigned int)j * magic) >> 20);  // j / Ns
             const int j0 = jq * Ns * (R - 1) + j;                   // (j / Ns) Ns R + j % Ns
 #pragma unroll
@@ -655,32 +668,32 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
 }
 
 // butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
-template <bool BIG, class Emit>
+template <bool BIG, bool INV, class Emit>
 __device__ __forceinline__ void fft_pass_any(const FftDev& pl, int st, double2* buf, const double2* tw, int tws, int Ns, int t,
-                                             bool inv, bool active, Emit emit) {
+                                             Emit emit) {
     const int R = pl.radix[st], S = pl.S;
     const unsigned int mg = pl.magic[st];
-    if (R == 4) fft_pass<4, BIG ? 4 : 3>(buf, tw, tws, S, Ns, mg, S >> 2, t, inv, active, emit);
-    else if (R == 2) fft_pass<2, BIG ? 8 : 5>(buf, tw, tws, S, Ns, mg, S >> 1, t, inv, active, emit);
-    else if (R == 3) fft_pass<3, BIG ? 6 : 4>(buf, tw, tws, S, Ns, mg, S / 3, t, inv, active, emit);
-    else fft_pass<5, BIG ? 4 : 2>(buf, tw, tws, S, Ns, mg, S / 5, t, inv, active, emit);
+    if (R == 4) fft_pass<4, BIG ? 4 : 3, INV>(buf, tw, tws, S, Ns, mg, S >> 2, t, emit);
+    else if (R == 2) fft_pass<2, BIG ? 8 : 5, INV>(buf, tw, tws, S, Ns, mg, S >> 1, t, emit);
+    else if (R == 3) fft_pass<3, BIG ? 6 : 4, INV>(buf, tw, tws, S, Ns, mg, S / 3, t, emit);
+    else fft_pass<5, BIG ? 4 : 2, INV>(buf, tw, tws, S, Ns, mg, S / 5, t, emit);
 }
 
 // all passes but the last; returns the sub-transform length the last pass starts from
-template <bool BIG>
-__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
+template <bool BIG, bool INV>
+__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
     int Ns = 1;
     for (int st = 0; st + 1 < pl.nst; ++st) {
-        fft_pass_any<BIG>(pl, st, buf, tw, tws, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+        fft_pass_any<BIG, INV>(pl, st, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
         Ns *= pl.radix[st];
     }
     return Ns;
 }
 
-template <bool BIG>
-__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t, bool inv, bool active) {
-    const int Ns = fft_head<BIG>(buf, tw, tws, pl, t, inv, active);
-    fft_pass_any<BIG>(pl, pl.nst - 1, buf, tw, tws, Ns, t, inv, active, [&](int pos, double2 v) { buf[pos] = v; });
+template <bool BIG, bool INV>
+__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
+    const int Ns = fft_head<BIG, INV>(buf, tw, tws, pl, t);
+    fft_pass_any<BIG, INV>(pl, pl.nst - 1, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
 }
 
 // grid (ceil(F / RPB), B), RPB * 32 threads = RPB (16) rows of pair b per block: the transposed store then writes 256-byte
@@ -720,7 +733,7 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
         for (int n = t; n < H; n += FT) buf[n] = make_double2(value(2 * n), value(2 * n + 1));
     }
     group_sync();
-    fft_full<false>(buf, tw, 2, plH, t, false, active);
+    fft_full<false, false>(buf, tw, 2, plH, t);
     if (active) {
         double2* out = Xt + (int64_t)b * Sh * F + y;  // out[kx * F]
         for (int k = t; 2 * k <= H; k += FT) {
@@ -802,7 +815,7 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    fft_full<BIG>(bw, tw, 1, pl, t, false, active);
+    fft_full<BIG, false>(bw, tw, 1, pl, t);
     if (active) {
         // the window is even, so the spectrum of an even moment (px + py even) is real and that of an odd one imaginary:
         // one double per entry, the other part is rounding noise of the sums
@@ -836,14 +849,14 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    const int Ns = fft_head<BIG>(bh, tw, 1, pl, t, false, active);
+    const int Ns = fft_head<BIG, false>(bh, tw, 1, pl, t);
     const double scale = 1.0 / ((double)S * (double)S);
     const double* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;  // real part (even moment) or imaginary part (odd)
-    fft_pass_any<BIG>(pl, pl.nst - 1, bh, tw, 1, Ns, t, false, active, [&](int pos, double2 v) {
+    fft_pass_any<BIG, false>(pl, pl.nst - 1, bh, tw, 1, Ns, t, [&](int pos, double2 v) {
         const double ws = wcol[pos] * scale;
         bh[pos] = w_odd ? make_double2(-v.y * ws, v.x * ws) : make_double2(v.x * ws, v.y * ws);
     });
-    fft_full<BIG>(bh, tw, 1, pl, t, true, active);
+    fft_full<BIG, true>(bh, tw, 1, pl, t);
     if (active) {
         double2* col = Yt + ((int64_t)b * Sh + kx) * F;
         for (int r = t; r < F; r += FT) col[r] = bh[r + w];
@@ -892,7 +905,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    fft_full<false>(buf, tw, 2, plH, t, true, active);
+    fft_full<false, true>(buf, tw, 2, plH, t);
     double m = -INFINITY;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
