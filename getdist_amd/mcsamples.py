@@ -2776,16 +2776,8 @@ class MCSamples:
 
         # ---- convolution + corrections, batched per (F, bounded?, FFT frame size) class
         out = [None] * len(info)
-        axes = {}
         max_bytes = float(os.environ.get("GETDIST_AMD_BATCH_BYTES", 24e9))
         inflight = []  # (device grid buffer, pinned host array, pair indices, status)
-
-        def axis(par, lo, hi, F):
-            key = (par.name, F)
-            if key not in axes:
-                a = np.linspace(lo, hi, F)
-                axes[key] = (a, a[1] - a[0])
-            return axes[key]
 
         # per-pair flag bits, window half-widths and FFT frame sizes for all pairs at once.  Edge masks only on
         # non-periodic axes (mcsamples.py:1688-1703); bits 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic.
