@@ -710,3 +710,48 @@ def test_batched_call_leaves_no_reference_cycles_of_its_own(zoo):
         gc.garbage.clear()
         if was:
             gc.enable()
+
+
+def test_array_forms_of_the_host_decisions_equal_the_scalar_ones(zoo):
+    """What sits between two kernels is evaluated on arrays (bin edges of all parameters, the plan's side-car arrays, the
+    dealing of pairs by class): each must be the scalar code's result element by element."""
+    from getdist_amd import parallel
+
+    fx = zoo["block50"]
+    mc = make(fx)
+    mc.prepareParams()
+    names = mc.paramNames.names
+    js = list(range(mc.n))
+    bmin, bmax = mc._bin_edge_arrays(js)
+    for j in js:
+        for F in (256, 384, 960):
+            fw, lo, hi = mc._bin_edges(names[j], F)
+            assert lo == bmin[j] and hi == bmax[j] and fw == (bmax[j] - bmin[j]) / (F - 1)
+    pairs = [(i, j) for i in range(12) for j in range(i + 1, 12)]
+    corr = np.asarray(mc.getCorrelationMatrix())
+    ranges_xy = []
+    for a, b in pairs:
+        ea, eb = mc._bin_edges(names[a], 256), mc._bin_edges(names[b], 256)
+        ranges_xy.append((ea[2] - ea[1], eb[2] - eb[1]))
+    plan = mc._bandwidth_plan(pairs, [corr[b, a] for a, b in pairs], ranges_xy, 256)
+    arr = plan.arr
+    code = {"A": 0, "B": 1, "C": 2}
+    for k, e in enumerate(plan):
+        assert arr["branch"][k] == code[e["branch"]] and bool(arr["has_limits"][k]) == bool(e["has_limits"])
+        assert arr["corr"][k] == e["corr"] and arr["rangex"][k] == e["rangex"] and arr["rangey"][k] == e["rangey"]
+        assert arr["neff"][k] == e["neff"]
+        if e["branch"] == "C":
+            assert arr["fallback_t"][k] == e["fallback_t"]
+    # dealing by class on arrays == the per-pair key version
+    cls = (np.arange(len(pairs)) * 7919) % 5
+    for world in (2, 3, 8):
+        for rank in range(world):
+            a = parallel.partition_pairs_by_class(pairs, cls, world, rank)
+            b = parallel.partition_pairs(pairs, dict(zip(pairs, cls.tolist())).__getitem__, world, rank)
+            assert a[0] == b[0] and a[1] == b[1]
+    # index arrays and lists of names / indices give the same call
+    d_list = mc.get2DDensities(pairs[:9])
+    d_arr = mc.get2DDensities(np.array(pairs[:9]))
+    d_names = mc.get2DDensities([(names[a].name, names[b].name) for a, b in pairs[:9]])
+    for x, y, z in zip(d_list, d_arr, d_names):
+        assert np.array_equal(x.P, y.P) and np.array_equal(x.P, z.P)
