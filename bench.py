@@ -46,8 +46,8 @@ LDS_ROOF_FILE = os.path.join(ROOT, "profiles", "r03_lds_atomic_roof.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nsamples", type=int, default=10_000_000)
     ap.add_argument("--nparams", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
