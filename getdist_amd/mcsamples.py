@@ -1585,6 +1585,10 @@ class MCSamples:
     # batched 2D calls of this many pairs convolve their batches on two streams (below: not worth a second context's
     # plans and scratch; above: one batch fills the chip)
     CONV_TWO_STREAMS_PAIRS = (64, 400)
+    # large calls: the share of the base grid's pairs whose bandwidths are optimised first, so that their convolution
+    # (second stream) runs beside the optimisation of the rest
+    KOPT_FIRST_FRACTION = 0.5
+    KOPT_SPLIT_MIN = 256  # ... when the launch has at least this many pairs
     DIRECT_LAGS_MAX = 512  # beyond this many lags the length-2N FFT (gd_autoconvolve) is cheaper than lag sums
 
     def _autocov(self, col, mean, k0, nlags):
@@ -2335,7 +2339,8 @@ class MCSamples:
                                    base_F)
         return dict(d_rot=d_rot, r1s=r1s, r2s=r2s)
 
-    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order, shear=None, deferred=None):
+    def _bandwidth_2d(self, plan, hists_by_F, pair_F, base_F, mult_bias_correction_order, shear=None, deferred=None,
+                      on_chunk=None, first_fraction=None, more_deferred=None):
         """
         getAutoBandwidth2D for a batch (mcsamples.py:1325-1419).  ``hists_by_F``: F -> (device buffer of that class's
         histograms, list of plan indices in buffer order); ``pair_F[k]`` the fine grid size of plan entry k.  Returns the
@@ -2344,6 +2349,11 @@ class MCSamples:
         unit conversions, on arrays over the pairs: this code sits between the optimiser's kernels and the convolution's.
         The per-pair records (``plan[k]["kopt"]``) are written by a callable appended to ``deferred`` (the caller runs it
         once the next kernels are enqueued), or at once when ``deferred`` is None.
+
+        ``on_chunk(ks, last, W)`` is called after every optimiser launch with the plan indices whose triples are final
+        (rule-of-thumb pairs ride with the first launch); with ``first_fraction`` the base grid's launch is cut in two at
+        that fraction of its pairs, so that the caller can convolve the first part (on another stream) while the second
+        part is being optimised.
         """
         npair = len(plan)
         ctx = self.ctx
@@ -2352,16 +2362,33 @@ class MCSamples:
         kopt_rows = []  # (plan indices, optimiser output rows) per launch
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order
         branch = arr["branch"]
+        if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416); few distinct N_eff values, each
+            # scale a Python-float power as before
+            uniq, inv = np.unique(arr["neff"], return_inverse=True)
+            widen = np.array([1.1 * ne ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m))) for ne in uniq.tolist()])[inv]
+        else:
+            widen = None
 
         # -- branch A: sheared re-binning at base_F, optimiser with corr=0 and no fallback_t
         A = np.nonzero(branch == 0)[0]
         if shear is None:
             shear = self._shear_histograms(plan, base_F)
         # -- branch B: rule of thumb
-        for k in np.nonzero(branch == 1)[0].tolist():
+        kB = np.nonzero(branch == 1)[0]
+        for k in kB.tolist():
             e = plan[k]
             c = max(min(e["corr"], self.max_corr_2D), -self.max_corr_2D)
             W[k] = (e["parx"].sigma_range / e["neff"] ** (1.0 / 6), e["pary"].sigma_range / e["neff"] ** (1.0 / 6), c)
+        waiting = [kB]  # final triples not yet reported to on_chunk
+
+        def report(ks, last):
+            ks = np.concatenate(waiting + [ks]) if waiting else ks
+            waiting.clear()
+            if widen is not None:
+                W[ks, 0] *= widen[ks]
+                W[ks, 1] *= widen[ks]
+            if on_chunk is not None and (len(ks) or last):
+                on_chunk(ks, last, W)
 
         def optimise(F, d_batch, ks, row_A, r1, r2):
             """One device-optimiser launch over plan entries ``ks`` (batch order); ``row_A`` marks the sheared rows,
@@ -2408,38 +2435,7 @@ class MCSamples:
         nA = len(A)
         r1s = np.asarray(shear["r1s"], dtype=np.float64) if nA else None
         r2s = np.asarray(shear["r2s"], dtype=np.float64) if nA else None
-        merged = False
-        for F, (d_hist, members) in hists_by_F.items():
-            mem = np.asarray(members, dtype=np.int64)
-            pos_C = np.nonzero(branch[mem] == 2)[0]
-            if F == base_F and nA and len(pos_C):
-                d_all = ctx.alloc((nA + len(pos_C)) * item)
-                ctx.gather_items(d_all, shear["d_rot"], np.arange(nA, dtype=np.int32), item)
-                ctx.gather_items(d_all, d_hist, pos_C, item, dst_offset=nA)
-                optimise(F, d_all, np.concatenate([A, mem[pos_C]]), np.arange(nA + len(pos_C)) < nA, r1s, r2s)
-                d_all.free()
-                merged = True
-                continue
-            if not len(pos_C):
-                continue
-            if len(pos_C) == len(mem):
-                d_sub, own = d_hist, False
-            else:
-                d_sub, own = ctx.alloc(len(pos_C) * F * F * 8), True
-                self._gather_device(d_hist, d_sub, pos_C, F * F * 8)
-            optimise(F, d_sub, mem[pos_C], np.zeros(len(pos_C), dtype=bool), None, None)
-            if own:
-                d_sub.free()
-        if nA and not merged:
-            optimise(base_F, shear["d_rot"], A, np.ones(nA, dtype=bool), r1s, r2s)
-        if shear is not None:
-            shear["d_rot"].free()
-        if m:  # higher-order bias correction widens the kernel (mcsamples.py:1412-1416); few distinct N_eff values, each
-            # scale a Python-float power as before
-            uniq, inv = np.unique(arr["neff"], return_inverse=True)
-            scale = np.array([1.1 * ne ** (1.0 / 6 - 1.0 / (2 + 4 * (1 + m))) for ne in uniq.tolist()])[inv]
-            W[:, 0] *= scale
-            W[:, 1] *= scale
+        launches = []  # callables (last) -> None, in launch order
 
         def book():
             for e in plan:
@@ -2448,10 +2444,71 @@ class MCSamples:
                 for k, row in zip(ks.tolist(), out):
                     plan[k]["kopt"] = row
 
+        if deferred is not None:  # queued before on_chunk enqueues anything: it runs when the caller drains the list
+            deferred.append(book)
+            if more_deferred is not None:
+                deferred.append(more_deferred)
+
+        def add_launch(F, build, ks, row_A, r1, r2):
+            def go(last):
+                d_batch, own = build()
+                try:
+                    optimise(F, d_batch, ks, row_A, r1, r2)
+                finally:
+                    if own:
+                        d_batch.free()
+                report(ks, last)
+
+            launches.append(go)
+
+        merged = False
+        for F, (d_hist, members) in hists_by_F.items():
+            mem = np.asarray(members, dtype=np.int64)
+            pos_C = np.nonzero(branch[mem] == 2)[0]
+            if F == base_F and len(pos_C):
+                cuts = [0, len(pos_C)]
+                if first_fraction and len(pos_C) >= self.KOPT_SPLIT_MIN:
+                    cuts = [0, int(len(pos_C) * first_fraction), len(pos_C)]
+                for part in range(len(cuts) - 1):
+                    pc = pos_C[cuts[part]:cuts[part + 1]]
+                    na = nA if part == 0 else 0  # the sheared pairs ride with the first part
+
+                    def build(pc=pc, na=na, d_hist=d_hist, whole=len(mem)):
+                        if na == 0 and len(pc) == whole:
+                            return d_hist, False  # the class's buffer as it is
+                        d_all = ctx.alloc((na + len(pc)) * item)
+                        if na:
+                            ctx.gather_items(d_all, shear["d_rot"], np.arange(na, dtype=np.int32), item)
+                        ctx.gather_items(d_all, d_hist, pc, item, dst_offset=na)
+                        return d_all, True
+
+                    add_launch(F, build, np.concatenate([A[:na], mem[pc]]), np.arange(na + len(pc)) < na, r1s if na else None,
+                               r2s if na else None)
+                merged = True
+                continue
+            if not len(pos_C):
+                continue
+
+            def build(pos_C=pos_C, mem=mem, d_hist=d_hist, F=F):
+                if len(pos_C) == len(mem):
+                    return d_hist, False
+                d_sub = ctx.alloc(len(pos_C) * F * F * 8)
+                self._gather_device(d_hist, d_sub, pos_C, F * F * 8)
+                return d_sub, True
+
+            add_launch(F, build, mem[pos_C], np.zeros(len(pos_C), dtype=bool), None, None)
+        if nA and not merged:
+            add_launch(base_F, lambda: (shear["d_rot"], False), A, np.ones(nA, dtype=bool), r1s, r2s)
+        try:
+            for q, go in enumerate(launches):
+                go(q == len(launches) - 1)
+            if not launches:
+                report(np.zeros(0, dtype=np.int64), True)
+        finally:
+            if shear is not None:
+                shear["d_rot"].free()
         if deferred is None:
             book()
-        else:
-            deferred.append(book)
         return W
 
     def _gather_device(self, d_src, d_dst, positions, item_bytes, ctx=None):
@@ -2734,53 +2791,18 @@ class MCSamples:
         else:
             build_info()
             binning()
-        # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
+        # ---- convolution set-up: everything that does not depend on the bandwidths
         _hostlog("binning / N_eff / plan joined")
         npair = len(info)
-        # Bookkeeping that no kernel waits for (per-pair records, log messages) is collected here and run once the first
-        # convolution batch has been enqueued: between the optimiser's last kernel and the convolution's first one the
-        # GPU is idle, so only what decides the window sizes is evaluated there, on arrays.
+        # Bookkeeping that no kernel waits for (per-pair records, log messages) is collected here and run once enough
+        # convolution batches are queued: between the optimiser's last kernel and the convolution's first one the GPU is
+        # idle, so only what decides the window sizes is evaluated there, on arrays.
         deferred = []
-        if smooth_scale_2D < 0:
-            if _bandwidths is not None:
-                wv = np.array(list(_bandwidths), dtype=np.float64).reshape(npair, 3)
-            else:
-                if plan is None:
-                    with _Phase(self, "2d.host_bandwidth_plan"):
-                        plan = self._bandwidth_plan(*plan_args())
-                with _Phase(self, "2d.bandwidth.device"):
-                    wv = self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred)
-
-                def book_plan(plan=plan):
-                    for e, pl in zip(info, plan):
-                        e["branch"], e["kopt"] = pl["branch"], pl["kopt"]
-
-                deferred.append(book_plan)
-            rx_v = wv[:, 0] * abs(smooth_scale_2D) / fwx_v
-            ry_v = wv[:, 1] * abs(smooth_scale_2D) / fwy_v
-            cc_v = wv[:, 2]
-
-            def book_widths():
-                for e, bw_k in zip(info, wv.tolist()):
-                    e["bandwidth"] = tuple(bw_k)
-
-            deferred.append(book_widths)
-        elif smooth_scale_2D < 1.0:
-            rx_v = smooth_scale_2D * np.array([e["parx"].err for e in info]) / fwx_v
-            ry_v = smooth_scale_2D * np.array([e["pary"].err for e in info]) / fwy_v
-            cc_v = np.array([e["corr"] for e in info], dtype=np.float64)
-        else:
-            rx_v = ry_v = np.array([smooth_scale_2D * e["F"] / e["nbin2D"] for e in info], dtype=np.float64)
-            cc_v = np.array([e["corr"] for e in info], dtype=np.float64)
-        rx, ry, cc = rx_v.tolist(), ry_v.tolist(), cc_v.tolist()
-
-        # ---- convolution + corrections, batched per (F, bounded?, FFT frame size) class
         out = [None] * len(info)
         max_bytes = float(os.environ.get("GETDIST_AMD_BATCH_BYTES", 24e9))
         inflight = []  # (device grid buffer, pinned host array, pair indices, status)
-
-        # per-pair flag bits, window half-widths and FFT frame sizes for all pairs at once.  Edge masks only on
-        # non-periodic axes (mcsamples.py:1688-1703); bits 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic.
+        # per-pair flag bits.  Edge masks only on non-periodic axes (mcsamples.py:1688-1703); bits 0/1 = x bot/top,
+        # 2/3 = y bot/top, 4/5 = x/y periodic.
         nmax = max(used) + 1
         lim_bits, per_bit, has_lim = np.zeros(nmax, np.int64), np.zeros(nmax, np.int64), np.zeros(nmax, bool)
         for j in used:
@@ -2790,147 +2812,24 @@ class MCSamples:
             has_lim[j] = bool(p_.has_limits)
         has_prior_v = has_lim[jx] | has_lim[jy] | (mask_function is not None)  # mcsamples.py:1794
         flags_v = lim_bits[jx] | (per_bit[jx] << 4) | (lim_bits[jy] << 2) | (per_bit[jy] << 5) | (has_prior_v.astype(np.int64) << 6)
-        smooth_v = np.maximum(rx_v, ry_v)
+        group_v = (flags_v & 48) * 2 + (has_prior_v & (bco >= 0))
+        # window scales in fine-grid units, window half-widths: filled as the bandwidths become known
+        rx_v, ry_v, cc_v = np.full(npair, np.nan), np.full(npair, np.nan), np.full(npair, np.nan)
+        smooth_v, winw_v = np.full(npair, np.nan), np.zeros(npair, dtype=np.int64)
+        wv = np.full((npair, 3), np.nan)
+
+        def set_scales(ks, rx_k, ry_k, cc_k):
+            rx_v[ks], ry_v[ks], cc_v[ks] = rx_k, ry_k, cc_k
+            smooth_v[ks] = np.maximum(rx_v[ks], ry_v[ks])
+            winw_v[ks] = np.maximum(1, np.rint(2.5 * smooth_v[ks]).astype(np.int64))  # max(1, int(round(2.5 * smooth_scale)))
+
         def warn_coarse():
             for k in np.nonzero(smooth_v < 2)[0].tolist():
                 logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", info[k]["parx"].name,
                                 info[k]["pary"].name)
 
         deferred.append(warn_coarse)
-        winw_v = np.maximum(1, np.rint(2.5 * smooth_v).astype(np.int64))  # max(1, int(round(2.5 * smooth_scale)))
-        group_v = (flags_v & 48) * 2 + (has_prior_v & (bco >= 0))
-        flags_l, winw_l = flags_v.tolist(), winw_v.tolist()
 
-        def run_deferred():
-            while deferred:
-                deferred.pop(0)()
-
-        def run_class(F, d_hist, members):
-            """Convolve the pairs of one grid-size class: a generator that returns control after every batch it has
-            enqueued, so that the caller can interleave the classes' batches."""
-            mem = np.asarray(members, dtype=np.int64)
-            # batches of a few hundred grids (default cap 320) keep the FFTs efficient and the D2H copy of batch k hidden behind the
-            # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
-            max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 320))))
-            batches = []
-            first_batch = int(os.environ.get("GETDIST_AMD_FIRST_BATCH", 128))
-            gk = group_v[mem]
-            frame = {w_: next_fft_size(F + 2 * w_) for w_ in np.unique(winw_v[mem]).tolist()}
-            S_v = np.array([frame[w_] for w_ in winw_v[mem].tolist()], dtype=np.int64)
-            for g_ in dict.fromkeys(gk.tolist()):  # groups in order of first appearance
-                in_g = np.nonzero(gk == g_)[0]
-                carry = []
-                sizes = np.unique(S_v[in_g]).tolist()  # sub-batches of equal FFT frame size S >= F + 2 winw (small classes merged upwards)
-                for q, S in enumerate(sizes):
-                    pos_S = in_g[S_v[in_g] == S]
-                    cur = carry + [(int(pos), members[pos]) for pos in pos_S.tolist()]
-                    if len(cur) < 24 and q + 1 < len(sizes):
-                        carry = cur
-                        continue
-                    carry = []
-                    # a short first batch starts the result copies early; from then on a batch's copy (PCIe) is shorter
-                    # than the next batch's kernels, so only the last batch's copy is exposed
-                    s0 = 0
-                    if not batches and len(cur) > first_batch:
-                        batches.append(cur[:first_batch])
-                        s0 = first_batch
-                    for s1 in range(s0, len(cur), max_batch):
-                        batches.append(cur[s1:s1 + max_batch])
-            if mask_function is not None:
-                batches = [[item] for b in batches for item in b]  # the callback edits one pair's mask at a time
-            for sel in batches:
-                if mask_function is not None:
-                    (pos, k), = sel
-                    e = info[k]
-                    if flags_l[k] & 48:
-                        raise NotImplementedError("mask_function on periodic parameters")
-                    w_ = winw_l[k]
-                    prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
-                    mask_function(e["xbinmin"] - w_ * e["fwx"], e["ybinmin"] - w_ * e["fwy"], e["fwx"], e["fwy"], prior_mask)
-                    e["mask"] = bool_mask = prior_mask[w_:-w_, w_:-w_] < 1e-8
-                    mask_bc = mask_mbc = None
-                    if bco >= 0:
-                        _set_edge_mask_2d(e["parx"], e["pary"], prior_mask, w_)
-                        mask_bc = prior_mask.copy()
-                    if mbc:
-                        _set_all_edge_mask_2d(prior_mask, w_)
-                        mask_mbc = prior_mask
-                    run_deferred()
-                    with _Phase(self, "2d.convolve"):
-                        d_P, status = ctx.density2d_masked(d_hist, pos, F, rx[k], ry[k], cc[k], w_,
-                                                           flags_l[k], bco, mbc, mask_bc, mask_mbc, bool_mask)
-                    levels = None
-                    if not get_density:
-                        ncontours = len(self.contours)
-                        if num_plot_contours:
-                            ncontours = min(num_plot_contours, ncontours)
-                        levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
-                    inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
-                    assemble_new()
-                    yield
-                    continue
-                # a small call (one rank's share of a triangle, a handful of pairs) cannot fill the chip with one
-                # batch's kernels: its batches go alternately to the streams of the two contexts and run side by side
-                if side_classes:
-                    bctx = conv_ctxs[1 if F in side_classes else 0]
-                else:
-                    bctx = conv_ctxs[batch_no[0] % len(conv_ctxs)]
-                batch_no[0] += 1
-                if bctx is ctx:
-                    main_no[0] += 1
-                if [pos for pos, _ in sel] == list(range(len(members))):
-                    d_sub, own = d_hist, False
-                else:
-                    d_sub, own = bctx.alloc(len(sel) * F * F * 8), True
-                    self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8, ctx=bctx)
-                ks = [k for _, k in sel]
-                with _Phase(self, "2d.convolve"):
-                    if enqueue_only:
-                        # returns once enqueued: the next batch is prepared, and at the end the result objects are
-                        # built, while this one computes; its status words land in page-locked memory
-                        status = status_all[status_at[0]:status_at[0] + len(sel)]
-                        status_at[0] += len(sel)
-                        d_P = bctx.density2d_enqueue(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                     [cc[k] for k in ks], [winw_l[k] for k in ks],
-                                                     [flags_l[k] for k in ks], bco, mbc, status)
-                    else:
-                        d_P, status = ctx.density2d(d_sub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                                    [cc[k] for k in ks], [winw_l[k] for k in ks],
-                                                    [flags_l[k] for k in ks], bco, mbc)
-                # the first batch is short (it starts the result copies early) and would be through before the
-                # bookkeeping: that runs once the second batch is queued behind it
-                if main_no[0] >= 2:
-                    run_deferred()
-                levels = None
-                if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
-                    ncontours = len(self.contours)
-                    if num_plot_contours:
-                        ncontours = min(num_plot_contours, ncontours)
-                    levels = bctx.contour_levels(d_P, len(sel), F, self.contours[:ncontours])
-                d_L = L = None
-                if meanlikes:
-                    if own:
-                        d_lsub = ctx.alloc(len(sel) * F * F * 8)
-                        self._gather_device(likehists[F], d_lsub, [pos for pos, _ in sel], F * F * 8)
-                    else:
-                        d_lsub = likehists[F]
-                    d_L, lstatus = ctx.likes2d(d_sub, d_lsub, len(sel), F, [rx[k] for k in ks], [ry[k] for k in ks],
-                                               [cc[k] for k in ks], [winw_l[k] for k in ks],
-                                               [flags_l[k] for k in ks], mbc)
-                    if own:
-                        d_lsub.free()
-                    if np.any(lstatus != 0):
-                        raise DensitiesError("no likelihood weight in any bin")
-                    L = d_L.to_host_async((len(sel), F, F))
-                if own:
-                    release.append(d_sub)  # freeing waits for the stream: after the last batch
-                # the copy runs on the copy stream while the next batch computes
-                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
-                if not self._timing and not deferred:
-                    assemble_new()
-                yield
-
-        _hostlog("bandwidths done")
         enqueue_only = (hasattr(ctx, "density2d_enqueue") and not self._timing and not meanlikes and mask_function is None
                         and os.environ.get("GETDIST_AMD_ASYNC_CONVOLVE", "1") == "1")
         release = []
@@ -2939,7 +2838,7 @@ class MCSamples:
         # flight: the grids' first reader (or the next batched call, or the collection of the results) completes them.
         lazy = (enqueue_only and get_density and hasattr(ctx, "copy_mark")
                 and os.environ.get("GETDIST_AMD_LAZY_RESULTS", "1") == "1")
-        conv_ctxs, batch_no, main_no = [ctx], [0], [0]
+        conv_ctxs, batch_no, main_no, widths_complete = [ctx], [0], [0], [True]
         # Second stream for the convolution.  A small call (one rank's share of a triangle) cannot fill the chip with one
         # batch's kernels: its batches alternate between the streams of the two contexts.  A large call keeps its main
         # grid class on this context and sends the few pairs of the up-scaled classes (large frames, a handful of grids
@@ -2950,10 +2849,9 @@ class MCSamples:
                 side_classes = {F_ for F_, (_, mem_) in hists.items() if len(mem_) < 64}
                 if len(side_classes) == len(hists):
                     side_classes = set()
-            if npair <= self.CONV_TWO_STREAMS_PAIRS[1] or side_classes:
-                nlanes = self._nlanes
-                conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
-                self._nlanes = nlanes
+            nlanes = self._nlanes
+            conv_ctxs.append(self._second_lane().ctx)  # idle by now: its binning has been joined
+            self._nlanes = nlanes
         completion = _PendingResults(ctx, inflight, release, conv_ctxs[1:]) if lazy else None  # shares the two lists filled below
         if lazy and self._pending_results is not None:
             # the previous call's copies landed long ago: its device blocks are handed back while this call's first
@@ -3016,17 +2914,226 @@ class MCSamples:
                     out[k] = dens
             assembled[0] = len(inflight)
 
-        _ph_asm = _Phase(self, "2d.host_assemble_results")
-        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one; classes that go to
-        # the second stream are queued there right after the main class's first batch
+        def run_deferred():
+            while deferred:
+                deferred.pop(0)()
+
+        def run_class(F, d_hist, members, only=None, force_ctx=None):
+            """Convolve the pairs of one grid-size class (``only``: a mask over the pair indices -- the members outside
+            it are left for a later call; ``force_ctx``: the context whose stream takes the batches): a generator that
+            returns control after every batch it has enqueued, so that the caller can interleave the classes' batches."""
+            mem = np.asarray(members, dtype=np.int64)
+            pos_all = np.arange(len(mem)) if only is None else np.nonzero(only[mem])[0]
+            if not len(pos_all):
+                return
+            # batches of a few hundred grids (default cap 320) keep the FFTs efficient and the D2H copy of batch k hidden behind the
+            # convolution of batch k+1; only the last (small) batch's copy is exposed at the end
+            max_batch = max(1, min(int(max_bytes // (F * F * 8 * 30)), int(os.environ.get("GETDIST_AMD_MAX_BATCH", 320))))
+            batches = []
+            first_batch = int(os.environ.get("GETDIST_AMD_FIRST_BATCH", 128))
+            gk = np.full(len(mem), -1, dtype=np.int64)
+            gk[pos_all] = group_v[mem[pos_all]]
+            frame = {w_: next_fft_size(F + 2 * w_) for w_ in np.unique(winw_v[mem[pos_all]]).tolist()}
+            S_v = np.zeros(len(mem), dtype=np.int64)
+            S_v[pos_all] = [frame[w_] for w_ in winw_v[mem[pos_all]].tolist()]
+            for g_ in dict.fromkeys(gk[pos_all].tolist()):  # groups in order of first appearance
+                in_g = np.nonzero(gk == g_)[0]
+                # sub-batches of equal frame size S >= F + 2 winw.  A pair's frame follows from its own window only (no
+                # merging of small sub-batches into the next size): its grid is then the same bit for bit in whatever
+                # call, share or chunk it is computed
+                for S in np.unique(S_v[in_g]).tolist():
+                    pos_S = in_g[S_v[in_g] == S]
+                    cur = [(int(pos), members[pos]) for pos in pos_S.tolist()]
+                    # a short first batch starts the result copies early; from then on a batch's copy (PCIe) is shorter
+                    # than the next batch's kernels, so only the last batch's copy is exposed
+                    s0 = 0
+                    if not batches and len(cur) > first_batch:
+                        batches.append(cur[:first_batch])
+                        s0 = first_batch
+                    for s1 in range(s0, len(cur), max_batch):
+                        batches.append(cur[s1:s1 + max_batch])
+            if mask_function is not None:
+                batches = [[item] for b in batches for item in b]  # the callback edits one pair's mask at a time
+            for sel in batches:
+                if mask_function is not None:
+                    (pos, k), = sel
+                    e = info[k]
+                    if int(flags_v[k]) & 48:
+                        raise NotImplementedError("mask_function on periodic parameters")
+                    w_ = int(winw_v[k])
+                    prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
+                    mask_function(e["xbinmin"] - w_ * e["fwx"], e["ybinmin"] - w_ * e["fwy"], e["fwx"], e["fwy"], prior_mask)
+                    e["mask"] = bool_mask = prior_mask[w_:-w_, w_:-w_] < 1e-8
+                    mask_bc = mask_mbc = None
+                    if bco >= 0:
+                        _set_edge_mask_2d(e["parx"], e["pary"], prior_mask, w_)
+                        mask_bc = prior_mask.copy()
+                    if mbc:
+                        _set_all_edge_mask_2d(prior_mask, w_)
+                        mask_mbc = prior_mask
+                    run_deferred()
+                    with _Phase(self, "2d.convolve"):
+                        d_P, status = ctx.density2d_masked(d_hist, pos, F, float(rx_v[k]), float(ry_v[k]), float(cc_v[k]), w_,
+                                                           int(flags_v[k]), bco, mbc, mask_bc, mask_mbc, bool_mask)
+                    levels = None
+                    if not get_density:
+                        ncontours = len(self.contours)
+                        if num_plot_contours:
+                            ncontours = min(num_plot_contours, ncontours)
+                        levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
+                    inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
+                    assemble_new()
+                    yield
+                    continue
+                # a small call (one rank's share of a triangle, a handful of pairs) cannot fill the chip with one
+                # batch's kernels: its batches go alternately to the streams of the two contexts and run side by side
+                if force_ctx is not None:
+                    bctx = force_ctx
+                elif side_classes or npair > self.CONV_TWO_STREAMS_PAIRS[1]:
+                    bctx = conv_ctxs[1 if F in side_classes else 0]
+                else:
+                    bctx = conv_ctxs[batch_no[0] % len(conv_ctxs)]
+                batch_no[0] += 1
+                if widths_complete[0] and (bctx is ctx or len(sel) >= 64):
+                    main_no[0] += 1
+                if [pos for pos, _ in sel] == list(range(len(members))):
+                    d_sub, own = d_hist, False
+                else:
+                    d_sub, own = bctx.alloc(len(sel) * F * F * 8), True
+                    self._gather_device(d_hist, d_sub, [pos for pos, _ in sel], F * F * 8, ctx=bctx)
+                ks = [k for _, k in sel]
+                ka = np.asarray(ks, dtype=np.int64)
+                with _Phase(self, "2d.convolve"):
+                    if enqueue_only:
+                        # returns once enqueued: the next batch is prepared, and at the end the result objects are
+                        # built, while this one computes; its status words land in page-locked memory
+                        status = status_all[status_at[0]:status_at[0] + len(sel)]
+                        status_at[0] += len(sel)
+                        d_P = bctx.density2d_enqueue(d_sub, len(sel), F, rx_v[ka], ry_v[ka], cc_v[ka], winw_v[ka], flags_v[ka],
+                                                     bco, mbc, status)
+                    else:
+                        d_P, status = ctx.density2d(d_sub, len(sel), F, rx_v[ka], ry_v[ka], cc_v[ka], winw_v[ka], flags_v[ka],
+                                                    bco, mbc)
+                # the first batch is short (it starts the result copies early) and would be through before the
+                # bookkeeping: that runs once every bandwidth is known and two more batches are queued
+                if main_no[0] >= 2:
+                    run_deferred()
+                levels = None
+                if not get_density:  # contour levels on the device while the grids are still resident (densities.py:19-56)
+                    ncontours = len(self.contours)
+                    if num_plot_contours:
+                        ncontours = min(num_plot_contours, ncontours)
+                    levels = bctx.contour_levels(d_P, len(sel), F, self.contours[:ncontours])
+                d_L = L = None
+                if meanlikes:
+                    if own:
+                        d_lsub = ctx.alloc(len(sel) * F * F * 8)
+                        self._gather_device(likehists[F], d_lsub, [pos for pos, _ in sel], F * F * 8)
+                    else:
+                        d_lsub = likehists[F]
+                    d_L, lstatus = ctx.likes2d(d_sub, d_lsub, len(sel), F, rx_v[ka], ry_v[ka], cc_v[ka], winw_v[ka], flags_v[ka], mbc)
+                    if own:
+                        d_lsub.free()
+                    if np.any(lstatus != 0):
+                        raise DensitiesError("no likelihood weight in any bin")
+                    L = d_L.to_host_async((len(sel), F, F))
+                if own:
+                    release.append(d_sub)  # freeing waits for the stream: after the last batch
+                # the copy runs on the copy stream while the next batch computes
+                inflight.append((d_P, d_P.to_host_async((len(sel), F, F)), ks, status, d_L, L, levels))
+                if not self._timing and not deferred:
+                    assemble_new()
+                yield
+
+        # largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
         order = sorted(hists.items(), key=lambda kv: -len(kv[1][1]) * kv[0] * kv[0])
-        main = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F not in side_classes]
-        side = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F in side_classes]
-        if side and main:
-            next(main[0], None)  # the main class's short first batch goes out before the second stream is fed
-        for gen in side + main:
-            for _ in gen:
-                pass
+
+        def enqueue_all():
+            """Every class, all pairs: classes that go to the second stream are queued there right after the main class's
+            first batch."""
+            main = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F not in side_classes]
+            side = [run_class(F, d_hist, members) for F, (d_hist, members) in order if F in side_classes]
+            if side and main:
+                next(main[0], None)  # the main class's short first batch goes out before the second stream is fed
+            for gen in side + main:
+                for _ in gen:
+                    pass
+
+        # ---- bandwidths: the whole optimiser (fixed point, functionals, TNC) runs on the device
+        all_k = np.arange(npair)
+        if smooth_scale_2D < 0:
+
+            def book_widths():  # (queued before anything is enqueued: the result objects carry the triples)
+                for e, bw_k in zip(info, wv.tolist()):
+                    e["bandwidth"] = tuple(bw_k)
+
+            deferred.append(book_widths)
+            if _bandwidths is not None:
+                wv[:] = np.array(list(_bandwidths), dtype=np.float64).reshape(npair, 3)
+                set_scales(all_k, wv[:, 0] * abs(smooth_scale_2D) / fwx_v, wv[:, 1] * abs(smooth_scale_2D) / fwy_v, wv[:, 2])
+                enqueue_all()
+            else:
+                if plan is None:
+                    with _Phase(self, "2d.host_bandwidth_plan"):
+                        plan = self._bandwidth_plan(*plan_args())
+                # A large call on two streams: the optimiser's launch of the base grid is cut in two, and the first part's
+                # pairs are convolved on the second context's stream while the second part is still being optimised on
+                # this one (the optimiser re-streams its matrices from the memory-side cache, the convolution is
+                # arithmetic in LDS: they share the chip well).
+                pipelined = len(conv_ctxs) > 1 and npair > self.CONV_TWO_STREAMS_PAIRS[1]
+
+                def book_plan(plan=plan):
+                    for e, pl in zip(info, plan):
+                        e["branch"], e["kopt"] = pl["branch"], pl["kopt"]
+
+                enqueueing = []  # the first part's enqueue, running on the second context's thread
+
+                def enqueue_part(only, last):
+                    for F, (d_hist, members) in order:
+                        target = conv_ctxs[1] if (F in side_classes or not last) else conv_ctxs[0]
+                        for _ in run_class(F, d_hist, members, only=only, force_ctx=target):
+                            pass
+
+                def on_chunk(ks, last, W):
+                    wv[ks] = W[ks]
+                    set_scales(ks, wv[ks, 0] * abs(smooth_scale_2D) / fwx_v[ks], wv[ks, 1] * abs(smooth_scale_2D) / fwy_v[ks],
+                               wv[ks, 2])
+                    only = np.zeros(npair, dtype=bool)
+                    only[ks] = True
+                    if not last:
+                        # the second context's own thread enqueues this part's convolution while this thread goes
+                        # straight on to the next optimiser launch (a blocking call that releases the interpreter lock)
+                        enqueueing.append(self._lane_thread(self._second_lane()).submit(enqueue_part, only, False))
+                        return
+                    for f in enqueueing:
+                        f.result()
+                    widths_complete[0] = True
+                    _hostlog("bandwidths done")
+                    enqueue_part(only, True)
+
+                with _Phase(self, "2d.bandwidth.device"):
+                    if pipelined:
+                        widths_complete[0] = False
+                        self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred, on_chunk=on_chunk,
+                                           first_fraction=self.KOPT_FIRST_FRACTION, more_deferred=book_plan)
+                    else:
+                        W = self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred,
+                                               more_deferred=book_plan)
+                        wv[:] = W
+                        set_scales(all_k, wv[:, 0] * abs(smooth_scale_2D) / fwx_v, wv[:, 1] * abs(smooth_scale_2D) / fwy_v, wv[:, 2])
+                        _hostlog("bandwidths done")
+                        enqueue_all()
+
+        else:
+            if smooth_scale_2D < 1.0:
+                set_scales(all_k, smooth_scale_2D * np.array([e["parx"].err for e in info]) / fwx_v,
+                           smooth_scale_2D * np.array([e["pary"].err for e in info]) / fwy_v,
+                           np.array([e["corr"] for e in info], dtype=np.float64))
+            else:
+                fixed = np.array([smooth_scale_2D * e["F"] / e["nbin2D"] for e in info], dtype=np.float64)
+                set_scales(all_k, fixed, fixed, np.array([e["corr"] for e in info], dtype=np.float64))
+            enqueue_all()
+        _ph_asm = _Phase(self, "2d.host_assemble_results")
         _hostlog("classes enqueued (%s)" % ", ".join("F=%d: %d pairs" % (F, len(m_)) for F, (_, m_) in order))
         run_deferred()  # (nothing was enqueued: no pairs)
         release += [d_hist for d_hist, _ in hists.values()] + list(likehists.values())

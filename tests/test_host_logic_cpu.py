@@ -755,3 +755,30 @@ def test_array_forms_of_the_host_decisions_equal_the_scalar_ones(zoo):
     d_names = mc.get2DDensities([(names[a].name, names[b].name) for a, b in pairs[:9]])
     for x, y, z in zip(d_list, d_arr, d_names):
         assert np.array_equal(x.P, y.P) and np.array_equal(x.P, z.P)
+
+
+def test_pipelined_optimiser_and_convolution_equal_the_plain_order(zoo):
+    """Large calls cut the optimiser's launch in two and convolve the first part on the second stream while the second
+    part is optimised: same grids, bandwidths and records as the plain order (thresholds lowered so that a 78-pair call
+    takes the pipelined route on the numpy double)."""
+    fx = zoo["block50"]
+    pairs = [(i, j) for i in range(13) for j in range(i + 1, 13)]
+    ref = make(fx)
+    ref.CONV_TWO_STREAMS_PAIRS = (1 << 30, 0)
+    plain = ref.get2DDensities(pairs)
+    mc = make(fx)
+    mc.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc.KOPT_SPLIT_MIN = 8
+    calls = []
+    orig = mc.ctx.kopt2d
+
+    def counting(*a, **k):
+        calls.append(a[1])
+        return orig(*a, **k)
+
+    mc.ctx.kopt2d = counting
+    piped = mc.get2DDensities(pairs)
+    assert mc._twin is not None and len(calls) >= 2 and sum(calls) == sum(1 for d in plain if d.bandwidth_branch != "B")
+    for a, b in zip(piped, plain):
+        assert np.array_equal(a.P, b.P) and a.bandwidth == b.bandwidth and a.bandwidth_branch == b.bandwidth_branch
+        assert (a.kopt is None) == (b.kopt is None) and (a.kopt is None or np.array_equal(a.kopt, b.kopt, equal_nan=True))
