@@ -18,7 +18,6 @@ import logging
 import os
 import threading
 import time
-import warnings
 
 import numpy as np
 

@@ -4,7 +4,7 @@ import os, sys, time
 os.environ["GETDIST_AMD_HOSTLOG"] = "1"
 sys.path.insert(0, ".")
 import bench
-from getdist_amd import mcsamples, synth, parallel
+from getdist_amd import mcsamples, synth
 from getdist_amd.mcsamples import MCSamples
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 s, w, names, ranges = synth.config_c3()

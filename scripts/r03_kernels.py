@@ -12,7 +12,6 @@ compared bit for bit with the present ones; they have been removed since, the sw
 import json
 import os
 import sys
-import time
 
 import numpy as np
 

@@ -1,6 +1,5 @@
 """Time gd_kopt2d (DCT GEMMs + fixed point + get_h) on C3-like histograms; used to compare build variants on the GPU box."""
 import sys, time
-import numpy as np
 sys.path.insert(0, ".")
 from getdist_amd._lib import Context
 from getdist_amd import synth
