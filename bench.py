@@ -115,6 +115,8 @@ def reset_caches(mc):
     # the index columns are per-step work: every entry is marked stale (its device block is kept for the rewrite)
     mc._idx_cols = {k: (buf, None) for k, (buf, _) in mc._idx_cols.items()}
     mc.density1D = {}
+    if hasattr(mc.ctx, "batch2d_invalidate"):
+        mc.ctx.batch2d_invalidate()  # (the library's cache of index columns: binned again every step)
     if getattr(mc, "_twin", None) is not None:  # the second lane's as well
         mc._twin._idx_cols = {k: (buf, None) for k, (buf, _) in mc._twin._idx_cols.items()}
 
@@ -190,7 +192,9 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
     try:
         out = mc.get2DDensities(my_pairs)
     finally:
-        mc._neff_share = None
+        share, mc._neff_share = getattr(mc, "_neff_share", None), None
+        if share is not None:
+            share.complete(mc)  # whatever this rank's share needed, it enters the step's collective exactly once
     _REPLAY["last_pairs"] = my_pairs  # the order of `out`
     if mc._timing:
         mc.timings["step.total"] = mc.timings.get("step.total", 0.0) + time.perf_counter() - t_step0

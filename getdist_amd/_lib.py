@@ -115,6 +115,11 @@ SIGNATURES = {
     "gd_convolve1d_direct": (C.c_int, [_p, _pd, _i64, _pd, _i64, _pd]),
     "gd_autoconvolve": (C.c_int, [_p, _i32, _f64, _i32, _pd, _i64, _i64, _i64, _i32, _pd]),
     "gd_like_stats": (C.c_int, [_p, _i32, _pd]),
+    "gd_batch2d_grid_sizes": (C.c_int, [_p, _i32, _pd, _pi32, _i32, _pi32]),
+    "gd_density2d_batch": (C.c_int, [_p, _p, _p, _p, _i32, _pd, _pd, _pd, _pi32, _i32, _p, _p, _p, _i64, _pi32, _pd, _pd, _pi32,
+                                     _pi32]),
+    "gd_batch2d_finish": (C.c_int, [_p]),
+    "gd_batch2d_invalidate": (C.c_int, [_p]),
 }
 
 _lib = None
@@ -729,6 +734,32 @@ class Context:
         self._check(self.lib.gd_like_stats(self.h, int(col), _dp(out)))
         return dict(min=out[0], max=out[1], norm=out[2], sum_wl=out[3], sum_wl2=out[4], sum_w_exp_plus=out[5],
                     sum_w_exp_minus=out[6], argmin=int(out[7]))
+
+    # ---- one native entry for a batch of pairs (getdist_amd/batch2d.py packs the arguments)
+    def batch2d_grid_sizes(self, settings, n, corr, pairs32):
+        F = np.zeros(len(pairs32), dtype=np.int32)
+        rc = self.lib.gd_batch2d_grid_sizes(C.byref(settings), int(n), _dp(corr), _ip(pairs32), len(pairs32), _ip(F))
+        if rc != 0:
+            raise GdhipError(rc, "gd_batch2d_grid_sizes: bad argument")
+        return F
+
+    def density2d_batch(self, twin, settings, params, n, corr, cov, lag_probe, pairs32, exchange, grids, status, meta, levels,
+                        level_status):
+        """gd_density2d_batch; returns the copy-stream tokens (this context's, the twin's)."""
+        tokens = np.full(2, -1, dtype=np.int32)
+        self._check(self.lib.gd_density2d_batch(
+            self.h, None if twin is None else twin.h, C.byref(settings), C.cast(params, _p), int(n), _dp(corr), _dp(cov),
+            None if lag_probe is None else _dp(lag_probe), _ip(pairs32), len(pairs32),
+            None if exchange is None else C.cast(exchange, _p), None, grids.ctypes.data, int(grids.size),
+            status.ctypes.data_as(_pi32), _dp(meta), None if levels is None else _dp(levels),
+            None if level_status is None else _ip(level_status), _ip(tokens)))
+        return int(tokens[0]), int(tokens[1])
+
+    def batch2d_finish(self):
+        self._check(self.lib.gd_batch2d_finish(self.h))
+
+    def batch2d_invalidate(self):
+        self._check(self.lib.gd_batch2d_invalidate(self.h))
 
     def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t, corr):
         """B x 12: {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status, hx, hy, corr, get_h status}"""

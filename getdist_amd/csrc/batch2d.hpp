@@ -1,0 +1,1331 @@
+// batch2d.hpp -- the host side of gd_density2d_batch: every decision MCSamples.get2DDensityGridData and
+// getAutoBandwidth2D make for a batch of parameter pairs (/root/reference/getdist/mcsamples.py:1285-1419, 1486-1498,
+// 1748-2010; chains.py:477-574 for the effective sample numbers), in the reference's own expression order, plus the
+// choreography of the device work over two streams.
+//
+// Pure C++17, no HIP: the device is reached through a table of entry points (`Ops`).  libgdhip.so binds the table to its
+// own C ABI (batch2d.hip); the CPU test-suite binds it to callbacks of the numpy context double and checks the grids of
+// this orchestration against the Python-planned path (tests/native/batch_harness.cpp, tests/test_native_batch.py).
+//
+// Scalars that decide bits downstream (bin edges, shear coefficients, fallback times, window sizes) are evaluated with
+// exactly the operations numpy / CPython perform: libm `pow` where Python writes `**` on scalars, x*x where numpy
+// squares an array, round-half-even where numpy rounds, the LAPACK 2 x 2 factorisations spelled out (`chol_shear`).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <future>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gdhip.h"
+
+namespace gdb {
+
+// ---- device entry points (the C ABI of include/gdhip.h, handle first) -------------------------------------------------
+struct Ops {
+    int (*bind_thread)(void* h);
+    int (*num_rows)(void* h, int64_t* N, int64_t* n);
+    int (*weights_kind)(void* h, int32_t* has_weights);  // 0: unit weights (chains.py:313-315)
+    int (*dev_alloc)(void* h, int64_t bytes, void** out);
+    int (*dev_free)(void* h, void* p);
+    int (*prebin8_batch)(void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                         void* const* d_idx, int64_t* bad);
+    int (*hist2d_prebinned8)(void* h, int32_t B, const void* const* ix, const void* const* iy, void* d_hist);
+    int (*prebin)(void* h, int32_t col, double binmin, double width, int32_t F, void* d_idx);
+    int (*hist2d_prebinned)(void* h, int32_t B, const void* const* ix, const void* const* iy, int32_t F, void* d_hist);
+    int (*minmax_affine)(void* h, int32_t B, const int32_t* ci, const int32_t* cj, const double* a, const double* b, double* out);
+    int (*hist2d_sheared)(void* h, int32_t B, const int32_t* ci, const int32_t* cj, const double* r0, const double* r1,
+                          const double* xmin, const double* dx, const double* ymin, const double* dy, int32_t F, void* d_hist);
+    int (*kopt2d)(void* h, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
+                  const double* fallback_t, const double* corr, double* out);
+    // d_dst[(dst_first + k)] = d_src[index[k]], items of item_bytes
+    int (*gather_items)(void* h, void* d_dst, int64_t dst_first, const void* d_src, const int32_t* index, int32_t count,
+                        int64_t item_bytes);
+    int (*density2d_enqueue)(void* h, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry,
+                             const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
+                             void* d_P, int32_t* status_pinned);
+    int (*d2h_async)(void* h, void* dst, const void* d_src, int64_t bytes);
+    int (*copy_mark)(void* h, int32_t* token);
+    int (*copy_wait)(void* h, int32_t token);
+    int (*copy_sync)(void* h);
+    int (*contour_levels)(void* h, int32_t B, int32_t F, const void* d_P, const double* contours, int32_t nc, double* out,
+                          int32_t* status);
+    int (*autocov_lags_batch)(void* h, const int32_t* cols, int32_t ncols, const double* means, int64_t k0, int32_t nlags,
+                              double* out);
+    int (*kde_lag_sums_batch)(void* h, const int32_t* cols, int32_t ncols, const double* inv4s2, const int64_t* lags,
+                              int32_t nlags, double* out);
+    int (*kde_lag_sums)(void* h, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out);
+    const char* (*last_error)(void* h);
+};
+
+// ---- numpy / CPython scalar semantics --------------------------------------------------------------------------------
+// `x ** y` on Python floats and numpy float64 scalars is libm pow(x, y).  The exponent goes through a volatile so that
+// no compiler rewrites pow(x, 2.0) as x * x (glibc's pow is not correctly rounded in every case; numpy ARRAY squares,
+// written x * x below, are).
+static inline double py_pow(double x, double y) {
+    volatile double e = y;
+    return pow(x, e);
+}
+static inline double np_minimum(double a, double b) { return (a < b || isnan(a)) ? a : b; }
+static inline double np_maximum(double a, double b) { return (a > b || isnan(a)) ? a : b; }
+static inline double np_sign(double x) { return isnan(x) ? x : (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)); }
+
+// Smallest 2^a * {1,3,5,9,15} (a >= 4) >= n: the frame ladder of the convolution (density2d.hip).
+static inline int frame_size(int n) {
+    long long best = 1LL << 40;
+    const int odd[5] = {1, 3, 5, 9, 15};
+    for (int a = 4; a < 28; ++a)
+        for (int q = 0; q < 5; ++q) {
+            const long long v = (1LL << a) * odd[q];
+            if (v >= n && v < best) best = v;
+        }
+    return (int)best;
+}
+
+// np.linalg.cholesky + np.linalg.inv of a 2 x 2 covariance exactly as LAPACK (OpenBLAS potrf / getrf + getrs)
+// evaluates them -- reciprocal scaling of the sub-diagonal, partial pivoting in the inverse -- followed by
+// mcsamples.py:1352-1356: S *= ichol[0,0]; r = ichol[1,:] / ichol[0,0].  Checked against numpy on random matrices
+// (tests/test_native_batch.py).  Returns false when the matrix is not positive definite (numpy raises LinAlgError).
+static inline bool chol_shear(double c00, double c10, double c11, double S[4], double r[2]) {
+    if (!(c00 > 0)) return false;
+    const double l00 = sqrt(c00);
+    const double l10 = c10 * (1.0 / l00);
+    const double d = c11 - l10 * l10;
+    if (!(d > 0)) return false;
+    const double l11 = sqrt(d);
+    double i00, i10, i11;
+    if (fabs(l10) > fabs(l00)) {  // row interchange in dgetrf
+        const double l = l00 * (1.0 / l10);
+        const double u11 = 0.0 - l * l11;
+        i10 = 1.0 * (1.0 / u11);
+        i00 = (0.0 - l11 * i10) * (1.0 / l10);
+        i11 = (0.0 - l * 1.0) * (1.0 / u11);
+    } else {
+        const double l = l10 * (1.0 / l00);
+        i00 = 1.0 * (1.0 / l00);
+        i10 = (0.0 - l * 1.0) * (1.0 / l11);
+        i11 = 1.0 * (1.0 / l11);
+    }
+    S[0] = l00 * i00, S[1] = 0.0 * i00, S[2] = l10 * i00, S[3] = l11 * i00;
+    r[0] = i10 / i00, r[1] = i11 / i00;
+    return true;
+}
+
+// ---- per-pair scalars of get2DDensityGridData (mcsamples.py:1794-1822) ----------------------------------------------
+struct PairScalars {
+    std::vector<int32_t> jx, jy, F, warn;
+    std::vector<int64_t> nbin2D;
+    std::vector<double> actual, corr;
+};
+
+static inline void pair_scalars(const gd_batch2d_settings& s, int n, const double* corrmat, const int32_t* pairs, int P,
+                                PairScalars& ps) {
+    ps.jx.resize(P), ps.jy.resize(P), ps.F.resize(P), ps.warn.assign(P, 0), ps.nbin2D.resize(P), ps.actual.resize(P),
+        ps.corr.resize(P);
+    const int base_F = s.fine_bins_2D;
+    for (int k = 0; k < P; ++k) {
+        const int a = pairs[2 * k], b = pairs[2 * k + 1];
+        ps.jx[k] = a, ps.jy[k] = b;
+        const double actual = corrmat[(size_t)b * n + a];  // correlationMatrix[j2, j]
+        double c = actual;
+        if (fabs(fabs(c) - 1.0) <= 1e-8) {  // "Parameters are 100% correlated" (mcsamples.py:1798-1803)
+            ps.warn[k] |= 1;
+            c = np_sign(c) * s.max_corr_2D;
+        }
+        if (fabs(c) < 0.1) c = 0.0;
+        const double m = np_minimum(s.max_corr_2D, fabs(c));
+        const double angle_scale = np_maximum(0.2, sqrt(1 - m * m));
+        ps.nbin2D[k] = (int64_t)nearbyint((double)s.num_bins_2D / angle_scale);
+        const int64_t scaled = 192 * (int64_t)(3 / angle_scale) / 3;
+        ps.F[k] = (c != 0 && base_F < scaled && (int64_t)(1 / angle_scale) > 1) ? (int32_t)scaled : base_F;
+        ps.actual[k] = actual, ps.corr[k] = c;
+    }
+}
+
+// binmin / binmax of _binSamples (mcsamples.py:1486-1496)
+static inline void bin_edges(const gd_param2d& p, double* binmin, double* binmax) {
+    const double border = (p.range_max - p.range_min) * 0.1;
+    double lo = np_minimum(p.param_min, p.range_min);
+    if (!p.has_limits_bot) lo = lo - border;
+    double hi = np_maximum(p.param_max, p.range_max);
+    if (!p.has_limits_top) hi = hi + border;
+    *binmin = lo, *binmax = hi;
+}
+
+// ---- effective sample numbers (chains.py:477-574 via mcsamples.py:1230-1235) -------------------------------------------
+struct NeffInput {
+    int64_t N;
+    double norm, sum_w2;
+};
+
+// the scalar half of getEffectiveSamplesGaussianKDE given the seven batched lag sums; `lag_sum(k)` fetches another lag
+static inline int neff_from_lags(const NeffInput& in, int64_t maxoff, double min_corr, const double* sums, int nseed_tail,
+                                 const std::function<int(int64_t, double*)>& lag_sum, double* neff_out) {
+    const int64_t N = in.N;
+    if (maxoff > N / 10) maxoff = N / 10;
+    const int64_t uncorr_len = N / 2;
+    int64_t nav = 0;
+    for (int64_t k = uncorr_len; k < uncorr_len + 5; ++k) nav += N - k;
+    double s5 = 0.0;
+    for (int q = 0; q < 5; ++q) s5 += sums[q];
+    const double uncorr_term = s5 / (double)nav;
+    const double n = (double)N;
+    std::map<int64_t, double> cache;
+    for (int q = 0; q < nseed_tail; ++q) cache[q + 1] = sums[5 + q];  // lags 1, 2
+    int rc = 0;
+    auto corr_k = [&](int64_t k) -> double {
+        auto it = cache.find(k);
+        double v;
+        if (it == cache.end()) {
+            v = NAN;
+            const int e = lag_sum(k, &v);
+            if (e) rc = e;
+            cache[k] = v;
+        } else {
+            v = it->second;
+        }
+        return v - (n - (double)k) * uncorr_term;
+    };
+    const double corr0 = in.sum_w2;
+    const double threshold = min_corr * corr0;
+    const double c1 = corr_k(1);
+    double Nn;
+    if (c1 < threshold) {
+        Nn = corr0;
+    } else {
+        const double c2 = corr_k(2);
+        if (c2 > threshold) {
+            int64_t max_k = maxoff;
+            while (max_k > 10) {
+                if (corr_k(max_k / 3) >= threshold) break;
+                max_k /= 3;
+            }
+            const int64_t step_size = max_k < 20 ? 1 : max_k / 10;
+            double cum_sum = c1 + c2;
+            for (int64_t k = 3; k < maxoff + 1; k += step_size) {
+                const double test_val = corr_k(k);
+                if (test_val < threshold) break;
+                cum_sum += k > 3 ? test_val * (double)step_size : (test_val * (double)step_size) / 2;
+            }
+            Nn = corr0 + 2 * cum_sum;
+        } else {
+            Nn = corr0 + 2 * c1;
+        }
+    }
+    if (rc) return rc;
+    *neff_out = py_pow(in.norm, 2.0) / Nn;
+    return 0;
+}
+
+// ---- the bandwidth plan (mcsamples.py:1325-1409) ----------------------------------------------------------------------
+struct Plan {
+    std::vector<int8_t> branch;        // 0 A, 1 B, 2 C
+    std::vector<uint8_t> has_limits;   // parx.has_limits or pary.has_limits
+    std::vector<double> rangex, rangey, ratio, neff, fallback_t;
+    // branch A only (indexed by pair; valid where branch == 0)
+    std::vector<int32_t> si, sj;       // the sheared pair's columns (swapped when y carries the limit)
+    std::vector<uint8_t> swap, has_imin, has_imax;
+    std::vector<double> imin, imax, S, r;  // S: 4 per pair, r: 2 per pair
+};
+
+static inline bool has_limits(const gd_param2d& p) { return p.has_limits_bot || p.has_limits_top; }
+
+static inline int make_plan(const gd_batch2d_settings& s, const gd_param2d* par, int n, const double* cov,
+                            const PairScalars& ps, const std::vector<double>& rngx, const std::vector<double>& rngy,
+                            double min_corr, Plan& pl, std::string& err) {
+    const int P = (int)ps.jx.size();
+    pl.branch.resize(P), pl.has_limits.resize(P), pl.rangex = rngx, pl.rangey = rngy, pl.ratio.resize(P);
+    pl.neff.assign(P, NAN), pl.fallback_t.assign(P, NAN);
+    pl.si.assign(P, -1), pl.sj.assign(P, -1), pl.swap.assign(P, 0), pl.has_imin.assign(P, 0), pl.has_imax.assign(P, 0);
+    pl.imin.assign(P, NAN), pl.imax.assign(P, NAN), pl.S.assign((size_t)4 * P, NAN), pl.r.assign((size_t)2 * P, NAN);
+    for (int k = 0; k < P; ++k) {
+        const gd_param2d &px = par[ps.jx[k]], &py = par[ps.jy[k]];
+        const bool limx = has_limits(px), limy = has_limits(py);
+        pl.has_limits[k] = limx || limy;
+        const bool do_correlated = !limx || !limy;
+        const double c = ps.actual[k], absc = fabs(c);
+        const bool is_A = (min_corr < absc) && (absc <= s.max_corr_2D) && do_correlated;
+        const bool is_B = !is_A && ((absc > s.max_corr_2D) || (!do_correlated && (c > 0.8)));
+        pl.branch[k] = is_A ? 0 : (is_B ? 1 : 2);
+        pl.ratio[k] = np_minimum(py.sigma_range / rngy[k], px.sigma_range / rngx[k]);
+        if (!is_A) continue;
+        int i = ps.jx[k], j = ps.jy[k];
+        if (px.has_limits_bot) pl.has_imin[k] = 1, pl.imin[k] = px.range_min;
+        if (px.has_limits_top) pl.has_imax[k] = 1, pl.imax[k] = px.range_max;
+        if (limy) {
+            std::swap(i, j);
+            pl.swap[k] = 1;
+            if (py.has_limits_bot) pl.has_imin[k] = 1, pl.imin[k] = py.range_min;
+            if (py.has_limits_top) pl.has_imax[k] = 1, pl.imax[k] = py.range_max;
+        }
+        pl.si[k] = i, pl.sj[k] = j;
+        if (!chol_shear(cov[(size_t)i * n + i], cov[(size_t)j * n + i], cov[(size_t)j * n + j], &pl.S[(size_t)4 * k],
+                        &pl.r[(size_t)2 * k])) {
+            err = "Matrix is not positive definite";  // numpy.linalg.LinAlgError out of np.linalg.cholesky
+            return GD_ERR_BADARG;
+        }
+    }
+    return 0;
+}
+
+// N_eff per pair (min of the two parameters', mcsamples.py:1329-1331) and the fallback time of branch C (:1396-1397)
+static inline void fill_plan(const gd_param2d* par, const PairScalars& ps, Plan& pl) {
+    const int P = (int)ps.jx.size();
+    for (int k = 0; k < P; ++k) {
+        pl.neff[k] = np_minimum(par[ps.jx[k]].neff, par[ps.jy[k]].neff);
+        if (pl.branch[k] == 2) pl.fallback_t[k] = py_pow(pl.ratio[k] / py_pow(pl.neff[k], 1.0 / 6), 2.0);
+    }
+}
+
+// ---- persistent state of a context's batched calls --------------------------------------------------------------------
+struct IdxCol {
+    void* ptr = nullptr;
+    double binmin = NAN, width = NAN;
+    bool valid = false;
+};
+
+struct Pending {  // a call whose result copies may still be in flight
+    std::vector<void*> blocks;
+    int32_t tok_main = -1, tok_twin = -1;
+    void* twin = nullptr;
+    bool live = false;
+};
+
+struct State {
+    std::mutex mu;
+    std::vector<std::pair<void*, int64_t>> free_blocks;  // (device pointer, capacity)
+    std::map<void*, int64_t> capacity;                   // of every block handed out
+    int64_t cached_bytes = 0;
+    std::map<std::tuple<int, int, int>, IdxCol> idx;     // (column, F, 1 = bytes / 2 = u16)
+    Pending prev;                                        // the last lazily delivered call
+    static constexpr int64_t kCacheLimit = 16LL << 30;
+};
+
+struct Pool {
+    State& st;
+    const Ops& ops;
+    void* h;
+    void* take(int64_t bytes, int* rc) {
+        {
+            std::lock_guard<std::mutex> g(st.mu);
+            int best = -1;
+            for (size_t k = 0; k < st.free_blocks.size(); ++k) {
+                const int64_t cap = st.free_blocks[k].second;
+                if (cap >= bytes && cap <= 2 * bytes + (1 << 20) && (best < 0 || cap < st.free_blocks[best].second)) best = (int)k;
+            }
+            if (best >= 0) {
+                void* p = st.free_blocks[best].first;
+                st.cached_bytes -= st.free_blocks[best].second;
+                st.free_blocks.erase(st.free_blocks.begin() + best);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        int e = ops.dev_alloc(h, bytes, &p);
+        if (e == GD_ERR_NOMEM) {  // hand the cached blocks back and retry once
+            drop_cached();
+            e = ops.dev_alloc(h, bytes, &p);
+        }
+        if (e) {
+            *rc = e;
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> g(st.mu);
+        st.capacity[p] = bytes;
+        return p;
+    }
+    void give(void* p) {
+        if (!p) return;
+        std::unique_lock<std::mutex> g(st.mu);
+        const int64_t cap = st.capacity[p];
+        if (st.cached_bytes + cap > State::kCacheLimit) {
+            st.capacity.erase(p);
+            g.unlock();
+            ops.dev_free(h, p);
+            return;
+        }
+        st.free_blocks.emplace_back(p, cap);
+        st.cached_bytes += cap;
+    }
+    void drop_cached() {
+        std::vector<std::pair<void*, int64_t>> blocks;
+        {
+            std::lock_guard<std::mutex> g(st.mu);
+            blocks.swap(st.free_blocks);
+            st.cached_bytes = 0;
+            for (auto& b : blocks) st.capacity.erase(b.first);
+        }
+        for (auto& b : blocks) ops.dev_free(h, b.first);
+    }
+};
+
+static inline int complete_pending(State& st, const Ops& ops, void* h, Pending& pd) {
+    if (!pd.live) return 0;
+    int rc = 0;
+    if (pd.tok_main >= 0) rc = ops.copy_wait(h, pd.tok_main);
+    if (!rc && pd.twin && pd.tok_twin >= 0) rc = ops.copy_wait(pd.twin, pd.tok_twin);
+    Pool pool{st, ops, h};
+    for (void* p : pd.blocks) pool.give(p);
+    pd.blocks.clear();
+    pd.live = false;
+    return rc;
+}
+
+static inline int finish_all(State& st, const Ops& ops, void* h) { return complete_pending(st, ops, h, st.prev); }
+
+static inline void invalidate_index_columns(State& st) {
+    std::lock_guard<std::mutex> g(st.mu);
+    for (auto& kv : st.idx) kv.second.valid = false;
+}
+
+// frees every device block the state holds (context teardown / new sample set)
+static inline void release_all(State& st, const Ops& ops, void* h) {
+    finish_all(st, ops, h);
+    Pool pool{st, ops, h};
+    {
+        std::lock_guard<std::mutex> g(st.mu);
+        for (auto& kv : st.idx)
+            if (kv.second.ptr) st.free_blocks.emplace_back(kv.second.ptr, st.capacity[kv.second.ptr]);
+        st.idx.clear();
+    }
+    pool.drop_cached();
+}
+
+// ---- the call ----------------------------------------------------------------------------------------------------------
+struct Call {
+    State& st;
+    const Ops& ops;
+    void* h;     // main context: first stream
+    void* twin;  // second stream (may be null)
+    const gd_batch2d_settings& s;
+    gd_param2d* par;
+    int n;
+    const double* corrmat;
+    const double* cov;
+    const double* lag_probe;
+    const int32_t* pairs;
+    int P;
+    gd_neff_exchange_fn exchange;
+    void* exchange_user;
+    double* grids;
+    int64_t grids_doubles;
+    int32_t* status_pinned;
+    double* meta;
+    double* levels;
+    int32_t* level_status;
+    std::string err;
+
+    Call(State& st_, const Ops& ops_, void* h_, void* twin_, const gd_batch2d_settings& s_, gd_param2d* par_, int n_,
+         const double* corr_, const double* cov_, const double* lag_probe_, const int32_t* pairs_, int P_,
+         gd_neff_exchange_fn ex_, void* ex_user_, double* grids_, int64_t grids_doubles_, int32_t* status_, double* meta_,
+         double* levels_, int32_t* level_status_)
+        : st(st_), ops(ops_), h(h_), twin(twin_), s(s_), par(par_), n(n_), corrmat(corr_), cov(cov_), lag_probe(lag_probe_),
+          pairs(pairs_), P(P_), exchange(ex_), exchange_user(ex_user_), grids(grids_), grids_doubles(grids_doubles_),
+          status_pinned(status_), meta(meta_), levels(levels_), level_status(level_status_), pool{st_, ops_, h_} {}
+
+    int64_t N = 0;
+    bool unit_weights = true;
+    Pool pool;
+    PairScalars ps;
+    std::vector<int> used;
+    std::vector<double> bmin, bmax;  // per column
+    std::vector<double> fwx, fwy;    // per pair
+    std::vector<int> F_list;         // grid sizes in order of first appearance
+    std::map<int, std::vector<int>> classes;  // F -> pair indices, ascending
+    std::map<int, void*> hists;               // F -> device histograms of the class, in member order
+    Plan plan;
+    struct Shear {
+        void* d_rot = nullptr;
+        std::vector<int> A;
+        std::vector<double> r1s, r2s;
+    } shear;
+    bool have_shear = false;
+    // convolution state
+    std::vector<double> rx, ry, cc, smooth, W;  // W: P x 3
+    std::vector<int64_t> winw;
+    std::vector<int32_t> flags, group;
+    std::vector<void*> call_blocks;  // everything to release once the copies have landed
+    std::mutex enq_mu;
+    int64_t grid_off = 0;
+    int status_at = 0;
+    int batch_no = 0;
+    std::vector<void*> conv_ctxs;
+    std::vector<int> side_classes;
+    std::vector<int> order;  // grid sizes, largest class (in bytes) first
+
+    std::mutex err_mu;
+    int fail(int code, const std::string& msg) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (err.empty()) err = msg;
+        return code;
+    }
+    int dev_fail(int code, void* ctx) {
+        const char* m = ops.last_error(ctx);
+        return fail(code, m && *m ? m : "device call failed");
+    }
+#define GDB_DEV(ctx_, call_)                       \
+    do {                                           \
+        const int rc__ = (call_);                  \
+        if (rc__) return dev_fail(rc__, (ctx_));   \
+    } while (0)
+#define GDB_TRY(call_)            \
+    do {                          \
+        const int rc__ = (call_); \
+        if (rc__) return rc__;    \
+    } while (0)
+
+    double* M(int k) { return meta + (size_t)k * GD_BATCH2D_META; }
+
+    // -- N_eff of the listed columns that have none yet (the batched form of _get1DNeff, mcsamples.py:1230-1235)
+    int neff_batch(const std::vector<int>& js, bool owned_only, double min_corr = 0.05) {
+        std::vector<int32_t> todo;
+        for (int j : js)
+            if (isnan(par[j].neff) && (!owned_only || par[j].owned)) todo.push_back(j);
+        if (todo.empty()) return 0;
+        if (s.uncorrelated_sampler) {
+            for (int j : todo) par[j].neff = py_pow(s.norm, 2.0) / s.sum_w2;
+            return 0;
+        }
+        const int m = (int)todo.size();
+        const int64_t max_off = N / 10;
+        const int nl = (int)std::min<int64_t>(8, max_off + 1);
+        std::vector<double> lag0((size_t)m * nl);
+        bool have = lag_probe != nullptr && nl == 8;
+        if (have)
+            for (int row = 0; row < m && have; ++row)
+                for (int k = 0; k < nl; ++k) {
+                    lag0[(size_t)row * nl + k] = lag_probe[(size_t)todo[row] * 8 + k];
+                    if (isnan(lag0[(size_t)row * nl + k])) have = false;
+                }
+        if (!have) {
+            std::vector<double> means(m);
+            for (int row = 0; row < m; ++row) means[row] = par[todo[row]].mean;
+            GDB_DEV(h, ops.autocov_lags_batch(h, todo.data(), m, means.data(), 0, nl, lag0.data()));
+        }
+        std::vector<double> kstd(m), inv4s2(m);
+        std::vector<int64_t> maxoffs(m);
+        for (int row = 0; row < m; ++row) {
+            const gd_param2d& p = par[todo[row]];
+            double c[8];
+            for (int k = 0; k < nl; ++k) c[k] = lag0[(size_t)row * nl + k] / (double)(N - k) / p.var;
+            int first_below = -1;
+            for (int k = 0; k < nl; ++k)
+                if (!(c[k] > min_corr * c[0])) {
+                    first_below = k;
+                    break;
+                }
+            double corrlen;
+            if (first_below >= 0) {
+                double sum = 0.0;
+                for (int k = 1; k < first_below; ++k) sum += c[k];
+                corrlen = c[0] + 2 * sum;
+            } else if (nl == max_off + 1) {
+                corrlen = c[0];
+            } else {
+                char buf[160];
+                snprintf(buf, sizeof buf, "column %d: the chain's correlation outlasts the 8-lag probe (getCorrelationLength's long route)",
+                         (int)todo[row]);
+                return fail(GD_BATCH2D_NEED_NEFF, buf);
+            }
+            const double sr = p.sigma_range;
+            kstd[row] = ((isnan(sr) || sr == 0.0) ? p.err : sr) * 0.2;  // (par.sigma_range or self.sddev[j]) * 0.2
+            inv4s2[row] = 1.0 / (4 * py_pow(kstd[row], 2.0));
+            maxoffs[row] = (int64_t)(corrlen * 1.5) + 4;
+        }
+        std::vector<int64_t> lags;
+        const int64_t uncorr_len = N / 2;
+        for (int64_t k = uncorr_len; k < uncorr_len + 5; ++k) lags.push_back(k);
+        int ntail = 0;
+        for (int64_t k : {1, 2})
+            if (k <= N / 10) lags.push_back(k), ++ntail;
+        const int L = (int)lags.size();
+        std::vector<double> sums((size_t)m * L);
+        GDB_DEV(h, ops.kde_lag_sums_batch(h, todo.data(), m, inv4s2.data(), lags.data(), L, sums.data()));
+        const NeffInput in{N, s.norm, s.sum_w2};
+        for (int row = 0; row < m; ++row) {
+            const int col = todo[row];
+            const double i4 = inv4s2[row];
+            auto lag_sum = [&](int64_t k, double* out) -> int { return ops.kde_lag_sums(h, col, i4, &k, 1, out); };
+            double v = NAN;
+            const int e = neff_from_lags(in, maxoffs[row], min_corr, &sums[(size_t)row * L], ntail, lag_sum, &v);
+            if (e) return dev_fail(e, h);
+            par[col].neff = v;
+        }
+        return 0;
+    }
+
+    // -- multi-rank: the other ranks' N_eff values, then whatever nobody owned (mcsamples._neff_complete)
+    int neff_exchange(bool* exchanged) {
+        if (exchange && !*exchanged) {
+            *exchanged = true;
+            std::vector<double> v(n);
+            for (int j = 0; j < n; ++j) v[j] = par[j].neff;
+            if (exchange(exchange_user, v.data(), n)) return fail(GD_ERR_HIP, "N_eff exchange failed");
+            for (int j = 0; j < n; ++j)
+                if (isnan(par[j].neff)) par[j].neff = v[j];
+        }
+        return 0;
+    }
+    int neff_complete(bool* exchanged) {
+        const int rc = neff_exchange(exchanged);
+        return rc ? rc : neff_batch(used, false);
+    }
+
+    // -- index columns
+    int index_columns8(void* ctx, const std::vector<int>& js, bool* ok) {
+        std::vector<int32_t> todo;
+        std::vector<double> b0, w;
+        std::vector<void*> bufs;
+        {
+            std::lock_guard<std::mutex> g(st.mu);
+            for (int j : js) {
+                const double fw = (bmax[j] - bmin[j]) / 255;
+                IdxCol& c = st.idx[std::make_tuple(j, 256, 1)];
+                if (c.valid && c.binmin == bmin[j] && c.width == fw) continue;
+                todo.push_back(j), b0.push_back(bmin[j]), w.push_back(fw);
+            }
+        }
+        if (!todo.empty()) {
+            for (int j : todo) {
+                void* p;
+                {
+                    std::lock_guard<std::mutex> g(st.mu);
+                    p = st.idx[std::make_tuple(j, 256, 1)].ptr;
+                }
+                if (!p) {
+                    int rc = 0;
+                    p = pool.take(N + 64, &rc);
+                    if (!p) return dev_fail(rc, h);
+                }
+                bufs.push_back(p);
+            }
+            std::vector<int64_t> bad(todo.size());
+            GDB_DEV(ctx, ops.prebin8_batch(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), 256, bufs.data(), bad.data()));
+            std::lock_guard<std::mutex> g(st.mu);
+            for (size_t q = 0; q < todo.size(); ++q) {
+                IdxCol& c = st.idx[std::make_tuple(todo[q], 256, 1)];
+                c.ptr = bufs[q], c.binmin = b0[q], c.width = w[q], c.valid = bad[q] == 0;
+            }
+        }
+        bool all = true;
+        std::lock_guard<std::mutex> g(st.mu);
+        for (int j : js) {
+            const IdxCol& c = st.idx[std::make_tuple(j, 256, 1)];
+            all = all && c.valid && c.binmin == bmin[j] && c.width == (bmax[j] - bmin[j]) / 255;
+        }
+        *ok = all;
+        return 0;
+    }
+
+    int index_column16(void* ctx, int j, int F, void** out) {
+        const double fw = (bmax[j] - bmin[j]) / (F - 1);
+        IdxCol c;
+        {
+            std::lock_guard<std::mutex> g(st.mu);
+            c = st.idx[std::make_tuple(j, F, 2)];
+        }
+        if (!(c.valid && c.binmin == bmin[j] && c.width == fw)) {
+            if (!c.ptr) {
+                int rc = 0;
+                c.ptr = pool.take(N * 2 + 64, &rc);
+                if (!c.ptr) return dev_fail(rc, h);
+            }
+            GDB_DEV(ctx, ops.prebin(ctx, j, bmin[j], fw, F, c.ptr));
+            c.binmin = bmin[j], c.width = fw, c.valid = true;
+            std::lock_guard<std::mutex> g(st.mu);
+            st.idx[std::make_tuple(j, F, 2)] = c;
+        }
+        *out = c.ptr;
+        return 0;
+    }
+
+    // -- prebin + batched 2D histograms of every grid-size class on context `ctx` (mcsamples.py:1486-1498, 1724-1728)
+    int binning(void* ctx) {
+        for (int F : F_list) {
+            const std::vector<int>& members = classes.at(F);
+            const int B = (int)members.size();
+            int rc = 0;
+            if (F == 256 && unit_weights && B >= 64) {
+                // the base grid of a unit-weight triangle: byte indices, packed 16-bit counters, one block per pair
+                std::vector<int> cols;
+                std::vector<char> seen(n, 0);
+                for (int k : members)
+                    if (!seen[ps.jx[k]]) seen[ps.jx[k]] = 1, cols.push_back(ps.jx[k]);
+                for (int k : members)
+                    if (!seen[ps.jy[k]]) seen[ps.jy[k]] = 1, cols.push_back(ps.jy[k]);
+                bool ok = false;
+                GDB_TRY(index_columns8(ctx, cols, &ok));
+                if (ok) {
+                    std::vector<const void*> ix(B), iy(B);
+                    {
+                        std::lock_guard<std::mutex> g(st.mu);
+                        for (int q = 0; q < B; ++q) {
+                            ix[q] = st.idx[std::make_tuple((int)ps.jx[members[q]], 256, 1)].ptr;
+                            iy[q] = st.idx[std::make_tuple((int)ps.jy[members[q]], 256, 1)].ptr;
+                        }
+                    }
+                    void* d = pool.take((int64_t)B * 65536 * 8, &rc);
+                    if (!d) return dev_fail(rc, h);
+                    const int e = ops.hist2d_prebinned8(ctx, B, ix.data(), iy.data(), d);
+                    if (e == 0) {
+                        std::lock_guard<std::mutex> g(enq_mu);
+                        hists[F] = d;
+                        continue;
+                    }
+                    pool.give(d);
+                    if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (a 16-bit counter wrapped: the u16 / u32 path redoes the class)
+                }
+            }
+            std::vector<const void*> ix(B), iy(B);
+            for (int q = 0; q < B; ++q) {
+                void* p;
+                GDB_TRY(index_column16(ctx, ps.jx[members[q]], F, &p));
+                ix[q] = p;
+            }
+            for (int q = 0; q < B; ++q) {
+                void* p;
+                GDB_TRY(index_column16(ctx, ps.jy[members[q]], F, &p));
+                iy[q] = p;
+            }
+            void* d = pool.take((int64_t)B * F * F * 8, &rc);
+            if (!d) return dev_fail(rc, h);
+            const int e = ops.hist2d_prebinned(ctx, B, ix.data(), iy.data(), F, d);
+            if (e) {
+                pool.give(d);
+                return dev_fail(e, ctx);
+            }
+            std::lock_guard<std::mutex> g(enq_mu);
+            hists[F] = d;
+        }
+        return 0;
+    }
+
+    // -- branch A of getAutoBandwidth2D (mcsamples.py:1347-1378): min/max of the sheared coordinate and the re-binned
+    //    base grid of every sheared pair, two batched launches
+    int shear_histograms(void* ctx) {
+        const int base_F = s.fine_bins_2D;
+        shear.A.clear();
+        for (int k = 0; k < P; ++k)
+            if (plan.branch[k] == 0) shear.A.push_back(k);
+        have_shear = true;
+        const int nA = (int)shear.A.size();
+        if (!nA) return 0;
+        std::vector<int32_t> ci(nA), cj(nA);
+        std::vector<double> r0(nA), r1(nA), mm((size_t)2 * nA);
+        for (int row = 0; row < nA; ++row) {
+            const int k = shear.A[row];
+            ci[row] = plan.si[k], cj[row] = plan.sj[k], r0[row] = plan.r[(size_t)2 * k], r1[row] = plan.r[(size_t)2 * k + 1];
+        }
+        GDB_DEV(ctx, ops.minmax_affine(ctx, nA, ci.data(), cj.data(), r0.data(), r1.data(), mm.data()));
+        std::vector<double> xmin(nA), dx(nA), ymin(nA), dy(nA);
+        shear.r1s.resize(nA), shear.r2s.resize(nA);
+        for (int row = 0; row < nA; ++row) {
+            const int k = shear.A[row];
+            // kde.bin_samples(p1, nbins, range_min=imin, range_max=imax) (kde_bandwidth.py:76-87)
+            const double mn = par[plan.si[k]].param_min, mx = par[plan.si[k]].param_max;
+            const double delta = mx - mn;
+            const double rmin = plan.has_imin[k] ? plan.imin[k] : mn - delta * 0.1;
+            const double rmax = plan.has_imax[k] ? plan.imax[k] : mx + delta * 0.1;
+            const double R1 = rmax - rmin;
+            const double mn2 = mm[(size_t)2 * row], mx2 = mm[(size_t)2 * row + 1];
+            const double delta2 = mx2 - mn2;
+            const double rmin2 = mn2 - delta2 * 0.1;
+            const double R2 = (mx2 + delta2 * 0.1) - rmin2;
+            xmin[row] = rmin, dx[row] = R1 / (base_F - 1), ymin[row] = rmin2, dy[row] = R2 / (base_F - 1);
+            shear.r1s[row] = R1, shear.r2s[row] = R2;
+        }
+        int rc = 0;
+        shear.d_rot = pool.take((int64_t)nA * base_F * base_F * 8, &rc);
+        if (!shear.d_rot) return dev_fail(rc, h);
+        GDB_DEV(ctx, ops.hist2d_sheared(ctx, nA, ci.data(), cj.data(), r0.data(), r1.data(), xmin.data(), dx.data(), ymin.data(),
+                                        dy.data(), base_F, shear.d_rot));
+        return 0;
+    }
+
+    void set_scales(const std::vector<int>& ks) {
+        const double a = fabs(s.smooth_scale_2D);
+        for (int k : ks) {
+            rx[k] = W[(size_t)3 * k] * a / fwx[k];
+            ry[k] = W[(size_t)3 * k + 1] * a / fwy[k];
+            cc[k] = W[(size_t)3 * k + 2];
+            finish_scale(k);
+        }
+    }
+    void finish_scale(int k) {
+        smooth[k] = np_maximum(rx[k], ry[k]);
+        const double w = nearbyint(2.5 * smooth[k]);  // max(1, int(round(2.5 * smooth_scale)))
+        winw[k] = (isfinite(w) && w > 1) ? (int64_t)w : 1;
+        if (smooth[k] < 2) ps.warn[k] |= 2;  // "fine_bins_2D not large enough for optimal density"
+    }
+
+    // -- convolution of the pairs of one grid-size class (`only`: mask over the pairs, empty = all) on `force_ctx`, or
+    //    on the stream the two-stream rules pick; `limit_batches` > 0 stops after that many batches and returns the
+    //    remaining ones in `rest` (the caller interleaves classes)
+    struct Batch {
+        std::vector<int> pos, ks;
+    };
+    int class_batches(int F, const std::vector<char>& only, std::vector<Batch>& batches) {
+        const std::vector<int>& members = classes.at(F);
+        std::vector<int> pos_all;
+        for (int q = 0; q < (int)members.size(); ++q)
+            if (only.empty() || only[members[q]]) pos_all.push_back(q);
+        batches.clear();
+        if (pos_all.empty()) return 0;
+        int64_t mb = (int64_t)(s_max_batch_bytes() / ((double)F * F * 8 * 30));
+        int max_batch = (int)std::max<int64_t>(1, std::min<int64_t>(mb, s_max_batch()));
+        const int first_batch = s_first_batch();
+        // groups in order of first appearance; within a group sub-batches of equal frame size S >= F + 2 winw, ascending
+        std::vector<int> gorder;
+        for (int q : pos_all) {
+            const int g = group[members[q]];
+            if (std::find(gorder.begin(), gorder.end(), g) == gorder.end()) gorder.push_back(g);
+        }
+        for (int g : gorder) {
+            std::map<int, std::vector<int>> byS;
+            for (int q : pos_all) {
+                const int k = members[q];
+                if (group[k] != g) continue;
+                const int64_t w = winw[k];
+                if (w < 1 || w > 2 * (int64_t)F) return fail(GD_ERR_BADARG, "bad window half-width");
+                byS[frame_size(F + 2 * (int)w)].push_back(q);
+            }
+            for (auto& kv : byS) {
+                const std::vector<int>& cur = kv.second;
+                size_t s0 = 0;
+                if (batches.empty() && (int)cur.size() > first_batch) {
+                    Batch b;
+                    b.pos.assign(cur.begin(), cur.begin() + first_batch);
+                    batches.push_back(b);
+                    s0 = first_batch;
+                }
+                for (size_t s1 = s0; s1 < cur.size(); s1 += max_batch) {
+                    Batch b;
+                    b.pos.assign(cur.begin() + s1, cur.begin() + std::min(cur.size(), s1 + (size_t)max_batch));
+                    batches.push_back(b);
+                }
+            }
+        }
+        for (auto& b : batches)
+            for (int q : b.pos) b.ks.push_back(members[q]);
+        return 0;
+    }
+    int s_first_batch() const { return s.first_batch > 0 ? s.first_batch : 128; }
+    int s_max_batch() const { return s.max_batch > 0 ? s.max_batch : 320; }
+    double s_max_batch_bytes() const { return s.max_batch_bytes > 0 ? s.max_batch_bytes : 24e9; }
+    int s_two_min() const { return s.two_streams_min > 0 ? s.two_streams_min : 64; }
+    int s_two_split() const { return s.two_streams_split > 0 ? s.two_streams_split : 400; }
+    int s_kopt_split_min() const { return s.kopt_split_min > 0 ? s.kopt_split_min : 256; }
+    double s_kopt_first() const { return s.kopt_first_fraction > 0 ? s.kopt_first_fraction : 0.5; }
+
+    bool is_side(int F) const { return std::find(side_classes.begin(), side_classes.end(), F) != side_classes.end(); }
+
+    int enqueue_batch(int F, const Batch& b, void* force_ctx) {
+        const std::vector<int>& members = classes.at(F);
+        void* bctx;
+        if (force_ctx)
+            bctx = force_ctx;
+        else if (!side_classes.empty() || P > s_two_split())
+            bctx = conv_ctxs[is_side(F) && conv_ctxs.size() > 1 ? 1 : 0];
+        else
+            bctx = conv_ctxs[batch_no % conv_ctxs.size()];
+        ++batch_no;
+        const int B = (int)b.pos.size();
+        const int64_t item = (int64_t)F * F * 8;
+        void* d_hist = hists.at(F);
+        void* d_sub = d_hist;
+        int rc = 0;
+        bool whole = B == (int)members.size();
+        for (int q = 0; q < B && whole; ++q) whole = b.pos[q] == q;
+        if (!whole) {
+            d_sub = pool.take((int64_t)B * item, &rc);
+            if (!d_sub) return dev_fail(rc, h);
+            call_blocks.push_back(d_sub);
+            std::vector<int32_t> idx(b.pos.begin(), b.pos.end());
+            GDB_DEV(bctx, ops.gather_items(bctx, d_sub, 0, d_hist, idx.data(), B, item));
+        }
+        std::vector<double> rxb(B), ryb(B), ccb(B);
+        std::vector<int32_t> wb(B), fb(B);
+        for (int q = 0; q < B; ++q) {
+            const int k = b.ks[q];
+            rxb[q] = rx[k], ryb[q] = ry[k], ccb[q] = cc[k], wb[q] = (int32_t)winw[k], fb[q] = flags[k];
+        }
+        void* d_P = pool.take((int64_t)B * item, &rc);
+        if (!d_P) return dev_fail(rc, h);
+        call_blocks.push_back(d_P);
+        int32_t* status = status_pinned + status_at;
+        if (grid_off + (int64_t)B * F * F > grids_doubles) return fail(GD_ERR_BADARG, "grids_pinned is too small");
+        GDB_DEV(bctx, ops.density2d_enqueue(bctx, B, F, d_sub, rxb.data(), ryb.data(), ccb.data(), wb.data(), fb.data(),
+                                            s.boundary_correction_order, s.mult_bias_correction_order, d_P, status));
+        if (s.want_levels && levels) {
+            std::vector<double> lv((size_t)B * s.ncontours);
+            std::vector<int32_t> ls(B);
+            GDB_DEV(bctx, ops.contour_levels(bctx, B, F, d_P, s.contours, s.ncontours, lv.data(), ls.data()));
+            for (int q = 0; q < B; ++q) {
+                memcpy(levels + (size_t)b.ks[q] * s.ncontours, &lv[(size_t)q * s.ncontours], sizeof(double) * s.ncontours);
+                level_status[b.ks[q]] = ls[q];
+            }
+        }
+        GDB_DEV(bctx, ops.d2h_async(bctx, grids + grid_off, d_P, (int64_t)B * item));
+        for (int q = 0; q < B; ++q) {
+            double* m = M(b.ks[q]);
+            m[1] = (double)(grid_off + (int64_t)q * F * F);
+            m[29] = bctx == h ? 0.0 : 1.0;
+            m[30] = (double)(status_at + q);
+        }
+        grid_off += (int64_t)B * F * F;
+        status_at += B;
+        return 0;
+    }
+
+    int run_class(int F, const std::vector<char>& only, void* force_ctx) {
+        std::vector<Batch> batches;
+        GDB_TRY(class_batches(F, only, batches));
+        for (const Batch& b : batches) GDB_TRY(enqueue_batch(F, b, force_ctx));
+        return 0;
+    }
+
+    // every class, all pairs: classes that go to the second stream are queued there right after the main class's first batch
+    int enqueue_all() {
+        std::vector<int> main_, side;
+        for (int F : order) (is_side(F) ? side : main_).push_back(F);
+        const std::vector<char> all;
+        std::vector<Batch> first;
+        size_t first_done = 0;
+        if (!side.empty() && !main_.empty()) {
+            GDB_TRY(class_batches(main_[0], all, first));
+            if (!first.empty()) {
+                GDB_TRY(enqueue_batch(main_[0], first[0], nullptr));
+                first_done = 1;
+            }
+        }
+        for (int F : side) GDB_TRY(run_class(F, all, nullptr));
+        for (size_t q = 0; q < main_.size(); ++q) {
+            if (q == 0 && !side.empty()) {
+                for (size_t b = first_done; b < first.size(); ++b) GDB_TRY(enqueue_batch(main_[0], first[b], nullptr));
+                continue;
+            }
+            GDB_TRY(run_class(main_[q], all, nullptr));
+        }
+        return 0;
+    }
+
+    int enqueue_part(const std::vector<char>& only, bool last) {
+        for (int F : order) {
+            void* target = (is_side(F) || !last) && conv_ctxs.size() > 1 ? conv_ctxs[1] : conv_ctxs[0];
+            GDB_TRY(run_class(F, only, target));
+        }
+        return 0;
+    }
+
+    // -- getAutoBandwidth2D for the batch (mcsamples.py:1325-1419): the optimiser's launches, unit conversions,
+    //    de-rotation of the sheared kernels, fallbacks, widening; on_chunk(ks, last) after every launch
+    int bandwidth_2d(bool pipelined, const std::function<int(const std::vector<int>&, bool)>& on_chunk) {
+        const int base_F = s.fine_bins_2D;
+        const int m = s.mult_bias_correction_order;
+        std::vector<double> widen;
+        if (m) {
+            widen.resize(P);
+            const double e = 1.0 / 6 - 1.0 / (2 + 4 * (1 + m));
+            for (int k = 0; k < P; ++k) widen[k] = 1.1 * py_pow(plan.neff[k], e);
+        }
+        if (!have_shear) GDB_TRY(shear_histograms(h));
+        const std::vector<int>& A = shear.A;
+        const int nA = (int)A.size();
+        std::vector<int> waiting;
+        for (int k = 0; k < P; ++k)
+            if (plan.branch[k] == 1) {  // rule of thumb (mcsamples.py:1391-1395)
+                const double c = std::max(std::min(ps.actual[k], s.max_corr_2D), -s.max_corr_2D);
+                const double d = py_pow(plan.neff[k], 1.0 / 6);
+                W[(size_t)3 * k] = par[ps.jx[k]].sigma_range / d, W[(size_t)3 * k + 1] = par[ps.jy[k]].sigma_range / d, W[(size_t)3 * k + 2] = c;
+                waiting.push_back(k);
+            }
+        auto report = [&](std::vector<int> ks, bool last) -> int {
+            if (!waiting.empty()) {
+                std::vector<int> all = waiting;
+                all.insert(all.end(), ks.begin(), ks.end());
+                ks.swap(all);
+                waiting.clear();
+            }
+            if (m)
+                for (int k : ks) W[(size_t)3 * k] *= widen[k], W[(size_t)3 * k + 1] *= widen[k];
+            if (!ks.empty() || last) return on_chunk(ks, last);
+            return 0;
+        };
+        struct Launch {
+            int F;
+            std::vector<int> ks;   // plan indices in batch order
+            int na;                // leading sheared rows
+            void* d_hist;          // class buffer
+            std::vector<int> pos;  // positions within the class buffer of the non-sheared rows
+            bool whole;            // the class's buffer as it is
+            bool shear_only;
+        };
+        std::vector<Launch> launches;
+        bool merged = false;
+        const int64_t item = (int64_t)base_F * base_F * 8;
+        for (int F : F_list) {
+            const std::vector<int>& mem = classes.at(F);
+            std::vector<int> pos_C;
+            for (int q = 0; q < (int)mem.size(); ++q)
+                if (plan.branch[mem[q]] == 2) pos_C.push_back(q);
+            if (F == base_F && !pos_C.empty()) {
+                std::vector<size_t> cuts{0, pos_C.size()};
+                if (pipelined && (int)pos_C.size() >= s_kopt_split_min())
+                    cuts = {0, (size_t)((double)pos_C.size() * s_kopt_first()), pos_C.size()};
+                for (size_t part = 0; part + 1 < cuts.size(); ++part) {
+                    Launch L;
+                    L.F = F, L.na = part == 0 ? nA : 0, L.d_hist = hists.at(F), L.shear_only = false;
+                    L.pos.assign(pos_C.begin() + cuts[part], pos_C.begin() + cuts[part + 1]);
+                    L.whole = L.na == 0 && L.pos.size() == mem.size();
+                    for (int q = 0; q < L.na; ++q) L.ks.push_back(A[q]);
+                    for (int q : L.pos) L.ks.push_back(mem[q]);
+                    launches.push_back(L);
+                }
+                merged = true;
+                continue;
+            }
+            if (pos_C.empty()) continue;
+            Launch L;
+            L.F = F, L.na = 0, L.d_hist = hists.at(F), L.pos = pos_C, L.whole = pos_C.size() == mem.size(), L.shear_only = false;
+            for (int q : pos_C) L.ks.push_back(mem[q]);
+            launches.push_back(L);
+        }
+        if (nA && !merged) {
+            Launch L;
+            L.F = base_F, L.na = nA, L.d_hist = shear.d_rot, L.whole = true, L.shear_only = true;
+            L.ks = A;
+            launches.push_back(L);
+        }
+        int rc = 0;
+        for (size_t q = 0; q < launches.size() && !rc; ++q) {
+            Launch& L = launches[q];
+            const int B = (int)L.ks.size();
+            const int F = L.F;
+            void* d_batch = L.d_hist;
+            bool own = false;
+            if (!L.whole) {
+                d_batch = pool.take((int64_t)B * F * F * 8, &rc);
+                if (!d_batch) {
+                    dev_fail(rc, h);
+                    break;
+                }
+                own = true;
+                if (L.na) {
+                    std::vector<int32_t> idx(L.na);
+                    for (int a = 0; a < L.na; ++a) idx[a] = a;
+                    rc = ops.gather_items(h, d_batch, 0, shear.d_rot, idx.data(), L.na, item);
+                }
+                if (!rc && !L.pos.empty()) {
+                    std::vector<int32_t> idx(L.pos.begin(), L.pos.end());
+                    rc = ops.gather_items(h, d_batch, L.na, L.d_hist, idx.data(), (int)idx.size(), (int64_t)F * F * 8);
+                }
+                if (rc) dev_fail(rc, h);
+            }
+            std::vector<double> out((size_t)B * 12);
+            if (!rc) {
+                std::vector<double> ne(B), fb(B), ci(B);
+                std::vector<int32_t> dc(B);
+                for (int row = 0; row < B; ++row) {
+                    const int k = L.ks[row];
+                    const bool rowA = row < L.na;
+                    ne[row] = plan.neff[k], dc[row] = plan.has_limits[k] ? 0 : 1;
+                    fb[row] = rowA ? -1.0 : plan.fallback_t[k];
+                    ci[row] = rowA ? 0.0 : ps.actual[k];
+                }
+                rc = ops.kopt2d(h, B, F, d_batch, ne.data(), dc.data(), fb.data(), ci.data(), out.data());
+                if (rc) dev_fail(rc, h);
+            }
+            if (own) pool.give(d_batch);  // (the entry point has waited for its kernels)
+            if (rc) break;
+            for (int row = 0; row < B; ++row) {
+                const double* o = &out[(size_t)row * 12];
+                if (o[7] == 0 && o[11] != 0) {
+                    rc = fail(GD_ERR_BADARG, "bias not positive definite");  // kde_bandwidth.py:229-230, raised out of get_h
+                    break;
+                }
+            }
+            if (rc) break;
+            for (int row = 0; row < B; ++row) {
+                const int k = L.ks[row];
+                const double* o = &out[(size_t)row * 12];
+                memcpy(M(k) + 6, o, 12 * sizeof(double));
+                double hx, hy, c;
+                if (row < L.na) {
+                    // de-rotate the sheared kernel (mcsamples.py:1379-1390): kernelC = S K S^T for the 2 x 2 case
+                    const double hxa = o[8] * shear.r1s[row], hya = o[9] * shear.r2s[row], ca = o[10];
+                    const double* S = &plan.S[(size_t)4 * k];
+                    const double k00 = hxa * hxa, k01 = hxa * hya * ca, k11 = hya * hya;
+                    const double t00 = S[0] * k00 + S[1] * k01, t01 = S[0] * k01 + S[1] * k11;
+                    const double t10 = S[2] * k00 + S[3] * k01, t11 = S[2] * k01 + S[3] * k11;
+                    const double c00 = t00 * S[0] + t01 * S[1], c01 = t00 * S[2] + t01 * S[3], c11 = t10 * S[2] + t11 * S[3];
+                    const double sx = sqrt(c00), sy = sqrt(c11);
+                    hx = plan.swap[k] ? sy : sx, hy = plan.swap[k] ? sx : sy, c = c01 / sqrt(c00 * c11);
+                } else {
+                    hx = o[8] * plan.rangex[k], hy = o[9] * plan.rangey[k], c = o[10];
+                }
+                if (o[7] != 0) {  // "2D fixed point: no root in [0, 0.1]": the fallback widths (mcsamples.py:1402-1409)
+                    if (s.raise_on_bandwidth_errors) {
+                        char buf[200];
+                        snprintf(buf, sizeof buf, "2D kernel density bandwidth optimizer failed for pair %d (columns %d, %d). "
+                                 "Using fallback width: 2D fixed point: no root in [0, 0.1]", k, (int)ps.jx[k], (int)ps.jy[k]);
+                        rc = fail(GD_ERR_SOLVER, buf);
+                        break;
+                    }
+                    ps.warn[k] |= 4;
+                    const double d = py_pow(plan.neff[k], 1.0 / 6);
+                    hx = par[ps.jx[k]].sigma_range / d, hy = par[ps.jy[k]].sigma_range / d;
+                    c = std::max(std::min(ps.actual[k], s.max_corr_2D), -s.max_corr_2D);
+                }
+                W[(size_t)3 * k] = hx, W[(size_t)3 * k + 1] = hy, W[(size_t)3 * k + 2] = c;
+            }
+            if (rc) break;
+            rc = report(L.ks, q + 1 == launches.size());
+        }
+        if (!rc && launches.empty()) rc = report({}, true);
+        if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
+        return rc;
+    }
+
+    int run(int32_t* tokens_out2) {
+        tokens_out2[0] = tokens_out2[1] = -1;
+        const int base_F = s.fine_bins_2D, bco = s.boundary_correction_order;
+        const double ss = s.smooth_scale_2D;
+        if (fabs(s.max_corr_2D) > 1) return fail(GD_ERR_BADARG, "max_corr_2D cannot be >=1");
+        if (bco > 1) return fail(GD_ERR_BADARG, "unknown boundary_correction_order (expected 0 or 1)");
+        if (base_F < 8 || base_F > 4096) return fail(GD_ERR_BADARG, "fine_bins_2D out of range");
+        bool exchanged = false;
+        if (P == 0) {  // (a rank without pairs still takes part in the exchange)
+            GDB_TRY(neff_exchange(&exchanged));
+            return 0;
+        }
+        int64_t ncols = 0;
+        GDB_DEV(h, ops.num_rows(h, &N, &ncols));
+        if (ncols < n) return fail(GD_ERR_BADARG, "more parameters than resident columns");
+        int32_t hw = 0;
+        GDB_DEV(h, ops.weights_kind(h, &hw));
+        unit_weights = hw == 0;
+        for (int k = 0; k < P; ++k)
+            if (pairs[2 * k] < 0 || pairs[2 * k] >= n || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= n)
+                return fail(GD_ERR_BADARG, "pair index out of range");
+        {  // columns in order of first appearance
+            std::vector<char> seen(n, 0);
+            for (int k = 0; k < 2 * P; ++k)
+                if (!seen[pairs[k]]) seen[pairs[k]] = 1, used.push_back(pairs[k]);
+        }
+        const bool auto_bw = ss < 0;
+        bool need_neff = false;
+        if (auto_bw)
+            for (int j : used) need_neff = need_neff || isnan(par[j].neff);
+        const bool overlap = auto_bw && need_neff && P >= 64 && twin != nullptr;
+        std::future<int> neff_f, bin_f, shear_f;
+        // the N_eff kernels need nothing but the parameter ranges: they start first, on their own thread, and run beside
+        // the binning on the second stream while the per-pair scalars are worked out here
+        if (overlap)
+            neff_f = std::async(std::launch::async, [this] {
+                ops.bind_thread(h);
+                return neff_batch(used, true);
+            });
+        bmin.assign(n, NAN), bmax.assign(n, NAN);
+        for (int j : used) bin_edges(par[j], &bmin[j], &bmax[j]);
+        pair_scalars(s, n, corrmat, pairs, P, ps);
+        fwx.resize(P), fwy.resize(P);
+        for (int k = 0; k < P; ++k) {
+            const int F = ps.F[k];
+            if (!classes.count(F)) F_list.push_back(F);
+            classes[F].push_back(k);
+            fwx[k] = (bmax[ps.jx[k]] - bmin[ps.jx[k]]) / (F - 1);
+            fwy[k] = (bmax[ps.jy[k]] - bmin[ps.jy[k]]) / (F - 1);
+            double* m = M(k);
+            for (int q = 0; q < GD_BATCH2D_META; ++q) m[q] = NAN;
+            m[0] = F, m[5] = -1, m[23] = bmin[ps.jx[k]], m[24] = bmax[ps.jx[k]], m[25] = bmin[ps.jy[k]], m[26] = bmax[ps.jy[k]];
+            m[27] = ps.corr[k], m[28] = (double)ps.nbin2D[k];
+        }
+        int64_t need = 0;
+        for (int k = 0; k < P; ++k) need += (int64_t)ps.F[k] * ps.F[k];
+        if (need > grids_doubles) {
+            if (neff_f.valid()) neff_f.get();
+            return fail(GD_ERR_BADARG, "grids_pinned is too small");
+        }
+        std::vector<double> rngx(P), rngy(P);
+        for (int k = 0; k < P; ++k) rngx[k] = bmax[ps.jx[k]] - bmin[ps.jx[k]], rngy[k] = bmax[ps.jy[k]] - bmin[ps.jy[k]];
+        int rc = 0;
+        if (auto_bw) {
+            if (overlap) {
+                bin_f = std::async(std::launch::async, [this] {
+                    ops.bind_thread(twin);
+                    return binning(twin);
+                });
+                rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
+                int e = neff_f.get();
+                if (!rc) rc = e;
+                if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)
+                if (!rc) {
+                    // a context is not re-entrant: the shear launches start once the N_eff call has returned
+                    shear_f = std::async(std::launch::async, [this] {
+                        ops.bind_thread(h);
+                        return shear_histograms(h);
+                    });
+                    fill_plan(par, ps, plan);
+                    e = shear_f.get();
+                    if (!rc) rc = e;
+                }
+                e = bin_f.get();
+                if (!rc) rc = e;
+            } else {
+                rc = neff_batch(used, true);
+                if (!rc) rc = neff_complete(&exchanged);
+                if (!rc) rc = binning(h);
+                if (!rc) rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
+                if (!rc) fill_plan(par, ps, plan);
+            }
+        } else {
+            rc = neff_exchange(&exchanged);  // the collective is unconditional: once per call on every rank
+            if (!rc) rc = binning(h);
+        }
+        if (rc) return cleanup(rc);
+        // ---- convolution set-up: flag bits (mcsamples.py:1688-1703, 1794): bits 0/1 = x bot/top, 2/3 = y bot/top,
+        //      4/5 = x/y periodic, 6 = has_prior
+        flags.resize(P), group.resize(P);
+        for (int k = 0; k < P; ++k) {
+            const gd_param2d &px = par[ps.jx[k]], &py = par[ps.jy[k]];
+            const int lbx = px.periodic ? 0 : (px.has_limits_bot ? 1 : 0) | (px.has_limits_top ? 2 : 0);
+            const int lby = py.periodic ? 0 : (py.has_limits_bot ? 1 : 0) | (py.has_limits_top ? 2 : 0);
+            const int has_prior = has_limits(px) || has_limits(py);
+            flags[k] = lbx | ((px.periodic ? 1 : 0) << 4) | (lby << 2) | ((py.periodic ? 1 : 0) << 5) | (has_prior << 6);
+            group[k] = (flags[k] & 48) * 2 + ((has_prior && bco >= 0) ? 1 : 0);
+        }
+        rx.assign(P, NAN), ry.assign(P, NAN), cc.assign(P, NAN), smooth.assign(P, NAN), winw.assign(P, 0), W.assign((size_t)3 * P, NAN);
+        const bool lazy = !s.want_levels;
+        conv_ctxs = {h};
+        if (lazy && twin && P >= s_two_min()) {
+            if (P > s_two_split()) {
+                for (int F : F_list)
+                    if ((int)classes.at(F).size() < 64) side_classes.push_back(F);
+                if (side_classes.size() == F_list.size()) side_classes.clear();
+            }
+            conv_ctxs.push_back(twin);
+        }
+        // largest class (in bytes) first: the copy of the last, smallest one is the only exposed one
+        order = F_list;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return (int64_t)classes.at(a).size() * a * a > (int64_t)classes.at(b).size() * b * b;
+        });
+        std::vector<int> all_k(P);
+        for (int k = 0; k < P; ++k) all_k[k] = k;
+        if (auto_bw) {
+            const bool pipelined = conv_ctxs.size() > 1 && P > s_two_split();
+            std::vector<std::future<int>> enqueueing;
+            std::function<int(const std::vector<int>&, bool)> on_chunk;
+            if (pipelined) {
+                on_chunk = [&](const std::vector<int>& ks, bool last) -> int {
+                    set_scales(ks);
+                    auto only = std::make_shared<std::vector<char>>(P, 0);
+                    for (int k : ks) (*only)[k] = 1;
+                    if (!last) {
+                        // the second stream's own thread enqueues this part's convolution while this thread goes straight
+                        // on to the next optimiser launch; parts follow one another (one thread's worth of order)
+                        std::shared_future<int> prev;
+                        if (!enqueueing.empty()) prev = enqueueing.back().share(), enqueueing.pop_back();
+                        enqueueing.push_back(std::async(std::launch::async, [this, only, prev] {
+                            if (prev.valid()) {
+                                const int e = prev.get();
+                                if (e) return e;
+                            }
+                            ops.bind_thread(conv_ctxs[1]);
+                            return enqueue_part(*only, false);
+                        }));
+                        return 0;
+                    }
+                    int e = 0;
+                    for (auto& f : enqueueing) {
+                        const int e1 = f.get();
+                        if (e1 && !e) e = e1;
+                    }
+                    enqueueing.clear();
+                    if (e) return e;
+                    return enqueue_part(*only, true);
+                };
+                rc = bandwidth_2d(true, on_chunk);
+                for (auto& f : enqueueing)
+                    if (f.valid()) {
+                        const int e1 = f.get();
+                        if (e1 && !rc) rc = e1;
+                    }
+            } else {
+                on_chunk = [&](const std::vector<int>&, bool) -> int { return 0; };
+                rc = bandwidth_2d(false, on_chunk);
+                if (!rc) {
+                    set_scales(all_k);
+                    rc = enqueue_all();
+                }
+            }
+            for (int k = 0; k < P && !rc; ++k) {
+                double* m = M(k);
+                m[2] = W[(size_t)3 * k], m[3] = W[(size_t)3 * k + 1], m[4] = W[(size_t)3 * k + 2];
+                m[5] = plan.branch[k], m[31] = plan.neff[k];
+            }
+        } else {
+            for (int k = 0; k < P; ++k) {
+                if (ss < 1.0) {
+                    rx[k] = ss * par[ps.jx[k]].err / fwx[k];
+                    ry[k] = ss * par[ps.jy[k]].err / fwy[k];
+                } else {
+                    rx[k] = ry[k] = ss * ps.F[k] / (double)ps.nbin2D[k];
+                }
+                cc[k] = ps.corr[k];
+                finish_scale(k);
+            }
+            rc = enqueue_all();
+        }
+        if (rc) return cleanup(rc);
+        for (int k = 0; k < P; ++k) {
+            double* m = M(k);
+            m[18] = rx[k], m[19] = ry[k], m[20] = cc[k], m[21] = (double)winw[k], m[22] = ps.warn[k];
+        }
+        for (auto& kv : hists) call_blocks.push_back(kv.second);
+        hists.clear();
+        GDB_DEV(h, ops.copy_mark(h, &tokens_out2[0]));
+        if (conv_ctxs.size() > 1) GDB_DEV(twin, ops.copy_mark(twin, &tokens_out2[1]));
+        if (!lazy) {
+            for (void* c : conv_ctxs) GDB_DEV(c, ops.copy_sync(c));
+            for (void* p : call_blocks) pool.give(p);
+            call_blocks.clear();
+            return 0;
+        }
+        // This call's blocks wait for its copies.  The previous call's copies are ahead of this call's on the copy
+        // streams: completing it here costs no waiting, and its device blocks return to the pool even if nobody ever
+        // read its grids.
+        Pending cur;
+        cur.blocks.swap(call_blocks);
+        cur.tok_main = tokens_out2[0], cur.tok_twin = tokens_out2[1], cur.twin = conv_ctxs.size() > 1 ? twin : nullptr;
+        cur.live = true;
+        const int e_prev = complete_pending(st, ops, h, st.prev);
+        st.prev = std::move(cur);
+        if (e_prev) return dev_fail(e_prev, h);
+        return 0;
+    }
+
+    // an error after device work was started: wait for whatever is in flight, hand every block back
+    int cleanup(int rc) {
+        ops.copy_sync(h);
+        if (twin) ops.copy_sync(twin);
+        for (auto& kv : hists) pool.give(kv.second);
+        hists.clear();
+        if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
+        for (void* p : call_blocks) pool.give(p);
+        call_blocks.clear();
+        return rc;
+    }
+#undef GDB_DEV
+#undef GDB_TRY
+};
+
+}  // namespace gdb

@@ -127,6 +127,14 @@ void* gd_scratch2(gd_ctx* ctx, int64_t bytes) {
 }
 
 
+// live contexts (a batched call may remember a second context that its owner has destroyed meanwhile)
+static std::mutex g_live_mu;
+static std::set<gd_ctx*> g_live;
+bool gd_ctx_alive(gd_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_live_mu);
+    return g_live.count(ctx) != 0;
+}
+
 extern "C" {
 
 const char* gd_version(void) { return "gdhip 0.1 (gfx950)"; }
@@ -154,6 +162,10 @@ int gd_create(int device, gd_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    {
+        std::lock_guard<std::mutex> g(g_live_mu);
+        g_live.insert(ctx);
+    }
     *out = ctx;
     return GD_OK;
 }
@@ -162,6 +174,11 @@ void gd_destroy(gd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->batch_state_release) ctx->batch_state_release(ctx, true);
+    {
+        std::lock_guard<std::mutex> g(g_live_mu);
+        g_live.erase(ctx);
+    }
     gd_fft_cache_destroy(ctx);
     for (auto& kv : ctx->dctmat) (void)hipFree(kv.second);
     for (auto& kv : ctx->fft_tw) (void)hipFree(kv.second);
@@ -450,6 +467,7 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
     GD_HIP(hipSetDevice(ctx->device));
     GD_TRY(gd_stream_sync(ctx));
+    if (ctx->batch_state_release) ctx->batch_state_release(ctx, false);  // index columns of the old sample set
     if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {
         if (ctx->cols) (void)hipFree(ctx->cols);

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,9 @@ struct gd_ctx {
     void* fetch_block = nullptr;
     size_t fetch_off = 0;
     std::vector<Fetch> fetch_pending;
+    // gd_density2d_batch (batch2d.hip): device-block pool, cached index columns and the last call's blocks in flight
+    void* batch_state = nullptr;
+    void (*batch_state_release)(gd_ctx*, bool destroy) = nullptr;
 };
 
 // Stream-ordered H2D copy of a small host table whose storage the caller may release as soon as this returns.
@@ -96,6 +101,7 @@ int gd_fetch_pinned(gd_ctx* ctx, void* pinned_dst, const void* d_src, size_t byt
 int gd_stream_sync(gd_ctx* ctx);
 
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
+bool gd_ctx_alive(gd_ctx* ctx);  // false once gd_destroy has run on it (core.hip)
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure
 void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
 

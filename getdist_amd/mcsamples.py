@@ -638,6 +638,8 @@ class MCSamples:
         pend, self._pending_results = getattr(self, "_pending_results", None), None
         if pend is not None:
             pend.wait()
+        if getattr(self.ctx, "h", None) is not None and hasattr(self.ctx, "batch2d_finish"):
+            self.ctx.batch2d_finish()  # the library hands the call's device blocks back (before a second context goes away)
         twin = getattr(self, "_twin", None)
         if twin is not None and getattr(twin, "_pending_results", None) is not None:
             pend, twin._pending_results = twin._pending_results, None
@@ -1768,7 +1770,10 @@ class MCSamples:
         share = getattr(self, "_neff_share", None)
         if share is None:
             return
-        if any(self.paramNames.names[j].N_eff_kde is None for j in js):
+        if not getattr(share, "exchanged", False):
+            # unconditional, once per step on every rank: a rank whose own parameters cover its pairs must still enter
+            # the collective the other ranks are waiting in
+            share.exchanged = True
             share.exchange(self)
         self._neff_share = None
         try:
@@ -2582,6 +2587,23 @@ class MCSamples:
                 pa = None
         pairs = pa.astype(np.int64, copy=False) if pa is not None else [(self._col(a), self._col(b)) for a, b in pairs]
         lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
+        if (hasattr(self.ctx, "density2d_batch") and os.environ.get("GETDIST_AMD_NATIVE_BATCH", "1") == "1" and lanes < 2
+                and self._lane == 0 and not self._timing and not meanlikes and _bandwidths is None and mask_function is None
+                and not self.use_effective_samples_2D):
+            # ONE native call: every decision between the kernels is taken inside the library (csrc/batch2d.hpp); the
+            # Python-planned pipeline below remains for the optional branches (mean likelihoods, mask callbacks, injected
+            # bandwidths, per-phase timing, 2D effective sample numbers)
+            from . import batch2d
+
+            base_F = kwargs.get("fine_bins_2D", self.fine_bins_2D)
+            bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
+            mbc = kwargs.get("mult_bias_correction_order", self.mult_bias_correction_order)
+            if abs(self.max_corr_2D) > 1:
+                raise SettingError("max_corr_2D cannot be >=1")
+            if bco > 1:
+                raise SettingError("unknown boundary_correction_order (expected 0 or 1)")
+            return batch2d.run(self, np.asarray(pairs, dtype=np.int64).reshape(-1, 2), base_F, bco, mbc,
+                               float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D)), num_plot_contours, get_density)
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
                 or self.use_effective_samples_2D or mask_function is not None):
             with _FastThreadSwitch(len(pairs) >= 64):

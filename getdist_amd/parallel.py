@@ -47,6 +47,14 @@ class NeffShare:
     def __init__(self, params, exchange):
         self.params = set(params)
         self.exchange = exchange
+        self.exchanged = False  # the collective is entered exactly once per step (complete())
+
+    def complete(self, mc):
+        """Enter the exchange if the step has not done so yet (a rank without pairs, a call with a fixed smoothing scale,
+        a call that raised): every rank issues the same collectives in the same order, whatever its share needed."""
+        if not self.exchanged:
+            self.exchanged = True
+            self.exchange(mc)
 
 
 def allgather_neff(mc, my_js, n_params, dist=None, device=None):

@@ -373,6 +373,97 @@ int gd_autoconvolve(gd_ctx* ctx, int32_t col, double mean, int32_t use_weights, 
  *           first row index attaining min L (np.argmin)}. */
 int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8);
 
+
+/* ---------------------------------------------------------------- one native entry for a batch of pairs ----------
+ * gd_density2d_batch: MCSamples.get2DDensityGridData (mcsamples.py:1748-2010) for P parameter pairs in ONE call, with
+ * every host decision of the reference made inside the library (csrc/batch2d.hpp):
+ *   - the per-pair correlation handling, angle_scale and the up-scaling of the fine grid (mcsamples.py:1796-1816),
+ *   - the bin edges of _binSamples (mcsamples.py:1486-1498) and the 2D histograms (:1724-1728), index columns cached
+ *     per (parameter, grid size) and shared by the pairs of a triangle,
+ *   - the effective sample numbers of the parameters that have none yet (_get1DNeff -> getEffectiveSamplesGaussianKDE,
+ *     chains.py:477-574, mcsamples.py:1230-1235), on the first stream BESIDE the binning on the second,
+ *   - getAutoBandwidth2D (mcsamples.py:1285-1419): branch A (sheared re-binning + Cholesky de-rotation), B (rule of
+ *     thumb), C (KernelOptimizer2D on the pair's own grid), the fallback widths and the higher-order widening,
+ *   - window half-widths and frame sizes, batches of equal frame size, the convolution / boundary correction /
+ *     multiplicative bias correction / normalisation of gd_density2d_enqueue (mcsamples.py:1857-1990) on two streams,
+ *     the optimiser's launch cut in two so that the first half is convolved while the second is optimised,
+ *   - the D2H copies of the finished grids into ONE page-locked block of the caller, batch by batch on the copy streams.
+ * The call returns when everything is enqueued; the grids are complete after gd_copy_wait(ctx, tokens_out[0]) and, when
+ * `twin` was given, gd_copy_wait(twin, tokens_out[1]).
+ *
+ * ctx    : the context holding the samples.  twin: a second context on the same device attached to it
+ *          (gd_attach_samples) = the second stream; NULL runs everything on one stream.
+ * params : n records, index = column number; only the columns that occur in `pairs` are read.  `neff` is in/out: NaN on
+ *          entry = not known yet, computed here when the bandwidth is automatic (smooth_scale_2D < 0).  `owned` != 0
+ *          marks the parameters whose N_eff THIS rank computes in a multi-rank job; the others arrive through `exchange`.
+ * corr / cov : the n x n correlation and covariance matrices of the columns (chains.py:155-169, 709-733), row-major.
+ * lag_probe  : optional n x 8 autocovariance lag sums (gd_autocov_lags_batch of all columns, lags 0..7) a caller may have
+ *          prefetched beside its quantile select; NULL = computed here.
+ * pairs  : P x 2 column indices (x, y).
+ * exchange : optional; called exactly once per call, on the calling thread, after this rank's own N_eff kernels are
+ *          through: it receives the n-vector of N_eff values (NaN = unknown here) and fills in the other ranks' values
+ *          (an all-gather); return non-zero to abort.  NULL with a communicator on the context (gd_comm_init) uses RCCL.
+ * grids_pinned : page-locked block of >= sum F_k^2 doubles (F_k from gd_batch2d_grid_sizes); pair k's grid lands at
+ *          meta[k][1] doubles from its start, F x F row-major, [y][x].
+ * status_pinned : P int32, page-locked; after the copies have landed status_pinned[(int)meta[k][30]] is GD_OK or
+ *          GD_ERR_EMPTY ("no samples in bin", densities.py:83-84) for pair k.
+ * meta   : P x GD_BATCH2D_META doubles:
+ *          [0] F  [1] offset of the grid  [2..4] (hx, hy, corr) of the kernel in parameter units (NaN when the scale is fixed)
+ *          [5] bandwidth branch 0/1/2 = A/B/C (-1: fixed scale)  [6..17] the optimiser's record as gd_kopt2d writes it
+ *          [18..20] window scales rx, ry in fine-bin units and the window's correlation  [21] window half-width
+ *          [22] bits: 1 = "Parameters are 100% correlated", 2 = "fine_bins_2D not large enough", 4 = fallback widths used
+ *          [23..26] xbinmin, xbinmax, ybinmin, ybinmax  [27] the pair's correlation as used for the grid  [28] nbin2D
+ *          [29] 0 / 1 = the grid's copy runs on ctx's / twin's copy stream  [30] index into status_pinned  [31] N_eff used
+ * levels / level_status : when settings->want_levels, P x ncontours contour levels (gd_contour_levels) and P states.
+ * Errors: GD_ERR_BADARG "bias not positive definite" (kde_bandwidth.py:229-230) and setting errors; GD_ERR_SOLVER when
+ *   raise_on_bandwidth_errors and the optimiser found no root; GD_ERR_FFT + 1000 * ... never; a parameter whose chain
+ *   correlation outlasts the 8-lag probe returns GD_BATCH2D_NEED_NEFF with its column in gd_last_error -- the caller
+ *   computes that N_eff (getCorrelationLength's long route) and calls again. */
+#define GD_BATCH2D_META 32
+#define GD_BATCH2D_NEED_NEFF (-20)
+
+typedef struct gd_param2d {
+    double range_min, range_max; /* par.range_min / range_max after _initParam (mcsamples.py:1421-1484) */
+    double param_min, param_max; /* column extrema */
+    double sigma_range, err;     /* par.sigma_range, par.err */
+    double mean, var;            /* weighted mean and variance of the column (the N_eff probe) */
+    double neff;                 /* par.N_eff_kde; NaN = unknown (in/out) */
+    int32_t has_limits_bot, has_limits_top, periodic, owned;
+} gd_param2d;
+
+typedef struct gd_batch2d_settings {
+    int32_t fine_bins_2D, boundary_correction_order, mult_bias_correction_order, num_bins_2D;
+    double smooth_scale_2D, max_corr_2D;
+    double norm, sum_w2;                /* sum w, sum w^2 of the sample weights (chains.py:312,499) */
+    int32_t uncorrelated_sampler;       /* sampler in ("nested", "uncorrelated"): N_eff = norm^2 / sum_w2 (chains.py:507-508) */
+    int32_t raise_on_bandwidth_errors;
+    int32_t want_levels, ncontours;     /* contour levels on the device instead of lazily delivered grids */
+    const double* contours;
+    /* choreography (defaults in parentheses; 0 = default) */
+    int32_t two_streams_min;            /* (64)  pairs from which the convolution uses both streams */
+    int32_t two_streams_split;          /* (400) pairs above which the optimiser's launch is cut in two */
+    int32_t kopt_split_min;             /* (256) ... when the base grid's launch has at least this many pairs */
+    double kopt_first_fraction;         /* (0.5) */
+    int32_t first_batch, max_batch;     /* (128, 320) grids in the first / in every further convolution batch */
+    double max_batch_bytes;             /* (24e9) device scratch a batch may take */
+} gd_batch2d_settings;
+
+typedef int (*gd_neff_exchange_fn)(void* user, double* neff_n, int32_t n);
+
+/* F_out[k] = the fine grid size pair k will get (mcsamples.py:1796-1816: 256, or 192 * (3 / angle_scale) // 3 for
+ * strongly correlated pairs); host only. */
+int gd_batch2d_grid_sizes(const gd_batch2d_settings* settings, int32_t n, const double* corr, const int32_t* pairs,
+                          int32_t P, int32_t* F_out);
+int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* settings, gd_param2d* params, int32_t n,
+                       const double* corr, const double* cov, const double* lag_probe, const int32_t* pairs, int32_t P,
+                       gd_neff_exchange_fn exchange, void* exchange_user, void* grids_pinned, int64_t grids_doubles,
+                       int32_t* status_pinned, double* meta, double* levels, int32_t* level_status, int32_t* tokens_out2);
+/* Completes the last batched call(s) of the context (waits for their result copies, hands their device blocks back to
+ * the library's pool); gd_batch2d_invalidate additionally marks every cached index column stale (the next call bins
+ * again -- what a benchmark does between steps, and what gd_upload does by itself). */
+int gd_batch2d_finish(gd_ctx* ctx);
+int gd_batch2d_invalidate(gd_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,209 @@
+"""
+CPU tests of the native batch entry's HOST side (getdist_amd/csrc/batch2d.hpp: the plan of a pair batch and the
+choreography of the device work), compiled with g++ and driven against the numpy context double: the grids, bandwidths
+and optimiser records of MCSamples.get2DDensities through gd_density2d_batch's code must equal those of the
+Python-planned route bit for bit, for every branch / grid class / setting the route serves.  (On the GPU the same
+comparison runs against the real kernels: tests/test_gpu_native_batch.py.)
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import native_batch_util as nb
+
+
+def make(fx, factory, **kw):
+    from getdist_amd.mcsamples import MCSamples
+
+    return MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"],
+                     _context_factory=factory, **kw)
+
+
+def same(native, plain):
+    assert len(native) == len(plain)
+    for k, (a, b) in enumerate(zip(native, plain)):
+        assert a.P.shape == b.P.shape, k
+        assert np.array_equal(a.P, b.P), (k, float(np.max(np.abs(a.P - b.P))))
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and a.spacing == b.spacing, k
+        assert a.bandwidth_branch == b.bandwidth_branch, k
+        assert (a.bandwidth is None) == (b.bandwidth is None) and (a.bandwidth is None or a.bandwidth == b.bandwidth), k
+        assert (a.kopt is None) == (b.kopt is None), k
+        assert a.kopt is None or np.array_equal(a.kopt, b.kopt, equal_nan=True), k
+        assert a.view_ranges == b.view_ranges
+
+
+def test_cholesky_shear_equals_numpy_lapack():
+    """np.linalg.cholesky / inv of the 2 x 2 covariance (mcsamples.py:1352-1356) spelled out, pivoting case included."""
+    lib = nb.harness()
+    rng = np.random.default_rng(5)
+    S, r = np.zeros(4), np.zeros(2)
+    pivoted = 0
+    for t in range(20000):
+        a = rng.normal(size=(2, 3)) * 10 ** rng.uniform(-3, 3, size=(2, 1))
+        cov = a @ a.T
+        Sref = np.linalg.cholesky(cov)
+        ich = np.linalg.inv(Sref)
+        pivoted += abs(Sref[1, 0]) > abs(Sref[0, 0])
+        Sref = Sref * ich[0, 0]
+        rref = ich[1, :] / ich[0, 0]
+        assert lib.gdt_chol_shear(cov[0, 0], cov[1, 0], cov[1, 1], S.ctypes.data_as(nb._pd), r.ctypes.data_as(nb._pd)) == 0
+        assert np.array_equal(S.reshape(2, 2), Sref) and np.array_equal(r, rref), (t, cov)
+    assert pivoted > 1000
+    assert lib.gdt_chol_shear(1.0, 2.0, 1.0, S.ctypes.data_as(nb._pd), r.ctypes.data_as(nb._pd)) == 1  # not positive definite
+
+
+def test_scalar_power_is_libm_pow():
+    """Python's ``x ** y`` on floats is libm pow; the native plan must not turn pow(x, 2.0) into x * x."""
+    lib = nb.harness()
+    rng = np.random.default_rng(7)
+    for x in (rng.uniform(0.1, 1e7, size=20000)).tolist():
+        assert lib.gdt_py_pow(x, 2.0) == x ** 2.0 and lib.gdt_py_pow(x, 1.0 / 6) == x ** (1.0 / 6)
+
+
+def test_native_route_equals_python_route_block50(zoo):
+    """block50: branches A / B / C, four grid sizes, bounded and unbounded pairs; u8 and u16 binning; one and two streams."""
+    fx = zoo["block50"]
+    plain = make(fx, nb.PlainContext).get2DDensities(fx["pairs"])
+    nb.CALLS.clear()
+    mc = make(fx, nb.HarnessContext)
+    native = mc.get2DDensities(fx["pairs"])
+    same(native, plain)
+    assert {d.bandwidth_branch for d in native} == {"A", "B", "C"} and len({d.P.shape[0] for d in native}) == 4
+    ops = [c[0] for c in nb.CALLS]
+    assert "density2d_enqueue" in ops and "kopt2d" in ops and "hist2d_sheared" in ops
+    # a second call finds the index columns made and the effective sample numbers known: same grids
+    nb.CALLS.clear()
+    again = mc.get2DDensities(fx["pairs"])
+    same(again, plain)
+    assert not any(c[0] in ("prebin8_batch", "autocov_lags_batch", "kde_lag_sums_batch") for c in nb.CALLS)
+    mc.ctx.batch2d_invalidate()
+    nb.CALLS.clear()
+    mc.get2DDensities(fx["pairs"][:5])
+    assert any(c[0] == "hist2d_prebinned" for c in nb.CALLS)
+
+
+def triangle(n):
+    return [(i, j) for i in range(n) for j in range(i + 1, n)]
+
+
+def test_native_route_large_call_two_streams_pipelined(zoo):
+    """78 pairs with the thresholds lowered so that the call takes the routes of a full triangle: byte-index binning on
+    the second context beside the N_eff kernels on the first, the optimiser's launch cut in two, the first part convolved
+    on the second stream, side classes."""
+    fx = zoo["block50"]
+    pairs = triangle(13)
+    ref = make(fx, nb.PlainContext)
+    plain = ref.get2DDensities(pairs)
+    mc = make(fx, nb.HarnessContext)
+    mc.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc.KOPT_SPLIT_MIN = 8
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs)
+    same(native, plain)
+    lanes = {c[1] for c in nb.CALLS if c[0] == "density2d_enqueue"}
+    assert len(lanes) == 2, "the convolution used one stream only"
+    assert sum(1 for c in nb.CALLS if c[0] == "kopt2d") >= 2
+    main, twin = mc.ctx.lane, mc._twin.ctx.lane
+    # N_eff on the first context, the base grid's binning on the second
+    assert all(c[1] == main for c in nb.CALLS if c[0] in ("kde_lag_sums_batch", "autocov_lags_batch", "hist2d_sheared", "kopt2d"))
+    assert all(c[1] == twin for c in nb.CALLS if c[0] in ("prebin8_batch", "hist2d_prebinned8", "hist2d_prebinned"))
+    assert any(c[0] == "hist2d_prebinned8" for c in nb.CALLS)
+    assert [p.N_eff_kde for p in mc.paramNames.names[:13]] == [p.N_eff_kde for p in ref.paramNames.names[:13]]
+
+
+@pytest.mark.parametrize("kw", [dict(mult_bias_correction_order=0), dict(boundary_correction_order=0),
+                                dict(boundary_correction_order=-1, mult_bias_correction_order=2),
+                                dict(smooth_scale_2D=0.5), dict(smooth_scale_2D=2.5), dict(fine_bins_2D=128)])
+def test_native_route_settings(zoo, kw):
+    fx = zoo["block10_weighted"]
+    pairs = triangle(6) + [(7, 2), (9, 8)]
+    plain = make(fx, nb.PlainContext).get2DDensities(pairs, **kw)
+    native = make(fx, nb.HarnessContext).get2DDensities(pairs, **kw)
+    same(native, plain)
+
+
+def test_native_route_contour_levels_and_names(zoo):
+    fx = zoo["c1_bounded"]
+    names = fx["names"]
+    pairs = [(names[0], names[1]), (names[2], names[3]), (names[3], names[1])]
+    plain = make(fx, nb.PlainContext).get2DDensities(pairs, get_density=False, num_plot_contours=2)
+    native = make(fx, nb.HarnessContext).get2DDensities(pairs, get_density=False, num_plot_contours=2)
+    same(native, plain)
+    for a, b in zip(native, plain):
+        assert np.array_equal(a.contours, b.contours)
+
+
+def test_native_route_periodic(zoo):
+    fx = zoo["periodic"]
+    pairs = triangle(len(fx["names"]))
+    plain = make(fx, nb.PlainContext).get2DDensities(pairs)
+    native = make(fx, nb.HarnessContext).get2DDensities(pairs)
+    same(native, plain)
+
+
+def test_native_exchange_is_unconditional_and_owned_parameters_only(zoo):
+    """Multi-rank N_eff share through the native entry: this rank computes the parameters it owns, the callback -- called
+    exactly once, also for a call that needs nothing from it -- delivers the others."""
+    from getdist_amd import parallel
+
+    fx = zoo["block50"]
+    pairs = triangle(8)
+    ref = make(fx, nb.PlainContext)
+    plain = ref.get2DDensities(pairs)
+    truth = [p.N_eff_kde for p in ref.paramNames.names]
+    mc = make(fx, nb.HarnessContext)
+    calls = []
+
+    def exchange(mc_):
+        calls.append([p.N_eff_kde for p in mc_.paramNames.names[:8]])
+        for j in (1, 3, 5, 7):  # what the other rank owns
+            mc_.paramNames.names[j].N_eff_kde = truth[j]
+
+    mc._neff_share = parallel.NeffShare([0, 2, 4, 6], exchange)
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs)
+    assert len(calls) == 1 and mc._neff_share.exchanged
+    assert all(calls[0][j] is not None for j in (0, 2, 4, 6)) and all(calls[0][j] is None for j in (1, 3, 5, 7))
+    same(native, plain)
+    # a call that needs no N_eff from anybody still enters the collective once
+    mc2 = make(fx, nb.HarnessContext)
+    calls.clear()
+    mc2._neff_share = parallel.NeffShare([0, 1], exchange)
+    mc2.get2DDensities([(0, 1)], smooth_scale_2D=0.3)
+    assert len(calls) == 1
+    # ... and so does a rank without pairs
+    mc3 = make(fx, nb.HarnessContext)
+    calls.clear()
+    mc3._neff_share = parallel.NeffShare([], exchange)
+    assert mc3.get2DDensities([]) == [] and len(calls) == 1
+
+
+def test_native_route_correlated_chain_falls_back_to_the_long_route():
+    """A chain whose correlation outlasts the 8-lag probe: the entry asks for that N_eff (GD_BATCH2D_NEED_NEFF), the host
+    computes it by getCorrelationLength's long route, the second call succeeds; same grids as the Python-planned route."""
+    from getdist_amd.mcsamples import MCSamples
+
+    rng = np.random.default_rng(11)
+    N = 6000
+    e = rng.normal(size=(N, 3))
+    x = np.zeros((N, 3))
+    for i in range(1, N):
+        x[i] = 0.97 * x[i - 1] + e[i]
+    kw = dict(samples=x, names=["a", "b", "c"])
+    plain = MCSamples(_context_factory=nb.PlainContext, **kw).get2DDensities(triangle(3))
+    native = MCSamples(_context_factory=nb.HarnessContext, **kw).get2DDensities(triangle(3))
+    same(native, plain)
+
+
+def test_grid_sizes_entry(zoo):
+    fx = zoo["block50"]
+    mc = make(fx, nb.HarnessContext)
+    dens = mc.get2DDensities(fx["pairs"])
+    from getdist_amd import batch2d
+
+    s = batch2d.settings_of(mc, mc.fine_bins_2D, 1, 1, -1.0, False, None)
+    F = mc.ctx.batch2d_grid_sizes(s, mc.n, np.ascontiguousarray(mc.getCorrelationMatrix()), np.asarray(fx["pairs"], dtype=np.int32))
+    assert F.tolist() == [d.P.shape[0] for d in dens]
+    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 112
