@@ -81,6 +81,7 @@ SIGNATURES = {
     "gd_prebin_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p)]),
     "gd_prebin8_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p), _pi64]),
     "gd_hist2d_prebinned8": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _p]),
+    "gd_prebin8_hist2d": (C.c_int, [_p, _pi32, _i32, _pd, _pd, C.POINTER(_p), _pi64, _i32, C.POINTER(_p), C.POINTER(_p), _p]),
     "gd_hist2d": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _i32, _p]),
     "gd_hist2d_prebinned": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "gd_minmax_affine": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     "gd_isj1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pi32]),
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd]),
+    "gd_kopt2d_enqueue": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _p, _pi32]),
+    "gd_kopt2d_finish": (C.c_int, [_p, _p, _i32, _i32, _p, _pd]),
     "gd_get_h": (C.c_int, [_p, _i32, _pd, _pd, _pd, _pi32, _pd]),
     "gd_density2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32]),
     "gd_copy_mark": (C.c_int, [_p, _pi32]),

@@ -25,6 +25,11 @@ const gdb::Ops kOps = {
     [](void* h, int32_t B, const void* const* ix, const void* const* iy, void* d_hist) {
         return gd_hist2d_prebinned8(C(h), B, ix, iy, d_hist);
     },
+    /* prebin8_hist2d */
+    [](void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, void* const* d_idx, int64_t* bad,
+       int32_t B, const void* const* ix, const void* const* iy, void* d_hist) {
+        return gd_prebin8_hist2d(C(h), cols, ncols, binmin, width, d_idx, bad, B, ix, iy, d_hist);
+    },
     /* prebin */
     [](void* h, int32_t col, double binmin, double width, int32_t F, void* d_idx) {
         return gd_prebin(C(h), col, binmin, width, F, d_idx);
@@ -80,6 +85,33 @@ const gdb::Ops kOps = {
         return gd_kde_lag_sums(C(h), col, inv4s2, lags, nlags, out);
     },
     /* last_error */ [](void* h) { return gd_last_error(C(h)); },
+    /* create_aux */
+    [](void* h, void** aux) {
+        gd_ctx* a = nullptr;
+        int rc = gd_create(C(h)->device, &a);
+        if (rc == 0) rc = gd_attach_samples(a, C(h));
+        if (rc == 0) rc = gd_stream_priority(a, 1);  // small latency-critical kernels (get_h) beside saturating launches
+        if (rc) {
+            if (a) gd_destroy(a);
+            return gd_fail(C(h), rc, "could not create the third context of a batched call");
+        }
+        *aux = a;
+        return 0;
+    },
+    /* destroy_aux */
+    [](void* aux) {
+        gd_destroy(C(aux));
+        return 0;
+    },
+    /* kopt2d_enqueue */
+    [](void* h, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr, const double* fallback_t,
+       const double* corr, void* d_rows, int32_t* ticket) {
+        return gd_kopt2d_enqueue(C(h), B, F, d_hist, neff, do_corr, fallback_t, corr, d_rows, ticket);
+    },
+    /* kopt2d_finish */
+    [](void* h, void* stage_a_h, int32_t ticket, int32_t B, void* d_rows, double* out) {
+        return gd_kopt2d_finish(C(h), C(stage_a_h), ticket, B, d_rows, out);
+    },
 };
 
 void release_state(gd_ctx* ctx, bool destroy) {

@@ -14,9 +14,12 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <functional>
 #include <future>
 #include <map>
@@ -39,6 +42,9 @@ struct Ops {
     int (*prebin8_batch)(void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
                          void* const* d_idx, int64_t* bad);
     int (*hist2d_prebinned8)(void* h, int32_t B, const void* const* ix, const void* const* iy, void* d_hist);
+    // both of the above back to back with one wait (ncols may be 0); GD_ERR_SOLVER: a sample outside the grid or a wrapped counter
+    int (*prebin8_hist2d)(void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+                          void* const* d_idx, int64_t* bad, int32_t B, const void* const* ix, const void* const* iy, void* d_hist);
     int (*prebin)(void* h, int32_t col, double binmin, double width, int32_t F, void* d_idx);
     int (*hist2d_prebinned)(void* h, int32_t B, const void* const* ix, const void* const* iy, int32_t F, void* d_hist);
     int (*minmax_affine)(void* h, int32_t B, const int32_t* ci, const int32_t* cj, const double* a, const double* b, double* out);
@@ -64,6 +70,14 @@ struct Ops {
                               int32_t nlags, double* out);
     int (*kde_lag_sums)(void* h, int32_t col, double inv4s2, const int64_t* lags, int32_t nlags, double* out);
     const char* (*last_error)(void* h);
+    // a further context on h's device over the same resident samples (its own stream and scratch) / its end
+    int (*create_aux)(void* h, void** aux);
+    int (*destroy_aux)(void* aux);
+    // gd_kopt2d in two stream-ordered stages (gdhip.h): everything up to the functionals on h's stream, returning at once;
+    // get_h for those rows on ANOTHER context's stream behind the ticket, blocking until the rows are on the host
+    int (*kopt2d_enqueue)(void* h, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
+                          const double* fallback_t, const double* corr, void* d_rows, int32_t* ticket);
+    int (*kopt2d_finish)(void* h, void* stage_a_h, int32_t ticket, int32_t B, void* d_rows, double* out);
 };
 
 // ---- numpy / CPython scalar semantics --------------------------------------------------------------------------------
@@ -306,6 +320,7 @@ struct State {
     int64_t cached_bytes = 0;
     std::map<std::tuple<int, int, int>, IdxCol> idx;     // (column, F, 1 = bytes / 2 = u16)
     Pending prev;                                        // the last lazily delivered call
+    void* aux = nullptr;                                 // third context (stream) of large calls: shear chain, get_h
     static constexpr int64_t kCacheLimit = 16LL << 30;
 };
 
@@ -397,6 +412,10 @@ static inline void release_all(State& st, const Ops& ops, void* h) {
         st.idx.clear();
     }
     pool.drop_cached();
+    if (st.aux) {  // (attached to the sample set that is going away)
+        ops.destroy_aux(st.aux);
+        st.aux = nullptr;
+    }
 }
 
 // ---- the call ----------------------------------------------------------------------------------------------------------
@@ -461,6 +480,34 @@ struct Call {
     std::vector<int> side_classes;
     std::vector<int> order;  // grid sizes, largest class (in bytes) first
 
+    // host-side timeline of the call (GDHIP_BATCH_LOG=1 prints it to stderr when the call returns)
+    std::mutex tl_mu;
+    std::vector<std::pair<double, std::string>> tl;
+    bool tl_on = getenv("GDHIP_BATCH_LOG") != nullptr;
+    static double now_ms() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    void mark(const char* what, int a = -1, int b = -1) {
+        if (!tl_on) return;
+        char buf[160];
+        if (a >= 0 && b >= 0)
+            snprintf(buf, sizeof buf, "%s (%d, %d)", what, a, b);
+        else if (a >= 0)
+            snprintf(buf, sizeof buf, "%s (%d)", what, a);
+        else
+            snprintf(buf, sizeof buf, "%s", what);
+        std::lock_guard<std::mutex> g(tl_mu);
+        tl.emplace_back(now_ms(), buf);
+    }
+    void dump_timeline() {
+        if (!tl_on || tl.empty()) return;
+        std::sort(tl.begin(), tl.end());
+        fprintf(stderr, "---- gd_density2d_batch host timeline (ms)\n");
+        for (auto& e : tl) fprintf(stderr, "%9.3f  %s\n", e.first - tl[0].first, e.second.c_str());
+    }
+
     std::mutex err_mu;
     int fail(int code, const std::string& msg) {
         std::lock_guard<std::mutex> g(err_mu);
@@ -490,6 +537,7 @@ struct Call {
         for (int j : js)
             if (isnan(par[j].neff) && (!owned_only || par[j].owned)) todo.push_back(j);
         if (todo.empty()) return 0;
+        mark("neff: start", (int)todo.size());
         if (s.uncorrelated_sampler) {
             for (int j : todo) par[j].neff = py_pow(s.norm, 2.0) / s.sum_w2;
             return 0;
@@ -548,7 +596,9 @@ struct Call {
             if (k <= N / 10) lags.push_back(k), ++ntail;
         const int L = (int)lags.size();
         std::vector<double> sums((size_t)m * L);
+        mark("neff: probe done");
         GDB_DEV(h, ops.kde_lag_sums_batch(h, todo.data(), m, inv4s2.data(), lags.data(), L, sums.data()));
+        mark("neff: lag sums done");
         const NeffInput in{N, s.norm, s.sum_w2};
         for (int row = 0; row < m; ++row) {
             const int col = todo[row];
@@ -608,7 +658,9 @@ struct Call {
                 bufs.push_back(p);
             }
             std::vector<int64_t> bad(todo.size());
+            mark("binning: prebin8 launch", (int)todo.size());
             GDB_DEV(ctx, ops.prebin8_batch(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), 256, bufs.data(), bad.data()));
+            mark("binning: prebin8 done");
             std::lock_guard<std::mutex> g(st.mu);
             for (size_t q = 0; q < todo.size(); ++q) {
                 IdxCol& c = st.idx[std::make_tuple(todo[q], 256, 1)];
@@ -661,28 +713,56 @@ struct Call {
                     if (!seen[ps.jx[k]]) seen[ps.jx[k]] = 1, cols.push_back(ps.jx[k]);
                 for (int k : members)
                     if (!seen[ps.jy[k]]) seen[ps.jy[k]] = 1, cols.push_back(ps.jy[k]);
-                bool ok = false;
-                GDB_TRY(index_columns8(ctx, cols, &ok));
-                if (ok) {
-                    std::vector<const void*> ix(B), iy(B);
-                    {
-                        std::lock_guard<std::mutex> g(st.mu);
-                        for (int q = 0; q < B; ++q) {
-                            ix[q] = st.idx[std::make_tuple((int)ps.jx[members[q]], 256, 1)].ptr;
-                            iy[q] = st.idx[std::make_tuple((int)ps.jy[members[q]], 256, 1)].ptr;
-                        }
+                // the stale byte index columns and the histograms over them go out back to back: one wait for both
+                std::vector<int32_t> todo;
+                std::vector<double> b0, w;
+                std::vector<void*> bufs;
+                {
+                    std::lock_guard<std::mutex> g(st.mu);
+                    for (int j : cols) {
+                        const double fw = (bmax[j] - bmin[j]) / 255;
+                        IdxCol& c = st.idx[std::make_tuple(j, 256, 1)];
+                        if (c.valid && c.binmin == bmin[j] && c.width == fw) continue;
+                        todo.push_back(j), b0.push_back(bmin[j]), w.push_back(fw), bufs.push_back(c.ptr);
                     }
-                    void* d = pool.take((int64_t)B * 65536 * 8, &rc);
-                    if (!d) return dev_fail(rc, h);
-                    const int e = ops.hist2d_prebinned8(ctx, B, ix.data(), iy.data(), d);
-                    if (e == 0) {
-                        std::lock_guard<std::mutex> g(enq_mu);
-                        hists[F] = d;
-                        continue;
-                    }
-                    pool.give(d);
-                    if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (a 16-bit counter wrapped: the u16 / u32 path redoes the class)
                 }
+                for (size_t q = 0; q < todo.size(); ++q)
+                    if (!bufs[q]) {
+                        bufs[q] = pool.take(N + 64, &rc);
+                        if (!bufs[q]) return dev_fail(rc, h);
+                        std::lock_guard<std::mutex> g(st.mu);
+                        IdxCol& c = st.idx[std::make_tuple((int)todo[q], 256, 1)];
+                        c.ptr = bufs[q], c.valid = false;
+                    }
+                std::vector<const void*> ix(B), iy(B);
+                {
+                    std::lock_guard<std::mutex> g(st.mu);
+                    for (int q = 0; q < B; ++q) {
+                        ix[q] = st.idx[std::make_tuple((int)ps.jx[members[q]], 256, 1)].ptr;
+                        iy[q] = st.idx[std::make_tuple((int)ps.jy[members[q]], 256, 1)].ptr;
+                    }
+                }
+                void* d = pool.take((int64_t)B * 65536 * 8, &rc);
+                if (!d) return dev_fail(rc, h);
+                std::vector<int64_t> bad(todo.size() + 1, 0);
+                mark("binning: prebin8 + hist2d launch", (int)todo.size(), B);
+                const int e = ops.prebin8_hist2d(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), bufs.data(), bad.data(), B,
+                                                 ix.data(), iy.data(), d);
+                mark("binning: prebin8 + hist2d done");
+                if (e == 0 || e == GD_ERR_SOLVER) {
+                    std::lock_guard<std::mutex> g(st.mu);
+                    for (size_t q = 0; q < todo.size(); ++q) {
+                        IdxCol& c = st.idx[std::make_tuple((int)todo[q], 256, 1)];
+                        c.binmin = b0[q], c.width = w[q], c.valid = bad[q] == 0;
+                    }
+                }
+                if (e == 0) {
+                    std::lock_guard<std::mutex> g(enq_mu);
+                    hists[F] = d;
+                    continue;
+                }
+                pool.give(d);
+                if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (else: the u16 / u32 path below redoes the class)
             }
             std::vector<const void*> ix(B), iy(B);
             for (int q = 0; q < B; ++q) {
@@ -698,6 +778,7 @@ struct Call {
             void* d = pool.take((int64_t)B * F * F * 8, &rc);
             if (!d) return dev_fail(rc, h);
             const int e = ops.hist2d_prebinned(ctx, B, ix.data(), iy.data(), F, d);
+            mark("binning: hist2d_prebinned done", B, F);
             if (e) {
                 pool.give(d);
                 return dev_fail(e, ctx);
@@ -724,7 +805,9 @@ struct Call {
             const int k = shear.A[row];
             ci[row] = plan.si[k], cj[row] = plan.sj[k], r0[row] = plan.r[(size_t)2 * k], r1[row] = plan.r[(size_t)2 * k + 1];
         }
+        mark("shear: start", nA);
         GDB_DEV(ctx, ops.minmax_affine(ctx, nA, ci.data(), cj.data(), r0.data(), r1.data(), mm.data()));
+        mark("shear: minmax done");
         std::vector<double> xmin(nA), dx(nA), ymin(nA), dy(nA);
         shear.r1s.resize(nA), shear.r2s.resize(nA);
         for (int row = 0; row < nA; ++row) {
@@ -747,6 +830,7 @@ struct Call {
         if (!shear.d_rot) return dev_fail(rc, h);
         GDB_DEV(ctx, ops.hist2d_sheared(ctx, nA, ci.data(), cj.data(), r0.data(), r1.data(), xmin.data(), dx.data(), ymin.data(),
                                         dy.data(), base_F, shear.d_rot));
+        mark("shear: histograms done");
         return 0;
     }
 
@@ -862,8 +946,10 @@ struct Call {
         call_blocks.push_back(d_P);
         int32_t* status = status_pinned + status_at;
         if (grid_off + (int64_t)B * F * F > grids_doubles) return fail(GD_ERR_BADARG, "grids_pinned is too small");
+        mark(bctx == h ? "conv: enqueue on main" : "conv: enqueue on twin", B, F);
         GDB_DEV(bctx, ops.density2d_enqueue(bctx, B, F, d_sub, rxb.data(), ryb.data(), ccb.data(), wb.data(), fb.data(),
                                             s.boundary_correction_order, s.mult_bias_correction_order, d_P, status));
+        mark("conv: enqueued");
         if (s.want_levels && levels) {
             std::vector<double> lv((size_t)B * s.ncontours);
             std::vector<int32_t> ls(B);
@@ -926,8 +1012,103 @@ struct Call {
     }
 
     // -- getAutoBandwidth2D for the batch (mcsamples.py:1325-1419): the optimiser's launches, unit conversions,
-    //    de-rotation of the sheared kernels, fallbacks, widening; on_chunk(ks, last) after every launch
-    int bandwidth_2d(bool pipelined, const std::function<int(const std::vector<int>&, bool)>& on_chunk) {
+    //    de-rotation of the sheared kernels, fallbacks, widening; on_chunk(ks, index of the launch, number of launches)
+    //    after every launch.
+    //    Sequential mode (`staged` false): every launch is one blocking gd_kopt2d call on the main context.
+    //    Staged mode (large calls with a second and a third stream): the base grid's pairs are cut into parts of about one
+    //    block per CU; the calling thread enqueues stage A of every part (DCT, fixed point, functionals) back to back on the
+    //    main stream, a second thread runs stage B (get_h: the serial TNC minimisations) of part k on the third stream --
+    //    beside stage A of part k + 1 -- and hands the part's final bandwidths to on_chunk, which enqueues its convolution.
+    struct Launch {
+        int F = 0;
+        std::vector<int> ks;   // plan indices in batch order
+        int na = 0;            // leading sheared rows
+        void* d_hist = nullptr;  // class buffer
+        std::vector<int> pos;  // positions within the class buffer of the non-sheared rows
+        bool whole = false;    // the class's buffer as it is
+        // staged mode
+        void* d_batch = nullptr;
+        bool own = false;
+        void* d_rows = nullptr;
+        int32_t ticket = -1;
+        std::vector<double> ne, fb, ci;
+        std::vector<int32_t> dc;
+    };
+    typedef std::function<int(const std::vector<int>&, int, int)> ChunkFn;
+
+    int build_batch(Launch& L) {  // the launch's histograms as one device block (a gather unless the class buffer serves)
+        const int B = (int)L.ks.size(), F = L.F;
+        const int64_t item = (int64_t)F * F * 8;
+        L.d_batch = L.d_hist, L.own = false;
+        if (!L.whole) {
+            int rc = 0;
+            L.d_batch = pool.take((int64_t)B * item, &rc);
+            if (!L.d_batch) return dev_fail(rc, h);
+            L.own = true;
+            if (L.na) {
+                std::vector<int32_t> idx(L.na);
+                for (int a = 0; a < L.na; ++a) idx[a] = a;
+                GDB_DEV(h, ops.gather_items(h, L.d_batch, 0, shear.d_rot, idx.data(), L.na, item));
+            }
+            if (!L.pos.empty()) {
+                std::vector<int32_t> idx(L.pos.begin(), L.pos.end());
+                GDB_DEV(h, ops.gather_items(h, L.d_batch, L.na, L.d_hist, idx.data(), (int)idx.size(), item));
+            }
+        }
+        L.ne.resize(B), L.fb.resize(B), L.ci.resize(B), L.dc.resize(B);
+        for (int row = 0; row < B; ++row) {
+            const int k = L.ks[row];
+            const bool rowA = row < L.na;
+            L.ne[row] = plan.neff[k], L.dc[row] = plan.has_limits[k] ? 0 : 1;
+            L.fb[row] = rowA ? -1.0 : plan.fallback_t[k];
+            L.ci[row] = rowA ? 0.0 : ps.actual[k];
+        }
+        return 0;
+    }
+
+    // the optimiser's rows of one launch -> bandwidths in parameter units (W), records, fallbacks
+    int absorb_rows(const Launch& L, const std::vector<double>& out) {
+        const int B = (int)L.ks.size();
+        for (int row = 0; row < B; ++row) {
+            const double* o = &out[(size_t)row * 12];
+            if (o[7] == 0 && o[11] != 0) return fail(GD_ERR_BADARG, "bias not positive definite");  // kde_bandwidth.py:229-230, out of get_h
+        }
+        for (int row = 0; row < B; ++row) {
+            const int k = L.ks[row];
+            const double* o = &out[(size_t)row * 12];
+            memcpy(M(k) + 6, o, 12 * sizeof(double));
+            double hx, hy, c;
+            if (row < L.na) {
+                // de-rotate the sheared kernel (mcsamples.py:1379-1390): kernelC = S K S^T for the 2 x 2 case
+                const double hxa = o[8] * shear.r1s[row], hya = o[9] * shear.r2s[row], ca = o[10];
+                const double* S = &plan.S[(size_t)4 * k];
+                const double k00 = hxa * hxa, k01 = hxa * hya * ca, k11 = hya * hya;
+                const double t00 = S[0] * k00 + S[1] * k01, t01 = S[0] * k01 + S[1] * k11;
+                const double t10 = S[2] * k00 + S[3] * k01, t11 = S[2] * k01 + S[3] * k11;
+                const double c00 = t00 * S[0] + t01 * S[1], c01 = t00 * S[2] + t01 * S[3], c11 = t10 * S[2] + t11 * S[3];
+                const double sx = sqrt(c00), sy = sqrt(c11);
+                hx = plan.swap[k] ? sy : sx, hy = plan.swap[k] ? sx : sy, c = c01 / sqrt(c00 * c11);
+            } else {
+                hx = o[8] * plan.rangex[k], hy = o[9] * plan.rangey[k], c = o[10];
+            }
+            if (o[7] != 0) {  // "2D fixed point: no root in [0, 0.1]": the fallback widths (mcsamples.py:1402-1409)
+                if (s.raise_on_bandwidth_errors) {
+                    char buf[200];
+                    snprintf(buf, sizeof buf, "2D kernel density bandwidth optimizer failed for pair %d (columns %d, %d). "
+                             "Using fallback width: 2D fixed point: no root in [0, 0.1]", k, (int)ps.jx[k], (int)ps.jy[k]);
+                    return fail(GD_ERR_SOLVER, buf);
+                }
+                ps.warn[k] |= 4;
+                const double d = py_pow(plan.neff[k], 1.0 / 6);
+                hx = par[ps.jx[k]].sigma_range / d, hy = par[ps.jy[k]].sigma_range / d;
+                c = std::max(std::min(ps.actual[k], s.max_corr_2D), -s.max_corr_2D);
+            }
+            W[(size_t)3 * k] = hx, W[(size_t)3 * k + 1] = hy, W[(size_t)3 * k + 2] = c;
+        }
+        return 0;
+    }
+
+    int bandwidth_2d(bool staged, void* aux, const ChunkFn& on_chunk) {
         const int base_F = s.fine_bins_2D;
         const int m = s.mult_bias_correction_order;
         std::vector<double> widen;
@@ -947,7 +1128,53 @@ struct Call {
                 W[(size_t)3 * k] = par[ps.jx[k]].sigma_range / d, W[(size_t)3 * k + 1] = par[ps.jy[k]].sigma_range / d, W[(size_t)3 * k + 2] = c;
                 waiting.push_back(k);
             }
-        auto report = [&](std::vector<int> ks, bool last) -> int {
+        std::vector<Launch> launches;
+        bool merged = false;
+        for (int F : F_list) {
+            const std::vector<int>& mem = classes.at(F);
+            std::vector<int> pos_C;
+            for (int q = 0; q < (int)mem.size(); ++q)
+                if (plan.branch[mem[q]] == 2) pos_C.push_back(q);
+            if (F == base_F && !pos_C.empty()) {
+                // the sheared pairs ride with the first part of the base grid's own pairs
+                const size_t total = pos_C.size() + (size_t)nA;
+                size_t part = total;
+                if (staged && (int)pos_C.size() >= s_kopt_split_min()) {
+                    // Two parts: the second's DCT / fixed point beside the first's get_h and convolution.  More, smaller
+                    // parts were measured (3 / 4 / 12: 31.2 / 32.1 / 31.4 ms per C3 step against 30.5 with two): the chip is
+                    // busy either way, and a part below two blocks per CU leaves the fixed-point kernel's tail exposed.
+                    size_t want = 2;  // GDHIP_KOPT_PARTS: tuning knob
+                    if (const char* e = getenv("GDHIP_KOPT_PARTS")) want = (size_t)std::max(1, atoi(e));
+                    part = std::max<size_t>((size_t)s_kopt_split_min(), (total + want - 1) / want);
+                }
+                for (size_t c0 = 0, first = 1; c0 < pos_C.size(); first = 0) {
+                    Launch L;
+                    L.F = F, L.na = first ? nA : 0, L.d_hist = hists.at(F);
+                    const size_t take_ = std::min(pos_C.size() - c0, part > (size_t)L.na ? part - (size_t)L.na : (size_t)1);
+                    L.pos.assign(pos_C.begin() + c0, pos_C.begin() + c0 + take_);
+                    c0 += take_;
+                    L.whole = L.na == 0 && L.pos.size() == mem.size();
+                    for (int q = 0; q < L.na; ++q) L.ks.push_back(A[q]);
+                    for (int q : L.pos) L.ks.push_back(mem[q]);
+                    launches.push_back(std::move(L));
+                }
+                merged = true;
+                continue;
+            }
+            if (pos_C.empty()) continue;
+            Launch L;
+            L.F = F, L.na = 0, L.d_hist = hists.at(F), L.pos = pos_C, L.whole = pos_C.size() == mem.size();
+            for (int q : pos_C) L.ks.push_back(mem[q]);
+            launches.push_back(std::move(L));
+        }
+        if (nA && !merged) {
+            Launch L;
+            L.F = base_F, L.na = nA, L.d_hist = shear.d_rot, L.whole = true;
+            L.ks = A;
+            launches.push_back(std::move(L));
+        }
+        const int nl = (int)launches.size();
+        auto report = [&](std::vector<int> ks, int index) -> int {
             if (!waiting.empty()) {
                 std::vector<int> all = waiting;
                 all.insert(all.end(), ks.begin(), ks.end());
@@ -956,140 +1183,98 @@ struct Call {
             }
             if (m)
                 for (int k : ks) W[(size_t)3 * k] *= widen[k], W[(size_t)3 * k + 1] *= widen[k];
-            if (!ks.empty() || last) return on_chunk(ks, last);
+            if (!ks.empty() || index + 1 >= nl) return on_chunk(ks, index, nl);
             return 0;
         };
-        struct Launch {
-            int F;
-            std::vector<int> ks;   // plan indices in batch order
-            int na;                // leading sheared rows
-            void* d_hist;          // class buffer
-            std::vector<int> pos;  // positions within the class buffer of the non-sheared rows
-            bool whole;            // the class's buffer as it is
-            bool shear_only;
-        };
-        std::vector<Launch> launches;
-        bool merged = false;
-        const int64_t item = (int64_t)base_F * base_F * 8;
-        for (int F : F_list) {
-            const std::vector<int>& mem = classes.at(F);
-            std::vector<int> pos_C;
-            for (int q = 0; q < (int)mem.size(); ++q)
-                if (plan.branch[mem[q]] == 2) pos_C.push_back(q);
-            if (F == base_F && !pos_C.empty()) {
-                std::vector<size_t> cuts{0, pos_C.size()};
-                if (pipelined && (int)pos_C.size() >= s_kopt_split_min())
-                    cuts = {0, (size_t)((double)pos_C.size() * s_kopt_first()), pos_C.size()};
-                for (size_t part = 0; part + 1 < cuts.size(); ++part) {
-                    Launch L;
-                    L.F = F, L.na = part == 0 ? nA : 0, L.d_hist = hists.at(F), L.shear_only = false;
-                    L.pos.assign(pos_C.begin() + cuts[part], pos_C.begin() + cuts[part + 1]);
-                    L.whole = L.na == 0 && L.pos.size() == mem.size();
-                    for (int q = 0; q < L.na; ++q) L.ks.push_back(A[q]);
-                    for (int q : L.pos) L.ks.push_back(mem[q]);
-                    launches.push_back(L);
-                }
-                merged = true;
-                continue;
-            }
-            if (pos_C.empty()) continue;
-            Launch L;
-            L.F = F, L.na = 0, L.d_hist = hists.at(F), L.pos = pos_C, L.whole = pos_C.size() == mem.size(), L.shear_only = false;
-            for (int q : pos_C) L.ks.push_back(mem[q]);
-            launches.push_back(L);
-        }
-        if (nA && !merged) {
-            Launch L;
-            L.F = base_F, L.na = nA, L.d_hist = shear.d_rot, L.whole = true, L.shear_only = true;
-            L.ks = A;
-            launches.push_back(L);
-        }
         int rc = 0;
-        for (size_t q = 0; q < launches.size() && !rc; ++q) {
-            Launch& L = launches[q];
-            const int B = (int)L.ks.size();
-            const int F = L.F;
-            void* d_batch = L.d_hist;
-            bool own = false;
-            if (!L.whole) {
-                d_batch = pool.take((int64_t)B * F * F * 8, &rc);
-                if (!d_batch) {
-                    dev_fail(rc, h);
-                    break;
+        if (!staged || nl == 0) {
+            for (int q = 0; q < nl && !rc; ++q) {
+                Launch& L = launches[q];
+                const int B = (int)L.ks.size();
+                rc = build_batch(L);
+                std::vector<double> out((size_t)B * 12);
+                if (!rc) {
+                    mark("kopt: launch", B, L.F);
+                    rc = ops.kopt2d(h, B, L.F, L.d_batch, L.ne.data(), L.dc.data(), L.fb.data(), L.ci.data(), out.data());
+                    mark("kopt: done");
+                    if (rc) dev_fail(rc, h);
                 }
-                own = true;
-                if (L.na) {
-                    std::vector<int32_t> idx(L.na);
-                    for (int a = 0; a < L.na; ++a) idx[a] = a;
-                    rc = ops.gather_items(h, d_batch, 0, shear.d_rot, idx.data(), L.na, item);
-                }
-                if (!rc && !L.pos.empty()) {
-                    std::vector<int32_t> idx(L.pos.begin(), L.pos.end());
-                    rc = ops.gather_items(h, d_batch, L.na, L.d_hist, idx.data(), (int)idx.size(), (int64_t)F * F * 8);
-                }
-                if (rc) dev_fail(rc, h);
+                if (L.own) pool.give(L.d_batch);  // (the entry point has waited for its kernels)
+                if (!rc) rc = absorb_rows(L, out);
+                if (!rc) rc = report(L.ks, q);
             }
-            std::vector<double> out((size_t)B * 12);
-            if (!rc) {
-                std::vector<double> ne(B), fb(B), ci(B);
-                std::vector<int32_t> dc(B);
-                for (int row = 0; row < B; ++row) {
-                    const int k = L.ks[row];
-                    const bool rowA = row < L.na;
-                    ne[row] = plan.neff[k], dc[row] = plan.has_limits[k] ? 0 : 1;
-                    fb[row] = rowA ? -1.0 : plan.fallback_t[k];
-                    ci[row] = rowA ? 0.0 : ps.actual[k];
-                }
-                rc = ops.kopt2d(h, B, F, d_batch, ne.data(), dc.data(), fb.data(), ci.data(), out.data());
-                if (rc) dev_fail(rc, h);
-            }
-            if (own) pool.give(d_batch);  // (the entry point has waited for its kernels)
-            if (rc) break;
-            for (int row = 0; row < B; ++row) {
-                const double* o = &out[(size_t)row * 12];
-                if (o[7] == 0 && o[11] != 0) {
-                    rc = fail(GD_ERR_BADARG, "bias not positive definite");  // kde_bandwidth.py:229-230, raised out of get_h
-                    break;
-                }
-            }
-            if (rc) break;
-            for (int row = 0; row < B; ++row) {
-                const int k = L.ks[row];
-                const double* o = &out[(size_t)row * 12];
-                memcpy(M(k) + 6, o, 12 * sizeof(double));
-                double hx, hy, c;
-                if (row < L.na) {
-                    // de-rotate the sheared kernel (mcsamples.py:1379-1390): kernelC = S K S^T for the 2 x 2 case
-                    const double hxa = o[8] * shear.r1s[row], hya = o[9] * shear.r2s[row], ca = o[10];
-                    const double* S = &plan.S[(size_t)4 * k];
-                    const double k00 = hxa * hxa, k01 = hxa * hya * ca, k11 = hya * hya;
-                    const double t00 = S[0] * k00 + S[1] * k01, t01 = S[0] * k01 + S[1] * k11;
-                    const double t10 = S[2] * k00 + S[3] * k01, t11 = S[2] * k01 + S[3] * k11;
-                    const double c00 = t00 * S[0] + t01 * S[1], c01 = t00 * S[2] + t01 * S[3], c11 = t10 * S[2] + t11 * S[3];
-                    const double sx = sqrt(c00), sy = sqrt(c11);
-                    hx = plan.swap[k] ? sy : sx, hy = plan.swap[k] ? sx : sy, c = c01 / sqrt(c00 * c11);
-                } else {
-                    hx = o[8] * plan.rangex[k], hy = o[9] * plan.rangey[k], c = o[10];
-                }
-                if (o[7] != 0) {  // "2D fixed point: no root in [0, 0.1]": the fallback widths (mcsamples.py:1402-1409)
-                    if (s.raise_on_bandwidth_errors) {
-                        char buf[200];
-                        snprintf(buf, sizeof buf, "2D kernel density bandwidth optimizer failed for pair %d (columns %d, %d). "
-                                 "Using fallback width: 2D fixed point: no root in [0, 0.1]", k, (int)ps.jx[k], (int)ps.jy[k]);
-                        rc = fail(GD_ERR_SOLVER, buf);
-                        break;
+            if (!rc && nl == 0) rc = report({}, 0);
+        } else {
+            // ---- staged: stage A of every launch from this thread, stage B + the hand-over from a second one
+            std::mutex mu;
+            std::condition_variable cv;
+            int n_staged = 0;
+            bool abort_ = false;
+            std::future<int> finisher = std::async(std::launch::async, [&]() -> int {
+                ops.bind_thread(aux);
+                int e = 0;
+                for (int q = 0; q < nl; ++q) {
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return n_staged > q || abort_; });
+                        if (n_staged <= q) return e;  // (the staging thread gave up)
                     }
-                    ps.warn[k] |= 4;
-                    const double d = py_pow(plan.neff[k], 1.0 / 6);
-                    hx = par[ps.jx[k]].sigma_range / d, hy = par[ps.jy[k]].sigma_range / d;
-                    c = std::max(std::min(ps.actual[k], s.max_corr_2D), -s.max_corr_2D);
+                    Launch& L = launches[q];
+                    const int B = (int)L.ks.size();
+                    std::vector<double> out((size_t)B * 12);
+                    if (!e) {
+                        e = ops.kopt2d_finish(aux, h, L.ticket, B, L.d_rows, out.data());
+                        mark("kopt: part finished", q, B);
+                        if (e) dev_fail(e, aux);
+                    } else {
+                        ops.copy_sync(h);  // (never reached in a healthy run: blocks are not freed under running kernels)
+                    }
+                    // stage B has waited for stage A: the part's input blocks are free
+                    if (L.own) pool.give(L.d_batch);
+                    pool.give(L.d_rows);
+                    if (!e) e = absorb_rows(L, out);
+                    if (!e) {
+                        {  // a part's convolution may use the main context: the staging thread must be done with it
+                            std::unique_lock<std::mutex> g(mu);
+                            cv.wait(g, [&] { return n_staged >= nl || abort_; });
+                        }
+                        e = report(L.ks, q);
+                    }
                 }
-                W[(size_t)3 * k] = hx, W[(size_t)3 * k + 1] = hy, W[(size_t)3 * k + 2] = c;
+                return e;
+            });
+            for (int q = 0; q < nl && !rc; ++q) {
+                Launch& L = launches[q];
+                const int B = (int)L.ks.size();
+                rc = build_batch(L);
+                if (!rc) {
+                    L.d_rows = pool.take((int64_t)B * GD_KOPT_BLOCK_DOUBLES * 8, &rc);
+                    if (!L.d_rows) dev_fail(rc, h);
+                }
+                if (!rc) {
+                    mark("kopt: stage A enqueue", q, B);
+                    rc = ops.kopt2d_enqueue(h, B, L.F, L.d_batch, L.ne.data(), L.dc.data(), L.fb.data(), L.ci.data(), L.d_rows, &L.ticket);
+                    if (rc) dev_fail(rc, h);
+                }
+                std::lock_guard<std::mutex> g(mu);
+                if (rc) {
+                    abort_ = true;
+                    if (L.own && L.d_batch) ops.copy_sync(h), pool.give(L.d_batch);
+                    if (L.d_rows) pool.give(L.d_rows);
+                } else {
+                    ++n_staged;
+                }
+                cv.notify_all();
             }
-            if (rc) break;
-            rc = report(L.ks, q + 1 == launches.size());
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (n_staged < nl) abort_ = true;
+                cv.notify_all();
+            }
+            mark("kopt: every stage A enqueued");
+            const int e = finisher.get();
+            if (!rc) rc = e;
         }
-        if (!rc && launches.empty()) rc = report({}, true);
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
         return rc;
     }
@@ -1106,6 +1291,7 @@ struct Call {
             GDB_TRY(neff_exchange(&exchanged));
             return 0;
         }
+        mark("call: start", P);
         int64_t ncols = 0;
         GDB_DEV(h, ops.num_rows(h, &N, &ncols));
         if (ncols < n) return fail(GD_ERR_BADARG, "more parameters than resident columns");
@@ -1124,11 +1310,17 @@ struct Call {
         bool need_neff = false;
         if (auto_bw)
             for (int j : used) need_neff = need_neff || isnan(par[j].neff);
-        const bool overlap = auto_bw && need_neff && P >= 64 && twin != nullptr;
+        // Large calls keep three streams busy from the start: the N_eff kernels (fp64 exp-bound) on the main context, the
+        // byte-index binning (LDS atomics) on the second, the sheared min/max + re-binning (HBM-bound) on a third the
+        // library creates for itself; the per-pair scalars and the branch plan are worked out here meanwhile.
+        void* aux = nullptr;
+        const bool overlap = auto_bw && P >= 64 && twin != nullptr;
+        if (overlap) {
+            if (!st.aux) GDB_DEV(h, ops.create_aux(h, &st.aux));
+            aux = st.aux;
+        }
         std::future<int> neff_f, bin_f, shear_f;
-        // the N_eff kernels need nothing but the parameter ranges: they start first, on their own thread, and run beside
-        // the binning on the second stream while the per-pair scalars are worked out here
-        if (overlap)
+        if (overlap && need_neff)
             neff_f = std::async(std::launch::async, [this] {
                 ops.bind_thread(h);
                 return neff_batch(used, true);
@@ -1164,16 +1356,16 @@ struct Call {
                     return binning(twin);
                 });
                 rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
-                int e = neff_f.get();
+                if (!rc)  // the branch plan needs the limits and the covariance only: the shear chain starts at once
+                    shear_f = std::async(std::launch::async, [this, aux] {
+                        ops.bind_thread(aux);
+                        return shear_histograms(aux);
+                    });
+                int e = neff_f.valid() ? neff_f.get() : 0;
                 if (!rc) rc = e;
                 if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)
-                if (!rc) {
-                    // a context is not re-entrant: the shear launches start once the N_eff call has returned
-                    shear_f = std::async(std::launch::async, [this] {
-                        ops.bind_thread(h);
-                        return shear_histograms(h);
-                    });
-                    fill_plan(par, ps, plan);
+                if (!rc) fill_plan(par, ps, plan);
+                if (shear_f.valid()) {
                     e = shear_f.get();
                     if (!rc) rc = e;
                 }
@@ -1190,6 +1382,7 @@ struct Call {
             rc = neff_exchange(&exchanged);  // the collective is unconditional: once per call on every rank
             if (!rc) rc = binning(h);
         }
+        mark("binning / N_eff / plan joined");
         if (rc) return cleanup(rc);
         // ---- convolution set-up: flag bits (mcsamples.py:1688-1703, 1794): bits 0/1 = x bot/top, 2/3 = y bot/top,
         //      4/5 = x/y periodic, 6 = has_prior
@@ -1221,47 +1414,26 @@ struct Call {
         std::vector<int> all_k(P);
         for (int k = 0; k < P; ++k) all_k[k] = k;
         if (auto_bw) {
-            const bool pipelined = conv_ctxs.size() > 1 && P > s_two_split();
-            std::vector<std::future<int>> enqueueing;
-            std::function<int(const std::vector<int>&, bool)> on_chunk;
-            if (pipelined) {
-                on_chunk = [&](const std::vector<int>& ks, bool last) -> int {
+            const bool staged = aux != nullptr && conv_ctxs.size() > 1 && P > s_two_split();
+            if (staged) {
+                // every part's convolution is enqueued (by the thread that finishes the parts) as soon as its bandwidths are
+                // final: the first parts on the second stream, beside the optimiser's stage A of the later parts on the
+                // main stream; the last parts behind stage A on the main stream, so that both streams end together
+                ChunkFn on_chunk = [&](const std::vector<int>& ks, int index, int nparts) -> int {
                     set_scales(ks);
-                    auto only = std::make_shared<std::vector<char>>(P, 0);
-                    for (int k : ks) (*only)[k] = 1;
-                    if (!last) {
-                        // the second stream's own thread enqueues this part's convolution while this thread goes straight
-                        // on to the next optimiser launch; parts follow one another (one thread's worth of order)
-                        std::shared_future<int> prev;
-                        if (!enqueueing.empty()) prev = enqueueing.back().share(), enqueueing.pop_back();
-                        enqueueing.push_back(std::async(std::launch::async, [this, only, prev] {
-                            if (prev.valid()) {
-                                const int e = prev.get();
-                                if (e) return e;
-                            }
-                            ops.bind_thread(conv_ctxs[1]);
-                            return enqueue_part(*only, false);
-                        }));
-                        return 0;
+                    std::vector<char> only(P, 0);
+                    for (int k : ks) only[k] = 1;
+                    const bool to_main = nparts > 1 && index >= nparts - std::max(1, 2 * nparts / 5);
+                    for (int F : order) {
+                        void* target = (is_side(F) || !to_main) ? conv_ctxs[1] : conv_ctxs[0];
+                        GDB_TRY(run_class(F, only, target));
                     }
-                    int e = 0;
-                    for (auto& f : enqueueing) {
-                        const int e1 = f.get();
-                        if (e1 && !e) e = e1;
-                    }
-                    enqueueing.clear();
-                    if (e) return e;
-                    return enqueue_part(*only, true);
+                    return 0;
                 };
-                rc = bandwidth_2d(true, on_chunk);
-                for (auto& f : enqueueing)
-                    if (f.valid()) {
-                        const int e1 = f.get();
-                        if (e1 && !rc) rc = e1;
-                    }
+                rc = bandwidth_2d(true, aux, on_chunk);
             } else {
-                on_chunk = [&](const std::vector<int>&, bool) -> int { return 0; };
-                rc = bandwidth_2d(false, on_chunk);
+                ChunkFn on_chunk = [&](const std::vector<int>&, int, int) -> int { return 0; };
+                rc = bandwidth_2d(false, nullptr, on_chunk);
                 if (!rc) {
                     set_scales(all_k);
                     rc = enqueue_all();
@@ -1290,6 +1462,7 @@ struct Call {
             double* m = M(k);
             m[18] = rx[k], m[19] = ry[k], m[20] = cc[k], m[21] = (double)winw[k], m[22] = ps.warn[k];
         }
+        mark("all batches enqueued");
         for (auto& kv : hists) call_blocks.push_back(kv.second);
         hists.clear();
         GDB_DEV(h, ops.copy_mark(h, &tokens_out2[0]));
@@ -1309,6 +1482,8 @@ struct Call {
         cur.live = true;
         const int e_prev = complete_pending(st, ops, h, st.prev);
         st.prev = std::move(cur);
+        mark("previous call completed; return");
+        dump_timeline();
         if (e_prev) return dev_fail(e_prev, h);
         return 0;
     }

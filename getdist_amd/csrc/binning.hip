@@ -778,7 +778,7 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     Hist2DPair* d_pairs = (Hist2DPair*)(base + o_pairs);
     int* d_flags = (int*)(base + o_flags);
     unsigned int* d_part = (unsigned int*)(base + o_part);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair)));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_f64_p16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
     k_hist2d_f64_p16<MODE><<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes,
@@ -826,7 +826,7 @@ static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, 
     const int64_t nblocks = (int64_t)units * nstripes;
     Hist2DPair* d_pairs = (Hist2DPair*)gd_scratch2(ctx, (int64_t)B * sizeof(Hist2DPair));
     if (!d_pairs) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair)));
     if (nchunks > 1) GD_HIP(hipMemsetAsync(d_hist, 0, (size_t)B * F * F * 8, ctx->stream));
     const size_t lds = (size_t)R * F * binbytes;
     if (has_w && !u32bins) {
@@ -872,9 +872,9 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_b = (double*)(base + o_b);
     double* d_w = (double*)(base + o_w);
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_b, binmin, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_w, width, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
+    GD_TRY(gd_h2d(ctx, d_b, binmin, (size_t)ncols * 8));
+    GD_TRY(gd_h2d(ctx, d_w, width, (size_t)ncols * 8));
     dim3 grid(nblk, ncols);
     const size_t lds = (size_t)4 * F * 8;
     if (ctx->w) {
@@ -940,7 +940,7 @@ int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doubl
     }
     PrebinCol* d_c = (PrebinCol*)gd_scratch2(ctx, (int64_t)ncols * sizeof(PrebinCol));
     if (!d_c) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol)));
     int nblk = (int)((ctx->N / 8 + 255) / 256);  // one 8-sample iteration per thread at most, like the single-column kernel
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
     if (nblk < 1) nblk = 1;
@@ -978,7 +978,7 @@ static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     if (!base) return GD_ERR_NOMEM;
     Hist2DPair* d_pairs = (Hist2DPair*)base;
     int* d_flags = (int*)(base + o_flags);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair)));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
     const size_t lds = ((size_t)R * F + 1) / 2 * 4;
     if (ctx->w8) {
@@ -1031,7 +1031,7 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             Hist2DPair* d_pairs = (Hist2DPair*)base;
             int* d_flags = (int*)(base + o_flags);
             unsigned int* d_part = (unsigned int*)(base + o_part);
-            GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+            GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair)));
             GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
             GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u16_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
             k_hist2d_u16_chunks<<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes, nchunks,
@@ -1107,7 +1107,7 @@ int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doub
     if (!base) return GD_ERR_NOMEM;
     PrebinCol8* d_c = (PrebinCol8*)base;
     unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
-    GD_HIP(hipMemcpyAsync(d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol8), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol8)));
     GD_HIP(hipMemsetAsync(d_bad, 0, (size_t)ncols * 8, ctx->stream));
     int nblk = (int)((ctx->N / 8 + 255) / 256);
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
@@ -1137,7 +1137,7 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
     if (!base) return GD_ERR_NOMEM;
     Hist2DPair8* d_pairs = (Hist2DPair8*)base;
     int* d_flags = (int*)(base + o_flags);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8)));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
     const int nblocks = (B + 7) / 8 * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
@@ -1150,6 +1150,75 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
     for (int b = 0; b < B && rc == GD_OK; ++b)
         if (hf[b]) rc = gd_fail(ctx, GD_ERR_SOLVER, "16-bit bin counter wrapped in pair %d: redo with gd_hist2d_prebinned", b);
     return rc;
+}
+
+// gd_prebin8_hist2d: gd_prebin8_batch (for the `ncols` stale columns) and gd_hist2d_prebinned8 in ONE stream-ordered
+// sequence with ONE wait at the end: the out-of-range counts and the wrap flags come back together.  Between the two
+// kernels the host would otherwise wait for a 400-byte fetch that queues behind the previous call's result copies on PCIe.
+int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+                      void* const* d_idx_out, int64_t* bad_out, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y,
+                      void* d_hist) {
+    GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0 && ncols >= 0, "bad argument");
+    GD_REQUIRE(ncols == 0 || (cols && binmin && width && d_idx_out && bad_out), "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(!ctx->w, "byte-index binning is for unit weights");
+    const int F = 256;
+    std::vector<PrebinCol8> hc((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) {
+        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
+        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        hc[c].idx = (unsigned char*)d_idx_out[c];
+        hc[c].binmin = binmin[c];
+        hc[c].width = width[c];
+    }
+    std::vector<Hist2DPair8> hp((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        hp[b].ix = (const unsigned char*)d_idx_x[b];
+        hp[b].iy = (const unsigned char*)d_idx_y[b];
+        GD_REQUIRE(hp[b].ix && hp[b].iy, "null index column");
+    }
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_cols = take((int64_t)ncols * sizeof(PrebinCol8)), o_pairs = take((int64_t)B * sizeof(Hist2DPair8));
+    const int64_t table_bytes = off;
+    const int64_t o_bad = take((int64_t)ncols * 8), o_flags = take((int64_t)B * 4);
+    char* base = (char*)gd_scratch2(ctx, off);
+    if (!base) return GD_ERR_NOMEM;
+    {
+        std::vector<char> tab((size_t)table_bytes, 0);
+        if (ncols) memcpy(tab.data() + o_cols, hc.data(), (size_t)ncols * sizeof(PrebinCol8));
+        memcpy(tab.data() + o_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8));
+        GD_TRY(gd_stage_h2d(ctx, base, tab.data(), (size_t)table_bytes));
+    }
+    GD_HIP(hipMemsetAsync(base + o_bad, 0, (size_t)(off - o_bad), ctx->stream));
+    if (ncols) {
+        int nblk = (int)((ctx->N / 8 + 255) / 256);
+        if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+        if (nblk < 1) nblk = 1;
+        k_prebin8_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>((const PrebinCol8*)(base + o_cols), ctx->N, F,
+                                                                   (unsigned long long*)(base + o_bad));
+        GD_KERNEL_CHECK();
+    }
+    const int nblocks = (B + 7) / 8 * 8;
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
+    k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>((const Hist2DPair8*)(base + o_pairs), B, ctx->N,
+                                                                            (double*)d_hist, (int*)(base + o_flags));
+    GD_KERNEL_CHECK();
+    std::vector<unsigned long long> hb((size_t)ncols);
+    std::vector<int> hf((size_t)B);
+    if (ncols) GD_TRY(gd_fetch(ctx, hb.data(), base + o_bad, (size_t)ncols * 8));
+    GD_TRY(gd_fetch(ctx, hf.data(), base + o_flags, (size_t)B * 4));
+    GD_TRY(gd_stream_sync(ctx));
+    int64_t nbad = 0;
+    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)hb[c], nbad += bad_out[c];
+    if (nbad) return gd_fail(ctx, GD_ERR_SOLVER, "%lld samples outside the byte-index grid: use the u16 path", (long long)nbad);
+    for (int b = 0; b < B; ++b)
+        if (hf[b]) return gd_fail(ctx, GD_ERR_SOLVER, "16-bit bin counter wrapped in pair %d: redo with gd_hist2d_prebinned", b);
+    return GD_OK;
 }
 
 int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t* colj, const double* r0,
@@ -1233,7 +1302,7 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
         const int64_t part_doubles = (int64_t)ng * nblk * MMG_PAIRS * 2;
         char* base = (char*)gd_scratch(ctx, o_part + part_doubles * 8);
         if (!base) return GD_ERR_NOMEM;
-        GD_HIP(hipMemcpyAsync(base, groups.data(), (size_t)ng * sizeof(MinmaxGroup), hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, base, groups.data(), (size_t)ng * sizeof(MinmaxGroup)));
         k_minmax_affine_grouped<<<dim3(nblk, ng), 256, 0, ctx->stream>>>((const MinmaxGroup*)base, ctx->N,
                                                                         (double*)(base + o_part));
         GD_KERNEL_CHECK();
@@ -1260,7 +1329,7 @@ int gd_minmax_affine(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t*
     if (!base) return GD_ERR_NOMEM;
     Hist2DPair* d_pairs = (Hist2DPair*)base;
     double* d_part = (double*)(base + o_part);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair)));
     k_minmax_affine<<<dim3(nblk, B), 256, 0, ctx->stream>>>(d_pairs, ctx->N, d_part);
     GD_KERNEL_CHECK();
     std::vector<double> h((size_t)B * nblk * 2);

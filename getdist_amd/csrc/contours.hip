@@ -163,7 +163,7 @@ int gd_contour_levels(gd_ctx* ctx, int32_t B, int32_t F, const void* d_P, const 
     const int64_t o_c = take(nc * 8), o_out = take((int64_t)B * nc * 8), o_st = take((int64_t)B * 4);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(base + o_c, contours, (size_t)nc * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, base + o_c, contours, (size_t)nc * 8));
     k_contour_levels<<<B, 1024, 0, ctx->stream>>>((const double*)d_P, F, (const double*)(base + o_c), nc,
                                                   (double*)(base + o_out), (int*)(base + o_st));
     GD_KERNEL_CHECK();

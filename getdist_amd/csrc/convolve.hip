@@ -99,8 +99,8 @@ int gd_circ_convolve(gd_ctx* ctx, int32_t n0, int32_t n1, const double* a, const
     if (!base) return GD_ERR_NOMEM;
     double *d_a = (double*)(base + o_a), *d_b = (double*)(base + o_b);
     double2 *za = (double2*)(base + o_za), *zb = (double2*)(base + o_zb);
-    GD_HIP(hipMemcpyAsync(d_a, a, (size_t)nr * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_b, b, (size_t)nr * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_a, a, (size_t)nr * 8));
+    GD_TRY(gd_h2d(ctx, d_b, b, (size_t)nr * 8));
     int rc;
     if ((rc = gd_fft_r2c_2d(ctx, n0, n1, 1, d_a, za))) return rc;
     if ((rc = gd_fft_r2c_2d(ctx, n0, n1, 1, d_b, zb))) return rc;
@@ -119,8 +119,8 @@ int gd_convolve1d_direct(gd_ctx* ctx, const double* x, int64_t nx, const double*
     char* base = (char*)gd_scratch(ctx, o_o + up(nout * 8));
     if (!base) return GD_ERR_NOMEM;
     double *d_x = (double*)base, *d_y = (double*)(base + o_y), *d_o = (double*)(base + o_o);
-    GD_HIP(hipMemcpyAsync(d_x, x, (size_t)nx * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_y, y, (size_t)ny * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_x, x, (size_t)nx * 8));
+    GD_TRY(gd_h2d(ctx, d_y, y, (size_t)ny * 8));
     k_conv1d_direct<<<(unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256), 256, 0, ctx->stream>>>(d_x, nx, d_y, ny, d_o);
     GD_KERNEL_CHECK();
     GD_TRY(gd_fetch(ctx, out_full, d_o, (size_t)nout * 8));
@@ -145,7 +145,7 @@ int gd_autoconvolve(gd_ctx* ctx, int32_t col, double mean, int32_t use_weights, 
     double2* z = (double2*)(base + o_z);
     double* d_out = (double*)(base + o_o);
     if (x_host) {
-        GD_HIP(hipMemcpyAsync(frame, x_host, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, frame, x_host, (size_t)N * 8));
         GD_HIP(hipMemsetAsync(frame + N, 0, (size_t)(s - N) * 8, ctx->stream));
     } else {
         k_fill_centered<<<4096, 256, 0, ctx->stream>>>(ctx->cols + (int64_t)col * ctx->ld, use_weights ? ctx->w : nullptr, N, mean, s,
@@ -185,7 +185,7 @@ int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8) {
         sw += h[(size_t)b * 5 + 2], swl += h[(size_t)b * 5 + 3], swl2 += h[(size_t)b * 5 + 4];
     }
     const unsigned long long none = ~0ull;
-    GD_HIP(hipMemcpyAsync(d_first, &none, 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_first, &none, 8));
     k_like_pass2<<<nblk, 256, 0, ctx->stream>>>(L, ctx->w, ctx->N, mn, d_part, d_first);
     GD_KERNEL_CHECK();
     unsigned long long first = 0;

@@ -99,9 +99,21 @@ int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
         sl.cap = bytes, sl.own = true;
     }
     memcpy(sl.host, src, bytes);
-    GD_HIP(hipMemcpyAsync(d_dst, sl.host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // a copy KERNEL reading the page-locked slot, not a DMA copy: those queue behind the result copies of the previous
+    // batched call on the copy engines (measured: a 20-KB table then arrives up to 3.6 ms after it was enqueued, with the
+    // stream idle in front of it)
+    GD_TRY(fetch_kernel(ctx, d_dst, sl.host, bytes));
     GD_HIP(hipEventRecord(sl.ev, ctx->stream));
     sl.used = true;
+    return GD_OK;
+}
+
+// Stream-ordered upload of a host table the caller may release on return: small ones through the staging ring above,
+// large ones (whole histograms, masks) by DMA.
+int gd_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (bytes == 0) return GD_OK;
+    if (bytes <= gd_ctx::kStageBytes) return gd_stage_h2d(ctx, d_dst, src, bytes);
+    GD_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return GD_OK;
 }
 
@@ -133,6 +145,18 @@ static std::set<gd_ctx*> g_live;
 bool gd_ctx_alive(gd_ctx* ctx) {
     std::lock_guard<std::mutex> g(g_live_mu);
     return g_live.count(ctx) != 0;
+}
+
+int gd_stream_priority(gd_ctx* ctx, int high) {
+    int least = 0, greatest = 0;
+    GD_HIP(hipSetDevice(ctx->device));
+    GD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically lower = more urgent
+    GD_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t fresh = nullptr;
+    GD_HIP(hipStreamCreateWithPriority(&fresh, hipStreamDefault, high ? greatest : least));
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = fresh;
+    return GD_OK;
 }
 
 extern "C" {
@@ -193,6 +217,8 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     for (auto& ev : ctx->copy_marks)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->kopt_evs)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->stage) {
         if (sl.own && sl.host) (void)hipHostFree(sl.host);

@@ -75,6 +75,10 @@ struct gd_ctx {
     void* fetch_block = nullptr;
     size_t fetch_off = 0;
     std::vector<Fetch> fetch_pending;
+    // gd_kopt2d_enqueue / gd_kopt2d_finish: "stage A has run" events a second context's stream waits for
+    static constexpr int kKoptEvents = 32;
+    hipEvent_t kopt_evs[kKoptEvents] = {};
+    int kopt_ev_next = 0;
     // gd_density2d_batch (batch2d.hip): device-block pool, cached index columns and the last call's blocks in flight
     void* batch_state = nullptr;
     void (*batch_state_release)(gd_ctx*, bool destroy) = nullptr;
@@ -82,6 +86,7 @@ struct gd_ctx {
 
 // Stream-ordered H2D copy of a small host table whose storage the caller may release as soon as this returns.
 int gd_stage_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int gd_h2d(gd_ctx* ctx, void* d_dst, const void* src, size_t bytes);  // the same for any size (large tables by DMA)
 
 // fft.hip: batched 2D real FFTs through rocFFT (plans cached per ctx); n0 = slow axis, n1 = fast axis.
 // r2c: in batch x n0 x n1 doubles -> out batch x n0 x (n1/2+1) complex.  c2r is unnormalised and
@@ -101,7 +106,8 @@ int gd_fetch_pinned(gd_ctx* ctx, void* pinned_dst, const void* d_src, size_t byt
 int gd_stream_sync(gd_ctx* ctx);
 
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
-bool gd_ctx_alive(gd_ctx* ctx);  // false once gd_destroy has run on it (core.hip)
+bool gd_ctx_alive(gd_ctx* ctx);
+int gd_stream_priority(gd_ctx* ctx, int high);  // re-create the (idle) compute stream with high / normal priority  // false once gd_destroy has run on it (core.hip)
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure
 void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
 

@@ -420,7 +420,7 @@ int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_ou
     double* d_in = (double*)base;
     double* d_out = (double*)(base + (nb + 255) / 256 * 256);
     double* d_tab = (double*)(base + 2 * ((nb + 255) / 256 * 256));
-    GD_HIP(hipMemcpyAsync(d_in, hist, (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_in, hist, (size_t)nb));
     k_cos_table<<<(4 * F + 255) / 256, 256, 0, ctx->stream>>>(F, d_tab);
     GD_KERNEL_CHECK();
     k_dct1d<<<dim3((F + 255) / 256, B), 256, (size_t)F * 8, ctx->stream>>>(d_in, F, d_tab, d_out);
@@ -459,9 +459,9 @@ int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double
         GD_REQUIRE(neff[b] > 0, "effective sample number must be positive");
         nscale[b] = pow(neff[b], -1.0 / 5);
     }
-    GD_HIP(hipMemcpyAsync(d_in, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_neff, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_nscale, nscale.data(), (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_in, hist, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, d_neff, neff, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, d_nscale, nscale.data(), (size_t)B * 8));
     k_cos_table<<<(4 * F + 255) / 256, 256, 0, ctx->stream>>>(F, d_tab);
     GD_KERNEL_CHECK();
     k_dct1d<<<dim3((F + 255) / 256, B), 256, (size_t)F * 8, ctx->stream>>>(d_in, F, d_tab, d_a);
@@ -498,10 +498,10 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
     int* d_winw = (int*)(base + 2 * nb + ns);
     int* d_flags = (int*)(base + 2 * nb + 2 * ns);
     int* d_status = (int*)(base + 2 * nb + 3 * ns);
-    GD_HIP(hipMemcpyAsync(d_hist, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_smooth, smooth, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_winw, winw, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_flags, flags, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_hist, hist, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, d_smooth, smooth, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, d_winw, winw, (size_t)B * 4));
+    GD_TRY(gd_h2d(ctx, d_flags, flags, (size_t)B * 4));
     D1Args A{F, bco, mbc};
     const size_t lds = (size_t)4 * F * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_density1d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
@@ -529,12 +529,12 @@ int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const doub
            *d_out = (double*)(base + 3 * nb), *d_smooth = (double*)(base + 4 * nb);
     int *d_winw = (int*)(base + 4 * nb + ns), *d_flags = (int*)(base + 4 * nb + 2 * ns),
         *d_status = (int*)(base + 4 * nb + 3 * ns);
-    GD_HIP(hipMemcpyAsync(d_hist, hist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_lh, likehist, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_P, P, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_smooth, smooth, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_winw, winw, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_flags, flags, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_hist, hist, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, d_lh, likehist, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, d_P, P, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, d_smooth, smooth, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, d_winw, winw, (size_t)B * 4));
+    GD_TRY(gd_h2d(ctx, d_flags, flags, (size_t)B * 4));
     const size_t lds = (size_t)4 * F * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_likes1d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
     k_likes1d<<<B, 256, lds, ctx->stream>>>(d_hist, d_lh, d_P, d_smooth, d_winw, d_flags, F, shade_mean_loglikes, d_out,

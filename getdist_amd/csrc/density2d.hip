@@ -560,141 +560,7 @@ __global__ void k_box(const double* __restrict__ hist, const double* __restrict_
 // registers, the group synchronises, and the outputs go back to their auto-sorted places.  One buffer per transform is
 // what lets ~30 transforms be resident per CU -- their number, not the arithmetic, bounds these kernels.  Any frame size of
 // the ladder up to 512 is handled (larger grids keep the rocFFT route).
-#define FT 32
-struct FftDev {
-    int S, nst;
-    int radix[12];
-    unsigned int magic[12];  // ceil(2^20 / Ns) of pass st (Ns = product of the earlier radices): j / Ns = (j * magic) >> 20
-                             // exactly for j < 512 -- the passes are VALU-bound and a runtime division costs ~40 instructions
-};
-
-// The FT lanes of a transform sit inside one wavefront, whose LDS operations execute in order: passes are separated by a
-// compiler-level fence, not by a block barrier, so the waves of a block run their transforms independently.
-__device__ __forceinline__ void group_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// complex product with explicit fused multiply-adds (the library is built with -ffp-contract=off for the kernels whose
-// results must match numpy's operation by operation; these transforms are VALU-bound and have no such twin)
-__device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
-    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
-}
-
-// One in-place Stockham pass of radix R over the length-S sequence in `buf`; MAXIT >= ceil(S / R / FT) butterflies per
-// lane; INV: inverse transform (conjugate twiddles).  `emit(pos, value)` receives the outputs after the group has read all
-// its inputs (default: store to buf).  tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its
-// stride.  Groups without work run the passes on their (unused) buffer like the others -- the passes are VALU-bound and a
-// per-lane `active` test in every butterfly costs more than the idle arithmetic of the last block of a grid.
-template <int R, int MAXIT, bool INV, class Emit>
-__device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns,
-                                         unsigned int magic, int nb, int t, Emit emit) {
-    const int step = (nb / Ns) * tws;  // S / (Ns R) twiddle-table entries per unit of q k
-    const bool twiddles = Ns > 1;      // (wave-uniform) the first pass has none
-    double2 o[MAXIT][R];
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int j = t + it * FT;
-        if (j < nb) {
-            const int k = j - (int)(((unsigned int)j * magic) >> 20) * Ns;  // j % Ns
-            double2 v[R];
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                double2 x = buf[j + q * nb];
-                if (q > 0 && twiddles) {
-                    double2 w = tw[q * k * step];
-                    if (INV) w.y = -w.y;
-                    x = cmulf(x, w);
-                }
-                v[q] = x;
-            }
-            if (R == 2) {
-                o[it][0] = make_double2(v[0].x + v[1].x, v[0].y + v[1].y);
-                o[it][1] = make_double2(v[0].x - v[1].x, v[0].y - v[1].y);
-            } else if (R == 4) {
-                const double2 t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
-                const double2 t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y);
-                const double2 d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
-                const double2 t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) : d * (-i)
-                o[it][0] = make_double2(t0.x + t2.x, t0.y + t2.y);
-                o[it][1] = make_double2(t1.x + t3.x, t1.y + t3.y);
-                o[it][2] = make_double2(t0.x - t2.x, t0.y - t2.y);
-                o[it][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
-            } else if (R == 3) {
-                // o0 = v0 + (v1 + v2);  o1, o2 = v0 - (v1 + v2) / 2  -+ i sin(60) (v1 - v2)   (forward; + - for the inverse)
-                constexpr double SIN60 = 0.86602540378443864676;
-                const double2 sm = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), df = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
-                const double2 md = make_double2(fma(-0.5, sm.x, v[0].x), fma(-0.5, sm.y, v[0].y));
-                // -i s df = (s df.y, -s df.x) forward;  +i s df = (-s df.y, s df.x) inverse
-                const double rx = (INV ? -SIN60 : SIN60) * df.y, ry = (INV ? SIN60 : -SIN60) * df.x;
-                o[it][0] = make_double2(v[0].x + sm.x, v[0].y + sm.y);
-                o[it][1] = make_double2(md.x + rx, md.y + ry);
-                o[it][2] = make_double2(md.x - rx, md.y - ry);
-            } else {  // small DFT by its definition; cos / sin of 2 pi m / R as literals (R = 5)
-                constexpr double C3[3] = {1.0, -0.5, -0.5};
-                constexpr double S3[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
-                constexpr double C5[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410,
-                                          0.30901699437494742410};
-                constexpr double S5[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917,
-                                          -0.95105651629515357212};
-#pragma unroll
-                for (int p = 0; p < R; ++p) {
-                    double2 acc = v[0];
-#pragma unroll
-                    for (int q = 1; q < R; ++q) {
-                        const int m = (p * q) % R;
-                        const double c = R == 3 ? C3[m] : C5[m];
-                        const double sn = (R == 3 ? S3[m] : S5[m]) * (INV ? 1.0 : -1.0);  // e^{-+ 2 pi i m / R}
-                        acc.x = fma(v[q].x, c, fma(-v[q].y, sn, acc.x));
-                        acc.y = fma(v[q].x, sn, fma(v[q].y, c, acc.y));
-                    }
-                    o[it][p] = acc;
-                }
-            }
-        }
-    }
-    group_sync();
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int j = t + it * FT;
-        if (j < nb) {
-            const int jq = (int)(((unsigned int)j * magic) >> 20);  // j / Ns
-            const int j0 = jq * Ns * (R - 1) + j;                   // (j / Ns) Ns R + j % Ns
-#pragma unroll
-            for (int q = 0; q < R; ++q) emit(j0 + q * Ns, o[it][q]);
-        }
-    }
-    group_sync();
-}
-
-// butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
-template <bool BIG, bool INV, class Emit>
-__device__ __forceinline__ void fft_pass_any(const FftDev& pl, int st, double2* buf, const double2* tw, int tws, int Ns, int t,
-                                             Emit emit) {
-    const int R = pl.radix[st], S = pl.S;
-    const unsigned int mg = pl.magic[st];
-    if (R == 4) fft_pass<4, BIG ? 4 : 3, INV>(buf, tw, tws, S, Ns, mg, S >> 2, t, emit);
-    else if (R == 2) fft_pass<2, BIG ? 8 : 5, INV>(buf, tw, tws, S, Ns, mg, S >> 1, t, emit);
-    else if (R == 3) fft_pass<3, BIG ? 6 : 4, INV>(buf, tw, tws, S, Ns, mg, S / 3, t, emit);
-    else fft_pass<5, BIG ? 4 : 2, INV>(buf, tw, tws, S, Ns, mg, S / 5, t, emit);
-}
-
-// all passes but the last; returns the sub-transform length the last pass starts from
-template <bool BIG, bool INV>
-__device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
-    int Ns = 1;
-    for (int st = 0; st + 1 < pl.nst; ++st) {
-        fft_pass_any<BIG, INV>(pl, st, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
-        Ns *= pl.radix[st];
-    }
-    return Ns;
-}
-
-template <bool BIG, bool INV>
-__device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
-    const int Ns = fft_head<BIG, INV>(buf, tw, tws, pl, t);
-    fft_pass_any<BIG, INV>(pl, pl.nst - 1, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
-}
+#include "ldsfft.hpp"
 
 // grid (ceil(F / RPB), B), RPB * 32 threads = RPB (16) rows of pair b per block: the transposed store then writes 256-byte
 // runs.  A row is real: its even and odd samples are packed into one complex sequence of half the frame length H = S / 2
@@ -939,38 +805,6 @@ static int next_fft_size(int n) {
     return best;
 }
 
-// The LDS route's plan for frame size S (radices 4, 2, 3, 5) and its twiddle table on the device (cached per context).
-// false: S has another prime factor (not on the ladder) -- the caller keeps the rocFFT route.
-static bool lds_fft_plan(gd_ctx* ctx, int S, FftDev* pl, const double2** tw) {
-    pl->S = S, pl->nst = 0;
-    int n = S;
-    // odd radices first: a pass writes its outputs R * (length of the finished sub-transforms) apart, and a power-of-two
-    // stride in the first pass (sub-transform length 1) would put every lane's 16-byte store on a few LDS banks
-    const int order[4] = {3, 5, 4, 2};
-    for (int q = 0; q < 4; ++q)
-        while (n % order[q] == 0 && pl->nst < 12) pl->radix[pl->nst++] = order[q], n /= order[q];
-    if (n != 1 || pl->nst == 0) return false;
-    for (int st = 0, Ns = 1; st < pl->nst; Ns *= pl->radix[st], ++st) pl->magic[st] = (unsigned int)(((1u << 20) + Ns - 1) / Ns);
-    if (!tw) return true;  // plan only (the rows' half-length transforms use the frame's table with stride 2)
-    auto it = ctx->fft_tw.find(S);
-    if (it == ctx->fft_tw.end()) {
-        std::vector<double2> h((size_t)S);
-        for (int k = 0; k < S; ++k) {
-            const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)S;
-            h[k] = make_double2((double)cosl(a), (double)sinl(a));
-        }
-        void* d = nullptr;
-        if (hipMalloc(&d, (size_t)S * 16) != hipSuccess) return false;
-        if (hipMemcpy(d, h.data(), (size_t)S * 16, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d);
-            return false;
-        }
-        it = ctx->fft_tw.emplace(S, d).first;
-    }
-    *tw = (const double2*)it->second;
-    return true;
-}
-
 // Periodic variant (one or both axes periodic, the same for the whole batch).  Histogram-side convolutions are
 // circular on the folded (Ny x Nx) grid -- including along a non-periodic axis, which the reference also wraps
 // (convolve.py:226-251 takes the FFT at the array size without zero-padding); mask-side 'valid' convolutions use the
@@ -1015,7 +849,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
             *ZPc = (double2*)(base + o_ZPc), *ZW = (double2*)(base + o_ZW), *ZM = (double2*)(base + o_ZM),
             *ZK = (double2*)(base + o_ZK), *ZP = (double2*)(base + o_ZP);
     if (wait) {
-        GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair)));
     } else {  // hp dies with this frame before the copy executes
         const int rc_stage = gd_stage_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair));
         if (rc_stage) return rc_stage;
@@ -1207,7 +1041,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     double* d_conv = (double*)(base + o_conv);
     double* d_sat = (double*)(base + o_sat);
     if (wait) {
-        GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair)));
     } else {  // hp dies with this frame before the copy executes
         const int rc_stage = gd_stage_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair));
         if (rc_stage) return rc_stage;
@@ -1416,15 +1250,15 @@ int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, d
     if (!base) return GD_ERR_NOMEM;
     MaskOv ov{nullptr, nullptr, nullptr};
     if (mask_bc) {
-        GD_HIP(hipMemcpyAsync(base, mask_bc, (size_t)(Mp * Mp * 8), hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, base, mask_bc, (size_t)(Mp * Mp * 8)));
         ov.d_mask_bc = (const double*)base;
     }
     if (mask_mbc) {
-        GD_HIP(hipMemcpyAsync(base + nb, mask_mbc, (size_t)(Mp * Mp * 8), hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, base + nb, mask_mbc, (size_t)(Mp * Mp * 8)));
         ov.d_mask_mbc = (const double*)(base + nb);
     }
     if (zero_mask) {
-        GD_HIP(hipMemcpyAsync(base + 2 * nb, zero_mask, (size_t)F * F, hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, base + 2 * nb, zero_mask, (size_t)F * F));
         ov.d_zero = (const unsigned char*)(base + 2 * nb);
     }
     const int32_t fl = flags | 64;  // a mask function always counts as a prior (mcsamples.py:1794)
@@ -1479,7 +1313,7 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
     int* d_status = (int*)(base + o_status);
     double *C1 = (double*)(base + o_C1), *C2 = (double*)(base + o_C2), *d_P0 = (double*)(base + o_P0),
            *d_T = (double*)(base + o_T), *d_L2 = (double*)(base + o_L2);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(D2Pair), hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair)));
     const dim3 gN(64, B), gF(64, B);
     const dim3 gC((unsigned)(((n1 + 63) / 64) * ((n0 + 4 * CONV_RY - 1) / (4 * CONV_RY))), B);
     k_win_sum<<<B, 256, 0, ctx->stream>>>(d_pairs, d_wsum);

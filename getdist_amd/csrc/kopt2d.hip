@@ -7,6 +7,7 @@
 // psi functionals get_h needs, and -- when the pair is unbounded -- the odd functionals from |fft2|^2
 // (rocFFT).  Reference: kde_bandwidth.py:146-270.
 #include "ctx.hpp"
+#include "ldsfft.hpp"
 #include "solvers.hpp"
 
 #ifndef KT
@@ -116,6 +117,93 @@ __global__ void __launch_bounds__(256) k_gemm_nt(const double* __restrict__ A, i
                     }
                 }
             }
+}
+
+
+// ---- DCT-II of the rows of a batch of F x F matrices through a half-length complex transform in LDS ---------------------
+// y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2F))  (scipy.fftpack.dct type 2, unnormalised) by Makhoul's reordering:
+// v[m] = x[2m] (m < F/2), v[F-1-m] = x[2m+1]; V = DFT_F(v) from ONE complex transform of length H = F/2 of the packed
+// sequence z[n] = v[2n] + i v[2n+1] (the real-input un-mixing of k_rows_fwd); y[k] = 2 Re(c_k V[k]), c_k = e^{-i pi k / 2F},
+// and y[F-k] = 2 Re(c_{F-k} conj V[k]).  The result is stored TRANSPOSED: dst[b][k][row], so that two passes make the 2D
+// transform (pass 1: along x, pass 2: along y) -- 2 x (read + write) of the matrix instead of two F^3 GEMMs (which ran at
+// 37 TFLOP/s of fp64 MFMA: 2.0 ms per 1225 pairs; this: memory-bound).
+// EPI 1 (second pass): v = y / sums[b]; out = v * v  (the squared, normalised coefficients the fixed point works on).
+// grid (ceil(F / RPB), B), RPB * 32 threads: RPB rows per block, one 32-lane group per row (ldsfft.hpp).
+// dynamic LDS: F twiddles e^{-2 pi i k / F} | F post-twiddles c_k | RPB x (H complex transform buffer + F doubles staging)
+template <int EPI, bool BIG>
+__global__ void __launch_bounds__(512) k_dct_pass(const double* __restrict__ src, int F, FftDev plH, const double2* __restrict__ twg,
+                                                  const double2* __restrict__ cg, const double* __restrict__ sums,
+                                                  double* __restrict__ dst) {
+    extern __shared__ double2 dsh[];
+    const int H = F >> 1, b = blockIdx.y, RPB = blockDim.x / FT;
+    double2* tw = dsh;
+    double2* ck = dsh + F;
+    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    double2* buf = dsh + 2 * F + (size_t)g * F;  // H complex
+    double* stage = (double*)(buf + H);           // F doubles
+    for (int i = threadIdx.x; i < F; i += blockDim.x) tw[i] = twg[i], ck[i] = cg[i];
+    const int row = blockIdx.x * RPB + g;
+    const bool active = row < F;
+    if (active) {
+        const double* x = src + (int64_t)b * F * F + (int64_t)row * F;
+        for (int i = t; i < F; i += FT) stage[i] = x[i];
+    }
+    __syncthreads();
+    if (active) {
+        auto v = [&](int m) { return m < H ? stage[2 * m] : stage[2 * (F - 1 - m) + 1]; };
+        for (int n = t; n < H; n += FT) buf[n] = make_double2(v(2 * n), v(2 * n + 1));
+    }
+    group_sync();
+    fft_full<BIG, false>(buf, tw, 2, plH, t);
+    if (active) {
+        const double inv = EPI == 1 ? sums[b] : 1.0;
+        auto put = [&](int k, double y) {
+            if (EPI == 1) {
+                const double val = y / inv;
+                stage[k] = val * val;
+            } else {
+                stage[k] = y;
+            }
+        };
+        for (int k = t; 2 * k <= H; k += FT) {
+            if (k == 0) {
+                const double2 z = buf[0];
+                put(0, 2.0 * (z.x + z.y));
+                const double vh = z.x - z.y;  // V[H], real
+                put(H, 2.0 * (ck[H].x * vh));
+                continue;
+            }
+            const double2 zk = buf[k], zm = buf[H - k];
+            const double ax = zk.x + zm.x, ay = zk.y - zm.y, bx = zk.x - zm.x, by = zk.y + zm.y;
+            {
+                const double2 e = tw[k];
+                const double u = fma(e.x, bx, -(e.y * by)), w = fma(e.x, by, e.y * bx);
+                const double vx = 0.5 * (ax + w), vy = 0.5 * (ay - u);  // V[k]
+                const double2 c1 = ck[k], c2 = ck[F - k];
+                put(k, 2.0 * fma(c1.x, vx, -(c1.y * vy)));
+                put(F - k, 2.0 * fma(c2.x, vx, c2.y * vy));
+            }
+            if (2 * k < H) {  // V[H - k] from the same two values
+                const double2 f = tw[H - k];
+                const double u2 = -fma(f.x, bx, f.y * by), w2 = fma(f.x, by, -(f.y * bx));
+                const double vx = 0.5 * (ax + w2), vy = 0.5 * (-ay - u2);
+                const double2 c1 = ck[H - k], c2 = ck[H + k];
+                put(H - k, 2.0 * fma(c1.x, vx, -(c1.y * vy)));
+                put(H + k, 2.0 * fma(c2.x, vx, c2.y * vy));
+            }
+        }
+    }
+    __syncthreads();
+    // transposed store: the block's RPB rows are RPB consecutive doubles of every output row k
+    double* out = dst + (int64_t)b * F * F + (int64_t)blockIdx.x * RPB;
+    const int nrows = min(RPB, F - blockIdx.x * RPB);
+    for (int e = threadIdx.x; e < F * RPB; e += blockDim.x) {
+        const int k = e / RPB, r = e - k * RPB;
+        if (r < nrows) {
+            const double* st = (const double*)(dsh + 2 * F + (size_t)r * F + H);
+            out[(int64_t)k * F + r] = st[k];
+        }
+    }
 }
 
 // DCT-II matrix: D[k][n] = 2 cos(pi k (2n+1) / (2F))   (scipy.fftpack.dct type 2, unnormalised)
@@ -616,10 +704,10 @@ int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, cons
         for (int q = 0; q < 6; ++q) hk[(size_t)b * KOPT_STRIDE + 1 + q] = psi[(size_t)b * 6 + q];
         hk[(size_t)b * KOPT_STRIDE + 7] = (double)GD_OK;
     }
-    GD_HIP(hipMemcpyAsync(base + o_k, hk.data(), hk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_n, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_c, corr, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_d, do_corr, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, base + o_k, hk.data(), hk.size() * 8));
+    GD_TRY(gd_h2d(ctx, base + o_n, neff, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, base + o_c, corr, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, base + o_d, do_corr, (size_t)B * 4));
     k_get_h<<<B, 64, 0, ctx->stream>>>((double*)(base + o_k), (const double*)(base + o_n), (const double*)(base + o_c),
                                       (const int*)(base + o_d), B);
     GD_KERNEL_CHECK();
@@ -630,22 +718,53 @@ int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, cons
     return GD_OK;
 }
 
-int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* neff, const int32_t* do_corr,
-              const double* fallback_t, const double* corr, double* out) {
-    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && corr && out && B > 0, "bad argument");
+// Stage A of gd_kopt2d (everything up to the functionals), enqueued on ctx's stream: d_rows (device, B x 12) receives
+// {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status} per pair.
+static int kopt_stage_a(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* neff, const int32_t* do_corr,
+                        const double* fallback_t, double* d_rows) {
+    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && d_rows && B > 0, "bad argument");
     GD_REQUIRE(F >= 16 && F <= 1024, "KernelOptimizer2D grid size out of range (16..1024)");
     const double* d_hist = (const double*)d_hist_v;
     const int64_t FF = (int64_t)F * F;
-    // cached DCT matrix
+    // DCT route: half-length transforms in LDS (k_dct_pass) where F / 2 is on the transform ladder, else two GEMMs against
+    // the cached DCT-II matrix
+    FftDev plH;
+    const double2 *d_tw = nullptr, *d_ck = nullptr;
+    bool dct_fft = F % 2 == 0 && F / 2 <= 512 && F >= 64 && getenv("GDHIP_KOPT_DCT_GEMM") == nullptr &&
+                   lds_fft_plan(ctx, F / 2, &plH, nullptr);
+    if (dct_fft) {
+        FftDev plF;
+        dct_fft = lds_fft_plan(ctx, F, &plF, &d_tw);  // (only its table of F twiddles is used)
+    }
+    if (dct_fft) {
+        auto it = ctx->fft_tw.find(-F);  // key -F: the post-twiddles e^{-i pi k / 2F}
+        if (it == ctx->fft_tw.end()) {
+            std::vector<double2> hck((size_t)F);
+            for (int k = 0; k < F; ++k) {
+                const long double a = -3.141592653589793238462643383279502884L * (long double)k / (2.0L * (long double)F);
+                hck[k] = make_double2((double)cosl(a), (double)sinl(a));
+            }
+            void* d = nullptr;
+            GD_HIP(hipMalloc(&d, (size_t)F * 16));
+            if (hipMemcpy(d, hck.data(), (size_t)F * 16, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d);
+                return gd_fail(ctx, GD_ERR_HIP, "upload of the DCT post-twiddles failed");
+            }
+            it = ctx->fft_tw.emplace(-F, d).first;
+        }
+        d_ck = (const double2*)it->second;
+    }
     double* D = nullptr;
-    auto it = ctx->dctmat.find(F);
-    if (it == ctx->dctmat.end()) {
-        GD_HIP(hipMalloc((void**)&D, (size_t)FF * 8));
-        k_dct_matrix<<<(unsigned)((FF + 255) / 256), 256, 0, ctx->stream>>>(F, D);
-        GD_KERNEL_CHECK();
-        ctx->dctmat[F] = D;
-    } else {
-        D = it->second;
+    if (!dct_fft) {
+        auto it = ctx->dctmat.find(F);
+        if (it == ctx->dctmat.end()) {
+            GD_HIP(hipMalloc((void**)&D, (size_t)FF * 8));
+            k_dct_matrix<<<(unsigned)((FF + 255) / 256), 256, 0, ctx->stream>>>(F, D);
+            GD_KERNEL_CHECK();
+            ctx->dctmat[F] = D;
+        } else {
+            D = it->second;
+        }
     }
     std::vector<KoptPair> hp((size_t)B);
     std::vector<int> which;
@@ -667,32 +786,54 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_sums = take((int64_t)B * 8), o_pairs = take((int64_t)B * sizeof(KoptPair)), o_out = take((int64_t)B * KOPT_STRIDE * 8), o_neff = take((int64_t)B * 8), o_corr = take((int64_t)B * 8),
-                  o_dc = take((int64_t)B * 4),
-                  o_which = take((int64_t)(nc + 1) * 4), o_E = take((int64_t)B * FF * 8), o_SQ = take((int64_t)B * FF * 8),
-                  o_Z = take((int64_t)nc * F * Fh * 16), o_PW = take((int64_t)nc * FF * 8);
+    // the per-pair tables sit next to one another: ONE staged upload instead of five pageable copies (each of which
+    // would wait for the copy engine behind the previous call's result copies)
+    const int64_t o_pairs = take((int64_t)B * sizeof(KoptPair)), o_which = take((int64_t)(nc + 1) * 4);
+    const int64_t table_bytes = off;
+    const int64_t o_sums = take((int64_t)B * 8), o_E = take((int64_t)B * FF * 8),
+                  o_SQ = take((int64_t)B * FF * 8), o_Z = take((int64_t)nc * F * Fh * 16), o_PW = take((int64_t)nc * FF * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     double* d_sums = (double*)(base + o_sums);
     KoptPair* d_pairs = (KoptPair*)(base + o_pairs);
-    double* d_out = (double*)(base + o_out);
+    double* d_out = d_rows;
     int* d_which = (int*)(base + o_which);
     double* d_E = (double*)(base + o_E);
     double* d_SQ = (double*)(base + o_SQ);
     double2* d_Z = (double2*)(base + o_Z);
     double* d_PW = (double*)(base + o_PW);
-    GD_HIP(hipMemcpyAsync(d_pairs, hp.data(), (size_t)B * sizeof(KoptPair), hipMemcpyHostToDevice, ctx->stream));
+    {
+        std::vector<char> tab((size_t)table_bytes, 0);
+        memcpy(tab.data() + o_pairs, hp.data(), (size_t)B * sizeof(KoptPair));
+        if (nc) memcpy(tab.data() + o_which, which.data(), (size_t)nc * 4);
+        GD_TRY(gd_stage_h2d(ctx, base, tab.data(), (size_t)table_bytes));
+    }
     k_hist_sums<<<B, 1024, 0, ctx->stream>>>(d_hist, (int)FF, d_sums);
     GD_KERNEL_CHECK();
-    const dim3 ggrid((F + 63) / 64, (F + 63) / 64, B);
-    // E[l][r] = sum_c D[l][c] X[r][c]      (DCT along axis 1, transposed)
-    k_gemm_nt<0><<<ggrid, 256, 0, ctx->stream>>>(D, 0, d_hist, FF, F, d_E, FF, nullptr);
-    GD_KERNEL_CHECK();
-    // A^T[l][k] = sum_r E[l][r] D[k][r];  SQ[k][l] = (A[k][l] / sum)^2
-    k_gemm_nt<1><<<ggrid, 256, 0, ctx->stream>>>(d_E, FF, D, 0, F, d_SQ, FF, d_sums);
-    GD_KERNEL_CHECK();
+    if (dct_fft) {
+        const int RPB = F <= 256 ? 16 : (F <= 512 ? 8 : 4);
+        const size_t lds = ((size_t)2 * F + (size_t)RPB * F) * 16;
+        const dim3 grid((F + RPB - 1) / RPB, B);
+        const bool big = F / 2 > 320;
+        auto k0 = big ? k_dct_pass<0, true> : k_dct_pass<0, false>;
+        auto k1 = big ? k_dct_pass<1, true> : k_dct_pass<1, false>;
+        GD_HIP(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GD_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // E[l][r] = DCT along x of row r (transposed);  SQ[k][l] = (DCT along y of E[l][.] / sum)^2
+        k0<<<grid, RPB * FT, lds, ctx->stream>>>(d_hist, F, plH, d_tw, d_ck, nullptr, d_E);
+        GD_KERNEL_CHECK();
+        k1<<<grid, RPB * FT, lds, ctx->stream>>>(d_E, F, plH, d_tw, d_ck, d_sums, d_SQ);
+        GD_KERNEL_CHECK();
+    } else {
+        const dim3 ggrid((F + 63) / 64, (F + 63) / 64, B);
+        // E[l][r] = sum_c D[l][c] X[r][c]      (DCT along axis 1, transposed)
+        k_gemm_nt<0><<<ggrid, 256, 0, ctx->stream>>>(D, 0, d_hist, FF, F, d_E, FF, nullptr);
+        GD_KERNEL_CHECK();
+        // A^T[l][k] = sum_r E[l][r] D[k][r];  SQ[k][l] = (A[k][l] / sum)^2
+        k_gemm_nt<1><<<ggrid, 256, 0, ctx->stream>>>(d_E, FF, D, 0, F, d_SQ, FF, d_sums);
+        GD_KERNEL_CHECK();
+    }
     if (nc > 0) {
-        GD_HIP(hipMemcpyAsync(d_which, which.data(), (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
         // reuse E as the gathered, normalised input of the FFT (E is dead after the second GEMM)
         k_gather_norm<<<dim3(64, nc), 256, 0, ctx->stream>>>(d_hist, d_which, d_sums, (int)FF, d_E);
         GD_KERNEL_CHECK();
@@ -727,16 +868,64 @@ int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const dou
         GD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), hp, sizeof(hp)));
     }
 #endif
-    // get_h on the device: the optimiser's functionals never leave HBM
-    GD_HIP(hipMemcpyAsync(base + o_neff, neff, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_corr, corr, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_dc, do_corr, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    k_get_h<<<B, 64, 0, ctx->stream>>>(d_out, (const double*)(base + o_neff), (const double*)(base + o_corr),
-                                      (const int*)(base + o_dc), B);
+    return GD_OK;
+}
+
+// Stage B: KernelOptimizer2D.get_h for the rows stage A left in d_rows, on ctx's stream (which may be another context's
+// than stage A's: `after` is then an event recorded behind stage A's kernels); the finished rows come back to `out`.
+// The per-pair inputs of get_h (N_eff, correlation, do_corr) sit behind the rows in the same block, uploaded with stage
+// A's tables: stage B reads nothing from the host, so its launch never waits for a table to cross PCIe.
+#define KOPT_BLOCK_DOUBLES 15  // per pair: 12 result doubles + neff + corr + do_corr (as int in the low half of a double slot)
+static int kopt_stage_b(gd_ctx* ctx, hipEvent_t after, int32_t B, double* d_rows, double* out) {
+    GD_REQUIRE(ctx && d_rows && out && B > 0, "bad argument");
+    if (after) GD_HIP(hipStreamWaitEvent(ctx->stream, after, 0));
+    const double* d_neff = d_rows + (int64_t)B * KOPT_STRIDE;
+    const double* d_corr = d_neff + B;
+    const int* d_dc = (const int*)(d_corr + B);
+    k_get_h<<<B, 64, 0, ctx->stream>>>(d_rows, d_neff, d_corr, d_dc, B);
     GD_KERNEL_CHECK();
-    GD_TRY(gd_fetch(ctx, out, d_out, (size_t)B * KOPT_STRIDE * 8));
+    GD_TRY(gd_fetch(ctx, out, d_rows, (size_t)B * KOPT_STRIDE * 8));
     GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
+}
+
+// upload of get_h's inputs behind the rows (on the stream stage A runs on)
+static int kopt_upload_get_h_inputs(gd_ctx* ctx, int32_t B, double* d_rows, const double* neff, const double* corr,
+                                    const int32_t* do_corr) {
+    std::vector<double> tab((size_t)3 * B, 0.0);
+    memcpy(tab.data(), neff, (size_t)B * 8);
+    memcpy(tab.data() + B, corr, (size_t)B * 8);
+    memcpy(tab.data() + 2 * (size_t)B, do_corr, (size_t)B * 4);
+    return gd_h2d(ctx, d_rows + (int64_t)B * KOPT_STRIDE, tab.data(), tab.size() * 8);
+}
+
+int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* neff, const int32_t* do_corr,
+              const double* fallback_t, const double* corr, double* out) {
+    GD_REQUIRE(ctx && d_hist_v && neff && do_corr && fallback_t && corr && out && B > 0, "bad argument");
+    double* d_rows = (double*)gd_scratch2(ctx, (int64_t)B * KOPT_BLOCK_DOUBLES * 8);
+    if (!d_rows) return GD_ERR_NOMEM;
+    GD_TRY(kopt_upload_get_h_inputs(ctx, B, d_rows, neff, corr, do_corr));
+    GD_TRY(kopt_stage_a(ctx, B, F, d_hist_v, neff, do_corr, fallback_t, d_rows));
+    return kopt_stage_b(ctx, nullptr, B, d_rows, out);
+}
+
+int gd_kopt2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
+                      const double* fallback_t, const double* corr, void* d_rows, int32_t* ticket_out) {
+    GD_REQUIRE(ctx && ticket_out && d_rows && neff && corr && do_corr && B > 0, "bad argument");
+    GD_TRY(kopt_upload_get_h_inputs(ctx, B, (double*)d_rows, neff, corr, do_corr));
+    GD_TRY(kopt_stage_a(ctx, B, F, d_hist, neff, do_corr, fallback_t, (double*)d_rows));
+    const int slot = ctx->kopt_ev_next;
+    ctx->kopt_ev_next = (slot + 1) % gd_ctx::kKoptEvents;
+    if (!ctx->kopt_evs[slot]) GD_HIP(hipEventCreateWithFlags(&ctx->kopt_evs[slot], hipEventDisableTiming));
+    GD_HIP(hipEventRecord(ctx->kopt_evs[slot], ctx->stream));
+    *ticket_out = slot;
+    return GD_OK;
+}
+
+int gd_kopt2d_finish(gd_ctx* ctx, gd_ctx* stage_a_ctx, int32_t ticket, int32_t B, void* d_rows, double* out) {
+    GD_REQUIRE(ctx && stage_a_ctx && ticket >= 0 && ticket < gd_ctx::kKoptEvents && stage_a_ctx->kopt_evs[ticket], "bad ticket");
+    GD_HIP(hipSetDevice(ctx->device));
+    return kopt_stage_b(ctx, ctx == stage_a_ctx ? nullptr : stage_a_ctx->kopt_evs[ticket], B, (double*)d_rows, out);
 }
 
 }  // extern "C"

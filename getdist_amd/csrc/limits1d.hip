@@ -248,10 +248,10 @@ int gd_limits1d(gd_ctx* ctx, int32_t B, int32_t F, const double* P, const double
                   o_G = take((int64_t)B * A.bign * 8), o_out = take((int64_t)B * nc * 32), o_st = take((int64_t)B * 4);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(base + o_P, P, (size_t)B * F * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_x, x0, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_s, spacing, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_c, contours, (size_t)nc * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, base + o_P, P, (size_t)B * F * 8));
+    GD_TRY(gd_h2d(ctx, base + o_x, x0, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, base + o_s, spacing, (size_t)B * 8));
+    GD_TRY(gd_h2d(ctx, base + o_c, contours, (size_t)nc * 8));
     GD_HIP(hipFuncSetAttribute((const void*)k_limits1d, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4096 * 8));
     k_limits1d<<<B, LM_T, (size_t)3 * F * 8, ctx->stream>>>((const double*)(base + o_P), (const double*)(base + o_x),
                                                            (const double*)(base + o_s), (const double*)(base + o_c), A,

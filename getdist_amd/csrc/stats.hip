@@ -1220,7 +1220,7 @@ int gd_kde_lag_sums_2d(gd_ctx* ctx, int32_t coli, int32_t colj, const double* ki
     if (!base) return GD_ERR_NOMEM;
     double* part = (double*)base;
     int64_t* d_lags = (int64_t*)(base + o_l);
-    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_lags, lags, (size_t)nlags * 8));
     const double* x = ctx->cols + (int64_t)coli * ctx->ld;
     const double* y = ctx->cols + (int64_t)colj * ctx->ld;
     const dim3 grid(nblk, nlags);
@@ -1320,7 +1320,7 @@ int gd_col_minmax(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, i
     if (!base) return GD_ERR_NOMEM;
     int32_t* d_idx = (int32_t*)base;
     double* d_part = (double*)(base + idx_bytes);
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     dim3 grid(nblk, ncols);
     if (cond_col >= 0)
         k_col_minmax<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->cols + (int64_t)cond_col * ctx->ld,
@@ -1393,7 +1393,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         int32_t* d_idx = (int32_t*)(base + o_idx);
         double* d_cpart = (double*)(base + o_cpart);
         d_cov = (double*)(base + o_cov);
-        GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)m * 4));
         int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
         if (rc) return rc;
 #define GD_COV2(HW, MCAP, NW, NH, PP)                                                                                     \
@@ -1452,8 +1452,8 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     int2* d_tiles = (int2*)(base + o_tiles);
     double* d_cpart = (double*)(base + o_cpart);
     d_cov = (double*)(base + o_cov);
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntp * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)m * 4));
+    GD_TRY(gd_h2d(ctx, d_tiles, tiles.data(), (size_t)ntp * 8));
     int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
     if (rc) return rc;
     dim3 grid(nchunks, ntp);
@@ -1527,9 +1527,9 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     double* d_lw = (double*)(base + o_lw);
     void* d_part = base + o_part;
     double* d_tot = (double*)(base + o_tot);
-    GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_ql, hql.data(), hql.size() * sizeof(QLin), hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_st, hst.data(), hst.size() * sizeof(QState)));
+    GD_TRY(gd_h2d(ctx, d_ql, hql.data(), hql.size() * sizeof(QLin)));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     GD_HIP(hipMemsetAsync(d_cnt, 0, (size_t)ncols * QK_MAX * 4 + 256, ctx->stream));
     const size_t lds = (size_t)nb * (hw ? 8 : 4);
     if (hw) {
@@ -1618,8 +1618,8 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
     int* d_cnt = (int*)(base + o_cnt);
     unsigned long long* d_lk = (unsigned long long*)(base + o_lk);
     double* d_lw = (double*)(base + o_lw);
-    GD_HIP(hipMemcpyAsync(d_st, hst.data(), hst.size() * sizeof(QState), hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_st, hst.data(), hst.size() * sizeof(QState)));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     GD_HIP(hipMemsetAsync(d_h, 0, (size_t)ncols * QK_MAX * 256 * 8, ctx->stream));
     // few blocks per column: every block flushes its private LDS histograms with global atomics on the same
     // per-column bins, so the flush cost (and its contention) grows with the block count
@@ -1700,8 +1700,8 @@ int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols,
     double* d_out = (double*)(base + o_out);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_mean = (double*)(base + o_mean);
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_mean, means, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
+    GD_TRY(gd_h2d(ctx, d_mean, means, (size_t)ncols * 8));
     std::vector<double> h((size_t)ncols * AL);
     for (int32_t done = 0; done < nlags;) {
         const dim3 grid(nblk, ncols);
@@ -1758,9 +1758,9 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     int64_t* d_lags = (int64_t*)(base + o_lags);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_c = (double*)(base + o_c);
-    GD_HIP(hipMemcpyAsync(d_lags, lags, (size_t)nlags * 8, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(d_c, inv4s2, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, d_lags, lags, (size_t)nlags * 8));
+    GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
+    GD_TRY(gd_h2d(ctx, d_c, inv4s2, (size_t)ncols * 8));
     if (multi) {
         const dim3 grid(nblk, ncols);
 #define KDE_LAUNCH(NLV)                                                                                                 \

@@ -236,8 +236,8 @@ int gd_binary_transitions(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     const int64_t o_idx = take((int64_t)ncols * 4), o_thr = take((int64_t)ncols * nthr * 8), o_cnt = take(nc * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(base + o_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_thr, thresholds, (size_t)ncols * nthr * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, base + o_idx, cols, (size_t)ncols * 4));
+    GD_TRY(gd_h2d(ctx, base + o_thr, thresholds, (size_t)ncols * nthr * 8));
     GD_HIP(hipMemsetAsync(base + o_cnt, 0, (size_t)nc * 8, ctx->stream));
     int nblk = (int)((K + 255) / 256);
     if (nblk > 512) nblk = 512;
@@ -267,8 +267,8 @@ int gd_thinned_lag_sums(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const d
     const int64_t o_idx = take((int64_t)ncols * 4), o_mean = take((int64_t)ncols * 8), o_part = take(np * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
-    GD_HIP(hipMemcpyAsync(base + o_idx, cols, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
-    GD_HIP(hipMemcpyAsync(base + o_mean, means, (size_t)ncols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GD_TRY(gd_h2d(ctx, base + o_idx, cols, (size_t)ncols * 4));
+    GD_TRY(gd_h2d(ctx, base + o_mean, means, (size_t)ncols * 8));
     k_thinned_lag<<<dim3(nblk, maxoff, ncols), 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, (const int32_t*)(base + o_idx),
                                                                      (const double*)(base + o_mean), (const int32_t*)d_rows, K,
                                                                      (double*)(base + o_part));

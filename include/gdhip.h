@@ -167,6 +167,13 @@ int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, 
 int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
                      void* const* d_idx_out, int64_t* bad_out);
 int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, void* d_hist);
+/* gd_prebin8_hist2d: both of the above enqueued back to back with ONE wait: first the `ncols` byte index columns that have
+ * to be (re)made (ncols may be 0), then the B histograms over index columns d_idx_x / d_idx_y (which may be among the
+ * columns just made).  bad_out as gd_prebin8_batch; GD_ERR_SOLVER when any sample fell outside the grid or a counter
+ * wrapped -- the histograms are then invalid and the caller takes gd_prebin_batch + gd_hist2d_prebinned. */
+int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+                      void* const* d_idx_out, int64_t* bad_out, int32_t B, const void* const* d_idx_x,
+                      const void* const* d_idx_y, void* d_hist);
 
 /* several index columns in one launch (d_idx_u16[c] receives column cols[c] binned with binmin[c], width[c]) */
 int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
@@ -219,6 +226,19 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
  *   hx, hy are fractions of the histogram's bin range. */
 int gd_kopt2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
               const double* fallback_t, const double* corr, double* out);
+/* The same work in two stream-ordered stages, for callers that keep several launches in flight:
+ *   gd_kopt2d_enqueue: everything up to the functionals (sums, DCT, power spectra, the fixed point) on ctx's stream; returns
+ *     at once.  d_rows: device block of B x GD_KOPT_BLOCK_DOUBLES doubles: the B x 12 result rows
+ *     {t_star, p02, p20, p11, p00, p13, p31, status, ...} followed by get_h's per-pair inputs, which this call uploads.
+ *     *ticket_out identifies the point on ctx's stream behind those kernels (32 tickets are kept).
+ *   gd_kopt2d_finish: get_h (the closed forms and the TNC minimisations) for those rows on `ctx`'s stream -- which may be
+ *     ANOTHER context of the same device than stage_a_ctx: its stream waits for the ticket, so the serial TNC stage of one
+ *     launch runs beside the next launch's DCT / fixed point -- and the finished B x 12 rows in `out` (host).  Blocks
+ *     until they are there. */
+#define GD_KOPT_BLOCK_DOUBLES 15
+int gd_kopt2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
+                      const double* fallback_t, const double* corr, void* d_rows, int32_t* ticket_out);
+int gd_kopt2d_finish(gd_ctx* ctx, gd_ctx* stage_a_ctx, int32_t ticket, int32_t B, void* d_rows, double* out);
 /* gd_get_h: the get_h stage alone, from host arrays: psi is B x 6 = {p02, p20, p11, p00, p13, p31};
  *   out: B x 4 = {hx, hy, corr, status}. */
 int gd_get_h(gd_ctx* ctx, int32_t B, const double* psi, const double* neff, const double* corr, const int32_t* do_corr,

@@ -28,6 +28,7 @@ _OPS = [
     ("dev_free", C.CFUNCTYPE(C.c_int, _p, _p)),
     ("prebin8_batch", C.CFUNCTYPE(C.c_int, _p, _pi32, _i32, _pd, _pd, _i32, _pp, _pi64)),
     ("hist2d_prebinned8", C.CFUNCTYPE(C.c_int, _p, _i32, _pp, _pp, _p)),
+    ("prebin8_hist2d", C.CFUNCTYPE(C.c_int, _p, _pi32, _i32, _pd, _pd, _pp, _pi64, _i32, _pp, _pp, _p)),
     ("prebin", C.CFUNCTYPE(C.c_int, _p, _i32, _f64, _f64, _i32, _p)),
     ("hist2d_prebinned", C.CFUNCTYPE(C.c_int, _p, _i32, _pp, _pp, _i32, _p)),
     ("minmax_affine", C.CFUNCTYPE(C.c_int, _p, _i32, _pi32, _pi32, _pd, _pd, _pd)),
@@ -44,6 +45,10 @@ _OPS = [
     ("kde_lag_sums_batch", C.CFUNCTYPE(C.c_int, _p, _pi32, _i32, _pd, _pi64, _i32, _pd)),
     ("kde_lag_sums", C.CFUNCTYPE(C.c_int, _p, _i32, _f64, _pi64, _i32, _pd)),
     ("last_error", C.CFUNCTYPE(C.c_char_p, _p)),
+    ("create_aux", C.CFUNCTYPE(C.c_int, _p, _pp)),
+    ("destroy_aux", C.CFUNCTYPE(C.c_int, _p)),
+    ("kopt2d_enqueue", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _p, _pi32)),
+    ("kopt2d_finish", C.CFUNCTYPE(C.c_int, _p, _p, _i32, _i32, _p, _pd)),
 ]
 
 
@@ -124,6 +129,13 @@ def _make_ops():
             return -5  # a 16-bit counter would have wrapped
         buf_of(d_hist).a = H
         return 0
+
+    def prebin8_hist2d(h, cols, ncols, binmin, width, d_idx, bad, B, ix, iy, d_hist):
+        if ncols:
+            prebin8_batch(h, cols, ncols, binmin, width, 256, d_idx, bad)
+            if any(bad[q] for q in range(ncols)):
+                return -5
+        return hist2d_prebinned8(h, B, ix, iy, d_hist)
 
     def prebin(h, col, binmin, width, F, d_idx):
         c = ctx_of(h)
@@ -225,6 +237,34 @@ def _make_ops():
     def kde_lag_sums(h, col, inv4s2, lags, nlags, out):
         c = ctx_of(h)
         _arr(out, nlags)[:] = c.kde_lag_sums(col, inv4s2, [lags[q] for q in range(nlags)])
+        return 0
+
+    def create_aux(h, out):
+        aux = HarnessContext(0)
+        aux.attach(ctx_of(h))
+        out[0] = aux.handle
+        return 0
+
+    def destroy_aux(aux):
+        _CTX.pop(int(aux), None)
+        return 0
+
+    def kopt2d_enqueue(h, B, F, d_hist, neff, do_corr, fallback_t, corr, d_rows, ticket):
+        c = ctx_of(h)
+        CALLS.append(("kopt2d_enqueue", c.lane, B, F))
+        H = np.asarray(buf_of(d_hist).a, dtype=np.float64).reshape(-1, F * F)[:B].copy()
+        buf_of(d_rows).a = (H, F, _arr(neff, B).copy(), _arr(do_corr, B, np.int32).copy(), _arr(fallback_t, B).copy(),
+                            _arr(corr, B).copy())
+        ticket[0] = 0
+        return 0
+
+    def kopt2d_finish(h, ha, ticket, B, d_rows, out):
+        c = ctx_of(h)
+        CALLS.append(("kopt2d_finish", c.lane, B))
+        H, F, ne, dc, fb, co = buf_of(d_rows).a
+        o = _arr(out, 12 * B).reshape(B, 12)
+        for q in range(B):
+            o[q] = c.kopt2d_cached(H[q].reshape(F, F), ne[q], dc[q], fb[q], co[q])
         return 0
 
     def last_error(h):

@@ -1,0 +1,133 @@
+"""
+GPU tests of gd_density2d_batch, the one native entry for a batch of parameter pairs (include/gdhip.h; replaces the span
+mcsamples.py:1748-2010 + getAutoBandwidth2D :1285-1419 of the reference for P pairs at once): its grids, bandwidths,
+branches and optimiser records must be `array_equal` to those of the Python-planned route over the same kernels
+(GETDIST_AMD_NATIVE_BATCH=0), for every setting the route serves, at fixture size and on the C3 shape; calls from two
+host threads on two objects sharing a device must not disturb one another.
+"""
+
+import threading
+
+import numpy as np
+import pytest
+
+from getdist_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def both_routes(monkeypatch, build, call):
+    """(native results, Python-planned results) of ``call(mc)`` on two fresh objects."""
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "0")
+    plain = call(build())
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "1")
+    mc = build()
+    native = call(mc)
+    assert mc._pending_results is None or type(mc._pending_results).__name__ == "PendingBatch"
+    return native, plain, mc
+
+
+def same(native, plain):
+    assert len(native) == len(plain)
+    for k, (a, b) in enumerate(zip(native, plain)):
+        assert a.P.shape == b.P.shape, k
+        assert np.array_equal(a.P, b.P), (k, float(np.max(np.abs(a.P - b.P))))
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and a.spacing == b.spacing, k
+        assert a.bandwidth_branch == b.bandwidth_branch and a.bandwidth == b.bandwidth, k
+        assert (a.kopt is None) == (b.kopt is None) and (a.kopt is None or np.array_equal(a.kopt, b.kopt, equal_nan=True)), k
+
+
+def mc_of(recipe):
+    from getdist_amd.mcsamples import MCSamples
+
+    s, w, names, ranges = recipe
+    return MCSamples(samples=s, weights=w, names=names, ranges=ranges)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mult_bias_correction_order=0, boundary_correction_order=0),
+                                dict(boundary_correction_order=-1, mult_bias_correction_order=2), dict(smooth_scale_2D=0.4),
+                                dict(smooth_scale_2D=2.0), dict(fine_bins_2D=128)])
+def test_native_entry_equals_python_planned_route(monkeypatch, kw):
+    recipe = synth.block_recipe(30, 400_000, weighted=False, stream=61)
+    pairs = synth.triangle_pairs(30)
+    native, plain, mc = both_routes(monkeypatch, lambda: mc_of(recipe), lambda m: m.get2DDensities(pairs, **kw))
+    same(native, plain)
+    if not kw:
+        assert {d.bandwidth_branch for d in native} == {"A", "B", "C"} and len({d.P.shape[0] for d in native}) >= 3
+        # a second call on the same object (index columns and N_eff cached) and after an invalidation: same bits
+        same(mc.get2DDensities(pairs), plain)
+        mc.ctx.batch2d_invalidate()
+        same(mc.get2DDensities(pairs[:70]), plain[:70])
+
+
+def test_native_entry_weighted_and_small_calls(monkeypatch):
+    recipe = synth.block_recipe(12, 300_000, weighted=True, stream=62)
+    pairs = synth.triangle_pairs(12)
+    # real weights: the fp64 LDS atomics of the weighted binning kernels add in an order that differs from run to run, so
+    # two runs of ONE route agree to rounding only (and a chaotic TNC pair may amplify that)
+    for sel in (pairs, [(3, 1), (5, 9)]):
+        native, plain, _ = both_routes(monkeypatch, lambda: mc_of(recipe), lambda m: m.get2DDensities(sel))
+        errs = np.array([float(np.max(np.abs(a.P - b.P))) for a, b in zip(native, plain)])
+        assert [a.bandwidth_branch for a in native] == [b.bandwidth_branch for b in plain]
+        assert [a.P.shape for a in native] == [b.P.shape for b in plain]
+        assert np.all(errs < 5e-4) and np.sum(errs >= 1e-9) <= max(1, 0.4 * len(errs)), errs
+    rec_int = list(recipe)
+    rec_int[1] = np.floor(recipe[1] * 3) + 1.0  # integer multiplicities: the byte-weight kernels
+    native, plain, _ = both_routes(monkeypatch, lambda: mc_of(rec_int), lambda m: m.get2DDensities(pairs))
+    same(native, plain)
+
+
+def test_native_entry_contour_levels(monkeypatch):
+    recipe = synth.block_recipe(10, 200_000, weighted=False, stream=63)
+    pairs = synth.triangle_pairs(10)
+    native, plain, _ = both_routes(monkeypatch, lambda: mc_of(recipe),
+                                   lambda m: m.get2DDensities(pairs, get_density=False, num_plot_contours=2))
+    same(native, plain)
+    for a, b in zip(native, plain):  # (the level kernel accumulates masses with fp64 atomics: equal to rounding)
+        assert np.allclose(a.contours, b.contours, rtol=1e-12, atol=0)
+
+
+def test_native_entry_c3_shape(monkeypatch):
+    """The bench's shape: 50 parameters, 1225 pairs (N = 2e6 here; the full row count runs in test_gpu_fullsize.py and in
+    bench.py): the pipelined two-stream route with the optimiser's launch cut in two."""
+    recipe = synth.config_c3(2_000_000, 50)
+    pairs = synth.triangle_pairs(50)
+    native, plain, mc = both_routes(monkeypatch, lambda: mc_of(recipe), lambda m: m.get2DDensities(pairs))
+    same(native, plain)
+    census = {}
+    for d in native:
+        census[(d.bandwidth_branch, d.P.shape[0])] = census.get((d.bandwidth_branch, d.P.shape[0]), 0) + 1
+    assert len(census) >= 6, census
+
+
+def test_two_objects_from_two_threads_share_a_device(monkeypatch):
+    """Two sample sets on one device, each driven from its own host thread (three library threads and two streams
+    each): the grids equal those of the same calls made one after the other."""
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "1")
+    recipes = [synth.block_recipe(20, 300_000, weighted=False, stream=64), synth.block_recipe(20, 250_000, weighted=True, stream=65)]
+    pairs = synth.triangle_pairs(20)
+    serial = [mc_of(r).get2DDensities(pairs) for r in recipes]
+    serial = [[d.P.copy() for d in ds] for ds in serial]
+    objs = [mc_of(r) for r in recipes]
+    out, errs = [None, None], []
+
+    def work(q):
+        try:
+            for _ in range(3):
+                objs[q].ctx.batch2d_invalidate()
+                for p in objs[q].paramNames.names:
+                    p.N_eff_kde = None
+                out[q] = objs[q].get2DDensities(pairs)
+                out[q][-1].P
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(q,)) for q in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for q in (0, 1):
+        for d, ref in zip(out[q], serial[q]):
+            assert np.array_equal(d.P, ref)

@@ -104,11 +104,15 @@ def test_native_route_large_call_two_streams_pipelined(zoo):
     same(native, plain)
     lanes = {c[1] for c in nb.CALLS if c[0] == "density2d_enqueue"}
     assert len(lanes) == 2, "the convolution used one stream only"
-    assert sum(1 for c in nb.CALLS if c[0] == "kopt2d") >= 2
+    assert sum(1 for c in nb.CALLS if c[0] == "kopt2d_enqueue") >= 2 and not any(c[0] == "kopt2d" for c in nb.CALLS)
     main, twin = mc.ctx.lane, mc._twin.ctx.lane
-    # N_eff on the first context, the base grid's binning on the second
-    assert all(c[1] == main for c in nb.CALLS if c[0] in ("kde_lag_sums_batch", "autocov_lags_batch", "hist2d_sheared", "kopt2d"))
+    aux = {c[1] for c in nb.CALLS if c[0] == "kopt2d_finish"}
+    assert len(aux) == 1 and not aux & {main, twin}
+    # N_eff and the optimiser's stage A on the first context, the base grid's binning on the second, the shear chain and
+    # get_h on the third
+    assert all(c[1] == main for c in nb.CALLS if c[0] in ("kde_lag_sums_batch", "autocov_lags_batch", "kopt2d_enqueue"))
     assert all(c[1] == twin for c in nb.CALLS if c[0] in ("prebin8_batch", "hist2d_prebinned8", "hist2d_prebinned"))
+    assert all(c[1] in aux for c in nb.CALLS if c[0] in ("minmax_affine", "hist2d_sheared"))
     assert any(c[0] == "hist2d_prebinned8" for c in nb.CALLS)
     assert [p.N_eff_kde for p in mc.paramNames.names[:13]] == [p.N_eff_kde for p in ref.paramNames.names[:13]]
 
