@@ -140,8 +140,9 @@ def prepare_replay(mc, W):
     _REPLAY["moments"] = {W: [mc._partial_moments(min(r * per, mc.numrows), min((r + 1) * per, mc.numrows)) for r in range(W)]}
 
 
-def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
-    """The timed unit of work.  Returns the list of Density2D this rank produced."""
+def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0, comm=None):
+    """The timed unit of work.  Returns the list of Density2D this rank produced.  ``comm``: a parallel.LibraryComm (RCCL
+    through the C ABI) carries the step's three small exchanges instead of torch.distributed."""
     from getdist_amd import parallel
 
     t_step0 = time.perf_counter()
@@ -152,7 +153,7 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
         if emulate:
             mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: [mine] + _REPLAY["moments"][world][1:])
         else:
-            mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: parallel.allgather_vector(mine, dist, torch_device))
+            mc.updateBaseStatistics(row_share=(rank, world), exchange=lambda mine: parallel.allgather_vector(mine, dist, torch_device, comm))
     else:
         mc.updateBaseStatistics()  # means, variances, covariance, weight statistics; clears every per-parameter cache
     _hostlog("step: base statistics done")
@@ -173,10 +174,10 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
             for j, v in zip(others, neff.tolist()):
                 mc_.paramNames.names[j].N_eff_kde = v
     else:
-        parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device)
+        parallel.allgather_param_state(mc, my_params, mc.n, dist if world > 1 else None, torch_device, comm if world > 1 else None)
 
         def exchange(mc_):
-            parallel.allgather_neff(mc_, my_params, mc_.n, dist, torch_device)
+            parallel.allgather_neff(mc_, my_params, mc_.n, dist, torch_device, comm)
     _hostlog("step: parameter state exchanged")
     t_part0 = time.perf_counter()
     _pair_index(pairs_all)
@@ -186,6 +187,7 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0):
         mine, _ = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
         my_pairs = _PAIR_INDEX["array"][mine]
         mc._neff_share = parallel.NeffShare(my_params, exchange)
+        mc._neff_share.library_comm = comm is not None and not emulate
     if mc._timing:
         mc.timings["step.partition"] = mc.timings.get("step.partition", 0.0) + time.perf_counter() - t_part0
     _hostlog("step: pairs dealt")
@@ -596,6 +598,13 @@ def main():
     mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=local_rank, **extra)
     t_ctor = time.perf_counter() - t0
     pairs_all = synth.triangle_pairs(args.nparams)
+    comm = None
+    if dist is not None and args.backend == "nccl" and os.environ.get("GETDIST_AMD_COMM", "lib") == "lib":
+        # the step's collectives through the C ABI: RCCL on the library's own stream (torch.distributed only carries the
+        # 128-byte id at start-up, and the barriers / the max over ranks around the timed region)
+        from getdist_amd import parallel
+
+        comm = parallel.init_library_comm(mc.ctx, dist, rank, world)
 
     def barrier():
         mc.ctx.sync()
@@ -611,7 +620,7 @@ def main():
         prepare_replay(mc, args.emulate_world)
     dens = None
     for _ in range(args.warmup):
-        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)  # held like the timed results
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world, comm)  # held like the timed results
     if args.warmup > 0:
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
         if getattr(mc, "_twin", None) is not None:
@@ -637,7 +646,7 @@ def main():
     t0 = time.perf_counter()
     step_returned = []
     for _ in range(args.steps):
-        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world)
+        dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world, comm)
         step_returned.append(time.perf_counter())
     if dens:
         dens[-1].P  # first read of a grid: waits for this step's copies and checks every grid's status
@@ -694,6 +703,8 @@ def main():
         if dist is not None:
             line["ranks"] = world
             line["backend"] = "%s%s" % (args.backend, " (RCCL)" if args.backend == "nccl" else "")
+            line["collectives"] = ("libgdhip gd_comm_* (ncclAllGather / ncclAllReduce on the library's stream)" if comm is not None
+                                   else "torch.distributed")
             line["ms_per_step_by_rank"] = [round(v, 3) for v in per_rank_ms]
         if args.emulate_world:
             line["emulated_world"] = args.emulate_world

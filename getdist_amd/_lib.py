@@ -121,6 +121,14 @@ SIGNATURES = {
     "gd_batch2d_grid_sizes": (C.c_int, [_p, _i32, _pd, _pi32, _i32, _pi32]),
     "gd_density2d_batch": (C.c_int, [_p, _p, _p, _p, _i32, _pd, _pd, _pd, _pi32, _i32, _p, _p, _p, _i64, _pi32, _pd, _pd, _pi32,
                                      _pi32]),
+    "gd_comm_unique_id": (C.c_int, [_p]),
+    "gd_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
+    "gd_comm_info": (C.c_int, [_p, _pi32, _pi32]),
+    "gd_comm_destroy": (C.c_int, [_p]),
+    "gd_comm_allgather": (C.c_int, [_p, _pd, _i64, _pd]),
+    "gd_comm_allreduce_sum": (C.c_int, [_p, _pd, _i64]),
+    "gd_comm_allgather_dev": (C.c_int, [_p, _p, _i64, _p]),
+    "gd_comm_allreduce_sum_dev": (C.c_int, [_p, _p, _i64, _p]),
     "gd_batch2d_finish": (C.c_int, [_p]),
     "gd_batch2d_invalidate": (C.c_int, [_p]),
 }
@@ -217,6 +225,7 @@ class Context:
         self._pinned = []  # (ptr, nbytes, ctypes buffer): page-locked result buffers, recycled when unreferenced
         self._free_blocks = []  # (device ptr, capacity) returned by DevBuf.free(), reused by alloc()
         self._pinned_blocks = []
+        self.comm_world = self.comm_rank = 0
 
     PINNED_POOL_LIMIT = 8 << 30
 
@@ -757,6 +766,35 @@ class Context:
             status.ctypes.data_as(_pi32), _dp(meta), None if levels is None else _dp(levels),
             None if level_status is None else _ip(level_status), _ip(tokens)))
         return int(tokens[0]), int(tokens[1])
+
+    # ---- RCCL communicator of a multi-GPU job (one process per GPU)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load_library().gd_comm_unique_id(buf)
+        if rc != 0:
+            raise GdhipError(rc, "gd_comm_unique_id failed (librccl.so missing?)")
+        return buf.raw
+
+    def comm_init(self, world, rank, id128):
+        self._check(self.lib.gd_comm_init(self.h, int(world), int(rank), C.create_string_buffer(bytes(id128), 128)))
+        self.comm_world, self.comm_rank = int(world), int(rank)
+
+    def comm_allgather(self, vec):
+        """(world, len(vec)) array: every rank's vector, through ncclAllGather on the context's stream."""
+        v = _f64arr(vec).ravel()
+        out = np.empty((self.comm_world, v.size))
+        self._check(self.lib.gd_comm_allgather(self.h, _dp(v), v.size, _dp(out)))
+        return out
+
+    def comm_allreduce_sum(self, vec):
+        v = _f64arr(vec).ravel().copy()
+        self._check(self.lib.gd_comm_allreduce_sum(self.h, _dp(v), v.size))
+        return v
+
+    def comm_destroy(self):
+        self._check(self.lib.gd_comm_destroy(self.h))
+        self.comm_world = 0
 
     def batch2d_finish(self):
         self._check(self.lib.gd_batch2d_finish(self.h))

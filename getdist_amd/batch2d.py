@@ -38,7 +38,7 @@ class BatchSettings(C.Structure):
                 ("want_levels", C.c_int32), ("ncontours", C.c_int32), ("contours", C.POINTER(C.c_double)),
                 ("two_streams_min", C.c_int32), ("two_streams_split", C.c_int32), ("kopt_split_min", C.c_int32),
                 ("kopt_first_fraction", C.c_double), ("first_batch", C.c_int32), ("max_batch", C.c_int32),
-                ("max_batch_bytes", C.c_double)]
+                ("max_batch_bytes", C.c_double), ("comm_exchange", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
@@ -162,7 +162,9 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
     if not get_density:
         levels, level_status = np.zeros((max(P, 1), len(contours))), np.zeros(max(P, 1), dtype=np.int32)
     cb = None
-    if share is not None and not share.exchanged:
+    library_exchange = share is not None and not share.exchanged and getattr(share, "library_comm", False)
+    settings.comm_exchange = int(library_exchange)
+    if share is not None and not share.exchanged and not library_exchange:
         def exchange(user, neff_ptr, n):
             try:
                 v = np.ctypeslib.as_array(neff_ptr, shape=(n,))
@@ -194,6 +196,7 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
                 # parameters, so the second call finds them
                 mc._neff_batch(used)
                 cb = None if share is None or share.exchanged else cb
+                settings.comm_exchange = int(library_exchange and not share.exchanged)
                 continue
             msg = str(e)
             if "bias not positive definite" in msg:
@@ -203,7 +206,9 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
             if e.code == -1:
                 raise M.SettingError(msg.split(": ", 1)[-1])
             raise
-    for j in used:
+    if settings.comm_exchange:
+        share.exchanged = True  # (the library entered the collective)
+    for j in (range(mc.n) if share is not None else used):
         if names[j].N_eff_kde is None and not np.isnan(params[j].neff):
             names[j].N_eff_kde = float(params[j].neff)
     warn = meta[:P, 22].astype(np.int64)

@@ -112,6 +112,8 @@ const gdb::Ops kOps = {
     [](void* h, void* stage_a_h, int32_t ticket, int32_t B, void* d_rows, double* out) {
         return gd_kopt2d_finish(C(h), C(stage_a_h), ticket, B, d_rows, out);
     },
+    /* comm_world */ [](void* h) { return C(h)->comm ? C(h)->comm_world : 0; },
+    /* comm_allreduce_sum */ [](void* h, double* inout, int64_t count) { return gd_comm_allreduce_sum(C(h), inout, count); },
 };
 
 void release_state(gd_ctx* ctx, bool destroy) {

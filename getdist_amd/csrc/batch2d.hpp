@@ -78,6 +78,9 @@ struct Ops {
     int (*kopt2d_enqueue)(void* h, int32_t B, int32_t F, const void* d_hist, const double* neff, const int32_t* do_corr,
                           const double* fallback_t, const double* corr, void* d_rows, int32_t* ticket);
     int (*kopt2d_finish)(void* h, void* stage_a_h, int32_t ticket, int32_t B, void* d_rows, double* out);
+    // the context's communicator (gd_comm_init): number of ranks (0: none) / sum all-reduce of a host vector
+    int (*comm_world)(void* h);
+    int (*comm_allreduce_sum)(void* h, double* inout, int64_t count);
 };
 
 // ---- numpy / CPython scalar semantics --------------------------------------------------------------------------------
@@ -621,6 +624,17 @@ struct Call {
             if (exchange(exchange_user, v.data(), n)) return fail(GD_ERR_HIP, "N_eff exchange failed");
             for (int j = 0; j < n; ++j)
                 if (isnan(par[j].neff)) par[j].neff = v[j];
+        } else if (!exchange && s.comm_exchange && !*exchanged) {
+            // the library's own exchange: every parameter is owned by exactly one rank, so a sum all-reduce of the owners'
+            // values (zero elsewhere) delivers all of them; one collective per call on every rank, whatever its share needs
+            *exchanged = true;
+            if (!ops.comm_world || ops.comm_world(h) < 1) return fail(GD_ERR_BADARG, "comm_exchange without a communicator (gd_comm_init)");
+            std::vector<double> v(n, 0.0);
+            for (int j = 0; j < n; ++j)
+                if (par[j].owned && !isnan(par[j].neff)) v[j] = par[j].neff;
+            GDB_DEV(h, ops.comm_allreduce_sum(h, v.data(), n));
+            for (int j = 0; j < n; ++j)
+                if (isnan(par[j].neff) && v[j] > 0) par[j].neff = v[j];
         }
         return 0;
     }

@@ -199,6 +199,7 @@ void gd_destroy(gd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->batch_state_release) ctx->batch_state_release(ctx, true);
+    gd_comm_release(ctx);
     {
         std::lock_guard<std::mutex> g(g_live_mu);
         g_live.erase(ctx);

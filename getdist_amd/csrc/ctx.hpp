@@ -79,6 +79,11 @@ struct gd_ctx {
     static constexpr int kKoptEvents = 32;
     hipEvent_t kopt_evs[kKoptEvents] = {};
     int kopt_ev_next = 0;
+    // RCCL communicator of a multi-GPU job (comm.hip) and its staging block
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    void* comm_buf = nullptr;
+    size_t comm_buf_bytes = 0;
     // gd_density2d_batch (batch2d.hip): device-block pool, cached index columns and the last call's blocks in flight
     void* batch_state = nullptr;
     void (*batch_state_release)(gd_ctx*, bool destroy) = nullptr;
@@ -106,6 +111,7 @@ int gd_fetch_pinned(gd_ctx* ctx, void* pinned_dst, const void* d_src, size_t byt
 int gd_stream_sync(gd_ctx* ctx);
 
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
+void gd_comm_release(gd_ctx* ctx);  // comm.hip
 bool gd_ctx_alive(gd_ctx* ctx);
 int gd_stream_priority(gd_ctx* ctx, int high);  // re-create the (idle) compute stream with high / normal priority  // false once gd_destroy has run on it (core.hip)
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure

@@ -48,6 +48,7 @@ class NeffShare:
         self.params = set(params)
         self.exchange = exchange
         self.exchanged = False  # the collective is entered exactly once per step (complete())
+        self.library_comm = False  # True: gd_density2d_batch exchanges the values itself over the context's communicator
 
     def complete(self, mc):
         """Enter the exchange if the step has not done so yet (a rank without pairs, a call with a fixed smoothing scale,
@@ -57,9 +58,50 @@ class NeffShare:
             self.exchange(mc)
 
 
-def allgather_neff(mc, my_js, n_params, dist=None, device=None):
-    """The second, small exchange of a step: N_eff_kde of the parameters each rank owns (one (index, value) row each)."""
+class LibraryComm:
+    """
+    The collectives of a step through the C ABI (gd_comm_* in include/gdhip.h: RCCL on the context's own stream, device
+    buffers inside the library) instead of torch.distributed.  The 128-byte RCCL id travels once, at start-up, by whatever
+    the host application has -- here torch.distributed's broadcast.
+    """
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    @property
+    def world(self):
+        return self.ctx.comm_world
+
+    def allgather(self, vec):
+        return self.ctx.comm_allgather(vec)
+
+    def allreduce_sum(self, vec):
+        return self.ctx.comm_allreduce_sum(vec)
+
+
+def init_library_comm(ctx, dist, rank, world):
+    """Rank 0 makes the RCCL id, every rank joins (collective).  Returns a LibraryComm."""
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(world, rank, box[0])
+    return LibraryComm(ctx)
+
+
+def allgather_neff(mc, my_js, n_params, dist=None, device=None, comm=None):
+    """The second, small exchange of a step: N_eff_kde of the parameters each rank owns.  With a library communicator:
+    ONE sum all-reduce of n doubles (a rank contributes the values it owns, zero elsewhere) -- the same collective
+    gd_density2d_batch issues when it exchanges them itself, so ranks may mix the two routes."""
     names = mc.paramNames.names
+    if comm is not None:
+        v = np.zeros(n_params)
+        for j in my_js:
+            if names[j].N_eff_kde is not None:
+                v[j] = float(names[j].N_eff_kde)
+        out = comm.allreduce_sum(v)
+        for j in np.nonzero(out > 0)[0].tolist():
+            if names[j].N_eff_kde is None:
+                names[j].N_eff_kde = float(out[j])
+        return
     mine = np.array([[j, np.nan if names[j].N_eff_kde is None else float(names[j].N_eff_kde)] for j in my_js]).reshape(-1, 2)
     if dist is None or dist.get_world_size() == 1:
         return
@@ -105,11 +147,20 @@ def unpack_param_state(mc, rows):
         par._ranges_done = True
 
 
-def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
+def allgather_param_state(mc, my_js, n_params, dist=None, device=None, comm=None):
     """
     All-gather the prepared per-parameter scalars so every rank knows every parameter.
-    ``dist`` is torch.distributed (initialised) or None for single-process runs.
+    ``dist`` is torch.distributed (initialised) or None for single-process runs; ``comm`` a LibraryComm (RCCL through
+    the C ABI) takes precedence.
     """
+    if comm is not None:
+        mine = pack_param_state(mc, my_js)
+        per = (n_params + comm.world - 1) // comm.world
+        buf = np.full((per, mine.shape[1]), -1.0)
+        buf[:len(mine)] = mine
+        rows = comm.allgather(buf.ravel()).reshape(-1, mine.shape[1])
+        unpack_param_state(mc, rows[rows[:, 0] >= 0])
+        return
     if dist is None or dist.get_world_size() == 1:
         return  # one rank prepared every parameter: nothing to exchange
     mine = pack_param_state(mc, my_js)
@@ -128,11 +179,13 @@ def allgather_param_state(mc, my_js, n_params, dist=None, device=None):
     unpack_param_state(mc, rows[rows[:, 0] >= 0])
 
 
-def allgather_vector(vec, dist=None, device=None):
+def allgather_vector(vec, dist=None, device=None, comm=None):
     """All-gather one equal-length fp64 vector per rank -> list of numpy vectors.  Every rank must pass a vector of the
     same length (a rank with nothing to contribute passes its neutral element, see updateBaseStatistics)."""
     if vec is None:
         raise ValueError("allgather_vector: every rank contributes a vector of the common length")
+    if comm is not None:
+        return list(comm.allgather(np.ascontiguousarray(vec, dtype=np.float64)))
     if dist is None or dist.get_world_size() == 1:
         return [vec]
     import torch

@@ -422,7 +422,8 @@ int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8);
  * pairs  : P x 2 column indices (x, y).
  * exchange : optional; called exactly once per call, on the calling thread, after this rank's own N_eff kernels are
  *          through: it receives the n-vector of N_eff values (NaN = unknown here) and fills in the other ranks' values
- *          (an all-gather); return non-zero to abort.  NULL with a communicator on the context (gd_comm_init) uses RCCL.
+ *          (an all-gather); return non-zero to abort.  NULL with settings->comm_exchange and a communicator on the context
+ *          (gd_comm_init): the library exchanges them itself (ncclAllReduce on the context's stream).
  * grids_pinned : page-locked block of >= sum F_k^2 doubles (F_k from gd_batch2d_grid_sizes); pair k's grid lands at
  *          meta[k][1] doubles from its start, F x F row-major, [y][x].
  * status_pinned : P int32, page-locked; after the copies have landed status_pinned[(int)meta[k][30]] is GD_OK or
@@ -466,6 +467,9 @@ typedef struct gd_batch2d_settings {
     double kopt_first_fraction;         /* (0.5) */
     int32_t first_batch, max_batch;     /* (128, 320) grids in the first / in every further convolution batch */
     double max_batch_bytes;             /* (24e9) device scratch a batch may take */
+    int32_t comm_exchange;              /* 1: exchange the N_eff values over the context's communicator (gd_comm_init): one
+                                           sum all-reduce of n doubles, every rank contributing the parameters it owns */
+    int32_t reserved;
 } gd_batch2d_settings;
 
 typedef int (*gd_neff_exchange_fn)(void* user, double* neff_n, int32_t n);
@@ -483,6 +487,28 @@ int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* set
  * again -- what a benchmark does between steps, and what gd_upload does by itself). */
 int gd_batch2d_finish(gd_ctx* ctx);
 int gd_batch2d_invalidate(gd_ctx* ctx);
+
+
+/* ---------------------------------------------------------------- multi-GPU: RCCL over xGMI ------------------------
+ * One process per GPU.  The path has no data-path collective: pairs are partitioned and every rank copies
+ * its own grids to its host.  What is exchanged are small per-rank vectors -- the partial moments of a row share
+ * (chains.py:709-733 pooled over ranks), the per-parameter state _initParam leaves (mcsamples.py:1421-1484; ~12 doubles
+ * per parameter) and the N_eff values (one double per parameter) -- by ALL-GATHER, and additive partial tables
+ * (histograms, bucket counts: chains.py:793-838, mcsamples.py:1486-1498,1724-1728) by SUM ALL-REDUCE.
+ * gd_comm_unique_id: rank 0 obtains the 128-byte RCCL id and hands it to the other ranks by whatever means the host
+ *   application has (torch.distributed's store, MPI, a file); gd_comm_init: every rank then joins with it (collective).
+ * gd_comm_allgather: recv[r * count ..] = rank r's `send` (host vectors; staged through the context's device block, the
+ *   collective itself runs on device memory on the context's stream: ncclAllGather).  gd_comm_allreduce_sum likewise.
+ * The *_dev forms take device pointers and return once enqueued on the context's stream.
+ * With a communicator on the context gd_density2d_batch exchanges the N_eff values itself when `exchange` is NULL. */
+int gd_comm_unique_id(void* id128_out);
+int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128);
+int gd_comm_info(gd_ctx* ctx, int32_t* world_out, int32_t* rank_out);
+int gd_comm_destroy(gd_ctx* ctx);
+int gd_comm_allgather(gd_ctx* ctx, const double* send, int64_t count, double* recv);
+int gd_comm_allreduce_sum(gd_ctx* ctx, double* inout, int64_t count);
+int gd_comm_allgather_dev(gd_ctx* ctx, const void* d_send, int64_t count, void* d_recv);
+int gd_comm_allreduce_sum_dev(gd_ctx* ctx, const void* d_send, int64_t count, void* d_recv);
 
 #ifdef __cplusplus
 }

@@ -35,5 +35,23 @@ dist.barrier()
 torch.cuda.synchronize()
 d2 = mc.get2DDensities(synth.triangle_pairs(12))
 assert all(np.array_equal(a.P, b.P) for a, b in zip(d1, d2))
+# RCCL through the C ABI (gd_comm_*): a single-rank communicator made from an id that travelled through torch.distributed,
+# the two collectives on the library's stream, and a batched call that exchanges its N_eff values over it
+from getdist_amd import parallel
+
+comm = parallel.init_library_comm(mc.ctx, dist, 0, 1)
+v = np.arange(12, dtype=np.float64) * 1.5
+assert comm.world == 1 and np.array_equal(comm.allgather(v), v[None, :]) and np.array_equal(comm.allreduce_sum(v), v)
+for p in mc.paramNames.names:
+    p.N_eff_kde = None
+mc.ctx.batch2d_invalidate()
+share = parallel.NeffShare(list(range(mc.n)), lambda mc_: parallel.allgather_neff(mc_, list(range(mc_.n)), mc_.n, comm=comm))
+share.library_comm = True
+mc._neff_share = share
+d3 = mc.get2DDensities(synth.triangle_pairs(12))
+mc._neff_share = None
+assert share.exchanged and all(np.array_equal(a.P, b.P) for a, b in zip(d1, d3))
+parallel.allgather_param_state(mc, list(range(mc.n)), mc.n, comm=comm)
+mc.ctx.comm_destroy()
 dist.destroy_process_group()
-print("nccl smoke ok: torch %s, %d densities twice, bit-equal" % (torch.__version__, len(d1)))
+print("nccl smoke ok (torch.distributed + gd_comm_*): torch %s, %d densities three times, bit-equal" % (torch.__version__, len(d1)))

@@ -49,6 +49,8 @@ _OPS = [
     ("destroy_aux", C.CFUNCTYPE(C.c_int, _p)),
     ("kopt2d_enqueue", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _p, _pi32)),
     ("kopt2d_finish", C.CFUNCTYPE(C.c_int, _p, _p, _i32, _i32, _p, _pd)),
+    ("comm_world", C.CFUNCTYPE(C.c_int, _p)),
+    ("comm_allreduce_sum", C.CFUNCTYPE(C.c_int, _p, _pd, _i64)),
 ]
 
 
@@ -265,6 +267,15 @@ def _make_ops():
         o = _arr(out, 12 * B).reshape(B, 12)
         for q in range(B):
             o[q] = c.kopt2d_cached(H[q].reshape(F, F), ne[q], dc[q], fb[q], co[q])
+        return 0
+
+    def comm_world(h):
+        return getattr(ctx_of(h), "comm_world", 0)
+
+    def comm_allreduce_sum(h, inout, count):
+        c = ctx_of(h)
+        v = _arr(inout, count)
+        v[:] = c.comm_allreduce_sum(v.copy())
         return 0
 
     def last_error(h):

@@ -109,7 +109,7 @@ def _write_parity_report():
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r03_parity_2d.json"), "w") as f:
+    with open(os.path.join(out, "r04_parity_2d.json"), "w") as f:
         json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
 
 

@@ -215,6 +215,20 @@ def test_weighted_full_size_properties():
     assert all(x.P.max() == 1.0 for x in d)
     d2 = mc.get2DDensities(pairs)
     assert all(x.P.max() == 1.0 and x.P.shape == (F, F) for x in d2)
+    # ... and the finished real-weight 2D grids at full size against the oracle (mcsamples.py:1728: np.bincount with
+    # weights, then the whole density path), 1e-6 or the oracle-ensemble criterion for a chaotic TNC pair
+    import golden_util as gu
+    from oracle import kde_oracle as ko
+
+    for (a, b), dd in zip(pairs, d2):
+        orc = ko.OracleSamples(s[:, [a, b]], w, names=[names[a], names[b]], ranges={k: v for k, v in ranges.items() if k in (names[a], names[b])})
+        for k in (0, 1):
+            orc.init_param(k)
+            orc.pars[k].N_eff_kde = par[(a, b)[k]].N_eff_kde  # (checked to 1e-9 elsewhere; its FFT route costs ~10 s per column here)
+        tr = {}
+        o = orc.density_2d(0, 1, trace=tr)
+        err, loose = gu.assert_grid_or_oracle_ensemble(dd, o, tr, "weighted %s-%s" % (names[a], names[b]))
+        _report("weighted_2d_full_size_%d_%d" % (a, b), dict(max_abs_dP=err, loose=loose, N=N_FULL))
 
 
 def test_full_size_grids_match_the_oracle(big):
@@ -298,7 +312,7 @@ def _report(key, value):
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "r03_configs.json")
+    path = os.path.join(out, "r04_configs.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[key] = value
     with open(path, "w") as f:

@@ -184,6 +184,48 @@ def test_native_exchange_is_unconditional_and_owned_parameters_only(zoo):
     assert mc3.get2DDensities([]) == [] and len(calls) == 1
 
 
+def test_native_exchange_over_the_library_communicator(zoo):
+    """settings.comm_exchange: the entry exchanges the N_eff values itself -- one sum all-reduce of n doubles, this rank
+    contributing the parameters it owns -- and parallel.allgather_neff(comm=...) issues the very same collective, so a
+    rank on the Python route and a rank on the native route meet in it."""
+    from getdist_amd import parallel
+
+    fx = zoo["block50"]
+    pairs = triangle(8)
+    ref = make(fx, nb.PlainContext)
+    plain = ref.get2DDensities(pairs)
+    truth = np.array([0.0 if p.N_eff_kde is None else p.N_eff_kde for p in ref.paramNames.names])
+    mc = make(fx, nb.HarnessContext)
+    seen = []
+
+    def allreduce(v):  # the other rank owns 1, 3, 5, 7
+        seen.append(v.copy())
+        other = np.zeros_like(v)
+        other[[1, 3, 5, 7]] = truth[[1, 3, 5, 7]]
+        return v + other
+
+    mc.ctx.comm_world, mc.ctx.comm_allreduce_sum = 2, allreduce
+    share = parallel.NeffShare([0, 2, 4, 6], lambda mc_: (_ for _ in ()).throw(AssertionError("the Python exchange was used")))
+    share.library_comm = True
+    mc._neff_share = share
+    native = mc.get2DDensities(pairs)
+    assert len(seen) == 1 and share.exchanged and len(seen[0]) == mc.n
+    assert np.all(seen[0][[0, 2, 4, 6]] == truth[[0, 2, 4, 6]]) and np.all(seen[0][[1, 3, 5, 7]] == 0)
+    same(native, plain)
+    # the Python-level form of the same collective
+    mc2 = make(fx, nb.PlainContext)
+    for j in (0, 2):
+        mc2.paramNames.names[j].N_eff_kde = truth[j]
+    seen.clear()
+
+    class Comm:
+        world = 2
+        allreduce_sum = staticmethod(allreduce)
+
+    parallel.allgather_neff(mc2, [0, 2, 4], mc2.n, comm=Comm())
+    assert len(seen) == 1 and seen[0][0] == truth[0] and seen[0][4] == 0 and mc2.paramNames.names[3].N_eff_kde == truth[3]
+
+
 def test_native_route_correlated_chain_falls_back_to_the_long_route():
     """A chain whose correlation outlasts the 8-lag probe: the entry asks for that N_eff (GD_BATCH2D_NEED_NEFF), the host
     computes it by getCorrelationLength's long route, the second call succeeds; same grids as the Python-planned route."""
@@ -210,4 +252,4 @@ def test_grid_sizes_entry(zoo):
     s = batch2d.settings_of(mc, mc.fine_bins_2D, 1, 1, -1.0, False, None)
     F = mc.ctx.batch2d_grid_sizes(s, mc.n, np.ascontiguousarray(mc.getCorrelationMatrix()), np.asarray(fx["pairs"], dtype=np.int32))
     assert F.tolist() == [d.P.shape[0] for d in dens]
-    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 112
+    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 120
