@@ -204,6 +204,53 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0, comm=Non
 
 
 # ---- roofline of the batched 2D binning kernel ------------------------------------------------------------------------
+def live_counter_traffic(mc, npairs, kernel):
+    """
+    HBM bytes per launch of the roofline kernel measured IN THIS RUN: two separate `rocprofv3 --kernel-trace --pmc` passes
+    (FETCH_SIZE, then WRITE_SIZE: MI355X_MICROARCH.md -- one counter group per pass, never together with the tracing
+    domains) over scripts/pmc_hist2d.py --only-u8, which launches the kernel on this very configuration.  bytes =
+    FETCH_SIZE (KiB) x 2 (gfx950 tallies 128-byte requests at 64 B for 16-byte-per-lane streams) x 1024 + WRITE_SIZE x 1024.
+    None when rocprofv3 is not on the box, a pass fails or times out: the caller falls back to the tracked counter file.
+    """
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    want = kernel.split(" ")[0]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="gdamd_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "h", "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "pmc_hist2d.py"), "--only-u8", "--nsamples=%d" % mc.numrows, "--nparams=%d" % mc.n]
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=240)
+            if r.returncode != 0:
+                return None
+            got = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Kernel_Name"].split("(")[0].replace("void ", "").startswith(want) and row["Counter_Name"] == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None
+            vals[counter] = sum(got) / len(got)
+    except Exception:  # a profiler problem must not cost the bench line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                     "scripts/pmc_hist2d.py --only-u8; FETCH_SIZE %.0f KiB x 2 + WRITE_SIZE %.0f KiB per %d-pair launch"
+                     % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], npairs))
+
+
 def binning_kernel_roofline(mc, pairs_all, reps=5):
     """
     The O(N) kernel the path is built around -- the batched 2D binning of every base-grid pair (k_hist2d_u16) -- timed
@@ -252,12 +299,15 @@ def binning_kernel_roofline(mc, pairs_all, reps=5):
     model_bytes = len(sel) * ((24.0 if weighted else 16.0) * mc.numrows + 8.0 * F * F)
     traffic = None
     source = "none"
-    if os.path.exists(PMC_FILE):
+    live = live_counter_traffic(mc, len(sel), kernel) if (use_u8 and not weighted and os.environ.get("GETDIST_AMD_LIVE_PMC", "1") == "1") else None
+    if live is not None:
+        traffic, source = live
+    elif os.path.exists(PMC_FILE):
         pmc = json.load(open(PMC_FILE))
         if (pmc.get("N") == mc.numrows and pmc.get("n") == mc.n and pmc.get("F") == F and bool(pmc.get("weighted")) == weighted
                 and pmc.get("pairs") and pmc.get("kernel", "").split(" ")[0].split("<")[0].replace("_pf", "") == kernel.split(" ")[0].replace("_pf", "")):
             traffic = float(pmc["hbm_bytes_per_launch"]) * len(sel) / pmc["pairs"]
-            source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled by pairs)" % os.path.basename(PMC_FILE)
+            source = "TRACKED FILE (no live counter pass in this run) profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled by pairs)" % os.path.basename(PMC_FILE)
     frac_model = model_bytes / t / 1e9 / HBM_PEAK_GBS
     if traffic is not None:
         achieved = traffic / t / 1e9

@@ -10,6 +10,7 @@ import ctypes as C
 import functools
 import logging
 import threading
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -72,6 +73,93 @@ class PendingBatch:
         self.wait()
         if k in self.failed:
             raise DensitiesError("no samples in bin")
+
+
+class DensityBatch(Sequence):
+    """
+    The results of one native batched call: a sequence of Density2D that are made when they are first asked for.  The
+    grids are views of the call's page-locked block (filled by the copy streams while the caller goes on), the axes, the
+    bandwidth records and the contour levels come from the call's per-pair table; building 1225 result objects costs a few
+    milliseconds of interpreter time, which a caller that loops over batched calls would otherwise spend between the last
+    enqueue of one call and the first launch of the next.
+    """
+
+    def __init__(self, mc, pairs32, F_v, meta, grids, completion, levels, level_status, contours, auto):
+        self._names = mc.paramNames.names
+        self._view = [(getattr(p, "range_min", None), getattr(p, "range_max", None)) for p in self._names]  # as of this call
+        self._all_contours = mc.contours
+        self._n = mc.n
+        self._pairs, self._F, self._meta, self._grids = pairs32, F_v, meta, grids
+        self._completion, self._levels, self._level_status, self._contours, self._auto = completion, levels, level_status, contours, auto
+        self._items = [None] * len(pairs32)
+        self._ax = None
+
+    def __len__(self):
+        return len(self._items)
+
+    def _axes(self):
+        """The grid axes of every (parameter, F) in use: np.linspace(lo, hi, F) written out on one 2D array per F."""
+        P = len(self._items)
+        meta, F_v = self._meta, self._F
+        jx, jy = self._pairs[:, 0], self._pairs[:, 1]
+        lo_all, hi_all = np.zeros(self._n), np.zeros(self._n)  # binmin / binmax per column (the same for every grid size)
+        lo_all[jx], hi_all[jx] = meta[:P, 23], meta[:P, 24]
+        lo_all[jy], hi_all[jy] = meta[:P, 25], meta[:P, 26]
+        ax = {}
+        for F_ in np.unique(F_v).tolist():
+            sel = F_v == F_
+            js_ = np.unique(np.concatenate([jx[sel], jy[sel]]))
+            lo_, hi_ = lo_all[js_], hi_all[js_]
+            A = np.arange(F_, dtype=np.float64)[None, :] * ((hi_ - lo_) / (F_ - 1))[:, None] + lo_[:, None]
+            A[:, -1] = hi_
+            for row, j in enumerate(js_.tolist()):
+                ax[(j, F_)] = (A[row], A[row, 1] - A[row, 0], self._view[j])
+        self._ax = ax
+        return ax
+
+    def _make(self, k):
+        ax_cache = self._ax or self._axes()
+        meta = self._meta
+        F = int(self._F[k])
+        j, j2 = int(self._pairs[k, 0]), int(self._pairs[k, 1])
+        ax, sx, vrx = ax_cache[(j, F)]
+        ay, sy, vry = ax_cache[(j2, F)]
+        off = int(meta[k, 1])
+        Pk = self._grids[off:off + F * F].reshape(F, F)
+        cont = None
+        state = None if self._level_status is None else int(self._level_status[k])
+        if state == 0:
+            cont = self._levels[k].copy()
+        auto = self._auto
+        dens = Density2D._from_fields(dict(
+            x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=None, likes=None, contours=cont, spl=None,
+            _P=Pk, _wait=functools.partial(self._completion.wait_grid, k) if self._completion is not None else None,
+            bandwidth=tuple(meta[k, 2:5].tolist()) if auto else None, bandwidth_branch="ABC"[int(meta[k, 5])] if auto else None,
+            kopt=None if np.isnan(meta[k, 13]) else meta[k, 6:18].copy()))
+        if cont is None and state is not None:  # more exactly equal grid values at the level than the kernel's tie list holds
+            dens.contours = dens.getContourLevels(self._all_contours[:len(self._contours)])
+        return dens
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[q] for q in range(*k.indices(len(self._items)))]
+        k = int(k)
+        if k < 0:
+            k += len(self._items)
+        d = self._items[k]
+        if d is None:
+            d = self._items[k] = self._make(k)
+        return d
+
+    def __iter__(self):
+        for k in range(len(self._items)):
+            yield self[k]
+
+    def __reduce__(self):  # pickles / copies as the plain list of its densities
+        return (list, (list(self),))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
 
 
 def settings_of(mc, base_F, bco, mbc, smooth_scale_2D, want_levels, contours):
@@ -225,52 +313,13 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
     completion = PendingBatch(ctxs, list(tokens)[:len(ctxs)], status, meta[:P, 30].astype(np.int64))
     if not lazy:
         completion.wait()
-    # the grid axes of every (parameter, F) in use: np.linspace(lo, hi, F) written out on one 2D array per F
-    ax_cache = {}
-    jx, jy = pairs32[:, 0], pairs32[:, 1]
-    lo_all, hi_all = np.zeros(mc.n), np.zeros(mc.n)  # binmin / binmax per column (the same for every grid size)
-    lo_all[jx], hi_all[jx] = meta[:P, 23], meta[:P, 24]
-    lo_all[jy], hi_all[jy] = meta[:P, 25], meta[:P, 26]
-    for F_ in np.unique(F_v).tolist():
-        sel = F_v == F_
-        js_ = np.unique(np.concatenate([jx[sel], jy[sel]]))
-        lo_, hi_ = lo_all[js_], hi_all[js_]
-        A = np.arange(F_, dtype=np.float64)[None, :] * ((hi_ - lo_) / (F_ - 1))[:, None] + lo_[:, None]
-        A[:, -1] = hi_
-        for row, j in enumerate(js_.tolist()):
-            ax_cache[(j, F_)] = (A[row], A[row, 1] - A[row, 0], (names[j].range_min, names[j].range_max))
-    auto = smooth_scale_2D < 0
-    letters = "ABC"
-    offs = meta[:P, 1].astype(np.int64).tolist()
-    Fl = F_v.tolist()
-    bw = meta[:P, 2:5].tolist()
-    br = meta[:P, 5].astype(np.int64).tolist()
-    has_kopt = (~np.isnan(meta[:P, 13])).tolist()
-    lev_state = None if level_status is None else level_status[:P].tolist()
-    out = []
-    ncont = None if contours is None else len(contours)
-    for k in range(P):
-        F = Fl[k]
-        ax, sx, vrx = ax_cache[(int(jx[k]), F)]
-        ay, sy, vry = ax_cache[(int(jy[k]), F)]
-        Pk = grids[offs[k]:offs[k] + F * F].reshape(F, F)
-        cont = None
-        if lev_state is not None:
-            if lev_state[k] == 0:
-                cont = levels[k].copy()
-            elif lev_state[k] == -4:
-                raise DensitiesError("Contour level outside plotted ranges")
-        dens = Density2D._from_fields(dict(
-            x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=None, likes=None, contours=cont, spl=None,
-            _P=Pk, _wait=functools.partial(completion.wait_grid, k) if lazy else None,
-            bandwidth=tuple(bw[k]) if auto else None, bandwidth_branch=letters[br[k]] if auto else None,
-            kopt=meta[k, 6:18].copy() if has_kopt[k] else None))
-        if cont is None and lev_state is not None:  # more exactly equal grid values at the level than the kernel's tie list holds
-            dens.contours = dens.getContourLevels(mc.contours[:ncont])
-        out.append(dens)
-    if not lazy:
+        if level_status is not None and np.any(level_status[:P] == -4):
+            raise DensitiesError("Contour level outside plotted ranges")
         if completion.failed:
             raise DensitiesError("no samples in bin")
+    out = DensityBatch(mc, pairs32, F_v, meta, grids, completion if lazy else None, levels, level_status, contours,
+                       smooth_scale_2D < 0)
+    if not lazy:
         return out
     mc._pending_results = completion
     if previous is not None:

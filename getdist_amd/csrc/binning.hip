@@ -201,6 +201,16 @@ __device__ __forceinline__ void decode_block(int nstripes, int nchunks, int& pai
     pair = unit / nchunks;
     chunk = unit % nchunks;
 }
+// Tile-major order: the blocks of ONE row tile (all pairs) are neighbours in the grid, so the pairs that share a column
+// read the same megabyte of it at the same time and all but the first find it in the memory-side cache; pair >= B marks
+// the padding blocks.
+__device__ __forceinline__ void decode_block_tiles(int B, int nstripes, int nchunks, int& pair, int& chunk, int& stripe) {
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    stripe = q % nstripes;
+    const int unit = (q / nstripes) * 8 + xcd;
+    chunk = unit / B;
+    pair = chunk < nchunks ? unit % B : B;
+}
 
 template <typename BinT>
 __device__ __forceinline__ void flush_stripe(const BinT* sh, int row0, int R, int F, double* __restrict__ hist,
@@ -505,15 +515,21 @@ __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restr
 // (pair, chunk of rows, stripe of R rows); its packed counters go to scratch and k_p16_reduce adds the chunks, so no
 // global atomics and every sample's two divisions are done once per stripe (ONE stripe at F <= 256; the 32-bit kernel
 // needs two and therefore reads and divides twice).
+#ifndef P16_UNROLL
+#define P16_UNROLL 4
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __restrict__ pairs, int B, int64_t N, int F, int R,
-                                                         int nstripes, int nchunks, unsigned int* __restrict__ part,
-                                                         int* __restrict__ overflow) {
+                                                         int nstripes, int nchunks, int tile_major,
+                                                         unsigned int* __restrict__ part, int* __restrict__ overflow) {
     extern __shared__ double sh_raw[];
     unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
     __shared__ double red[16];
     int pair, chunk, stripe;
-    decode_block(nstripes, nchunks, pair, chunk, stripe);
+    if (tile_major)
+        decode_block_tiles(B, nstripes, nchunks, pair, chunk, stripe);
+    else
+        decode_block(nstripes, nchunks, pair, chunk, stripe);
     if (pair >= B) return;
     const Hist2DPair P = pairs[pair];
     const BinDiv bdx = make_bindiv(P.bx, P.wx), bdy = make_bindiv(P.by, P.wy);
@@ -526,6 +542,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
     const int64_t lo = (int64_t)chunk * per;
     int64_t hi = lo + per;
     if (hi > N) hi = N;
+    if (hi < lo) hi = lo;  // (a tile behind the last row)
     unsigned int nacc = 0;
     auto visit = [&](double xv, double yv) {
         int cx, cy;
@@ -543,7 +560,23 @@ __global__ void __launch_bounds__(1024) k_hist2d_f64_p16(const Hist2DPair* __res
         }
     };
     const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
-    for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * 1024) {
+    // P16_UNROLL pairs of 16-byte loads per lane are requested before the first sample is binned (the index arithmetic of
+    // a sample is ~60 fp64 operations: with one pair of loads in flight the lane waits a memory latency per two samples)
+    int64_t i = lo + 2 * (int64_t)threadIdx.x;
+    for (; i + (int64_t)(P16_UNROLL - 1) * 2 * 1024 < hi2; i += (int64_t)P16_UNROLL * 2 * 1024) {
+        double2 xv[P16_UNROLL], yv[P16_UNROLL];
+#pragma unroll
+        for (int u = 0; u < P16_UNROLL; ++u) {
+            xv[u] = gload_d2(P.x + i + (int64_t)u * 2 * 1024);
+            yv[u] = gload_d2(P.y + i + (int64_t)u * 2 * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < P16_UNROLL; ++u) {
+            visit(xv[u].x, yv[u].x);
+            visit(xv[u].y, yv[u].y);
+        }
+    }
+    for (; i < hi2; i += 2 * 1024) {
         const double2 xv = gload_d2(P.x + i);
         const double2 yv = gload_d2(P.y + i);
         visit(xv.x, yv.x);
@@ -761,10 +794,22 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     int R = LDS_HIST_BYTES / (F * 2);
     if (R > F) R = F;
     const int nstripes = (F + R - 1) / R;
-    const int nchunks = pick_chunks(ctx, (int64_t)B * nstripes, ctx->N);
+    int nchunks = pick_chunks(ctx, (int64_t)B * nstripes, ctx->N);
+    const int nwords = (R * F + 1) / 2;
+    // Many pairs over few columns (the sheared pairs of a triangle: ten pairs per correlated block of five columns): row
+    // TILES of 128 K samples, tile-major, so that a column's megabyte is fetched from HBM once for all the pairs that read
+    // it; the price is one 128-KB partial table per (pair, tile) through scratch (6 % of the tile's 2 MB of samples).
+    int tile_major = 0;
+    // Measured (scripts/r04_shear_order.py, 79 pairs, N = 1e7): 2.60 ms against 2.43 ms pair-major -- the kernel is bound by
+    // the loads a lane keeps in flight, not by HBM; kept as an experiment switch.
+    if (B >= 16 && nstripes == 1 && ctx->N >= (1 << 20) && getenv("GDHIP_P16_TILE_MAJOR") != nullptr) {
+        int64_t tiles = (ctx->N + 131071) / 131072;
+        const int64_t cap = ((int64_t)3 << 30) / ((int64_t)B * nwords * 4);  // at most 3 GB of partial tables
+        if (tiles > cap) tiles = cap;
+        if (tiles > nchunks) nchunks = (int)tiles, tile_major = 1;
+    }
     const int units = (B * nchunks + 7) / 8 * 8;
     const int64_t nblocks = (int64_t)units * nstripes;
-    const int nwords = (R * F + 1) / 2;
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
         int64_t o = off;
@@ -782,7 +827,7 @@ static int launch_hist2d_p16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_f64_p16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
     k_hist2d_f64_p16<MODE><<<(unsigned)nblocks, 1024, (size_t)nwords * 4, ctx->stream>>>(d_pairs, B, ctx->N, F, R, nstripes,
-                                                                                      nchunks, d_part, d_flags);
+                                                                                      nchunks, tile_major, d_part, d_flags);
     GD_KERNEL_CHECK();
     k_p16_reduce<<<dim3((unsigned)((nwords + 255) / 256), nstripes, B), 256, 0, ctx->stream>>>(d_part, F, R, nstripes, nchunks, d_hist);
     GD_KERNEL_CHECK();

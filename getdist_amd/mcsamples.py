@@ -3385,11 +3385,13 @@ def _next_fft_size(n):
 
 
 def covToCorr(cov, copy=True):
-    """chains.py:155-169"""
-    if copy:
-        cov = cov.copy()
-    for i, di in enumerate(np.sqrt(cov.diagonal())):
-        if di:
-            cov[i, :] /= di
-            cov[:, i] /= di
+    """chains.py:155-169: for i in order, row i and then column i are divided by sqrt(cov[i, i]) -- so element (a, b) is
+    divided by the standard deviation of min(a, b) FIRST and by that of max(a, b) second (zero deviations are skipped).
+    The same two divisions per element, on the whole matrix at once."""
+    cov = np.array(cov, dtype=np.float64) if copy else cov
+    d = np.sqrt(cov.diagonal())
+    d = np.where(d != 0, d, 1.0)
+    idx = np.arange(len(d))
+    first, second = np.minimum(idx[:, None], idx[None, :]), np.maximum(idx[:, None], idx[None, :])
+    cov[...] = (cov / d[first]) / d[second]
     return cov

@@ -19,7 +19,13 @@ from getdist_amd.mcsamples import MCSamples  # noqa: E402
 
 
 def main():
+    only_u8 = "--only-u8" in sys.argv  # bench.py's live counter pass: the roofline kernel alone, three launches
     N, n, F = 10_000_000, 50, 256
+    for a in sys.argv[1:]:
+        if a.startswith("--nsamples="):
+            N = int(a.split("=")[1])
+        if a.startswith("--nparams="):
+            n = int(a.split("=")[1])
     s, w, names, ranges = synth.config_c3(N, n)
     mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges)
     mc.prepareParams(neff=False)
@@ -30,10 +36,14 @@ def main():
     pairs = [p for p in synth.triangle_pairs(n) if abs(corr[p[1]][p[0]]) <= 0.866]  # the 1200 base-grid pairs
     assert mc._index_columns8({j: (e[j][1], e[j][0]) for j in range(n)})
     i8 = [mc._idx_cols[(j, 256, "u8")][0] for j in range(n)]
-    idx = [mc._index_column(j, F, e[j][1], e[j][0]) for j in range(n)]
+    idx = [] if only_u8 else [mc._index_column(j, F, e[j][1], e[j][0]) for j in range(n)]
     out = ctx.alloc(len(pairs) * F * F * 8)
     for _ in range(3):
         ctx.hist2d_prebinned8([i8[a] for a, b in pairs], [i8[b] for a, b in pairs], out=out)
+    if only_u8:
+        ctx.sync()
+        print("done: %d pairs (byte-index kernel only)" % len(pairs))
+        return
     for _ in range(3):
         ctx.hist2d_prebinned([idx[a] for a, b in pairs], [idx[b] for a, b in pairs], F, out=out)
     for _ in range(3):
