@@ -97,6 +97,7 @@ SIGNATURES = {
     "gd_copy_mark": (C.c_int, [_p, _pi32]),
     "gd_copy_wait": (C.c_int, [_p, _i32]),
     "gd_density2d_enqueue": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _p]),
+    "gd_density2d_enqueue_indexed": (C.c_int, [_p, _i32, _i32, _p, _pi32, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _p]),
     "gd_attach_samples": (C.c_int, [_p, _p]),
     "gd_bind_thread": (C.c_int, [_p]),
     "gd_contour_levels": (C.c_int, [_p, _i32, _i32, _p, _pd, _i32, _pd, _pi32]),

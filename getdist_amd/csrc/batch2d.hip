@@ -55,9 +55,9 @@ const gdb::Ops kOps = {
         return gd_gather_items(C(h), (char*)d_dst + dst_first * item_bytes, d_src, index, count, item_bytes);
     },
     /* density2d_enqueue */
-    [](void* h, int32_t B, int32_t F, const void* d_hist, const double* rx, const double* ry, const double* corr,
-       const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P, int32_t* status_pinned) {
-        return gd_density2d_enqueue(C(h), B, F, d_hist, rx, ry, corr, winw, flags, bco, mbc, d_P, status_pinned);
+    [](void* h, int32_t B, int32_t F, const void* d_hist, const int32_t* hist_index, const double* rx, const double* ry,
+       const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, void* d_P, int32_t* status_pinned) {
+        return gd_density2d_enqueue_indexed(C(h), B, F, d_hist, hist_index, rx, ry, corr, winw, flags, bco, mbc, d_P, status_pinned);
     },
     /* d2h_async */ [](void* h, void* dst, const void* d_src, int64_t bytes) { return gd_memcpy_d2h_async(C(h), dst, d_src, bytes); },
     /* copy_mark */ [](void* h, int32_t* token) { return gd_copy_mark(C(h), token); },

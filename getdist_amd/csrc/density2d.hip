@@ -14,6 +14,8 @@ struct D2Pair {
     double c00, c11, c10;  // inverse bandwidth matrix (mcsamples.py:1864)
     int w;                 // winw
     int flags;             // bit0/1 x bot/top, bit2/3 y bot/top, bit4/5 x/y periodic, bit6 boundary correction applies
+    int hidx;              // which histogram of the source block this pair convolves (the batch need not be contiguous)
+    int pad;
 };
 
 __device__ __forceinline__ double win_raw(const D2Pair& p, int i1, int i2) {
@@ -55,7 +57,7 @@ __global__ void k_fill_window(const D2Pair* __restrict__ pairs, const double* __
 __global__ void k_fill_embed(const D2Pair* __restrict__ pairs, const double* __restrict__ src, int F, int S,
                              double* __restrict__ frames) {
     const int w = pairs[blockIdx.y].w;
-    const double* s = src + (int64_t)blockIdx.y * F * F;
+    const double* s = src + (int64_t)pairs[blockIdx.y].hidx * F * F;
     double* fr = frames + (int64_t)blockIdx.y * S * S;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
         const int r = e / S - w, c = e % S - w;
@@ -161,7 +163,41 @@ __device__ __forceinline__ MaskIv mask_interval(int F, int w, bool bot, bool top
     return iv;
 }
 
-// grid (blocks, n moments, B)
+// Which entries of a moment's summed-area table a pixel's mask moment is made of (the same for every moment of one mask).
+struct MaskGeom {
+    int a0, a1, b0, b1, ner, nec, er[2], ec[2];
+    bool any, full;  // any: the window meets the mask at all; full: the whole window lies inside it, away from any half row
+};
+__device__ __forceinline__ MaskGeom mask_geom(int F, int w, const MaskIv& ix, const MaskIv& iy, int x, int y) {
+    MaskGeom g;
+    // window offset i covers padded position  (pixel + w - i)
+    const int i_lo = max(-w, y + w - iy.hi), i_hi = min(w, y + w - iy.lo);
+    const int j_lo = max(-w, x + w - ix.hi), j_hi = min(w, x + w - ix.lo);
+    g.any = i_lo <= i_hi && j_lo <= j_hi;
+    g.ner = g.nec = 0;
+    g.a0 = i_lo + w, g.a1 = i_hi + w, g.b0 = j_lo + w, g.b1 = j_hi + w;
+    if (g.any) {
+        if (iy.hlo && y + w - iy.lo <= w) g.er[g.ner++] = y + 2 * w - iy.lo;
+        if (iy.hhi && y + w - iy.hi >= -w) g.er[g.ner++] = y + 2 * w - iy.hi;
+        if (ix.hlo && x + w - ix.lo <= w) g.ec[g.nec++] = x + 2 * w - ix.lo;
+        if (ix.hhi && x + w - ix.hi >= -w) g.ec[g.nec++] = x + 2 * w - ix.hi;
+    }
+    g.full = g.any && g.ner == 0 && g.nec == 0 && g.a0 == 0 && g.b0 == 0 && g.a1 == 2 * w && g.b1 == 2 * w;
+    return g;
+}
+// the moment itself from its table: rectangle sum, minus half of the edge rows / columns, plus a quarter of the corners
+__device__ __forceinline__ double mask_moment(const double* __restrict__ s, int M1, const MaskGeom& g) {
+    if (!g.any) return 0.0;
+    double v = sat_rect(s, M1, g.a0, g.a1, g.b0, g.b1);
+    for (int k = 0; k < g.ner; ++k) v -= 0.5 * sat_rect(s, M1, g.er[k], g.er[k], g.b0, g.b1);
+    for (int k = 0; k < g.nec; ++k) v -= 0.5 * sat_rect(s, M1, g.a0, g.a1, g.ec[k], g.ec[k]);
+    for (int k = 0; k < g.ner; ++k)
+        for (int l = 0; l < g.nec; ++l) v += 0.25 * sat_rect(s, M1, g.er[k], g.er[k], g.ec[l], g.ec[l]);
+    return v;
+}
+
+// grid (blocks, n moments, B): the moments as F x F arrays (the rocFFT route and explicit masks read them; the LDS route
+// evaluates them where they are used: k_boundary<true>, k_rows_inv<1>)
 __global__ void k_mask_eval(const D2Pair* __restrict__ pairs, MomList L, int F, int64_t sat_stride,
                             const double* __restrict__ sat) {
     const D2Pair p = pairs[blockIdx.z];
@@ -175,24 +211,7 @@ __global__ void k_mask_eval(const D2Pair* __restrict__ pairs, MomList L, int F, 
     const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, sp.kind, use_edges);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * F; e += gridDim.x * blockDim.x) {
         const int y = e / F, x = e % F;
-        // window offset i covers padded position  (pixel + w - i)
-        const int i_lo = max(-w, y + w - iy.hi), i_hi = min(w, y + w - iy.lo);
-        const int j_lo = max(-w, x + w - ix.hi), j_hi = min(w, x + w - ix.lo);
-        double v = 0.0;
-        if (i_lo <= i_hi && j_lo <= j_hi) {
-            const int a0 = i_lo + w, a1 = i_hi + w, b0 = j_lo + w, b1 = j_hi + w;
-            v = sat_rect(s, M1, a0, a1, b0, b1);
-            int er[2], ec[2], ner = 0, nec = 0;
-            if (iy.hlo && y + w - iy.lo <= w) er[ner++] = y + 2 * w - iy.lo;
-            if (iy.hhi && y + w - iy.hi >= -w) er[ner++] = y + 2 * w - iy.hi;
-            if (ix.hlo && x + w - ix.lo <= w) ec[nec++] = x + 2 * w - ix.lo;
-            if (ix.hhi && x + w - ix.hi >= -w) ec[nec++] = x + 2 * w - ix.hi;
-            for (int k = 0; k < ner; ++k) v -= 0.5 * sat_rect(s, M1, er[k], er[k], b0, b1);
-            for (int k = 0; k < nec; ++k) v -= 0.5 * sat_rect(s, M1, a0, a1, ec[k], ec[k]);
-            for (int k = 0; k < ner; ++k)
-                for (int l = 0; l < nec; ++l) v += 0.25 * sat_rect(s, M1, er[k], er[k], ec[l], ec[l]);
-        }
-        dst[e] = v;
+        dst[e] = mask_moment(s, M1, mask_geom(F, w, ix, iy, x, y));
     }
 }
 
@@ -266,20 +285,46 @@ struct BcArrays {
 
 // linear boundary correction (mcsamples.py:1921-1961), in place on P; only pairs with a limit
 // mx_out (may be nullptr; must not alias mx: other blocks of the pair are still folding mx): the block maxima of the
-// grid after the correction (grid (PM_PARTS, B))
+// grid after the correction (grid (PM_PARTS, B)).
+// FUSED: the prior-mask moments a_pq are not read from F x F arrays but evaluated here from the pair's summed-area tables
+// (sat: moment q of pair b at (b * nmom + q) * sat_stride; the six moments share one MaskGeom, interior pixels -- the whole
+// window inside the mask -- take the tables' totals from registers, and the higher moments are only formed where the pixel
+// passes the threshold): the same operations in the same order as k_mask_eval + the array form, without writing and
+// re-reading six grids per bounded pair.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF,
-                                                  int bco, double* __restrict__ mx_out) {
+                                                  int bco, double* __restrict__ mx_out, const double* __restrict__ sat,
+                                                  int64_t sat_stride, int nmom, int F) {
     __shared__ double red[16];
     const int b = blockIdx.y;
-    if ((pairs[b].flags & 64) == 0) {  // untouched grid: its maxima move to the output set unchanged
+    const D2Pair p = pairs[b];
+    if ((p.flags & 64) == 0) {  // untouched grid: its maxima move to the output set unchanged
         if (mx_out && threadIdx.x == 0) mx_out[(int64_t)b * PM_PARTS + blockIdx.x] = mx[(int64_t)b * PM_PARTS + blockIdx.x];
         return;
     }
     const double thresh = pair_max(mx, b) * 1e-8;
     const int64_t o = (int64_t)b * FF;
+    const int w = p.w, M1 = 2 * w + 2;
+    const double* s0 = FUSED ? sat + (int64_t)b * nmom * sat_stride : nullptr;
+    const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, 0, true);
+    const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, 0, true);
+    double tot[6] = {0, 0, 0, 0, 0, 0};
+    if (FUSED) {
+        const int nq = bco == 1 ? 6 : 1;
+        for (int q = 0; q < nq; ++q) tot[q] = sat_rect(s0 + q * sat_stride, M1, 0, 2 * w, 0, 2 * w);
+    }
     double m = -INFINITY;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
-        const double P = A.P[o + i], a00 = A.a00[o + i];
+        const double P = A.P[o + i];
+        MaskGeom g;
+        double a00;
+        if (FUSED) {
+            const int y = i / F, x = i - y * F;
+            g = mask_geom(F, w, ix, iy, x, y);
+            a00 = g.full ? tot[0] : mask_moment(s0, M1, g);
+        } else {
+            a00 = A.a00[o + i];
+        }
         if (!(a00 * P > thresh)) {
             m = fmax(m, P);
             continue;
@@ -290,8 +335,19 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
             m = fmax(m, normed);
             continue;
         }
-        const double a10 = A.a10[o + i], a01 = A.a01[o + i], a20 = A.a20[o + i], a02 = A.a02[o + i],
-                     a11 = A.a11[o + i], xP = A.xP[o + i], yP = A.yP[o + i];
+        double a10, a01, a20, a02, a11;
+        if (FUSED) {
+            if (g.full) {
+                a10 = tot[1], a01 = tot[2], a20 = tot[3], a02 = tot[4], a11 = tot[5];
+            } else {
+                a10 = mask_moment(s0 + 1 * sat_stride, M1, g), a01 = mask_moment(s0 + 2 * sat_stride, M1, g);
+                a20 = mask_moment(s0 + 3 * sat_stride, M1, g), a02 = mask_moment(s0 + 4 * sat_stride, M1, g);
+                a11 = mask_moment(s0 + 5 * sat_stride, M1, g);
+            }
+        } else {
+            a10 = A.a10[o + i], a01 = A.a01[o + i], a20 = A.a20[o + i], a02 = A.a02[o + i], a11 = A.a11[o + i];
+        }
+        const double xP = A.xP[o + i], yP = A.yP[o + i];
         const double denom = a20 * (a01 * a01) + (a10 * a10) * a02 - a00 * a02 * a20 + (a11 * a11) * a00 - 2 * a01 * a10 * a11;
         const double Aq = a11 * a11 - a02 * a20;
         const double Ax = a10 * a02 - a01 * a11;
@@ -312,13 +368,13 @@ __global__ void k_fill_box(const D2Pair* __restrict__ pairs, const double* __res
                            const double* __restrict__ mx, int F, int S, double* __restrict__ frames) {
     const int w = pairs[blockIdx.y].w;
     const double thresh = pair_max(mx, blockIdx.y) * 1e-8;
-    const int64_t o = (int64_t)blockIdx.y * F * F;
+    const int64_t o = (int64_t)blockIdx.y * F * F, oh = (int64_t)pairs[blockIdx.y].hidx * F * F;
     double* fr = frames + (int64_t)blockIdx.y * S * S;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S * S; e += gridDim.x * blockDim.x) {
         const int r = e / S - w, c = e % S - w;
         double v = 0;
         if (r >= 0 && r < F && c >= 0 && c < F) {
-            const double h = hist[o + (int64_t)r * F + c], p = P[o + (int64_t)r * F + c];
+            const double h = hist[oh + (int64_t)r * F + c], p = P[o + (int64_t)r * F + c];
             v = (p > thresh) ? h / p : h;
         }
         fr[e] = v;
@@ -583,12 +639,12 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
     const int y = blockIdx.x * (blockDim.x / FT) + g;
     const bool active = y < F;
     if (active) {
-        const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
+        const int64_t o = (int64_t)b * F * F + (int64_t)y * F, oh = (int64_t)pairs[b].hidx * F * F + (int64_t)y * F;
         auto value = [&](int x) {  // the frame's row at position x: the source row embedded at offset w
             const int c = x - w;
             double v = 0.0;
             if (c >= 0 && c < F) {
-                v = src[o + c];
+                v = src[oh + c];
                 if (MODE == 1) {
                     const double p = P[o + c];
                     if (p > thresh_sh) v = v / p;
@@ -734,10 +790,13 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
 // and the odd ones in its imaginary part (unnormalised like a length-S inverse).  MODE 0: dst = crop; MODE 1: dst = dst *
 // crop / a00 (the multiplicative bias-correction update); mx (may be nullptr): block maxima of what was written, parts the
 // grid does not cover set to -inf.
+// MODE 1 takes the divisor a00 (the all-edge mask's zeroth moment) from its F x F array, or -- sat1 given: the pair's
+// summed-area table of that moment at sat1 + b * sat1_pair_stride -- evaluates it per pixel (k_mask_eval's operations).
 template <int MODE>
 __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
-                                                  const double* __restrict__ a00, double* __restrict__ mx) {
+                                                  const double* __restrict__ a00, double* __restrict__ mx,
+                                                  const double* __restrict__ sat1, int64_t sat1_pair_stride, int edge_applied) {
     extern __shared__ double2 sh2[];
     __shared__ double red[16];
     const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
@@ -775,11 +834,25 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     double m = -INFINITY;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
+        const int fl = pairs[b].flags, M1 = 2 * w + 2;
+        const double* s1 = (MODE == 1 && sat1) ? sat1 + (int64_t)b * sat1_pair_stride : nullptr;
+        const MaskIv ix = mask_interval(F, w, fl & 1, fl & 2, 1, edge_applied != 0);
+        const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
+        const double tot = s1 ? sat_rect(s1, M1, 0, 2 * w, 0, 2 * w) : 0.0;
         for (int x = t; x < F; x += FT) {
             const int pos = x + w;
             const double2 z = buf[pos >> 1];
             double v = (pos & 1) ? z.y : z.x;
-            if (MODE == 1) v = (dst[o + x] * v) / a00[o + x];
+            if (MODE == 1) {
+                double div;
+                if (s1) {
+                    const MaskGeom g = mask_geom(F, w, ix, iy, x, y);
+                    div = g.full ? tot : mask_moment(s1, M1, g);
+                } else {
+                    div = a00[o + x];
+                }
+                v = (dst[o + x] * v) / div;
+            }
             dst[o + x] = v;
             m = fmax(m, v);
         }
@@ -921,7 +994,7 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
                 }
             }
         }
-        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, nullptr);
+        k_boundary<false><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, nullptr, nullptr, 0, 0, F);
         GD_KERNEL_CHECK();
     }
     if (do_mbc) {
@@ -959,7 +1032,8 @@ extern "C" {
 
 static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const double* rx, const double* ry,
                           const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
-                          void* d_P_out, int32_t* status_out, const MaskOv* ov, bool wait = true) {
+                          void* d_P_out, int32_t* status_out, const MaskOv* ov, bool wait = true,
+                          const int32_t* hist_index = nullptr) {
     GD_REQUIRE(ctx && d_hist_v && rx && ry && corr && winw && flags && d_P_out && status_out && B > 0, "bad argument");
     GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins_2D out of range");
     GD_REQUIRE(bco >= -1 && bco <= 1, "unknown boundary_correction_order (expected 0 or 1)");
@@ -978,6 +1052,9 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         hp[b].c11 = a / det;
         hp[b].c10 = -o / det;
         hp[b].w = winw[b];
+        hp[b].hidx = hist_index ? hist_index[b] : b;
+        hp[b].pad = 0;
+        GD_REQUIRE(hp[b].hidx >= 0, "negative histogram index");
         hp[b].flags = flags[b] & 127;
         // bit 6 = "has_prior" (mcsamples.py:1794): default it from the limit bits for callers that do not set it
         if ((hp[b].flags & 15) != 0) hp[b].flags |= 64;
@@ -988,6 +1065,12 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     const int per = flags[0] & 48;
     if (per) {
         GD_REQUIRE(!ov, "explicit prior masks are not supported on periodic axes");
+        if (hist_index) {  // the periodic route reads its batch contiguously: gather first (rare)
+            double* d_sub = (double*)gd_scratch2(ctx, (int64_t)B * F * F * 8);
+            if (!d_sub) return GD_ERR_NOMEM;
+            GD_TRY(gd_gather_items(ctx, d_sub, d_hist, hist_index, B, (int64_t)F * F * 8));
+            return density2d_periodic(ctx, B, F, d_sub, hp, maxw, per, bco, mbc, d_P, status_out, wait);
+        }
         return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out, wait);
     }
     const bool do_bc = any_limits && bco >= 0;
@@ -1014,6 +1097,8 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     const bool lds_conv = !ov && S <= 512 && (F + RPB - 1) / RPB <= PM_PARTS && lds_win <= 150u * 1024u &&
                           getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw) &&
                           lds_fft_plan(ctx, S / 2, &plH, nullptr);
+    // the prior-mask moments are evaluated inside their consumers (k_boundary<true>, k_rows_inv<1>) on the LDS route
+    const bool fused = lds_conv && !ov && getenv("GDHIP_CONV_MOMENT_ARRAYS") == nullptr;
     const int64_t XT = (int64_t)B * Sh * F * 16;  // transposed half spectra of the LDS route
     const int64_t WT = (int64_t)B * Sh * S * 8;  // a window moment's spectrum by columns (its real or its imaginary part)
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
@@ -1021,7 +1106,8 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
                   o_status = take((int64_t)B * 4), o_RF = take(lds_conv ? XT : B * SS * 8), o_RO = take(lds_conv ? XT : B * SS * 8),
                   o_ZH = take(lds_conv ? WT : B * SC * 16), o_ZW = take(lds_conv ? WT : B * SC * 16),
                   o_ZK = take(!lds_conv && do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(lds_conv ? 0 : B * SC * 16),
-                  o_arr = take((do_bc ? (bco == 1 ? 8 : 1) : 0) * B * FF * 8), o_a00m = take(mbc ? B * FF * 8 : 0),
+                  o_arr = take((do_bc ? (bco == 1 ? (fused ? 2 : 8) : (fused ? 0 : 1)) : 0) * B * FF * 8),
+                  o_a00m = take(mbc && !fused ? B * FF * 8 : 0),
                   o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
@@ -1102,7 +1188,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         GD_KERNEL_CHECK();
         auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
         GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kr<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp);
+        // (update && fused: the divisor comes from the all-edge mask's table, the last of the pair's n_mom tables)
+        const double* sat1 = (update && fused) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
+        kr<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
+                                                    do_bc ? 1 : 0);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
@@ -1124,9 +1213,13 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     A.P = d_P;
     A.a00 = arr;
     A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
-    if (do_bc && bco == 1)
+    if (do_bc && bco == 1 && !fused)
         A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
         A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
+    if (fused) {  // no moment arrays: only the two histogram-side convolutions of the linear correction are grids
+        A.a00 = nullptr;
+        if (do_bc && bco == 1) A.xP = arr, A.yP = arr + B * FF;
+    }
     if (n_mom) {
         MomList L;
         L.n = 0;
@@ -1145,8 +1238,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         if (!ov) {
             k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
             GD_KERNEL_CHECK();
-            k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
-            GD_KERNEL_CHECK();
+            if (!fused) {
+                k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
+                GD_KERNEL_CHECK();
+            }
         } else {
             for (int q = 0; q < L.n; ++q) {  // d_sat doubles as the window-moment buffer ((2w+1)^2 <= sat_stride)
                 const double* mask = L.m[q].kind == 0 ? ov->d_mask_bc : ov->d_mask_mbc;
@@ -1176,7 +1271,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             FWD(RF, ZK);
             CONV_TO(ZH, ZK, A.yP, (double*)nullptr);
         }
-        k_boundary<<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2);
+        if (fused)
+            k_boundary<true><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, d_sat, sat_stride, n_mom, F);
+        else
+            k_boundary<false><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, nullptr, 0, 0, F);
         GD_KERNEL_CHECK();
         mx_cur = d_mx2;
     }
@@ -1240,6 +1338,12 @@ int gd_density2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v
     return density2d_main(ctx, B, F, d_hist_v, rx, ry, corr, winw, flags, bco, mbc, d_P_out, status_pinned, nullptr, false);
 }
 
+int gd_density2d_enqueue_indexed(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const int32_t* hist_index,
+                                 const double* rx, const double* ry, const double* corr, const int32_t* winw, const int32_t* flags,
+                                 int32_t bco, int32_t mbc, void* d_P_out, int32_t* status_pinned) {
+    return density2d_main(ctx, B, F, d_hist_v, rx, ry, corr, winw, flags, bco, mbc, d_P_out, status_pinned, nullptr, false, hist_index);
+}
+
 int gd_density2d_masked(gd_ctx* ctx, int32_t F, const void* d_hist, double rx, double ry, double corr, int32_t winw,
                         int32_t flags, int32_t bco, int32_t mbc, const double* mask_bc, const double* mask_mbc,
                         const unsigned char* zero_mask, void* d_P_out, int32_t* status_out) {
@@ -1285,6 +1389,8 @@ int gd_likes2d(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v, const vo
         hp[b].c11 = a / det;
         hp[b].c10 = -o / det;
         hp[b].w = winw[b];
+        hp[b].hidx = b;
+        hp[b].pad = 0;
         hp[b].flags = flags[b] & 127;
         if (winw[b] > maxw) maxw = winw[b];
         GD_REQUIRE((hp[b].flags & 48) == (flags[0] & 48), "a batch must not mix periodic and non-periodic pairs");

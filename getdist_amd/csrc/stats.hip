@@ -1502,6 +1502,20 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     if (nblk > 32) nblk = 32;
     if ((int64_t)nblk * 262144 > hi - lo) nblk = (int)((hi - lo + 262143) / 262144);
     if (nblk < 1) nblk = 1;
+    {
+        // one block per CU (the table is 128 KB): ncols * nblk blocks run in ceil(blocks / CUs) rounds, so a count just
+        // above a multiple of the CU number wastes most of a round (50 columns x 11 blocks = 2.15 rounds took the time of
+        // 3; x 10 = 1.95 rounds: 1.40 -> 1.05 ms).  Among the counts down to half of the first choice take the one that
+        // fills its rounds best.
+        int best = nblk;
+        double best_eff = 0;
+        for (int q = nblk; q >= (nblk + 1) / 2 && q >= 1; --q) {
+            const double rounds = (double)ncols * q / ctx->cu_count;
+            const double eff = rounds / ceil(rounds);
+            if (eff > best_eff + 0.02) best_eff = eff, best = q;
+        }
+        nblk = best;
+    }
     int nblk2 = (8 * ctx->cu_count + ncols - 1) / ncols;
     if (nblk2 < 8) nblk2 = 8;
     if (nblk2 > 2 * ctx->cu_count) nblk2 = 2 * ctx->cu_count;

