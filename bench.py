@@ -230,7 +230,7 @@ def live_counter_traffic(mc, npairs, kernel):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "h", "--", sys.executable,
                    os.path.join(ROOT, "scripts", "pmc_hist2d.py"), "--only-u8", "--nsamples=%d" % mc.numrows, "--nparams=%d" % mc.n]
             r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                               timeout=240)
+                               timeout=150)
             if r.returncode != 0:
                 return None
             got = []

@@ -1,6 +1,7 @@
 """Time gd_kopt2d (DCT GEMMs + fixed point + get_h) on C3-like histograms; used to compare build variants on the GPU box."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from getdist_amd._lib import Context
 from getdist_amd import synth
 

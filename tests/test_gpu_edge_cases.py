@@ -278,9 +278,12 @@ def test_lazy_result_delivery_and_overlapping_calls(monkeypatch):
     P2 = [d.P.copy() for d in second]
     P1 = [d.P.copy() for d in first]
     assert pending.done
+    # the eager form is the Python-planned route's (the native entry always delivers lazily): waits inside the call
     monkeypatch.setenv("GETDIST_AMD_LAZY_RESULTS", "0")
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "0")
     eager = mc.get2DDensities(pairs)
-    assert mc._pending_results is not pending and all(d.__dict__.get("_wait") is None for d in eager)
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "1")
+    assert all(d.__dict__.get("_wait") is None for d in eager)
     for a, b, c in zip(P1, P2, eager):
         assert a.max() == 1.0 and np.array_equal(a, b) and np.array_equal(a, c.P)
     # the per-pair methods are views over the batched path and read their grid before returning
