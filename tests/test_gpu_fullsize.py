@@ -499,6 +499,13 @@ def test_c5_stress_full_size_properties():
             classes.add(int(d.P.shape[0]))
         done += len(dens)
     t_tri = time.perf_counter() - t0
+    # the same triangle again: plans (rocFFT's run-time compiled kernels for the 1152- and 1440-point frames of the
+    # up-scaled classes: ~0.6 s each), scratch, page-locked result blocks and index columns exist now
+    t0 = time.perf_counter()
+    for a in range(0, len(pairs), 2000):
+        dens = mc.get2DDensities(pairs[a:a + 2000])
+        dens[len(dens) - 1].P
+    t_tri_warm = time.perf_counter() - t0
     d1 = mc.get2DDensities([pairs[5]])[0]
     d2 = mc.get2DDensities([pairs[5]])[0]
     assert np.array_equal(d1.P, d2.P)  # the same call twice on one device: bit for bit
@@ -518,6 +525,6 @@ def test_c5_stress_full_size_properties():
     assert np.allclose(d.bandwidth, (tr["hx"], tr["hy"], tr["c"]), rtol=1e-6, atol=1e-12)
     c5_err = float(np.max(np.abs(d.P - o["P"])))
     assert c5_err < 1e-6, (sub, c5_err)
-    _report("C5", dict(oracle_pair=sub, oracle_pair_max_abs_dP=c5_err, oracle_pair_cpu_s=round(t_oracle, 1), params=n, rows=N, pairs=done, generate_s=round(t_gen, 1), construct_upload_s=round(t_ctor, 1),
+    _report("C5", dict(oracle_pair=sub, oracle_pair_max_abs_dP=c5_err, oracle_pair_cpu_s=round(t_oracle, 1), params=n, rows=N, pairs=done, generate_s=round(t_gen, 1), construct_upload_s=round(t_ctor, 1), triangle_warm_s=round(t_tri_warm, 2), densities_per_s_warm=round(done / t_tri_warm, 1),
                        margestats_200_params_s=round(t_marge, 2), triangle_s=round(t_tri, 1),
                        densities_per_s=round(done / t_tri, 1), F_classes=sorted(classes)))
