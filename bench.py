@@ -378,13 +378,15 @@ def _cpu_task(task):
             out["P"] = o["P"]
             if "p_13" in tr:  # a TNC pair: the oracle's own spread for rounding-equal inputs, and where the device's triple lies
                 psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-                ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
-                moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
-                out["chaotic"] = (moved > 1e-6, moved)
                 if task.get("gpu_kopt") is not None:
-                    trip = np.asarray(task["gpu_kopt"])[8:11]
-                    out["inside_oracle_spread"], out["excess"] = ko.within_oracle_spread(trip, ens)
-                    out["amise_ok"] = ko.amise_within_oracle_range(trip, ens, psi, tr["opt_N"])[0]
+                    v = ko.judge_triple(np.asarray(task["gpu_kopt"])[8:11], psi, tr["opt_N"], tr["opt_corr"])
+                    out["chaotic"] = (v["moved"] > 1e-6, v["moved"])
+                    out["inside_oracle_spread"], out["excess"], out["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                    out["ensemble_perturbation"] = v["scale"]
+                else:
+                    ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
+                    moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
+                    out["chaotic"] = (moved > 1e-6, moved)
         return out
     # share of a full triangle: this worker's pairs, parameter state cached across them.  The CPU time is the oracle's
     # alone; afterwards (outside the timed span) every grid is compared with the GPU's grid of the same pair, read from
@@ -411,10 +413,10 @@ def _cpu_task(task):
             row["sum_rel"] = float(abs(np.sum(G) - np.sum(P)) / np.sum(P))
             if row["err"] > 1e-6 and row["tnc"] and kopt is not None:
                 psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-                ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
-                row["oracle_moves_by"] = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
-                row["inside_oracle_spread"], row["excess"] = ko.within_oracle_spread(kopt[8:11], ens)
-                row["amise_ok"] = ko.amise_within_oracle_range(kopt[8:11], ens, psi, tr["opt_N"])[0]
+                v = ko.judge_triple(kopt[8:11], psi, tr["opt_N"], tr["opt_corr"])
+                row["oracle_moves_by"] = v["moved"]
+                row["inside_oracle_spread"], row["excess"], row["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                row["ensemble_perturbation"] = v["scale"]
         rows.append(row)
     return dict(kind=kind, seconds=seconds, rows=rows)
 

@@ -217,6 +217,7 @@ void gd_destroy(gd_ctx* ctx) {
     if (ctx->wcum) (void)hipFree(ctx->wcum);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->gather_index) (void)hipFree(ctx->gather_index);
     for (auto& ev : ctx->copy_marks)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->kopt_evs)
@@ -421,8 +422,11 @@ extern "C" {
 
 int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes) {
     GD_REQUIRE(ctx && d_dst && d_src && index && count > 0 && item_bytes > 0 && item_bytes % 16 == 0, "bad argument");
-    int* d_index = (int*)gd_scratch2(ctx, (int64_t)count * 4);
-    if (!d_index) return GD_ERR_NOMEM;
+    // (a block of its own: density2d's periodic route gathers INTO scratch2 -- with the index list at the head of the same
+    // block the kernel read its indices from under its own stores, and the second pair of a call came out as noise in ~7 %
+    // of the calls)
+    if (grow(ctx, &ctx->gather_index, &ctx->gather_index_bytes, (int64_t)count * 4)) return GD_ERR_NOMEM;
+    int* d_index = (int*)ctx->gather_index;
     // stream-ordered: returns once enqueued (every consumer of d_dst is an entry point of this context)
     int rc = gd_stage_h2d(ctx, d_index, index, (size_t)count * 4);
     if (rc) return rc;

@@ -45,6 +45,8 @@ struct gd_ctx {
     int64_t scratch_bytes = 0;
     void* scratch2 = nullptr;
     int64_t scratch2_bytes = 0;
+    void* gather_index = nullptr;  // the index list of gd_gather_items (its destination may be one of the scratch blocks)
+    int64_t gather_index_bytes = 0;
     FftPlanCache* fft = nullptr;
     std::map<int, double*> dctmat;  // F -> F x F DCT-II matrix 2cos(pi k (2n+1) / 2F) (kopt2d.hip)
     std::map<int, void*> fft_tw;    // S -> the S twiddles e^{-2 pi i k / S} of the LDS transforms (density2d.hip)

@@ -15,7 +15,8 @@
 #endif
 #define MAXF 6  // forms per level
 #ifdef KOPT_PROFILE
-__device__ long long g_prof[8];  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
+__device__ long long g_prof[8];
+__device__ long long g_wave[8];  // k_kopt2d_res: cycles each wave of block 0 spent in the forms  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
 #define PROF_T0 long long prof_t0 = clock64()
 #define PROF_ADD(slot)                                                        \
     do {                                                                      \
@@ -665,6 +666,476 @@ __global__ void __launch_bounds__(KT) k_kopt2d(const double* __restrict__ SQ_all
     }
 }
 
+#ifdef KOPT_PROFILE
+#define RPROF_T0 long long prof_t0 = clock64()
+#define RPROF_ADD(slot)                                                              \
+    do {                                                                             \
+        const long long prof_t1 = clock64();                                         \
+        if (threadIdx.x == 0 && blockIdx.x == 0) V.sh->prof[slot] += prof_t1 - prof_t0; \
+        prof_t0 = prof_t1;                                                           \
+    } while (0)
+#else
+#define RPROF_T0
+#define RPROF_ADD(slot)
+#endif
+// ---- the same solver with the matrix RESIDENT on the CU (F = 256) ----------------------------------------------------
+// k_kopt2d streams the 512-KB matrix of a pair through LDS ~25 times (6-7 Brent evaluations x 4 dependent levels).  Here
+// the block loads it ONCE: 512 threads, wave w owns rows [32w, 32w+32), lane l the four columns {2l, 2l+1, 128+2l,
+// 129+2l} of each -- 24 of those rows live in the lane's registers (96 doubles = 192 VGPRs of the 256 a wave has at two
+// waves per SIMD), the other 8 in LDS (8 waves x 8 rows x 2 KB = 128 KB) next to the weight tables (24 KB).  A level is
+// then m x (128 FMAs from registers/LDS + 16 broadcast reads of the row weights) per lane and one block reduction; the
+// scalar control flow (scipy's brentq, the plug-in times) is run by thread 0 / thread a on state kept in LDS so that no
+// lane carries it across the passes.  Same formulas and evaluation points as k_kopt2d; only the order in which the
+// 65 536 products of a form are added differs (per column over the lane's 32 rows, then columns, lanes, waves).
+#define KR_F 256
+#define KR_T 512
+#define KR_REG 24  // rows of a wave's 32 held in registers
+#define KR_LDS 8   // ... and in LDS
+
+struct KresShared {
+    double part[8 * MAXF];
+    double times[8];
+    double scale[16];
+    double lev[6][MAXF];
+    double odd[4][MAXF];
+    double N, fallback_t;
+    double x, f;  // the evaluation point handed to the block, the function value handed back
+    double xpre, xcur, xblk, fpre, fcur, fblk, spre, scur, t_star;
+    double t;             // the time the current chain of levels is evaluated at
+    double p00;           // psi_00 (odd launch)
+    double ceven[5][MAXF];  // -2 cst(Ls) K(a) K(Ls-a)
+    double kodd[10], codd[3];
+    int status, done, it, do_corr;
+    int stage, Ls, Lmin;
+#ifdef KOPT_PROFILE
+    long long prof[8], wave_cycles[8];
+#endif
+};
+
+struct KresView {
+    double* wxs;   // MAXF x 256
+    double* wys;   // MAXF x 256
+    double* mt;    // 8 waves x KR_LDS rows x 256
+    double* logI;  // 256: log(k^2)
+    KresShared* sh;
+};
+
+__device__ __forceinline__ void kres_load(const double* __restrict__ M, double (&m)[KR_REG][4], double* mt, int w, int l) {
+    const double* base = M + (int64_t)(32 * w) * KR_F + 2 * l;
+#pragma unroll
+    for (int r = 0; r < KR_REG; ++r) {
+        const double2 a = *reinterpret_cast<const double2*>(base + r * KR_F);
+        const double2 b = *reinterpret_cast<const double2*>(base + r * KR_F + 128);
+        m[r][0] = a.x, m[r][1] = a.y, m[r][2] = b.x, m[r][3] = b.y;
+    }
+    double* row = mt + (w * KR_LDS) * KR_F + 2 * l;
+#pragma unroll
+    for (int r = 0; r < KR_LDS; ++r) {
+        const double2 a = *reinterpret_cast<const double2*>(base + (KR_REG + r) * KR_F);
+        const double2 b = *reinterpret_cast<const double2*>(base + (KR_REG + r) * KR_F + 128);
+        *reinterpret_cast<double2*>(row + r * KR_F) = a;
+        *reinterpret_cast<double2*>(row + r * KR_F + 128) = b;
+    }
+}
+
+// acc += y[lane J of the 16-lane row] * m : the row weight is broadcast inside the instruction (DPP row_newbcast), so a
+// form's 32 row weights cost two LDS reads per lane instead of sixteen wave-uniform ones in front of every eight FMAs
+// (measured: the FMA phase of a level fell from 10.7 to X k cycles; the compiler does not form DPP for f64 by itself).
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, double y, double m) {
+#ifdef KOPT_PROFILE  // pinned between the cycle-counter reads
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y), "v"(m), "n"(J));
+#else
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y), "v"(m), "n"(J));
+#endif
+}
+#define KR_ROW(R, C0, C1, C2, C3, M0, M1, M2, M3)        \
+    fmac_bc<(R) & 15>(C0, (R) < 16 ? y0 : y1, M0);      \
+    fmac_bc<(R) & 15>(C1, (R) < 16 ? y0 : y1, M1);      \
+    fmac_bc<(R) & 15>(C2, (R) < 16 ? y0 : y1, M2);      \
+    fmac_bc<(R) & 15>(C3, (R) < 16 ? y0 : y1, M3);
+#define KR_REG_PAIR(R)                                                         \
+    KR_ROW(R, c0, c1, c2, c3, m[R][0], m[R][1], m[R][2], m[R][3])              \
+    KR_ROW(R + 1, d0, d1, d2, d3, m[R + 1][0], m[R + 1][1], m[R + 1][2], m[R + 1][3])
+#define KR_LDS_LOAD(G)                                                                                  \
+    const double2 a0_##G = *reinterpret_cast<const double2*>(mt_l + (2 * (G)) * KR_F);                    \
+    const double2 b0_##G = *reinterpret_cast<const double2*>(mt_l + (2 * (G)) * KR_F + 128);              \
+    const double2 a1_##G = *reinterpret_cast<const double2*>(mt_l + (2 * (G) + 1) * KR_F);                \
+    const double2 b1_##G = *reinterpret_cast<const double2*>(mt_l + (2 * (G) + 1) * KR_F + 128);
+#define KR_LDS_USE(G)                                                                      \
+    KR_ROW(KR_REG + 2 * (G), c0, c1, c2, c3, a0_##G.x, a0_##G.y, b0_##G.x, b0_##G.y)       \
+    KR_ROW(KR_REG + 2 * (G) + 1, d0, d1, d2, d3, a1_##G.x, a1_##G.y, b1_##G.x, b1_##G.y)
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// v + v[lane ^ K] inside each half of the wave: ds_swizzle carries its pattern in the instruction (no address register,
+// no LDS memory touched), so the five steps of a form's lane sum ride on the LDS pipe between the FMAs of the NEXT form.
+template <int K>
+__device__ __forceinline__ double add_xor(double v) {
+    constexpr int pat = 0x1f | (K << 10);  // bit mode: and 0x1f, or 0, xor K
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+    return v + __hiloint2double(hi, lo);
+}
+// the same step cut in two so that its LDS round trip lies under a few rows of FMAs; sched_barrier pins both halves where
+// they are written (left alone, the scheduler starts the ladder at the top of the loop and waits for every step)
+#define KR_SW_ISSUE(K)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    slo = __builtin_amdgcn_ds_swizzle(__double2loint(vp), 0x1f | ((K) << 10));    \
+    shi = __builtin_amdgcn_ds_swizzle(__double2hiint(vp), 0x1f | ((K) << 10));    \
+    __builtin_amdgcn_sched_barrier(0);
+#define KR_SW_ADD()                            \
+    __builtin_amdgcn_sched_barrier(0);         \
+    vp = vp + __hiloint2double(shi, slo);      \
+    __builtin_amdgcn_sched_barrier(0);
+
+// mforms bilinear forms with the weights in wxs / wys: per-wave partial sums into sh->part (the caller adds the eight).
+// (Measured on the way here, cycles of block 0 per level: wave-uniform LDS reads of the row weights in front of every
+// eight FMAs 10.7 k; DPP broadcast 5.5 k but a DPP/readlane lane sum per form added 3.3 k of waiting at the barrier.)
+__device__ __forceinline__ void kres_forms(const double (&m)[KR_REG][4], KresView V, int mforms, int w, int l) {
+    static_assert(KR_REG == 24 && KR_LDS == 8, "the row lists below are written out for 24 + 8 rows");
+    const double* mt_l = V.mt + (w * KR_LDS) * KR_F + 2 * l;
+    RPROF_T0;
+#ifdef KOPT_PROFILE
+    const long long wave_t0 = clock64();
+#endif
+    const double* wy = V.wys + 32 * w + (l & 15);
+    double y0n = wy[0], y1n = wy[16];  // lane 16k + j holds the weights of rows j and 16 + j
+    double vp = 0;                      // the previous form's per-lane value, summed over the lanes during this form
+#pragma unroll 1
+    for (int q = 0; q <= mforms; ++q) {
+        if (q == mforms) {  // drain: the last form's lane sum
+            vp = add_xor<1>(vp), vp = add_xor<2>(vp), vp = add_xor<4>(vp), vp = add_xor<8>(vp), vp = add_xor<16>(vp);
+            vp = readlane_f64(vp, 0) + readlane_f64(vp, 32);
+            if (l == 0) V.sh->part[w * MAXF + q - 1] = vp;
+            break;
+        }
+        double y0 = y0n, y1 = y1n;
+        // a VALU write of a DPP source needs two wait states before the DPP read (the compiler does not see into the asm)
+        asm volatile("s_nop 1" : "+v"(y0), "+v"(y1));
+        // the rows in LDS are requested a group ahead of their use, between the register rows
+        KR_LDS_LOAD(0)
+        if (q + 1 < mforms) y0n = wy[(q + 1) * KR_F], y1n = wy[(q + 1) * KR_F + 16];
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        int slo, shi;
+        KR_SW_ISSUE(1)
+        KR_REG_PAIR(0) KR_REG_PAIR(2)
+        KR_SW_ADD() KR_SW_ISSUE(2)
+        KR_REG_PAIR(4)
+        KR_LDS_USE(0) KR_LDS_LOAD(1)
+        KR_REG_PAIR(6)
+        KR_SW_ADD() KR_SW_ISSUE(4)
+        KR_REG_PAIR(8) KR_REG_PAIR(10)
+        KR_LDS_USE(1) KR_LDS_LOAD(2)
+        KR_SW_ADD() KR_SW_ISSUE(8)
+        KR_REG_PAIR(12) KR_REG_PAIR(14)
+        KR_SW_ADD() KR_SW_ISSUE(16)
+        KR_REG_PAIR(16)
+        KR_LDS_USE(2) KR_LDS_LOAD(3)
+        const double2 xa = *reinterpret_cast<const double2*>(V.wxs + q * KR_F + 2 * l);
+        const double2 xb = *reinterpret_cast<const double2*>(V.wxs + q * KR_F + 128 + 2 * l);
+        KR_REG_PAIR(18)
+        KR_SW_ADD()
+        KR_REG_PAIR(20) KR_REG_PAIR(22)
+        KR_LDS_USE(3)
+        vp = readlane_f64(vp, 0) + readlane_f64(vp, 32);
+        if (l == 0 && q > 0) V.sh->part[w * MAXF + q - 1] = vp;
+        double v = (c0 + d0) * xa.x;
+        v = fma(c1 + d1, xa.y, v);
+        v = fma(c2 + d2, xb.x, v);
+        v = fma(c3 + d3, xb.y, v);
+        vp = v;
+    }
+    RPROF_ADD(2);
+#ifdef KOPT_PROFILE
+    if (l == 0 && blockIdx.x == 0) V.sh->wave_cycles[w] += clock64() - wave_t0;
+#endif
+}
+
+// scipy.optimize.brentq's loop (xtol = 1e-6, rtol = 4 eps, maxiter = 100) cut at its function evaluation: consumes the
+// value of the last evaluation (sh->f), leaves the next point in sh->x or sets sh->done.  Thread 0 only.
+__device__ void kres_brent_step(KresShared* S) {
+    const double xtol = 0.001 * 0.001, rtol = 4.0 * 2.220446049250313e-16;
+    if (S->it == -2) {  // f(0) arrived
+        S->fpre = S->f;
+        S->x = S->xcur;
+        S->it = -1;
+        return;
+    }
+    if (S->it == -1) {  // f(0.1) arrived
+        S->fcur = S->f;
+        const double fpre = S->fpre, fcur = S->fcur;
+        S->status = GD_OK;
+        if (fpre != fpre || fcur != fcur) {
+            S->status = GD_ERR_SOLVER, S->done = 1;
+        } else if (fpre == 0) {
+            S->t_star = S->xpre, S->done = 1;
+        } else if (fcur == 0) {
+            S->t_star = S->xcur, S->done = 1;
+        } else if (signbit(fpre) == signbit(fcur)) {
+            S->status = GD_ERR_SOLVER, S->done = 1;  // "f(a) and f(b) must have different signs"
+        }
+        if (S->done) return;
+        S->status = GD_ERR_SOLVER;  // convergence error unless the loop returns
+        S->it = 0;
+    } else {  // the evaluation that ended iteration it
+        S->fcur = S->f;
+        if (S->fcur != S->fcur) {  // NaN: scipy would wander to a convergence error
+            S->done = 1;
+            return;
+        }
+        S->it += 1;
+        if (S->it >= 100) {
+            S->done = 1;
+            return;
+        }
+    }
+    double xpre = S->xpre, xcur = S->xcur, xblk = S->xblk, fpre = S->fpre, fcur = S->fcur, fblk = S->fblk;
+    double spre = S->spre, scur = S->scur;
+    if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+        xblk = xpre;
+        fblk = fpre;
+        spre = scur = xcur - xpre;
+    }
+    if (fabs(fblk) < fabs(fcur)) {
+        xpre = xcur, xcur = xblk, xblk = xpre;
+        fpre = fcur, fcur = fblk, fblk = fpre;
+    }
+    const double delta = (xtol + rtol * fabs(xcur)) / 2;
+    const double sbis = (xblk - xcur) / 2;
+    if (fcur == 0 || fabs(sbis) < delta) {
+        S->t_star = xcur;
+        S->status = GD_OK;
+        S->done = 1;
+        return;
+    }
+    if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+        double stry;
+        if (xpre == xblk) {
+            stry = -fcur * (xcur - xpre) / (fcur - fpre);
+        } else {
+            const double dpre = (fpre - fcur) / (xpre - xcur);
+            const double dblk = (fblk - fcur) / (xblk - xcur);
+            stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+        }
+        if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
+            spre = scur;
+            scur = stry;
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+    } else {
+        spre = sbis;
+        scur = sbis;
+    }
+    xpre = xcur;
+    fpre = fcur;
+    if (fabs(scur) > delta)
+        xcur += scur;
+    else
+        xcur += (sbis > 0 ? delta : -delta);
+    S->xpre = xpre, S->xcur = xcur, S->xblk = xblk, S->fpre = fpre, S->fcur = fcur, S->fblk = fblk;
+    S->spre = spre, S->scur = scur;
+    S->x = xcur;
+}
+
+// One code instance of "a level" (plug-in times -> weight tables -> forms -> scaled sums) serves the even chains
+// 5 -> Lmin of every fixed-point evaluation, the final chain at t* and the odd chain 10 -> 4 on the power spectrum: the
+// kernel is a loop over levels whose next state (level below / next Brent point / final chain / odd chain / exit) is
+// decided by thread 0 at the end of a chain.  (With the chains inlined at their seven call sites the compiler carried
+// each site's hoisted addresses across the others and spilled ~90 VGPRs, a reload in nearly every basic block.)
+enum { KR_STAGE_BRENT = 0, KR_STAGE_FINAL = 1, KR_STAGE_ODD = 2, KR_STAGE_EXIT = 3 };
+
+// The scalar section between two levels is a real call: inlined, its pow() constants were hoisted out of the level loop
+// into VGPR pairs and, with 192 VGPRs pinned by the matrix, spilled -- ~18 scratch reloads in front of their uses, each a
+// round trip to memory on the serial path of the block (measured: 24 k cycles per level against 8 k).
+//
+// Called by threads 0..MAXF-1 after the per-wave partial sums of level Ls are in S->part.  Inside a chain, thread a adds
+// up the two forms it needs, ([a, Ls-a] and [a+1, Ls-a-1]; each by the same eight additions whoever computes it), and
+// leaves the plug-in time of form a of the level below (kde_bandwidth.py:191-193 / 215-219) -- no barrier between "sum"
+// and "time".  At the end of a chain thread 0 decides what follows: the next point of Brent's iteration, the final chain
+// at t*, or the end.
+template <bool ODD>
+__device__ __attribute__((noinline)) void kres_tail(KresShared* S, int Ls, int tid) {
+    const int mf = ODD ? Ls / 2 : Ls + 1;
+    double* row = ODD ? S->odd[Ls / 2 - 2] : S->lev[Ls];
+    const double sc = ODD ? S->scale[6 + Ls / 2] : S->scale[Ls];
+    auto level_value = [&](int q) {
+        double r = 0;
+        for (int i = 0; i < KR_T / 64; ++i) r += S->part[i * MAXF + q];
+        return ODD ? r * sc : (Ls & 1 ? -1.0 : 1.0) * r * sc / 4.0;
+    };
+    if (Ls > S->Lmin) {
+        const int nLs = Ls - (ODD ? 2 : 1), nmf = ODD ? nLs / 2 : nLs + 1;
+        if (tid < nmf) {
+            const double la = level_value(tid), la1 = level_value(tid + 1);
+            row[tid] = la;
+            if (tid == nmf - 1) row[tid + 1] = la1;
+            const double sum_func = la1 + la;
+            if (!ODD) {
+                S->times[tid] = pow(S->ceven[nLs][tid] / S->N / sum_func, 1.0 / (2.0 + nLs));
+            } else {
+                const int s0 = 1 + 2 * tid, s1 = nLs - s0;
+                S->times[tid] = pow(S->codd[nLs / 2 - 2] * S->p00 * S->kodd[s0] * S->kodd[s1] / (S->N * S->N) / (sum_func * sum_func),
+                                    1.0 / (3.0 + nLs));
+            }
+        }
+        if (tid == 0) S->Ls = nLs;
+        return;
+    }
+    if (tid != 0) return;
+    for (int q = 0; q < mf; ++q) row[q] = level_value(q);
+    if (!ODD && S->stage == KR_STAGE_BRENT) {
+        const double t = S->t;
+        const double sum_func = S->lev[2][0] + S->lev[2][2] + 2.0 * S->lev[2][1];
+        const double time = pow(2.0 * PI * S->N * sum_func, -1.0 / 3.0);
+        S->f = (t - time) / time;  // fixed_point_2d
+        kres_brent_step(S);
+        S->Ls = 5;
+        if (!S->done) {
+            S->t = S->x;
+        } else {
+            const bool have_fb = S->fallback_t > 0;
+            if (S->status == GD_OK) {
+                if (have_fb && S->t_star > 0.01 && S->t_star > 2 * S->fallback_t) S->t_star = S->fallback_t;  // kde_bandwidth.py:164-167
+            } else if (have_fb) {
+                S->t_star = S->fallback_t;  // kde_bandwidth.py:168-173
+                S->status = GD_OK;
+            }
+            S->t = S->t_star;
+            S->Lmin = S->do_corr ? 0 : 2;
+            S->stage = S->status == GD_OK ? KR_STAGE_FINAL : KR_STAGE_EXIT;
+        }
+        for (int q = 0; q < MAXF; ++q) S->times[q] = S->t;  // the top level of a chain runs at t
+    } else {
+        S->stage = KR_STAGE_EXIT;
+    }
+}
+
+// The weight tables of a level (psi / psi_odd of kde_bandwidth.py:198-229): x and y entries are separate work items, 2 mf 256
+// of them over the 512 threads.  A real call for the reason given at kres_tail: inlined, the constants of exp() stayed
+// in VGPRs across the level loop and pushed rows of the matrix into scratch, reloaded inside the FMA loop.
+template <bool ODD>
+__device__ __attribute__((noinline)) void kres_weights(double* wxs, double* wys, const double* logI, const double* times, int Ls,
+                                                       int mf, int tid) {
+    for (int e = tid; e < 2 * mf * KR_F; e += KR_T) {
+        const int isy = e & 1, idx = e >> 1, q = idx >> 8, k = idx & 255;
+        double v;
+        if (!ODD) {
+            v = 0;
+            if (k > 0) {
+                const double I = (double)k * (double)k;
+                v = exp(-I * (PISQ * times[q]) + logI[k] * (double)(isy ? Ls - q : q));
+            }
+        } else {
+            const double f = (k <= (KR_F - 1) / 2) ? (double)k : (double)(k - KR_F);
+            const int s0 = 1 + 2 * q;
+            v = exp(-(f * f) * (4.0 * PISQ * times[q])) * pow(f, (double)(isy ? Ls - s0 : s0));
+        }
+        (isy ? wys : wxs)[idx] = v;
+    }
+}
+
+// ODD = false: the fixed point and the even functionals on a2.  ODD = true (a second launch, pairs with do_corr only): the
+// odd functionals on the power spectrum at the t* and psi_00 the first launch left in `out`.  (One kernel that reloaded
+// its registers with the second matrix half-way kept neither in registers: 1200 VGPRs spilled.)
+// A level costs three barriers: [weight tables] | [forms -> per-wave partials] | [kres_tail] |.
+template <bool ODD>
+__global__ void __launch_bounds__(KR_T) k_kopt2d_res(const double* __restrict__ M_all, const KoptPair* __restrict__ pairs,
+                                                     double* __restrict__ out) {
+    extern __shared__ double lds[];
+    KresView V;
+    V.wxs = lds;
+    V.wys = lds + MAXF * KR_F;
+    V.mt = V.wys + MAXF * KR_F;
+    V.logI = V.mt + 8 * KR_LDS * KR_F;
+    V.sh = reinterpret_cast<KresShared*>(V.logI + KR_F);
+    KresShared* S = V.sh;
+    const int b = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double* o = out + (int64_t)b * KOPT_STRIDE;
+    if (ODD && !(pairs[b].do_corr && o[7] == (double)GD_OK)) return;  // uniform
+    double m[KR_REG][4];
+    RPROF_T0;
+    kres_load(M_all + (int64_t)(ODD ? pairs[b].pw_index : b) * KR_F * KR_F, m, V.mt, w, l);
+    // tables of the constants in the plug-in times, built with the operations (and their order) of kde_bandwidth.py:191-193
+    // and :215-219 so that times come out bit for bit as in k_kopt2d; their pow / sqrt run beside the matrix load
+    if (!ODD) {
+        if (threadIdx.x < 6) S->scale[threadIdx.x] = pow(PI, (double)(2 * threadIdx.x));  // pi^(2L)
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + 5 * MAXF) {  // level Ls = 0..4, form a <= Ls
+            const int Ls = (threadIdx.x - 64) / MAXF, a = (threadIdx.x - 64) % MAXF;
+            if (a <= Ls) {
+                const double cst = (1.0 + pow(0.5, (double)(Ls + 1))) / 3.0;
+                S->ceven[Ls][a] = -2.0 * cst * k_even(a) * k_even(Ls - a);
+            }
+        }
+        if (threadIdx.x >= 256) V.logI[threadIdx.x - 256] = log((double)(threadIdx.x - 256) * (double)(threadIdx.x - 256));
+    } else {
+        if (threadIdx.x >= 8 && threadIdx.x < 14) S->scale[threadIdx.x - 2] = pow(2.0 * PI, (double)(2 * (threadIdx.x - 8)));  // (2pi)^L
+        if (threadIdx.x >= 128 && threadIdx.x < 138) S->kodd[threadIdx.x - 128] = k_odd(threadIdx.x - 128);
+        if (threadIdx.x >= 192 && threadIdx.x < 195) {  // level Ls = 4, 6, 8
+            const int Ls = 4 + 2 * (threadIdx.x - 192);
+            S->codd[threadIdx.x - 192] = 8.0 * (1.0 - pow(2.0, (double)(-Ls - 1))) / 3.0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const KoptPair P = pairs[b];
+        S->N = P.N, S->fallback_t = P.fallback_t, S->do_corr = P.do_corr;
+        S->xpre = 0.0, S->xcur = 0.1, S->xblk = 0.0, S->fblk = 0.0, S->spre = 0.0, S->scur = 0.0, S->t_star = 0.0;
+        S->fpre = 0.0, S->fcur = 0.0;
+        S->status = GD_OK, S->done = 0, S->it = -2;
+        S->x = 0.0;
+        if (!ODD) {
+            S->stage = KR_STAGE_BRENT, S->Ls = 5, S->Lmin = 2, S->t = 0.0;
+        } else {
+            S->stage = KR_STAGE_ODD, S->Ls = 10, S->Lmin = 4, S->t = o[0];
+            S->p00 = o[4];
+        }
+        for (int q = 0; q < MAXF; ++q) S->times[q] = S->t;
+    }
+    for (int e = threadIdx.x; e < 6 * MAXF; e += KR_T) (&S->lev[0][0])[e] = 0.0;
+#ifdef KOPT_PROFILE
+    if (threadIdx.x < 8) S->prof[threadIdx.x] = 0, S->wave_cycles[threadIdx.x] = 0;
+#endif
+    __syncthreads();
+    RPROF_ADD(1);
+#pragma unroll 1
+    for (;;) {
+        const int stage = S->stage, Ls = S->Ls;
+        if (stage == KR_STAGE_EXIT) break;
+        const int mf = ODD ? Ls / 2 : Ls + 1;  // odd: forms [1+2q, Ls-1-2q]; even: [a, Ls-a]
+        kres_weights<ODD>(V.wxs, V.wys, V.logI, S->times, Ls, mf, threadIdx.x);
+        RPROF_ADD(0);
+        __syncthreads();
+        RPROF_ADD(5);
+        kres_forms(m, V, mf, w, l);
+        __syncthreads();
+        RPROF_ADD(3);
+        if (threadIdx.x < MAXF) kres_tail<ODD>(S, Ls, threadIdx.x);
+        RPROF_ADD(7);
+        __syncthreads();
+        RPROF_ADD(4);
+    }
+#ifdef KOPT_PROFILE
+    if (threadIdx.x < 8 && blockIdx.x == 0 && !ODD) g_prof[threadIdx.x] += S->prof[threadIdx.x], g_wave[threadIdx.x] += S->wave_cycles[threadIdx.x];
+#endif
+    if (threadIdx.x == 0) {
+        if (!ODD) {
+            const bool ok = S->status == GD_OK;
+            const bool dc = ok && S->do_corr;
+            o[0] = ok ? S->t_star : NAN;
+            o[1] = ok ? S->lev[2][0] : NAN, o[2] = ok ? S->lev[2][2] : NAN, o[3] = ok ? S->lev[2][1] : NAN;
+            o[4] = dc ? S->lev[0][0] : NAN;
+            o[5] = NAN, o[6] = NAN;
+            o[7] = (double)S->status;
+        } else {
+            o[5] = S->odd[0][0];  // [1,3]
+            o[6] = S->odd[0][1];  // [3,1]
+        }
+    }
+}
+
 // ---- get_h: closed-form bandwidths + the two TNC minimisations of the AMISE (kde_bandwidth.py:234-306) -------------
 // The AMISE is a function of ~9 scalars; scipy's TNC (tnc.c + finite-difference gradients) is ported in solvers.hpp and
 // pinned against scipy evaluation by evaluation.  One wavefront per pair, lane 0 runs the scalar optimiser (a few
@@ -853,19 +1324,34 @@ static int kopt_stage_a(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_v,
         tile_bytes = tile_bytes / ((size_t)F * 8) * ((size_t)F * 8);  // whole rows even when every segment is needed
     }
     const size_t lds = lds_base + tile_bytes;
-    GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, (int)(tile_bytes / 8), d_out);
+    if (F == KR_F && getenv("GDHIP_KOPT_STREAMED") == nullptr) {  // matrix resident on the CU (the switch: A/B tests)
+        const size_t lds_res = ((size_t)2 * MAXF * KR_F + (size_t)8 * KR_LDS * KR_F + KR_F) * 8 + sizeof(KresShared);
+        GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d_res<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res));
+        k_kopt2d_res<false><<<B, KR_T, lds_res, ctx->stream>>>(d_SQ, d_pairs, d_out);
+        if (nc > 0) {
+            GD_KERNEL_CHECK();
+            GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d_res<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res));
+            k_kopt2d_res<true><<<B, KR_T, lds_res, ctx->stream>>>(d_PW, d_pairs, d_out);
+        }
+    } else {
+        GD_HIP(hipFuncSetAttribute((const void*)k_kopt2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_kopt2d<<<B, KT, lds, ctx->stream>>>(d_SQ, d_PW, d_pairs, F, (int)(tile_bytes / 8), d_out);
+    }
     GD_KERNEL_CHECK();
 #ifdef KOPT_PROFILE
     {
         long long hp[8];
         GD_TRY(gd_stream_sync(ctx));
         GD_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp)));
-        fprintf(stderr, "kopt block 0 cycles (100 MHz clock): weights %lld  tile-load %lld  tile-fma %lld  reduce %lld  "
-                        "entry-barrier %lld  times/pow %lld | levels %lld  mean kmax %.1f\n",
-                hp[0], hp[1], hp[2], hp[3], hp[4], hp[7], hp[5], hp[5] ? (double)hp[6] / hp[5] : 0.0);
+        fprintf(stderr, "kopt block 0 cycles: weights %lld  tile-load %lld  tile-fma %lld  reduce %lld  "
+                        "entry-barrier %lld  times/pow %lld | levels (streamed) or barrier after the weights (resident) %lld  kmax sum %lld\n",
+                hp[0], hp[1], hp[2], hp[3], hp[4], hp[7], hp[5], hp[6]);
+        long long hw[8];
+        GD_HIP(hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wave), sizeof(hw)));
+        fprintf(stderr, "  forms per wave: %lld %lld %lld %lld %lld %lld %lld %lld\n", hw[0], hw[1], hw[2], hw[3], hw[4], hw[5], hw[6], hw[7]);
         memset(hp, 0, sizeof(hp));
         GD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), hp, sizeof(hp)));
+        GD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wave), hp, sizeof(hp)));
     }
 #endif
     return GD_OK;

@@ -495,6 +495,42 @@ def amise_within_oracle_range(triple, ensemble, psi, N, margin=10.0, floor=1e-7)
     return bool(excess <= max(margin * rng, floor)), float(excess), float(rng)
 
 
+ENSEMBLE_SCALES = (1e-15, 1e-14, 1e-13, 1e-12)
+
+
+def get_h_ensembles(psi, N, corr_in, scales=ENSEMBLE_SCALES):
+    """get_h_ensemble at each relative perturbation size in ``scales`` (a list of arrays, in that order)."""
+    return [get_h_ensemble(psi, N, corr_in, rel=r) for r in scales]
+
+
+def judge_triple(triple, psi, N, corr_in=None, ensembles=None, scales=ENSEMBLE_SCALES):
+    """
+    Is a bandwidth triple one of the outcomes the reference's get_h has for inputs that are equal to rounding?  The
+    reference's map psi -> (hx, hy, c) is chaotic for some pairs (TNC's path forks on the last bits of the AMISE), and 24
+    one-ulp perturbations sample only part of its outcomes: a kernel that adds the same 65 536 products in another order
+    lands on a triple those 24 may not contain.  So the ensemble is widened scale by scale -- +-1..12 x 1e-15, then x 1e-14,
+    1e-13, 1e-12, all far below the 1e-10 to which the functionals themselves are gated -- until the triple lies inside
+    the accumulated ensemble's spread (within_oracle_spread) or is as good in the reference's own objective
+    (amise_within_oracle_range); rejected if no scale admits it.
+    ``ensembles``: precomputed get_h_ensembles(...) (worker processes), else built here from ``corr_in``.
+    Returns a dict: ok, inside, amise_ok, excess, amise_excess, amise_range, moved (of the accumulated ensemble), scale
+    (the largest perturbation used), members.
+    """
+    acc = None
+    out = {}
+    for k, rel in enumerate(scales):
+        ens = ensembles[k] if ensembles is not None else get_h_ensemble(psi, N, corr_in, rel=rel)
+        acc = ens if acc is None else np.concatenate([acc, ens[1:]])
+        inside, excess = within_oracle_spread(triple, acc)
+        amise_ok, amise_excess, amise_range = amise_within_oracle_range(triple, acc, psi, N)
+        out = dict(ok=bool(inside or amise_ok), inside=bool(inside), amise_ok=bool(amise_ok), excess=excess,
+                   amise_excess=amise_excess, amise_range=amise_range,
+                   moved=float(np.max(np.abs(acc - acc[0])) / np.max(np.abs(acc[0]))), scale=rel, members=int(len(acc)))
+        if out["ok"]:
+            break
+    return out
+
+
 def get_h_from_psi(psi, N, corr_in, do_correlation, owner=None):
     """
     The scalar half of KernelOptimizer2D.get_h (kde_bandwidth.py:234-306) given psi = (p02, p20, p11, p00, p13, p31):

@@ -2,7 +2,8 @@
 Full-size parity census: EVERY pair of the C3 triangle (50 parameters, 1225 pairs, N = 1e7 by default) computed on the
 GPU through the product path and by the oracle (numpy / scipy restatement of the reference, oracle/kde_oracle.py) in a
 pool of host workers, compared pixel by pixel.  For every pair above 1e-6 the oracle's own sensitivity is examined: its
-get_h on 24 copies of its OWN functionals perturbed by +-1..12e-15 (the ensemble), whether the device's bandwidth
+get_h on 24 copies of its OWN functionals perturbed by +-1..12e-15 (the ensemble; widened to 1e-14 .. 1e-12 only if the
+triple is not admitted, ko.judge_triple), whether the device's bandwidth
 triple lies inside that spread, how far it is from the NEAREST ensemble member, and whether its AMISE is as good.
 
     python scripts/parity_census.py [--nsamples 10000000] [--nparams 50] [--workers 0] [--weighted] [--out profiles/...json]
@@ -82,11 +83,15 @@ def pair_task(t):
         row["t_star_rel_err"] = float(abs(kopt[0] - tr["t_star"]) / abs(tr["t_star"]))
     if row["err"] > 1e-6 and row["tnc"] and kopt is not None:
         psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-        ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
         trip = np.asarray(kopt[8:11], dtype=float)
-        row["oracle_moves_by"] = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
-        row["inside_oracle_spread"], row["excess_over_spread"] = ko.within_oracle_spread(trip, ens)
-        row["amise_ok"], row["amise_excess"], row["amise_range"] = ko.amise_within_oracle_range(trip, ens, psi, tr["opt_N"])
+        ensembles = ko.get_h_ensembles(psi, tr["opt_N"], tr["opt_corr"])
+        verdict = ko.judge_triple(trip, psi, tr["opt_N"], ensembles=ensembles)
+        nscales = ko.ENSEMBLE_SCALES.index(verdict["scale"]) + 1
+        ens = np.concatenate([ensembles[0]] + [e[1:] for e in ensembles[1:nscales]])  # what the verdict was reached on
+        row["oracle_moves_by"] = verdict["moved"]
+        row["inside_oracle_spread"], row["excess_over_spread"] = verdict["inside"], verdict["excess"]
+        row["amise_ok"], row["amise_excess"], row["amise_range"] = verdict["amise_ok"], verdict["amise_excess"], verdict["amise_range"]
+        row["ensemble_perturbation"], row["ensemble_members"] = verdict["scale"], verdict["members"]
         scale = np.array([np.max(np.abs(ens[:, 0])), np.max(np.abs(ens[:, 1])), 1.0])
         d = np.max(np.abs(ens - trip) / scale, axis=1)
         row["nearest_member_distance"] = float(np.min(d))  # largest relative component difference to the closest member

@@ -294,13 +294,17 @@ def root_constructor_checks(tmp_path, factory=None):
     assert excl.numrows == len(weights) - (offsets[2] - offsets[1]) and len(excl.chain_offsets) == 3
 
 
-def assert_grid_or_oracle_ensemble(d, o, tr, key, tol=1e-6, cap=5e-4):
+def assert_grid_or_oracle_ensemble(d, o, tr, key, tol=1e-6, cap=5e-4, oracle_at=None):
     """
     The 2D grid gate used wherever a pair may go through TNC: ``d`` the device's Density2D,
     ``o`` / ``tr`` the oracle's result and trace.  Either the grids agree to ``tol`` of the grid maximum, or the pair
-    must EARN the loose gate: it went through TNC, the oracle itself moves by more than ``tol`` under +-1..12e-15
-    perturbations of its own functionals (get_h_ensemble), the device's raw bandwidth triple lies inside that ensemble's
-    range or is as good in the reference's own objective (AMISE), and the grids still agree to ``cap``.
+    must EARN the loose gate: it went through TNC, the oracle itself moves by more than ``tol`` under rounding-size
+    perturbations of its own functionals (ko.judge_triple: +-1..12e-15, widened up to 1e-12 only if needed), the device's
+    raw bandwidth triple lies inside that ensemble's range or is as good in the reference's own objective (AMISE), and
+    the grids still agree to ``cap``.  With ``oracle_at`` (a callable: bandwidth triple -> the oracle's grid computed with
+    that triple instead of its own, OracleSamples.density_2d(..., _bandwidths=)) the cap is replaced by the closed loop:
+    the oracle's grid AT THE DEVICE'S TRIPLE equals the device's grid to ``tol`` -- everything but the triple is then
+    pinned at the strict tolerance, and the triple by the ensemble.
     Returns (error, loose?).
     """
     from oracle import kde_oracle as ko
@@ -311,11 +315,12 @@ def assert_grid_or_oracle_ensemble(d, o, tr, key, tol=1e-6, cap=5e-4):
         return err, False
     assert "p_13" in tr and d.kopt is not None, (key, "grids differ by %.2e and the pair did not go through TNC" % err)
     psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-    ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
-    moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
-    assert moved > tol, (key, "grids differ by %.2e but the oracle is stable here (moves %.2e)" % (err, moved))
-    inside, excess = ko.within_oracle_spread(d.kopt[8:11], ens)
-    amise_ok, amise_excess, amise_range = ko.amise_within_oracle_range(d.kopt[8:11], ens, psi, tr["opt_N"])
-    assert inside or amise_ok, (key, "device triple outside the oracle's spread and worse in AMISE", d.kopt[8:11], excess, amise_excess)
-    assert err < cap, (key, err)
+    verdict = ko.judge_triple(d.kopt[8:11], psi, tr["opt_N"], tr["opt_corr"])
+    assert verdict["moved"] > tol, (key, "grids differ by %.2e but the oracle is stable here (moves %.2e)" % (err, verdict["moved"]))
+    assert verdict["ok"], (key, "device triple outside the oracle's spread and worse in AMISE", d.kopt[8:11], verdict)
+    if oracle_at is not None:
+        err_at = float(np.max(np.abs(d.P - oracle_at(d.bandwidth))))
+        assert err_at <= tol, (key, "oracle grid at the device's bandwidth triple", err_at)
+    else:
+        assert err < cap, (key, err)
     return err, True

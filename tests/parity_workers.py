@@ -26,5 +26,6 @@ def oracle_pair(task):
     if out["tnc"]:
         psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
         out["t_star"], out["psi"], out["opt_N"] = tr["t_star"], psi, tr["opt_N"]
-        out["ensemble"] = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
+        out["ensembles"] = ko.get_h_ensembles(psi, tr["opt_N"], tr["opt_corr"])  # one per scale of ko.ENSEMBLE_SCALES
+        out["ensemble"] = out["ensembles"][0]
     return out

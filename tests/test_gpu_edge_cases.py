@@ -35,7 +35,7 @@ def test_small_and_ragged_row_counts(N):
         tr = {}
         o2 = orc.density_2d(0, 1, trace=tr)
         # unbounded pair: the TNC path -- 1e-6, or the oracle-ensemble criterion where the reference's own map is chaotic
-        gu.assert_grid_or_oracle_ensemble(d2, o2, tr, "N=%d" % N)
+        gu.assert_grid_or_oracle_ensemble(d2, o2, tr, "N=%d" % N, oracle_at=lambda bw: orc.density_2d(0, 1, _bandwidths=bw)["P"])
 
 
 def test_single_column_and_unknown_names():

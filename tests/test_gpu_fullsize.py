@@ -136,10 +136,9 @@ def test_c3_full_shape_determinism_and_one_pair_per_census_class_against_the_ora
             assert np.max(np.abs(np.asarray(d.kopt[1:7]) - r["psi"]) / np.abs(r["psi"])) <= 1e-10
         if err >= 1e-6:
             assert r["tnc"], (r["pair"], err)
-            ens = r["ensemble"]
-            assert np.max(np.abs(ens - ens[0])) > 1e-6 * np.max(np.abs(ens[0])), (r["pair"], "oracle stable, device off", err)
-            assert (ko.within_oracle_spread(d.kopt[8:11], ens)[0]
-                    or ko.amise_within_oracle_range(d.kopt[8:11], ens, r["psi"], r["opt_N"])[0]), (r["pair"], d.kopt[8:11], ens.min(axis=0), ens.max(axis=0))
+            verdict = ko.judge_triple(d.kopt[8:11], r["psi"], r["opt_N"], ensembles=r["ensembles"])
+            assert verdict["moved"] > 1e-6, (r["pair"], "oracle stable, device off", err, verdict)
+            assert verdict["ok"], (r["pair"], d.kopt[8:11], verdict)
             assert err < 5e-4, (r["pair"], err)
     _report("C3_census_parity", dict(classes=len(klass), pairs_checked=len(results), per_pair=report,
                                      identical_reruns=len(pairs)))
@@ -227,7 +226,8 @@ def test_weighted_full_size_properties():
             orc.pars[k].N_eff_kde = par[(a, b)[k]].N_eff_kde  # (checked to 1e-9 elsewhere; its FFT route costs ~10 s per column here)
         tr = {}
         o = orc.density_2d(0, 1, trace=tr)
-        err, loose = gu.assert_grid_or_oracle_ensemble(dd, o, tr, "weighted %s-%s" % (names[a], names[b]))
+        err, loose = gu.assert_grid_or_oracle_ensemble(dd, o, tr, "weighted %s-%s" % (names[a], names[b]),
+                                                       oracle_at=lambda bw: orc.density_2d(0, 1, _bandwidths=bw)["P"])
         _report("weighted_2d_full_size_%d_%d" % (a, b), dict(max_abs_dP=err, loose=loose, N=N_FULL))
 
 
@@ -274,11 +274,9 @@ def test_full_size_grids_match_the_oracle(big):
             assert np.max(np.abs(d.P - o["P"])) < 1e-6, (names[ucols[a]], names[ucols[b]])
         else:
             psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
-            ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
-            moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
-            assert moved > 1e-6, (names[ucols[a]], names[ucols[b]], bw_err, moved)
-            assert (ko.within_oracle_spread(d.kopt[8:11], ens)[0]
-                    or ko.amise_within_oracle_range(d.kopt[8:11], ens, psi, tr["opt_N"])[0]), (d.kopt[8:11], ens.min(axis=0), ens.max(axis=0))
+            verdict = ko.judge_triple(d.kopt[8:11], psi, tr["opt_N"], tr["opt_corr"])
+            assert verdict["moved"] > 1e-6, (names[ucols[a]], names[ucols[b]], bw_err, verdict)
+            assert verdict["ok"], (d.kopt[8:11], verdict)
             assert np.max(np.abs(d.P - o["P"])) < 5e-4
     print("full-size unbounded TNC pairs on the strict gate: %d of 2" % strict)
 

@@ -151,3 +151,23 @@ def test_mask_moments_evaluated_in_their_consumers_equal_the_array_form(monkeypa
         assert any(p.has_limits for p in mc_of(recipe).paramNames.names) or True
         for k, (a, b) in enumerate(zip(got, ref)):
             assert np.array_equal(a.P, b), (kw, k, float(np.max(np.abs(a.P - b))))
+
+
+def test_periodic_pairs_in_both_orientations_repeatedly(monkeypatch, zoo):
+    """A periodic parameter as x of one pair and as y of the next (getdist_test.py:181-225's angle / radius set): the two
+    pairs cannot share a convolution batch (circular along different axes), so each is gathered out of the class's
+    histogram block before its rocFFT frames -- and gd_gather_items once kept its index list at the head of the very
+    block it gathered into: the second pair came out as noise in a few percent of the calls.  Forty calls of either
+    grid size, every grid `array_equal` to the Python-planned route's."""
+    from getdist_amd.mcsamples import MCSamples
+
+    fx = zoo["periodic"]
+    build = lambda: MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    for kw in fx["kw2"]:
+        for pairs in (fx["pairs"], fx["pairs"][::-1]):
+            native, plain, mc = both_routes(monkeypatch, build, lambda m: m.get2DDensities(pairs, **kw))
+            same(native, plain)
+            for rep in range(40):
+                again = mc.get2DDensities(pairs, **kw)
+                for a, b in zip(again, plain):
+                    assert np.array_equal(a.P, b.P), (kw, pairs, rep, float(np.max(np.abs(a.P - b.P))))

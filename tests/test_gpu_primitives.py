@@ -582,3 +582,74 @@ def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
         assert np.array_equal(d_P.to_host((B, F, F)), out["lds"][0])
     finally:
         ctx.close()
+
+
+def test_resident_fixed_point_kernel_equals_the_streamed_one(monkeypatch):
+    """gd_kopt2d at F = 256: k_kopt2d_res (matrix resident in registers + LDS, one launch for the even functionals and one
+    for the odd) against k_kopt2d (matrix streamed through LDS, GDHIP_KOPT_STREAMED=1) on random histograms -- peaked,
+    broad, bimodal, nearly empty, a delta spike, a flat histogram (every coefficient but the mean vanishes: NaN function
+    values, so the fallback time, or the solver status without one), mixed do_corr.  Same evaluation points and formulas, another summation order: t* and the even functionals to
+    1e-12, the odd ones (alternating sums over the power spectrum) to 1e-8; status words and NaN pattern equal.
+    Reference: kde_bandwidth.py:146-229."""
+    from getdist_amd._lib import Context
+
+    F = 256
+    r = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:F, 0:F]
+    hists = []
+    for b in range(40):
+        cx, cy = r.uniform(0.25, 0.75, 2) * F
+        sx, sy = r.uniform(0.02, 0.25, 2) * F
+        rho = r.uniform(-0.8, 0.8)
+        u, v = (xx - cx) / sx, (yy - cy) / sy
+        lam = np.exp(-0.5 * (u * u - 2 * rho * u * v + v * v) / (1 - rho * rho))
+        if b % 5 == 0:  # a second mode
+            lam = lam + 0.6 * np.exp(-0.5 * (((xx - 0.3 * F) / (0.05 * F)) ** 2 + ((yy - 0.7 * F) / (0.08 * F)) ** 2))
+        lam *= 10.0 ** r.uniform(3.0, 6.5) / lam.sum()
+        hists.append(r.poisson(lam).astype(np.float64))
+    spike = np.zeros((F, F))
+    spike[100, 57] = 1e5
+    hists += [spike, np.ones((F, F)), np.ones((F, F))]
+    sparse = np.zeros((F, F))
+    sparse[r.integers(0, F, 40), r.integers(0, F, 40)] = 1.0
+    hists.append(sparse)
+    hists = np.array(hists)
+    B = len(hists)
+    neff = 10.0 ** r.uniform(2.5, 6.5, B)
+    do_corr = (np.arange(B) % 3 != 0).astype(np.int32)
+    fallback = np.full(B, 1e-4)
+    fallback[-2] = 0.0  # the second flat histogram has no fallback: its status word says so
+    corr = r.uniform(-0.6, 0.6, B)
+    ctx = Context(0)
+    try:
+        ctx.upload(r.standard_normal((1000, 2)), None)
+        d_hist = ctx.alloc(hists.nbytes)
+        d_hist.from_host(hists)
+        out = {}
+        for mode in ("resident", "streamed", "resident_again"):
+            if mode == "streamed":
+                monkeypatch.setenv("GDHIP_KOPT_STREAMED", "1")
+            else:
+                monkeypatch.delenv("GDHIP_KOPT_STREAMED", raising=False)
+            out[mode] = ctx.kopt2d(d_hist, B, F, neff, do_corr, fallback, corr).copy()
+        a, s = out["resident"], out["streamed"]
+        assert np.array_equal(a, out["resident_again"], equal_nan=True)  # deterministic
+        assert np.array_equal(a[:, 7], s[:, 7]) and np.array_equal(np.isnan(a[:, :7]), np.isnan(s[:, :7]))
+        assert a[-2, 7] != 0 and a[-3, 7] == 0 and a[-3, 0] == 1e-4 and np.sum(a[:, 7] == 0) >= B - 2, a[-4:, :8]
+        ok = a[:, 7] == 0
+
+        def close(x, y, tol):  # relative, and equal where the streamed kernel says exactly zero or infinity
+            with np.errstate(invalid="ignore"):
+                return bool(np.all((np.abs(x - y) <= tol * np.abs(y)) | (x == y) | (np.isnan(x) & np.isnan(y))))
+
+        assert close(a[ok, 0], s[ok, 0], 1e-12), (a[ok, 0], s[ok, 0])
+        assert close(a[ok, 1:4], s[ok, 1:4], 1e-12), (a[ok, 1:4], s[ok, 1:4])
+        dc = ok & (do_corr == 1)
+        assert np.all(np.isnan(a[ok & (do_corr == 0), 4:7]))
+        assert close(a[dc, 4], s[dc, 4], 1e-12)
+        # (at t* = 0, the spike, the odd sums have no Gaussian factor: sums of +-f^10 over a flat spectrum that cancel to
+        # ~1e-20 of their terms -- any order of additions gives another remainder)
+        dc &= a[:, 0] > 0
+        assert close(a[dc, 5:7], s[dc, 5:7], 1e-8), (a[dc, 5:7], s[dc, 5:7])
+    finally:
+        ctx.close()
