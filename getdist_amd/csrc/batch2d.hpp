@@ -1156,6 +1156,12 @@ struct Call {
                     size_t want = 2;  // GDHIP_KOPT_PARTS: tuning knob
                     if (const char* e = getenv("GDHIP_KOPT_PARTS")) want = (size_t)std::max(1, atoi(e));
                     part = std::max<size_t>((size_t)s_kopt_split_min(), (total + want - 1) / want);
+                    // the fixed-point kernel holds one pair per CU (its matrix lives in the CU's registers and LDS): parts of
+                    // a whole number of rounds over the 256 CUs leave no extra, mostly empty round (1279 pairs as 640 + 639
+                    // are 3 + 3 rounds, as 512 + 767 they are 2 + 3)
+                    size_t align = 256;  // GDHIP_KOPT_PART_ALIGN: tuning knob (0: off)
+                    if (const char* e = getenv("GDHIP_KOPT_PART_ALIGN")) align = (size_t)std::max(0, atoi(e));
+                    if (align > 1 && F == 256 && part > align) part = std::max<size_t>(align, (part + align / 2 - 1) / align * align);
                 }
                 for (size_t c0 = 0, first = 1; c0 < pos_C.size(); first = 0) {
                     Launch L;

@@ -882,8 +882,14 @@ static int next_fft_size(int n) {
 // circular on the folded (Ny x Nx) grid -- including along a non-periodic axis, which the reference also wraps
 // (convolve.py:226-251 takes the FFT at the array size without zero-padding); mask-side 'valid' convolutions use the
 // ordinary zero-padded frames.  mcsamples.py:1874-1976.
+// With an explicit prior mask (`ov`, one pair: a user's mask_function, mcsamples.py:1907-1919) the mask moments are summed
+// directly over the (F + 2w)^2 array the caller edited -- 'valid' and not circular, exactly as the reference convolves
+// the mask (:1924-1951, :1967) while the histogram side stays circular -- and the excluded region is exempted from the
+// a00 division (:1973-1976) and zeroed at the end (:1978-1979).
 static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, const std::vector<D2Pair>& hp, int maxw,
-                              int per, int bco, int mbc, double* d_P, int32_t* status_out, bool wait) {
+                              int per, int bco, int mbc, double* d_P, int32_t* status_out, bool wait,
+                              const MaskOv* ov = nullptr) {
+    GD_REQUIRE(!ov || B == 1, "an explicit prior mask belongs to one pair");
     const bool px = per & 16, py = per & 32, both = px && py;
     const int Nx = px ? F - 1 : F, Ny = py ? F - 1 : F;
     GD_REQUIRE(2 * maxw + 1 <= Nx && 2 * maxw + 1 <= Ny, "window wider than the periodic grid");
@@ -900,7 +906,8 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const bool need_S = do_bc || do_mbc;
+    const bool need_S = (do_bc || do_mbc) && !ov;
+    const int64_t o_kwin = take(ov ? (int64_t)(2 * maxw + 1) * (2 * maxw + 1) * 8 : 0);
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_status = take((int64_t)B * 4), o_RC = take(B * NN * 8), o_ROc = take(B * NN * 8),
                   o_ZHc = take(B * NC * 16), o_ZWc = take(B * NC * 16), o_ZKc = take(B * NC * 16),
@@ -915,6 +922,16 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
     double* d_wsum = (double*)(base + o_wsum);
     double* d_mx = (double*)(base + o_mx);
     int* d_status = (int*)(base + o_status);
+    double* d_kwin = (double*)(base + o_kwin);
+    // a mask moment of the explicit mask: dst = conv(mask, Win x^px y^py, 'valid')
+    auto direct_moment = [&](const double* mask, int px_, int py_, double* dst) -> int {
+        if (!mask) return gd_fail(ctx, GD_ERR_BADARG, "explicit mask missing for a requested correction");
+        k_moment_window<<<64, 256, 0, ctx->stream>>>(d_pairs, d_wsum, px_, py_, d_kwin);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_moment_window launch failed");
+        k_mask_moment_direct<<<1024, 256, 0, ctx->stream>>>(d_kwin, mask, F, maxw, dst);
+        if (hipGetLastError() != hipSuccess) return gd_fail(ctx, GD_ERR_HIP, "k_mask_moment_direct launch failed");
+        return GD_OK;
+    };
     double *RC = (double*)(base + o_RC), *ROc = (double*)(base + o_ROc), *RF = (double*)(base + o_RF),
            *RO = (double*)(base + o_RO), *arr = (double*)(base + o_arr), *d_a00m = (double*)(base + o_a00m),
            *d_conv = (double*)(base + o_conv), *d_box = (double*)(base + o_box);
@@ -968,10 +985,14 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         A.a10 = A.a01 = A.a20 = A.a02 = A.a11 = A.xP = A.yP = nullptr;
         k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
         GD_KERNEL_CHECK();
-        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
-        GD_KERNEL_CHECK();
-        if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
-        if ((rc = mask_conv(ZM, ZW, A.a00))) return rc;
+        if (ov) {
+            if ((rc = direct_moment(ov->d_mask_bc, 0, 0, A.a00))) return rc;
+        } else {
+            k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 0, 1, RF);
+            GD_KERNEL_CHECK();
+            if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
+            if ((rc = mask_conv(ZM, ZW, A.a00))) return rc;
+        }
         if (bco == 1) {
             A.a10 = arr + 1 * B * FF, A.a01 = arr + 2 * B * FF, A.a20 = arr + 3 * B * FF, A.a02 = arr + 4 * B * FF,
             A.a11 = arr + 5 * B * FF, A.xP = arr + 6 * B * FF, A.yP = arr + 7 * B * FF;
@@ -982,10 +1003,14 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
             } moms[5] = {{1, 0, A.a10, A.xP}, {0, 1, A.a01, A.yP}, {2, 0, A.a20, nullptr}, {0, 2, A.a02, nullptr},
                          {1, 1, A.a11, nullptr}};
             for (const Mom& m : moms) {
-                k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, m.px, m.py, RF);
-                GD_KERNEL_CHECK();
-                if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZK))) return rc;
-                if ((rc = mask_conv(ZM, ZK, m.mask_dst))) return rc;
+                if (ov) {
+                    if ((rc = direct_moment(ov->d_mask_bc, m.px, m.py, m.mask_dst))) return rc;
+                } else {
+                    k_fill_window<<<gS, 256, 0, ctx->stream>>>(d_pairs, d_wsum, S, m.px, m.py, RF);
+                    GD_KERNEL_CHECK();
+                    if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZK))) return rc;
+                    if ((rc = mask_conv(ZM, ZK, m.mask_dst))) return rc;
+                }
                 if (m.hist_dst) {
                     k_fill_window_rect<<<gN, 256, 0, ctx->stream>>>(d_pairs, d_wsum, Ny, Nx, m.px, m.py, RC);
                     GD_KERNEL_CHECK();
@@ -998,10 +1023,14 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
         GD_KERNEL_CHECK();
     }
     if (do_mbc) {
-        k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 1, do_bc ? 1 : 0, RF);
-        GD_KERNEL_CHECK();
-        if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
-        if ((rc = mask_conv(ZM, ZW, d_a00m))) return rc;
+        if (ov) {
+            if ((rc = direct_moment(ov->d_mask_mbc, 0, 0, d_a00m))) return rc;
+        } else {
+            k_fill_mask<<<gS, 256, 0, ctx->stream>>>(d_pairs, F, S, 1, do_bc ? 1 : 0, RF);
+            GD_KERNEL_CHECK();
+            if ((rc = gd_fft_r2c_2d(ctx, S, S, B, RF, ZM))) return rc;
+            if ((rc = mask_conv(ZM, ZW, d_a00m))) return rc;
+        }
         for (int round = 0; round < mbc; ++round) {
             k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
             GD_KERNEL_CHECK();
@@ -1011,9 +1040,16 @@ static int density2d_periodic(gd_ctx* ctx, int B, int F, const double* d_hist, c
             GD_KERNEL_CHECK();
             if ((rc = gd_fft_r2c_2d(ctx, Ny, Nx, B, RC, ZKc))) return rc;
             if ((rc = circ_conv(ZKc, ZWc, d_conv))) return rc;
-            k_mbc_update<<<2048, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
+            if (ov && ov->d_zero)
+                k_mbc_update_masked<<<2048, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, ov->d_zero, B * FF);
+            else
+                k_mbc_update<<<2048, 256, 0, ctx->stream>>>(d_P, d_conv, d_a00m, B * FF);
             GD_KERNEL_CHECK();
         }
+    }
+    if (ov && ov->d_zero) {  // bins2D[bool_mask] = 0  (mcsamples.py:1978-1979)
+        k_zero_masked<<<2048, 256, 0, ctx->stream>>>(d_P, ov->d_zero, B * FF);
+        GD_KERNEL_CHECK();
     }
     k_pair_max<<<dim3(PM_PARTS, B), 256, 0, ctx->stream>>>(d_P, (int)FF, d_mx);
     GD_KERNEL_CHECK();
@@ -1064,14 +1100,14 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     }
     const int per = flags[0] & 48;
     if (per) {
-        GD_REQUIRE(!ov, "explicit prior masks are not supported on periodic axes");
         if (hist_index) {  // the periodic route reads its batch contiguously: gather first (rare)
+            GD_REQUIRE(!ov, "an explicit prior mask comes with its pair's histogram, not with an index list");
             double* d_sub = (double*)gd_scratch2(ctx, (int64_t)B * F * F * 8);
             if (!d_sub) return GD_ERR_NOMEM;
             GD_TRY(gd_gather_items(ctx, d_sub, d_hist, hist_index, B, (int64_t)F * F * 8));
             return density2d_periodic(ctx, B, F, d_sub, hp, maxw, per, bco, mbc, d_P, status_out, wait);
         }
-        return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out, wait);
+        return density2d_periodic(ctx, B, F, d_hist, hp, maxw, per, bco, mbc, d_P, status_out, wait, ov);
     }
     const bool do_bc = any_limits && bco >= 0;
     const int S = next_fft_size(F + 2 * maxw);

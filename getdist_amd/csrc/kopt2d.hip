@@ -1019,9 +1019,12 @@ __device__ __attribute__((noinline)) void kres_tail(KresShared* S, int Ls, int t
 // in VGPRs across the level loop and pushed rows of the matrix into scratch, reloaded inside the FMA loop.
 template <bool ODD>
 __device__ __attribute__((noinline)) void kres_weights(double* wxs, double* wys, const double* logI, const double* times, int Ls,
-                                                       int mf, int tid) {
-    for (int e = tid; e < 2 * mf * KR_F; e += KR_T) {
-        const int isy = e & 1, idx = e >> 1, q = idx >> 8, k = idx & 255;
+                                                       int mf, int top, int tid) {
+    // at the top level of a chain every form runs at the same time t, and the y exponent of form q is the x exponent of
+    // form mf-1-q: the y tables are the x tables in reverse order (the same expression, the same bits) -- half the exp()
+    const int items = top ? mf * KR_F : 2 * mf * KR_F;
+    for (int e = tid; e < items; e += KR_T) {
+        const int isy = top ? 0 : (e & 1), idx = top ? e : (e >> 1), q = idx >> 8, k = idx & 255;
         double v;
         if (!ODD) {
             v = 0;
@@ -1034,7 +1037,12 @@ __device__ __attribute__((noinline)) void kres_weights(double* wxs, double* wys,
             const int s0 = 1 + 2 * q;
             v = exp(-(f * f) * (4.0 * PISQ * times[q])) * pow(f, (double)(isy ? Ls - s0 : s0));
         }
-        (isy ? wys : wxs)[idx] = v;
+        if (top) {
+            wxs[idx] = v;
+            wys[(mf - 1 - q) * KR_F + k] = v;
+        } else {
+            (isy ? wys : wxs)[idx] = v;
+        }
     }
 }
 
@@ -1105,7 +1113,7 @@ __global__ void __launch_bounds__(KR_T) k_kopt2d_res(const double* __restrict__ 
         const int stage = S->stage, Ls = S->Ls;
         if (stage == KR_STAGE_EXIT) break;
         const int mf = ODD ? Ls / 2 : Ls + 1;  // odd: forms [1+2q, Ls-1-2q]; even: [a, Ls-a]
-        kres_weights<ODD>(V.wxs, V.wys, V.logI, S->times, Ls, mf, threadIdx.x);
+        kres_weights<ODD>(V.wxs, V.wys, V.logI, S->times, Ls, mf, Ls == (ODD ? 10 : 5), threadIdx.x);
         RPROF_ADD(0);
         __syncthreads();
         RPROF_ADD(5);

@@ -415,27 +415,31 @@ def _g2_independence_vs_markov(tran2, thin_rows):
 
 
 def _set_edge_mask_2d(parx, pary, prior_mask, winw):
-    """mcsamples.py:1688-1703 (non-periodic axes): half weight on a limit's edge bins, zero beyond"""
-    if parx.has_limits_bot:
-        prior_mask[:, winw] /= 2
+    """mcsamples.py:1688-1703: half weight on a limit's edge bins, zero beyond -- on non-periodic axes only"""
+    if not parx.periodic:
+        if parx.has_limits_bot:
+            prior_mask[:, winw] /= 2
+            prior_mask[:, :winw] = 0
+        if parx.has_limits_top:
+            prior_mask[:, -(winw + 1)] /= 2
+            prior_mask[:, -winw:] = 0
+    if not pary.periodic:
+        if pary.has_limits_bot:
+            prior_mask[winw, :] /= 2
+            prior_mask[:winw] = 0
+        if pary.has_limits_top:
+            prior_mask[-(winw + 1), :] /= 2
+            prior_mask[-winw:, :] = 0
+
+
+def _set_all_edge_mask_2d(prior_mask, winw, periodic_x=False, periodic_y=False):
+    """mcsamples.py:1705-1712: zero the padding margins along non-periodic axes"""
+    if not periodic_x:
         prior_mask[:, :winw] = 0
-    if parx.has_limits_top:
-        prior_mask[:, -(winw + 1)] /= 2
         prior_mask[:, -winw:] = 0
-    if pary.has_limits_bot:
-        prior_mask[winw, :] /= 2
+    if not periodic_y:
         prior_mask[:winw] = 0
-    if pary.has_limits_top:
-        prior_mask[-(winw + 1), :] /= 2
         prior_mask[-winw:, :] = 0
-
-
-def _set_all_edge_mask_2d(prior_mask, winw):
-    """mcsamples.py:1705-1712 (non-periodic axes): zero the padding margins"""
-    prior_mask[:, :winw] = 0
-    prior_mask[:, -winw:] = 0
-    prior_mask[:winw] = 0
-    prior_mask[-winw:, :] = 0
 
 
 class MCSamples:
@@ -2188,8 +2192,6 @@ class MCSamples:
 
     def get2DDensityGridData(self, j, j2, num_plot_contours=None, get_density=False, meanlikes=False,
                              mask_function=None, **kwargs):
-        if mask_function is not None and meanlikes:
-            raise NotImplementedError("mask_function together with meanlikes")
         if self.needs_update:
             self.updateBaseStatistics()
         j = self._parAndNumber(j)[0]
@@ -2979,8 +2981,6 @@ class MCSamples:
                 if mask_function is not None:
                     (pos, k), = sel
                     e = info[k]
-                    if int(flags_v[k]) & 48:
-                        raise NotImplementedError("mask_function on periodic parameters")
                     w_ = int(winw_v[k])
                     prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
                     mask_function(e["xbinmin"] - w_ * e["fwx"], e["ybinmin"] - w_ * e["fwy"], e["fwx"], e["fwy"], prior_mask)
@@ -2990,7 +2990,7 @@ class MCSamples:
                         _set_edge_mask_2d(e["parx"], e["pary"], prior_mask, w_)
                         mask_bc = prior_mask.copy()
                     if mbc:
-                        _set_all_edge_mask_2d(prior_mask, w_)
+                        _set_all_edge_mask_2d(prior_mask, w_, e["parx"].periodic, e["pary"].periodic)
                         mask_mbc = prior_mask
                     run_deferred()
                     with _Phase(self, "2d.convolve"):
@@ -3002,7 +3002,21 @@ class MCSamples:
                         if num_plot_contours:
                             ncontours = min(num_plot_contours, ncontours)
                         levels = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
-                    inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, None, None, levels))
+                    d_L = L = None
+                    if meanlikes:
+                        # the mean-likelihood grid does not see the mask (mcsamples.py:1886-1903 precede it): the pair's
+                        # ordinary likes2d call
+                        d_one, d_lone = ctx.alloc(F * F * 8), ctx.alloc(F * F * 8)
+                        self._gather_device(d_hist, d_one, [pos], F * F * 8)
+                        self._gather_device(likehists[F], d_lone, [pos], F * F * 8)
+                        ka1 = np.asarray([k], dtype=np.int64)
+                        d_L, lstatus = ctx.likes2d(d_one, d_lone, 1, F, rx_v[ka1], ry_v[ka1], cc_v[ka1], winw_v[ka1], flags_v[ka1], mbc)
+                        d_one.free()
+                        d_lone.free()
+                        if np.any(lstatus != 0):
+                            raise DensitiesError("no likelihood weight in any bin")
+                        L = d_L.to_host_async((1, F, F))
+                    inflight.append((d_P, d_P.to_host_async((1, F, F)), [k], status, d_L, L, levels))
                     assemble_new()
                     yield
                     continue

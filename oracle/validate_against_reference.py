@@ -367,7 +367,31 @@ def compare_mask_function():
                 d_orc = orc.density_2d(a, b, mask_function=example_mask_function, **kw)
                 ok &= relerr(d_orc["P"], d_ref.P) <= 1e-10 and np.array_equal(d_orc["mask"], d_ref.mask)
                 ok &= bool(np.any(d_ref.mask)) and not bool(np.all(d_ref.mask))
-    print(("ok  " if ok else "FAIL") + " mask_function densities and masks")
+    # a mask on periodic axes (either orientation; the mask moments stay 'valid' while the histogram side is circular,
+    # mcsamples.py:1874-1881,1907-1987) and a mask together with meanlikes (the mean-likelihood grid does not see it)
+    fx = zoo["periodic"]
+    ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"])
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    for a, b in fx["pairs"]:
+        for kw in ({"fine_bins_2D": 64}, dict(fine_bins_2D=64, mult_bias_correction_order=0),
+                   dict(fine_bins_2D=32, boundary_correction_order=0, mult_bias_correction_order=2)):
+            d_ref = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], get_density=True,
+                                             mask_function=example_mask_function, **kw)
+            d_orc = orc.density_2d(a, b, mask_function=example_mask_function, **kw)
+            ok &= relerr(d_orc["P"], d_ref.P) <= 1e-10 and np.array_equal(d_orc["mask"], d_ref.mask)
+            ok &= bool(np.any(d_ref.mask)) and not bool(np.all(d_ref.mask))
+    fx = zoo["c1_bounded"]
+    ll = loglikes_for(fx["samples"])
+    ref = ref_samples(fx["samples"], fx["weights"], fx["names"], fx["ranges"], loglikes=ll)
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=ll)
+    for a, b in ((0, 3), (2, 3)):
+        for kw in ({}, dict(mult_bias_correction_order=0)):
+            d_ref = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], meanlikes=True,
+                                             mask_function=example_mask_function, **kw)
+            d_orc = orc.density_2d(a, b, meanlikes=True, mask_function=example_mask_function, **kw)
+            ok &= relerr(d_orc["P"], d_ref.P) <= 1e-10 and relerr(d_orc["likes"], d_ref.likes) <= 1e-10
+            ok &= np.array_equal(d_orc["mask"], d_ref.mask)
+    print(("ok  " if ok else "FAIL") + " mask_function densities and masks (incl. periodic axes, with meanlikes)")
     return ok
 
 

@@ -110,8 +110,10 @@ class FakeContext:
         Win = np.exp(-(i1**2 * Cinv[0, 0] + i2**2 * Cinv[1, 1] + 2 * Cinv[1, 0] * i1 * i2) / 2)
         Win /= np.sum(Win)
         big = F + 4 * w_ + 1
-        bins2D = ko.conv2d(hist, Win, "same", largest_size=big)
-        if bco >= 0:
+        px, py = bool(int(flags) & 16), bool(int(flags) & 32)  # histogram side circular on periodic axes (:1874-1881)
+        mode = "periodic_both" if px and py else "periodic_x" if px else "periodic_y" if py else "same"
+        bins2D = ko.conv2d(hist, Win, mode, largest_size=big)
+        if bco >= 0 and not (px and py):
             a00 = ko.conv2d(mask_bc, Win, "valid", largest_size=big)
             ix = a00 * bins2D > np.max(bins2D) * 1e-8
             a00 = a00[ix]
@@ -127,20 +129,20 @@ class FakeContext:
                 a20 = ko.conv2d(mask_bc, winx * idx, "valid", largest_size=big)[ix]
                 a02 = ko.conv2d(mask_bc, winy * y, "valid", largest_size=big)[ix]
                 a11 = ko.conv2d(mask_bc, winy * idx, "valid", largest_size=big)[ix]
-                xP = ko.conv2d(hist, winx, "same", largest_size=big)[ix]
-                yP = ko.conv2d(hist, winy, "same", largest_size=big)[ix]
+                xP = ko.conv2d(hist, winx, mode, largest_size=big)[ix]
+                yP = ko.conv2d(hist, winy, mode, largest_size=big)[ix]
                 denom = a20 * a01**2 + a10**2 * a02 - a00 * a02 * a20 + a11**2 * a00 - 2 * a01 * a10 * a11
                 with np.errstate(divide="ignore", invalid="ignore"):
                     corrected = (bins2D[ix] * (a11**2 - a02 * a20) + xP * (a10 * a02 - a01 * a11) + yP * (a01 * a20 - a10 * a11)) / denom
                     bins2D[ix] = normed * np.exp(np.minimum(corrected / normed, 4) - 1)
         zero = np.asarray(zero_mask, dtype=bool)
-        if mbc:
+        if mbc and not (px and py):
             a00 = ko.conv2d(mask_mbc, Win, "valid", largest_size=big)
             for _ in range(mbc):
                 box = hist.copy()
                 ix2 = bins2D > np.max(bins2D) * 1e-8
                 box[ix2] /= bins2D[ix2]
-                bins2D *= ko.conv2d(box, Win, "same", largest_size=big)
+                bins2D *= ko.conv2d(box, Win, mode, largest_size=big)
                 bins2D[~zero] /= a00[~zero]
         bins2D[zero] = 0
         mx = np.max(bins2D)

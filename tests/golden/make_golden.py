@@ -234,6 +234,38 @@ def golden_mask_function(zoo):
     return out
 
 
+MASK_CORNER_KW_PERIODIC = ({"fine_bins_2D": 64}, dict(fine_bins_2D=64, mult_bias_correction_order=0),
+                           dict(fine_bins_2D=32, boundary_correction_order=0, mult_bias_correction_order=2))
+MASK_CORNER_KW_LIKES = ({}, dict(mult_bias_correction_order=0))
+
+
+def golden_mask_corners(zoo):
+    """mask_function on periodic parameters (either orientation) and together with meanlikes, of the reference
+    (mcsamples.py:1874-1903, 1907-1987, 2004-2006).  Written to mask_function_corners.npz by --mask-corners."""
+    from oracle.fixtures import example_mask_function, loglikes_for
+
+    out = {}
+    fx = zoo["periodic"]
+    ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    for a, b in fx["pairs"]:
+        for kw in MASK_CORNER_KW_PERIODIC:
+            d = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], get_density=True, mask_function=example_mask_function, **kw)
+            key = "periodic/%d_%d/%s" % (a, b, kwkey(kw))
+            out[key + "/P"] = d.P.copy()
+            out[key + "/mask_crc"] = crc(np.asarray(d.mask, dtype=np.uint8))
+    fx = zoo["c1_bounded"]
+    ref = MCSamples(samples=np.ascontiguousarray(fx["samples"]), weights=fx["weights"], names=fx["names"], ranges=fx["ranges"],
+                    loglikes=loglikes_for(fx["samples"]))
+    for a, b in ((0, 3), (2, 3)):
+        for kw in MASK_CORNER_KW_LIKES:
+            d = ref.get2DDensityGridData(fx["names"][a], fx["names"][b], meanlikes=True, mask_function=example_mask_function, **kw)
+            key = "c1_bounded/%d_%d/%s" % (a, b, kwkey(kw))
+            out[key + "/P"] = d.P[::4, ::4].copy()
+            out[key + "/likes"] = d.likes[::4, ::4].copy()
+            out[key + "/mask_crc"] = crc(np.asarray(d.mask, dtype=np.uint8))
+    return out
+
+
 def golden_convergence():
     samples, weights, names, offsets = synth.config_c4(nchains=4, N=20000, n=8)
     chains = [np.ascontiguousarray(samples[a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
@@ -401,6 +433,12 @@ def golden_mutators():
 
 
 def main():
+    if "--mask-corners" in sys.argv:
+        out = golden_mask_corners({fx["name"]: fx for fx in fixture_zoo()})
+        path = os.path.join(HERE, "mask_function_corners.npz")
+        np.savez_compressed(path, **out)
+        print("mask corners:", len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+        return
     if "--mutators" in sys.argv:
         out = golden_mutators()
         path = os.path.join(HERE, "mutators.npz")

@@ -294,6 +294,11 @@ def root_constructor_checks(tmp_path, factory=None):
     assert excl.numrows == len(weights) - (offsets[2] - offsets[1]) and len(excl.chain_offsets) == 3
 
 
+MASK_CORNER_KW_PERIODIC = ({"fine_bins_2D": 64}, dict(fine_bins_2D=64, mult_bias_correction_order=0),
+                           dict(fine_bins_2D=32, boundary_correction_order=0, mult_bias_correction_order=2))
+MASK_CORNER_KW_LIKES = ({}, dict(mult_bias_correction_order=0))
+
+
 def assert_grid_or_oracle_ensemble(d, o, tr, key, tol=1e-6, cap=5e-4, oracle_at=None):
     """
     The 2D grid gate used wherever a pair may go through TNC: ``d`` the device's Density2D,

@@ -260,6 +260,18 @@ def test_mask_function(zoo):
     mask_function_check(zoo, tol=1e-6)
 
 
+def test_mask_function_on_periodic_axes_and_with_meanlikes(zoo):
+    """gd_density2d_masked through the periodic route (explicit masks summed directly, histogram side circular) and the
+    masked pair's mean-likelihood grid (gd_likes2d), against the oracle.  mcsamples.py:1874-1903, 1907-1987."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic_cpu import mask_corners_check
+
+    mask_corners_check(zoo, tol=1e-6)
+
+
 def test_lazy_result_delivery_and_overlapping_calls(monkeypatch):
     """A large batched 2D call returns once its work is enqueued: the grids complete at their first read (a mark on
     the copy stream), they stay valid when another call is issued before anything was read, and they equal the grids of

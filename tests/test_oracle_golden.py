@@ -141,3 +141,28 @@ def test_oracle_mask_function_golden(zoo):
                 key = "%s/%d_%d/%s" % (nm, a, b, gu.kwkey(kw))
                 assert gu.relerr(o["P"][::4, ::4], g[key + "/P"]) <= TOL_GRID, key
                 assert gu.crc(np.asarray(o["mask"], dtype=np.uint8)) == g[key + "/mask_crc"], key
+
+
+def test_oracle_mask_corners_golden(zoo):
+    """mask_function on periodic parameters (either orientation) and together with meanlikes against the reference's
+    stored outputs (tests/golden/make_golden.py --mask-corners; mcsamples.py:1874-1903, 1907-1987)."""
+    from oracle.fixtures import example_mask_function, loglikes_for
+
+    g = np.load(gu.GOLDEN_DIR + "/mask_function_corners.npz")
+    fx = zoo["periodic"]
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
+    for a, b in fx["pairs"]:
+        for kw in gu.MASK_CORNER_KW_PERIODIC:
+            o = orc.density_2d(a, b, mask_function=example_mask_function, **kw)
+            key = "periodic/%d_%d/%s" % (a, b, gu.kwkey(kw))
+            assert gu.relerr(o["P"], g[key + "/P"]) <= TOL_GRID, key
+            assert gu.crc(np.asarray(o["mask"], dtype=np.uint8)) == g[key + "/mask_crc"], key
+    fx = zoo["c1_bounded"]
+    orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"], loglikes=loglikes_for(fx["samples"]))
+    for a, b in ((0, 3), (2, 3)):
+        for kw in gu.MASK_CORNER_KW_LIKES:
+            o = orc.density_2d(a, b, meanlikes=True, mask_function=example_mask_function, **kw)
+            key = "c1_bounded/%d_%d/%s" % (a, b, gu.kwkey(kw))
+            assert gu.relerr(o["P"][::4, ::4], g[key + "/P"]) <= TOL_GRID, key
+            assert gu.relerr(o["likes"][::4, ::4], g[key + "/likes"]) <= TOL_GRID, key
+            assert gu.crc(np.asarray(o["mask"], dtype=np.uint8)) == g[key + "/mask_crc"], key
