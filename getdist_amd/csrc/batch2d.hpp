@@ -644,54 +644,6 @@ struct Call {
         return rc ? rc : neff_batch(used, false);
     }
 
-    // -- index columns
-    int index_columns8(void* ctx, const std::vector<int>& js, bool* ok) {
-        std::vector<int32_t> todo;
-        std::vector<double> b0, w;
-        std::vector<void*> bufs;
-        {
-            std::lock_guard<std::mutex> g(st.mu);
-            for (int j : js) {
-                const double fw = (bmax[j] - bmin[j]) / 255;
-                IdxCol& c = st.idx[std::make_tuple(j, 256, 1)];
-                if (c.valid && c.binmin == bmin[j] && c.width == fw) continue;
-                todo.push_back(j), b0.push_back(bmin[j]), w.push_back(fw);
-            }
-        }
-        if (!todo.empty()) {
-            for (int j : todo) {
-                void* p;
-                {
-                    std::lock_guard<std::mutex> g(st.mu);
-                    p = st.idx[std::make_tuple(j, 256, 1)].ptr;
-                }
-                if (!p) {
-                    int rc = 0;
-                    p = pool.take(N + 64, &rc);
-                    if (!p) return dev_fail(rc, h);
-                }
-                bufs.push_back(p);
-            }
-            std::vector<int64_t> bad(todo.size());
-            mark("binning: prebin8 launch", (int)todo.size());
-            GDB_DEV(ctx, ops.prebin8_batch(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), 256, bufs.data(), bad.data()));
-            mark("binning: prebin8 done");
-            std::lock_guard<std::mutex> g(st.mu);
-            for (size_t q = 0; q < todo.size(); ++q) {
-                IdxCol& c = st.idx[std::make_tuple(todo[q], 256, 1)];
-                c.ptr = bufs[q], c.binmin = b0[q], c.width = w[q], c.valid = bad[q] == 0;
-            }
-        }
-        bool all = true;
-        std::lock_guard<std::mutex> g(st.mu);
-        for (int j : js) {
-            const IdxCol& c = st.idx[std::make_tuple(j, 256, 1)];
-            all = all && c.valid && c.binmin == bmin[j] && c.width == (bmax[j] - bmin[j]) / 255;
-        }
-        *ok = all;
-        return 0;
-    }
-
     int index_column16(void* ctx, int j, int F, void** out) {
         const double fw = (bmax[j] - bmin[j]) / (F - 1);
         IdxCol c;
@@ -922,7 +874,6 @@ struct Call {
     int s_two_min() const { return s.two_streams_min > 0 ? s.two_streams_min : 64; }
     int s_two_split() const { return s.two_streams_split > 0 ? s.two_streams_split : 400; }
     int s_kopt_split_min() const { return s.kopt_split_min > 0 ? s.kopt_split_min : 256; }
-    double s_kopt_first() const { return s.kopt_first_fraction > 0 ? s.kopt_first_fraction : 0.5; }
 
     bool is_side(int F) const { return std::find(side_classes.begin(), side_classes.end(), F) != side_classes.end(); }
 
@@ -1009,14 +960,6 @@ struct Call {
                 continue;
             }
             GDB_TRY(run_class(main_[q], all, nullptr));
-        }
-        return 0;
-    }
-
-    int enqueue_part(const std::vector<char>& only, bool last) {
-        for (int F : order) {
-            void* target = (is_side(F) || !last) && conv_ctxs.size() > 1 ? conv_ctxs[1] : conv_ctxs[0];
-            GDB_TRY(run_class(F, only, target));
         }
         return 0;
     }

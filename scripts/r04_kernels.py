@@ -80,6 +80,10 @@ def main():
             os.environ.pop("GDHIP_KOPT_DCT_GEMM", None)
         res["kopt2d_whole_call_%d_pairs_dct_%s" % (B, route)] = timed(ctx, lambda: ctx.kopt2d(out, B, F, neff, dc, fb, cc), 3)
     os.environ.pop("GDHIP_KOPT_DCT_GEMM", None)
+    # the fixed-point kernel alone: matrix resident on the CU (default) against streamed through LDS
+    os.environ["GDHIP_KOPT_STREAMED"] = "1"
+    res["kopt2d_whole_call_%d_pairs_streamed_fixed_point_kernel" % B] = timed(ctx, lambda: ctx.kopt2d(out, B, F, neff, dc, fb, cc), 3)
+    os.environ.pop("GDHIP_KOPT_STREAMED", None)
     mc.ctx.close()
     # real weights and integer multiplicities: the whole triangle's 2D binning
     for tag, wts in (("real_weights", None), ("integer_weights", "int")):
