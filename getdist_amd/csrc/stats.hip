@@ -1587,6 +1587,10 @@ int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo,
     // the expected length of a live bucket's list is rows / buckets times the peak-to-mean density ratio (about 4 for a
     // Gaussian over its sampled range); beyond these row counts the lists would overflow QCAP
     if (linear && (hi - lo) > (ctx->w ? 12000000 : 25000000)) linear = false;
+    // real weights: the bucket sums of the counting pass are fp64 LDS atomics, whose order -- hence rounding -- differs from
+    // run to run, and a target within rounding of a bucket boundary could pick another sample; unit weights and integer
+    // multiplicities add exactly, in any order.  The radix path is deterministic for every kind of weight.
+    if (linear && ctx->w && !ctx->w_integral) linear = false;
     for (int c = 0; linear && c < ncols; ++c) {
         const double a = minmax[2 * c], b = minmax[2 * c + 1];
         if (!(b > a) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite((double)QLIN_NB_U / (b - a))) linear = false;

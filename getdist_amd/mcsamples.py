@@ -3149,8 +3149,26 @@ class MCSamples:
                 with _Phase(self, "2d.bandwidth.device"):
                     if pipelined:
                         widths_complete[0] = False
-                        self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred, on_chunk=on_chunk,
-                                           first_fraction=self.KOPT_FIRST_FRACTION, more_deferred=book_plan)
+                        try:
+                            self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred, on_chunk=on_chunk,
+                                               first_fraction=self.KOPT_FIRST_FRACTION, more_deferred=book_plan)
+                        except BaseException:
+                            # a later optimiser launch failed ("bias not positive definite", a device error) while the
+                            # second context's thread may still be enqueueing an earlier part: let it finish and the
+                            # queued work drain before the error leaves -- the contexts are not re-entrant, and the
+                            # blocks of this call are released only once nothing runs on them
+                            for f in enqueueing:
+                                try:
+                                    f.result()
+                                except BaseException:
+                                    pass
+                            if lazy:
+                                try:
+                                    completion.mark()
+                                    completion.wait()
+                                except BaseException:
+                                    pass
+                            raise
                     else:
                         W = self._bandwidth_2d(plan, hists, pF, base_F, mbc, shear=shear, deferred=deferred,
                                                more_deferred=book_plan)

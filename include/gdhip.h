@@ -109,7 +109,8 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo
  * row range -- minmax[2c], minmax[2c+1]; the base statistics have them (gd_cov's minmax_out).  Then ONE counting pass
  * over the monotone linear bucket index (int)((x - min) * nbuckets / (max - min)) in 32768 (unit weights) or 16384
  * (fp64 weights) LDS buckets narrows every target to a few hundred rows, which one collect pass gathers and a sorted walk
- * of the cumulative weight finishes exactly as above: two reads of the columns instead of four.  minmax == NULL, a
+ * of the cumulative weight finishes exactly as above: two reads of the columns instead of four.  Taken for unit weights
+ * and integer multiplicities (whose bucket sums are exact in any order of addition); minmax == NULL, real weights, a
  * degenerate range, more rows than the bucket lists can hold, or a list overflow (heavily tied data) take the radix
  * path of gd_quantiles; the result is the same sample value either way. */
 int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
