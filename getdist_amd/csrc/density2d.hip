@@ -910,8 +910,18 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
     double2* buf = sh2 + S + (size_t)g * H;
     for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
-    __syncthreads();
     const int w = pairs[b].w;
+    // MODE 1 with tables: the pair's summed-area table of the divisor comes into LDS once -- the border pixels of every row
+    // read a dozen of its entries each, and from global memory each such read sat on the row's critical path
+    // (measured with the interior shortcut below: 141 -> 107 us per 136-pair launch; requesting the row of the grid ahead of the
+    // transform instead of at its use: 117, not kept)
+    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)(blockDim.x / FT) * H);
+    if (MODE == 1 && sat1) {
+        const double* s1g = sat1 + (int64_t)b * sat1_pair_stride;
+        const int n1 = (2 * w + 2) * (2 * w + 2);
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) sat_l[i] = s1g[i];
+    }
+    __syncthreads();
     const int y = blockIdx.x * (blockDim.x / FT) + g;
     const bool active = y < F;
     if (active) {
@@ -944,10 +954,14 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
         const int fl = pairs[b].flags, M1 = 2 * w + 2;
-        const double* s1 = (MODE == 1 && sat1) ? sat1 + (int64_t)b * sat1_pair_stride : nullptr;
+        const double* s1 = (MODE == 1 && sat1) ? sat_l : nullptr;
         const MaskIv ix = mask_interval(F, w, fl & 1, fl & 2, 1, edge_applied != 0);
         const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
         const double tot = s1 ? sat_rect(s1, M1, 0, 2 * w, 0, 2 * w) : 0.0;
+        // where mask_geom's `full` holds (the whole window inside the mask, no half row or column): a rectangle of pixels,
+        // known per row -- the interior pixels skip the geometry altogether
+        const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
+        const bool row_full = y >= iy.lo + (iy.hlo ? 1 : 0) && y <= iy.hi - 2 * w - (iy.hhi ? 1 : 0);
         for (int x = t; x < F; x += FT) {
             const int pos = x + w;
             const double2 z = buf[pos >> 1];
@@ -955,8 +969,12 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
             if (MODE == 1) {
                 double div;
                 if (s1) {
-                    const MaskGeom g = mask_geom(F, w, ix, iy, x, y);
-                    div = g.full ? tot : mask_moment(s1, M1, g);
+                    if (row_full && x >= xf_lo && x <= xf_hi) {
+                        div = tot;
+                    } else {
+                        const MaskGeom g = mask_geom(F, w, ix, iy, x, y);
+                        div = g.full ? tot : mask_moment(s1, M1, g);
+                    }
                 } else {
                     div = a00[o + x];
                 }
@@ -1338,10 +1356,11 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         }
         GD_KERNEL_CHECK();
         auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
-        GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        const size_t lds_rows_inv = lds_rows + (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0);
+        GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows_inv));
         // (update && fused: the divisor comes from the all-edge mask's table, the last of the pair's n_mom tables)
         const double* sat1 = (update && fused) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
-        kr<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
+        kr<<<gR, RPB * FT, lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
                                                     do_bc ? 1 : 0);
         GD_KERNEL_CHECK();
         return GD_OK;
