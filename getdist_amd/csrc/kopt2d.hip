@@ -15,8 +15,8 @@
 #endif
 #define MAXF 6  // forms per level
 #ifdef KOPT_PROFILE
-__device__ long long g_prof[8];
-__device__ long long g_wave[8];  // k_kopt2d_res: cycles each wave of block 0 spent in the forms  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
+__device__ long long g_prof[8];  // weights, tile loads, tile FMAs, reductions, times/pow, levels, evaluations
+__device__ long long g_wave[8];  // k_kopt2d_res: cycles each wave of block 0 spent in the forms
 #define PROF_T0 long long prof_t0 = clock64()
 #define PROF_ADD(slot)                                                        \
     do {                                                                      \
@@ -740,7 +740,7 @@ __device__ __forceinline__ void kres_load(const double* __restrict__ M, double (
 
 // acc += y[lane J of the 16-lane row] * m : the row weight is broadcast inside the instruction (DPP row_newbcast), so a
 // form's 32 row weights cost two LDS reads per lane instead of sixteen wave-uniform ones in front of every eight FMAs
-// (measured: the FMA phase of a level fell from 10.7 to X k cycles; the compiler does not form DPP for f64 by itself).
+// (measured: the FMA phase of a level fell from 10.7 to 5.5 k cycles; the compiler does not form DPP for f64 by itself).
 template <int J>
 __device__ __forceinline__ void fmac_bc(double& acc, double y, double m) {
 #ifdef KOPT_PROFILE  // pinned between the cycle-counter reads
