@@ -294,7 +294,7 @@ struct BcArrays {
 template <bool FUSED>
 __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF,
                                                   int bco, double* __restrict__ mx_out, const double* __restrict__ sat,
-                                                  int64_t sat_stride, int nmom, int F) {
+                                                  int64_t sat_stride, int nmom, int F, int stage_lds = 0) {
     __shared__ double red[16];
     const int b = blockIdx.y;
     const D2Pair p = pairs[b];
@@ -305,14 +305,27 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
     const double thresh = pair_max(mx, b) * 1e-8;
     const int64_t o = (int64_t)b * FF;
     const int w = p.w, M1 = 2 * w + 2;
-    const double* s0 = FUSED ? sat + (int64_t)b * nmom * sat_stride : nullptr;
+    // FUSED: the pair's tables come into LDS once per block (dynamic shared memory: nq * sat_stride doubles) -- a border
+    // pixel reads up to nine rectangles of each of the six, and from global memory those reads were its critical path
+    extern __shared__ double sat_sh[];
+    const double* s0 = nullptr;
     const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, 0, true);
     const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, 0, true);
     double tot[6] = {0, 0, 0, 0, 0, 0};
     if (FUSED) {
         const int nq = bco == 1 ? 6 : 1;
+        const double* sg = sat + (int64_t)b * nmom * sat_stride;
+        s0 = sg;
+        if (stage_lds) {  // (uniform; wide windows' tables stay in global memory)
+            for (int64_t e = threadIdx.x; e < (int64_t)nq * sat_stride; e += blockDim.x) sat_sh[e] = sg[e];
+            __syncthreads();
+            s0 = sat_sh;
+        }
         for (int q = 0; q < nq; ++q) tot[q] = sat_rect(s0 + q * sat_stride, M1, 0, 2 * w, 0, 2 * w);
     }
+    // where mask_geom's `full` holds: a rectangle of pixels (see k_rows_inv); they skip the geometry
+    const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
+    const int yf_lo = iy.lo + (iy.hlo ? 1 : 0), yf_hi = iy.hi - 2 * w - (iy.hhi ? 1 : 0);
     double m = -INFINITY;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
         const double P = A.P[o + i];
@@ -320,8 +333,13 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
         double a00;
         if (FUSED) {
             const int y = i / F, x = i - y * F;
-            g = mask_geom(F, w, ix, iy, x, y);
-            a00 = g.full ? tot[0] : mask_moment(s0, M1, g);
+            if (x >= xf_lo && x <= xf_hi && y >= yf_lo && y <= yf_hi) {
+                g.full = true, g.any = true;
+                a00 = tot[0];
+            } else {
+                g = mask_geom(F, w, ix, iy, x, y);
+                a00 = g.full ? tot[0] : mask_moment(s0, M1, g);
+            }
         } else {
             a00 = A.a00[o + i];
         }
@@ -902,7 +920,8 @@ template <int MODE>
 __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
                                                   const double* __restrict__ a00, double* __restrict__ mx,
-                                                  const double* __restrict__ sat1, int64_t sat1_pair_stride, int edge_applied) {
+                                                  const double* __restrict__ sat1, int64_t sat1_pair_stride, int edge_applied,
+                                                  int sat_in_lds) {
     extern __shared__ double2 sh2[];
     __shared__ double red[16];
     const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
@@ -916,7 +935,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     // (measured with the interior shortcut below: 141 -> 107 us per 136-pair launch; requesting the row of the grid ahead of the
     // transform instead of at its use: 117, not kept)
     double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)(blockDim.x / FT) * H);
-    if (MODE == 1 && sat1) {
+    if (MODE == 1 && sat1 && sat_in_lds) {
         const double* s1g = sat1 + (int64_t)b * sat1_pair_stride;
         const int n1 = (2 * w + 2) * (2 * w + 2);
         for (int i = threadIdx.x; i < n1; i += blockDim.x) sat_l[i] = s1g[i];
@@ -954,7 +973,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
         const int fl = pairs[b].flags, M1 = 2 * w + 2;
-        const double* s1 = (MODE == 1 && sat1) ? sat_l : nullptr;
+        const double* s1 = (MODE == 1 && sat1) ? (sat_in_lds ? sat_l : sat1 + (int64_t)b * sat1_pair_stride) : nullptr;
         const MaskIv ix = mask_interval(F, w, fl & 1, fl & 2, 1, edge_applied != 0);
         const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
         const double tot = s1 ? sat_rect(s1, M1, 0, 2 * w, 0, 2 * w) : 0.0;
@@ -1356,12 +1375,14 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         }
         GD_KERNEL_CHECK();
         auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
-        const size_t lds_rows_inv = lds_rows + (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0);
+        size_t lds_rows_inv = lds_rows + (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0);
+        const int sat_in_lds = lds_rows_inv <= 156u * 1024u;  // (else the table is read where it lies)
+        if (!sat_in_lds) lds_rows_inv = lds_rows;
         GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows_inv));
         // (update && fused: the divisor comes from the all-edge mask's table, the last of the pair's n_mom tables)
         const double* sat1 = (update && fused) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
         kr<<<gR, RPB * FT, lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
-                                                    do_bc ? 1 : 0);
+                                                        do_bc ? 1 : 0, sat_in_lds);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
@@ -1441,10 +1462,15 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             FWD(RF, ZK);
             CONV_TO(ZH, ZK, A.yP, (double*)nullptr);
         }
-        if (fused)
-            k_boundary<true><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, d_sat, sat_stride, n_mom, F);
-        else
+        if (fused) {
+            size_t lds_bc = (size_t)(bco == 1 ? 6 : 1) * sat_stride * 8;
+            const int stage = lds_bc <= 64u * 1024u;  // (windows up to 17 bins; wider ones read their tables from global memory)
+            if (!stage) lds_bc = 0;
+            GD_HIP(hipFuncSetAttribute((const void*)k_boundary<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bc));
+            k_boundary<true><<<gF, 256, lds_bc, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, d_sat, sat_stride, n_mom, F, stage);
+        } else {
             k_boundary<false><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, nullptr, 0, 0, F);
+        }
         GD_KERNEL_CHECK();
         mx_cur = d_mx2;
     }
