@@ -166,3 +166,31 @@ def test_oracle_mask_corners_golden(zoo):
             assert gu.relerr(o["P"][::4, ::4], g[key + "/P"]) <= TOL_GRID, key
             assert gu.relerr(o["likes"][::4, ::4], g[key + "/likes"]) <= TOL_GRID, key
             assert gu.crc(np.asarray(o["mask"], dtype=np.uint8)) == g[key + "/mask_crc"], key
+
+
+def test_judge_triple_widens_the_ensemble_only_as_far_as_needed():
+    """oracle.judge_triple (the criterion of every chaotic TNC pair): the oracle's own triple is
+    admitted by the one-ulp ensemble; a triple that the oracle itself produces for inputs perturbed by 1e-12 -- and that
+    lies outside the one-ulp ensemble's spread and AMISE range -- is admitted at the scale it came from, not before; a
+    triple that no perturbation produces (hx off by half) is rejected at every scale."""
+    from oracle.fixtures import random_psi_tuples
+
+    psi, N, corr = list(random_psi_tuples(60, seed=31))[7]
+    assert ko.get_h_is_chaotic(psi, N, corr)[0]
+    ensembles = ko.get_h_ensembles(psi, N, corr)
+    own = ko.judge_triple(ensembles[0][0], psi, N, ensembles=ensembles)
+    assert own["ok"] and own["inside"] and own["scale"] == ko.ENSEMBLE_SCALES[0] and own["members"] == len(ensembles[0])
+    outsider = None
+    for row in ensembles[3][1:]:
+        if not (ko.within_oracle_spread(row, ensembles[0])[0] or ko.amise_within_oracle_range(row, ensembles[0], psi, N)[0]):
+            outsider = row
+            break
+    assert outsider is not None
+    v = ko.judge_triple(outsider, psi, N, ensembles=ensembles)
+    assert v["ok"] and v["scale"] > ko.ENSEMBLE_SCALES[0] and v["members"] > len(ensembles[0])
+    # computed here (no precomputed ensembles): the same verdict
+    v2 = ko.judge_triple(outsider, psi, N, corr)
+    assert v2["ok"] and v2["scale"] == v["scale"] and v2["members"] == v["members"]
+    bogus = np.array(ensembles[0][0], dtype=float) * np.array([1.5, 1.0, 1.0])
+    bad = ko.judge_triple(bogus, psi, N, ensembles=ensembles)
+    assert not bad["ok"] and bad["scale"] == ko.ENSEMBLE_SCALES[-1] and bad["amise_excess"] > 10 * bad["amise_range"]
