@@ -656,7 +656,7 @@ def main():
         # 128-byte id at start-up, and the barriers / the max over ranks around the timed region)
         from getdist_amd import parallel
 
-        comm = parallel.init_library_comm(mc.ctx, dist, rank, world)
+        comm = parallel.init_library_comm(mc.ctx, dist, rank, world, torch_device)  # None on every rank if any rank cannot
 
     def barrier():
         mc.ctx.sync()

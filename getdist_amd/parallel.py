@@ -79,12 +79,60 @@ class LibraryComm:
         return self.ctx.comm_allreduce_sum(vec)
 
 
-def init_library_comm(ctx, dist, rank, world):
-    """Rank 0 makes the RCCL id, every rank joins (collective).  Returns a LibraryComm."""
-    box = [ctx.comm_unique_id() if rank == 0 else None]
+def init_library_comm(ctx, dist, rank, world, device=None):
+    """
+    Rank 0 makes the RCCL id, every rank joins (collective).  Returns a LibraryComm -- or None ON EVERY RANK when any rank
+    cannot take part (librccl not loadable, the communicator not created, a test all-reduce with the wrong answer): the
+    ranks agree over torch.distributed after each stage, so that either all of them use the library's collectives or all
+    of them keep torch.distributed's, and a half-initialised job neither crashes nor deadlocks in a mismatched collective.
+    """
+    import logging
+
+    import torch
+
+    def everyone(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def give_up(stage):
+        if rank == 0:
+            logging.warning("library communicator not available (%s): the step's collectives stay with torch.distributed", stage)
+        return None
+
+    try:  # stage 1, local: the RCCL library loads and resolves on this rank (gd_comm_unique_id needs nothing else)
+        my_id = ctx.comm_unique_id()
+        ok = True
+    except Exception:
+        my_id, ok = None, False
+    if not everyone(ok):
+        return give_up("librccl could not be loaded on a rank")
+    box = [my_id if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    ctx.comm_init(world, rank, box[0])
-    return LibraryComm(ctx)
+    try:  # stage 2, collective
+        ctx.comm_init(world, rank, box[0])
+        ok = True
+    except Exception:
+        ok = False
+    if not everyone(ok):
+        if ok:
+            ctx.comm_destroy()
+        return give_up("communicator creation failed on a rank")
+    comm = LibraryComm(ctx)
+    try:  # stage 3: a sum whose answer every rank knows
+        out = comm.allreduce_sum(np.array([rank + 1.0, 1.0]))
+        ok = bool(out[0] == world * (world + 1) / 2 and out[1] == world)
+    except Exception:
+        ok = False
+    if not everyone(ok):
+        try:
+            ctx.comm_destroy()
+        except Exception:
+            pass
+        return give_up("test all-reduce failed on a rank")
+    return comm
 
 
 def allgather_neff(mc, my_js, n_params, dist=None, device=None, comm=None):

@@ -216,3 +216,75 @@ def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     bad = subprocess.run(cmd, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
+
+
+COMM_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from getdist_amd import parallel
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeLibCtx:  # the gd_comm_* surface of _lib.Context, its collectives carried by gloo
+        def __init__(self, fail=None):
+            self.fail, self.comm_world, self.destroyed = fail, 0, 0
+        def comm_unique_id(self):
+            if self.fail == "load":
+                raise RuntimeError("librccl.so: cannot open shared object file")
+            return b"x" * 128
+        def comm_init(self, world, rank, id128):
+            assert id128 == b"x" * 128
+            if self.fail == "init":
+                raise RuntimeError("ncclCommInitRank failed")
+            self.comm_world = world
+        def comm_allreduce_sum(self, vec):
+            t = torch.from_numpy(np.array(vec, dtype=np.float64))
+            dist.all_reduce(t)
+            out = t.numpy()
+            if self.fail == "sum":
+                out = out + 1.0
+            return out
+        def comm_destroy(self):
+            self.destroyed += 1
+            self.comm_world = 0
+
+    # every rank healthy: the library's communicator on both
+    ctx = FakeLibCtx()
+    comm = parallel.init_library_comm(ctx, dist, rank, world)
+    assert isinstance(comm, parallel.LibraryComm) and comm.world == world and ctx.destroyed == 0
+    assert np.array_equal(comm.allreduce_sum(np.array([1.0, rank])), [world, world * (world - 1) / 2])
+    # one rank cannot: None on EVERY rank, whatever stage fails, and nobody is left inside a collective
+    for stage, bad_rank in (("load", 1), ("init", 0), ("sum", 1)):
+        ctx = FakeLibCtx(stage if rank == bad_rank else None)
+        assert parallel.init_library_comm(ctx, dist, rank, world) is None, (stage, rank)
+        if stage == "init":
+            assert ctx.destroyed == (0 if rank == bad_rank else 1)
+        if stage == "sum":
+            assert ctx.destroyed == 1
+    dist.barrier()
+    print("rank", rank, "ok")
+""")
+
+
+def test_library_communicator_is_all_or_nothing_gloo_world2(tmp_path):
+    """parallel.init_library_comm: the ranks agree after each stage (library loadable, communicator created, a test
+    all-reduce right) whether the step's collectives go through the C ABI or stay with torch.distributed -- a failure on one
+    rank at any stage gives None on every rank, never a mismatched collective."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER % dict(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
