@@ -759,8 +759,13 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    if (!BIG && S == 288)  // (uniform) 16 x 18 in registers, fft288.hpp
-        f288::fft288_group<false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
+    // (uniform) 16 x M in registers, fft288.hpp
+    if (!BIG && S == 288)
+        f288::fft16_group<18, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
+    else if (!BIG && S == 320)
+        f288::fft16_group<20, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
+    else if (BIG && S == 384)
+        f288::fft16_group<24, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
     else
         fft_full<BIG, false>(bw, tw, 1, pl, t);
     if (active) {
@@ -810,36 +815,36 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
     }
 }
 
-// The same column convolution for S = 288 (F = 256 with windows up to 16 bins: the triangle's main class) on the 16 x 18
-// register transforms of fft288.hpp.  grid (ceil(145 / 9), B), 192 threads: a wave carries three columns -- lane
-// 18 c + n2 does the 16-point transforms of column c (forward: straight from the source column in global memory, zero
-// padding included), lane 16 c + k1 the 18-point ones (the inverse's straight into the cropped output).  Six LDS
-// accesses per value where the radix passes make forty (measured on 136 pairs, `scripts/r04_conv_bench.py`: 43.7 against
-// 89.7 us per launch; the C3 step 27.3 against 28.0 ms).
-#define C288_COLS 9
-__global__ void __launch_bounds__(192) k_col_conv288(const D2Pair* __restrict__ pairs, int F, const double2* __restrict__ twg,
-                                                     const double* __restrict__ Wt, int w_odd, const double2* __restrict__ Xt,
-                                                     double2* __restrict__ Yt) {
+// The same column convolution for S = 16 M, M = 18 / 20 / 24 (288: F = 256 with windows up to 16 bins, the triangle's main
+// class; 320 and 384: wider windows) on the 16 x M register transforms of fft288.hpp.  grid (ceil(Sh / cols per block), B),
+// 192 threads: a wave carries 64 / M columns -- lane M c + n2 does the 16-point transforms of column c (forward: straight
+// from the source column in global memory, zero padding included), lane 16 c + k1 the M-point ones (the inverse's straight
+// into the cropped output).  Six LDS accesses per value where the radix passes make forty (measured on 136 pairs of
+// 288-point frames, `scripts/r04_conv_bench.py`: 43.7 against 89.7 us per launch; the C3 step 27.3 against 28.0 ms).
+template <int M>
+__global__ void __launch_bounds__(192) k_col_conv16(const D2Pair* __restrict__ pairs, int F, const double2* __restrict__ twg,
+                                                    const double* __restrict__ Wt, int w_odd, const double2* __restrict__ Xt,
+                                                    double2* __restrict__ Yt) {
     using namespace f288;
     extern __shared__ double2 sh2[];
-    constexpr int S = 288, Sh = 145;
+    constexpr int S = 16 * M, Sh = S / 2 + 1, CW = 64 / M, COLS = 3 * CW;
     const int b = blockIdx.y, w = pairs[b].w;
     C2* tw = reinterpret_cast<C2*>(sh2);
     for (int i = threadIdx.x; i < S; i += 192) sh2[i] = twg[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c1 = lane / 18, n2 = lane - 18 * c1, c2 = lane >> 4, k1 = lane & 15;
-    const int kx1 = blockIdx.x * C288_COLS + wave * 3 + c1, kx2 = blockIdx.x * C288_COLS + wave * 3 + c2;
-    const bool act1 = lane < 54 && kx1 < Sh, act2 = lane < 48 && kx2 < Sh;
-    C2* buf1 = reinterpret_cast<C2*>(sh2) + S + (size_t)(wave * 3 + (c1 < 3 ? c1 : 0)) * S;
-    C2* buf2 = reinterpret_cast<C2*>(sh2) + S + (size_t)(wave * 3 + (c2 < 3 ? c2 : 0)) * S;
-    C2 v[18];
-    // ---- forward, 16-point transforms over n1 of x[18 n1 + n2]; the frame's row p holds source row p - w
+    const int c1 = lane / M, n2 = lane - M * c1, c2 = lane >> 4, k1 = lane & 15;
+    const int kx1 = blockIdx.x * COLS + wave * CW + c1, kx2 = blockIdx.x * COLS + wave * CW + c2;
+    const bool act1 = c1 < CW && kx1 < Sh, act2 = c2 < CW && kx2 < Sh;
+    C2* buf1 = reinterpret_cast<C2*>(sh2) + S + (size_t)(wave * CW + (c1 < CW ? c1 : 0)) * S;
+    C2* buf2 = reinterpret_cast<C2*>(sh2) + S + (size_t)(wave * CW + (c2 < CW ? c2 : 0)) * S;
+    C2 v[M];
+    // ---- forward, 16-point transforms over n1 of x[M n1 + n2]; the frame's row p holds source row p - w
     if (act1) {
         const double2* col = Xt + ((int64_t)b * Sh + kx1) * F;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            const int r = 18 * n1 + n2 - w;
+            const int r = M * n1 + n2 - w;
             const double2 x = (r >= 0 && r < F) ? col[r] : make_double2(0.0, 0.0);
             v[n1] = C2{x.x, x.y};
         }
@@ -848,40 +853,40 @@ __global__ void __launch_bounds__(192) k_col_conv288(const D2Pair* __restrict__ 
         for (int q = 0; q < 16; ++q) {
             C2 a = v[dft16_at(q)];
             if (q > 0) {
-                const C2 e = tw[n2 * q];  // e^{-2 pi i n2 q / 288} = (cos, -sin)
+                const C2 e = tw[n2 * q];  // e^{-2 pi i n2 q / S} = (cos, -sin)
                 a = rot<false>(a, e.x, -e.y);
             }
-            buf1[18 * q + n2] = a;
+            buf1[M * q + n2] = a;
         }
     }
     group_sync();
-    // ---- forward, 18-point transforms over n2; times the window's spectrum (real or imaginary, scaled)
+    // ---- forward, M-point transforms over n2; times the window's spectrum (real or imaginary, scaled)
     if (act2) {
         const double* wcol = Wt + ((int64_t)b * Sh + kx2) * S;
-        double ws[18];
+        double ws[M];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) ws[q] = wcol[k1 + 16 * q];
+        for (int q = 0; q < M; ++q) ws[q] = wcol[k1 + 16 * q];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) v[q] = buf2[18 * k1 + q];
-        dft18<false>(v);
+        for (int q = 0; q < M; ++q) v[q] = buf2[M * k1 + q];
+        Second<M>::template run<false>(v);
         const double scale = 1.0 / ((double)S * (double)S);
 #pragma unroll
-        for (int q = 0; q < 18; ++q) {
+        for (int q = 0; q < M; ++q) {
             const double m = ws[q] * scale;
-            const C2 a = v[dft18_at(q)];
-            v[dft18_at(q)] = w_odd ? C2{-a.y * m, a.x * m} : C2{a.x * m, a.y * m};
+            const C2 a = v[Second<M>::at(q)];
+            v[Second<M>::at(q)] = w_odd ? C2{-a.y * m, a.x * m} : C2{a.x * m, a.y * m};
         }
     }
-    group_sync();  // every lane of the wave has read its 18 values
+    group_sync();  // every lane of the wave has read its M values
     if (act2) {
 #pragma unroll
-        for (int q = 0; q < 18; ++q) buf2[k1 + 16 * q] = v[dft18_at(q)];
+        for (int q = 0; q < M; ++q) buf2[k1 + 16 * q] = v[Second<M>::at(q)];
     }
     group_sync();
     // ---- inverse, 16-point transforms
     if (act1) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf1[18 * n1 + n2];
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf1[M * n1 + n2];
         dft16<true>(v);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -890,20 +895,20 @@ __global__ void __launch_bounds__(192) k_col_conv288(const D2Pair* __restrict__ 
                 const C2 e = tw[n2 * q];
                 a = rot<true>(a, e.x, -e.y);
             }
-            buf1[18 * q + n2] = a;
+            buf1[M * q + n2] = a;
         }
     }
     group_sync();
-    // ---- inverse, 18-point transforms; the crop rows go straight out
+    // ---- inverse, M-point transforms; the crop rows go straight out
     if (act2) {
 #pragma unroll
-        for (int q = 0; q < 18; ++q) v[q] = buf2[18 * k1 + q];
-        dft18<true>(v);
+        for (int q = 0; q < M; ++q) v[q] = buf2[M * k1 + q];
+        Second<M>::template run<true>(v);
         double2* col = Yt + ((int64_t)b * Sh + kx2) * F;
 #pragma unroll
-        for (int q = 0; q < 18; ++q) {
+        for (int q = 0; q < M; ++q) {
             const int r = k1 + 16 * q - w;
-            const C2 a = v[dft18_at(q)];
+            const C2 a = v[Second<M>::at(q)];
             if (r >= 0 && r < F) col[r] = make_double2(a.x, a.y);
         }
     }
@@ -1364,10 +1369,12 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     };
     // convolution of the source in Xt with the window spectrum WT_, cropped into dst (update: dst *= crop / a00)
     auto lds_conv_to = [&](const double* WT_, int w_odd, bool update, double* dst, const double* a00_, double* mxp) -> int {
-        if (S == 288 && getenv("GDHIP_CONV_RADIX_PASSES") == nullptr) {  // (the switch: A/B tests)
-            const size_t lds288 = (size_t)(1 + C288_COLS) * 288 * 16;
-            GD_HIP(hipFuncSetAttribute((const void*)k_col_conv288, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds288));
-            k_col_conv288<<<dim3((Sh + C288_COLS - 1) / C288_COLS, B), 192, lds288, ctx->stream>>>(d_pairs, F, d_tw, WT_, w_odd, Xt, Yt);
+        if ((S == 288 || S == 320 || S == 384) && getenv("GDHIP_CONV_RADIX_PASSES") == nullptr) {  // (the switch: A/B tests)
+            const int M = S / 16, cols = 3 * (64 / M);
+            const size_t lds16 = (size_t)(1 + cols) * S * 16;
+            auto k16 = M == 18 ? k_col_conv16<18> : M == 20 ? k_col_conv16<20> : k_col_conv16<24>;
+            GD_HIP(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            k16<<<dim3((Sh + cols - 1) / cols, B), 192, lds16, ctx->stream>>>(d_pairs, F, d_tw, WT_, w_odd, Xt, Yt);
         } else {
             auto kc = big ? k_col_conv<true> : k_col_conv<false>;
             GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));

@@ -112,6 +112,111 @@ F288_HD void dft16(C2* v) {
 }
 F288_HD int dft16_at(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// ---- 320 = 16 x 20 and 384 = 16 x 24: the second factors
+constexpr double C18 = 0.95105651629515357212, S18 = 0.30901699437494742410;  // also sin 72, cos 72
+constexpr double C36 = 0.80901699437494742410, S36 = 0.58778525229247312917;  // also sin 54, cos 54
+constexpr double C15 = 0.96592582628906828675, S15 = 0.25881904510252076235;
+
+template <bool INV>
+F288_HD void dft5(C2& x0, C2& x1, C2& x2, C2& x3, C2& x4) {
+    const C2 t1 = add(x1, x4), t2 = add(x2, x3), t3 = sub(x1, x4), t4 = sub(x2, x3);
+    // cos 72 = S18, cos 144 = -C36, sin 72 = C18, sin 144 = S36
+    const C2 m1 = C2{__builtin_fma(S18, t1.x, __builtin_fma(-C36, t2.x, x0.x)), __builtin_fma(S18, t1.y, __builtin_fma(-C36, t2.y, x0.y))};
+    const C2 m2 = C2{__builtin_fma(-C36, t1.x, __builtin_fma(S18, t2.x, x0.x)), __builtin_fma(-C36, t1.y, __builtin_fma(S18, t2.y, x0.y))};
+    const C2 s1 = C2{__builtin_fma(C18, t3.x, S36 * t4.x), __builtin_fma(C18, t3.y, S36 * t4.y)};
+    const C2 s2 = C2{__builtin_fma(S36, t3.x, -(C18 * t4.x)), __builtin_fma(S36, t3.y, -(C18 * t4.y))};
+    // forward: X1 = m1 - i s1, X4 = m1 + i s1, X2 = m2 - i s2, X3 = m2 + i s2;  -i z = (z.y, -z.x)
+    const C2 r1 = rot90<INV>(s1), r2 = rot90<INV>(s2);
+    x0 = add(x0, add(t1, t2));
+    x1 = add(m1, r1), x4 = sub(m1, r1);
+    x2 = add(m2, r2), x3 = sub(m2, r2);
+}
+// v[0..5] -> Y; Y[j1 + 2 j2] is left in v[3 j1 + j2]
+template <bool INV>
+F288_HD void dft6(C2* v) {
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const C2 a = v[m2], b = v[3 + m2];
+        v[m2] = add(a, b), v[3 + m2] = sub(a, b);
+    }
+    v[4] = rot<INV>(v[4], 0.5, SIN60);   // W6^1
+    v[5] = rot<INV>(v[5], -0.5, SIN60);  // W6^2
+    dft3<INV>(v[0], v[1], v[2]);
+    dft3<INV>(v[3], v[4], v[5]);
+}
+F288_HD int dft6_at(int k) { return 3 * (k & 1) + (k >> 1); }
+
+// v[0..19] -> X (n = 5 n1 + n2, k = k1 + 4 k2); X[k1 + 4 k2] is left in v[5 k1 + k2]
+template <bool INV>
+F288_HD void dft20(C2* v) {
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) dft4<INV>(v[n2], v[5 + n2], v[10 + n2], v[15 + n2]);
+    // A[k1][n2] *= W20^{n2 k1}: 18 degrees per unit
+    v[6] = rot<INV>(v[6], C18, S18);     // 1
+    v[7] = rot<INV>(v[7], C36, S36);     // 2
+    v[8] = rot<INV>(v[8], S36, C36);     // 3: 54
+    v[9] = rot<INV>(v[9], S18, C18);     // 4: 72
+    v[11] = rot<INV>(v[11], C36, S36);   // 2
+    v[12] = rot<INV>(v[12], S18, C18);   // 4
+    v[13] = rot<INV>(v[13], -S18, C18);  // 6: 108
+    v[14] = rot<INV>(v[14], -C36, S36);  // 8: 144
+    v[16] = rot<INV>(v[16], S36, C36);   // 3
+    v[17] = rot<INV>(v[17], -S18, C18);  // 6
+    v[18] = rot<INV>(v[18], -C18, S18);  // 9: 162
+    v[19] = rot<INV>(v[19], -C36, -S36); // 12: 216
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft5<INV>(v[5 * k1], v[5 * k1 + 1], v[5 * k1 + 2], v[5 * k1 + 3], v[5 * k1 + 4]);
+}
+F288_HD int dft20_at(int k) { return 5 * (k & 3) + (k >> 2); }
+
+// v[0..23] -> X (n = 6 n1 + n2, k = k1 + 4 k2); X[k1 + 4 k2] is left in v[6 k1 + dft6_at(k2)]
+template <bool INV>
+F288_HD void dft24(C2* v) {
+#pragma unroll
+    for (int n2 = 0; n2 < 6; ++n2) dft4<INV>(v[n2], v[6 + n2], v[12 + n2], v[18 + n2]);
+    // A[k1][n2] *= W24^{n2 k1}: 15 degrees per unit
+    v[7] = rot<INV>(v[7], C15, S15);        // 1
+    v[8] = rot<INV>(v[8], SIN60, 0.5);      // 2: 30
+    v[9] = rot<INV>(v[9], R2, R2);          // 3: 45
+    v[10] = rot<INV>(v[10], 0.5, SIN60);    // 4: 60
+    v[11] = rot<INV>(v[11], S15, C15);      // 5: 75
+    v[13] = rot<INV>(v[13], SIN60, 0.5);    // 2
+    v[14] = rot<INV>(v[14], 0.5, SIN60);    // 4
+    v[15] = rot90<INV>(v[15]);              // 6: 90
+    v[16] = rot<INV>(v[16], -0.5, SIN60);   // 8: 120
+    v[17] = rot<INV>(v[17], -SIN60, 0.5);   // 10: 150
+    v[19] = rot<INV>(v[19], R2, R2);        // 3
+    v[20] = rot90<INV>(v[20]);              // 6
+    v[21] = rot<INV>(v[21], -R2, R2);       // 9: 135
+    v[22] = C2{-v[22].x, -v[22].y};         // 12: 180
+    v[23] = rot<INV>(v[23], -R2, -R2);      // 15: 225
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft6<INV>(v + 6 * k1);
+}
+F288_HD int dft24_at(int k) { return 6 * (k & 3) + dft6_at(k >> 2); }
+
+// the second factor M of a 16 x M frame: its transform and where that leaves output k
+template <int M>
+struct Second;
+template <>
+struct Second<18> {
+    template <bool INV>
+    static F288_HD void run(C2* v) { dft18<INV>(v); }
+    static F288_HD int at(int k) { return dft18_at(k); }
+};
+template <>
+struct Second<20> {
+    template <bool INV>
+    static F288_HD void run(C2* v) { dft20<INV>(v); }
+    static F288_HD int at(int k) { return dft20_at(k); }
+};
+template <>
+struct Second<24> {
+    template <bool INV>
+    static F288_HD void run(C2* v) { dft24<INV>(v); }
+    static F288_HD int at(int k) { return dft24_at(k); }
+};
+
 #ifdef __HIPCC__
 // ---- a transform by ONE 32-lane group in LDS (the lane mapping of ldsfft.hpp's passes: two groups per wave), for the
 // kernels whose other stages use all 32 lanes.  buf: the sequence, transformed in place; tw: e^{-2 pi i k / 288}, k < 288;
@@ -120,12 +225,12 @@ __device__ __forceinline__ void group_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template <bool INV>
-__device__ __forceinline__ void fft288_group(C2* __restrict__ buf, const C2* __restrict__ tw, int t) {
-    C2 v[18];
-    if (t < 18) {  // 16-point transforms over n1 of x[18 n1 + t], twiddle, back to the lane's own positions
+template <int M, bool INV>
+__device__ __forceinline__ void fft16_group(C2* __restrict__ buf, const C2* __restrict__ tw, int t) {
+    C2 v[M];
+    if (t < M) {  // 16-point transforms over n1 of x[M n1 + t], twiddle, back to the lane's own positions
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf[18 * n1 + t];
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf[M * n1 + t];
         dft16<INV>(v);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -134,19 +239,19 @@ __device__ __forceinline__ void fft288_group(C2* __restrict__ buf, const C2* __r
                 const C2 e = tw[t * q];
                 a = rot<INV>(a, e.x, -e.y);
             }
-            buf[18 * q + t] = a;
+            buf[M * q + t] = a;
         }
     }
     group_fence();
     if (t < 16) {
 #pragma unroll
-        for (int q = 0; q < 18; ++q) v[q] = buf[18 * t + q];
-        dft18<INV>(v);
+        for (int q = 0; q < M; ++q) v[q] = buf[M * t + q];
+        Second<M>::template run<INV>(v);
     }
     group_fence();
     if (t < 16) {
 #pragma unroll
-        for (int q = 0; q < 18; ++q) buf[t + 16 * q] = v[dft18_at(q)];
+        for (int q = 0; q < M; ++q) buf[t + 16 * q] = v[Second<M>::at(q)];
     }
     group_fence();
 }

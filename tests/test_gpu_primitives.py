@@ -531,7 +531,7 @@ def test_fused_fp64_binning_packed_counters_match_the_32_bit_kernel(monkeypatch)
     c.close()
 
 
-@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (384, 40), (100, 9), (24, 3), (101, 5), (450, 30)])
+@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (256, 40), (384, 40), (100, 9), (24, 3), (101, 5), (450, 30)])  # S = 288, 320, 384 (16 x M register transforms), 480, 128, 32, 128, 512 (radix passes)
 def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
     """gd_density2d: the convolutions through LDS transforms (k_rows_fwd / k_col_conv / k_rows_inv) against the same call
     through rocFFT frames (GDHIP_CONV_ROCFFT=1), on random histograms with bounded and unbounded pairs, linear boundary
