@@ -90,6 +90,9 @@ def init_library_comm(ctx, dist, rank, world, device=None):
 
     import torch
 
+    if device is None and dist.get_backend() == "nccl":  # RCCL reduces device tensors only
+        device = torch.device("cuda", torch.cuda.current_device())
+
     def everyone(flag):
         t = torch.tensor([1 if flag else 0], dtype=torch.int32)
         if device is not None:
