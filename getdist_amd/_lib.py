@@ -132,6 +132,10 @@ SIGNATURES = {
     "gd_comm_allreduce_sum_dev": (C.c_int, [_p, _p, _i64, _p]),
     "gd_batch2d_finish": (C.c_int, [_p]),
     "gd_batch2d_invalidate": (C.c_int, [_p]),
+    "gd_batch2d_exchanges": (C.c_int, [_p, C.POINTER(C.c_int64)]),
+    "gd_comm_rccl_path": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "gd_upload_shard": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "gd_comm_share_columns": (C.c_int, [_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -420,6 +424,36 @@ class Context:
         self._check(self.lib.gd_upload(self.h, s.ctypes.data, N, n, rs, cs, None if w is None else w.ctypes.data))
         self._keep = None
         self.N, self.n, self.weighted = N, n, w is not None
+
+    def upload_shard(self, cols_f, N, n, col_first, weights=None):
+        """This rank's block of columns only (``cols_f``: (N, count) Fortran-ordered fp64, the columns
+        [col_first, col_first + count) of the (N, n) set); the rest arrives by comm_share_columns."""
+        c = np.asfortranarray(cols_f, dtype=np.float64)
+        if c.ndim == 1:
+            c = c.reshape(-1, 1, order="F")
+        count = c.shape[1]
+        assert c.shape[0] == N or count == 0
+        w = None if weights is None else _f64arr(weights)
+        self._keep = (c, w)
+        self._check(self.lib.gd_upload_shard(self.h, c.ctypes.data if count else None, int(N), int(n), int(col_first), int(count),
+                                             int(c.strides[1] // 8) if count else int(N), None if w is None else w.ctypes.data))
+        self._keep = None
+        self.N, self.n, self.weighted = int(N), int(n), w is not None
+
+    def comm_share_columns(self, first_by_rank):
+        f = np.ascontiguousarray(first_by_rank, dtype=np.int64)
+        assert f.size == self.comm_world + 1
+        self._check(self.lib.gd_comm_share_columns(self.h, f.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @staticmethod
+    def comm_rccl_path():
+        lib = load_library()
+        buf = C.create_string_buffer(1024)
+        pre = C.c_int32(0)
+        rc = lib.gd_comm_rccl_path(buf, 1024, C.byref(pre))
+        if rc != 0:
+            raise GdhipError(rc, "librccl.so could not be loaded")
+        return buf.value.decode(), bool(pre.value)
 
     def attach(self, owner):
         """Borrow ``owner``'s resident sample set (same device, no copy): this context becomes a second lane."""
@@ -802,6 +836,12 @@ class Context:
 
     def batch2d_invalidate(self):
         self._check(self.lib.gd_batch2d_invalidate(self.h))
+
+    def batch2d_exchanges(self):
+        """N_eff collectives gd_density2d_batch has entered on this context so far (also by calls that failed later)."""
+        c = C.c_int64(0)
+        self._check(self.lib.gd_batch2d_exchanges(self.h, C.byref(c)))
+        return int(c.value)
 
     def kopt2d(self, d_hist, B, F, neff, do_corr, fallback_t, corr):
         """B x 12: {t*, psi_02, psi_20, psi_11, psi_00, psi_13, psi_31, status, hx, hy, corr, get_h status}"""

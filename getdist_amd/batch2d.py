@@ -274,17 +274,37 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
 
         cb = EXCHANGE_FN(exchange)
     previous = mc._pending_results
+    # The library's own exchange (comm_exchange) may have been ENTERED by a call that failed afterwards -- 'Matrix is not
+    # positive definite', a BandwidthError, a device error, NEED_NEFF from the columns nobody owned: the library counts the
+    # collectives it issued (gd_batch2d_exchanges), and the flag follows the count in a `finally`, before the NEED_NEFF
+    # retry and before any exception leaves -- so that neither the retry, nor NeffShare.complete() in the caller's error
+    # path, enters a second all-reduce that no other rank matches (advisor finding, round 4).
+    count0 = ctx.batch2d_exchanges() if library_exchange else 0
+
+    def note_exchange():
+        if library_exchange and not share.exchanged and ctx.batch2d_exchanges() > count0:
+            share.exchanged = True
+
     for attempt in (0, 1):
         params = pack_params(mc, used, None if share is None else share.params)
         try:
-            tokens = ctx.density2d_batch(twin, settings, params, mc.n, corr, cov, lag_probe, pairs32, cb, grids, status, meta,
-                                         levels, level_status)
+            try:
+                tokens = ctx.density2d_batch(twin, settings, params, mc.n, corr, cov, lag_probe, pairs32, cb, grids, status, meta,
+                                             levels, level_status)
+            finally:
+                note_exchange()
             break
         except GdhipError as e:
             if e.code == NEED_NEFF and attempt == 0:
                 # a chain whose correlation outlasts the 8-lag probe: getCorrelationLength's long route stays on the
                 # Python side (growing chunks of lag sums, then the length-2N transform); the values are cached on the
                 # parameters, so the second call finds them
+                if share is not None and share.exchanged:
+                    # the other ranks' values arrived with the collective this rank has already taken part in: keep them,
+                    # so that _neff_batch's completion step does not look for an exchange
+                    for j in range(mc.n):
+                        if names[j].N_eff_kde is None and not np.isnan(params[j].neff):
+                            names[j].N_eff_kde = float(params[j].neff)
                 mc._neff_batch(used)
                 cb = None if share is None or share.exchanged else cb
                 settings.comm_exchange = int(library_exchange and not share.exchanged)
@@ -297,8 +317,6 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
             if e.code == -1:
                 raise M.SettingError(msg.split(": ", 1)[-1])
             raise
-    if settings.comm_exchange:
-        share.exchanged = True  # (the library entered the collective)
     for j in (range(mc.n) if share is not None else used):
         if names[j].N_eff_kde is None and not np.isnan(params[j].neff):
             names[j].N_eff_kde = float(params[j].neff)

@@ -179,6 +179,17 @@ int gd_batch2d_finish(gd_ctx* ctx) {
     return gdb::finish_all(*(gdb::State*)ctx->batch_state, kOps, ctx);
 }
 
+int gd_batch2d_exchanges(gd_ctx* ctx, int64_t* count_out) {
+    GD_REQUIRE(ctx && count_out, "null argument");
+    *count_out = 0;
+    if (ctx->batch_state) {
+        gdb::State& st = *(gdb::State*)ctx->batch_state;
+        std::lock_guard<std::mutex> g(st.mu);
+        *count_out = st.exchanges_entered;
+    }
+    return GD_OK;
+}
+
 int gd_batch2d_invalidate(gd_ctx* ctx) {
     GD_REQUIRE(ctx, "null context");
     if (!ctx->batch_state) return GD_OK;

@@ -325,6 +325,8 @@ struct State {
     std::map<std::tuple<int, int, int>, IdxCol> idx;     // (column, F, 1 = bytes / 2 = u16)
     Pending prev;                                        // the last lazily delivered call
     void* aux = nullptr;                                 // third context (stream) of large calls: shear chain, get_h
+    int64_t exchanges_entered = 0;                       // N_eff collectives the library ENTERED over the communicator (whether or
+                                                         // not the call went on to succeed): gd_batch2d_exchanges
     static constexpr int64_t kCacheLimit = 16LL << 30;
 };
 
@@ -630,6 +632,10 @@ struct Call {
             // values (zero elsewhere) delivers all of them; one collective per call on every rank, whatever its share needs
             *exchanged = true;
             if (!ops.comm_world || ops.comm_world(h) < 1) return fail(GD_ERR_BADARG, "comm_exchange without a communicator (gd_comm_init)");
+            {  // counted BEFORE the collective is issued: a caller whose call fails later must know that this rank took part
+                std::lock_guard<std::mutex> g(st.mu);
+                ++st.exchanges_entered;
+            }
             std::vector<double> v(n, 0.0);
             for (int j = 0; j < n; ++j)
                 if (par[j].owned && !isnan(par[j].neff)) v[j] = par[j].neff;

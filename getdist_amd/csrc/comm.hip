@@ -1,8 +1,28 @@
-// RCCL inside the C ABI: a communicator per context, the two collectives the multi-GPU decomposition of the path needs
-// (an all-gather of per-rank vectors -- partial moments, per-parameter state, N_eff -- and a sum
-// all-reduce for additive partial tables), issued on the context's stream on device buffers.  librccl.so is resolved
-// at the first gd_comm_* call (dlopen), so single-GPU users never load it.
+// RCCL inside the C ABI: a communicator per context and the collectives the multi-GPU decomposition of the path needs
+// (an all-gather of per-rank vectors -- partial moments, per-parameter state, chain moments --, a sum
+// all-reduce for additive partial tables and the N_eff values, and the distribution of column shards of the sample set over
+// xGMI), issued on the context's stream on device buffers.
+//
+// Robustness (round 5; none of this had run with more than one rank on hardware):
+//  * ONE RCCL per process: the library is looked up among the objects the process has already mapped first
+//    (dlopen(RTLD_NOLOAD): PyTorch's bundled librccl.so when the host application is torch.distributed), and only
+//    loaded from the ROCm installation when nobody has; gd_comm_rccl_path reports which file serves.
+//  * ncclCommInitRank runs on a helper thread under a watchdog (GDHIP_COMM_TIMEOUT_S, default 120 s): a rank that never
+//    arrives makes gd_comm_init return an error instead of hanging the job, and the caller's all-or-nothing agreement
+//    (parallel.init_library_comm) falls back to the host application's collectives.  A late-returning helper aborts the
+//    communicator it obtained.
+//  * the host-vector collectives do not block in hipStreamSynchronize: they poll the stream together with
+//    ncclCommGetAsyncError and give up after the same timeout (ncclCommAbort, communicator dropped), so a dead peer is an
+//    error code and not a hang inside the library.
+//  * GDHIP_COMM_INJECT_HANG_MS (test hook): the helper thread sleeps that long before it joins -- the watchdog path can be
+//    exercised with a single rank on a single GPU (tests/test_gpu_rccl_smoke.py).
 #include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 
 #include "ctx.hpp"
 
@@ -13,15 +33,21 @@ typedef struct {
     char internal[128];
 } rcclUniqueId;
 typedef void* rcclComm_t;
-enum { rcclSuccess = 0, rcclSum = 0, rcclFloat64 = 8 };
+enum { rcclSuccess = 0, rcclInProgress = 7, rcclSum = 0, rcclFloat64 = 8 };
 
 struct Rccl {
     void* lib = nullptr;
+    bool preloaded = false;  // found among the objects already mapped (the host application's RCCL)
     int (*GetUniqueId)(rcclUniqueId*) = nullptr;
     int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int) = nullptr;
     int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*CommAbort)(rcclComm_t) = nullptr;                 // optional
+    int (*CommGetAsyncError)(rcclComm_t, int*) = nullptr;   // optional
     int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;  // optional (column shards)
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -31,19 +57,33 @@ Rccl g_rccl;
 const char* load_rccl() {
     std::lock_guard<std::mutex> g(g_mu);
     if (g_rccl.lib) return nullptr;
-    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    static const char* names[] = {"librccl.so", "librccl.so.1"};
+    void* lib = nullptr;
+    bool preloaded = false;
+    for (const char* nm : names)  // the RCCL this process already holds, if any: never a second copy beside it
+        if (!lib && (lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) preloaded = true;
+    for (const char* nm : names)
+        if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return "librccl.so not found";
     Rccl r;
     r.lib = lib;
+    r.preloaded = preloaded;
     *(void**)&r.GetUniqueId = dlsym(lib, "ncclGetUniqueId");
     *(void**)&r.CommInitRank = dlsym(lib, "ncclCommInitRank");
     *(void**)&r.CommDestroy = dlsym(lib, "ncclCommDestroy");
+    *(void**)&r.CommAbort = dlsym(lib, "ncclCommAbort");
+    *(void**)&r.CommGetAsyncError = dlsym(lib, "ncclCommGetAsyncError");
     *(void**)&r.AllGather = dlsym(lib, "ncclAllGather");
     *(void**)&r.AllReduce = dlsym(lib, "ncclAllReduce");
+    *(void**)&r.Broadcast = dlsym(lib, "ncclBroadcast");
+    *(void**)&r.GroupStart = dlsym(lib, "ncclGroupStart");
+    *(void**)&r.GroupEnd = dlsym(lib, "ncclGroupEnd");
     *(void**)&r.GetErrorString = dlsym(lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce) return "librccl.so lacks the collective entry points";
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce) {
+        dlclose(lib);  // (drops the reference this call took; an object the process had mapped stays mapped)
+        return "librccl.so lacks the collective entry points";
+    }
     g_rccl = r;
     return nullptr;
 }
@@ -51,6 +91,67 @@ const char* load_rccl() {
 int rccl_fail(gd_ctx* ctx, const char* what, int rc) {
     return gd_fail(ctx, GD_ERR_HIP, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
 }
+
+double comm_timeout_s() {
+    const char* e = getenv("GDHIP_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0 ? v : 120.0;
+}
+
+// a communicator that can no longer be trusted (timeout, asynchronous error): abort it -- ncclCommDestroy would wait for
+// the peers -- and drop it from the context; the device staging block stays (a later gd_comm_init reuses it)
+void comm_drop(gd_ctx* ctx) {
+    if (ctx->comm) {
+        if (g_rccl.CommAbort)
+            g_rccl.CommAbort((rcclComm_t)ctx->comm);
+        else if (g_rccl.CommDestroy)
+            g_rccl.CommDestroy((rcclComm_t)ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->comm_world = ctx->comm_rank = 0;
+}
+
+// Wait for everything enqueued on the context's stream WITHOUT blocking in the driver: poll the stream and the
+// communicator's asynchronous error state; a dead peer or a rank that never arrives ends in an error after the timeout.
+int comm_wait(gd_ctx* ctx, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_s();
+    for (int spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return GD_OK;
+        if (q != hipErrorNotReady) {
+            comm_drop(ctx);
+            return gd_fail(ctx, GD_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        }
+        if (g_rccl.CommGetAsyncError && ctx->comm && (spin & 63) == 63) {
+            int async = rcclSuccess;
+            const int rc = g_rccl.CommGetAsyncError((rcclComm_t)ctx->comm, &async);
+            if (rc != rcclSuccess || (async != rcclSuccess && async != rcclInProgress)) {
+                const int bad = rc != rcclSuccess ? rc : async;
+                comm_drop(ctx);
+                return rccl_fail(ctx, what, bad);
+            }
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            comm_drop(ctx);
+            return gd_fail(ctx, GD_ERR_HIP, "%s: no completion after %.0f s (GDHIP_COMM_TIMEOUT_S): a peer rank is missing or dead; the communicator was aborted",
+                           what, limit);
+        }
+        if (spin < 2000)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// ncclCommInitRank under a watchdog
+struct InitJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    int rc = 0;
+    rcclComm_t comm = nullptr;
+};
 
 }  // namespace
 
@@ -88,17 +189,65 @@ int gd_comm_unique_id(void* id128_out) {
     return GD_OK;
 }
 
+int gd_comm_rccl_path(char* buf, int32_t len, int32_t* preloaded_out) {
+    if (!buf || len <= 0) return GD_ERR_BADARG;
+    buf[0] = 0;
+    if (load_rccl()) return GD_ERR_NODEVICE;
+    Dl_info info;
+    if (dladdr((void*)g_rccl.AllReduce, &info) && info.dli_fname) snprintf(buf, (size_t)len, "%s", info.dli_fname);
+    if (preloaded_out) *preloaded_out = g_rccl.preloaded ? 1 : 0;
+    return GD_OK;
+}
+
 int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128) {
     GD_REQUIRE(ctx && id128 && world >= 1 && rank >= 0 && rank < world, "bad argument");
     if (const char* e = load_rccl()) return gd_fail(ctx, GD_ERR_NODEVICE, "%s", e);
     GD_HIP(hipSetDevice(ctx->device));
-    if (ctx->comm) gd_comm_release(ctx);
+    if (ctx->comm) {  // a communicator is replaced only once its work has drained
+        GD_TRY(gd_stream_sync(ctx));
+        if (g_rccl.CommDestroy) g_rccl.CommDestroy((rcclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_world = ctx->comm_rank = 0;
+    }
+    auto job = std::make_shared<InitJob>();
     rcclUniqueId id;
     memcpy(id.internal, id128, 128);
-    rcclComm_t comm = nullptr;
-    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
-    if (rc != rcclSuccess) return rccl_fail(ctx, "ncclCommInitRank", rc);
-    ctx->comm = comm;
+    const int device = ctx->device;
+    const char* inject = getenv("GDHIP_COMM_INJECT_HANG_MS");
+    const int hang_ms = inject ? atoi(inject) : 0;
+    std::thread helper([job, id, world, rank, device, hang_ms] {
+        (void)hipSetDevice(device);
+        if (hang_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(hang_ms));
+        rcclComm_t comm = nullptr;
+        const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (job->abandoned) {  // the caller gave up: nobody will ever use this communicator
+            lk.unlock();
+            if (rc == rcclSuccess && comm) {
+                if (g_rccl.CommAbort)
+                    g_rccl.CommAbort(comm);
+                else
+                    g_rccl.CommDestroy(comm);
+            }
+            return;
+        }
+        job->rc = rc, job->comm = comm, job->done = true;
+        job->cv.notify_all();
+    });
+    const double limit = comm_timeout_s();
+    {
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; })) {
+            job->abandoned = true;
+            lk.unlock();
+            helper.detach();
+            return gd_fail(ctx, GD_ERR_HIP, "ncclCommInitRank: rank %d of %d did not join within %.0f s (GDHIP_COMM_TIMEOUT_S)", (int)rank,
+                           (int)world, limit);
+        }
+    }
+    helper.join();
+    if (job->rc != rcclSuccess) return rccl_fail(ctx, "ncclCommInitRank", job->rc);
+    ctx->comm = job->comm;
     ctx->comm_world = world, ctx->comm_rank = rank;
     return GD_OK;
 }
@@ -143,7 +292,7 @@ int gd_comm_allgather(gd_ctx* ctx, const double* send, int64_t count, double* re
     GD_TRY(gd_h2d(ctx, d_send, send, (size_t)count * 8));
     GD_TRY(gd_comm_allgather_dev(ctx, d_send, count, d_recv));
     GD_TRY(gd_fetch(ctx, recv, d_recv, (size_t)W * count * 8));
-    return gd_stream_sync(ctx);
+    return comm_wait(ctx, "ncclAllGather");
 }
 
 int gd_comm_allreduce_sum(gd_ctx* ctx, double* inout, int64_t count) {
@@ -156,7 +305,33 @@ int gd_comm_allreduce_sum(gd_ctx* ctx, double* inout, int64_t count) {
     GD_TRY(gd_h2d(ctx, d_send, inout, (size_t)count * 8));
     GD_TRY(gd_comm_allreduce_sum_dev(ctx, d_send, count, d_recv));
     GD_TRY(gd_fetch(ctx, inout, d_recv, (size_t)count * 8));
-    return gd_stream_sync(ctx);
+    return comm_wait(ctx, "ncclAllReduce");
+}
+
+// Sample distribution over xGMI (SURVEY.md 8e "broadcast once"): after gd_upload_shard every rank holds the columns
+// [first[r], first[r + 1]) of ITS rank r; each rank broadcasts its block to the others, all W broadcasts in one RCCL
+// group on the context's stream (7 links x ~153 GB/s per GPU against ~50 GB/s of host link: C5's 80 GB per GPU arrive in
+// about a tenth of the time W full uploads take, and a host process need only hold its own columns).
+int gd_comm_share_columns(gd_ctx* ctx, const int64_t* first_by_rank) {
+    GD_REQUIRE(ctx && ctx->comm && first_by_rank, "no communicator / bad argument");
+    GD_REQUIRE(ctx->cols && !ctx->borrowed, "no sample set of this context's own");
+    GD_REQUIRE(g_rccl.Broadcast && g_rccl.GroupStart && g_rccl.GroupEnd, "librccl.so lacks ncclBroadcast / ncclGroupStart");
+    GD_HIP(hipSetDevice(ctx->device));
+    const int W = ctx->comm_world;
+    GD_REQUIRE(first_by_rank[0] == 0 && first_by_rank[W] == ctx->n, "column blocks must cover [0, n)");
+    for (int r = 0; r < W; ++r) GD_REQUIRE(first_by_rank[r] <= first_by_rank[r + 1], "column blocks must be ascending");
+    int rc = g_rccl.GroupStart();
+    if (rc != rcclSuccess) return rccl_fail(ctx, "ncclGroupStart", rc);
+    for (int r = 0; r < W && rc == rcclSuccess; ++r) {
+        const int64_t cnt = (first_by_rank[r + 1] - first_by_rank[r]) * ctx->ld;
+        if (cnt == 0) continue;
+        double* blk = ctx->cols + first_by_rank[r] * ctx->ld;
+        rc = g_rccl.Broadcast(blk, blk, (size_t)cnt, rcclFloat64, r, (rcclComm_t)ctx->comm, ctx->stream);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc != rcclSuccess) return rccl_fail(ctx, "ncclBroadcast", rc);
+    if (rc_end != rcclSuccess) return rccl_fail(ctx, "ncclGroupEnd", rc_end);
+    return comm_wait(ctx, "ncclBroadcast (column shards)");
 }
 
 }  // extern "C"

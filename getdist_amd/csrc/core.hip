@@ -439,15 +439,24 @@ int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* 
 
 // Builds the new sample set in locals; the context is only touched once everything has succeeded, so a failed upload
 // leaves it EMPTY (cols == nullptr, N == 0), never half-initialised.
+// shard_first >= 0: X holds only the columns [shard_first, shard_first + shard_count) of the n (column-major); the others
+// are filled in by gd_comm_share_columns
 static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
                         const double* weights, int64_t ld, double** cols_out, double** w_out, unsigned char** w8_out,
-                        bool* integral_out) {
+                        bool* integral_out, int64_t shard_first = -1, int64_t shard_count = 0) {
     double*& cols = *cols_out;
     double*& w = *w_out;
     unsigned char*& w8 = *w8_out;
     GD_HIP(hipMalloc((void**)&cols, (size_t)(ld * (n + GD_EXTRA_COLS) * 8)));
     GD_HIP(hipMemsetAsync(cols + ld * n, 0, (size_t)(ld * GD_EXTRA_COLS * 8), ctx->stream));
-    if (row_stride == 1) {
+    if (shard_first >= 0) {
+        // (the pad rows of every column are zeroed: the other ranks receive whole ld-row blocks)
+        if (ld > N)
+            for (int64_t j = 0; j < shard_count; ++j)
+                GD_HIP(hipMemsetAsync(cols + (shard_first + j) * ld + N, 0, (size_t)((ld - N) * 8), ctx->stream));
+        for (int64_t j = 0; j < shard_count; ++j)
+            GD_HIP(hipMemcpyAsync(cols + (shard_first + j) * ld, X + j * col_stride, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
+    } else if (row_stride == 1) {
         // column-major host input: one contiguous copy per column
         for (int64_t j = 0; j < n; ++j)
             GD_HIP(hipMemcpyAsync(cols + j * ld, X + j * col_stride, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
@@ -493,9 +502,24 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
     return GD_OK;
 }
 
+static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
+                         const double* weights, int64_t shard_first, int64_t shard_count);
+
 int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
               const double* weights) {
     GD_REQUIRE(ctx && X && N > 0 && n > 0, "bad sample array");
+    return upload_common(ctx, X, N, n, row_stride, col_stride, weights, -1, 0);
+}
+
+int gd_upload_shard(gd_ctx* ctx, const double* X_cols, int64_t N, int64_t n, int64_t col_first, int64_t col_count,
+                    int64_t col_stride, const double* weights) {
+    GD_REQUIRE(ctx && N > 0 && n > 0 && col_first >= 0 && col_count >= 0 && col_first + col_count <= n, "bad column shard");
+    GD_REQUIRE(col_count == 0 || (X_cols && col_stride >= N), "bad column shard");
+    return upload_common(ctx, X_cols, N, n, 1, col_stride, weights, col_first, col_count);
+}
+
+static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
+                         const double* weights, int64_t shard_first, int64_t shard_count) {
     GD_HIP(hipSetDevice(ctx->device));
     GD_TRY(gd_stream_sync(ctx));
     if (ctx->batch_state_release) ctx->batch_state_release(ctx, false);  // index columns of the old sample set
@@ -518,7 +542,7 @@ int gd_upload(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_st
     double *cols = nullptr, *w = nullptr;
     unsigned char* w8 = nullptr;
     bool integral = false;
-    const int rc = upload_build(ctx, X, N, n, row_stride, col_stride, weights, ld, &cols, &w, &w8, &integral);
+    const int rc = upload_build(ctx, X, N, n, row_stride, col_stride, weights, ld, &cols, &w, &w8, &integral, shard_first, shard_count);
     if (rc != GD_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         if (cols) (void)hipFree(cols);

@@ -196,6 +196,43 @@ __device__ __forceinline__ double mask_moment(const double* __restrict__ s, int 
     return v;
 }
 
+// ---- class tables of the mask moments (round 5) -----------------------------------------------------------------
+// mask_geom(x, y) depends on x only through how the window is clipped by the mask's x interval: not at all for
+// f_lo <= x <= f_hi (the `full` columns), and otherwise through the distance to the clipping edge -- at most w + 1 columns
+// on each side.  So a moment takes (2w + 3)^2 distinct values over the grid: class c = x for x < f_lo, w + 1 for the full
+// columns, w + 1 + (x - f_hi) beyond (likewise in y).  k_mask_tables evaluates mask_moment once per class pair from the
+// summed-area table -- the same function on the same operands as the per-pixel evaluation, hence the same bits -- and the
+// consumers (k_boundary<true>, k_rows_inv<1>) look a pixel's moments up instead of running the geometry and up to nine
+// rectangle sums per moment on every border pixel (and staging 9-55 KB of summed-area tables per block to do so).
+// Needs f_lo <= f_hi + 1 on both axes (no pixel clipped on both sides): the host uses the tables for F >= 4 w + 8.
+__device__ __forceinline__ int mask_class(int x, int f_lo, int f_hi, int w) {
+    return x < f_lo ? x : (x > f_hi ? w + 1 + (x - f_hi) : w + 1);
+}
+__device__ __forceinline__ int mask_class_rep(int c, int f_lo, int f_hi, int w) {  // a pixel of class c
+    return c <= w ? c : (c == w + 1 ? f_lo : f_hi + (c - w - 1));
+}
+// grid (n moments, B), after k_window_sat: tab[(b * n + q) * tab_stride + cy * (2w + 3) + cx]
+__global__ void __launch_bounds__(256) k_mask_tables(const D2Pair* __restrict__ pairs, MomList L, int F, int64_t sat_stride,
+                                                     const double* __restrict__ sat, int64_t tab_stride, double* __restrict__ tab) {
+    const D2Pair p = pairs[blockIdx.y];
+    const MomSpec sp = L.m[blockIdx.x];
+    if (sp.kind == 0 && !(p.flags & 64)) return;
+    const int w = p.w, M1 = 2 * w + 2, NC = 2 * w + 3;
+    const double* s = sat + ((int64_t)blockIdx.y * L.n + blockIdx.x) * sat_stride;
+    double* T = tab + ((int64_t)blockIdx.y * L.n + blockIdx.x) * tab_stride;
+    const bool use_edges = (sp.kind == 0) || L.edge_applied;
+    const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, sp.kind, use_edges);
+    const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, sp.kind, use_edges);
+    const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
+    const int yf_lo = iy.lo + (iy.hlo ? 1 : 0), yf_hi = iy.hi - 2 * w - (iy.hhi ? 1 : 0);
+    for (int e = threadIdx.x; e < NC * NC; e += blockDim.x) {
+        const int cy = e / NC, cx = e - cy * NC;
+        const int x = mask_class_rep(cx, xf_lo, xf_hi, w), y = mask_class_rep(cy, yf_lo, yf_hi, w);
+        const bool valid = x >= 0 && x < F && y >= 0 && y < F && mask_class(x, xf_lo, xf_hi, w) == cx && mask_class(y, yf_lo, yf_hi, w) == cy;
+        T[e] = valid ? mask_moment(s, M1, mask_geom(F, w, ix, iy, x, y)) : 0.0;
+    }
+}
+
 // grid (blocks, n moments, B): the moments as F x F arrays (the rocFFT route and explicit masks read them; the LDS route
 // evaluates them where they are used: k_boundary<true>, k_rows_inv<1>)
 __global__ void k_mask_eval(const D2Pair* __restrict__ pairs, MomList L, int F, int64_t sat_stride,
@@ -294,7 +331,8 @@ struct BcArrays {
 template <bool FUSED>
 __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pairs, BcArrays A, const double* __restrict__ mx, int FF,
                                                   int bco, double* __restrict__ mx_out, const double* __restrict__ sat,
-                                                  int64_t sat_stride, int nmom, int F, int stage_lds = 0) {
+                                                  int64_t sat_stride, int nmom, int F, int stage_lds = 0,
+                                                  const double* __restrict__ tab = nullptr, int64_t tab_stride = 0) {
     __shared__ double red[16];
     const int b = blockIdx.y;
     const D2Pair p = pairs[b];
@@ -305,6 +343,56 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
     const double thresh = pair_max(mx, b) * 1e-8;
     const int64_t o = (int64_t)b * FF;
     const int w = p.w, M1 = 2 * w + 2;
+    if (FUSED && tab) {
+        // class tables (k_mask_tables): a pixel's six moments are six look-ups (L2-resident, 6 x (2w+3)^2 doubles per pair;
+        // interior pixels -- nine in ten -- take the full-window entries from registers); nothing is staged, so the block
+        // starts on its pixels at once.  The same values, operations and order as the per-pixel evaluation below.
+        const int NC = 2 * w + 3;
+        const double* T = tab + (int64_t)b * nmom * tab_stride;
+        const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, 0, true);
+        const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, 0, true);
+        const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
+        const int yf_lo = iy.lo + (iy.hlo ? 1 : 0), yf_hi = iy.hi - 2 * w - (iy.hhi ? 1 : 0);
+        const int nq = bco == 1 ? 6 : 1, mid = (w + 1) * NC + (w + 1);
+        double tot[6] = {0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < nq; ++q) tot[q] = T[q * tab_stride + mid];
+        double m = -INFINITY;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
+            const double P = A.P[o + i];
+            const int y = i / F, x = i - y * F;
+            const int e = mask_class(y, yf_lo, yf_hi, w) * NC + mask_class(x, xf_lo, xf_hi, w);
+            const bool full = e == mid;
+            const double a00 = full ? tot[0] : T[e];
+            if (!(a00 * P > thresh)) {
+                m = fmax(m, P);
+                continue;
+            }
+            const double normed = P / a00;
+            if (bco == 0) {
+                A.P[o + i] = normed;
+                m = fmax(m, normed);
+                continue;
+            }
+            double a10 = tot[1], a01 = tot[2], a20 = tot[3], a02 = tot[4], a11 = tot[5];
+            if (!full)
+                a10 = T[tab_stride + e], a01 = T[2 * tab_stride + e], a20 = T[3 * tab_stride + e], a02 = T[4 * tab_stride + e],
+                a11 = T[5 * tab_stride + e];
+            const double xP = A.xP[o + i], yP = A.yP[o + i];
+            const double denom = a20 * (a01 * a01) + (a10 * a10) * a02 - a00 * a02 * a20 + (a11 * a11) * a00 - 2 * a01 * a10 * a11;
+            const double Aq = a11 * a11 - a02 * a20;
+            const double Ax = a10 * a02 - a01 * a11;
+            const double Ay = a01 * a20 - a10 * a11;
+            const double corrected = (P * Aq + xP * Ax + yP * Ay) / denom;
+            const double out = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
+            A.P[o + i] = out;
+            m = fmax(m, out);
+        }
+        if (mx_out) {
+            m = block_max(m, red);
+            if (threadIdx.x == 0) mx_out[(int64_t)b * PM_PARTS + blockIdx.x] = m;
+        }
+        return;
+    }
     // FUSED: the pair's tables come into LDS once per block (dynamic shared memory: nq * sat_stride doubles) -- a border
     // pixel reads up to nine rectangles of each of the six, and from global memory those reads were its critical path
     extern __shared__ double sat_sh[];
@@ -637,9 +725,23 @@ __global__ void k_box(const double* __restrict__ hist, const double* __restrict_
 #include "ldsfft.hpp"
 #include "fft288.hpp"
 
-// grid (ceil(F / RPB), B), RPB * 32 threads = RPB (16) rows of pair b per block: the transposed store then writes 256-byte
-// runs.  A row is real: its even and odd samples are packed into one complex sequence of half the frame length H = S / 2
-// (plH), transformed, and un-mixed into the S / 2 + 1 spectrum values (twg: the S twiddles, stride 2 for the transform).
+// Layout of the half spectra between the row and the column kernels (round 5): TILED by 16 rows,
+//     T[b][y / 16][kx][y % 16]   (NT = ceil(F / 16) tiles of Sh x 16 complex values per pair),
+// so that the 16 rows a row-kernel block transforms are ONE contiguous run of Sh * 256 bytes (37 KB at S = 288): the block
+// transposes inside LDS (un-mixed spectra stay in the rows' own buffers, row stride H + 1 complex values so that the 16
+// rows of one kx fall on different banks) and stores / loads its tile with consecutive lanes on consecutive addresses.
+// Until round 4 the layout was [b][kx][y] and a 64-lane store of the row kernels touched 32 different cache lines with 32
+// bytes each (lanes = 32 different kx, two rows).  The column kernels read / write a column as 256-byte segments of
+// adjacent kx (a block carries 8-12 adjacent columns: 2-3 KB runs per tile).
+#define XT_ROWS 16
+__device__ __forceinline__ int64_t xt_at(int b, int NT, int Sh, int y, int kx) {
+    return (((int64_t)b * NT + (y >> 4)) * Sh + kx) * XT_ROWS + (y & (XT_ROWS - 1));
+}
+
+// grid (ceil(F / 16), B), 16 * 32 threads = the 16 rows of one tile of pair b per block.  A row is real: its even and odd
+// samples are packed into one complex sequence of half the frame length H = S / 2 (plH), transformed, and un-mixed into the
+// S / 2 + 1 spectrum values (twg: the S twiddles, stride 2 for the transform) IN PLACE (X[0] and X[H] are real and share
+// slot 0); after a block barrier the tile goes out in one contiguous run.
 // MODE 0: rows of src (B x F x F); MODE 1: rows of the bias-correction box src / P where P > max * 1e-8 (k_fill_box).
 template <int MODE>
 __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
@@ -647,15 +749,15 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
                                                   const double2* __restrict__ twg, double2* __restrict__ Xt) {
     extern __shared__ double2 sh2[];
     __shared__ double thresh_sh;
-    const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
+    const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
     double2* tw = sh2;
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
-    double2* buf = sh2 + S + (size_t)g * H;
+    double2* buf = sh2 + S + (size_t)g * RP;
     for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
     __syncthreads();
     const int w = pairs[b].w;
-    const int y = blockIdx.x * (blockDim.x / FT) + g;
+    const int y = blockIdx.x * XT_ROWS + g;
     const bool active = y < F;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F, oh = (int64_t)pairs[b].hidx * F * F + (int64_t)y * F;
@@ -678,13 +780,11 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
         f288::fft144_group<false>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
     else
         fft_full<false, false>(buf, tw, 2, plH, t);
-    if (active) {
-        double2* out = Xt + (int64_t)b * Sh * F + y;  // out[kx * F]
+    if (active) {  // un-mix in place: the lane that consumes (buf[k], buf[H - k]) writes (X[k], X[H - k]) there
         for (int k = t; 2 * k <= H; k += FT) {
             if (k == 0) {
                 const double2 z = buf[0];
-                out[0] = make_double2(z.x + z.y, 0.0);
-                out[(int64_t)H * F] = make_double2(z.x - z.y, 0.0);
+                buf[0] = make_double2(z.x + z.y, z.x - z.y);  // (X[0], X[H]): both real
                 continue;
             }
             const double2 zk = buf[k], zm = buf[H - k];
@@ -692,13 +792,31 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
             const double ax = zk.x + zm.x, ay = zk.y - zm.y, bx = zk.x - zm.x, by = zk.y + zm.y;
             const double2 e = tw[k];
             const double u = fma(e.x, bx, -(e.y * by)), v = fma(e.x, by, e.y * bx);
-            out[(int64_t)k * F] = make_double2(0.5 * (ax + v), 0.5 * (ay - u));
+            buf[k] = make_double2(0.5 * (ax + v), 0.5 * (ay - u));
             if (2 * k < H) {  // X[H - k] from the same two values (roles exchanged, w^(H - k))
                 const double2 f = tw[H - k];
                 const double u2 = -fma(f.x, bx, f.y * by), v2 = fma(f.x, by, -(f.y * bx));
-                out[(int64_t)(H - k) * F] = make_double2(0.5 * (ax + v2), 0.5 * (-ay - u2));
+                buf[H - k] = make_double2(0.5 * (ax + v2), 0.5 * (-ay - u2));
             }
         }
+    }
+    __syncthreads();
+    // the tile [kx][16 rows] in one contiguous run (rows of the tile past F carry whatever their idle buffers held: the
+    // column kernels never read them)
+    const int NT = (F + XT_ROWS - 1) / XT_ROWS;
+    double2* tile = Xt + ((int64_t)b * NT + blockIdx.x) * Sh * XT_ROWS;
+    const double2* rows = sh2 + S;
+    for (int i = threadIdx.x; i < Sh * XT_ROWS; i += blockDim.x) {
+        const int kx = i >> 4, row = i & (XT_ROWS - 1);
+        const double2* rb = rows + (size_t)row * RP;
+        double2 v;
+        if (kx == 0)
+            v = make_double2(rb[0].x, 0.0);
+        else if (kx == H)
+            v = make_double2(rb[0].y, 0.0);
+        else
+            v = rb[kx];
+        tile[i] = v;
     }
 }
 
@@ -793,11 +911,11 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
     __syncthreads();
     const int kx = blockIdx.x * 8 + g;
     const bool active = kx < Sh;
+    const int NT = (F + XT_ROWS - 1) / XT_ROWS;
     if (active) {
-        const double2* col = Xt + ((int64_t)b * Sh + kx) * F;
         for (int idx = t; idx < S; idx += FT) {
             const int r = idx - w;
-            bh[idx] = (r >= 0 && r < F) ? col[r] : make_double2(0.0, 0.0);
+            bh[idx] = (r >= 0 && r < F) ? Xt[xt_at(b, NT, Sh, r, kx)] : make_double2(0.0, 0.0);
         }
     }
     group_sync();
@@ -810,8 +928,7 @@ __global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pai
     });
     fft_full<BIG, true>(bh, tw, 1, pl, t);
     if (active) {
-        double2* col = Yt + ((int64_t)b * Sh + kx) * F;
-        for (int r = t; r < F; r += FT) col[r] = bh[r + w];
+        for (int r = t; r < F; r += FT) Yt[xt_at(b, NT, Sh, r, kx)] = bh[r + w];
     }
 }
 
@@ -840,12 +957,13 @@ __global__ void __launch_bounds__(192) k_col_conv16(const D2Pair* __restrict__ p
     C2* buf2 = reinterpret_cast<C2*>(sh2) + S + (size_t)(wave * CW + (c2 < CW ? c2 : 0)) * S;
     C2 v[M];
     // ---- forward, 16-point transforms over n1 of x[M n1 + n2]; the frame's row p holds source row p - w
+    const int NT = (F + XT_ROWS - 1) / XT_ROWS;
     if (act1) {
-        const double2* col = Xt + ((int64_t)b * Sh + kx1) * F;
+        const double2* col = Xt + xt_at(b, NT, Sh, 0, kx1);  // row r of the column: + (r / 16) * Sh * 16 + r % 16
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int r = M * n1 + n2 - w;
-            const double2 x = (r >= 0 && r < F) ? col[r] : make_double2(0.0, 0.0);
+            const double2 x = (r >= 0 && r < F) ? col[(int64_t)(r >> 4) * (Sh * XT_ROWS) + (r & (XT_ROWS - 1))] : make_double2(0.0, 0.0);
             v[n1] = C2{x.x, x.y};
         }
         dft16<false>(v);
@@ -904,12 +1022,12 @@ __global__ void __launch_bounds__(192) k_col_conv16(const D2Pair* __restrict__ p
 #pragma unroll
         for (int q = 0; q < M; ++q) v[q] = buf2[M * k1 + q];
         Second<M>::template run<true>(v);
-        double2* col = Yt + ((int64_t)b * Sh + kx2) * F;
+        double2* col = Yt + xt_at(b, NT, Sh, 0, kx2);
 #pragma unroll
         for (int q = 0; q < M; ++q) {
             const int r = k1 + 16 * q - w;
             const C2 a = v[Second<M>::at(q)];
-            if (r >= 0 && r < F) col[r] = make_double2(a.x, a.y);
+            if (r >= 0 && r < F) col[(int64_t)(r >> 4) * (Sh * XT_ROWS) + (r & (XT_ROWS - 1))] = make_double2(a.x, a.y);
         }
     }
 }
@@ -926,37 +1044,51 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
                                                   const double* __restrict__ a00, double* __restrict__ mx,
                                                   const double* __restrict__ sat1, int64_t sat1_pair_stride, int edge_applied,
-                                                  int sat_in_lds) {
+                                                  int sat_in_lds, const double* __restrict__ tab1 = nullptr,
+                                                  int64_t tab1_pair_stride = 0) {
     extern __shared__ double2 sh2[];
     __shared__ double red[16];
-    const int H = plH.S, S = 2 * H, Sh = H + 1, b = blockIdx.y;
+    const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
     double2* tw = sh2;
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
-    double2* buf = sh2 + S + (size_t)g * H;
+    double2* buf = sh2 + S + (size_t)g * RP;
     for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
+    {  // the block's tile of Yt, one contiguous run, into the rows' buffers (row stride H + 1: slot kx of row r)
+        const int NT = (F + XT_ROWS - 1) / XT_ROWS;
+        const double2* tile = Yt + ((int64_t)b * NT + blockIdx.x) * Sh * XT_ROWS;
+        double2* rows = sh2 + S;
+        for (int i = threadIdx.x; i < Sh * XT_ROWS; i += blockDim.x) rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = tile[i];
+    }
     const int w = pairs[b].w;
     // MODE 1 with tables: the pair's summed-area table of the divisor comes into LDS once -- the border pixels of every row
     // read a dozen of its entries each, and from global memory each such read sat on the row's critical path
     // (measured with the interior shortcut below: 141 -> 107 us per 136-pair launch; requesting the row of the grid ahead of the
     // transform instead of at its use: 117, not kept)
-    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)(blockDim.x / FT) * H);
-    if (MODE == 1 && sat1 && sat_in_lds) {
+    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)(blockDim.x / FT) * RP);
+    // MODE 1 with class tables (k_mask_tables): a row needs the 2w + 3 entries of its y class only -- its group fetches
+    // them (LDS: 16 x (2w + 3) doubles) and a pixel's divisor is one look-up
+    if (MODE == 1 && tab1) {
+        const int fl = pairs[b].flags, NC = 2 * w + 3, yy = blockIdx.x * XT_ROWS + g;
+        const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
+        const int cy = mask_class(min(yy, F - 1), iy.lo + (iy.hlo ? 1 : 0), iy.hi - 2 * w - (iy.hhi ? 1 : 0), w);
+        const double* trow = tab1 + (int64_t)b * tab1_pair_stride + (int64_t)cy * NC;
+        for (int c = t; c < NC; c += FT) sat_l[g * NC + c] = trow[c];
+    } else if (MODE == 1 && sat1 && sat_in_lds) {
         const double* s1g = sat1 + (int64_t)b * sat1_pair_stride;
         const int n1 = (2 * w + 2) * (2 * w + 2);
         for (int i = threadIdx.x; i < n1; i += blockDim.x) sat_l[i] = s1g[i];
     }
     __syncthreads();
-    const int y = blockIdx.x * (blockDim.x / FT) + g;
+    const int y = blockIdx.x * XT_ROWS + g;
     const bool active = y < F;
-    if (active) {
-        const double2* in = Yt + (int64_t)b * Sh * F + y;  // in[kx * F]
+    if (active) {  // in place: the lane that consumes (X[k], X[H - k]) writes (Z[k], Z[H - k]) there
         for (int k = t; 2 * k <= H; k += FT) {
             if (k == 0) {
-                const double x0 = in[0].x, xh = in[(int64_t)H * F].x;  // the imaginary parts of X[0], X[H] do not enter
+                const double x0 = buf[0].x, xh = buf[H].x;  // the imaginary parts of X[0], X[H] do not enter
                 buf[0] = make_double2(x0 + xh, x0 - xh);
                 continue;
             }
-            const double2 xk = in[(int64_t)k * F], xm = in[(int64_t)(H - k) * F];
+            const double2 xk = buf[k], xm = buf[H - k];
             // Z[k] = (xk + conj xm) + i conj(w^k) (xk - conj xm)
             const double ax = xk.x + xm.x, ay = xk.y - xm.y, bx = xk.x - xm.x, by = xk.y + xm.y;
             const double2 e = tw[k];  // w^k = (e.x, e.y); conj: (e.x, -e.y)
@@ -981,18 +1113,21 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
         const double* s1 = (MODE == 1 && sat1) ? (sat_in_lds ? sat_l : sat1 + (int64_t)b * sat1_pair_stride) : nullptr;
         const MaskIv ix = mask_interval(F, w, fl & 1, fl & 2, 1, edge_applied != 0);
         const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
-        const double tot = s1 ? sat_rect(s1, M1, 0, 2 * w, 0, 2 * w) : 0.0;
+        const double tot = (s1 && !tab1) ? sat_rect(s1, M1, 0, 2 * w, 0, 2 * w) : 0.0;
         // where mask_geom's `full` holds (the whole window inside the mask, no half row or column): a rectangle of pixels,
         // known per row -- the interior pixels skip the geometry altogether
         const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
         const bool row_full = y >= iy.lo + (iy.hlo ? 1 : 0) && y <= iy.hi - 2 * w - (iy.hhi ? 1 : 0);
+        const double* drow = sat_l + g * (2 * w + 3);
         for (int x = t; x < F; x += FT) {
             const int pos = x + w;
             const double2 z = buf[pos >> 1];
             double v = (pos & 1) ? z.y : z.x;
             if (MODE == 1) {
                 double div;
-                if (s1) {
+                if (tab1) {
+                    div = drow[mask_class(x, xf_lo, xf_hi, w)];
+                } else if (s1) {
                     if (row_full && x >= xf_lo && x <= xf_hi) {
                         div = tot;
                     } else {
@@ -1278,7 +1413,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     const double2* d_tw = nullptr;
     const int Mmax = 2 * maxw + 1;
     const int RPB = 16;  // rows per block of the row passes
-    const size_t lds_rows = ((size_t)S + (size_t)RPB * (S / 2)) * 16;  // twiddles + a half-length buffer per row
+    const size_t lds_rows = ((size_t)S + (size_t)RPB * (S / 2 + 1)) * 16;  // twiddles + a half-length buffer per row (+ 1: bank padding, X[H])
     const size_t lds_cols = ((size_t)S + (size_t)8 * S) * 16;
     const size_t lds_win = ((size_t)S + (size_t)(Mmax * Mmax + 1) / 2 + (size_t)8 * S) * 16;  // + the window table
     const bool lds_conv = !ov && S <= 512 && (F + RPB - 1) / RPB <= PM_PARTS && lds_win <= 150u * 1024u &&
@@ -1286,7 +1421,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
                           lds_fft_plan(ctx, S / 2, &plH, nullptr);
     // the prior-mask moments are evaluated inside their consumers (k_boundary<true>, k_rows_inv<1>) on the LDS route
     const bool fused = lds_conv && !ov && getenv("GDHIP_CONV_MOMENT_ARRAYS") == nullptr;
-    const int64_t XT = (int64_t)B * Sh * F * 16;  // transposed half spectra of the LDS route
+    // the mask moments of a pixel from their class tables (k_mask_tables) wherever no pixel is clipped on both sides
+    const bool class_tables = fused && n_mom > 0 && F >= 4 * maxw + 8 && getenv("GDHIP_CONV_NO_CLASS_TABLES") == nullptr;
+    const int64_t tab_stride = (int64_t)(2 * maxw + 3) * (2 * maxw + 3);
+    const int64_t XT = (int64_t)B * ((F + 15) / 16) * 16 * Sh * 16;  // tiled half spectra of the LDS route (whole tiles of 16 rows)
     const int64_t WT = (int64_t)B * Sh * S * 8;  // a window moment's spectrum by columns (its real or its imaginary part)
     const int64_t o_pairs = take((int64_t)B * sizeof(D2Pair)), o_wsum = take((int64_t)B * 8), o_mx = take((int64_t)B * 8 * PM_PARTS),
                   o_mx2 = take((int64_t)B * 8 * PM_PARTS),
@@ -1295,7 +1433,8 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
                   o_ZK = take(!lds_conv && do_bc && bco == 1 ? B * SC * 16 : 0), o_ZP = take(lds_conv ? 0 : B * SC * 16),
                   o_arr = take((do_bc ? (bco == 1 ? (fused ? 2 : 8) : (fused ? 0 : 1)) : 0) * B * FF * 8),
                   o_a00m = take(mbc && !fused ? B * FF * 8 : 0),
-                  o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8);
+                  o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8),
+                  o_tab = take(class_tables ? (int64_t)n_mom * B * tab_stride * 8 : 0);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
@@ -1313,6 +1452,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     double* d_a00m = (double*)(base + o_a00m);
     double* d_conv = (double*)(base + o_conv);
     double* d_sat = (double*)(base + o_sat);
+    double* d_tab = class_tables ? (double*)(base + o_tab) : nullptr;
     if (wait) {
         GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair)));
     } else {  // hp dies with this frame before the copy executes
@@ -1382,14 +1522,18 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         }
         GD_KERNEL_CHECK();
         auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
-        size_t lds_rows_inv = lds_rows + (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0);
+        const bool tabs = update && fused && class_tables;  // the divisor by class: one table row per row of the tile
+        size_t lds_rows_inv = lds_rows + (tabs ? (size_t)RPB * (2 * maxw + 3) * 8
+                                               : (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0));
         const int sat_in_lds = lds_rows_inv <= 156u * 1024u;  // (else the table is read where it lies)
         if (!sat_in_lds) lds_rows_inv = lds_rows;
         GD_HIP(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows_inv));
         // (update && fused: the divisor comes from the all-edge mask's table, the last of the pair's n_mom tables)
-        const double* sat1 = (update && fused) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
+        const double* sat1 = (update && fused && !tabs) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
+        const double* tab1 = (tabs && sat_in_lds) ? d_tab + (int64_t)(n_mom - 1) * tab_stride : nullptr;
+        if (tabs && !tab1) sat1 = d_sat + (int64_t)(n_mom - 1) * sat_stride;  // (no room for the rows: the older path)
         kr<<<gR, RPB * FT, lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
-                                                        do_bc ? 1 : 0, sat_in_lds);
+                                                        do_bc ? 1 : 0, sat_in_lds, tab1, (int64_t)n_mom * tab_stride);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
@@ -1436,6 +1580,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         if (!ov) {
             k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
             GD_KERNEL_CHECK();
+            if (class_tables) {
+                k_mask_tables<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat, tab_stride, d_tab);
+                GD_KERNEL_CHECK();
+            }
             if (!fused) {
                 k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);
                 GD_KERNEL_CHECK();
@@ -1469,7 +1617,10 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             FWD(RF, ZK);
             CONV_TO(ZH, ZK, A.yP, (double*)nullptr);
         }
-        if (fused) {
+        if (fused && class_tables) {
+            k_boundary<true><<<gF, 256, 0, ctx->stream>>>(d_pairs, A, d_mx, (int)FF, bco, d_mx2, d_sat, sat_stride, n_mom, F, 0, d_tab,
+                                                          tab_stride);
+        } else if (fused) {
             size_t lds_bc = (size_t)(bco == 1 ? 6 : 1) * sat_stride * 8;
             const int stage = lds_bc <= 64u * 1024u;  // (windows up to 17 bins; wider ones read their tables from global memory)
             if (!stage) lds_bc = 0;

@@ -495,6 +495,12 @@ int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* set
  * again -- what a benchmark does between steps, and what gd_upload does by itself). */
 int gd_batch2d_finish(gd_ctx* ctx);
 int gd_batch2d_invalidate(gd_ctx* ctx);
+/* How many times gd_density2d_batch has ENTERED its own N_eff collective (settings->comm_exchange) on this context, counted
+ * when the all-reduce is issued -- i.e. also for a call that failed afterwards (a matrix that is not positive definite, a
+ * bandwidth error, GD_BATCH2D_NEED_NEFF from the columns nobody owned).  A multi-rank caller reads it around a call to
+ * learn whether this rank has already taken part in the step's collective, so that its error path neither skips nor
+ * repeats it ("exactly once per rank and step"; the reference has no such exchange: mcsamples.py:1230-1235 is per process). */
+int gd_batch2d_exchanges(gd_ctx* ctx, int64_t* count_out);
 
 
 /* ---------------------------------------------------------------- multi-GPU: RCCL over xGMI ------------------------
@@ -509,6 +515,19 @@ int gd_batch2d_invalidate(gd_ctx* ctx);
  *   collective itself runs on device memory on the context's stream: ncclAllGather).  gd_comm_allreduce_sum likewise.
  * The *_dev forms take device pointers and return once enqueued on the context's stream.
  * With a communicator on the context gd_density2d_batch exchanges the N_eff values itself when `exchange` is NULL. */
+/* gd_comm_rccl_path: the file the collectives resolve to and whether it was already mapped by the process (the host
+ *   application's RCCL, e.g. PyTorch's bundled copy: the library never maps a second RCCL beside it).
+ * gd_comm_init runs ncclCommInitRank under a watchdog and the host-vector collectives poll the stream and the
+ *   communicator's asynchronous error state instead of blocking: a rank that never arrives or dies is an error return
+ *   (GD_ERR_HIP, after GDHIP_COMM_TIMEOUT_S seconds, default 120; the communicator is aborted and dropped), not a hang.
+ * gd_upload_shard + gd_comm_share_columns: sample distribution over xGMI -- rank r uploads only its block of columns
+ *   [first[r], first[r+1]) (column-major, column stride col_stride >= N; weights by every rank), then every rank
+ *   broadcasts its block to the others (W ncclBroadcast in one group).  After gd_comm_share_columns the context holds the
+ *   full set exactly as after gd_upload of the whole array (chains.py:276-300: one sample array per process). */
+int gd_comm_rccl_path(char* buf, int32_t len, int32_t* preloaded_out);
+int gd_upload_shard(gd_ctx* ctx, const double* X_cols, int64_t N, int64_t n, int64_t col_first, int64_t col_count,
+                    int64_t col_stride, const double* weights);
+int gd_comm_share_columns(gd_ctx* ctx, const int64_t* first_by_rank /* world + 1 entries */);
 int gd_comm_unique_id(void* id128_out);
 int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128);
 int gd_comm_info(gd_ctx* ctx, int32_t* world_out, int32_t* rank_out);

@@ -1,0 +1,55 @@
+#!/bin/bash
+# One parameterised wrapper for the GPU-box sessions of a round:  gpurun -- 'bash scripts/gpu_session.sh <tag> <stage>...'
+# Stages write under gpurun_out/<tag>/ (merged back by gpurun); the summaries that are judged are copied to profiles/ by hand.
+#   tests        pytest -m gpu (whole suite)            tests:<expr>  pytest -m gpu -k <expr>
+#   conv         scripts/r04_conv_bench.py under rocprofv3 --kernel-trace --stats (one 136-pair batch of the convolution stage)
+#   bench        bench.py --steps 40 --warmup 5 --no-cpu-baseline      benchfull   bench.py (the driver's invocation)
+#   trace        rocprofv3 kernel trace + stream timeline of 4 bench steps
+#   c2 / c4 / c5 scripts/run_configs.py <config> (+ kernel trace for c4)
+#   kernels      scripts/r04_kernels.py (isolated O(N) kernels)
+#   pmcconv      scripts/pmc_conv.sh (counter passes of the convolution kernels)
+#   emulate      bench.py --emulate-world 2/4/8 (+ C5 / C4 forms when present)
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG="$1"; shift
+O=gpurun_out/$TAG; mkdir -p "$O"; export TMPDIR=/tmp
+prof() {  # prof <name> <cmd...>: kernel trace + stats of a command, the stats csv kept as $O/<name>_kernel_stats.csv
+    local name="$1"; shift
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof_$name" -o "$name" -- "$@" > "$GRAFT_REPO_ROOT/$O/$name.log" 2>&1)
+    cp "$(find "$O/prof_$name" -name '*kernel_stats.csv' | head -1)" "$O/${name}_kernel_stats.csv" 2>/dev/null
+}
+for stage in "$@"; do
+    echo "==== stage $stage"
+    case "$stage" in
+        tests) timeout 900 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; tail -5 "$O/pytest.log" ;;
+        tests:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${stage#tests:}" > "$O/pytest_k.log" 2>&1; tail -5 "$O/pytest_k.log" ;;
+        conv)
+            prof conv python "$GRAFT_REPO_ROOT/scripts/r04_conv_bench.py" 8
+            grep "density2d" "$O/conv.log"; rm -rf "$O/prof_conv"
+            python - "$O/conv_kernel_stats.csv" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if float(r["Percentage"]) > 0.4: print("%-60s calls %4s avg %9.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+            ;;
+        bench) GETDIST_AMD_LIVE_PMC=0 timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > "$O/bench_40.json" 2> "$O/bench_40.err"
+               python -c "import json,sys; d=json.loads(open('$O/bench_40.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], 'value', d['value'], 'latency', d['ms_single_triangle_latency'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'])" ;;
+        benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
+               python -c "import json,sys; d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], 'value', d['value'], 'roofline', d['roofline']['frac'], 'cpu', d['cpu_baseline']['value'], 'parity loose', d.get('parity',{}).get('n_pairs_on_loose_gate'))" ;;
+        trace)
+            prof bench python "$GRAFT_REPO_ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline
+            python scripts/stream_timeline.py "$(find "$O/prof_bench" -name '*kernel_trace.csv' | head -1)" 4 0.1 > "$O/bench_stream_timeline.txt" 2>&1
+            rm -rf "$O/prof_bench"; head -30 "$O/bench_kernel_stats.csv" | cut -c1-150 ;;
+        c2|c5) timeout 900 python scripts/run_configs.py "$stage" > "$O/config_$stage.json" 2> "$O/config_$stage.err"; tail -c 600 "$O/config_$stage.json" ;;
+        c4)
+            prof c4 python "$GRAFT_REPO_ROOT/scripts/run_configs.py" c4
+            tail -3 "$O/c4.log" | cut -c1-400; rm -rf "$O/prof_c4"; head -8 "$O/c4_kernel_stats.csv" | cut -c1-170 ;;
+        kernels) timeout 900 python scripts/r04_kernels.py > "$O/kernels.log" 2>&1; cp gpurun_out/r04_kernels.json "$O/kernels.json" 2>/dev/null; tail -3 "$O/kernels.log" ;;
+        pmcconv) timeout 900 bash scripts/pmc_conv.sh "$O" > "$O/pmc_conv.log" 2>&1; tail -5 "$O/pmc_conv.log" ;;
+        emulate)
+            for W in 2 4 8; do
+                GETDIST_AMD_LIVE_PMC=0 timeout 300 python bench.py --steps 30 --warmup 5 --emulate-world $W --no-cpu-baseline > "$O/emulate_w$W.json" 2> "$O/emulate_w$W.err"
+                python -c "import json; d=json.loads(open('$O/emulate_w$W.json').read().strip().splitlines()[-1]); print('W', $W, 'ms_per_step', d['ms_per_step'])"
+            done ;;
+        *) echo "unknown stage $stage" ;;
+    esac
+done

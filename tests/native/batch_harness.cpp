@@ -17,6 +17,12 @@ int gdt_batch_finish(const gdb::Ops* ops, void* st, void* h) { return gdb::finis
 
 void gdt_batch_invalidate(void* st) { gdb::invalidate_index_columns(*(gdb::State*)st); }
 
+int64_t gdt_batch_exchanges(void* st) {
+    gdb::State* s = (gdb::State*)st;
+    std::lock_guard<std::mutex> g(s->mu);
+    return s->exchanges_entered;
+}
+
 int gdt_density2d_batch(const gdb::Ops* ops, void* st, void* h, void* twin, const gd_batch2d_settings* settings,
                         gd_param2d* params, int32_t n, const double* corr, const double* cov, const double* lag_probe,
                         const int32_t* pairs, int32_t P, gd_neff_exchange_fn exchange, void* exchange_user, double* grids,

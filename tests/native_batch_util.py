@@ -384,6 +384,13 @@ class HarnessContext(FakeContext):
         if self.state is not None:
             harness().gdt_batch_invalidate(self.state)
 
+    def batch2d_exchanges(self):
+        if self.state is None:
+            return 0
+        fn = harness().gdt_batch_exchanges
+        fn.restype, fn.argtypes = C.c_int64, [C.c_void_p]
+        return int(fn(self.state))
+
 
 class PlainContext(FakeContext):
     """The double WITHOUT the batch entry points (the Python-planned route), sharing the optimiser cache."""

@@ -243,6 +243,49 @@ def test_native_route_correlated_chain_falls_back_to_the_long_route():
     same(native, plain)
 
 
+def test_library_exchange_entered_by_a_call_that_fails_afterwards_is_not_repeated():
+    """Advisor finding of round 4: on the library-communicator route the entry may have ENTERED the step's all-reduce before
+    it fails (here: GD_BATCH2D_NEED_NEFF from a correlated column nobody owns, raised by the completion step that follows
+    the collective).  The library counts the collectives it issued (gd_batch2d_exchanges); the host sets share.exchanged
+    from that count before the retry, so the retry and NeffShare.complete() issue no second all-reduce that no other rank
+    would match, and the other rank's values -- delivered by the first call -- are kept."""
+    from getdist_amd import parallel
+    from getdist_amd.mcsamples import MCSamples
+
+    rng = np.random.default_rng(11)
+    N = 6000
+    e = rng.normal(size=(N, 3))
+    x = np.zeros((N, 3))
+    for i in range(1, N):
+        x[i] = 0.97 * x[i - 1] + e[i]
+    kw = dict(samples=x, names=["a", "b", "c"])
+    ref = MCSamples(_context_factory=nb.PlainContext, **kw)
+    plain = ref.get2DDensities(triangle(3))
+    truth = np.array([p.N_eff_kde for p in ref.paramNames.names])
+    mc = MCSamples(_context_factory=nb.HarnessContext, **kw)
+    seen = []
+
+    def allreduce(v):  # the other rank owns column 1; column 2 belongs to nobody
+        seen.append(v.copy())
+        other = np.zeros_like(v)
+        other[1] = truth[1]
+        return v + other
+
+    mc.ctx.comm_world, mc.ctx.comm_allreduce_sum = 2, allreduce
+    share = parallel.NeffShare([0], lambda mc_: (_ for _ in ()).throw(AssertionError("a second exchange was entered")))
+    share.library_comm = True
+    mc._neff_share = share
+    # column 0 is this rank's own and correlated as well: give it its value so that the first failure comes AFTER the collective
+    mc._init_params([0, 1, 2])
+    mc.paramNames.names[0].N_eff_kde = float(truth[0])
+    native = mc.get2DDensities(triangle(3))
+    assert len(seen) == 1 and share.exchanged and mc.ctx.batch2d_exchanges() == 1
+    share.complete(mc)  # what bench.one_step's `finally` does: nothing left to enter
+    assert len(seen) == 1
+    assert mc.paramNames.names[1].N_eff_kde == truth[1]
+    same(native, plain)
+
+
 def test_grid_sizes_entry(zoo):
     fx = zoo["block50"]
     mc = make(fx, nb.HarnessContext)
