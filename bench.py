@@ -184,7 +184,12 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0, comm=Non
     if world == 1:
         my_pairs = _PAIR_INDEX["array"]  # nothing to deal out; the (npairs, 2) index array of the list, made once
     else:
-        mine, _ = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
+        # whole tiles of the triangle per rank (a rank pre-bins only the columns its pairs touch), cost classes balanced;
+        # GETDIST_AMD_PAIR_DEAL=class restores the round-robin deal over cost classes (every rank touches every column)
+        if os.environ.get("GETDIST_AMD_PAIR_DEAL", "blocks") == "class":
+            mine, _ = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
+        else:
+            mine, _ = parallel.partition_pairs_by_column_blocks(pairs_all, pair_cost_classes(mc, pairs_all), world, rank, mc.n)
         my_pairs = _PAIR_INDEX["array"][mine]
         mc._neff_share = parallel.NeffShare(my_params, exchange)
         mc._neff_share.library_comm = comm is not None and not emulate
@@ -647,16 +652,20 @@ def main():
 
         mod, attr = args.context_factory.split(":")
         extra["_context_factory"] = getattr(importlib.import_module(mod), attr)
+    share = None
+    if dist is not None and args.backend == "nccl" and os.environ.get("GETDIST_AMD_COMM", "lib") == "lib":
+        # the step's collectives through the C ABI: RCCL on the library's own stream (torch.distributed only carries the
+        # 128-byte id at start-up, and the barriers / the max over ranks around the timed region).  The communicator is made
+        # by the FIRST upload (all-or-nothing over the ranks, every stage under a watchdog: parallel.init_library_comm), which
+        # then sends only this rank's block of columns over PCIe and receives the others over xGMI (parallel.ColumnShare)
+        from getdist_amd import parallel
+
+        share = parallel.ColumnShare(dist, rank, world, torch_device)
+        extra["column_share"] = share
     mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=local_rank, **extra)
     t_ctor = time.perf_counter() - t0
     pairs_all = synth.triangle_pairs(args.nparams)
-    comm = None
-    if dist is not None and args.backend == "nccl" and os.environ.get("GETDIST_AMD_COMM", "lib") == "lib":
-        # the step's collectives through the C ABI: RCCL on the library's own stream (torch.distributed only carries the
-        # 128-byte id at start-up, and the barriers / the max over ranks around the timed region)
-        from getdist_amd import parallel
-
-        comm = parallel.init_library_comm(mc.ctx, dist, rank, world, torch_device)  # None on every rank if any rank cannot
+    comm = share.comm if share is not None else None  # None on every rank if any rank cannot use the library's collectives
 
     def barrier():
         mc.ctx.sync()
@@ -758,6 +767,9 @@ def main():
             line["collectives"] = ("libgdhip gd_comm_* (ncclAllGather / ncclAllReduce on the library's stream)" if comm is not None
                                    else "torch.distributed")
             line["ms_per_step_by_rank"] = [round(v, 3) for v in per_rank_ms]
+            line["sample_distribution"] = ("each rank uploads n/W columns (%.2f GB on rank 0), the blocks are broadcast over xGMI "
+                                           "(gd_comm_share_columns)" % (share.bytes_uploaded / 1e9) if comm is not None else
+                                           "every rank uploads the full set")
         if args.emulate_world:
             line["emulated_world"] = args.emulate_world
             line["n_gpus"] = args.emulate_world

@@ -233,6 +233,59 @@ __global__ void __launch_bounds__(256) k_mask_tables(const D2Pair* __restrict__ 
     }
 }
 
+// k_window_sat + k_mask_tables in one kernel with the summed-area table in LDS (dynamic: (2w+2)^2 doubles of the widest
+// window of the batch): the table kernel alone took 27 us per 136-pair batch reading the tables back from L2 entry by
+// entry -- as long as what the class tables saved in their consumers.  Same operations in the same order as the two
+// kernels (column prefixes, row prefixes, mask_moment per class pair), hence the same bits; the summed-area table is still
+// written out for the consumers' fallback paths.  grid (n moments, B)
+__global__ void __launch_bounds__(256) k_window_sat_tab(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, MomList L,
+                                                        int F, int64_t sat_stride, double* __restrict__ sat, int64_t tab_stride,
+                                                        double* __restrict__ tab) {
+    extern __shared__ double sl[];
+    const D2Pair p = pairs[blockIdx.y];
+    const MomSpec sp = L.m[blockIdx.x];
+    if (sp.kind == 0 && !(p.flags & 64)) return;
+    const int w = p.w, M = 2 * w + 1, M1 = M + 1, NC = 2 * w + 3;
+    const double ws = wsum[blockIdx.y];
+    for (int t = threadIdx.x; t < M1; t += blockDim.x) sl[t] = 0.0, sl[t * M1] = 0.0;
+    for (int c = threadIdx.x; c < M; c += blockDim.x) {
+        const int i2 = c - w;
+        double run = 0;
+        for (int r = 0; r < M; ++r) {
+            const int i1 = r - w;
+            double v = win_raw(p, i1, i2) / ws;
+            for (int q = 0; q < sp.px; ++q) v = v * (double)i2;
+            for (int q = 0; q < sp.py; ++q) v = v * (double)i1;
+            run += v;
+            sl[(r + 1) * M1 + c + 1] = run;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < M; r += blockDim.x) {
+        double* row = sl + (r + 1) * M1 + 1;
+        double run = 0;
+        for (int c = 0; c < M; ++c) {
+            run += row[c];
+            row[c] = run;
+        }
+    }
+    __syncthreads();
+    double* sg = sat + ((int64_t)blockIdx.y * L.n + blockIdx.x) * sat_stride;
+    for (int e = threadIdx.x; e < M1 * M1; e += blockDim.x) sg[e] = sl[e];
+    double* T = tab + ((int64_t)blockIdx.y * L.n + blockIdx.x) * tab_stride;
+    const bool use_edges = (sp.kind == 0) || L.edge_applied;
+    const MaskIv ix = mask_interval(F, w, p.flags & 1, p.flags & 2, sp.kind, use_edges);
+    const MaskIv iy = mask_interval(F, w, p.flags & 4, p.flags & 8, sp.kind, use_edges);
+    const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
+    const int yf_lo = iy.lo + (iy.hlo ? 1 : 0), yf_hi = iy.hi - 2 * w - (iy.hhi ? 1 : 0);
+    for (int e = threadIdx.x; e < NC * NC; e += blockDim.x) {
+        const int cy = e / NC, cx = e - cy * NC;
+        const int x = mask_class_rep(cx, xf_lo, xf_hi, w), y = mask_class_rep(cy, yf_lo, yf_hi, w);
+        const bool valid = x >= 0 && x < F && y >= 0 && y < F && mask_class(x, xf_lo, xf_hi, w) == cx && mask_class(y, yf_lo, yf_hi, w) == cy;
+        T[e] = valid ? mask_moment(sl, M1, mask_geom(F, w, ix, iy, x, y)) : 0.0;
+    }
+}
+
 // grid (blocks, n moments, B): the moments as F x F arrays (the rocFFT route and explicit masks read them; the LDS route
 // evaluates them where they are used: k_boundary<true>, k_rows_inv<1>)
 __global__ void k_mask_eval(const D2Pair* __restrict__ pairs, MomList L, int F, int64_t sat_stride,
@@ -1578,11 +1631,18 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         }
         if (mbc) L.m[L.n++] = {0, 0, 1, d_a00m};
         if (!ov) {
-            k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
-            GD_KERNEL_CHECK();
-            if (class_tables) {
-                k_mask_tables<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat, tab_stride, d_tab);
+            if (class_tables && sat_stride * 8 <= 64 * 1024) {  // tables built with the summed-area table in LDS
+                GD_HIP(hipFuncSetAttribute((const void*)k_window_sat_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sat_stride * 8)));
+                k_window_sat_tab<<<dim3(L.n, B), 256, (size_t)(sat_stride * 8), ctx->stream>>>(d_pairs, d_wsum, L, F, sat_stride, d_sat,
+                                                                                               tab_stride, d_tab);
                 GD_KERNEL_CHECK();
+            } else {
+                k_window_sat<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, L, sat_stride, d_sat);
+                GD_KERNEL_CHECK();
+                if (class_tables) {
+                    k_mask_tables<<<dim3(L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat, tab_stride, d_tab);
+                    GD_KERNEL_CHECK();
+                }
             }
             if (!fused) {
                 k_mask_eval<<<dim3(32, L.n, B), 256, 0, ctx->stream>>>(d_pairs, L, F, sat_stride, d_sat);

@@ -1153,14 +1153,22 @@ __global__ void __launch_bounds__(KR_T) k_kopt2d_res(const double* __restrict__ 
 __global__ void __launch_bounds__(64) k_get_h(double* __restrict__ kopt, const double* __restrict__ neff,
                                               const double* __restrict__ corr, const int* __restrict__ do_corr, int B) {
     const int b = blockIdx.x;
-    if (b >= B || threadIdx.x != 0) return;
+    // lanes 0..3 run the optimiser in lock step (identical state); inside Tnc::function each of them evaluates one of the
+    // n + 1 points of a function-and-gradient call (solvers.hpp); lane 0 writes the result
+    if (b >= B || threadIdx.x >= 4) return;
     double* o = kopt + (int64_t)b * KOPT_STRIDE;
-    o[8] = o[9] = o[10] = NAN;
-    o[11] = (double)GD_ERR_SOLVER;
-    if (o[7] != (double)GD_OK) return;
-    const gdsolve::GetHResult r = gdsolve::get_h(o + 1, neff[b], corr[b], do_corr[b] != 0);
-    o[8] = r.hx, o[9] = r.hy, o[10] = r.corr;
-    o[11] = r.status ? (double)GD_ERR_BADARG : (double)GD_OK;  // status 1: "bias not positive definite"
+    const bool ok = o[7] == (double)GD_OK;
+    double psi[6];
+    for (int q = 0; q < 6; ++q) psi[q] = o[1 + q];
+    if (!ok) {
+        if (threadIdx.x == 0) o[8] = o[9] = o[10] = NAN, o[11] = (double)GD_ERR_SOLVER;
+        return;
+    }
+    const gdsolve::GetHResult r = gdsolve::get_h(psi, neff[b], corr[b], do_corr[b] != 0);
+    if (threadIdx.x == 0) {
+        o[8] = r.hx, o[9] = r.hy, o[10] = r.corr;
+        o[11] = r.status ? (double)GD_ERR_BADARG : (double)GD_OK;  // status 1: "bias not positive definite"
+    }
 }
 
 extern "C" {

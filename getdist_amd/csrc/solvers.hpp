@@ -332,9 +332,60 @@ struct Tnc {
     GD_HD Tnc(Fcn& f, int n_) : fcn(f), n(n_), sf(0), have(false), nfev_total(0) {}
 
     // --- scipy ScalarFunction.fun_and_grad with '2-point' differences, abs_step = 1e-8, bounds
+    // Device form (round 5): the n + 1 function values of one call -- f(x) and one forward difference per unknown -- are
+    // independent, and every evaluation of TNC (iterates, line-search trials, the finite-difference Hessian-vector
+    // products) goes through this function.  The FOUR lowest lanes of the wavefront run the whole optimiser in lock step
+    // on identical state; here lane q evaluates its own point (lane 0: x, lane i + 1: x + h_i e_i) and the values are
+    // exchanged by wave shuffles: one AMISE evaluation (two pow, a square root, a division) per call instead of n + 1 in
+    // sequence.  Every value is computed by the same operations on the same operands as in the sequential form, the
+    // fail / bound tests are applied in its order: the same bits, the same evaluation count (tests/test_gpu_primitives.py
+    // compares with the host build evaluation by evaluation as before).  The caller keeps lanes 0..3 active and converged.
     GD_HD int function(const double* x, double* f, double* g) {
         bool same = have;
         for (int i = 0; i < n && same; ++i) same = (x[i] == sx[i]);
+#ifdef __HIP_DEVICE_COMPILE__
+        if (!same) {
+            for (int i = 0; i < n; ++i) sx[i] = x[i];
+            have = false;
+            double h[TNC_MAXN];
+            for (int i = 0; i < n; ++i) {
+                double hi = 1e-8;
+                const double dx = (sx[i] + hi) - sx[i];
+                if (dx == 0.0) hi = EPSMCH_SQRT() * ((sx[i] >= 0) ? 1.0 : -1.0) * fmax(1.0, fabs(sx[i]));
+                const double lower_dist = sx[i] - low[i], upper_dist = up[i] - sx[i];
+                const double xt = sx[i] + hi;
+                const bool violated = (xt < low[i]) || (xt > up[i]);
+                const bool fitting = fabs(hi) <= fmax(lower_dist, upper_dist);
+                double ha = hi;
+                if (violated && fitting) ha = -hi;
+                if (!fitting) ha = (upper_dist >= lower_dist) ? upper_dist : -lower_dist;
+                h[i] = ha;
+            }
+            const int me = (int)(threadIdx.x & 3) - 1;  // -1: the point itself
+            double xp[TNC_MAXN];
+            for (int q = 0; q < n; ++q) xp[q] = sx[q];
+            for (int q = 0; q < n; ++q)
+                if (q == me) xp[q] = sx[q] + h[q];
+            bool my_fail = false;
+            const double my_f = fcn(xp, &my_fail);
+            const int my_fail_i = my_fail ? 1 : 0;
+            sf = __shfl(my_f, 0, 4);
+            nfev_total += 1;
+            if (__shfl(my_fail_i, 0, 4)) return 1;
+            for (int i = 0; i < n; ++i) {
+                if (sx[i] < low[i] || sx[i] > up[i]) return 1;  // "`x0` violates bound constraints."
+            }
+            for (int i = 0; i < n; ++i) {
+                const double f1 = __shfl(my_f, i + 1, 4);
+                const int fl = __shfl(my_fail_i, i + 1, 4);
+                nfev_total += 1;
+                if (fl) return 1;
+                const double dx = (sx[i] + h[i]) - sx[i];
+                sg[i] = (f1 - sf) / dx;
+            }
+            have = true;
+        }
+#else
         if (!same) {
             bool fail = false;
             for (int i = 0; i < n; ++i) sx[i] = x[i];
@@ -372,6 +423,7 @@ struct Tnc {
             }
             have = true;
         }
+#endif
         *f = sf;
         for (int i = 0; i < n; ++i) g[i] = sg[i];
         return 0;

@@ -467,6 +467,9 @@ class MCSamples:
             settings = dict(settings or {})
             settings["ignore_rows"] = kwargs.pop("ignore_rows")
         chain_exclude, no_cache = kwargs.pop("_chain_exclude", None), kwargs.pop("_no_cache", False)
+        # multi-rank jobs: a parallel.ColumnShare -- this rank uploads only its block of columns over PCIe and the ranks
+        # broadcast their blocks to one another over xGMI (gd_upload_shard / gd_comm_share_columns); additive keyword
+        self._column_share = kwargs.pop("column_share", None)
         if kwargs:
             raise TypeError("unexpected keyword arguments: %s" % ", ".join(kwargs))
         if ini is not None:
@@ -677,7 +680,11 @@ class MCSamples:
                 if self.loglikes is not None:
                     self.loglikes = self.loglikes[keep]
                 self.numrows = self.samples.shape[0]
-        self.ctx.upload(self.samples, w)
+        share = getattr(self, "_column_share", None)
+        if share is not None:
+            share.upload(self.ctx, self.samples, w)  # (collective: every rank of the job uploads at the same point)
+        else:
+            self.ctx.upload(self.samples, w)
         self._idx_cols = {}
         self.mean_loglike = None  # chains.py:317; recomputed on the device when a mean-likelihood is asked for
         self._like_mode = None

@@ -78,18 +78,68 @@ class LibraryComm:
     def allreduce_sum(self, vec):
         return self.ctx.comm_allreduce_sum(vec)
 
+    def share_columns(self, first_by_rank):
+        return self.ctx.comm_share_columns(first_by_rank)
 
-def init_library_comm(ctx, dist, rank, world, device=None):
+
+class StageTimeout(RuntimeError):
+    pass
+
+
+def call_with_watchdog(fn, seconds, what):
+    """Run ``fn()`` on a helper thread and wait at most ``seconds`` for it: the set-up stages of the library communicator
+    are collectives, and a rank that never arrives must end in the all-or-nothing fallback, not in a hung job.  (The C ABI
+    has its own watchdog around ncclCommInitRank -- GDHIP_COMM_TIMEOUT_S -- which normally fires first; this one also
+    covers a binding whose call never returns.)  On a timeout the helper thread is left behind (daemon) and StageTimeout
+    is raised."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:  # noqa: BLE001 -- delivered to the caller below
+            box["error"] = exc
+
+    th = threading.Thread(target=run, name="gdamd-comm-%s" % what, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        raise StageTimeout("%s did not finish within %.0f s" % (what, seconds))
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def comm_stage_timeout():
+    import os
+
+    try:
+        lib_limit = float(os.environ.get("GDHIP_COMM_TIMEOUT_S", "") or 120.0)
+    except ValueError:
+        lib_limit = 120.0
+    try:
+        return float(os.environ["GETDIST_AMD_COMM_STAGE_TIMEOUT_S"])
+    except (KeyError, ValueError):
+        return lib_limit + 30.0  # the library's own watchdog comes first
+
+
+def init_library_comm(ctx, dist, rank, world, device=None, stage_timeout=None):
     """
     Rank 0 makes the RCCL id, every rank joins (collective).  Returns a LibraryComm -- or None ON EVERY RANK when any rank
-    cannot take part (librccl not loadable, the communicator not created, a test all-reduce with the wrong answer): the
-    ranks agree over torch.distributed after each stage, so that either all of them use the library's collectives or all
-    of them keep torch.distributed's, and a half-initialised job neither crashes nor deadlocks in a mismatched collective.
+    cannot take part (librccl not loadable, the communicator not created or not created IN TIME, a test all-reduce with
+    the wrong answer or none at all): the ranks agree over torch.distributed after each stage, so that either all of them
+    use the library's collectives or all of them keep torch.distributed's, and a half-initialised job neither crashes nor
+    deadlocks in a mismatched collective.  Every stage runs under a watchdog (call_with_watchdog): a hang counts as a
+    failure of that stage on the rank that saw it.
     """
     import logging
 
     import torch
 
+    if stage_timeout is None:
+        stage_timeout = comm_stage_timeout()
     if device is None and dist.get_backend() == "nccl":  # RCCL reduces device tensors only
         device = torch.device("cuda", torch.cuda.current_device())
 
@@ -105,8 +155,14 @@ def init_library_comm(ctx, dist, rank, world, device=None):
             logging.warning("library communicator not available (%s): the step's collectives stay with torch.distributed", stage)
         return None
 
+    def destroy_quietly():
+        try:
+            call_with_watchdog(ctx.comm_destroy, stage_timeout, "comm_destroy")
+        except Exception:  # noqa: BLE001 -- (a communicator whose peers are gone: the library aborts it on its own timeout)
+            pass
+
     try:  # stage 1, local: the RCCL library loads and resolves on this rank (gd_comm_unique_id needs nothing else)
-        my_id = ctx.comm_unique_id()
+        my_id = call_with_watchdog(ctx.comm_unique_id, stage_timeout, "comm_unique_id")
         ok = True
     except Exception:
         my_id, ok = None, False
@@ -114,28 +170,127 @@ def init_library_comm(ctx, dist, rank, world, device=None):
         return give_up("librccl could not be loaded on a rank")
     box = [my_id if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
+    hung = False
     try:  # stage 2, collective
-        ctx.comm_init(world, rank, box[0])
+        call_with_watchdog(lambda: ctx.comm_init(world, rank, box[0]), stage_timeout, "comm_init")
         ok = True
+    except StageTimeout:
+        ok, hung = False, True
     except Exception:
         ok = False
     if not everyone(ok):
         if ok:
-            ctx.comm_destroy()
-        return give_up("communicator creation failed on a rank")
+            destroy_quietly()
+        return give_up("communicator creation failed or timed out on a rank")
     comm = LibraryComm(ctx)
     try:  # stage 3: a sum whose answer every rank knows
-        out = comm.allreduce_sum(np.array([rank + 1.0, 1.0]))
+        out = call_with_watchdog(lambda: comm.allreduce_sum(np.array([rank + 1.0, 1.0])), stage_timeout, "test all-reduce")
         ok = bool(out[0] == world * (world + 1) / 2 and out[1] == world)
+    except StageTimeout:
+        ok, hung = False, True
     except Exception:
         ok = False
     if not everyone(ok):
-        try:
-            ctx.comm_destroy()
-        except Exception:
-            pass
-        return give_up("test all-reduce failed on a rank")
+        if not hung:  # (a context whose helper thread is still inside the library is left alone)
+            destroy_quietly()
+        return give_up("test all-reduce failed or timed out on a rank")
     return comm
+
+
+def column_blocks(n, world):
+    """first_by_rank (world + 1 entries): contiguous blocks of columns, sizes differing by at most one."""
+    base, extra = divmod(int(n), int(world))
+    sizes = [base + (1 if r < extra else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+class ColumnShare:
+    """
+    Sample distribution of a multi-rank job over xGMI instead of W full uploads over PCIe ("broadcast once"):
+    rank r uploads only its block of columns (gd_upload_shard; the weights, 1 / n of the data, by every rank) and the
+    ranks broadcast their blocks to one another over the library communicator (gd_comm_share_columns: W ncclBroadcast in one
+    group on the context's stream).  Pass as ``MCSamples(..., column_share=ColumnShare(dist, rank, world))``: the first
+    upload creates the communicator (all-or-nothing, init_library_comm) and keeps it in ``.comm`` for the step's other
+    exchanges; when no rank can use the library's collectives every rank uploads the full array as before.  A host process
+    then needs only its own columns in memory: ``samples`` may be the full (N, n) array or a callable ``cols(first, last)``
+    returning the (N, last - first) block.
+    """
+
+    def __init__(self, dist, rank, world, device=None, comm=None):
+        self.dist, self.rank, self.world, self.device = dist, int(rank), int(world), device
+        self.comm = comm
+        self.tried = comm is not None
+        self.bytes_uploaded = 0
+
+    def upload(self, ctx, samples, weights, n=None):
+        if not self.tried:
+            self.tried = True
+            self.comm = init_library_comm(ctx, self.dist, self.rank, self.world, self.device)
+        full = samples if not callable(samples) else None
+        if self.comm is None:
+            if full is None:
+                nn = int(n)
+                full = samples(0, nn)
+            ctx.upload(full, weights)
+            self.bytes_uploaded = int(np.asarray(full).nbytes)
+            return
+        if full is not None:
+            N, nn = np.shape(full)
+        else:
+            nn = int(n)
+        first = column_blocks(nn, self.world)
+        a, b = int(first[self.rank]), int(first[self.rank + 1])
+        block = np.asarray(full)[:, a:b] if full is not None else np.asarray(samples(a, b))
+        N = block.shape[0]
+        ctx.upload_shard(block, N, nn, a, weights)
+        self.bytes_uploaded = int(block.shape[0]) * (b - a) * 8
+        self.comm.share_columns(first)
+
+
+def partition_pairs_by_column_blocks(pairs, class_ids, world, rank, n):
+    """
+    Deal the pairs of a triangle so that a rank touches FEW columns: the columns are cut into G contiguous groups, pairs
+    fall into the G (G + 1) / 2 group pairs ("tiles"), and whole tiles are dealt to the ranks, heaviest first to the least
+    loaded rank with a preference for the rank that already holds the tile's column groups (weights: the pair count by
+    cost class -- a sheared or bounded pair costs more than a plain one).  A rank's pairs then touch a part of the columns: the
+    per-rank pre-binning (all n columns at 0.83 ms of a 6.8-ms step at 8 ranks, round 4) shrinks with the world size.
+    Falls back to the class deal (partition_pairs_by_class) when the triangle is too small to tile.
+    Returns (indices, pairs) like the other partitioners; deterministic, the same on every rank.
+    """
+    pa = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    P = len(pa)
+    if world <= 1 or P == 0:
+        return list(range(P)), [pairs[i] for i in range(P)]
+    G = 1
+    while G * (G + 1) // 2 < 6 * world and G < n:  # >= 6 tiles per rank: shares within ~3 % of one another
+        G += 1
+    if G < 2 or n < 2 * G:
+        return partition_pairs_by_class(pairs, class_ids, world, rank)
+    group_of = (np.arange(n) * G) // n  # column -> group
+    ga, gb = group_of[pa[:, 0]], group_of[pa[:, 1]]
+    lo, hi = np.minimum(ga, gb), np.maximum(ga, gb)
+    tile = lo * G + hi
+    class_ids = np.asarray(class_ids)
+    # cost of a pair by class: upscaled grid (x6), sheared / optimiser (x1.5), per bounded parameter (+0.5)
+    cost = 1.0 + 5.0 * (class_ids >= 100) + 0.5 * ((class_ids // 10) % 10) + 0.5 * (class_ids % 10 > 0)
+    tiles = np.unique(tile)
+    tcost = np.array([cost[tile == t].sum() for t in tiles])
+    order = np.argsort(-tcost, kind="stable")
+    load = np.zeros(world)
+    cols_of = [set() for _ in range(world)]
+    owner = {}
+    for k in order:
+        t = int(tiles[k])
+        tl, th = divmod(t, G)
+        # least loaded rank; ties go to the rank that already holds this tile's column groups
+        # (tile counts / affinity weight swept on the C3 and C5 triangles: 6 tiles per rank and 0.2 give 30 of 50 columns
+        # at 8 ranks with the heaviest share 3 % above the mean; heavier affinity buys nothing, fewer tiles unbalance)
+        best = min(range(world), key=lambda r: (load[r] + 0.2 * tcost[k] * len({tl, th} - cols_of[r]), r))
+        owner[t] = best
+        load[best] += tcost[k]
+        cols_of[best].update((tl, th))
+    mine = np.nonzero(np.array([owner[int(t)] for t in tile]) == rank)[0].tolist()
+    return mine, [pairs[i] for i in mine]
 
 
 def allgather_neff(mc, my_js, n_params, dist=None, device=None, comm=None):
@@ -275,16 +430,20 @@ def gelman_rubin_from_chain_stats(stats, total_means):
     return None
 
 
-def allgather_chain_stats(local_means, local_cov, local_norm, dist=None, device=None):
+def allgather_chain_stats(local_means, local_cov, local_norm, dist=None, device=None, comm=None):
     """
     Every rank holds ONE chain and has computed its weighted means / covariance / norm on its GPU (gd_cov);
     exchange the n^2+n+1 doubles per rank (RCCL all-gather over xGMI; latency-bound, one fused buffer) and return
     the list of per-chain (means, cov, norm) plus the pooled means  sum_c norm_c mean_c / sum_c norm_c.
+    ``comm``: a LibraryComm -- the all-gather runs inside the C ABI (gd_comm_allgather: ncclAllGather on the context's
+    stream), so a binding that is not Python has the same path; otherwise torch.distributed.
     """
     n = len(local_means)
     buf = np.concatenate([np.asarray(local_means, dtype=np.float64), np.asarray(local_cov, dtype=np.float64).ravel(),
                           [float(local_norm)]])
-    if dist is None or dist.get_world_size() == 1:
+    if comm is not None:
+        rows = list(np.asarray(comm.allgather(buf)).reshape(comm.world, -1))
+    elif dist is None or dist.get_world_size() == 1:
         rows = [buf]
     else:
         import torch
@@ -301,17 +460,18 @@ def allgather_chain_stats(local_means, local_cov, local_norm, dist=None, device=
     return stats, pooled
 
 
-def convergence_chain_per_rank(mc, dist=None, device=None, nparam=None):
+def convergence_chain_per_rank(mc, dist=None, device=None, nparam=None, comm=None):
     """
     SURVEY.md 8e, convergence configuration: every rank holds ONE chain in ``mc`` (an MCSamples on that rank's GPU).
     The local weighted means / covariance / norm come from one gd_cov launch, the n^2+n+1 doubles per rank are
-    all-gathered (RCCL over xGMI with backend "nccl"), and every rank evaluates the Gelman-Rubin eigenvalues
+    all-gathered (RCCL over xGMI: through the library communicator ``comm`` -- gd_comm_allgather, inside the C ABI -- or
+    torch.distributed with backend "nccl"), and every rank evaluates the Gelman-Rubin eigenvalues
     (chains.py:1446-1474) and the per-parameter MeanVar statistic (mcsamples.py:964-985) of the pooled set.
     Returns dict(D, R_minus_1, meanvar, pooled_means, total_norm).
     """
     nparam = nparam or mc.paramNames.numNonDerived()
     means, cov, norm = mc.ctx.cov(list(range(nparam)))
-    stats, pooled = allgather_chain_stats(means, cov, norm, dist, device)
+    stats, pooled = allgather_chain_stats(means, cov, norm, dist, device, comm)
     D = gelman_rubin_from_chain_stats(stats, pooled)
     total = sum(st[2] for st in stats)
     between = sum((st[0] - pooled) ** 2 for st in stats) / (len(stats) - 1) if len(stats) > 1 else np.zeros(nparam)

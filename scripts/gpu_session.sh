@@ -50,6 +50,11 @@ PY
                 GETDIST_AMD_LIVE_PMC=0 timeout 300 python bench.py --steps 30 --warmup 5 --emulate-world $W --no-cpu-baseline > "$O/emulate_w$W.json" 2> "$O/emulate_w$W.err"
                 python -c "import json; d=json.loads(open('$O/emulate_w$W.json').read().strip().splitlines()[-1]); print('W', $W, 'ms_per_step', d['ms_per_step'])"
             done ;;
+        emu_c3) GETDIST_AMD_LIVE_PMC=0 timeout 600 python scripts/emulate_scaling.py --nparams 50 --nsamples 10000000 > "$O/emulate_c3.json" 2> "$O/emulate_c3.err"; cat "$O/emulate_c3.err" | grep "^W=" ;;
+        emu_c3_class) GETDIST_AMD_PAIR_DEAL=class GETDIST_AMD_LIVE_PMC=0 timeout 600 python scripts/emulate_scaling.py --nparams 50 --nsamples 10000000 --worlds 1,8 > "$O/emulate_c3_class.json" 2> "$O/emulate_c3_class.err"; cat "$O/emulate_c3_class.err" | grep "^W=" ;;
+        emu_c5) GETDIST_AMD_LIVE_PMC=0 timeout 900 python scripts/emulate_scaling.py --nparams 200 --nsamples 2000000 --steps 5 --warmup 2 > "$O/emulate_c5.json" 2> "$O/emulate_c5.err"; cat "$O/emulate_c5.err" | grep "^W=" ;;
+        emu_c4) for W in 1 2 4 8; do timeout 300 python scripts/gelman_rubin_multi_gpu.py --emulate-world $W > "$O/emulate_c4_w$W.json" 2> "$O/emulate_c4_w$W.err"; tail -1 "$O/emulate_c4_w$W.json" | cut -c1-300; done ;;
+        rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac
 done

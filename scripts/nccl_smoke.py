@@ -52,6 +52,35 @@ d3 = mc.get2DDensities(synth.triangle_pairs(12))
 mc._neff_share = None
 assert share.exchanged and all(np.array_equal(a.P, b.P) for a, b in zip(d1, d3))
 parallel.allgather_param_state(mc, list(range(mc.n)), mc.n, comm=comm)
+# ONE RCCL in the process: the library resolved its collectives from the copy torch had already mapped
+path, preloaded = mc.ctx.comm_rccl_path()
+maps = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln]
+assert preloaded and len(set(maps)) == 1 and os.path.samefile(path, maps[0]), (path, preloaded, sorted(set(maps)))
+# the convergence configuration's all-gather through the library communicator (one chain per rank; here one rank)
+res = parallel.convergence_chain_per_rank(mc, comm=comm)
+assert res["D"] is None and np.allclose(res["pooled_means"], mc.means[:len(res["pooled_means"])], rtol=1e-13)
+# sample distribution by column shards: this rank's block over PCIe, the broadcast group over the communicator; the set
+# on the device is the one a full upload leaves (densities bit-equal)
+share2 = parallel.ColumnShare(dist, 0, 1)  # (a single rank: its block is everything, the broadcast goes to itself)
+mc2 = MCSamples(samples=s, weights=w, names=names, ranges=ranges, device=0, column_share=share2)
+assert share2.comm is not None and share2.bytes_uploaded == s.size * 8
+d4 = mc2.get2DDensities(synth.triangle_pairs(12))
+assert all(np.array_equal(a.P, b.P) for a, b in zip(d1, d4))
+mc2.ctx.comm_destroy()
+mc.ctx.comm_destroy()
+# the watchdog of gd_comm_init: a rank that takes longer than GDHIP_COMM_TIMEOUT_S to join is an error return, not a hang
+# (GDHIP_COMM_INJECT_HANG_MS delays the helper thread that calls ncclCommInitRank), and the all-or-nothing set-up then
+# leaves the job on torch.distributed's collectives
+import time
+
+os.environ["GDHIP_COMM_TIMEOUT_S"], os.environ["GDHIP_COMM_INJECT_HANG_MS"] = "1", "4000"
+t0 = time.time()
+assert parallel.init_library_comm(mc.ctx, dist, 0, 1) is None and time.time() - t0 < 3.5
+del os.environ["GDHIP_COMM_INJECT_HANG_MS"]
+os.environ["GDHIP_COMM_TIMEOUT_S"] = "120"
+time.sleep(3.5)  # (the abandoned helper finishes and aborts the communicator it obtained)
+comm = parallel.init_library_comm(mc.ctx, dist, 0, 1)  # and the next set-up works
+assert comm is not None and np.array_equal(comm.allreduce_sum(v), v)
 mc.ctx.comm_destroy()
 dist.destroy_process_group()
-print("nccl smoke ok (torch.distributed + gd_comm_*): torch %s, %d densities three times, bit-equal" % (torch.__version__, len(d1)))
+print("nccl smoke ok (torch.distributed + gd_comm_*): torch %s, %d densities four times, bit-equal; RCCL = %s" % (torch.__version__, len(d1), path))

@@ -95,6 +95,25 @@ class FakeContext:
         self.weighted = self.w is not None
         self._like_w, self._w_sel = None, 0
 
+    def upload_shard(self, cols_f, N, n, col_first, weights=None):
+        """gd_upload_shard: this rank's block of columns only; the others are NaN until comm_share_columns."""
+        block = np.asarray(cols_f, dtype=np.float64).reshape(N, -1)
+        self.N, self.n = int(N), int(n)
+        self.s = np.full((self.N, self.n + self.EXTRA_COLS), np.nan)
+        self.s[:, self.n:] = 0.0
+        self.s[:, col_first:col_first + block.shape[1]] = block
+        self.w = None if weights is None else np.asarray(weights, dtype=np.float64)
+        self.weighted = self.w is not None
+        self._like_w, self._w_sel = None, 0
+
+    def comm_share_columns(self, first_by_rank):
+        """gd_comm_share_columns: rank r broadcasts its block; ``comm_broadcast(array, root)`` is supplied by the test."""
+        first = np.asarray(first_by_rank, dtype=np.int64)
+        for r in range(len(first) - 1):
+            a, b = int(first[r]), int(first[r + 1])
+            if b > a:
+                self.s[:, a:b] = self.comm_broadcast(np.ascontiguousarray(self.s[:, a:b]), r)
+
     def _w(self, lo=0, hi=None):
         hi = self.N if hi is None else hi
         if getattr(self, "_w_sel", 0):

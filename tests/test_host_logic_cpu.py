@@ -394,8 +394,7 @@ WORKER = textwrap.dedent("""
     dens = bench.one_step(mc, pairs, dist, rank, world, None)
     # which pairs did this rank take, and what did it get?
     from getdist_amd import parallel
-    classes = dict(zip(pairs, bench.pair_cost_classes(mc, pairs)))
-    idx, mine = parallel.partition_pairs(pairs, classes.__getitem__, world, rank)
+    idx, mine = parallel.partition_pairs_by_column_blocks(pairs, bench.pair_cost_classes(mc, pairs), world, rank, mc.n)
     assert len(mine) == len(dens)
     np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), idx=np.array(idx), P=np.array([d.P for d in dens]),
              neff=np.array([p.N_eff_kde for p in mc.paramNames.names]))

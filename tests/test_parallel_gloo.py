@@ -229,21 +229,31 @@ COMM_WORKER = textwrap.dedent("""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    import datetime, time
+    # the "library's" collectives travel on a group of their own, as RCCL's do beside torch.distributed's
+    lib_group = dist.new_group(timeout=datetime.timedelta(seconds=6))
+
     class FakeLibCtx:  # the gd_comm_* surface of _lib.Context, its collectives carried by gloo
         def __init__(self, fail=None):
             self.fail, self.comm_world, self.destroyed = fail, 0, 0
         def comm_unique_id(self):
             if self.fail == "load":
                 raise RuntimeError("librccl.so: cannot open shared object file")
+            if self.fail == "hang_load":
+                time.sleep(3600)
             return b"x" * 128
         def comm_init(self, world, rank, id128):
             assert id128 == b"x" * 128
             if self.fail == "init":
                 raise RuntimeError("ncclCommInitRank failed")
+            if self.fail == "hang_init":
+                time.sleep(3600)  # a rank that never joins
             self.comm_world = world
         def comm_allreduce_sum(self, vec):
+            if self.fail == "hang_sum":
+                time.sleep(3600)  # never enters the collective: the peer's all-reduce has no partner
             t = torch.from_numpy(np.array(vec, dtype=np.float64))
-            dist.all_reduce(t)
+            dist.all_reduce(t, group=lib_group)
             out = t.numpy()
             if self.fail == "sum":
                 out = out + 1.0
@@ -265,15 +275,30 @@ COMM_WORKER = textwrap.dedent("""
             assert ctx.destroyed == (0 if rank == bad_rank else 1)
         if stage == "sum":
             assert ctx.destroyed == 1
+    # a HANG at any stage (a rank that never arrives, a collective without its partner) ends the same way: every stage runs
+    # under a watchdog, the rank that timed out reports failure, and every rank keeps torch.distributed's collectives
+    for stage, bad_rank in (("hang_load", 0), ("hang_init", 1), ("hang_sum", 0)):
+        ctx = FakeLibCtx(stage if rank == bad_rank else None)
+        t0 = time.time()
+        assert parallel.init_library_comm(ctx, dist, rank, world, stage_timeout=1.5) is None, (stage, rank)
+        assert time.time() - t0 < 30.0, (stage, rank)
+    # ... and torch.distributed itself is still in step afterwards
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    assert t.item() == world * (world + 1) / 2
     dist.barrier()
     print("rank", rank, "ok")
+    sys.stdout.flush()
+    os._exit(0)  # (helper threads left inside the injected hangs do not keep the worker alive)
 """)
 
 
 def test_library_communicator_is_all_or_nothing_gloo_world2(tmp_path):
     """parallel.init_library_comm: the ranks agree after each stage (library loadable, communicator created, a test
     all-reduce right) whether the step's collectives go through the C ABI or stay with torch.distributed -- a failure on one
-    rank at any stage gives None on every rank, never a mismatched collective."""
+    rank at any stage gives None on every rank, never a mismatched collective.  Round 5: so does a HANG injected at each
+    stage (unique id, communicator creation, test all-reduce): the stages run under watchdogs (parallel.call_with_watchdog
+    here, GDHIP_COMM_TIMEOUT_S inside the C ABI)."""
     script = tmp_path / "comm_worker.py"
     script.write_text(COMM_WORKER % dict(root=ROOT))
     with socket.socket() as s:
@@ -288,3 +313,113 @@ def test_library_communicator_is_all_or_nothing_gloo_world2(tmp_path):
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out
         assert "rank %d ok" % rank in out
+
+
+SHARE_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from fake_ctx import FakeContext
+    from getdist_amd import parallel, synth
+    from getdist_amd.mcsamples import MCSamples
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class CommCtx(FakeContext):  # the numpy double plus the gd_comm_* surface, carried by gloo
+        comm_world = 0
+        def comm_unique_id(self):
+            return b"y" * 128
+        def comm_init(self, world, rank, id128):
+            self.comm_world, self.comm_rank = world, rank
+        def comm_destroy(self):
+            self.comm_world = 0
+        def comm_allreduce_sum(self, vec):
+            t = torch.from_numpy(np.array(vec, dtype=np.float64))
+            dist.all_reduce(t)
+            return t.numpy()
+        def comm_allgather(self, vec):
+            t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+            out = [torch.empty_like(t) for _ in range(self.comm_world)]
+            dist.all_gather(out, t)
+            return np.stack([o.numpy() for o in out])
+        def comm_broadcast(self, arr, root):
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            dist.broadcast(t, src=root)
+            return t.numpy()
+
+    s, w, names, ranges = synth.config_c1(20000, bounded=True)
+    w = np.random.default_rng(3).exponential(size=len(s))
+    share = parallel.ColumnShare(dist, rank, world)
+    mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=CommCtx, column_share=share)
+    first = parallel.column_blocks(s.shape[1], world)
+    # this rank sent only its own block over "PCIe" ...
+    assert share.comm is not None and share.bytes_uploaded == len(s) * int(first[rank + 1] - first[rank]) * 8
+    # ... and holds the whole set afterwards, bit for bit
+    assert np.array_equal(mc.ctx.s[:, :s.shape[1]], s)
+    ref = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=FakeContext)
+    assert np.array_equal(mc.means, ref.means) and np.array_equal(mc.fullcov, ref.fullcov)
+    d, r = mc.get2DDensity(names[0], names[1]), ref.get2DDensity(names[0], names[1])
+    assert np.array_equal(d.P, r.P)
+    # the convergence configuration through the library communicator: one chain per rank
+    chain = s[rank::world][:, :3]
+    wc = w[rank::world]
+    mc1 = MCSamples(samples=chain, weights=wc, names=names[:3], _context_factory=CommCtx)
+    mc1.ctx.comm_init(world, rank, b"y" * 128)
+    out = parallel.convergence_chain_per_rank(mc1, comm=parallel.LibraryComm(mc1.ctx))
+    out_t = parallel.convergence_chain_per_rank(mc1, dist=dist)
+    assert np.array_equal(out["D"], out_t["D"]) and np.array_equal(out["meanvar"], out_t["meanvar"]) and out["total_norm"] == out_t["total_norm"]
+    dist.barrier()
+    print("rank", rank, "ok")
+""")
+
+
+def test_column_shards_and_chain_statistics_over_the_library_communicator_gloo_world2(tmp_path):
+    """Sample distribution for multi-rank jobs (parallel.ColumnShare: every rank uploads its block of columns only and the
+    ranks broadcast their blocks to one another -- gd_upload_shard / gd_comm_share_columns in the C ABI) leaves every rank
+    with the full set bit for bit, and the convergence configuration's all-gather (chains.py:1446-1474 per-chain moments)
+    runs through the library communicator with the same result as through torch.distributed."""
+    script = tmp_path / "share_worker.py"
+    script.write_text(SHARE_WORKER % dict(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+
+
+def test_partition_by_column_blocks_covers_every_pair_once_and_touches_few_columns():
+    """parallel.partition_pairs_by_column_blocks: whole tiles of the triangle go to one rank, so a rank's pairs touch a
+    fraction of the columns (what it pre-bins), every pair is dealt exactly once, and the shares stay balanced."""
+    from getdist_amd import parallel, synth
+
+    n = 50
+    pairs = synth.triangle_pairs(n)
+    rng = np.random.default_rng(0)
+    klass = rng.choice([0, 1, 10, 11, 21, 101], size=len(pairs), p=[0.55, 0.25, 0.08, 0.06, 0.04, 0.02])
+    for world in (2, 4, 8):
+        seen, touched, sizes = [], [], []
+        for rank in range(world):
+            mine, mp = parallel.partition_pairs_by_column_blocks(pairs, klass, world, rank, n)
+            assert mp == [pairs[i] for i in mine]
+            seen += mine
+            touched.append(len({c for pr in mp for c in pr}))
+            sizes.append(len(mine))
+        assert sorted(seen) == list(range(len(pairs)))
+        assert max(sizes) <= 1.35 * len(pairs) / world, (world, sizes)
+        if world >= 4:
+            assert max(touched) <= (0.9 if world == 4 else 0.65) * n, (world, touched)
+    # a triangle too small to tile falls back to the class deal
+    small = synth.triangle_pairs(4)
+    got = sorted(i for r in range(2) for i in parallel.partition_pairs_by_column_blocks(small, [0] * len(small), 2, r, 4)[0])
+    assert got == list(range(len(small)))
