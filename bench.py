@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
     ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock cap of each CPU-baseline pool stage; "
                     "a stage that exceeds it is abandoned and reported as such (the GPU numbers are printed regardless)")
+    ap.add_argument("--census-budget-s", type=float, default=420.0, help="wall-clock cap of the all-pairs full-size parity "
+                    "census (hosts with >= 64 cores); abandoned and reported as such beyond it")
     ap.add_argument("--context-factory", default="", help="testing only: 'module:attr' of a Context stand-in (the CPU "
                     "suite runs the launcher and the multi-rank step with tests/fake_ctx.py); the product path never sets it")
     return ap.parse_args()
@@ -344,6 +346,16 @@ def _cpu_noop(k):
     return k
 
 
+def _verdict_record(v):
+    """What is reported per loose pair (review item, round 4): the criterion and the perturbation scale that admitted the
+    device's bandwidth triple under the frozen rules, the distance to the nearest member of the oracle's ensemble, and the
+    verdict at the strict slack of 0.25."""
+    return dict(admitted=bool(v["ok"]), admitted_by=v.get("admitted_by"), perturbation_scale=v["scale"],
+                nearest_member_rel=v.get("nearest_member"), excess_over_spread=v["excess"], amise_excess=v["amise_excess"],
+                amise_range=v["amise_range"], strict_slack_0p25_admits=bool(v.get("strict_ok")),
+                strict_scale=v.get("strict_scale"), strict_admitted_by=v.get("strict_admitted_by"), members=v["members"])
+
+
 def _cpu_task(task):
     """Worker: one oracle task on memory-mapped sample columns.  kinds: 'prep' (ranges + N_eff of one parameter),
     'pair' (one 2D density with its parameters' N_eff prepared beforehand, as in a triangle) and 'triangle' (a share of
@@ -388,6 +400,7 @@ def _cpu_task(task):
                     out["chaotic"] = (v["moved"] > 1e-6, v["moved"])
                     out["inside_oracle_spread"], out["excess"], out["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
                     out["ensemble_perturbation"] = v["scale"]
+                    out["verdict"] = _verdict_record(v)
                 else:
                     ens = ko.get_h_ensemble(psi, tr["opt_N"], tr["opt_corr"])
                     moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
@@ -395,11 +408,21 @@ def _cpu_task(task):
         return out
     # share of a full triangle: this worker's pairs, parameter state cached across them.  The CPU time is the oracle's
     # alone; afterwards (outside the timed span) every grid is compared with the GPU's grid of the same pair, read from
-    # the flat file the GPU run left in shared memory, and a pair above 1e-6 is put to the oracle-ensemble test
-    orc = ko.OracleSamples(np.array(s), names=names, ranges=ranges)
+    # the flat file the GPU run left in shared memory, and a pair above 1e-6 is put to the oracle-ensemble test.
+    # task["cols"]: only these columns are copied out of the mapped file (the full-size census: a worker's share touches
+    # a tile of the triangle, about ten columns); pair indices are remapped to them
+    pairs_here = task["pairs"]
+    if task.get("cols") is not None:
+        cols = list(task["cols"])
+        at_col = {c: k for k, c in enumerate(cols)}
+        sub_names = [names[c] for c in cols]
+        orc = ko.OracleSamples(np.asfortranarray(s[:, cols]), names=sub_names, ranges={k: v for k, v in ranges.items() if k in sub_names})
+        pairs_here = [(at_col[a], at_col[b]) for a, b in task["pairs"]]
+    else:
+        orc = ko.OracleSamples(np.array(s), names=names, ranges=ranges)
     t0 = time.perf_counter()
     grids, traces = [], []
-    for a, b in task["pairs"]:
+    for a, b in pairs_here:
         for k in (a, b):
             if orc.pars[k].N_eff_kde is None:
                 orc.init_param(k)
@@ -422,8 +445,114 @@ def _cpu_task(task):
                 row["oracle_moves_by"] = v["moved"]
                 row["inside_oracle_spread"], row["excess"], row["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
                 row["ensemble_perturbation"] = v["scale"]
+                row["verdict"] = _verdict_record(v)
         rows.append(row)
     return dict(kind=kind, seconds=seconds, rows=rows)
+
+
+def _census_summary(rows, has_limits, names):
+    """Per-class table and the loose pairs (with their verdict records) of an all-pairs comparison."""
+    census = {}
+    for row in rows:
+        a, b = row["pair"]
+        key = "%s/%d/%d" % (row["branch"], int(bool(has_limits[a])) + int(bool(has_limits[b])), row["F"])
+        c = census.setdefault(key, dict(pairs=0, errs=[], loose=0))
+        c["pairs"] += 1
+        c["errs"].append(row.get("err", float("inf")))
+        c["loose"] += row.get("err", float("inf")) > 1e-6
+    loose_rows = [r for r in rows if r.get("err", float("inf")) > 1e-6]
+    return dict(
+        gate="max|dP| of the max-normalised grids, GPU vs oracle, every pair of the triangle",
+        pairs_compared=len(rows), grid_shapes_equal=int(sum(r["shape_ok"] for r in rows)),
+        pairs_within_1e_6=int(sum(r.get("err", 9.0) <= 1e-6 for r in rows)),
+        pairs_above_1e_6=len(loose_rows), worst_abs_dP=float(max([r.get("err", 0.0) for r in rows] or [0.0])),
+        loose_pairs_that_use_tnc=int(sum(bool(r["tnc"]) for r in loose_rows)),
+        loose_pairs_chaotic_in_the_oracle=int(sum(r.get("oracle_moves_by", 0.0) > 1e-6 for r in loose_rows)),
+        loose_pairs_inside_the_oracle_spread=int(sum(bool(r.get("inside_oracle_spread")) for r in loose_rows)),
+        loose_pairs_inside_spread_or_as_good_in_amise=int(sum(bool(r.get("inside_oracle_spread") or r.get("amise_ok")) for r in loose_rows)),
+        loose_pairs_admitted_at_strict_slack_0p25=int(sum(bool((r.get("verdict") or {}).get("strict_slack_0p25_admits")) for r in loose_rows)),
+        worst_excess_over_oracle_spread=float(max([r.get("excess", 0.0) for r in loose_rows] or [0.0])),
+        loose_pairs=[dict(pair=[names[r["pair"][0]], names[r["pair"][1]]], max_abs_dP=r.get("err"), verdict=r.get("verdict"))
+                     for r in loose_rows],
+        per_class={k: dict(pairs=v["pairs"], above_1e_6=int(v["loose"]), max_abs_dP=float(np.max(v["errs"])),
+                           median_abs_dP=float(np.median(v["errs"]))) for k, v in sorted(census.items())})
+
+
+def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, tmp, cores):
+    """EVERY pair of the triangle at full N against the oracle (review item, round 4: the driver-run parity was a sample of
+    31), when the host has the cores for it: the pairs are dealt to the workers by tiles of the triangle
+    (parallel.partition_pairs_by_column_blocks), so that a worker prepares and copies only the ~10 columns its tile touches;
+    the GPU grids travel in one flat file in shared memory.  Guarded by the free memory of the host (a worker holds its
+    columns: ~1 GB) and by a wall-clock budget; returns None when it does not run, a dict with 'abandoned' when it ran out
+    of time."""
+    import multiprocessing as mp
+
+    from getdist_amd import parallel
+
+    min_cores = int(os.environ.get("GETDIST_AMD_CENSUS_MIN_CORES", "64"))  # (lowered by the CPU smoke of this function only)
+    if cores < min_cores or os.environ.get("GETDIST_AMD_FULL_CENSUS", "1") != "1":
+        return None
+    N = int(np.load(s_path, mmap_mode="r").shape[0])
+    workers = int(max(2, min(cores // 2, 96, len(pairs_all))))
+    try:
+        import psutil
+
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    per_worker = 14 * N * 8 * 1.6 + 600e6  # its columns (a tile: <= 14), the oracle's temporaries, the interpreter
+    if avail < workers * per_worker + 8e9:
+        workers = int(max(0, (avail - 8e9) // per_worker))
+    if workers < min(32, min_cores // 2):
+        return dict(ran=False, reason="not enough free host memory for >= 32 census workers (%.0f GB available)" % (avail / 1e9))
+    sizes = np.array([d.P.size for d in dens], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    flat = np.empty(int(offs[-1]))
+    for d, o in zip(dens, offs[:-1]):
+        flat[o:o + d.P.size] = d.P.ravel()
+    path_gpu = os.path.join(tmp, "gpu_grids_full.npy")
+    np.save(path_gpu, flat)
+    del flat
+    at = {pr: k for k, pr in enumerate(pairs_all)}
+    n = len(names)
+    tasks = []
+    for r in range(workers):
+        mine, sh = parallel.partition_pairs_by_column_blocks(pairs_all, np.zeros(len(pairs_all), dtype=np.int64), workers, r, n)
+        if not sh:
+            continue
+        cols = sorted({c for pr in sh for c in pr})
+        tasks.append(dict(kind="triangle", path=s_path, names=list(names), ranges=dict(ranges), pairs=sh, cols=cols,
+                          gpu_path=path_gpu, gpu_offsets=[int(offs[at[pr]]) for pr in sh],
+                          gpu_F=[int(dens[at[pr]].P.shape[0]) for pr in sh],
+                          gpu_kopt=[None if dens[at[pr]].kopt is None else np.asarray(dens[at[pr]].kopt) for pr in sh]))
+    saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved_env:
+        os.environ[k] = "1"
+    t0 = time.perf_counter()
+    try:
+        with mp.get_context("spawn").Pool(len(tasks)) as pool:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            try:
+                tri = pool.map_async(_cpu_task, tasks, chunksize=1).get(timeout=args.census_budget_s)
+            except mp.TimeoutError:
+                return dict(ran=True, abandoned=True, reason="wall-clock budget of %.0f s exceeded" % args.census_budget_s,
+                            workers=len(tasks))
+    finally:
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    rows = [row for r in tri for row in r["rows"]]
+    out = _census_summary(rows, has_limits, names)
+    out.update(ran=True, N=N, workers=len(tasks), wall_s=round(time.perf_counter() - t0, 1),
+               cpu_core_seconds=round(sum(r["seconds"] for r in tri), 1),
+               note="every pair of the timed triangle at full size against the oracle; workers hold one tile of the triangle each")
+    return out
 
 
 def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
@@ -448,9 +577,14 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
         key = "%s/%d/%d" % (d.bandwidth_branch, int(bool(par[a].has_limits)) + int(bool(par[b].has_limits)), d.P.shape[0])
         klass.setdefault(key, []).append((a, b))
     # up to 3 pairs per class, 6 from the classes that hold a hundred pairs or more (spread over the class, not its head)
+    # (a host without the cores for the all-pairs census below takes every sheared -- branch A -- pair instead: they are
+    # the ones whose bandwidth goes through the re-binned grid)
+    census_will_run = cores >= int(os.environ.get("GETDIST_AMD_CENSUS_MIN_CORES", "64")) and os.environ.get("GETDIST_AMD_FULL_CENSUS", "1") == "1"
     sample = []
     for key, members in sorted(klass.items()):
         want = 6 if len(members) >= 100 else 3
+        if key.startswith("A/") and not census_will_run:
+            want = len(members)
         step = max(1, len(members) // want)
         sample += [(key, pr) for pr in members[::step][:want]]
     base = dict(path=path_full, names=list(names), ranges=dict(ranges))
@@ -507,7 +641,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                                   oracle_chaotic=bool(chaotic[0]), oracle_moves_by=float(chaotic[1]),
                                   inside_oracle_spread=bool(r.get("inside_oracle_spread", False)),
                                   as_good_in_amise=bool(r.get("amise_ok", False)),
-                                  excess_over_oracle_spread=float(r.get("excess", 0.0))))
+                                  excess_over_oracle_spread=float(r.get("excess", 0.0)), verdict=r.get("verdict")))
         parity_block = dict(N=int(N), tolerance=1e-6, classes=parity, n_pairs_checked=len(sample), n_pairs_on_loose_gate=len(loose),
                             loose_pairs=loose,
                             n_loose_pairs_chaotic_in_the_oracle=int(sum(e_["oracle_chaotic"] for e_ in loose)),
@@ -562,32 +696,18 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
             wall_cpu = max(r["seconds"] for r in tri)  # the slowest worker's oracle time = the pool's wall time
             rows = [row for r in tri for row in r["rows"]]
             par2 = mc2.paramNames.names
-            census = {}
-            for row in rows:
-                a, b = row["pair"]
-                key = "%s/%d/%d" % (row["branch"], int(bool(par2[a].has_limits)) + int(bool(par2[b].has_limits)), row["F"])
-                c = census.setdefault(key, dict(pairs=0, errs=[], loose=0))
-                c["pairs"] += 1
-                c["errs"].append(row.get("err", float("inf")))
-                c["loose"] += row.get("err", float("inf")) > 1e-6
-            loose_rows = [r for r in rows if r.get("err", float("inf")) > 1e-6]
             small = dict(N=int(args.cpu_small_n), pairs=len(pairs_all), cpu_wall_s=round(wall_cpu, 2), cpu_workers=workers,
                          cpu_densities_per_s=round(len(pairs_all) / wall_cpu, 2), cpu_core_seconds=round(sum(r["seconds"] for r in tri), 1),
                          gpu_wall_s=round(wall_gpu, 4), gpu_densities_per_s=round(len(pairs_all) / wall_gpu, 1),
                          gpu_over_cpu_pool=round(wall_cpu / wall_gpu, 1),
-                         parity_census=dict(
-                             gate="max|dP| of the max-normalised grids, GPU vs oracle, every pair of the triangle",
-                             pairs_compared=len(rows), grid_shapes_equal=int(sum(r["shape_ok"] for r in rows)),
-                             pairs_within_1e_6=int(sum(r.get("err", 9.0) <= 1e-6 for r in rows)),
-                             pairs_above_1e_6=len(loose_rows), worst_abs_dP=float(max(r.get("err", 0.0) for r in rows)),
-                             loose_pairs_that_use_tnc=int(sum(bool(r["tnc"]) for r in loose_rows)),
-                             loose_pairs_chaotic_in_the_oracle=int(sum(r.get("oracle_moves_by", 0.0) > 1e-6 for r in loose_rows)),
-                             loose_pairs_inside_the_oracle_spread=int(sum(bool(r.get("inside_oracle_spread")) for r in loose_rows)),
-                             loose_pairs_inside_spread_or_as_good_in_amise=int(sum(bool(r.get("inside_oracle_spread") or r.get("amise_ok")) for r in loose_rows)),
-                             worst_excess_over_oracle_spread=float(max([r.get("excess", 0.0) for r in loose_rows] or [0.0])),
-                             per_class={k: dict(pairs=v["pairs"], above_1e_6=int(v["loose"]), max_abs_dP=float(np.max(v["errs"])),
-                                                median_abs_dP=float(np.median(v["errs"]))) for k, v in sorted(census.items())}))
+                         parity_census=_census_summary(rows, [bool(p.has_limits) for p in par2], list(names2)))
             mc2.ctx.close()
+    # ---- every pair of the timed triangle at full size (hosts with >= 64 cores; behind the clock)
+    try:
+        full = full_size_census(args, path_full, names, ranges, pairs_all, dens, [bool(p.has_limits) for p in par], tmp, cores)
+    except Exception as exc:  # the sample above stands on its own
+        full = dict(ran=False, reason="census failed: %r" % (exc,))
+    parity_block["full_size_census"] = full
     try:
         import shutil
 

@@ -77,7 +77,9 @@ class PendingBatch:
 
 class DensityBatch(Sequence):
     """
-    The results of one native batched call: a sequence of Density2D that are made when they are first asked for.  The
+    The results of one native batched call: a sequence of Density2D that are made when they are first asked for
+    (``collections.abc.Sequence``: indexing, slicing -- slices are lists --, iteration, ``len``, ``in``; ``+`` and ``*`` give
+    plain lists; it is not a ``list`` instance: ``list(out)`` makes one).  The
     grids are views of the call's page-locked block (filled by the copy streams while the caller goes on), the axes, the
     bandwidth records and the contour levels come from the call's per-pair table; building 1225 result objects costs a few
     milliseconds of interpreter time, which a caller that loops over batched calls would otherwise spend between the last
@@ -160,6 +162,21 @@ class DensityBatch(Sequence):
 
     def __eq__(self, other):
         return list(self) == list(other)
+
+    __hash__ = None  # (a mutable sequence of results, like the list the Python-planned route returns: unhashable)
+
+    # list arithmetic, so that callers written against the list the reference's triangle loop builds keep working
+    # (`out + other_list`, `other_list + out`, `out * 2`): the result is a plain list
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __mul__(self, k):
+        return list(self) * k
+
+    __rmul__ = __mul__
 
 
 def settings_of(mc, base_F, bco, mbc, smooth_scale_2D, want_levels, contours):

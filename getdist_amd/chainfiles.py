@@ -47,11 +47,8 @@ def loadNumpyTxt(fname, skiprows=None):
             # pandas pads a short row with NaN where np.loadtxt -- the reference -- raises: a chain file that is still
             # being written must fail loudly, not yield a NaN sample (and poison the binary cache).  NaN written in the
             # file itself parses identically in np.loadtxt, which then decides.
-            try:
-                return np.atleast_2d(np.loadtxt(fname, skiprows=skiprows or 0))
-            except ValueError:
-                print("Error reading %s" % fname)  # (only when the reference's parser fails too, chains.py:121-125)
-                raise
+            # (a ValueError of the reference's parser is reported once, by the handler below: chains.py:121-125)
+            return np.atleast_2d(np.loadtxt(fname, skiprows=skiprows or 0))
         return arr
     except ImportError:
         return np.atleast_2d(np.loadtxt(fname, skiprows=skiprows or 0))

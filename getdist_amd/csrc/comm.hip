@@ -118,7 +118,7 @@ int comm_wait(gd_ctx* ctx, const char* what) {
     const double limit = comm_timeout_s();
     for (int spin = 0;; ++spin) {
         const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) return GD_OK;
+        if (q == hipSuccess) return gd_stream_sync(ctx);  // (drained: returns at once; delivers the staged result vectors)
         if (q != hipErrorNotReady) {
             comm_drop(ctx);
             return gd_fail(ctx, GD_ERR_HIP, "%s: %s", what, hipGetErrorString(q));

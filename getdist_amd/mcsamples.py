@@ -36,6 +36,16 @@ class WeightedSampleError(Exception):
     pass
 
 
+def _where_rows(where, numrows):
+    """Row indices of a ``where=`` index array with numpy's semantics of x[where]: negative indices count from the end,
+    anything outside [-numrows, numrows) raises IndexError (it used to wrap around silently)."""
+    ix = np.asarray(where).astype(np.int64).ravel()
+    if ix.size and (ix.min() < -numrows or ix.max() >= numrows):
+        bad = ix[(ix < -numrows) | (ix >= numrows)][0]
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(bad), int(numrows)))
+    return np.where(ix < 0, ix + numrows, ix)
+
+
 class MCSamplesError(WeightedSampleError):
     pass
 
@@ -822,7 +832,13 @@ class MCSamples:
     def removeBurn(self, remove=0.3):
         """chains.py:1047-1061: drop the first ``remove`` fraction of the rows (or that many rows if >= 1)"""
         ix = int(remove) if remove >= 1 else int(round(self.numrows * remove))
-        offsets = None if self.chain_offsets is None else np.maximum(self.chain_offsets - ix, 0)
+        offsets = None
+        if self.chain_offsets is not None:
+            # the rows go from the front of the stacked array (the reference, chains.py:1047-1061, knows no chains here);
+            # chains that lose all their rows are dropped from the chain list instead of staying behind with zero length
+            offsets = np.unique(np.maximum(self.chain_offsets - ix, 0))
+            if len(offsets) < 2:
+                offsets = None
         self._replace_samples(self.samples[ix:, :], None if self.weights is None else self.weights[ix:],
                               None if self.loglikes is None else self.loglikes[ix:], offsets)
 
@@ -1121,17 +1137,37 @@ class MCSamples:
         reference's two branches applies is decided by factor >= max weight of that chain, as there.
         """
         hi = self.numrows if hi is None else hi
+        return self._thin_rows_on(self.ctx, factor, lo, hi)
+
+    @staticmethod
+    def _thin_rows_on(ctx, factor, lo, hi):
         if factor != int(factor):
             raise WeightedSampleError("Thin factor must be integer")
-        ws = self.ctx.weight_stats(lo, hi)
+        ws = ctx.weight_stats(lo, hi)
         unique_mode = int(factor) >= ws["max_w"]
         capacity = int(ws["norm"]) // int(factor) + 2
-        return self.ctx.thin_rows(lo, hi, int(factor), unique_mode, capacity)
+        return ctx.thin_rows(lo, hi, int(factor), unique_mode, capacity)
 
     def thin_indices(self, factor, weights=None):
-        """chains.py:853-863: indices that make single-weight samples (the device list copied to the host)."""
+        """chains.py:853-863: indices that make single-weight samples (the device list copied to the host).  ``weights``:
+        thin THAT weight vector instead of the resident one (any length, as the reference's static
+        thin_indices_single_samples does): it is uploaded to a short-lived context of its own -- the cached prefix sum and the
+        thinning kernels belong to a context's sample weights -- and thinned by the same kernels."""
         if weights is not None:
-            raise NotImplementedError("thinning of weights that are not resident on the device")
+            w = np.ascontiguousarray(weights, dtype=np.float64).ravel()
+            if w.size == 0:
+                return np.zeros(0, dtype=np.int64)
+            tmp = self._context_factory(self._device)
+            try:
+                tmp.upload(np.zeros((w.size, 1)), w)
+                if not tmp.weights_integral():
+                    raise WeightedSampleError("Can only thin with integer weights")
+                buf, K = self._thin_rows_on(tmp, factor, 0, w.size)
+                out = buf.to_host((K,), dtype=np.int32).astype(np.int64) if K else np.zeros(0, dtype=np.int64)
+                buf.free()
+            finally:
+                tmp.close()
+            return out
         if not self.ctx.weights_integral():
             raise WeightedSampleError("Can only thin with integer weights")
         buf, K = self._thin_rows(factor)
@@ -1463,7 +1499,7 @@ class MCSamples:
             if where.shape != (self.numrows,):
                 raise WeightedSampleError("where must have one entry per sample")
             return w * where
-        return w * np.bincount(where.astype(np.int64) % self.numrows, minlength=self.numrows)
+        return w * np.bincount(_where_rows(where, self.numrows), minlength=self.numrows)
 
     def _with_weights(self, w_host, fn):
         """Run ``fn`` with the auxiliary weight vector ``w_host`` selected on the device."""
@@ -3330,7 +3366,7 @@ class ChainView:
                 raise WeightedSampleError("where must have one entry per sample of the chain")
             w[self.lo:self.hi] = base * where
         else:
-            w[self.lo:self.hi] = base * np.bincount(where.astype(np.int64) % self.numrows, minlength=self.numrows)
+            w[self.lo:self.hi] = base * np.bincount(_where_rows(where, self.numrows), minlength=self.numrows)
         return w
 
     def _moments(self, pars, where):

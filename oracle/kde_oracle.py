@@ -461,13 +461,15 @@ def get_h_ensemble(psi, N, corr_in, rel=1e-15, trials=12):
     return np.array(rows, dtype=float)
 
 
-def within_oracle_spread(triple, ensemble, slack=1.0, floor=1e-6):
+def within_oracle_spread(triple, ensemble, slack=None, floor=1e-6):
     """
     Does a bandwidth triple (hx, hy, c) lie inside what the reference itself produces for rounding-equal inputs?
     Component by component: between the ensemble's minimum and maximum, widened on both sides by ``slack`` times the
     ensemble's own spread (and by ``floor`` of the largest bandwidth, the strict tolerance).  Returns (ok, the largest
     excess over the ensemble's range in units of that component's spread).
     """
+    if slack is None:
+        slack = SPREAD_SLACK
     t = np.asarray(triple, dtype=float)
     lo, hi = ensemble.min(axis=0), ensemble.max(axis=0)
     spread = hi - lo
@@ -478,13 +480,21 @@ def within_oracle_spread(triple, ensemble, slack=1.0, floor=1e-6):
     return ok, float(np.max(excess))
 
 
-def amise_within_oracle_range(triple, ensemble, psi, N, margin=10.0, floor=1e-7):
+def nearest_member_distance(triple, ensemble):
+    """max-norm distance of a bandwidth triple to the nearest ensemble member, relative to the largest bandwidth."""
+    t = np.asarray(triple, dtype=float)
+    return float(np.min(np.max(np.abs(ensemble - t), axis=1)) / np.max(np.abs(ensemble[:, :2])))
+
+
+def amise_within_oracle_range(triple, ensemble, psi, N, margin=None, floor=1e-7):
     """
     The reference's own objective as the judge of a bandwidth triple: TNC stops somewhere on the flat floor of the AMISE
     (kde_bandwidth.py:216-232), and where exactly depends on rounding.  A triple is as good as the reference's if its
     AMISE does not exceed the smallest AMISE of the oracle ensemble by more than ``margin`` times the ensemble's own
     AMISE range (at least ``floor`` relative).  Returns (ok, relative excess over the ensemble minimum, ensemble range).
     """
+    if margin is None:
+        margin = AMISE_MARGIN
     p = np.zeros((5, 5))
     p[0, 4], p[4, 0], p[2, 2], p[0, 0], p[1, 3], p[3, 1] = psi
     vals = np.array([amise_from_psi(np.asarray(row, dtype=float), p, N) for row in ensemble])
@@ -495,7 +505,20 @@ def amise_within_oracle_range(triple, ensemble, psi, N, margin=10.0, floor=1e-7)
     return bool(excess <= max(margin * rng, floor)), float(excess), float(rng)
 
 
+# ---- the admission criterion of chaotic TNC pairs: FROZEN at its round-4 values ------------------------------------
+# (review, round 4: "no further widening of ENSEMBLE_SCALES, slack, margin or the raw-difference cap".)  These four numbers
+# define which device triples count as "one of the reference's own outcomes"; tests/test_oracle_golden.py pins them, so a
+# change shows up as a failing CPU test and not as a quietly greener GPU run.  judge_triple additionally reports, for every
+# triple it examines, the STRICT verdict (slack 0.25, the level the review asks for), the criterion that admitted it
+# ("inside" the ensemble's spread / "amise": as good in the reference's own objective), the perturbation scale it took,
+# and the distance to the nearest ensemble member -- bench.py and scripts/parity_census.py print them per loose pair.
 ENSEMBLE_SCALES = (1e-15, 1e-14, 1e-13, 1e-12)
+SPREAD_SLACK = 1.0       # within_oracle_spread: widening of the ensemble's range, in units of its own spread
+SPREAD_SLACK_STRICT = 0.25
+AMISE_MARGIN = 10.0      # amise_within_oracle_range: multiples of the ensemble's own AMISE range
+RAW_DIFFERENCE_CAP = 2e-3  # tests: a loose pair's grid may differ from the oracle's by at most this (4 x TOL_GRID_TNC)
+FROZEN_CARVE_OUT = dict(scales=ENSEMBLE_SCALES, slack=SPREAD_SLACK, slack_strict=SPREAD_SLACK_STRICT, margin=AMISE_MARGIN,
+                        raw_cap=RAW_DIFFERENCE_CAP)
 
 
 def get_h_ensembles(psi, N, corr_in, scales=ENSEMBLE_SCALES):
@@ -514,20 +537,41 @@ def judge_triple(triple, psi, N, corr_in=None, ensembles=None, scales=ENSEMBLE_S
     (amise_within_oracle_range); rejected if no scale admits it.
     ``ensembles``: precomputed get_h_ensembles(...) (worker processes), else built here from ``corr_in``.
     Returns a dict: ok, inside, amise_ok, excess, amise_excess, amise_range, moved (of the accumulated ensemble), scale
-    (the largest perturbation used), members.
+    (the largest perturbation used), members; and for the record of every loose pair: admitted_by ("inside" | "amise" |
+    None), strict_ok / strict_scale (the same walk with slack SPREAD_SLACK_STRICT = 0.25; strict_scale None when no scale
+    admits it at that slack), nearest_member (distance to the nearest member of the admitting ensemble, relative to the
+    largest bandwidth).
     """
     acc = None
     out = {}
+    strict_scale = None
+    strict_by = None
     for k, rel in enumerate(scales):
         ens = ensembles[k] if ensembles is not None else get_h_ensemble(psi, N, corr_in, rel=rel)
         acc = ens if acc is None else np.concatenate([acc, ens[1:]])
         inside, excess = within_oracle_spread(triple, acc)
         amise_ok, amise_excess, amise_range = amise_within_oracle_range(triple, acc, psi, N)
+        if strict_scale is None:
+            s_inside = within_oracle_spread(triple, acc, slack=SPREAD_SLACK_STRICT)[0]
+            if s_inside or amise_ok:
+                strict_scale, strict_by = rel, ("inside" if s_inside else "amise")
         out = dict(ok=bool(inside or amise_ok), inside=bool(inside), amise_ok=bool(amise_ok), excess=excess,
                    amise_excess=amise_excess, amise_range=amise_range,
-                   moved=float(np.max(np.abs(acc - acc[0])) / np.max(np.abs(acc[0]))), scale=rel, members=int(len(acc)))
+                   moved=float(np.max(np.abs(acc - acc[0])) / np.max(np.abs(acc[0]))), scale=rel, members=int(len(acc)),
+                   admitted_by=("inside" if inside else "amise" if amise_ok else None),
+                   nearest_member=nearest_member_distance(triple, acc))
         if out["ok"]:
             break
+    if out.get("ok") and strict_scale is None:  # admitted at slack 1.0 only: does a later scale admit it at 0.25?
+        acc2 = acc
+        for k2 in range(list(scales).index(out["scale"]) + 1, len(scales)):
+            ens = ensembles[k2] if ensembles is not None else get_h_ensemble(psi, N, corr_in, rel=scales[k2])
+            acc2 = np.concatenate([acc2, ens[1:]])
+            s_inside = within_oracle_spread(triple, acc2, slack=SPREAD_SLACK_STRICT)[0]
+            if s_inside or amise_within_oracle_range(triple, acc2, psi, N)[0]:
+                strict_scale, strict_by = scales[k2], ("inside" if s_inside else "amise")
+                break
+    out["strict_ok"], out["strict_scale"], out["strict_admitted_by"] = strict_scale is not None, strict_scale, strict_by
     return out
 
 

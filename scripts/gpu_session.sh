@@ -54,6 +54,11 @@ PY
         emu_c3_class) GETDIST_AMD_PAIR_DEAL=class GETDIST_AMD_LIVE_PMC=0 timeout 600 python scripts/emulate_scaling.py --nparams 50 --nsamples 10000000 --worlds 1,8 > "$O/emulate_c3_class.json" 2> "$O/emulate_c3_class.err"; cat "$O/emulate_c3_class.err" | grep "^W=" ;;
         emu_c5) GETDIST_AMD_LIVE_PMC=0 timeout 900 python scripts/emulate_scaling.py --nparams 200 --nsamples 2000000 --steps 5 --warmup 2 > "$O/emulate_c5.json" 2> "$O/emulate_c5.err"; cat "$O/emulate_c5.err" | grep "^W=" ;;
         emu_c4) for W in 1 2 4 8; do timeout 300 python scripts/gelman_rubin_multi_gpu.py --emulate-world $W > "$O/emulate_c4_w$W.json" 2> "$O/emulate_c4_w$W.err"; tail -1 "$O/emulate_c4_w$W.json" | cut -c1-300; done ;;
+        emu8trace)
+            (cd /tmp && GDHIP_BATCH_LOG=1 GETDIST_AMD_HOSTLOG=1 GETDIST_AMD_LIVE_PMC=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof_emu8" -o emu8 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 3 --emulate-world 8 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$O/emu8.log" 2> "$GRAFT_REPO_ROOT/$O/emu8.err")
+            python scripts/stream_timeline.py "$(find "$O/prof_emu8" -name '*kernel_trace.csv' | head -1)" 6 0.02 > "$O/emu8_stream_timeline.txt" 2>&1
+            cp "$(find "$O/prof_emu8" -name '*kernel_stats.csv' | head -1)" "$O/emu8_kernel_stats.csv"; rm -rf "$O/prof_emu8"
+            head -120 "$O/emu8_stream_timeline.txt" | cut -c1-120; grep -v WARNING "$O/emu8.err" | tail -60 | cut -c1-120 ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac

@@ -109,7 +109,7 @@ def _write_parity_report():
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_parity_2d.json"), "w") as f:
+    with open(os.path.join(out, "r05_parity_2d.json"), "w") as f:
         json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -174,7 +174,13 @@ def test_density_2d(zoo, name):
                                             excess_over_oracle_spread=excess, inside_oracle_spread=bool(inside),
                                             amise_excess_over_ensemble_minimum=amise_excess, ensemble_amise_range=amise_range,
                                             oracle_on_device_psi_gives_device_triple=oracle_on_device_psi_gives_device_triple,
-                                            ensemble_perturbation=ens_rel))
+                                            ensemble_perturbation=ens_rel,
+                                            # the record the review asks for: what admitted the triple under the FROZEN
+                                            # rules (ko.FROZEN_CARVE_OUT), how far the nearest ensemble member is, and
+                                            # whether the strict slack of 0.25 admits it as well
+                                            admitted_by=verdict["admitted_by"], nearest_member_rel=verdict["nearest_member"],
+                                            strict_slack_0p25_admits=bool(verdict["strict_ok"]),
+                                            strict_scale=verdict["strict_scale"], strict_admitted_by=verdict["strict_admitted_by"]))
                 report["worst_excess_over_oracle_spread"] = max(report["worst_excess_over_oracle_spread"], excess)
                 assert moved > 1e-6, (key, "device and oracle bandwidths differ by %.2e but the oracle is stable (moves %.2e)"
                                       % (bw_err, moved))
@@ -200,7 +206,7 @@ def test_density_2d(zoo, name):
                 e_at = float(np.max(np.abs(d.P - orc.density_2d(a, b, _bandwidths=d.bandwidth, **kw)["P"])))
                 report["worst_grid_at_device_triple"] = max(report.get("worst_grid_at_device_triple", 0.0), e_at)
                 assert e_at < TOL_GRID, (key, "vs the oracle at the device's triple", e_at)
-                assert e_grid < 4 * TOL_GRID_TNC, (key, "vs oracle", e_grid)
+                assert e_grid < ko.RAW_DIFFERENCE_CAP == 4 * TOL_GRID_TNC, (key, "vs oracle", e_grid)
             if bw_agrees and not tnc:
                 gu.check_grid_2d(g, key, d.P, tol)
                 assert gu.relerr(d.contours, g[key + "/contours"]) < (10 * tol), key

@@ -843,3 +843,27 @@ def test_pipelined_optimiser_and_convolution_equal_the_plain_order(zoo):
     for a, b in zip(piped, plain):
         assert np.array_equal(a.P, b.P) and a.bandwidth == b.bandwidth and a.bandwidth_branch == b.bandwidth_branch
         assert (a.kopt is None) == (b.kopt is None) and (a.kopt is None or np.array_equal(a.kopt, b.kopt, equal_nan=True))
+
+
+def test_bench_cpu_baseline_and_all_pairs_census_run_on_the_numpy_double(tmp_path):
+    """bench.py's post-clock legs on CPU (the C ABI replaced by tests/fake_ctx.py): the oracle baseline with its stratified
+    sample, the un-extrapolated small-N triangle, and the all-pairs full-size census that hosts with >= 64 cores run (here
+    forced on, workers dealt one tile of the triangle each): every pair compared, none above the tolerance, and every loose
+    pair would carry its verdict record (criterion, perturbation scale, nearest ensemble member)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, GETDIST_AMD_CENSUS_MIN_CORES="2", PYTHONPATH=os.path.join(ROOT, "tests"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nsamples", "20000", "--nparams", "8", "--steps", "1", "--warmup", "1",
+           "--cpu-small-n", "6000", "--cpu-workers", "2", "--context-factory", "fake_ctx:FakeContext"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    par = line["parity"]
+    assert par["n_pairs_on_loose_gate"] == 0 and par["n_pairs_checked"] >= 3
+    full = par["full_size_census"]
+    assert full["ran"] and full["pairs_compared"] == 28 and full["pairs_above_1e_6"] == 0 and full["N"] == 20000
+    assert line["cpu_baseline"]["full_triangle_small_n"]["parity_census"]["pairs_compared"] == 28

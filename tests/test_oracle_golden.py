@@ -194,3 +194,22 @@ def test_judge_triple_widens_the_ensemble_only_as_far_as_needed():
     bogus = np.array(ensembles[0][0], dtype=float) * np.array([1.5, 1.0, 1.0])
     bad = ko.judge_triple(bogus, psi, N, ensembles=ensembles)
     assert not bad["ok"] and bad["scale"] == ko.ENSEMBLE_SCALES[-1] and bad["amise_excess"] > 10 * bad["amise_range"]
+
+
+def test_tnc_carve_out_is_frozen():
+    """The four numbers that define which device bandwidth triples of a chaotic TNC pair count as the reference's own
+    outcomes (oracle.kde_oracle: perturbation scales, spread slack, AMISE margin) and the raw-difference cap of the GPU tests
+    stay at their round-4 values: widening any of them is a visible change of this test, not a quietly greener GPU run."""
+    import inspect
+
+    from oracle import kde_oracle as ko
+
+    assert ko.FROZEN_CARVE_OUT == dict(scales=(1e-15, 1e-14, 1e-13, 1e-12), slack=1.0, slack_strict=0.25, margin=10.0, raw_cap=2e-3)
+    assert inspect.signature(ko.within_oracle_spread).parameters["slack"].default is None  # (= SPREAD_SLACK)
+    assert inspect.signature(ko.amise_within_oracle_range).parameters["margin"].default is None
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("tgd", os.path.join(os.path.dirname(__file__), "test_gpu_densities.py"))
+    src = open(spec.origin).read()
+    assert "TOL_GRID_TNC = 5e-4" in src and "4 * TOL_GRID_TNC" in src and 4 * 5e-4 == ko.RAW_DIFFERENCE_CAP
