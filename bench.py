@@ -191,7 +191,7 @@ def one_step(mc, pairs_all, dist, rank, world, torch_device, emulate=0, comm=Non
         if os.environ.get("GETDIST_AMD_PAIR_DEAL", "blocks") == "class":
             mine, _ = parallel.partition_pairs_by_class(pairs_all, pair_cost_classes(mc, pairs_all), world, rank)
         else:
-            mine, _ = parallel.partition_pairs_by_column_blocks(pairs_all, pair_cost_classes(mc, pairs_all), world, rank, mc.n)
+            mine, _ = parallel.partition_pairs_by_column_blocks(_PAIR_INDEX["array"], pair_cost_classes(mc, pairs_all), world, rank, mc.n)
         my_pairs = _PAIR_INDEX["array"][mine]
         mc._neff_share = parallel.NeffShare(my_params, exchange)
         mc._neff_share.library_comm = comm is not None and not emulate

@@ -319,6 +319,183 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
 }
 
 
+// ---- real weights, F = 256, many pairs: samples sorted by stripe once per y column ----------------------------------
+// The fp64 table of a 256 x 256 grid is 512 KB, so a block owns a stripe of 64 rows and k_hist2d<2, true, double> above
+// makes every (pair, stripe) block read ALL N samples -- two u16 indices and the 8-byte weight, 12 bytes x 4 stripes per
+// sample and pair, three in four of them rejected: 588 GB through L2 / MALL per weighted triangle, 41 ms per 1225 pairs
+// (14 x the unit-weight launch; measured in every round since the first).  The stripe a sample falls in depends on its y
+// column only, and a y column serves up to n - 1 pairs: so ONCE per y column the samples are partitioned by stripe --
+// a stable counting sort in wave-sized units: (row index, row within the stripe, weight) = 13 bytes per sample -- and a
+// (pair, stripe) block then walks only its quarter of the samples: 13 bytes each, plus the x index gathered through the
+// row list (rows ascend within a bucket, so the gathers walk the x column forward a few bytes at a time and the four
+// stripe blocks of a pair, neighbours on one XCD, share its cache lines).  Per sample and pair: 13 + ~2-8 bytes instead
+// of 48, a quarter of the instructions, every atomic a hit.  The adds are the same fp64 LDS atomics on the same values
+// (their order within a bin is as unspecified as before; np.bincount agreement 1e-12 as gated by the tests).
+struct SortedCol {             // one y column's stripe-sorted samples
+    const unsigned short* iy;  // its u16 bin indices
+    unsigned int* rows;        // [N] sample rows, bucket by bucket
+    unsigned char* yrow;       // [N] row within the stripe (0..63)
+    double* ws;                // [N] weights in the same order
+    unsigned int* counts;      // [units][4] -> after the scan: start of (unit, bucket) in the sorted arrays
+    unsigned int* bucket_off;  // [5] bucket starts (bucket_off[4] = number of samples inside the grid)
+};
+#define WSORT_UNITS 2048        // wave-sized units per column (each a contiguous range of rows)
+#define WSORT_STRIPE_ROWS 64
+
+// pass 1: per (column, unit) the number of samples in each of the four stripes.  grid (WSORT_UNITS / 4, ncols) x 256
+__global__ void __launch_bounds__(256) k_wsort_count(const SortedCol* __restrict__ colsv, int64_t N) {
+    const SortedCol C = colsv[blockIdx.y];
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t per = (N + WSORT_UNITS - 1) / WSORT_UNITS;
+    const int64_t lo = (int64_t)unit * per, hi = min(N, lo + per);
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int64_t i = lo + lane; i < hi; i += 64) {
+        const unsigned y = C.iy[i];
+        if (y < 256u) {
+            const unsigned b = y >> 6;
+            c0 += b == 0, c1 += b == 1, c2 += b == 2, c3 += b == 3;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c0 += __shfl_down(c0, o, 64), c1 += __shfl_down(c1, o, 64);
+        c2 += __shfl_down(c2, o, 64), c3 += __shfl_down(c3, o, 64);
+    }
+    if (lane == 0) {
+        unsigned int* o = C.counts + (size_t)unit * 4;
+        o[0] = c0, o[1] = c1, o[2] = c2, o[3] = c3;
+    }
+}
+
+// scan: counts[unit][b] -> start of (unit, b); bucket_off.  One block of 1024 threads per column.
+__global__ void __launch_bounds__(1024) k_wsort_scan(const SortedCol* __restrict__ colsv) {
+    __shared__ unsigned int tot[4][16];  // per-wave partial sums (1024 threads = 16 waves)
+    __shared__ unsigned int base[5];
+    const SortedCol C = colsv[blockIdx.x];
+    constexpr int PER = WSORT_UNITS / 1024;  // units per thread (consecutive)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int mine[4][PER], sum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            mine[b][q] = C.counts[((size_t)threadIdx.x * PER + q) * 4 + b];
+            sum[b] += mine[b][q];
+        }
+    // exclusive scan of sum[b] over the 1024 threads: within the wave by shuffles, across waves through LDS
+    unsigned int incl[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        unsigned int v = sum[b];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        incl[b] = v;
+        if (lane == 63) tot[b][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int b = 0; b < 4; ++b) {
+            base[b] = run;
+            unsigned int acc = 0;
+            for (int wv = 0; wv < 16; ++wv) {
+                const unsigned int t = tot[b][wv];
+                tot[b][wv] = acc;
+                acc += t;
+            }
+            run += acc;
+        }
+        base[4] = run;
+        for (int b = 0; b < 5; ++b) C.bucket_off[b] = base[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        unsigned int start = base[b] + tot[b][wave] + incl[b] - sum[b];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            C.counts[((size_t)threadIdx.x * PER + q) * 4 + b] = start;
+            start += mine[b][q];
+        }
+    }
+}
+
+// pass 2: every unit (one wave) scatters its rows, in order, to the places the scan assigned.  grid as pass 1
+__global__ void __launch_bounds__(256) k_wsort_scatter(const SortedCol* __restrict__ colsv, const double* __restrict__ w, int64_t N) {
+    const SortedCol C = colsv[blockIdx.y];
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t per = (N + WSORT_UNITS - 1) / WSORT_UNITS;
+    const int64_t lo = (int64_t)unit * per, hi = min(N, lo + per);
+    unsigned int pos[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pos[b] = C.counts[(size_t)unit * 4 + b];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        unsigned y = 0xffffu;
+        double wt = 0.0;
+        if (i < hi) y = C.iy[i], wt = w[i];
+        const int b = y < 256u ? (int)(y >> 6) : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long m = __ballot(b == q);
+            if (b == q) {
+                const unsigned int at = pos[q] + (unsigned int)__popcll(m & below);
+                C.rows[at] = (unsigned int)i;
+                C.yrow[at] = (unsigned char)(y & 63u);
+                C.ws[at] = wt;
+            }
+            pos[q] += (unsigned int)__popcll(m);
+        }
+    }
+}
+
+struct SortedPair {
+    const unsigned short* ix;  // the pair's x index column
+    int ycol;                  // which SortedCol of the launch
+    int dest;                  // which grid of the output block
+};
+
+// grid: 4 blocks (stripes) per pair, block ids of a pair congruent mod 8 (one XCD); 1024 threads; LDS: the 64 x 256 fp64
+// stripe.  Four samples per lane in flight: their row indices first, then the x gathers, then the adds.
+__global__ void __launch_bounds__(1024) k_hist2d_wsorted(const SortedPair* __restrict__ pairs, const SortedCol* __restrict__ colsv, int B,
+                                                         double* __restrict__ hist_all) {
+    extern __shared__ double sh_raw[];
+    double* sh = sh_raw;
+    int pair, chunk, stripe;
+    decode_block(4, 1, pair, chunk, stripe);
+    if (pair >= B) return;
+    const SortedPair P = pairs[pair];
+    const SortedCol C = colsv[P.ycol];
+    for (int i = threadIdx.x; i < WSORT_STRIPE_ROWS * 256; i += 1024) sh[i] = 0.0;
+    __syncthreads();
+    const unsigned int lo = C.bucket_off[stripe], hi = C.bucket_off[stripe + 1];
+    unsigned int i = lo + threadIdx.x;
+    for (; i + 3 * 1024 < hi; i += 4 * 1024) {
+        unsigned int r[4], yr[4];
+        double wt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = C.rows[i + q * 1024], yr[q] = C.yrow[i + q * 1024], wt[q] = C.ws[i + q * 1024];
+        unsigned int x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = P.ix[r[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (x[q] < 256u) atomicAdd(&sh[yr[q] * 256u + x[q]], wt[q]);
+    }
+    for (; i < hi; i += 1024) {
+        const unsigned int x = P.ix[C.rows[i]];
+        if (x < 256u) atomicAdd(&sh[(unsigned int)C.yrow[i] * 256u + x], C.ws[i]);
+    }
+    __syncthreads();
+    double* hist = hist_all + (int64_t)P.dest * 65536 + (int64_t)stripe * WSORT_STRIPE_ROWS * 256;
+    for (int e = 2 * threadIdx.x; e < WSORT_STRIPE_ROWS * 256; e += 2048)
+        *reinterpret_cast<double2*>(&hist[e]) = *reinterpret_cast<const double2*>(&sh[e]);
+}
+
 // Unit-weight, pre-binned variant with 16-bit LDS counters packed two per word: a 256 x 256 grid fits one
 // 128 KB stripe, so every sample is visited once instead of once per stripe.  A counter can wrap if a bin receives
 // more than 65535 samples; a wrap always lowers the sum of all counters, so comparing that sum with the number of
@@ -404,18 +581,29 @@ struct Hist2DPair8 {
 // at LDS address 0 and the increment is 1 + 0xffff * (top bit of y): 4.5 VALU operations per sample.
 // (profiles/r03_kernels_ab.json: 3.43 ms for the flat-load, no-ring form of round 2 -> 2.88 ms at DEPTH 3; 1, 2, 4: 3.19,
 // 3.00, 2.89 ms.)
+// nchunks > 1 (round 5; a rank's share of a triangle, or any call with fewer pairs than twice the CUs): the rows of a pair
+// are cut into nchunks ranges, one block each, the packed counters go to `part` as they are and k_p8_reduce adds the
+// chunks -- 125 pairs on 256 CUs used to leave half the chip idle for the whole launch, 294 pairs took two rounds where
+// 1.15 would do.  Counter wraps are detected per chunk as before; the sum over chunks is formed in 32 bits.
 template <int DEPTH>
 __global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __restrict__ pairs, int B, int64_t N,
-                                                       double* __restrict__ hist_all, int* __restrict__ overflow) {
+                                                       double* __restrict__ hist_all, int* __restrict__ overflow, int nchunks = 1,
+                                                       unsigned int* __restrict__ part = nullptr) {
     extern __shared__ double sh_raw[];  // 32768 words of counters, then 16 doubles for the block reduction
     unsigned int* sh = reinterpret_cast<unsigned int*>(sh_raw);
     double* red = sh_raw + 16384;
-    const int per_xcd = (B + 7) / 8;
-    const int pair = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (pair >= B || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int units = B * nchunks, per_xcd = (units + 7) / 8;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (unit >= units || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int pair = unit / nchunks, chunk = unit - pair * nchunks;
     const Hist2DPair8 P = pairs[pair];
-    const uint4* gx = reinterpret_cast<const uint4*>(P.ix);
-    const uint4* gy = reinterpret_cast<const uint4*>(P.iy);
+    const int64_t nvec_all = N >> 4;  // 16-byte vectors per column
+    int64_t per = (nvec_all + nchunks - 1) / nchunks;
+    per = (per + 1023) & ~(int64_t)1023;
+    const int64_t v0 = min(nvec_all, (int64_t)chunk * per), v1 = (nchunks == 1) ? nvec_all : min(nvec_all, v0 + per);
+    const bool last = chunk == nchunks - 1;
+    const uint4* gx = reinterpret_cast<const uint4*>(P.ix) + v0;
+    const uint4* gy = reinterpret_cast<const uint4*>(P.iy) + v0;
     for (int i = threadIdx.x; i < 32768; i += 1024) sh[i] = 0;
     __syncthreads();
     auto visit2 = [&](unsigned v) {  // v = (y1 x1 y0 x0): two samples
@@ -430,7 +618,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __rest
             visit2(__builtin_amdgcn_perm(ys[q], xs[q], 0x07030602u));
         }
     };
-    const int64_t nvec = N >> 4;  // 16-byte vectors per column
+    const int64_t nvec = v1 - v0;  // this block's vectors
     const int64_t K = (nvec >> 10) / DEPTH * DEPTH;  // rounds in which every lane has a vector, a multiple of the ring depth
     if (K > 0) {
         uint4 rx[DEPTH], ry[DEPTH];
@@ -452,12 +640,25 @@ __global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __rest
         }
     }
     for (int64_t u = K * 1024 + threadIdx.x; u < nvec; u += 1024) visit16(gload_u4(gx + u), gload_u4(gy + u));
-    if (threadIdx.x == 0)
-        for (int64_t i = nvec << 4; i < N; ++i) {
+    if (threadIdx.x == 0 && last)
+        for (int64_t i = nvec_all << 4; i < N; ++i) {
             const unsigned a = ((unsigned)P.iy[i] << 8) | (unsigned)P.ix[i];
             atomicAdd(&sh[a & 0x7fffu], (a >> 15) * 0xffffu + 1u);
         }
     __syncthreads();
+    if (nchunks > 1) {  // the packed counters as they are; k_p8_reduce adds the chunks
+        unsigned int* out = part + (int64_t)unit * 32768;
+        unsigned int total = 0;
+        for (int i = 4 * threadIdx.x; i < 32768; i += 4096) {
+            const uint4 c = *reinterpret_cast<const uint4*>(&sh[i]);
+            total += (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu) + (c.y >> 16) + (c.z & 0xffffu) + (c.z >> 16) + (c.w & 0xffffu) + (c.w >> 16);
+            *reinterpret_cast<uint4*>(&out[i]) = c;
+        }
+        const double t = block_sum((double)total, red);
+        const double mine = (double)((v1 - v0) << 4) + (last ? (double)(N - (nvec_all << 4)) : 0.0);
+        if (threadIdx.x == 0 && t != mine) atomicOr(&overflow[pair], 1);
+        return;
+    }
     double* hist = hist_all + (int64_t)pair * 65536;
     unsigned int total = 0;
     for (int i = 2 * threadIdx.x; i < 32768; i += 2048) {  // two words per lane: 16-byte stores (the tail is store-issue bound)
@@ -468,6 +669,32 @@ __global__ void __launch_bounds__(1024) k_hist2d_u8_pf(const Hist2DPair8* __rest
     }
     const double t = block_sum((double)total, red);
     if (threadIdx.x == 0 && t != (double)N) atomicOr(&overflow[pair], 1);
+}
+
+// hist[pair][a] = sum over chunks of the low (a < 32768) / high halves of word a & 0x7fff.  grid (32, B) x 256: four words per lane
+__global__ void __launch_bounds__(256) k_p8_reduce(const unsigned int* __restrict__ part, int nchunks, double* __restrict__ hist_all) {
+    const int pair = blockIdx.y;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const unsigned int* p = part + (int64_t)pair * nchunks * 32768 + i;
+    unsigned int lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    for (int c = 0; c < nchunks; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + (int64_t)c * 32768);
+        lo[0] += v.x & 0xffffu, hi[0] += v.x >> 16, lo[1] += v.y & 0xffffu, hi[1] += v.y >> 16;
+        lo[2] += v.z & 0xffffu, hi[2] += v.z >> 16, lo[3] += v.w & 0xffffu, hi[3] += v.w >> 16;
+    }
+    double* hist = hist_all + (int64_t)pair * 65536;
+    *reinterpret_cast<double2*>(&hist[i]) = make_double2((double)lo[0], (double)lo[1]);
+    *reinterpret_cast<double2*>(&hist[i + 2]) = make_double2((double)lo[2], (double)lo[3]);
+    *reinterpret_cast<double2*>(&hist[i + 32768]) = make_double2((double)hi[0], (double)hi[1]);
+    *reinterpret_cast<double2*>(&hist[i + 32768 + 2]) = make_double2((double)hi[2], (double)hi[3]);
+}
+
+// chunks per pair of the byte-index launch: none for a whole triangle (the partial tables would cost more than the round
+// quantisation), else what fills the rounds (pick_chunks)
+static int pick_chunks(const gd_ctx* ctx, int64_t units, int64_t rows);
+static int u8_chunks(const gd_ctx* ctx, int B, int64_t N) {
+    if (B >= 2 * ctx->cu_count || getenv("GDHIP_U8_NO_CHUNKS") != nullptr) return 1;
+    return pick_chunks(ctx, B, N);
 }
 
 struct PrebinCol8 {
@@ -1045,6 +1272,77 @@ static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     return GD_OK;
 }
 
+// real weights, F = 256: y columns in groups whose sorted arrays fit the scratch budget; per group the three sort kernels
+// over its columns, then one launch over the pairs of those columns
+static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, double* d_hist) {
+    const int64_t N = ctx->N;
+    // distinct y columns in order of first appearance, and the pairs of each
+    std::vector<const unsigned short*> ycols;
+    std::vector<std::vector<int>> members;
+    {
+        std::map<const unsigned short*, int> at;
+        for (int b = 0; b < B; ++b) {
+            auto it = at.find(hp[b].iy);
+            if (it == at.end()) {
+                it = at.emplace(hp[b].iy, (int)ycols.size()).first;
+                ycols.push_back(hp[b].iy);
+                members.emplace_back();
+            }
+            members[it->second].push_back(b);
+        }
+    }
+    const int ny = (int)ycols.size();
+    const int64_t per_col = ((N * 4 + 255) / 256 + (N + 255) / 256 + (N * 8 + 255) / 256) * 256 + (int64_t)WSORT_UNITS * 16 + 256;
+    int64_t budget = (int64_t)3 << 30;  // sorted arrays of a group of y columns (13 bytes per sample and column)
+    if (const char* e = getenv("GDHIP_WSORT_BYTES")) budget = atoll(e);
+    int group = (int)std::max<int64_t>(1, std::min<int64_t>(ny, budget / per_col));
+    const int64_t o_cols = 0, o_pairs = ((int64_t)group * sizeof(SortedCol) + 255) / 256 * 256,
+                  o_data = o_pairs + ((int64_t)B * sizeof(SortedPair) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_data + (int64_t)group * per_col);
+    if (!base) return GD_ERR_NOMEM;
+    SortedCol* d_cols = (SortedCol*)(base + o_cols);
+    SortedPair* d_pairs = (SortedPair*)(base + o_pairs);
+    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_wsorted, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+    for (int g0 = 0; g0 < ny; g0 += group) {
+        const int ng = std::min(group, ny - g0);
+        std::vector<SortedCol> hc((size_t)ng);
+        std::vector<SortedPair> hpairs;
+        for (int c = 0; c < ng; ++c) {
+            char* p = base + o_data + (int64_t)c * per_col;
+            hc[c].iy = ycols[g0 + c];
+            hc[c].rows = (unsigned int*)p;
+            p += (N * 4 + 255) / 256 * 256;
+            hc[c].yrow = (unsigned char*)p;
+            p += (N + 255) / 256 * 256;
+            hc[c].ws = (double*)p;
+            p += (N * 8 + 255) / 256 * 256;
+            hc[c].counts = (unsigned int*)p;
+            hc[c].bucket_off = (unsigned int*)(p + (int64_t)WSORT_UNITS * 16);
+            for (int b : members[g0 + c]) {
+                SortedPair sp;
+                sp.ix = hp[b].ix, sp.ycol = c, sp.dest = b;
+                hpairs.push_back(sp);
+            }
+        }
+        const int nb = (int)hpairs.size();
+        // (the launches of the previous group read the tables being replaced: the staged uploads are consumed in stream
+        // order, behind them)
+        GD_TRY(gd_h2d(ctx, d_cols, hc.data(), (size_t)ng * sizeof(SortedCol)));
+        GD_TRY(gd_h2d(ctx, d_pairs, hpairs.data(), (size_t)nb * sizeof(SortedPair)));
+        k_wsort_count<<<dim3(WSORT_UNITS / 4, ng), 256, 0, ctx->stream>>>(d_cols, N);
+        GD_KERNEL_CHECK();
+        k_wsort_scan<<<ng, 1024, 0, ctx->stream>>>(d_cols);
+        GD_KERNEL_CHECK();
+        k_wsort_scatter<<<dim3(WSORT_UNITS / 4, ng), 256, 0, ctx->stream>>>(d_cols, ctx->w, N);
+        GD_KERNEL_CHECK();
+        const int units = (nb + 7) / 8 * 8;
+        k_hist2d_wsorted<<<(unsigned)(units * 4), 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, d_cols, nb, d_hist);
+        GD_KERNEL_CHECK();
+        if (g0 + group < ny) GD_TRY(gd_stream_sync(ctx));  // the next group's tables go into the same scratch
+    }
+    return gd_stream_sync(ctx);
+}
+
 int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
                         void* d_hist) {
     GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
@@ -1107,6 +1405,10 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             }
             return rc;
         }
+        // real weights on the base grid of a triangle: samples sorted by stripe once per y column (k_hist2d_wsorted)
+        if (ctx->w && !ctx->w8 && !ctx->w_integral && F == 256 && B >= 32 && ctx->N >= (1 << 16) && ctx->N < (int64_t)4294967295LL &&
+            getenv("GDHIP_NO_WSORT") == nullptr)
+            return hist2d_weighted_sorted(ctx, B, hp, (double*)d_hist);
         // the 16-bit kernel gives each (pair, stripe) to ONE block: only worth it when that fills the chip
         if ((ctx->w && !ctx->w8) || (int64_t)B * nstripes16 < ctx->cu_count)
             return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);
@@ -1177,17 +1479,23 @@ int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, con
         hp[b].iy = (const unsigned char*)d_idx_y[b];
         GD_REQUIRE(hp[b].ix && hp[b].iy, "null index column");
     }
-    const int64_t o_flags = ((int64_t)B * sizeof(Hist2DPair8) + 255) / 256 * 256;
-    char* base = (char*)gd_scratch2(ctx, o_flags + (int64_t)B * 4);
+    const int nchunks = u8_chunks(ctx, B, ctx->N);
+    const int64_t o_flags = ((int64_t)B * sizeof(Hist2DPair8) + 255) / 256 * 256, o_part = o_flags + ((int64_t)B * 4 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_part + (nchunks > 1 ? (int64_t)B * nchunks * 32768 * 4 : 0));
     if (!base) return GD_ERR_NOMEM;
     Hist2DPair8* d_pairs = (Hist2DPair8*)base;
     int* d_flags = (int*)(base + o_flags);
     GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8)));
     GD_HIP(hipMemsetAsync(d_flags, 0, (size_t)B * 4, ctx->stream));
-    const int nblocks = (B + 7) / 8 * 8;
+    const int nblocks = (B * nchunks + 7) / 8 * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
-    k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags);
+    k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>(d_pairs, B, ctx->N, (double*)d_hist, d_flags, nchunks,
+                                                                              (unsigned int*)(base + o_part));
     GD_KERNEL_CHECK();
+    if (nchunks > 1) {
+        k_p8_reduce<<<dim3(32, B), 256, 0, ctx->stream>>>((const unsigned int*)(base + o_part), nchunks, (double*)d_hist);
+        GD_KERNEL_CHECK();
+    }
     std::vector<int> hf((size_t)B);
     GD_TRY(gd_fetch(ctx, hf.data(), d_flags, (size_t)B * 4));
     GD_TRY(gd_stream_sync(ctx));
@@ -1231,6 +1539,9 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
     const int64_t o_cols = take((int64_t)ncols * sizeof(PrebinCol8)), o_pairs = take((int64_t)B * sizeof(Hist2DPair8));
     const int64_t table_bytes = off;
     const int64_t o_bad = take((int64_t)ncols * 8), o_flags = take((int64_t)B * 4);
+    const int64_t zero_end = off;
+    const int nchunks = u8_chunks(ctx, B, ctx->N);
+    const int64_t o_part = take(nchunks > 1 ? (int64_t)B * nchunks * 32768 * 4 : 0);
     char* base = (char*)gd_scratch2(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     {
@@ -1239,7 +1550,7 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
         memcpy(tab.data() + o_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8));
         GD_TRY(gd_stage_h2d(ctx, base, tab.data(), (size_t)table_bytes));
     }
-    GD_HIP(hipMemsetAsync(base + o_bad, 0, (size_t)(off - o_bad), ctx->stream));
+    GD_HIP(hipMemsetAsync(base + o_bad, 0, (size_t)(zero_end - o_bad), ctx->stream));
     if (ncols) {
         int nblk = (int)((ctx->N / 8 + 255) / 256);
         if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
@@ -1248,11 +1559,16 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
                                                                    (unsigned long long*)(base + o_bad));
         GD_KERNEL_CHECK();
     }
-    const int nblocks = (B + 7) / 8 * 8;
+    const int nblocks = (B * nchunks + 7) / 8 * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
     k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>((const Hist2DPair8*)(base + o_pairs), B, ctx->N,
-                                                                            (double*)d_hist, (int*)(base + o_flags));
+                                                                            (double*)d_hist, (int*)(base + o_flags), nchunks,
+                                                                            (unsigned int*)(base + o_part));
     GD_KERNEL_CHECK();
+    if (nchunks > 1) {
+        k_p8_reduce<<<dim3(32, B), 256, 0, ctx->stream>>>((const unsigned int*)(base + o_part), nchunks, (double*)d_hist);
+        GD_KERNEL_CHECK();
+    }
     std::vector<unsigned long long> hb((size_t)ncols);
     std::vector<int> hf((size_t)B);
     if (ncols) GD_TRY(gd_fetch(ctx, hb.data(), base + o_bad, (size_t)ncols * 8));

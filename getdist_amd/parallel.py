@@ -247,6 +247,9 @@ class ColumnShare:
         self.comm.share_columns(first)
 
 
+_TILE_DEALS = {}
+
+
 def partition_pairs_by_column_blocks(pairs, class_ids, world, rank, n):
     """
     Deal the pairs of a triangle so that a rank touches FEW columns: the columns are cut into G contiguous groups, pairs
@@ -261,10 +264,24 @@ def partition_pairs_by_column_blocks(pairs, class_ids, world, rank, n):
     P = len(pa)
     if world <= 1 or P == 0:
         return list(range(P)), [pairs[i] for i in range(P)]
+    # the deal is a pure function of (pairs, classes, world, n): a job that repeats its triangle (every step of a bench,
+    # every refresh of a plot grid) pays the ~0.5 ms of tile bookkeeping once -- it sits between the quantile kernels and the
+    # first binning launch of a rank's step
+    class_ids = np.ascontiguousarray(class_ids)
+    key = (pa.tobytes(), class_ids.tobytes(), int(world), int(n))
+    owner_of_pair = _TILE_DEALS.get(key)
+    if owner_of_pair is not None:
+        if owner_of_pair is False:
+            return partition_pairs_by_class(pairs, class_ids, world, rank)
+        mine = np.nonzero(owner_of_pair == rank)[0].tolist()
+        return mine, [pairs[i] for i in mine]
+    if len(_TILE_DEALS) >= 16:
+        _TILE_DEALS.clear()
     G = 1
     while G * (G + 1) // 2 < 6 * world and G < n:  # >= 6 tiles per rank: shares within ~3 % of one another
         G += 1
     if G < 2 or n < 2 * G:
+        _TILE_DEALS[key] = False
         return partition_pairs_by_class(pairs, class_ids, world, rank)
     group_of = (np.arange(n) * G) // n  # column -> group
     ga, gb = group_of[pa[:, 0]], group_of[pa[:, 1]]
@@ -289,7 +306,9 @@ def partition_pairs_by_column_blocks(pairs, class_ids, world, rank, n):
         owner[t] = best
         load[best] += tcost[k]
         cols_of[best].update((tl, th))
-    mine = np.nonzero(np.array([owner[int(t)] for t in tile]) == rank)[0].tolist()
+    owner_of_pair = np.array([owner[int(t)] for t in tile])
+    _TILE_DEALS[key] = owner_of_pair
+    mine = np.nonzero(owner_of_pair == rank)[0].tolist()
     return mine, [pairs[i] for i in mine]
 
 
