@@ -673,8 +673,20 @@ struct Call {
     }
 
     // -- prebin + batched 2D histograms of every grid-size class on context `ctx` (mcsamples.py:1486-1498, 1724-1728)
-    int binning(void* ctx) {
+    // part 0: every grid-size class; 1: the class with the most pairs only; 2: the others.  Large calls bin the main class
+    // on the second stream and the few pairs of the up-scaled classes behind the shear chain on the third: they used to
+    // follow the main class on the second stream -- 1.4 ms of small launches between the end of the O(N) phase and the
+    // first optimiser kernel, with the other two streams idle.
+    int main_class() const {
+        int best = F_list.empty() ? 0 : F_list[0];
+        for (int F : F_list)
+            if (classes.at(F).size() > classes.at(best).size()) best = F;
+        return best;
+    }
+    int binning(void* ctx, int part = 0) {
+        const int main_F = main_class();
         for (int F : F_list) {
+            if ((part == 1 && F != main_F) || (part == 2 && F == main_F)) continue;
             const std::vector<int>& members = classes.at(F);
             const int B = (int)members.size();
             int rc = 0;
@@ -1316,16 +1328,19 @@ struct Call {
         int rc = 0;
         if (auto_bw) {
             if (overlap) {
-                bin_f = std::async(std::launch::async, [this] {
+                const bool split_classes = F_list.size() > 1 && getenv("GDHIP_BATCH_SIDE_CLASSES_ON_TWIN") == nullptr;
+                bin_f = std::async(std::launch::async, [this, split_classes] {
                     ops.bind_thread(twin);
-                    return binning(twin);
+                    return binning(twin, split_classes ? 1 : 0);
                 });
                 rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
                 if (!rc)  // the branch plan needs the limits and the covariance only: the shear chain starts at once
-                    shear_f = std::async(std::launch::async, [this, aux] {
+                    shear_f = std::async(std::launch::async, [this, aux, split_classes] {
                         ops.bind_thread(aux);
-                        return shear_histograms(aux);
-                    });
+                        const int e = shear_histograms(aux);
+                        const int e2 = split_classes ? binning(aux, 2) : 0;  // the up-scaled classes, behind the shear chain
+                        return e ? e : e2;
+                    });  // (no plan: the call fails; the side classes are not needed)
                 int e = neff_f.valid() ? neff_f.get() : 0;
                 if (!rc) rc = e;
                 if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)

@@ -44,7 +44,8 @@ PY
             prof c4 python "$GRAFT_REPO_ROOT/scripts/run_configs.py" c4
             tail -3 "$O/c4.log" | cut -c1-400; rm -rf "$O/prof_c4"; head -8 "$O/c4_kernel_stats.csv" | cut -c1-170 ;;
         kernels) timeout 900 python scripts/r04_kernels.py > "$O/kernels.log" 2>&1; cp gpurun_out/r04_kernels.json "$O/kernels.json" 2>/dev/null; tail -3 "$O/kernels.log" ;;
-        pmcconv) timeout 900 bash scripts/pmc_conv.sh "$O" > "$O/pmc_conv.log" 2>&1; tail -5 "$O/pmc_conv.log" ;;
+        pmcconv) timeout 900 python scripts/pmc_kernels.py "$O/pmc_conv.json" -- python "$GRAFT_REPO_ROOT/scripts/r04_conv_bench.py" 4 2>&1 | tail -16 ;;
+        pmcc4) timeout 900 python scripts/pmc_kernels.py "$O/pmc_c4.json" --match k_cov,k_col_pass -- python "$GRAFT_REPO_ROOT/scripts/run_configs.py" c4 2>&1 | tail -6 ;;
         emulate)
             for W in 2 4 8; do
                 GETDIST_AMD_LIVE_PMC=0 timeout 300 python bench.py --steps 30 --warmup 5 --emulate-world $W --no-cpu-baseline > "$O/emulate_w$W.json" 2> "$O/emulate_w$W.err"
@@ -59,6 +60,7 @@ PY
             python scripts/stream_timeline.py "$(find "$O/prof_emu8" -name '*kernel_trace.csv' | head -1)" 6 0.02 > "$O/emu8_stream_timeline.txt" 2>&1
             cp "$(find "$O/prof_emu8" -name '*kernel_stats.csv' | head -1)" "$O/emu8_kernel_stats.csv"; rm -rf "$O/prof_emu8"
             head -120 "$O/emu8_stream_timeline.txt" | cut -c1-120; grep -v WARNING "$O/emu8.err" | tail -60 | cut -c1-120 ;;
+        f64roof) (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_atomic_f64_roof "$GRAFT_REPO_ROOT/scripts/micro/lds_atomic_f64_roof.hip" && ./lds_atomic_f64_roof 400) > "$O/lds_atomic_f64_roof.txt" 2>&1; cat "$O/lds_atomic_f64_roof.txt" ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac
