@@ -325,18 +325,20 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
 // sample and pair, three in four of them rejected: 588 GB through L2 / MALL per weighted triangle, 41 ms per 1225 pairs
 // (14 x the unit-weight launch; measured in every round since the first).  The stripe a sample falls in depends on its y
 // column only, and a y column serves up to n - 1 pairs: so ONCE per y column the samples are partitioned by stripe --
-// a stable counting sort in wave-sized units: (row index, row within the stripe, weight) = 13 bytes per sample -- and a
-// (pair, stripe) block then walks only its quarter of the samples: 13 bytes each, plus the x index gathered through the
-// row list (rows ascend within a bucket, so the gathers walk the x column forward a few bytes at a time and the four
-// stripe blocks of a pair, neighbours on one XCD, share its cache lines).  Per sample and pair: 13 + ~2-8 bytes instead
+// a stable counting sort in wave-sized units into 16-byte records (row index, row within the stripe, weight) -- and a
+// (pair, stripe) block then walks only its quarter of the samples: ONE 16-byte load each, plus the x index gathered through
+// the row (rows ascend within a bucket, so the gathers walk the x column forward a few bytes at a time and the four
+// stripe blocks of a pair, neighbours on one XCD, share its cache lines).  Per sample and pair: 16 + ~2-8 bytes instead
 // of 48, a quarter of the instructions, every atomic a hit.  The adds are the same fp64 LDS atomics on the same values
 // (their order within a bin is as unspecified as before; np.bincount agreement 1e-12 as gated by the tests).
+// What bounds it: ds_add_f64 on random entries of a 128-KB table retires 2.5 lanes per clock and CU
+// (scripts/micro/lds_atomic_f64_roof.hip: 7.8 ms for the 1.2e10 adds of a triangle; ds_add_u32: 8.6 lanes, 2.3 ms) -- and
+// before that the two dependent memory latencies of a sample (record, then x): a lane keeps eight samples in flight and
+// requests the next eight records before it waits for the gathers of the current ones.
 struct SortedCol {             // one y column's stripe-sorted samples
     const unsigned short* iy;  // its u16 bin indices
-    unsigned int* rows;        // [N] sample rows, bucket by bucket
-    unsigned char* yrow;       // [N] row within the stripe (0..63)
-    double* ws;                // [N] weights in the same order
-    unsigned int* counts;      // [units][4] -> after the scan: start of (unit, bucket) in the sorted arrays
+    uint4* recs;               // [N] 16-byte records {sample row, row within the stripe (0..63), weight (two words)}, bucket by bucket
+    unsigned int* counts;      // [units][4] -> after the scan: start of (unit, bucket) in the sorted records
     unsigned int* bucket_off;  // [5] bucket starts (bucket_off[4] = number of samples inside the grid)
 };
 #define WSORT_UNITS 2048        // wave-sized units per column (each a contiguous range of rows)
@@ -444,13 +446,16 @@ __global__ void __launch_bounds__(256) k_wsort_scatter(const SortedCol* __restri
             const unsigned long long m = __ballot(b == q);
             if (b == q) {
                 const unsigned int at = pos[q] + (unsigned int)__popcll(m & below);
-                C.rows[at] = (unsigned int)i;
-                C.yrow[at] = (unsigned char)(y & 63u);
-                C.ws[at] = wt;
+                C.recs[at] = make_uint4((unsigned int)i, y & 63u, (unsigned int)__double2loint(wt), (unsigned int)__double2hiint(wt));
             }
             pos[q] += (unsigned int)__popcll(m);
         }
     }
+}
+
+// (a global_load: a flat load through the table's generic pointer would also count on lgkmcnt and drain the LDS atomics)
+__device__ __forceinline__ unsigned int gload_u16(const unsigned short* p) {
+    return *(const __attribute__((address_space(1))) unsigned short*)p;
 }
 
 struct SortedPair {
@@ -473,22 +478,34 @@ __global__ void __launch_bounds__(1024) k_hist2d_wsorted(const SortedPair* __res
     for (int i = threadIdx.x; i < WSORT_STRIPE_ROWS * 256; i += 1024) sh[i] = 0.0;
     __syncthreads();
     const unsigned int lo = C.bucket_off[stripe], hi = C.bucket_off[stripe + 1];
-    unsigned int i = lo + threadIdx.x;
-    for (; i + 3 * 1024 < hi; i += 4 * 1024) {
-        unsigned int r[4], yr[4];
-        double wt[4];
+    constexpr int DEPTH = 8;
+    auto add = [&](const uint4& r, unsigned int x) {
+        if (x < 256u) atomicAdd(&sh[r.y * 256u + x], __hiloint2double((int)r.w, (int)r.z));
+    };
+    const unsigned int groups = (hi - lo) / (DEPTH * 1024u);
+    if (groups > 0) {
+        uint4 cur[DEPTH];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = C.rows[i + q * 1024], yr[q] = C.yrow[i + q * 1024], wt[q] = C.ws[i + q * 1024];
-        unsigned int x[4];
+        for (int q = 0; q < DEPTH; ++q) cur[q] = gload_u4(C.recs + lo + q * 1024u + threadIdx.x);
+        for (unsigned int g = 0; g < groups; ++g) {
+            // the x indices of the current records first, then the next group's records: the gathers are the older loads, so
+            // waiting for them leaves the record loads in flight behind the adds
+            unsigned int x[DEPTH];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = P.ix[r[q]];
+            for (int q = 0; q < DEPTH; ++q) x[q] = gload_u16(P.ix + cur[q].x);
+            uint4 nxt[DEPTH];
+            const unsigned int gn = (g + 1 < groups ? g + 1 : g) * (DEPTH * 1024u) + lo + threadIdx.x;  // (last: a harmless re-read)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (x[q] < 256u) atomicAdd(&sh[yr[q] * 256u + x[q]], wt[q]);
+            for (int q = 0; q < DEPTH; ++q) nxt[q] = gload_u4(C.recs + gn + q * 1024u);
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) add(cur[q], x[q]);
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) cur[q] = nxt[q];
+        }
     }
-    for (; i < hi; i += 1024) {
-        const unsigned int x = P.ix[C.rows[i]];
-        if (x < 256u) atomicAdd(&sh[(unsigned int)C.yrow[i] * 256u + x], C.ws[i]);
+    for (unsigned int i = lo + groups * (DEPTH * 1024u) + threadIdx.x; i < hi; i += 1024u) {
+        const uint4 r = gload_u4(C.recs + i);
+        add(r, gload_u16(P.ix + r.x));
     }
     __syncthreads();
     double* hist = hist_all + (int64_t)P.dest * 65536 + (int64_t)stripe * WSORT_STRIPE_ROWS * 256;
@@ -1292,8 +1309,8 @@ static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPa
         }
     }
     const int ny = (int)ycols.size();
-    const int64_t per_col = ((N * 4 + 255) / 256 + (N + 255) / 256 + (N * 8 + 255) / 256) * 256 + (int64_t)WSORT_UNITS * 16 + 256;
-    int64_t budget = (int64_t)3 << 30;  // sorted arrays of a group of y columns (13 bytes per sample and column)
+    const int64_t per_col = (N * 16 + 255) / 256 * 256 + (int64_t)WSORT_UNITS * 16 + 256;
+    int64_t budget = (int64_t)3 << 30;  // sorted records of a group of y columns (16 bytes per sample and column)
     if (const char* e = getenv("GDHIP_WSORT_BYTES")) budget = atoll(e);
     int group = (int)std::max<int64_t>(1, std::min<int64_t>(ny, budget / per_col));
     const int64_t o_cols = 0, o_pairs = ((int64_t)group * sizeof(SortedCol) + 255) / 256 * 256,
@@ -1310,12 +1327,8 @@ static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPa
         for (int c = 0; c < ng; ++c) {
             char* p = base + o_data + (int64_t)c * per_col;
             hc[c].iy = ycols[g0 + c];
-            hc[c].rows = (unsigned int*)p;
-            p += (N * 4 + 255) / 256 * 256;
-            hc[c].yrow = (unsigned char*)p;
-            p += (N + 255) / 256 * 256;
-            hc[c].ws = (double*)p;
-            p += (N * 8 + 255) / 256 * 256;
+            hc[c].recs = (uint4*)p;
+            p += (N * 16 + 255) / 256 * 256;
             hc[c].counts = (unsigned int*)p;
             hc[c].bucket_off = (unsigned int*)(p + (int64_t)WSORT_UNITS * 16);
             for (int b : members[g0 + c]) {
