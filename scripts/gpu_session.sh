@@ -61,6 +61,8 @@ PY
             cp "$(find "$O/prof_emu8" -name '*kernel_stats.csv' | head -1)" "$O/emu8_kernel_stats.csv"; rm -rf "$O/prof_emu8"
             head -120 "$O/emu8_stream_timeline.txt" | cut -c1-120; grep -v WARNING "$O/emu8.err" | tail -60 | cut -c1-120 ;;
         f64roof) (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_atomic_f64_roof "$GRAFT_REPO_ROOT/scripts/micro/lds_atomic_f64_roof.hip" && ./lds_atomic_f64_roof 400) > "$O/lds_atomic_f64_roof.txt" 2>&1; cat "$O/lds_atomic_f64_roof.txt" ;;
+        pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/r05_weighted_binning.py" 2>&1 | tail -8
+              grep -E "SQ_|conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac
