@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(1024) k_hist2d_wsorted(const SortedPair* __res
     decode_block(4, 1, pair, chunk, stripe);
     if (pair >= B) return;
     const SortedPair P = pairs[pair];
+    if (P.dest < 0) return;
     const SortedCol C = colsv[P.ycol];
     for (int i = threadIdx.x; i < WSORT_STRIPE_ROWS * 256; i += 1024) sh[i] = 0.0;
     __syncthreads();
@@ -1314,7 +1315,7 @@ static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPa
     if (const char* e = getenv("GDHIP_WSORT_BYTES")) budget = atoll(e);
     int group = (int)std::max<int64_t>(1, std::min<int64_t>(ny, budget / per_col));
     const int64_t o_cols = 0, o_pairs = ((int64_t)group * sizeof(SortedCol) + 255) / 256 * 256,
-                  o_data = o_pairs + ((int64_t)B * sizeof(SortedPair) + 255) / 256 * 256;
+                  o_data = o_pairs + ((int64_t)8 * (B + 8) * sizeof(SortedPair) + 255) / 256 * 256;  // (the lane layout pads)
     char* base = (char*)gd_scratch2(ctx, o_data + (int64_t)group * per_col);
     if (!base) return GD_ERR_NOMEM;
     SortedCol* d_cols = (SortedCol*)(base + o_cols);
@@ -1331,12 +1332,35 @@ static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPa
             p += (N * 16 + 255) / 256 * 256;
             hc[c].counts = (unsigned int*)p;
             hc[c].bucket_off = (unsigned int*)(p + (int64_t)WSORT_UNITS * 16);
-            for (int b : members[g0 + c]) {
-                SortedPair sp;
-                sp.ix = hp[b].ix, sp.ycol = c, sp.dest = b;
-                hpairs.push_back(sp);
+        }
+        // Pair order: the pairs of ONE y column run on ONE XCD, one after the other in groups of eight (32 CUs / 4 stripes).
+        // A pair's blocks are congruent mod 8 (decode_block), so the pair list is laid out in eight lanes -- position p
+        // belongs to lane p mod 8 -- and every y column goes to the lane with the fewest pairs so far: the eight pairs a
+        // lane has in flight read the same 160-MB record stream at the same pace, and all but the first find it in that
+        // XCD's L2.  (In plain order the pairs of a y column were spread over all eight XCDs: the counters showed 80 GB of
+        // L2 misses per 400-pair launch -- every pair fetching its records itself -- at 0.74 of the fabric's peak.)
+        std::vector<std::vector<SortedPair>> lanes(8);
+        {
+            std::vector<int> order(ng);
+            for (int c = 0; c < ng; ++c) order[c] = c;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return members[g0 + a].size() > members[g0 + b].size(); });
+            for (int c : order) {
+                int best = 0;
+                for (int l = 1; l < 8; ++l)
+                    if (lanes[l].size() < lanes[best].size()) best = l;
+                for (int b : members[g0 + c]) {
+                    SortedPair sp;
+                    sp.ix = hp[b].ix, sp.ycol = c, sp.dest = b;
+                    lanes[best].push_back(sp);
+                }
             }
         }
+        size_t depth = 0;
+        for (int l = 0; l < 8; ++l) depth = std::max(depth, lanes[l].size());
+        SortedPair idle;
+        idle.ix = nullptr, idle.ycol = 0, idle.dest = -1;  // (a lane that has run out: its blocks return at once)
+        for (size_t t = 0; t < depth; ++t)
+            for (int l = 0; l < 8; ++l) hpairs.push_back(t < lanes[l].size() ? lanes[l][t] : idle);
         const int nb = (int)hpairs.size();
         // (the launches of the previous group read the tables being replaced: the staged uploads are consumed in stream
         // order, behind them)
