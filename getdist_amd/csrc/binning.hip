@@ -319,201 +319,6 @@ __global__ void __launch_bounds__(1024) k_hist2d(const Hist2DPair* __restrict__ 
 }
 
 
-// ---- real weights, F = 256, many pairs: samples sorted by stripe once per y column ----------------------------------
-// The fp64 table of a 256 x 256 grid is 512 KB, so a block owns a stripe of 64 rows and k_hist2d<2, true, double> above
-// makes every (pair, stripe) block read ALL N samples -- two u16 indices and the 8-byte weight, 12 bytes x 4 stripes per
-// sample and pair, three in four of them rejected: 588 GB through L2 / MALL per weighted triangle, 41 ms per 1225 pairs
-// (14 x the unit-weight launch; measured in every round since the first).  The stripe a sample falls in depends on its y
-// column only, and a y column serves up to n - 1 pairs: so ONCE per y column the samples are partitioned by stripe --
-// a stable counting sort in wave-sized units into 16-byte records (row index, row within the stripe, weight) -- and a
-// (pair, stripe) block then walks only its quarter of the samples: ONE 16-byte load each, plus the x index gathered through
-// the row (rows ascend within a bucket, so the gathers walk the x column forward a few bytes at a time and the four
-// stripe blocks of a pair, neighbours on one XCD, share its cache lines).  Per sample and pair: 16 + ~2-8 bytes instead
-// of 48, a quarter of the instructions, every atomic a hit.  The adds are the same fp64 LDS atomics on the same values
-// (their order within a bin is as unspecified as before; np.bincount agreement 1e-12 as gated by the tests).
-// What bounds it: ds_add_f64 on random entries of a 128-KB table retires 2.5 lanes per clock and CU
-// (scripts/micro/lds_atomic_f64_roof.hip: 7.8 ms for the 1.2e10 adds of a triangle; ds_add_u32: 8.6 lanes, 2.3 ms) -- and
-// before that the two dependent memory latencies of a sample (record, then x): a lane keeps eight samples in flight and
-// requests the next eight records before it waits for the gathers of the current ones.
-struct SortedCol {             // one y column's stripe-sorted samples
-    const unsigned short* iy;  // its u16 bin indices
-    uint4* recs;               // [N] 16-byte records {sample row, row within the stripe (0..63), weight (two words)}, bucket by bucket
-    unsigned int* counts;      // [units][4] -> after the scan: start of (unit, bucket) in the sorted records
-    unsigned int* bucket_off;  // [5] bucket starts (bucket_off[4] = number of samples inside the grid)
-};
-#define WSORT_UNITS 2048        // wave-sized units per column (each a contiguous range of rows)
-#define WSORT_STRIPE_ROWS 64
-
-// pass 1: per (column, unit) the number of samples in each of the four stripes.  grid (WSORT_UNITS / 4, ncols) x 256
-__global__ void __launch_bounds__(256) k_wsort_count(const SortedCol* __restrict__ colsv, int64_t N) {
-    const SortedCol C = colsv[blockIdx.y];
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t per = (N + WSORT_UNITS - 1) / WSORT_UNITS;
-    const int64_t lo = (int64_t)unit * per, hi = min(N, lo + per);
-    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int64_t i = lo + lane; i < hi; i += 64) {
-        const unsigned y = C.iy[i];
-        if (y < 256u) {
-            const unsigned b = y >> 6;
-            c0 += b == 0, c1 += b == 1, c2 += b == 2, c3 += b == 3;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        c0 += __shfl_down(c0, o, 64), c1 += __shfl_down(c1, o, 64);
-        c2 += __shfl_down(c2, o, 64), c3 += __shfl_down(c3, o, 64);
-    }
-    if (lane == 0) {
-        unsigned int* o = C.counts + (size_t)unit * 4;
-        o[0] = c0, o[1] = c1, o[2] = c2, o[3] = c3;
-    }
-}
-
-// scan: counts[unit][b] -> start of (unit, b); bucket_off.  One block of 1024 threads per column.
-__global__ void __launch_bounds__(1024) k_wsort_scan(const SortedCol* __restrict__ colsv) {
-    __shared__ unsigned int tot[4][16];  // per-wave partial sums (1024 threads = 16 waves)
-    __shared__ unsigned int base[5];
-    const SortedCol C = colsv[blockIdx.x];
-    constexpr int PER = WSORT_UNITS / 1024;  // units per thread (consecutive)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int mine[4][PER], sum[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            mine[b][q] = C.counts[((size_t)threadIdx.x * PER + q) * 4 + b];
-            sum[b] += mine[b][q];
-        }
-    // exclusive scan of sum[b] over the 1024 threads: within the wave by shuffles, across waves through LDS
-    unsigned int incl[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        unsigned int v = sum[b];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned int u = __shfl_up(v, o, 64);
-            if (lane >= o) v += u;
-        }
-        incl[b] = v;
-        if (lane == 63) tot[b][wave] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int b = 0; b < 4; ++b) {
-            base[b] = run;
-            unsigned int acc = 0;
-            for (int wv = 0; wv < 16; ++wv) {
-                const unsigned int t = tot[b][wv];
-                tot[b][wv] = acc;
-                acc += t;
-            }
-            run += acc;
-        }
-        base[4] = run;
-        for (int b = 0; b < 5; ++b) C.bucket_off[b] = base[b];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        unsigned int start = base[b] + tot[b][wave] + incl[b] - sum[b];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            C.counts[((size_t)threadIdx.x * PER + q) * 4 + b] = start;
-            start += mine[b][q];
-        }
-    }
-}
-
-// pass 2: every unit (one wave) scatters its rows, in order, to the places the scan assigned.  grid as pass 1
-__global__ void __launch_bounds__(256) k_wsort_scatter(const SortedCol* __restrict__ colsv, const double* __restrict__ w, int64_t N) {
-    const SortedCol C = colsv[blockIdx.y];
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t per = (N + WSORT_UNITS - 1) / WSORT_UNITS;
-    const int64_t lo = (int64_t)unit * per, hi = min(N, lo + per);
-    unsigned int pos[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) pos[b] = C.counts[(size_t)unit * 4 + b];
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
-        const int64_t i = i0 + lane;
-        unsigned y = 0xffffu;
-        double wt = 0.0;
-        if (i < hi) y = C.iy[i], wt = w[i];
-        const int b = y < 256u ? (int)(y >> 6) : -1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned long long m = __ballot(b == q);
-            if (b == q) {
-                const unsigned int at = pos[q] + (unsigned int)__popcll(m & below);
-                C.recs[at] = make_uint4((unsigned int)i, y & 63u, (unsigned int)__double2loint(wt), (unsigned int)__double2hiint(wt));
-            }
-            pos[q] += (unsigned int)__popcll(m);
-        }
-    }
-}
-
-// (a global_load: a flat load through the table's generic pointer would also count on lgkmcnt and drain the LDS atomics)
-__device__ __forceinline__ unsigned int gload_u16(const unsigned short* p) {
-    return *(const __attribute__((address_space(1))) unsigned short*)p;
-}
-
-struct SortedPair {
-    const unsigned short* ix;  // the pair's x index column
-    int ycol;                  // which SortedCol of the launch
-    int dest;                  // which grid of the output block
-};
-
-// grid: 4 blocks (stripes) per pair, block ids of a pair congruent mod 8 (one XCD); 1024 threads; LDS: the 64 x 256 fp64
-// stripe.  Four samples per lane in flight: their row indices first, then the x gathers, then the adds.
-__global__ void __launch_bounds__(1024) k_hist2d_wsorted(const SortedPair* __restrict__ pairs, const SortedCol* __restrict__ colsv, int B,
-                                                         double* __restrict__ hist_all) {
-    extern __shared__ double sh_raw[];
-    double* sh = sh_raw;
-    int pair, chunk, stripe;
-    decode_block(4, 1, pair, chunk, stripe);
-    if (pair >= B) return;
-    const SortedPair P = pairs[pair];
-    if (P.dest < 0) return;
-    const SortedCol C = colsv[P.ycol];
-    for (int i = threadIdx.x; i < WSORT_STRIPE_ROWS * 256; i += 1024) sh[i] = 0.0;
-    __syncthreads();
-    const unsigned int lo = C.bucket_off[stripe], hi = C.bucket_off[stripe + 1];
-    constexpr int DEPTH = 8;
-    auto add = [&](const uint4& r, unsigned int x) {
-        if (x < 256u) atomicAdd(&sh[r.y * 256u + x], __hiloint2double((int)r.w, (int)r.z));
-    };
-    const unsigned int groups = (hi - lo) / (DEPTH * 1024u);
-    if (groups > 0) {
-        uint4 cur[DEPTH];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q) cur[q] = gload_u4(C.recs + lo + q * 1024u + threadIdx.x);
-        for (unsigned int g = 0; g < groups; ++g) {
-            // the x indices of the current records first, then the next group's records: the gathers are the older loads, so
-            // waiting for them leaves the record loads in flight behind the adds
-            unsigned int x[DEPTH];
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) x[q] = gload_u16(P.ix + cur[q].x);
-            uint4 nxt[DEPTH];
-            const unsigned int gn = (g + 1 < groups ? g + 1 : g) * (DEPTH * 1024u) + lo + threadIdx.x;  // (last: a harmless re-read)
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) nxt[q] = gload_u4(C.recs + gn + q * 1024u);
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) add(cur[q], x[q]);
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) cur[q] = nxt[q];
-        }
-    }
-    for (unsigned int i = lo + groups * (DEPTH * 1024u) + threadIdx.x; i < hi; i += 1024u) {
-        const uint4 r = gload_u4(C.recs + i);
-        add(r, gload_u16(P.ix + r.x));
-    }
-    __syncthreads();
-    double* hist = hist_all + (int64_t)P.dest * 65536 + (int64_t)stripe * WSORT_STRIPE_ROWS * 256;
-    for (int e = 2 * threadIdx.x; e < WSORT_STRIPE_ROWS * 256; e += 2048)
-        *reinterpret_cast<double2*>(&hist[e]) = *reinterpret_cast<const double2*>(&sh[e]);
-}
-
 // Unit-weight, pre-binned variant with 16-bit LDS counters packed two per word: a 256 x 256 grid fits one
 // 128 KB stripe, so every sample is visited once instead of once per stripe.  A counter can wrap if a bin receives
 // more than 65535 samples; a wrap always lowers the sum of all counters, so comparing that sum with the number of
@@ -1290,96 +1095,6 @@ static int launch_hist2d_u16(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& 
     return GD_OK;
 }
 
-// real weights, F = 256: y columns in groups whose sorted arrays fit the scratch budget; per group the three sort kernels
-// over its columns, then one launch over the pairs of those columns
-static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, double* d_hist) {
-    const int64_t N = ctx->N;
-    // distinct y columns in order of first appearance, and the pairs of each
-    std::vector<const unsigned short*> ycols;
-    std::vector<std::vector<int>> members;
-    {
-        std::map<const unsigned short*, int> at;
-        for (int b = 0; b < B; ++b) {
-            auto it = at.find(hp[b].iy);
-            if (it == at.end()) {
-                it = at.emplace(hp[b].iy, (int)ycols.size()).first;
-                ycols.push_back(hp[b].iy);
-                members.emplace_back();
-            }
-            members[it->second].push_back(b);
-        }
-    }
-    const int ny = (int)ycols.size();
-    const int64_t per_col = (N * 16 + 255) / 256 * 256 + (int64_t)WSORT_UNITS * 16 + 256;
-    int64_t budget = (int64_t)3 << 30;  // sorted records of a group of y columns (16 bytes per sample and column)
-    if (const char* e = getenv("GDHIP_WSORT_BYTES")) budget = atoll(e);
-    int group = (int)std::max<int64_t>(1, std::min<int64_t>(ny, budget / per_col));
-    const int64_t o_cols = 0, o_pairs = ((int64_t)group * sizeof(SortedCol) + 255) / 256 * 256,
-                  o_data = o_pairs + ((int64_t)8 * (B + 8) * sizeof(SortedPair) + 255) / 256 * 256;  // (the lane layout pads)
-    char* base = (char*)gd_scratch2(ctx, o_data + (int64_t)group * per_col);
-    if (!base) return GD_ERR_NOMEM;
-    SortedCol* d_cols = (SortedCol*)(base + o_cols);
-    SortedPair* d_pairs = (SortedPair*)(base + o_pairs);
-    GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_wsorted, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
-    for (int g0 = 0; g0 < ny; g0 += group) {
-        const int ng = std::min(group, ny - g0);
-        std::vector<SortedCol> hc((size_t)ng);
-        std::vector<SortedPair> hpairs;
-        for (int c = 0; c < ng; ++c) {
-            char* p = base + o_data + (int64_t)c * per_col;
-            hc[c].iy = ycols[g0 + c];
-            hc[c].recs = (uint4*)p;
-            p += (N * 16 + 255) / 256 * 256;
-            hc[c].counts = (unsigned int*)p;
-            hc[c].bucket_off = (unsigned int*)(p + (int64_t)WSORT_UNITS * 16);
-        }
-        // Pair order: the pairs of ONE y column run on ONE XCD, one after the other in groups of eight (32 CUs / 4 stripes).
-        // A pair's blocks are congruent mod 8 (decode_block), so the pair list is laid out in eight lanes -- position p
-        // belongs to lane p mod 8 -- and every y column goes to the lane with the fewest pairs so far: the eight pairs a
-        // lane has in flight read the same 160-MB record stream at the same pace, and all but the first find it in that
-        // XCD's L2.  (In plain order the pairs of a y column were spread over all eight XCDs: the counters showed 80 GB of
-        // L2 misses per 400-pair launch -- every pair fetching its records itself -- at 0.74 of the fabric's peak.)
-        std::vector<std::vector<SortedPair>> lanes(8);
-        {
-            std::vector<int> order(ng);
-            for (int c = 0; c < ng; ++c) order[c] = c;
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return members[g0 + a].size() > members[g0 + b].size(); });
-            for (int c : order) {
-                int best = 0;
-                for (int l = 1; l < 8; ++l)
-                    if (lanes[l].size() < lanes[best].size()) best = l;
-                for (int b : members[g0 + c]) {
-                    SortedPair sp;
-                    sp.ix = hp[b].ix, sp.ycol = c, sp.dest = b;
-                    lanes[best].push_back(sp);
-                }
-            }
-        }
-        size_t depth = 0;
-        for (int l = 0; l < 8; ++l) depth = std::max(depth, lanes[l].size());
-        SortedPair idle;
-        idle.ix = nullptr, idle.ycol = 0, idle.dest = -1;  // (a lane that has run out: its blocks return at once)
-        for (size_t t = 0; t < depth; ++t)
-            for (int l = 0; l < 8; ++l) hpairs.push_back(t < lanes[l].size() ? lanes[l][t] : idle);
-        const int nb = (int)hpairs.size();
-        // (the launches of the previous group read the tables being replaced: the staged uploads are consumed in stream
-        // order, behind them)
-        GD_TRY(gd_h2d(ctx, d_cols, hc.data(), (size_t)ng * sizeof(SortedCol)));
-        GD_TRY(gd_h2d(ctx, d_pairs, hpairs.data(), (size_t)nb * sizeof(SortedPair)));
-        k_wsort_count<<<dim3(WSORT_UNITS / 4, ng), 256, 0, ctx->stream>>>(d_cols, N);
-        GD_KERNEL_CHECK();
-        k_wsort_scan<<<ng, 1024, 0, ctx->stream>>>(d_cols);
-        GD_KERNEL_CHECK();
-        k_wsort_scatter<<<dim3(WSORT_UNITS / 4, ng), 256, 0, ctx->stream>>>(d_cols, ctx->w, N);
-        GD_KERNEL_CHECK();
-        const int units = (nb + 7) / 8 * 8;
-        k_hist2d_wsorted<<<(unsigned)(units * 4), 1024, LDS_HIST_BYTES, ctx->stream>>>(d_pairs, d_cols, nb, d_hist);
-        GD_KERNEL_CHECK();
-        if (g0 + group < ny) GD_TRY(gd_stream_sync(ctx));  // the next group's tables go into the same scratch
-    }
-    return gd_stream_sync(ctx);
-}
-
 int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, int32_t F,
                         void* d_hist) {
     GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
@@ -1442,10 +1157,12 @@ int gd_hist2d_prebinned(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, cons
             }
             return rc;
         }
-        // real weights on the base grid of a triangle: samples sorted by stripe once per y column (k_hist2d_wsorted)
-        if (ctx->w && !ctx->w8 && !ctx->w_integral && F == 256 && B >= 32 && ctx->N >= (1 << 16) && ctx->N < (int64_t)4294967295LL &&
-            getenv("GDHIP_NO_WSORT") == nullptr)
-            return hist2d_weighted_sorted(ctx, B, hp, (double*)d_hist);
+        // (real weights: four stripe passes with ds_add_f64.  Round 5 measured a one-pass alternative -- samples partitioned by
+        // stripe once per y column into 16-byte records (row, row in stripe, weight), a (pair, stripe) block walking only its
+        // quarter -- at 43.6 ms per 1225 pairs against 41.3 ms here: 16 bytes per (sample, pair) make it bound by the L2-miss
+        // path (80 GB per 400-pair launch at 0.74 of the peak; with the pairs of a y column on one XCD 42 GB, but 19 ms).  The
+        // roof of the adds themselves is 7.8 ms (2.5 ds_add_f64 lanes per clock and CU, scripts/micro/lds_atomic_f64_roof.hip);
+        // what keeps both forms away from it is the 12-16 bytes every (sample, pair) visit must fetch.  Not kept; DESIGN.md.)
         // the 16-bit kernel gives each (pair, stripe) to ONE block: only worth it when that fills the chip
         if ((ctx->w && !ctx->w8) || (int64_t)B * nstripes16 < ctx->cu_count)
             return launch_hist2d<2>(ctx, B, hp, F, (double*)d_hist);

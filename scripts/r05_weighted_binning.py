@@ -1,5 +1,5 @@
-"""The real-weight 2D binning of a whole triangle alone (50 columns, 1225 pairs, N = 1e7, w ~ Exp(1)): the stripe-sorted route
-and, with GDHIP_NO_WSORT=1, the four-pass kernel it replaces.  For kernel traces / counter passes.
+"""The real-weight 2D binning of a whole triangle alone (50 columns, 1225 pairs, N = 1e7, w ~ Exp(1)), for kernel traces /
+counter passes.
 python scripts/r05_weighted_binning.py [reps]"""
 import os
 import sys
@@ -22,4 +22,4 @@ out = mc.ctx.alloc(len(allp) * F * F * 8)
 for _ in range(reps):
     mc.ctx.timer_start()
     mc.ctx.hist2d_prebinned([idx[a] for a, b in allp], [idx[b] for a, b in allp], F, out=out)
-    print("weighted 2D binning of %d pairs: %.2f ms (%s)" % (len(allp), mc.ctx.timer_stop_ms(), "four-pass kernel" if os.environ.get("GDHIP_NO_WSORT") else "stripe-sorted"))
+    print("weighted 2D binning of %d pairs: %.2f ms" % (len(allp), mc.ctx.timer_stop_ms()))

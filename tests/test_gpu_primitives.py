@@ -692,43 +692,3 @@ def test_byte_index_binning_in_row_chunks_sums_partial_tables_exactly():
         c.hist2d_prebinned8([b2[0]], [b2[1]])
     assert err.value.code == -5
     c.close()
-
-
-def test_real_weight_binning_through_stripe_sorted_samples(monkeypatch):
-    """Real (non-integer) weights on the base grid of many pairs: gd_hist2d_prebinned partitions the samples by stripe once
-    per y column (k_wsort_*) and a (pair, stripe) block adds only its quarter of them (k_hist2d_wsorted).  Against
-    np.bincount(weights=...) at the 1e-12 of the histogram gate, with samples outside the grid (the u16 sentinel), pairs
-    listed in x-major order (the y columns' pairs are not contiguous), one scratch group and several, and against the
-    four-pass kernel it replaces."""
-    from getdist_amd._lib import Context
-
-    N, n, F = 260_011, 9, 256
-    r = np.random.default_rng(21)
-    s = r.standard_normal((N, n)) * r.uniform(0.5, 2.0, n) + r.uniform(-1, 1, n)
-    w = r.exponential(1.0, N) + 1e-3
-    c = Context(0)
-    c.upload(np.asfortranarray(s), w)
-    lo, hi = s.min(axis=0), s.max(axis=0)
-    binmin = lo - 0.02 * (hi - lo)
-    width = (hi + 0.02 * (hi - lo) - binmin) / (F - 1)
-    binmin[3] += 30 * width[3]  # column 3: a grid that leaves samples outside on the low side
-    pre = [c.prebin(j, binmin[j], width[j], F) for j in range(n)]
-    ix = [((s[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64) for j in range(n)]
-    pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]  # 36 pairs, x-major
-    assert len(pairs) >= 32
-
-    def run():
-        return c.hist2d_prebinned([pre[a] for a, b in pairs], [pre[b] for a, b in pairs], F).to_host((len(pairs), F, F))
-
-    H = run()
-    for k, (a, b) in enumerate(pairs):
-        ok = (ix[a] >= 0) & (ix[a] < F) & (ix[b] >= 0) & (ix[b] < F)
-        want = np.bincount(ix[a][ok] + ix[b][ok] * F, weights=w[ok], minlength=F * F).reshape(F, F)
-        assert np.allclose(H[k], want, rtol=1e-12, atol=1e-12), (a, b, float(np.max(np.abs(H[k] - want))))
-    monkeypatch.setenv("GDHIP_WSORT_BYTES", str(3 * 13 * N))  # room for two or three y columns at a time: several groups
-    H2 = run()
-    assert np.allclose(H2, H, rtol=1e-13, atol=1e-13)
-    monkeypatch.setenv("GDHIP_NO_WSORT", "1")  # the four-pass kernel of rounds 1-4
-    H3 = run()
-    assert np.allclose(H3, H, rtol=1e-12, atol=1e-12)
-    c.close()
