@@ -21,8 +21,6 @@
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
-#include <atomic>
-#include <chrono>
 #include <future>
 #include <map>
 #include <mutex>
@@ -475,7 +473,6 @@ struct Call {
         std::vector<double> r1s, r2s;
     } shear;
     bool have_shear = false;
-    std::atomic<bool> neff_may_launch{true};  // see run(): the lag-sum launch follows the binning launch
     // convolution state
     std::vector<double> rx, ry, cc, smooth, W;  // W: P x 3
     std::vector<int64_t> winw;
@@ -606,7 +603,6 @@ struct Call {
         const int L = (int)lags.size();
         std::vector<double> sums((size_t)m * L);
         mark("neff: probe done");
-        for (int spin = 0; !neff_may_launch.load() && spin < 20000; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(10));
         GDB_DEV(h, ops.kde_lag_sums_batch(h, todo.data(), m, inv4s2.data(), lags.data(), L, sums.data()));
         mark("neff: lag sums done");
         const NeffInput in{N, s.norm, s.sum_w2};
@@ -735,15 +731,8 @@ struct Call {
                 if (!d) return dev_fail(rc, h);
                 std::vector<int64_t> bad(todo.size() + 1, 0);
                 mark("binning: prebin8 + hist2d launch", (int)todo.size(), B);
-                std::thread release;
-                if (!neff_may_launch.load())
-                    release = std::thread([this] {  // (the call below returns only when its kernels have finished)
-                        std::this_thread::sleep_for(std::chrono::microseconds(100));
-                        neff_may_launch.store(true);
-                    });
                 const int e = ops.prebin8_hist2d(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), bufs.data(), bad.data(), B,
                                                  ix.data(), iy.data(), d);
-                if (release.joinable()) release.join();
                 mark("binning: prebin8 + hist2d done");
                 if (e == 0 || e == GD_ERR_SOLVER) {
                     std::lock_guard<std::mutex> g(st.mu);
@@ -1308,13 +1297,6 @@ struct Call {
             aux = st.aux;
         }
         std::future<int> neff_f, bin_f, shear_f;
-        // The N_eff lag sums are ONE saturating launch (thousands of long blocks) that nothing waits for until the join,
-        // while the binning chain on the second stream is the critical path of the call (binning -> optimiser ->
-        // convolution) and starts with a 64-thread table copy: enqueued behind the lag sums, that copy found no free wave
-        // slot for 1.3 ms (round-4 trace: k_fetch_copy16 5.03 -> 6.34 ms on both side streams).  So the lag-sum launch is held
-        // back until the binning thread has announced its launch (+ 100 us for its tables and kernels to be enqueued).
-        static const bool neff_first = getenv("GDHIP_BATCH_NEFF_FIRST") != nullptr;  // A/B switch: the order of rounds 1-4
-        neff_may_launch.store(neff_first || !overlap);
         if (overlap && need_neff)
             neff_f = std::async(std::launch::async, [this] {
                 ops.bind_thread(h);
@@ -1359,7 +1341,6 @@ struct Call {
                         const int e2 = split_classes ? binning(aux, 2) : 0;  // the up-scaled classes, behind the shear chain
                         return e ? e : e2;
                     });  // (no plan: the call fails; the side classes are not needed)
-                neff_may_launch.store(true);  // (a call whose binning took another route: nothing to wait for)
                 int e = neff_f.valid() ? neff_f.get() : 0;
                 if (!rc) rc = e;
                 if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)
