@@ -464,7 +464,8 @@ class MCSamples:
                  _context_factory=None, **kwargs):
         self.sampler = sampler or "mcmc"
         self.temperature, self.cooled = temperature, 1
-        self.likeStats = None
+        self._likeStats = None
+        self._loglikes_col = None
         self.label, self.name_tag = label, name_tag
         self.root = root
         self.raise_on_bandwidth_errors = False
@@ -894,10 +895,11 @@ class MCSamples:
         loglikes column on the device (gd_like_stats) give every weighted mean the reference forms from exp / square
         of that vector; the N-D limits come from _setNDLimits (weighted quantile + conditional min / max)."""
         if self.loglikes is None:
-            self.likeStats = None
+            self._likeStats = None
             return None
         ctx = self.ctx
         col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
+        self._loglikes_col = col  # (_setNDLimits below reads the same resident copy instead of uploading it again)
         st = ctx.like_stats(col)
         norm = self.norm
         maxlike = st["min"]
@@ -914,13 +916,25 @@ class MCSamples:
         best = self.samples[st["argmin"]]
         for j, par in enumerate(self.paramNames.names):
             par.bestfit_sample = best[j]
-        self.likeStats = m
+        self._likeStats = m
+        self._loglikes_col = None
         return m
+
+    @property
+    def likeStats(self):
+        """The reference sets this attribute inside updateBaseStatistics (mcsamples.py:552-576); here it is computed when first
+        read after a change of the samples (three passes over the sample set) -- reading the attribute and calling
+        getLikeStats() are the same thing, as are the parameters' ``bestfit_sample`` values it leaves."""
+        return self._likeStats if self._likeStats is not None else self._setLikeStats()
+
+    @likeStats.setter
+    def likeStats(self, value):
+        self._likeStats = value
 
     def getLikeStats(self):
         """mcsamples.py:2369-2378 (computed on first use after a change of the samples, not inside every
         updateBaseStatistics: it costs three passes over the sample set)"""
-        return self.likeStats or self._setLikeStats()
+        return self.likeStats
 
     def _use_like_weights(self, mode):
         """
@@ -1886,7 +1900,9 @@ class MCSamples:
         if self._nd_limits_done:
             return
         ctx = self.ctx
-        col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
+        col = getattr(self, "_loglikes_col", None)  # (resident already when _setLikeStats is the caller)
+        if col is None:
+            col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
         contours = np.asarray(self.contours, dtype=np.float64)
         thr = ctx.quantiles([col], (self.norm * contours)[None, :])[0]
         lims = np.empty((len(contours), self.n, 2))

@@ -53,7 +53,7 @@ PY
             done ;;
         emu_c3) GETDIST_AMD_LIVE_PMC=0 timeout 600 python scripts/emulate_scaling.py --nparams 50 --nsamples 10000000 > "$O/emulate_c3.json" 2> "$O/emulate_c3.err"; cat "$O/emulate_c3.err" | grep "^W=" ;;
         emu_c3_class) GETDIST_AMD_PAIR_DEAL=class GETDIST_AMD_LIVE_PMC=0 timeout 600 python scripts/emulate_scaling.py --nparams 50 --nsamples 10000000 --worlds 1,8 > "$O/emulate_c3_class.json" 2> "$O/emulate_c3_class.err"; cat "$O/emulate_c3_class.err" | grep "^W=" ;;
-        emu_c5) GETDIST_AMD_LIVE_PMC=0 timeout 900 python scripts/emulate_scaling.py --nparams 200 --nsamples 2000000 --steps 5 --warmup 2 > "$O/emulate_c5.json" 2> "$O/emulate_c5.err"; cat "$O/emulate_c5.err" | grep "^W=" ;;
+        emu_c5) GETDIST_AMD_LIVE_PMC=0 timeout 900 python scripts/emulate_scaling.py --nparams 200 --nsamples 2000000 --steps 8 --warmup 3 > "$O/emulate_c5.json" 2> "$O/emulate_c5.err"; cat "$O/emulate_c5.err" | grep "^W=" ;;
         emu_c4) for W in 1 2 4 8; do timeout 300 python scripts/gelman_rubin_multi_gpu.py --emulate-world $W > "$O/emulate_c4_w$W.json" 2> "$O/emulate_c4_w$W.err"; tail -1 "$O/emulate_c4_w$W.json" | cut -c1-300; done ;;
         emu8trace)
             (cd /tmp && GDHIP_BATCH_LOG=1 GETDIST_AMD_HOSTLOG=1 GETDIST_AMD_LIVE_PMC=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof_emu8" -o emu8 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 3 --emulate-world 8 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$O/emu8.log" 2> "$GRAFT_REPO_ROOT/$O/emu8.err")
@@ -63,6 +63,7 @@ PY
         f64roof) (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_atomic_f64_roof "$GRAFT_REPO_ROOT/scripts/micro/lds_atomic_f64_roof.hip" && ./lds_atomic_f64_roof 400) > "$O/lds_atomic_f64_roof.txt" 2>&1; cat "$O/lds_atomic_f64_roof.txt" ;;
         pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/r05_weighted_binning.py" 2>&1 | tail -8
               grep -E "SQ_|conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
+        gloo2) GETDIST_AMD_LIVE_PMC=0 timeout 600 python bench.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_gloo2_shared_gpu.json" 2> "$O/bench_gloo2.err"; tail -c 900 "$O/bench_gloo2_shared_gpu.json"; tail -3 "$O/bench_gloo2.err" | cut -c1-300 ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac
