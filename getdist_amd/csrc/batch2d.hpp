@@ -1328,7 +1328,7 @@ struct Call {
         int rc = 0;
         if (auto_bw) {
             if (overlap) {
-                const bool split_classes = F_list.size() > 1 && getenv("GDHIP_BATCH_SIDE_CLASSES_ON_TWIN") == nullptr;
+                const bool split_classes = F_list.size() > 1;
                 bin_f = std::async(std::launch::async, [this, split_classes] {
                     ops.bind_thread(twin);
                     return binning(twin, split_classes ? 1 : 0);

@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256) k_p8_reduce(const unsigned int* __restric
 // quantisation), else what fills the rounds (pick_chunks)
 static int pick_chunks(const gd_ctx* ctx, int64_t units, int64_t rows);
 static int u8_chunks(const gd_ctx* ctx, int B, int64_t N) {
-    if (B >= 2 * ctx->cu_count || getenv("GDHIP_U8_NO_CHUNKS") != nullptr) return 1;
+    if (B >= 2 * ctx->cu_count) return 1;
     return pick_chunks(ctx, B, N);
 }
 

@@ -113,32 +113,13 @@ __global__ void k_col_minmax(const double* __restrict__ cols, int64_t ld, const 
 }
 
 // pass 1: min, max, sum w, sum w x      pass 2: sum w (x-mean)^2
-template <bool HAS_W>
-__global__ void k_col_pass1(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
-                            const double* __restrict__ w, int64_t lo, int64_t hi, double* __restrict__ part) {
-    __shared__ double red[16];
-    const int c = colidx ? colidx[blockIdx.y] : blockIdx.y;
-    const double* x = cols + (int64_t)c * ld;
-    double mn = INFINITY, mx = -INFINITY, sw = 0, swx = 0;
-    stream_xw<HAS_W>(x, w, lo, hi, [&](double v, double wt) {
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
-        sw += wt;
-        swx += wt * v;
-    });
-    double r0 = block_min(mn, red), r1 = block_max(mx, red), r2 = block_sum(sw, red), r3 = block_sum(swx, red);
-    if (threadIdx.x == 0) {
-        double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-        p[0] = r0, p[1] = r1, p[2] = r2, p[3] = r3;
-    }
-}
-
 // pass 1 over a GROUP of G columns per block: the weights of a row are loaded once for the G columns (the one-column
-// kernel re-read them for every column: 14.2 GB of traffic against 4.04 GB of samples + weights at 100 columns x 5e6
-// rows), and a thread has G + 1 independent 16-byte loads in flight.  grid (NBLK_STREAM, ceil(ncols / G)); the row
-// traversal, the per-thread order of the additions, the wave reduction and the order over the waves are those of
-// k_col_pass1 / block_sum, so the partials are bit-equal to the one-column kernel's.  Columns past ncols are clamped
-// to the last one (loads stay in range, nothing is stored for them).
+// kernel of rounds 1-4 re-read them for every column: 14.2 GB of traffic against 4.04 GB of samples + weights at 100
+// columns x 5e6 rows, 2.13 ms per chain; this one 5.5 GB, 0.73 ms: profiles/r05_pmc_c4.json), and a thread has G + 1
+// independent 16-byte loads in flight.  grid (NBLK_STREAM, ceil(ncols / G)); the row traversal (stream_xw's), the per-thread
+// order of the additions, the wave reduction and the order over the waves (block_sum's) are those of the one-column
+// kernel, so the partials -- and every mean downstream -- kept their bits.  Columns past ncols are clamped to the last
+// one (loads stay in range, nothing is stored for them).
 template <bool HAS_W, int G>
 __global__ void __launch_bounds__(256) k_col_pass1g(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
                                                     int ncols, const double* __restrict__ w, int64_t lo, int64_t hi,
@@ -1346,13 +1327,7 @@ static int col_stats_device(gd_ctx* ctx, const int32_t* d_colidx, int ncols, int
                             double* d_part, double* d_out) {
     const int nblk = NBLK_STREAM;
     dim3 grid(nblk, ncols);
-    static const bool one_column = getenv("GDHIP_STATS_ONE_COLUMN") != nullptr;  // A/B switch: the kernel of rounds 1-4
-    if (one_column) {
-        if (ctx->w)
-            k_col_pass1<true><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, ctx->w, lo, hi, d_part);
-        else
-            k_col_pass1<false><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_colidx, nullptr, lo, hi, d_part);
-    } else {
+    {
         constexpr int G = 8;
         const dim3 ggrid(nblk, (ncols + G - 1) / G);
         if (ctx->w)

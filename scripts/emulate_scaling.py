@@ -56,18 +56,23 @@ def main():
         mc.ctx.sync()
         mc.ctx.copy_sync()
         t0 = time.perf_counter()
+        returned = [t0]
         for _ in range(args.steps):
             dens = bench.one_step(mc, pairs_all, None, 0, 1, None, emu)
+            returned.append(time.perf_counter())
         if len(dens):
             dens[-1].P
         mc.ctx.sync()
         mc.ctx.copy_sync()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
+        between = np.diff(returned) * 1e3  # host time between the returns of consecutive steps (steady state = the GPU's pace)
         gc.enable()
         mine = np.asarray(bench._REPLAY["last_pairs"]).reshape(-1, 2)
         if W == 1:
             t1 = ms
-        rows.append(dict(world=W, ms_per_step_rank0=round(ms, 3), pairs_rank0=int(len(mine)), columns_touched_rank0=int(len(np.unique(mine))),
+        rows.append(dict(world=W, ms_per_step_rank0=round(ms, 3), ms_between_step_returns_median=round(float(np.median(between)), 3),
+                         ms_between_step_returns=[round(float(x), 2) for x in between],
+                         pairs_rank0=int(len(mine)), columns_touched_rank0=int(len(np.unique(mine))),
                          efficiency=None if t1 is None else round(t1 / (W * ms), 3)))
         print("W=%d  %.2f ms  pairs %d  columns %d" % (W, ms, len(mine), len(np.unique(mine))), file=sys.stderr)
     print(json.dumps(dict(what="rank 0's share of a W-rank step on one GPU (other ranks' exchange contributions replayed)",
