@@ -376,8 +376,8 @@ def _cpu_task(task):
         orc = ko.OracleSamples(np.array(s[:, [j]]), names=[names[j]], ranges={k: v for k, v in ranges.items() if k == names[j]})
         t0 = time.perf_counter()
         orc.init_param(0)
-        orc.neff_1d(0)
-        return dict(kind=kind, j=j, seconds=time.perf_counter() - t0)
+        neff = orc.neff_1d(0)
+        return dict(kind=kind, j=j, seconds=time.perf_counter() - t0, neff=float(neff))
     if kind == "pair":
         a, b = task["pair"]
         sub = [names[a], names[b]]
@@ -406,6 +406,36 @@ def _cpu_task(task):
                     moved = float(np.max(np.abs(ens - ens[0])) / np.max(np.abs(ens[0])))
                     out["chaotic"] = (moved > 1e-6, moved)
         return out
+    if kind == "census_pair":
+        # one pair of the full-size census: its two columns only (160 MB at N = 1e7), the parameters' N_eff preset from the
+        # preparation stage (as inside a triangle), the oracle's grid against the GPU grid read from the flat file
+        import resource
+
+        a, b = task["pair"]
+        sub = [names[a], names[b]]
+        orc = ko.OracleSamples(np.array(s[:, [a, b]]), names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
+        for k, j in enumerate((a, b)):
+            orc.init_param(k)
+            orc.pars[k].N_eff_kde = task["neff"][j]
+        tr = {}
+        t0 = time.perf_counter()
+        P = orc.density_2d(0, 1, trace=tr)["P"]
+        seconds = time.perf_counter() - t0
+        F = task["gpu_F"]
+        row = dict(pair=(a, b), F=int(P.shape[0]), branch=tr.get("branch"), shape_ok=bool(P.shape[0] == F), tnc="p_13" in tr,
+                   seconds=seconds, max_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0)
+        if row["shape_ok"]:
+            G = np.asarray(np.load(task["gpu_path"], mmap_mode="r")[task["gpu_off"]:task["gpu_off"] + F * F]).reshape(F, F)
+            row["err"] = float(np.max(np.abs(G - P)))
+            kopt = task["gpu_kopt"]
+            if row["err"] > 1e-6 and row["tnc"] and kopt is not None:
+                psi = (tr["p_02"], tr["p_20"], tr["p_11"], tr["p_00"], tr["p_13"], tr["p_31"])
+                v = ko.judge_triple(np.asarray(kopt)[8:11], psi, tr["opt_N"], tr["opt_corr"])
+                row["oracle_moves_by"] = v["moved"]
+                row["inside_oracle_spread"], row["excess"], row["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                row["ensemble_perturbation"] = v["scale"]
+                row["verdict"] = _verdict_record(v)
+        return row
     # share of a full triangle: this worker's pairs, parameter state cached across them.  The CPU time is the oracle's
     # alone; afterwards (outside the timed span) every grid is compared with the GPU's grid of the same pair, read from
     # the flat file the GPU run left in shared memory, and a pair above 1e-6 is put to the oracle-ensemble test.
@@ -478,33 +508,55 @@ def _census_summary(rows, has_limits, names):
                            median_abs_dP=float(np.median(v["errs"]))) for k, v in sorted(census.items())})
 
 
-def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, tmp, cores):
-    """EVERY pair of the triangle at full N against the oracle (review item, round 4: the driver-run parity was a sample of
-    31), when the host has the cores for it: the pairs are dealt to the workers by tiles of the triangle
-    (parallel.partition_pairs_by_column_blocks), so that a worker prepares and copies only the ~10 columns its tile touches;
-    the GPU grids travel in one flat file in shared memory.  Guarded by the free memory of the host (a worker holds its
-    columns: ~1 GB) and by a wall-clock budget; returns None when it does not run, a dict with 'abandoned' when it ran out
-    of time."""
-    import multiprocessing as mp
+def _host_memory_budget():
+    """Bytes this process tree may safely use: the smaller of the cgroup limit (v2 memory.max / v1 limit_in_bytes -- a
+    container's ceiling, which /proc/meminfo does not show) and MemAvailable.  None when neither can be read."""
+    vals = []
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            txt = open(path).read().strip()
+            if txt != "max" and int(txt) < (1 << 60):
+                used = 0
+                for upath in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                    try:
+                        used = int(open(upath).read().strip())
+                        break
+                    except (OSError, ValueError):
+                        pass
+                vals.append(int(txt) - used)
+        except (OSError, ValueError):
+            pass
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                vals.append(int(line.split()[1]) * 1024)
+    except OSError:
+        pass
+    return min(vals) if vals else None
 
-    from getdist_amd import parallel
+
+def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, tmp, cores, neff_by_param):
+    """EVERY pair of the triangle at full N against the oracle (review item, round 4: the driver-run parity was a sample of
+    31), when the host has the cores for it: one task per pair -- its two columns only, the parameters' N_eff taken from
+    the preparation stage of the CPU baseline -- the GPU grids in one flat file in shared memory.  A worker's peak is
+    ~1 GB at N = 1e7; the pool is sized so that all workers together stay below a QUARTER of what the host / the container
+    allows (cgroup limit and MemAvailable), and the stage has a wall-clock budget.  Returns None when it does not run, a
+    dict saying why when it gives up."""
+    import multiprocessing as mp
 
     min_cores = int(os.environ.get("GETDIST_AMD_CENSUS_MIN_CORES", "64"))  # (lowered by the CPU smoke of this function only)
     if cores < min_cores or os.environ.get("GETDIST_AMD_FULL_CENSUS", "1") != "1":
         return None
     N = int(np.load(s_path, mmap_mode="r").shape[0])
-    workers = int(max(2, min(cores // 2, 96, len(pairs_all))))
-    try:
-        import psutil
-
-        avail = psutil.virtual_memory().available
-    except Exception:
-        avail = 0
-    per_worker = 14 * N * 8 * 1.6 + 600e6  # its columns (a tile: <= 14), the oracle's temporaries, the interpreter
-    if avail < workers * per_worker + 8e9:
-        workers = int(max(0, (avail - 8e9) // per_worker))
-    if workers < min(32, min_cores // 2):
-        return dict(ran=False, reason="not enough free host memory for >= 32 census workers (%.0f GB available)" % (avail / 1e9))
+    budget = _host_memory_budget()
+    per_worker = 12 * N * 8 + 400e6  # two columns, the oracle's copies and sort temporaries, the interpreter (measured: max_rss)
+    workers = int(os.environ.get("GETDIST_AMD_CENSUS_WORKERS", "0")) or int(min(cores // 2, 64, len(pairs_all)))
+    if budget is None:
+        workers = min(workers, 8)
+    else:
+        workers = int(min(workers, (0.25 * budget) // per_worker))
+    if workers < 2:
+        return dict(ran=False, reason="not enough free host memory for the census pool (budget %s bytes)" % budget)
     sizes = np.array([d.P.size for d in dens], dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(sizes)])
     flat = np.empty(int(offs[-1]))
@@ -513,45 +565,41 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     path_gpu = os.path.join(tmp, "gpu_grids_full.npy")
     np.save(path_gpu, flat)
     del flat
-    at = {pr: k for k, pr in enumerate(pairs_all)}
-    n = len(names)
-    tasks = []
-    for r in range(workers):
-        mine, sh = parallel.partition_pairs_by_column_blocks(pairs_all, np.zeros(len(pairs_all), dtype=np.int64), workers, r, n)
-        if not sh:
-            continue
-        cols = sorted({c for pr in sh for c in pr})
-        tasks.append(dict(kind="triangle", path=s_path, names=list(names), ranges=dict(ranges), pairs=sh, cols=cols,
-                          gpu_path=path_gpu, gpu_offsets=[int(offs[at[pr]]) for pr in sh],
-                          gpu_F=[int(dens[at[pr]].P.shape[0]) for pr in sh],
-                          gpu_kopt=[None if dens[at[pr]].kopt is None else np.asarray(dens[at[pr]].kopt) for pr in sh]))
+    base = dict(kind="census_pair", path=s_path, names=list(names), ranges=dict(ranges), gpu_path=path_gpu, neff=dict(neff_by_param))
+    tasks = [dict(base, pair=pr, gpu_off=int(offs[k]), gpu_F=int(dens[k].P.shape[0]),
+                  gpu_kopt=None if dens[k].kopt is None else np.asarray(dens[k].kopt)) for k, pr in enumerate(pairs_all)]
+    limit = int(os.environ.get("GETDIST_AMD_CENSUS_MAX_PAIRS", "0"))  # (probing a new host: the first K pairs only)
+    if limit:
+        tasks = tasks[:limit]
     saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     for k in saved_env:
         os.environ[k] = "1"
     t0 = time.perf_counter()
     try:
-        with mp.get_context("spawn").Pool(len(tasks)) as pool:
+        with mp.get_context("spawn").Pool(workers, maxtasksperchild=8) as pool:  # (a worker's heap is handed back regularly)
             for k, v in saved_env.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
             try:
-                tri = pool.map_async(_cpu_task, tasks, chunksize=1).get(timeout=args.census_budget_s)
+                rows = pool.map_async(_cpu_task, tasks, chunksize=1).get(timeout=args.census_budget_s)
             except mp.TimeoutError:
                 return dict(ran=True, abandoned=True, reason="wall-clock budget of %.0f s exceeded" % args.census_budget_s,
-                            workers=len(tasks))
+                            workers=workers)
     finally:
         for k, v in saved_env.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    rows = [row for r in tri for row in r["rows"]]
     out = _census_summary(rows, has_limits, names)
-    out.update(ran=True, N=N, workers=len(tasks), wall_s=round(time.perf_counter() - t0, 1),
-               cpu_core_seconds=round(sum(r["seconds"] for r in tri), 1),
-               note="every pair of the timed triangle at full size against the oracle; workers hold one tile of the triangle each")
+    out.update(ran=True, N=N, workers=workers, wall_s=round(time.perf_counter() - t0, 1),
+               cpu_core_seconds=round(sum(r["seconds"] for r in rows), 1),
+               worker_max_rss_mb=round(max(r.get("max_rss_mb", 0.0) for r in rows), 0),
+               host_memory_budget_gb=None if budget is None else round(budget / 1e9, 1),
+               note="every pair of the timed triangle at full size against the oracle; one task per pair (two columns), N_eff "
+                    "from the preparation stage; the pool is sized to a quarter of the host / container memory")
     return out
 
 
@@ -612,6 +660,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
                              chunksize=1).get(timeout=args.cpu_budget_s)
         wall_sample = time.perf_counter() - t0
         prep = {r["j"]: r["seconds"] for r in res if r["kind"] == "prep"}
+        neff_by_param = {r["j"]: r["neff"] for r in res if r["kind"] == "prep"}
         pair_res = {tuple(r["pair"]): r for r in res if r["kind"] == "pair"}
         by_class = {}
         for key, pr in sample:
@@ -704,7 +753,8 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
             mc2.ctx.close()
     # ---- every pair of the timed triangle at full size (hosts with >= 64 cores; behind the clock)
     try:
-        full = full_size_census(args, path_full, names, ranges, pairs_all, dens, [bool(p.has_limits) for p in par], tmp, cores)
+        full = full_size_census(args, path_full, names, ranges, pairs_all, dens, [bool(p.has_limits) for p in par], tmp, cores,
+                                neff_by_param)
     except Exception as exc:  # the sample above stands on its own
         full = dict(ran=False, reason="census failed: %r" % (exc,))
     parity_block["full_size_census"] = full
