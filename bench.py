@@ -346,6 +346,17 @@ def _cpu_noop(k):
     return k
 
 
+def _peak_rss_mb():
+    """Peak resident set of THIS process image (VmHWM; ru_maxrss would carry the parent's size across fork + exec)."""
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("VmHWM:"):
+                return int(line.split()[1]) / 1024.0
+    except OSError:
+        pass
+    return 0.0
+
+
 def _verdict_record(v):
     """What is reported per loose pair (review item, round 4): the criterion and the perturbation scale that admitted the
     device's bandwidth triple under the frozen rules, the distance to the nearest member of the oracle's ensemble, and the
@@ -409,8 +420,6 @@ def _cpu_task(task):
     if kind == "census_pair":
         # one pair of the full-size census: its two columns only (160 MB at N = 1e7), the parameters' N_eff preset from the
         # preparation stage (as inside a triangle), the oracle's grid against the GPU grid read from the flat file
-        import resource
-
         a, b = task["pair"]
         sub = [names[a], names[b]]
         orc = ko.OracleSamples(np.array(s[:, [a, b]]), names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
@@ -423,7 +432,7 @@ def _cpu_task(task):
         seconds = time.perf_counter() - t0
         F = task["gpu_F"]
         row = dict(pair=(a, b), F=int(P.shape[0]), branch=tr.get("branch"), shape_ok=bool(P.shape[0] == F), tnc="p_13" in tr,
-                   seconds=seconds, max_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0)
+                   seconds=seconds, max_rss_mb=_peak_rss_mb())
         if row["shape_ok"]:
             G = np.asarray(np.load(task["gpu_path"], mmap_mode="r")[task["gpu_off"]:task["gpu_off"] + F * F]).reshape(F, F)
             row["err"] = float(np.max(np.abs(G - P)))
