@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
     ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock cap of each CPU-baseline pool stage; "
                     "a stage that exceeds it is abandoned and reported as such (the GPU numbers are printed regardless)")
-    ap.add_argument("--census-budget-s", type=float, default=420.0, help="wall-clock cap of the all-pairs full-size parity "
+    ap.add_argument("--census-budget-s", type=float, default=240.0, help="wall-clock cap of the all-pairs full-size parity "
                     "census (hosts with >= 64 cores); abandoned and reported as such beyond it")
     ap.add_argument("--context-factory", default="", help="testing only: 'module:attr' of a Context stand-in (the CPU "
                     "suite runs the launcher and the multi-rank step with tests/fake_ctx.py); the product path never sets it")
@@ -585,12 +585,9 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
         os.environ[k] = "1"
     t0 = time.perf_counter()
     try:
-        with mp.get_context("spawn").Pool(workers, maxtasksperchild=8) as pool:  # (a worker's heap is handed back regularly)
-            for k, v in saved_env.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        # (the single-thread settings stay in the environment until the pool is closed: a worker spawned later -- after a
+        # crash, or with maxtasksperchild -- would otherwise start with one BLAS / OpenMP thread per core)
+        with mp.get_context("spawn").Pool(workers) as pool:
             try:
                 rows = pool.map_async(_cpu_task, tasks, chunksize=1).get(timeout=args.census_budget_s)
             except mp.TimeoutError:
