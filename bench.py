@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--cpu-small-n", type=int, default=1_000_000, help="rows of the un-extrapolated CPU/GPU triangle")
     ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock cap of each CPU-baseline pool stage; "
                     "a stage that exceeds it is abandoned and reported as such (the GPU numbers are printed regardless)")
-    ap.add_argument("--census-budget-s", type=float, default=240.0, help="wall-clock cap of the all-pairs full-size parity "
+    ap.add_argument("--census-budget-s", type=float, default=300.0, help="wall-clock cap of the all-pairs full-size parity "
                     "census (hosts with >= 64 cores); abandoned and reported as such beyond it")
     ap.add_argument("--context-factory", default="", help="testing only: 'module:attr' of a Context stand-in (the CPU "
                     "suite runs the launcher and the multi-rank step with tests/fake_ctx.py); the product path never sets it")
@@ -548,7 +548,7 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     """EVERY pair of the triangle at full N against the oracle (review item, round 4: the driver-run parity was a sample of
     31), when the host has the cores for it: one task per pair -- its two columns only, the parameters' N_eff taken from
     the preparation stage of the CPU baseline -- the GPU grids in one flat file in shared memory.  A worker's peak is
-    ~1 GB at N = 1e7; the pool is sized so that all workers together stay below a QUARTER of what the host / the container
+    ~1 GB at N = 1e7; the pool is sized so that all workers together stay below a THIRD of what the host / the container
     allows (cgroup limit and MemAvailable), and the stage has a wall-clock budget.  Returns None when it does not run, a
     dict saying why when it gives up."""
     import multiprocessing as mp
@@ -559,11 +559,11 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     N = int(np.load(s_path, mmap_mode="r").shape[0])
     budget = _host_memory_budget()
     per_worker = 12 * N * 8 + 400e6  # two columns, the oracle's copies and sort temporaries, the interpreter (measured: max_rss)
-    workers = int(os.environ.get("GETDIST_AMD_CENSUS_WORKERS", "0")) or int(min(cores // 2, 64, len(pairs_all)))
+    workers = int(os.environ.get("GETDIST_AMD_CENSUS_WORKERS", "0")) or int(min(cores // 2, 96, len(pairs_all)))
     if budget is None:
         workers = min(workers, 8)
     else:
-        workers = int(min(workers, (0.25 * budget) // per_worker))
+        workers = int(min(workers, (0.35 * budget) // per_worker))  # (measured peak of a worker: 1.0 GB at N = 1e7, VmHWM)
     if workers < 2:
         return dict(ran=False, reason="not enough free host memory for the census pool (budget %s bytes)" % budget)
     sizes = np.array([d.P.size for d in dens], dtype=np.int64)
@@ -577,6 +577,8 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     base = dict(kind="census_pair", path=s_path, names=list(names), ranges=dict(ranges), gpu_path=path_gpu, neff=dict(neff_by_param))
     tasks = [dict(base, pair=pr, gpu_off=int(offs[k]), gpu_F=int(dens[k].P.shape[0]),
                   gpu_kopt=None if dens[k].kopt is None else np.asarray(dens[k].kopt)) for k, pr in enumerate(pairs_all)]
+    # longest first: the up-scaled grids (the oracle's frames grow with F^2), then the sheared branch, then the rest
+    tasks.sort(key=lambda t: (-t["gpu_F"], dens[pairs_all.index(t["pair"])].bandwidth_branch != "A"))
     limit = int(os.environ.get("GETDIST_AMD_CENSUS_MAX_PAIRS", "0"))  # (probing a new host: the first K pairs only)
     if limit:
         tasks = tasks[:limit]
