@@ -578,7 +578,8 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     tasks = [dict(base, pair=pr, gpu_off=int(offs[k]), gpu_F=int(dens[k].P.shape[0]),
                   gpu_kopt=None if dens[k].kopt is None else np.asarray(dens[k].kopt)) for k, pr in enumerate(pairs_all)]
     # longest first: the up-scaled grids (the oracle's frames grow with F^2), then the sheared branch, then the rest
-    tasks.sort(key=lambda t: (-t["gpu_F"], dens[pairs_all.index(t["pair"])].bandwidth_branch != "A"))
+    branch_of = {pr: d.bandwidth_branch for pr, d in zip(pairs_all, dens)}
+    tasks.sort(key=lambda t: (-t["gpu_F"], branch_of[t["pair"]] != "A"))
     limit = int(os.environ.get("GETDIST_AMD_CENSUS_MAX_PAIRS", "0"))  # (probing a new host: the first K pairs only)
     if limit:
         tasks = tasks[:limit]
