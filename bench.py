@@ -17,10 +17,16 @@ After the timed region rank 0 adds, on one GPU only (SURVEY.md 8d protocol):
     per-parameter preparations plus up to 3 pairs of every (bandwidth branch, #bounded, grid size) class at N = 1e7,
     timed in a pool of min(cores, 32) single-threaded workers and extrapolated over the class census, a short
     single-process sample of the same tasks, and the UN-extrapolated full triangle at N = 1e6 on CPU and GPU;
-  * parity: the GPU grids of those stratified pairs against the oracle's at full size.
+  * parity: the GPU grids of those stratified pairs against the oracle's at full size; on hosts with >= 64 cores EVERY pair of
+    the timed triangle at full size (parity.full_size_census: a pool sized to a third of the container's memory, longest
+    pairs first, behind a wall-clock budget), else every sheared pair in addition to the stratified sample.  Each pair
+    above 1e-6 carries its verdict record: which criterion of the frozen oracle-ensemble rule admitted it, at which
+    perturbation scale, how far the nearest ensemble member is, and whether the strict slack of 0.25 admits it too.
 
-Multi-GPU: every rank holds a replica of the samples; parameter preparation is split over ranks and its scalars
-all-gathered (RCCL), pairs are partitioned by cost class with no data-path collective; total work is fixed
+Multi-GPU: every rank ends up with a replica of the samples -- it uploads its own block of columns and receives the others
+over xGMI (parallel.ColumnShare: gd_upload_shard + gd_comm_share_columns) when the library communicator is available;
+parameter preparation is split over ranks and its scalars all-gathered (RCCL inside the C ABI), pairs are dealt by tiles of
+the triangle (a rank pre-bins only the columns its pairs touch) with no data-path collective; total work is fixed
 ("strong" scaling); `value` = 1225 * K / max-over-ranks time.
 """
 
