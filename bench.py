@@ -394,7 +394,9 @@ def _cpu_task(task):
         t0 = time.perf_counter()
         orc.init_param(0)
         neff = orc.neff_1d(0)
-        return dict(kind=kind, j=j, seconds=time.perf_counter() - t0, neff=float(neff))
+        # (the parameter's prepared state -- ranges, limit flags, sigma_range, N_eff: plain scalars -- travels to the census tasks)
+        state = {k: v for k, v in vars(orc.pars[0]).items() if k != "name"}
+        return dict(kind=kind, j=j, seconds=time.perf_counter() - t0, neff=float(neff), state=state)
     if kind == "pair":
         a, b = task["pair"]
         sub = [names[a], names[b]]
@@ -430,7 +432,10 @@ def _cpu_task(task):
         sub = [names[a], names[b]]
         orc = ko.OracleSamples(np.array(s[:, [a, b]]), names=sub, ranges={k: v for k, v in ranges.items() if k in sub})
         for k, j in enumerate((a, b)):
-            orc.init_param(k)
+            if task.get("state") is not None:  # prepared once per parameter by the CPU baseline's preparation stage
+                vars(orc.pars[k]).update(task["state"][j])
+            else:
+                orc.init_param(k)
             orc.pars[k].N_eff_kde = task["neff"][j]
         tr = {}
         t0 = time.perf_counter()
@@ -550,7 +555,7 @@ def _host_memory_budget():
     return min(vals) if vals else None
 
 
-def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, tmp, cores, neff_by_param):
+def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, tmp, cores, neff_by_param, state_by_param=None):
     """EVERY pair of the triangle at full N against the oracle (review item, round 4: the driver-run parity was a sample of
     31), when the host has the cores for it: one task per pair -- its two columns only, the parameters' N_eff taken from
     the preparation stage of the CPU baseline -- the GPU grids in one flat file in shared memory.  A worker's peak is
@@ -565,7 +570,8 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     N = int(np.load(s_path, mmap_mode="r").shape[0])
     budget = _host_memory_budget()
     per_worker = 12 * N * 8 + 400e6  # two columns, the oracle's copies and sort temporaries, the interpreter (measured: max_rss)
-    workers = int(os.environ.get("GETDIST_AMD_CENSUS_WORKERS", "0")) or int(min(cores // 2, 96, len(pairs_all)))
+    # (the oracle's sorts are memory-bound: 56 workers took 5.2 s per pair where 32 take 2.7 -- half the cores, at most 48)
+    workers = int(os.environ.get("GETDIST_AMD_CENSUS_WORKERS", "0")) or int(min(cores // 2, 48, len(pairs_all)))
     if budget is None:
         workers = min(workers, 8)
     else:
@@ -580,7 +586,8 @@ def full_size_census(args, s_path, names, ranges, pairs_all, dens, has_limits, t
     path_gpu = os.path.join(tmp, "gpu_grids_full.npy")
     np.save(path_gpu, flat)
     del flat
-    base = dict(kind="census_pair", path=s_path, names=list(names), ranges=dict(ranges), gpu_path=path_gpu, neff=dict(neff_by_param))
+    base = dict(kind="census_pair", path=s_path, names=list(names), ranges=dict(ranges), gpu_path=path_gpu, neff=dict(neff_by_param),
+                state=state_by_param)
     tasks = [dict(base, pair=pr, gpu_off=int(offs[k]), gpu_F=int(dens[k].P.shape[0]),
                   gpu_kopt=None if dens[k].kopt is None else np.asarray(dens[k].kopt)) for k, pr in enumerate(pairs_all)]
     # longest first: the up-scaled grids (the oracle's frames grow with F^2), then the sheared branch, then the rest
@@ -676,6 +683,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
         wall_sample = time.perf_counter() - t0
         prep = {r["j"]: r["seconds"] for r in res if r["kind"] == "prep"}
         neff_by_param = {r["j"]: r["neff"] for r in res if r["kind"] == "prep"}
+        state_by_param = {r["j"]: r["state"] for r in res if r["kind"] == "prep"}
         pair_res = {tuple(r["pair"]): r for r in res if r["kind"] == "pair"}
         by_class = {}
         for key, pr in sample:
@@ -769,7 +777,7 @@ def cpu_baseline_and_parity(args, mc, s, names, ranges, pairs_all, dens):
     # ---- every pair of the timed triangle at full size (hosts with >= 64 cores; behind the clock)
     try:
         full = full_size_census(args, path_full, names, ranges, pairs_all, dens, [bool(p.has_limits) for p in par], tmp, cores,
-                                neff_by_param)
+                                neff_by_param, state_by_param)
     except Exception as exc:  # the sample above stands on its own
         full = dict(ran=False, reason="census failed: %r" % (exc,))
     parity_block["full_size_census"] = full
