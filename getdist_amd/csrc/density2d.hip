@@ -796,15 +796,19 @@ __device__ __forceinline__ int64_t xt_at(int b, int NT, int Sh, int y, int kx) {
 // S / 2 + 1 spectrum values (twg: the S twiddles, stride 2 for the transform) IN PLACE (X[0] and X[H] are real and share
 // slot 0); after a block barrier the tile goes out in one contiguous run.
 // MODE 0: rows of src (B x F x F); MODE 1: rows of the bias-correction box src / P where P > max * 1e-8 (k_fill_box).
-template <int MODE>
-__global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
+// FTL lanes per row: 32 for the Stockham passes; 16 for the 144-point register transform (round 5) -- its 16-point step
+// keeps 9 lanes of a row's group busy and its 9-point step 16, so with 32-lane groups a wave carried two rows with 18 and
+// 32 of its 64 lanes at work; with 16-lane groups it carries four (36 and 64 lanes): the transform's instructions per row
+// halve, everything else (pack, un-mix, tile store) is lane-parallel either way.  The arithmetic of a row is unchanged.
+template <int MODE, int FTL>
+__global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
                                                   const double* __restrict__ P, const double* __restrict__ mx, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double2* __restrict__ Xt) {
     extern __shared__ double2 sh2[];
     __shared__ double thresh_sh;
     const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
     double2* tw = sh2;
-    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
     double2* buf = sh2 + S + (size_t)g * RP;
     for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
@@ -826,15 +830,17 @@ __global__ void __launch_bounds__(512) k_rows_fwd(const D2Pair* __restrict__ pai
             }
             return v;
         };
-        for (int n = t; n < H; n += FT) buf[n] = make_double2(value(2 * n), value(2 * n + 1));
+        for (int n = t; n < H; n += FTL) buf[n] = make_double2(value(2 * n), value(2 * n + 1));
     }
     group_sync();
-    if (H == 144)  // (uniform) 16 x 9 in registers, fft288.hpp
+    if (FTL == 16)  // 16 x 9 in registers, fft288.hpp (the host launches this form for H = 144 only)
+        f288::fft144_group<false>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
+    else if (H == 144)  // (uniform)
         f288::fft144_group<false>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
     else
         fft_full<false, false>(buf, tw, 2, plH, t);
     if (active) {  // un-mix in place: the lane that consumes (buf[k], buf[H - k]) writes (X[k], X[H - k]) there
-        for (int k = t; 2 * k <= H; k += FT) {
+        for (int k = t; 2 * k <= H; k += FTL) {
             if (k == 0) {
                 const double2 z = buf[0];
                 buf[0] = make_double2(z.x + z.y, z.x - z.y);  // (X[0], X[H]): both real
@@ -1092,8 +1098,8 @@ __global__ void __launch_bounds__(192) k_col_conv16(const D2Pair* __restrict__ p
 // grid does not cover set to -inf.
 // MODE 1 takes the divisor a00 (the all-edge mask's zeroth moment) from its F x F array, or -- sat1 given: the pair's
 // summed-area table of that moment at sat1 + b * sat1_pair_stride -- evaluates it per pixel (k_mask_eval's operations).
-template <int MODE>
-__global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
+template <int MODE, int FTL>
+__global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
                                                   const double* __restrict__ a00, double* __restrict__ mx,
                                                   const double* __restrict__ sat1, int64_t sat1_pair_stride, int edge_applied,
@@ -1103,7 +1109,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     __shared__ double red[16];
     const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
     double2* tw = sh2;
-    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
     double2* buf = sh2 + S + (size_t)g * RP;
     for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     {  // the block's tile of Yt, one contiguous run, into the rows' buffers (row stride H + 1: slot kx of row r)
@@ -1117,7 +1123,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     // read a dozen of its entries each, and from global memory each such read sat on the row's critical path
     // (measured with the interior shortcut below: 141 -> 107 us per 136-pair launch; requesting the row of the grid ahead of the
     // transform instead of at its use: 117, not kept)
-    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)(blockDim.x / FT) * RP);
+    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)XT_ROWS * RP);
     // MODE 1 with class tables (k_mask_tables): a row needs the 2w + 3 entries of its y class only -- its group fetches
     // them (LDS: 16 x (2w + 3) doubles) and a pixel's divisor is one look-up
     if (MODE == 1 && tab1) {
@@ -1125,7 +1131,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
         const MaskIv iy = mask_interval(F, w, fl & 4, fl & 8, 1, edge_applied != 0);
         const int cy = mask_class(min(yy, F - 1), iy.lo + (iy.hlo ? 1 : 0), iy.hi - 2 * w - (iy.hhi ? 1 : 0), w);
         const double* trow = tab1 + (int64_t)b * tab1_pair_stride + (int64_t)cy * NC;
-        for (int c = t; c < NC; c += FT) sat_l[g * NC + c] = trow[c];
+        for (int c = t; c < NC; c += FTL) sat_l[g * NC + c] = trow[c];
     } else if (MODE == 1 && sat1 && sat_in_lds) {
         const double* s1g = sat1 + (int64_t)b * sat1_pair_stride;
         const int n1 = (2 * w + 2) * (2 * w + 2);
@@ -1135,7 +1141,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
     const int y = blockIdx.x * XT_ROWS + g;
     const bool active = y < F;
     if (active) {  // in place: the lane that consumes (X[k], X[H - k]) writes (Z[k], Z[H - k]) there
-        for (int k = t; 2 * k <= H; k += FT) {
+        for (int k = t; 2 * k <= H; k += FTL) {
             if (k == 0) {
                 const double x0 = buf[0].x, xh = buf[H].x;  // the imaginary parts of X[0], X[H] do not enter
                 buf[0] = make_double2(x0 + xh, x0 - xh);
@@ -1155,7 +1161,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
         }
     }
     group_sync();
-    if (H == 144)
+    if (FTL == 16 || H == 144)
         f288::fft144_group<true>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
     else
         fft_full<false, true>(buf, tw, 2, plH, t);
@@ -1172,7 +1178,7 @@ __global__ void __launch_bounds__(512) k_rows_inv(const D2Pair* __restrict__ pai
         const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
         const bool row_full = y >= iy.lo + (iy.hlo ? 1 : 0) && y <= iy.hi - 2 * w - (iy.hhi ? 1 : 0);
         const double* drow = sat_l + g * (2 * w + 3);
-        for (int x = t; x < F; x += FT) {
+        for (int x = t; x < F; x += FTL) {
             const int pos = x + w;
             const double2 z = buf[pos >> 1];
             double v = (pos & 1) ? z.y : z.x;
@@ -1542,6 +1548,9 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     // ---- LDS route: launches.  ZW's block holds the plain window's spectrum by columns (kept for the bias-correction
     //      round), ZH's block the moment windows' one after the other.
     const bool big = S > 320;  // size class of the transforms (butterflies per lane)
+    // 288-point frames: the rows' 144-point register transform on 16-lane groups (four rows per wave); GDHIP_CONV_ROWS32=1: the
+    // 32-lane groups of round 4 (A/B switch)
+    const bool rows16 = S == 288 && getenv("GDHIP_CONV_ROWS32") == nullptr;
     double* Wt0 = (double*)ZW;
     double* Wt1 = (double*)ZH;
     // the window moment's spectrum
@@ -1554,9 +1563,9 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     };
     // row spectra of a source into Xt (box: the bias-correction box of src and P)
     auto lds_rows_fwd = [&](bool box, const double* P_, const double* mx_) -> int {
-        auto kern = box ? k_rows_fwd<1> : k_rows_fwd<0>;
+        auto kern = rows16 ? (box ? k_rows_fwd<1, 16> : k_rows_fwd<0, 16>) : (box ? k_rows_fwd<1, 32> : k_rows_fwd<0, 32>);
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kern<<<gR, RPB * FT, lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, plH, d_tw, Xt);
+        kern<<<gR, RPB * (rows16 ? 16 : 32), lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, plH, d_tw, Xt);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
@@ -1574,7 +1583,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             kc<<<gC, 256, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, w_odd, Xt, Yt);
         }
         GD_KERNEL_CHECK();
-        auto kr = update ? k_rows_inv<1> : k_rows_inv<0>;
+        auto kr = rows16 ? (update ? k_rows_inv<1, 16> : k_rows_inv<0, 16>) : (update ? k_rows_inv<1, 32> : k_rows_inv<0, 32>);
         const bool tabs = update && fused && class_tables;  // the divisor by class: one table row per row of the tile
         size_t lds_rows_inv = lds_rows + (tabs ? (size_t)RPB * (2 * maxw + 3) * 8
                                                : (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0));
@@ -1585,7 +1594,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         const double* sat1 = (update && fused && !tabs) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
         const double* tab1 = (tabs && sat_in_lds) ? d_tab + (int64_t)(n_mom - 1) * tab_stride : nullptr;
         if (tabs && !tab1) sat1 = d_sat + (int64_t)(n_mom - 1) * sat_stride;  // (no room for the rows: the older path)
-        kr<<<gR, RPB * FT, lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
+        kr<<<gR, RPB * (rows16 ? 16 : 32), lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
                                                         do_bc ? 1 : 0, sat_in_lds, tab1, (int64_t)n_mom * tab_stride);
         GD_KERNEL_CHECK();
         return GD_OK;
