@@ -810,7 +810,13 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
     double2* tw = sh2;
     const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
     double2* buf = sh2 + S + (size_t)g * RP;
-    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
+    {  // (both of a thread's twiddle loads requested before the first is stored)
+        const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+        const double2 a0 = twg[min(i0, S - 1)], a1 = twg[min(i1, S - 1)];
+        if (i0 < S) tw[i0] = a0;
+        if (i1 < S) tw[i1] = a1;
+        for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) tw[i] = twg[i];
+    }
     if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
     __syncthreads();
     const int w = pairs[b].w;
@@ -818,19 +824,37 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
     const bool active = y < F;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F, oh = (int64_t)pairs[b].hidx * F * F + (int64_t)y * F;
-        auto value = [&](int x) {  // the frame's row at position x: the source row embedded at offset w
-            const int c = x - w;
-            double v = 0.0;
-            if (c >= 0 && c < F) {
-                v = src[oh + c];
-                if (MODE == 1) {
-                    const double p = P[o + c];
-                    if (p > thresh_sh) v = v / p;
-                }
+        // The frame's row at position x is the source row embedded at offset w.  ALL of a lane's loads are requested before
+        // the first value is used (unconditional loads from clamped addresses, the padding selected afterwards): the loop
+        // this replaces issued two predicated 8-byte loads per iteration and waited for them before the next -- nine
+        // memory latencies in sequence per block, which is what the row kernels' time was made of (ISA reading, round 5).
+        constexpr int MAXIT = (FTL == 16) ? 9 : 8;  // ceil(H / FTL): H = 144 on 16 lanes, H <= 256 on 32
+        double hv[2 * MAXIT], pv[2 * MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = 2 * (t + it * FTL) + e - w;
+                const int cc = min(max(c, 0), F - 1);
+                hv[2 * it + e] = src[oh + cc];
+                if (MODE == 1) pv[2 * it + e] = P[o + cc];
             }
-            return v;
-        };
-        for (int n = t; n < H; n += FTL) buf[n] = make_double2(value(2 * n), value(2 * n + 1));
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int n = t + it * FTL;
+            double ve[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = 2 * n + e - w;
+                double v = hv[2 * it + e];
+                if (MODE == 1) {
+                    const double pp = pv[2 * it + e];
+                    if (pp > thresh_sh) v = v / pp;
+                }
+                ve[e] = (c >= 0 && c < F) ? v : 0.0;
+            }
+            if (n < H) buf[n] = make_double2(ve[0], ve[1]);
+        }
     }
     group_sync();
     if (FTL == 16)  // 16 x 9 in registers, fft288.hpp (the host launches this form for H = 144 only)
@@ -1111,12 +1135,28 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
     double2* tw = sh2;
     const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
     double2* buf = sh2 + S + (size_t)g * RP;
-    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
-    {  // the block's tile of Yt, one contiguous run, into the rows' buffers (row stride H + 1: slot kx of row r)
+    {  // the block's tile of Yt, one contiguous run, into the rows' buffers (row stride H + 1: slot kx of row r); the twiddles.
+        // A thread's loads of a batch are all requested before the first is stored (the plain loop waited for each one).
         const int NT = (F + XT_ROWS - 1) / XT_ROWS;
         const double2* tile = Yt + ((int64_t)b * NT + blockIdx.x) * Sh * XT_ROWS;
         double2* rows = sh2 + S;
-        for (int i = threadIdx.x; i < Sh * XT_ROWS; i += blockDim.x) rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = tile[i];
+        const int total = Sh * XT_ROWS;
+        constexpr int BATCH = 5;
+        for (int i0 = threadIdx.x; i0 < total; i0 += BATCH * blockDim.x) {
+            double2 v[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) v[q] = tile[min(i0 + q * (int)blockDim.x, total - 1)];
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                const int i = i0 + q * (int)blockDim.x;
+                if (i < total) rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = v[q];
+            }
+        }
+        const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+        const double2 a0 = twg[min(i0, S - 1)], a1 = twg[min(i1, S - 1)];
+        if (i0 < S) tw[i0] = a0;
+        if (i1 < S) tw[i1] = a1;
+        for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) tw[i] = twg[i];
     }
     const int w = pairs[b].w;
     // MODE 1 with tables: the pair's summed-area table of the divisor comes into LDS once -- the border pixels of every row
@@ -1178,7 +1218,15 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
         const int xf_lo = ix.lo + (ix.hlo ? 1 : 0), xf_hi = ix.hi - 2 * w - (ix.hhi ? 1 : 0);
         const bool row_full = y >= iy.lo + (iy.hlo ? 1 : 0) && y <= iy.hi - 2 * w - (iy.hhi ? 1 : 0);
         const double* drow = sat_l + g * (2 * w + 3);
-        for (int x = t; x < F; x += FTL) {
+        // (MODE 1: the row of the grid that is updated is requested in one go -- up to MAXX loads in flight per lane -- instead
+        // of one load, waited for, per pixel)
+        constexpr int MAXX = 16;
+        double dv[MAXX];
+        if (MODE == 1) {
+#pragma unroll
+            for (int it = 0; it < MAXX; ++it) dv[it] = dst[o + min(t + it * FTL, F - 1)];
+        }
+        auto pixel = [&](int x, double old) {
             const int pos = x + w;
             const double2 z = buf[pos >> 1];
             double v = (pos & 1) ? z.y : z.x;
@@ -1196,11 +1244,17 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
                 } else {
                     div = a00[o + x];
                 }
-                v = (dst[o + x] * v) / div;
+                v = (old * v) / div;
             }
             dst[o + x] = v;
             m = fmax(m, v);
+        };
+#pragma unroll
+        for (int it = 0; it < MAXX; ++it) {
+            const int x = t + it * FTL;
+            if (x < F) pixel(x, MODE == 1 ? dv[it] : 0.0);
         }
+        for (int x = t + MAXX * FTL; x < F; x += FTL) pixel(x, MODE == 1 ? dst[o + x] : 0.0);
     }
     if (mx) {
         m = block_max(m, red);
