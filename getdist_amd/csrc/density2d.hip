@@ -410,8 +410,25 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
         double tot[6] = {0, 0, 0, 0, 0, 0};
         for (int q = 0; q < nq; ++q) tot[q] = T[q * tab_stride + mid];
         double m = -INFINITY;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FF; i += gridDim.x * blockDim.x) {
-            const double P = A.P[o + i];
+        // a thread's pixels, PIX at a time with their P, xP, yP requested together (the plain loop waited for P, then for xP
+        // and yP, pixel by pixel: twelve memory latencies in sequence at F = 256)
+        constexpr int PIX = 4;
+        const int stride = gridDim.x * blockDim.x;
+        for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < FF; i0 += PIX * stride) {
+            double Pv[PIX], xPv[PIX], yPv[PIX];
+#pragma unroll
+            for (int q = 0; q < PIX; ++q) {
+                const int ii = min(i0 + q * stride, FF - 1);
+                Pv[q] = A.P[o + ii];
+                xPv[q] = bco == 1 ? A.xP[o + ii] : 0.0;
+                yPv[q] = bco == 1 ? A.yP[o + ii] : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PIX; ++q) {
+            const int i = i0 + q * stride;
+            if (i >= FF) break;
+            const double P = Pv[q];
             const int y = i / F, x = i - y * F;
             const int e = mask_class(y, yf_lo, yf_hi, w) * NC + mask_class(x, xf_lo, xf_hi, w);
             const bool full = e == mid;
@@ -430,7 +447,7 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
             if (!full)
                 a10 = T[tab_stride + e], a01 = T[2 * tab_stride + e], a20 = T[3 * tab_stride + e], a02 = T[4 * tab_stride + e],
                 a11 = T[5 * tab_stride + e];
-            const double xP = A.xP[o + i], yP = A.yP[o + i];
+            const double xP = xPv[q], yP = yPv[q];
             const double denom = a20 * (a01 * a01) + (a10 * a10) * a02 - a00 * a02 * a20 + (a11 * a11) * a00 - 2 * a01 * a10 * a11;
             const double Aq = a11 * a11 - a02 * a20;
             const double Ax = a10 * a02 - a01 * a11;
@@ -439,6 +456,7 @@ __global__ void __launch_bounds__(256) k_boundary(const D2Pair* __restrict__ pai
             const double out = normed * exp(fmin(corrected / normed, 4.0) - 1.0);
             A.P[o + i] = out;
             m = fmax(m, out);
+            }
         }
         if (mx_out) {
             m = block_max(m, red);
@@ -839,6 +857,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
                 hv[2 * it + e] = src[oh + cc];
                 if (MODE == 1) pv[2 * it + e] = P[o + cc];
             }
+        __builtin_amdgcn_sched_barrier(0);  // (keep the loads together: the scheduler would sink each to its use)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int n = t + it * FTL;
@@ -1146,10 +1165,12 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
             double2 v[BATCH];
 #pragma unroll
             for (int q = 0; q < BATCH; ++q) v[q] = tile[min(i0 + q * (int)blockDim.x, total - 1)];
+            __builtin_amdgcn_sched_barrier(0);  // (or the scheduler sinks every load to its store again)
 #pragma unroll
-            for (int q = 0; q < BATCH; ++q) {
-                const int i = i0 + q * (int)blockDim.x;
-                if (i < total) rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = v[q];
+            for (int q = 0; q < BATCH; ++q) {  // (unconditional: past the end the last element is stored again, by design --
+                // a predicated store gets its load sunk into its own basic block and waited for there)
+                const int i = min(i0 + q * (int)blockDim.x, total - 1);
+                rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = v[q];
             }
         }
         const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
@@ -1225,6 +1246,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
         if (MODE == 1) {
 #pragma unroll
             for (int it = 0; it < MAXX; ++it) dv[it] = dst[o + min(t + it * FTL, F - 1)];
+            __builtin_amdgcn_sched_barrier(0);
         }
         auto pixel = [&](int x, double old) {
             const int pos = x + w;
