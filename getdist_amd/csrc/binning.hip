@@ -781,13 +781,15 @@ __global__ void __launch_bounds__(256) k_minmax_affine_grouped(const MinmaxGroup
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     const int64_t Ne = N & ~(int64_t)1;
     for (int64_t i = 2 * gtid; i < Ne; i += 2 * gsz) {
+        // all MMG_COLS loads unconditionally (slots past ncols re-read the last column: an L1 hit) and all of them requested
+        // before the first is stored: predicated on the group's column count, every load sat in its own basic block with its
+        // LDS store and was waited for there -- eight memory latencies in sequence per iteration (ISA reading, round 5)
         double2 v[MMG_COLS];
 #pragma unroll
-        for (int c = 0; c < MMG_COLS; ++c)
-            v[c] = (c < ncols) ? gload_d2(G.col[c] + i) : make_double2(0.0, 0.0);
+        for (int c = 0; c < MMG_COLS; ++c) v[c] = gload_d2(G.col[min(c, ncols - 1)] + i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < MMG_COLS; ++c)
-            if (c < ncols) slot[c][threadIdx.x] = v[c];
+        for (int c = 0; c < MMG_COLS; ++c) slot[c][threadIdx.x] = v[c];
 #pragma unroll
         for (int p = 0; p < MMG_PAIRS; ++p)
             if (p < npairs) {

@@ -142,12 +142,27 @@ __global__ void __launch_bounds__(512) k_dct_pass(const double* __restrict__ src
     const int g = threadIdx.x / FT, t = threadIdx.x % FT;
     double2* buf = dsh + 2 * F + (size_t)g * F;  // H complex
     double* stage = (double*)(buf + H);           // F doubles
-    for (int i = threadIdx.x; i < F; i += blockDim.x) tw[i] = twg[i], ck[i] = cg[i];
     const int row = blockIdx.x * RPB + g;
     const bool active = row < F;
-    if (active) {
-        const double* x = src + (int64_t)b * F * F + (int64_t)row * F;
-        for (int i = t; i < F; i += FT) stage[i] = x[i];
+    {
+        // a lane's loads -- eight elements of its row, its share of the two tables -- are all requested before the first is
+        // stored (clamped addresses, unconditional stores: the plain loops waited for every load before the next was issued,
+        // eight memory latencies in sequence per block; ISA reading, round 5)
+        const double* x = src + (int64_t)b * F * F + (int64_t)min(row, F - 1) * F;
+        for (int i0 = t; i0 < F; i0 += 8 * FT) {
+            double xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = x[min(i0 + q * FT, F - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stage[min(i0 + q * FT, F - 1)] = xv[q];
+        }
+        for (int i0 = threadIdx.x; i0 < F; i0 += 2 * blockDim.x) {
+            const int i1 = min(i0 + (int)blockDim.x, F - 1);
+            const double2 a0 = twg[i0], a1 = twg[i1], c0 = cg[i0], c1 = cg[i1];
+            __builtin_amdgcn_sched_barrier(0);
+            tw[i0] = a0, tw[i1] = a1, ck[i0] = c0, ck[i1] = c1;
+        }
     }
     __syncthreads();
     if (active) {
