@@ -678,15 +678,39 @@ __global__ void __launch_bounds__(1024) k_hist2d_u16_chunks(const Hist2DPair* __
         }
     };
     const int64_t hi8 = lo < hi ? lo + ((hi - lo) & ~(int64_t)7) : lo;
-    for (int64_t i = lo + 8 * (int64_t)threadIdx.x; i < hi8; i += 8 * 1024) {
-        const uint4 ax = gload_u4(P.ix + i), ay = gload_u4(P.iy + i);
+    auto visit8 = [&](const uint4& ax, const uint4& ay) {
         const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w}, ys[4] = {ay.x, ay.y, ay.z, ay.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             visit(xs[q] & 0xFFFFu, ys[q] & 0xFFFFu);
             visit(xs[q] >> 16, ys[q] >> 16);
         }
+    };
+    // a register ring of DEPTH iterations of loads, as in k_hist2d_u8_pf (round 5: with one pair of loads per lane in flight
+    // and ONE block per CU, the kernel paid a memory latency per eight samples)
+    constexpr int DEPTH = 3;
+    const int64_t nvec = (hi8 - lo) >> 3;  // 16-byte vectors (eight u16 samples) of this chunk
+    const int64_t K = (nvec >> 10) / DEPTH * DEPTH;
+    const uint4* gx = reinterpret_cast<const uint4*>(P.ix + lo);
+    const uint4* gy = reinterpret_cast<const uint4*>(P.iy + lo);
+    if (K > 0) {
+        uint4 rx[DEPTH], ry[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            rx[d] = gload_u4(gx + d * 1024 + threadIdx.x), ry[d] = gload_u4(gy + d * 1024 + threadIdx.x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int64_t k = 0; k < K; k += DEPTH) {
+            const int64_t kn = (k + DEPTH < K ? k + DEPTH : K - DEPTH) * 1024 + threadIdx.x;  // (past the end: a harmless re-read)
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                visit8(rx[d], ry[d]);
+                rx[d] = gload_u4(gx + kn + d * 1024), ry[d] = gload_u4(gy + kn + d * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
+    for (int64_t u = K * 1024 + threadIdx.x; u < nvec; u += 1024) visit8(gload_u4(gx + u), gload_u4(gy + u));
     if (threadIdx.x == 0)
         for (int64_t i = hi8; i < hi; ++i) visit(P.ix[i], P.iy[i]);
     __syncthreads();
