@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <future>
 #include <map>
@@ -1187,14 +1188,48 @@ struct Call {
             std::condition_variable cv;
             int n_staged = 0;
             bool abort_ = false;
+            // Hand-over of finished parts (round 5): the finisher only runs stage B; a third thread enqueues a part's
+            // convolution.  When the finisher did both, the get_h launch of part k + 1 waited for the ~2 ms of host work
+            // that enqueueing part k's ~120 convolution launches takes (trace: stage A of part 2 done at 18.9 ms, its get_h
+            // started at 22.9), and the convolutions of the later parts were launch-bound behind it.
+            std::deque<int> handed;  // parts whose bandwidths are final, in order; -1: no more
+            std::future<int> enqueuer = std::async(std::launch::async, [&]() -> int {
+                ops.bind_thread(h);
+                int e = 0;
+                for (;;) {
+                    int q;
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return !handed.empty(); });
+                        q = handed.front();
+                        handed.pop_front();
+                    }
+                    if (q < 0) return e;
+                    if (e) continue;
+                    {  // a part's convolution may use the main context: the staging thread must be done with it
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return n_staged >= nl || abort_; });
+                        if (n_staged < nl) {
+                            e = GD_ERR_HIP;  // (the staging thread gave up: its error is the call's)
+                            continue;
+                        }
+                    }
+                    e = report(launches[q].ks, q);
+                }
+            });
             std::future<int> finisher = std::async(std::launch::async, [&]() -> int {
                 ops.bind_thread(aux);
                 int e = 0;
+                auto hand = [&](int q) {
+                    std::lock_guard<std::mutex> g(mu);
+                    handed.push_back(q);
+                    cv.notify_all();
+                };
                 for (int q = 0; q < nl; ++q) {
                     {
                         std::unique_lock<std::mutex> g(mu);
                         cv.wait(g, [&] { return n_staged > q || abort_; });
-                        if (n_staged <= q) return e;  // (the staging thread gave up)
+                        if (n_staged <= q) break;  // (the staging thread gave up)
                     }
                     Launch& L = launches[q];
                     const int B = (int)L.ks.size();
@@ -1210,14 +1245,9 @@ struct Call {
                     if (L.own) pool.give(L.d_batch);
                     pool.give(L.d_rows);
                     if (!e) e = absorb_rows(L, out);
-                    if (!e) {
-                        {  // a part's convolution may use the main context: the staging thread must be done with it
-                            std::unique_lock<std::mutex> g(mu);
-                            cv.wait(g, [&] { return n_staged >= nl || abort_; });
-                        }
-                        e = report(L.ks, q);
-                    }
+                    if (!e) hand(q);
                 }
+                hand(-1);
                 return e;
             });
             for (int q = 0; q < nl && !rc; ++q) {
@@ -1250,7 +1280,9 @@ struct Call {
             }
             mark("kopt: every stage A enqueued");
             const int e = finisher.get();
+            const int e2 = enqueuer.get();
             if (!rc) rc = e;
+            if (!rc) rc = e2;
         }
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
         return rc;
