@@ -410,7 +410,9 @@ __global__ void k_weights_integral(const double* __restrict__ w, int64_t N, int*
     }
     if (b) atomicOr(bad, b);
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(sum, s);
+    // one slot per wave, added by the host in slot order: the total is the same in every run (the quantile buckets'
+    // fixed-point scale is derived from it)
+    if ((threadIdx.x & 63) == 0) sum[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = s;
 }
 
 __global__ void k_weights_to_u8(const double* __restrict__ w, int64_t N, unsigned char* __restrict__ w8) {
@@ -443,7 +445,7 @@ int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* 
 // are filled in by gd_comm_share_columns
 static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int64_t row_stride, int64_t col_stride,
                         const double* weights, int64_t ld, double** cols_out, double** w_out, unsigned char** w8_out,
-                        bool* integral_out, int64_t shard_first = -1, int64_t shard_count = 0) {
+                        bool* integral_out, double* wsum_out, int64_t shard_first = -1, int64_t shard_count = 0) {
     double*& cols = *cols_out;
     double*& w = *w_out;
     unsigned char*& w8 = *w8_out;
@@ -477,19 +479,24 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
         }
     }
     *integral_out = false;
+    *wsum_out = 0;
     if (weights) {
         GD_HIP(hipMalloc((void**)&w, (size_t)(ld * 8)));
         GD_HIP(hipMemcpyAsync(w, weights, (size_t)(N * 8), hipMemcpyHostToDevice, ctx->stream));
-        char* chk = (char*)gd_scratch(ctx, 256);
+        constexpr int WSLOTS = 1024 * 4;
+        char* chk = (char*)gd_scratch(ctx, 128 + WSLOTS * 8);
         if (!chk) return GD_ERR_NOMEM;
-        GD_HIP(hipMemsetAsync(chk, 0, 256, ctx->stream));
+        GD_HIP(hipMemsetAsync(chk, 0, 128, ctx->stream));
         k_weights_integral<<<1024, 256, 0, ctx->stream>>>(w, N, (int*)chk, (double*)(chk + 128));
         GD_KERNEL_CHECK();
         int bad = 1;
         double sum = 0;
+        std::vector<double> slots(WSLOTS);
         GD_TRY(gd_fetch(ctx, &bad, chk, 4));
-        GD_TRY(gd_fetch(ctx, &sum, chk + 128, 8));
+        GD_TRY(gd_fetch(ctx, slots.data(), chk + 128, (size_t)WSLOTS * 8));
         GD_TRY(gd_stream_sync(ctx));
+        for (double v : slots) sum += v;
+        *wsum_out = sum;
         *integral_out = ((bad & 1) == 0) && sum < 4.0e9;
         if (*integral_out && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
             GD_HIP(hipMalloc((void**)&w8, (size_t)ld));
@@ -537,12 +544,15 @@ static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int
     ctx->cols = ctx->w = ctx->like_w = ctx->w_main = nullptr;
     ctx->w_sel = 0;
     ctx->w_integral = false;
+    ctx->w_sum = ctx->w_main_sum = 0;
     ctx->N = ctx->n = ctx->ld = 0;
     const int64_t ld = (N + 511) / 512 * 512;
     double *cols = nullptr, *w = nullptr;
     unsigned char* w8 = nullptr;
     bool integral = false;
-    const int rc = upload_build(ctx, X, N, n, row_stride, col_stride, weights, ld, &cols, &w, &w8, &integral, shard_first, shard_count);
+    double wsum = 0;
+    const int rc = upload_build(ctx, X, N, n, row_stride, col_stride, weights, ld, &cols, &w, &w8, &integral, &wsum, shard_first,
+                                shard_count);
     if (rc != GD_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         if (cols) (void)hipFree(cols);
@@ -554,6 +564,7 @@ static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int
     ctx->w = w;
     ctx->w8 = w8;
     ctx->w_integral = integral;
+    ctx->w_sum = wsum;
     ctx->N = N;
     ctx->n = n;
     ctx->ld = ld;
@@ -639,10 +650,13 @@ int gd_select_weights(gd_ctx* ctx, int32_t which) {
         ctx->w8_main = ctx->w8;
         ctx->w = ctx->like_w;
         ctx->w_integral = false;
+        ctx->w_main_sum = ctx->w_sum;
+        ctx->w_sum = 0;
         ctx->w8 = nullptr;
     } else {
         ctx->w = ctx->w_main;
         ctx->w_integral = ctx->w_main_integral;
+        ctx->w_sum = ctx->w_main_sum;
         ctx->w8 = ctx->w8_main;
         ctx->w_main = nullptr;
         ctx->w8_main = nullptr;
@@ -703,6 +717,7 @@ int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner) {
     ctx->w = owner->w;
     ctx->w8 = owner->w8;
     ctx->w_integral = owner->w_integral;
+    ctx->w_sum = owner->w_sum;
     ctx->N = owner->N;
     ctx->n = owner->n;
     ctx->ld = owner->ld;

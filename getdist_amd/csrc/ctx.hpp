@@ -36,6 +36,8 @@ struct gd_ctx {
     double* like_w = nullptr;
     double* w_main = nullptr;
     bool w_main_integral = false;
+    // total of the weights `w` points at, added in a fixed order at upload; 0 = not known (auxiliary weights)
+    double w_sum = 0, w_main_sum = 0;
     int w_sel = 0;
     bool borrowed = false;  // cols / w belong to another context of this process (gd_attach_samples)
     long long* wcum = nullptr;  // inclusive cumulative integer sample weights (thin.hip), built on first use

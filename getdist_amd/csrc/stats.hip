@@ -850,24 +850,28 @@ __device__ __forceinline__ int qlin_bucket(double v, double mn, double scale, in
 template <bool HAS_W>
 __global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
                                                      const double* __restrict__ w, int64_t lo, int64_t hi,
-                                                     const QLin* __restrict__ ql, void* __restrict__ part) {
+                                                     const QLin* __restrict__ ql, void* __restrict__ part, double wscale) {
     extern __shared__ double qsh[];
     const int c = blockIdx.y;
     const double* x = cols + (int64_t)colidx[c] * ld;
     const double mn = ql[c].mn, scale = ql[c].scale;
     constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
     unsigned int* hu = reinterpret_cast<unsigned int*>(qsh);
+    unsigned long long* hq = reinterpret_cast<unsigned long long*>(qsh);
     for (int i = threadIdx.x; i < nb; i += 1024) {
         if (HAS_W)
-            qsh[i] = 0.0;
+            hq[i] = 0ull;
         else
             hu[i] = 0u;
     }
     __syncthreads();
+    // weights are added as 64-bit integers, round(w * 2^k) with 2^k * (sum of all weights) < 2^62: integer sums are the
+    // same in any order, so the bucket totals -- and the sample every target selects -- repeat from run to run, which
+    // fp64 LDS atomics did not give for real weights (and ds_add_u64 issues at twice the rate of ds_add_f64)
     auto add = [&](double v, double wt) {
         const int b = qlin_bucket(v, mn, scale, nb);
         if (HAS_W)
-            atomicAdd(&qsh[b], wt);
+            atomicAdd(&hq[b], __double2ull_rn(wt * wscale));
         else
             atomicAdd(&hu[b], 1u);
     };
@@ -907,8 +911,8 @@ __global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ 
     }
     __syncthreads();
     if (HAS_W) {
-        double* p = (double*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
-        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = qsh[i];
+        unsigned long long* p = (unsigned long long*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
+        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = hq[i];
     } else {
         unsigned int* p = (unsigned int*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
         for (int i = threadIdx.x; i < nb; i += 1024) p[i] = hu[i];
@@ -917,13 +921,16 @@ __global__ void __launch_bounds__(1024) k_qlin_count(const double* __restrict__ 
 
 // bucket totals: the blocks' partial tables added in block order; grid (nb / 256, ncols)
 template <bool HAS_W>
-__global__ void __launch_bounds__(256) k_qlin_reduce(const void* __restrict__ part, int nblk, double* __restrict__ tot) {
+__global__ void __launch_bounds__(256) k_qlin_reduce(const void* __restrict__ part, int nblk, double* __restrict__ tot,
+                                                      double inv_wscale) {
     constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
     const int c = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
     double v = 0;
     if (HAS_W) {
-        const double* p = (const double*)part + (int64_t)c * nblk * nb + b;
-        for (int k = 0; k < nblk; ++k) v += p[(int64_t)k * nb];
+        const unsigned long long* p = (const unsigned long long*)part + (int64_t)c * nblk * nb + b;
+        unsigned long long u = 0;
+        for (int k = 0; k < nblk; ++k) u += p[(int64_t)k * nb];
+        v = (double)u * inv_wscale;  // a power of two: the only rounding is the conversion of the exact integer total
     } else {
         const unsigned int* p = (const unsigned int*)part + (int64_t)c * nblk * nb + b;
         unsigned long long u = 0;
@@ -1606,11 +1613,13 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     GD_HIP(hipMemsetAsync(d_cnt, 0, (size_t)ncols * QK_MAX * 4 + 256, ctx->stream));
     const size_t lds = (size_t)nb * (hw ? 8 : 4);
+    // 2^k with 2^k * (sum of all weights) < 2^62 (gd_quantiles_mm checked that the sum is known and positive)
+    const double wscale = hw ? ldexp(1.0, 61 - ilogb(ctx->w_sum)) : 1.0;
     if (hw) {
         GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_qlin_count<true><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part);
+        k_qlin_count<true><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part, wscale);
         GD_KERNEL_CHECK();
-        k_qlin_reduce<true><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot);
+        k_qlin_reduce<true><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot, 1.0 / wscale);
         GD_KERNEL_CHECK();
         k_qlin_scan<true><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
         GD_KERNEL_CHECK();
@@ -1618,9 +1627,9 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
                                                                           d_lw, d_cnt);
     } else {
         GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_qlin_count<false><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_ql, d_part);
+        k_qlin_count<false><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_ql, d_part, 1.0);
         GD_KERNEL_CHECK();
-        k_qlin_reduce<false><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot);
+        k_qlin_reduce<false><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot, 1.0);
         GD_KERNEL_CHECK();
         k_qlin_scan<false><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
         GD_KERNEL_CHECK();
@@ -1647,10 +1656,9 @@ int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo,
     // the expected length of a live bucket's list is rows / buckets times the peak-to-mean density ratio (about 4 for a
     // Gaussian over its sampled range); beyond these row counts the lists would overflow QCAP
     if (linear && (hi - lo) > (ctx->w ? 12000000 : 25000000)) linear = false;
-    // real weights: the bucket sums of the counting pass are fp64 LDS atomics, whose order -- hence rounding -- differs from
-    // run to run, and a target within rounding of a bucket boundary could pick another sample; unit weights and integer
-    // multiplicities add exactly, in any order.  The radix path is deterministic for every kind of weight.
-    if (linear && ctx->w && !ctx->w_integral) linear = false;
+    // weighted bucket sums are fixed-point integers scaled from the weights' total, which is known for the uploaded sample
+    // weights (any kind: multiplicities or real); auxiliary weights (gd_select_weights) take the radix path
+    if (linear && ctx->w && !(ctx->w_sum > 0 && std::isfinite(ctx->w_sum))) linear = false;
     for (int c = 0; linear && c < ncols; ++c) {
         const double a = minmax[2 * c], b = minmax[2 * c + 1];
         if (!(b > a) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite((double)QLIN_NB_U / (b - a))) linear = false;

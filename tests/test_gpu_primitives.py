@@ -318,7 +318,7 @@ def test_quantiles_with_ties_take_the_radix_fallback(weights):
         c.close()
 
 
-@pytest.mark.parametrize("weights", ["unit", "integer", "real"])
+@pytest.mark.parametrize("weights", ["unit", "integer", "real", "wide"])
 def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
     """gd_quantiles_mm (one linear-bucket counting pass + collect, given the columns' min / max) against the radix path
     and against argsort semantics: continuous, bounded, heavily tied (list overflow -> radix fallback inside the call),
@@ -332,6 +332,8 @@ def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
     s = np.column_stack([cont, np.abs(cont), rng.uniform(-3, 9, N), np.round(cont, 1), np.full(N, 3.25),
                          np.where(rng.random(N) < 0.5, cont * 1e-9, cont * 1e6)])
     w = None if weights == "unit" else (rng.integers(1, 5, N).astype(float) if weights == "integer" else rng.exponential(1.0, N))
+    if weights == "wide":  # importance weights over nine decades: the fixed-point bucket sums keep 2^-62 of the total
+        w = w * 10.0 ** rng.uniform(-6, 3, N)
     wv = np.ones(N) if w is None else w
     c = Context(0)
     try:
@@ -343,6 +345,8 @@ def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
             norm = wv[lo:hi].sum()
             targets = np.tile(norm * fracs, (len(cols), 1))
             lin = c.quantiles(cols, targets, lo=lo, hi=hi, minmax=mm)
+            # integer bucket sums: the same picks in every run, for every kind of weight
+            assert np.array_equal(lin, c.quantiles(cols, targets, lo=lo, hi=hi, minmax=mm))
             monkeypatch.setenv("GDHIP_QSEL_RADIX", "1")
             rad = c.quantiles(cols, targets, lo=lo, hi=hi, minmax=mm)
             monkeypatch.delenv("GDHIP_QSEL_RADIX")
@@ -354,7 +358,7 @@ def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
                 xs = x[idx]
                 cum = np.cumsum(wv[lo:hi][idx])
                 want = xs[np.minimum(np.searchsorted(cum, norm * fracs), len(idx) - 1)]
-                if weights == "real":  # the weight below a bucket is summed in another order: a knife-edge target may
+                if weights in ("real", "wide"):  # the weight below a bucket is summed in another order: a knife-edge target may
                     for got in (lin[ci], rad[ci]):  # pick the neighbouring sample; both paths within one row of numpy
                         assert np.all(np.abs(np.searchsorted(xs, got) - np.searchsorted(xs, want)) <= 1), (col, lo)
                         assert np.mean(got == want) >= 0.75, (col, lo, got, want)
