@@ -76,6 +76,7 @@ SIGNATURES = {
     "gd_autocov_lags": (C.c_int, [_p, _i32, _f64, _i64, _i32, _pd]),
     "gd_kde_lag_sums": (C.c_int, [_p, _i32, _f64, _pi64, _i32, _pd]),
     "gd_hist1d": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, _pd]),
+    "gd_hist1d_dev": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, _p]),
     "gd_bin_indices": (C.c_int, [_p, _i32, _f64, _f64, _i32, _i32, _pi32, _pi64]),
     "gd_prebin": (C.c_int, [_p, _i32, _f64, _f64, _i32, _p]),
     "gd_prebin_batch": (C.c_int, [_p, _pi32, _i32, _pd, _pd, _i32, C.POINTER(_p)]),
@@ -88,7 +89,10 @@ SIGNATURES = {
     "gd_hist2d_sheared": (C.c_int, [_p, _i32, _pi32, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _i32, _p]),
     "gd_dct1d": (C.c_int, [_p, _i32, _i32, _pd, _pd]),
     "gd_isj1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pd, _pi32]),
+    "gd_isj1d_dev": (C.c_int, [_p, _i32, _i32, _p, _pd, _pd, _pi32]),
     "gd_density1d": (C.c_int, [_p, _i32, _i32, _pd, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
+    "gd_density1d_dev": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32]),
+    "gd_density1d_batch": (C.c_int, [_p, _p, _p, _i32, _pi32, _i32, _pd, _pd, _pd]),
     "gd_kopt2d": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _pd]),
     "gd_kopt2d_enqueue": (C.c_int, [_p, _i32, _i32, _p, _pd, _pi32, _pd, _pd, _p, _pi32]),
     "gd_kopt2d_finish": (C.c_int, [_p, _p, _i32, _i32, _p, _pd]),
@@ -830,6 +834,17 @@ class Context:
     def comm_destroy(self):
         self._check(self.lib.gd_comm_destroy(self.h))
         self.comm_world = 0
+
+    def density1d_batch(self, settings, params, n, cols32, want_hist=False):
+        """gd_density1d_batch: (P[B, F], hist[B, F] or None, meta[B, 8]) of the listed columns."""
+        cols32 = _i32arr(cols32)
+        B, F = len(cols32), int(settings.fine_bins)
+        P = np.zeros((B, F))
+        hist = np.zeros((B, F)) if want_hist else None
+        meta = np.zeros((B, 8))
+        self._check(self.lib.gd_density1d_batch(self.h, C.byref(settings), C.cast(params, _p), int(n), _ip(cols32), B, _dp(P),
+                                                None if hist is None else _dp(hist), _dp(meta)))
+        return P, hist, meta
 
     def batch2d_finish(self):
         self._check(self.lib.gd_batch2d_finish(self.h))

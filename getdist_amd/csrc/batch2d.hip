@@ -1,6 +1,7 @@
 // gd_density2d_batch: the native entry for a batch of parameter pairs.  The plan and the choreography live in
 // batch2d.hpp (host C++, shared with the CPU test harness); this file binds its table of device entry points to the
 // library's own C ABI and keeps the per-context state (block pool, cached index columns, the last call in flight).
+#include "batch1d.hpp"
 #include "batch2d.hpp"
 #include "ctx.hpp"
 
@@ -116,6 +117,27 @@ const gdb::Ops kOps = {
     /* comm_allreduce_sum */ [](void* h, double* inout, int64_t count) { return gd_comm_allreduce_sum(C(h), inout, count); },
 };
 
+const gdb::Ops1D kOps1D = {
+    /* hist1d_dev */
+    [](void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F, void* d_hist) {
+        return gd_hist1d_dev(C(h), cols, ncols, binmin, width, F, d_hist);
+    },
+    /* isj1d_dev */
+    [](void* h, int32_t B, int32_t F, const void* d_hist, const double* neff, double* hfrac, int32_t* status) {
+        return gd_isj1d_dev(C(h), B, F, d_hist, neff, hfrac, status);
+    },
+    /* density1d_dev */
+    [](void* h, int32_t B, int32_t F, const void* d_hist, const double* smooth, const int32_t* winw, const int32_t* flags,
+       int32_t bco, int32_t mbc, double* P_out, int32_t* status) {
+        return gd_density1d_dev(C(h), B, F, d_hist, smooth, winw, flags, bco, mbc, P_out, status);
+    },
+    /* fetch */
+    [](void* h, void* dst, const void* d_src, int64_t bytes) {
+        const int rc = gd_fetch(C(h), dst, d_src, (size_t)bytes);
+        return rc ? rc : gd_stream_sync(C(h));
+    },
+};
+
 void release_state(gd_ctx* ctx, bool destroy) {
     gdb::State* st = (gdb::State*)ctx->batch_state;
     if (!st) return;
@@ -168,6 +190,23 @@ int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* set
         if (rc) ctx->err = call.err;
     } catch (const std::exception& e) {
         rc = gd_fail(ctx, GD_ERR_NOMEM, "gd_density2d_batch: %s", e.what());
+    }
+    return rc;
+}
+
+int gd_density1d_batch(gd_ctx* ctx, const gd_density1d_settings* settings, gd_param2d* params, int32_t n, const int32_t* cols,
+                       int32_t B, double* P_out, double* hist_out, double* meta) {
+    GD_REQUIRE(ctx && settings && params && cols && P_out && meta && n > 0 && B > 0, "bad argument");
+    GD_REQUIRE(ctx->cols, "no samples uploaded");
+    GD_REQUIRE(ctx->w_sel == 0, "auxiliary weights are selected");
+    GD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    try {
+        std::string err;
+        rc = gdb::density1d_batch(state_of(ctx), kOps, kOps1D, ctx, *settings, params, n, cols, B, P_out, hist_out, meta, &err);
+        if (rc) ctx->err = err;
+    } catch (const std::exception& e) {
+        rc = gd_fail(ctx, GD_ERR_NOMEM, "gd_density1d_batch: %s", e.what());
     }
     return rc;
 }

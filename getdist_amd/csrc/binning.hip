@@ -971,8 +971,9 @@ static int launch_hist2d(gd_ctx* ctx, int B, const std::vector<Hist2DPair>& hp, 
 
 extern "C" {
 
-int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
-              double* out) {
+// out: host ncols x F, or -- with `out_on_device` -- device memory the histograms are left in (no copy, no sync)
+static int hist1d_core(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                       double* out, bool out_on_device) {
     GD_REQUIRE(ctx && cols && binmin && width && out && ncols > 0, "bad argument");
     GD_REQUIRE(F >= 2 && F <= 4096, "fine_bins out of range (2..4096)");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
@@ -989,7 +990,7 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     double* d_part = (double*)(base + o_part);
-    double* d_out = (double*)(base + o_out);
+    double* d_out = out_on_device ? out : (double*)(base + o_out);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_b = (double*)(base + o_b);
     double* d_w = (double*)(base + o_w);
@@ -1008,9 +1009,19 @@ int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* bin
     GD_KERNEL_CHECK();
     k_hist1d_reduce<<<dim3((F + 255) / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, F, d_out);
     GD_KERNEL_CHECK();
+    if (out_on_device) return GD_OK;
     GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * F * 8));
     GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
+}
+
+int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+              double* out) {
+    return hist1d_core(ctx, cols, ncols, binmin, width, F, out, false);
+}
+int gd_hist1d_dev(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                  void* d_out) {
+    return hist1d_core(ctx, cols, ncols, binmin, width, F, (double*)d_out, true);
 }
 
 int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,

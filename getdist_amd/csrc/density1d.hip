@@ -430,14 +430,15 @@ int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_ou
     return GD_OK;
 }
 
-int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* neff, double* hfrac_out,
-             int32_t* status_out) {
+// hist on the host (copied in) or, with `hist_on_device`, B x F doubles in device memory (read in place)
+static int isj1d_core(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, bool hist_on_device, const double* neff,
+                      double* hfrac_out, int32_t* status_out) {
     GD_REQUIRE(ctx && hist && neff && hfrac_out && status_out && B > 0, "bad argument");
     GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins out of range (8..4096)");
     const int64_t nb = ((int64_t)B * F * 8 + 255) / 256 * 256, ns = ((int64_t)B * 16 + 255) / 256 * 256;
     char* base = (char*)gd_scratch(ctx, 2 * nb + 3 * ns + (int64_t)4 * F * 8 + 512);
     if (!base) return GD_ERR_NOMEM;
-    double* d_in = (double*)base;
+    const double* d_in = hist_on_device ? hist : (const double*)base;
     double* d_a = (double*)(base + nb);
     double* d_neff = (double*)(base + 2 * nb);
     double* d_nscale = (double*)(base + 2 * nb + ns);
@@ -459,7 +460,7 @@ int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double
         GD_REQUIRE(neff[b] > 0, "effective sample number must be positive");
         nscale[b] = pow(neff[b], -1.0 / 5);
     }
-    GD_TRY(gd_h2d(ctx, d_in, hist, (size_t)B * F * 8));
+    if (!hist_on_device) GD_TRY(gd_h2d(ctx, (double*)base, hist, (size_t)B * F * 8));
     GD_TRY(gd_h2d(ctx, d_neff, neff, (size_t)B * 8));
     GD_TRY(gd_h2d(ctx, d_nscale, nscale.data(), (size_t)B * 8));
     k_cos_table<<<(4 * F + 255) / 256, 256, 0, ctx->stream>>>(F, d_tab);
@@ -479,8 +480,10 @@ int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double
     return GD_OK;
 }
 
-int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* smooth, const int32_t* winw,
-                 const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out) {
+// hist, P_out on the host, or with `on_device` both in device memory (the density is left there: no copy, no sync)
+static int density1d_core(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, bool hist_on_device, const double* smooth,
+                          const int32_t* winw, const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out) {
+
     GD_REQUIRE(ctx && hist && smooth && winw && flags && P_out && status_out && B > 0, "bad argument");
     GD_REQUIRE(F >= 8 && F <= 4096, "fine_bins out of range (8..4096)");
     GD_REQUIRE(bco >= -1 && bco <= 2, "Unknown boundary_correction_order (expected 0, 1, 2)");
@@ -492,13 +495,13 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
     const int64_t nb = ((int64_t)B * F * 8 + 255) / 256 * 256, ns = ((int64_t)B * 8 + 255) / 256 * 256;
     char* base = (char*)gd_scratch(ctx, 2 * nb + 4 * ns);
     if (!base) return GD_ERR_NOMEM;
-    double* d_hist = (double*)base;
+    const double* d_hist = hist_on_device ? hist : (const double*)base;
     double* d_P = (double*)(base + nb);
     double* d_smooth = (double*)(base + 2 * nb);
     int* d_winw = (int*)(base + 2 * nb + ns);
     int* d_flags = (int*)(base + 2 * nb + 2 * ns);
     int* d_status = (int*)(base + 2 * nb + 3 * ns);
-    GD_TRY(gd_h2d(ctx, d_hist, hist, (size_t)B * F * 8));
+    if (!hist_on_device) GD_TRY(gd_h2d(ctx, (double*)base, hist, (size_t)B * F * 8));
     GD_TRY(gd_h2d(ctx, d_smooth, smooth, (size_t)B * 8));
     GD_TRY(gd_h2d(ctx, d_winw, winw, (size_t)B * 4));
     GD_TRY(gd_h2d(ctx, d_flags, flags, (size_t)B * 4));
@@ -511,6 +514,23 @@ int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const do
     GD_TRY(gd_fetch(ctx, status_out, d_status, (size_t)B * 4));
     GD_TRY(gd_stream_sync(ctx));
     return GD_OK;
+}
+
+int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* neff, double* hfrac_out,
+             int32_t* status_out) {
+    return isj1d_core(ctx, B, F, hist, false, neff, hfrac_out, status_out);
+}
+int gd_isj1d_dev(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, double* hfrac_out,
+                 int32_t* status_out) {
+    return isj1d_core(ctx, B, F, (const double*)d_hist, true, neff, hfrac_out, status_out);
+}
+int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* smooth, const int32_t* winw,
+                 const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out) {
+    return density1d_core(ctx, B, F, hist, false, smooth, winw, flags, bco, mbc, P_out, status_out);
+}
+int gd_density1d_dev(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* smooth, const int32_t* winw,
+                     const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out) {
+    return density1d_core(ctx, B, F, (const double*)d_hist, true, smooth, winw, flags, bco, mbc, P_out, status_out);
 }
 
 int gd_likes1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* likehist, const double* P,

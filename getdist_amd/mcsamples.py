@@ -2101,6 +2101,17 @@ class MCSamples:
             raise SettingError("Unknown boundary_correction_order (expected 0, 1, 2)")
         self._init_params(js)
         pars = [self.paramNames.names[j] for j in js]
+        if (hasattr(self.ctx, "density1d_batch") and os.environ.get("GETDIST_AMD_NATIVE_BATCH", "1") == "1"
+                and getattr(self, "_neff_share", None) is None and len(set(js)) == len(js)):
+            # ONE native call (csrc/batch1d.hpp); the Python-planned sequence below remains for multi-rank N_eff sharing
+            from . import batch1d
+
+            P, hist, meta = batch1d.run(self, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist=meanlikes)
+            edges = [((meta[b, 1] - meta[b, 0]) / (fine_bins - 1), meta[b, 0], meta[b, 1]) for b in range(len(js))]
+            smooth, winw = meta[:, 3].tolist(), meta[:, 4].astype(np.int64).tolist()
+            flags = [(1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0)
+                     for par in pars]
+            return self._finish_1d(js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs)
         edges = []
         for par in pars:
             if par.range_max - par.range_min <= 0:
@@ -2134,6 +2145,10 @@ class MCSamples:
         P, status = self.ctx.density1d(hist, smooth, winw, flags, bco, mbc)
         if np.any(status != 0):
             raise DensitiesError("no samples in bin")
+        return self._finish_1d(js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs)
+
+    def _finish_1d(self, js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs):
+        """Mean-likelihood profiles (mcsamples.py:1556-1561,1672-1682) and the Density1D objects of get1DDensities."""
         likes = None
         if meanlikes:
             shade = bool(self.shade_likes_is_mean_loglikes)

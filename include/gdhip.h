@@ -154,6 +154,10 @@ int gd_autocov_lags_range_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols,
  *   y index = trunc(((r0*x_i + r1*x_j) - ymin)/dy). */
 int gd_hist1d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
               int32_t F, double* out);
+/* the same with the histograms left in device memory (d_out: ncols x F doubles from gd_dev_alloc); returns when the
+ * kernels are enqueued on the context's stream */
+int gd_hist1d_dev(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+                  int32_t F, void* d_out);
 int gd_bin_indices(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t round_half, int32_t F,
                    int32_t* idx_out, int64_t* n_out_of_range);
 int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, void* d_idx_u16);
@@ -197,6 +201,9 @@ int gd_hist2d_sheared(gd_ctx* ctx, int32_t B, const int32_t* coli, const int32_t
  *   reference returns None ("1D auto bandwidth failed": zero functional). */
 int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* neff, double* hfrac_out,
              int32_t* status_out);
+/* the same reading the histograms in device memory (gd_hist1d_dev) */
+int gd_isj1d_dev(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* neff, double* hfrac_out,
+                 int32_t* status_out);
 
 /* ---------------------------------------------------------------- 1D density -------------------
  * gd_dct1d: a = DCT-II(data/sum(data)) (scipy.fftpack.dct type 2, unnormalised), for the Botev ISJ
@@ -210,6 +217,9 @@ int gd_isj1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double
 int gd_dct1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, double* a_out);
 int gd_density1d(gd_ctx* ctx, int32_t B, int32_t F, const double* hist, const double* smooth, const int32_t* winw,
                  const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out);
+/* the same reading the histograms in device memory (gd_hist1d_dev); P_out is on the host */
+int gd_density1d_dev(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist, const double* smooth, const int32_t* winw,
+                     const int32_t* flags, int32_t bco, int32_t mbc, double* P_out, int32_t* status_out);
 
 /* ---------------------------------------------------------------- 2D bandwidth -----------------
  * gd_kopt2d: KernelOptimizer2D.__init__ + the psi functionals get_h needs (kde_bandwidth.py:146-270)
@@ -490,6 +500,41 @@ int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* set
                        const double* corr, const double* cov, const double* lag_probe, const int32_t* pairs, int32_t P,
                        gd_neff_exchange_fn exchange, void* exchange_user, void* grids_pinned, int64_t grids_doubles,
                        int32_t* status_pinned, double* meta, double* levels, int32_t* level_status, int32_t* tokens_out2);
+/* ---------------------------------------------------------------- one native entry for a batch of 1D densities ----
+ * gd_density1d_batch: MCSamples.get1DDensityGridData (mcsamples.py:1500-1686) for B parameters in ONE call, the host
+ * decisions of the reference made inside the library (csrc/batch1d.hpp):
+ *   - the bin edges of _binSamples (mcsamples.py:1486-1496) and the fused index + weighted bincount (:1554),
+ *   - with smooth_scale_1D <= 0: the effective sample numbers of the parameters that have none yet (as gd_density2d_batch
+ *     computes them), the Botev ISJ bandwidth (gd_isj1d) and the scalar tail of getAutoBandwidth1D (:1256-1283: the rule
+ *     of thumb when the solver fails or the width is very small, the higher-order rescaling); otherwise the fixed scales
+ *     of :1572-1582,
+ *   - the smoothing scale in fine-bin units, the window half-width, and everything of gd_density1d (:1588-1668).
+ * The histograms stay in device memory between the three stages.  Blocking: P_out is complete on return.
+ *
+ * params : n records as for gd_density2d_batch, index = column number; only the listed columns are read.  `neff` is in/out
+ *          (NaN = not known; computed here when the bandwidth is automatic; GD_BATCH2D_NEED_NEFF as for the 2D entry).
+ * cols   : B column indices (a parameter may be listed once).  P_out : B x F doubles (host), normalised to max = 1.
+ * hist_out : optional B x F doubles (host): the histograms (the mean-likelihood profiles of gd_likes1d need them).
+ * meta   : B x GD_BATCH1D_META doubles: [0] binmin [1] binmax [2] the bandwidth h in units of the bin range (par.kde_h;
+ *          NaN when the scale is fixed) [3] smooth_1D in fine-bin units [4] window half-width
+ *          [5] bits: 1 = "1D auto bandwidth failed" (solver returned None), 2 = very small or failed: rule-of-thumb
+ *          fallback used, 4 = "fine_bins not large enough to well sample smoothing scale"
+ *          [6] N_eff used (NaN when the scale is fixed) [7] GD_OK or GD_ERR_EMPTY ("no samples in bin") for the density.
+ * Errors: GD_ERR_BADARG for setting errors ("Parameter range is <= 0", an unknown boundary_correction_order); GD_ERR_SOLVER
+ *   when raise_on_bandwidth_errors is set and the fallback would have been used. */
+#define GD_BATCH1D_META 8
+
+typedef struct gd_density1d_settings {
+    int32_t fine_bins, num_bins, boundary_correction_order, mult_bias_correction_order;
+    double smooth_scale_1D;
+    double norm, sum_w2;           /* sum w, sum w^2 of the sample weights (N_eff of parameters that have none yet) */
+    int32_t uncorrelated_sampler;  /* as gd_batch2d_settings */
+    int32_t raise_on_bandwidth_errors;
+} gd_density1d_settings;
+
+int gd_density1d_batch(gd_ctx* ctx, const gd_density1d_settings* settings, gd_param2d* params, int32_t n, const int32_t* cols,
+                       int32_t B, double* P_out, double* hist_out, double* meta);
+
 /* Completes the last batched call(s) of the context (waits for their result copies, hands their device blocks back to
  * the library's pool); gd_batch2d_invalidate additionally marks every cached index column stale (the next call bins
  * again -- what a benchmark does between steps, and what gd_upload does by itself). */

@@ -1,6 +1,7 @@
 // Host-only build (g++) of getdist_amd/csrc/batch2d.hpp for the CPU test-suite: the plan and the choreography of
 // gd_density2d_batch run here exactly as inside libgdhip.so, with the table of device entry points supplied by the
 // caller (tests/native_batch_util.py binds it to the numpy context double).  Test infrastructure only.
+#include "../../getdist_amd/csrc/batch1d.hpp"
 #include "../../getdist_amd/csrc/batch2d.hpp"
 
 extern "C" {
@@ -39,6 +40,30 @@ int gdt_density2d_batch(const gdb::Ops* ops, void* st, void* h, void* twin, cons
         if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "exception: %s", e.what());
     }
     return rc;
+}
+
+int gdt_density1d_batch(const gdb::Ops* ops, const gdb::Ops1D* ops1, void* st, void* h, const gd_density1d_settings* settings,
+                        gd_param2d* params, int32_t n, const int32_t* cols, int32_t B, double* P_out, double* hist_out,
+                        double* meta, char* errbuf, int32_t errlen) {
+    int rc;
+    try {
+        std::string err;
+        rc = gdb::density1d_batch(*(gdb::State*)st, *ops, *ops1, h, *settings, params, n, cols, B, P_out, hist_out, meta, &err);
+        if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "%s", err.c_str());
+    } catch (const std::exception& e) {
+        rc = -99;
+        if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "exception: %s", e.what());
+    }
+    return rc;
+}
+
+// the scalar tail alone: out8 = {kde_h, smooth, neff, winw, flags, bits, ok, 0}
+void gdt_smoothing_1d(const gd_density1d_settings* s, const gd_param2d* p, double binmin, double binmax, int have_h, double h,
+                      double* out8) {
+    gdb::Smoothing1D sm;
+    const bool ok = gdb::smoothing_1d(*s, *p, binmin, binmax, have_h != 0, h, &sm);
+    out8[0] = sm.kde_h, out8[1] = sm.smooth, out8[2] = sm.neff, out8[3] = sm.winw, out8[4] = sm.flags, out8[5] = sm.bits;
+    out8[6] = ok ? 1 : 0, out8[7] = 0;
 }
 
 int gdt_grid_sizes(const gd_batch2d_settings* settings, int32_t n, const double* corr, const int32_t* pairs, int32_t P,

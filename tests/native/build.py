@@ -23,4 +23,4 @@ def load():
 def load_batch():
     """batch2d.hpp (the plan and choreography of gd_density2d_batch) compiled for the host."""
     return _build(SO_BATCH, os.path.join(HERE, "batch_harness.cpp"),
-                  [os.path.join(CSRC, "batch2d.hpp"), os.path.join(HERE, "..", "..", "include", "gdhip.h")], ["-pthread"])
+                  [os.path.join(CSRC, "batch2d.hpp"), os.path.join(CSRC, "batch1d.hpp"), os.path.join(HERE, "..", "..", "include", "gdhip.h")], ["-pthread"])

@@ -295,6 +295,63 @@ def _make_ops():
 _OPS_STRUCT = None
 
 
+_OPS1D = [
+    ("hist1d_dev", C.CFUNCTYPE(C.c_int, _p, _pi32, _i32, _pd, _pd, _i32, _p)),
+    ("isj1d_dev", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pd, _pi32)),
+    ("density1d_dev", C.CFUNCTYPE(C.c_int, _p, _i32, _i32, _p, _pd, _pi32, _pi32, _i32, _i32, _pd, _pi32)),
+    ("fetch", C.CFUNCTYPE(C.c_int, _p, _p, _p, _i64)),
+]
+
+
+class Ops1D(C.Structure):
+    _fields_ = _OPS1D
+
+
+_OPS1D_STRUCT = None
+
+
+def ops1d_struct():
+    """The 1D stages of gd_density1d_batch bound to the numpy context double (device pointers = FakeBuf handles)."""
+    global _OPS1D_STRUCT
+    if _OPS1D_STRUCT is not None:
+        return _OPS1D_STRUCT[0]
+
+    def hist1d_dev(h, cols, ncols, binmin, width, F, d_hist):
+        c = _CTX[int(h)]
+        CALLS.append(("hist1d_dev", c.lane, ncols))
+        _BUF[int(d_hist)].a = c.hist1d([cols[q] for q in range(ncols)], [binmin[q] for q in range(ncols)],
+                                       [width[q] for q in range(ncols)], F)
+        return 0
+
+    def isj1d_dev(h, B, F, d_hist, neff, hfrac, status):
+        c = _CTX[int(h)]
+        CALLS.append(("isj1d_dev", c.lane, B))
+        hh, st = c.isj1d(np.asarray(_BUF[int(d_hist)].a).reshape(B, F), [neff[b] for b in range(B)])
+        for b in range(B):
+            hfrac[b], status[b] = hh[b], int(st[b])
+        return 0
+
+    def density1d_dev(h, B, F, d_hist, smooth, winw, flags, bco, mbc, P_out, status):
+        c = _CTX[int(h)]
+        CALLS.append(("density1d_dev", c.lane, B))
+        P, st = c.density1d(np.asarray(_BUF[int(d_hist)].a).reshape(B, F), [smooth[b] for b in range(B)],
+                            [winw[b] for b in range(B)], [flags[b] for b in range(B)], bco, mbc)
+        np.ctypeslib.as_array(P_out, shape=(B * F,))[:] = np.asarray(P).ravel()
+        for b in range(B):
+            status[b] = int(st[b])
+        return 0
+
+    def fetch(h, dst, d_src, nbytes):
+        a = np.ascontiguousarray(_BUF[int(d_src)].a, dtype=np.float64).ravel()
+        C.memmove(dst, a.ctypes.data, int(nbytes))
+        return 0
+
+    fns = dict(hist1d_dev=hist1d_dev, isj1d_dev=isj1d_dev, density1d_dev=density1d_dev, fetch=fetch)
+    keep = [t(_guard(fns[name])) for name, t in _OPS1D]
+    _OPS1D_STRUCT = (Ops1D(*keep), keep)
+    return _OPS1D_STRUCT[0]
+
+
 def ops_struct():
     global _OPS_STRUCT
     if _OPS_STRUCT is None:
@@ -375,6 +432,26 @@ class HarnessContext(FakeContext):
         if rc != 0:
             raise GdhipError(rc, err.value.decode())
         return int(tokens[0]), int(tokens[1])
+
+    def density1d_batch(self, settings, params, n, cols32, want_hist=False):
+        from getdist_amd._lib import GdhipError
+
+        lib = harness()
+        if self.state is None:
+            self.state = lib.gdt_batch_state_new()
+        cols32 = np.ascontiguousarray(cols32, dtype=np.int32)
+        B, F = len(cols32), int(settings.fine_bins)
+        P = np.zeros((B, F))
+        hist = np.zeros((B, F)) if want_hist else None
+        meta = np.zeros((B, 8))
+        err = C.create_string_buffer(512)
+        lib.gdt_density1d_batch.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _pi32, _i32, _pd, _pd, _pd, C.c_char_p, _i32]
+        rc = lib.gdt_density1d_batch(C.byref(ops_struct()), C.byref(ops1d_struct()), self.state, self.handle, C.byref(settings),
+                                     C.cast(params, _p), int(n), cols32.ctypes.data_as(_pi32), B, P.ctypes.data_as(_pd),
+                                     None if hist is None else hist.ctypes.data_as(_pd), meta.ctypes.data_as(_pd), err, 512)
+        if rc != 0:
+            raise GdhipError(rc, err.value.decode())
+        return P, hist, meta
 
     def batch2d_finish(self):
         if self.state is not None:

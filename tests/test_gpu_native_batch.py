@@ -171,3 +171,34 @@ def test_periodic_pairs_in_both_orientations_repeatedly(monkeypatch, zoo):
                 again = mc.get2DDensities(pairs, **kw)
                 for a, b in zip(again, plain):
                     assert np.array_equal(a.P, b.P), (kw, pairs, rep, float(np.max(np.abs(a.P - b.P))))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(smooth_scale_1D=0.3), dict(smooth_scale_1D=1.5), dict(boundary_correction_order=2),
+                                dict(mult_bias_correction_order=0, boundary_correction_order=0), dict(fine_bins=512)])
+def test_native_1d_entry_equals_python_planned_sequence(monkeypatch, kw):
+    """gd_density1d_batch (include/gdhip.h; mcsamples.py:1500-1686 for all parameters in one call) against the
+    Python-planned sequence of gd_hist1d / gd_isj1d / gd_density1d over the same kernels: densities, kde_h and N_eff
+    `array_equal`; mean-likelihood profiles through the histograms the entry hands back."""
+    recipe = synth.block_recipe(12, 300_000, weighted=False, stream=71)
+
+    def call(m):
+        return m.get1DDensities(**kw), [p.kde_h for p in m.paramNames.names], [p.N_eff_kde for p in m.paramNames.names]
+
+    (native, h_n, neff_n), (plain, h_p, neff_p), _ = both_routes(monkeypatch, lambda: mc_of(recipe), call)
+    assert len(native) == 12
+    for a, b in zip(native, plain):
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.P, b.P)
+    if kw.get("smooth_scale_1D", -1.0) <= 0:
+        assert h_n == h_p and neff_n == neff_p and all(h is not None for h in h_n)
+    # integer multiplicities and mean likelihoods; real weights (fp64 LDS atomics in the binning: rounding differs run to run)
+    s, w, names, ranges = synth.block_recipe(8, 200_000, weighted=True, stream=72)
+    loglikes = np.random.default_rng(3).chisquare(4, size=len(s)) / 2
+    for weights, tol in ((np.floor(w * 3) + 1.0, 0.0), (w, 1e-9)):
+        def build():
+            from getdist_amd.mcsamples import MCSamples
+
+            return MCSamples(samples=s, weights=weights, names=names, ranges=ranges, loglikes=loglikes)
+
+        native, plain, _ = both_routes(monkeypatch, build, lambda m: m.get1DDensities([5, 0, 3], meanlikes=True, **kw))
+        for a, b in zip(native, plain):
+            assert np.max(np.abs(a.P - b.P)) <= tol and np.max(np.abs(a.likes - b.likes)) <= max(tol, 1e-12)
