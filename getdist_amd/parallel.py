@@ -125,6 +125,19 @@ def comm_stage_timeout():
         return lib_limit + 30.0  # the library's own watchdog comes first
 
 
+def _everyone(dist, device, flag):
+    """True on every rank iff ``flag`` is true on every rank (the agreement step between the stages of the set-up)."""
+    import torch
+
+    if device is None and dist.get_backend() == "nccl":  # RCCL reduces device tensors only
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def init_library_comm(ctx, dist, rank, world, device=None, stage_timeout=None):
     """
     Rank 0 makes the RCCL id, every rank joins (collective).  Returns a LibraryComm -- or None ON EVERY RANK when any rank
@@ -144,11 +157,7 @@ def init_library_comm(ctx, dist, rank, world, device=None, stage_timeout=None):
         device = torch.device("cuda", torch.cuda.current_device())
 
     def everyone(flag):
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-        if device is not None:
-            t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t.item()))
+        return _everyone(dist, device, flag)
 
     def give_up(stage):
         if rank == 0:
@@ -242,9 +251,38 @@ class ColumnShare:
         a, b = int(first[self.rank]), int(first[self.rank + 1])
         block = np.asarray(full)[:, a:b] if full is not None else np.asarray(samples(a, b))
         N = block.shape[0]
-        ctx.upload_shard(block, N, nn, a, weights)
-        self.bytes_uploaded = int(block.shape[0]) * (b - a) * 8
-        self.comm.share_columns(first)
+        # stage 4 of the all-or-nothing set-up (init_library_comm has done 1-3): the broadcasts themselves, under the same
+        # watchdog and followed by the same agreement -- a rank whose exchange failed or timed out (the library aborts a
+        # communicator it has waited GDHIP_COMM_TIMEOUT_S for) sends every rank back to the full upload, and the step's
+        # other exchanges back to torch.distributed
+        hung = False
+        try:
+            ctx.upload_shard(block, N, nn, a, weights)
+            call_with_watchdog(lambda: self.comm.share_columns(first), comm_stage_timeout(), "share_columns")
+            ok = True
+        except StageTimeout:
+            ok, hung = False, True
+        except Exception:  # noqa: BLE001 -- any failure of this rank is a failure of the stage
+            ok = False
+        if _everyone(self.dist, self.device, ok):
+            self.bytes_uploaded = int(block.shape[0]) * (b - a) * 8
+            return
+        import logging
+
+        if self.rank == 0:
+            logging.warning("column shards could not be exchanged over the library communicator on a rank: every rank uploads "
+                            "the full sample array, the step's collectives stay with torch.distributed")
+        if hung:
+            raise StageTimeout("gd_comm_share_columns never returned on rank %d: the context cannot be reused" % self.rank)
+        try:
+            call_with_watchdog(ctx.comm_destroy, comm_stage_timeout(), "comm_destroy")
+        except Exception:  # noqa: BLE001 -- (already aborted by the library)
+            pass
+        self.comm = None
+        if full is None:
+            full = samples(0, nn)
+        ctx.upload(full, weights)
+        self.bytes_uploaded = int(np.asarray(full).nbytes)
 
 
 _TILE_DEALS = {}

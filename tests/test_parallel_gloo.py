@@ -353,6 +353,16 @@ SHARE_WORKER = textwrap.dedent("""
 
     s, w, names, ranges = synth.config_c1(20000, bounded=True)
     w = np.random.default_rng(3).exponential(size=len(s))
+    # a rank whose broadcasts fail sends EVERY rank back to the full upload and the torch collectives
+    class Broken(CommCtx):
+        def comm_share_columns(self, first_by_rank):
+            if rank == 1:
+                raise RuntimeError("injected: ncclBroadcast failed")
+            return None  # (rank 0 believes its part went through)
+    bad = parallel.ColumnShare(dist, rank, world)
+    mcb = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=Broken, column_share=bad)
+    assert bad.comm is None and bad.bytes_uploaded == s.nbytes and mcb.ctx.comm_world == 0
+    assert np.array_equal(mcb.ctx.s[:, :s.shape[1]], s)
     share = parallel.ColumnShare(dist, rank, world)
     mc = MCSamples(samples=s, weights=w, names=names, ranges=ranges, _context_factory=CommCtx, column_share=share)
     first = parallel.column_blocks(s.shape[1], world)
