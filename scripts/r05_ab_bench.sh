@@ -1,10 +1,15 @@
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r05ab; export GETDIST_AMD_LIVE_PMC=0
-cp getdist_amd/csrc/libgdhip.so /tmp/new.so
+#!/bin/bash
+# Same-box A/B of one library switch on the C3 bench:  gpurun -- 'bash scripts/r05_ab_bench.sh GDHIP_BATCH_CONV_ON_MAIN'
+# (the variable set = the old behaviour).  Alternating runs, three of each.
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r05ab; export GETDIST_AMD_LIVE_PMC=0
+VAR="${1:-GDHIP_BATCH_CONV_ON_MAIN}"
 for round in 1 2 3; do
   for which in new old; do
-    if [ $which = old ]; then cp gpurun_ab/libgdhip_prev.so getdist_amd/csrc/libgdhip.so; else cp /tmp/new.so getdist_amd/csrc/libgdhip.so; fi
+    if [ $which = old ]; then export "$VAR"=1; else unset "$VAR"; fi
     python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$which', round(d['ms_per_step'],3), round(d['ms_single_triangle_latency'],2))"
   done
 done
-cp /tmp/new.so getdist_amd/csrc/libgdhip.so
-python -m pytest tests -m gpu -x -q -k "native or c3_full or density_2d" 2>&1 | tail -2
+unset "$VAR"
+python -m pytest tests -m gpu -x -q -k "native or c3_full or density_2d or smoke" 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
