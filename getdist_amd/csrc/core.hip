@@ -406,6 +406,7 @@ __global__ void k_weights_integral(const double* __restrict__ w, int64_t N, int*
         const double v = w[i];
         if (!(v >= 0.0) || v != trunc(v) || v > 1048576.0) b |= 1;
         if (v > 255.0) b |= 2;  // too large for the byte copy
+        if (!(v >= 0.0)) b |= 4;  // negative or NaN: no fixed-point bucket sums for the quantile select (w_sum stays unknown)
         s += v;
     }
     if (b) atomicOr(bad, b);
@@ -496,7 +497,7 @@ static int upload_build(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int6
         GD_TRY(gd_fetch(ctx, slots.data(), chk + 128, (size_t)WSLOTS * 8));
         GD_TRY(gd_stream_sync(ctx));
         for (double v : slots) sum += v;
-        *wsum_out = sum;
+        *wsum_out = (bad & 4) ? 0.0 : sum;
         *integral_out = ((bad & 1) == 0) && sum < 4.0e9;
         if (*integral_out && bad == 0) {  // byte multiplicities for the 16-bit packed 2D binning
             GD_HIP(hipMalloc((void**)&w8, (size_t)ld));

@@ -1658,7 +1658,7 @@ int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo,
     if (linear && (hi - lo) > (ctx->w ? 12000000 : 25000000)) linear = false;
     // weighted bucket sums are fixed-point integers scaled from the weights' total, which is known for the uploaded sample
     // weights (any kind: multiplicities or real); auxiliary weights (gd_select_weights) take the radix path
-    if (linear && ctx->w && !(ctx->w_sum > 0 && std::isfinite(ctx->w_sum))) linear = false;
+    if (linear && ctx->w && !(ctx->w_sum > 1e-200 && ctx->w_sum < 1e200)) linear = false;
     for (int c = 0; linear && c < ncols; ++c) {
         const double a = minmax[2 * c], b = minmax[2 * c + 1];
         if (!(b > a) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite((double)QLIN_NB_U / (b - a))) linear = false;

@@ -696,3 +696,25 @@ def test_byte_index_binning_in_row_chunks_sums_partial_tables_exactly():
         c.hist2d_prebinned8([b2[0]], [b2[1]])
     assert err.value.code == -5
     c.close()
+
+
+def test_weighted_quantiles_without_a_usable_weight_total_take_the_radix_path(monkeypatch):
+    """The fixed-point bucket sums of the linear-bucket select need the total of non-negative weights; a set with a negative
+    weight (not a GetDist chain, but the entry takes any array) or auxiliary weights keeps the radix select -- same answers."""
+    from getdist_amd._lib import Context
+
+    rng = np.random.default_rng(9)
+    N = 300_001
+    s = rng.standard_normal((N, 3))
+    w = rng.exponential(1.0, N)
+    w[17] = -0.25
+    c = Context(0)
+    try:
+        c.upload(s, w)
+        mm = np.stack([s.min(axis=0), s.max(axis=0)], axis=1)
+        targets = np.tile(w.sum() * np.array([0.1, 0.5, 0.9]), (3, 1))
+        lin = c.quantiles([0, 1, 2], targets, minmax=mm)
+        monkeypatch.setenv("GDHIP_QSEL_RADIX", "1")
+        assert np.array_equal(lin, c.quantiles([0, 1, 2], targets, minmax=mm))
+    finally:
+        c.close()
