@@ -530,6 +530,14 @@ static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int
                          const double* weights, int64_t shard_first, int64_t shard_count) {
     GD_HIP(hipSetDevice(ctx->device));
     GD_TRY(gd_stream_sync(ctx));
+    // The stream of a context that OWNS a sample set is urgent: in a batched call it carries the optimiser's stage A, whose
+    // small launches (table copies, 128-thread sums) otherwise wait for a wave slot behind the saturating launches of the
+    // convolution on the second stream (C3 step 24.2 against 24.8 ms, three alternating runs; the second stream high as
+    // well, or low: no difference).  Once, at the first upload -- before any plan or communicator is tied to the stream.
+    if (!ctx->main_high && !getenv("GDHIP_MAIN_STREAM_NORMAL")) {
+        GD_TRY(gd_stream_priority(ctx, 1));
+        ctx->main_high = true;
+    }
     if (ctx->batch_state_release) ctx->batch_state_release(ctx, false);  // index columns of the old sample set
     if (ctx->w_sel) ctx->w = ctx->w_main, ctx->w8 = ctx->w8_main;
     if (!ctx->borrowed) {

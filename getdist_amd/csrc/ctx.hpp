@@ -22,6 +22,7 @@ struct gd_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // D2H of finished grids overlaps the next batch's kernels
     hipEvent_t copy_ev = nullptr;
+    bool main_high = false;  // the compute stream was re-created with high priority at the first upload (core.hip)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 256;
     std::string err;

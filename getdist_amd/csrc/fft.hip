@@ -57,6 +57,7 @@ static int exec_plan(gd_ctx* ctx, bool forward, int n0, int n1, int batch, void*
     if (rc) return rc;
     void* ib[1] = {in};
     void* ob[1] = {out};
+    rocfft_execution_info_set_stream(p->info, ctx->stream);  // (the context's stream may have been re-created: gd_stream_priority)
     rocfft_status st = rocfft_execute(p->plan, ib, ob, p->info);
     if (st != rocfft_status_success)
         return gd_fail(ctx, GD_ERR_FFT, "rocfft_execute(%s %dx%d x%d) failed: %d", forward ? "r2c" : "c2r", n0, n1, batch, (int)st);
