@@ -19,7 +19,7 @@ cp $S/emulate_c5.json $P/r05_emulate_world_c5.json
 cp $S/emu8_stream_timeline.txt $P/r05_emu8_timeline.txt
 cp $S/emu8_kernel_stats.csv $P/r05_emu8_kernel_stats.csv
 cp $S/lds_atomic_f64_roof.txt $P/r05_lds_atomic_f64_roof.txt
-grep -v '^[WE]2026' $S/rccl_smoke.log | tail -3 > $P/r05_rccl_smoke.txt
+grep -v "^[WE]2026" $S/rccl_smoke.log | grep -E "library communicator not available|nccl smoke ok|RCCL version|Librccl path" > $P/r05_rccl_smoke.txt
 cp $S/bench_gloo2_shared_gpu.json $P/r05_bench_gloo2_shared_gpu.json
 tail -5 $S/pytest.log > $P/r05_pytest_gpu_tail.txt
 cp gpurun_out/r05_parity_2d.json $P/r05_parity_2d.json
