@@ -187,3 +187,14 @@ def test_native_1d_route_correlated_chain_takes_the_long_route():
     mc = MCSamples(_context_factory=nb.HarnessContext, **kw)
     same1d(mc.get1DDensities(), ref.get1DDensities())
     assert [p.N_eff_kde for p in mc.paramNames.names] == [p.N_eff_kde for p in ref.paramNames.names]
+
+
+def test_native_1d_route_uncorrelated_sampler(zoo):
+    """sampler = "nested": N_eff = norm^2 / sum w^2 for every parameter (chains.py:507-508), decided inside the entry."""
+    fx = zoo["block10_weighted"]
+    ref = make(fx, nb.PlainContext, sampler="nested")
+    mc = make(fx, nb.HarnessContext, sampler="nested")
+    nb.CALLS.clear()
+    same1d(mc.get1DDensities([1, 2, 7]), ref.get1DDensities([1, 2, 7]))
+    assert not any(c[0] in ("autocov_lags_batch", "kde_lag_sums_batch") for c in nb.CALLS)
+    assert [mc.paramNames.names[j].N_eff_kde for j in (1, 2, 7)] == [ref.paramNames.names[j].N_eff_kde for j in (1, 2, 7)]
