@@ -198,3 +198,34 @@ def test_native_1d_route_uncorrelated_sampler(zoo):
     same1d(mc.get1DDensities([1, 2, 7]), ref.get1DDensities([1, 2, 7]))
     assert not any(c[0] in ("autocov_lags_batch", "kde_lag_sums_batch") for c in nb.CALLS)
     assert [mc.paramNames.names[j].N_eff_kde for j in (1, 2, 7)] == [ref.paramNames.names[j].N_eff_kde for j in (1, 2, 7)]
+
+
+def test_native_1d_route_solver_failure_falls_back_or_raises(zoo, monkeypatch, caplog):
+    """The ISJ solver returning None (mcsamples.py:1258-1268): rule-of-thumb width + the reference's two warnings, the same
+    density as the Python-planned sequence; with raise_on_bandwidth_errors the entry's GD_ERR_SOLVER becomes BandwidthError
+    naming the parameter."""
+    import fake_ctx
+    from getdist_amd.mcsamples import BandwidthError
+
+    fx = zoo["c1_bounded"]
+    real = fake_ctx.FakeContext.isj1d
+
+    def failing(self, hist, neff):
+        h, status = real(self, hist, neff)
+        status[0] = -5  # the first histogram of the call: "zero f in _bandwidth_fixed_point"
+        return h, status
+
+    monkeypatch.setattr(fake_ctx.FakeContext, "isj1d", failing)
+    ref = make(fx, nb.PlainContext)
+    mc = make(fx, nb.HarnessContext)
+    with caplog.at_level(logging.WARNING):
+        native = mc.get1DDensities([2, 0])
+    assert any("1D auto bandwidth failed" in r.getMessage() for r in caplog.records)
+    assert any("very small or failed" in r.getMessage() for r in caplog.records)
+    same1d(native, ref.get1DDensities([2, 0]))
+    assert mc.paramNames.names[2].kde_h == ref.paramNames.names[2].kde_h
+    strict = make(fx, nb.HarnessContext)
+    strict.raise_on_bandwidth_errors = True
+    with pytest.raises(BandwidthError) as e:
+        strict.get1DDensities([2, 0])
+    assert fx["names"][2] in str(e.value) and "column" not in str(e.value)
