@@ -718,3 +718,32 @@ def test_weighted_quantiles_without_a_usable_weight_total_take_the_radix_path(mo
         assert np.array_equal(lin, c.quantiles([0, 1, 2], targets, minmax=mm))
     finally:
         c.close()
+
+
+def test_partial_column_shard_lands_at_its_columns():
+    """gd_upload_shard with a block in the MIDDLE of the column range (what rank r > 0 of a multi-rank job uploads before
+    gd_comm_share_columns brings the rest): the block's columns are resident at their own indices -- statistics and
+    quantiles of exactly those columns equal numpy's; the extra columns behind the set are zero."""
+    from getdist_amd._lib import Context
+
+    rng = np.random.default_rng(21)
+    N, n, a, b = 100_003, 7, 2, 5
+    s = rng.standard_normal((N, n)) * np.arange(1, n + 1) + np.arange(n)
+    w = rng.integers(1, 4, N).astype(float)
+    c = Context(0)
+    try:
+        c.upload_shard(s[:, a:b], N, n, a, w)
+        cols = list(range(a, b))
+        means, cov, norm, mm = c.cov(cols, minmax=True)
+        assert norm == w.sum()
+        assert np.allclose(means, np.average(s[:, a:b], axis=0, weights=w), rtol=1e-13, atol=1e-13)
+        assert np.array_equal(mm[:, 0], s[:, a:b].min(axis=0)) and np.array_equal(mm[:, 1], s[:, a:b].max(axis=0))
+        d = s[:, a:b] - means
+        assert np.allclose(cov, (d * w[:, None]).T @ d / w.sum(), rtol=1e-11, atol=1e-12)
+        q = c.quantiles(cols, np.tile(w.sum() * np.array([0.25, 0.5, 0.75]), (len(cols), 1)), minmax=mm)
+        for ci, j in enumerate(cols):
+            idx = s[:, j].argsort(kind="stable")
+            want = s[:, j][idx[np.searchsorted(np.cumsum(w[idx]), w.sum() * np.array([0.25, 0.5, 0.75]))]]
+            assert np.array_equal(q[ci], want)
+    finally:
+        c.close()
