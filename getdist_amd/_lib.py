@@ -12,14 +12,19 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgdhip.so")
 
-GD_OK, GD_ERR_BADARG, GD_ERR_NOMEM, GD_ERR_HIP, GD_ERR_EMPTY, GD_ERR_SOLVER, GD_ERR_FFT, GD_ERR_NODEVICE = \
-    0, -1, -2, -3, -4, -5, -6, -7
+GD_OK, GD_ERR_BADARG, GD_ERR_NOMEM, GD_ERR_HIP, GD_ERR_EMPTY, GD_ERR_SOLVER, GD_ERR_FFT, GD_ERR_NODEVICE, GD_ERR_TIMEOUT = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class GdhipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libgdhip error %d: %s" % (code, msg))
         self.code = code
+
+
+class GdhipTimeout(GdhipError):
+    """GD_ERR_TIMEOUT: a collective or the communicator set-up gave up waiting for a peer; the library has aborted and dropped
+    the communicator, so the ranks renegotiate over the host application's own channel (parallel.init_library_comm)."""
 
 
 def build_native(force=False):
@@ -130,6 +135,7 @@ SIGNATURES = {
     "gd_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
     "gd_comm_info": (C.c_int, [_p, _pi32, _pi32]),
     "gd_comm_destroy": (C.c_int, [_p]),
+    "gd_comm_abandon": (C.c_int, [_p]),
     "gd_comm_allgather": (C.c_int, [_p, _pd, _i64, _pd]),
     "gd_comm_allreduce_sum": (C.c_int, [_p, _pd, _i64]),
     "gd_comm_allgather_dev": (C.c_int, [_p, _p, _i64, _p]),
@@ -309,6 +315,9 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             msg = self.lib.gd_last_error(self.h)
+            if rc == GD_ERR_TIMEOUT:
+                self.comm_world = self.comm_rank = 0  # the library has aborted and dropped the communicator
+                raise GdhipTimeout(rc, msg.decode() if msg else "?")
             raise GdhipError(rc, msg.decode() if msg else "?")
 
     # ---- memory / info
@@ -835,13 +844,26 @@ class Context:
         self._check(self.lib.gd_comm_destroy(self.h))
         self.comm_world = 0
 
+    def comm_info(self):
+        """(world, rank) of the context's communicator as the LIBRARY sees it; (0, 0) when there is none (never made, or
+        aborted and dropped after a timeout)."""
+        wd, rk = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.gd_comm_info(self.h, C.byref(wd), C.byref(rk)))
+        return int(wd.value), int(rk.value)
+
+    def comm_abandon(self):
+        """The one call that may be made from another thread while a gd_comm_* call of this context has not returned: a
+        gd_comm_init that comes back after its caller gave up installs nothing."""
+        if self.h is not None:
+            self.lib.gd_comm_abandon(self.h)
+
     def density1d_batch(self, settings, params, n, cols32, want_hist=False):
-        """gd_density1d_batch: (P[B, F], hist[B, F] or None, meta[B, 8]) of the listed columns."""
+        """gd_density1d_batch: (P[B, F], hist[B, F] or None, meta[B, 9]) of the listed columns."""
         cols32 = _i32arr(cols32)
         B, F = len(cols32), int(settings.fine_bins)
         P = np.zeros((B, F))
         hist = np.zeros((B, F)) if want_hist else None
-        meta = np.zeros((B, 8))
+        meta = np.zeros((B, 9))
         self._check(self.lib.gd_density1d_batch(self.h, C.byref(settings), C.cast(params, _p), int(n), _ip(cols32), B, _dp(P),
                                                 None if hist is None else _dp(hist), _dp(meta)))
         return P, hist, meta

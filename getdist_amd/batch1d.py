@@ -22,7 +22,7 @@ class Density1DSettings(C.Structure):
 
 
 def run(mc, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist):
-    """(P[B, F], hist[B, F] or None, meta[B, 8]) for the columns ``js`` (their parameters initialised by the caller)."""
+    """(P[B, F], hist[B, F] or None, meta[B, 9]) for the columns ``js`` (their parameters initialised by the caller)."""
     from . import mcsamples as M
     from ._lib import GdhipError
 
@@ -47,7 +47,7 @@ def run(mc, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist):
                 continue
             msg = str(e).split(": ", 1)[-1]
             if e.code == -5:
-                raise M.BandwidthError(_with_names(msg, names))
+                raise M.BandwidthError(_as_python_prints(_with_names(msg, names)))
             if "Parameter range is <= 0" in msg:
                 raise M.MCSamplesError("Parameter range is <= 0: " + names[int(msg.rsplit(" ", 1)[-1])].name)
             if e.code == -1:
@@ -61,9 +61,10 @@ def run(mc, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist):
         par = names[j]
         if bits[b] & 1:
             logging.warning("1D auto bandwidth failed. Using fallback: zero f in _bandwidth_fixed_point (non-convergence)")
-        if bits[b] & 2:
-            logging.warning("auto bandwidth for %s very small or failed (N_eff=%s). Using fallback (h=%s)", par.name, meta[b, 6],
-                            meta[b, 2])
+        if bits[b] & 2:  # the reference's message (mcsamples.py:1262): the solver's own width, N_eff, the fallback width
+            h_isj = None if np.isnan(meta[b, 8]) else float(meta[b, 8])
+            logging.warning(f"auto bandwidth for {par.name} very small or failed (h={h_isj},N_eff={float(meta[b, 6])}). "
+                            f"Using fallback (h={float(meta[b, 2])})")
         if bits[b] & 4:
             logging.warning("fine_bins not large enough to well sample smoothing scale - " + par.name)
         if smooth_scale_1D <= 0:
@@ -71,6 +72,13 @@ def run(mc, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist):
     if np.any(meta[:, 7] != 0):
         raise M.DensitiesError("no samples in bin")
     return P, hist, meta
+
+
+def _as_python_prints(msg):
+    """the library writes its doubles with 17 significant digits; the reference's f-string shows repr(float)"""
+    import re
+
+    return re.sub(r"=(-?\d[0-9.e+-]*)", lambda m: "=" + repr(float(m.group(1))), msg)
 
 
 def _with_names(msg, names):

@@ -211,7 +211,7 @@ def pack_params(mc, used, owned=None):
         r.err, r.mean, r.var = p.err, means[j], vars_[j]
         r.neff = np.nan if p.N_eff_kde is None else p.N_eff_kde
         r.has_limits_bot, r.has_limits_top, r.periodic = bool(p.has_limits_bot), bool(p.has_limits_top), bool(p.periodic)
-        r.owned = 1 if owned is None or j in owned else 0
+        r.owned = (1 if owned is None or j in owned else 0) | (2 if mc._no_bandwidth_warning(p) else 0)
     return arr
 
 

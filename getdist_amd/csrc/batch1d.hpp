@@ -21,6 +21,7 @@ struct Ops1D {
 
 struct Smoothing1D {
     double kde_h = NAN, smooth = NAN, neff = NAN;
+    double h_isj = NAN;  // the solver's width when the fallback replaced it (NaN: the solver returned None): the message's "h="
     int32_t winw = 0, flags = 0, bits = 0;
 };
 
@@ -40,10 +41,14 @@ static inline bool smoothing_1d(const gd_density1d_settings& s, const gd_param2d
         if (!have_h) out->bits |= 1;
         const double bin_range = np_maximum(p.param_max, p.range_max) - np_minimum(p.param_min, p.range_min);
         if (!have_h || h < 0.01 * py_pow(N_eff, -1.0 / 5) * (p.range_max - p.range_min) / bin_range) {
-            out->bits |= 2;
-            out->kde_h = h;  // what the message quotes
-            if (s.raise_on_bandwidth_errors) return false;
+            // (p.owned & 2): the parameter is in no_warning_params / a chi2 parameter under no_warning_chi2_params: the
+            // reference then neither warns nor raises (mcsamples.py:1259-1266) and takes the fallback silently
+            const bool quiet = (p.owned & 2) != 0;
+            if (!quiet) out->bits |= 2;
+            out->h_isj = have_h ? h : NAN;  // what the message quotes as h=
             h = 1.06 * p.sigma_range * py_pow(N_eff, -1.0 / 5) / bin_range;
+            out->kde_h = h;  // ... and as "Using fallback (h=...)"
+            if (s.raise_on_bandwidth_errors && !quiet) return false;
         }
         out->kde_h = h;
         int m = s.mult_bias_correction_order;
@@ -156,18 +161,19 @@ static inline int density1d_batch(State& st, const Ops& ops, const Ops1D& o1, vo
         const gd_param2d& p = par[cols[b]];
         Smoothing1D sm;
         if (!smoothing_1d(s, p, binmin[b], binmax[b], isj_status[b] == 0, hfrac[b], &sm)) {
+            // the reference's message (mcsamples.py:1262); the binding prints the three numbers as Python's repr does
             if (isj_status[b] != 0)
-                snprintf(buf, sizeof buf, "auto bandwidth for column %d very small or failed (h=None,N_eff=%.17g)", (int)cols[b],
-                         sm.neff);
+                snprintf(buf, sizeof buf, "auto bandwidth for column %d very small or failed (h=None,N_eff=%.17g). Using fallback (h=%.17g)",
+                         (int)cols[b], sm.neff, sm.kde_h);
             else
-                snprintf(buf, sizeof buf, "auto bandwidth for column %d very small or failed (h=%.17g,N_eff=%.17g)", (int)cols[b],
-                         sm.kde_h, sm.neff);
+                snprintf(buf, sizeof buf, "auto bandwidth for column %d very small or failed (h=%.17g,N_eff=%.17g). Using fallback (h=%.17g)",
+                         (int)cols[b], sm.h_isj, sm.neff, sm.kde_h);
             return fail(GD_ERR_SOLVER, buf);
         }
         smooth[b] = sm.smooth, winw[b] = sm.winw, flags[b] = sm.flags;
         double* m = meta + (size_t)b * GD_BATCH1D_META;
         m[0] = binmin[b], m[1] = binmax[b], m[2] = sm.kde_h, m[3] = sm.smooth, m[4] = sm.winw, m[5] = sm.bits, m[6] = sm.neff;
-        m[7] = 0;
+        m[7] = 0, m[8] = sm.h_isj;
         if (!(sm.smooth > 0) || sm.winw < 0 || 2 * sm.winw + 1 > F) {
             snprintf(buf, sizeof buf, "smoothing scale of column %d is not usable (smooth_1D=%g)", (int)cols[b], sm.smooth);
             return fail(GD_ERR_BADARG, buf);

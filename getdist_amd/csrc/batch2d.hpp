@@ -542,7 +542,7 @@ struct Call {
     int neff_batch(const std::vector<int>& js, bool owned_only, double min_corr = 0.05) {
         std::vector<int32_t> todo;
         for (int j : js)
-            if (isnan(par[j].neff) && (!owned_only || par[j].owned)) todo.push_back(j);
+            if (isnan(par[j].neff) && (!owned_only || (par[j].owned & 1))) todo.push_back(j);
         if (todo.empty()) return 0;
         mark("neff: start", (int)todo.size());
         if (s.uncorrelated_sampler) {
@@ -639,7 +639,7 @@ struct Call {
             }
             std::vector<double> v(n, 0.0);
             for (int j = 0; j < n; ++j)
-                if (par[j].owned && !isnan(par[j].neff)) v[j] = par[j].neff;
+                if ((par[j].owned & 1) && !isnan(par[j].neff)) v[j] = par[j].neff;
             GDB_DEV(h, ops.comm_allreduce_sum(h, v.data(), n));
             for (int j = 0; j < n; ++j)
                 if (isnan(par[j].neff) && v[j] > 0) par[j].neff = v[j];

@@ -14,6 +14,11 @@
 //  * the host-vector collectives do not block in hipStreamSynchronize: they poll the stream together with
 //    ncclCommGetAsyncError and give up after the same timeout (ncclCommAbort, communicator dropped), so a dead peer is an
 //    error code and not a hang inside the library.
+//  * Round 6: a wait that gives up drains the stream (bounded) and forgets the pending result deliveries before the error is
+//    returned -- nothing is written to the caller's vectors afterwards; steady-state collectives have their own, much larger
+//    limit (GDHIP_COMM_STEADY_TIMEOUT_S) and timeouts their own status code (GD_ERR_TIMEOUT); gd_comm_abandon lets a caller
+//    whose own watchdog gave up on gd_comm_init make sure a late success installs nothing.
+//  * GDHIP_COMM_INJECT_WAIT_TIMEOUT (test hook): the next host-vector collective's wait gives up at once.
 //  * GDHIP_COMM_INJECT_HANG_MS (test hook): the helper thread sleeps that long before it joins -- the watchdog path can be
 //    exercised with a single rank on a single GPU (tests/test_gpu_rccl_smoke.py).
 #include <dlfcn.h>
@@ -98,6 +103,29 @@ double comm_timeout_s() {
     return v > 0 ? v : 120.0;
 }
 
+// The set-up limit above is for "does the peer exist at all".  A collective of a RUNNING job (the N_eff all-reduce inside
+// gd_density2d_batch, the chain moments) may legitimately wait long for a rank that is late -- a long N_eff route, chain
+// loading, load imbalance -- and aborting the communicator there leaves the other ranks without a way to renegotiate: the
+// steady-state limit is separate and much larger (GDHIP_COMM_STEADY_TIMEOUT_S, default 3600 s; 0 or negative = the set-up limit).
+double comm_steady_timeout_s() {
+    const char* e = getenv("GDHIP_COMM_STEADY_TIMEOUT_S");
+    if (!e) return 3600.0;
+    const double v = atof(e);
+    return v > 0 ? v : comm_timeout_s();
+}
+
+// After a communicator was aborted the stream still holds what was queued behind the dead collective (the copy kernels of
+// gd_fetch, a DMA copy into the caller's vector for a large result).  Give it a bounded time to run dry so that nothing is
+// written to a host buffer after this entry point has returned its error; then the pending deliveries are forgotten.
+void drain_after_abort(gd_ctx* ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(ctx->stream) == hipErrorNotReady &&
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 5.0)
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    ctx->fetch_pending.clear();  // (their destinations belong to the caller that is about to see the error)
+    ctx->fetch_off = 0;
+}
+
 // a communicator that can no longer be trusted (timeout, asynchronous error): abort it -- ncclCommDestroy would wait for
 // the peers -- and drop it from the context; the device staging block stays (a later gd_comm_init reuses it)
 void comm_drop(gd_ctx* ctx) {
@@ -109,16 +137,25 @@ void comm_drop(gd_ctx* ctx) {
     }
     ctx->comm = nullptr;
     ctx->comm_world = ctx->comm_rank = 0;
+    ctx->comm_completed = 0;
+    drain_after_abort(ctx);
 }
 
 // Wait for everything enqueued on the context's stream WITHOUT blocking in the driver: poll the stream and the
 // communicator's asynchronous error state; a dead peer or a rank that never arrives ends in an error after the timeout.
-int comm_wait(gd_ctx* ctx, const char* what) {
+int comm_wait(gd_ctx* ctx, const char* what, bool setup = false) {
     const auto t0 = std::chrono::steady_clock::now();
-    const double limit = comm_timeout_s();
+    // the first host-vector collective after gd_comm_init is the set-up's test exchange; the column broadcasts are set-up too
+    const bool steady = !setup && ctx->comm_completed > 0;
+    double limit = steady ? comm_steady_timeout_s() : comm_timeout_s();
+    if (const char* inj = getenv("GDHIP_COMM_INJECT_WAIT_TIMEOUT"))  // test hook: this wait gives up at once
+        if (atoi(inj) > 0) limit = -1.0;
     for (int spin = 0;; ++spin) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) return gd_stream_sync(ctx);  // (drained: returns at once; delivers the staged result vectors)
+        const hipError_t q = limit < 0 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) {
+            ctx->comm_completed++;
+            return gd_stream_sync(ctx);  // (drained: returns at once; delivers the staged result vectors)
+        }
         if (q != hipErrorNotReady) {
             comm_drop(ctx);
             return gd_fail(ctx, GD_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
@@ -134,8 +171,8 @@ int comm_wait(gd_ctx* ctx, const char* what) {
         }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
             comm_drop(ctx);
-            return gd_fail(ctx, GD_ERR_HIP, "%s: no completion after %.0f s (GDHIP_COMM_TIMEOUT_S): a peer rank is missing or dead; the communicator was aborted",
-                           what, limit);
+            return gd_fail(ctx, GD_ERR_TIMEOUT, "%s: no completion after %.0f s (%s): a peer rank is missing, dead or very late; the communicator was aborted",
+                           what, limit < 0 ? 0.0 : limit, steady ? "GDHIP_COMM_STEADY_TIMEOUT_S" : "GDHIP_COMM_TIMEOUT_S");
         }
         if (spin < 2000)
             std::this_thread::yield();
@@ -158,6 +195,7 @@ struct InitJob {
 void gd_comm_release(gd_ctx* ctx) {  // gd_destroy
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((rcclComm_t)ctx->comm);
     ctx->comm = nullptr;
+    ctx->comm_completed = 0;
     if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
     ctx->comm_buf = nullptr;
     ctx->comm_buf_bytes = 0;
@@ -209,6 +247,8 @@ int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128) {
         ctx->comm = nullptr;
         ctx->comm_world = ctx->comm_rank = 0;
     }
+    const int abandon_gen = ctx->comm_abandon_gen.load();
+    ctx->comm_completed = 0;
     auto job = std::make_shared<InitJob>();
     rcclUniqueId id;
     memcpy(id.internal, id128, 128);
@@ -241,14 +281,27 @@ int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128) {
             job->abandoned = true;
             lk.unlock();
             helper.detach();
-            return gd_fail(ctx, GD_ERR_HIP, "ncclCommInitRank: rank %d of %d did not join within %.0f s (GDHIP_COMM_TIMEOUT_S)", (int)rank,
+            return gd_fail(ctx, GD_ERR_TIMEOUT, "ncclCommInitRank: rank %d of %d did not join within %.0f s (GDHIP_COMM_TIMEOUT_S)", (int)rank,
                            (int)world, limit);
         }
     }
     helper.join();
     if (job->rc != rcclSuccess) return rccl_fail(ctx, "ncclCommInitRank", job->rc);
+    if (ctx->comm_abandon_gen.load() != abandon_gen) {  // the caller's own watchdog gave up on this call (gd_comm_abandon)
+        if (g_rccl.CommAbort)
+            g_rccl.CommAbort(job->comm);
+        else
+            g_rccl.CommDestroy(job->comm);
+        return gd_fail(ctx, GD_ERR_TIMEOUT, "gd_comm_init: abandoned by the caller while it ran; no communicator installed");
+    }
     ctx->comm = job->comm;
     ctx->comm_world = world, ctx->comm_rank = rank;
+    return GD_OK;
+}
+
+int gd_comm_abandon(gd_ctx* ctx) {
+    if (!ctx) return GD_ERR_BADARG;
+    ctx->comm_abandon_gen.fetch_add(1);  // nothing else of the context is touched: this may run beside a stuck gd_comm_* call
     return GD_OK;
 }
 
@@ -331,7 +384,7 @@ int gd_comm_share_columns(gd_ctx* ctx, const int64_t* first_by_rank) {
     const int rc_end = g_rccl.GroupEnd();
     if (rc != rcclSuccess) return rccl_fail(ctx, "ncclBroadcast", rc);
     if (rc_end != rcclSuccess) return rccl_fail(ctx, "ncclGroupEnd", rc_end);
-    return comm_wait(ctx, "ncclBroadcast (column shards)");
+    return comm_wait(ctx, "ncclBroadcast (column shards)", true);
 }
 
 }  // extern "C"

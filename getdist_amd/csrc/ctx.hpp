@@ -9,6 +9,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/gdhip.h"
@@ -89,6 +90,10 @@ struct gd_ctx {
     int comm_world = 0, comm_rank = 0;
     void* comm_buf = nullptr;
     size_t comm_buf_bytes = 0;
+    // gd_comm_abandon (the ONE entry another thread may call on a context that is inside gd_comm_*): a set-up call that
+    // comes back after the caller gave up on it must not install a communicator
+    std::atomic<int> comm_abandon_gen{0};
+    int comm_completed = 0;  // host-vector collectives that have completed since gd_comm_init (the first one is set-up)
     // gd_density2d_batch (batch2d.hip): device-block pool, cached index columns and the last call's blocks in flight
     void* batch_state = nullptr;
     void (*batch_state_release)(gd_ctx*, bool destroy) = nullptr;

@@ -469,6 +469,8 @@ class MCSamples:
         self.label, self.name_tag = label, name_tag
         self.root = root
         self.raise_on_bandwidth_errors = False
+        self.no_warning_params = []          # mcsamples.py:259-260,438-439: parameters whose 1D bandwidth fallback is silent
+        self.no_warning_chi2_params = True
         self.chain_offsets = None
         self.chains = None
         self.ctx = None
@@ -680,6 +682,7 @@ class MCSamples:
         setSamples applies to a single sample array only: chain lists are filtered per chain before they are stacked."""
         self._drop_second_lane()
         self._chain_stats_cache = {}
+        self._loglikes_col = None  # (an extra-column slot of the old sample set)
         w = self.weights
         if (filter_weights and self.chain_offsets is None and w is not None and self.min_weight_ratio is not None
                 and self.min_weight_ratio >= 0):
@@ -900,24 +903,26 @@ class MCSamples:
         ctx = self.ctx
         col = ctx.set_extra_column(ctx.EXTRA_COLS - 1, self.loglikes)
         self._loglikes_col = col  # (_setNDLimits below reads the same resident copy instead of uploading it again)
-        st = ctx.like_stats(col)
-        norm = self.norm
-        maxlike = st["min"]
-        m = LikeStats()
-        m.logLike_sample = maxlike
-        m.logMeanInvLike = (np.log(st["sum_w_exp_plus"] / norm) + maxlike) if st["max"] - maxlike < 30 else None
-        self.mean_loglike = st["sum_wl"] / norm  # chains.py:380-383
-        m.meanLogLike = self.mean_loglike
-        m.logMeanLike = -np.log(st["sum_w_exp_minus"] / norm) + maxlike
-        m.complexity = 2 * (self.mean_loglike - maxlike)
-        m.varLogLike = st["sum_wl2"] / norm - self.mean_loglike**2
-        m.names = self.paramNames.names
-        self._setNDLimits()
+        try:  # whatever happens below, the column id must not outlive this call: the slot is rewritten by later uploads
+            st = ctx.like_stats(col)
+            norm = self.norm
+            maxlike = st["min"]
+            m = LikeStats()
+            m.logLike_sample = maxlike
+            m.logMeanInvLike = (np.log(st["sum_w_exp_plus"] / norm) + maxlike) if st["max"] - maxlike < 30 else None
+            self.mean_loglike = st["sum_wl"] / norm  # chains.py:380-383
+            m.meanLogLike = self.mean_loglike
+            m.logMeanLike = -np.log(st["sum_w_exp_minus"] / norm) + maxlike
+            m.complexity = 2 * (self.mean_loglike - maxlike)
+            m.varLogLike = st["sum_wl2"] / norm - self.mean_loglike**2
+            m.names = self.paramNames.names
+            self._setNDLimits()
+        finally:
+            self._loglikes_col = None
         best = self.samples[st["argmin"]]
         for j, par in enumerate(self.paramNames.names):
             par.bestfit_sample = best[j]
         self._likeStats = m
-        self._loglikes_col = None
         return m
 
     @property
@@ -1330,6 +1335,12 @@ class MCSamples:
             if k.startswith("max_frac_twotail") and k[len("max_frac_twotail"):].isdigit():
                 self._max_frac_overrides = dict(getattr(self, "_max_frac_overrides", {}))
                 self._max_frac_overrides[int(k[len("max_frac_twotail"):]) - 1] = float(v)
+                continue
+            if k == "no_warning_params":  # (ini: a space-separated list, mcsamples.py:438)
+                self.no_warning_params = v.split() if isinstance(v, str) else list(v)
+                continue
+            if k == "no_warning_chi2_params":
+                self.no_warning_chi2_params = v in (True, "T", "t", "True", "true", 1)
                 continue
             if k not in DEFAULT_SETTINGS:
                 raise SettingError("unknown setting: %s" % k)
@@ -2042,6 +2053,11 @@ class MCSamples:
         h, status = self.ctx.isj1d(np.asarray(bins, dtype=np.float64)[None, :], [N_eff])
         return self._bandwidth_1d(None if status[0] else h[0], par, N_eff, mult_bias_correction_order, kernel_order)
 
+    def _no_bandwidth_warning(self, par):
+        """mcsamples.py:1259-1261: parameters for which a failed / very small 1D bandwidth neither warns nor raises."""
+        return par.name in self.no_warning_params or (
+            bool(self.no_warning_chi2_params) and ("chi2_" in par.name or "minuslog" in par.name))
+
     def _bandwidth_1d(self, h, par, N_eff, mult_bias_correction_order, kernel_order):
         """The scalar tail of getAutoBandwidth1D (mcsamples.py:1256-1283) given the device's ISJ solution ``h`` (None
         where the solver failed): rule-of-thumb fallback when it failed or is very small, higher-order rescaling."""
@@ -2050,10 +2066,11 @@ class MCSamples:
         bin_range = max(par.param_max, par.range_max) - min(par.param_min, par.range_min)
         if h is None or h < 0.01 * N_eff ** (-1.0 / 5) * (par.range_max - par.range_min) / bin_range:
             hnew = 1.06 * par.sigma_range * N_eff ** (-1.0 / 5) / bin_range
-            msg = f"auto bandwidth for {par.name} very small or failed (h={h},N_eff={N_eff}). Using fallback (h={hnew})"
-            if self.raise_on_bandwidth_errors:
-                raise BandwidthError(msg)
-            logging.warning(msg)
+            if not self._no_bandwidth_warning(par):
+                msg = f"auto bandwidth for {par.name} very small or failed (h={h},N_eff={N_eff}). Using fallback (h={hnew})"
+                if self.raise_on_bandwidth_errors:
+                    raise BandwidthError(msg)
+                logging.warning(msg)
             h = hnew
         par.kde_h = h
         m = self.mult_bias_correction_order if mult_bias_correction_order is None else mult_bias_correction_order

@@ -86,6 +86,9 @@ class StageTimeout(RuntimeError):
     pass
 
 
+from ._lib import GdhipTimeout as CommTimeout  # noqa: E402,F401 -- GD_ERR_TIMEOUT of a gd_comm_* call (communicator dropped)
+
+
 def call_with_watchdog(fn, seconds, what):
     """Run ``fn()`` on a helper thread and wait at most ``seconds`` for it: the set-up stages of the library communicator
     are collectives, and a rank that never arrives must end in the all-or-nothing fallback, not in a hung job.  (The C ABI
@@ -106,7 +109,9 @@ def call_with_watchdog(fn, seconds, what):
     th.start()
     th.join(seconds)
     if th.is_alive():
-        raise StageTimeout("%s did not finish within %.0f s" % (what, seconds))
+        exc = StageTimeout("%s did not finish within %.0f s" % (what, seconds))
+        exc.thread = th  # still inside fn(): whatever fn works on must not be touched by anybody else
+        raise exc
     if "error" in box:
         raise box["error"]
     return box.get("value")
@@ -119,10 +124,32 @@ def comm_stage_timeout():
         lib_limit = float(os.environ.get("GDHIP_COMM_TIMEOUT_S", "") or 120.0)
     except ValueError:
         lib_limit = 120.0
+    # the library's own watchdog must come first: a stage that times out HERE means a call that did not return even after the
+    # library gave up on it, and the context it runs on is then treated as lost (mark_stuck).  A value from the environment
+    # below the library's limit would let this watchdog fire while the library is still legitimately waiting -- and the
+    # fallback would then use a context another thread is still working on -- so it is raised to the library's limit + 10 s
     try:
-        return float(os.environ["GETDIST_AMD_COMM_STAGE_TIMEOUT_S"])
+        return max(float(os.environ["GETDIST_AMD_COMM_STAGE_TIMEOUT_S"]), lib_limit + 10.0)
     except (KeyError, ValueError):
-        return lib_limit + 30.0  # the library's own watchdog comes first
+        return lib_limit + 30.0
+
+
+def mark_stuck(ctx):
+    """A gd_comm_* call on ``ctx`` outlived its watchdog: its helper thread may still be inside the C ABI on this context,
+    which is documented as not thread-safe.  Tell the library not to install a communicator should that call come back
+    (gd_comm_abandon -- the one call allowed from another thread) and flag the context so that no other work is put on it
+    (ColumnShare.upload and bench.py raise instead of falling back onto it)."""
+    ctx._comm_helper_stuck = True
+    abandon = getattr(ctx, "comm_abandon", None)
+    if abandon is not None:
+        try:
+            abandon()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def context_is_stuck(ctx):
+    return bool(getattr(ctx, "_comm_helper_stuck", False))
 
 
 def _everyone(dist, device, flag):
@@ -185,6 +212,7 @@ def init_library_comm(ctx, dist, rank, world, device=None, stage_timeout=None):
         ok = True
     except StageTimeout:
         ok, hung = False, True
+        mark_stuck(ctx)
     except Exception:
         ok = False
     if not everyone(ok):
@@ -197,6 +225,7 @@ def init_library_comm(ctx, dist, rank, world, device=None, stage_timeout=None):
         ok = bool(out[0] == world * (world + 1) / 2 and out[1] == world)
     except StageTimeout:
         ok, hung = False, True
+        mark_stuck(ctx)
     except Exception:
         ok = False
     if not everyone(ok):
@@ -235,6 +264,10 @@ class ColumnShare:
         if not self.tried:
             self.tried = True
             self.comm = init_library_comm(ctx, self.dist, self.rank, self.world, self.device)
+        if context_is_stuck(ctx):
+            # a set-up stage hung on THIS rank beyond the library's own watchdog: its helper thread may still be inside the
+            # C ABI on this context (it is not thread-safe), so the fallback upload must not run on it either
+            raise StageTimeout("a gd_comm_* set-up call never returned on rank %d: the context cannot be reused" % self.rank)
         full = samples if not callable(samples) else None
         if self.comm is None:
             if full is None:
@@ -273,6 +306,7 @@ class ColumnShare:
             logging.warning("column shards could not be exchanged over the library communicator on a rank: every rank uploads "
                             "the full sample array, the step's collectives stay with torch.distributed")
         if hung:
+            mark_stuck(ctx)
             raise StageTimeout("gd_comm_share_columns never returned on rank %d: the context cannot be reused" % self.rank)
         try:
             call_with_watchdog(ctx.comm_destroy, comm_stage_timeout(), "comm_destroy")

@@ -33,7 +33,9 @@ typedef enum gd_status {
     GD_ERR_EMPTY = -4,     /* "no samples in bin" -> DensitiesError (densities.py:83-84) */
     GD_ERR_SOLVER = -5,    /* bandwidth root-find failed -> fallback / BandwidthError (mcsamples.py:1258-1268) */
     GD_ERR_FFT = -6,       /* rocFFT failure */
-    GD_ERR_NODEVICE = -7   /* no HIP device visible */
+    GD_ERR_NODEVICE = -7,  /* no HIP device visible */
+    GD_ERR_TIMEOUT = -8    /* a collective / communicator set-up gave up waiting for a peer (the communicator was aborted and
+                              dropped: renegotiate over the host application's own channel) -> parallel.CommTimeout */
 } gd_status;
 
 /* ---------------------------------------------------------------- context / memory ------------- */
@@ -467,7 +469,8 @@ typedef struct gd_param2d {
     double sigma_range, err;     /* par.sigma_range, par.err */
     double mean, var;            /* weighted mean and variance of the column (the N_eff probe) */
     double neff;                 /* par.N_eff_kde; NaN = unknown (in/out) */
-    int32_t has_limits_bot, has_limits_top, periodic, owned;
+    int32_t has_limits_bot, has_limits_top, periodic;
+    int32_t owned; /* bit 0: this rank computes the parameter's N_eff; bit 1: no bandwidth warning / error for it (1D) */
 } gd_param2d;
 
 typedef struct gd_batch2d_settings {
@@ -519,10 +522,14 @@ int gd_density2d_batch(gd_ctx* ctx, gd_ctx* twin, const gd_batch2d_settings* set
  *          NaN when the scale is fixed) [3] smooth_1D in fine-bin units [4] window half-width
  *          [5] bits: 1 = "1D auto bandwidth failed" (solver returned None), 2 = very small or failed: rule-of-thumb
  *          fallback used, 4 = "fine_bins not large enough to well sample smoothing scale"
- *          [6] N_eff used (NaN when the scale is fixed) [7] GD_OK or GD_ERR_EMPTY ("no samples in bin") for the density.
+ *          [6] N_eff used (NaN when the scale is fixed) [7] GD_OK or GD_ERR_EMPTY ("no samples in bin") for the density
+ *          [8] with bit 2: the solver's own width that the fallback replaced (NaN = it returned None) -- the "h=" of the
+ *          reference's message "auto bandwidth for X very small or failed (h=..,N_eff=..). Using fallback (h=..)" (:1262).
+ *          A parameter whose record has (owned & 2) set is one the caller lists in no_warning_params (or a chi2 parameter
+ *          under no_warning_chi2_params, :1259-1261): the fallback is then taken without bit 2 and without an error.
  * Errors: GD_ERR_BADARG for setting errors ("Parameter range is <= 0", an unknown boundary_correction_order); GD_ERR_SOLVER
  *   when raise_on_bandwidth_errors is set and the fallback would have been used. */
-#define GD_BATCH1D_META 8
+#define GD_BATCH1D_META 9
 
 typedef struct gd_density1d_settings {
     int32_t fine_bins, num_bins, boundary_correction_order, mult_bias_correction_order;
@@ -576,6 +583,10 @@ int gd_comm_share_columns(gd_ctx* ctx, const int64_t* first_by_rank /* world + 1
 int gd_comm_unique_id(void* id128_out);
 int gd_comm_init(gd_ctx* ctx, int32_t world, int32_t rank, const void* id128);
 int gd_comm_info(gd_ctx* ctx, int32_t* world_out, int32_t* rank_out);
+/* gd_comm_abandon: the one entry point that may be called from ANOTHER thread while a gd_comm_* call of this context has not
+ * returned (a binding-side watchdog giving up on gd_comm_init): the stuck call, should it come back, installs no communicator
+ * and returns GD_ERR_TIMEOUT.  (The reference has no multi-process path; this belongs to the build's RCCL seam) */
+int gd_comm_abandon(gd_ctx* ctx);
 int gd_comm_destroy(gd_ctx* ctx);
 int gd_comm_allgather(gd_ctx* ctx, const double* send, int64_t count, double* recv);
 int gd_comm_allreduce_sum(gd_ctx* ctx, double* inout, int64_t count);

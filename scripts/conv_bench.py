@@ -1,6 +1,6 @@
 """The convolution stage alone on one batch of 136 random F = 256 histograms (S = 288 frames, bounded and unbounded pairs,
 linear boundary correction + one bias-correction round): for kernel traces of the LDS-transform kernels.
-python scripts/r04_conv_bench.py [reps]"""
+python scripts/conv_bench.py [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -2,11 +2,11 @@
 # One parameterised wrapper for the GPU-box sessions of a round:  gpurun -- 'bash scripts/gpu_session.sh <tag> <stage>...'
 # Stages write under gpurun_out/<tag>/ (merged back by gpurun); the summaries that are judged are copied to profiles/ by hand.
 #   tests        pytest -m gpu (whole suite)            tests:<expr>  pytest -m gpu -k <expr>
-#   conv         scripts/r04_conv_bench.py under rocprofv3 --kernel-trace --stats (one 136-pair batch of the convolution stage)
+#   conv         scripts/conv_bench.py under rocprofv3 --kernel-trace --stats (one 136-pair batch of the convolution stage)
 #   bench        bench.py --steps 40 --warmup 5 --no-cpu-baseline      benchfull   bench.py (the driver's invocation)
 #   trace        rocprofv3 kernel trace + stream timeline of 4 bench steps
 #   c2 / c4 / c5 scripts/run_configs.py <config> (+ kernel trace for c4)
-#   kernels      scripts/r04_kernels.py (isolated O(N) kernels)
+#   kernels      scripts/kernels_isolated.py (isolated O(N) kernels)
 #   pmcconv      scripts/pmc_conv.sh (counter passes of the convolution kernels)
 #   emulate      bench.py --emulate-world 2/4/8 (+ C5 / C4 forms when present)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -23,7 +23,7 @@ for stage in "$@"; do
         tests) timeout 900 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; tail -5 "$O/pytest.log" ;;
         tests:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${stage#tests:}" > "$O/pytest_k.log" 2>&1; tail -5 "$O/pytest_k.log" ;;
         conv)
-            prof conv python "$GRAFT_REPO_ROOT/scripts/r04_conv_bench.py" 8
+            prof conv python "$GRAFT_REPO_ROOT/scripts/conv_bench.py" 8
             grep "density2d" "$O/conv.log"; rm -rf "$O/prof_conv"
             python - "$O/conv_kernel_stats.csv" <<'PY'
 import csv, sys
@@ -43,8 +43,8 @@ PY
         c4)
             prof c4 python "$GRAFT_REPO_ROOT/scripts/run_configs.py" c4
             tail -3 "$O/c4.log" | cut -c1-400; rm -rf "$O/prof_c4"; head -8 "$O/c4_kernel_stats.csv" | cut -c1-170 ;;
-        kernels) timeout 900 python scripts/r04_kernels.py > "$O/kernels.log" 2>&1; cp gpurun_out/r04_kernels.json "$O/kernels.json" 2>/dev/null; tail -3 "$O/kernels.log" ;;
-        pmcconv) timeout 900 python scripts/pmc_kernels.py "$O/pmc_conv.json" -- python "$GRAFT_REPO_ROOT/scripts/r04_conv_bench.py" 4 2>&1 | tail -16 ;;
+        kernels) timeout 900 python scripts/kernels_isolated.py > "$O/kernels.log" 2>&1; cp gpurun_out/kernels_isolated.json "$O/kernels.json" 2>/dev/null; tail -3 "$O/kernels.log" ;;
+        pmcconv) timeout 900 python scripts/pmc_kernels.py "$O/pmc_conv.json" -- python "$GRAFT_REPO_ROOT/scripts/conv_bench.py" 4 2>&1 | tail -16 ;;
         pmcc4) timeout 900 python scripts/pmc_kernels.py "$O/pmc_c4.json" --match k_cov,k_col_pass -- python "$GRAFT_REPO_ROOT/scripts/run_configs.py" c4 2>&1 | tail -6 ;;
         emulate)
             for W in 2 4 8; do
@@ -61,7 +61,7 @@ PY
             cp "$(find "$O/prof_emu8" -name '*kernel_stats.csv' | head -1)" "$O/emu8_kernel_stats.csv"; rm -rf "$O/prof_emu8"
             head -120 "$O/emu8_stream_timeline.txt" | cut -c1-120; grep -v WARNING "$O/emu8.err" | tail -60 | cut -c1-120 ;;
         f64roof) (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_atomic_f64_roof "$GRAFT_REPO_ROOT/scripts/micro/lds_atomic_f64_roof.hip" && ./lds_atomic_f64_roof 400) > "$O/lds_atomic_f64_roof.txt" 2>&1; cat "$O/lds_atomic_f64_roof.txt" ;;
-        pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/r05_weighted_binning.py" 2>&1 | tail -8
+        pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/weighted_binning.py" 2>&1 | tail -8
               grep -E "SQ_|conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
         gloo2) GETDIST_AMD_LIVE_PMC=0 timeout 600 python bench.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_gloo2_shared_gpu.json" 2> "$O/bench_gloo2.err"; tail -c 900 "$O/bench_gloo2_shared_gpu.json"; tail -3 "$O/bench_gloo2.err" | cut -c1-300 ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;

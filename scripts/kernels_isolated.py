@@ -1,8 +1,8 @@
 """
-Isolated kernel timings of round 4 on the MI355X (HIP events through the C ABI):  python scripts/r04_kernels.py
+Isolated kernel timings on the MI355X (HIP events through the C ABI):  python scripts/kernels_isolated.py
   the O(N) kernels of a C3 step one by one (statistics, quantile select, N_eff lag sums, pre-binning, byte-index binning,
   sheared min/max + re-binning), the optimiser in its two stages with both DCT routes, real-weight and integer-weight 2D
-  binning of the whole triangle.  Writes gpurun_out/r04_kernels.json.
+  binning of the whole triangle.  Writes gpurun_out/kernels_isolated.json.
 """
 import json
 import os
@@ -100,7 +100,7 @@ def main():
             mc2.ctx, lambda: mc2.ctx.hist2d_prebinned([idx[a] for a, b in allp], [idx[b] for a, b in allp], F, out=o2), 3)
         mc2.ctx.close()
     os.makedirs(OUT, exist_ok=True)
-    json.dump(res, open(os.path.join(OUT, "r04_kernels.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(OUT, "kernels_isolated.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 

@@ -81,6 +81,26 @@ os.environ["GDHIP_COMM_TIMEOUT_S"] = "120"
 time.sleep(3.5)  # (the abandoned helper finishes and aborts the communicator it obtained)
 comm = parallel.init_library_comm(mc.ctx, dist, 0, 1)  # and the next set-up works
 assert comm is not None and np.array_equal(comm.allreduce_sum(v), v)
+# a host-vector collective whose wait gives up (GDHIP_COMM_INJECT_WAIT_TIMEOUT: as after GDHIP_COMM_[STEADY_]TIMEOUT_S with a
+# missing peer): a distinct status (GD_ERR_TIMEOUT -> parallel.CommTimeout), the communicator aborted and dropped, the stream
+# drained and the pending result deliveries forgotten -- the caller's vector (released by the binding when the error is
+# raised) is not written afterwards, and the NEXT synchronising call on the same context (an upload) works
+import gc
+
+os.environ["GDHIP_COMM_INJECT_WAIT_TIMEOUT"] = "1"
+try:
+    comm.allgather(v)
+    raise AssertionError("the injected timeout did not surface")
+except parallel.CommTimeout as exc:
+    assert exc.code == -8 and "aborted" in str(exc)
+del os.environ["GDHIP_COMM_INJECT_WAIT_TIMEOUT"]
+gc.collect()
+world_after, _ = mc.ctx.comm_info()
+assert world_after == 0  # dropped by the library
+mc.ctx.upload(s, w)  # gd_upload -> gd_stream_sync on the same context: nothing left to deliver into freed memory
+mc.ctx.sync()
+comm = parallel.init_library_comm(mc.ctx, dist, 0, 1)  # and a fresh communicator can be made
+assert comm is not None and np.array_equal(comm.allreduce_sum(v), v)
 mc.ctx.comm_destroy()
 dist.destroy_process_group()
 print("nccl smoke ok (torch.distributed + gd_comm_*): torch %s, %d densities four times, bit-equal; RCCL = %s" % (torch.__version__, len(d1), path))

@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--weighted", action="store_true", help="real weights w ~ Exp(1) (the block recipe's weighted variant)")
     ap.add_argument("--max-pairs", type=int, default=0, help="testing: only the first K pairs")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity_census_1e7.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_census_1e7.json"))
     args = ap.parse_args()
     _quiet()
     from getdist_amd import synth

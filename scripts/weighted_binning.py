@@ -1,6 +1,6 @@
 """The real-weight 2D binning of a whole triangle alone (50 columns, 1225 pairs, N = 1e7, w ~ Exp(1)), for kernel traces /
 counter passes.
-python scripts/r05_weighted_binning.py [reps]"""
+python scripts/weighted_binning.py [reps]"""
 import os
 import sys
 

@@ -443,7 +443,7 @@ class HarnessContext(FakeContext):
         B, F = len(cols32), int(settings.fine_bins)
         P = np.zeros((B, F))
         hist = np.zeros((B, F)) if want_hist else None
-        meta = np.zeros((B, 8))
+        meta = np.zeros((B, 9))
         err = C.create_string_buffer(512)
         lib.gdt_density1d_batch.argtypes = [_p, _p, _p, _p, _p, _p, _i32, _pi32, _i32, _pd, _pd, _pd, C.c_char_p, _i32]
         rc = lib.gdt_density1d_batch(C.byref(ops_struct()), C.byref(ops1d_struct()), self.state, self.handle, C.byref(settings),

@@ -867,3 +867,53 @@ def test_bench_cpu_baseline_and_all_pairs_census_run_on_the_numpy_double(tmp_pat
     full = par["full_size_census"]
     assert full["ran"] and full["pairs_compared"] == 28 and full["pairs_above_1e_6"] == 0 and full["N"] == 20000
     assert line["cpu_baseline"]["full_triangle_small_n"]["parity_census"]["pairs_compared"] == 28
+
+
+def test_comm_stage_timeout_never_undercuts_the_library_watchdog(monkeypatch):
+    """parallel.comm_stage_timeout: the Python-side watchdog of a communicator set-up stage must fire AFTER the library's own
+    (GDHIP_COMM_TIMEOUT_S) -- a value from the environment below it is raised, since a Python-side timeout is taken to mean
+    "the call did not even return after the library gave up" and the context is then treated as lost."""
+    from getdist_amd import parallel
+
+    monkeypatch.setenv("GDHIP_COMM_TIMEOUT_S", "60")
+    monkeypatch.setenv("GETDIST_AMD_COMM_STAGE_TIMEOUT_S", "5")
+    assert parallel.comm_stage_timeout() == 70.0
+    monkeypatch.setenv("GETDIST_AMD_COMM_STAGE_TIMEOUT_S", "500")
+    assert parallel.comm_stage_timeout() == 500.0
+    monkeypatch.delenv("GETDIST_AMD_COMM_STAGE_TIMEOUT_S")
+    assert parallel.comm_stage_timeout() == 90.0
+    monkeypatch.delenv("GDHIP_COMM_TIMEOUT_S")
+    assert parallel.comm_stage_timeout() == 150.0
+
+    class Ctx:
+        abandoned = 0
+
+        def comm_abandon(self):
+            self.abandoned += 1
+
+    c = Ctx()
+    assert not parallel.context_is_stuck(c)
+    parallel.mark_stuck(c)
+    assert parallel.context_is_stuck(c) and c.abandoned == 1
+
+
+def test_like_stats_column_id_does_not_survive_a_failure():
+    """_setLikeStats hands the resident loglikes column to _setNDLimits through instance state; the id is reset whatever
+    happens (a later _setNDLimits must upload the CURRENT loglikes, not read a slot a re-upload has rewritten)."""
+    import fake_ctx
+    from getdist_amd.mcsamples import MCSamples
+
+    rng = np.random.default_rng(5)
+    s = rng.normal(size=(4000, 3))
+    mc = MCSamples(samples=s, loglikes=0.5 * np.sum(s**2, axis=1), names=["a", "b", "c"], _context_factory=fake_ctx.FakeContext)
+
+    def boom():
+        raise RuntimeError("injected")
+
+    mc._setNDLimits = boom
+    try:
+        mc._setLikeStats()
+        raise AssertionError("the injected failure did not surface")
+    except RuntimeError:
+        pass
+    assert mc._loglikes_col is None

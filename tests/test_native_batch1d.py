@@ -115,6 +115,9 @@ def test_smoothing_scalars_equal_the_python_expressions():
     class Host:  # the two methods under test need these attributes only
         raise_on_bandwidth_errors = False
         mult_bias_correction_order = 1
+        no_warning_params = []
+        no_warning_chi2_params = True
+        _no_bandwidth_warning = MCSamples._no_bandwidth_warning
 
     seen = set()
     for t in range(4000):
@@ -229,3 +232,63 @@ def test_native_1d_route_solver_failure_falls_back_or_raises(zoo, monkeypatch, c
     with pytest.raises(BandwidthError) as e:
         strict.get1DDensities([2, 0])
     assert fx["names"][2] in str(e.value) and "column" not in str(e.value)
+
+
+def test_native_1d_route_fallback_messages_and_no_warning_params(zoo, monkeypatch, caplog):
+    """The messages of getAutoBandwidth1D (mcsamples.py:1259-1266) character by character on both routes: the solver's own
+    width, N_eff and the fallback width in the warning and in the BandwidthError; a parameter in ``no_warning_params`` (or a
+    chi2 / minuslog parameter under ``no_warning_chi2_params``) neither warns nor raises and still takes the fallback."""
+    import fake_ctx
+    from getdist_amd.mcsamples import BandwidthError
+
+    fx = zoo["c1_bounded"]
+    real = fake_ctx.FakeContext.isj1d
+
+    def failing(self, hist, neff):
+        h, status = real(self, hist, neff)
+        status[0] = -5  # solver returned None for the first histogram
+        if len(h) > 1:
+            h[1] = 1e-9  # "very small" for the second
+        return h, status
+
+    monkeypatch.setattr(fake_ctx.FakeContext, "isj1d", failing)
+
+    def messages(ctxcls, **attrs):
+        mc = make(fx, ctxcls)
+        for k, v in attrs.items():
+            setattr(mc, k, v)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            d = mc.get1DDensities([2, 0])
+        return mc, d, [r.getMessage() for r in caplog.records if "very small or failed" in r.getMessage()]
+
+    ref, dref, mref = messages(nb.PlainContext)
+    mc, dnat, mnat = messages(nb.HarnessContext)
+    assert len(mref) == 2 and mnat == mref  # the same text, digits included
+    p2, p0 = ref.paramNames.names[2], ref.paramNames.names[0]
+    assert mref[0] == f"auto bandwidth for {p2.name} very small or failed (h=None,N_eff={p2.N_eff_kde}). Using fallback (h={p2.kde_h})"
+    assert mref[1] == f"auto bandwidth for {p0.name} very small or failed (h=1e-09,N_eff={p0.N_eff_kde}). Using fallback (h={p0.kde_h})"
+    same1d(dnat, dref)
+    # the raise carries the same message on both routes
+    texts = []
+    for ctxcls in (nb.PlainContext, nb.HarnessContext):
+        strict = make(fx, ctxcls)
+        strict.raise_on_bandwidth_errors = True
+        with pytest.raises(BandwidthError) as e:
+            strict.get1DDensities([2, 0])
+        texts.append(str(e.value))
+    assert texts[0] == texts[1] == mref[0]
+    # silenced parameters: no warning, no error (even with raise_on_bandwidth_errors), the same fallback density
+    quiet = [fx["names"][2], fx["names"][0]]
+    for ctxcls in (nb.PlainContext, nb.HarnessContext):
+        mq, dq, msgs = messages(ctxcls, no_warning_params=quiet, raise_on_bandwidth_errors=True)
+        assert msgs == []
+        same1d(dq, dref)
+    # one silenced, one not: the other one still raises, naming itself
+    for ctxcls in (nb.PlainContext, nb.HarnessContext):
+        part = make(fx, ctxcls)
+        part.no_warning_params = [fx["names"][2]]
+        part.raise_on_bandwidth_errors = True
+        with pytest.raises(BandwidthError) as e:
+            part.get1DDensities([2, 0])
+        assert str(e.value) == mref[1]

@@ -282,6 +282,18 @@ COMM_WORKER = textwrap.dedent("""
         t0 = time.time()
         assert parallel.init_library_comm(ctx, dist, rank, world, stage_timeout=1.5) is None, (stage, rank)
         assert time.time() - t0 < 30.0, (stage, rank)
+        # a gd_comm_* call that outlived its watchdog may still be inside the library on that context: the context is
+        # flagged, and the fallback upload refuses to run on it (round 6, advisor finding)
+        # (hang_sum: the peer's all-reduce has no partner and outlives its watchdog too)
+        assert parallel.context_is_stuck(ctx) == (stage == "hang_sum" or (rank == bad_rank and stage == "hang_init")), (stage, rank)
+        if parallel.context_is_stuck(ctx):
+            share = parallel.ColumnShare(dist, rank, world)
+            share.tried = True
+            try:
+                share.upload(ctx, np.zeros((4, 2)), None)
+                raise AssertionError("a stuck context was reused")
+            except parallel.StageTimeout:
+                pass
     # ... and torch.distributed itself is still in step afterwards
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
