@@ -77,6 +77,7 @@ SIGNATURES = {
     "gd_col_stats": (C.c_int, [_p, _i64, _i64, _pd]),
     "gd_cov": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _pd, _pd, _pd]),
     "gd_quantiles": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd]),
+    "gd_quantiles_mm_probe": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd, _pd, _pd, _pd, C.POINTER(C.c_int32)]),
     "gd_quantiles_mm": (C.c_int, [_p, _pi32, _i32, _i64, _i64, _pd, _i32, _pd, _pd]),
     "gd_autocov_lags": (C.c_int, [_p, _i32, _f64, _i64, _i32, _pd]),
     "gd_kde_lag_sums": (C.c_int, [_p, _i32, _f64, _pi64, _i32, _pd]),
@@ -512,6 +513,21 @@ class Context:
         self._check(self.lib.gd_quantiles_mm(self.h, _ip(cols), len(cols), lo, self.N if hi is None else hi, _dp(targets),
                                              targets.shape[1], None if mm is None else _dp(mm), _dp(out)))
         return out
+
+    def quantiles_probe(self, cols, targets, minmax, means):
+        """gd_quantiles_mm_probe over whole columns: (quantiles, lag probe or None).  The probe -- the first 8
+        autocovariance lag sums of the columns about ``means``, what autocov_lags_batch(cols, means, 0, 8) returns -- rides on
+        the select's counting pass; None when the select took a path without it."""
+        cols = _i32arr(cols)
+        targets = _f64arr(targets).reshape(len(cols), -1)
+        out = np.zeros_like(targets)
+        mm = _f64arr(minmax).reshape(len(cols), 2)
+        means = _f64arr(means)
+        probe = np.zeros((len(cols), 8))
+        done = C.c_int32(0)
+        self._check(self.lib.gd_quantiles_mm_probe(self.h, _ip(cols), len(cols), 0, self.N, _dp(targets), targets.shape[1], _dp(mm),
+                                                   _dp(out), _dp(means), _dp(probe), C.byref(done)))
+        return out, (probe if done.value else None)
 
     def autocov_lags(self, col, mean, k0, nlags):
         out = np.zeros(nlags)

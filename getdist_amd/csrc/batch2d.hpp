@@ -19,6 +19,8 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -480,6 +482,11 @@ struct Call {
     std::vector<int32_t> flags, group;
     std::vector<void*> call_blocks;  // everything to release once the copies have landed
     std::mutex enq_mu;
+    // three-stream choreography: the N_eff launch (2000 resident blocks for ~3 ms: whatever is enqueued behind it on another
+    // stream waits for a wave slot) holds back until the binning thread is about to enqueue its chain -- the binning is on
+    // the critical path, the N_eff values are needed after it (round 6: a race the binning used to win by ~0.2 ms)
+    std::atomic<int> bin_launching{0};
+    bool hold_neff_for_binning = false;
     int64_t grid_off = 0;
     int status_at = 0;
     int batch_no = 0;
@@ -604,6 +611,12 @@ struct Call {
         const int L = (int)lags.size();
         std::vector<double> sums((size_t)m * L);
         mark("neff: probe done");
+        if (hold_neff_for_binning) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!bin_launching.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) std::this_thread::yield();
+            if (bin_launching.load()) std::this_thread::sleep_for(std::chrono::microseconds(120));  // (its launches go out)
+            mark("neff: binning chain enqueued");
+        }
         GDB_DEV(h, ops.kde_lag_sums_batch(h, todo.data(), m, inv4s2.data(), lags.data(), L, sums.data()));
         mark("neff: lag sums done");
         const NeffInput in{N, s.norm, s.sum_w2};
@@ -732,6 +745,7 @@ struct Call {
                 if (!d) return dev_fail(rc, h);
                 std::vector<int64_t> bad(todo.size() + 1, 0);
                 mark("binning: prebin8 + hist2d launch", (int)todo.size(), B);
+                bin_launching.store(1);
                 const int e = ops.prebin8_hist2d(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), bufs.data(), bad.data(), B,
                                                  ix.data(), iy.data(), d);
                 mark("binning: prebin8 + hist2d done");
@@ -750,6 +764,7 @@ struct Call {
                 pool.give(d);
                 if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (else: the u16 / u32 path below redoes the class)
             }
+            bin_launching.store(1);  // (this class enqueues as it goes)
             std::vector<const void*> ix(B), iy(B);
             for (int q = 0; q < B; ++q) {
                 void* p;
@@ -772,6 +787,7 @@ struct Call {
             std::lock_guard<std::mutex> g(enq_mu);
             hists[F] = d;
         }
+        bin_launching.store(1);
         return 0;
     }
 
@@ -1329,6 +1345,8 @@ struct Call {
             aux = st.aux;
         }
         std::future<int> neff_f, bin_f, shear_f;
+        bin_launching.store(0);
+        hold_neff_for_binning = overlap && need_neff && unit_weights && !getenv("GDHIP_BATCH_NO_NEFF_HOLD");
         if (overlap && need_neff)
             neff_f = std::async(std::launch::async, [this] {
                 ops.bind_thread(h);

@@ -560,6 +560,240 @@ __global__ void __launch_bounds__(256) k_prebin8_batch(const PrebinCol8* __restr
     if (nbad) atomicAdd(&bad[blockIdx.y], (unsigned long long)nbad);
 }
 
+// ---- index columns from the BUCKET columns of the quantile select (round 6; ctx.hpp BucketCols) ----------------------------
+// The select's counting pass left bucket = clamp((int)((x - mn) scale), 0, nb - 1) of every sample (2 bytes).  The bin index
+// ix = (int)((x - binmin) / width + 0.5) is a non-decreasing function of x (a correctly rounded quotient by a positive
+// divisor, an addition, a truncation), so a bucket whose whole x interval -- widened on both sides by far more than the
+// rounding of the bucket arithmetic -- has ONE index at both ends has that index for every sample in it: a table look-up
+// replaces the 8-byte read and the division.  Buckets that straddle a bin edge (F - 1 edges among nb buckets: about 1 %
+// of the samples), the two end buckets (they also hold whatever was clamped) and anything that maps outside [0, F) take
+// the exact fp64 route on the sample itself, so every index is bit-equal to k_prebin8_batch's / k_prebin_batch's.
+struct PrebinColB {
+    const double* x;
+    const unsigned short* bq;
+    void* idx;
+    double binmin, width;
+    double mn, inv_scale, slack;  // bucket b holds x in [mn + b inv_scale, mn + (b + 1) inv_scale), up to rounding
+    int nb, pad;
+};
+
+// lut[c][b] = the bin index of every sample of bucket b, or 0xFFFF = decide on the sample.  grid (nbmax / 256, ncols)
+__global__ void __launch_bounds__(256) k_bucket_lut(const PrebinColB* __restrict__ colsv, int F, int nbmax,
+                                                    unsigned short* __restrict__ lut) {
+    const PrebinColB C = colsv[blockIdx.y];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= C.nb) return;
+    unsigned short v = 0xFFFF;
+    if (b > 0 && b < C.nb - 1) {
+        const BinDiv bd = make_bindiv(C.binmin, C.width);
+        const double x_lo = (C.mn + ((double)b - 1e-3) * C.inv_scale) - C.slack;
+        const double x_hi = (C.mn + ((double)b + 1.0 + 1e-3) * C.inv_scale) + C.slack;
+        const int a = bin_round(x_lo, bd), c = bin_round(x_hi, bd);
+        if (a == c && (unsigned)a < (unsigned)F) v = (unsigned short)a;
+    }
+    lut[(int64_t)blockIdx.y * nbmax + b] = v;
+}
+
+// OUT8: byte indices + out-of-range count (k_prebin8_batch's contract); else u16 indices with the 0xFFFF sentinel
+// (k_prebin_batch's).  grid (blocks, ncols), 512 threads, the column's table in LDS; block b owns the rows
+// [b R, (b + 1) R) (R a multiple of 8).  A sample whose bucket does not decide its bin is NOT resolved here -- a dependent
+// 8-byte load inside the loop would expose one memory latency per wave and iteration (nearly every 512-sample iteration of a
+// wave holds one) -- its row goes to the block's list and k_prebin_fix settles the lists afterwards, all loads independent.
+template <bool OUT8>
+__global__ void __launch_bounds__(512) k_prebin_bq(const PrebinColB* __restrict__ colsv, int64_t N, int64_t R, int cap, int nbmax,
+                                                   const unsigned short* __restrict__ lut, unsigned int* __restrict__ lists,
+                                                   int* __restrict__ counts) {
+    extern __shared__ unsigned short slut[];
+    __shared__ int nlist;
+    const PrebinColB C = colsv[blockIdx.y];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(lut + (int64_t)blockIdx.y * nbmax);
+        uint4* dst = reinterpret_cast<uint4*>(slut);
+        for (int i = threadIdx.x; i < C.nb / 8; i += 512) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    const int mask = C.nb - 1;
+    unsigned int* mylist = lists + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * cap;
+    const int64_t g_lo = (int64_t)blockIdx.x * R / 8;
+    int64_t g_hi = g_lo + R / 8;
+    if (g_hi > N / 8) g_hi = N / 8;  // whole groups of 8 only; the last N % 8 rows are k_prebin_fix's
+    auto group = [&](const uint4& v, int64_t g) {
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned r = slut[(wd[e >> 1] >> (16 * (e & 1))) & mask];
+            if (r == 0xFFFFu) {
+                const int pos = atomicAdd(&nlist, 1);
+                if (pos < cap) mylist[pos] = (unsigned)(8 * g + e);
+                r = 0;
+            }
+            o[e] = r;
+        }
+        if (OUT8) {
+            uint2 pk;
+            pk.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+            pk.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+            *reinterpret_cast<uint2*>((unsigned char*)C.idx + 8 * g) = pk;
+        } else {
+            uint4 pk;
+            pk.x = o[0] | (o[1] << 16), pk.y = o[2] | (o[3] << 16), pk.z = o[4] | (o[5] << 16), pk.w = o[6] | (o[7] << 16);
+            *reinterpret_cast<uint4*>((unsigned short*)C.idx + 8 * g) = pk;
+        }
+    };
+    constexpr int U = 4;
+    int64_t i = g_lo + threadIdx.x;
+    for (; i + (U - 1) * 512 < g_hi; i += U * 512) {
+        uint4 v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = gload_u4(C.bq + 8 * (i + q * 512));
+#pragma unroll
+        for (int q = 0; q < U; ++q) group(v[q], i + q * 512);
+    }
+    for (; i < g_hi; i += 512) group(gload_u4(C.bq + 8 * i), i);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = nlist;
+}
+
+// settles what k_prebin_bq left open, with the exact fp64 expression on the sample itself: the rows of each block's list (a
+// list that overflowed -- heavily tied data sitting on a bin edge -- means the block's whole row range is redone), and the
+// last N % 8 rows.  Same grid as k_prebin_bq.
+template <bool OUT8>
+__global__ void __launch_bounds__(256) k_prebin_fix(const PrebinColB* __restrict__ colsv, int64_t N, int64_t R, int cap, int F,
+                                                    const unsigned int* __restrict__ lists, const int* __restrict__ counts,
+                                                    unsigned long long* __restrict__ bad) {
+    const PrebinColB C = colsv[blockIdx.y];
+    const BinDiv bd = make_bindiv(C.binmin, C.width);
+    unsigned nbad = 0;
+    auto settle = [&](int64_t row) {
+        const int a = bin_round(C.x[row], bd);
+        if (OUT8) {
+            nbad += ((unsigned)a >= (unsigned)F);
+            ((unsigned char*)C.idx)[row] = (unsigned char)a;
+        } else {
+            ((unsigned short*)C.idx)[row] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
+        }
+    };
+    const int cnt = counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x];
+    if (cnt <= cap) {
+        const unsigned int* mylist = lists + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * cap;
+        for (int k = threadIdx.x; k < cnt; k += 256) settle((int64_t)mylist[k]);
+    } else {
+        const int64_t lo = (int64_t)blockIdx.x * R;
+        int64_t hi = lo + R;
+        if (hi > N / 8 * 8) hi = N / 8 * 8;
+        for (int64_t r = lo + threadIdx.x; r < hi; r += 256) settle(r);
+    }
+    if (blockIdx.x == gridDim.x - 1)
+        for (int64_t r = N / 8 * 8 + threadIdx.x; r < N; r += 256) settle(r);
+    if (OUT8 && nbad) atomicAdd(&bad[blockIdx.y], (unsigned long long)nbad);
+}
+
+// Host side of the bucket route: which of the requested columns have valid bucket columns, their records, and the launches.
+// `which[c]` = slot among the bucket-route columns or -1.  Everything is enqueued on ctx->stream; the records and tables
+// live in `base` (device scratch the caller reserved: bucket_route_bytes()).
+struct BucketRoute {
+    std::vector<PrebinColB> recs;
+    std::vector<int> slot_of;  // per requested column
+    int nbmax = 0;
+};
+static BucketRoute bucket_route(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const double* binmin, const double* width,
+                                void* const* d_idx) {
+    BucketRoute R;
+    R.slot_of.assign((size_t)ncols, -1);
+    if (!ctx->bq || getenv("GDHIP_NO_BUCKET_COLS")) return R;
+    {
+        // the route costs three small launches and a table per column before it saves anything: below a handful of columns
+        // (the single index columns of an up-scaled grid class) the fp64 kernel, one launch, is quicker (measured: 12 columns
+        // 0.33 against 0.25 ms, 50 columns 0.69 against 0.93 ms)
+        const char* e = getenv("GDHIP_BUCKET_ROUTE_MIN");
+        const int min_cols = e ? atoi(e) : 24;
+        if (ncols < min_cols) return R;
+    }
+    BucketCols& B = *ctx->bq;
+    std::lock_guard<std::mutex> g(B.mu);
+    if (!B.buf || B.ld != ctx->ld) return R;
+    for (int c = 0; c < ncols; ++c) {
+        const int col = cols[c];
+        if (col < 0 || col >= B.n || B.nb[col] <= 0) continue;
+        PrebinColB r;
+        memset(&r, 0, sizeof r);
+        r.x = ctx->cols + (int64_t)col * ctx->ld;
+        r.bq = B.buf + (int64_t)col * B.ld;
+        r.idx = d_idx[c];
+        r.binmin = binmin[c], r.width = width[c];
+        r.mn = B.mn[col];
+        r.inv_scale = 1.0 / B.scale[col];
+        const double mx = r.mn + (double)B.nb[col] * r.inv_scale;
+        r.slack = 8.0 * 2.220446049250313e-16 * fmax(fabs(r.mn), fabs(mx));
+        r.nb = B.nb[col];
+        if (!(r.inv_scale > 0) || !std::isfinite(r.inv_scale) || !std::isfinite(r.slack)) continue;
+        R.slot_of[c] = (int)R.recs.size();
+        R.recs.push_back(r);
+        if (r.nb > R.nbmax) R.nbmax = r.nb;
+    }
+    return R;
+}
+// launch shape of the bucket route: blocks per column and rows per block (a multiple of 4096: whole iterations of 512
+// threads x 8 rows), list capacity per block
+struct BucketShape {
+    int nblk;
+    int64_t R;
+    int cap;
+};
+static BucketShape bucket_shape(const gd_ctx* ctx, int nc) {
+    BucketShape S;
+    int nblk = (4 * ctx->cu_count + nc - 1) / nc;  // two blocks per CU hold their tables
+    int64_t R = (ctx->N + nblk - 1) / nblk;
+    if (R < 131072) R = 131072;  // a block's 64-KB table against >= 256 KB of buckets
+    R = (R + 4095) / 4096 * 4096;
+    nblk = (int)((ctx->N + R - 1) / R);
+    if (nblk < 1) nblk = 1;
+    S.nblk = nblk, S.R = R, S.cap = (int)(R / 8);
+    if (const char* e = getenv("GDHIP_BUCKET_LIST_CAP"))  // test hook: tiny lists, every block takes the redo path
+        if (atoi(e) > 0 && atoi(e) < S.cap) S.cap = atoi(e);
+    return S;
+}
+static int64_t bucket_route_bytes(const gd_ctx* ctx, const BucketRoute& R) {
+    if (R.recs.empty()) return 0;
+    const int nc = (int)R.recs.size();
+    const BucketShape S = bucket_shape(ctx, nc);
+    return ((int64_t)nc * sizeof(PrebinColB) + 255) / 256 * 256 + ((int64_t)nc * R.nbmax * 2 + 255) / 256 * 256 +
+           ((int64_t)nc * 8 + 255) / 256 * 256 + ((int64_t)nc * S.nblk * 4 + 255) / 256 * 256 + (int64_t)nc * S.nblk * S.cap * 4 + 256;
+}
+// the out-of-range counters (R.recs.size() of them, zeroed here) come back through bad_dev
+template <bool OUT8>
+static int bucket_route_launch(gd_ctx* ctx, const BucketRoute& R, char* base, int F, unsigned long long** bad_dev) {
+    const int nc = (int)R.recs.size();
+    const BucketShape S = bucket_shape(ctx, nc);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const int64_t o_recs = take((int64_t)nc * sizeof(PrebinColB)), o_lut = take((int64_t)nc * R.nbmax * 2), o_bad = take((int64_t)nc * 8),
+                  o_cnt = take((int64_t)nc * S.nblk * 4), o_list = take((int64_t)nc * S.nblk * S.cap * 4);
+    PrebinColB* d_recs = (PrebinColB*)(base + o_recs);
+    unsigned short* d_lut = (unsigned short*)(base + o_lut);
+    unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
+    int* d_cnt = (int*)(base + o_cnt);
+    unsigned int* d_list = (unsigned int*)(base + o_list);
+    GD_TRY(gd_h2d(ctx, d_recs, R.recs.data(), (size_t)nc * sizeof(PrebinColB)));
+    GD_HIP(hipMemsetAsync(d_bad, 0, (size_t)nc * 8, ctx->stream));
+    k_bucket_lut<<<dim3(R.nbmax / 256, nc), 256, 0, ctx->stream>>>(d_recs, F, R.nbmax, d_lut);
+    GD_KERNEL_CHECK();
+    const size_t lds = (size_t)R.nbmax * 2;
+    GD_HIP(hipFuncSetAttribute((const void*)k_prebin_bq<OUT8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_prebin_bq<OUT8><<<dim3(S.nblk, nc), 512, lds, ctx->stream>>>(d_recs, ctx->N, S.R, S.cap, R.nbmax, d_lut, d_list, d_cnt);
+    GD_KERNEL_CHECK();
+    k_prebin_fix<OUT8><<<dim3(S.nblk, nc), 256, 0, ctx->stream>>>(d_recs, ctx->N, S.R, S.cap, F, d_list, d_cnt, d_bad);
+    GD_KERNEL_CHECK();
+    *bad_dev = d_bad;
+    return GD_OK;
+}
+
 // ---- fused fp64 index + binning with packed 16-bit counters (unit weights): one stripe at F <= 256 --------------------
 // MODE 0: rounded indices of two columns; MODE 1: the sheared, truncating indices of kde.bin_samples.  A block owns a
 // (pair, chunk of rows, stripe of R rows); its packed counters go to scratch and k_p16_reduce adds the chunks, so no
@@ -1051,6 +1285,16 @@ int gd_prebin(gd_ctx* ctx, int32_t col, double binmin, double width, int32_t F, 
     GD_REQUIRE(ctx && d_idx_u16, "bad argument");
     GD_REQUIRE(ctx->cols && col >= 0 && col < ctx->n + GD_EXTRA_COLS, "bad column");
     GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
+    {
+        void* const idx1[1] = {d_idx_u16};
+        const BucketRoute R = bucket_route(ctx, &col, 1, &binmin, &width, idx1);
+        if (!R.recs.empty()) {  // from the column's 2-byte buckets (stream-ordered like the kernel below: no wait here)
+            char* base = (char*)gd_scratch2(ctx, bucket_route_bytes(ctx, R));
+            if (!base) return GD_ERR_NOMEM;
+            unsigned long long* unused = nullptr;
+            return bucket_route_launch<false>(ctx, R, base, F, &unused);
+        }
+    }
     const double* x = ctx->cols + (int64_t)col * ctx->ld;
     k_prebin<<<8 * ctx->cu_count, 256, 0, ctx->stream>>>(x, ctx->N, binmin, width, F, (unsigned short*)d_idx_u16);
     GD_KERNEL_CHECK();
@@ -1062,22 +1306,36 @@ int gd_prebin_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doubl
     GD_REQUIRE(ctx && cols && binmin && width && d_idx_u16 && ncols > 0, "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     GD_REQUIRE(F >= 2 && F < 65535, "F out of range for u16 indices");
-    std::vector<PrebinCol> hc((size_t)ncols);
-    for (int c = 0; c < ncols; ++c) {
+    for (int c = 0; c < ncols; ++c)
         GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_u16[c], "bad column / null index buffer");
-        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
-        hc[c].idx = (unsigned short*)d_idx_u16[c];
-        hc[c].binmin = binmin[c];
-        hc[c].width = width[c];
+    const BucketRoute R = bucket_route(ctx, cols, ncols, binmin, width, d_idx_u16);
+    std::vector<PrebinCol> hc;
+    for (int c = 0; c < ncols; ++c) {
+        if (R.slot_of[c] >= 0) continue;
+        PrebinCol r;
+        r.x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        r.idx = (unsigned short*)d_idx_u16[c];
+        r.binmin = binmin[c];
+        r.width = width[c];
+        hc.push_back(r);
     }
-    PrebinCol* d_c = (PrebinCol*)gd_scratch2(ctx, (int64_t)ncols * sizeof(PrebinCol));
-    if (!d_c) return GD_ERR_NOMEM;
-    GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol)));
-    int nblk = (int)((ctx->N / 8 + 255) / 256);  // one 8-sample iteration per thread at most, like the single-column kernel
-    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
-    if (nblk < 1) nblk = 1;
-    k_prebin_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F);
-    GD_KERNEL_CHECK();
+    const int nfp = (int)hc.size();
+    const int64_t o_route = ((int64_t)nfp * sizeof(PrebinCol) + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_route + bucket_route_bytes(ctx, R));
+    if (!base) return GD_ERR_NOMEM;
+    PrebinCol* d_c = (PrebinCol*)base;
+    if (nfp) {
+        GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)nfp * sizeof(PrebinCol)));
+        int nblk = (int)((ctx->N / 8 + 255) / 256);  // one 8-sample iteration per thread at most, like the single-column kernel
+        if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+        if (nblk < 1) nblk = 1;
+        k_prebin_batch<<<dim3(nblk, nfp), 256, 0, ctx->stream>>>(d_c, ctx->N, F);
+        GD_KERNEL_CHECK();
+    }
+    if (!R.recs.empty()) {
+        unsigned long long* unused = nullptr;
+        GD_TRY(bucket_route_launch<false>(ctx, R, base + o_route, F, &unused));
+    }
     GD_TRY(gd_stream_sync(ctx));  // hc / d_c lifetime
     return GD_OK;
 }
@@ -1232,30 +1490,44 @@ int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doub
     GD_REQUIRE(ctx && cols && binmin && width && d_idx_out && bad_out && ncols > 0, "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     GD_REQUIRE(F >= 2 && F <= 256, "byte indices need fine_bins_2D <= 256");
-    std::vector<PrebinCol8> hc((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
+    // columns whose bucket columns are valid (the quantile select has walked them) are binned from those 2 bytes per sample
+    const BucketRoute R = bucket_route(ctx, cols, ncols, binmin, width, d_idx_out);
+    std::vector<PrebinCol8> hc;
+    std::vector<int> fp_of((size_t)ncols, -1);
     for (int c = 0; c < ncols; ++c) {
-        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
-        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
-        hc[c].idx = (unsigned char*)d_idx_out[c];
-        hc[c].binmin = binmin[c];
-        hc[c].width = width[c];
+        if (R.slot_of[c] >= 0) continue;
+        PrebinCol8 r;
+        r.x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        r.idx = (unsigned char*)d_idx_out[c];
+        r.binmin = binmin[c];
+        r.width = width[c];
+        fp_of[c] = (int)hc.size();
+        hc.push_back(r);
     }
-    const int64_t o_bad = ((int64_t)ncols * sizeof(PrebinCol8) + 255) / 256 * 256;
-    char* base = (char*)gd_scratch2(ctx, o_bad + (int64_t)ncols * 8);
+    const int nfp = (int)hc.size();
+    const int64_t o_bad = ((int64_t)nfp * sizeof(PrebinCol8) + 255) / 256 * 256;
+    const int64_t o_route = o_bad + ((int64_t)nfp * 8 + 255) / 256 * 256;
+    char* base = (char*)gd_scratch2(ctx, o_route + bucket_route_bytes(ctx, R));
     if (!base) return GD_ERR_NOMEM;
     PrebinCol8* d_c = (PrebinCol8*)base;
     unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
-    GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)ncols * sizeof(PrebinCol8)));
-    GD_HIP(hipMemsetAsync(d_bad, 0, (size_t)ncols * 8, ctx->stream));
-    int nblk = (int)((ctx->N / 8 + 255) / 256);
-    if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
-    if (nblk < 1) nblk = 1;
-    k_prebin8_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>(d_c, ctx->N, F, d_bad);
-    GD_KERNEL_CHECK();
-    std::vector<unsigned long long> hb((size_t)ncols);
-    GD_TRY(gd_fetch(ctx, hb.data(), d_bad, (size_t)ncols * 8));
+    if (nfp) {
+        GD_TRY(gd_h2d(ctx, d_c, hc.data(), (size_t)nfp * sizeof(PrebinCol8)));
+        GD_HIP(hipMemsetAsync(d_bad, 0, (size_t)nfp * 8, ctx->stream));
+        int nblk = (int)((ctx->N / 8 + 255) / 256);
+        if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
+        if (nblk < 1) nblk = 1;
+        k_prebin8_batch<<<dim3(nblk, nfp), 256, 0, ctx->stream>>>(d_c, ctx->N, F, d_bad);
+        GD_KERNEL_CHECK();
+    }
+    unsigned long long* d_bad_bq = nullptr;
+    if (!R.recs.empty()) GD_TRY(bucket_route_launch<true>(ctx, R, base + o_route, F, &d_bad_bq));
+    std::vector<unsigned long long> hb((size_t)nfp), hq(R.recs.size());
+    if (nfp) GD_TRY(gd_fetch(ctx, hb.data(), d_bad, (size_t)nfp * 8));
+    if (!R.recs.empty()) GD_TRY(gd_fetch(ctx, hq.data(), d_bad_bq, hq.size() * 8));
     GD_TRY(gd_stream_sync(ctx));
-    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)hb[c];
+    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)(R.slot_of[c] >= 0 ? hq[R.slot_of[c]] : hb[fp_of[c]]);
     return GD_OK;
 }
 
@@ -1307,14 +1579,21 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
     GD_REQUIRE(ctx->cols, "no samples uploaded");
     GD_REQUIRE(!ctx->w, "byte-index binning is for unit weights");
     const int F = 256;
-    std::vector<PrebinCol8> hc((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
+    const BucketRoute R = ncols ? bucket_route(ctx, cols, ncols, binmin, width, d_idx_out) : BucketRoute();
+    std::vector<PrebinCol8> hc;
+    std::vector<int> fp_of((size_t)ncols, -1);
     for (int c = 0; c < ncols; ++c) {
-        GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
-        hc[c].x = ctx->cols + (int64_t)cols[c] * ctx->ld;
-        hc[c].idx = (unsigned char*)d_idx_out[c];
-        hc[c].binmin = binmin[c];
-        hc[c].width = width[c];
+        if (R.slot_of[c] >= 0) continue;
+        PrebinCol8 r;
+        r.x = ctx->cols + (int64_t)cols[c] * ctx->ld;
+        r.idx = (unsigned char*)d_idx_out[c];
+        r.binmin = binmin[c];
+        r.width = width[c];
+        fp_of[c] = (int)hc.size();
+        hc.push_back(r);
     }
+    const int nfp = (int)hc.size();
     std::vector<Hist2DPair8> hp((size_t)B);
     for (int b = 0; b < B; ++b) {
         hp[b].ix = (const unsigned char*)d_idx_x[b];
@@ -1327,29 +1606,32 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const int64_t o_cols = take((int64_t)ncols * sizeof(PrebinCol8)), o_pairs = take((int64_t)B * sizeof(Hist2DPair8));
+    const int64_t o_cols = take((int64_t)nfp * sizeof(PrebinCol8)), o_pairs = take((int64_t)B * sizeof(Hist2DPair8));
     const int64_t table_bytes = off;
-    const int64_t o_bad = take((int64_t)ncols * 8), o_flags = take((int64_t)B * 4);
+    const int64_t o_bad = take((int64_t)nfp * 8), o_flags = take((int64_t)B * 4);
     const int64_t zero_end = off;
     const int nchunks = u8_chunks(ctx, B, ctx->N);
     const int64_t o_part = take(nchunks > 1 ? (int64_t)B * nchunks * 32768 * 4 : 0);
+    const int64_t o_route = take(bucket_route_bytes(ctx, R));
     char* base = (char*)gd_scratch2(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     {
         std::vector<char> tab((size_t)table_bytes, 0);
-        if (ncols) memcpy(tab.data() + o_cols, hc.data(), (size_t)ncols * sizeof(PrebinCol8));
+        if (nfp) memcpy(tab.data() + o_cols, hc.data(), (size_t)nfp * sizeof(PrebinCol8));
         memcpy(tab.data() + o_pairs, hp.data(), (size_t)B * sizeof(Hist2DPair8));
         GD_TRY(gd_stage_h2d(ctx, base, tab.data(), (size_t)table_bytes));
     }
     GD_HIP(hipMemsetAsync(base + o_bad, 0, (size_t)(zero_end - o_bad), ctx->stream));
-    if (ncols) {
+    if (nfp) {
         int nblk = (int)((ctx->N / 8 + 255) / 256);
         if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
         if (nblk < 1) nblk = 1;
-        k_prebin8_batch<<<dim3(nblk, ncols), 256, 0, ctx->stream>>>((const PrebinCol8*)(base + o_cols), ctx->N, F,
-                                                                   (unsigned long long*)(base + o_bad));
+        k_prebin8_batch<<<dim3(nblk, nfp), 256, 0, ctx->stream>>>((const PrebinCol8*)(base + o_cols), ctx->N, F,
+                                                                 (unsigned long long*)(base + o_bad));
         GD_KERNEL_CHECK();
     }
+    unsigned long long* d_bad_bq = nullptr;
+    if (!R.recs.empty()) GD_TRY(bucket_route_launch<true>(ctx, R, base + o_route, F, &d_bad_bq));
     const int nblocks = (B * nchunks + 7) / 8 * 8;
     GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_u8_pf<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES + 128));
     k_hist2d_u8_pf<3><<<nblocks, 1024, LDS_HIST_BYTES + 128, ctx->stream>>>((const Hist2DPair8*)(base + o_pairs), B, ctx->N,
@@ -1360,13 +1642,14 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
         k_p8_reduce<<<dim3(32, B), 256, 0, ctx->stream>>>((const unsigned int*)(base + o_part), nchunks, (double*)d_hist);
         GD_KERNEL_CHECK();
     }
-    std::vector<unsigned long long> hb((size_t)ncols);
+    std::vector<unsigned long long> hb((size_t)nfp), hq(R.recs.size());
     std::vector<int> hf((size_t)B);
-    if (ncols) GD_TRY(gd_fetch(ctx, hb.data(), base + o_bad, (size_t)ncols * 8));
+    if (nfp) GD_TRY(gd_fetch(ctx, hb.data(), base + o_bad, (size_t)nfp * 8));
+    if (!R.recs.empty()) GD_TRY(gd_fetch(ctx, hq.data(), d_bad_bq, hq.size() * 8));
     GD_TRY(gd_fetch(ctx, hf.data(), base + o_flags, (size_t)B * 4));
     GD_TRY(gd_stream_sync(ctx));
     int64_t nbad = 0;
-    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)hb[c], nbad += bad_out[c];
+    for (int c = 0; c < ncols; ++c) bad_out[c] = (int64_t)(R.slot_of[c] >= 0 ? hq[R.slot_of[c]] : hb[fp_of[c]]), nbad += bad_out[c];
     if (nbad) return gd_fail(ctx, GD_ERR_SOLVER, "%lld samples outside the byte-index grid: use the u16 path", (long long)nbad);
     for (int b = 0; b < B; ++b)
         if (hf[b]) return gd_fail(ctx, GD_ERR_SOLVER, "16-bit bin counter wrapped in pair %d: redo with gd_hist2d_prebinned", b);

@@ -215,6 +215,7 @@ void gd_destroy(gd_ctx* ctx) {
     }
     if (ctx->like_w) (void)hipFree(ctx->like_w);
     if (ctx->wcum) (void)hipFree(ctx->wcum);
+    ctx->bq.reset();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->gather_index) (void)hipFree(ctx->gather_index);
@@ -555,6 +556,7 @@ static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int
     ctx->w_integral = false;
     ctx->w_sum = ctx->w_main_sum = 0;
     ctx->N = ctx->n = ctx->ld = 0;
+    ctx->bq.reset();
     const int64_t ld = (N + 511) / 512 * 512;
     double *cols = nullptr, *w = nullptr;
     unsigned char* w8 = nullptr;
@@ -577,6 +579,7 @@ static int upload_common(gd_ctx* ctx, const double* X, int64_t N, int64_t n, int
     ctx->N = N;
     ctx->n = n;
     ctx->ld = ld;
+    ctx->bq = std::make_shared<BucketCols>();  // (the old set's bucket columns go with its last user)
     return GD_OK;
 }
 
@@ -730,6 +733,7 @@ int gd_attach_samples(gd_ctx* ctx, gd_ctx* owner) {
     ctx->N = owner->N;
     ctx->n = owner->n;
     ctx->ld = owner->ld;
+    ctx->bq = owner->bq;
     ctx->borrowed = true;
     return GD_OK;
 }

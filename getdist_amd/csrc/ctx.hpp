@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -15,6 +16,24 @@
 #include "../../include/gdhip.h"
 
 struct FftPlanCache;  // density2d.hip
+
+// Bucket columns (stats.hip, round 6): the 15-bit (weighted: 14-bit) linear bucket index of every sample of a column, written
+// by the counting pass of the quantile select while it has the fp64 value in a register.  Every later pass whose result is
+// a function of "which interval is x in" reads these 2 bytes instead of the 8-byte sample: the collect pass of the select
+// (live buckets), the pre-binning of the 2D / 1D index columns (a bucket that lies inside one bin maps through a table;
+// the ~1 % of buckets that straddle a bin edge re-read the sample and take the exact fp64 route, so the indices stay
+// bit-exact).  One object per resident sample set, shared by the contexts that borrow it (gd_attach_samples).
+struct BucketCols {
+    std::mutex mu;
+    unsigned short* buf = nullptr;  // [n][ld]
+    int64_t n = 0, ld = 0;
+    bool tried = false;             // allocation attempted (a failure is not retried for this sample set)
+    std::vector<double> mn, scale;  // per column: bucket = clamp((int)((x - mn) * scale), 0, nb - 1)
+    std::vector<int> nb;            // 0 = the column's buckets are not valid
+    ~BucketCols() {
+        if (buf) (void)hipFree(buf);
+    }
+};
 
 #define GD_EXTRA_COLS 4  // spare columns behind the sample columns (gd_set_extra_column): loglikes, derived vectors
 
@@ -43,6 +62,7 @@ struct gd_ctx {
     int w_sel = 0;
     bool borrowed = false;  // cols / w belong to another context of this process (gd_attach_samples)
     long long* wcum = nullptr;  // inclusive cumulative integer sample weights (thin.hip), built on first use
+    std::shared_ptr<BucketCols> bq;  // bucket columns of the resident sample set (nullptr until the first upload)
     int64_t N = 0, n = 0, ld = 0;
     // reusable scratch (grown on demand)
     void* scratch = nullptr;

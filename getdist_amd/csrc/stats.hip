@@ -1065,6 +1065,184 @@ __global__ void k_qlin_collect(const double* __restrict__ cols, int64_t ld, cons
     });
 }
 
+// ---- the counting pass over WHOLE columns, fused (round 6) --------------------------------------------------------------
+// One read of a column serves three consumers that all need nothing but pass-1 results (min / max / mean):
+//   * the bucket counts of the linear quantile select (as k_qlin_count),
+//   * the column's BUCKET COLUMN: the 16-bit bucket index of every sample, stored for the passes that follow (collect,
+//     pre-binning: ctx.hpp BucketCols) -- 2 bytes per sample written here save 8 bytes per sample read there, twice,
+//   * (PROBE) the first QP_LAGS autocovariance lag sums sum_i d_i d_{i+l}, d = (x - mean) w, of getCorrelationLength's first
+//     probe (chains.py:423-466; k_autocov computes the same sums from a read of its own).
+// Rows are walked in tiles of QP_TILE = 2 x 1024 consecutive rows (a thread owns two consecutive rows of a tile), U tiles of
+// loads in flight per lane.  The lag products need no block barrier: a wave's 128 consecutive d values go through a
+// wave-private LDS strip, the 8 rows behind the strip (the next wave's / next tile's first rows) come from a load of their
+// own (one cache line the neighbour fetches anyway).  The table leaves one block per CU, as for k_qlin_count.
+#define QP_TILE 2048
+#define QP_LAGS 8
+template <bool HAS_W, bool PROBE>
+__global__ void __launch_bounds__(1024) k_qlin_count_tiles(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                                                           const double* __restrict__ w, int64_t N, const QLin* __restrict__ ql,
+                                                           void* __restrict__ part, double wscale, unsigned short* __restrict__ bq,
+                                                           const double* __restrict__ means, double* __restrict__ probe_part) {
+    extern __shared__ double qsh[];
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
+    constexpr int STRIP = 128 + QP_LAGS;  // doubles per wave
+    const int c = blockIdx.y, col = colidx[c];
+    const double* x = cols + (int64_t)col * ld;
+    unsigned short* bqc = bq ? bq + (int64_t)col * ld : nullptr;
+    const double mn = ql[c].mn, scale = ql[c].scale;
+    unsigned int* hu = reinterpret_cast<unsigned int*>(qsh);
+    unsigned long long* hq = reinterpret_cast<unsigned long long*>(qsh);
+    double* strip = qsh + (size_t)nb * (HAS_W ? 8 : 4) / 8 + (threadIdx.x >> 6) * STRIP;  // behind the table
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+        if (HAS_W)
+            hq[i] = 0ull;
+        else
+            hu[i] = 0u;
+    }
+    __syncthreads();
+    const double mean = PROBE ? means[c] : 0.0;
+    double acc[QP_LAGS];
+#pragma unroll
+    for (int l = 0; l < QP_LAGS; ++l) acc[l] = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (N + QP_TILE - 1) / QP_TILE;
+    // (the probe's strip values and accumulators take registers: four tiles in flight keep the kernel free of spills)
+    constexpr int U = (HAS_W || PROBE) ? 4 : 8;
+    const int64_t G = gridDim.x;
+    for (int64_t t = blockIdx.x; t < ntiles; t += U * G) {
+        double2 xv[U], wv[U];
+        double hx[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t tq = t + q * G;
+            // tiles past the end: the loads stay in range (clamped, nothing of them is used)
+            const int64_t base = (tq < ntiles ? tq : ntiles - 1) * QP_TILE;
+            int64_t r = base + 2 * threadIdx.x;
+            if (r > ld - 2) r = ld - 2;
+            xv[q] = gload_d2(x + r);
+            wv[q] = HAS_W ? gload_d2(w + r) : make_double2(1.0, 1.0);
+            if (PROBE) {
+                int64_t rh = base + (int64_t)((threadIdx.x >> 6) + 1) * 128 + (lane & (QP_LAGS - 1));
+                const bool in = tq < ntiles && rh < N;
+                if (rh > ld - 1) rh = ld - 1;
+                const double v = x[rh];
+                const double ww = HAS_W ? w[rh] : 1.0;
+                hx[q] = in ? (v - mean) * ww : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t tq = t + q * G;
+            const int64_t row0 = tq < ntiles ? tq * QP_TILE + 2 * threadIdx.x : N;  // (>= N: both rows masked)
+            const bool m0 = row0 < N, m1 = row0 + 1 < N;
+            const int b0 = qlin_bucket(xv[q].x, mn, scale, nb), b1 = qlin_bucket(xv[q].y, mn, scale, nb);
+            if (HAS_W) {
+                if (m0) atomicAdd(&hq[b0], __double2ull_rn(wv[q].x * wscale));
+                if (m1) atomicAdd(&hq[b1], __double2ull_rn(wv[q].y * wscale));
+            } else {
+                if (m0) atomicAdd(&hu[b0], 1u);
+                if (m1) atomicAdd(&hu[b1], 1u);
+            }
+            if (bqc && m0) *reinterpret_cast<unsigned int*>(bqc + row0) = (unsigned)b0 | ((unsigned)b1 << 16);
+            if (PROBE) {
+                const double d0 = m0 ? (xv[q].x - mean) * wv[q].x : 0.0, d1 = m1 ? (xv[q].y - mean) * wv[q].y : 0.0;
+                __builtin_amdgcn_wave_barrier();  // the previous tile's strip reads are done (DS operations of a wave are in order)
+                strip[2 * lane] = d0;
+                strip[2 * lane + 1] = d1;
+                if (lane < QP_LAGS) strip[128 + lane] = hx[q];
+                // (no fence: a fence would also wait for the U tiles of global loads in flight; the reads below may alias the
+                // stores above, so the compiler keeps their order, and the LDS executes a wave's operations in order)
+                __builtin_amdgcn_wave_barrier();
+                double v[QP_LAGS + 1];
+#pragma unroll
+                for (int l = 0; l <= QP_LAGS; ++l) v[l] = strip[2 * lane + l];
+#pragma unroll
+                for (int l = 0; l < QP_LAGS; ++l) acc[l] = fma(d1, v[l + 1], fma(d0, v[l], acc[l]));
+            }
+        }
+    }
+    __syncthreads();
+    if (HAS_W) {
+        unsigned long long* p = (unsigned long long*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
+        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = hq[i];
+    } else {
+        unsigned int* p = (unsigned int*)part + ((int64_t)c * gridDim.x + blockIdx.x) * nb;
+        for (int i = threadIdx.x; i < nb; i += 1024) p[i] = hu[i];
+    }
+    if (PROBE) {
+        __syncthreads();
+        double* red = qsh;  // the table has been flushed
+        double* p = probe_part + ((int64_t)c * gridDim.x + blockIdx.x) * QP_LAGS;
+#pragma unroll
+        for (int l = 0; l < QP_LAGS; ++l) {
+            const double r = block_sum(acc[l], red);
+            if (threadIdx.x == 0) p[l] = r;
+        }
+    }
+}
+
+// the collect pass from the bucket column: 2 bytes per sample instead of 8; a sample is re-read (with its weight) only when
+// its bucket is live -- about 11 buckets of 32768.  Same lists, same order-independent finish (k_qsel_finish sorts them).
+template <bool HAS_W>
+__global__ void __launch_bounds__(512) k_qlin_collect_bq(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                                                         const double* __restrict__ w, int64_t N, const QState* __restrict__ st,
+                                                         const QLin* __restrict__ ql, const unsigned short* __restrict__ bq,
+                                                         unsigned long long* __restrict__ lkeys, double* __restrict__ lw,
+                                                         int* __restrict__ counts) {
+    constexpr int nb = HAS_W ? QLIN_NB_W : QLIN_NB_U;
+    __shared__ unsigned int live[nb / 32];  // one bit per bucket
+    __shared__ int ub[QK_MAX];
+    const int c = blockIdx.y, col = colidx[c];
+    const double* x = cols + (int64_t)col * ld;
+    const unsigned short* bqc = bq + (int64_t)col * ld;
+    const int nuniq = st[c].nuniq;
+    for (int i = threadIdx.x; i < nb / 32; i += blockDim.x) live[i] = 0u;
+    if (threadIdx.x < QK_MAX) ub[threadIdx.x] = threadIdx.x < nuniq ? ql[c].ubucket[threadIdx.x] : -1;
+    __syncthreads();
+    if ((int)threadIdx.x < nuniq) atomicOr(&live[ub[threadIdx.x] >> 5], 1u << (ub[threadIdx.x] & 31));
+    __syncthreads();
+    auto hit = [&](int64_t row, int b) {
+        int slot = 0;
+        for (int u = 1; u < nuniq; ++u)
+            if (ub[u] == b) slot = u;
+        const int pos = atomicAdd(&counts[c * QK_MAX + slot], 1);
+        if (pos < QCAP) {
+            const int64_t o = ((int64_t)c * QK_MAX + slot) * QCAP + pos;
+            lkeys[o] = f64_key(x[row]);
+            lw[o] = HAS_W ? w[row] : 1.0;
+        }
+    };
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n8 = (N + 7) / 8;  // 16-byte groups; the column's storage is padded to a multiple of 512 rows
+    constexpr int U = 4;
+    int64_t i = gtid;
+    for (; i + (U - 1) * gsz < n8; i += U * gsz) {
+        uint4 v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = gload_u4(bqc + 8 * (i + q * gsz));
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const unsigned int wd[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int b = (wd[e >> 1] >> (16 * (e & 1))) & (nb - 1);  // (rows past N hold whatever the padding held)
+                const int64_t row = 8 * (i + q * gsz) + e;
+                if (((live[b >> 5] >> (b & 31)) & 1u) && row < N) hit(row, b);
+            }
+        }
+    }
+    for (; i < n8; i += gsz) {
+        const uint4 v = gload_u4(bqc + 8 * i);
+        const unsigned int wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = (wd[e >> 1] >> (16 * (e & 1))) & (nb - 1);
+            const int64_t row = 8 * i + e;
+            if (((live[b >> 5] >> (b & 31)) & 1u) && row < N) hit(row, b);
+        }
+    }
+}
+
 // ---- autocovariance lag sums: out[l] = sum_i d_i d_{i+k0+l},  d = (x-mean)*w ---------------------------------
 #define AL 32     // lags per launch
 #define AT 2048   // rows per tile
@@ -1546,8 +1724,32 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
 }
 
 // the linear-bucket path of gd_quantiles_mm; returns 1 when a bucket list overflowed (the caller takes the radix path)
+// Bucket columns of the resident sample set (ctx.hpp BucketCols): allocated on first use when the device has room for them
+// beside what a large call needs (they are an optimisation: without them the later passes read the fp64 samples).
+static unsigned short* bucket_columns(gd_ctx* ctx) {
+    if (!ctx->bq || getenv("GDHIP_NO_BUCKET_COLS")) return nullptr;
+    BucketCols& B = *ctx->bq;
+    std::lock_guard<std::mutex> g(B.mu);
+    if (B.buf) return B.buf;
+    if (B.tried) return nullptr;
+    B.tried = true;
+    const size_t bytes = (size_t)ctx->n * ctx->ld * 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * bytes + ((size_t)8 << 30)) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    B.buf = (unsigned short*)p;
+    B.n = ctx->n, B.ld = ctx->ld;
+    B.mn.assign((size_t)ctx->n, 0.0), B.scale.assign((size_t)ctx->n, 0.0), B.nb.assign((size_t)ctx->n, 0);
+    return B.buf;
+}
+
 static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets,
-                            int32_t k, const double* minmax, double* out, int* overflowed) {
+                            int32_t k, const double* minmax, double* out, int* overflowed, const double* probe_means,
+                            double* probe_out) {
     const bool hw = ctx->w != nullptr;
     const int nb = hw ? QLIN_NB_W : QLIN_NB_U;
     std::vector<QState> hst((size_t)ncols);
@@ -1596,9 +1798,23 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
                   o_idx = take((int64_t)ncols * 4), o_out = take((int64_t)ncols * k * 8),
                   o_cnt = take((int64_t)ncols * QK_MAX * 4 + 256), o_lk = take((int64_t)ncols * QK_MAX * QCAP * 8),
                   o_lw = take((int64_t)ncols * QK_MAX * QCAP * 8), o_part = take((int64_t)ncols * nblk * nb * (hw ? 8 : 4)),
-                  o_tot = take((int64_t)ncols * nb * 8);
+                  o_tot = take((int64_t)ncols * nb * 8), o_pmean = take((int64_t)ncols * 8),
+                  o_ppart = take((int64_t)ncols * nblk * QP_LAGS * 8), o_pout = take((int64_t)ncols * QP_LAGS * 8);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
+    // whole columns of the sample set: the fused pass (tiles; bucket columns for the later passes; the lag probe on request)
+    bool whole = lo == 0 && hi == ctx->N && !getenv("GDHIP_QLIN_UNFUSED");
+    for (int c = 0; whole && c < ncols; ++c) whole = cols[c] < ctx->n;
+    unsigned short* bq = whole ? bucket_columns(ctx) : nullptr;
+    const bool probe = whole && probe_means && probe_out;
+    double* d_pmean = (double*)(base + o_pmean);
+    double* d_ppart = (double*)(base + o_ppart);
+    double* d_pout = (double*)(base + o_pout);
+    if (probe) GD_TRY(gd_h2d(ctx, d_pmean, probe_means, (size_t)ncols * 8));
+    if (bq) {  // the columns' buckets are being rewritten: not valid until this call has seen its kernels complete
+        std::lock_guard<std::mutex> g(ctx->bq->mu);
+        for (int c = 0; c < ncols; ++c) ctx->bq->nb[cols[c]] = 0;
+    }
     QState* d_st = (QState*)(base + o_st);
     QLin* d_ql = (QLin*)(base + o_ql);
     int32_t* d_idx = (int32_t*)(base + o_idx);
@@ -1613,43 +1829,72 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
     GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     GD_HIP(hipMemsetAsync(d_cnt, 0, (size_t)ncols * QK_MAX * 4 + 256, ctx->stream));
     const size_t lds = (size_t)nb * (hw ? 8 : 4);
+    const size_t lds_tiles = lds + (probe ? (size_t)16 * (128 + QP_LAGS) * 8 : 0);
     // 2^k with 2^k * (sum of all weights) < 2^62 (gd_quantiles_mm checked that the sum is known and positive)
     const double wscale = hw ? ldexp(1.0, 61 - ilogb(ctx->w_sum)) : 1.0;
-    if (hw) {
-        GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_qlin_count<true><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part, wscale);
-        GD_KERNEL_CHECK();
-        k_qlin_reduce<true><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot, 1.0 / wscale);
-        GD_KERNEL_CHECK();
-        k_qlin_scan<true><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
-        GD_KERNEL_CHECK();
-        k_qlin_collect<true><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_st, d_ql, d_lk,
-                                                                          d_lw, d_cnt);
-    } else {
-        GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_qlin_count<false><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_ql, d_part, 1.0);
-        GD_KERNEL_CHECK();
-        k_qlin_reduce<false><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot, 1.0);
-        GD_KERNEL_CHECK();
-        k_qlin_scan<false><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);
-        GD_KERNEL_CHECK();
-        k_qlin_collect<false><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, nullptr, lo, hi, d_st, d_ql,
-                                                                           d_lk, d_lw, d_cnt);
-    }
+#define GD_QLIN(HW)                                                                                                                  \
+    do {                                                                                                                             \
+        if (whole) {                                                                                                                 \
+            if (probe) {                                                                                                             \
+                GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count_tiles<HW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles)); \
+                k_qlin_count_tiles<HW, true><<<dim3(nblk, ncols), 1024, lds_tiles, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_ql, \
+                                                                                                 d_part, wscale, bq, d_pmean, d_ppart);  \
+            } else {                                                                                                                 \
+                GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count_tiles<HW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles)); \
+                k_qlin_count_tiles<HW, false><<<dim3(nblk, ncols), 1024, lds_tiles, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_ql, \
+                                                                                                  d_part, wscale, bq, nullptr, nullptr); \
+            }                                                                                                                        \
+        } else {                                                                                                                     \
+            GD_HIP(hipFuncSetAttribute((const void*)k_qlin_count<HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+            k_qlin_count<HW><<<dim3(nblk, ncols), 1024, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_ql, d_part, wscale); \
+        }                                                                                                                            \
+        GD_KERNEL_CHECK();                                                                                                           \
+        if (probe) {                                                                                                                 \
+            k_sum_partials_batched<<<dim3(QP_LAGS, ncols), 256, 0, ctx->stream>>>(d_ppart, nblk, QP_LAGS, d_pout);                   \
+            GD_KERNEL_CHECK();                                                                                                       \
+        }                                                                                                                            \
+        k_qlin_reduce<HW><<<dim3(nb / 256, ncols), 256, 0, ctx->stream>>>(d_part, nblk, d_tot, 1.0 / wscale);                        \
+        GD_KERNEL_CHECK();                                                                                                           \
+        k_qlin_scan<HW><<<ncols, 1024, 0, ctx->stream>>>(d_st, d_ql, d_tot);                                                         \
+        GD_KERNEL_CHECK();                                                                                                           \
+        if (bq)                                                                                                                      \
+            k_qlin_collect_bq<HW><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_st, d_ql, bq, d_lk, \
+                                                                               d_lw, d_cnt);                                         \
+        else                                                                                                                         \
+            k_qlin_collect<HW><<<dim3(nblk2, ncols), 512, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, lo, hi, d_st, d_ql, d_lk, d_lw,  \
+                                                                            d_cnt);                                                  \
+    } while (0)
+    if (hw)
+        GD_QLIN(true);
+    else
+        GD_QLIN(false);
+#undef GD_QLIN
     GD_KERNEL_CHECK();
     k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
     GD_KERNEL_CHECK();
     int overflow = 0;
     GD_TRY(gd_fetch(ctx, &overflow, d_cnt + (int64_t)ncols * QK_MAX, 4));
     GD_TRY(gd_fetch(ctx, out, d_out, (size_t)ncols * k * 8));
+    if (probe) GD_TRY(gd_fetch(ctx, probe_out, d_pout, (size_t)ncols * QP_LAGS * 8));
     GD_TRY(gd_stream_sync(ctx));
+    if (bq) {
+        std::lock_guard<std::mutex> g(ctx->bq->mu);
+        for (int c = 0; c < ncols; ++c)
+            ctx->bq->mn[cols[c]] = hql[c].mn, ctx->bq->scale[cols[c]] = hql[c].scale, ctx->bq->nb[cols[c]] = nb;
+    }
     *overflowed = overflow;
     return GD_OK;
 }
 
 int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets, int32_t k,
                     const double* minmax, double* out) {
+    return gd_quantiles_mm_probe(ctx, cols, ncols, lo, hi, targets, k, minmax, out, nullptr, nullptr, nullptr);
+}
+
+int gd_quantiles_mm_probe(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, int64_t hi, const double* targets, int32_t k,
+                          const double* minmax, double* out, const double* probe_means, double* probe_out, int32_t* probe_done) {
     GD_REQUIRE(ctx && cols && targets && out && ncols > 0, "bad argument");
+    if (probe_done) *probe_done = 0;
     GD_REQUIRE(k > 0 && k <= QK_MAX, "at most 16 quantiles per call");
     GD_REQUIRE(ctx->cols && lo >= 0 && hi <= ctx->N && lo < hi, "bad row range");
     bool linear = minmax != nullptr && getenv("GDHIP_QSEL_RADIX") == nullptr;
@@ -1666,7 +1911,14 @@ int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo,
     if (linear) {
         for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
         int overflowed = 0;
-        const int rc = quantiles_linear(ctx, cols, ncols, lo, hi, targets, k, minmax, out, &overflowed);
+        const bool want_probe = probe_means && probe_out && probe_done && lo == 0 && hi == ctx->N && !getenv("GDHIP_QLIN_UNFUSED");
+        const int rc = quantiles_linear(ctx, cols, ncols, lo, hi, targets, k, minmax, out, &overflowed, want_probe ? probe_means : nullptr,
+                                        want_probe ? probe_out : nullptr);
+        if (rc == GD_OK && want_probe) {
+            bool whole = true;  // (the fused pass ran: every column is one of the sample set's own)
+            for (int c = 0; c < ncols; ++c) whole = whole && cols[c] < ctx->n;
+            *probe_done = whole ? 1 : 0;
+        }
         if (rc || !overflowed) return rc;  // heavily tied or very peaked data: the radix path below redoes the call
     }
     return gd_quantiles(ctx, cols, ncols, lo, hi, targets, k, out);

@@ -350,6 +350,16 @@ class _Plan(list):
     arr = None
 
 
+class _Done:
+    """A finished future (the lag probe that came back with the quantile select)."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
 class _FastThreadSwitch:
     """While a helper thread drives a second stream, a thread returning from a C call would wait for the GIL up to the
     interpreter's switch interval (5 ms by default) whenever the other thread is in Python scalar code -- longer than
@@ -1932,15 +1942,23 @@ class MCSamples:
         js = np.asarray(js, dtype=np.int64)
         return np.stack([np.asarray(self._col_min)[js], np.asarray(self._col_max)[js]], axis=1)
 
-    def _init_params(self, js):
-        """_initParam for several parameters with ONE batched quantile-select launch."""
+    def _init_params(self, js, lag_probe=False):
+        """_initParam for several parameters with ONE batched quantile-select launch.  ``lag_probe``: the select's counting
+        pass also delivers the autocovariance probe of the N_eff estimate for the same columns (one read of the samples
+        serves both; kept in ``_lag_prefetch`` for _probe_lags / the batched 2D entry)."""
         todo = [j for j in dict.fromkeys(js) if not getattr(self.paramNames.names[j], "_ranges_done", False)]
         if not todo:
             return
         rc = self.range_confidence
         fracs = np.array([rc, 1 - rc] + list(np.linspace(0.1, 0.9, 9)))
         targets = np.tile(self.norm * fracs, (len(todo), 1))
-        q = np.asarray(self.ctx.quantiles(todo, targets, minmax=self._minmax_of(todo)))
+        if lag_probe:
+            q, lags = self.ctx.quantiles_probe(todo, targets, self._minmax_of(todo), self.means[todo])
+            q = np.asarray(q)
+            if lags is not None:
+                self._lag_prefetch = (todo, 8, _Done(lags))
+        else:
+            q = np.asarray(self.ctx.quantiles(todo, targets, minmax=self._minmax_of(todo)))
         # mcsamples.py:1440-1452 for all parameters at once: [param_min, deciles 0.1..0.9, param_max], spans of four
         err_v = np.asarray(self.sddev)[todo]
         confids = np.empty_like(q)
@@ -1997,7 +2015,16 @@ class MCSamples:
             self.updateBaseStatistics()
         js = list(range(self.n)) if params is None else [self._col(p) for p in params]
         todo = [j for j in js if self.paramNames.names[j].N_eff_kde is None]
-        if (todo and self._lane == 0 and not self._timing and self.sampler not in ("nested", "uncorrelated")
+        # the autocovariance probe of the N_eff estimate needs the means only.  Round 6: it rides on the counting pass of the
+        # quantile select (gd_quantiles_mm_probe: one read of the columns for both) when every parameter that needs it is
+        # about to go through that select; else, as before, it runs on the second context beside the select
+        fused = (bool(todo) and self.sampler not in ("nested", "uncorrelated") and self.numrows // 10 + 1 >= 8
+                 and hasattr(self.ctx, "quantiles_probe") and os.environ.get("GETDIST_AMD_FUSED_PROBE", "1") == "1"
+                 and all(not getattr(self.paramNames.names[j], "_ranges_done", False) for j in todo))
+        if fused:
+            with _Phase(self, "prep.ranges"):
+                self._init_params(js, lag_probe=True)
+        elif (todo and self._lane == 0 and not self._timing and self.sampler not in ("nested", "uncorrelated")
                 and len(todo) >= 2 and os.environ.get("GETDIST_AMD_OVERLAP_NEFF", "1") == "1"):
             # the autocovariance probe of the N_eff estimate depends on the means only: start it on the second context
             # (own stream) while this one runs the quantile select

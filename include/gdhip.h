@@ -118,6 +118,20 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo
 int gd_quantiles_mm(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
                     const double* targets, int32_t k, const double* minmax, double* out);
 
+/* gd_quantiles_mm_probe: gd_quantiles_mm whose counting pass -- when it walks WHOLE columns of the sample set (row_lo = 0,
+ * row_hi = N, the linear path) -- also serves two other consumers of the same read (round 6):
+ *   - the first 8 autocovariance lag sums of getCorrelationLength's probe (chains.py:423-466, what gd_autocov_lags_batch(cols,
+ *     probe_means, 0, 8) returns: sum_i d_i d_{i+l}, d = (x - mean) w) into probe_out[c * 8 + l]; *probe_done = 1 when they
+ *     were computed (0: the select took another path -- call gd_autocov_lags_batch);
+ *   - the columns' 16-bit bucket indices are kept on the device: the select's own collect pass, and later gd_prebin8_batch /
+ *     gd_prebin8_hist2d / gd_prebin_batch of the same columns, read those 2 bytes per sample instead of the 8-byte value
+ *     (a bucket that lies inside one bin maps through a table; the ~1 % that straddle a bin edge re-read the sample and
+ *     take the exact fp64 route of mcsamples.py:1497 -- the indices are bit-equal either way).
+ * probe_means / probe_out / probe_done may be NULL (then this is gd_quantiles_mm). */
+int gd_quantiles_mm_probe(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t row_lo, int64_t row_hi,
+                          const double* targets, int32_t k, const double* minmax, double* out, const double* probe_means,
+                          double* probe_out, int32_t* probe_done);
+
 /* ---------------------------------------------------------------- autocorrelation / N_eff ------
  * gd_autocov_lags: out[l] = sum_{i} d_i d_{i+k0+l}, d=(x-mean)*w, l<nlags -- the un-normalised lag
  *   sums convolve.autoConvolve (convolve.py:458-478) obtains by FFT for chains.py:441.

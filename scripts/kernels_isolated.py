@@ -46,11 +46,28 @@ def main():
     mm = mc._minmax_of(cols)
     res["quantiles_linear_50x11"] = timed(ctx, lambda: ctx.quantiles(cols, tg, minmax=mm), 3)
     res["autocov_probe_8_lags_50"] = timed(ctx, lambda: ctx.autocov_lags_batch(cols, mc.means, 0, 8))
+    # round 6: the select's counting pass also writes the bucket columns and computes the lag probe (one read for the three)
+    res["quantiles_linear_50x11_with_lag_probe_and_bucket_columns"] = timed(ctx, lambda: ctx.quantiles_probe(cols, tg, mm, mc.means), 3)
+    os.environ["GDHIP_QLIN_UNFUSED"] = "1"
+    res["quantiles_linear_50x11_unfused_round5_kernels"] = timed(ctx, lambda: ctx.quantiles(cols, tg, minmax=mm), 3)
+    os.environ.pop("GDHIP_QLIN_UNFUSED")
+    ctx.quantiles_probe(cols, tg, mm, mc.means)  # (bucket columns valid for what follows)
     kstd = np.array([(p.sigma_range or mc.sddev[j]) * 0.2 for j, p in enumerate(par)])
     lags = mc._neff_lag_list()
     res["kde_lag_sums_7_lags_50"] = timed(ctx, lambda: ctx.kde_lag_sums_batch(cols, 1.0 / (4 * kstd**2), lags), 3)
     bufs = [ctx.alloc(N + 64) for _ in range(n)]
-    res["prebin8_batch_50"] = timed(ctx, lambda: ctx.prebin8_batch(cols, [e[j][1] for j in cols], [e[j][0] for j in cols], 256, bufs))
+    res["prebin8_batch_50_from_bucket_columns"] = timed(ctx, lambda: ctx.prebin8_batch(cols, [e[j][1] for j in cols], [e[j][0] for j in cols], 256, bufs))
+    os.environ["GDHIP_NO_BUCKET_COLS"] = "1"
+    res["prebin8_batch_50_from_fp64_samples"] = timed(ctx, lambda: ctx.prebin8_batch(cols, [e[j][1] for j in cols], [e[j][0] for j in cols], 256, bufs))
+    os.environ.pop("GDHIP_NO_BUCKET_COLS")
+    b16 = [ctx.alloc(2 * N + 64) for _ in range(12)]
+    e960 = [mc._bin_edges(p, 960) for p in par[:12]]
+    res["prebin_u16_12_columns_F960_from_bucket_columns"] = timed(ctx, lambda: ctx.prebin_batch(cols[:12], [x[1] for x in e960], [x[0] for x in e960], 960, b16))
+    os.environ["GDHIP_NO_BUCKET_COLS"] = "1"
+    res["prebin_u16_12_columns_F960_from_fp64_samples"] = timed(ctx, lambda: ctx.prebin_batch(cols[:12], [x[1] for x in e960], [x[0] for x in e960], 960, b16))
+    os.environ.pop("GDHIP_NO_BUCKET_COLS")
+    for b in b16:
+        b.free()
     pairs = [p for p in synth.triangle_pairs(n) if abs(corr[p[1]][p[0]]) <= 0.866]
     out = ctx.alloc(len(pairs) * F * F * 8)
     ix, iy = [bufs[a] for a, b in pairs], [bufs[b] for a, b in pairs]

@@ -355,6 +355,10 @@ class FakeContext:
             out[r] = x[idx[np.minimum(np.searchsorted(cum, targets[r]), len(idx) - 1)]]
         return out
 
+    def quantiles_probe(self, cols, targets, minmax, means):
+        """gd_quantiles_mm_probe: the select plus the first 8 autocovariance lag sums of the same columns"""
+        return self.quantiles(cols, targets, minmax=minmax), self.autocov_lags_batch(cols, means, 0, 8)
+
     # ---- lag sums
     # ---- stand-alone convolutions / likelihood statistics (numpy statements of the four entry points)
     def circ_convolve(self, a, b):

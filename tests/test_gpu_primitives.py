@@ -747,3 +747,112 @@ def test_partial_column_shard_lands_at_its_columns():
             assert np.array_equal(q[ci], want)
     finally:
         c.close()
+
+
+def _bucket_test_columns(N, rng):
+    """Columns that stress the bucket route: a plain Gaussian, a far-offset narrow one (|mean| >> sigma: few fp64 values per
+    bucket), a reflected (hard-bounded) one piled at its minimum, heavy ties, an exponential tail, a uniform."""
+    g = rng.standard_normal(N)
+    tied = np.round(rng.standard_normal(N) * 3) / 3.0
+    tied[0], tied[1] = tied.min() - 1.5, tied.max() + 0.25  # (keeps max > min however the ties fall)
+    return np.column_stack([g, 1e6 + 1e-3 * rng.standard_normal(N), np.abs(rng.standard_normal(N)), tied,
+                            rng.exponential(1.0, N), rng.uniform(-2, 5, N)])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_bucket_columns_serve_the_select_the_probe_and_bit_exact_index_columns(monkeypatch, weighted):
+    """Round 6: the counting pass of the quantile select (gd_quantiles_mm_probe over whole columns) leaves each sample's
+    bucket index on the device and computes the autocovariance probe from the same read.  (a) the quantiles equal the
+    unfused select's exactly; (b) the probe equals gd_autocov_lags_batch to rounding; (c) byte and u16 index columns made
+    FROM THE BUCKETS (table look-up, exact fp64 route for buckets on a bin edge) are bit-equal to the fp64 kernels' and to
+    numpy's expression, out-of-range reports included; (d) a new upload forgets the buckets."""
+    from getdist_amd._lib import Context
+
+    monkeypatch.setenv("GDHIP_BUCKET_ROUTE_MIN", "1")  # (the route is for many columns at once; here six must take it)
+    N = 400_003
+    rng = np.random.default_rng(17)
+    s = _bucket_test_columns(N, rng)
+    w = rng.exponential(1.0, N) if weighted else None
+    wn = w if weighted else np.ones(N)
+    n = s.shape[1]
+    c = Context(0)
+    c.upload(np.asfortranarray(s), w)
+    cols = list(range(n))
+    mm = np.column_stack([s.min(axis=0), s.max(axis=0)])
+    means = (wn[:, None] * s).sum(axis=0) / wn.sum()
+    fr = np.array([0.001, 0.999] + list(np.linspace(0.1, 0.9, 9)))
+    tg = np.tile(wn.sum() * fr, (n, 1))
+    # (a) + (b)
+    monkeypatch.setenv("GDHIP_QLIN_UNFUSED", "1")
+    q_ref = c.quantiles(cols, tg, minmax=mm)
+    monkeypatch.delenv("GDHIP_QLIN_UNFUSED")
+    q, probe = c.quantiles_probe(cols, tg, mm, means)
+    assert np.array_equal(q, q_ref)
+    assert probe is not None
+    lag_ref = c.autocov_lags_batch(cols, means, 0, 8)
+    d = (s - means) * wn[:, None]
+    for j in range(n):
+        want = np.array([np.dot(d[: N - l, j], d[l:, j]) for l in range(8)])
+        scale = np.abs(want[0])
+        assert np.max(np.abs(probe[j] - want)) <= 1e-11 * scale, (j, probe[j], want)
+        assert np.max(np.abs(probe[j] - lag_ref[j])) <= 1e-11 * scale
+    # a second run delivers the same bits (fixed reduction order)
+    q2, probe2 = c.quantiles_probe(cols, tg, mm, means)
+    assert np.array_equal(q2, q) and np.array_equal(probe2, probe)
+    # (c) index columns from the buckets against the fp64 kernels and numpy, three grids per column: the usual padded one,
+    # a narrow one that leaves samples outside, and one with an awkward width
+    lo, hi = mm[:, 0], mm[:, 1]
+    for F, kind in ((256, "u8"), (256, "u8-narrow"), (960, "u16"), (384, "u16-narrow")):
+        narrow = kind.endswith("narrow")
+        binmin = lo + (0.2 if narrow else -0.05) * (hi - lo)
+        width = (hi + (-0.3 if narrow else 0.05) * (hi - lo) - binmin) / (F - 1)
+        ix = [((s[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64) for j in range(n)]
+        if kind.startswith("u8"):
+            bufs = [c.alloc(N + 64) for _ in range(n)]
+            bad = c.prebin8_batch(cols, binmin, width, F, bufs)
+            got = [b.to_host((N,), dtype=np.uint8) for b in bufs]
+            monkeypatch.setenv("GDHIP_NO_BUCKET_COLS", "1")
+            bufs2 = [c.alloc(N + 64) for _ in range(n)]
+            bad2 = c.prebin8_batch(cols, binmin, width, F, bufs2)
+            monkeypatch.delenv("GDHIP_NO_BUCKET_COLS")
+            assert np.array_equal(bad, bad2)
+            for j in range(n):
+                assert np.array_equal(got[j], bufs2[j].to_host((N,), dtype=np.uint8)), (kind, j)
+                assert np.array_equal(got[j], (ix[j] & 0xff).astype(np.uint8)), (kind, j)
+                assert bad[j] == np.sum((ix[j] < 0) | (ix[j] >= F)), (kind, j)
+            if narrow:
+                assert bad.sum() > 0
+        else:
+            bufs = [c.alloc(2 * N + 64) for _ in range(n)]
+            c.prebin_batch(cols, binmin, width, F, bufs)
+            one = c.prebin(2, binmin[2], width[2], F)  # the single-column entry takes the same route
+            c.sync()
+            for j in range(n):
+                want = np.where((ix[j] >= 0) & (ix[j] < F), ix[j], 0xFFFF).astype(np.uint16)
+                assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint16), want), (kind, j)
+            assert np.array_equal(one.to_host((N,), dtype=np.uint16), bufs[2].to_host((N,), dtype=np.uint16))
+    # lists that overflow (heavily tied data on a bin edge; here forced by a tiny capacity): the block's rows are redone exactly
+    monkeypatch.setenv("GDHIP_BUCKET_LIST_CAP", "3")
+    binmin = lo - 0.05 * (hi - lo)
+    width = (hi + 0.05 * (hi - lo) - binmin) / 255
+    bufs = [c.alloc(N + 64) for _ in range(n)]
+    assert np.all(c.prebin8_batch(cols, binmin, width, 256, bufs) == 0)
+    for j in range(n):
+        assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint8), ((s[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64).astype(np.uint8))
+    monkeypatch.delenv("GDHIP_BUCKET_LIST_CAP")
+    # a sub-range select must not disturb (or use) the whole-column buckets; a later prebin still agrees
+    c.quantiles(cols[:2], tg[:2] * 0.25, lo=1000, hi=N // 2, minmax=mm[:2])
+    binmin = lo - 0.05 * (hi - lo)
+    width = (hi + 0.05 * (hi - lo) - binmin) / 255
+    bufs = [c.alloc(N + 64) for _ in range(n)]
+    c.prebin8_batch(cols, binmin, width, 256, bufs)
+    for j in range(n):
+        assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint8), ((s[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64).astype(np.uint8))
+    # (d) new samples: the old buckets are gone with the old set (indices follow the NEW values without a select)
+    s2 = s[::-1].copy()
+    c.upload(np.asfortranarray(s2), w)
+    bufs = [c.alloc(N + 64) for _ in range(n)]
+    c.prebin8_batch(cols, binmin, width, 256, bufs)
+    for j in range(n):
+        assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint8), ((s2[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64).astype(np.uint8))
+    c.close()
