@@ -364,13 +364,14 @@ def _peak_rss_mb():
 
 
 def _verdict_record(v):
-    """What is reported per loose pair (review item, round 4): the criterion and the perturbation scale that admitted the
-    device's bandwidth triple under the frozen rules, the distance to the nearest member of the oracle's ensemble, and the
-    verdict at the strict slack of 0.25."""
+    """What is reported per loose pair: the criterion ("inside" = between the oracle ensemble's extremes, "spread" = within
+    0.25 of its spread beyond them, "amise" = as good in the reference's own objective) and the perturbation scale that admitted
+    the device's bandwidth triple under the frozen rules (gate: slack 0.25 since round 6), the distance to the nearest member
+    of the oracle's ensemble, and whether the wider slack of rounds 3-5 (1.0) would have admitted it (reported only)."""
     return dict(admitted=bool(v["ok"]), admitted_by=v.get("admitted_by"), perturbation_scale=v["scale"],
                 nearest_member_rel=v.get("nearest_member"), excess_over_spread=v["excess"], amise_excess=v["amise_excess"],
-                amise_range=v["amise_range"], strict_slack_0p25_admits=bool(v.get("strict_ok")),
-                strict_scale=v.get("strict_scale"), strict_admitted_by=v.get("strict_admitted_by"), members=v["members"])
+                amise_range=v["amise_range"], between_the_ensemble_extremes=bool(v.get("inside")),
+                admitted_at_slack_1p0_reported_only=bool(v.get("ok_at_slack_1")), members=v["members"])
 
 
 def _cpu_task(task):
@@ -418,6 +419,7 @@ def _cpu_task(task):
                     v = ko.judge_triple(np.asarray(task["gpu_kopt"])[8:11], psi, tr["opt_N"], tr["opt_corr"])
                     out["chaotic"] = (v["moved"] > 1e-6, v["moved"])
                     out["inside_oracle_spread"], out["excess"], out["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                    out["within_spread_slack_0p25"] = v["within_slack"]
                     out["ensemble_perturbation"] = v["scale"]
                     out["verdict"] = _verdict_record(v)
                 else:
@@ -453,6 +455,7 @@ def _cpu_task(task):
                 v = ko.judge_triple(np.asarray(kopt)[8:11], psi, tr["opt_N"], tr["opt_corr"])
                 row["oracle_moves_by"] = v["moved"]
                 row["inside_oracle_spread"], row["excess"], row["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                row["within_spread_slack_0p25"] = v["within_slack"]
                 row["ensemble_perturbation"] = v["scale"]
                 row["verdict"] = _verdict_record(v)
         return row
@@ -494,6 +497,7 @@ def _cpu_task(task):
                 v = ko.judge_triple(kopt[8:11], psi, tr["opt_N"], tr["opt_corr"])
                 row["oracle_moves_by"] = v["moved"]
                 row["inside_oracle_spread"], row["excess"], row["amise_ok"] = v["inside"], v["excess"], v["amise_ok"]
+                row["within_spread_slack_0p25"] = v["within_slack"]
                 row["ensemble_perturbation"] = v["scale"]
                 row["verdict"] = _verdict_record(v)
         rows.append(row)
@@ -518,9 +522,10 @@ def _census_summary(rows, has_limits, names):
         pairs_above_1e_6=len(loose_rows), worst_abs_dP=float(max([r.get("err", 0.0) for r in rows] or [0.0])),
         loose_pairs_that_use_tnc=int(sum(bool(r["tnc"]) for r in loose_rows)),
         loose_pairs_chaotic_in_the_oracle=int(sum(r.get("oracle_moves_by", 0.0) > 1e-6 for r in loose_rows)),
-        loose_pairs_inside_the_oracle_spread=int(sum(bool(r.get("inside_oracle_spread")) for r in loose_rows)),
-        loose_pairs_inside_spread_or_as_good_in_amise=int(sum(bool(r.get("inside_oracle_spread") or r.get("amise_ok")) for r in loose_rows)),
-        loose_pairs_admitted_at_strict_slack_0p25=int(sum(bool((r.get("verdict") or {}).get("strict_slack_0p25_admits")) for r in loose_rows)),
+        # the admission rule (oracle.kde_oracle.judge_triple; gate = slack 0.25 of the ensemble's spread since round 6):
+        loose_pairs_between_the_oracle_ensembles_extremes=int(sum(bool(r.get("inside_oracle_spread")) for r in loose_rows)),
+        loose_pairs_within_0p25_of_the_spread_or_as_good_in_amise=int(sum(bool(r.get("within_spread_slack_0p25") or r.get("amise_ok")) for r in loose_rows)),
+        loose_pairs_admitted=int(sum(bool((r.get("verdict") or {}).get("admitted")) for r in loose_rows)),
         worst_excess_over_oracle_spread=float(max([r.get("excess", 0.0) for r in loose_rows] or [0.0])),
         loose_pairs=[dict(pair=[names[r["pair"][0]], names[r["pair"][1]]], max_abs_dP=r.get("err"), verdict=r.get("verdict"))
                      for r in loose_rows],
@@ -897,25 +902,30 @@ def main():
 
         prof = cProfile.Profile()
         prof.enable()
+    # ---- the timed region: K triangles, each one DELIVERED before the next starts (t spans "columns resident in
+    # HBM" -> "all 1225 normalised grids available on host"; the first read of a grid waits for the step's result copies and
+    # checks every grid's status).  This is the headline.
     t0 = time.perf_counter()
     step_returned = []
     for _ in range(args.steps):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world, comm)
+        if dens:
+            dens[-1].P
         step_returned.append(time.perf_counter())
-    if dens:
-        dens[-1].P  # first read of a grid: waits for this step's copies and checks every grid's status
     barrier()
     elapsed = time.perf_counter() - t0
-    # the same step with its results consumed before the next one starts (no overlap of the result copies with the
-    # following step): the latency of ONE triangle, reported next to the sustained rate
-    serial_ms = None
-    if world == 1 and not args.emulate_world and prof is None:
+    # ---- the same K steps as a stream of triangles: the PCIe copy of step k's grids (642 MB) lands while step k + 1 computes
+    # (what a caller that keeps asking for triangles gets: reported beside the headline, never as `value`)
+    pipelined_ms = None
+    if prof is None:
         ts = time.perf_counter()
-        for _ in range(3):
-            dens = one_step(mc, pairs_all, dist, rank, world, torch_device, 0)
+        for _ in range(args.steps):
+            dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world, comm)
+        if dens:
             dens[-1].P
         barrier()
-        serial_ms = (time.perf_counter() - ts) / 3 * 1e3
+        pipelined_ms = (time.perf_counter() - ts) / args.steps * 1e3
+    serial_ms = elapsed / args.steps * 1e3
     gc.enable()
     if prof is not None:
         import pstats
@@ -939,9 +949,11 @@ def main():
             "metric": "2D KDE densities/sec (triangle, %d params, %s samples)" % (args.nparams, "{:.0e}".format(args.nsamples)),
             "value": value, "unit": "densities/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_single_triangle_latency": serial_ms,
-            # host time between the returns of consecutive steps (a step returns once its last batch is enqueued, so in
-            # steady state this is the GPU's pace); the last entry is the wait for the final step's grids
-            "ms_between_step_returns": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_returned, step_returned + [t0 + elapsed])],
+            # the stream-of-triangles rate (result copies of step k under step k + 1): a second figure, not the headline
+            "ms_per_step_pipelined": pipelined_ms,
+            "value_pipelined": (None if pipelined_ms is None else npairs / (pipelined_ms * 1e-3)),
+            # host time from one delivered triangle to the next
+            "ms_between_delivered_triangles": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_returned[:-1], step_returned)],
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded block recipe, SURVEY.md 8d C3)",
             "config": {"workload": "C3: 2D KDE triangle, %d params (%d pairs), N=%d unit-weight samples, base fine_bins_2D=256, "
@@ -949,9 +961,10 @@ def main():
                                    "per-parameter prep, bandwidth selection (fixed point + TNC on the device) and D2H of all grids"
                                    % (args.nparams, npairs, args.nsamples),
                        "parallelism": "pairs partitioned over %d GPU(s), samples replicated" % world,
-                       "pipelining": "the PCIe copy of a step's grids to the host (642 MB) finishes while the next step "
-                                     "computes; the clock stops after the last step's copies have landed. "
-                                     "ms_single_triangle_latency = the same step with its grids read before the next starts",
+                       "timed_region": "K triangles one after the other, each with all its grids on the host before the next "
+                                       "starts (SURVEY 8d's t); value = pairs / that time.  value_pipelined / "
+                                       "ms_per_step_pipelined = the same K steps with the PCIe copy of a step's grids (642 MB) "
+                                       "landing while the next step computes",
                        "setup_s": {"generate": round(t_gen, 2), "construct_upload_basestats": round(t_ctor, 2)}},
         }
         if dist is not None:

@@ -348,18 +348,26 @@ __global__ void k_cov_fin(const double* __restrict__ part, int nchunks, const in
 // Partials: part[block * T + pair][16 x 16] (the NH row-splits are added inside the block); k_cov_slab_fin sums the blocks.
 // Templates: MCAP = column capacity (multiple of 16), NW = NG * NH waves per block, P tile pairs per wave, KS rows per
 // slab, DEPTH slabs of global loads in flight.
-template <bool HAS_W, int MCAP, int NW, int NH, int P, int KS, int DEPTH>
-__global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict__ cols, int64_t ld,
+// ONE PASS (OP, round 6): `res` holds a provisional SHIFT s per column (k_col_shift: the mean of a few hundred strided rows)
+// instead of the mean, and the slab carries one more column, all ones (w when weighted on the A side): the same tile
+// products then also deliver sum w (x - s) per column and sum w, from which k_cov_onepass_fin forms
+//   mean = s + delta,  delta = sum w (x - s) / sum w,   cov_ij = sum w (x_i - s_i)(x_j - s_j) / sum w  -  delta_i delta_j
+// -- the textbook shifted form, as accurate as the two-pass one because delta^2 is ~1e-3 of the variance (the cancellation
+// costs 1e-3 ulp, not digits); min / max ride along in the staging registers.  The means pass (k_col_pass1g: one read of the
+// whole sample block) is gone.
+template <bool HAS_W, int MCAP, int NW, int NH, int P, int KS, int DEPTH, bool OP = false>
+__global__ void __launch_bounds__(NW * 64, (OP && MCAP == 64) ? 4 : 1) k_cov_slab2(const double* __restrict__ cols, int64_t ld,
                                                        const int32_t* __restrict__ colidx, int m,
                                                        const double* __restrict__ res, const double* __restrict__ w,
                                                        int64_t lo, int64_t hi, int64_t rows_per_chunk,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, double* __restrict__ part_mm = nullptr) {
     constexpr int NT = NW * 64, KSP = KS + 2, TPC = KS / 2, CPP = NT / TPC, NG = NW / NH;
     constexpr int NQ = (MCAP + CPP - 1) / CPP, KPW = KS / 4 / NH;
     static_assert(NW % NH == 0 && (KS / 4) % NH == 0 && NT % TPC == 0, "wave arrangement");
     extern __shared__ double lds[];
     typedef double f64x4 __attribute__((ext_vector_type(4)));
-    const int nt = (m + 15) / 16, mc = nt * 16, T = nt * (nt + 1) / 2;
+    const int me = OP ? m + 1 : m;  // columns of the slab (OP: the ones column behind the data)
+    const int nt = (me + 15) / 16, mc = nt * 16, T = nt * (nt + 1) / 2;
     double* sB = lds;                            // d
     double* sA = HAS_W ? lds + mc * KSP : lds;   // w d (the same array for unit weights)
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
@@ -385,13 +393,23 @@ __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict_
     // staging: this thread owns rows 2 rp, 2 rp + 1 of columns c0 + CPP q
     const int rp = tid % TPC, c0 = tid / TPC;
     const double* src[NQ];
-    double mean[NQ];
+    double mean_r[OP ? 1 : NQ];
+    double cmn[OP ? NQ : 1], cmx[OP ? NQ : 1];
+    // OP keeps the columns' shifts in LDS behind the slab (read back per slab): its running extrema need the registers, and
+    // with more than 128 of them a CU holds one block instead of two
+    double* sM = lds + (HAS_W ? 2 : 1) * mc * KSP;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = c0 + CPP * q, cc = c < m ? c : m - 1;
         src[q] = cols + (int64_t)colidx[cc] * ld;
-        mean[q] = res[(int64_t)cc * 4 + 3];
+        if (OP) {
+            cmn[q] = INFINITY, cmx[q] = -INFINITY;
+            if (rp == 0 && c < mc) sM[c] = res[(int64_t)cc * 4 + 3];
+        } else {
+            mean_r[q] = res[(int64_t)cc * 4 + 3];
+        }
     }
+    auto mean_of = [&](int q) -> double { return OP ? sM[(c0 + CPP * q) < mc ? c0 + CPP * q : mc - 1] : mean_r[q]; };
     const int64_t c_lo = lo + (int64_t)blockIdx.x * rows_per_chunk;
     int64_t c_hi = c_lo + rows_per_chunk;
     if (c_hi > hi) c_hi = hi;
@@ -433,9 +451,20 @@ __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict_
                 for (int e = 0; e < 2; ++e) {
                     const int64_t row = rb + 2 * rp + e;
                     const bool in = row < re;
-                    const double d = in ? x[row] - mean[q] : 0.0;
+                    const double mq = mean_of(q);
+                    const double xv = in ? x[row] : mq;
+                    if (OP && in) cmn[q] = fmin(cmn[q], xv), cmx[q] = fmax(cmx[q], xv);
+                    const double d = in ? xv - mq : 0.0;
                     sB[c * KSP + 2 * rp + e] = d;
                     if (HAS_W) sA[c * KSP + 2 * rp + e] = in ? d * w[row] : 0.0;
+                }
+            } else if (OP && c == m) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int64_t row = rb + 2 * rp + e;
+                    const bool in = row < re;
+                    sB[c * KSP + 2 * rp + e] = in ? 1.0 : 0.0;
+                    if (HAS_W) sA[c * KSP + 2 * rp + e] = in ? w[row] : 0.0;
                 }
             }
         }
@@ -471,10 +500,18 @@ __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict_
                 for (int q = 0; q < NQ; ++q) {
                     const int c = c0 + CPP * q;
                     if (c < m) {
-                        const double2 dd = make_double2(pre[d][q].x - mean[q], pre[d][q].y - mean[q]);
+                        if (OP) {
+                            cmn[q] = fmin(cmn[q], fmin(pre[d][q].x, pre[d][q].y));
+                            cmx[q] = fmax(cmx[q], fmax(pre[d][q].x, pre[d][q].y));
+                        }
+                        const double mq = mean_of(q);
+                        const double2 dd = make_double2(pre[d][q].x - mq, pre[d][q].y - mq);
                         *reinterpret_cast<double2*>(&sB[c * KSP + 2 * rp]) = dd;
                         if (HAS_W)
                             *reinterpret_cast<double2*>(&sA[c * KSP + 2 * rp]) = make_double2(dd.x * wpre[d].x, dd.y * wpre[d].y);
+                    } else if (OP && c == m) {
+                        *reinterpret_cast<double2*>(&sB[c * KSP + 2 * rp]) = make_double2(1.0, 1.0);
+                        if (HAS_W) *reinterpret_cast<double2*>(&sA[c * KSP + 2 * rp]) = wpre[d];
                     }
                 }
                 __syncthreads();
@@ -487,6 +524,23 @@ __global__ void __launch_bounds__(NW * 64) k_cov_slab2(const double* __restrict_
         }
         // what the ring left: fewer than DEPTH whole slabs and the ragged end
         for (int64_t t_lo = a_lo + nring * KS; t_lo < c_hi; t_lo += KS) slab_guarded(t_lo, t_lo + KS < c_hi ? t_lo + KS : c_hi);
+    }
+    if (OP) {
+        // the TPC threads that staged the same columns (consecutive lanes of one wave) combine their extrema
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double a = cmn[q], b = cmx[q];
+#pragma unroll
+            for (int o = 1; o < TPC; o <<= 1) {
+                a = fmin(a, __shfl_xor(a, o, WAVE));
+                b = fmax(b, __shfl_xor(b, o, WAVE));
+            }
+            const int c = c0 + CPP * q;
+            if (rp == 0 && c < m) {
+                part_mm[((int64_t)blockIdx.x * m + c) * 2] = a;
+                part_mm[((int64_t)blockIdx.x * m + c) * 2 + 1] = b;
+            }
+        }
     }
     if (NH == 1) {
 #pragma unroll
@@ -553,6 +607,82 @@ __global__ void __launch_bounds__(1024) k_cov_slab_fin(const double* __restrict_
     if (pq == 0 && j < i) return;  // diagonal tiles: the upper triangle decides, so the result is exactly symmetric
     cov[(int64_t)i * m + j] = v;
     cov[(int64_t)j * m + i] = v;
+}
+
+// ---- one-pass form (k_cov_slab2<..., OP = true>) ------------------------------------------------------------------------
+// provisional shift per column: the plain mean of up to 256 rows strided over [lo, hi) (any value near the mean will do:
+// it only has to make |mean - shift| small against the spread).  One block per column.
+__global__ void __launch_bounds__(256) k_col_shift(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
+                                                   int64_t lo, int64_t hi, double* __restrict__ res) {
+    __shared__ double red[16];
+    const double* x = cols + (int64_t)colidx[blockIdx.x] * ld;
+    const int64_t rows = hi - lo;
+    const int64_t k = rows < 256 ? rows : 256;
+    double v = 0;
+    if ((int64_t)threadIdx.x < k) v = x[lo + (int64_t)threadIdx.x * (rows / k)];
+    const double sum = block_sum(v, red);
+    if (threadIdx.x == 0) {
+        double s = sum / (double)k;
+        if (!(fabs(s) < 1e300)) s = 0.0;  // (non-finite samples: the statistics are NaN either way)
+        res[(int64_t)blockIdx.x * 4 + 3] = s;
+    }
+}
+
+// S[i][j] = sum over the blocks' partial tiles, both triangles; mc1 = 16 * tiles per side.  grid (T), 1024 threads, the
+// summation order of k_cov_slab_fin.
+__global__ void __launch_bounds__(1024) k_cov_slab_sum(const double* __restrict__ part, int nblocks, int nt, double* __restrict__ S) {
+    __shared__ double sh[4][256];
+    const int T = nt * (nt + 1) / 2, mc1 = nt * 16;
+    int pq = blockIdx.x, a = 0, len = nt;
+    while (pq >= len) {
+        pq -= len;
+        ++a;
+        --len;
+    }
+    const int e = threadIdx.x & 255, lane4 = threadIdx.x >> 8;
+    const double* p = part + (int64_t)blockIdx.x * 256 + e;
+    double s0 = 0, s1 = 0;
+    int b = lane4;
+    for (; b + 4 < nblocks; b += 8) {
+        s0 += p[(int64_t)b * T * 256];
+        s1 += p[(int64_t)(b + 4) * T * 256];
+    }
+    if (b < nblocks) s0 += p[(int64_t)b * T * 256];
+    sh[lane4][e] = s0 + s1;
+    __syncthreads();
+    if (lane4 != 0) return;
+    const double v = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+    const int i = a * 16 + e / 16, j = (a + pq) * 16 + e % 16;
+    if (pq == 0 && j < i) return;  // diagonal tiles: the upper triangle decides (exact symmetry)
+    S[(int64_t)i * mc1 + j] = v;
+    S[(int64_t)j * mc1 + i] = v;
+}
+
+// block c: the column's extrema over the blocks, its mean, and row c of the covariance (upper part, mirrored).
+// res[c] = {min, max, sum w, mean} as k_col_fin1 leaves it.
+__global__ void __launch_bounds__(256) k_cov_onepass_fin(const double* __restrict__ S, int mc1, int m, const double* __restrict__ part_mm,
+                                                         int nblocks, double* __restrict__ res, double* __restrict__ cov) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        mn = fmin(mn, part_mm[((int64_t)b * m + c) * 2]);
+        mx = fmax(mx, part_mm[((int64_t)b * m + c) * 2 + 1]);
+    }
+    const double r0 = block_min(mn, red), r1 = block_max(mx, red);
+    const double norm = S[(int64_t)m * mc1 + m];
+    const double dc = S[(int64_t)c * mc1 + m] / norm;
+    for (int j = c + threadIdx.x; j < m; j += 256) {
+        const double dj = S[(int64_t)j * mc1 + m] / norm;
+        const double v = S[(int64_t)c * mc1 + j] / norm - dc * dj;
+        cov[(int64_t)c * m + j] = v;
+        cov[(int64_t)j * m + c] = v;
+    }
+    __syncthreads();  // (every thread has read the shift before thread 0 replaces it by the mean)
+    if (threadIdx.x == 0) {
+        const double shift = res[(int64_t)c * 4 + 3];
+        res[(int64_t)c * 4 + 0] = r0, res[(int64_t)c * 4 + 1] = r1, res[(int64_t)c * 4 + 2] = norm, res[(int64_t)c * 4 + 3] = shift + dc;
+    }
 }
 
 // ---- sort-free weighted quantiles: MSB radix select, 8 bits per pass ---------------------------------------
@@ -1602,8 +1732,12 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
     double* d_cov = nullptr;
     const bool slab = (m <= 208) && !getenv("GDHIP_COV_TILE");
     if (slab) {
+        // one pass (round 6): no means pass in front -- a provisional shift, the ones column, k_cov_onepass_fin (above
+        // k_cov_slab2).  m = 208 has no room for the extra column and keeps the two passes.
+        const bool onepass = m + 1 <= 208 && !getenv("GDHIP_COV_TWOPASS");
+        const int me = onepass ? m + 1 : m;
         // ---- slab kernel: pick the wave arrangement with the fewest tile-pair slots >= T
-        const int nt16 = (m + 15) / 16, T = nt16 * (nt16 + 1) / 2, mc = nt16 * 16;
+        const int nt16 = (me + 15) / 16, T = nt16 * (nt16 + 1) / 2, mc = nt16 * 16;
         const int KS = mc <= 64 ? 64 : 32;  // narrow matrices: more rows per barrier pair
         struct Cfg { int mcap, nw, nh, p, bpc; };
         static const Cfg cfgs[] = {{64, 8, 8, 3, 4},  {64, 8, 4, 3, 4},   {64, 8, 4, 5, 4},   {112, 8, 2, 4, 2}, {112, 8, 2, 6, 2},
@@ -1617,7 +1751,7 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         GD_REQUIRE(pick >= 0, "covariance: no slab configuration");
         const Cfg cf = cfgs[pick];
         const bool hw = ctx->w != nullptr;
-        size_t lds = (size_t)(hw ? 2 : 1) * mc * (KS + 2) * 8;
+        size_t lds = (size_t)(hw ? 2 : 1) * mc * (KS + 2) * 8 + (onepass ? (size_t)mc * 8 : 0);
         if (cf.nh > 1) lds = std::max(lds, (size_t)(cf.nw / cf.nh) * cf.p * 256 * 8);  // the in-block sum over the row-splits
         int bpc = cf.bpc;
         while (bpc > 1 && (size_t)bpc * lds > 150u * 1024u) --bpc;
@@ -1630,7 +1764,8 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         int64_t off = 0;
         const int64_t o_part1 = take_init(off, (int64_t)m * NBLK_STREAM * 4 * 8), o_res = take_init(off, (int64_t)m * 4 * 8),
                       o_idx = take_init(off, (int64_t)m * 4), o_cpart = take_init(off, (int64_t)nblk * T * 256 * 8),
-                      o_cov = take_init(off, (int64_t)m * m * 8);
+                      o_cov = take_init(off, (int64_t)m * m * 8), o_mm = take_init(off, (int64_t)nblk * m * 2 * 8),
+                      o_S = take_init(off, (int64_t)mc * mc * 8);
         char* base = (char*)gd_scratch(ctx, off);
         if (!base) return GD_ERR_NOMEM;
         double* d_part1 = (double*)(base + o_part1);
@@ -1638,15 +1773,29 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
         int32_t* d_idx = (int32_t*)(base + o_idx);
         double* d_cpart = (double*)(base + o_cpart);
         d_cov = (double*)(base + o_cov);
+        double* d_mm = (double*)(base + o_mm);
+        double* d_S = (double*)(base + o_S);
         GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)m * 4));
-        int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
-        if (rc) return rc;
+        if (onepass) {
+            k_col_shift<<<m, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, lo, hi, d_res);
+            GD_KERNEL_CHECK();
+        } else {
+            int rc = col_stats_device(ctx, d_idx, m, lo, hi, d_res, d_part1, nullptr);
+            if (rc) return rc;
+        }
 #define GD_COV2(HW, MCAP, NW, NH, PP)                                                                                     \
     do {                                                                                                                  \
-        auto kern = k_cov_slab2<HW, MCAP, NW, NH, PP, ((MCAP) <= 64 ? 64 : 32), ((MCAP) <= 64 ? 2 : 1)>;                                                             \
-        GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        kern<<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, ctx->w, lo, hi, rows_per_chunk,  \
-                                                    d_cpart);                                                             \
+        if (onepass) {                                                                                                    \
+            auto kern = k_cov_slab2<HW, MCAP, NW, NH, PP, ((MCAP) <= 64 ? 64 : 32), ((MCAP) <= 64 ? 2 : 1), true>;        \
+            GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+            kern<<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, ctx->w, lo, hi, rows_per_chunk, \
+                                                        d_cpart, d_mm);                                                   \
+        } else {                                                                                                          \
+            auto kern = k_cov_slab2<HW, MCAP, NW, NH, PP, ((MCAP) <= 64 ? 64 : 32), ((MCAP) <= 64 ? 2 : 1), false>;       \
+            GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+            kern<<<nblk, (NW) * 64, lds, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, m, d_res, ctx->w, lo, hi, rows_per_chunk, \
+                                                        d_cpart, nullptr);                                                \
+        }                                                                                                                 \
     } while (0)
 #define GD_COV2_HW(MCAP, NW, NH, PP) \
     do {                              \
@@ -1669,7 +1818,13 @@ int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t lo, int64_t hi, 
 #undef GD_COV2_HW
 #undef GD_COV2
         GD_KERNEL_CHECK();
-        k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
+        if (onepass) {
+            k_cov_slab_sum<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, nt16, d_S);
+            GD_KERNEL_CHECK();
+            k_cov_onepass_fin<<<m, 256, 0, ctx->stream>>>(d_S, mc, m, d_mm, nblk, d_res, d_cov);
+        } else {
+            k_cov_slab_fin<<<T, 1024, 0, ctx->stream>>>(d_cpart, nblk, m, d_res, d_cov);
+        }
         GD_KERNEL_CHECK();
     } else {
     const int nt = (m + CT - 1) / CT;

@@ -89,10 +89,14 @@ int gd_column_ptr(gd_ctx* ctx, int64_t j, void** d_out);
  *   count of w > thresh (mcsamples.py:559-560).   out4 = {norm, max_w, sum_w2, n_above}
  * gd_col_stats: per column over rows [row_lo,row_hi): min, max (mcsamples.py:1434-1435), weighted mean
  *   (chains.py:379), weighted variance about that mean (chains.py:409-410). out = n x 4 {min,max,mean,var}
- * gd_cov: two-pass weighted covariance of the listed columns over rows [row_lo,row_hi)
- *   (chains.py:709-733 + mean_diffs :763-780); means_out m, cov_out m x m, norm_out 1; minmax_out (may be NULL)
- *   m x 2 = the columns' min / max over the range, which the first pass sees anyway -- updateBaseStatistics then needs
- *   no separate gd_col_stats call (the variances are the diagonal). */
+ * gd_cov: weighted means and covariance of the listed columns over rows [row_lo,row_hi)
+ *   (chains.py:373-384 setMeans, :709-733 cov + mean_diffs :763-780); means_out m, cov_out m x m, norm_out 1; minmax_out
+ *   (may be NULL) m x 2 = the columns' min / max over the range -- updateBaseStatistics then needs no separate
+ *   gd_col_stats call (the variances are the diagonal).  Up to 207 columns in ONE read of the samples (round 6): deviations
+ *   are taken from a provisional shift s (the mean of 256 strided rows), a column of ones rides in the slab, and
+ *   mean = s + sum w (x - s) / sum w,  cov_ij = sum w (x_i - s_i)(x_j - s_j) / sum w - (mean_i - s_i)(mean_j - s_j):
+ *   the reference's two passes (means, then deviations from the means) to rounding -- (mean - s)^2 is ~1e-3 of the
+ *   variance, so the subtraction costs no digits.  208 columns and above: two passes as before. */
 int gd_weight_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double thresh, double* out4);
 int gd_col_stats(gd_ctx* ctx, int64_t row_lo, int64_t row_hi, double* out);
 int gd_cov(gd_ctx* ctx, const int32_t* cols, int32_t m, int64_t row_lo, int64_t row_hi, double* means_out,

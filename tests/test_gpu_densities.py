@@ -32,8 +32,8 @@ def test_stats_and_ranges(zoo, name):
     mc = make(fx)
     assert gu.relerr(mc.means, g["means"]) < 1e-12
     assert gu.relerr(mc.vars, g["vars"]) < 1e-12
-    assert gu.relerr(mc.fullcov, g["cov"]) < 1e-11
-    assert gu.relerr(mc.getCorrelationMatrix(), g["corr"]) < 1e-11
+    assert gu.relerr(mc.fullcov, g["cov"]) < 1e-12  # cov / means rel 1e-12
+    assert gu.relerr(mc.getCorrelationMatrix(), g["corr"]) < 1e-12
     fracs = g["quantile_fracs"]
     for j in range(mc.n):
         q = mc.confidence(j, fracs)
@@ -72,9 +72,24 @@ def test_density_1d(zoo, name):
                 got = np.array([float(getattr(par, a)) for a in gu.PAR_ATTS])
                 want = g["par/%s" % nm]
                 assert np.array_equal(got[7:9], want[7:9]), (nm, "limit flags")
-                assert gu.relerr(got[:7], want[:7]) < 1e-11, (nm, got, want)
+                assert gu.relerr(got[:7], want[:7]) < 1e-12, (nm, got, want)
                 assert abs(got[9] - want[9]) <= 1e-9 * want[9], (nm, "N_eff", got[9], want[9])
-                assert abs(got[10] - want[10]) <= 1e-6 * want[10], (nm, "kde_h", got[10], want[10])
+                # kde_h rel 1e-9.  A flat shape has no fixed point: fsolve wanders over rounding noise until it
+                # gives up or "converges" on it, and the width it leaves is reproducible only to ~1e-4
+                flat = nm in FLAT_1D_SHAPES
+                assert abs(got[10] - want[10]) <= (1e-4 if flat else 1e-9) * want[10], (nm, "kde_h", got[10], want[10])
+
+
+# 1D shapes whose ISJ fixed point has no root (uniform between hard bounds and the like): see test_density_1d
+FLAT_1D_SHAPES = ()
+
+
+def chaotic_pair_names():
+    """tests/golden/tnc_chaotic_pairs.json: the pairs on which the oracle itself is chaotic (made and re-checked on the CPU)"""
+    import json
+    import os
+
+    return set(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tnc_chaotic_pairs.json")))["pairs"])
 
 
 def uses_tnc(d, mc, a, b):
@@ -98,6 +113,7 @@ TOL_PSI = 1e-10     # psi functionals at t* (fp64 bilinear forms, different summ
 # (amise_within_oracle_range), AND per fixture there may not be more loose pairs than pairs
 # on which the oracle is chaotic.  The report also counts the pairs on which the ORACLE's TNC, fed the DEVICE's
 # functionals, leaves its own result: the part of the looseness that is nothing but psi rounding.
+TOL_BW = 1e-9       # kde_h, t*, (hx, hy, c) rel 1e-9 (measured <= 5e-16 on every pair that does not go through TNC)
 TOL_GRID_TNC = 5e-4
 TOL_BW_TNC = 0.25  # the AMISE is nearly flat in the correlation direction; the grid tolerance is the real gate
 PARITY_REPORT = {}
@@ -109,7 +125,7 @@ def _write_parity_report():
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r05_parity_2d.json"), "w") as f:
+    with open(os.path.join(out, "r06_parity_2d.json"), "w") as f:
         json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -120,6 +136,7 @@ def test_density_2d(zoo, name):
         pytest.skip("1D-only fixture")
     g = gu.load(name)
     mc = make(fx)
+    CHAOTIC = chaotic_pair_names()
     orc = ko.OracleSamples(fx["samples"], fx["weights"], names=fx["names"], ranges=fx["ranges"])
     report = PARITY_REPORT.setdefault(name, dict(pairs=0, tnc_pairs=0, loose=[], worst_tstar=0.0, worst_psi=0.0,
                                                  worst_grid_strict=0.0, worst_grid_loose=0.0, worst_bw_strict=0.0,
@@ -149,7 +166,9 @@ def test_density_2d(zoo, name):
                     assert e_t <= TOL_TSTAR, (key, d.kopt[0], tr["t_star"])
                     assert e_p <= TOL_PSI, (key, d.kopt, want)
             bw_err = gu.relerr(d.bandwidth, (tr["hx"], tr["hy"], tr["c"])) if auto else 0.0
-            bw_agrees = bw_err < 1e-6
+            # (hx, hy, c) rel 1e-9.  A pair that goes through TNC may differ by what the ORACLE differs from
+            # itself for rounding-equal inputs (4 x the spread of its +-1..12e-15 ensemble, computed below) when that is more
+            bw_tol = TOL_BW
             ens = None
             if tnc and "p_13" in tr and d.kopt is not None:
                 # every TNC pair: what the oracle does for rounding-equal inputs, and for the device's own functionals
@@ -162,6 +181,11 @@ def test_density_2d(zoo, name):
                 # (reported only) does scipy's TNC on the DEVICE's functionals land on the device's triple?
                 oracle_on_device_psi_gives_device_triple = bool(
                     np.max(np.abs(on_dev - d.kopt[8:11])) <= 1e-6 * np.max(np.abs(on_dev)))
+                bw_tol = min(max(TOL_BW, 4 * moved), 1e-6)
+            bw_agrees = bw_err < bw_tol
+            if bw_agrees and bw_err >= TOL_BW:
+                report.setdefault("tnc_pairs_between_1e_9_and_the_oracles_own_spread", []).append(
+                    dict(pair=key, bandwidth_error=float(bw_err), oracle_moves_by=moved))
             if not bw_agrees:
                 # the loose gate must be earned: a TNC pair whose bandwidth the ORACLE cannot reproduce under a 1e-15
                 # perturbation of its own inputs, and a device result inside the oracle's own spread
@@ -179,11 +203,12 @@ def test_density_2d(zoo, name):
                                             # rules (ko.FROZEN_CARVE_OUT), how far the nearest ensemble member is, and
                                             # whether the strict slack of 0.25 admits it as well
                                             admitted_by=verdict["admitted_by"], nearest_member_rel=verdict["nearest_member"],
-                                            strict_slack_0p25_admits=bool(verdict["strict_ok"]),
-                                            strict_scale=verdict["strict_scale"], strict_admitted_by=verdict["strict_admitted_by"]))
+                                            admitted_at_slack_1p0_reported_only=bool(verdict["ok_at_slack_1"])))
                 report["worst_excess_over_oracle_spread"] = max(report["worst_excess_over_oracle_spread"], excess)
                 assert moved > 1e-6, (key, "device and oracle bandwidths differ by %.2e but the oracle is stable (moves %.2e)"
                                       % (bw_err, moved))
+                # ... and the pair must be one of the committed list (frozen: tests/test_oracle_golden.py recomputes it)
+                assert "%s/%s" % (name, key) in CHAOTIC, (key, "loose, but not on tests/golden/tnc_chaotic_pairs.json")
                 # the chaotic map has more outcomes than 24 perturbations sample: a triple outside their range must at
                 # least be as good in the reference's own objective (the AMISE floor is flat where TNC stops)
                 assert verdict["ok"], (key, "device triple outside the oracle's spread and worse in AMISE", d.kopt[8:11], verdict)
@@ -191,7 +216,7 @@ def test_density_2d(zoo, name):
             elif auto:
                 report["worst_bw_strict"] = max(report["worst_bw_strict"], float(bw_err))
                 if not tnc:
-                    assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < 1e-6, (key, d.bandwidth, g[key + "/hxhyc"])
+                    assert gu.relerr(d.bandwidth, g[key + "/hxhyc"]) < TOL_BW, (key, d.bandwidth, g[key + "/hxhyc"])
             tol = TOL_GRID if bw_agrees else TOL_GRID_TNC
             e_grid = float(np.max(np.abs(d.P - o["P"])))
             report["worst_grid_strict" if bw_agrees else "worst_grid_loose"] = max(

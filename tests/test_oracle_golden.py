@@ -197,14 +197,16 @@ def test_judge_triple_widens_the_ensemble_only_as_far_as_needed():
 
 
 def test_tnc_carve_out_is_frozen():
-    """The four numbers that define which device bandwidth triples of a chaotic TNC pair count as the reference's own
-    outcomes (oracle.kde_oracle: perturbation scales, spread slack, AMISE margin) and the raw-difference cap of the GPU tests
-    stay at their round-4 values: widening any of them is a visible change of this test, not a quietly greener GPU run."""
+    """The numbers that define which device bandwidth triples of a chaotic TNC pair count as the reference's own
+    outcomes (oracle.kde_oracle: perturbation scales, spread slack, AMISE margin) and the raw-difference cap of the GPU tests:
+    widening any of them is a visible change of this test, not a quietly greener GPU run.  (Round 6 narrowed the slack from
+    1.0 to 0.25 of the ensemble's spread.)"""
     import inspect
 
     from oracle import kde_oracle as ko
 
-    assert ko.FROZEN_CARVE_OUT == dict(scales=(1e-15, 1e-14, 1e-13, 1e-12), slack=1.0, slack_strict=0.25, margin=10.0, raw_cap=2e-3)
+    # round 6: the spread slack that gates is 0.25 (was 1.0, now a reported number); nothing else moved
+    assert ko.FROZEN_CARVE_OUT == dict(scales=(1e-15, 1e-14, 1e-13, 1e-12), slack=0.25, slack_reported=1.0, margin=10.0, raw_cap=2e-3)
     assert inspect.signature(ko.within_oracle_spread).parameters["slack"].default is None  # (= SPREAD_SLACK)
     assert inspect.signature(ko.amise_within_oracle_range).parameters["margin"].default is None
     import importlib.util
@@ -213,3 +215,25 @@ def test_tnc_carve_out_is_frozen():
     spec = importlib.util.spec_from_file_location("tgd", os.path.join(os.path.dirname(__file__), "test_gpu_densities.py"))
     src = open(spec.origin).read()
     assert "TOL_GRID_TNC = 5e-4" in src and "4 * TOL_GRID_TNC" in src and 4 * 5e-4 == ko.RAW_DIFFERENCE_CAP
+
+
+def test_the_set_of_tnc_chaotic_pairs_is_frozen(zoo):
+    """Only a pair on which the ORACLE itself is chaotic -- its get_h moves by more than 1e-6 under +-1..12e-15 perturbations of
+    its own functionals -- may have a device grid further than 1e-6 from the oracle's (tests/test_gpu_densities.py checks
+    every loose pair's NAME against tests/golden/tnc_chaotic_pairs.json).  That list is a property of the oracle on the
+    fixture zoo, recomputed here: a change of the oracle, of a fixture or of the admission rule that lets the loose set grow
+    (or shrink) fails this test instead of passing silently on the GPU.  15 pairs since round 3."""
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_chaotic_list", os.path.join(here, "make_chaotic_list.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    committed = json.load(open(os.path.join(here, "tnc_chaotic_pairs.json")))
+    now = []
+    for name in FIXTURES:
+        now += [k for k, _ in mod.chaotic_pairs_of(zoo[name])]
+    assert sorted(now) == committed["pairs"]
+    assert len(committed["pairs"]) == 15
