@@ -62,10 +62,21 @@ class ParamError(MCSamplesError):
     pass
 
 
-class ParamInfo:
+try:
+    # GetDist's plotting layer -- the caller this package is a drop-in for -- recognises a parameter object by
+    # isinstance(param, getdist.paramnames.ParamInfo) (plots.py:607,1981,2027).  Where GetDist is installed beside this
+    # package our parameter objects therefore derive from its class; without it they stand alone.
+    from getdist.paramnames import ParamInfo as _PlotParamInfo
+except Exception:  # noqa: BLE001 -- not installed (or not importable): nothing of the path needs it
+    _PlotParamInfo = object
+
+
+class ParamInfo(_PlotParamInfo):
     """Per-parameter state bag; the attributes the hot path reads and writes (paramnames.py:69-154)."""
 
     def __init__(self, name, label=None):
+        if _PlotParamInfo is not object:
+            super().__init__(name=name, label=label or name)
         self.name = name
         self.label = label or name
         self.isDerived = False
@@ -74,6 +85,16 @@ class ParamInfo:
         self.periodic = False
         self.N_eff_kde = None
         self.kde_h = None
+        self.renames = []   # alternative names a caller may use for this parameter (paramnames.py:86)
+        self.comment = ""
+
+    def getLabel(self):
+        """paramnames.py:120-124"""
+        return self.label if self.label else self.name
+
+    def latexLabel(self):
+        """paramnames.py:126-130: what the plotting layer writes on an axis"""
+        return "$" + self.label + "$" if self.label else self.name
 
     def __repr__(self):
         return "ParamInfo(%s)" % self.name
@@ -143,13 +164,60 @@ class ParamNames:
         labels = labels or [None] * len(names)
         self.names = [ParamInfo(n, lab) for n, lab in zip(names, labels)]
 
-    def parWithName(self, name, error=False):
+    def parWithName(self, name, error=False, renames=None):
+        """paramnames.py:232-255: the parameter called ``name`` -- by its own name, by one of its ``renames``, or through the
+        optional ``renames`` mapping {name: alternative name(s)} the plotting layer passes along."""
+        if not isinstance(name, str):
+            raise ValueError('"name" must be a parameter name string not %s: %s' % (type(name), name))
+
+        def alts(key):
+            v = renames.get(key, []) if renames else []
+            return [v] if isinstance(v, str) else list(v)
+
+        asked = {name, *alts(name)}
         for p in self.names:
-            if p.name == name:
+            if asked & {p.name, *getattr(p, "renames", []), *alts(p.name)}:
                 return p
         if error:
             raise ParamError("parameter name not found: %s" % name)
         return None
+
+    def hasParam(self, name):
+        return self.numberOfName(name) != -1
+
+    def getMatches(self, pattern, strings=False):
+        """paramnames.py:299-307: parameters whose name matches a shell-style pattern"""
+        import fnmatch
+
+        return [(p.name if strings else p) for p in self.names if fnmatch.fnmatchcase(p.name, pattern)]
+
+    def parsWithNames(self, names, error=False, renames=None):
+        """paramnames.py:273-297: ParamInfo per name (None where a name is unknown and ``error`` is false for it); names
+        holding * or ? expand to every match; ``error`` may be one flag or one per name."""
+        if isinstance(names, str):
+            names = [names]
+        flags = list(error) if isinstance(error, (list, tuple)) else [error]
+        if len(flags) < len(names):
+            flags = len(names) * flags
+        out = []
+        for nm, flag in zip(names, flags):
+            if isinstance(nm, ParamInfo):
+                out.append(nm)
+            elif "?" in nm or "*" in nm:
+                out += self.getMatches(nm)
+            else:
+                out.append(self.parWithName(nm, flag, renames))
+        return out
+
+    def getRenames(self, keep_empty=False):
+        """paramnames.py:324-332"""
+        return {p.name: list(getattr(p, "renames", [])) for p in self.names if keep_empty or getattr(p, "renames", [])}
+
+    def numParams(self):
+        return len(self.names)
+
+    def labels(self):
+        return [p.label for p in self.names]
 
     def numberOfName(self, name):
         for i, p in enumerate(self.names):
@@ -890,6 +958,33 @@ class MCSamples:
         self.paramNames.names.append(par)
         self._replace_samples(new, self.weights, self.loglikes, self.chain_offsets)
         return par
+
+    # ---- what GetDist's plotting layer asks a sample set for besides densities (plots.py:655-690,933-955,2262-2290) ------
+    def getParamNames(self):
+        """chains.py:1221-1225"""
+        return self.paramNames
+
+    def getRenames(self):
+        return self.paramNames.getRenames()
+
+    def getName(self):
+        return self.name_tag
+
+    def getLabel(self):
+        """chains.py:260-266: the samples' label for legends (the name tag with LaTeX specials escaped when there is none)"""
+        if self.label:
+            return self.label
+        name = self.getName()
+        return None if name is None else "".join("\\" + ch if ch in "_&%$#{}" else ch for ch in name)
+
+    def getUpper(self, name):
+        """mcsamples.py:2311-2321: the hard upper bound in force for the parameter (None: unbounded / unknown name)"""
+        par = self.paramNames.parWithName(name)
+        return getattr(par, "limmax", None) if par else None
+
+    def getLower(self, name):
+        par = self.paramNames.parWithName(name)
+        return getattr(par, "limmin", None) if par else None
 
     def getParams(self):
         """chains.py:1252-1268 in spirit: an object with one attribute per parameter name holding its sample vector"""

@@ -20,6 +20,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+REFERENCE = os.environ.get("GETDIST_REFERENCE", "/root/reference")
+# GetDist "installed beside" the package: getdist_amd's parameter objects then derive from getdist.paramnames.ParamInfo, which
+# is how the plotting layer recognises them (must be importable BEFORE getdist_amd is imported)
+sys.path.insert(0, REFERENCE)
 GOLD = os.path.join(ROOT, "tests", "golden", "triangle_plot_levels.npz")
 FIXTURE, NPAR, ROOTNAME = "c1_bounded", 4, "amd_chain"
 
@@ -39,7 +43,6 @@ def draw(mc, params):
     import matplotlib
 
     matplotlib.use("Agg")
-    sys.path.insert(0, "/root/reference")
     from getdist import plots
     from matplotlib.contour import QuadContourSet
 
@@ -85,11 +88,48 @@ def draw(mc, params):
     return out
 
 
+def draw_reference(params):
+    """The same figure from the reference's own MCSamples on the same arrays (its per-pair calls, its numpy / scipy path)."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from getdist import MCSamples as RefSamples
+    from getdist import plots
+    from matplotlib.contour import QuadContourSet
+    from oracle.fixtures import fixture_zoo
+
+    fx = {f["name"]: f for f in fixture_zoo()}[FIXTURE]
+    ref = RefSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"], label="reference")
+    g = plots.get_subplot_plotter()
+    g.triangle_plot([ref], params, filled=True)
+    out = {}
+    n = len(params)
+    for i in range(n):
+        line = g.subplots[i, i].get_lines()[0]
+        out["1d/%s/y" % params[i]] = np.asarray(line.get_ydata(), float)
+        for i2 in range(i + 1, n):
+            ax = g.subplots[i2, i]
+            sets = [c for c in ax.get_children() if isinstance(c, QuadContourSet)]
+            out["2d/%s/%s/levels" % (params[i], params[i2])] = np.unique(np.concatenate([np.asarray(c.levels, float) for c in sets]))
+            out["2d/%s/%s/lims" % (params[i], params[i2])] = np.asarray(list(ax.get_xlim()) + list(ax.get_ylim()), float)
+    import matplotlib.pyplot as plt
+
+    plt.close("all")
+    return out
+
+
 def main():
     import fake_ctx
 
     mc, params = make_samples(fake_ctx.FakeContext)
     got = draw(mc, params)
+    # the figure the reference draws of the same samples by itself: same contour levels, axis limits and 1D curves
+    ref = draw_reference(params)
+    # (levels of a pair whose bandwidth goes through TNC follow the grid to ~1e-5: the numpy double is not the reference bit
+    # for bit there, DESIGN.md section 4; everything else to 1e-6)
+    for k, v in ref.items():
+        tol = 1e-4 if k.endswith("/levels") else 1e-6
+        assert got[k].shape == v.shape and np.allclose(got[k], v, rtol=tol, atol=1e-9), (k, got[k], v)
     if "--write" in sys.argv:
         np.savez_compressed(GOLD, **got)
         print("wrote", GOLD, len(got), "arrays")
@@ -98,8 +138,8 @@ def main():
     assert sorted(want.files) == sorted(got), (sorted(set(want.files) ^ set(got)))
     for k in want.files:
         assert got[k].shape == want[k].shape and np.allclose(got[k], want[k], rtol=1e-9, atol=1e-12), k
-    print("triangle plot drawn by getdist.plots from the prefilled caches: %d panels, levels / limits / curves equal the golden file"
-          % (len(params) * (len(params) + 1) // 2))
+    print("triangle plot drawn by getdist.plots from the prefilled caches: %d panels; levels / limits / curves equal the golden "
+          "file and the figure the reference draws of the same samples by itself" % (len(params) * (len(params) + 1) // 2))
 
 
 if __name__ == "__main__":

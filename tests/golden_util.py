@@ -329,3 +329,46 @@ def assert_grid_or_oracle_ensemble(d, o, tr, key, tol=1e-6, cap=5e-4, oracle_at=
     else:
         assert err < cap, (key, err)
     return err, True
+
+
+def triangle_plot_golden_checks(zoo, factory=None):
+    """tests/golden/triangle_plot_levels.npz holds what GetDist's REAL plotter (plots.triangle_plot through
+    MCSampleAnalysis.get_density / get_density_grid, plots.py:594-645,2845-2878) drew from caches filled by
+    getdist_amd.plotting.prefill_plot_caches, with the per-pair getters patched to raise (scripts/drive_real_caller.py, build
+    container, reference imported; also compared there with the figure the reference draws of the same samples by itself).
+    Here the same caches are filled on this tier's context (numpy double / HIP path) and compared with that record: the
+    contour levels the plotter drew, the grids and 1D curves it read."""
+    import os
+
+    from getdist_amd.mcsamples import MCSamples
+    from getdist_amd.plotting import prefill_plot_caches
+
+    gold = np.load(os.path.join(GOLDEN_DIR, "triangle_plot_levels.npz"))
+    fx = zoo["c1_bounded"]
+    params = fx["names"][:4]
+    kw = {} if factory is None else dict(_context_factory=factory)
+    mc = MCSamples(samples=fx["samples"], weights=fx["weights"], names=fx["names"], ranges=fx["ranges"], **kw)
+
+    class Analysis:
+        def __init__(self):
+            self.densities_1D, self.densities_2D = {}, {}
+
+    an = Analysis()
+    assert prefill_plot_caches(an, "amd_chain", mc, params=params, conts=2) == (4, 6)
+    exact = factory is not None  # the record was made on the numpy double: that tier reproduces it to rounding
+    for i, a in enumerate(params):
+        d1 = an.densities_1D["amd_chain"][(a, False)]
+        assert np.max(np.abs(d1.P[::8] - gold["cache1d/%s/P8" % a])) < (1e-12 if exact else 1e-6), a
+        # the curve the plotter drew IS the cached density (plots.py:1760-1790 normalises to the maximum, already 1)
+        assert np.max(np.abs(np.interp(gold["1d/%s/x" % a], d1.x, d1.P) - gold["1d/%s/y" % a])) < 1e-6, a
+        for b in params[i + 1:]:
+            d2 = an.densities_2D["amd_chain"][(a, b, False, 2)]
+            drawn = gold["2d/%s/%s/levels" % (a, b)]
+            # matplotlib drew the cache's levels (ascending, closed by an upper level above the maximum of 1)
+            lv = np.sort(np.asarray(d2.contours, dtype=float))
+            assert drawn.size == lv.size + 1 and drawn[-1] > 1.0
+            # (a pair whose bandwidth goes through TNC follows rounding to ~1e-5: DESIGN.md section 4)
+            assert np.allclose(lv, drawn[:-1], rtol=(1e-12 if exact else 1e-4)), (a, b, lv, drawn)
+            assert np.max(np.abs(d2.P[::16, ::16] - gold["cache2d/%s/%s/P16" % (a, b)])) < (1e-12 if exact else 2e-5), (a, b)
+            lims = gold["2d/%s/%s/lims" % (a, b)]
+            assert d2.x[0] <= lims[0] + 1e-9 and d2.x[-1] >= lims[1] - 1e-9 and d2.y[0] <= lims[2] + 1e-9 and d2.y[-1] >= lims[3] - 1e-9

@@ -49,6 +49,12 @@ def test_prefill_plot_caches_on_the_device(zoo):
     gu.prefill_plot_caches_checks(zoo, None)
 
 
+def test_triangle_plot_levels_on_the_device(zoo):
+    """The HIP path's plot caches against the record of GetDist's real plotter (tests/golden/triangle_plot_levels.npz,
+    scripts/drive_real_caller.py): contour levels drawn, grids, 1D curves, axis limits."""
+    gu.triangle_plot_golden_checks(zoo, None)
+
+
 def test_root_constructor_and_binary_cache_on_the_device(tmp_path):
     """SURVEY.md 8f rank 4 on the HIP path: text chains -> MCSamples(root=), the .gdamd_soa cache read into page-locked
     memory and uploaded from there, reload equality, statistics from the reloaded object."""

@@ -11,6 +11,7 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
 import numpy as np
 
 import golden_util as gu
@@ -318,6 +319,29 @@ def test_host_logic_mask_corners(zoo):
 def test_prefill_plot_caches(zoo):
     """plots.MCSampleAnalysis cache layout (plots.py:594-645): keys, contour counts, one batched call per dimension."""
     gu.prefill_plot_caches_checks(zoo, FakeContext)
+
+
+def test_triangle_plot_golden(zoo):
+    """The record of GetDist's real plotter drawing from the prefilled caches (tests/golden/triangle_plot_levels.npz) against
+    the numpy double's caches."""
+    gu.triangle_plot_golden_checks(zoo, FakeContext)
+
+
+def test_real_plotter_draws_from_the_prefilled_caches():
+    """scripts/drive_real_caller.py where GetDist is importable (the build container: /root/reference): the REAL
+    getdist.plots.triangle_plot over MCSampleAnalysis.get_density / get_density_grid draws a 4-parameter triangle of a
+    getdist_amd sample set from caches filled by two batched calls -- the per-parameter / per-pair getters raise -- and the
+    levels, limits and curves equal the committed record and the figure the reference draws by itself."""
+    import subprocess
+    import sys
+
+    ref = os.environ.get("GETDIST_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "getdist")):
+        pytest.skip("GetDist is not available on this box (the record is checked by test_triangle_plot_golden)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "drive_real_caller.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600, env=dict(os.environ, MPLBACKEND="Agg"))
+    assert out.returncode == 0 and "triangle plot drawn by getdist.plots" in out.stdout, out.stdout[-3000:]
 
 
 def test_two_lanes_equal_one_lane(zoo, monkeypatch):
