@@ -115,6 +115,7 @@ const gdb::Ops kOps = {
     },
     /* comm_world */ [](void* h) { return C(h)->comm ? C(h)->comm_world : 0; },
     /* comm_allreduce_sum */ [](void* h, double* inout, int64_t count) { return gd_comm_allreduce_sum(C(h), inout, count); },
+    /* stream_priority */ [](void* ctx, int level) { return gd_stream_priority(C(ctx), level); },
 };
 
 const gdb::Ops1D kOps1D = {

@@ -85,6 +85,8 @@ struct Ops {
     // the context's communicator (gd_comm_init): number of ranks (0: none) / sum all-reduce of a host vector
     int (*comm_world)(void* h);
     int (*comm_allreduce_sum)(void* h, double* inout, int64_t count);
+    // the (idle) context's stream re-created with high (1) / normal (0) / low (-1) priority
+    int (*stream_priority)(void* ctx, int level);
 };
 
 // ---- numpy / CPython scalar semantics --------------------------------------------------------------------------------
@@ -328,6 +330,7 @@ struct State {
     std::map<std::tuple<int, int, int>, IdxCol> idx;     // (column, F, 1 = bytes / 2 = u16)
     Pending prev;                                        // the last lazily delivered call
     void* aux = nullptr;                                 // third context (stream) of large calls: shear chain, get_h
+    void* aux2 = nullptr;                                // fourth: the DEFERRED shear chain + up-scaled classes (round 6)
     int64_t exchanges_entered = 0;                       // N_eff collectives the library ENTERED over the communicator (whether or
                                                          // not the call went on to succeed): gd_batch2d_exchanges
     static constexpr int64_t kCacheLimit = 16LL << 30;
@@ -425,6 +428,10 @@ static inline void release_all(State& st, const Ops& ops, void* h) {
         ops.destroy_aux(st.aux);
         st.aux = nullptr;
     }
+    if (st.aux2) {
+        ops.destroy_aux(st.aux2);
+        st.aux2 = nullptr;
+    }
 }
 
 // ---- the call ----------------------------------------------------------------------------------------------------------
@@ -487,6 +494,27 @@ struct Call {
     // the critical path, the N_eff values are needed after it (round 6: a race the binning used to win by ~0.2 ms)
     std::atomic<int> bin_launching{0};
     bool hold_neff_for_binning = false;
+    // the sheared pairs (and the up-scaled grid classes behind them) are convolved LAST: their O(N) chain -- as long as the
+    // main class's -- may wait until the main binning has run instead of sharing the machine with it (the main class's
+    // histograms gate the optimiser and with it the first result copies: single-triangle latency)
+    std::atomic<int> bin_done{0};
+    bool shear_after_binning = false;
+    // Deferred shear chain (round 6, single-triangle latency): the first result copies can leave once the FIRST optimiser
+    // part's pairs are convolved, and 642 MB of grids then take ~13 ms of PCIe -- so what that first part has to wait for
+    // decides when a triangle is delivered.  The sheared pairs (branch A: min/max of the sheared coordinate, a re-binning pass
+    // over the fp64 samples) and the up-scaled grid classes used to be joined BEFORE any optimiser launch and the sheared pairs
+    // rode in the first part; now their chain runs on a context of its own, starts when the main class has been binned,
+    // the sheared pairs ride in the LAST base part, and the main thread joins the chain only when it builds the first launch
+    // that needs it.  Results are unchanged bit for bit (a pair's grid does not depend on the part it is computed in).
+    std::future<int> shear_future;
+    bool shear_deferred = false, shear_joined = true;
+    int join_shear() {
+        if (shear_joined) return 0;
+        shear_joined = true;
+        const int e = shear_future.valid() ? shear_future.get() : 0;
+        mark("shear: joined");
+        return e;
+    }
     int64_t grid_off = 0;
     int status_at = 0;
     int batch_no = 0;
@@ -924,7 +952,11 @@ struct Call {
         ++batch_no;
         const int B = (int)b.pos.size();
         const int64_t item = (int64_t)F * F * 8;
-        void* d_hist = hists.at(F);
+        void* d_hist;
+        {
+            std::lock_guard<std::mutex> g(enq_mu);  // (the deferred shear chain may be adding the up-scaled classes' buffers)
+            d_hist = hists.at(F);
+        }
         int rc = 0;
         bool whole = B == (int)members.size();
         for (int q = 0; q < B && whole; ++q) whole = b.pos[q] == q;
@@ -1024,6 +1056,18 @@ struct Call {
     };
     typedef std::function<int(const std::vector<int>&, int, int)> ChunkFn;
 
+    // a launch that holds sheared rows, or belongs to a class the deferred chain bins, waits for that chain here
+    template <class BufFn>
+    int ready_for(Launch& L, const BufFn& class_buffer) {
+        if (L.na > 0 || !L.d_hist) {
+            const int e = join_shear();
+            if (e) return e;
+            if (!L.d_hist) L.d_hist = class_buffer(L.F);
+            if (!L.d_hist) return fail(GD_ERR_BADARG, "a grid-size class has no histograms");
+        }
+        return 0;
+    }
+
     int build_batch(Launch& L) {  // the launch's histograms as one device block (a gather unless the class buffer serves)
         const int B = (int)L.ks.size(), F = L.F;
         const int64_t item = (int64_t)F * F * 8;
@@ -1096,6 +1140,9 @@ struct Call {
         return 0;
     }
 
+    // which parts' convolutions go to the main stream (behind the optimiser's stage A there): the last two fifths
+    static bool part_on_main(int index, int nparts) { return nparts > 1 && index >= nparts - std::max(1, 2 * nparts / 5); }
+
     int bandwidth_2d(bool staged, void* aux, const ChunkFn& on_chunk) {
         const int base_F = s.fine_bins_2D;
         const int m = s.mult_bias_correction_order;
@@ -1105,9 +1152,16 @@ struct Call {
             const double e = 1.0 / 6 - 1.0 / (2 + 4 * (1 + m));
             for (int k = 0; k < P; ++k) widen[k] = 1.1 * py_pow(plan.neff[k], e);
         }
-        if (!have_shear) GDB_TRY(shear_histograms(h));
-        const std::vector<int>& A = shear.A;
+        if (!have_shear && !shear_deferred) GDB_TRY(shear_histograms(h));
+        std::vector<int> A;  // (= shear.A, which the deferred chain may still be filling)
+        for (int k = 0; k < P; ++k)
+            if (plan.branch[k] == 0) A.push_back(k);
         const int nA = (int)A.size();
+        auto class_buffer = [&](int F) -> void* {  // (the up-scaled classes' buffers arrive with the deferred chain)
+            std::lock_guard<std::mutex> g(enq_mu);
+            auto it = hists.find(F);
+            return it == hists.end() ? nullptr : it->second;
+        };
         std::vector<int> waiting;
         for (int k = 0; k < P; ++k)
             if (plan.branch[k] == 1) {  // rule of thumb (mcsamples.py:1391-1395)
@@ -1141,10 +1195,14 @@ struct Call {
                     if (const char* e = getenv("GDHIP_KOPT_PART_ALIGN")) align = (size_t)std::max(0, atoi(e));
                     if (align > 1 && F == 256 && part > align) part = std::max<size_t>(align, (part + align / 2 - 1) / align * align);
                 }
-                for (size_t c0 = 0, first = 1; c0 < pos_C.size(); first = 0) {
+                // (deferred shear chain: the sheared rows lead the LAST part instead of the first)
+                const size_t nparts = shear_deferred ? std::max<size_t>(1, (total + part - 1) / part) : 0;
+                for (size_t c0 = 0, first = 1, ip = 0; c0 < pos_C.size(); first = 0, ++ip) {
                     Launch L;
-                    L.F = F, L.na = first ? nA : 0, L.d_hist = hists.at(F);
-                    const size_t take_ = std::min(pos_C.size() - c0, part > (size_t)L.na ? part - (size_t)L.na : (size_t)1);
+                    const bool carries = shear_deferred ? (ip + 1 == nparts || pos_C.size() - c0 <= part) : first != 0;
+                    L.F = F, L.na = carries ? nA : 0, L.d_hist = class_buffer(F);
+                    size_t take_ = std::min(pos_C.size() - c0, part > (size_t)L.na ? part - (size_t)L.na : (size_t)1);
+                    if (shear_deferred && carries) take_ = pos_C.size() - c0;  // the last part takes what is left
                     L.pos.assign(pos_C.begin() + c0, pos_C.begin() + c0 + take_);
                     c0 += take_;
                     L.whole = L.na == 0 && L.pos.size() == mem.size();
@@ -1157,11 +1215,12 @@ struct Call {
             }
             if (pos_C.empty()) continue;
             Launch L;
-            L.F = F, L.na = 0, L.d_hist = hists.at(F), L.pos = pos_C, L.whole = pos_C.size() == mem.size();
+            L.F = F, L.na = 0, L.d_hist = class_buffer(F), L.pos = pos_C, L.whole = pos_C.size() == mem.size();
             for (int q : pos_C) L.ks.push_back(mem[q]);
             launches.push_back(std::move(L));
         }
         if (nA && !merged) {
+            GDB_TRY(join_shear());
             Launch L;
             L.F = base_F, L.na = nA, L.d_hist = shear.d_rot, L.whole = true;
             L.ks = A;
@@ -1170,10 +1229,13 @@ struct Call {
         const int nl = (int)launches.size();
         auto report = [&](std::vector<int> ks, int index) -> int {
             if (!waiting.empty()) {
-                std::vector<int> all = waiting;
+                // the rule-of-thumb pairs ride with the first report -- except, with the deferred shear chain, those of a
+                // class that chain bins (an up-scaled grid): they wait for the last report, when the chain has been joined
+                std::vector<int> all, later;
+                for (int k : waiting) ((shear_deferred && ps.F[k] != base_F && index + 1 < nl) ? later : all).push_back(k);
                 all.insert(all.end(), ks.begin(), ks.end());
                 ks.swap(all);
-                waiting.clear();
+                waiting.swap(later);
             }
             if (m)
                 for (int k : ks) W[(size_t)3 * k] *= widen[k], W[(size_t)3 * k + 1] *= widen[k];
@@ -1185,7 +1247,8 @@ struct Call {
             for (int q = 0; q < nl && !rc; ++q) {
                 Launch& L = launches[q];
                 const int B = (int)L.ks.size();
-                rc = build_batch(L);
+                rc = ready_for(L, class_buffer);
+                if (!rc) rc = build_batch(L);
                 std::vector<double> out((size_t)B * 12);
                 if (!rc) {
                     mark("kopt: launch", B, L.F);
@@ -1222,7 +1285,11 @@ struct Call {
                     }
                     if (q < 0) return e;
                     if (e) continue;
-                    {  // a part's convolution may use the main context: the staging thread must be done with it
+                    if (part_on_main(q, nl) || !shear_deferred) {
+                        // this part's convolution uses the main context: the staging thread must be done with it.  (The
+                        // earlier parts go to the second context only -- with the deferred shear chain the staging thread
+                        // may still be waiting for that chain when the first part's bandwidths are final, and the first
+                        // part's grids are what the result copies start with.)
                         std::unique_lock<std::mutex> g(mu);
                         cv.wait(g, [&] { return n_staged >= nl || abort_; });
                         if (n_staged < nl) {
@@ -1269,7 +1336,8 @@ struct Call {
             for (int q = 0; q < nl && !rc; ++q) {
                 Launch& L = launches[q];
                 const int B = (int)L.ks.size();
-                rc = build_batch(L);
+                rc = ready_for(L, class_buffer);
+                if (!rc) rc = build_batch(L);
                 if (!rc) {
                     L.d_rows = pool.take((int64_t)B * GD_KOPT_BLOCK_DOUBLES * 8, &rc);
                     if (!L.d_rows) dev_fail(rc, h);
@@ -1299,6 +1367,10 @@ struct Call {
             const int e2 = enqueuer.get();
             if (!rc) rc = e;
             if (!rc) rc = e2;
+        }
+        {
+            const int e = join_shear();  // (an error path may get here before any launch asked for it)
+            if (!rc) rc = e;
         }
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
         return rc;
@@ -1379,16 +1451,46 @@ struct Call {
         if (auto_bw) {
             if (overlap) {
                 const bool split_classes = F_list.size() > 1;
+                bin_done.store(0);
+                {
+                    // deferred shear chain (see shear_future): large unit-weight calls whose main class takes the byte-index
+                    // route; GDHIP_BATCH_SHEAR_DEFERRED=0 restores the join in front of the optimiser
+                    const char* e = getenv("GDHIP_BATCH_SHEAR_DEFERRED");
+                    const char* emin = getenv("GDHIP_BATCH_SHEAR_DEFERRED_MIN");  // (tests lower it)
+                    shear_deferred = (e ? atoi(e) != 0 : true) && unit_weights && P >= (emin ? atoi(emin) : 256);
+                    if (shear_deferred && !st.aux2) {
+                        // (measured: the chain's stream at the LOWEST priority, so that the optimiser's blocks would be
+                        // dispatched ahead of it -- 30.0-30.4 ms per delivered triangle against 29.5-29.7 with the high
+                        // priority create_aux gives it, 30.6-30.8 with the chain joined in front of the optimiser: its
+                        // 1024-thread blocks hold their CUs either way, and a low priority only delays the chain's end)
+                        int rc2 = ops.create_aux(h, &st.aux2);
+                        if (!rc2 && ops.stream_priority && getenv("GDHIP_BATCH_SHEAR_LOW_PRIORITY")) rc2 = ops.stream_priority(st.aux2, -1);
+                        if (rc2) {
+                            if (st.aux2) ops.destroy_aux(st.aux2), st.aux2 = nullptr;
+                            shear_deferred = false, (void)ops.last_error(h);
+                        }
+                    }
+                    shear_after_binning = shear_deferred;
+                }
                 bin_f = std::async(std::launch::async, [this, split_classes] {
                     ops.bind_thread(twin);
-                    return binning(twin, split_classes ? 1 : 0);
+                    const int e = binning(twin, split_classes ? 1 : 0);
+                    bin_done.store(1);
+                    return e;
                 });
                 rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
                 if (!rc)  // the branch plan needs the limits and the covariance only: the shear chain starts at once
                     shear_f = std::async(std::launch::async, [this, aux, split_classes] {
-                        ops.bind_thread(aux);
-                        const int e = shear_histograms(aux);
-                        const int e2 = split_classes ? binning(aux, 2) : 0;  // the up-scaled classes, behind the shear chain
+                        void* sctx = shear_deferred ? st.aux2 : aux;
+                        ops.bind_thread(sctx);
+                        if (shear_after_binning) {
+                            const auto t0 = std::chrono::steady_clock::now();
+                            while (!bin_done.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
+                                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                            mark("shear: main binning has run");
+                        }
+                        const int e = shear_histograms(sctx);
+                        const int e2 = split_classes ? binning(sctx, 2) : 0;  // the up-scaled classes, behind the shear chain
                         return e ? e : e2;
                     });  // (no plan: the call fails; the side classes are not needed)
                 int e = neff_f.valid() ? neff_f.get() : 0;
@@ -1396,11 +1498,16 @@ struct Call {
                 if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)
                 if (!rc) fill_plan(par, ps, plan);
                 if (shear_f.valid()) {
-                    e = shear_f.get();
-                    if (!rc) rc = e;
+                    if (shear_deferred) {
+                        shear_future = std::move(shear_f), shear_joined = false;  // joined by the first launch that needs it
+                    } else {
+                        e = shear_f.get();
+                        if (!rc) rc = e;
+                    }
                 }
                 e = bin_f.get();
                 if (!rc) rc = e;
+                if (rc) (void)join_shear();
             } else {
                 rc = neff_batch(used, true);
                 if (!rc) rc = neff_complete(&exchanged);
@@ -1453,7 +1560,7 @@ struct Call {
                     set_scales(ks);
                     std::vector<char> only(P, 0);
                     for (int k : ks) only[k] = 1;
-                    const bool to_main = nparts > 1 && index >= nparts - std::max(1, 2 * nparts / 5);
+                    const bool to_main = part_on_main(index, nparts);
                     // (measured alternatives, C3 step: every part on the second stream 31.4 ms, the last parts on the third
                     // -- high-priority -- stream 36.3 ms, against 30.4 ms as below)
                     for (int F : order) {
@@ -1522,6 +1629,7 @@ struct Call {
 
     // an error after device work was started: wait for whatever is in flight, hand every block back
     int cleanup(int rc) {
+        (void)join_shear();  // (a deferred chain still running on its own context uses the pool and the class table)
         ops.copy_sync(h);
         if (twin) ops.copy_sync(twin);
         for (auto& kv : hists) pool.give(kv.second);

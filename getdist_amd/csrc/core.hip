@@ -147,13 +147,14 @@ bool gd_ctx_alive(gd_ctx* ctx) {
     return g_live.count(ctx) != 0;
 }
 
-int gd_stream_priority(gd_ctx* ctx, int high) {
+int gd_stream_priority(gd_ctx* ctx, int level) {  // > 0: most urgent, 0: the default, < 0: least urgent
     int least = 0, greatest = 0;
     GD_HIP(hipSetDevice(ctx->device));
     GD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically lower = more urgent
     GD_HIP(hipStreamSynchronize(ctx->stream));
     hipStream_t fresh = nullptr;
-    GD_HIP(hipStreamCreateWithPriority(&fresh, hipStreamDefault, high ? greatest : least));
+    const int prio = level > 0 ? greatest : (level < 0 ? least : (least + greatest) / 2);
+    GD_HIP(hipStreamCreateWithPriority(&fresh, hipStreamDefault, prio));
     (void)hipStreamDestroy(ctx->stream);
     ctx->stream = fresh;
     return GD_OK;

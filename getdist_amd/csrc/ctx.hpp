@@ -143,7 +143,7 @@ int gd_stream_sync(gd_ctx* ctx);
 int gd_fail(gd_ctx* ctx, int code, const char* fmt, ...);
 void gd_comm_release(gd_ctx* ctx);  // comm.hip
 bool gd_ctx_alive(gd_ctx* ctx);
-int gd_stream_priority(gd_ctx* ctx, int high);  // re-create the (idle) compute stream with high / normal priority  // false once gd_destroy has run on it (core.hip)
+int gd_stream_priority(gd_ctx* ctx, int level);  // re-create the (idle) compute stream: > 0 most urgent, 0 default, < 0 least urgent  // false once gd_destroy has run on it (core.hip)
 void* gd_scratch(gd_ctx* ctx, int64_t bytes);   // returns nullptr (and sets err) on failure
 void* gd_scratch2(gd_ctx* ctx, int64_t bytes);
 

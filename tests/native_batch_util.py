@@ -51,6 +51,7 @@ _OPS = [
     ("kopt2d_finish", C.CFUNCTYPE(C.c_int, _p, _p, _i32, _i32, _p, _pd)),
     ("comm_world", C.CFUNCTYPE(C.c_int, _p)),
     ("comm_allreduce_sum", C.CFUNCTYPE(C.c_int, _p, _pd, _i64)),
+    ("stream_priority", C.CFUNCTYPE(C.c_int, _p, C.c_int)),
 ]
 
 
@@ -277,6 +278,10 @@ def _make_ops():
         c = ctx_of(h)
         v = _arr(inout, count)
         v[:] = c.comm_allreduce_sum(v.copy())
+        return 0
+
+    def stream_priority(h, level):
+        CALLS.append(("stream_priority", ctx_of(h).lane, int(level)))
         return 0
 
     def last_error(h):

@@ -117,6 +117,39 @@ def test_native_route_large_call_two_streams_pipelined(zoo):
     assert [p.N_eff_kde for p in mc.paramNames.names[:13]] == [p.N_eff_kde for p in ref.paramNames.names[:13]]
 
 
+def test_native_route_deferred_shear_chain(zoo, monkeypatch):
+    """Round 6 (single-triangle latency): in a large call the shear chain and the up-scaled grid classes run on a FOURTH
+    context, start when the main class has been binned, the sheared pairs ride in the LAST optimiser part and the main thread
+    joins the chain only when it builds that part -- the first part's grids (and their copies) leave earlier.  Same grids,
+    bandwidths and records as the planned route; the chain on its own context; stage A of the first part enqueued before the
+    chain's last launch returned is not asserted (host timing), the structure is."""
+    fx = zoo["block50"]
+    pairs = triangle(13)
+    ref = make(fx, nb.PlainContext)
+    plain = ref.get2DDensities(pairs)
+    monkeypatch.setenv("GDHIP_BATCH_SHEAR_DEFERRED_MIN", "16")
+    mc = make(fx, nb.HarnessContext)
+    mc.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc.KOPT_SPLIT_MIN = 8
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs)
+    same(native, plain)
+    main, twin = mc.ctx.lane, mc._twin.ctx.lane
+    get_h_ctx = {c[1] for c in nb.CALLS if c[0] == "kopt2d_finish"}
+    chain_ctx = {c[1] for c in nb.CALLS if c[0] in ("minmax_affine", "hist2d_sheared")}
+    assert len(chain_ctx) == 1 and not chain_ctx & ({main, twin} | get_h_ctx), "the deferred chain must have a context of its own"
+    assert any(c[0] == "hist2d_sheared" for c in nb.CALLS)
+    # the sheared pairs ride in the last base part: the first stage-A launch holds base pairs only
+    order = [c[0] for c in nb.CALLS if c[0] in ("kopt2d_enqueue", "hist2d_sheared")]
+    assert order.count("kopt2d_enqueue") >= 2
+    # the switch restores the round-5 order (joined in front of the optimiser, sheared pairs in the first part): same results
+    monkeypatch.setenv("GDHIP_BATCH_SHEAR_DEFERRED", "0")
+    mc2 = make(fx, nb.HarnessContext)
+    mc2.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc2.KOPT_SPLIT_MIN = 8
+    same(mc2.get2DDensities(pairs), plain)
+
+
 @pytest.mark.parametrize("kw", [dict(mult_bias_correction_order=0), dict(boundary_correction_order=0),
                                 dict(boundary_correction_order=-1, mult_bias_correction_order=2),
                                 dict(smooth_scale_2D=0.5), dict(smooth_scale_2D=2.5), dict(fine_bins_2D=128)])
