@@ -13,8 +13,9 @@ const gdb::Ops kOps = {
     /* bind_thread */ [](void* h) { return gd_bind_thread(C(h)); },
     /* num_rows */ [](void* h, int64_t* N, int64_t* n) { return gd_num_rows(C(h), N, n); },
     /* weights_kind */
-    [](void* h, int32_t* hw) {
-        *hw = C(h)->w != nullptr;
+    [](void* h, int32_t* hw) {  // 0: unit weights, 1: weights, 2: real (non-integral) weights with a known total
+        gd_ctx* c = C(h);
+        *hw = c->w == nullptr ? 0 : ((!c->w8 && !c->w_integral && c->w_sum > 1e-200 && c->w_sum < 1e200) ? 2 : 1);
         return 0;
     },
     /* dev_alloc */ [](void* h, int64_t bytes, void** out) { return gd_dev_alloc(C(h), bytes, out); },

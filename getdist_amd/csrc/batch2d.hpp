@@ -39,7 +39,8 @@ namespace gdb {
 struct Ops {
     int (*bind_thread)(void* h);
     int (*num_rows)(void* h, int64_t* N, int64_t* n);
-    int (*weights_kind)(void* h, int32_t* has_weights);  // 0: unit weights (chains.py:313-315)
+    int (*weights_kind)(void* h, int32_t* has_weights);  // 0: unit weights (chains.py:313-315), 1: weights, 2: real weights
+                                                         //    whose byte-index binning the library serves (sorted by stripe)
     int (*dev_alloc)(void* h, int64_t bytes, void** out);
     int (*dev_free)(void* h, void* p);
     int (*prebin8_batch)(void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
@@ -483,6 +484,7 @@ struct Call {
         std::vector<double> r1s, r2s;
     } shear;
     bool have_shear = false;
+    bool byte_index_weights = false;  // real weights: the byte-index route is served too (round 6: gd_hist2d_prebinned8's sorted form)
     // convolution state
     std::vector<double> rx, ry, cc, smooth, W;  // W: P x 3
     std::vector<int64_t> winw;
@@ -602,6 +604,7 @@ struct Call {
         }
         std::vector<double> kstd(m), inv4s2(m);
         std::vector<int64_t> maxoffs(m);
+        bool all_uncorrelated_at_lag_1 = true;  // by the probe: then the speculative corr_k(2) is left out of the launch
         for (int row = 0; row < m; ++row) {
             const gd_param2d& p = par[todo[row]];
             double c[8];
@@ -612,6 +615,7 @@ struct Call {
                     first_below = k;
                     break;
                 }
+            if (first_below != 1) all_uncorrelated_at_lag_1 = false;
             double corrlen;
             if (first_below >= 0) {
                 double sum = 0.0;
@@ -633,9 +637,12 @@ struct Call {
         std::vector<int64_t> lags;
         const int64_t uncorr_len = N / 2;
         for (int64_t k = uncorr_len; k < uncorr_len + 5; ++k) lags.push_back(k);
+        // corr_k(1) always; corr_k(2) -- needed only by a chain still correlated at lag 1 (chains.py:541-545) -- rides along
+        // unless the probe shows every column below the threshold at lag 1 already: six exponentials per sample instead of
+        // seven (the launch is bound by them); a column the probe misjudged fetches its lag 2 by itself (neff_from_lags)
         int ntail = 0;
         for (int64_t k : {1, 2})
-            if (k <= N / 10) lags.push_back(k), ++ntail;
+            if (k <= N / 10 && (k == 1 || !all_uncorrelated_at_lag_1)) lags.push_back(k), ++ntail;
         const int L = (int)lags.size();
         std::vector<double> sums((size_t)m * L);
         mark("neff: probe done");
@@ -732,7 +739,7 @@ struct Call {
             const std::vector<int>& members = classes.at(F);
             const int B = (int)members.size();
             int rc = 0;
-            if (F == 256 && unit_weights && B >= 64) {
+            if (F == 256 && (unit_weights || byte_index_weights) && B >= 64) {
                 // the base grid of a unit-weight triangle: byte indices, packed 16-bit counters, one block per pair
                 std::vector<int> cols;
                 std::vector<char> seen(n, 0);
@@ -1395,6 +1402,7 @@ struct Call {
         int32_t hw = 0;
         GDB_DEV(h, ops.weights_kind(h, &hw));
         unit_weights = hw == 0;
+        byte_index_weights = hw == 2 && !getenv("GDHIP_NO_WSORT");
         for (int k = 0; k < P; ++k)
             if (pairs[2 * k] < 0 || pairs[2 * k] >= n || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= n)
                 return fail(GD_ERR_BADARG, "pair index out of range");

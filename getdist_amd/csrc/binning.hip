@@ -12,6 +12,9 @@
 // stripe, native ds_add_u32); weighted ones use fp64 LDS atomics (ds_add_f64).
 #include "ctx.hpp"
 
+#include <array>
+#include <map>
+
 #define LDS_HIST_BYTES (128 * 1024)
 
 // The quotient (x - binmin) / width must be the correctly rounded IEEE quotient (bin indices are bit-exact against
@@ -1531,10 +1534,387 @@ int gd_prebin8_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const doub
     return GD_OK;
 }
 
+// ---- real weights, F = 256: samples partitioned by stripe once per y column (round 6) ------------------------------------
+// A pair's fp64 (here: 64-bit fixed point) table is 512 KB; a CU's LDS holds 128 KB.  The four-pass kernel
+// (k_hist2d<.., true>) lets four 64-row stripe blocks each read ALL samples -- index bytes and the 8-byte weight four times per
+// (sample, pair), 40+ bytes and ~40 instructions -- and ran at 0.19 of the atomics' roof.  Here the samples are PARTITIONED BY
+// STRIPE once per y column ("key": the pairs of a triangle share their y columns) by a streaming counting sort, into WS = 16
+// stripes of 16 rows, so that ONE block holds the 32-KB stripe tables of FOUR pairs of the key and feeds all four from one
+// read of the stripe's weights (measured first with 4 stripes x 1 pair per block: the 8-byte weight per (sample, pair) came
+// from HBM -- blocks meant to share it through their XCD's L2 drift apart -- and bound the kernel at 4.9 TB/s):
+//   k_wpart_count   per (key, tile of 4096 rows): how many rows fall in each stripe of the key's index column
+//   k_wpart_scan    per key: the stripe-major layout -- every (tile, stripe) run padded to 16 entries, so that all later
+//                   accesses are aligned 16-byte vectors; pad entries carry weight 0 (they add 0 to bin 0)
+//   k_wpart_scatter per (key, tile): a slot per row (LDS cursors; the order inside a run is immaterial: the sums are
+//                   integers), then the key's row-in-stripe bytes and FIXED-POINT weights (round(w 2^k), 2^k sum(w) < 2^62:
+//                   exact in any order, reruns bit-equal, and ds_add_u64 retires at twice the rate of ds_add_f64) and, for
+//                   EVERY x column paired with the key, eight at a time, that column's index bytes in the same order --
+//                   sequential reads, run-wise sequential writes, no gathers
+//   k_hist2d_wsorted per (key, stripe, group of <= 4 pairs): walks only its sixteenth of the key's stream: per entry 4 x 1
+//                   index bytes + 1 + 8 shared bytes, four ds_add_u64; units of one (key, stripe) get block ids on one XCD.
+#define WP_TILE 4096
+#ifndef WS
+#define WS 16          // stripes
+#endif
+#define WR (256 / WS)  // rows per stripe
+#define WPG (WS / 4)   // pairs per block: WPG tables of WR x 256 u64 fill the 128-KB LDS
+#define WXB 8          // x columns per staging round of the scatter kernel
+struct WKey {
+    const unsigned char* iy;   // the key column's byte indices (N)
+    unsigned char* ij_perm;    // row within the stripe, partitioned order (npad)
+    unsigned long long* wq_perm;  // fixed-point weights, partitioned order (npad)
+    int64_t npad;              // entries of the partitioned stream
+    int x_first, x_count;      // this key's x columns: entries [x_first, x_first + x_count) of the WX table
+};
+struct WX {
+    const unsigned char* ix;   // an x column's byte indices (N)
+    unsigned char* ix_perm;    // the same in the key's partitioned order (npad)
+};
+
+__global__ void __launch_bounds__(256) k_wpart_count(const WKey* __restrict__ keys, int64_t N, int ntiles, int* __restrict__ counts) {
+    __shared__ int c[WS];
+    const WKey K = keys[blockIdx.y];
+    if (threadIdx.x < WS) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * WP_TILE;
+    for (int e = threadIdx.x * 16; e < WP_TILE; e += 256 * 16) {
+        const int64_t r = base + e;
+        if (r + 16 <= N) {
+            const uint4 v = gload_u4(K.iy + r);
+            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) atomicAdd(&c[((wd[q >> 2] >> (8 * (q & 3))) & 0xff) / WR], 1);
+        } else {
+            for (int q = 0; q < 16 && r + q < N; ++q) atomicAdd(&c[K.iy[r + q] / WR], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < WS) counts[((int64_t)blockIdx.y * ntiles + blockIdx.x) * WS + threadIdx.x] = c[threadIdx.x];
+}
+
+// one block per key: offsets[key][tile][s] = start of the (tile, s) run in the partitioned stream (entries), stripe-major;
+// starts[key][0..WS] = where the stripes begin / the stream ends.  One wave per stripe walks the tiles (lane-strided sums,
+// then a serial pass of lane 0 over 64-tile blocks would be shorter still; the kernel is < 1 % of the call).
+#define WLPS (1024 / WS)  // threads per stripe in the scan
+__global__ void __launch_bounds__(1024) k_wpart_scan(const int* __restrict__ counts, int ntiles, int64_t* __restrict__ offsets,
+                                                     int64_t* __restrict__ starts) {
+    __shared__ int64_t tot[WS];
+    __shared__ int64_t chunk_base[WS][WLPS + 1];
+    const int s = threadIdx.x / WLPS, lane = threadIdx.x % WLPS;
+    const int* c = counts + (int64_t)blockIdx.x * ntiles * WS;
+    // thread l of a stripe owns the tiles [l * per, (l + 1) * per)
+    const int per = (ntiles + WLPS - 1) / WLPS;
+    const int t0 = lane * per, t1 = min(ntiles, t0 + per);
+    int64_t mine = 0;
+    for (int i = t0; i < t1; ++i) mine += (c[(int64_t)i * WS + s] + 15) & ~15;
+    chunk_base[s][lane] = mine;
+    __syncthreads();
+    if (lane == 0) {
+        int64_t run = 0;
+        for (int l = 0; l < WLPS; ++l) {
+            const int64_t v = chunk_base[s][l];
+            chunk_base[s][l] = run;
+            run += v;
+        }
+        tot[s] = run;
+    }
+    __syncthreads();
+    int64_t off = 0;
+    for (int q = 0; q < s; ++q) off += tot[q];
+    if (lane == 0) {
+        starts[(int64_t)blockIdx.x * (WS + 1) + s] = off;
+        if (s == WS - 1) starts[(int64_t)blockIdx.x * (WS + 1) + WS] = off + tot[s];
+    }
+    off += chunk_base[s][lane];
+    int64_t* o = offsets + (int64_t)blockIdx.x * ntiles * WS;
+    for (int i = t0; i < t1; ++i) {
+        o[(int64_t)i * WS + s] = off;
+        off += (c[(int64_t)i * WS + s] + 15) & ~15;
+    }
+}
+
+// grid (ntiles, nkeys), 1024 threads x 4 rows.
+__global__ void __launch_bounds__(1024) k_wpart_scatter(const WKey* __restrict__ keys, const WX* __restrict__ xs, const double* __restrict__ w,
+                                                        int64_t N, int ntiles, const int* __restrict__ counts,
+                                                        const int64_t* __restrict__ offsets, double wscale) {
+    constexpr int STG = WP_TILE + WS * 16;  // the tile's padded runs
+    __shared__ unsigned long long stage_w[STG];
+    __shared__ unsigned char stage_b[WXB][STG];
+    __shared__ int run_start[WS + 1], cursor[WS];
+    __shared__ int64_t run_off[WS];
+    const WKey K = keys[blockIdx.y];
+    const int tile = blockIdx.x;
+    const int64_t base = (int64_t)tile * WP_TILE;
+    const int tid = threadIdx.x;
+    const int* cnt = counts + ((int64_t)blockIdx.y * ntiles + tile) * WS;
+    if (tid < WS) cursor[tid] = 0, run_off[tid] = offsets[((int64_t)blockIdx.y * ntiles + tile) * WS + tid];
+    if (tid == 0) {
+        int a = 0;
+        for (int s = 0; s < WS; ++s) {
+            run_start[s] = a;
+            a += (cnt[s] + 15) & ~15;
+        }
+        run_start[WS] = a;
+    }
+    __syncthreads();
+    const int total = run_start[WS];  // staged entries of the tile (a multiple of 16)
+    for (int e = tid; e < total; e += 1024) stage_w[e] = 0ull;
+    for (int e = tid; e < WXB * STG / 4; e += 1024) reinterpret_cast<unsigned int*>(&stage_b[0][0])[e] = 0u;
+    // the thread's four consecutive rows, their stripes and slots
+    const int64_t r0 = base + 4 * tid;
+    unsigned iy4 = 0;
+    if (r0 + 4 <= N)
+        iy4 = *reinterpret_cast<const unsigned int*>(K.iy + r0);
+    else
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < N) iy4 |= (unsigned)K.iy[r0 + q] << (8 * q);
+    __syncthreads();
+    int pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pos[q] = -1;
+        if (r0 + q < N) {
+            const int st = (int)((iy4 >> (8 * q)) & 0xff) / WR;
+            pos[q] = run_start[st] + atomicAdd(&cursor[st], 1);
+        }
+    }
+    // ---- the key's own streams: row in stripe, fixed-point weight
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (pos[q] >= 0) {
+            stage_b[0][pos[q]] = (unsigned char)(((iy4 >> (8 * q)) & 0xff) % WR);
+            stage_w[pos[q]] = __double2ull_rn(w[r0 + q] * wscale);
+        }
+    __syncthreads();
+    // a staged run s goes to [run_off[s], + padded count) of the stream: 16-byte vectors throughout
+    auto stripe_of = [&](int e) {
+        int s = 0;
+#pragma unroll
+        for (int q = WS / 2; q > 0; q >>= 1)
+            if (e >= run_start[s + q]) s += q;
+        return s;
+    };
+    for (int v = tid; v < total / 16; v += 1024) {
+        const int e = v * 16, s = stripe_of(e);
+        *reinterpret_cast<uint4*>(K.ij_perm + run_off[s] + (e - run_start[s])) = *reinterpret_cast<const uint4*>(&stage_b[0][e]);
+    }
+    for (int v = tid; v < total / 2; v += 1024) {
+        const int e = v * 2, s = stripe_of(e);
+        *reinterpret_cast<uint4*>(K.wq_perm + run_off[s] + (e - run_start[s])) = *reinterpret_cast<const uint4*>(stage_w + e);
+    }
+    // ---- every x column paired with the key, WXB at a time, in the same order
+    for (int x0 = 0; x0 < K.x_count; x0 += WXB) {
+        const int nx = min(WXB, K.x_count - x0);
+        unsigned ix4[WXB];
+#pragma unroll
+        for (int u = 0; u < WXB; ++u) {
+            const WX X = xs[K.x_first + x0 + (u < nx ? u : 0)];
+            ix4[u] = 0;
+            if (r0 + 4 <= N)
+                ix4[u] = *reinterpret_cast<const unsigned int*>(X.ix + r0);
+            else
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < N) ix4[u] |= (unsigned)X.ix[r0 + q] << (8 * q);
+        }
+        __syncthreads();  // the previous flush has read the staging area (pad bytes stay 0: they are never written)
+#pragma unroll
+        for (int u = 0; u < WXB; ++u)
+            if (u < nx)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (pos[q] >= 0) stage_b[u][pos[q]] = (unsigned char)((ix4[u] >> (8 * q)) & 0xff);
+        __syncthreads();
+        for (int v = tid; v < nx * (total / 16); v += 1024) {
+            const int u = v / (total / 16), e = (v % (total / 16)) * 16, s = stripe_of(e);
+            unsigned char* dst = xs[K.x_first + x0 + u].ix_perm;
+            *reinterpret_cast<uint4*>(dst + run_off[s] + (e - run_start[s])) = *reinterpret_cast<const uint4*>(&stage_b[u][e]);
+        }
+    }
+}
+
+struct WUnit {  // one block of k_hist2d_wsorted: stripe `stripe` of up to WPG pairs of key `key`
+    int pair[WPG];  // -1: unused slot; pair[0] < 0: nothing to do (padding of an XCD's list)
+    int stripe, key;
+};
+
+__global__ void __launch_bounds__(1024) k_hist2d_wsorted(const WUnit* __restrict__ units, const WKey* __restrict__ keys,
+                                                         const unsigned char* const* __restrict__ ix_perm_of_pair,
+                                                         const int64_t* __restrict__ starts, double inv_wscale, double* __restrict__ hist) {
+    extern __shared__ double wsorted_sh[];
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(wsorted_sh);  // WPG tables of WR rows x 256 columns
+    const WUnit U = units[blockIdx.x];
+    if (U.pair[0] < 0) return;
+    for (int i = threadIdx.x; i < WPG * WR * 256; i += 1024) tab[i] = 0ull;
+    __syncthreads();
+    const WKey K = keys[U.key];
+    const unsigned char* ixp[WPG];
+#pragma unroll
+    for (int p = 0; p < WPG; ++p) ixp[p] = ix_perm_of_pair[U.pair[p] >= 0 ? U.pair[p] : U.pair[0]];
+    const int64_t a = starts[(int64_t)U.key * (WS + 1) + U.stripe], b = starts[(int64_t)U.key * (WS + 1) + U.stripe + 1];  // multiples of 16
+    // (measured and not kept: a second register set with the next 16 entries' loads in flight under the adds -- 11.0 against
+    // 10.6 ms per 1225 pairs; 32 stripes x 8 pairs per block -- the adds 8.4 ms, the partitioning 9.9 instead of 8.4: the
+    // kernel sits between the ds_add_u64 rate (3.9 ms for the triangle's 1.2e10 adds at random targets, more with a Gaussian's
+    // conflicts) and the 39 GB of streams it reads once)
+    for (int64_t e = a + 16 * (int64_t)threadIdx.x; e < b; e += 16 * 1024) {
+        uint4 vx[WPG], vw[8];
+#pragma unroll
+        for (int p = 0; p < WPG; ++p) vx[p] = gload_u4(ixp[p] + e);
+        const uint4 vy = gload_u4(K.ij_perm + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vw[q] = gload_u4(K.wq_perm + e + 2 * q);
+        const unsigned wy[4] = {vy.x, vy.y, vy.z, vy.w};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned cy = (wy[q >> 2] >> (8 * (q & 3))) & 0xff;
+            const uint4 pw = vw[q >> 1];
+            const unsigned long long wq = (q & 1) ? ((unsigned long long)pw.w << 32 | pw.z) : ((unsigned long long)pw.y << 32 | pw.x);
+#pragma unroll
+            for (int p = 0; p < WPG; ++p) {
+                const unsigned wx[4] = {vx[p].x, vx[p].y, vx[p].z, vx[p].w};
+                const unsigned cx = (wx[q >> 2] >> (8 * (q & 3))) & 0xff;
+                if (U.pair[p] >= 0) atomicAdd(&tab[p * WR * 256 + ((cy << 8) | cx)], wq);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < WPG; ++p) {
+        if (U.pair[p] < 0) continue;
+        double* out = hist + (int64_t)U.pair[p] * 65536 + (int64_t)U.stripe * WR * 256;
+        for (int i = threadIdx.x; i < WR * 256; i += 1024) out[i] = (double)tab[p * WR * 256 + i] * inv_wscale;
+    }
+}
+
+// host side: B pairs of byte index columns, real weights with a known total.  Keys are processed in groups that fit the
+// scratch budget; returns GD_OK or an error.  The caller has checked F = 256, ctx->w, ctx->w_sum.
+static int hist2d_weighted_sorted(gd_ctx* ctx, int B, const void* const* d_idx_x, const void* const* d_idx_y, double* d_hist) {
+    const int64_t N = ctx->N;
+    const int ntiles = (int)((N + WP_TILE - 1) / WP_TILE);
+    const int64_t npad_max = N + (int64_t)ntiles * WS * 15 + 64;
+    const double wscale = ldexp(1.0, 61 - ilogb(ctx->w_sum));
+    // group the pairs by their y column
+    std::map<const void*, std::vector<int>> by_key;
+    std::vector<const void*> key_order;
+    for (int b = 0; b < B; ++b) {
+        if (!by_key.count(d_idx_y[b])) key_order.push_back(d_idx_y[b]);
+        by_key[d_idx_y[b]].push_back(b);
+    }
+    double budget = 20e9;
+    if (const char* e = getenv("GDHIP_WSORT_BYTES")) budget = atof(e);
+    size_t k0 = 0;
+    while (k0 < key_order.size()) {
+        // keys [k0, k1): as many as fit
+        size_t k1 = k0;
+        int64_t bytes = 0;
+        int npairs = 0;
+        while (k1 < key_order.size()) {
+            const int np = (int)by_key[key_order[k1]].size();
+            const int64_t add = npad_max * 9 + (int64_t)np * npad_max;
+            if (k1 > k0 && bytes + add > budget) break;
+            bytes += add, npairs += np, ++k1;
+        }
+        const int nk = (int)(k1 - k0);
+        // units: (key, stripe) groups on one XCD each, consecutive there (block id = 8 position + XCD)
+        std::vector<std::vector<WUnit>> lane(8);
+        {
+            std::vector<int64_t> load(8, 0);
+            for (int k = 0; k < nk; ++k) {
+                const std::vector<int>& prs = by_key[key_order[k0 + k]];
+                for (int s = 0; s < WS; ++s) {
+                    int best = 0;
+                    for (int x = 1; x < 8; ++x)
+                        if (load[x] < load[best]) best = x;
+                    for (size_t q = 0; q < prs.size(); q += WPG) {
+                        WUnit u;
+                        for (int p = 0; p < WPG; ++p) u.pair[p] = q + p < prs.size() ? prs[q + p] : -1;
+                        u.stripe = s, u.key = k;
+                        lane[best].push_back(u);
+                    }
+                    load[best] += (int64_t)prs.size();
+                }
+            }
+        }
+        size_t longest = 0;
+        for (auto& l : lane) longest = std::max(longest, l.size());
+        WUnit none;
+        for (int p = 0; p < WPG; ++p) none.pair[p] = -1;
+        none.stripe = none.key = 0;
+        std::vector<WUnit> units(longest * 8, none);
+        for (int x = 0; x < 8; ++x)
+            for (size_t q = 0; q < lane[x].size(); ++q) units[q * 8 + x] = lane[x][q];
+        std::vector<WKey> hk((size_t)nk);
+        std::vector<WX> hx;
+        std::vector<const unsigned char*> ixp((size_t)B, nullptr);
+        int64_t off = 0;
+        auto take = [&](int64_t nbytes) {
+            int64_t o = off;
+            off += (nbytes + 255) / 256 * 256;
+            return o;
+        };
+        const int64_t o_keys = take((int64_t)nk * sizeof(WKey)), o_xs = take((int64_t)npairs * sizeof(WX)),
+                      o_counts = take((int64_t)nk * ntiles * WS * 4), o_offsets = take((int64_t)nk * ntiles * WS * 8),
+                      o_starts = take((int64_t)nk * (WS + 1) * 8), o_ixp = take((int64_t)B * 8),
+                      o_units = take((int64_t)units.size() * sizeof(WUnit));
+        std::vector<int64_t> o_ij((size_t)nk), o_wq((size_t)nk);
+        std::vector<int64_t> o_ix;
+        for (int k = 0; k < nk; ++k) o_ij[k] = take(npad_max), o_wq[k] = take(npad_max * 8);
+        for (int k = 0; k < nk; ++k)
+            for (size_t q = 0; q < by_key[key_order[k0 + k]].size(); ++q) o_ix.push_back(take(npad_max));
+        char* base = (char*)gd_scratch2(ctx, off);
+        if (!base) return GD_ERR_NOMEM;
+        int xi = 0;
+        for (int k = 0; k < nk; ++k) {
+            const std::vector<int>& prs = by_key[key_order[k0 + k]];
+            WKey& K = hk[k];
+            K.iy = (const unsigned char*)key_order[k0 + k];
+            K.ij_perm = (unsigned char*)(base + o_ij[k]);
+            K.wq_perm = (unsigned long long*)(base + o_wq[k]);
+            K.npad = npad_max;
+            K.x_first = xi, K.x_count = (int)prs.size();
+            for (int b : prs) {
+                WX X;
+                X.ix = (const unsigned char*)d_idx_x[b];
+                X.ix_perm = (unsigned char*)(base + o_ix[xi]);
+                ixp[b] = X.ix_perm;
+                hx.push_back(X);
+                ++xi;
+            }
+        }
+        WKey* d_keys = (WKey*)(base + o_keys);
+        WX* d_xs = (WX*)(base + o_xs);
+        int* d_counts = (int*)(base + o_counts);
+        int64_t* d_offsets = (int64_t*)(base + o_offsets);
+        int64_t* d_starts = (int64_t*)(base + o_starts);
+        const unsigned char** d_ixp = (const unsigned char**)(base + o_ixp);
+        WUnit* d_units = (WUnit*)(base + o_units);
+        GD_TRY(gd_h2d(ctx, d_keys, hk.data(), hk.size() * sizeof(WKey)));
+        GD_TRY(gd_h2d(ctx, d_xs, hx.data(), hx.size() * sizeof(WX)));
+        GD_TRY(gd_h2d(ctx, d_ixp, ixp.data(), ixp.size() * 8));
+        GD_TRY(gd_h2d(ctx, d_units, units.data(), units.size() * sizeof(WUnit)));
+        k_wpart_count<<<dim3(ntiles, nk), 256, 0, ctx->stream>>>(d_keys, N, ntiles, d_counts);
+        GD_KERNEL_CHECK();
+        k_wpart_scan<<<nk, 1024, 0, ctx->stream>>>(d_counts, ntiles, d_offsets, d_starts);
+        GD_KERNEL_CHECK();
+        k_wpart_scatter<<<dim3(ntiles, nk), 1024, 0, ctx->stream>>>(d_keys, d_xs, ctx->w, N, ntiles, d_counts, d_offsets, wscale);
+        GD_KERNEL_CHECK();
+        GD_HIP(hipFuncSetAttribute((const void*)k_hist2d_wsorted, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_BYTES));
+        k_hist2d_wsorted<<<(unsigned)units.size(), 1024, LDS_HIST_BYTES, ctx->stream>>>(d_units, d_keys, d_ixp, d_starts, 1.0 / wscale, d_hist);
+        GD_KERNEL_CHECK();
+        GD_TRY(gd_stream_sync(ctx));  // (the host tables above; the next group reuses the scratch)
+        k0 = k1;
+    }
+    return GD_OK;
+}
+
 int gd_hist2d_prebinned8(gd_ctx* ctx, int32_t B, const void* const* d_idx_x, const void* const* d_idx_y, void* d_hist) {
     GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0, "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
-    GD_REQUIRE(!ctx->w, "byte-index binning is for unit weights");
+    if (ctx->w) {  // real weights: partitioned by stripe once per y column, one 10-byte visit per (sample, pair)
+        GD_REQUIRE(!ctx->w8 && ctx->w_sum > 1e-200 && ctx->w_sum < 1e200,
+                   "byte-index binning takes unit weights or real weights with a known total (multiplicities: gd_hist2d_prebinned)");
+        for (int b = 0; b < B; ++b) GD_REQUIRE(d_idx_x[b] && d_idx_y[b], "null index column");
+        return hist2d_weighted_sorted(ctx, B, d_idx_x, d_idx_y, (double*)d_hist);
+    }
     const int F = 256;
     std::vector<Hist2DPair8> hp((size_t)B);
     for (int b = 0; b < B; ++b) {
@@ -1577,7 +1957,15 @@ int gd_prebin8_hist2d(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const dou
     GD_REQUIRE(ctx && d_idx_x && d_idx_y && d_hist && B > 0 && ncols >= 0, "bad argument");
     GD_REQUIRE(ncols == 0 || (cols && binmin && width && d_idx_out && bad_out), "bad argument");
     GD_REQUIRE(ctx->cols, "no samples uploaded");
-    GD_REQUIRE(!ctx->w, "byte-index binning is for unit weights");
+    if (ctx->w) {  // real weights: the two steps one after the other (the weighted histograms are several launches anyway)
+        if (ncols) {
+            GD_TRY(gd_prebin8_batch(ctx, cols, ncols, binmin, width, 256, d_idx_out, bad_out));
+            int64_t nbad = 0;
+            for (int c = 0; c < ncols; ++c) nbad += bad_out[c];
+            if (nbad) return gd_fail(ctx, GD_ERR_SOLVER, "%lld samples outside the byte-index grid: use the u16 path", (long long)nbad);
+        }
+        return gd_hist2d_prebinned8(ctx, B, d_idx_x, d_idx_y, d_hist);
+    }
     const int F = 256;
     for (int c = 0; c < ncols; ++c) GD_REQUIRE(cols[c] >= 0 && cols[c] < ctx->n + GD_EXTRA_COLS && d_idx_out[c], "bad column");
     const BucketRoute R = ncols ? bucket_route(ctx, cols, ncols, binmin, width, d_idx_out) : BucketRoute();

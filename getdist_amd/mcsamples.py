@@ -1833,16 +1833,21 @@ class MCSamples:
             maxoff = int(self.getCorrelationLength(j, weight_units=False) * 1.5) + 4
         return self._neff_from_lags(j, kernel_std, maxoff, min_corr, None)
 
-    def _neff_lag_list(self):
+    def _neff_lag_list(self, tail=2):
+        """The lags of the batched kernel-sum launch: the five of the uncorrelated term (chains.py:514-519) and the first
+        ``tail`` of the scan (corr_k(1), corr_k(2): :541-545).  corr_k(2) is needed only by a chain that is still correlated
+        at lag 1; _neff_batch asks for it up front (tail = 2) unless the autocorrelation probe shows every column of the
+        batch below the threshold already at lag 1 -- then the launch carries six exponentials per sample instead of seven,
+        and a column the probe misjudged fetches its lag 2 by itself (same value, one more launch)."""
         uncorr_len = self.numrows // 2
-        return list(range(uncorr_len, uncorr_len + 5)) + [k for k in (1, 2) if k <= self.numrows // 10]
+        return list(range(uncorr_len, uncorr_len + 5)) + [k for k in (1, 2)[:tail] if k <= self.numrows // 10]
 
     def _neff_from_lags(self, j, kernel_std, maxoff, min_corr, seed_sums):
         """The scalar part of chains.py:509-574 given (optionally pre-computed) Gaussian-kernel lag sums."""
         maxoff = min(maxoff, self.numrows // 10)
         uncorr_len = self.numrows // 2
         inv4s2 = 1.0 / (4 * kernel_std**2)
-        lags = self._neff_lag_list()
+        lags = self._neff_lag_list() if seed_sums is None else self._neff_lag_list(len(seed_sums) - 5)
         sums = self.ctx.kde_lag_sums(j, inv4s2, lags) if seed_sums is None else seed_sums
         nav = sum(self.numrows - k for k in range(uncorr_len, uncorr_len + 5))
         uncorr_term = float(np.sum(sums[:5])) / nav
@@ -1937,7 +1942,9 @@ class MCSamples:
                 corrlen = self.getCorrelationLength(j, weight_units=False, min_corr=min_corr)
             kstd.append((par.sigma_range or self.sddev[j]) * 0.2)
             maxoffs.append(int(corrlen * 1.5) + 4)
-        sums = self.ctx.kde_lag_sums_batch(todo, [1.0 / (4 * k**2) for k in kstd], self._neff_lag_list())
+        # (the rule of csrc/batch2d.hpp neff_batch: lag 2 rides along unless every column is uncorrelated at lag 1 by the probe)
+        tail = 1 if all(fb == 1 for fb in first_below) else 2
+        sums = self.ctx.kde_lag_sums_batch(todo, [1.0 / (4 * k**2) for k in kstd], self._neff_lag_list(tail))
         for row, j in enumerate(todo):
             self.paramNames.names[j].N_eff_kde = self._neff_from_lags(j, kstd[row], maxoffs[row], min_corr, sums[row])
 

@@ -9,6 +9,8 @@
 #   kernels      scripts/kernels_isolated.py (isolated O(N) kernels)
 #   pmcconv      scripts/pmc_conv.sh (counter passes of the convolution kernels)
 #   emulate      bench.py --emulate-world 2/4/8 (+ C5 / C4 forms when present)
+#   pmcprep      scripts/pmc_kernels.py over the O(N) preparation kernels of a C3 step      latency   kernel + copy trace of a delivered triangle
+#   covab        scripts/cov_ab.py (one-pass against two-pass covariance)                   ab:ENV=V  same-box A/B of an environment switch
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG="$1"; shift
 O=gpurun_out/$TAG; mkdir -p "$O"; export TMPDIR=/tmp
@@ -32,7 +34,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 PY
             ;;
         bench) GETDIST_AMD_LIVE_PMC=0 timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > "$O/bench_40.json" 2> "$O/bench_40.err"
-               python -c "import json,sys; d=json.loads(open('$O/bench_40.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], 'value', d['value'], 'latency', d['ms_single_triangle_latency'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'])" ;;
+               python -c "import json,sys; d=json.loads(open('$O/bench_40.json').read().strip().splitlines()[-1]); print('delivered triangle ms', d['ms_per_step'], 'value', d['value'], 'pipelined ms', d['ms_per_step_pipelined'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'])" ;;
         benchfull) timeout 900 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
                python -c "import json,sys; d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], 'value', d['value'], 'roofline', d['roofline']['frac'], 'cpu', d['cpu_baseline']['value'], 'parity loose', d.get('parity',{}).get('n_pairs_on_loose_gate'))" ;;
         trace)
@@ -64,6 +66,21 @@ PY
         pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/weighted_binning.py" 2>&1 | tail -8
               grep -E "SQ_|conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
         gloo2) GETDIST_AMD_LIVE_PMC=0 timeout 600 python bench.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_gloo2_shared_gpu.json" 2> "$O/bench_gloo2.err"; tail -c 900 "$O/bench_gloo2_shared_gpu.json"; tail -3 "$O/bench_gloo2.err" | cut -c1-300 ;;
+        pmcprep)  # counter traffic of the O(N) preparation kernels of a C3 step (review item: <= 18 GB per step)
+              timeout 1500 python scripts/pmc_kernels.py "$O/pmc_prep.json" --match k_col_,k_cov_,k_qlin,k_qsel,k_autocov,k_kde_lag,k_prebin,k_bucket,k_sum_partials -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -14 ;;
+        latency)  # one delivered triangle on the time axis: pipeline stages and result copies
+              (cd /tmp && GETDIST_AMD_LIVE_PMC=0 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/lat_$TAG -o lat -- python "$GRAFT_REPO_ROOT/bench.py" --steps 4 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$O/lat.log" 2>&1)
+              python scripts/latency_timeline.py /tmp/lat_$TAG 5 > "$O/latency_timeline.txt" 2>&1; head -14 "$O/latency_timeline.txt" ;;
+        covab) timeout 600 python scripts/cov_ab.py > "$O/cov_ab.json" 2> "$O/cov_ab.err"; grep -E "N[0-9]|ms_" "$O/cov_ab.json" ;;
+        ab:*)  # same-box A/B of one environment switch: ab:NAME=VALUE  (three alternating pairs of 30-step runs)
+              SW="${stage#ab:}"
+              for rep in 1 2 3; do
+                  for side in base "$SW"; do
+                      if [ "$side" = base ]; then envs="GDAMD_AB=base"; else envs="$SW"; fi
+                      env $envs GETDIST_AMD_LIVE_PMC=0 timeout 400 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > "$O/ab_tmp.json" 2> "$O/ab_tmp.err"
+                      python -c "import json; d=json.loads(open('$O/ab_tmp.json').read().strip().splitlines()[-1]); print('$side', 'delivered', round(d['ms_per_step'],3), 'pipelined', round(d['ms_per_step_pipelined'],3))" | tee -a "$O/ab_${SW%%=*}.txt"
+                  done
+              done ;;
         rccl) timeout 300 python scripts/nccl_smoke.py > "$O/rccl_smoke.log" 2>&1; tail -5 "$O/rccl_smoke.log" ;;
         *) echo "unknown stage $stage" ;;
     esac

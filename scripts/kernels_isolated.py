@@ -115,6 +115,11 @@ def main():
         o2 = mc2.ctx.alloc(len(allp) * F * F * 8)
         res["hist2d_prebinned_%s_%d_pairs" % (tag, len(allp))] = timed(
             mc2.ctx, lambda: mc2.ctx.hist2d_prebinned([idx[a] for a, b in allp], [idx[b] for a, b in allp], F, out=o2), 3)
+        if wts is None:  # round 6: real weights over byte indices, samples partitioned by stripe once per y column
+            b8 = [mc2.ctx.alloc(N + 64) for _ in range(n)]
+            mc2.ctx.prebin8_batch(list(range(n)), [x[1] for x in e2], [x[0] for x in e2], 256, b8)
+            res["hist2d_byte_index_real_weights_sorted_by_stripe_%d_pairs" % len(allp)] = timed(
+                mc2.ctx, lambda: mc2.ctx.hist2d_prebinned8([b8[a] for a, b in allp], [b8[b] for a, b in allp], out=o2), 3)
         mc2.ctx.close()
     os.makedirs(OUT, exist_ok=True)
     json.dump(res, open(os.path.join(OUT, "kernels_isolated.json"), "w"), indent=1)

@@ -856,3 +856,49 @@ def test_bucket_columns_serve_the_select_the_probe_and_bit_exact_index_columns(m
     for j in range(n):
         assert np.array_equal(bufs[j].to_host((N,), dtype=np.uint8), ((s2[:, j] - binmin[j]) / width[j] + 0.5).astype(np.int64).astype(np.uint8))
     c.close()
+
+
+def test_real_weight_byte_index_binning_sorted_by_stripe(monkeypatch):
+    """Round 6: gd_hist2d_prebinned8 with REAL weights -- samples partitioned by 64-row stripe once per y column (streaming
+    counting sort with 16-entry padded runs), fixed-point weights, one ds_add_u64 per (sample, pair) -- against numpy's
+    bincount on the reference's index expression (mcsamples.py:1724-1728): 1e-12 of the largest bin, every bin within
+    1e-12 relative + 2 quanta absolute; pairs that share and that do not share their y column, x = y, a ragged N, reruns
+    bit-equal, a scratch budget that forces several groups of keys, and the four-pass kernel (gd_hist2d_prebinned) as a
+    second witness."""
+    from getdist_amd._lib import Context
+
+    N, F = 300_011, 256
+    r = np.random.default_rng(9)
+    s = np.column_stack([r.standard_normal(N), r.standard_normal(N) * 2 + 1, r.exponential(1.0, N), r.uniform(-1, 1, N),
+                         np.abs(r.standard_normal(N))])
+    w = r.exponential(1.0, N) * 10.0 ** r.uniform(-3, 2, N)  # five decades of weight
+    c = Context(0)
+    c.upload(np.asfortranarray(s), w)
+    n = s.shape[1]
+    lo, hi = s.min(axis=0), s.max(axis=0)
+    binmin = lo - 0.05 * (hi - lo)
+    width = (hi + 0.05 * (hi - lo) - binmin) / (F - 1)
+    bufs = [c.alloc(N + 64) for _ in range(n)]
+    assert np.all(c.prebin8_batch(list(range(n)), binmin, width, F, bufs) == 0)
+    ix = [((s[:, j] - binmin[j]) / width[j] + 0.5).astype(int) for j in range(n)]
+    pairs = [(0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 3), (3, 0), (2, 2), (4, 1), (0, 4)]
+    H = c.hist2d_prebinned8([bufs[a] for a, b in pairs], [bufs[b] for a, b in pairs]).to_host((len(pairs), F, F))
+    quantum = 2.0 ** -(61 - int(np.floor(np.log2(w.sum()))))
+    for k, (a, b) in enumerate(pairs):
+        want = np.bincount(ix[a] + ix[b] * F, weights=w, minlength=F * F).reshape(F, F)
+        cnt = np.bincount(ix[a] + ix[b] * F, minlength=F * F).reshape(F, F)
+        assert np.max(np.abs(H[k] - want)) <= 1e-12 * want.max(), (a, b)
+        assert np.all(np.abs(H[k] - want) <= 1e-12 * want + (cnt + 2) * quantum), (a, b)
+        assert abs(H[k].sum() - w.sum()) <= 1e-12 * w.sum()
+    H2 = c.hist2d_prebinned8([bufs[a] for a, b in pairs], [bufs[b] for a, b in pairs]).to_host((len(pairs), F, F))
+    assert np.array_equal(H, H2)  # integer sums: the same bits in every run
+    monkeypatch.setenv("GDHIP_WSORT_BYTES", str(3 * (N + 50_000) * 10))  # a key or two per group
+    H3 = c.hist2d_prebinned8([bufs[a] for a, b in pairs], [bufs[b] for a, b in pairs]).to_host((len(pairs), F, F))
+    monkeypatch.delenv("GDHIP_WSORT_BYTES")
+    assert np.array_equal(H, H3)
+    # the four-pass fp64-atomic kernel over u16 index columns: the same histograms to rounding
+    b16 = [c.alloc(2 * N + 64) for _ in range(n)]
+    c.prebin_batch(list(range(n)), binmin, width, F, b16)
+    H4 = c.hist2d_prebinned([b16[a] for a, b in pairs], [b16[b] for a, b in pairs], F).to_host((len(pairs), F, F))
+    assert np.max(np.abs(H4 - H)) <= 1e-12 * H.max()
+    c.close()
