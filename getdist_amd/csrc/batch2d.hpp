@@ -1495,6 +1495,8 @@ struct Call {
                             const auto t0 = std::chrono::steady_clock::now();
                             while (!bin_done.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
                                 std::this_thread::sleep_for(std::chrono::microseconds(50));
+                            if (const char* d = getenv("GDHIP_BATCH_SHEAR_DELAY_US"))  // (experiment: let the first part's stage A run first)
+                                std::this_thread::sleep_for(std::chrono::microseconds(atoi(d)));
                             mark("shear: main binning has run");
                         }
                         const int e = shear_histograms(sctx);

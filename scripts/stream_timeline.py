@@ -11,7 +11,7 @@ for r in rows:
     r["n"] = r["Kernel_Name"].split("(")[0].replace("void ", "")
     r["q"] = r.get("Stream_Id") or r.get("Queue_Id")
 rows.sort(key=lambda r: r["s"])
-starts = [i for i, r in enumerate(rows) if r["n"].startswith("k_col_pass1")]
+starts = [i for i, r in enumerate(rows) if r["n"].startswith("k_col_pass1") or r["n"].startswith("k_col_shift")]
 # (a step of a multi-rank share has one statistics pass as well; launches of it closer than 2 ms belong to one step)
 starts = [i for k, i in enumerate(starts) if k == 0 or rows[i]["s"] - rows[starts[k - 1]]["s"] > 2_000_000]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
