@@ -510,7 +510,17 @@ struct Call {
     // that needs it.  Results are unchanged bit for bit (a pair's grid does not depend on the part it is computed in).
     std::future<int> shear_future;
     bool shear_deferred = false, shear_joined = true;
-    int join_shear() {
+    // ... and it starts only when the FIRST optimiser part's convolution has been enqueued (its stage A, get_h and first
+    // batches get the machine ahead of the chain's 1024-thread blocks; the chain then runs beside the later parts): same-box
+    // A/B, delivered triangle: chain at once 29.4-29.9 ms, released on the first part's bandwidths 28.8-29.5, on its
+    // convolution 28.1-28.9; the stream of triangles 21.7 -> 21.9.  Released at once when the first launch itself needs the
+    // chain, when nothing is staged, and on every error path (and after 20 ms whatever happens).
+    std::atomic<int> first_part_done{0};
+    int join_shear(bool release = false) {
+        // release: the caller is not going to enqueue a first part the chain could wait for (error paths, a call whose only
+        // launch needs the chain).  The staging thread's ordinary join does NOT release: by then the first part is enqueued
+        // and the finisher releases the chain when that part's bandwidths are final.
+        if (release) first_part_done.store(1);
         if (shear_joined) return 0;
         shear_joined = true;
         const int e = shear_future.valid() ? shear_future.get() : 0;
@@ -1227,13 +1237,15 @@ struct Call {
             launches.push_back(std::move(L));
         }
         if (nA && !merged) {
-            GDB_TRY(join_shear());
+            GDB_TRY(join_shear(true));
             Launch L;
             L.F = base_F, L.na = nA, L.d_hist = shear.d_rot, L.whole = true;
             L.ks = A;
             launches.push_back(std::move(L));
         }
         const int nl = (int)launches.size();
+        // (the deferred shear chain waits for the first part's bandwidths -- unless that part itself waits for the chain)
+        if (!staged || nl == 0 || launches[0].na > 0 || !launches[0].d_hist) first_part_done.store(1);
         auto report = [&](std::vector<int> ks, int index) -> int {
             if (!waiting.empty()) {
                 // the rule-of-thumb pairs ride with the first report -- except, with the deferred shear chain, those of a
@@ -1305,6 +1317,7 @@ struct Call {
                         }
                     }
                     e = report(launches[q].ks, q);
+                    first_part_done.store(1);  // the first part's convolution is enqueued: the deferred shear chain may start
                 }
             });
             std::future<int> finisher = std::async(std::launch::async, [&]() -> int {
@@ -1335,8 +1348,10 @@ struct Call {
                     if (L.own) pool.give(L.d_batch);
                     pool.give(L.d_rows);
                     if (!e) e = absorb_rows(L, out);
+                    if (e || getenv("GDHIP_BATCH_SHEAR_AFTER_GET_H")) first_part_done.store(1);  // (A/B: release on the bandwidths already)
                     if (!e) hand(q);
                 }
+                first_part_done.store(1);
                 hand(-1);
                 return e;
             });
@@ -1376,7 +1391,7 @@ struct Call {
             if (!rc) rc = e2;
         }
         {
-            const int e = join_shear();  // (an error path may get here before any launch asked for it)
+            const int e = join_shear(true);  // (an error path may get here before any launch asked for it)
             if (!rc) rc = e;
         }
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
@@ -1460,6 +1475,7 @@ struct Call {
             if (overlap) {
                 const bool split_classes = F_list.size() > 1;
                 bin_done.store(0);
+                first_part_done.store(0);
                 {
                     // deferred shear chain (see shear_future): large unit-weight calls whose main class takes the byte-index
                     // route; GDHIP_BATCH_SHEAR_DEFERRED=0 restores the join in front of the optimiser
@@ -1495,9 +1511,12 @@ struct Call {
                             const auto t0 = std::chrono::steady_clock::now();
                             while (!bin_done.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
                                 std::this_thread::sleep_for(std::chrono::microseconds(50));
-                            if (const char* d = getenv("GDHIP_BATCH_SHEAR_DELAY_US"))  // (experiment: let the first part's stage A run first)
-                                std::this_thread::sleep_for(std::chrono::microseconds(atoi(d)));
-                            mark("shear: main binning has run");
+                            if (!getenv("GDHIP_BATCH_SHEAR_AT_ONCE")) {
+                                const auto t1 = std::chrono::steady_clock::now();
+                                while (!first_part_done.load() && std::chrono::steady_clock::now() - t1 < std::chrono::milliseconds(20))
+                                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                            }
+                            mark("shear: main binning has run, first part's bandwidths final");
                         }
                         const int e = shear_histograms(sctx);
                         const int e2 = split_classes ? binning(sctx, 2) : 0;  // the up-scaled classes, behind the shear chain
@@ -1517,7 +1536,7 @@ struct Call {
                 }
                 e = bin_f.get();
                 if (!rc) rc = e;
-                if (rc) (void)join_shear();
+                if (rc) (void)join_shear(true);
             } else {
                 rc = neff_batch(used, true);
                 if (!rc) rc = neff_complete(&exchanged);
@@ -1639,7 +1658,7 @@ struct Call {
 
     // an error after device work was started: wait for whatever is in flight, hand every block back
     int cleanup(int rc) {
-        (void)join_shear();  // (a deferred chain still running on its own context uses the pool and the class table)
+        (void)join_shear(true);  // (a deferred chain still running on its own context uses the pool and the class table)
         ops.copy_sync(h);
         if (twin) ops.copy_sync(twin);
         for (auto& kv : hists) pool.give(kv.second);
