@@ -117,6 +117,10 @@ const gdb::Ops kOps = {
     /* comm_world */ [](void* h) { return C(h)->comm ? C(h)->comm_world : 0; },
     /* comm_allreduce_sum */ [](void* h, double* inout, int64_t count) { return gd_comm_allreduce_sum(C(h), inout, count); },
     /* stream_priority */ [](void* ctx, int level) { return gd_stream_priority(C(ctx), level); },
+    /* prebin_batch */
+    [](void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F, void* const* d_idx) {
+        return gd_prebin_batch(C(h), cols, ncols, binmin, width, F, d_idx);
+    },
 };
 
 const gdb::Ops1D kOps1D = {

@@ -88,6 +88,9 @@ struct Ops {
     int (*comm_allreduce_sum)(void* h, double* inout, int64_t count);
     // the (idle) context's stream re-created with high (1) / normal (0) / low (-1) priority
     int (*stream_priority)(void* ctx, int level);
+    // u16 index columns of several sample columns in ONE launch (gd_prebin_batch; blocking).  May be null: `prebin` per column
+    int (*prebin_batch)(void* h, const int32_t* cols, int32_t ncols, const double* binmin, const double* width, int32_t F,
+                        void* const* d_idx);
 };
 
 // ---- numpy / CPython scalar semantics --------------------------------------------------------------------------------
@@ -731,6 +734,40 @@ struct Call {
         return 0;
     }
 
+    // the stale u16 index columns of a grid-size class in ONE launch (round 6: the up-scaled classes used to cost a launch
+    // per column -- 12 launches of 20-70 us between the shear chain and their histograms)
+    int index_columns16(void* ctx, const std::vector<int>& cols, int F) {
+        if (!ops.prebin_batch) return 0;  // (index_column16 makes them one by one)
+        std::vector<int32_t> todo;
+        std::vector<double> b0, w;
+        std::vector<void*> bufs;
+        for (int j : cols) {
+            const double fw = (bmax[j] - bmin[j]) / (F - 1);
+            IdxCol c;
+            {
+                std::lock_guard<std::mutex> g(st.mu);
+                c = st.idx[std::make_tuple(j, F, 2)];
+            }
+            if (c.valid && c.binmin == bmin[j] && c.width == fw) continue;
+            if (!c.ptr) {
+                int rc = 0;
+                c.ptr = pool.take(N * 2 + 64, &rc);
+                if (!c.ptr) return dev_fail(rc, h);
+                std::lock_guard<std::mutex> g(st.mu);
+                st.idx[std::make_tuple(j, F, 2)] = c;  // (the block is the column's from now on, valid or not)
+            }
+            todo.push_back(j), b0.push_back(bmin[j]), w.push_back(fw), bufs.push_back(c.ptr);
+        }
+        if (todo.size() < 2) return 0;  // nothing, or one column: the single-column entry serves it
+        GDB_DEV(ctx, ops.prebin_batch(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), F, bufs.data()));
+        std::lock_guard<std::mutex> g(st.mu);
+        for (size_t q = 0; q < todo.size(); ++q) {
+            IdxCol& c = st.idx[std::make_tuple((int)todo[q], F, 2)];
+            c.binmin = b0[q], c.width = w[q], c.valid = true;
+        }
+        return 0;
+    }
+
     // -- prebin + batched 2D histograms of every grid-size class on context `ctx` (mcsamples.py:1486-1498, 1724-1728)
     // part 0: every grid-size class; 1: the class with the most pairs only; 2: the others.  Large calls bin the main class
     // on the second stream and the few pairs of the up-scaled classes behind the shear chain on the third: they used to
@@ -810,6 +847,15 @@ struct Call {
                 if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (else: the u16 / u32 path below redoes the class)
             }
             bin_launching.store(1);  // (this class enqueues as it goes)
+            {
+                std::vector<int> cols;
+                std::vector<char> seen(n, 0);
+                for (int k : members) {
+                    if (!seen[ps.jx[k]]) seen[ps.jx[k]] = 1, cols.push_back(ps.jx[k]);
+                    if (!seen[ps.jy[k]]) seen[ps.jy[k]] = 1, cols.push_back(ps.jy[k]);
+                }
+                GDB_TRY(index_columns16(ctx, cols, F));
+            }
             std::vector<const void*> ix(B), iy(B);
             for (int q = 0; q < B; ++q) {
                 void* p;
@@ -1220,6 +1266,8 @@ struct Call {
                     L.F = F, L.na = carries ? nA : 0, L.d_hist = class_buffer(F);
                     size_t take_ = std::min(pos_C.size() - c0, part > (size_t)L.na ? part - (size_t)L.na : (size_t)1);
                     if (shear_deferred && carries) take_ = pos_C.size() - c0;  // the last part takes what is left
+                    // (measured: a first part of 256 pairs only, the others unchanged -- delivered triangle 27.9-28.0 against
+                    // 27.9-28.6, the stream of triangles 22.1 against 21.5: the result copies saturate PCIe from the first batch on)
                     L.pos.assign(pos_C.begin() + c0, pos_C.begin() + c0 + take_);
                     c0 += take_;
                     L.whole = L.na == 0 && L.pos.size() == mem.size();

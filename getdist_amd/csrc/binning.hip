@@ -681,7 +681,28 @@ __global__ void __launch_bounds__(256) k_prebin_fix(const PrebinColB* __restrict
     const int cnt = counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x];
     if (cnt <= cap) {
         const unsigned int* mylist = lists + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * cap;
-        for (int k = threadIdx.x; k < cnt; k += 256) settle((int64_t)mylist[k]);
+        // four list entries per thread and iteration, their rows and samples requested before the first is settled (every
+        // entry is a dependent chain list -> sample -> store of its own: one at a time exposed two round trips per entry)
+        int k = threadIdx.x;
+        for (; k + 3 * 256 < cnt; k += 4 * 256) {
+            unsigned int r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = mylist[k + q * 256];
+            double xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = C.x[r[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = bin_round(xv[q], bd);
+                if (OUT8) {
+                    nbad += ((unsigned)a >= (unsigned)F);
+                    ((unsigned char*)C.idx)[r[q]] = (unsigned char)a;
+                } else {
+                    ((unsigned short*)C.idx)[r[q]] = (unsigned)a < (unsigned)F ? (unsigned short)a : (unsigned short)0xFFFF;
+                }
+            }
+        }
+        for (; k < cnt; k += 256) settle((int64_t)mylist[k]);
     } else {
         const int64_t lo = (int64_t)blockIdx.x * R;
         int64_t hi = lo + R;

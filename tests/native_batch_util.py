@@ -52,6 +52,7 @@ _OPS = [
     ("comm_world", C.CFUNCTYPE(C.c_int, _p)),
     ("comm_allreduce_sum", C.CFUNCTYPE(C.c_int, _p, _pd, _i64)),
     ("stream_priority", C.CFUNCTYPE(C.c_int, _p, C.c_int)),
+    ("prebin_batch", C.CFUNCTYPE(C.c_int, _p, _pi32, _i32, _pd, _pd, _i32, _pp)),
 ]
 
 
@@ -143,6 +144,13 @@ def _make_ops():
     def prebin(h, col, binmin, width, F, d_idx):
         c = ctx_of(h)
         buf_of(d_idx).a = c.prebin(col, binmin, width, F).a
+        return 0
+
+    def prebin_batch(h, cols, ncols, binmin, width, F, d_idx):
+        c = ctx_of(h)
+        CALLS.append(("prebin_batch", c.lane, ncols, F))
+        for q in range(ncols):
+            buf_of(d_idx[q]).a = c.prebin(cols[q], binmin[q], width[q], F).a
         return 0
 
     def hist2d_prebinned(h, B, ix, iy, F, d_hist):
