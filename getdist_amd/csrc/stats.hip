@@ -1535,6 +1535,128 @@ __global__ void __launch_bounds__(256) k_kde_lag_multi(const double* __restrict_
     }
 }
 
+// The same sums with every sample read from HBM once, for the lag sets the N_eff estimate asks for (mcsamples.py:
+// NF lags K0 + delta near N/2 and NN short ones).  The kernel above reads the second half of a column twice: as the far
+// partners of the first half and again as the x_i of the short lags.  Here only rows i < R = N - K0 are walked and each
+// thread also takes the short-lag terms of row j = i + K0, whose lines its far loads have just brought in (rows
+// [0, R) as x_i and rows [R, N) as x_j partition the column when 2 K0 <= N; for odd N row i = 0 has no second role).
+// lags[]: the NF far lags, then the NN short ones; sums come out in that order.
+template <bool HAS_W, int NF, int NN>
+__global__ void __launch_bounds__(256) k_kde_lag_folded(const double* __restrict__ cols, int64_t ld,
+                                                        const int32_t* __restrict__ colidx, const double* __restrict__ w,
+                                                        int64_t N, const double* __restrict__ cvals,
+                                                        const int64_t* __restrict__ lags, double* __restrict__ part) {
+    __shared__ double red[16];
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64));
+    __syncthreads();
+    const double* x = cols + (int64_t)colidx[blockIdx.y] * ld;
+    const double c = cvals[blockIdx.y];
+    int64_t kf[NF], kn[NN];
+    int64_t K0 = N, kmax = 0, nmax = 0;
+#pragma unroll
+    for (int l = 0; l < NF; ++l) {
+        kf[l] = lags[l];
+        K0 = kf[l] < K0 ? kf[l] : K0;
+        kmax = kf[l] > kmax ? kf[l] : kmax;
+    }
+#pragma unroll
+    for (int l = 0; l < NN; ++l) {
+        kn[l] = lags[NF + l];
+        nmax = kn[l] > nmax ? kn[l] : nmax;
+    }
+    const int64_t R = N - K0, J0 = N - 2 * K0;  // rows walked; first row with a second role
+    double s[NF + NN];
+#pragma unroll
+    for (int l = 0; l < NF + NN; ++l) s[l] = 0;
+    const double* xj = x + K0;
+    const double* wj = HAS_W ? w + K0 : nullptr;
+    // chunks [cA, cB): every term of every thread exists
+    const int64_t nT = (R + 255) / 256, cA = (J0 + 255) / 256;
+    int64_t cB = (N - kmax < R - nmax ? N - kmax : R - nmax) / 256;
+    if (cB < cA) cB = cA;
+    for (int64_t ch = cA + blockIdx.x; ch < cB; ch += gridDim.x) {
+        const int64_t i = ch * 256 + threadIdx.x;
+        const double xi = x[i], xs = xj[i];
+        const double wi = HAS_W ? w[i] : 1.0, ws = HAS_W ? wj[i] : 1.0;
+        double xk[NF], wk[NF], xa[NN], wa[NN], xb[NN], wb[NN];
+#pragma unroll
+        for (int l = 0; l < NF; ++l) {
+            xk[l] = (x + kf[l])[i];
+            wk[l] = HAS_W ? (w + kf[l])[i] : 1.0;
+        }
+#pragma unroll
+        for (int l = 0; l < NN; ++l) {
+            xa[l] = (x + kn[l])[i];
+            xb[l] = (xj + kn[l])[i];
+            wa[l] = HAS_W ? (w + kn[l])[i] : 1.0;
+            wb[l] = HAS_W ? (wj + kn[l])[i] : 1.0;
+        }
+#pragma unroll
+        for (int l = 0; l < NF; ++l) {
+            const double d = xi - xk[l];
+            double e = exp_neg((d * d) * c, tab);
+            if (HAS_W) e = e * wi * wk[l];
+            s[l] += e;
+        }
+#pragma unroll
+        for (int l = 0; l < NN; ++l) {
+            const double d = xi - xa[l], d2 = xs - xb[l];
+            double e = exp_neg((d * d) * c, tab), e2 = exp_neg((d2 * d2) * c, tab);
+            if (HAS_W) {
+                e = e * wi * wa[l];
+                e2 = e2 * ws * wb[l];
+            }
+            s[NF + l] += e + e2;
+        }
+    }
+    for (int64_t ch = blockIdx.x; ch < nT; ch += gridDim.x) {
+        if (ch >= cA && ch < cB) continue;
+        const int64_t i = ch * 256 + threadIdx.x;
+        const bool row = i < R;
+        const double xi = row ? x[i] : 0.0;
+        const double wi = (HAS_W && row) ? w[i] : 1.0;
+#pragma unroll
+        for (int l = 0; l < NF; ++l) {
+            const bool valid = i < N - kf[l];
+            const int64_t r = valid ? i + kf[l] : N - 1;
+            const double d = xi - x[r];
+            double e = exp_neg((d * d) * c, tab);
+            if (HAS_W) e = e * wi * w[r];
+            s[l] += valid ? e : 0.0;
+        }
+        const bool second = row && i >= J0;
+        const int64_t j = second ? i + K0 : N - 1;
+        const double xs = x[j];
+        const double ws = HAS_W ? w[j] : 1.0;
+#pragma unroll
+        for (int l = 0; l < NN; ++l) {
+            {
+                const bool valid = row && i + kn[l] < N;
+                const int64_t r = valid ? i + kn[l] : N - 1;
+                const double d = xi - x[r];
+                double e = exp_neg((d * d) * c, tab);
+                if (HAS_W) e = e * wi * w[r];
+                s[NF + l] += valid ? e : 0.0;
+            }
+            {
+                const bool valid = second && j + kn[l] < N;
+                const int64_t r = valid ? j + kn[l] : N - 1;
+                const double d = xs - x[r];
+                double e = exp_neg((d * d) * c, tab);
+                if (HAS_W) e = e * ws * w[r];
+                s[NF + l] += valid ? e : 0.0;
+            }
+        }
+    }
+    double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * KDE_LAG_MAX;
+#pragma unroll
+    for (int l = 0; l < NF + NN; ++l) {
+        const double r = block_sum(s[l], red);
+        if (threadIdx.x == 0) p[l] = r;
+    }
+}
+
 template <bool HAS_W>
 __global__ void k_kde_lag(const double* __restrict__ cols, int64_t ld, const int32_t* __restrict__ colidx,
                           const double* __restrict__ w, int64_t N, const double* __restrict__ cvals,
@@ -2251,11 +2373,46 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     int64_t* d_lags = (int64_t*)(base + o_lags);
     int32_t* d_idx = (int32_t*)(base + o_idx);
     double* d_c = (double*)(base + o_c);
-    GD_TRY(gd_h2d(ctx, d_lags, lags, (size_t)nlags * 8));
+    // the N_eff lag set (five lags from N/2, one or two short ones): every sample read once
+    int order[KDE_LAG_MAX];
+    int nf = 0, nn = 0;
+    bool folded = false;
+    if (multi && ctx->N >= 4096 && getenv("GDHIP_KDE_LAG_UNFOLDED") == nullptr) {
+        int64_t K0 = ctx->N, nmax = 0;
+        for (int i = 0; i < nlags; ++i)
+            if (4 * lags[i] >= ctx->N) {
+                order[nf++] = i;
+                K0 = lags[i] < K0 ? lags[i] : K0;
+            }
+        for (int i = 0; i < nlags; ++i)
+            if (4 * lags[i] < ctx->N) {
+                order[nf + nn++] = i;
+                nmax = lags[i] > nmax ? lags[i] : nmax;
+            }
+        folded = nf == 5 && (nn == 1 || nn == 2) && 2 * K0 <= ctx->N && nmax < 256;
+    }
+    if (folded) {
+        int64_t sorted[KDE_LAG_MAX];
+        for (int i = 0; i < nlags; ++i) sorted[i] = lags[order[i]];
+        GD_TRY(gd_h2d(ctx, d_lags, sorted, (size_t)nlags * 8));
+    } else {
+        for (int i = 0; i < nlags && i < KDE_LAG_MAX; ++i) order[i] = i;
+        GD_TRY(gd_h2d(ctx, d_lags, lags, (size_t)nlags * 8));
+    }
     GD_TRY(gd_h2d(ctx, d_idx, cols, (size_t)ncols * 4));
     GD_TRY(gd_h2d(ctx, d_c, inv4s2, (size_t)ncols * 8));
     if (multi) {
         const dim3 grid(nblk, ncols);
+        if (folded) {
+#define KDE_FOLDED(W, NNV)                                                                                           \
+    k_kde_lag_folded<W, 5, NNV><<<grid, 256, 0, ctx->stream>>>(ctx->cols, ctx->ld, d_idx, ctx->w, ctx->N, d_c, d_lags, part)
+            if (ctx->w) {
+                if (nn == 1) KDE_FOLDED(true, 1); else KDE_FOLDED(true, 2);
+            } else {
+                if (nn == 1) KDE_FOLDED(false, 1); else KDE_FOLDED(false, 2);
+            }
+#undef KDE_FOLDED
+        } else
 #define KDE_LAUNCH(NLV)                                                                                                 \
     case NLV:                                                                                                           \
         if (ctx->w)                                                                                                     \
@@ -2277,7 +2434,7 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
             for (int l = 0; l < nlags; ++l) {
                 double sum = 0;
                 for (int b = 0; b < nblk; ++b) sum += h[((size_t)c * nblk + b) * KDE_LAG_MAX + l];
-                out[(size_t)c * nlags + l] = sum;
+                out[(size_t)c * nlags + order[l]] = sum;
             }
         return GD_OK;
     }

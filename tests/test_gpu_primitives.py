@@ -1,5 +1,7 @@
 """GPU parity tests of the O(N) kernels, through the C ABI, against numpy / the oracle on seeded inputs."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -205,6 +207,32 @@ def test_lag_sums(ctx, data):
     got = ctx.kde_lag_sums(2, c, lags)
     ref = [np.dot(np.exp(-((x[:-k] - x[k:]) ** 2) * c) * w[:-k], w[k:]) for k in lags]
     assert np.allclose(got, ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("N", [4096, 4097, 50_000, 50_001, 131_075])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_neff_lag_set_reads_every_sample_once(ctx, N, weighted):
+    """The lag set of the N_eff estimate (mcsamples.py:1019 ff.: five lags from N//2, one or two short ones) takes a
+    kernel that walks only the first half and gives row i + N//2 its short-lag terms from the same loads: same sums as
+    the general kernel and as numpy, for even and odd N (odd: the halves overlap in one row), in the caller's order."""
+    r = np.random.default_rng(N + weighted)
+    x = np.cumsum(r.standard_normal((N, 3)), axis=0) * 0.05 + r.standard_normal((N, 3))
+    w = r.random(N) + 0.25 if weighted else None
+    ctx.upload(x, w)
+    ww = w if weighted else np.ones(N)
+    c = np.array([1.0 / (4 * 0.3**2), 0.8, 2.5])
+    for lags in ([N // 2 + d for d in range(5)] + [1, 2], [N // 2 + d for d in range(5)] + [1], [1, 2] + [N // 2 + d for d in (4, 0, 2, 1, 3)]):
+        lags = np.array(lags, dtype=np.int64)
+        ref = np.array([[np.dot(np.exp(-((x[:-k, j] - x[k:, j]) ** 2) * c[j]) * ww[:-k], ww[k:]) for k in lags] for j in range(3)])
+        got = ctx.kde_lag_sums_batch([0, 1, 2], c, lags)
+        assert np.allclose(got, ref, rtol=1e-12), (lags, np.abs(got / ref - 1).max())
+        os.environ["GDHIP_KDE_LAG_UNFOLDED"] = "1"
+        try:
+            general = ctx.kde_lag_sums_batch([0, 1, 2], c, lags)
+        finally:
+            del os.environ["GDHIP_KDE_LAG_UNFOLDED"]
+        assert np.allclose(got, general, rtol=1e-12)
+        assert not np.array_equal(got, general)  # the other order of summation: the folded kernel did run
 
 
 def test_hist2d_u16_counters_overflow_is_detected_and_redone(ctx):
