@@ -397,6 +397,37 @@ def test_linear_bucket_quantiles_equal_the_radix_path(weights, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("weights", ["unit", "integer"])
+def test_collect_stage_overflow_falls_through_to_the_lists(weights):
+    """The collect pass stages a block's hits in LDS (2048 rows) and appends them with one atomic per (block, bucket).
+    Many columns in one call leave 8 blocks per column; a lattice column whose live buckets hold ~3300 rows each then
+    puts ~4500 hits into one block: the rows beyond the stage go straight to the lists and the picks stay exact."""
+    from getdist_amd._lib import Context
+
+    rng = np.random.default_rng(31)
+    N = 1_000_003
+    s = np.column_stack([rng.integers(0, 300, N) / 7.0, rng.standard_normal(N)])
+    w = None if weights == "unit" else rng.integers(1, 4, N).astype(float)
+    wv = np.ones(N) if w is None else w
+    c = Context(0)
+    try:
+        c.upload(s, w)
+        cols = [0] * 255 + [1]
+        mm = np.stack([s.min(axis=0), s.max(axis=0)], axis=1)[cols]
+        fracs = np.array([0.003, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.997])
+        for lo, hi in ((0, N), (777, 900_001)):  # whole columns (bucket columns) and a row range (fp64 collect)
+            norm = wv[lo:hi].sum()
+            got = c.quantiles(cols, np.tile(norm * fracs, (len(cols), 1)), lo=lo, hi=hi, minmax=mm)
+            for ci in (0, 100, 254, 255):
+                x = s[lo:hi, cols[ci]]
+                idx = x.argsort(kind="stable")
+                cum = np.cumsum(wv[lo:hi][idx])
+                want = x[idx[np.minimum(np.searchsorted(cum, norm * fracs), len(idx) - 1)]]
+                assert np.array_equal(got[ci], want), (weights, ci, lo, got[ci], want)
+    finally:
+        c.close()
+
+
 def test_contour_levels_batch(ctx):
     """gd_contour_levels against the oracle's restatement of densities.py:19-56 on smooth, flat-topped and tied grids."""
     from oracle import kde_oracle as ko
