@@ -493,6 +493,7 @@ struct Call {
     std::vector<int64_t> winw;
     std::vector<int32_t> flags, group;
     std::vector<void*> call_blocks;  // everything to release once the copies have landed
+    std::vector<void*> bin_stale;    // a main-class buffer whose second launch failed (under enq_mu; joins call_blocks)
     std::mutex enq_mu;
     // three-stream choreography: the N_eff launch (2000 resident blocks for ~3 ms: whatever is enqueued behind it on another
     // stream waits for a wave slot) holds back until the binning thread is about to enqueue its chain -- the binning is on
@@ -519,6 +520,43 @@ struct Call {
     // convolution 28.1-28.9; the stream of triangles 21.7 -> 21.9.  Released at once when the first launch itself needs the
     // chain, when nothing is staged, and on every error path (and after 20 ms whatever happens).
     std::atomic<int> first_part_done{0};
+    // Main binning in two launches (round 6, single-triangle latency): the members of the base grid's class are put in the
+    // order the optimiser takes them (its own pairs first, the sheared and rule-of-thumb pairs behind), the rows of the FIRST
+    // optimiser part are binned by the fused prebin + histogram call, the other rows by a second histogram launch behind it
+    // -- and stage A of the first part starts when the first launch has run instead of waiting for both.  Everything else
+    // (the later parts, every convolution, the deferred chain) joins the whole binning as before.  A pair's histogram does
+    // not depend on its row or on the launch that fills it: results unchanged bit for bit.
+    std::shared_future<int> bin_future;
+    std::mutex bin_mu;
+    std::atomic<int> bins_first_done{0};
+    int bins_first_rows = 0;  // rows [0, bins_first_rows) of the main class's buffer are the first launch's; 0: one launch
+    int bin_rc = 0;
+    bool bin_joined = true;
+    int join_binning() {
+        std::lock_guard<std::mutex> g(bin_mu);
+        if (!bin_joined) {
+            bin_joined = true;
+            bin_rc = bin_future.valid() ? bin_future.get() : 0;
+            mark("binning: joined");
+        }
+        return bin_rc;
+    }
+    // the size of a part of the base grid's optimiser launches (total = its own pairs + the sheared pairs)
+    size_t base_part_size(size_t total, int F) const {
+        // Two parts: the second's DCT / fixed point beside the first's get_h and convolution.  More, smaller
+        // parts were measured (3 / 4 / 12: 31.2 / 32.1 / 31.4 ms per C3 step against 30.5 with two): the chip is
+        // busy either way, and a part below two blocks per CU leaves the fixed-point kernel's tail exposed.
+        size_t want = 2;  // GDHIP_KOPT_PARTS: tuning knob
+        if (const char* e = getenv("GDHIP_KOPT_PARTS")) want = (size_t)std::max(1, atoi(e));
+        size_t part = std::max<size_t>((size_t)s_kopt_split_min(), (total + want - 1) / want);
+        // the fixed-point kernel holds one pair per CU (its matrix lives in the CU's registers and LDS): parts of
+        // a whole number of rounds over the 256 CUs leave no extra, mostly empty round (1279 pairs as 640 + 639
+        // are 3 + 3 rounds, as 512 + 767 they are 2 + 3)
+        size_t align = 256;  // GDHIP_KOPT_PART_ALIGN: tuning knob (0: off)
+        if (const char* e = getenv("GDHIP_KOPT_PART_ALIGN")) align = (size_t)std::max(0, atoi(e));
+        if (align > 1 && F == 256 && part > align) part = std::max<size_t>(align, (part + align / 2 - 1) / align * align);
+        return part;
+    }
     int join_shear(bool release = false) {
         // release: the caller is not going to enqueue a first part the chain could wait for (error paths, a call whose only
         // launch needs the chain).  The staging thread's ordinary join does NOT release: by then the first part is enqueued
@@ -828,9 +866,11 @@ struct Call {
                 std::vector<int64_t> bad(todo.size() + 1, 0);
                 mark("binning: prebin8 + hist2d launch", (int)todo.size(), B);
                 bin_launching.store(1);
-                const int e = ops.prebin8_hist2d(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), bufs.data(), bad.data(), B,
-                                                 ix.data(), iy.data(), d);
-                mark("binning: prebin8 + hist2d done");
+                // (two launches: the first optimiser part's rows, then the others -- see bin_future)
+                const int B1 = (F == main_F && bins_first_rows > 0 && bins_first_rows < B) ? bins_first_rows : B;
+                int e = ops.prebin8_hist2d(ctx, todo.data(), (int)todo.size(), b0.data(), w.data(), bufs.data(), bad.data(), B1,
+                                           ix.data(), iy.data(), d);
+                mark("binning: prebin8 + hist2d done", B1);
                 if (e == 0 || e == GD_ERR_SOLVER) {
                     std::lock_guard<std::mutex> g(st.mu);
                     for (size_t q = 0; q < todo.size(); ++q) {
@@ -838,12 +878,30 @@ struct Call {
                         c.binmin = b0[q], c.width = w[q], c.valid = bad[q] == 0;
                     }
                 }
+                bool published = false;
+                if (e == 0 && B1 < B) {
+                    {
+                        std::lock_guard<std::mutex> g(enq_mu);
+                        hists[F] = d;
+                    }
+                    published = true;
+                    bins_first_done.store(1);
+                    e = ops.hist2d_prebinned8(ctx, B - B1, ix.data() + B1, iy.data() + B1, (char*)d + (int64_t)B1 * 65536 * 8);
+                    mark("binning: the other rows done", B - B1);
+                    if (e == 0) continue;
+                }
                 if (e == 0) {
                     std::lock_guard<std::mutex> g(enq_mu);
                     hists[F] = d;
                     continue;
                 }
-                pool.give(d);
+                if (published) {  // the first part may be reading its rows: the block lives until the call ends
+                    std::lock_guard<std::mutex> g(enq_mu);
+                    hists.erase(F);
+                    bin_stale.push_back(d);
+                } else {
+                    pool.give(d);
+                }
                 if (e != GD_ERR_SOLVER) return dev_fail(e, ctx);  // (else: the u16 / u32 path below redoes the class)
             }
             bin_launching.store(1);  // (this class enqueues as it goes)
@@ -881,6 +939,7 @@ struct Call {
         bin_launching.store(1);
         return 0;
     }
+    // (the thread that runs binning(ctx, 1) sets bins_first_done when binning returns, whatever the route taken)
 
     // -- branch A of getAutoBandwidth2D (mcsamples.py:1347-1378): min/max of the sheared coordinate and the re-binned
     //    base grid of every sheared pair, two batched launches
@@ -1244,20 +1303,7 @@ struct Call {
                 // the sheared pairs ride with the first part of the base grid's own pairs
                 const size_t total = pos_C.size() + (size_t)nA;
                 size_t part = total;
-                if (staged && (int)pos_C.size() >= s_kopt_split_min()) {
-                    // Two parts: the second's DCT / fixed point beside the first's get_h and convolution.  More, smaller
-                    // parts were measured (3 / 4 / 12: 31.2 / 32.1 / 31.4 ms per C3 step against 30.5 with two): the chip is
-                    // busy either way, and a part below two blocks per CU leaves the fixed-point kernel's tail exposed.
-                    size_t want = 2;  // GDHIP_KOPT_PARTS: tuning knob
-                    if (const char* e = getenv("GDHIP_KOPT_PARTS")) want = (size_t)std::max(1, atoi(e));
-                    part = std::max<size_t>((size_t)s_kopt_split_min(), (total + want - 1) / want);
-                    // the fixed-point kernel holds one pair per CU (its matrix lives in the CU's registers and LDS): parts of
-                    // a whole number of rounds over the 256 CUs leave no extra, mostly empty round (1279 pairs as 640 + 639
-                    // are 3 + 3 rounds, as 512 + 767 they are 2 + 3)
-                    size_t align = 256;  // GDHIP_KOPT_PART_ALIGN: tuning knob (0: off)
-                    if (const char* e = getenv("GDHIP_KOPT_PART_ALIGN")) align = (size_t)std::max(0, atoi(e));
-                    if (align > 1 && F == 256 && part > align) part = std::max<size_t>(align, (part + align / 2 - 1) / align * align);
-                }
+                if (staged && (int)pos_C.size() >= s_kopt_split_min()) part = base_part_size(total, F);
                 // (deferred shear chain: the sheared rows lead the LAST part instead of the first)
                 const size_t nparts = shear_deferred ? std::max<size_t>(1, (total + part - 1) / part) : 0;
                 for (size_t c0 = 0, first = 1, ip = 0; c0 < pos_C.size(); first = 0, ++ip) {
@@ -1310,11 +1356,27 @@ struct Call {
             return 0;
         };
         int rc = 0;
+        // a launch of the base class whose rows the FIRST binning launch has filled may go ahead of the second
+        auto rows_binned_first = [&](const Launch& L) {
+            if (bins_first_rows <= 0 || L.F != base_F || L.na > 0 || !L.d_hist) return false;
+            for (int q : L.pos)
+                if (q >= bins_first_rows) return false;
+            return true;
+        };
+        auto whole_binning_for = [&](Launch& L) -> int {
+            const int e = join_binning();
+            if (e) return e;
+            if (L.F == base_F && !L.pos.empty())  // (a class buffer whose second launch failed has been replaced)
+                if (void* p = class_buffer(L.F)) L.d_hist = p;
+            return 0;
+        };
         if (!staged || nl == 0) {
+            rc = join_binning();
             for (int q = 0; q < nl && !rc; ++q) {
                 Launch& L = launches[q];
                 const int B = (int)L.ks.size();
-                rc = ready_for(L, class_buffer);
+                rc = whole_binning_for(L);
+                if (!rc) rc = ready_for(L, class_buffer);
                 if (!rc) rc = build_batch(L);
                 std::vector<double> out((size_t)B * 12);
                 if (!rc) {
@@ -1364,7 +1426,8 @@ struct Call {
                             continue;
                         }
                     }
-                    e = report(launches[q].ks, q);
+                    e = join_binning();  // (long done by now: a report may convolve any row of the class)
+                    if (!e) e = report(launches[q].ks, q);
                     first_part_done.store(1);  // the first part's convolution is enqueued: the deferred shear chain may start
                 }
             });
@@ -1406,7 +1469,8 @@ struct Call {
             for (int q = 0; q < nl && !rc; ++q) {
                 Launch& L = launches[q];
                 const int B = (int)L.ks.size();
-                rc = ready_for(L, class_buffer);
+                if (!(q == 0 && rows_binned_first(L))) rc = whole_binning_for(L);
+                if (!rc) rc = ready_for(L, class_buffer);
                 if (!rc) rc = build_batch(L);
                 if (!rc) {
                     L.d_rows = pool.take((int64_t)B * GD_KOPT_BLOCK_DOUBLES * 8, &rc);
@@ -1439,7 +1503,9 @@ struct Call {
             if (!rc) rc = e2;
         }
         {
+            const int e0 = join_binning();
             const int e = join_shear(true);  // (an error path may get here before any launch asked for it)
+            if (!rc) rc = e0;
             if (!rc) rc = e;
         }
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
@@ -1487,7 +1553,7 @@ struct Call {
             if (!st.aux) GDB_DEV(h, ops.create_aux(h, &st.aux));
             aux = st.aux;
         }
-        std::future<int> neff_f, bin_f, shear_f;
+        std::future<int> neff_f, shear_f;
         bin_launching.store(0);
         hold_neff_for_binning = overlap && need_neff && unit_weights && !getenv("GDHIP_BATCH_NO_NEFF_HOLD");
         if (overlap && need_neff)
@@ -1544,14 +1610,31 @@ struct Call {
                     }
                     shear_after_binning = shear_deferred;
                 }
-                bin_f = std::async(std::launch::async, [this, split_classes] {
-                    ops.bind_thread(twin);
-                    const int e = binning(twin, split_classes ? 1 : 0);
-                    bin_done.store(1);
-                    return e;
-                });
+                // (the branch plan needs the limits and the covariance only)
                 rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
-                if (!rc)  // the branch plan needs the limits and the covariance only: the shear chain starts at once
+                bins_first_rows = 0;
+                bins_first_done.store(0);
+                const bool will_stage = aux != nullptr && !s.want_levels && P >= s_two_min() && P > s_two_split();
+                if (!rc && shear_deferred && will_stage && base_F == 256 && main_class() == 256 && !getenv("GDHIP_BATCH_ONE_BINNING")) {
+                    std::vector<int>& mem = classes[256];
+                    std::stable_partition(mem.begin(), mem.end(), [&](int k) { return plan.branch[k] == 2; });
+                    size_t nC = 0, nA = 0;
+                    for (int k : mem) nC += plan.branch[k] == 2;
+                    for (int k = 0; k < P; ++k) nA += plan.branch[k] == 0;
+                    if ((int)nC >= s_kopt_split_min()) {
+                        const size_t part = base_part_size(nC + nA, 256), first = std::min(nC, part);
+                        if (nC + nA > part && first < mem.size()) bins_first_rows = (int)first;
+                    }
+                }
+                bin_joined = false, bin_rc = 0;
+                bin_future = std::async(std::launch::async, [this, split_classes] {
+                                 ops.bind_thread(twin);
+                                 const int e = binning(twin, split_classes ? 1 : 0);
+                                 bins_first_done.store(1);
+                                 bin_done.store(1);
+                                 return e;
+                             }).share();
+                if (!rc)  // the shear chain starts at once
                     shear_f = std::async(std::launch::async, [this, aux, split_classes] {
                         void* sctx = shear_deferred ? st.aux2 : aux;
                         ops.bind_thread(sctx);
@@ -1582,8 +1665,14 @@ struct Call {
                         if (!rc) rc = e;
                     }
                 }
-                e = bin_f.get();
-                if (!rc) rc = e;
+                if (bins_first_rows > 0 && !rc) {
+                    // the first optimiser part's rows only; whoever needs more joins the binning (bandwidth_2d)
+                    while (!bins_first_done.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    mark("binning: first part's rows done", bins_first_rows);
+                } else {
+                    e = join_binning();
+                    if (!rc) rc = e;
+                }
                 if (rc) (void)join_shear(true);
             } else {
                 rc = neff_batch(used, true);
@@ -1681,6 +1770,8 @@ struct Call {
         mark("all batches enqueued");
         for (auto& kv : hists) call_blocks.push_back(kv.second);
         hists.clear();
+        for (void* p : bin_stale) call_blocks.push_back(p);
+        bin_stale.clear();
         GDB_DEV(h, ops.copy_mark(h, &tokens_out2[0]));
         if (conv_ctxs.size() > 1) GDB_DEV(twin, ops.copy_mark(twin, &tokens_out2[1]));
         if (!lazy) {
@@ -1706,11 +1797,14 @@ struct Call {
 
     // an error after device work was started: wait for whatever is in flight, hand every block back
     int cleanup(int rc) {
+        (void)join_binning();
         (void)join_shear(true);  // (a deferred chain still running on its own context uses the pool and the class table)
         ops.copy_sync(h);
         if (twin) ops.copy_sync(twin);
         for (auto& kv : hists) pool.give(kv.second);
         hists.clear();
+        for (void* p : bin_stale) pool.give(p);
+        bin_stale.clear();
         if (shear.d_rot) pool.give(shear.d_rot), shear.d_rot = nullptr;
         for (void* p : call_blocks) pool.give(p);
         call_blocks.clear();

@@ -91,6 +91,14 @@ def _make_ops():
     def buf_of(p):
         return _BUF[int(p)]
 
+    def buf_at(p):  # (block, byte offset) of a pointer INTO a block (the second binning launch fills the rows behind the first's)
+        p = int(p)
+        if p in _BUF:
+            return _BUF[p], 0
+        base = max(b for b in list(_BUF) if b <= p)
+        assert p - base < _BUF[base].nbytes, "a pointer outside every block"
+        return _BUF[base], p - base
+
     def bind_thread(h):
         return 0
 
@@ -105,7 +113,7 @@ def _make_ops():
 
     def dev_alloc(h, nbytes, out):
         handle = _next[0]
-        _next[0] += 0x1000
+        _next[0] += (int(nbytes) // 0x1000 + 2) * 0x1000  # handles are addresses: pointers into a block must not collide
         _BUF[handle] = FakeBuf(None, int(nbytes))
         out[0] = handle
         return 0
@@ -131,7 +139,12 @@ def _make_ops():
                       for q in range(B)])
         if H.max() > 65535:
             return -5  # a 16-bit counter would have wrapped
-        buf_of(d_hist).a = H
+        dst, off = buf_at(d_hist)
+        if off == 0:
+            dst.a = H
+        else:
+            first = off // (65536 * 8)
+            dst.a = np.concatenate([np.asarray(dst.a, dtype=np.float64).reshape(-1, 256, 256)[:first], H])
         return 0
 
     def prebin8_hist2d(h, cols, ncols, binmin, width, d_idx, bad, B, ix, iy, d_hist):

@@ -142,6 +142,18 @@ def test_native_route_deferred_shear_chain(zoo, monkeypatch):
     # the sheared pairs ride in the last base part: the first stage-A launch holds base pairs only
     order = [c[0] for c in nb.CALLS if c[0] in ("kopt2d_enqueue", "hist2d_sheared")]
     assert order.count("kopt2d_enqueue") >= 2
+    # the main class is binned in two launches: the first optimiser part's rows, then the others (same context)
+    bins = [c for c in nb.CALLS if c[0] == "hist2d_prebinned8"]
+    first_part = next(c for c in nb.CALLS if c[0] == "kopt2d_enqueue")
+    assert len(bins) == 2 and bins[0][1] == bins[1][1] == twin and bins[0][2] == first_part[2], (bins, first_part)
+    monkeypatch.setenv("GDHIP_BATCH_ONE_BINNING", "1")
+    mc1 = make(fx, nb.HarnessContext)
+    mc1.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc1.KOPT_SPLIT_MIN = 8
+    nb.CALLS.clear()
+    same(mc1.get2DDensities(pairs), plain)
+    assert len([c for c in nb.CALLS if c[0] == "hist2d_prebinned8"]) == 1
+    monkeypatch.delenv("GDHIP_BATCH_ONE_BINNING")
     # the switch restores the round-5 order (joined in front of the optimiser, sheared pairs in the first part): same results
     monkeypatch.setenv("GDHIP_BATCH_SHEAR_DEFERRED", "0")
     mc2 = make(fx, nb.HarnessContext)
