@@ -39,7 +39,8 @@ class BatchSettings(C.Structure):
                 ("want_levels", C.c_int32), ("ncontours", C.c_int32), ("contours", C.POINTER(C.c_double)),
                 ("two_streams_min", C.c_int32), ("two_streams_split", C.c_int32), ("kopt_split_min", C.c_int32),
                 ("kopt_first_fraction", C.c_double), ("first_batch", C.c_int32), ("max_batch", C.c_int32),
-                ("max_batch_bytes", C.c_double), ("comm_exchange", C.c_int32), ("reserved", C.c_int32)]
+                ("max_batch_bytes", C.c_double), ("comm_exchange", C.c_int32), ("bandwidths_only", C.c_int32),
+                ("pair_neff", C.POINTER(C.c_double)), ("bandwidths", C.POINTER(C.c_double))]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
@@ -136,7 +137,8 @@ class DensityBatch(Sequence):
         dens = Density2D._from_fields(dict(
             x=ax, y=ay, axes=[ay, ax], spacing=sx * sy, view_ranges=[vrx, vry], mask=None, likes=None, contours=cont, spl=None,
             _P=Pk, _wait=functools.partial(self._completion.wait_grid, k) if self._completion is not None else None,
-            bandwidth=tuple(meta[k, 2:5].tolist()) if auto else None, bandwidth_branch="ABC"[int(meta[k, 5])] if auto else None,
+            bandwidth=tuple(meta[k, 2:5].tolist()) if auto else None,
+            bandwidth_branch="ABC"[int(meta[k, 5])] if auto and meta[k, 5] >= 0 else None,  # (-1: injected bandwidths)
             kopt=None if np.isnan(meta[k, 13]) else meta[k, 6:18].copy()))
         if cont is None and state is not None:  # more exactly equal grid values at the level than the kernel's tie list holds
             dens.contours = dens.getContourLevels(self._all_contours[:len(self._contours)])
@@ -215,8 +217,12 @@ def pack_params(mc, used, owned=None):
     return arr
 
 
-def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_density):
-    """The native route of MCSamples.get2DDensities: ``pa`` is the (P, 2) int array of column pairs."""
+def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_density, bandwidths=None, pair_neff=None,
+        bandwidths_only=False):
+    """The native route of MCSamples.get2DDensities: ``pa`` is the (P, 2) int array of column pairs.
+    ``bandwidths`` (P x 3: hx, hy, corr in parameter units) replaces getAutoBandwidth2D, ``pair_neff`` (P) the effective
+    sample numbers it would use (use_effective_samples_2D); ``bandwidths_only`` returns the call's per-pair table
+    (``meta``, include/gdhip.h) and the grid sizes once the bandwidths are known, without convolving anything."""
     from . import mcsamples as M
     from ._lib import GdhipError
 
@@ -239,6 +245,14 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
             ncontours = min(num_plot_contours, ncontours)
         contours = np.ascontiguousarray(mc.contours[:ncontours], dtype=np.float64)
     settings = settings_of(mc, base_F, bco, mbc, smooth_scale_2D, not get_density, contours)
+    keep = []  # (arrays the settings point to)
+    if smooth_scale_2D < 0 and bandwidths is not None:
+        keep.append(np.ascontiguousarray(np.array(list(bandwidths), dtype=np.float64).reshape(P, 3)))
+        settings.bandwidths = keep[-1].ctypes.data_as(C.POINTER(C.c_double))
+    if smooth_scale_2D < 0 and pair_neff is not None:
+        keep.append(np.ascontiguousarray(pair_neff, dtype=np.float64).reshape(P))
+        settings.pair_neff = keep[-1].ctypes.data_as(C.POINTER(C.c_double))
+    settings.bandwidths_only = int(bool(bandwidths_only))
     corr = np.ascontiguousarray(mc.getCorrelationMatrix(), dtype=np.float64)
     cov = np.ascontiguousarray(mc.getCov(), dtype=np.float64)
     # the autocovariance probe prepareParams may have started beside its quantile select
@@ -263,7 +277,7 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
     # (size classes of an eighth of a power of two: calls of similar size recycle one another's page-locked blocks -- a fresh
     # gigabyte of page-locked memory costs ~0.2 s)
     gran = 1 << max(int(total).bit_length() - 4, 13)
-    grids = ctx.pinned_array(((max(total, 1) + gran - 1) // gran * gran,), np.float64)
+    grids = ctx.pinned_array(((max(0 if bandwidths_only else total, 1) + gran - 1) // gran * gran,), np.float64)
     status = ctx.pinned_array((max(P, 1),), np.int32)
     meta = np.empty((max(P, 1), META))
     levels = level_status = None
@@ -346,6 +360,8 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
     for k in np.nonzero(warn & 2)[0].tolist():
         logging.warning("fine_bins_2D not large enough for optimal density: %s, %s", names[pairs32[k, 0]].name,
                         names[pairs32[k, 1]].name)
+    if bandwidths_only:
+        return meta[:P], F_v
     lazy = get_density
     ctxs = [ctx] + ([twin] if twin is not None else [])
     completion = PendingBatch(ctxs, list(tokens)[:len(ctxs)], status, meta[:P, 30].astype(np.int64))

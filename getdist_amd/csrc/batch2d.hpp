@@ -304,10 +304,11 @@ static inline int make_plan(const gd_batch2d_settings& s, const gd_param2d* par,
 }
 
 // N_eff per pair (min of the two parameters', mcsamples.py:1329-1331) and the fallback time of branch C (:1396-1397)
-static inline void fill_plan(const gd_param2d* par, const PairScalars& ps, Plan& pl) {
+static inline void fill_plan(const gd_param2d* par, const PairScalars& ps, Plan& pl, const double* pair_neff = nullptr) {
     const int P = (int)ps.jx.size();
     for (int k = 0; k < P; ++k) {
-        pl.neff[k] = np_minimum(par[ps.jx[k]].neff, par[ps.jy[k]].neff);
+        // (pair_neff: the caller's own estimate per pair -- use_effective_samples_2D, mcsamples.py:1322-1328)
+        pl.neff[k] = pair_neff ? pair_neff[k] : np_minimum(par[ps.jx[k]].neff, par[ps.jy[k]].neff);
         if (pl.branch[k] == 2) pl.fallback_t[k] = py_pow(pl.ratio[k] / py_pow(pl.neff[k], 1.0 / 6), 2.0);
     }
 }
@@ -747,7 +748,8 @@ struct Call {
     }
     int neff_complete(bool* exchanged) {
         const int rc = neff_exchange(exchanged);
-        return rc ? rc : neff_batch(used, false);
+        if (rc || s.pair_neff) return rc;  // (per-pair values from the caller: no parameter's own N_eff is needed)
+        return neff_batch(used, false);
     }
 
     int index_column16(void* ctx, int j, int F, void** out) {
@@ -1540,9 +1542,12 @@ struct Call {
             for (int k = 0; k < 2 * P; ++k)
                 if (!seen[pairs[k]]) seen[pairs[k]] = 1, used.push_back(pairs[k]);
         }
-        const bool auto_bw = ss < 0;
+        // settings->bandwidths: the caller's (hx, hy, corr) per pair instead of getAutoBandwidth2D (tests inject the
+        // oracle's triples); settings->pair_neff: the caller's effective sample number per pair (use_effective_samples_2D)
+        const bool injected = ss < 0 && s.bandwidths != nullptr;
+        const bool auto_bw = ss < 0 && !injected;
         bool need_neff = false;
-        if (auto_bw)
+        if (auto_bw && !s.pair_neff)
             for (int j : used) need_neff = need_neff || isnan(par[j].neff);
         // Large calls keep three streams busy from the start: the N_eff kernels (fp64 exp-bound) on the main context, the
         // byte-index binning (LDS atomics) on the second, the sheared min/max + re-binning (HBM-bound) on a third the
@@ -1578,7 +1583,7 @@ struct Call {
         }
         int64_t need = 0;
         for (int k = 0; k < P; ++k) need += (int64_t)ps.F[k] * ps.F[k];
-        if (need > grids_doubles) {
+        if (need > grids_doubles && !s.bandwidths_only) {
             if (neff_f.valid()) neff_f.get();
             return fail(GD_ERR_BADARG, "grids_pinned is too small");
         }
@@ -1614,7 +1619,7 @@ struct Call {
                 rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
                 bins_first_rows = 0;
                 bins_first_done.store(0);
-                const bool will_stage = aux != nullptr && !s.want_levels && P >= s_two_min() && P > s_two_split();
+                const bool will_stage = aux != nullptr && !s.want_levels && P >= s_two_min() && P > s_two_split() && !s.bandwidths_only;
                 if (!rc && shear_deferred && will_stage && base_F == 256 && main_class() == 256 && !getenv("GDHIP_BATCH_ONE_BINNING")) {
                     std::vector<int>& mem = classes[256];
                     std::stable_partition(mem.begin(), mem.end(), [&](int k) { return plan.branch[k] == 2; });
@@ -1656,7 +1661,7 @@ struct Call {
                 int e = neff_f.valid() ? neff_f.get() : 0;
                 if (!rc) rc = e;
                 if (!rc) rc = neff_complete(&exchanged);  // (multi-rank: the other ranks' values, from this thread)
-                if (!rc) fill_plan(par, ps, plan);
+                if (!rc) fill_plan(par, ps, plan, s.pair_neff);
                 if (shear_f.valid()) {
                     if (shear_deferred) {
                         shear_future = std::move(shear_f), shear_joined = false;  // joined by the first launch that needs it
@@ -1675,15 +1680,15 @@ struct Call {
                 }
                 if (rc) (void)join_shear(true);
             } else {
-                rc = neff_batch(used, true);
+                rc = s.pair_neff ? 0 : neff_batch(used, true);
                 if (!rc) rc = neff_complete(&exchanged);
                 if (!rc) rc = binning(h);
                 if (!rc) rc = make_plan(s, par, n, cov, ps, rngx, rngy, 0.2, plan, err);
-                if (!rc) fill_plan(par, ps, plan);
+                if (!rc) fill_plan(par, ps, plan, s.pair_neff);
             }
         } else {
             rc = neff_exchange(&exchanged);  // the collective is unconditional: once per call on every rank
-            if (!rc) rc = binning(h);
+            if (!rc && !s.bandwidths_only) rc = binning(h);
         }
         mark("binning / N_eff / plan joined");
         if (rc) return cleanup(rc);
@@ -1717,7 +1722,7 @@ struct Call {
         std::vector<int> all_k(P);
         for (int k = 0; k < P; ++k) all_k[k] = k;
         if (auto_bw) {
-            const bool staged = aux != nullptr && conv_ctxs.size() > 1 && P > s_two_split();
+            const bool staged = aux != nullptr && conv_ctxs.size() > 1 && P > s_two_split() && !s.bandwidths_only;
             if (staged) {
                 // every part's convolution is enqueued (by the thread that finishes the parts) as soon as its bandwidths are
                 // final: the first parts on the second stream, beside the optimiser's stage A of the later parts on the
@@ -1741,7 +1746,7 @@ struct Call {
                 rc = bandwidth_2d(false, nullptr, on_chunk);
                 if (!rc) {
                     set_scales(all_k);
-                    rc = enqueue_all();
+                    if (!s.bandwidths_only) rc = enqueue_all();
                 }
             }
             for (int k = 0; k < P && !rc; ++k) {
@@ -1749,6 +1754,14 @@ struct Call {
                 m[2] = W[(size_t)3 * k], m[3] = W[(size_t)3 * k + 1], m[4] = W[(size_t)3 * k + 2];
                 m[5] = plan.branch[k], m[31] = plan.neff[k];
             }
+        } else if (injected) {
+            for (int k = 0; k < P; ++k) {
+                for (int q = 0; q < 3; ++q) W[(size_t)3 * k + q] = s.bandwidths[(size_t)3 * k + q];
+                double* m = M(k);
+                m[2] = W[(size_t)3 * k], m[3] = W[(size_t)3 * k + 1], m[4] = W[(size_t)3 * k + 2];
+            }
+            set_scales(all_k);
+            if (!s.bandwidths_only) rc = enqueue_all();
         } else {
             for (int k = 0; k < P; ++k) {
                 if (ss < 1.0) {
@@ -1760,7 +1773,7 @@ struct Call {
                 cc[k] = ps.corr[k];
                 finish_scale(k);
             }
-            rc = enqueue_all();
+            if (!s.bandwidths_only) rc = enqueue_all();
         }
         if (rc) return cleanup(rc);
         for (int k = 0; k < P; ++k) {

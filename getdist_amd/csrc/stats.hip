@@ -2410,7 +2410,9 @@ int gd_kde_lag_sums_batch(gd_ctx* ctx, const int32_t* cols, int32_t ncols, const
     for (int i = 0; i < ncols; ++i) GD_REQUIRE(cols[i] >= 0 && cols[i] < ctx->n + GD_EXTRA_COLS, "column out of range");
     for (int i = 0; i < nlags; ++i) GD_REQUIRE(lags[i] > 0 && lags[i] < ctx->N, "lag out of range");
     const bool multi = nlags <= KDE_LAG_MAX && getenv("GDHIP_KDE_LAG_SINGLE") == nullptr;
-    int nblk = multi ? (8 * ctx->cu_count + ncols - 1) / ncols : (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
+    int per_cu = 8;  // blocks of 256 threads per CU (GDHIP_KDE_LAG_BLOCKS_PER_CU: tuning knob)
+    if (const char* e = getenv("GDHIP_KDE_LAG_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    int nblk = multi ? (per_cu * ctx->cu_count + ncols - 1) / ncols : (8 * ctx->cu_count + ncols * nlags - 1) / (ncols * nlags);
     if (nblk < 8) nblk = 8;
     if (nblk > 2 * ctx->cu_count) nblk = 2 * ctx->cu_count;
     int64_t off = 0;

@@ -2810,22 +2810,35 @@ class MCSamples:
         pairs = pa.astype(np.int64, copy=False) if pa is not None else [(self._col(a), self._col(b)) for a, b in pairs]
         lanes = int(os.environ.get("GETDIST_AMD_LANES", "1"))
         if (hasattr(self.ctx, "density2d_batch") and os.environ.get("GETDIST_AMD_NATIVE_BATCH", "1") == "1" and lanes < 2
-                and self._lane == 0 and not self._timing and not meanlikes and _bandwidths is None and mask_function is None
-                and not self.use_effective_samples_2D):
-            # ONE native call: every decision between the kernels is taken inside the library (csrc/batch2d.hpp); the
-            # Python-planned pipeline below remains for the optional branches (mean likelihoods, mask callbacks, injected
-            # bandwidths, per-phase timing, 2D effective sample numbers)
+                and self._lane == 0 and not self._timing):
+            # ONE native call: every decision between the kernels is taken inside the library (csrc/batch2d.hpp), for the
+            # optional branches too -- injected bandwidths and the 2D effective sample numbers are inputs of the call, the
+            # mean-likelihood grids are a pass of their own over its per-pair table, and a mask callback gets the call's
+            # bandwidths (bandwidths_only) and then the explicit-mask entry point pair by pair.  (The Python-planned
+            # pipeline below serves contexts without the native entry -- the numpy double of the CPU tests -- and the
+            # per-phase timing mode.)
             from . import batch2d
 
             base_F = kwargs.get("fine_bins_2D", self.fine_bins_2D)
             bco = kwargs.get("boundary_correction_order", self.boundary_correction_order)
             mbc = kwargs.get("mult_bias_correction_order", self.mult_bias_correction_order)
+            ss = float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D))
             if abs(self.max_corr_2D) > 1:
                 raise SettingError("max_corr_2D cannot be >=1")
             if bco > 1:
                 raise SettingError("unknown boundary_correction_order (expected 0 or 1)")
-            return batch2d.run(self, np.asarray(pairs, dtype=np.int64).reshape(-1, 2), base_F, bco, mbc,
-                               float(kwargs.get("smooth_scale_2D", self.smooth_scale_2D)), num_plot_contours, get_density)
+            pa64 = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+            pair_neff = None
+            if self.use_effective_samples_2D and ss < 0 and _bandwidths is None and len(pa64):
+                pair_neff = self._pair_neff_2d(pa64)
+            if mask_function is not None and len(pa64):
+                return self._densities_with_mask_callback(pa64, base_F, bco, mbc, ss, num_plot_contours, get_density, _bandwidths,
+                                                          pair_neff, meanlikes, mask_function)
+            out = batch2d.run(self, pa64, base_F, bco, mbc, ss, num_plot_contours, get_density, bandwidths=_bandwidths,
+                              pair_neff=pair_neff)
+            if meanlikes and len(pa64):
+                self._attach_mean_likelihoods(out, pa64, mbc)
+            return out
         if (lanes < 2 or self._lane != 0 or len(pairs) < 64 or self._timing or meanlikes or _bandwidths is not None
                 or self.use_effective_samples_2D or mask_function is not None):
             with _FastThreadSwitch(len(pairs) >= 64):
@@ -2868,6 +2881,149 @@ class MCSamples:
             out[q] = d
         for q, d in zip(theirs, second):
             out[q] = d
+        return out
+
+    # ---- the optional branches of the native route -------------------------------------------------------------------
+    def _pair_neff_2d(self, pa):
+        """use_effective_samples_2D (mcsamples.py:1322-1328): the 2D estimate per pair, the smaller 1D one for a pair that is
+        correlated to 0.999."""
+        used = list(dict.fromkeys(pa.ravel().tolist()))
+        self._init_params(used)
+        names = self.paramNames.names
+        corr = np.asarray(self.getCorrelationMatrix())[pa[:, 1], pa[:, 0]]
+        return np.array([self.getEffectiveSamplesGaussianKDE_2d(a, b) if abs(c) < 0.999
+                         else min(self._get1DNeff(names[a], a), self._get1DNeff(names[b], b))
+                         for (a, b), c in zip(pa.tolist(), corr.tolist())], dtype=np.float64)
+
+    def _pair_flags(self, pa, with_prior_mask=False):
+        """Flag bits per pair (mcsamples.py:1688-1703, 1794): 0/1 = x bot/top, 2/3 = y bot/top, 4/5 = x/y periodic, 6 = has_prior."""
+        names = self.paramNames.names
+        lim_bits, per_bit, has_lim = np.zeros(self.n, np.int64), np.zeros(self.n, np.int64), np.zeros(self.n, bool)
+        for j in np.unique(pa).tolist():
+            p_ = names[j]
+            lim_bits[j] = 0 if p_.periodic else (1 if p_.has_limits_bot else 0) | (2 if p_.has_limits_top else 0)
+            per_bit[j] = 1 if p_.periodic else 0
+            has_lim[j] = bool(p_.has_limits)
+        jx, jy = pa[:, 0], pa[:, 1]
+        has_prior = has_lim[jx] | has_lim[jy] | bool(with_prior_mask)
+        return lim_bits[jx] | (per_bit[jx] << 4) | (lim_bits[jy] << 2) | (per_bit[jy] << 5) | (has_prior.astype(np.int64) << 6)
+
+    def _class_histograms(self, pa, members, F, meta, likes=False):
+        """Histograms (and, with ``likes``, the like-weighted ones: mcsamples.py:1829-1831) of the pairs ``members`` of one
+        grid-size class from the bin edges the native call used (meta[23..26])."""
+        ctx = self.ctx
+        ix = [self._index_column(int(pa[k, 0]), F, meta[k, 23], (meta[k, 24] - meta[k, 23]) / (F - 1)) for k in members]
+        iy = [self._index_column(int(pa[k, 1]), F, meta[k, 25], (meta[k, 26] - meta[k, 25]) / (F - 1)) for k in members]
+        d_hist = ctx.hist2d_prebinned(ix, iy, F)
+        d_like = self._like_histograms(0, lambda: ctx.hist2d_prebinned(ix, iy, F)) if likes else None
+        return d_hist, d_like
+
+    def _attach_mean_likelihoods(self, out, pa, mbc):
+        """``likes`` of every result of a native call (mcsamples.py:1829-1831, 1886-1903): the like-weighted histogram of
+        each pair convolved with the pair's own window (the call's per-pair table holds its scales), grid class by grid
+        class."""
+        ctx = self.ctx
+        meta, F_v = out._meta, np.asarray(out._F)
+        flags = self._pair_flags(pa)
+        for F, periodic_bits in sorted(set(zip(F_v.tolist(), (flags & 48).tolist()))):  # (a launch holds one kind of axes)
+            members = np.nonzero((F_v == F) & ((flags & 48) == periodic_bits))[0]
+            step = max(1, min(int(24e9 // (F * F * 8 * 30)), 320))
+            for s0 in range(0, len(members), step):
+                mem = members[s0:s0 + step]
+                d_hist, d_like = self._class_histograms(pa, mem.tolist(), F, meta, likes=True)
+                d_L, lstatus = ctx.likes2d(d_hist, d_like, len(mem), F, meta[mem, 18], meta[mem, 19], meta[mem, 20],
+                                           meta[mem, 21].astype(np.int64), flags[mem], mbc)
+                d_hist.free()
+                d_like.free()
+                if np.any(lstatus != 0):
+                    d_L.free()
+                    raise DensitiesError("no likelihood weight in any bin")
+                L = d_L.to_host((len(mem), F, F))
+                d_L.free()
+                for row, k in enumerate(mem.tolist()):
+                    out[k].likes = L[row]
+
+    def _densities_with_mask_callback(self, pa, base_F, bco, mbc, ss, num_plot_contours, get_density, bandwidths, pair_neff,
+                                      meanlikes, mask_function):
+        """get2DDensities with ``mask_function`` (mcsamples.py:1767-1770, 1905-1919, 1973-1979): the callback edits each pair's
+        prior mask on the padded frame, whose size follows from the pair's window -- so the native call runs up to the
+        bandwidths (bandwidths_only) and every pair then goes through the explicit-mask entry point."""
+        from . import batch2d
+
+        ctx = self.ctx
+        names = self.paramNames.names
+        meta, F_v = batch2d.run(self, pa, base_F, bco, mbc, ss, None, True, bandwidths=bandwidths, pair_neff=pair_neff,
+                                bandwidths_only=True)
+        F_v = np.asarray(F_v)
+        flags = self._pair_flags(pa, with_prior_mask=True)
+        ncontours = len(self.contours)
+        if num_plot_contours:
+            ncontours = min(num_plot_contours, ncontours)
+        out = [None] * len(pa)
+        for F in np.unique(F_v).tolist():
+            members = np.nonzero(F_v == F)[0].tolist()
+            d_hist, d_like = self._class_histograms(pa, members, F, meta, likes=meanlikes)
+            try:
+                for pos, k in enumerate(members):
+                    j, j2 = int(pa[k, 0]), int(pa[k, 1])
+                    parx, pary = names[j], names[j2]
+                    w_ = int(meta[k, 21])
+                    fwx, fwy = (meta[k, 24] - meta[k, 23]) / (F - 1), (meta[k, 26] - meta[k, 25]) / (F - 1)
+                    prior_mask = np.ones((F + 2 * w_, F + 2 * w_))
+                    mask_function(meta[k, 23] - w_ * fwx, meta[k, 25] - w_ * fwy, fwx, fwy, prior_mask)
+                    bool_mask = prior_mask[w_:-w_, w_:-w_] < 1e-8
+                    mask_bc = mask_mbc = None
+                    if bco >= 0:
+                        _set_edge_mask_2d(parx, pary, prior_mask, w_)
+                        mask_bc = prior_mask.copy()
+                    if mbc:
+                        _set_all_edge_mask_2d(prior_mask, w_, parx.periodic, pary.periodic)
+                        mask_mbc = prior_mask
+                    d_P, status = ctx.density2d_masked(d_hist, pos, F, float(meta[k, 18]), float(meta[k, 19]), float(meta[k, 20]),
+                                                       w_, int(flags[k]), bco, mbc, mask_bc, mask_mbc, bool_mask)
+                    contours = None
+                    if not get_density:
+                        lev, lev_state = ctx.contour_levels(d_P, 1, F, self.contours[:ncontours])
+                        state = int(np.asarray(lev_state)[0])
+                        if state == -4:
+                            raise DensitiesError("Contour level outside plotted ranges")
+                        contours = lev[0].copy() if state == 0 else None
+                    L = None
+                    if meanlikes:
+                        # the mean-likelihood grid does not see the mask (mcsamples.py:1886-1903 precede it)
+                        d_one, d_lone = ctx.alloc(F * F * 8), ctx.alloc(F * F * 8)
+                        self._gather_device(d_hist, d_one, [pos], F * F * 8)
+                        self._gather_device(d_like, d_lone, [pos], F * F * 8)
+                        d_L, lstatus = ctx.likes2d(d_one, d_lone, 1, F, meta[[k], 18], meta[[k], 19], meta[[k], 20],
+                                                   meta[[k], 21].astype(np.int64), flags[[k]], mbc)
+                        d_one.free()
+                        d_lone.free()
+                        if np.any(lstatus != 0):
+                            raise DensitiesError("no likelihood weight in any bin")
+                        L = d_L.to_host((1, F, F))[0]
+                        d_L.free()
+                    P = d_P.to_host((1, F, F))[0]
+                    d_P.free()
+                    if np.any(np.asarray(status) != 0):
+                        raise DensitiesError("no samples in bin")
+                    ax = np.arange(F, dtype=np.float64) * fwx + meta[k, 23]
+                    ay = np.arange(F, dtype=np.float64) * fwy + meta[k, 25]
+                    ax[-1], ay[-1] = meta[k, 24], meta[k, 26]
+                    auto = ss < 0
+                    dens = Density2D._from_fields(dict(
+                        x=ax, y=ay, axes=[ay, ax], spacing=(ax[1] - ax[0]) * (ay[1] - ay[0]),
+                        view_ranges=[(parx.range_min, parx.range_max), (pary.range_min, pary.range_max)], mask=bool_mask, likes=L,
+                        contours=contours, spl=None, _P=P, _wait=None,
+                        bandwidth=tuple(meta[k, 2:5].tolist()) if auto else None,
+                        bandwidth_branch="ABC"[int(meta[k, 5])] if auto and meta[k, 5] >= 0 else None,
+                        kopt=None if np.isnan(meta[k, 13]) else meta[k, 6:18].copy()))
+                    if contours is None and not get_density:
+                        dens.contours = dens.getContourLevels(self.contours[:ncontours])
+                    out[k] = dens
+            finally:
+                d_hist.free()
+                if d_like is not None:
+                    d_like.free()
         return out
 
     def _get2DDensities_lane(self, pairs, num_plot_contours=None, get_density=True, _bandwidths=None, meanlikes=False,

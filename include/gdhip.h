@@ -508,7 +508,13 @@ typedef struct gd_batch2d_settings {
     double max_batch_bytes;             /* (24e9) device scratch a batch may take */
     int32_t comm_exchange;              /* 1: exchange the N_eff values over the context's communicator (gd_comm_init): one
                                            sum all-reduce of n doubles, every rank contributing the parameters it owns */
-    int32_t reserved;
+    int32_t bandwidths_only;            /* 1: stop when the bandwidths are known -- meta[2..5], [18..22], [31] are filled, nothing is
+                                           convolved or copied (a caller that edits each pair's prior mask, mcsamples.py:1767-1770,
+                                           needs the window half-widths first and then convolves through gd_density2d_masked) */
+    /* optional per-pair inputs (NULL = none); with smooth_scale_2D < 0 only */
+    const double* pair_neff;            /* P effective sample numbers instead of min(N_eff x, N_eff y): the caller's 2D estimate
+                                           under use_effective_samples_2D (mcsamples.py:1322-1328, chains.py:576-635) */
+    const double* bandwidths;           /* P x 3 (hx, hy, corr) in parameter units instead of getAutoBandwidth2D */
 } gd_batch2d_settings;
 
 typedef int (*gd_neff_exchange_fn)(void* user, double* neff_n, int32_t n);

@@ -340,4 +340,90 @@ def test_grid_sizes_entry(zoo):
     s = batch2d.settings_of(mc, mc.fine_bins_2D, 1, 1, -1.0, False, None)
     F = mc.ctx.batch2d_grid_sizes(s, mc.n, np.ascontiguousarray(mc.getCorrelationMatrix()), np.asarray(fx["pairs"], dtype=np.int32))
     assert F.tolist() == [d.P.shape[0] for d in dens]
-    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 120
+    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 136
+
+
+def likes_same(native, plain):
+    for k, (a, b) in enumerate(zip(native, plain)):
+        assert (a.likes is None) == (b.likes is None), k
+        assert a.likes is None or np.array_equal(a.likes, b.likes), (k, float(np.max(np.abs(a.likes - b.likes))))
+        assert (a.mask is None) == (b.mask is None) and (a.mask is None or np.array_equal(a.mask, b.mask)), k
+
+
+def test_native_route_serves_injected_bandwidths(zoo):
+    """``_bandwidths`` (the parity tests' closed loop: the oracle's triples) is an input of the native call."""
+    fx = zoo["block50"]
+    pairs = triangle(7)
+    rng = np.random.default_rng(3)
+    plain_mc, mc = make(fx, nb.PlainContext), make(fx, nb.HarnessContext)
+    auto = plain_mc.get2DDensities(pairs)
+    triples = [(d.bandwidth[0] * rng.uniform(0.8, 1.3), d.bandwidth[1] * rng.uniform(0.8, 1.3), 0.9 * d.bandwidth[2]) for d in auto]
+    plain = plain_mc.get2DDensities(pairs, _bandwidths=triples)
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs, _bandwidths=triples)
+    same(native, plain)
+    assert not any(c[0].startswith("kopt2d") for c in nb.CALLS), "no optimiser launch with injected bandwidths"
+    assert [d.bandwidth for d in native] == [tuple(t) for t in triples]
+
+
+def test_native_route_serves_2d_effective_samples():
+    # a correlated chain (AR(1) with different memory per parameter): the 2D estimate differs from the smaller 1D one
+    rng = np.random.default_rng(8)
+    N, rho = 20000, np.array([0.6, 0.3, 0.0, 0.8])
+    e = rng.standard_normal((N, 4))
+    x = np.zeros((N, 4))
+    for t in range(1, N):
+        x[t] = rho * x[t - 1] + e[t]
+    x[:, 1] += 0.5 * x[:, 0]
+    fx = dict(samples=x, weights=None, names=["a", "b", "c", "d"], ranges={})
+    pairs = triangle(4)
+    plain_mc, mc = make(fx, nb.PlainContext), make(fx, nb.HarnessContext)
+    plain_mc.use_effective_samples_2D = mc.use_effective_samples_2D = True
+    plain = plain_mc.get2DDensities(pairs)
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs)
+    same(native, plain)
+    assert any(c[0] == "density2d_enqueue" for c in nb.CALLS)
+    ordinary = make(fx, nb.HarnessContext).get2DDensities(pairs)
+    assert any(a.bandwidth != b.bandwidth for a, b in zip(native, ordinary)), "the 2D estimate must have been used"
+
+
+def test_native_route_serves_mean_likelihoods(zoo):
+    fx = zoo["block10_weighted"]
+    pairs = triangle(5)
+    from oracle.fixtures import loglikes_for
+
+    ll = loglikes_for(fx["samples"])
+    plain = make(fx, nb.PlainContext, loglikes=ll).get2DDensities(pairs, meanlikes=True)
+    native = make(fx, nb.HarnessContext, loglikes=ll).get2DDensities(pairs, meanlikes=True)
+    same(native, plain)
+    likes_same(native, plain)
+    assert all(d.likes is not None for d in native)
+
+
+@pytest.mark.parametrize("meanlikes", [False, True])
+def test_native_route_serves_a_mask_callback(zoo, meanlikes):
+    fx = zoo["c1_bounded"]
+    names = fx["names"]
+    pairs = [(names[0], names[1]), (names[2], names[3]), (names[3], names[1])]
+
+    def mask_function(minx, miny, stepx, stepy, mask):
+        ny, nx = mask.shape
+        x = minx + stepx * np.arange(nx)
+        y = miny + stepy * np.arange(ny)
+        mask[(y[:, None] - y[ny // 2]) > 1.5 * (x[None, :] - x[nx // 2]) + 10 * stepy] = 0
+
+    from oracle.fixtures import loglikes_for
+
+    ll = loglikes_for(fx["samples"])
+    plain = make(fx, nb.PlainContext, loglikes=ll).get2DDensities(pairs, mask_function=mask_function, meanlikes=meanlikes)
+    nb.CALLS.clear()
+    native = make(fx, nb.HarnessContext, loglikes=ll).get2DDensities(pairs, mask_function=mask_function, meanlikes=meanlikes)
+    same(native, plain)
+    likes_same(native, plain)
+    assert all(d.mask is not None and d.mask.any() for d in native)
+    assert not any(c[0] == "density2d_enqueue" for c in nb.CALLS), "bandwidths_only: the call itself convolves nothing"
+    levels_plain = make(fx, nb.PlainContext).get2DDensities(pairs, mask_function=mask_function, get_density=False, num_plot_contours=2)
+    levels_native = make(fx, nb.HarnessContext).get2DDensities(pairs, mask_function=mask_function, get_density=False, num_plot_contours=2)
+    for a, b in zip(levels_native, levels_plain):
+        assert np.array_equal(a.contours, b.contours)
