@@ -13,6 +13,14 @@ from scipy import fftpack
 
 from oracle import kde_oracle as ko
 
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import planned_route  # noqa: E402
+
+planned_route.install()  # this double has no gd_density2d_batch: its 2D batches take the Python-planned comparison route
+
 
 class FakeBuf:
     def __init__(self, arr=None, nbytes=0):

@@ -344,37 +344,29 @@ def test_real_plotter_draws_from_the_prefilled_caches():
     assert out.returncode == 0 and "triangle plot drawn by getdist.plots" in out.stdout, out.stdout[-3000:]
 
 
-def test_two_lanes_equal_one_lane(zoo, monkeypatch):
-    """A batch of >= 64 pairs is dealt to two lanes (two contexts, second one driven from a helper thread): same grids,
-    same order, same bandwidths as the single-lane run; settings changed afterwards reach the second lane too.  The
-    default (one lane, binning and alternate convolution batches on the second context) equals it as well."""
+def test_planned_route_with_and_without_the_second_context(zoo, monkeypatch):
+    """The comparison route (tests/planned_route.py) runs the binning and alternate convolution batches on a second context
+    (own stream over the same resident samples) for batches of >= 64 pairs: same grids, same order, same bandwidths as
+    everything on one context; settings changed afterwards reach the second context too, a re-upload drops it."""
     fx = zoo["block50"]
     pairs = [(i, j) for i in range(13) for j in range(i + 1, 13)] + [(20, 21), (38, 39)]
     assert len(pairs) >= 64
-    monkeypatch.setenv("GETDIST_AMD_LANES", "2")
-    mc = make(fx)
-    two = mc.get2DDensities(pairs)
-    assert mc._twin is not None and mc._nlanes == 2
-    monkeypatch.setenv("GETDIST_AMD_LANES", "1")
     monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "0")
     ref = make(fx)
     ref.CONV_TWO_STREAMS_PAIRS = (1 << 30, 0)  # and every batch convolved on this context's stream
     one = ref.get2DDensities(pairs)
     assert ref._twin is None
-    monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "1")  # default: only the binning runs on the second context
-    ovl = make(fx)
-    for a, b in zip(ovl.get2DDensities(pairs), one):
-        assert np.array_equal(a.P, b.P) and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
-    assert ovl._twin is not None and ovl._nlanes == 1
-    for a, b in zip(two, one):
+    monkeypatch.setenv("GETDIST_AMD_OVERLAP_NEFF", "1")  # default: the binning runs on the second context
+    mc = make(fx)
+    for a, b in zip(mc.get2DDensities(pairs), one):
         assert np.array_equal(a.P, b.P) and np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
         assert a.bandwidth_branch == b.bandwidth_branch and np.allclose(a.bandwidth, b.bandwidth, rtol=1e-12)
-    monkeypatch.setenv("GETDIST_AMD_LANES", "2")
+    assert mc._twin is not None and mc._nlanes == 1
     mc.updateSettings({"fine_bins_2D": 128})
     mc.updateBaseStatistics()
     again = mc.get2DDensities(pairs)
     assert all(d.P.shape[0] in (128, 192, 384, 576, 768, 960) for d in again) and again[0].P.shape == (128, 128)
-    mc.setSamples(np.asarray(fx["samples"]) * 1.0)  # re-upload drops the second lane
+    mc.setSamples(np.asarray(fx["samples"]) * 1.0)  # re-upload drops the second context
     assert mc._twin is None
 
 
