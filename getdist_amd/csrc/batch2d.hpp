@@ -701,7 +701,9 @@ struct Call {
         if (hold_neff_for_binning) {
             const auto t0 = std::chrono::steady_clock::now();
             while (!bin_launching.load() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) std::this_thread::yield();
-            if (bin_launching.load()) std::this_thread::sleep_for(std::chrono::microseconds(120));  // (its launches go out)
+            int hold_us = 120;  // (its launches go out)  GDHIP_BATCH_NEFF_HOLD_US: tuning knob
+            if (const char* e = getenv("GDHIP_BATCH_NEFF_HOLD_US")) hold_us = atoi(e);
+            if (bin_launching.load()) std::this_thread::sleep_for(std::chrono::microseconds(hold_us));
             mark("neff: binning chain enqueued");
         }
         GDB_DEV(h, ops.kde_lag_sums_batch(h, todo.data(), m, inv4s2.data(), lags.data(), L, sums.data()));
