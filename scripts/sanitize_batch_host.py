@@ -14,6 +14,9 @@ stayed silent (its reports go to stderr and change the exit code).
 import os
 import sys
 
+os.environ.setdefault("GDHIP_BATCH_SHEAR_DEFERRED_MIN", "16")  # the deferred shear chain and the two-launch main binning (round 6)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # (OpenBLAS's own pool is not instrumented: its hand-offs read as races)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
