@@ -63,8 +63,8 @@ PY
             cp "$(find "$O/prof_emu8" -name '*kernel_stats.csv' | head -1)" "$O/emu8_kernel_stats.csv"; rm -rf "$O/prof_emu8"
             head -120 "$O/emu8_stream_timeline.txt" | cut -c1-120; grep -v WARNING "$O/emu8.err" | tail -60 | cut -c1-120 ;;
         f64roof) (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_atomic_f64_roof "$GRAFT_REPO_ROOT/scripts/micro/lds_atomic_f64_roof.hip" && ./lds_atomic_f64_roof 400) > "$O/lds_atomic_f64_roof.txt" 2>&1; cat "$O/lds_atomic_f64_roof.txt" ;;
-        pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match wsort,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/weighted_binning.py" 2>&1 | tail -8
-              grep -E "SQ_|conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
+        pmcw) timeout 900 python scripts/pmc_kernels.py "$O/pmc_weighted.json" --match k_wpart,k_hist2d -- python "$GRAFT_REPO_ROOT/scripts/weighted_binning.py" 2>&1 | tail -8
+              grep -E "conflict|valu" "$O/pmc_weighted.json" | head -20 ;;
         gloo2) GETDIST_AMD_LIVE_PMC=0 timeout 600 python bench.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_gloo2_shared_gpu.json" 2> "$O/bench_gloo2.err"; tail -c 900 "$O/bench_gloo2_shared_gpu.json"; tail -3 "$O/bench_gloo2.err" | cut -c1-300 ;;
         pmcprep)  # counter traffic of the O(N) preparation kernels of a C3 step (review item: <= 18 GB per step)
               timeout 1500 python scripts/pmc_kernels.py "$O/pmc_prep.json" --match k_col_,k_cov_,k_qlin,k_qsel,k_autocov,k_kde_lag,k_prebin,k_bucket,k_sum_partials -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -14 ;;

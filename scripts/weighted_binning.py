@@ -23,3 +23,12 @@ for _ in range(reps):
     mc.ctx.timer_start()
     mc.ctx.hist2d_prebinned([idx[a] for a, b in allp], [idx[b] for a, b in allp], F, out=out)
     print("weighted 2D binning of %d pairs: %.2f ms" % (len(allp), mc.ctx.timer_stop_ms()))
+
+# round 6: the same histograms over BYTE indices, the samples partitioned by 16-row stripe once per y column (k_wpart_* +
+# k_hist2d_wsorted, csrc/binning.hip): the route gd_density2d_batch takes for real weights
+b8 = [mc.ctx.alloc(N + 64) for _ in range(n)]
+mc.ctx.prebin8_batch(list(range(n)), [x[1] for x in e2], [x[0] for x in e2], 256, b8)
+for _ in range(reps):
+    mc.ctx.timer_start()
+    mc.ctx.hist2d_prebinned8([b8[a] for a, b in allp], [b8[b] for a, b in allp], out=out)
+    print("weighted 2D binning of %d pairs, byte indices sorted by stripe: %.2f ms" % (len(allp), mc.ctx.timer_stop_ms()))
