@@ -2176,51 +2176,30 @@ class MCSamples:
             raise SettingError("Unknown boundary_correction_order (expected 0, 1, 2)")
         self._init_params(js)
         pars = [self.paramNames.names[j] for j in js]
-        if (hasattr(self.ctx, "density1d_batch") and os.environ.get("GETDIST_AMD_NATIVE_BATCH", "1") == "1"
-                and getattr(self, "_neff_share", None) is None and len(set(js)) == len(js)):
-            # ONE native call (csrc/batch1d.hpp); the Python-planned sequence below remains for multi-rank N_eff sharing
+        if hasattr(self.ctx, "density1d_batch") and os.environ.get("GETDIST_AMD_NATIVE_BATCH", "1") == "1":
+            # ONE native call (csrc/batch1d.hpp) for every case: in a multi-rank job this rank's share of the N_eff values and
+            # the exchange happen first (the call then finds every value), a parameter listed twice is computed once
             from . import batch1d
 
-            P, hist, meta = batch1d.run(self, js, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist=meanlikes)
+            if getattr(self, "_neff_share", None) is not None and smooth_scale_1D <= 0:
+                self._neff_batch(js)
+            uniq = list(dict.fromkeys(js))
+            P, hist, meta = batch1d.run(self, uniq, fine_bins, num_bins, smooth_scale_1D, bco, mbc, want_hist=meanlikes)
+            if len(uniq) != len(js):
+                at = {j: b for b, j in enumerate(uniq)}
+                rows = [at[j] for j in js]
+                P, meta = P[rows], meta[rows]
+                hist = None if hist is None else hist[rows]
             edges = [((meta[b, 1] - meta[b, 0]) / (fine_bins - 1), meta[b, 0], meta[b, 1]) for b in range(len(js))]
             smooth, winw = meta[:, 3].tolist(), meta[:, 4].astype(np.int64).tolist()
             flags = [(1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0)
                      for par in pars]
             return self._finish_1d(js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs)
-        edges = []
-        for par in pars:
-            if par.range_max - par.range_min <= 0:
-                raise MCSamplesError("Parameter range is <= 0: " + par.name)
-            edges.append(self._bin_edges(par, fine_bins))
-        hist = self.ctx.hist1d(js, [e[1] for e in edges], [e[0] for e in edges], fine_bins)
-        smooth, winw, flags = [], [], []
-        isj_h = isj_status = None
-        if smooth_scale_1D <= 0:
-            self._neff_batch(js)
-            isj_h, isj_status = self.ctx.isj1d(hist, [self._get1DNeff(par, j) for j, par in zip(js, pars)])
-        for b, (j, par) in enumerate(zip(js, pars)):
-            fine_width, binmin, binmax = edges[b]
-            paramrange = par.range_max - par.range_min
-            width = paramrange / (num_bins - 1)
-            if smooth_scale_1D <= 0:
-                N_eff = self._get1DNeff(par, j)
-                bandwidth = self._bandwidth_1d(None if isj_status[b] else isj_h[b], par, N_eff, mbc, bco) * (binmax - binmin)
-                bandwidth = min(bandwidth, paramrange / 4)
-                smooth_1D = bandwidth * abs(smooth_scale_1D) / fine_width
-            elif smooth_scale_1D < 1.0:
-                smooth_1D = smooth_scale_1D * par.err / fine_width
-            else:
-                smooth_1D = smooth_scale_1D * width / fine_width
-            if smooth_1D < 2:
-                logging.warning("fine_bins not large enough to well sample smoothing scale - " + par.name)
-            smooth_1D = min(max(1.0, smooth_1D), fine_bins // 2)
-            smooth.append(smooth_1D)
-            winw.append(min(int(round(2.5 * smooth_1D)), ((fine_bins - 1) if par.periodic else fine_bins) // 2 - 2))
-            flags.append((1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0))
-        P, status = self.ctx.density1d(hist, smooth, winw, flags, bco, mbc)
-        if np.any(status != 0):
-            raise DensitiesError("no samples in bin")
-        return self._finish_1d(js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs)
+        # (no native entry on this context: the Python-planned sequence is tests/planned_route.py, as for the 2D path)
+        route = getattr(MCSamples, "_planned_route_1d", None)
+        if route is None:
+            raise MCSamplesError("get1DDensities needs a device context with gd_density1d_batch (libgdhip)")
+        return route(self, js, pars, fine_bins, num_bins, smooth_scale_1D, bco, mbc, meanlikes, kwargs)
 
     def _finish_1d(self, js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs):
         """Mean-likelihood profiles (mcsamples.py:1556-1561,1672-1682) and the Density1D objects of get1DDensities."""

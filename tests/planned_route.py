@@ -661,6 +661,46 @@ def get2DDensities_planned(self, pairs, num_plot_contours=None, get_density=True
     return out
 
 
+def get1DDensities_planned(self, js, pars, fine_bins, num_bins, smooth_scale_1D, bco, mbc, meanlikes, kwargs):
+    """The Python-planned sequence of get1DDensities (gd_hist1d, gd_isj1d, the scalar tail of getAutoBandwidth1D in
+    Python, gd_density1d): the comparison of the native gd_density1d_batch route (mcsamples.py:1500-1686 of the reference)."""
+    edges = []
+    for par in pars:
+        if par.range_max - par.range_min <= 0:
+            raise MCSamplesError("Parameter range is <= 0: " + par.name)
+        edges.append(self._bin_edges(par, fine_bins))
+    hist = self.ctx.hist1d(js, [e[1] for e in edges], [e[0] for e in edges], fine_bins)
+    smooth, winw, flags = [], [], []
+    isj_h = isj_status = None
+    if smooth_scale_1D <= 0:
+        self._neff_batch(js)
+        isj_h, isj_status = self.ctx.isj1d(hist, [self._get1DNeff(par, j) for j, par in zip(js, pars)])
+    for b, (j, par) in enumerate(zip(js, pars)):
+        fine_width, binmin, binmax = edges[b]
+        paramrange = par.range_max - par.range_min
+        width = paramrange / (num_bins - 1)
+        if smooth_scale_1D <= 0:
+            N_eff = self._get1DNeff(par, j)
+            bandwidth = self._bandwidth_1d(None if isj_status[b] else isj_h[b], par, N_eff, mbc, bco) * (binmax - binmin)
+            bandwidth = min(bandwidth, paramrange / 4)
+            smooth_1D = bandwidth * abs(smooth_scale_1D) / fine_width
+        elif smooth_scale_1D < 1.0:
+            smooth_1D = smooth_scale_1D * par.err / fine_width
+        else:
+            smooth_1D = smooth_scale_1D * width / fine_width
+        if smooth_1D < 2:
+            logging.warning("fine_bins not large enough to well sample smoothing scale - " + par.name)
+        smooth_1D = min(max(1.0, smooth_1D), fine_bins // 2)
+        smooth.append(smooth_1D)
+        winw.append(min(int(round(2.5 * smooth_1D)), ((fine_bins - 1) if par.periodic else fine_bins) // 2 - 2))
+        flags.append((1 if par.has_limits_bot else 0) | (2 if par.has_limits_top else 0) | (4 if par.periodic else 0))
+    P, status = self.ctx.density1d(hist, smooth, winw, flags, bco, mbc)
+    if np.any(status != 0):
+        raise DensitiesError("no samples in bin")
+    return self._finish_1d(js, pars, edges, P, hist, smooth, winw, flags, fine_bins, meanlikes, kwargs)
+
+
 def install():
     _M.MCSamples._planned_route = get2DDensities_planned
+    _M.MCSamples._planned_route_1d = get1DDensities_planned
     _M.MCSamples._helper = _helper
