@@ -558,6 +558,14 @@ struct Call {
         if (align > 1 && F == 256 && part > align) part = std::max<size_t>(align, (part + align / 2 - 1) / align * align);
         return part;
     }
+    // the FIRST part may be smaller than the others (GDHIP_KOPT_FIRST_PART: tuning knob; 0 = like the others)
+    static size_t first_part_size(size_t part) {
+        if (const char* e = getenv("GDHIP_KOPT_FIRST_PART")) {
+            const size_t f = (size_t)std::max(0, atoi(e));
+            if (f > 0 && f < part) return f;
+        }
+        return part;
+    }
     int join_shear(bool release = false) {
         // release: the caller is not going to enqueue a first part the chain could wait for (error paths, a call whose only
         // launch needs the chain).  The staging thread's ordinary join does NOT release: by then the first part is enqueued
@@ -1314,10 +1322,12 @@ struct Call {
                     Launch L;
                     const bool carries = shear_deferred ? (ip + 1 == nparts || pos_C.size() - c0 <= part) : first != 0;
                     L.F = F, L.na = carries ? nA : 0, L.d_hist = class_buffer(F);
-                    size_t take_ = std::min(pos_C.size() - c0, part > (size_t)L.na ? part - (size_t)L.na : (size_t)1);
+                    const size_t part_q = (ip == 0 && nparts > 1) ? first_part_size(part) : part;
+                    size_t take_ = std::min(pos_C.size() - c0, part_q > (size_t)L.na ? part_q - (size_t)L.na : (size_t)1);
                     if (shear_deferred && carries) take_ = pos_C.size() - c0;  // the last part takes what is left
-                    // (measured: a first part of 256 pairs only, the others unchanged -- delivered triangle 27.9-28.0 against
-                    // 27.9-28.6, the stream of triangles 22.1 against 21.5: the result copies saturate PCIe from the first batch on)
+                    // (measured, GDHIP_KOPT_FIRST_PART=256: a first part of 256 pairs, the others unchanged -- with the two-launch
+                    // binning delivered 27.2-27.6 against 27.3-27.7 ms, the stream of triangles 21.0-21.2 against 20.6-20.7: the
+                    // result copies saturate PCIe from the first batch on and the copy engine then waits for the second part)
                     L.pos.assign(pos_C.begin() + c0, pos_C.begin() + c0 + take_);
                     c0 += take_;
                     L.whole = L.na == 0 && L.pos.size() == mem.size();
@@ -1629,7 +1639,7 @@ struct Call {
                     for (int k : mem) nC += plan.branch[k] == 2;
                     for (int k = 0; k < P; ++k) nA += plan.branch[k] == 0;
                     if ((int)nC >= s_kopt_split_min()) {
-                        const size_t part = base_part_size(nC + nA, 256), first = std::min(nC, part);
+                        const size_t part = base_part_size(nC + nA, 256), first = std::min(nC, first_part_size(part));
                         if (nC + nA > part && first < mem.size()) bins_first_rows = (int)first;
                     }
                 }
