@@ -77,6 +77,60 @@ def test_native_entry_weighted_and_small_calls(monkeypatch):
     same(native, plain)
 
 
+def test_native_entry_serves_the_optional_branches(monkeypatch):
+    """Round 6: injected bandwidths, the 2D effective sample numbers, mean likelihoods and a mask callback go through
+    gd_density2d_batch (settings->bandwidths / pair_neff / bandwidths_only, gd_likes2d over the call's per-pair table): same
+    grids, `likes`, masks and contour levels as the Python-planned comparison route, on the device."""
+    from getdist_amd.mcsamples import MCSamples
+
+    recipe = synth.block_recipe(10, 200_000, weighted=False, stream=64)
+    s, w, names, ranges = recipe
+    loglikes = 0.5 * np.sum(np.asarray(s)[:, :4] ** 2, axis=1)
+    pairs = synth.triangle_pairs(10)[:20]
+
+    def build():
+        return MCSamples(samples=s, weights=w, loglikes=loglikes, names=names, ranges=ranges)
+
+    def extras_same(native, plain):
+        for k, (a, b) in enumerate(zip(native, plain)):
+            assert (a.likes is None) == (b.likes is None), k
+            # (the like-weighted histograms are sums of real weights by fp64 LDS atomics: two runs agree to rounding)
+            assert a.likes is None or np.allclose(a.likes, b.likes, rtol=1e-11, atol=1e-13), (k, float(np.max(np.abs(a.likes - b.likes))))
+            assert (a.mask is None) == (b.mask is None) and (a.mask is None or np.array_equal(a.mask, b.mask)), k
+
+    auto = build().get2DDensities(pairs)
+    triples = [(1.1 * d.bandwidth[0], 0.9 * d.bandwidth[1], 0.8 * d.bandwidth[2]) for d in auto]
+    native, plain, _ = both_routes(monkeypatch, build, lambda m: m.get2DDensities(pairs, _bandwidths=triples))
+    same(native, plain)
+    assert [d.bandwidth for d in native] == [tuple(t) for t in triples]
+
+    def with_2d_neff(m):
+        m.use_effective_samples_2D = True
+        return m.get2DDensities(pairs)
+
+    native, plain, _ = both_routes(monkeypatch, build, with_2d_neff)
+    same(native, plain)
+
+    native, plain, _ = both_routes(monkeypatch, build, lambda m: m.get2DDensities(pairs, meanlikes=True))
+    same(native, plain)
+    extras_same(native, plain)
+    assert all(d.likes is not None for d in native)
+
+    def mask_function(minx, miny, stepx, stepy, mask):
+        ny, nx = mask.shape
+        yy, xx = np.arange(ny)[:, None], np.arange(nx)[None, :]
+        mask[(yy - ny // 2) > 1.5 * (xx - nx // 2) + 10] = 0
+
+    for kw in (dict(), dict(meanlikes=True), dict(get_density=False, num_plot_contours=2)):
+        native, plain, _ = both_routes(monkeypatch, build, lambda m: m.get2DDensities(pairs[:6], mask_function=mask_function, **kw))
+        same(native, plain)
+        extras_same(native, plain)
+        assert all(d.mask is not None and d.mask.any() for d in native)
+        if "num_plot_contours" in kw:
+            for a, b in zip(native, plain):
+                assert np.allclose(a.contours, b.contours, rtol=1e-12, atol=0)
+
+
 def test_native_entry_contour_levels(monkeypatch):
     recipe = synth.block_recipe(10, 200_000, weighted=False, stream=63)
     pairs = synth.triangle_pairs(10)
