@@ -1065,8 +1065,17 @@ struct Call {
             for (int q : b.pos) b.ks.push_back(members[q]);
         return 0;
     }
-    int s_first_batch() const { return s.first_batch > 0 ? s.first_batch : 128; }
-    int s_max_batch() const { return s.max_batch > 0 ? s.max_batch : 320; }
+    // (GDHIP_BATCH_FIRST_BATCH / GDHIP_BATCH_MAX_BATCH: tuning knobs over the settings' defaults)
+    int s_first_batch() const {
+        if (s.first_batch > 0) return s.first_batch;
+        const char* e = getenv("GDHIP_BATCH_FIRST_BATCH");
+        return e && atoi(e) > 0 ? atoi(e) : 128;
+    }
+    int s_max_batch() const {
+        if (s.max_batch > 0) return s.max_batch;
+        const char* e = getenv("GDHIP_BATCH_MAX_BATCH");
+        return e && atoi(e) > 0 ? atoi(e) : 320;
+    }
     double s_max_batch_bytes() const { return s.max_batch_bytes > 0 ? s.max_batch_bytes : 24e9; }
     int s_two_min() const { return s.two_streams_min > 0 ? s.two_streams_min : 64; }
     int s_two_split() const { return s.two_streams_split > 0 ? s.two_streams_split : 400; }
