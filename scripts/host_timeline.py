@@ -25,6 +25,28 @@ for name in ("cov", "quantiles_probe", "density2d_batch", "copy_wait", "batch2d_
             mcsamples._hostlog("<- " + _name)
 
     setattr(type(mc.ctx), name, wrap)
+# finer marks inside the Python part of the batched 2D call (module functions of getdist_amd/batch2d.py and a few methods)
+from getdist_amd import batch2d as _b2  # noqa: E402
+
+
+def _mark_fn(owner, name, label=None):
+    fn = getattr(owner, name)
+
+    def wrap(*a, _fn=fn, _name=label or name, **k):
+        mcsamples._hostlog("   > " + _name)
+        try:
+            return _fn(*a, **k)
+        finally:
+            mcsamples._hostlog("   < " + _name)
+
+    setattr(owner, name, wrap)
+
+
+for _name in ("settings_of", "pack_params"):
+    _mark_fn(_b2, _name)
+for _name in ("getCorrelationMatrix", "getCov", "_init_params", "updateBaseStatistics"):
+    _mark_fn(MCSamples, _name)
+_mark_fn(type(mc.ctx), "pinned_array")
 for _ in range(4):
     d = bench.one_step(mc, pairs, None, 0, 1, None)
     d[-1].P
