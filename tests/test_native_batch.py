@@ -427,3 +427,31 @@ def test_native_route_serves_a_mask_callback(zoo, meanlikes):
     levels_native = make(fx, nb.HarnessContext).get2DDensities(pairs, mask_function=mask_function, get_density=False, num_plot_contours=2)
     for a, b in zip(levels_native, levels_plain):
         assert np.array_equal(a.contours, b.contours)
+
+
+def test_native_route_second_binning_launch_wraps_a_counter(monkeypatch):
+    """The main binning runs in two launches (the first optimiser part's rows first).  A 16-bit counter that wraps in the
+    SECOND launch -- a column with 60 % of its samples on one value, paired last -- sends the whole class through the u16
+    redo while the first part is already being optimised on rows of the first buffer: that buffer stays alive until the call
+    ends, the later parts and every convolution read the redone one; same grids as the planned route."""
+    rng = np.random.default_rng(12)
+    N = 150_000
+    x = rng.standard_normal((N, 12))
+    spike = rng.random(N) < 0.7  # the last two columns share it: their pair -- the triangle's last -- has a bin with 0.7 N samples
+    x[:, 10] = np.where(spike, -0.5, x[:, 10])
+    x[:, 11] = np.where(spike, 0.25, x[:, 11])
+    fx = dict(samples=x, weights=None, names=["q%d" % i for i in range(12)], ranges={})
+    pairs = triangle(12)
+    assert pairs[-1] == (10, 11)
+    plain = make(fx, nb.PlainContext).get2DDensities(pairs)
+    monkeypatch.setenv("GDHIP_BATCH_SHEAR_DEFERRED_MIN", "16")
+    mc = make(fx, nb.HarnessContext)
+    mc.CONV_TWO_STREAMS_PAIRS = (8, 20)
+    mc.KOPT_SPLIT_MIN = 8
+    nb.CALLS.clear()
+    native = mc.get2DDensities(pairs)
+    same(native, plain)
+    byte_launches = [c for c in nb.CALLS if c[0] == "hist2d_prebinned8"]
+    assert len(byte_launches) == 2 and byte_launches[0][2] < len(pairs), byte_launches
+    redo = [c for c in nb.CALLS if c[0] == "hist2d_prebinned" and c[3] == 256]
+    assert len(redo) == 1 and redo[0][2] == len(pairs), (redo, "the second launch's wrap sends the whole class through the u16 redo")
