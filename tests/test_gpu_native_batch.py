@@ -131,6 +131,26 @@ def test_native_entry_serves_the_optional_branches(monkeypatch):
                 assert np.allclose(a.contours, b.contours, rtol=1e-12, atol=0)
 
 
+def test_native_entry_counter_wrap_in_the_second_binning_launch(monkeypatch):
+    """A large call bins its main class in two launches; a 16-bit counter that wraps in the second one (the triangle's last
+    pair: two columns with 70 % of their samples on one value) redoes the class with wider counters while the first
+    optimiser part is already running on the first buffer's rows.  Same grids as the comparison route."""
+    from getdist_amd.mcsamples import MCSamples
+
+    rng = np.random.default_rng(21)
+    N, n = 200_000, 30
+    x = rng.standard_normal((N, n))
+    spike = rng.random(N) < 0.7
+    x[:, n - 2] = np.where(spike, -0.5, x[:, n - 2])
+    x[:, n - 1] = np.where(spike, 0.25, x[:, n - 1])
+    names = ["q%d" % i for i in range(n)]
+    pairs = synth.triangle_pairs(n)
+    assert len(pairs) > 400 and tuple(pairs[-1]) == (n - 2, n - 1)  # (a staged call: above CONV_TWO_STREAMS_PAIRS[1])
+    native, plain, _ = both_routes(monkeypatch, lambda: MCSamples(samples=x, names=names), lambda m: m.get2DDensities(pairs))
+    same(native, plain)
+    assert float(native[-1].P.max()) == 1.0
+
+
 def test_native_entry_contour_levels(monkeypatch):
     recipe = synth.block_recipe(10, 200_000, weighted=False, stream=63)
     pairs = synth.triangle_pairs(10)
