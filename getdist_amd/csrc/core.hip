@@ -1,5 +1,15 @@
 // Context, device memory, sample upload (SoA transpose), event timers.
 #include <stdarg.h>
+#include <stdint.h>
+#include <ctype.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <string>
+
+#include <map>
+#include <mutex>
 
 #include "ctx.hpp"
 
@@ -335,9 +345,63 @@ int gd_memcpy_d2d(gd_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes) {
     return GD_OK;
 }
 
+// Large page-locked blocks (the landing blocks of a triangle's grids: 642 MB) on transparent huge pages: anonymous memory
+// advised MADV_HUGEPAGE, touched, then registered with the runtime.  hipHostMalloc hands out 4-KB pages; a block allocated late
+// in a process comes from wherever the kernel finds them, and its result copies then run a few per cent slower than those
+// into a block allocated early (bench.py's delivered triangles alternate between two blocks: 29 / 27 ms in the processes
+// where that happened).  GDHIP_HOST_ALLOC_PLAIN=1: hipHostMalloc for every size.
+namespace {
+struct HugeBlock {
+    void* map;
+    size_t len;
+};
+std::mutex g_huge_mu;
+std::map<void*, HugeBlock> g_huge;
+constexpr size_t kHuge = (size_t)2 << 20;
+
+// the NUMA node the device hangs on (sysfs; -1: unknown / a single node)
+int device_numa_node(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+}  // namespace
+
 int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out) {
     GD_REQUIRE(ctx && out && bytes > 0, "bad argument");
     *out = nullptr;
+    if ((size_t)bytes >= 16 * kHuge && getenv("GDHIP_HOST_ALLOC_PLAIN") == nullptr) {
+        const size_t len = ((size_t)bytes + kHuge - 1) / kHuge * kHuge;
+        void* map = mmap(nullptr, len + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (map != MAP_FAILED) {
+            char* p = (char*)(((uintptr_t)map + kHuge - 1) / kHuge * kHuge);
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            const int node = device_numa_node(ctx->device);
+            if (node >= 0 && node < 64) {  // prefer the device's node, as hipHostMalloc does (best effort)
+                unsigned long mask = 1UL << node;
+                (void)syscall(SYS_mbind, p, len, 1 /* MPOL_PREFERRED */, &mask, sizeof(mask) * 8 + 1, 0);
+            }
+            for (size_t o = 0; o < len; o += 4096) p[o] = 0;  // first touch: the pages exist before they are pinned
+            if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_huge_mu);
+                g_huge[p] = HugeBlock{map, len + kHuge};
+                *out = p;
+                return GD_OK;
+            }
+            (void)hipGetLastError();
+            munmap(map, len + kHuge);
+        }
+    }
     GD_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
     return GD_OK;
 }
@@ -346,7 +410,18 @@ int gd_host_free(gd_ctx* ctx, void* ptr) {
     GD_REQUIRE(ctx, "null context");
     if (ptr) {
         GD_TRY(gd_stream_sync(ctx));
-        GD_HIP(hipHostFree(ptr));
+        HugeBlock hb{nullptr, 0};
+        {
+            std::lock_guard<std::mutex> g(g_huge_mu);
+            auto it = g_huge.find(ptr);
+            if (it != g_huge.end()) hb = it->second, g_huge.erase(it);
+        }
+        if (hb.map) {
+            GD_HIP(hipHostUnregister(ptr));
+            munmap(hb.map, hb.len);
+        } else {
+            GD_HIP(hipHostFree(ptr));
+        }
     }
     return GD_OK;
 }
