@@ -428,6 +428,33 @@ def test_collect_stage_overflow_falls_through_to_the_lists(weights):
         c.close()
 
 
+@pytest.mark.parametrize("plain", [False, True])
+def test_page_locked_blocks_small_and_large(plain, monkeypatch):
+    """gd_host_alloc: blocks of 32 MB and more are anonymous memory on transparent huge pages registered with the runtime
+    (round 6), smaller ones -- and everything with GDHIP_HOST_ALLOC_PLAIN=1 -- come from hipHostMalloc; both kinds take
+    result copies and are released with the context."""
+    from getdist_amd._lib import Context
+
+    if plain:
+        monkeypatch.setenv("GDHIP_HOST_ALLOC_PLAIN", "1")
+    c = Context(0)
+    try:
+        r = np.random.default_rng(3)
+        for n in (1000, 6_000_000):  # 8 KB (a 1-MB block), 48 MB
+            x = r.standard_normal(n)
+            d = c.alloc(n * 8)
+            d.from_host(x)
+            back = d.to_host((n,), pinned=True)
+            assert np.array_equal(back, x)
+            again = c.pinned_array((n,), np.float64)  # `back` is alive: a second block of the size
+            assert again.ctypes.data != back.ctypes.data
+            again[:] = 1.0
+            d.free()
+        del back, again  # nobody views the blocks any more: close() hands them back (hipHostUnregister + munmap / hipHostFree)
+    finally:
+        c.close()
+
+
 def test_contour_levels_batch(ctx):
     """gd_contour_levels against the oracle's restatement of densities.py:19-56 on smooth, flat-topped and tied grids."""
     from oracle import kde_oracle as ko
