@@ -66,7 +66,10 @@ int gd_memset(gd_ctx* ctx, void* d_dst, int value, int64_t bytes);
 /* d_dst[k] = d_src[index[k]] for `count` items of item_bytes each (item_bytes % 16 == 0), one kernel launch;
  * stream-ordered (returns once enqueued; `index` may be released on return) */
 int gd_gather_items(gd_ctx* ctx, void* d_dst, const void* d_src, const int32_t* index, int32_t count, int64_t item_bytes);
-/* page-locked host memory for fast, asynchronous D2H of result grids */
+/* page-locked host memory for fast, asynchronous D2H of result grids.  Blocks of 32 MB and more are anonymous memory on
+ * transparent huge pages (MADV_HUGEPAGE, the device's NUMA node preferred) registered with the runtime -- result copies into
+ * 4-KB-page blocks allocated late in a process ran measurably slower --, smaller ones hipHostMalloc;
+ * free with gd_host_free only. */
 int gd_host_alloc(gd_ctx* ctx, int64_t bytes, void** out);
 int gd_host_free(gd_ctx* ctx, void* ptr);
 /* HIP-event timing on the ctx stream (bench.py measures kernels with these, not torch events) */
