@@ -818,22 +818,26 @@ __device__ __forceinline__ int64_t xt_at(int b, int NT, int Sh, int y, int kx) {
 // keeps 9 lanes of a row's group busy and its 9-point step 16, so with 32-lane groups a wave carried two rows with 18 and
 // 32 of its 64 lanes at work; with 16-lane groups it carries four (36 and 64 lanes): the transform's instructions per row
 // halve, everything else (pack, un-mix, tile store) is lane-parallel either way.  The arithmetic of a row is unchanged.
-template <int MODE, int FTL>
+// FTL = 64 (round 6): the frames above 512 points (the up-scaled grid classes: half-length transforms of up to 576 points on
+// a whole wavefront); TWG: the twiddles are read where they lie (global memory, cache-resident) -- the 16 row buffers of a
+// 1152-point frame leave no room for the table in LDS.
+template <int MODE, int FTL, bool TWG = false>
 __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict__ pairs, const double* __restrict__ src,
                                                   const double* __restrict__ P, const double* __restrict__ mx, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double2* __restrict__ Xt) {
     extern __shared__ double2 sh2[];
     __shared__ double thresh_sh;
     const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
-    double2* tw = sh2;
+    const double2* tw = TWG ? twg : sh2;
+    double2* const rows0 = sh2 + (TWG ? 0 : S);
     const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
-    double2* buf = sh2 + S + (size_t)g * RP;
-    {  // (both of a thread's twiddle loads requested before the first is stored)
+    double2* buf = rows0 + (size_t)g * RP;
+    if (!TWG) {  // (both of a thread's twiddle loads requested before the first is stored)
         const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
         const double2 a0 = twg[min(i0, S - 1)], a1 = twg[min(i1, S - 1)];
-        if (i0 < S) tw[i0] = a0;
-        if (i1 < S) tw[i1] = a1;
-        for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) tw[i] = twg[i];
+        if (i0 < S) sh2[i0] = a0;
+        if (i1 < S) sh2[i1] = a1;
+        for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) sh2[i] = twg[i];
     }
     if (MODE == 1 && threadIdx.x == 0) thresh_sh = pair_max(mx, b) * 1e-8;
     __syncthreads();
@@ -846,7 +850,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
         // the first value is used (unconditional loads from clamped addresses, the padding selected afterwards): the loop
         // this replaces issued two predicated 8-byte loads per iteration and waited for them before the next -- nine
         // memory latencies in sequence per block, which is what the row kernels' time was made of (ISA reading, round 5).
-        constexpr int MAXIT = (FTL == 16) ? 9 : 8;  // ceil(H / FTL): H = 144 on 16 lanes, H <= 256 on 32
+        constexpr int MAXIT = (FTL == 32) ? 8 : 9;  // ceil(H / FTL): H = 144 on 16 lanes, H <= 256 on 32, H <= 576 on 64
         double hv[2 * MAXIT], pv[2 * MAXIT];
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
@@ -881,7 +885,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
     else if (H == 144)  // (uniform)
         f288::fft144_group<false>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
     else
-        fft_full<false, false>(buf, tw, 2, plH, t);
+        fft_full<0, false, (FTL == 64 ? 64 : FT)>(buf, tw, 2, plH, t);
     if (active) {  // un-mix in place: the lane that consumes (buf[k], buf[H - k]) writes (X[k], X[H - k]) there
         for (int k = t; 2 * k <= H; k += FTL) {
             if (k == 0) {
@@ -907,7 +911,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
     // column kernels never read them)
     const int NT = (F + XT_ROWS - 1) / XT_ROWS;
     double2* tile = Xt + ((int64_t)b * NT + blockIdx.x) * Sh * XT_ROWS;
-    const double2* rows = sh2 + S;
+    const double2* rows = rows0;
     for (int i = threadIdx.x; i < Sh * XT_ROWS; i += blockDim.x) {
         const int kx = i >> 4, row = i & (XT_ROWS - 1);
         const double2* rb = rows + (size_t)row * RP;
@@ -925,22 +929,28 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_fwd(const D2Pair* __restrict_
 // grid (ceil(Sh / 8), B), 256 threads = 8 columns per block.  The spectrum of the window moment Win * x^px * y^py, by
 // columns: Wt[b][kx][ky].  Built from the (2w+1)^2 window values: a direct sum over x for each window row, then the column
 // transform.  Once per pair and moment (the plain window serves the first convolution and the bias-correction round).
-template <bool BIG>
-__global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, FftDev pl,
+// SZ: size class of the transforms (ldsfft.hpp; 2 = the frames above 512 points on 64-lane groups, round 6); blockDim.x / lanes
+// columns per block (8 where the LDS has room).  WGLOB: a window whose (2w+1)^2 values do not fit the LDS next to the
+// transform buffers (w of 50+ bins) -- the sums over x come from k_win_rowdft (one thread per (window row, kx) instead of
+// 2w+1 lanes with (2w+1)/2 terms each: a 193-bin window took 315 us per moment in the form above), the same terms in the
+// same order, so the same spectrum bit for bit.
+template <int SZ, bool WGLOB = false>
+__global__ void __launch_bounds__(SZ == 2 ? 512 : 256) k_win_spec(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, FftDev pl,
                                                   const double2* __restrict__ twg, int px, int py, int maxw,
-                                                  double* __restrict__ Wt) {
+                                                  double* __restrict__ Wt, const double2* __restrict__ rowdft = nullptr) {
     extern __shared__ double2 sh2[];
-    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    constexpr int FTN = SZ == 2 ? 64 : FT;
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y, ncol = blockDim.x / FTN;
     const D2Pair p = pairs[b];
     const int w = p.w, M = 2 * w + 1, Mmax = 2 * maxw + 1;
     double2* tw = sh2;
     double* wn = reinterpret_cast<double*>(sh2 + S);  // (2w+1)^2 window values, row stride M
-    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
-    double2* bw = sh2 + S + (Mmax * Mmax + 1) / 2 + (size_t)g * S;
-    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
-    {
+    const int g = threadIdx.x / FTN, t = threadIdx.x % FTN;
+    double2* bw = sh2 + S + (WGLOB ? 0 : (Mmax * Mmax + 1) / 2) + (size_t)g * S;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
+    if (!WGLOB) {
         const double ws = wsum[b];
-        for (int e = threadIdx.x; e < M * M; e += 256) {
+        for (int e = threadIdx.x; e < M * M; e += blockDim.x) {
             const int i1 = e / M - w, i2 = e % M - w;
             double v = win_raw(p, i1, i2) / ws;
             for (int q = 0; q < px; ++q) v = v * (double)i2;
@@ -949,15 +959,23 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
         }
     }
     __syncthreads();
-    const int kx = blockIdx.x * 8 + g;
+    const int kx = blockIdx.x * ncol + g;
     const bool active = kx < Sh;
     // rows wrapped into the frame; two lanes per row (the halves of its x range, added lower + upper on both lanes), so
     // that the group's lanes share the (2w+1)^2 terms instead of 2w+1 of them doing a row each
-    for (int idx = t; idx < S; idx += FT) bw[idx] = make_double2(0.0, 0.0);
+    for (int idx = t; idx < S; idx += FTN) bw[idx] = make_double2(0.0, 0.0);
     group_sync();
-    {
+    if (WGLOB) {
+        if (active) {
+            const double2* rs = rowdft + (int64_t)b * Mmax * Sh + kx;  // row r of the window: + r * Sh
+            for (int r = t; r < M; r += FTN) {
+                const int i1 = r - w;
+                bw[i1 >= 0 ? i1 : i1 + S] = rs[(int64_t)r * Sh];
+            }
+        }
+    } else {
         const int half = (M + 1) / 2;
-        for (int task0 = 0; task0 < 2 * M; task0 += FT) {
+        for (int task0 = 0; task0 < 2 * M; task0 += FTN) {
             const int task = task0 + t, row_i = task >> 1, part = task & 1;
             double2 acc = make_double2(0.0, 0.0);
             if (active && row_i < M) {
@@ -980,57 +998,108 @@ __global__ void __launch_bounds__(256) k_win_spec(const D2Pair* __restrict__ pai
     }
     group_sync();
     // (uniform) 16 x M in registers, fft288.hpp
-    if (!BIG && S == 288)
+    if (SZ == 0 && S == 288)
         f288::fft16_group<18, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
-    else if (!BIG && S == 320)
+    else if (SZ == 0 && S == 320)
         f288::fft16_group<20, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
-    else if (BIG && S == 384)
+    else if (SZ == 1 && S == 384)
         f288::fft16_group<24, false>(reinterpret_cast<f288::C2*>(bw), reinterpret_cast<const f288::C2*>(tw), t);
     else
-        fft_full<BIG, false>(bw, tw, 1, pl, t);
+        fft_full<SZ, false, FTN>(bw, tw, 1, pl, t);
     if (active) {
         // the window is even, so the spectrum of an even moment (px + py even) is real and that of an odd one imaginary:
         // one double per entry, the other part is rounding noise of the sums
         double* col = Wt + ((int64_t)b * Sh + kx) * S;
         const bool odd = (px + py) & 1;
-        for (int idx = t; idx < S; idx += FT) col[idx] = odd ? bw[idx].y : bw[idx].x;
+        for (int idx = t; idx < S; idx += FTN) col[idx] = odd ? bw[idx].y : bw[idx].x;
     }
+}
+
+// The wide windows' sums over x (k_win_spec<SZ, true>), in two small launches.
+// k_win_table, grid (blocks, B): the (2w+1)^2 values of the window moment Win * x^px * y^py of every pair, row stride 2w + 1,
+// pair stride (2 maxw + 1)^2 -- k_win_spec's own expressions.
+// k_win_rowdft, grid (2 maxw + 1, ceil(Sh / 256), B), 256 threads = 256 adjacent kx of one window row:
+//     rowdft[b][r][kx] = sum_c wn[r][c] e^{-2 pi i kx (c - w) / S}
+// as k_win_spec's two lanes of a row form it: the lower and the upper half of the row each summed in order, then added.
+__global__ void __launch_bounds__(256) k_win_table(const D2Pair* __restrict__ pairs, const double* __restrict__ wsum, int px, int py,
+                                                   int maxw, double* __restrict__ wtab) {
+    const int b = blockIdx.y;
+    const D2Pair p = pairs[b];
+    const int w = p.w, M = 2 * w + 1, Mmax = 2 * maxw + 1;
+    const double ws = wsum[b];
+    double* wn = wtab + (int64_t)b * Mmax * Mmax;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < M * M; e += gridDim.x * 256) {
+        const int i1 = e / M - w, i2 = e % M - w;
+        double v = win_raw(p, i1, i2) / ws;
+        for (int q = 0; q < px; ++q) v = v * (double)i2;
+        for (int q = 0; q < py; ++q) v = v * (double)i1;
+        wn[e] = v;
+    }
+}
+__global__ void __launch_bounds__(256) k_win_rowdft(const D2Pair* __restrict__ pairs, const double* __restrict__ wtab, int S,
+                                                    const double2* __restrict__ twg, int maxw, double2* __restrict__ rowdft) {
+    extern __shared__ double2 sh2[];  // the S twiddles
+    const int b = blockIdx.z, r = blockIdx.x, Sh = S / 2 + 1, Mmax = 2 * maxw + 1;
+    const int w = pairs[b].w, M = 2 * w + 1;
+    if (r >= M) return;  // (uniform: a pair with a narrower window than the batch's widest)
+    for (int i = threadIdx.x; i < S; i += 256) sh2[i] = twg[i];
+    __syncthreads();
+    const int kx = blockIdx.y * 256 + threadIdx.x;
+    if (kx >= Sh) return;
+    const double* row = wtab + (int64_t)b * Mmax * Mmax + (int64_t)r * M;
+    const int half = (M + 1) / 2;
+    double2 lo = make_double2(0.0, 0.0), hi = make_double2(0.0, 0.0);
+    int pl = (int)(((int64_t)kx * (S - w)) % S), ph = (int)(((int64_t)kx * (S - w + half)) % S);
+    for (int c = 0; c < half; ++c) {  // (the upper half has `half` or `half - 1` terms)
+        const double2 e = sh2[pl];
+        lo.x = fma(row[c], e.x, lo.x), lo.y = fma(row[c], e.y, lo.y);
+        pl += kx;
+        if (pl >= S) pl -= S;
+        if (half + c < M) {
+            const double2 f = sh2[ph];
+            hi.x = fma(row[half + c], f.x, hi.x), hi.y = fma(row[half + c], f.y, hi.y);
+            ph += kx;
+            if (ph >= S) ph -= S;
+        }
+    }
+    rowdft[((int64_t)b * Mmax + r) * Sh + kx] = make_double2(lo.x + hi.x, lo.y + hi.y);
 }
 
 // grid (ceil(Sh / 8), B), 256 threads = 8 columns per block, one LDS buffer per column: transform the source's column,
 // multiply by the window's spectrum in the last pass (scaled), inverse transform, keep the F rows of the crop.
-template <bool BIG>
-__global__ void __launch_bounds__(256) k_col_conv(const D2Pair* __restrict__ pairs, int F, FftDev pl, const double2* __restrict__ twg,
+template <int SZ>
+__global__ void __launch_bounds__(SZ == 2 ? 512 : 256) k_col_conv(const D2Pair* __restrict__ pairs, int F, FftDev pl, const double2* __restrict__ twg,
                                                   const double* __restrict__ Wt, int w_odd, const double2* __restrict__ Xt,
                                                   double2* __restrict__ Yt) {
     extern __shared__ double2 sh2[];
-    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y;
+    constexpr int FTN = SZ == 2 ? 64 : FT;  // (SZ = 2: the frames above 512 points, blockDim.x / 64 columns per block)
+    const int S = pl.S, Sh = S / 2 + 1, b = blockIdx.y, ncol = blockDim.x / FTN;
     const int w = pairs[b].w;
     double2* tw = sh2;
-    const int g = threadIdx.x / FT, t = threadIdx.x % FT;
+    const int g = threadIdx.x / FTN, t = threadIdx.x % FTN;
     double2* bh = sh2 + S + (size_t)g * S;
-    for (int i = threadIdx.x; i < S; i += 256) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < S; i += blockDim.x) tw[i] = twg[i];
     __syncthreads();
-    const int kx = blockIdx.x * 8 + g;
+    const int kx = blockIdx.x * ncol + g;
     const bool active = kx < Sh;
     const int NT = (F + XT_ROWS - 1) / XT_ROWS;
     if (active) {
-        for (int idx = t; idx < S; idx += FT) {
+        for (int idx = t; idx < S; idx += FTN) {
             const int r = idx - w;
             bh[idx] = (r >= 0 && r < F) ? Xt[xt_at(b, NT, Sh, r, kx)] : make_double2(0.0, 0.0);
         }
     }
     group_sync();
-    const int Ns = fft_head<BIG, false>(bh, tw, 1, pl, t);
+    const int Ns = fft_head<SZ, false, FTN>(bh, tw, 1, pl, t);
     const double scale = 1.0 / ((double)S * (double)S);
     const double* wcol = Wt + ((int64_t)b * Sh + (active ? kx : 0)) * S;  // real part (even moment) or imaginary part (odd)
-    fft_pass_any<BIG, false>(pl, pl.nst - 1, bh, tw, 1, Ns, t, [&](int pos, double2 v) {
+    fft_pass_any<SZ, false, FTN>(pl, pl.nst - 1, bh, tw, 1, Ns, t, [&](int pos, double2 v) {
         const double ws = wcol[pos] * scale;
         bh[pos] = w_odd ? make_double2(-v.y * ws, v.x * ws) : make_double2(v.x * ws, v.y * ws);
     });
-    fft_full<BIG, true>(bh, tw, 1, pl, t);
+    fft_full<SZ, true, FTN>(bh, tw, 1, pl, t);
     if (active) {
-        for (int r = t; r < F; r += FT) Yt[xt_at(b, NT, Sh, r, kx)] = bh[r + w];
+        for (int r = t; r < F; r += FTN) Yt[xt_at(b, NT, Sh, r, kx)] = bh[r + w];
     }
 }
 
@@ -1141,7 +1210,7 @@ __global__ void __launch_bounds__(192) k_col_conv16(const D2Pair* __restrict__ p
 // grid does not cover set to -inf.
 // MODE 1 takes the divisor a00 (the all-edge mask's zeroth moment) from its F x F array, or -- sat1 given: the pair's
 // summed-area table of that moment at sat1 + b * sat1_pair_stride -- evaluates it per pixel (k_mask_eval's operations).
-template <int MODE, int FTL>
+template <int MODE, int FTL, bool TWG = false>
 __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict__ pairs, const double2* __restrict__ Yt, int F, FftDev plH,
                                                   const double2* __restrict__ twg, double* __restrict__ dst,
                                                   const double* __restrict__ a00, double* __restrict__ mx,
@@ -1151,14 +1220,15 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
     extern __shared__ double2 sh2[];
     __shared__ double red[16];
     const int H = plH.S, S = 2 * H, Sh = H + 1, RP = H + 1, b = blockIdx.y;
-    double2* tw = sh2;
+    const double2* tw = TWG ? twg : sh2;
+    double2* const rows0 = sh2 + (TWG ? 0 : S);
     const int g = threadIdx.x / FTL, t = threadIdx.x % FTL;
-    double2* buf = sh2 + S + (size_t)g * RP;
+    double2* buf = rows0 + (size_t)g * RP;
     {  // the block's tile of Yt, one contiguous run, into the rows' buffers (row stride H + 1: slot kx of row r); the twiddles.
         // A thread's loads of a batch are all requested before the first is stored (the plain loop waited for each one).
         const int NT = (F + XT_ROWS - 1) / XT_ROWS;
         const double2* tile = Yt + ((int64_t)b * NT + blockIdx.x) * Sh * XT_ROWS;
-        double2* rows = sh2 + S;
+        double2* rows = rows0;
         const int total = Sh * XT_ROWS;
         constexpr int BATCH = 5;
         for (int i0 = threadIdx.x; i0 < total; i0 += BATCH * blockDim.x) {
@@ -1173,18 +1243,20 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
                 rows[(size_t)(i & (XT_ROWS - 1)) * RP + (i >> 4)] = v[q];
             }
         }
-        const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
-        const double2 a0 = twg[min(i0, S - 1)], a1 = twg[min(i1, S - 1)];
-        if (i0 < S) tw[i0] = a0;
-        if (i1 < S) tw[i1] = a1;
-        for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) tw[i] = twg[i];
+        if (!TWG) {
+            const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+            const double2 a0 = twg[min(i0, S - 1)], a1 = twg[min(i1, S - 1)];
+            if (i0 < S) sh2[i0] = a0;
+            if (i1 < S) sh2[i1] = a1;
+            for (int i = threadIdx.x + 2 * blockDim.x; i < S; i += blockDim.x) sh2[i] = twg[i];
+        }
     }
     const int w = pairs[b].w;
     // MODE 1 with tables: the pair's summed-area table of the divisor comes into LDS once -- the border pixels of every row
     // read a dozen of its entries each, and from global memory each such read sat on the row's critical path
     // (measured with the interior shortcut below: 141 -> 107 us per 136-pair launch; requesting the row of the grid ahead of the
     // transform instead of at its use: 117, not kept)
-    double* sat_l = reinterpret_cast<double*>(sh2 + S + (size_t)XT_ROWS * RP);
+    double* sat_l = reinterpret_cast<double*>(rows0 + (size_t)XT_ROWS * RP);
     // MODE 1 with class tables (k_mask_tables): a row needs the 2w + 3 entries of its y class only -- its group fetches
     // them (LDS: 16 x (2w + 3) doubles) and a pixel's divisor is one look-up
     if (MODE == 1 && tab1) {
@@ -1225,7 +1297,7 @@ __global__ void __launch_bounds__(16 * FTL) k_rows_inv(const D2Pair* __restrict_
     if (FTL == 16 || H == 144)
         f288::fft144_group<true>(reinterpret_cast<f288::C2*>(buf), reinterpret_cast<const f288::C2*>(tw), t);
     else
-        fft_full<false, true>(buf, tw, 2, plH, t);
+        fft_full<0, true, (FTL == 64 ? 64 : FT)>(buf, tw, 2, plH, t);
     double m = -INFINITY;
     if (active) {
         const int64_t o = (int64_t)b * F * F + (int64_t)y * F;
@@ -1548,12 +1620,29 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     const double2* d_tw = nullptr;
     const int Mmax = 2 * maxw + 1;
     const int RPB = 16;  // rows per block of the row passes
-    const size_t lds_rows = ((size_t)S + (size_t)RPB * (S / 2 + 1)) * 16;  // twiddles + a half-length buffer per row (+ 1: bank padding, X[H])
-    const size_t lds_cols = ((size_t)S + (size_t)8 * S) * 16;
-    const size_t lds_win = ((size_t)S + (size_t)(Mmax * Mmax + 1) / 2 + (size_t)8 * S) * 16;  // + the window table
-    const bool lds_conv = !ov && S <= 512 && (F + RPB - 1) / RPB <= PM_PARTS && lds_win <= 150u * 1024u &&
+    const size_t lds_budget = 150u * 1024u;
+    // the row passes keep the twiddle table in LDS where it fits next to the 16 row buffers (not at S = 1152: read in place)
+    const bool rows_twg = ((size_t)S + (size_t)RPB * (S / 2 + 1)) * 16 > 156u * 1024u;
+    const size_t lds_rows = ((size_t)(rows_twg ? 0 : S) + (size_t)RPB * (S / 2 + 1)) * 16;  // twiddles + a half-length buffer per row (+ 1: bank padding, X[H])
+    // columns per block of the column passes: 8 where the LDS has room (every frame up to 512 points), 7 at S = 1152
+    const int ncol = (int)std::max<int64_t>(1, std::min<int64_t>(8, ((int64_t)lds_budget - (int64_t)S * 16) / ((int64_t)S * 16)));
+    const size_t lds_cols = ((size_t)S + (size_t)ncol * S) * 16;
+    // the window spectra: the (2 maxw + 1)^2 window values sit in LDS next to the column buffers while at least four columns
+    // fit beside them; a wider window is read from a table in global memory (k_win_table, round 6)
+    const size_t wtab_lds = (size_t)(Mmax * Mmax + 1) / 2 * 16;
+    const int64_t ncol_win_lds = ((int64_t)lds_budget - (int64_t)S * 16 - (int64_t)wtab_lds) / ((int64_t)S * 16);
+    const bool wglob = ncol_win_lds < 4 || getenv("GDHIP_CONV_WIN_GLOBAL") != nullptr;
+    const int ncol_win = wglob ? ncol : (int)std::min<int64_t>(8, ncol_win_lds);
+    const size_t lds_win = ((size_t)S + (wglob ? 0 : wtab_lds / 16) + (size_t)ncol_win * S) * 16;  // + the window table
+    // frames up to 1152 points (round 6: the up-scaled grid classes F = 768 / 960 and the wide windows; until then 512 points
+    // and windows whose table fits the LDS beside eight columns -- GDHIP_CONV_LDS_OLD_LIMITS: that rule, for A/B runs)
+    const bool size_ok = getenv("GDHIP_CONV_LDS_OLD_LIMITS") ? (S <= 512 && ncol_win_lds >= 8) : S <= 1152;
+    const bool lds_conv = !ov && size_ok && (F + RPB - 1) / RPB <= PM_PARTS &&
                           getenv("GDHIP_CONV_ROCFFT") == nullptr && lds_fft_plan(ctx, S, &pl, &d_tw) &&
                           lds_fft_plan(ctx, S / 2, &plH, nullptr);
+    if (getenv("GDHIP_CONV_LOG"))  // (route of every batch, for the evidence scripts)
+        fprintf(stderr, "gdhip conv: B=%d F=%d maxw=%d S=%d lds_win=%zu cols=%d/%d wglob=%d rows_twg=%d route=%s\n", B, F, maxw, S, lds_win,
+                ncol_win, ncol, (int)wglob, (int)rows_twg, lds_conv ? "lds" : "rocfft");
     // the prior-mask moments are evaluated inside their consumers (k_boundary<true>, k_rows_inv<1>) on the LDS route
     const bool fused = lds_conv && !ov && getenv("GDHIP_CONV_MOMENT_ARRAYS") == nullptr;
     // the mask moments of a pixel from their class tables (k_mask_tables) wherever no pixel is clipped on both sides
@@ -1569,7 +1658,9 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
                   o_arr = take((do_bc ? (bco == 1 ? (fused ? 2 : 8) : (fused ? 0 : 1)) : 0) * B * FF * 8),
                   o_a00m = take(mbc && !fused ? B * FF * 8 : 0),
                   o_conv = take(mbc ? B * FF * 8 : 0), o_sat = take((int64_t)n_mom * B * sat_stride * 8),
-                  o_tab = take(class_tables ? (int64_t)n_mom * B * tab_stride * 8 : 0);
+                  o_tab = take(class_tables ? (int64_t)n_mom * B * tab_stride * 8 : 0),
+                  o_wtab = take(lds_conv && wglob ? (int64_t)B * Mmax * Mmax * 8 : 0),
+                  o_rowdft = take(lds_conv && wglob ? (int64_t)B * Mmax * Sh * 16 : 0);
     char* base = (char*)gd_scratch(ctx, off);
     if (!base) return GD_ERR_NOMEM;
     D2Pair* d_pairs = (D2Pair*)(base + o_pairs);
@@ -1588,6 +1679,8 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     double* d_conv = (double*)(base + o_conv);
     double* d_sat = (double*)(base + o_sat);
     double* d_tab = class_tables ? (double*)(base + o_tab) : nullptr;
+    double* d_wtab = (double*)(base + o_wtab);
+    double2* d_rowdft = (double2*)(base + o_rowdft);
     if (wait) {
         GD_TRY(gd_h2d(ctx, d_pairs, hp.data(), (size_t)B * sizeof(D2Pair)));
     } else {  // hp dies with this frame before the copy executes
@@ -1620,10 +1713,11 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     // LDS route: Xt = row spectra of the source (RF's block), Yt = columns after the convolution (RO's block)
     double2* Xt = (double2*)RF;
     double2* Yt = (double2*)RO;
-    const dim3 gR((F + RPB - 1) / RPB, B), gC((Sh + 7) / 8, B);
+    const dim3 gR((F + RPB - 1) / RPB, B), gC((Sh + ncol - 1) / ncol, B), gW((Sh + ncol_win - 1) / ncol_win, B);
     // ---- LDS route: launches.  ZW's block holds the plain window's spectrum by columns (kept for the bias-correction
     //      round), ZH's block the moment windows' one after the other.
-    const bool big = S > 320;  // size class of the transforms (butterflies per lane)
+    const int sz = S <= 320 ? 0 : S <= 512 ? 1 : 2;  // size class of the transforms (butterflies per lane; 2: 64-lane groups)
+    const int ftn = sz == 2 ? 64 : 32;
     // 288-point frames: the rows' 144-point register transform on 16-lane groups (four rows per wave); GDHIP_CONV_ROWS32=1: the
     // 32-lane groups of round 4 (A/B switch)
     const bool rows16 = S == 288 && getenv("GDHIP_CONV_ROWS32") == nullptr;
@@ -1631,17 +1725,27 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
     double* Wt1 = (double*)ZH;
     // the window moment's spectrum
     auto lds_win_spec = [&](int px_, int py_, double* WT_) -> int {
-        auto kern = big ? k_win_spec<true> : k_win_spec<false>;
+        if (wglob) {
+            k_win_table<<<dim3(8, B), 256, 0, ctx->stream>>>(d_pairs, d_wsum, px_, py_, maxw, d_wtab);
+            GD_KERNEL_CHECK();
+            k_win_rowdft<<<dim3(Mmax, (Sh + 255) / 256, B), 256, (size_t)S * 16, ctx->stream>>>(d_pairs, d_wtab, S, d_tw, maxw, d_rowdft);
+            GD_KERNEL_CHECK();
+        }
+        auto kern = wglob ? (sz == 2 ? k_win_spec<2, true> : sz == 1 ? k_win_spec<1, true> : k_win_spec<0, true>)
+                          : (sz == 2 ? k_win_spec<2, false> : sz == 1 ? k_win_spec<1, false> : k_win_spec<0, false>);
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        kern<<<gC, 256, lds_win, ctx->stream>>>(d_pairs, d_wsum, pl, d_tw, px_, py_, maxw, WT_);
+        kern<<<gW, ncol_win * ftn, lds_win, ctx->stream>>>(d_pairs, d_wsum, pl, d_tw, px_, py_, maxw, WT_, d_rowdft);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
     // row spectra of a source into Xt (box: the bias-correction box of src and P)
     auto lds_rows_fwd = [&](bool box, const double* P_, const double* mx_) -> int {
-        auto kern = rows16 ? (box ? k_rows_fwd<1, 16> : k_rows_fwd<0, 16>) : (box ? k_rows_fwd<1, 32> : k_rows_fwd<0, 32>);
+        auto kern = rows16    ? (box ? k_rows_fwd<1, 16> : k_rows_fwd<0, 16>)
+                    : sz != 2 ? (box ? k_rows_fwd<1, 32> : k_rows_fwd<0, 32>)
+                    : rows_twg ? (box ? k_rows_fwd<1, 64, true> : k_rows_fwd<0, 64, true>)
+                               : (box ? k_rows_fwd<1, 64> : k_rows_fwd<0, 64>);
         GD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        kern<<<gR, RPB * (rows16 ? 16 : 32), lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, plH, d_tw, Xt);
+        kern<<<gR, RPB * (rows16 ? 16 : ftn), lds_rows, ctx->stream>>>(d_pairs, d_hist, P_, mx_, F, plH, d_tw, Xt);
         GD_KERNEL_CHECK();
         return GD_OK;
     };
@@ -1654,12 +1758,15 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
             GD_HIP(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
             k16<<<dim3((Sh + cols - 1) / cols, B), 192, lds16, ctx->stream>>>(d_pairs, F, d_tw, WT_, w_odd, Xt, Yt);
         } else {
-            auto kc = big ? k_col_conv<true> : k_col_conv<false>;
+            auto kc = sz == 2 ? k_col_conv<2> : sz == 1 ? k_col_conv<1> : k_col_conv<0>;
             GD_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
-            kc<<<gC, 256, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, w_odd, Xt, Yt);
+            kc<<<gC, ncol * ftn, lds_cols, ctx->stream>>>(d_pairs, F, pl, d_tw, WT_, w_odd, Xt, Yt);
         }
         GD_KERNEL_CHECK();
-        auto kr = rows16 ? (update ? k_rows_inv<1, 16> : k_rows_inv<0, 16>) : (update ? k_rows_inv<1, 32> : k_rows_inv<0, 32>);
+        auto kr = rows16    ? (update ? k_rows_inv<1, 16> : k_rows_inv<0, 16>)
+                  : sz != 2 ? (update ? k_rows_inv<1, 32> : k_rows_inv<0, 32>)
+                  : rows_twg ? (update ? k_rows_inv<1, 64, true> : k_rows_inv<0, 64, true>)
+                             : (update ? k_rows_inv<1, 64> : k_rows_inv<0, 64>);
         const bool tabs = update && fused && class_tables;  // the divisor by class: one table row per row of the tile
         size_t lds_rows_inv = lds_rows + (tabs ? (size_t)RPB * (2 * maxw + 3) * 8
                                                : (update && fused ? (size_t)(2 * maxw + 2) * (2 * maxw + 2) * 8 : 0));
@@ -1670,7 +1777,7 @@ static int density2d_main(gd_ctx* ctx, int32_t B, int32_t F, const void* d_hist_
         const double* sat1 = (update && fused && !tabs) ? d_sat + (int64_t)(n_mom - 1) * sat_stride : nullptr;
         const double* tab1 = (tabs && sat_in_lds) ? d_tab + (int64_t)(n_mom - 1) * tab_stride : nullptr;
         if (tabs && !tab1) sat1 = d_sat + (int64_t)(n_mom - 1) * sat_stride;  // (no room for the rows: the older path)
-        kr<<<gR, RPB * (rows16 ? 16 : 32), lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
+        kr<<<gR, RPB * (rows16 ? 16 : ftn), lds_rows_inv, ctx->stream>>>(d_pairs, Yt, F, plH, d_tw, dst, a00_, mxp, sat1, (int64_t)n_mom * sat_stride,
                                                         do_bc ? 1 : 0, sat_in_lds, tab1, (int64_t)n_mom * tab_stride);
         GD_KERNEL_CHECK();
         return GD_OK;

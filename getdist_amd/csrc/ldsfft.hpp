@@ -8,7 +8,8 @@ struct FftDev {
     int S, nst;
     int radix[12];
     unsigned int magic[12];  // ceil(2^20 / Ns) of pass st (Ns = product of the earlier radices): j / Ns = (j * magic) >> 20
-                             // exactly for j < 512 -- the passes are VALU-bound and a runtime division costs ~40 instructions
+                             // exactly for j < 1024 and Ns <= 1024 (the excess e = magic Ns - 2^20 < Ns, and the quotient is
+                             // exact while j e < 2^20) -- the passes are VALU-bound and a runtime division costs ~40 instructions
 };
 
 // The FT lanes of a transform sit inside one wavefront, whose LDS operations execute in order: passes are separated by a
@@ -29,7 +30,7 @@ __device__ __forceinline__ double2 cmulf(const double2 a, const double2 b) {
 // its inputs (default: store to buf).  tw[k * tws] = e^{-2 pi i k / S}: a table made for a multiple of S serves with its
 // stride.  Groups without work run the passes on their (unused) buffer like the others -- the passes are VALU-bound and a
 // per-lane `active` test in every butterfly costs more than the idle arithmetic of the last block of a grid.
-template <int R, int MAXIT, bool INV, class Emit>
+template <int R, int MAXIT, bool INV, int FTN = FT, class Emit>
 __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double2* __restrict__ tw, int tws, int S, int Ns,
                                          unsigned int magic, int nb, int t, Emit emit) {
     const int step = (nb / Ns) * tws;  // S / (Ns R) twiddle-table entries per unit of q k
@@ -37,7 +38,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
     double2 o[MAXIT][R];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int j = t + it * FT;
+        const int j = t + it * FTN;
         if (j < nb) {
             const int k = j - (int)(((unsigned int)j * magic) >> 20) * Ns;  // j % Ns
             double2 v[R];
@@ -99,7 +100,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
     group_sync();
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int j = t + it * FT;
+        const int j = t + it * FTN;
         if (j < nb) {
             const int jq = (int)(((unsigned int)j * magic) >> 20);  // j / Ns
             const int j0 = jq * Ns * (R - 1) + j;                   // (j / Ns) Ns R + j % Ns
@@ -110,33 +111,35 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ buf, const double
     group_sync();
 }
 
-// butterflies per lane: ceil(S / R / 32); BIG = false for S <= 320 (the triangle's frames), true up to 512
-template <bool BIG, bool INV, class Emit>
+// butterflies per lane: ceil(S / R / lanes).  Size class SZ = 0 for S <= 320 (the triangle's frames), 1 up to 512 -- both on
+// FTN = 32 lanes --, 2 up to 1280 on FTN = 64 lanes (the up-scaled grid classes; round 6).  The classes 0 / 1 on 64 lanes
+// serve twice their lengths (the half-length row transforms of the large frames).
+template <int SZ, bool INV, int FTN = FT, class Emit>
 __device__ __forceinline__ void fft_pass_any(const FftDev& pl, int st, double2* buf, const double2* tw, int tws, int Ns, int t,
                                              Emit emit) {
     const int R = pl.radix[st], S = pl.S;
     const unsigned int mg = pl.magic[st];
-    if (R == 4) fft_pass<4, BIG ? 4 : 3, INV>(buf, tw, tws, S, Ns, mg, S >> 2, t, emit);
-    else if (R == 2) fft_pass<2, BIG ? 8 : 5, INV>(buf, tw, tws, S, Ns, mg, S >> 1, t, emit);
-    else if (R == 3) fft_pass<3, BIG ? 6 : 4, INV>(buf, tw, tws, S, Ns, mg, S / 3, t, emit);
-    else fft_pass<5, BIG ? 4 : 2, INV>(buf, tw, tws, S, Ns, mg, S / 5, t, emit);
+    if (R == 4) fft_pass<4, SZ == 2 ? 5 : SZ == 1 ? 4 : 3, INV, FTN>(buf, tw, tws, S, Ns, mg, S >> 2, t, emit);
+    else if (R == 2) fft_pass<2, SZ == 2 ? 10 : SZ == 1 ? 8 : 5, INV, FTN>(buf, tw, tws, S, Ns, mg, S >> 1, t, emit);
+    else if (R == 3) fft_pass<3, SZ == 2 ? 7 : SZ == 1 ? 6 : 4, INV, FTN>(buf, tw, tws, S, Ns, mg, S / 3, t, emit);
+    else fft_pass<5, SZ == 2 ? 4 : SZ == 1 ? 4 : 2, INV, FTN>(buf, tw, tws, S, Ns, mg, S / 5, t, emit);
 }
 
 // all passes but the last; returns the sub-transform length the last pass starts from
-template <bool BIG, bool INV>
+template <int SZ, bool INV, int FTN = FT>
 __device__ __forceinline__ int fft_head(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
     int Ns = 1;
     for (int st = 0; st + 1 < pl.nst; ++st) {
-        fft_pass_any<BIG, INV>(pl, st, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
+        fft_pass_any<SZ, INV, FTN>(pl, st, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
         Ns *= pl.radix[st];
     }
     return Ns;
 }
 
-template <bool BIG, bool INV>
+template <int SZ, bool INV, int FTN = FT>
 __device__ __forceinline__ void fft_full(double2* buf, const double2* tw, int tws, const FftDev& pl, int t) {
-    const int Ns = fft_head<BIG, INV>(buf, tw, tws, pl, t);
-    fft_pass_any<BIG, INV>(pl, pl.nst - 1, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
+    const int Ns = fft_head<SZ, INV, FTN>(buf, tw, tws, pl, t);
+    fft_pass_any<SZ, INV, FTN>(pl, pl.nst - 1, buf, tw, tws, Ns, t, [&](int pos, double2 v) { buf[pos] = v; });
 }
 
 // The LDS route's plan for frame size S (radices 4, 2, 3, 5) and its twiddle table on the device (cached per context).

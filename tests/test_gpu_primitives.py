@@ -621,13 +621,20 @@ def test_fused_fp64_binning_packed_counters_match_the_32_bit_kernel(monkeypatch)
     c.close()
 
 
-@pytest.mark.parametrize("F,wmax", [(256, 16), (256, 30), (256, 40), (384, 40), (100, 9), (24, 3), (101, 5), (450, 30)])  # S = 288, 320, 384 (16 x M register transforms), 480, 128, 32, 128, 512 (radix passes)
-def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
+@pytest.mark.parametrize(
+    "F,wmax",
+    [(256, 16), (256, 30), (256, 40), (384, 40), (100, 9), (24, 3), (101, 5), (450, 30),  # S = 288, 320, 384 (16 x M register transforms), 480, 128, 32, 128, 512 (radix passes)
+     # round 6 -- frames above 512 points on 64-lane groups: S = 576, 640, 768, 960, 1152 (row twiddles read in place, 7
+     # columns per block), 1152 with 63 row tiles; windows whose table does not fit the LDS (k_win_table): S = 480, 512, 1152
+     (384, 70), (500, 40), (600, 60), (768, 36), (960, 45), (1000, 20), (256, 96), (256, 116), (960, 90)])
+def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch, capfd):
     """gd_density2d: the convolutions through LDS transforms (k_rows_fwd / k_col_conv / k_rows_inv) against the same call
     through rocFFT frames (GDHIP_CONV_ROCFFT=1), on random histograms with bounded and unbounded pairs, linear boundary
     correction and the multiplicative bias correction: both are exact transforms of the same sums, so the normalised
     grids agree to rounding."""
     from getdist_amd._lib import Context
+
+    monkeypatch.setenv("GDHIP_CONV_LOG", "1")
 
     r = np.random.default_rng(F + wmax)
     B = 21
@@ -663,11 +670,17 @@ def test_lds_convolution_route_equals_the_rocfft_route(F, wmax, monkeypatch):
                 res.append(d_P.to_host((B, F, F)).copy())
                 d_P.free()
             out[route] = res
+        routes = [ln.rsplit("route=", 1)[1] for ln in capfd.readouterr().err.splitlines() if ln.startswith("gdhip conv:")]
+        assert routes == ["lds"] * 3 + ["rocfft"] * 3, routes  # (the first three calls did take the LDS route)
         for a, b_ in zip(out["lds"], out["rocfft"]):
             assert np.all(a.max(axis=(1, 2)) == 1.0)
             assert float(np.max(np.abs(a - b_))) < 1e-11, float(np.max(np.abs(a - b_)))
-        # the same call twice: bit-equal
+        # the same call twice: bit-equal; and a window table read from global memory gives the spectrum of the one in LDS
         monkeypatch.delenv("GDHIP_CONV_ROCFFT", raising=False)
+        d_P, _ = ctx.density2d(d_hist, B, F, rx, ry, corr, winw, flags, 1, 1)
+        assert np.array_equal(d_P.to_host((B, F, F)), out["lds"][0])
+        d_P.free()
+        monkeypatch.setenv("GDHIP_CONV_WIN_GLOBAL", "1")
         d_P, _ = ctx.density2d(d_hist, B, F, rx, ry, corr, winw, flags, 1, 1)
         assert np.array_equal(d_P.to_host((B, F, F)), out["lds"][0])
     finally:
