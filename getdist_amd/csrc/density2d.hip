@@ -981,8 +981,29 @@ __global__ void __launch_bounds__(SZ == 2 ? 512 : 256) k_win_spec(const D2Pair* 
             if (active && row_i < M) {
                 const double* row = wn + row_i * M;
                 const int c0 = part ? half : 0, c1 = part ? M : half;
-                int ph = (int)(((int64_t)kx * (S - w + c0)) % S);  // x offset c0 - w: e^{-2 pi i kx (c0 - w) / S}
-                for (int c = c0; c < c1; ++c) {
+                // x offset c0 - w: e^{-2 pi i kx (c0 - w) / S}  (kx (S - w + c0) < 2 S^2: 32-bit)
+                int ph = (int)(((unsigned int)kx * (unsigned int)(S - w + c0)) % (unsigned int)S);
+                // four terms per trip with their eight LDS loads requested together (the plain loop waited for a load
+                // pair per term: one LDS latency per term and wave); the sums keep their order term by term
+                int c = c0;
+                for (; c + 4 <= c1; c += 4) {
+                    int p1 = ph + kx;
+                    if (p1 >= S) p1 -= S;
+                    int p2 = p1 + kx;
+                    if (p2 >= S) p2 -= S;
+                    int p3 = p2 + kx;
+                    if (p3 >= S) p3 -= S;
+                    const double r0 = row[c], r1 = row[c + 1], r2 = row[c + 2], r3 = row[c + 3];
+                    const double2 e0 = tw[ph], e1 = tw[p1], e2 = tw[p2], e3 = tw[p3];
+                    __builtin_amdgcn_sched_barrier(0);  // (or each load is sunk to its use again)
+                    acc.x = fma(r0, e0.x, acc.x), acc.y = fma(r0, e0.y, acc.y);
+                    acc.x = fma(r1, e1.x, acc.x), acc.y = fma(r1, e1.y, acc.y);
+                    acc.x = fma(r2, e2.x, acc.x), acc.y = fma(r2, e2.y, acc.y);
+                    acc.x = fma(r3, e3.x, acc.x), acc.y = fma(r3, e3.y, acc.y);
+                    ph = p3 + kx;
+                    if (ph >= S) ph -= S;
+                }
+                for (; c < c1; ++c) {
                     const double2 e = tw[ph];
                     acc.x = fma(row[c], e.x, acc.x), acc.y = fma(row[c], e.y, acc.y);
                     ph += kx;

@@ -897,7 +897,8 @@ __global__ void k_qsel_collect(const double* __restrict__ cols, int64_t ld, cons
 // every target that lives in it.  (One block per column sorting its up to 11 lists in turn took 1.1 ms of a 45-ms step.)
 __global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__ st, const unsigned long long* __restrict__ lkeys,
                                                       const double* __restrict__ lw, const int* __restrict__ counts, int k,
-                                                      int passes_done, double* __restrict__ out, int* __restrict__ overflow) {
+                                                      int passes_done, double* __restrict__ out, int* __restrict__ overflow,
+                                                      int unit) {
     __shared__ unsigned long long sk[QCAP];
     __shared__ double sw[QCAP];
     const int c = blockIdx.x;
@@ -940,7 +941,18 @@ __global__ void __launch_bounds__(1024) k_qsel_finish(const QState* __restrict__
             const int q = threadIdx.x;
             double cum = s.cum_below[q];
             int pick = -1, last = -1;
-            for (int i = 0; i < n; ++i) {
+            if (unit && n > 0) {
+                // unit weights (round 6): after i rows the walk below holds cum_below + i exactly (row counts), so the row it
+                // stops at is known without walking -- a guess from the difference, settled with the walk's own comparison
+                // on its own operands.  (One thread reading ~1000 list entries one LDS latency apart was what this kernel's
+                // 0.25 ms consisted of; it sits on the chain in front of a triangle's first grids.)
+                const double tq = s.target[q];
+                int g = (int)fmin(fmax(ceil(tq - cum) - 1.0, 0.0), (double)(n - 1));
+                while (g > 0 && (cum + (double)(g - 1)) + 1.0 >= tq) --g;
+                while (g < n - 1 && !((cum + (double)g) + 1.0 >= tq)) ++g;
+                pick = g;  // (no row reaches the target: the walk's clamp to the last row, g = n - 1)
+            }
+            for (int i = 0; i < n && pick < 0; ++i) {
                 const double wv = sw[i];
                 if (wv != 0) {
                     last = i;
@@ -2201,7 +2213,8 @@ static int quantiles_linear(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int
         GD_QLIN(false);
 #undef GD_QLIN
     GD_KERNEL_CHECK();
-    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, 8, d_out, d_cnt + (int64_t)ncols * QK_MAX,
+                                                                 hw || getenv("GDHIP_QSEL_WALK") ? 0 : 1);
     GD_KERNEL_CHECK();
     int overflow = 0;
     GD_TRY(gd_fetch(ctx, &overflow, d_cnt + (int64_t)ncols * QK_MAX, 4));
@@ -2323,7 +2336,8 @@ int gd_quantiles(gd_ctx* ctx, const int32_t* cols, int32_t ncols, int64_t lo, in
                                                                    d_lw, d_cnt);
         GD_KERNEL_CHECK();
     }
-    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX);
+    k_qsel_finish<<<dim3(ncols, QK_MAX), 1024, 0, ctx->stream>>>(d_st, d_lk, d_lw, d_cnt, k, P, d_out, d_cnt + (int64_t)ncols * QK_MAX,
+                                                                 ctx->w || getenv("GDHIP_QSEL_WALK") ? 0 : 1);
     GD_KERNEL_CHECK();
     int overflow = 0;
     GD_TRY(gd_fetch(ctx, &overflow, d_cnt + (int64_t)ncols * QK_MAX, 4));
