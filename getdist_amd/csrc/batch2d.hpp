@@ -515,6 +515,12 @@ struct Call {
     // that needs it.  Results are unchanged bit for bit (a pair's grid does not depend on the part it is computed in).
     std::future<int> shear_future;
     bool shear_deferred = false, shear_joined = true;
+    // The chain's two halves are awaited separately: a launch that carries sheared rows needs the SHEARED HISTOGRAMS only
+    // (shear_hist_state: 0 running, 1 done, 2 failed with shear_hist_rc), not the up-scaled grid classes the chain bins behind
+    // them -- the last base part's stage A used to start 2.5 ms later than its rows existed (stream timeline of a C3 step:
+    // sheared histograms done at 16.9 ms, the up-scaled classes at 19.4, the last part's first kernel at 19.6).
+    std::atomic<int> shear_hist_state{1};
+    int shear_hist_rc = 0;
     // ... and it starts only when the FIRST optimiser part's convolution has been enqueued (its stage A, get_h and first
     // batches get the machine ahead of the chain's 1024-thread blocks; the chain then runs beside the later parts): same-box
     // A/B, delivered triangle: chain at once 29.4-29.9 ms, released on the first part's bandwidths 28.8-29.5, on its
@@ -1202,7 +1208,15 @@ struct Call {
     // a launch that holds sheared rows, or belongs to a class the deferred chain bins, waits for that chain here
     template <class BufFn>
     int ready_for(Launch& L, const BufFn& class_buffer) {
-        if (L.na > 0 || !L.d_hist) {
+        if (L.na > 0 && L.d_hist && !shear_joined && !getenv("GDHIP_BATCH_SHEAR_JOIN_WHOLE")) {
+            // the sheared rows are all this launch is waiting for (its own class has its buffer)
+            while (shear_hist_state.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            mark("shear: histograms awaited");
+            if (shear_hist_state.load(std::memory_order_acquire) == 2) {
+                (void)join_shear();
+                return shear_hist_rc ? shear_hist_rc : GD_ERR_HIP;
+            }
+        } else if (L.na > 0 || !L.d_hist) {
             const int e = join_shear();
             if (e) return e;
             if (!L.d_hist) L.d_hist = class_buffer(L.F);
@@ -1660,6 +1674,7 @@ struct Call {
                                  bin_done.store(1);
                                  return e;
                              }).share();
+                if (!rc) shear_hist_state.store(0);
                 if (!rc)  // the shear chain starts at once
                     shear_f = std::async(std::launch::async, [this, aux, split_classes] {
                         void* sctx = shear_deferred ? st.aux2 : aux;
@@ -1676,6 +1691,8 @@ struct Call {
                             mark("shear: main binning has run, first part's bandwidths final");
                         }
                         const int e = shear_histograms(sctx);
+                        shear_hist_rc = e;
+                        shear_hist_state.store(e ? 2 : 1, std::memory_order_release);
                         const int e2 = split_classes ? binning(sctx, 2) : 0;  // the up-scaled classes, behind the shear chain
                         return e ? e : e2;
                     });  // (no plan: the call fails; the side classes are not needed)
