@@ -514,7 +514,9 @@ struct Call {
     // the sheared pairs ride in the LAST base part, and the main thread joins the chain only when it builds the first launch
     // that needs it.  Results are unchanged bit for bit (a pair's grid does not depend on the part it is computed in).
     std::future<int> shear_future;
-    bool shear_deferred = false, shear_joined = true;
+    bool shear_deferred = false;
+    std::atomic<bool> shear_joined{true};
+    std::mutex shear_mu;  // (join_shear is entered by the staging thread and, for the last report, by the enqueuing thread)
     // The chain's two halves are awaited separately: a launch that carries sheared rows needs the SHEARED HISTOGRAMS only
     // (shear_hist_state: 0 running, 1 done, 2 failed with shear_hist_rc), not the up-scaled grid classes the chain bins behind
     // them -- the last base part's stage A used to start 2.5 ms later than its rows existed (stream timeline of a C3 step:
@@ -577,9 +579,10 @@ struct Call {
         // launch needs the chain).  The staging thread's ordinary join does NOT release: by then the first part is enqueued
         // and the finisher releases the chain when that part's bandwidths are final.
         if (release) first_part_done.store(1);
-        if (shear_joined) return 0;
-        shear_joined = true;
+        std::lock_guard<std::mutex> g(shear_mu);
+        if (shear_joined.load()) return 0;
         const int e = shear_future.valid() ? shear_future.get() : 0;
+        shear_joined.store(true);
         mark("shear: joined");
         return e;
     }
@@ -1208,7 +1211,7 @@ struct Call {
     // a launch that holds sheared rows, or belongs to a class the deferred chain bins, waits for that chain here
     template <class BufFn>
     int ready_for(Launch& L, const BufFn& class_buffer) {
-        if (L.na > 0 && L.d_hist && !shear_joined && !getenv("GDHIP_BATCH_SHEAR_JOIN_WHOLE")) {
+        if (L.na > 0 && L.d_hist && !shear_joined.load() && !getenv("GDHIP_BATCH_SHEAR_JOIN_WHOLE")) {
             // the sheared rows are all this launch is waiting for (its own class has its buffer)
             while (shear_hist_state.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
             mark("shear: histograms awaited");
@@ -1389,6 +1392,12 @@ struct Call {
             }
             if (m)
                 for (int k : ks) W[(size_t)3 * k] *= widen[k], W[(size_t)3 * k + 1] *= widen[k];
+            if (shear_deferred && index + 1 >= nl) {
+                // the last report convolves the rule-of-thumb pairs of the classes the chain bins: the WHOLE chain, not only
+                // its sheared histograms (ready_for), has to be through
+                const int e = join_shear();
+                if (e) return e;
+            }
             if (!ks.empty() || index + 1 >= nl) return on_chunk(ks, index, nl);
             return 0;
         };
@@ -1693,6 +1702,8 @@ struct Call {
                         const int e = shear_histograms(sctx);
                         shear_hist_rc = e;
                         shear_hist_state.store(e ? 2 : 1, std::memory_order_release);
+                        if (const char* d = getenv("GDHIP_BATCH_TEST_SIDE_BINNING_DELAY_MS"))  // test hook: a slow second half
+                            std::this_thread::sleep_for(std::chrono::milliseconds(atoi(d)));
                         const int e2 = split_classes ? binning(sctx, 2) : 0;  // the up-scaled classes, behind the shear chain
                         return e ? e : e2;
                     });  // (no plan: the call fails; the side classes are not needed)
@@ -1702,7 +1713,7 @@ struct Call {
                 if (!rc) fill_plan(par, ps, plan, s.pair_neff);
                 if (shear_f.valid()) {
                     if (shear_deferred) {
-                        shear_future = std::move(shear_f), shear_joined = false;  // joined by the first launch that needs it
+                        shear_future = std::move(shear_f), shear_joined.store(false);  // joined by the first launch that needs it
                     } else {
                         e = shear_f.get();
                         if (!rc) rc = e;

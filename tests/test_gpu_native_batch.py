@@ -174,6 +174,22 @@ def test_native_entry_c3_shape(monkeypatch):
     assert len(census) >= 6, census
 
 
+def test_native_entry_c3_shape_with_a_slow_second_half_of_the_deferred_chain(monkeypatch):
+    """The last base part waits for the chain's SHEARED HISTOGRAMS only (round 6); the up-scaled grid classes the chain bins
+    behind them may still be running when that part's bandwidths are final -- the last report, which convolves the
+    rule-of-thumb pairs of those classes, has to join the whole chain first.  GDHIP_BATCH_TEST_SIDE_BINNING_DELAY_MS holds
+    the chain's second half back (without the join: 'map::at' from the class table, seen once with a slower copy path)."""
+    recipe = synth.config_c3(2_000_000, 50)
+    pairs = synth.triangle_pairs(50)
+    monkeypatch.setenv("GETDIST_AMD_NATIVE_BATCH", "1")
+    ref = mc_of(recipe).get2DDensities(pairs)
+    ref[-1].P
+    monkeypatch.setenv("GDHIP_BATCH_TEST_SIDE_BINNING_DELAY_MS", "40")
+    slow = mc_of(recipe).get2DDensities(pairs)
+    same(slow, ref)
+    assert any(d.bandwidth_branch == "B" and d.P.shape[0] != 256 for d in slow), "no rule-of-thumb pair in an up-scaled class"
+
+
 def test_two_objects_from_two_threads_share_a_device(monkeypatch):
     """Two sample sets on one device, each driven from its own host thread (three library threads and two streams
     each): the grids equal those of the same calls made one after the other."""
