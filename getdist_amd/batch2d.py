@@ -40,7 +40,8 @@ class BatchSettings(C.Structure):
                 ("two_streams_min", C.c_int32), ("two_streams_split", C.c_int32), ("kopt_split_min", C.c_int32),
                 ("kopt_first_fraction", C.c_double), ("first_batch", C.c_int32), ("max_batch", C.c_int32),
                 ("max_batch_bytes", C.c_double), ("comm_exchange", C.c_int32), ("bandwidths_only", C.c_int32),
-                ("pair_neff", C.POINTER(C.c_double)), ("bandwidths", C.POINTER(C.c_double))]
+                ("pair_neff", C.POINTER(C.c_double)), ("bandwidths", C.POINTER(C.c_double)),
+                ("results_in_flight", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
@@ -305,6 +306,9 @@ def run(mc, pa, base_F, bco, mbc, smooth_scale_2D, num_plot_contours, get_densit
 
         cb = EXCHANGE_FN(exchange)
     previous = mc._pending_results
+    # (a stream of calls: this call's first grids queue behind the previous call's copies -- the library schedules for
+    # throughput then, for the delivery of this call's grids otherwise)
+    settings.results_in_flight = int(previous is not None and not previous.done)
     # The library's own exchange (comm_exchange) may have been ENTERED by a call that failed afterwards -- 'Matrix is not
     # positive definite', a BandwidthError, a device error, NEED_NEFF from the columns nobody owned: the library counts the
     # collectives it issued (gd_batch2d_exchanges), and the flag follows the count in a `finally`, before the NEED_NEFF

@@ -529,6 +529,20 @@ struct Call {
     // convolution 28.1-28.9; the stream of triangles 21.7 -> 21.9.  Released at once when the first launch itself needs the
     // chain, when nothing is staged, and on every error path (and after 20 ms whatever happens).
     std::atomic<int> first_part_done{0};
+    // ... and, since the end of round 6, only when that convolution has RUN: the chain's 1024-thread blocks take every CU for
+    // ~3 ms, and started on the enqueue they ran beside the first part's convolution -- the triangle's first grids, which the
+    // 13 ms of result copies wait for.  Found through a profiler artefact: under rocprofv3's kernel trace the enqueue of the
+    // first batches takes 2.5 ms instead of 0.3, the chain started that much later, and a delivered triangle took 24.6 ms instead
+    // of 26.5 (the stream of triangles 22.4 instead of 19.9).  A timed hold showed the same (GDHIP_BATCH_SHEAR_HOLD_US = 1000 /
+    // 2000 / 3000 / 4500: delivered 26.1 / 24.6 / 24.5 / 24.3 ms, stream 20.4 / 20.6 / 21.6 / 22.2 against 26.5 / 19.9 without).
+    // The release is the status word of the first report's last batch: enqueue_batch pre-sets a batch's words to a sentinel, the
+    // batch's last launch (a copy kernel into page-locked memory) overwrites them, and the chain's thread polls the word.
+    // GDHIP_BATCH_SHEAR_ON_ENQUEUE=1: the release of the enqueue, as before -- which is also what a STREAM of calls gets
+    // (settings.results_in_flight: this call's first grids queue behind the previous call's copies, its delivery does not wait
+    // for them, and the chain beside the first convolution is the better use of the machine: 19.9 against 21.0 ms per triangle).
+    static constexpr int32_t kStatusPending = 0x7fffffff;
+    std::atomic<const volatile int32_t*> first_part_flag{nullptr};
+    int reports_enqueued = 0;  // (enqueuing thread only)
     // Main binning in two launches (round 6, single-triangle latency): the members of the base grid's class are put in the
     // order the optimiser takes them (its own pairs first, the sheared and rule-of-thumb pairs behind), the rows of the FIRST
     // optimiser part are binned by the fused prebin + histogram call, the other rows by a second histogram launch behind it
@@ -573,6 +587,10 @@ struct Call {
             if (f > 0 && f < part) return f;
         }
         return part;
+    }
+    static int shear_hold_us() {
+        const char* e = getenv("GDHIP_BATCH_SHEAR_HOLD_US");
+        return e ? atoi(e) : 0;
     }
     int join_shear(bool release = false) {
         // release: the caller is not going to enqueue a first part the chain could wait for (error paths, a call whose only
@@ -1124,6 +1142,7 @@ struct Call {
         if (!d_P) return dev_fail(rc, h);
         call_blocks.push_back(d_P);
         int32_t* status = status_pinned + status_at;
+        for (int q = 0; q < B; ++q) status[q] = kStatusPending;  // (overwritten by the batch's last launch: see first_part_flag)
         if (grid_off + (int64_t)B * F * F > grids_doubles) return fail(GD_ERR_BADARG, "grids_pinned is too small");
         mark(bctx == h ? "conv: enqueue on main" : "conv: enqueue on twin", B, F);
         GDB_DEV(bctx, ops.density2d_enqueue(bctx, B, F, d_hist, whole ? nullptr : hidx.data(), rxb.data(), ryb.data(), ccb.data(),
@@ -1474,6 +1493,8 @@ struct Call {
                     }
                     e = join_binning();  // (long done by now: a report may convolve any row of the class)
                     if (!e) e = report(launches[q].ks, q);
+                    if (reports_enqueued++ == 0 && status_at > 0 && !s.results_in_flight && !getenv("GDHIP_BATCH_SHEAR_ON_ENQUEUE"))
+                        first_part_flag.store(status_pinned + status_at - 1);  // the last word of the first report's last batch
                     first_part_done.store(1);  // the first part's convolution is enqueued: the deferred shear chain may start
                 }
             });
@@ -1639,6 +1660,7 @@ struct Call {
                 const bool split_classes = F_list.size() > 1;
                 bin_done.store(0);
                 first_part_done.store(0);
+                first_part_flag.store(nullptr), reports_enqueued = 0;
                 {
                     // deferred shear chain (see shear_future): large unit-weight calls whose main class takes the byte-index
                     // route; GDHIP_BATCH_SHEAR_DEFERRED=0 restores the join in front of the optimiser
@@ -1697,6 +1719,14 @@ struct Call {
                                 while (!first_part_done.load() && std::chrono::steady_clock::now() - t1 < std::chrono::milliseconds(20))
                                     std::this_thread::sleep_for(std::chrono::microseconds(50));
                             }
+                            // (GDHIP_BATCH_SHEAR_HOLD_US: the chain's start held back further -- tuning knob)
+                            if (const volatile int32_t* flag = first_part_flag.load()) {  // ... and has run (first_part_flag)
+                                const auto t2 = std::chrono::steady_clock::now();
+                                while (*flag == kStatusPending && std::chrono::steady_clock::now() - t2 < std::chrono::milliseconds(20))
+                                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                            }
+                            if (first_part_done.load() && shear_hold_us() > 0)
+                                std::this_thread::sleep_for(std::chrono::microseconds(shear_hold_us()));
                             mark("shear: main binning has run, first part's bandwidths final");
                         }
                         const int e = shear_histograms(sctx);

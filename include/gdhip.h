@@ -518,6 +518,10 @@ typedef struct gd_batch2d_settings {
     const double* pair_neff;            /* P effective sample numbers instead of min(N_eff x, N_eff y): the caller's 2D estimate
                                            under use_effective_samples_2D (mcsamples.py:1322-1328, chains.py:576-635) */
     const double* bandwidths;           /* P x 3 (hx, hy, corr) in parameter units instead of getAutoBandwidth2D */
+    int32_t results_in_flight;          /* 1: the caller has not waited for the PREVIOUS batched call's result copies (a stream of
+                                           calls): this call's first grids queue behind those copies anyway, so the deferred
+                                           shear chain starts when the first part's convolution is enqueued (throughput) instead
+                                           of when it has run (0: the first grids of THIS call are what its delivery waits for) */
 } gd_batch2d_settings;
 
 typedef int (*gd_neff_exchange_fn)(void* user, double* neff_n, int32_t n);

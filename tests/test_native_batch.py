@@ -340,7 +340,7 @@ def test_grid_sizes_entry(zoo):
     s = batch2d.settings_of(mc, mc.fine_bins_2D, 1, 1, -1.0, False, None)
     F = mc.ctx.batch2d_grid_sizes(s, mc.n, np.ascontiguousarray(mc.getCorrelationMatrix()), np.asarray(fx["pairs"], dtype=np.int32))
     assert F.tolist() == [d.P.shape[0] for d in dens]
-    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 136
+    assert C.sizeof(batch2d.ParamState) == 88 and C.sizeof(batch2d.BatchSettings) == 144
 
 
 def likes_same(native, plain):
