@@ -880,6 +880,8 @@ def main():
     dens = None
     for _ in range(args.warmup):
         dens = one_step(mc, pairs_all, dist, rank, world, torch_device, args.emulate_world, comm)  # held like the timed results
+        if dens:
+            dens[-1].P  # ... and delivered like them (the library schedules a call behind undelivered results for throughput)
     if args.warmup > 0:
         mc.ctx.reserve_pinned_twin()  # result buffers for "previous step still referenced" + "current step"
         if getattr(mc, "_twin", None) is not None:
