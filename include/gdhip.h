@@ -468,7 +468,10 @@ int gd_like_stats(gd_ctx* ctx, int32_t col, double* out8);
  * grids_pinned : page-locked block of >= sum F_k^2 doubles (F_k from gd_batch2d_grid_sizes); pair k's grid lands at
  *          meta[k][1] doubles from its start, F x F row-major, [y][x].
  * status_pinned : P int32, page-locked; after the copies have landed status_pinned[(int)meta[k][30]] is GD_OK or
- *          GD_ERR_EMPTY ("no samples in bin", densities.py:83-84) for pair k.
+ *          GD_ERR_EMPTY ("no samples in bin", densities.py:83-84) for pair k.  Until a batch of convolutions has run its
+ *          words hold 0x7fffffff: the call pre-sets them and the batch's last launch overwrites them -- the library's own
+ *          threads read the words of the first batches to learn that those batches have RUN (the deferred shear chain starts
+ *          then), so the block has to be host-visible while the call runs, as page-locked memory is.
  * meta   : P x GD_BATCH2D_META doubles:
  *          [0] F  [1] offset of the grid  [2..4] (hx, hy, corr) of the kernel in parameter units (NaN when the scale is fixed)
  *          [5] bandwidth branch 0/1/2 = A/B/C (-1: fixed scale)  [6..17] the optimiser's record as gd_kopt2d writes it
