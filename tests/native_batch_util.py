@@ -444,6 +444,7 @@ class HarnessContext(FakeContext):
         from getdist_amd._lib import GdhipError
 
         lib = harness()
+        CALLS.append(("density2d_batch", self.lane, len(pairs32), int(settings.results_in_flight)))
         if self.state is None:
             self.state = lib.gdt_batch_state_new()
         tokens = np.full(2, -1, dtype=np.int32)

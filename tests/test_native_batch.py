@@ -117,6 +117,24 @@ def test_native_route_large_call_two_streams_pipelined(zoo):
     assert [p.N_eff_kde for p in mc.paramNames.names[:13]] == [p.N_eff_kde for p in ref.paramNames.names[:13]]
 
 
+def test_results_in_flight_tells_the_library_about_a_stream_of_calls(zoo):
+    """settings.results_in_flight (end of round 6): 1 when the previous batched call's results have not been waited for -- the
+    library then schedules for throughput (the deferred chain beside the first convolution) --, 0 once they have been read:
+    the delivery of this call's first grids is what counts then.  Same grids either way."""
+    fx = zoo["block50"]
+    pairs = triangle(6)
+    mc = make(fx, nb.HarnessContext)
+    nb.CALLS.clear()
+    first = mc.get2DDensities(pairs)          # nothing before it
+    second = mc.get2DDensities(pairs)         # the first call's results are still pending
+    first[0].P, second[-1].P                  # delivered
+    third = mc.get2DDensities(pairs)
+    flags = [c[3] for c in nb.CALLS if c[0] == "density2d_batch"]
+    assert flags == [0, 1, 0], flags
+    same(second, first)
+    same(third, first)
+
+
 def test_native_route_deferred_shear_chain(zoo, monkeypatch):
     """Round 6 (single-triangle latency): in a large call the shear chain and the up-scaled grid classes run on a FOURTH
     context, start when the main class has been binned, the sheared pairs ride in the LAST optimiser part and the main thread
